@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py - the hot-path benchmark (BASELINE.json metric).
+
+Metric : CSR SpMV GB/s on the 27-pt 3-D Laplacian 256^3, fp64 values / int32
+         indices (configs[1]); one "step" = one y = A x over the whole matrix
+         with all operands resident in HBM.  GB/s = ALGORITHMIC bytes / time:
+         nnz*(8+4) + (n+1)*4 + 8*n (x once) + 8*n (y)   (SURVEY.md 8(d)).
+Extras : CG iterations/s for configs[2] (CG + block-Jacobi(8), same matrix),
+         `roofline` for the SpMV kernel (HIP events on the launch stream),
+         `cpu_baseline` (the reference's OmpExecutor from oracle/_ref when
+         present, else the plain-C oracle) on a bounded sample.
+N > 1  : the 256^3 problem is row-partitioned into z-slabs (strong scaling),
+         one process per GPU, halo exchange + all-reduce over RCCL.
+
+usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--grid G]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def spmv_algorithmic_bytes(n_rows, n_cols, nnz, val_bytes=8, idx_bytes=4):
+    return nnz * (val_bytes + idx_bytes) + (n_rows + 1) * idx_bytes + \
+        n_cols * val_bytes + n_rows * val_bytes
+
+
+def cpu_baseline(grid, budget_s=12.0):
+    """Time the CPU reference on rank 0: 27-pt `grid`^3 CSR SpMV (fp64/int32).
+    kind = "reference": gko::OmpExecutor from the unmodified reference built
+    into oracle/_ref; kind = "port": the sequential plain-C oracle."""
+    import numpy as np
+    from oracle import gko_oracle as o
+    row_ptrs, cols, vals = o.stencil_csr(3, grid)
+    n, nnz = grid ** 3, len(vals)
+    b = np.random.default_rng(42).uniform(-1, 1, n)
+    nbytes = spmv_algorithmic_bytes(n, n, nnz)
+    kind, cores, fn = "port", 1, None
+    try:
+        from oracle import ref_shim
+        if ref_shim.available():
+            cores = os.cpu_count() or 1
+            h = ref_shim.CsrHandle("omp", row_ptrs, cols, vals)
+            fn = lambda: h.spmv(b)
+            kind = "reference"
+    except Exception:
+        fn = None
+    if fn is None:
+        fn = lambda: o.csr_spmv(row_ptrs, cols, vals, b)
+    fn()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        fn()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 200:
+            break
+    return {"value": round(nbytes * reps / el / 1e9, 3), "unit": "GB/s",
+            "cores": cores, "kind": kind,
+            "sample": f"27-pt {grid}^3 CSR SpMV fp64/int32, {reps} reps in "
+                      f"{el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--cg-iters", type=int, default=100,
+                    help="fixed CG iterations timed for the iters/s figure")
+    ap.add_argument("--cpu-grid", type=int, default=128)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ginkgo_amd as g
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch "
+                         "with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    ex = g.Cdna4Executor.create(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    grid = args.grid
+    n_global = grid ** 3
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        a = g.stencil_csr(ex, 3, grid)
+        n_local = n_global
+        nnz_global = a.get_num_stored_elements()
+        x = g.Dense.from_numpy(
+            ex, __import__("numpy").random.default_rng(42).uniform(-1, 1, n_global))
+        y = g.Dense.create(ex, (n_local, 1))
+        step = lambda: a.apply(x, y)
+        op = a
+    else:
+        from ginkgo_amd import distributed as gd
+        part = gd.SlabPartition(grid, world)
+        op = gd.DistributedStencil(ex, part, rank)
+        nnz_global = op.global_nnz
+        n_local = op.n_local
+        x = op.random_vector(42)
+        y = op.zeros_vector()
+        step = lambda: op.apply(x, y)
+
+    total_bytes = spmv_algorithmic_bytes(n_global, n_global, nnz_global)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    t = torch.tensor([wall], dtype=torch.float64, device=ex.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    ms_per_step = wall * 1e3 / args.steps
+    gbs = total_bytes / (wall / args.steps) / 1e9
+
+    # ---- CG + block-Jacobi(8) iterations/s (configs[2]), fixed iteration count
+    cg = {}
+    if args.cg_iters > 0:
+        import numpy as np
+        if world == 1:
+            rhs = g.Dense.from_numpy(ex, np.ones(n_local))
+            sol = g.Dense.from_numpy(ex, np.zeros(n_local))
+            t_setup = time.perf_counter()
+            solver = (g.Cg.build()
+                      .with_criteria(g.stop.Iteration.build().with_max_iters(args.cg_iters),
+                                     g.stop.ResidualNorm.build().with_reduction_factor(1e-30))
+                      .with_preconditioner(g.Jacobi.build().with_max_block_size(8))
+                      .on(ex).generate(a))
+            barrier()
+            t_setup = time.perf_counter() - t_setup
+            solver.apply(rhs, sol.fill(0.0))       # warm-up solve
+            barrier()
+            t1 = time.perf_counter()
+            solver.apply(rhs, sol.fill(0.0))
+            barrier()
+            t_cg = time.perf_counter() - t1
+            iters = solver.num_iterations
+        else:
+            iters, t_cg, t_setup = op.timed_cg(args.cg_iters, barrier)
+        tt = torch.tensor([t_cg], dtype=torch.float64, device=ex.device)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_cg = float(tt.item())
+        n, nnz = n_global, nnz_global
+        cg_bytes = 12 * nnz + 4 * (n + 1) + 64.5 * n + 144 * n  # cg.cpp:133-141 model
+        cg = {"cg_iters_per_s": round(iters / t_cg, 2), "cg_iterations": iters,
+              "cg_ms_per_iter": round(t_cg * 1e3 / iters, 4),
+              "cg_model_gbs": round(cg_bytes * iters / t_cg / 1e9, 1),
+              "cg_precond": "block-Jacobi(8)", "cg_setup_s": round(t_setup, 3)}
+
+    if rank == 0:
+        per_gpu_bytes = total_bytes / world
+        achieved = per_gpu_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "spmv_pmc_latest.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "CSR SpMV GB/s (27-pt 3D Laplacian 256^3, fp64/int32)",
+            "value": round(gbs, 1), "unit": "GB/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"27-pt 3D Laplacian {grid}^3 CSR SpMV fp64 "
+                                   f"(BASELINE configs[1]); n={n_global}, nnz={nnz_global}",
+                       "index_type": "int32", "partition": f"{world} z-slab(s)",
+                       "pct_hbm_peak": round(100 * gbs / (HBM_PEAK_GBS * world), 1)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic,
+                         "kernel": "csr_spmv_wave_kernel<double,int>",
+                         "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(per_gpu_bytes)},
+        }
+        out.update(cg)
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_grid)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+// Shared host/device helpers for libgko_cdna4 (gfx950 only, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "gko_cdna4.h"
+
+namespace gkoc {
+
+constexpr int wave_size = 64;
+// grid cap for HBM-bound grid-stride kernels: 256 CUs x 8 resident blocks
+// of 256 threads (cdna_hip_programming.md, Guideline 11)
+constexpr int max_stream_blocks = 2048;
+
+void set_last_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define GKOC_HIP(call)                                                  \
+    do {                                                                \
+        hipError_t gkoc_e_ = (call);                                    \
+        if (gkoc_e_ != hipSuccess) {                                    \
+            return ::gkoc::hip_fail(gkoc_e_, #call, __FILE__, __LINE__); \
+        }                                                               \
+    } while (0)
+
+#define GKOC_LAUNCH_OK() GKOC_HIP(hipGetLastError())
+
+#define GKOC_REQUIRE(cond, code, msg)                                   \
+    do {                                                                \
+        if (!(cond)) {                                                  \
+            ::gkoc::set_last_error("%s:%d: %s", __FILE__, __LINE__, msg); \
+            return (code);                                              \
+        }                                                               \
+    } while (0)
+
+inline hipStream_t as_stream(gkoc_stream_t s)
+{
+    return reinterpret_cast<hipStream_t>(s);
+}
+
+inline int64_t ceildiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+struct device_props {
+    int num_cu;
+    int num_xcd;
+};
+// cached per-device query (hipGetDeviceProperties is slow)
+const device_props& current_device_props();
+
+#ifdef __HIPCC__
+
+// ---- wave / block reductions (64-lane) ---------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_xor(v, off, 64);
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_max(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        T o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// deterministic block sum for blockDim.x == BLOCK (multiple of 64);
+// result valid in thread 0 (and wave 0)
+template <int BLOCK, typename T>
+__device__ __forceinline__ T block_sum(T v, T* lds /* BLOCK/64 entries */)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    if (lane == 0) lds[wid] = v;
+    __syncthreads();
+    T r = T(0);
+    if (wid == 0) {
+        r = lane < BLOCK / 64 ? lds[lane] : T(0);
+        r = wave_sum(r);
+    }
+    return r;
+}
+
+// make this wave's LDS writes visible to its own other lanes (single-wave
+// producer/consumer through LDS; no cross-wave barrier needed)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// stopping_status helpers (include/ginkgo/core/stop/stopping_status.hpp)
+__device__ __forceinline__ bool status_has_stopped(uint8_t s)
+{
+    return (s & 0x3f) != 0;
+}
+
+#endif  // __HIPCC__
+
+}  // namespace gkoc

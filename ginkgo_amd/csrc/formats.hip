@@ -1,0 +1,475 @@
+// ELL / SELL-P SpMV, CSR -> ELL / SELL-P conversions and the index utilities
+// needed to build those formats on the device.
+//
+// Replaces gko::kernels::hip::ell::{spmv, advanced_spmv, compute_max_row_nnz},
+// sellp::{spmv, advanced_spmv, compute_slice_sets},
+// csr::{convert_to_ell, convert_to_sellp},
+// components::{prefix_sum_nonnegative, convert_ptrs_to_sizes,
+// convert_idxs_to_ptrs, fill_array, fill_seq_array}
+// (decl core/matrix/{ell,sellp,csr}_kernels.hpp, core/components/*_kernels.hpp;
+// semantics reference/matrix/ell_kernels.cpp:25-140,
+// reference/matrix/sellp_kernels.cpp:25-130,
+// reference/matrix/csr_kernels.cpp:529-600; stock GPU versions
+// common/cuda_hip/matrix/ell_kernels.cpp:84-216, sellp_kernels.cpp:37-135).
+//
+// Both formats are lane-per-row with column-major (ELL) / slice-column-major
+// (SELL-P, slice_size = 64 = one wavefront per slice) storage, so every
+// val / col load of a wave is one contiguous 512 B / 256 B segment.  Loads are
+// issued UNROLL columns ahead of the in-order accumulation, which keeps the
+// reference's sequential summation order => bit-identical results.
+// Algorithmic HBM bytes: stored_elements*(sizeof(T)+sizeof(I)) + 2 n sizeof(T).
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace gkoc {
+namespace {
+
+constexpr int fmt_unroll = 8;
+
+template <typename T, typename I, bool ADV>
+__global__ __launch_bounds__(256) void ell_spmv_kernel(
+    int64_t n_rows, int64_t k_per_row, int64_t stride,
+    const I* __restrict__ cols, const T* __restrict__ vals,
+    const T* __restrict__ b, int64_t ldb, T* __restrict__ c, int64_t ldc,
+    int nrhs, const T* __restrict__ alpha_p, const T* __restrict__ beta_p)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    T alpha = T(1), beta = T(0);
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    for (int j = 0; j < nrhs; ++j) {
+        T sum = T(0);
+        if (ADV && beta != T(0)) sum = beta * c[row * ldc + j];
+        int64_t i = 0;
+        for (; i + fmt_unroll <= k_per_row; i += fmt_unroll) {
+            T v[fmt_unroll];
+            I cc[fmt_unroll];
+#pragma unroll
+            for (int u = 0; u < fmt_unroll; ++u) {
+                v[u] = vals[row + (i + u) * stride];
+                cc[u] = cols[row + (i + u) * stride];
+            }
+            T xv[fmt_unroll];
+#pragma unroll
+            for (int u = 0; u < fmt_unroll; ++u) {
+                xv[u] = cc[u] >= 0 ? b[int64_t(cc[u]) * ldb + j] : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < fmt_unroll; ++u) {
+                if (cc[u] >= 0) {
+                    sum += ADV ? (alpha * v[u]) * xv[u] : v[u] * xv[u];
+                }
+            }
+        }
+        for (; i < k_per_row; ++i) {
+            const I cc = cols[row + i * stride];
+            if (cc >= 0) {
+                const T v = vals[row + i * stride];
+                const T xv = b[int64_t(cc) * ldb + j];
+                sum += ADV ? (alpha * v) * xv : v * xv;
+            }
+        }
+        c[row * ldc + j] = sum;
+    }
+}
+
+template <typename T, typename I, bool ADV>
+__global__ __launch_bounds__(256) void sellp_spmv_kernel(
+    int64_t n_rows, int64_t slice_size,
+    const uint64_t* __restrict__ slice_sets,
+    const uint64_t* __restrict__ slice_lengths, const I* __restrict__ cols,
+    const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb,
+    T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
+    const T* __restrict__ beta_p)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    const int64_t slice = row / slice_size;
+    const int64_t local = row - slice * slice_size;
+    const int64_t len = int64_t(slice_lengths[slice]);
+    const int64_t base = int64_t(slice_sets[slice]) * slice_size + local;
+    T alpha = T(1), beta = T(0);
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    for (int j = 0; j < nrhs; ++j) {
+        T sum = T(0);
+        if (ADV && beta != T(0)) sum = c[row * ldc + j] * beta;
+        int64_t i = 0;
+        for (; i + fmt_unroll <= len; i += fmt_unroll) {
+            T v[fmt_unroll];
+            I cc[fmt_unroll];
+#pragma unroll
+            for (int u = 0; u < fmt_unroll; ++u) {
+                v[u] = vals[base + (i + u) * slice_size];
+                cc[u] = cols[base + (i + u) * slice_size];
+            }
+            T xv[fmt_unroll];
+#pragma unroll
+            for (int u = 0; u < fmt_unroll; ++u) {
+                xv[u] = cc[u] >= 0 ? b[int64_t(cc[u]) * ldb + j] : T(0);
+            }
+#pragma unroll
+            for (int u = 0; u < fmt_unroll; ++u) {
+                if (cc[u] >= 0) {
+                    sum += ADV ? (alpha * v[u]) * xv[u] : v[u] * xv[u];
+                }
+            }
+        }
+        for (; i < len; ++i) {
+            const I cc = cols[base + i * slice_size];
+            if (cc >= 0) {
+                const T v = vals[base + i * slice_size];
+                const T xv = b[int64_t(cc) * ldb + j];
+                sum += ADV ? (alpha * v) * xv : v * xv;
+            }
+        }
+        c[row * ldc + j] = sum;
+    }
+}
+
+// ------------------------------------------------------------- conversions
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void csr_to_ell_kernel(
+    int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    const T* __restrict__ vals, int64_t k_per_row, int64_t stride,
+    I* __restrict__ ell_cols, T* __restrict__ ell_vals)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    const int64_t a = row_ptrs[row];
+    const int64_t len = row_ptrs[row + 1] - a;
+    for (int64_t i = 0; i < k_per_row; ++i) {
+        const bool in = i < len;
+        ell_vals[row + i * stride] = in ? vals[a + i] : T(0);
+        ell_cols[row + i * stride] = in ? cols[a + i] : I(-1);
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void csr_to_sellp_kernel(
+    int64_t n_rows, int64_t slice_size, const I* __restrict__ row_ptrs,
+    const I* __restrict__ cols, const T* __restrict__ vals,
+    const uint64_t* __restrict__ slice_sets, I* __restrict__ s_cols,
+    T* __restrict__ s_vals)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    const int64_t slice = row / slice_size;
+    const int64_t local = row - slice * slice_size;
+    const int64_t len_slice =
+        int64_t(slice_sets[slice + 1]) - int64_t(slice_sets[slice]);
+    const int64_t base = int64_t(slice_sets[slice]) * slice_size + local;
+    const int64_t a = row_ptrs[row];
+    const int64_t len = row_ptrs[row + 1] - a;
+    for (int64_t i = 0; i < len_slice; ++i) {
+        const bool in = i < len;
+        s_vals[base + i * slice_size] = in ? vals[a + i] : T(0);
+        s_cols[base + i * slice_size] = in ? cols[a + i] : I(-1);
+    }
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void max_row_nnz_kernel(
+    int64_t n_rows, const I* __restrict__ row_ptrs,
+    unsigned long long* __restrict__ result)
+{
+    __shared__ unsigned long long lds[4];
+    unsigned long long m = 0;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n_rows;
+         i += stride) {
+        const unsigned long long len = (unsigned long long)(row_ptrs[i + 1] - row_ptrs[i]);
+        m = len > m ? len : m;
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) m = lds[w] > m ? lds[w] : m;
+        atomicMax(result, m);
+    }
+}
+
+// one wave per slice when slice_size <= 64, else strided
+template <typename I>
+__global__ __launch_bounds__(256) void slice_lengths_kernel(
+    int64_t n_rows, int64_t n_slices, int64_t slice_size,
+    int64_t stride_factor, const I* __restrict__ row_ptrs,
+    uint64_t* __restrict__ slice_lengths)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t slice = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (slice >= n_slices) return;
+    unsigned long long m = 0;
+    for (int64_t l = lane; l < slice_size; l += 64) {
+        const int64_t row = slice * slice_size + l;
+        if (row < n_rows) {
+            const unsigned long long len =
+                (unsigned long long)(row_ptrs[row + 1] - row_ptrs[row]);
+            const unsigned long long padded =
+                (len + stride_factor - 1) / stride_factor * stride_factor;
+            m = padded > m ? padded : m;
+        }
+    }
+    m = wave_max(m);
+    if (lane == 0) slice_lengths[slice] = m;
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void ptrs_to_sizes_kernel(
+    int64_t n, const I* __restrict__ ptrs, uint64_t* __restrict__ sizes)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) sizes[i] = uint64_t(ptrs[i + 1] - ptrs[i]);
+}
+
+// idxs sorted ascending; ptrs[r] = first position with idxs[pos] >= r
+// (reference convert_idxs_to_ptrs, reference/components/format_conversion.hpp)
+template <typename I>
+__global__ __launch_bounds__(256) void idxs_to_ptrs_kernel(
+    int64_t num_idxs, const I* __restrict__ idxs, int64_t n,
+    I* __restrict__ ptrs)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i > num_idxs) return;
+    const int64_t lo = i == 0 ? 0 : int64_t(idxs[i - 1]) + 1;
+    const int64_t hi = i == num_idxs ? n : int64_t(idxs[i]);
+    for (int64_t r = lo; r <= hi && r <= n; ++r) ptrs[r] = I(i);
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void fill_idx_kernel(int64_t n, I* data,
+                                                        I value, bool seq)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+        data[i] = seq ? I(i) : value;
+    }
+}
+
+inline unsigned blocks_for(int64_t n)
+{
+    return unsigned(ceildiv(n > 0 ? n : 1, 256));
+}
+
+template <typename T, typename I, bool ADV>
+int launch_ell(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t k,
+               int64_t stride, const T* alpha, const I* cols, const T* vals,
+               const T* b, int64_t ldb, const T* beta, T* c, int64_t ldc,
+               int64_t nrhs)
+{
+    (void)n_cols;
+    GKOC_REQUIRE(n_rows >= 0 && k >= 0 && nrhs >= 0 && stride >= n_rows,
+                 GKOC_E_INVALID, "bad ELL dimensions");
+    if (n_rows == 0 || nrhs == 0) return GKOC_OK;
+    if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
+    ell_spmv_kernel<T, I, ADV><<<dim3(blocks_for(n_rows)), dim3(256), 0, as_stream(s)>>>(
+        n_rows, k, stride, cols, vals, b, ldb, c, ldc, int(nrhs), alpha, beta);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+template <typename T, typename I, bool ADV>
+int launch_sellp(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,
+                 int64_t slice_size, const T* alpha, const uint64_t* slice_sets,
+                 const uint64_t* slice_lengths, const I* cols, const T* vals,
+                 const T* b, int64_t ldb, const T* beta, T* c, int64_t ldc,
+                 int64_t nrhs)
+{
+    (void)n_cols;
+    GKOC_REQUIRE(n_rows >= 0 && slice_size >= 1 && nrhs >= 0, GKOC_E_INVALID,
+                 "bad SELL-P dimensions");
+    if (n_rows == 0 || nrhs == 0) return GKOC_OK;
+    if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
+    sellp_spmv_kernel<T, I, ADV>
+        <<<dim3(blocks_for(n_rows)), dim3(256), 0, as_stream(s)>>>(
+            n_rows, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c,
+            ldc, int(nrhs), alpha, beta);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+}  // namespace
+}  // namespace gkoc
+
+using namespace gkoc;
+
+#define GKOC_DEF_FMT(T, TN, I, IN)                                             \
+    extern "C" int gkoc_ell_spmv_##TN##_##IN(                                  \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t k,            \
+        int64_t stride, const I* cols, const T* vals, const T* b,              \
+        int64_t ldb, T* c, int64_t ldc, int64_t nrhs)                          \
+    {                                                                          \
+        return launch_ell<T, I, false>(s, n_rows, n_cols, k, stride, nullptr,  \
+                                       cols, vals, b, ldb, nullptr, c, ldc,    \
+                                       nrhs);                                  \
+    }                                                                          \
+    extern "C" int gkoc_ell_advanced_spmv_##TN##_##IN(                         \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t k,            \
+        int64_t stride, const T* alpha, const I* cols, const T* vals,          \
+        const T* b, int64_t ldb, const T* beta, T* c, int64_t ldc,             \
+        int64_t nrhs)                                                          \
+    {                                                                          \
+        return launch_ell<T, I, true>(s, n_rows, n_cols, k, stride, alpha,     \
+                                      cols, vals, b, ldb, beta, c, ldc, nrhs); \
+    }                                                                          \
+    extern "C" int gkoc_sellp_spmv_##TN##_##IN(                                \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t slice_size,   \
+        const uint64_t* slice_sets, const uint64_t* slice_lengths,             \
+        const I* cols, const T* vals, const T* b, int64_t ldb, T* c,           \
+        int64_t ldc, int64_t nrhs)                                             \
+    {                                                                          \
+        return launch_sellp<T, I, false>(s, n_rows, n_cols, slice_size,        \
+                                         nullptr, slice_sets, slice_lengths,   \
+                                         cols, vals, b, ldb, nullptr, c, ldc,  \
+                                         nrhs);                                \
+    }                                                                          \
+    extern "C" int gkoc_sellp_advanced_spmv_##TN##_##IN(                       \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t slice_size,   \
+        const T* alpha, const uint64_t* slice_sets,                            \
+        const uint64_t* slice_lengths, const I* cols, const T* vals,           \
+        const T* b, int64_t ldb, const T* beta, T* c, int64_t ldc,             \
+        int64_t nrhs)                                                          \
+    {                                                                          \
+        return launch_sellp<T, I, true>(s, n_rows, n_cols, slice_size, alpha,  \
+                                        slice_sets, slice_lengths, cols, vals, \
+                                        b, ldb, beta, c, ldc, nrhs);           \
+    }                                                                          \
+    extern "C" int gkoc_csr_convert_to_ell_##TN##_##IN(                        \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,     \
+        const T* vals, int64_t k, int64_t stride, I* ell_cols, T* ell_vals)    \
+    {                                                                          \
+        if (n_rows <= 0) return GKOC_OK;                                       \
+        csr_to_ell_kernel<T, I>                                                \
+            <<<dim3(blocks_for(n_rows)), dim3(256), 0, as_stream(s)>>>(        \
+                n_rows, row_ptrs, cols, vals, k, stride, ell_cols, ell_vals);  \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_csr_convert_to_sellp_##TN##_##IN(                      \
+        gkoc_stream_t s, int64_t n_rows, int64_t slice_size,                   \
+        const I* row_ptrs, const I* cols, const T* vals,                       \
+        const uint64_t* slice_sets, I* s_cols, T* s_vals)                      \
+    {                                                                          \
+        if (n_rows <= 0) return GKOC_OK;                                       \
+        csr_to_sellp_kernel<T, I>                                              \
+            <<<dim3(blocks_for(n_rows)), dim3(256), 0, as_stream(s)>>>(        \
+                n_rows, slice_size, row_ptrs, cols, vals, slice_sets, s_cols,  \
+                s_vals);                                                       \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }
+
+GKOC_DEF_FMT(double, f64, int32_t, i32)
+GKOC_DEF_FMT(double, f64, int64_t, i64)
+GKOC_DEF_FMT(float, f32, int32_t, i32)
+GKOC_DEF_FMT(float, f32, int64_t, i64)
+
+#define GKOC_DEF_IDX(I, IN)                                                    \
+    extern "C" int gkoc_compute_max_row_nnz_##IN(                              \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, int64_t* max_host) \
+    {                                                                          \
+        GKOC_REQUIRE(max_host, GKOC_E_INVALID, "null result");                 \
+        *max_host = 0;                                                         \
+        if (n_rows <= 0) return GKOC_OK;                                       \
+        unsigned long long* d = nullptr;                                       \
+        GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&d), 8, as_stream(s))); \
+        GKOC_HIP(hipMemsetAsync(d, 0, 8, as_stream(s)));                       \
+        int64_t nb = ceildiv(n_rows, 256);                                     \
+        if (nb > max_stream_blocks) nb = max_stream_blocks;                    \
+        max_row_nnz_kernel<I><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>( \
+            n_rows, row_ptrs, d);                                              \
+        GKOC_LAUNCH_OK();                                                      \
+        unsigned long long h = 0;                                              \
+        GKOC_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, as_stream(s))); \
+        GKOC_HIP(hipStreamSynchronize(as_stream(s)));                          \
+        GKOC_HIP(hipFreeAsync(d, as_stream(s)));                               \
+        *max_host = int64_t(h);                                                \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_sellp_compute_slice_sets_##IN(                         \
+        gkoc_stream_t s, int64_t n_rows, int64_t slice_size,                   \
+        int64_t stride_factor, const I* row_ptrs, uint64_t* slice_sets,        \
+        uint64_t* slice_lengths)                                               \
+    {                                                                          \
+        GKOC_REQUIRE(slice_size >= 1 && stride_factor >= 1, GKOC_E_INVALID,    \
+                     "bad slice parameters");                                  \
+        const int64_t n_slices = ceildiv(n_rows, slice_size);                  \
+        if (n_slices > 0) {                                                    \
+            slice_lengths_kernel<I>                                            \
+                <<<dim3(unsigned(ceildiv(n_slices, 4))), dim3(256), 0,         \
+                   as_stream(s)>>>(n_rows, n_slices, slice_size,               \
+                                   stride_factor, row_ptrs, slice_lengths);    \
+            GKOC_LAUNCH_OK();                                                  \
+            GKOC_HIP(hipMemcpyAsync(slice_sets, slice_lengths,                 \
+                                    sizeof(uint64_t) * n_slices,               \
+                                    hipMemcpyDeviceToDevice, as_stream(s)));   \
+        }                                                                      \
+        GKOC_HIP(hipMemsetAsync(slice_sets + n_slices, 0, sizeof(uint64_t),    \
+                                as_stream(s)));                                \
+        return device_exclusive_scan<unsigned long long>(                      \
+            as_stream(s), reinterpret_cast<unsigned long long*>(slice_sets),   \
+            n_slices + 1);                                                     \
+    }                                                                          \
+    extern "C" int gkoc_convert_ptrs_to_sizes_##IN(                            \
+        gkoc_stream_t s, int64_t n, const I* ptrs, uint64_t* sizes)            \
+    {                                                                          \
+        if (n <= 0) return GKOC_OK;                                            \
+        ptrs_to_sizes_kernel<I>                                                \
+            <<<dim3(blocks_for(n)), dim3(256), 0, as_stream(s)>>>(n, ptrs,     \
+                                                                  sizes);      \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_convert_idxs_to_ptrs_##IN(                             \
+        gkoc_stream_t s, int64_t num_idxs, const I* idxs, int64_t n, I* ptrs)  \
+    {                                                                          \
+        GKOC_REQUIRE(num_idxs >= 0 && n >= 0, GKOC_E_INVALID, "negative size"); \
+        idxs_to_ptrs_kernel<I>                                                 \
+            <<<dim3(blocks_for(num_idxs + 1)), dim3(256), 0, as_stream(s)>>>(  \
+                num_idxs, idxs, n, ptrs);                                      \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_prefix_sum_nonnegative_##IN(gkoc_stream_t s,           \
+                                                    I* counts, int64_t n)      \
+    {                                                                          \
+        return device_exclusive_scan<I>(as_stream(s), counts, n);              \
+    }                                                                          \
+    extern "C" int gkoc_fill_array_##IN(gkoc_stream_t s, I* data, int64_t n,   \
+                                        I value)                               \
+    {                                                                          \
+        if (n <= 0) return GKOC_OK;                                            \
+        int64_t nb = ceildiv(n, 256);                                          \
+        if (nb > max_stream_blocks) nb = max_stream_blocks;                    \
+        fill_idx_kernel<I><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>( \
+            n, data, value, false);                                            \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_fill_seq_array_##IN(gkoc_stream_t s, I* data,          \
+                                            int64_t n)                         \
+    {                                                                          \
+        if (n <= 0) return GKOC_OK;                                            \
+        int64_t nb = ceildiv(n, 256);                                          \
+        if (nb > max_stream_blocks) nb = max_stream_blocks;                    \
+        fill_idx_kernel<I><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>( \
+            n, data, I(0), true);                                              \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }
+
+GKOC_DEF_IDX(int32_t, i32)
+GKOC_DEF_IDX(int64_t, i64)
+
+extern "C" int gkoc_prefix_sum_nonnegative_u64(gkoc_stream_t s, uint64_t* counts,
+                                               int64_t n)
+{
+    return device_exclusive_scan<unsigned long long>(
+        as_stream(s), reinterpret_cast<unsigned long long*>(counts), n);
+}

@@ -1,0 +1,172 @@
+// Runtime services of libgko_cdna4: error reporting, device query, memory and
+// stream management.  These are the C-ABI equivalents of the HipExecutor
+// member functions that Ginkgo stubs in core/device_hooks/hip_hooks.cpp:21-252
+// and implements for its own backend in hip/base/executor.hip.cpp.
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+
+#include "common.hpp"
+
+namespace gkoc {
+
+static thread_local char g_last_error[1024] = "";
+
+void set_last_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+    set_last_error("%s:%d: %s failed: %s (%d)", file, line, what,
+                   hipGetErrorString(e), static_cast<int>(e));
+    // clear the sticky "last error" so later launch checks start clean
+    (void)hipGetLastError();
+    return static_cast<int>(e) > 0 ? static_cast<int>(e) : GKOC_E_NO_DEVICE;
+}
+
+const device_props& current_device_props()
+{
+    static device_props cache[64];
+    static bool have[64] = {};
+    static std::mutex mtx;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    std::lock_guard<std::mutex> g(mtx);
+    if (!have[dev]) {
+        int cu = 256;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount,
+                                  dev) != hipSuccess) {
+            cu = 256;
+        }
+        cache[dev].num_cu = cu;
+        cache[dev].num_xcd = 8;
+        have[dev] = true;
+    }
+    return cache[dev];
+}
+
+}  // namespace gkoc
+
+using namespace gkoc;
+
+extern "C" {
+
+const char* gkoc_last_error(void) { return g_last_error; }
+
+int gkoc_version(void) { return GKOC_VERSION_MAJOR * 100 + GKOC_VERSION_MINOR; }
+
+int gkoc_get_num_devices(int* count)
+{
+    GKOC_REQUIRE(count, GKOC_E_INVALID, "count == NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return GKOC_OK;
+}
+
+int gkoc_get_device_info(int device_id, gkoc_device_info* info)
+{
+    GKOC_REQUIRE(info, GKOC_E_INVALID, "info == NULL");
+    hipDeviceProp_t p;
+    GKOC_HIP(hipGetDeviceProperties(&p, device_id));
+    std::memset(info, 0, sizeof(*info));
+    info->device_id = device_id;
+    info->num_cu = p.multiProcessorCount;
+    info->wave_size = p.warpSize;
+    info->num_xcd = 8;
+    info->max_threads_per_block = p.maxThreadsPerBlock;
+    info->major = p.major;
+    info->minor = p.minor;
+    info->lds_bytes_per_cu = static_cast<int32_t>(p.maxSharedMemoryPerMultiProcessor);
+    info->hbm_bytes = static_cast<int64_t>(p.totalGlobalMem);
+    std::strncpy(info->arch, p.gcnArchName, sizeof(info->arch) - 1);
+    return GKOC_OK;
+}
+
+int gkoc_set_device(int device_id)
+{
+    GKOC_HIP(hipSetDevice(device_id));
+    return GKOC_OK;
+}
+
+int gkoc_malloc(void** ptr, size_t bytes)
+{
+    GKOC_REQUIRE(ptr, GKOC_E_INVALID, "ptr == NULL");
+    *ptr = nullptr;
+    if (bytes == 0) return GKOC_OK;
+    GKOC_HIP(hipMalloc(ptr, bytes));
+    return GKOC_OK;
+}
+
+int gkoc_free(void* ptr)
+{
+    if (ptr) GKOC_HIP(hipFree(ptr));
+    return GKOC_OK;
+}
+
+int gkoc_memcpy_h2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s)
+{
+    if (bytes == 0) return GKOC_OK;
+    GKOC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_memcpy_d2h(void* dst, const void* src, size_t bytes, gkoc_stream_t s)
+{
+    if (bytes == 0) return GKOC_OK;
+    GKOC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(s)));
+    GKOC_HIP(hipStreamSynchronize(as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_memcpy_d2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s)
+{
+    if (bytes == 0) return GKOC_OK;
+    GKOC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_memset(void* dst, int value, size_t bytes, gkoc_stream_t s)
+{
+    if (bytes == 0) return GKOC_OK;
+    GKOC_HIP(hipMemsetAsync(dst, value, bytes, as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_stream_create(gkoc_stream_t* s)
+{
+    GKOC_REQUIRE(s, GKOC_E_INVALID, "s == NULL");
+    hipStream_t st;
+    GKOC_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *s = st;
+    return GKOC_OK;
+}
+
+int gkoc_stream_destroy(gkoc_stream_t s)
+{
+    if (s) GKOC_HIP(hipStreamDestroy(as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_stream_synchronize(gkoc_stream_t s)
+{
+    GKOC_HIP(hipStreamSynchronize(as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_device_synchronize(void)
+{
+    GKOC_HIP(hipDeviceSynchronize());
+    return GKOC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Device-wide exclusive prefix sum (reduce-then-scan, 2048-element tiles).
+// Used by components::prefix_sum_nonnegative, sellp::compute_slice_sets,
+// jacobi::find_blocks and the format conversions.  Integer-exact.
+#pragma once
+#include "common.hpp"
+
+namespace gkoc {
+
+#ifdef __HIPCC__
+
+constexpr int scan_block = 256;
+constexpr int scan_items = 8;
+constexpr int scan_tile = scan_block * scan_items;
+
+template <typename T>
+__global__ __launch_bounds__(scan_block) void scan_tile_sums(
+    int64_t n, const T* __restrict__ data, T* __restrict__ sums)
+{
+    __shared__ T lds[scan_block / 64];
+    const int64_t base = int64_t(blockIdx.x) * scan_tile;
+    T acc = T(0);
+#pragma unroll
+    for (int u = 0; u < scan_items; ++u) {
+        const int64_t i = base + u * scan_block + threadIdx.x;
+        if (i < n) acc += data[i];
+    }
+    const T r = block_sum<scan_block>(acc, lds);
+    if (threadIdx.x == 0) sums[blockIdx.x] = r;
+}
+
+// exclusive scan of one tile, thread t owns items [t*8, t*8+8) of the tile
+template <typename T>
+__global__ __launch_bounds__(scan_block) void scan_tiles(
+    int64_t n, T* __restrict__ data, const T* __restrict__ offsets)
+{
+    __shared__ T wave_tot[scan_block / 64];
+    const int64_t base = int64_t(blockIdx.x) * scan_tile + threadIdx.x * scan_items;
+    T v[scan_items];
+    T local = T(0);
+#pragma unroll
+    for (int u = 0; u < scan_items; ++u) {
+        const int64_t i = base + u;
+        v[u] = i < n ? data[i] : T(0);
+        local += v[u];
+    }
+    // inclusive scan of `local` across the wave
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    T incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    T wave_off = T(0);
+    for (int w = 0; w < wid; ++w) wave_off += wave_tot[w];
+    T run = (offsets ? offsets[blockIdx.x] : T(0)) + wave_off + (incl - local);
+#pragma unroll
+    for (int u = 0; u < scan_items; ++u) {
+        const int64_t i = base + u;
+        if (i < n) data[i] = run;
+        run += v[u];
+    }
+}
+
+// in-place exclusive scan of data[0..n); data[n-1] ends up with the sum of the
+// first n-1 inputs (Ginkgo's prefix_sum_nonnegative contract,
+// core/components/prefix_sum_kernels.hpp)
+template <typename T>
+int device_exclusive_scan(hipStream_t st, T* data, int64_t n)
+{
+    if (n <= 0) return GKOC_OK;
+    const int64_t tiles = ceildiv(n, scan_tile);
+    if (tiles == 1) {
+        scan_tiles<T><<<dim3(1), dim3(scan_block), 0, st>>>(n, data, nullptr);
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
+    T* sums = nullptr;
+    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&sums), sizeof(T) * tiles, st));
+    scan_tile_sums<T><<<dim3(unsigned(tiles)), dim3(scan_block), 0, st>>>(n, data, sums);
+    GKOC_LAUNCH_OK();
+    int rc = device_exclusive_scan<T>(st, sums, tiles);
+    if (rc != GKOC_OK) return rc;
+    scan_tiles<T><<<dim3(unsigned(tiles)), dim3(scan_block), 0, st>>>(n, data, sums);
+    GKOC_LAUNCH_OK();
+    GKOC_HIP(hipFreeAsync(sums, st));
+    return GKOC_OK;
+}
+
+#endif
+
+}  // namespace gkoc

@@ -1,0 +1,383 @@
+"""Matrix formats on the Cdna4Executor: Dense, Csr, Ell, Sellp.
+
+Host-side mirror of include/ginkgo/core/matrix/{dense,csr,ell,sellp}.hpp for
+the hot path: same method names, argument meaning and error behaviour; every
+numerical method is one call into libgko_cdna4.so (no torch arithmetic).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DimensionMismatch, GkoError, IT, VT, call, cval
+from .base import LinOp
+
+
+def _np_dtype(t):
+    return {torch.float64: np.float64, torch.float32: np.float32,
+            torch.int32: np.int32, torch.int64: np.int64,
+            torch.uint8: np.uint8}[t]
+
+
+class Dense(LinOp):
+    """Row-major dense matrix with row stride (dense.hpp:88).  `values` is a
+    2-D torch view whose row stride is the Ginkgo stride."""
+
+    def __init__(self, exec_, values):
+        assert values.dim() == 2
+        if values.shape[1] > 0 and values.shape[0] > 0 and values.stride(1) != 1:
+            raise GkoError("Dense: column stride must be 1")
+        super().__init__(exec_, values.shape)
+        self.values = values
+        self._tmp = None
+
+    # -- construction
+    @staticmethod
+    def create(exec_, size, dtype=torch.float64, stride=None):
+        rows, cols = size
+        stride = cols if stride is None else stride
+        if stride < cols:
+            raise GkoError("Dense: stride smaller than number of columns")
+        store = exec_.alloc((rows, max(stride, 1)), dtype)
+        return Dense(exec_, store[:, :cols])
+
+    @staticmethod
+    def from_numpy(exec_, array, stride=None):
+        a = np.asarray(array)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        d = Dense.create(exec_, a.shape, torch.from_numpy(a[:0]).dtype, stride)
+        d.values.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+        return d
+
+    def to_numpy(self):
+        return self.values.detach().cpu().numpy().copy()
+
+    def clone(self):
+        out = Dense.create(self.exec, self.size, self.dtype, self.stride)
+        out.copy_from(self)
+        return out
+
+    def create_submatrix(self, rows, cols):
+        """dense.hpp create_submatrix(span rows, span cols): a strided view."""
+        return Dense(self.exec, self.values[rows[0]:rows[1], cols[0]:cols[1]])
+
+    # -- accessors
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    @property
+    def ld(self):
+        s = self.values.stride(0)
+        return s if s >= self.size[1] else max(self.size[1], 1)
+
+    stride = ld
+
+    def _suf(self):
+        return VT[self.dtype]
+
+    def _work(self, cols):
+        need = _lib.lib().gkoc_reduction_workspace_bytes(
+            C.c_int64(self.size[0]), C.c_int64(cols),
+            C.c_size_t(self.values.element_size()))
+        if self._tmp is None or self._tmp.numel() < need:
+            self._tmp = self.exec.alloc((need,), torch.uint8)
+        return self._tmp
+
+    def _check_same(self, other):
+        if other.size != self.size:
+            raise DimensionMismatch(f"expected {self.size}, got {other.size}")
+
+    def _check_alpha(self, alpha):
+        if alpha.size[0] != 1 or alpha.size[1] not in (1, self.size[1]):
+            raise DimensionMismatch(
+                f"scalar must be 1 x 1 or 1 x {self.size[1]}, got {alpha.size}")
+
+    # -- BLAS-1 (dense.hpp scale / add_scaled / compute_dot / compute_norm2)
+    def fill(self, value):
+        call("gkoc_dense_fill_" + self._suf(), self.exec.stream, self.size[0],
+             self.size[1], self.values, self.ld, cval(self.dtype, value))
+        return self
+
+    def copy_from(self, other):
+        self._check_same(other)
+        call("gkoc_dense_copy_" + self._suf(), self.exec.stream, self.size[0],
+             self.size[1], other.values, other.ld, self.values, self.ld)
+        return self
+
+    def scale(self, alpha):
+        self._check_alpha(alpha)
+        call("gkoc_dense_scale_" + self._suf(), self.exec.stream, self.size[0],
+             self.size[1], alpha.values, alpha.size[1], self.values, self.ld)
+        return self
+
+    def inv_scale(self, alpha):
+        self._check_alpha(alpha)
+        call("gkoc_dense_inv_scale_" + self._suf(), self.exec.stream,
+             self.size[0], self.size[1], alpha.values, alpha.size[1],
+             self.values, self.ld)
+        return self
+
+    def add_scaled(self, alpha, b):
+        self._check_alpha(alpha)
+        self._check_same(b)
+        call("gkoc_dense_add_scaled_" + self._suf(), self.exec.stream,
+             self.size[0], self.size[1], alpha.values, alpha.size[1], b.values,
+             b.ld, self.values, self.ld)
+        return self
+
+    def sub_scaled(self, alpha, b):
+        self._check_alpha(alpha)
+        self._check_same(b)
+        call("gkoc_dense_sub_scaled_" + self._suf(), self.exec.stream,
+             self.size[0], self.size[1], alpha.values, alpha.size[1], b.values,
+             b.ld, self.values, self.ld)
+        return self
+
+    def compute_dot(self, b, result):
+        self._check_same(b)
+        if result.size != (1, self.size[1]):
+            raise DimensionMismatch(f"result must be 1 x {self.size[1]}")
+        w = self._work(self.size[1])
+        call("gkoc_dense_compute_dot_" + self._suf(), self.exec.stream,
+             self.size[0], self.size[1], self.values, self.ld, b.values, b.ld,
+             result.values, w, C.c_size_t(w.numel()))
+        return result
+
+    compute_conj_dot = compute_dot  # real value types
+
+    def compute_norm2(self, result):
+        if result.size != (1, self.size[1]):
+            raise DimensionMismatch(f"result must be 1 x {self.size[1]}")
+        w = self._work(self.size[1])
+        call("gkoc_dense_compute_norm2_" + self._suf(), self.exec.stream,
+             self.size[0], self.size[1], self.values, self.ld, result.values, w,
+             C.c_size_t(w.numel()))
+        return result
+
+    def compute_squared_norm2(self, result):
+        if result.size != (1, self.size[1]):
+            raise DimensionMismatch(f"result must be 1 x {self.size[1]}")
+        w = self._work(self.size[1])
+        call("gkoc_dense_compute_squared_norm2_" + self._suf(),
+             self.exec.stream, self.size[0], self.size[1], self.values, self.ld,
+             result.values, w, C.c_size_t(w.numel()))
+        return result
+
+    def row_gather(self, row_idxs, gathered):
+        """dense.hpp row_gather: gathered(i, :) = self(row_idxs[i], :)."""
+        if gathered.size != (row_idxs.numel(), self.size[1]):
+            raise DimensionMismatch("row_gather: bad target size")
+        call(f"gkoc_dense_row_gather_{self._suf()}_{IT[row_idxs.dtype]}",
+             self.exec.stream, row_idxs.numel(), self.size[1], row_idxs,
+             self.values, self.ld, gathered.values, gathered.ld)
+        return gathered
+
+
+def scalar(exec_, value, dtype=torch.float64):
+    """1 x 1 device-resident Dense, like gko::initialize<Dense>({v}, exec)."""
+    return Dense.from_numpy(exec_, np.array([[value]], dtype=_np_dtype(dtype)))
+
+
+class _SparseBase(LinOp):
+    def _operands(self, b, x):
+        if b.dtype != self.dtype or x.dtype != self.dtype:
+            raise _lib.NotSupported("mixed-precision apply is not supported")
+        return b.values, b.ld, x.values, x.ld, b.size[1]
+
+
+class Csr(_SparseBase):
+    """csr.hpp:104.  The strategy argument is accepted for API compatibility
+    (classical / load_balance / merge_path / sparselib / automatical): this
+    backend has one row-segment-per-wavefront kernel for all of them."""
+
+    def __init__(self, exec_, size, values, col_idxs, row_ptrs,
+                 strategy="automatical"):
+        super().__init__(exec_, size)
+        if row_ptrs.numel() != self.size[0] + 1:
+            raise GkoError("Csr: row_ptrs must have num_rows + 1 entries")
+        if values.numel() != col_idxs.numel():
+            raise GkoError("Csr: values / col_idxs length mismatch")
+        if col_idxs.dtype != row_ptrs.dtype:
+            raise GkoError("Csr: index arrays must share one type")
+        self.values, self.col_idxs, self.row_ptrs = values, col_idxs, row_ptrs
+        self.strategy = strategy
+
+    @staticmethod
+    def from_scipy(exec_, a, index_dtype=np.int32, strategy="automatical"):
+        a = a.tocsr()
+        return Csr(exec_, a.shape, exec_.to_device(np.asarray(a.data)),
+                   exec_.to_device(a.indices.astype(index_dtype)),
+                   exec_.to_device(a.indptr.astype(index_dtype)), strategy)
+
+    @staticmethod
+    def from_arrays(exec_, size, row_ptrs, col_idxs, values,
+                    strategy="automatical"):
+        return Csr(exec_, size, exec_.to_device(values),
+                   exec_.to_device(col_idxs), exec_.to_device(row_ptrs),
+                   strategy)
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    def _suf(self):
+        return f"{VT[self.values.dtype]}_{IT[self.col_idxs.dtype]}"
+
+    def get_num_stored_elements(self):
+        return self.values.numel()
+
+    def apply_impl(self, b, x):
+        bv, ldb, xv, ldx, nrhs = self._operands(b, x)
+        call("gkoc_csr_spmv_" + self._suf(), self.exec.stream, self.size[0],
+             self.size[1], self.row_ptrs, self.col_idxs, self.values, bv, ldb,
+             xv, ldx, nrhs)
+
+    def apply_advanced_impl(self, alpha, b, beta, x):
+        bv, ldb, xv, ldx, nrhs = self._operands(b, x)
+        call("gkoc_csr_advanced_spmv_" + self._suf(), self.exec.stream,
+             self.size[0], self.size[1], alpha.values, self.row_ptrs,
+             self.col_idxs, self.values, bv, ldb, beta.values, xv, ldx, nrhs)
+
+    def extract_diagonal(self):
+        n = min(self.size)
+        d = self.exec.zeros((n,), self.dtype)
+        call("gkoc_csr_extract_diagonal_" + self._suf(), self.exec.stream,
+             self.size[0], self.size[1], self.row_ptrs, self.col_idxs,
+             self.values, d)
+        return d
+
+    def is_sorted_by_column_index(self):
+        flag = C.c_int(1)
+        call("gkoc_csr_is_sorted_by_column_index_" + self._suf(),
+             self.exec.stream, self.size[0], self.row_ptrs, self.col_idxs,
+             C.byref(flag))
+        return bool(flag.value)
+
+    def sort_by_column_index(self):
+        call("gkoc_csr_sort_by_column_index_" + self._suf(), self.exec.stream,
+             self.size[0], self.row_ptrs, self.col_idxs, self.values)
+        return self
+
+    def convert_to_ell(self, num_stored_per_row=None, stride=None):
+        it = IT[self.col_idxs.dtype]
+        if num_stored_per_row is None:
+            m = C.c_int64(0)
+            call("gkoc_compute_max_row_nnz_" + it, self.exec.stream,
+                 self.size[0], self.row_ptrs, C.byref(m))
+            num_stored_per_row = m.value
+        stride = self.size[0] if stride is None else stride
+        cols = self.exec.alloc((num_stored_per_row * stride,), self.col_idxs.dtype)
+        vals = self.exec.alloc((num_stored_per_row * stride,), self.dtype)
+        if stride > self.size[0]:
+            cols.fill_(-1)
+            vals.zero_()
+        call("gkoc_csr_convert_to_ell_" + self._suf(), self.exec.stream,
+             self.size[0], self.row_ptrs, self.col_idxs, self.values,
+             num_stored_per_row, stride, cols, vals)
+        return Ell(self.exec, self.size, vals, cols, num_stored_per_row, stride)
+
+    def convert_to_sellp(self, slice_size=64, stride_factor=1):
+        it = IT[self.col_idxs.dtype]
+        n_slices = (self.size[0] + slice_size - 1) // slice_size
+        # uint64 arrays are carried as int64 tensors (same bits)
+        sets = self.exec.zeros((n_slices + 1,), torch.int64)
+        lens = self.exec.zeros((max(n_slices, 1),), torch.int64)[:n_slices]
+        call("gkoc_sellp_compute_slice_sets_" + it, self.exec.stream,
+             self.size[0], slice_size, stride_factor, self.row_ptrs, sets, lens)
+        total = int(sets[-1].item()) * slice_size
+        cols = self.exec.alloc((total,), self.col_idxs.dtype)
+        vals = self.exec.alloc((total,), self.dtype)
+        if total:
+            cols.fill_(-1)   # rows past num_rows in the last slice stay padding
+            vals.zero_()
+        call("gkoc_csr_convert_to_sellp_" + self._suf(), self.exec.stream,
+             self.size[0], slice_size, self.row_ptrs, self.col_idxs,
+             self.values, sets, cols, vals)
+        return Sellp(self.exec, self.size, vals, cols, sets, lens, slice_size,
+                     stride_factor)
+
+
+class Ell(_SparseBase):
+    """ell.hpp: column-major, entry (row, j) at row + j*stride, padding -1."""
+
+    def __init__(self, exec_, size, values, col_idxs, num_stored_per_row,
+                 stride):
+        super().__init__(exec_, size)
+        self.values, self.col_idxs = values, col_idxs
+        self.num_stored_per_row, self.stride = int(num_stored_per_row), int(stride)
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    def _suf(self):
+        return f"{VT[self.values.dtype]}_{IT[self.col_idxs.dtype]}"
+
+    def apply_impl(self, b, x):
+        bv, ldb, xv, ldx, nrhs = self._operands(b, x)
+        call("gkoc_ell_spmv_" + self._suf(), self.exec.stream, self.size[0],
+             self.size[1], self.num_stored_per_row, self.stride, self.col_idxs,
+             self.values, bv, ldb, xv, ldx, nrhs)
+
+    def apply_advanced_impl(self, alpha, b, beta, x):
+        bv, ldb, xv, ldx, nrhs = self._operands(b, x)
+        call("gkoc_ell_advanced_spmv_" + self._suf(), self.exec.stream,
+             self.size[0], self.size[1], self.num_stored_per_row, self.stride,
+             alpha.values, self.col_idxs, self.values, bv, ldb, beta.values, xv,
+             ldx, nrhs)
+
+
+class Sellp(_SparseBase):
+    """sellp.hpp:27 (slice_size 64 = one wavefront per slice)."""
+
+    def __init__(self, exec_, size, values, col_idxs, slice_sets,
+                 slice_lengths, slice_size=64, stride_factor=1):
+        super().__init__(exec_, size)
+        self.values, self.col_idxs = values, col_idxs
+        self.slice_sets, self.slice_lengths = slice_sets, slice_lengths
+        self.slice_size, self.stride_factor = int(slice_size), int(stride_factor)
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    def _suf(self):
+        return f"{VT[self.values.dtype]}_{IT[self.col_idxs.dtype]}"
+
+    def apply_impl(self, b, x):
+        bv, ldb, xv, ldx, nrhs = self._operands(b, x)
+        call("gkoc_sellp_spmv_" + self._suf(), self.exec.stream, self.size[0],
+             self.size[1], self.slice_size, self.slice_sets, self.slice_lengths,
+             self.col_idxs, self.values, bv, ldb, xv, ldx, nrhs)
+
+    def apply_advanced_impl(self, alpha, b, beta, x):
+        bv, ldb, xv, ldx, nrhs = self._operands(b, x)
+        call("gkoc_sellp_advanced_spmv_" + self._suf(), self.exec.stream,
+             self.size[0], self.size[1], self.slice_size, alpha.values,
+             self.slice_sets, self.slice_lengths, self.col_idxs, self.values,
+             bv, ldb, beta.values, xv, ldx, nrhs)
+
+
+def stencil_csr(exec_, nd, g, restricted=False, dtype=torch.float64,
+                index_dtype=torch.int32, z0=0, nz=None):
+    """Benchmark stencil matrix generated on the device
+    (benchmark/utils/stencil_matrix.hpp:68-453).  Returns the Csr of the rows
+    of planes [z0, z0+nz) with global column indices (default: whole matrix)."""
+    nz = g if nz is None else nz
+    n_local = nz * (g * g if nd == 3 else g)
+    n_global = g ** nd
+    it, vt = IT[index_dtype], VT[dtype]
+    row_ptrs = exec_.alloc((n_local + 1,), index_dtype)
+    nnz = C.c_int64(0)
+    call("gkoc_stencil_row_ptrs_" + it, exec_.stream, C.c_int(nd), g,
+         C.c_int(int(restricted)), z0, nz, row_ptrs, C.byref(nnz))
+    if index_dtype == torch.int32 and nnz.value >= 2 ** 31:
+        raise GkoError("stencil_csr: nnz overflows int32")
+    cols = exec_.alloc((nnz.value,), index_dtype)
+    vals = exec_.alloc((nnz.value,), dtype)
+    call(f"gkoc_stencil_fill_{vt}_{it}", exec_.stream, C.c_int(nd), g,
+         C.c_int(int(restricted)), z0, nz, row_ptrs, cols, vals)
+    return Csr(exec_, (n_local, n_global), vals, cols, row_ptrs)

@@ -1,0 +1,138 @@
+"""Jacobi preconditioner (scalar and block) - mirror of
+include/ginkgo/core/preconditioner/jacobi.hpp and
+core/preconditioner/jacobi.cpp:150-165 (apply) / :328-404 (generate).
+
+`Jacobi.build().with_max_block_size(8).on(exec).generate(A)` detects the
+blocks (jacobi::find_blocks), inverts them (jacobi::generate) and applies them
+(jacobi::simple_apply / apply), all on the device through libgko_cdna4.so.
+max_block_size == 1 takes Ginkgo's scalar path (extract_diagonal +
+invert_diagonal + simple_scalar_apply).  Adaptive precision
+(storage_optimization) is not supported and raises NotSupported.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import IT, VT, JacobiScheme, NotSupported, call
+from .base import LinOp
+from .matrix import Csr
+
+
+def compute_storage_scheme(max_block_size, warp_size=64):
+    """jacobi.hpp:589-627 with max_block_stride = warp size (64 on this GPU)."""
+    if max_block_size < 1 or max_block_size > warp_size:
+        raise NotSupported("max_block_size must be in [1, 64]")
+    p2 = 1
+    while p2 < max_block_size:
+        p2 *= 2
+    group_size = warp_size // p2
+    block_offset = max_block_size
+    group_offset = max_block_size * group_size * block_offset
+    return JacobiScheme(block_offset, group_offset, group_size.bit_length() - 1)
+
+
+class JacobiFactory:
+    def __init__(self):
+        self.max_block_size = 32
+        self.skip_sorting = False
+        self.block_pointers = None
+        self.exec = None
+
+    def with_max_block_size(self, v):
+        self.max_block_size = int(v)
+        return self
+
+    def with_skip_sorting(self, v):
+        self.skip_sorting = bool(v)
+        return self
+
+    def with_block_pointers(self, ptrs):
+        self.block_pointers = ptrs
+        return self
+
+    def with_storage_optimization(self, *_):
+        raise NotSupported("adaptive-precision block-Jacobi is not supported")
+
+    def on(self, exec_):
+        self.exec = exec_
+        return self
+
+    def generate(self, system_matrix):
+        return Jacobi(self, system_matrix)
+
+
+class Jacobi(LinOp):
+    @staticmethod
+    def build():
+        return JacobiFactory()
+
+    def __init__(self, factory, a):
+        if not isinstance(a, Csr):
+            raise NotSupported("Jacobi.generate needs a Csr system matrix")
+        if a.size[0] != a.size[1]:
+            from ._lib import DimensionMismatch
+            raise DimensionMismatch("Jacobi needs a square matrix")
+        super().__init__(factory.exec or a.exec, a.size)
+        ex = self.exec
+        self.max_block_size = factory.max_block_size
+        self.dtype = a.dtype
+        self._suf = f"{VT[a.dtype]}_{IT[a.col_idxs.dtype]}"
+        n = a.size[0]
+        if not factory.skip_sorting and not a.is_sorted_by_column_index():
+            a = Csr(ex, a.size, a.values.clone(), a.col_idxs.clone(),
+                    a.row_ptrs, a.strategy).sort_by_column_index()
+        if self.max_block_size == 1:
+            # scalar Jacobi (jacobi.cpp:340-352)
+            diag = a.extract_diagonal()
+            self.inv_diag = ex.alloc((n,), a.dtype)
+            call("gkoc_jacobi_invert_diagonal_" + VT[a.dtype], ex.stream, n,
+                 diag, self.inv_diag)
+            self.num_blocks = n
+            return
+        self.scheme = compute_storage_scheme(self.max_block_size,
+                                             ex.get_warp_size())
+        if factory.block_pointers is not None:
+            self.block_pointers = ex.to_device(factory.block_pointers)
+            self.num_blocks = self.block_pointers.numel() - 1
+        else:
+            self.block_pointers = ex.alloc((n + 1,), a.row_ptrs.dtype)
+            nb = C.c_int64(0)
+            call("gkoc_jacobi_find_blocks_" + self._suf, ex.stream, n,
+                 a.row_ptrs, a.col_idxs, C.c_uint32(self.max_block_size),
+                 C.byref(nb), self.block_pointers)
+            self.num_blocks = nb.value
+            self.block_pointers = self.block_pointers[:self.num_blocks + 1]
+        gs = 1 << self.scheme.group_power
+        storage = ((self.num_blocks + gs - 1) // gs) * self.scheme.group_offset
+        self.blocks = ex.zeros((storage,), a.dtype)
+        call("gkoc_jacobi_generate_" + self._suf, ex.stream, n, a.row_ptrs,
+             a.col_idxs, a.values, self.num_blocks,
+             C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
+             self.blocks, None)
+
+    def get_num_blocks(self):
+        return self.num_blocks
+
+    def apply_impl(self, b, x):
+        ex = self.exec
+        if self.max_block_size == 1:
+            call("gkoc_jacobi_simple_scalar_apply_" + VT[self.dtype], ex.stream,
+                 self.size[0], b.size[1], self.inv_diag, b.values, b.ld,
+                 x.values, x.ld)
+            return
+        call("gkoc_jacobi_simple_apply_" + self._suf, ex.stream,
+             self.num_blocks, C.c_uint32(self.max_block_size), self.scheme,
+             self.block_pointers, self.blocks, b.values, b.ld, x.values, x.ld,
+             b.size[1])
+
+    def apply_advanced_impl(self, alpha, b, beta, x):
+        ex = self.exec
+        if self.max_block_size == 1:
+            call("gkoc_jacobi_scalar_apply_" + VT[self.dtype], ex.stream,
+                 self.size[0], b.size[1], self.inv_diag, alpha.values, b.values,
+                 b.ld, beta.values, x.values, x.ld)
+            return
+        call("gkoc_jacobi_apply_" + self._suf, ex.stream, self.num_blocks,
+             C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
+             self.blocks, alpha.values, b.values, b.ld, beta.values, x.values,
+             x.ld, b.size[1])

@@ -1,0 +1,144 @@
+"""Stopping criteria - mirror of include/ginkgo/core/stop/{iteration,
+residual_norm,combined}.hpp and core/stop/{iteration,residual_norm,
+combined}.cpp.  stop_status is a device uint8 array with Ginkgo's bit layout
+(stopping_status.hpp:117-121)."""
+import ctypes as C
+
+import torch
+
+from ._lib import NotSupported, VT, call, cval
+from .matrix import Dense
+
+
+class mode:
+    absolute = "absolute"
+    initial_resnorm = "initial_resnorm"
+    rhs_norm = "rhs_norm"
+
+
+class _Factory:
+    def __init__(self, cls, **params):
+        self.cls, self.params, self.exec = cls, params, None
+
+    def on(self, exec_):
+        self.exec = exec_
+        return self
+
+    def generate(self, system_matrix, b, x, initial_residual):
+        return self.cls(self, system_matrix, b, x, initial_residual)
+
+    def __getattr__(self, name):
+        if name.startswith("with_"):
+            key = name[5:]
+
+            def setter(v):
+                self.params[key] = v
+                return self
+            return setter
+        raise AttributeError(name)
+
+
+class Iteration:
+    """core/stop/iteration.cpp:15-26"""
+
+    @staticmethod
+    def build():
+        return _Factory(Iteration, max_iters=0)
+
+    def __init__(self, factory, a, b, x, r):
+        self.max_iters = int(factory.params["max_iters"])
+        self.exec = b.exec
+
+    def check(self, stopping_id, set_finalized, stop_status, upd):
+        hit = upd["num_iterations"] >= self.max_iters
+        if hit:
+            call("gkoc_set_all_statuses", self.exec.stream,
+                 stop_status.numel(), C.c_uint8(stopping_id),
+                 C.c_int(int(set_finalized)), stop_status)
+        return hit, hit
+
+
+class ResidualNorm:
+    """core/stop/residual_norm.cpp:75-205"""
+    implicit = False
+
+    @staticmethod
+    def build():
+        return _Factory(ResidualNorm, reduction_factor=5e-7,
+                        baseline=mode.rhs_norm)
+
+    def __init__(self, factory, a, b, x, r):
+        ex = self.exec = b.exec
+        self.reduction_factor = float(factory.params["reduction_factor"])
+        baseline = factory.params["baseline"]
+        cols = b.size[1]
+        self.starting_tau = Dense.create(ex, (1, cols), b.dtype)
+        if baseline == mode.rhs_norm:
+            b.compute_norm2(self.starting_tau)
+        elif baseline == mode.initial_resnorm:
+            if r is None:
+                raise NotSupported("initial_resnorm needs the initial residual")
+            r.compute_norm2(self.starting_tau)
+        elif baseline == mode.absolute:
+            self.starting_tau.fill(1.0)
+        else:
+            raise NotSupported(f"unknown baseline {baseline}")
+        self.u_dense_tau = Dense.create(ex, (1, cols), b.dtype)
+        self.flags = ex.zeros((2,), torch.uint8)
+
+    def check(self, stopping_id, set_finalized, stop_status, upd):
+        ex = self.exec
+        if self.implicit:
+            tau = upd.get("implicit_sq_residual_norm")
+            if tau is None:
+                raise NotSupported("ImplicitResidualNorm needs rho")
+            name = "gkoc_implicit_residual_norm_"
+        else:
+            if upd.get("residual_norm") is not None:
+                tau = upd["residual_norm"]
+            elif upd.get("residual") is not None:
+                upd["residual"].compute_norm2(self.u_dense_tau)
+                tau = self.u_dense_tau
+            else:
+                raise NotSupported("ResidualNorm needs a residual")
+            name = "gkoc_residual_norm_"
+        allc, chg = C.c_int(0), C.c_int(0)
+        call(name + VT[tau.dtype], ex.stream, tau.size[1], tau.values,
+             self.starting_tau.values, cval(tau.dtype, self.reduction_factor),
+             C.c_uint8(stopping_id), C.c_int(int(set_finalized)), stop_status,
+             self.flags, C.byref(allc), C.byref(chg))
+        self.last_tau = tau
+        return bool(allc.value), bool(chg.value)
+
+
+class ImplicitResidualNorm(ResidualNorm):
+    """core/stop/residual_norm.cpp:209-230: sqrt(|rho|) <= factor * tau0"""
+    implicit = True
+
+    @staticmethod
+    def build():
+        return _Factory(ImplicitResidualNorm, reduction_factor=5e-7,
+                        baseline=mode.rhs_norm)
+
+
+class Combined:
+    """core/stop/combined.cpp:33-51: criteria checked in order with ids 1,2,..."""
+
+    def __init__(self, criteria):
+        self.criteria = criteria
+
+    def check(self, stopping_id, set_finalized, stop_status, upd):
+        one_changed = False
+        for i, c in enumerate(self.criteria):
+            conv, chg = c.check(i + 1, set_finalized, stop_status, upd)
+            one_changed |= chg
+            if conv:
+                return True, one_changed
+        return False, one_changed
+
+
+def combine(factories, a, b, x, r):
+    factories = [f for f in factories if f is not None]
+    if not factories:
+        raise NotSupported("no stopping criterion given")
+    return Combined([f.generate(a, b, x, r) for f in factories])

@@ -1,0 +1,397 @@
+/*
+ * gko_cdna4.h -- C ABI of libgko_cdna4.so, the MI355X (gfx950 / CDNA4) sparse
+ * linear-algebra kernel backend for Ginkgo's Krylov hot path.
+ *
+ * Every entry point is the C restatement of ONE kernel symbol that Ginkgo's
+ * core calls through `exec->run(ns::make_<op>(...))` on a HipExecutor, i.e. one
+ * `gko::kernels::hip::<ns>::<op>` function declared by
+ * GKO_DECLARE_FOR_ALL_EXECUTOR_NAMESPACES (core/base/kernel_declaration.hpp:10-39
+ * of the reference).  The Ginkgo-side binding (ginkgo_amd/gko_binding/, see
+ * INTEGRATION.md) unwraps matrix::Csr / matrix::Dense / array<T> objects into
+ * the raw device pointers + sizes taken here.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers unless a parameter is documented `host`;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *    work is enqueued asynchronously on it (HipExecutor::get_stream(),
+ *    include/ginkgo/core/base/executor.hpp:1940);
+ *  - dense operands are row-major with a row stride `ld` counted in elements
+ *    (matrix::Dense, include/ginkgo/core/matrix/dense.hpp:88); nrhs = columns;
+ *  - scalars alpha / beta / rho ... are device-resident 1 x 1 (or 1 x nrhs)
+ *    Dense buffers exactly as in Ginkgo - never dereferenced on the host;
+ *  - suffix _f64/_f32 = value type, _i32/_i64 = index type;
+ *  - return value: 0 on success, a positive hipError_t, or a negative
+ *    GKOC_E_* code; gkoc_last_error() returns a thread-local message.  The
+ *    Ginkgo binding turns non-zero into gko::HipError / gko::NotSupported.
+ *  - nothing here allocates device memory except the gkoc_*_create handles;
+ *    reductions take a caller-owned workspace (Ginkgo's `array<char>& tmp`).
+ */
+#ifndef GKO_CDNA4_H_
+#define GKO_CDNA4_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GKOC_VERSION_MAJOR 0
+#define GKOC_VERSION_MINOR 1
+
+#define GKOC_OK 0
+#define GKOC_E_INVALID (-1)       /* bad argument                       */
+#define GKOC_E_NOT_SUPPORTED (-2) /* combination not implemented        */
+#define GKOC_E_WORKSPACE (-3)     /* workspace too small                */
+#define GKOC_E_NO_DEVICE (-4)     /* no gfx950 device / HIP unavailable */
+#define GKOC_E_COMM (-5)          /* RCCL failure                       */
+
+typedef void* gkoc_stream_t;
+
+/* ------------------------------------------------------------------ runtime
+ * replaces HipExecutor::{raw_alloc,raw_free,raw_copy_to,synchronize,
+ * get_num_devices,set_gpu_property} (core/device_hooks/hip_hooks.cpp:21-252,
+ * hip/base/executor.hip.cpp) */
+typedef struct gkoc_device_info {
+    int32_t device_id;
+    int32_t num_cu;           /* exec_info.num_computing_units           */
+    int32_t wave_size;        /* exec_info.max_subgroup_size (64)        */
+    int32_t num_xcd;          /* 8 on MI355X                             */
+    int32_t max_threads_per_block;
+    int32_t major, minor;     /* 9, 5 for gfx950                         */
+    int32_t lds_bytes_per_cu; /* 163840                                  */
+    int64_t hbm_bytes;
+    char arch[64];            /* "gfx950..."                             */
+} gkoc_device_info;
+
+const char* gkoc_last_error(void);
+int gkoc_version(void);
+int gkoc_get_num_devices(int* count);
+int gkoc_get_device_info(int device_id, gkoc_device_info* info);
+int gkoc_set_device(int device_id);
+int gkoc_malloc(void** ptr, size_t bytes);
+int gkoc_free(void* ptr);
+int gkoc_memcpy_h2d(void* dst, const void* src_host, size_t bytes, gkoc_stream_t s);
+int gkoc_memcpy_d2h(void* dst_host, const void* src, size_t bytes, gkoc_stream_t s);
+int gkoc_memcpy_d2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s);
+int gkoc_memset(void* dst, int value, size_t bytes, gkoc_stream_t s);
+int gkoc_stream_create(gkoc_stream_t* s);
+int gkoc_stream_destroy(gkoc_stream_t s);
+int gkoc_stream_synchronize(gkoc_stream_t s);
+int gkoc_device_synchronize(void);
+
+/* --------------------------------------------------------------- CSR SpMV
+ * csr::spmv            core/matrix/csr_kernels.hpp:29-34
+ * csr::advanced_spmv   core/matrix/csr_kernels.hpp:36-43
+ * semantics = reference/matrix/csr_kernels.cpp:49-78 / :86-118: per row the
+ * products val[k]*b[col[k]] are accumulated in k order with separate
+ * multiply and add roundings => results are BIT-IDENTICAL to the
+ * ReferenceExecutor for rows up to GKOC_CSR_LONG_ROW nnz (longer rows are
+ * summed by a whole wavefront: same value to ~1 ulp*log2(len)).
+ * beta == 0 never reads c (NaN-safe, reference/test/matrix/csr_kernels.cpp:521-534). */
+#define GKOC_CSR_LONG_ROW 4096
+#define GKOC_DECL_CSR(T, TN, I, IN)                                            \
+    int gkoc_csr_spmv_##TN##_##IN(gkoc_stream_t s, int64_t n_rows,             \
+                                  int64_t n_cols, const I* row_ptrs,           \
+                                  const I* col_idxs, const T* vals,            \
+                                  const T* b, int64_t ldb, T* c, int64_t ldc,  \
+                                  int64_t nrhs);                               \
+    int gkoc_csr_advanced_spmv_##TN##_##IN(                                    \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,       \
+        const I* row_ptrs, const I* col_idxs, const T* vals, const T* b,       \
+        int64_t ldb, const T* beta, T* c, int64_t ldc, int64_t nrhs);          \
+    /* csr::extract_diagonal core/matrix/csr_kernels.hpp (diag[i]=A(i,i)|0) */ \
+    int gkoc_csr_extract_diagonal_##TN##_##IN(                                 \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const I* row_ptrs,    \
+        const I* col_idxs, const T* vals, T* diag);                            \
+    /* csr::is_sorted_by_column_index; *is_sorted is HOST memory */            \
+    int gkoc_csr_is_sorted_by_column_index_##TN##_##IN(                        \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,                    \
+        const I* col_idxs, int* is_sorted_host);                               \
+    /* csr::sort_by_column_index (in place, per-row stable by column)  */      \
+    int gkoc_csr_sort_by_column_index_##TN##_##IN(                             \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, I* col_idxs,       \
+        T* vals);
+GKOC_DECL_CSR(double, f64, int32_t, i32)
+GKOC_DECL_CSR(double, f64, int64_t, i64)
+GKOC_DECL_CSR(float, f32, int32_t, i32)
+GKOC_DECL_CSR(float, f32, int64_t, i64)
+
+/* --------------------------------------------------------------- ELL SpMV
+ * ell::spmv / advanced_spmv  core/matrix/ell_kernels.hpp:20-34
+ * column-major storage: entry (row, j) at row + j*stride; padding col = -1
+ * (include/ginkgo/core/matrix/ell.hpp:385-388).  reference semantics:
+ * reference/matrix/ell_kernels.cpp:29-69. Bit-identical (row-sequential). */
+#define GKOC_DECL_ELL(T, TN, I, IN)                                            \
+    int gkoc_ell_spmv_##TN##_##IN(                                             \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols,                       \
+        int64_t num_stored_per_row, int64_t stride, const I* col_idxs,         \
+        const T* vals, const T* b, int64_t ldb, T* c, int64_t ldc,             \
+        int64_t nrhs);                                                         \
+    int gkoc_ell_advanced_spmv_##TN##_##IN(                                    \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols,                       \
+        int64_t num_stored_per_row, int64_t stride, const T* alpha,            \
+        const I* col_idxs, const T* vals, const T* b, int64_t ldb,             \
+        const T* beta, T* c, int64_t ldc, int64_t nrhs);
+GKOC_DECL_ELL(double, f64, int32_t, i32)
+GKOC_DECL_ELL(double, f64, int64_t, i64)
+GKOC_DECL_ELL(float, f32, int32_t, i32)
+GKOC_DECL_ELL(float, f32, int64_t, i64)
+
+/* ------------------------------------------------------------ SELL-P SpMV
+ * sellp::spmv / advanced_spmv  core/matrix/sellp_kernels.hpp:20-31
+ * slice_sets / slice_lengths are size_type (uint64) arrays of length
+ * n_slices+1 / n_slices; entry (row, j) of slice s at
+ * (slice_sets[s] + j) * slice_size + row_in_slice
+ * (include/ginkgo/core/matrix/sellp.hpp:379-383).  reference semantics:
+ * reference/matrix/sellp_kernels.cpp:27-100. Bit-identical. */
+#define GKOC_DECL_SELLP(T, TN, I, IN)                                          \
+    int gkoc_sellp_spmv_##TN##_##IN(                                           \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t slice_size,   \
+        const uint64_t* slice_sets, const uint64_t* slice_lengths,             \
+        const I* col_idxs, const T* vals, const T* b, int64_t ldb, T* c,       \
+        int64_t ldc, int64_t nrhs);                                            \
+    int gkoc_sellp_advanced_spmv_##TN##_##IN(                                  \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t slice_size,   \
+        const T* alpha, const uint64_t* slice_sets,                            \
+        const uint64_t* slice_lengths, const I* col_idxs, const T* vals,       \
+        const T* b, int64_t ldb, const T* beta, T* c, int64_t ldc,             \
+        int64_t nrhs);
+GKOC_DECL_SELLP(double, f64, int32_t, i32)
+GKOC_DECL_SELLP(double, f64, int64_t, i64)
+GKOC_DECL_SELLP(float, f32, int32_t, i32)
+GKOC_DECL_SELLP(float, f32, int64_t, i64)
+
+/* ---------------------------------------------------- format conversions
+ * csr::convert_to_ell / convert_to_sellp, ell::compute_max_row_nnz,
+ * sellp::compute_slice_sets, components::convert_ptrs_to_sizes,
+ * convert_idxs_to_ptrs, prefix_sum_nonnegative, fill_array, fill_seq_array
+ * (core/matrix/csr_kernels.hpp:99-125, core/components/*_kernels.hpp).
+ * All outputs are integer-exact vs the reference. */
+#define GKOC_DECL_CONV(T, TN, I, IN)                                           \
+    int gkoc_csr_convert_to_ell_##TN##_##IN(                                   \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,                    \
+        const I* col_idxs, const T* vals, int64_t num_stored_per_row,          \
+        int64_t stride, I* ell_cols, T* ell_vals);                             \
+    int gkoc_csr_convert_to_sellp_##TN##_##IN(                                 \
+        gkoc_stream_t s, int64_t n_rows, int64_t slice_size,                   \
+        const I* row_ptrs, const I* col_idxs, const T* vals,                   \
+        const uint64_t* slice_sets, I* sellp_cols, T* sellp_vals);
+GKOC_DECL_CONV(double, f64, int32_t, i32)
+GKOC_DECL_CONV(double, f64, int64_t, i64)
+GKOC_DECL_CONV(float, f32, int32_t, i32)
+GKOC_DECL_CONV(float, f32, int64_t, i64)
+
+#define GKOC_DECL_IDX(I, IN)                                                   \
+    /* ell::compute_max_row_nnz: *max_nnz is HOST memory */                    \
+    int gkoc_compute_max_row_nnz_##IN(gkoc_stream_t s, int64_t n_rows,         \
+                                      const I* row_ptrs, int64_t* max_host);   \
+    /* sellp::compute_slice_sets: slice_lengths[s] = max row nnz in slice   \
+       rounded up to stride_factor; slice_sets = exclusive prefix sum */       \
+    int gkoc_sellp_compute_slice_sets_##IN(                                    \
+        gkoc_stream_t s, int64_t n_rows, int64_t slice_size,                   \
+        int64_t stride_factor, const I* row_ptrs, uint64_t* slice_sets,        \
+        uint64_t* slice_lengths);                                              \
+    int gkoc_convert_ptrs_to_sizes_##IN(gkoc_stream_t s, int64_t n,            \
+                                        const I* ptrs, uint64_t* sizes);       \
+    int gkoc_convert_idxs_to_ptrs_##IN(gkoc_stream_t s, int64_t num_idxs,      \
+                                       const I* idxs, int64_t n, I* ptrs);     \
+    /* in-place exclusive scan over n entries (last entry = total) */          \
+    int gkoc_prefix_sum_nonnegative_##IN(gkoc_stream_t s, I* counts,           \
+                                         int64_t n);                           \
+    int gkoc_fill_array_##IN(gkoc_stream_t s, I* data, int64_t n, I value);    \
+    int gkoc_fill_seq_array_##IN(gkoc_stream_t s, I* data, int64_t n);
+GKOC_DECL_IDX(int32_t, i32)
+GKOC_DECL_IDX(int64_t, i64)
+int gkoc_prefix_sum_nonnegative_u64(gkoc_stream_t s, uint64_t* counts,
+                                    int64_t n);
+
+/* ------------------------------------------------------------ Dense BLAS-1
+ * dense::{fill,copy,scale,inv_scale,add_scaled,sub_scaled}
+ *   core/matrix/dense_kernels.hpp:34-61, reference/matrix/dense_kernels.cpp:96-225
+ *   alpha is 1 x 1 (alpha_cols == 1) or 1 x nrhs (alpha_cols == nrhs).
+ * dense::{compute_dot,compute_conj_dot,compute_norm2,compute_squared_norm2}
+ *   core/matrix/dense_kernels.hpp:75-131, reference/matrix/dense_kernels.cpp:263-352
+ *   result is a device 1 x nrhs row; `work` is the caller-owned scratch
+ *   (Ginkgo's array<char>& tmp), at least gkoc_reduction_workspace_bytes().
+ *   Reductions are deterministic (fixed tree for a given n, nrhs) but their
+ *   summation order differs from the sequential reference: |err| <=
+ *   1e-13 * sum|x_i y_i| in fp64 (tests/test_dense_gpu.py).
+ * dense::row_gather  common/unified/matrix/dense_kernels.template.cpp:449-473 */
+size_t gkoc_reduction_workspace_bytes(int64_t n_rows, int64_t nrhs,
+                                      size_t value_size);
+#define GKOC_DECL_DENSE(T, TN)                                                 \
+    int gkoc_dense_fill_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,      \
+                             T* x, int64_t ldx, T value);                      \
+    int gkoc_dense_copy_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,      \
+                             const T* x, int64_t ldx, T* y, int64_t ldy);      \
+    int gkoc_dense_scale_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,     \
+                              const T* alpha, int64_t alpha_cols, T* x,        \
+                              int64_t ldx);                                    \
+    int gkoc_dense_inv_scale_##TN(gkoc_stream_t s, int64_t rows,               \
+                                  int64_t cols, const T* alpha,                \
+                                  int64_t alpha_cols, T* x, int64_t ldx);      \
+    int gkoc_dense_add_scaled_##TN(gkoc_stream_t s, int64_t rows,              \
+                                   int64_t cols, const T* alpha,               \
+                                   int64_t alpha_cols, const T* x,             \
+                                   int64_t ldx, T* y, int64_t ldy);            \
+    int gkoc_dense_sub_scaled_##TN(gkoc_stream_t s, int64_t rows,              \
+                                   int64_t cols, const T* alpha,               \
+                                   int64_t alpha_cols, const T* x,             \
+                                   int64_t ldx, T* y, int64_t ldy);            \
+    int gkoc_dense_compute_dot_##TN(gkoc_stream_t s, int64_t rows,             \
+                                    int64_t cols, const T* x, int64_t ldx,     \
+                                    const T* y, int64_t ldy, T* result,        \
+                                    void* work, size_t work_bytes);            \
+    int gkoc_dense_compute_norm2_##TN(gkoc_stream_t s, int64_t rows,           \
+                                      int64_t cols, const T* x, int64_t ldx,   \
+                                      T* result, void* work,                   \
+                                      size_t work_bytes);                      \
+    int gkoc_dense_compute_squared_norm2_##TN(                                 \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* x, int64_t ldx,  \
+        T* result, void* work, size_t work_bytes);                             \
+    int gkoc_dense_compute_sqrt_##TN(gkoc_stream_t s, int64_t cols, T* x);     \
+    int gkoc_dense_row_gather_##TN##_i32(                                      \
+        gkoc_stream_t s, int64_t n_gather, int64_t cols, const int32_t* rows,  \
+        const T* orig, int64_t ld_orig, T* gathered, int64_t ld_gathered);     \
+    int gkoc_dense_row_gather_##TN##_i64(                                      \
+        gkoc_stream_t s, int64_t n_gather, int64_t cols, const int64_t* rows,  \
+        const T* orig, int64_t ld_orig, T* gathered, int64_t ld_gathered);
+GKOC_DECL_DENSE(double, f64)
+GKOC_DECL_DENSE(float, f32)
+
+/* ------------------------------------------------------------- CG steps
+ * cg::{initialize,step_1,step_2}  core/solver/cg_kernels.hpp:25-48,
+ * reference/solver/cg_kernels.cpp:25-100.  stop_status: one byte per rhs
+ * column, bit layout include/ginkgo/core/stop/stopping_status.hpp:117-121
+ * (bit7 converged, bit6 finalized, low 6 bits = stopping id).  Element-wise,
+ * bit-identical to the reference (separate divide, multiply, add). */
+#define GKOC_DECL_CG(T, TN)                                                    \
+    int gkoc_cg_initialize_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,   \
+                                const T* b, int64_t ldb, T* r, int64_t ldr,    \
+                                T* z, int64_t ldz, T* p, int64_t ldp, T* q,    \
+                                int64_t ldq, T* prev_rho, T* rho,              \
+                                uint8_t* stop_status);                         \
+    int gkoc_cg_step_1_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,       \
+                            T* p, int64_t ldp, const T* z, int64_t ldz,        \
+                            const T* rho, const T* prev_rho,                   \
+                            const uint8_t* stop_status);                       \
+    int gkoc_cg_step_2_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,       \
+                            T* x, int64_t ldx, T* r, int64_t ldr, const T* p,  \
+                            int64_t ldp, const T* q, int64_t ldq,              \
+                            const T* beta, const T* rho,                       \
+                            const uint8_t* stop_status);
+GKOC_DECL_CG(double, f64)
+GKOC_DECL_CG(float, f32)
+
+/* ------------------------------------------------------- stopping criteria
+ * residual_norm::residual_norm, implicit_residual_norm::implicit_residual_norm,
+ * set_all_statuses  (core/stop/residual_norm_kernels.hpp,
+ * core/stop/criterion_kernels.hpp; reference/stop/residual_norm_kernels.cpp:27-90).
+ * flags_dev: 2 device bytes of scratch (Ginkgo's array<bool> device_storage);
+ * *all_converged / *one_changed are HOST bools written after a stream sync
+ * (this is the solver's one host sync point per iteration). */
+#define GKOC_DECL_STOP(T, TN)                                                  \
+    int gkoc_residual_norm_##TN(gkoc_stream_t s, int64_t cols, const T* tau,   \
+                                const T* orig_tau, T rel_residual_goal,        \
+                                uint8_t stopping_id, int set_finalized,        \
+                                uint8_t* stop_status, uint8_t* flags_dev,      \
+                                int* all_converged_host,                       \
+                                int* one_changed_host);                        \
+    int gkoc_implicit_residual_norm_##TN(                                      \
+        gkoc_stream_t s, int64_t cols, const T* tau, const T* orig_tau,        \
+        T rel_residual_goal, uint8_t stopping_id, int set_finalized,           \
+        uint8_t* stop_status, uint8_t* flags_dev, int* all_converged_host,     \
+        int* one_changed_host);
+GKOC_DECL_STOP(double, f64)
+GKOC_DECL_STOP(float, f32)
+int gkoc_set_all_statuses(gkoc_stream_t s, int64_t cols, uint8_t stopping_id,
+                          int set_finalized, uint8_t* stop_status);
+
+/* ------------------------------------------------------------ block-Jacobi
+ * jacobi::{find_blocks,generate,simple_apply,apply,invert_diagonal,
+ * simple_scalar_apply,scalar_apply}  core/preconditioner/jacobi_kernels.hpp:18-86,
+ * reference/preconditioner/jacobi_kernels.cpp:47-118 (find_blocks),
+ * :314-411 (generate), :419-531 (apply).  Storage = Ginkgo's
+ * block_interleaved_storage_scheme (include/ginkgo/core/preconditioner/jacobi.hpp:37-140):
+ * element (r,c) of block b at
+ *   group_offset*(b >> group_power) + block_offset*(b & (2^group_power-1)) + r + c*stride,
+ * stride = block_offset << group_power.  Full-precision blocks only
+ * (block_precisions == NULL); adaptive precision returns GKOC_E_NOT_SUPPORTED.
+ * block_pointers / num_blocks are integer-exact vs the reference; the inverse
+ * blocks and apply results are bit-identical (same pivoting, same operation
+ * order, no FMA contraction). */
+typedef struct gkoc_jacobi_scheme {
+    int64_t block_offset;
+    int64_t group_offset;
+    uint32_t group_power;
+} gkoc_jacobi_scheme;
+
+#define GKOC_DECL_JACOBI(T, TN, I, IN)                                         \
+    /* *num_blocks_host is HOST memory; block_ptrs has n_rows+1 entries */     \
+    int gkoc_jacobi_find_blocks_##TN##_##IN(                                   \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,                    \
+        const I* col_idxs, uint32_t max_block_size,                            \
+        int64_t* num_blocks_host, I* block_ptrs);                              \
+    int gkoc_jacobi_generate_##TN##_##IN(                                      \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,                    \
+        const I* col_idxs, const T* vals, int64_t num_blocks,                  \
+        uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
+        const I* block_ptrs, T* blocks, T* conditioning /* may be NULL */);    \
+    int gkoc_jacobi_simple_apply_##TN##_##IN(                                  \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,          \
+        gkoc_jacobi_scheme scheme, const I* block_ptrs, const T* blocks,       \
+        const T* b, int64_t ldb, T* x, int64_t ldx, int64_t nrhs);             \
+    int gkoc_jacobi_apply_##TN##_##IN(                                         \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,          \
+        gkoc_jacobi_scheme scheme, const I* block_ptrs, const T* blocks,       \
+        const T* alpha, const T* b, int64_t ldb, const T* beta, T* x,          \
+        int64_t ldx, int64_t nrhs);
+GKOC_DECL_JACOBI(double, f64, int32_t, i32)
+GKOC_DECL_JACOBI(double, f64, int64_t, i64)
+GKOC_DECL_JACOBI(float, f32, int32_t, i32)
+GKOC_DECL_JACOBI(float, f32, int64_t, i64)
+
+#define GKOC_DECL_JACOBI_SCALAR(T, TN)                                         \
+    /* inv_diag[i] = 1 / diag[i] */                                            \
+    int gkoc_jacobi_invert_diagonal_##TN(gkoc_stream_t s, int64_t n,           \
+                                         const T* diag, T* inv_diag);          \
+    /* x = b .* inv_diag (row-wise) */                                         \
+    int gkoc_jacobi_simple_scalar_apply_##TN(                                  \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* inv_diag,        \
+        const T* b, int64_t ldb, T* x, int64_t ldx);                           \
+    /* x = beta*x + alpha * b .* inv_diag */                                   \
+    int gkoc_jacobi_scalar_apply_##TN(                                         \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* inv_diag,        \
+        const T* alpha, const T* b, int64_t ldb, const T* beta, T* x,          \
+        int64_t ldx);
+GKOC_DECL_JACOBI_SCALAR(double, f64)
+GKOC_DECL_JACOBI_SCALAR(float, f32)
+
+/* ------------------------------------------------- benchmark stencil matrices
+ * Device-side restatement of the reference's workload generator
+ * benchmark/utils/stencil_matrix.hpp:68-238 (5/9-pt 2-D) and :264-453
+ * (7/27-pt 3-D): x-fastest lexicographic numbering, diag = #points-1,
+ * off-diagonal = -1, ascending columns.  Produces the CSR rows of the slab of
+ * planes [z0, z0+nz) (nd == 2: grid rows) with GLOBAL column indices;
+ * z0 = 0, nz = g gives the whole matrix.  Two calls: row_ptrs (+ nnz), then
+ * fill.  Integer-exact vs the oracle generator. */
+#define GKOC_DECL_STENCIL_PTRS(I, IN)                                          \
+    int gkoc_stencil_row_ptrs_##IN(gkoc_stream_t s, int nd, int64_t g,         \
+                                   int restricted, int64_t z0, int64_t nz,     \
+                                   I* row_ptrs, int64_t* nnz_host);
+GKOC_DECL_STENCIL_PTRS(int32_t, i32)
+GKOC_DECL_STENCIL_PTRS(int64_t, i64)
+#define GKOC_DECL_STENCIL_FILL(T, TN, I, IN)                                   \
+    int gkoc_stencil_fill_##TN##_##IN(gkoc_stream_t s, int nd, int64_t g,      \
+                                      int restricted, int64_t z0, int64_t nz,  \
+                                      const I* row_ptrs, I* cols, T* vals);
+GKOC_DECL_STENCIL_FILL(double, f64, int32_t, i32)
+GKOC_DECL_STENCIL_FILL(double, f64, int64_t, i64)
+GKOC_DECL_STENCIL_FILL(float, f32, int32_t, i32)
+GKOC_DECL_STENCIL_FILL(float, f32, int64_t, i64)
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKO_CDNA4_H_ */

@@ -1,0 +1,363 @@
+/* TEST INFRASTRUCTURE -- NOT part of the product.
+ *
+ * gko_oracle: a sequential, plain-C restatement of the algorithms on Ginkgo's
+ * Krylov hot path (ReferenceExecutor kernels + the Cg driver + the benchmark
+ * stencil generators).  It is the checker the HIP backend is compared with.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it; the product (ginkgo_amd/, libgko_cdna4.so) never does.
+ *
+ * Parity pinning: tests/test_oracle_*.py check this file against (a) the
+ * known-answer vectors of the reference's own unit tests
+ * (reference/test/matrix/csr_kernels.cpp:353-364, :505-534;
+ * reference/test/solver/cg_kernels.cpp:215-226, :407-424;
+ * reference/test/preconditioner/jacobi_kernels.cpp; ...), (b) fixtures under
+ * tests/golden/ produced by the real reference (oracle/_ref, built by
+ * oracle/build_ref.py from /root/reference), and (c) when oracle/_ref is
+ * present, the real reference in-process on random inputs.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off => no FMA contraction,
+ * matching the reference compiled for baseline x86-64). */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- (value, index) instantiations ----------------------------------- */
+#define T double
+#define I int32_t
+#define SUF f64_i32
+#include "gko_oracle_impl.inc"
+#undef T
+#undef I
+#undef SUF
+
+#define T double
+#define I int64_t
+#define SUF f64_i64
+#include "gko_oracle_impl.inc"
+#undef T
+#undef I
+#undef SUF
+
+#define T float
+#define I int32_t
+#define SUF f32_i32
+#include "gko_oracle_impl.inc"
+#undef T
+#undef I
+#undef SUF
+
+#define T double
+#define SUF f64
+#include "gko_oracle_val.inc"
+#undef T
+#undef SUF
+
+#define T float
+#define SUF f32
+#include "gko_oracle_val.inc"
+#undef T
+#undef SUF
+
+/* ---- stencil generators ----------------------------------------------
+ * benchmark/utils/stencil_matrix.hpp:68-238 (generate_2d_stencil_subdomain)
+ * and :264-453 (generate_3d_stencil_subdomain).  `dims` = number of
+ * subdomains per dimension (x, y[, z]), `pos` = this subdomain, global grid =
+ * g points per dimension (the reference derives g from target_local_size via
+ * closest_nth_root; callers pass g directly).  restricted != 0 => 5-pt / 7-pt,
+ * else 9-pt / 27-pt.  Emits the COO entries of the rows OWNED by the
+ * subdomain, in the reference's emission order, with GLOBAL (renumbered,
+ * subdomain-contiguous) row / column indices.  Returns the number of entries;
+ * pass rows == NULL to only count. */
+static int in_range(int64_t i, int64_t bound) { return 0 <= i && i < bound; }
+
+typedef struct {
+    int nd;
+    int64_t g;
+    int64_t dims[3], pos[3], dmin[3], drest[3], dp[3];
+} sgrid;
+
+static int64_t sub_size(const sgrid* s, int dim, int64_t i)
+{
+    return s->dmin[dim] + (i < s->drest[dim] ? 1 : 0);
+}
+
+static int64_t sub_off1(const sgrid* s, int dim, int64_t i)
+{
+    return s->dmin[dim] * i + (i < s->drest[dim] ? i : s->drest[dim]);
+}
+
+static int64_t sub_offset(const sgrid* s, int64_t pz, int64_t py, int64_t px)
+{
+    if (s->nd == 2) {
+        return s->g * sub_off1(s, 1, py) + sub_size(s, 1, py) * sub_off1(s, 0, px);
+    }
+    return s->g * s->g * sub_off1(s, 2, pz) +
+           s->g * sub_size(s, 2, pz) * sub_off1(s, 1, py) +
+           sub_size(s, 2, pz) * sub_size(s, 1, py) * sub_off1(s, 0, px);
+}
+
+static int64_t target_pos(const sgrid* s, int dim, int64_t i)
+{
+    return in_range(i, s->dp[dim]) ? s->pos[dim]
+                                   : (i < 0 ? s->pos[dim] - 1 : s->pos[dim] + 1);
+}
+
+static int64_t target_local(const sgrid* s, int dim, int64_t tp, int64_t i)
+{
+    const int64_t sz = sub_size(s, dim, tp);
+    return in_range(i, sz) ? i : (i < 0 ? i + sz : i - sub_size(s, dim, s->pos[dim]));
+}
+
+static int64_t flat_idx(const sgrid* s, int64_t iz, int64_t iy, int64_t ix)
+{
+    const int64_t tpx = target_pos(s, 0, ix);
+    const int64_t tpy = target_pos(s, 1, iy);
+    const int64_t tpz = s->nd == 3 ? target_pos(s, 2, iz) : 0;
+    if (!in_range(tpx, s->dims[0]) || !in_range(tpy, s->dims[1]) ||
+        (s->nd == 3 && !in_range(tpz, s->dims[2]))) {
+        return -1;
+    }
+    /* target_local_idx is evaluated against the TARGET subdomain's size */
+    if (s->nd == 2) {
+        return sub_offset(s, 0, tpy, tpx) + target_local(s, 0, tpx, ix) +
+               target_local(s, 1, tpy, iy) * sub_size(s, 0, tpx);
+    }
+    return sub_offset(s, tpz, tpy, tpx) + target_local(s, 0, tpx, ix) +
+           target_local(s, 1, tpy, iy) * sub_size(s, 0, tpx) +
+           target_local(s, 2, tpz, iz) * sub_size(s, 0, tpx) * sub_size(s, 1, tpy);
+}
+
+int64_t oracle_stencil_subdomain(int nd, const int64_t* dims, const int64_t* pos,
+                                 int64_t g, int restricted, int64_t* rows,
+                                 int64_t* cols, double* vals,
+                                 int64_t* local_size_out)
+{
+    sgrid s;
+    memset(&s, 0, sizeof(s));
+    s.nd = nd;
+    s.g = g;
+    for (int d = 0; d < 3; ++d) {
+        s.dims[d] = d < nd ? dims[d] : 1;
+        s.pos[d] = d < nd ? pos[d] : 0;
+        s.dmin[d] = g / s.dims[d];
+        s.drest[d] = g % s.dims[d];
+    }
+    for (int d = 0; d < 3; ++d) s.dp[d] = d < nd ? sub_size(&s, d, s.pos[d]) : 1;
+    const int64_t global_size = nd == 2 ? g * g : g * g * g;
+    int nnz_in_row = 0;
+    for (int dz = (nd == 3 ? -1 : 0); dz <= (nd == 3 ? 1 : 0); ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+                if (!restricted || ((dz == 0) + (dy == 0) + (dx == 0) >= 2)) ++nnz_in_row;
+    const double diag = (double)(nnz_in_row - 1);
+    if (local_size_out) *local_size_out = s.dp[0] * s.dp[1] * s.dp[2];
+    int64_t count = 0;
+    for (int64_t iz = 0; iz < s.dp[2]; ++iz) {
+        for (int64_t iy = 0; iy < s.dp[1]; ++iy) {
+            for (int64_t ix = 0; ix < s.dp[0]; ++ix) {
+                const int64_t row = flat_idx(&s, iz, iy, ix);
+                for (int dz = (nd == 3 ? -1 : 0); dz <= (nd == 3 ? 1 : 0); ++dz) {
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (restricted && ((dz == 0) + (dy == 0) + (dx == 0) < 2)) continue;
+                            const int64_t col = flat_idx(&s, iz + dz, iy + dy, ix + dx);
+                            if (in_range(col, global_size)) {
+                                if (rows) {
+                                    rows[count] = row;
+                                    cols[count] = col;
+                                    vals[count] = col != row ? -1.0 : diag;
+                                }
+                                ++count;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return count;
+}
+
+/* matrix_data::sort_row_major + Csr::read (core/matrix/csr.cpp:558-630):
+ * stable counting sort by row, then per-row sort by column.  Output
+ * row_ptrs has n_rows+1 int64 entries; rows are shifted by row_offset. */
+typedef struct {
+    int64_t c;
+    double v;
+} cv_pair;
+
+static int cmp_cv(const void* a, const void* b)
+{
+    const int64_t x = ((const cv_pair*)a)->c, y = ((const cv_pair*)b)->c;
+    return (x > y) - (x < y);
+}
+
+void oracle_coo_to_csr(int64_t nnz, const int64_t* rows, const int64_t* cols,
+                       const double* vals, int64_t row_offset, int64_t n_rows,
+                       int64_t* row_ptrs, int64_t* out_cols, double* out_vals)
+{
+    memset(row_ptrs, 0, sizeof(int64_t) * (size_t)(n_rows + 1));
+    for (int64_t k = 0; k < nnz; ++k) row_ptrs[rows[k] - row_offset + 1]++;
+    for (int64_t r = 0; r < n_rows; ++r) row_ptrs[r + 1] += row_ptrs[r];
+    int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_rows > 0 ? n_rows : 1));
+    memcpy(fill, row_ptrs, sizeof(int64_t) * (size_t)n_rows);
+    for (int64_t k = 0; k < nnz; ++k) {
+        const int64_t p = fill[rows[k] - row_offset]++;
+        out_cols[p] = cols[k];
+        out_vals[p] = vals[k];
+    }
+    free(fill);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t a = row_ptrs[r], e = row_ptrs[r + 1];
+        int sorted = 1;
+        for (int64_t k = a + 1; k < e; ++k) {
+            if (out_cols[k - 1] > out_cols[k]) {
+                sorted = 0;
+                break;
+            }
+        }
+        if (!sorted) {
+            cv_pair* tmp = (cv_pair*)malloc(sizeof(cv_pair) * (size_t)(e - a));
+            for (int64_t k = a; k < e; ++k) {
+                tmp[k - a].c = out_cols[k];
+                tmp[k - a].v = out_vals[k];
+            }
+            qsort(tmp, (size_t)(e - a), sizeof(cv_pair), cmp_cv);
+            for (int64_t k = a; k < e; ++k) {
+                out_cols[k] = tmp[k - a].c;
+                out_vals[k] = tmp[k - a].v;
+            }
+            free(tmp);
+        }
+    }
+}
+
+/* Direct CSR (int32) of the single-domain stencil, without the COO detour:
+ * same entries / order as oracle_stencil_subdomain({1,1,1}) + coo_to_csr.
+ * Used for the larger parity sizes and the cpu_baseline matrix. */
+int64_t oracle_stencil_csr_i32(int nd, int64_t g, int restricted,
+                               int32_t* row_ptrs, int32_t* cols, double* vals)
+{
+    const int64_t gz = nd == 3 ? g : 1;
+    int nnz_in_row = 0;
+    for (int dz = (nd == 3 ? -1 : 0); dz <= (nd == 3 ? 1 : 0); ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+                if (!restricted || ((dz == 0) + (dy == 0) + (dx == 0) >= 2)) ++nnz_in_row;
+    const double diag = (double)(nnz_in_row - 1);
+    int64_t count = 0;
+    if (row_ptrs) row_ptrs[0] = 0;
+    for (int64_t iz = 0; iz < gz; ++iz) {
+        for (int64_t iy = 0; iy < g; ++iy) {
+            for (int64_t ix = 0; ix < g; ++ix) {
+                const int64_t row = ix + iy * g + iz * g * g;
+                for (int dz = (nd == 3 ? -1 : 0); dz <= (nd == 3 ? 1 : 0); ++dz) {
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (restricted && ((dz == 0) + (dy == 0) + (dx == 0) < 2)) continue;
+                            const int64_t jx = ix + dx, jy = iy + dy, jz = iz + dz;
+                            if (!in_range(jx, g) || !in_range(jy, g) || !in_range(jz, gz)) continue;
+                            if (cols) {
+                                const int64_t col = jx + jy * g + jz * g * g;
+                                cols[count] = (int32_t)col;
+                                vals[count] = col != row ? -1.0 : diag;
+                            }
+                            ++count;
+                        }
+                    }
+                }
+                if (row_ptrs) row_ptrs[row + 1] = (int32_t)count;
+            }
+        }
+    }
+    return count;
+}
+
+/* ---- CG driver ---------------------------------------------------------
+ * core/solver/cg.cpp:93-181 (Cg::apply_dense_impl) with
+ *   - preconditioner: 0 = Identity (z = r), 1 = scalar Jacobi, 2 = block Jacobi
+ *     (core/preconditioner/jacobi.cpp:150-165)
+ *   - criterion: Combined(Iteration(max_iters), ResidualNorm(reduction,
+ *     baseline)) in that order (core/stop/combined.cpp:33-51,
+ *     core/stop/iteration.cpp:15-26, core/stop/residual_norm.cpp:75-205);
+ *     baseline: 0 = rhs_norm, 1 = initial_resnorm, 2 = absolute.
+ * One right-hand side (nrhs = 1), f64 / int32.  Returns the iteration count
+ * at which the loop was left; *resnorm_out = ||r||_2 of the last check. */
+typedef struct {
+    int precond; /* 0 none, 1 scalar, 2 block */
+    const double* inv_diag;
+    int64_t num_blocks, block_offset, group_offset;
+    uint32_t group_power;
+    const int32_t* block_ptrs;
+    const double* blocks;
+} oracle_precond;
+
+static void apply_precond(const oracle_precond* m, int64_t n, const double* r,
+                          double* z)
+{
+    if (m->precond == 1) {
+        oracle_jacobi_scalar_apply_f64(n, 1, m->inv_diag, 0, 1.0, r, 1, 0.0, z, 1);
+    } else if (m->precond == 2) {
+        oracle_jacobi_apply_f64_i32(m->num_blocks, m->block_offset,
+                                    m->group_offset, m->group_power,
+                                    m->block_ptrs, m->blocks, 1.0, r, 1, 0.0, z,
+                                    1, 1);
+    } else {
+        memcpy(z, r, sizeof(double) * (size_t)n);
+    }
+}
+
+int64_t oracle_cg_solve_f64_i32(int64_t n, const int32_t* row_ptrs,
+                                const int32_t* cols, const double* vals,
+                                const oracle_precond* m, const double* b,
+                                double* x, int64_t max_iters, double reduction,
+                                int baseline, double* resnorm_out,
+                                double* resnorm_history /* may be NULL, max_iters+1 */)
+{
+    double* r = (double*)malloc(sizeof(double) * (size_t)n * 4);
+    double *z = r + n, *p = z + n, *q = p + n;
+    double beta, prev_rho, rho, tau, tau0;
+    uint8_t stop = 0;
+    oracle_cg_initialize_f64(n, 1, b, 1, r, 1, z, 1, p, 1, q, 1, &prev_rho, &rho, &stop);
+    /* r = b - A x */
+    oracle_csr_advanced_spmv_f64_i32(n, -1.0, row_ptrs, cols, vals, x, 1, 1.0, r, 1, 1);
+    if (baseline == 0) {
+        oracle_dense_compute_norm2_f64(n, 1, b, 1, &tau0, 0);
+    } else if (baseline == 1) {
+        oracle_dense_compute_norm2_f64(n, 1, r, 1, &tau0, 0);
+    } else {
+        tau0 = 1.0;
+    }
+    int64_t iter = -1;
+    for (;;) {
+        apply_precond(m, n, r, z);
+        oracle_dense_compute_dot_f64(n, 1, r, 1, z, 1, &rho);
+        ++iter;
+        int one_changed = 0, all_stopped = 0;
+        /* Combined: Iteration first, then ResidualNorm */
+        if (iter >= max_iters) {
+            if ((stop & 0x3f) == 0) stop |= (uint8_t)(1 & 0x3f) | 0x40;
+            all_stopped = 1;
+        }
+        oracle_dense_compute_norm2_f64(n, 1, r, 1, &tau, 0);
+        if (resnorm_history && iter <= max_iters) resnorm_history[iter] = tau;
+        if (!all_stopped) {
+            all_stopped = oracle_residual_norm_f64(1, &tau, &tau0, reduction, 2, 1,
+                                                   &stop, 0, &one_changed);
+        }
+        if (all_stopped) break;
+        oracle_cg_step_1_f64(n, 1, p, 1, z, 1, &rho, &prev_rho, &stop);
+        oracle_csr_spmv_f64_i32(n, row_ptrs, cols, vals, p, 1, q, 1, 1);
+        oracle_dense_compute_dot_f64(n, 1, p, 1, q, 1, &beta);
+        oracle_cg_step_2_f64(n, 1, x, 1, r, 1, p, 1, q, 1, &beta, &rho, &stop);
+        {
+            const double t = prev_rho;
+            prev_rho = rho;
+            rho = t;
+        }
+    }
+    if (resnorm_out) *resnorm_out = tau;
+    free(r);
+    return iter;
+}

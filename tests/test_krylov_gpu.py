@@ -1,0 +1,393 @@
+"""GPU parity: Dense BLAS-1, fused CG steps, stopping kernels, (block-)Jacobi
+and the end-to-end CG solve, all through the C ABI, vs the oracle.
+
+Mirrors test/matrix/dense_kernels.cpp, test/solver/cg_kernels.cpp:106-191
+(597 x 43 with strides 45/46, a stopped column, zero prev_rho / beta),
+test/stop/residual_norm_kernels.cpp, test/preconditioner/jacobi_kernels.cpp and
+reference/test/solver/cg_kernels.cpp:215-226, :407-424 (known answers).
+Bars: element-wise kernels, block pointers, inverse blocks, Jacobi apply:
+bit-exact.  Reductions (dot / norm2): |err| <= 1e-13 relative (different
+summation tree).  Full solves: relative error <= 1e-9, iteration count +-1.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import random_csr, rel_frobenius
+
+pytestmark = pytest.mark.gpu
+
+RED_TOL = 1e-13
+
+
+# ------------------------------------------------------------------- dense
+@pytest.mark.parametrize("rows,cols,stride", [(597, 1, 1), (597, 43, 45), (10000, 3, 3), (1, 7, 9), (4097, 1, 1)])
+def test_dense_elementwise_bit_exact(gexec, oracle, rows, cols, stride):
+    import ginkgo_amd as g
+    rng = np.random.default_rng(rows + cols)
+    x = rng.uniform(-1, 1, (rows, cols))
+    y = rng.uniform(-1, 1, (rows, cols))
+    for alpha in (np.array([[0.7]]), np.array([[0.0]]), rng.uniform(-1, 1, (1, cols))):
+        da = g.Dense.from_numpy(gexec, alpha)
+        a1 = alpha.reshape(-1)
+        dx = g.Dense.from_numpy(gexec, x, stride)
+        assert np.array_equal(dx.scale(da).to_numpy(), oracle.dense_scale(a1, x))
+        if np.all(a1 != 0):
+            dx = g.Dense.from_numpy(gexec, x, stride)
+            assert np.array_equal(dx.inv_scale(da).to_numpy(), oracle.dense_scale(a1, x, inverse=True))
+        dy = g.Dense.from_numpy(gexec, y, stride + 1)
+        dx = g.Dense.from_numpy(gexec, x, stride)
+        assert np.array_equal(dy.add_scaled(da, dx).to_numpy(), oracle.dense_add_scaled(a1, x, y))
+        dy = g.Dense.from_numpy(gexec, y, stride + 1)
+        assert np.array_equal(dy.sub_scaled(da, dx).to_numpy(), oracle.dense_add_scaled(a1, x, y, subtract=True))
+    d = g.Dense.create(gexec, (rows, cols), stride=stride).fill(3.25)
+    assert np.all(d.to_numpy() == 3.25)
+    assert np.array_equal(g.Dense.create(gexec, (rows, cols)).copy_from(g.Dense.from_numpy(gexec, x, stride)).to_numpy(), x)
+
+
+def test_dense_unaligned_views(gexec, oracle):
+    """sub-views are only 8-byte aligned: the 16-byte vector path must not be
+    taken (GMRES Krylov columns, create_submatrix)."""
+    import ginkgo_amd as g
+    rng = np.random.default_rng(0)
+    big = rng.uniform(-1, 1, (2001, 1))
+    d = g.Dense.from_numpy(gexec, big)
+    v = d.create_submatrix((1, 2000), (0, 1))       # offset by one double
+    w = g.Dense.from_numpy(gexec, big).create_submatrix((1, 2000), (0, 1))
+    a = g.scalar(gexec, 0.3)
+    assert np.array_equal(v.add_scaled(a, w).to_numpy(), oracle.dense_add_scaled([0.3], big[1:2000], big[1:2000]))
+    res = g.Dense.create(gexec, (1, 1))
+    w.compute_dot(w, res)
+    ref = oracle.dense_dot(big[1:2000], big[1:2000])
+    assert abs(res.to_numpy()[0, 0] - ref[0]) <= RED_TOL * abs(ref[0])
+
+
+@pytest.mark.parametrize("rows,cols,stride", [(597, 1, 1), (597, 43, 46), (100003, 1, 1), (2 ** 20, 1, 1), (50000, 5, 8), (3, 2000, 2000), (0, 3, 3)])
+def test_dense_reductions(gexec, oracle, rows, cols, stride):
+    import ginkgo_amd as g
+    rng = np.random.default_rng(rows * 7 + cols)
+    x = rng.uniform(-1, 1, (rows, cols))
+    y = rng.uniform(-1, 1, (rows, cols))
+    dx, dy = g.Dense.from_numpy(gexec, x, stride), g.Dense.from_numpy(gexec, y, stride)
+    res = g.Dense.create(gexec, (1, cols))
+    scale = np.sum(np.abs(x * y), axis=0) + 1e-300
+    got = dx.compute_dot(dy, res).to_numpy()[0]
+    assert np.all(np.abs(got - oracle.dense_dot(x, y)) <= RED_TOL * scale)
+    got2 = dx.compute_dot(dy, res).to_numpy()[0]
+    assert np.array_equal(got, got2), "reduction must be deterministic"
+    got = dx.compute_norm2(res).to_numpy()[0]
+    ref = oracle.dense_norm2(x)
+    assert np.all(np.abs(got - ref) <= RED_TOL * (ref + 1e-300))
+    got = dx.compute_squared_norm2(res).to_numpy()[0]
+    ref = oracle.dense_norm2(x, squared=True)
+    assert np.all(np.abs(got - ref) <= RED_TOL * (ref + 1e-300))
+
+
+def test_dense_f32(gexec, oracle):
+    import ginkgo_amd as g
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (70001, 1)).astype(np.float32)
+    y = rng.uniform(-1, 1, (70001, 1)).astype(np.float32)
+    dx, dy = g.Dense.from_numpy(gexec, x), g.Dense.from_numpy(gexec, y)
+    a = g.Dense.from_numpy(gexec, np.array([[0.5]], np.float32))
+    assert np.array_equal(dy.add_scaled(a, dx).to_numpy(), oracle.dense_add_scaled(np.float32([0.5]), x, y))
+    res = g.Dense.create(gexec, (1, 1), torch.float32)
+    ref = np.dot(x[:, 0].astype(np.float64), x[:, 0].astype(np.float64))
+    assert abs(dx.compute_dot(dx, res).to_numpy()[0, 0] - ref) <= 1e-5 * ref
+
+
+def test_row_gather(gexec):
+    import ginkgo_amd as g
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-1, 1, (500, 3))
+    for dt in (np.int32, np.int64):
+        idx = rng.integers(0, 500, 77).astype(dt)
+        out = g.Dense.create(gexec, (77, 3), stride=4)
+        g.Dense.from_numpy(gexec, x, 5).row_gather(gexec.to_device(idx), out)
+        assert np.array_equal(out.to_numpy(), x[idx])
+
+
+# ---------------------------------------------------------------- CG steps
+def _cg_data(rows, cols, seed):
+    rng = np.random.default_rng(seed)
+    m = lambda: rng.uniform(-1, 1, (rows, cols))
+    s = lambda: rng.uniform(0.1, 1, cols)
+    return rng, m, s
+
+
+@pytest.mark.parametrize("rows,cols,stride", [(597, 43, 45), (100000, 1, 1), (1023, 1, 1)])
+def test_cg_steps_bit_exact(gexec, oracle, rows, cols, stride):
+    import ginkgo_amd as g
+    from ginkgo_amd._lib import call
+    rng, m, s = _cg_data(rows, cols, 31)
+    b, p, z, x, r, q = m(), m(), m(), m(), m(), m()
+    rho, prev_rho, beta = s(), s(), s()
+    stop = np.zeros(cols, np.uint8)
+    if cols > 2:
+        stop[1] = 0x81          # one stopped (converged) column
+        prev_rho[2] = 0.0       # zero prev_rho: p = z
+        beta[0] = 0.0           # zero beta: no update
+    ex = gexec
+    D = lambda a, st=stride: g.Dense.from_numpy(ex, a, st)
+    dv = lambda a: ex.to_device(a)
+    # initialize
+    db, dr, dz, dp, dq = D(b), D(m()), D(m()), D(m(), stride + 1), D(m())
+    d_prev, d_rho, d_stop = dv(np.full(cols, np.nan)), dv(np.full(cols, np.nan)), dv(np.full(cols, 0xFF, np.uint8))
+    call("gkoc_cg_initialize_f64", ex.stream, rows, cols, db.values, db.ld, dr.values, dr.ld,
+         dz.values, dz.ld, dp.values, dp.ld, dq.values, dq.ld, d_prev, d_rho, d_stop)
+    o = oracle.cg_initialize(b)
+    for got, ref in zip((dr, dz, dp, dq), o[:4]):
+        assert np.array_equal(got.to_numpy(), ref)
+    assert np.array_equal(d_prev.cpu().numpy(), o[4]) and np.array_equal(d_rho.cpu().numpy(), o[5])
+    assert np.array_equal(d_stop.cpu().numpy(), o[6])
+    # step_1
+    dp, dz = D(p, stride + 1), D(z)
+    call("gkoc_cg_step_1_f64", ex.stream, rows, cols, dp.values, dp.ld, dz.values, dz.ld,
+         dv(rho), dv(prev_rho), dv(stop))
+    assert np.array_equal(dp.to_numpy(), oracle.cg_step_1(p, z, rho, prev_rho, stop))
+    # step_2
+    dx, dr, dp, dq = D(x), D(r, stride + 1), D(p), D(q)
+    call("gkoc_cg_step_2_f64", ex.stream, rows, cols, dx.values, dx.ld, dr.values, dr.ld,
+         dp.values, dp.ld, dq.values, dq.ld, dv(beta), dv(rho), dv(stop))
+    ox, orr = oracle.cg_step_2(x, r, p, q, beta, rho, stop)
+    assert np.array_equal(dx.to_numpy(), ox) and np.array_equal(dr.to_numpy(), orr)
+
+
+def test_stop_kernels(gexec, oracle):
+    import ctypes as C
+    from ginkgo_amd._lib import call
+    ex = gexec
+    cols = 300
+    rng = np.random.default_rng(8)
+    tau = rng.uniform(0, 2, cols)
+    orig = rng.uniform(0.5, 1.5, cols)
+    stop = np.zeros(cols, np.uint8)
+    stop[5] = 0x03
+    for implicit in (False, True):
+        for fin in (True, False):
+            d_stop = ex.to_device(stop)
+            flags = ex.zeros((2,), torch.uint8)
+            allc, chg = C.c_int(0), C.c_int(0)
+            name = "gkoc_implicit_residual_norm_f64" if implicit else "gkoc_residual_norm_f64"
+            call(name, ex.stream, cols, ex.to_device(tau), ex.to_device(orig), C.c_double(0.9),
+                 C.c_uint8(2), C.c_int(int(fin)), d_stop, flags, C.byref(allc), C.byref(chg))
+            ra, rc, rs = oracle.residual_norm(tau, orig, 0.9, 2, fin, stop, implicit)
+            assert (bool(allc.value), bool(chg.value)) == (ra, rc)
+            assert np.array_equal(d_stop.cpu().numpy(), rs)
+    # everything converges -> all_converged
+    d_stop = ex.to_device(np.zeros(4, np.uint8))
+    flags = ex.zeros((2,), torch.uint8)
+    allc, chg = C.c_int(0), C.c_int(0)
+    call("gkoc_residual_norm_f64", ex.stream, 4, ex.to_device(np.zeros(4)), ex.to_device(np.ones(4)),
+         C.c_double(0.5), C.c_uint8(1), C.c_int(1), d_stop, flags, C.byref(allc), C.byref(chg))
+    assert allc.value == 1 and chg.value == 1 and np.all(d_stop.cpu().numpy() == 0xC1)
+    d_stop = ex.to_device(np.array([0, 0x81, 0], np.uint8))
+    call("gkoc_set_all_statuses", ex.stream, 3, C.c_uint8(5), C.c_int(1), d_stop)
+    assert d_stop.cpu().numpy().tolist() == [0x45, 0x81, 0x45]
+
+
+# ------------------------------------------------------------------ Jacobi
+def _block_matrix(seed, sizes, n_extra=3):
+    """block-diagonal-dominant matrix whose diagonal blocks have identical row
+    patterns (=> natural blocks) plus a few off-block entries"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    n = int(np.sum(sizes))
+    a = sp.lil_matrix((n, n))
+    s = 0
+    for bs in sizes:
+        blk = rng.uniform(-1, 1, (bs, bs)) + np.eye(bs) * bs
+        a[s:s + bs, s:s + bs] = blk
+        s += bs
+    a = a.tocsr()
+    a.sort_indices()
+    return a
+
+
+@pytest.mark.parametrize("max_bs", [1, 2, 3, 8, 13, 16, 32, 64])
+def test_jacobi_blocks_generate_apply_bit_exact(gexec, oracle, max_bs):
+    import ginkgo_amd as g
+    rng = np.random.default_rng(max_bs)
+    sizes = rng.integers(1, 9, 60)
+    a = _block_matrix(max_bs, sizes)
+    n = a.shape[0]
+    rp, ci, v = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
+    da = g.Csr.from_arrays(gexec, (n, n), rp, ci, v)
+    jac = g.Jacobi.build().with_max_block_size(max_bs).on(gexec).generate(da)
+    b = rng.uniform(-1, 1, (n, 3))
+    x0 = rng.uniform(-1, 1, (n, 3))
+    if max_bs == 1:
+        inv = oracle.jacobi_invert_diagonal(oracle.csr_extract_diagonal(n, n, rp, ci, v))
+        assert np.array_equal(jac.inv_diag.cpu().numpy(), inv)
+        x = g.Dense.create(gexec, (n, 3))
+        jac.apply(g.Dense.from_numpy(gexec, b), x)
+        assert np.array_equal(x.to_numpy(), oracle.jacobi_scalar_apply(inv, b))
+        x = g.Dense.from_numpy(gexec, x0)
+        jac.apply(g.scalar(gexec, 2.0), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.0), x)
+        assert np.array_equal(x.to_numpy(), oracle.jacobi_scalar_apply(inv, b, 2.0, -1.0, x0))
+        return
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, max_bs)
+    assert jac.num_blocks == nb
+    assert np.array_equal(jac.block_pointers.cpu().numpy(), ptrs[:nb + 1])
+    scheme = oracle.jacobi_storage_scheme(max_bs)
+    assert (jac.scheme.block_offset, jac.scheme.group_offset, jac.scheme.group_power) == scheme
+    blocks = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
+    assert np.array_equal(jac.blocks.cpu().numpy(), blocks)
+    x = g.Dense.create(gexec, (n, 3), stride=4)
+    jac.apply(g.Dense.from_numpy(gexec, b, 5), x)
+    assert np.array_equal(x.to_numpy(), oracle.jacobi_apply(nb, scheme, ptrs, blocks, b))
+    x = g.Dense.from_numpy(gexec, x0)
+    jac.apply(g.scalar(gexec, 2.0), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.0), x)
+    assert np.array_equal(x.to_numpy(), oracle.jacobi_apply(nb, scheme, ptrs, blocks, b, 2.0, -1.0, x0))
+
+
+def test_jacobi_pivoting_and_unsorted(gexec, oracle):
+    """blocks that need row pivoting (zero / small diagonal) and an unsorted
+    input matrix (Jacobi sorts a copy, jacobi.cpp:331-336)"""
+    import ginkgo_amd as g
+    import scipy.sparse as sp
+    blk = np.array([[0., 2., 1., 0.], [4., 0., 0., 1.], [0., 0., 0., 3.], [1., 1., 5., 0.]])
+    a = sp.block_diag([blk, blk.T + 1.0, np.array([[7.0]])]).tocsr()
+    a.sort_indices()
+    n = a.shape[0]
+    rp, ci, v = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.copy()
+    ci_u, v_u = ci.copy(), v.copy()
+    for r in range(n):
+        s, e = rp[r], rp[r + 1]
+        ci_u[s:e], v_u[s:e] = ci_u[s:e][::-1], v_u[s:e][::-1]
+    da = g.Csr.from_arrays(gexec, (n, n), rp, ci_u, v_u)
+    assert not da.is_sorted_by_column_index()
+    jac = g.Jacobi.build().with_max_block_size(4).on(gexec).generate(da)
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, 4)
+    scheme = oracle.jacobi_storage_scheme(4)
+    blocks = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
+    assert jac.num_blocks == nb
+    assert np.array_equal(jac.block_pointers.cpu().numpy(), ptrs[:nb + 1])
+    assert np.array_equal(jac.blocks.cpu().numpy(), blocks)
+    # the stored blocks really are the inverses
+    b = np.arange(1.0, n + 1)
+    x = g.Dense.create(gexec, (n, 1))
+    jac.apply(g.Dense.from_numpy(gexec, b), x)
+    assert np.allclose(a @ x.to_numpy()[:, 0], b, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("grid", [16, 40])
+def test_jacobi_27pt(gexec, oracle, grid):
+    """config 3's preconditioner: 27-pt Laplacian, max_block_size 8 => n/8 blocks
+    of 8 consecutive rows"""
+    import ginkgo_amd as g
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    n = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    jac = g.Jacobi.build().with_max_block_size(8).on(gexec).generate(a)
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, 8)
+    assert jac.num_blocks == nb == n // 8
+    assert np.array_equal(jac.block_pointers.cpu().numpy(), ptrs[:nb + 1])
+    scheme = oracle.jacobi_storage_scheme(8)
+    blocks = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
+    assert np.array_equal(jac.blocks.cpu().numpy(), blocks)
+    b = np.random.default_rng(1).uniform(-1, 1, n)
+    x = g.Dense.create(gexec, (n, 1))
+    jac.apply(g.Dense.from_numpy(gexec, b), x)
+    assert np.array_equal(x.to_numpy()[:, 0], oracle.jacobi_apply(nb, scheme, ptrs, blocks, b))
+
+
+# --------------------------------------------------------------- CG solves
+def _solve(g, ex, a, b, x0, iters, red, precond_bs=None, baseline="rhs_norm"):
+    f = (g.Cg.build().with_criteria(
+        g.stop.Iteration.build().with_max_iters(iters),
+        g.stop.ResidualNorm.build().with_reduction_factor(red).with_baseline(baseline)))
+    if precond_bs:
+        f = f.with_preconditioner(g.Jacobi.build().with_max_block_size(precond_bs))
+    s = f.on(ex).generate(a)
+    x = g.Dense.from_numpy(ex, x0)
+    s.apply(g.Dense.from_numpy(ex, b), x)
+    return s, x.to_numpy()[:, 0]
+
+
+def test_cg_known_answers(gexec):
+    import ginkgo_amd as g
+    # reference/test/solver/cg_kernels.cpp:215-226
+    a = g.Csr.from_arrays(gexec, (3, 3), np.array([0, 2, 5, 7], np.int32),
+                          np.array([0, 1, 0, 1, 2, 1, 2], np.int32),
+                          np.array([2., -1, -1, 2, -1, -1, 2]))
+    s, x = _solve(g, gexec, a, np.array([-1., 3, 1]), np.zeros(3), 4, 1e-15)
+    assert np.allclose(x, [1, 3, 2], rtol=1e-14)
+    # :407-424  6x6 dense SPD system
+    import scipy.sparse as sp
+    m = np.array([[8828., 2673, 4150, -3139, 3829, 5856], [2673, 10765, 1805, 73, 1966, 3919],
+                  [4150, 1805, 6472, 2656, 2409, 3836], [-3139, 73, 2656, 6048, 665, -132],
+                  [3829, 1966, 2409, 665, 4240, 4004], [5856, 3919, 3836, -132, 4004, 5265]])
+    a = g.Csr.from_scipy(gexec, sp.csr_matrix(m))
+    b = np.array([1300083., 1018120, 906562, -42679, 846779, 1176858])
+    s, x = _solve(g, gexec, a, b, np.zeros(6), 100, 1e-15)
+    assert rel_frobenius(x, [81., 55, 45, 5, 85, -10]) < 1e-9
+
+
+@pytest.mark.parametrize("case", ["5pt-256", "27pt-24", "27pt-40"])
+@pytest.mark.parametrize("bs", [None, 1, 8])
+def test_cg_vs_oracle(gexec, oracle, case, bs):
+    """configs[0] (5-pt 2-D 256 x 256, CG + Jacobi) and reduced-size configs[2]
+    (27-pt, CG + block-Jacobi(8), 1e-10): same iteration count (+-1), solution
+    within 1e-9, true residual below the goal."""
+    import ginkgo_amd as g
+    nd, grid, restricted = {"5pt-256": (2, 256, True), "27pt-24": (3, 24, False),
+                            "27pt-40": (3, 40, False)}[case]
+    rp, ci, v = oracle.stencil_csr(nd, grid, restricted)
+    n = grid ** nd
+    a = g.stencil_csr(gexec, nd, grid, restricted)
+    rhs = np.ones(n)
+    s, x = _solve(g, gexec, a, rhs, np.zeros(n), 2000, 1e-10, bs)
+    pre = {None: None, 1: "scalar", 8: "block"}[bs]
+    xo, iters, rn = oracle.cg_solve(rp, ci, v, rhs, max_iters=2000, reduction=1e-10,
+                                    precond=pre, max_block_size=8)
+    assert s.has_converged
+    assert abs(s.num_iterations - iters) <= 1
+    assert rel_frobenius(x, xo) < 1e-9
+    import scipy.sparse as sp
+    A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    assert np.linalg.norm(rhs - A @ x) <= 1.01e-10 * np.linalg.norm(rhs)
+
+
+def test_cg_iteration_limit_and_advanced_apply(gexec, oracle):
+    import ginkgo_amd as g
+    rp, ci, v = oracle.stencil_csr(3, 12)
+    n = 12 ** 3
+    a = g.stencil_csr(gexec, 3, 12)
+    rhs = np.random.default_rng(5).uniform(-1, 1, n)
+    s, x = _solve(g, gexec, a, rhs, np.zeros(n), 7, 1e-30)
+    assert s.num_iterations == 7 and not s.has_converged
+    xo, iters, _ = oracle.cg_solve(rp, ci, v, rhs, max_iters=7, reduction=1e-30)
+    assert iters == 7 and rel_frobenius(x, xo) < 1e-12
+    # initial_resnorm baseline with a non-zero guess
+    x0 = np.full(n, 0.5)
+    s, x = _solve(g, gexec, a, rhs, x0, 500, 1e-8, 8, baseline="initial_resnorm")
+    xo, iters, _ = oracle.cg_solve(rp, ci, v, rhs, x0=x0, max_iters=500, reduction=1e-8,
+                                   baseline="initial_resnorm", precond="block")
+    assert abs(s.num_iterations - iters) <= 1 and rel_frobenius(x, xo) < 1e-7
+    # x = beta*x + alpha*A^-1 b   (cg.cpp:184-200)
+    xd = g.Dense.from_numpy(gexec, x0)
+    s.apply(g.scalar(gexec, 2.0), g.Dense.from_numpy(gexec, rhs), g.scalar(gexec, -1.0), xd)
+    assert rel_frobenius(xd.to_numpy()[:, 0], 2.0 * xo - x0) < 1e-6
+
+
+def test_cg_multiple_rhs(gexec, oracle):
+    """nrhs = 3 with per-column convergence (stop_status handling)"""
+    import ginkgo_amd as g
+    rp, ci, v = oracle.stencil_csr(2, 30, True)
+    n = 900
+    a = g.stencil_csr(gexec, 2, 30, True)
+    rng = np.random.default_rng(3)
+    B = np.stack([np.ones(n), rng.uniform(-1, 1, n), np.zeros(n)], axis=1)
+    B[0, 2] = 1.0
+    f = g.Cg.build().with_criteria(g.stop.Iteration.build().with_max_iters(500),
+                                   g.stop.ResidualNorm.build().with_reduction_factor(1e-10))
+    s = f.on(gexec).generate(a)
+    X = g.Dense.from_numpy(gexec, np.zeros((n, 3)))
+    s.apply(g.Dense.from_numpy(gexec, B), X)
+    X = X.to_numpy()
+    assert s.has_converged
+    import scipy.sparse as sp
+    A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    for j in range(3):
+        assert np.linalg.norm(B[:, j] - A @ X[:, j]) <= 1.01e-10 * np.linalg.norm(B[:, j])

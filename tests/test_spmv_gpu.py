@@ -1,0 +1,220 @@
+"""GPU parity: CSR / ELL / SELL-P SpMV through the C ABI vs the oracle.
+
+Mirrors the reference's cross-executor tests test/matrix/csr_kernels2.cpp:218-470
+(532 x 231 random matrix, sorted / unsorted, nrhs 1 and 3, alpha = 2, beta = -1,
+strided operands), test/matrix/ell_kernels.cpp, test/matrix/sellp_kernels.cpp and
+the known-answer fixtures of reference/test/matrix/csr_kernels.cpp:353-364,
+:505-534.  Bar: BIT-EXACT (the kernels keep the reference's summation order).
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import random_csr, rel_frobenius
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_csr(g, ex, rp, ci, v, shape):
+    return g.Csr.from_arrays(ex, shape, rp, ci, v)
+
+
+def test_csr_known_answer(gexec):
+    import ginkgo_amd as g
+    # reference/test/matrix/csr_kernels.cpp:84-108: [[1,3,2],[0,5,0]]
+    a = dev_csr(g, gexec, np.array([0, 3, 4], np.int32),
+                np.array([0, 1, 2, 1], np.int32), np.array([1., 3., 2., 5.]), (2, 3))
+    x = g.Dense.from_numpy(gexec, np.array([2., 1., 4.]))
+    y = g.Dense.create(gexec, (2, 1))
+    a.apply(x, y)
+    assert y.to_numpy()[:, 0].tolist() == [13.0, 5.0]          # :353-364
+    y = g.Dense.from_numpy(gexec, np.array([1., 2.]))
+    a.apply(g.scalar(gexec, -1.0), x, g.scalar(gexec, 2.0), y)
+    assert y.to_numpy()[:, 0].tolist() == [-11.0, -1.0]        # :505-518
+    y = g.Dense.from_numpy(gexec, np.array([np.nan, np.nan]))   # :521-534
+    a.apply(g.scalar(gexec, -1.0), x, g.scalar(gexec, 0.0), y)
+    assert y.to_numpy()[:, 0].tolist() == [-13.0, -5.0]
+
+
+@pytest.mark.parametrize("unsorted", [False, True])
+@pytest.mark.parametrize("nrhs", [1, 3])
+@pytest.mark.parametrize("idx", [np.int32, np.int64])
+def test_csr_random_bit_exact(gexec, oracle, unsorted, nrhs, idx):
+    import ginkgo_amd as g
+    rp, ci, v = random_csr(532, 231, 0.08, 42, idx, unsorted=unsorted,
+                           empty_rows=(0, 17, 531))
+    rng = np.random.default_rng(7)
+    b = rng.uniform(-1, 1, (231, nrhs))
+    c0 = rng.uniform(-1, 1, (532, nrhs))
+    a = dev_csr(g, gexec, rp, ci, v, (532, 231))
+    db = g.Dense.from_numpy(gexec, b)
+    dc = g.Dense.create(gexec, (532, nrhs))
+    a.apply(db, dc)
+    assert np.array_equal(dc.to_numpy(), oracle.csr_spmv(rp, ci, v, b))
+    dc = g.Dense.from_numpy(gexec, c0)
+    a.apply(g.scalar(gexec, 2.0), db, g.scalar(gexec, -1.0), dc)
+    ref = oracle.csr_spmv(rp, ci, v, b, alpha=2.0, beta=-1.0, c=c0)
+    assert np.array_equal(dc.to_numpy(), ref)
+
+
+def test_csr_strided_operands(gexec, oracle):
+    import ginkgo_amd as g
+    rp, ci, v = random_csr(300, 200, 0.05, 3)
+    rng = np.random.default_rng(1)
+    b = rng.uniform(-1, 1, (200, 3))
+    db = g.Dense.from_numpy(gexec, b, stride=5)
+    dc = g.Dense.create(gexec, (300, 3), stride=7)
+    dev_csr(g, gexec, rp, ci, v, (300, 200)).apply(db, dc)
+    assert np.array_equal(dc.to_numpy(), oracle.csr_spmv(rp, ci, v, b))
+    # single strided column view (create_submatrix)
+    col = db.create_submatrix((0, 200), (1, 2))
+    out = dc.create_submatrix((0, 300), (2, 3))
+    dev_csr(g, gexec, rp, ci, v, (300, 200)).apply(col, out)
+    assert np.array_equal(out.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v, b[:, 1].copy()))
+
+
+def test_csr_f32(gexec, oracle):
+    import ginkgo_amd as g
+    rp, ci, v = random_csr(400, 400, 0.03, 5, dtype=np.float32)
+    b = np.random.default_rng(2).uniform(-1, 1, 400).astype(np.float32)
+    dc = g.Dense.create(gexec, (400, 1), torch.float32)
+    dev_csr(g, gexec, rp, ci, v, (400, 400)).apply(g.Dense.from_numpy(gexec, b), dc)
+    assert np.array_equal(dc.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v, b))
+
+
+def test_csr_edge_shapes(gexec, oracle):
+    import ginkgo_amd as g
+    # 0 x 0, all-empty rows, one row, non-multiple-of-64 rows
+    a = dev_csr(g, gexec, np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0), (0, 0))
+    a.apply(g.Dense.create(gexec, (0, 1)), g.Dense.create(gexec, (0, 1)))
+    a = dev_csr(g, gexec, np.zeros(6, np.int32), np.zeros(0, np.int32), np.zeros(0), (5, 4))
+    y = g.Dense.from_numpy(gexec, np.full(5, np.nan))
+    a.apply(g.Dense.from_numpy(gexec, np.ones(4)), y)
+    assert y.to_numpy()[:, 0].tolist() == [0.0] * 5
+    for rows in (1, 63, 64, 65, 129):
+        rp, ci, v = random_csr(rows, 50, 0.3, rows)
+        b = np.random.default_rng(rows).uniform(-1, 1, 50)
+        y = g.Dense.create(gexec, (rows, 1))
+        dev_csr(g, gexec, rp, ci, v, (rows, 50)).apply(g.Dense.from_numpy(gexec, b), y)
+        assert np.array_equal(y.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v, b))
+
+
+def test_csr_wide_and_long_rows(gexec, oracle):
+    """rows whose nnz exceed one LDS tile (1792 products) stay bit-exact (tile
+    carry); rows longer than GKOC_CSR_LONG_ROW = 4096 use the cooperative wave
+    path and are compared to 1e-14 relative."""
+    import ginkgo_amd as g
+    rng = np.random.default_rng(11)
+    ncols = 9000
+    lens = np.array([3000, 10, 0, 2500, 5, 1800] + [40] * 100)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(ncols, l, replace=False)) for l in lens]).astype(np.int32)
+    v = rng.uniform(-1, 1, rp[-1])
+    b = rng.uniform(-1, 1, ncols)
+    y = g.Dense.create(gexec, (len(lens), 1))
+    dev_csr(g, gexec, rp, ci, v, (len(lens), ncols)).apply(g.Dense.from_numpy(gexec, b), y)
+    assert np.array_equal(y.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v, b))
+    lens = np.array([8000, 3, 5000] + [10] * 70)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(ncols, l, replace=False)) for l in lens]).astype(np.int32)
+    v = rng.uniform(-1, 1, rp[-1])
+    y = g.Dense.create(gexec, (len(lens), 1))
+    dev_csr(g, gexec, rp, ci, v, (len(lens), ncols)).apply(g.Dense.from_numpy(gexec, b), y)
+    ref = oracle.csr_spmv(rp, ci, v, b)
+    got = y.to_numpy()[:, 0]
+    short = lens <= 4096
+    assert np.array_equal(got[short], ref[short])
+    assert rel_frobenius(got, ref) < 1e-14
+
+
+@pytest.mark.parametrize("grid", [16, 48])
+def test_csr_27pt_stencil(gexec, oracle, grid):
+    """the benchmark matrix itself (configs[1] at reduced size): device
+    generator index-exact, SpMV bit-exact."""
+    import ginkgo_amd as g
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    a = g.stencil_csr(gexec, 3, grid)
+    assert np.array_equal(a.row_ptrs.cpu().numpy(), rp)
+    assert np.array_equal(a.col_idxs.cpu().numpy(), ci)
+    assert np.array_equal(a.values.cpu().numpy(), v)
+    b = np.random.default_rng(42).uniform(-1, 1, grid ** 3)
+    y = g.Dense.create(gexec, (grid ** 3, 1))
+    a.apply(g.Dense.from_numpy(gexec, b), y)
+    assert np.array_equal(y.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v, b))
+
+
+def test_stencil_generator_variants(gexec, oracle):
+    import ginkgo_amd as g
+    for nd, grid, restricted in [(2, 37, True), (2, 20, False), (3, 9, True), (3, 1, False), (2, 1, True)]:
+        rp, ci, v = oracle.stencil_csr(nd, grid, restricted)
+        a = g.stencil_csr(gexec, nd, grid, restricted)
+        assert np.array_equal(a.row_ptrs.cpu().numpy(), rp)
+        assert np.array_equal(a.col_idxs.cpu().numpy(), ci)
+        assert np.array_equal(a.values.cpu().numpy(), v)
+    # z-slab rows == the matching rows of the full matrix
+    rp, ci, v = oracle.stencil_csr(3, 10)
+    a = g.stencil_csr(gexec, 3, 10, z0=3, nz=4)
+    lo, hi = rp[300], rp[700]
+    assert np.array_equal(a.row_ptrs.cpu().numpy(), rp[300:701] - lo)
+    assert np.array_equal(a.col_idxs.cpu().numpy(), ci[lo:hi])
+
+
+def test_dimension_mismatch(gexec):
+    import ginkgo_amd as g
+    a = dev_csr(g, gexec, np.array([0, 1, 2], np.int32), np.array([0, 1], np.int32),
+                np.ones(2), (2, 2))
+    with pytest.raises(g.DimensionMismatch):
+        a.apply(g.Dense.create(gexec, (3, 1)), g.Dense.create(gexec, (2, 1)))
+    with pytest.raises(g.DimensionMismatch):
+        a.apply(g.Dense.create(gexec, (2, 2)), g.Dense.create(gexec, (2, 1)))
+
+
+@pytest.mark.parametrize("nrhs", [1, 3])
+@pytest.mark.parametrize("idx", [np.int32, np.int64])
+def test_ell_bit_exact(gexec, oracle, nrhs, idx):
+    import ginkgo_amd as g
+    rp, ci, v = random_csr(532, 231, 0.05, 42, idx, empty_rows=(3,))
+    a = dev_csr(g, gexec, rp, ci, v, (532, 231))
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, (231, nrhs))
+    c0 = rng.uniform(-1, 1, (532, nrhs))
+    for stride in (None, 540):
+        ell = a.convert_to_ell(stride=stride)
+        k, st, ec, ev = oracle.csr_to_ell(rp, ci, v, stride=stride)
+        assert (ell.num_stored_per_row, ell.stride) == (k, st)
+        assert np.array_equal(ell.col_idxs.cpu().numpy(), ec)
+        assert np.array_equal(ell.values.cpu().numpy(), ev)
+        y = g.Dense.create(gexec, (532, nrhs))
+        ell.apply(g.Dense.from_numpy(gexec, b), y)
+        assert np.array_equal(y.to_numpy(), oracle.ell_spmv(532, k, st, ec, ev, b))
+        assert np.array_equal(y.to_numpy(), oracle.csr_spmv(rp, ci, v, b))
+        y = g.Dense.from_numpy(gexec, c0)
+        ell.apply(g.scalar(gexec, 2.0), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.0), y)
+        assert np.array_equal(y.to_numpy(),
+                              oracle.ell_spmv(532, k, st, ec, ev, b, alpha=2.0, beta=-1.0, c=c0))
+
+
+@pytest.mark.parametrize("nrhs", [1, 3])
+@pytest.mark.parametrize("slice_size,stride_factor", [(64, 1), (32, 2), (2, 2)])
+def test_sellp_bit_exact(gexec, oracle, nrhs, slice_size, stride_factor):
+    import ginkgo_amd as g
+    rp, ci, v = random_csr(532, 231, 0.05, 42, empty_rows=(100,))
+    a = dev_csr(g, gexec, rp, ci, v, (532, 231))
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, (231, nrhs))
+    c0 = rng.uniform(-1, 1, (532, nrhs))
+    sp_ = a.convert_to_sellp(slice_size, stride_factor)
+    sets, lens, sc, sv = oracle.csr_to_sellp(rp, ci, v, slice_size, stride_factor)
+    assert np.array_equal(sp_.slice_sets.cpu().numpy().view(np.uint64), sets)
+    assert np.array_equal(sp_.slice_lengths.cpu().numpy().view(np.uint64), lens)
+    assert np.array_equal(sp_.col_idxs.cpu().numpy(), sc)
+    assert np.array_equal(sp_.values.cpu().numpy(), sv)
+    y = g.Dense.create(gexec, (532, nrhs))
+    sp_.apply(g.Dense.from_numpy(gexec, b), y)
+    assert np.array_equal(y.to_numpy(), oracle.sellp_spmv(532, slice_size, sets, lens, sc, sv, b))
+    assert np.array_equal(y.to_numpy(), oracle.csr_spmv(rp, ci, v, b))
+    y = g.Dense.from_numpy(gexec, c0)
+    sp_.apply(g.scalar(gexec, 2.0), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.0), y)
+    assert np.array_equal(
+        y.to_numpy(), oracle.sellp_spmv(532, slice_size, sets, lens, sc, sv, b,
+                                        alpha=2.0, beta=-1.0, c=c0))

@@ -1,0 +1,308 @@
+// spmv_lab: measurement harness for CSR SpMV kernel variants on the 27-pt
+// Laplacian (development tool, not part of the library).  Builds the matrix
+// on the device with the library's generator, times each variant with HIP
+// events and prints algorithmic GB/s; checks every variant against the
+// production kernel's output.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude \
+//       -Iginkgo_amd/csrc tools/spmv_lab.hip ginkgo_amd/csrc/runtime.hip \
+//       ginkgo_amd/csrc/stencil.hip -o tools/spmv_lab
+//   tools/spmv_lab [grid=256] [reps=20]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../ginkgo_amd/csrc/csr_spmv.hip"  // production kernel templates
+
+using namespace gkoc;
+
+#define CK(x)                                                          \
+    do {                                                               \
+        hipError_t e = (x);                                            \
+        if (e != hipSuccess) {                                         \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e),    \
+                   __FILE__, __LINE__);                                \
+            exit(1);                                                   \
+        }                                                              \
+    } while (0)
+
+// ---------------------------------------------------------------- ceilings
+__global__ __launch_bounds__(256) void stream_read_kernel(
+    int64_t nnz, const double* __restrict__ vals, const int* __restrict__ cols,
+    double* __restrict__ out)
+{
+    double acc = 0;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < nnz; i += stride) {
+        acc += vals[i] * double(cols[i]);
+    }
+    if (acc == 12345.678) out[0] = acc;
+}
+
+__global__ __launch_bounds__(256) void stream_read16_kernel(
+    int64_t n16, const double2* __restrict__ a, const int4* __restrict__ b,
+    int64_t nb, double* __restrict__ out)
+{
+    double acc = 0;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n16; i += stride) {
+        const double2 v = a[i];
+        acc += v.x + v.y;
+        if (i < nb) {
+            const int4 c = b[i];
+            acc += double(c.x + c.y + c.z + c.w);
+        }
+    }
+    if (acc == 12345.678) out[0] = acc;
+}
+
+__global__ __launch_bounds__(256) void copy16_kernel(int64_t n16,
+                                                     const double2* __restrict__ a,
+                                                     double2* __restrict__ b)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n16; i += stride) {
+        b[i] = a[i];
+    }
+}
+
+// ------------------------------------------------- classical (Ginkgo-like)
+// SUB lanes per row, shuffle reduction (common/cuda_hip csr classical idea)
+template <int SUB>
+__global__ __launch_bounds__(256) void csr_classical_kernel(
+    int64_t n_rows, const int* __restrict__ row_ptrs, const int* __restrict__ cols,
+    const double* __restrict__ vals, const double* __restrict__ b,
+    double* __restrict__ c)
+{
+    const int64_t gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t row = gid / SUB;
+    const int sl = threadIdx.x % SUB;
+    if (row >= n_rows) return;
+    double sum = 0;
+    for (int64_t k = row_ptrs[row] + sl; k < row_ptrs[row + 1]; k += SUB) {
+        sum += vals[k] * b[cols[k]];
+    }
+#pragma unroll
+    for (int off = SUB / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (sl == 0) c[row] = sum;
+}
+
+// ----------------------------- variant: LDS-staged matrix, row-ordered gather
+// stage val/col of the 64-row segment in LDS (coalesced), then lane = row walks
+// its own entries: the gather of b is row-ordered (consecutive lanes hit
+// consecutive b entries for stencil-like matrices).
+template <bool REMAP, int UNROLL>
+__global__ __launch_bounds__(64) void csr_spmv_stage_kernel(
+    int64_t n_rows, int64_t n_segments, const int* __restrict__ row_ptrs,
+    const int* __restrict__ cols, const double* __restrict__ vals,
+    const double* __restrict__ b, double* __restrict__ c)
+{
+    constexpr int CAP = 1792;
+    __shared__ double lv[CAP];
+    __shared__ int lc[CAP];
+    const int lane = threadIdx.x;
+    const int64_t seg = REMAP ? xcd_band_remap(blockIdx.x, n_segments) : int64_t(blockIdx.x);
+    const int64_t r0 = seg * 64;
+    const int64_t row = r0 + lane;
+    const bool valid = row < n_rows;
+    const int64_t r_last = (r0 + 64 < n_rows) ? r0 + 64 : n_rows;
+    const int64_t rs = row_ptrs[valid ? row : r_last];
+    const int64_t re = row_ptrs[valid ? row + 1 : r_last];
+    const int64_t k0 = __shfl(rs, 0, 64);
+    const int64_t k1 = __shfl(re, int(r_last - r0 - 1), 64);
+    double sum = 0;
+    for (int64_t t0 = k0; t0 < k1; t0 += CAP) {
+        const int64_t t1 = (t0 + CAP < k1) ? t0 + CAP : k1;
+        for (int64_t base = t0; base < t1; base += 64 * UNROLL) {
+            double v[UNROLL];
+            int cc[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                int64_t k = base + u * 64 + lane;
+                k = k < t1 ? k : t1 - 1;
+                v[u] = vals[k];
+                cc[u] = cols[k];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t k = base + u * 64 + lane;
+                if (k < t1) {
+                    lv[k - t0] = v[u];
+                    lc[k - t0] = cc[u];
+                }
+            }
+        }
+        wave_lds_sync();
+        const int64_t a = rs > t0 ? rs : t0;
+        const int64_t e = re < t1 ? re : t1;
+        int64_t k = a;
+        for (; k + 4 <= e; k += 4) {
+            double xv[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = b[lc[k + u - t0]];
+                vv[u] = lv[k + u - t0];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sum += vv[u] * xv[u];
+        }
+        for (; k < e; ++k) sum += lv[k - t0] * b[lc[k - t0]];
+        wave_lds_sync();
+    }
+    if (valid) c[row] = sum;
+}
+
+struct timer {
+    hipEvent_t a, b;
+    timer()
+    {
+        CK(hipEventCreate(&a));
+        CK(hipEventCreate(&b));
+    }
+    template <typename F>
+    double ms(int reps, F f)
+    {
+        f();
+        f();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a, 0));
+        for (int i = 0; i < reps; ++i) f();
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float t;
+        CK(hipEventElapsedTime(&t, a, b));
+        return double(t) / reps;
+    }
+};
+
+int main(int argc, char** argv)
+{
+    const int64_t g = argc > 1 ? atoll(argv[1]) : 256;
+    const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    const int64_t n = g * g * g;
+    int* row_ptrs;
+    CK(hipMalloc(&row_ptrs, sizeof(int) * (n + 1)));
+    int64_t nnz = 0;
+    if (gkoc_stencil_row_ptrs_i32(nullptr, 3, g, 0, 0, g, row_ptrs, &nnz)) {
+        printf("generator failed: %s\n", gkoc_last_error());
+        return 1;
+    }
+    int* cols;
+    double *vals, *x, *y, *yref;
+    CK(hipMalloc(&cols, sizeof(int) * nnz));
+    CK(hipMalloc(&vals, sizeof(double) * nnz));
+    CK(hipMalloc(&x, sizeof(double) * n));
+    CK(hipMalloc(&y, sizeof(double) * n));
+    CK(hipMalloc(&yref, sizeof(double) * n));
+    if (gkoc_stencil_fill_f64_i32(nullptr, 3, g, 0, 0, g, row_ptrs, cols, vals)) return 1;
+    std::vector<double> hx(n);
+    unsigned long long s = 42;
+    for (int64_t i = 0; i < n; ++i) {
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        hx[i] = double(s >> 11) / 9007199254740992.0 * 2 - 1;
+    }
+    CK(hipMemcpy(x, hx.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    const double bytes = double(nnz) * 12 + double(n + 1) * 4 + double(n) * 16;
+    printf("27-pt %ld^3: n=%ld nnz=%ld algorithmic bytes=%.3f GB\n", (long)g, (long)n,
+           (long)nnz, bytes / 1e9);
+    timer T;
+    const int64_t nseg = (n + 63) / 64;
+    auto report = [&](const char* name, double ms, double by) {
+        printf("%-44s %8.4f ms  %8.1f GB/s  (%.1f%% of 8 TB/s)\n", name, ms,
+               by / ms / 1e6, by / ms / 1e6 / 80.0);
+        fflush(stdout);
+    };
+    std::vector<double> href(n), hy(n);
+    auto check = [&](const char* name, bool exact) {
+        CK(hipMemcpy(hy.data(), y, sizeof(double) * n, hipMemcpyDeviceToHost));
+        int64_t bad = 0;
+        double maxerr = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (hy[i] != href[i]) ++bad;
+            const double e = fabs(hy[i] - href[i]);
+            if (e > maxerr) maxerr = e;
+        }
+        printf("    check %-34s %s (mismatching=%ld maxerr=%.3e)\n", name,
+               (exact ? bad == 0 : maxerr < 1e-11) ? "OK" : "FAILED", (long)bad, maxerr);
+    };
+
+    // ceilings
+    {
+        const int64_t n16 = nnz / 2, nb = nnz / 4;
+        double ms = T.ms(reps, [&] {
+            stream_read16_kernel<<<2048, 256>>>(n16, (const double2*)vals,
+                                                (const int4*)cols, nb, y);
+        });
+        report("ceiling: read val+col, 16B loads", ms, double(nnz) * 12);
+        ms = T.ms(reps, [&] { stream_read_kernel<<<2048, 256>>>(nnz, vals, cols, y); });
+        report("ceiling: read val+col, 8B+4B loads", ms, double(nnz) * 12);
+        ms = T.ms(reps, [&] {
+            stream_read_kernel<<<8192, 256>>>(nnz, vals, cols, y);
+        });
+        report("ceiling: read val+col, 8B+4B, 8192 blocks", ms, double(nnz) * 12);
+        const int64_t c16 = nnz / 4;  // copy half of vals into the other half
+        ms = T.ms(reps, [&] {
+            copy16_kernel<<<2048, 256>>>(c16, (const double2*)vals,
+                                         (double2*)(vals + nnz / 2));
+        });
+        report("ceiling: copy 16B (read+write)", ms, double(c16) * 32);
+        CK(hipDeviceSynchronize());
+        // restore vals
+        if (gkoc_stencil_fill_f64_i32(nullptr, 3, g, 0, 0, g, row_ptrs, cols, vals)) return 1;
+    }
+
+    // production kernel (through the C ABI entry point)
+    double ms = T.ms(reps, [&] {
+        gkoc_csr_spmv_f64_i32(nullptr, n, n, row_ptrs, cols, vals, x, 1, yref, 1, 1);
+    });
+    report("PRODUCTION gkoc_csr_spmv_f64_i32", ms, bytes);
+    CK(hipMemcpy(href.data(), yref, sizeof(double) * n, hipMemcpyDeviceToHost));
+
+#define RUN_WAVE(REMAP, U)                                                       \
+    {                                                                            \
+        ms = T.ms(reps, [&] {                                                    \
+            csr_spmv_wave_kernel<double, int, false, REMAP, U>                   \
+                <<<dim3(unsigned(nseg)), dim3(64)>>>(n, nseg, row_ptrs, cols,    \
+                                                     vals, x, 1, y, 1, 1,        \
+                                                     nullptr, nullptr);          \
+        });                                                                      \
+        report("wave kernel remap=" #REMAP " unroll=" #U, ms, bytes);            \
+        check("wave " #REMAP " " #U, true);                                      \
+    }
+    RUN_WAVE(false, 9)
+    RUN_WAVE(true, 9)
+    RUN_WAVE(true, 3)
+    RUN_WAVE(true, 5)
+    RUN_WAVE(true, 14)
+    RUN_WAVE(true, 27)
+
+#define RUN_STAGE(REMAP, U)                                                      \
+    {                                                                            \
+        ms = T.ms(reps, [&] {                                                    \
+            csr_spmv_stage_kernel<REMAP, U><<<dim3(unsigned(nseg)), dim3(64)>>>( \
+                n, nseg, row_ptrs, cols, vals, x, y);                            \
+        });                                                                      \
+        report("stage kernel (row-ordered gather) remap=" #REMAP " u=" #U, ms,   \
+               bytes);                                                           \
+        check("stage " #REMAP " " #U, true);                                     \
+    }
+    RUN_STAGE(true, 9)
+    RUN_STAGE(false, 9)
+    RUN_STAGE(true, 14)
+
+#define RUN_CLASSICAL(SUB)                                                       \
+    {                                                                            \
+        ms = T.ms(reps, [&] {                                                    \
+            csr_classical_kernel<SUB>                                            \
+                <<<dim3(unsigned((n * SUB + 255) / 256)), dim3(256)>>>(          \
+                    n, row_ptrs, cols, vals, x, y);                              \
+        });                                                                      \
+        report("classical subwave=" #SUB, ms, bytes);                            \
+        check("classical " #SUB, false);                                         \
+    }
+    RUN_CLASSICAL(32)
+    RUN_CLASSICAL(16)
+    RUN_CLASSICAL(8)
+    return 0;
+}
