@@ -166,7 +166,7 @@ GKOC_DECL_SELLP(float, f32, int64_t, i64)
  * csr::convert_to_ell / convert_to_sellp, ell::compute_max_row_nnz,
  * sellp::compute_slice_sets, components::convert_ptrs_to_sizes,
  * convert_idxs_to_ptrs, prefix_sum_nonnegative, fill_array, fill_seq_array
- * (core/matrix/csr_kernels.hpp:99-125, core/components/*_kernels.hpp).
+ * (core/matrix/csr_kernels.hpp:99-125, core/components/prefix_sum_kernels.hpp etc.).
  * All outputs are integer-exact vs the reference. */
 #define GKOC_DECL_CONV(T, TN, I, IN)                                           \
     int gkoc_csr_convert_to_ell_##TN##_##IN(                                   \
