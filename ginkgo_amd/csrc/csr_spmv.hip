@@ -1,146 +1,30 @@
-// CSR SpMV for gfx950: row-segment-per-wavefront streaming kernel.
+// CSR SpMV for gfx950: software-pipelined row-segment-per-wavefront kernel.
 //
 // Replaces gko::kernels::hip::csr::{spmv, advanced_spmv}
 // (decl core/matrix/csr_kernels.hpp:29-43; semantics
 // reference/matrix/csr_kernels.cpp:49-118; stock GPU version
 // common/cuda_hip/matrix/csr_kernels.template.cpp:206-586,2351-2468).
 //
-// Design (not a translation of the stock classical/load-balance kernels):
-//  * one 64-lane wavefront owns a segment of 64 consecutive rows; its nnz
-//    range [row_ptrs[r0], row_ptrs[r0+64]) is contiguous in val / col_idx, so
-//    the wave streams it with perfectly coalesced 512 B (val) / 256 B (col)
-//    loads, lane = nnz index (no per-row alignment loss, no idle lanes on
-//    27-nnz rows);
-//  * the products val[k]*b[col[k]] are staged in LDS (14 KB per wave);
-//  * then lane = row: each lane adds its row's products from LDS in k order.
-//    => same summation order and same roundings as the sequential reference
-//    (separate multiply and add; this file is compiled with
-//    -ffp-contract=off), i.e. BIT-IDENTICAL results, no atomics, and one
-//    coalesced 512 B store of y per wave;
-//  * segments whose nnz exceed the LDS tile are processed tile by tile with the
-//    per-row partial sum carried in a register (order still sequential);
+// The kernel lives in csr_spmv_pipe.hpp (variant 3).  Summary:
+//  * one 64-lane wavefront owns 64 consecutive rows = one contiguous range of
+//    the val / col_idx streams, read with 16-byte-per-lane vector loads (no
+//    per-row alignment loss, no idle lanes on 27-nnz rows), double-buffered in
+//    registers so the HBM round trip overlaps the b-vector gather;
+//  * products val[k]*b[col[k]] go to an LDS ring (8 KB per wave, 20 waves/CU);
+//  * lane = row then adds its products from LDS in k order => same summation
+//    order and roundings as the sequential reference (this file is compiled
+//    with -ffp-contract=off): BIT-IDENTICAL results, no atomics, no zeroing
+//    pass over c, no host-built srow table, any strategy name accepted;
 //  * rows longer than GKOC_CSR_LONG_ROW are summed cooperatively by the whole
 //    wave (tolerance instead of bit-exactness for those rows only).
 //
 // Algorithmic HBM bytes: nnz*(sizeof(T)+sizeof(I)) + (n+1)*sizeof(I)
 //                        + n_cols*sizeof(T) (b once) + n*sizeof(T) (c).
 #include "common.hpp"
+#include "csr_spmv_pipe.hpp"
 
 namespace gkoc {
 namespace {
-
-template <typename T>
-struct tile_cap {
-    // products per wave: 14 KB of LDS => 11 single-wave workgroups per CU
-    static constexpr int value = 14336 / sizeof(T);
-};
-
-// bijective XCD-aware remap of the workgroup id: dispatcher places block b on
-// XCD b % 8 (MI355X_MICROARCH.md); give every XCD a contiguous band of row
-// segments so that the b-vector lines shared by neighbouring segments stay in
-// one XCD's L2.
-__device__ __forceinline__ int64_t xcd_band_remap(int64_t bid, int64_t n)
-{
-    constexpr int64_t nx = 8;
-    const int64_t q = n / nx, r = n % nx;
-    const int64_t xcd = bid % nx, idx = bid / nx;
-    const int64_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
-
-template <typename T, typename I, bool ADV, bool REMAP, int UNROLL>
-__global__ __launch_bounds__(64) void csr_spmv_wave_kernel(
-    int64_t n_rows, int64_t n_segments, const I* __restrict__ row_ptrs,
-    const I* __restrict__ cols, const T* __restrict__ vals,
-    const T* __restrict__ b, int64_t ldb, T* __restrict__ c, int64_t ldc,
-    int nrhs, const T* __restrict__ alpha_p, const T* __restrict__ beta_p)
-{
-    constexpr int CAP = tile_cap<T>::value;
-    __shared__ T prod[CAP];
-    const int lane = threadIdx.x;
-    const int64_t seg =
-        REMAP ? xcd_band_remap(blockIdx.x, n_segments) : int64_t(blockIdx.x);
-    const int64_t r0 = seg * 64;
-    const int64_t row = r0 + lane;
-    const bool valid = row < n_rows;
-    const int64_t r_last = (r0 + 64 < n_rows) ? r0 + 64 : n_rows;
-    const int64_t rs = row_ptrs[valid ? row : r_last];
-    const int64_t re = row_ptrs[valid ? row + 1 : r_last];
-    const int64_t k0 = __shfl(rs, 0, 64);
-    const int64_t k1 = __shfl(re, int(r_last - r0 - 1), 64);
-    const bool is_long = (re - rs) > GKOC_CSR_LONG_ROW;
-    const unsigned long long long_mask = __ballot(is_long);
-
-    T alpha = T(1), beta = T(0);
-    if (ADV) {
-        alpha = alpha_p[0];
-        beta = beta_p[0];
-    }
-
-    for (int j = 0; j < nrhs; ++j) {
-        T sum = T(0);
-        if (ADV && valid && beta != T(0)) {
-            sum = c[row * ldc + j] * beta;
-        }
-        for (int64_t t0 = k0; t0 < k1; t0 += CAP) {
-            const int64_t t1 = (t0 + CAP < k1) ? t0 + CAP : k1;
-            // phase 1: lane = nnz; coalesced stream of val/col, gather b
-            for (int64_t base = t0; base < t1; base += 64 * UNROLL) {
-                T v[UNROLL];
-                I cc[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    int64_t k = base + u * 64 + lane;
-                    k = k < t1 ? k : t1 - 1;
-                    v[u] = vals[k];
-                    cc[u] = cols[k];
-                }
-                T xv[UNROLL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    xv[u] = b[int64_t(cc[u]) * ldb + j];
-                }
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const int64_t k = base + u * 64 + lane;
-                    if (k < t1) {
-                        prod[k - t0] = ADV ? (alpha * v[u]) * xv[u]
-                                           : v[u] * xv[u];
-                    }
-                }
-            }
-            wave_lds_sync();
-            // phase 2: lane = row; sequential (reference-order) row sums
-            if (!is_long) {
-                const int64_t a = rs > t0 ? rs : t0;
-                const int64_t e = re < t1 ? re : t1;
-                for (int64_t k = a; k < e; ++k) {
-                    sum += prod[k - t0];
-                }
-            }
-            wave_lds_sync();
-        }
-        // long rows: whole-wave cooperative dot straight from global memory
-        unsigned long long m = long_mask;
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            const int64_t lrs = __shfl(rs, src, 64);
-            const int64_t lre = __shfl(re, src, 64);
-            T part = T(0);
-            for (int64_t k = lrs + lane; k < lre; k += 64) {
-                const T p = ADV ? (alpha * vals[k]) * b[int64_t(cols[k]) * ldb + j]
-                                : vals[k] * b[int64_t(cols[k]) * ldb + j];
-                part += p;
-            }
-            part = wave_sum(part);
-            if (lane == src) sum += part;
-        }
-        if (valid) {
-            c[row * ldc + j] = sum;
-        }
-    }
-}
 
 template <typename T, typename I, bool ADV>
 int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
@@ -154,21 +38,31 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     GKOC_REQUIRE(ldc >= nrhs && (n_cols == 0 || ldb >= nrhs), GKOC_E_INVALID,
                  "stride smaller than nrhs");
     if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
-    const int64_t n_seg = ceildiv(n_rows, 64);
-    GKOC_REQUIRE(n_seg < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED,
+    // 32-row segments, 2 segments (64 rows) per wavefront; in-order dispatch
+    // keeps the set of resident waves on a compact window of rows, which is
+    // what lets the b-vector lines shared by neighbouring rows hit in L2
+    constexpr int rows_per_seg = 32;
+    constexpr int segs_per_wave = 2;
+    const int64_t n_seg = ceildiv(n_rows, rows_per_seg);
+    const int64_t n_waves = ceildiv(n_seg, segs_per_wave);
+    GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED,
                  "more than 2^31 row segments");
-    // XCD band remap pays once every XCD gets a long band; tiny matrices keep
-    // the natural order
-    const bool remap = n_seg >= 4096;
-    dim3 grid(static_cast<unsigned>(n_seg)), block(64);
-    if (remap) {
-        csr_spmv_wave_kernel<T, I, ADV, true, 9><<<grid, block, 0, as_stream(s)>>>(
-            n_rows, n_seg, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
-            static_cast<int>(nrhs), alpha, beta);
+    dim3 grid(static_cast<unsigned>(n_waves)), block(64);
+    // 4-element vector loads need 4*sizeof(T) / 4*sizeof(I) alignment of the
+    // array bases (true for whole allocations; sub-views fall back to scalars)
+    const bool vec_ok =
+        reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
+        reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;
+    if (vec_ok) {
+        csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, 4, 1, 1024, 1>
+            <<<grid, block, 0, as_stream(s)>>>(
+                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb,
+                c, ldc, static_cast<int>(nrhs), alpha, beta);
     } else {
-        csr_spmv_wave_kernel<T, I, ADV, false, 9><<<grid, block, 0, as_stream(s)>>>(
-            n_rows, n_seg, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
-            static_cast<int>(nrhs), alpha, beta);
+        csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, 1, 4, 1024, 1>
+            <<<grid, block, 0, as_stream(s)>>>(
+                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb,
+                c, ldc, static_cast<int>(nrhs), alpha, beta);
     }
     GKOC_LAUNCH_OK();
     return GKOC_OK;

@@ -1,0 +1,231 @@
+// Software-pipelined row-segment-per-wavefront CSR SpMV (gfx950).
+//
+// Each wavefront owns a CONTIGUOUS range of row segments, hence one contiguous
+// range [K0, K1) of the val / col_idx streams, and walks it in groups of
+// G = 64*E*U nonzeros:
+//   * two register sets (A, B) hold the next two groups; the loads of group
+//     j+2 are issued as soon as group j's products are written, so the HBM
+//     stream round trip overlaps the b-vector gather round trip of the next
+//     group instead of being serialised with it (vmcnt is in-order, which is
+//     why the order "gather(j) -> wait -> write -> load(j+2)" is used);
+//   * lane = E consecutive nonzeros per batch: val / col loads are 16-byte
+//     vectors, every wave instruction reads one contiguous 64*E*8 B (val) or
+//     64*E*4 B (col) run;
+//   * products go to an LDS ring (index = nonzero index mod RING); whenever a
+//     segment of ROWS rows is complete, lane = row adds its products from the
+//     ring in k order (reference summation order, separate mul/add =>
+//     bit-identical to the sequential reference) and the wave stores ROWS
+//     contiguous results;
+//   * a segment larger than the ring is consumed in several passes with the
+//     partial sums carried in registers (order still sequential);
+//   * the next segment's row pointers are prefetched one segment ahead.
+// No atomics, no pre-zeroing of c, no host-side srow table.
+#pragma once
+#include "common.hpp"
+
+namespace gkoc {
+
+#ifdef __HIPCC__
+
+template <typename T, int E>
+struct alignas(sizeof(T) * E) vecT {
+    T v[E];
+};
+
+// All stream positions are 32-bit offsets from the wave's aligned stream start
+// K0a (keeps the address arithmetic in 32-bit registers: 72 VGPRs, 5 waves per
+// SIMD with the 8 KB ring).  WPS = minimum waves per SIMD the register
+// allocator must admit; ABL = measurement-only switches (1: skip the b gather,
+// 2: skip the LDS row sums) used by tools/spmv_lab.hip, 0 in the library.
+// (Earlier generations of this kernel - 64-bit indexing, LDS-staged matrix
+// with row-ordered gather - are kept in tools/lab_kernels.hpp for A/B runs.)
+template <typename T, typename I, bool ADV, int ROWS, int E, int U, int RING,
+          int WPS, int ABL = 0>
+__global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
+    int64_t n_rows, int64_t n_segments, int64_t segs_per_wave,
+    const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb,
+    T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
+    const T* __restrict__ beta_p)
+{
+    static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
+    constexpr int G = 64 * E * U;
+    static_assert(RING >= 2 * G, "ring too small for the group size");
+    static_assert(ROWS == 32 || ROWS == 64, "ROWS must be 32 or 64");
+    constexpr int MASK = RING - 1;
+    __shared__ __attribute__((aligned(16))) T ring[RING];
+
+    const int lane = threadIdx.x;
+    const int64_t sb = int64_t(blockIdx.x) * segs_per_wave;
+    const int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
+    if (sb >= se) return;
+    const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;
+    const int64_t K0 = row_ptrs[sb * ROWS];
+    const int64_t K1 = row_ptrs[row_e];
+    const int64_t NNZ = row_ptrs[n_rows];
+    const int64_t K0a = K0 & ~int64_t(E - 1);
+    // wave-relative 32-bit offsets (a wave's range is far below 2^31 entries;
+    // the launcher falls back to variant 1 otherwise)
+    const int k1o = int(K1 - K0a);
+    const int nnzo = (NNZ - K0a) > int64_t(0x7fffff00) ? 0x7fffff00 : int(NNZ - K0a);
+    const T* __restrict__ vals0 = vals + K0a;
+    const I* __restrict__ cols0 = cols + K0a;
+
+    T alpha = T(1), beta = T(0);
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+
+    using VT = vecT<T, E>;
+    using VI = vecT<I, E>;
+
+    auto load_group = [&](VT(&v)[U], VI(&ci)[U], int p) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = p + (u * 64 + lane) * E;
+            if (k >= k1o) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    v[u].v[e] = T(0);
+                    ci[u].v[e] = I(0);
+                }
+            } else if (k + E <= nnzo) {
+                v[u] = *reinterpret_cast<const VT*>(vals0 + k);
+                ci[u] = *reinterpret_cast<const VI*>(cols0 + k);
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool in = k + e < nnzo;
+                    v[u].v[e] = in ? vals0[k + e] : T(0);
+                    ci[u].v[e] = in ? cols0[k + e] : I(0);
+                }
+            }
+        }
+    };
+
+    for (int j = 0; j < nrhs; ++j) {
+        const T* __restrict__ bj = b + j;
+        auto produce = [&](VT(&v)[U], VI(&ci)[U], int p) {
+            VT xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    xv[u].v[e] = (ABL & 1) ? T(ci[u].v[e])
+                                           : bj[int64_t(ci[u].v[e]) * ldb];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                VT pr;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    pr.v[e] = ADV ? (alpha * v[u].v[e]) * xv[u].v[e]
+                                  : v[u].v[e] * xv[u].v[e];
+                }
+                const int k = p + (u * 64 + lane) * E;
+                *reinterpret_cast<VT*>(&ring[k & MASK]) = pr;
+            }
+        };
+
+        VT vA[U], vB[U];
+        VI cA[U], cB[U];
+        int p_load = 0;
+        load_group(vA, cA, p_load);
+        p_load += G;
+        load_group(vB, cB, p_load);
+        p_load += G;
+        int produced = 0;          // offsets relative to K0a
+        int cons = int(K0 - K0a);
+        bool use_a = true;
+
+        int64_t seg = sb;
+        auto seg_rows = [&](int64_t s, int& rs, int& re, int& s_end) {
+            const int64_t row = s * ROWS + lane;
+            const int64_t last = (s + 1) * ROWS < n_rows ? (s + 1) * ROWS : n_rows;
+            const bool valid = lane < ROWS && row < n_rows;
+            rs = int(int64_t(row_ptrs[valid ? row : last]) - K0a);
+            re = int(int64_t(row_ptrs[valid ? row + 1 : last]) - K0a);
+            s_end = int(int64_t(row_ptrs[last]) - K0a);
+        };
+        int rs, re, seg_end, nrs = 0, nre = 0, nseg_end = 0;
+        seg_rows(seg, rs, re, seg_end);
+        if (seg + 1 < se) seg_rows(seg + 1, nrs, nre, nseg_end);
+        T sum = T(0);
+        {
+            const int64_t row = seg * ROWS + lane;
+            if (ADV && beta != T(0) && lane < ROWS && row < n_rows) {
+                sum = c[row * ldc + j] * beta;
+            }
+        }
+
+        while (seg < se) {
+            if (produced >= seg_end || produced + G - cons > RING) {
+                const int upto = produced < seg_end ? produced : seg_end;
+                wave_lds_sync();
+                const bool is_long = (re - rs) > GKOC_CSR_LONG_ROW;
+                if (!is_long && !(ABL & 2)) {
+                    int k = rs > cons ? rs : cons;
+                    const int e_ = re < upto ? re : upto;
+                    for (; k + 4 <= e_; k += 4) {
+                        const T t0 = ring[k & MASK];
+                        const T t1 = ring[(k + 1) & MASK];
+                        const T t2 = ring[(k + 2) & MASK];
+                        const T t3 = ring[(k + 3) & MASK];
+                        sum += t0;
+                        sum += t1;
+                        sum += t2;
+                        sum += t3;
+                    }
+                    for (; k < e_; ++k) sum += ring[k & MASK];
+                }
+                wave_lds_sync();
+                cons = upto;
+                if (cons >= seg_end) {
+                    unsigned long long m = __ballot(is_long);
+                    while (m) {
+                        const int src = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const int lrs = __shfl(rs, src, 64);
+                        const int lre = __shfl(re, src, 64);
+                        T part = T(0);
+                        for (int k = lrs + lane; k < lre; k += 64) {
+                            const T xb = bj[int64_t(cols0[k]) * ldb];
+                            part += ADV ? (alpha * vals0[k]) * xb : vals0[k] * xb;
+                        }
+                        part = wave_sum(part);
+                        if (lane == src) sum += part;
+                    }
+                    const int64_t row = seg * ROWS + lane;
+                    if (lane < ROWS && row < n_rows) c[row * ldc + j] = sum;
+                    ++seg;
+                    rs = nrs;
+                    re = nre;
+                    seg_end = nseg_end;
+                    if (seg + 1 < se) seg_rows(seg + 1, nrs, nre, nseg_end);
+                    sum = T(0);
+                    const int64_t nrow = seg * ROWS + lane;
+                    if (ADV && beta != T(0) && seg < se && lane < ROWS && nrow < n_rows) {
+                        sum = c[nrow * ldc + j] * beta;
+                    }
+                }
+                continue;
+            }
+            if (use_a) {
+                produce(vA, cA, produced);
+                load_group(vA, cA, p_load);
+            } else {
+                produce(vB, cB, produced);
+                load_group(vB, cB, p_load);
+            }
+            p_load += G;
+            produced += G;
+            use_a = !use_a;
+        }
+    }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace gkoc

@@ -1,0 +1,167 @@
+"""TEST INFRASTRUCTURE -- ctypes front-end of oracle/_ref/libgko_ref_shim.so,
+i.e. the UNMODIFIED reference (Ginkgo 1.12.0 ReferenceExecutor / OmpExecutor)
+callable from the tests, the golden-fixture generator and bench.py's
+cpu_baseline.  available() is False when oracle/_ref has not been built."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_ref", "libgko_ref_shim.so")
+_LIB = None
+
+
+def available():
+    return os.path.exists(_PATH)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(_PATH)
+        _LIB.ref_version.restype = C.c_char_p
+        _LIB.ref_csr_create.restype = C.c_void_p
+        for n in ("ref_to_ell", "ref_to_sellp", "ref_jacobi_generate",
+                  "ref_cg_solve", "ref_stencil_subdomain"):
+            getattr(_LIB, n).restype = C.c_int64
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def version():
+    return lib().ref_version().decode()
+
+
+class CsrHandle:
+    """A gko::matrix::Csr<double,int32> on a Reference/Omp executor."""
+
+    def __init__(self, exec_kind, row_ptrs, cols, vals, n_cols=None,
+                 strategy="classical"):
+        self.n_rows = len(row_ptrs) - 1
+        self.n_cols = self.n_rows if n_cols is None else n_cols
+        self._keep = (np.ascontiguousarray(row_ptrs, np.int32),
+                      np.ascontiguousarray(cols, np.int32),
+                      np.ascontiguousarray(vals, np.float64))
+        self.h = C.c_void_p(lib().ref_csr_create(
+            exec_kind.encode(), C.c_int64(self.n_rows), C.c_int64(self.n_cols),
+            C.c_int64(len(vals)), _p(self._keep[0]), _p(self._keep[1]),
+            _p(self._keep[2]), strategy.encode()))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ref_destroy(self.h)
+            self.h = None
+
+    def spmv(self, b, alpha=None, beta=None, c=None):
+        b2 = np.ascontiguousarray(b if np.ndim(b) == 2 else np.reshape(b, (-1, 1)))
+        nrhs = b2.shape[1]
+        if alpha is None:
+            out = np.empty((self.n_rows, nrhs))
+            lib().ref_csr_spmv(self.h, _p(b2), C.c_int64(nrhs), _p(out),
+                               C.c_int64(nrhs), C.c_int64(nrhs))
+        else:
+            out = np.array(c if np.ndim(c) == 2 else np.reshape(c, (-1, 1)),
+                           dtype=np.float64, order="C", copy=True)
+            lib().ref_csr_advanced_spmv(self.h, C.c_double(alpha), _p(b2),
+                                        C.c_int64(nrhs), C.c_double(beta),
+                                        _p(out), C.c_int64(nrhs), C.c_int64(nrhs))
+        return out if np.ndim(b) == 2 else out[:, 0]
+
+    def to_ell(self):
+        k, st = C.c_int64(0), C.c_int64(0)
+        n = lib().ref_to_ell(self.h, C.byref(k), C.byref(st))
+        cols, vals = np.empty(n, np.int32), np.empty(n, np.float64)
+        lib().ref_ell_get(self.h, _p(cols), _p(vals))
+        return k.value, st.value, cols, vals
+
+    def ell_spmv(self, b):
+        b2 = np.ascontiguousarray(np.reshape(b, (len(b), -1)))
+        out = np.empty((self.n_rows, b2.shape[1]))
+        lib().ref_ell_spmv(self.h, _p(b2), _p(out), C.c_int64(b2.shape[1]))
+        return out if np.ndim(b) == 2 else out[:, 0]
+
+    def to_sellp(self, slice_size=64, stride_factor=1):
+        ns = C.c_int64(0)
+        n = lib().ref_to_sellp(self.h, C.c_int64(slice_size),
+                               C.c_int64(stride_factor), C.byref(ns))
+        sets = np.empty(ns.value + 1, np.uint64)
+        lens = np.empty(ns.value, np.uint64)
+        cols, vals = np.empty(n, np.int32), np.empty(n, np.float64)
+        lib().ref_sellp_get(self.h, _p(sets), _p(lens), _p(cols), _p(vals))
+        return sets, lens, cols, vals
+
+    def sellp_spmv(self, b):
+        b2 = np.ascontiguousarray(np.reshape(b, (len(b), -1)))
+        out = np.empty((self.n_rows, b2.shape[1]))
+        lib().ref_sellp_spmv(self.h, _p(b2), _p(out), C.c_int64(b2.shape[1]))
+        return out if np.ndim(b) == 2 else out[:, 0]
+
+    def jacobi_generate(self, max_block_size):
+        scheme = np.zeros(3, np.int64)
+        storage = C.c_int64(0)
+        nb = lib().ref_jacobi_generate(self.h, C.c_uint32(max_block_size),
+                                       _p(scheme), C.byref(storage))
+        ptrs = np.empty(nb + 1, np.int32)
+        blocks = np.empty(storage.value, np.float64)
+        lib().ref_jacobi_get(self.h, _p(ptrs), _p(blocks))
+        return nb, tuple(int(s) for s in scheme), ptrs, blocks
+
+    def jacobi_apply(self, b, alpha=None, beta=None, x=None):
+        b2 = np.ascontiguousarray(np.reshape(b, (len(b), -1)))
+        if alpha is None:
+            out = np.empty_like(b2)
+            lib().ref_jacobi_apply(self.h, _p(b2), _p(out), C.c_int64(b2.shape[1]),
+                                   C.c_int(0), C.c_double(1), C.c_double(0))
+        else:
+            out = np.array(np.reshape(x, (len(x), -1)), dtype=np.float64,
+                           order="C", copy=True)
+            lib().ref_jacobi_apply(self.h, _p(b2), _p(out), C.c_int64(b2.shape[1]),
+                                   C.c_int(1), C.c_double(alpha), C.c_double(beta))
+        return out if np.ndim(b) == 2 else out[:, 0]
+
+    def cg_solve(self, b, x0=None, max_iters=1000, reduction=1e-10,
+                 baseline="rhs_norm", precond_block_size=0):
+        x = np.zeros(self.n_rows) if x0 is None else np.array(x0, dtype=np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        rn = C.c_double(0)
+        base = {"rhs_norm": 0, "initial_resnorm": 1, "absolute": 2}[baseline]
+        it = lib().ref_cg_solve(self.h, C.c_uint32(precond_block_size), _p(b),
+                                _p(x), C.c_int64(max_iters), C.c_double(reduction),
+                                C.c_int(base), C.byref(rn))
+        return x, int(it), rn.value
+
+
+def dense_dot(x, y, exec_kind="reference"):
+    x2 = np.ascontiguousarray(np.reshape(x, (len(x), -1)))
+    y2 = np.ascontiguousarray(np.reshape(y, (len(y), -1)))
+    res = np.zeros(x2.shape[1])
+    lib().ref_dense_dot(exec_kind.encode(), C.c_int64(x2.shape[0]),
+                        C.c_int64(x2.shape[1]), _p(x2), _p(y2), _p(res))
+    return res
+
+
+def dense_norm2(x, exec_kind="reference"):
+    x2 = np.ascontiguousarray(np.reshape(x, (len(x), -1)))
+    res = np.zeros(x2.shape[1])
+    lib().ref_dense_norm2(exec_kind.encode(), C.c_int64(x2.shape[0]),
+                          C.c_int64(x2.shape[1]), _p(x2), _p(res))
+    return res
+
+
+def stencil_subdomain(nd, dims, pos, target_local_size, restricted):
+    """the reference's generate_{2,3}d_stencil_subdomain (COO, global idx)"""
+    dims = np.asarray(dims, np.int32)
+    pos = np.asarray(pos, np.int32)
+    ls = C.c_int64(0)
+    f = lib().ref_stencil_subdomain
+    nnz = f(C.c_int(nd), _p(dims), _p(pos), C.c_int64(target_local_size),
+            C.c_int(int(restricted)), None, None, None, C.byref(ls))
+    rows, cols = np.empty(nnz, np.int64), np.empty(nnz, np.int64)
+    vals = np.empty(nnz, np.float64)
+    f(C.c_int(nd), _p(dims), _p(pos), C.c_int64(target_local_size),
+      C.c_int(int(restricted)), _p(rows), _p(cols), _p(vals), C.byref(ls))
+    return rows, cols, vals, int(ls.value)

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz with the UNMODIFIED reference (oracle/_ref, i.e.
+Ginkgo 1.12.0's ReferenceExecutor built from /root/reference by
+oracle/build_ref.py + oracle/build_shim.py).  Run in the build container:
+
+    python tests/golden/make_golden.py
+
+The fixtures pin oracle/gko_oracle.c (tests/test_oracle_cpu.py) and travel to
+the GPU box, where /root/reference does not exist.  Inputs are seeded; the
+script is deterministic."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import ref_shim as ref  # noqa: E402
+from util import random_csr  # noqa: E402
+
+
+def save(name, **arrays):
+    np.savez_compressed(os.path.join(HERE, name), **arrays)
+    print("wrote", name, {k: getattr(v, "shape", v) for k, v in arrays.items()})
+
+
+def main():
+    assert ref.available(), "build oracle/_ref first (python oracle/build_ref.py; build_shim.py)"
+    print("reference version", ref.version())
+    rng = np.random.default_rng(2024)
+
+    # --- CSR / ELL / SELL-P on the 532 x 231 matrix of test/matrix/csr_kernels2.cpp
+    rp, ci, v = random_csr(532, 231, 0.08, 42, empty_rows=(0, 17, 531))
+    b = rng.uniform(-1, 1, (231, 3))
+    c0 = rng.uniform(-1, 1, (532, 3))
+    h = ref.CsrHandle("reference", rp, ci, v, n_cols=231)
+    k, stride, ecols, evals = h.to_ell()
+    sets, lens, scols, svals = h.to_sellp(64, 1)
+    save("spmv_532x231.npz", row_ptrs=rp, cols=ci, vals=v, b=b, c0=c0,
+         y=h.spmv(b), y_adv=h.spmv(b, alpha=2.0, beta=-1.0, c=c0),
+         ell_k=k, ell_stride=stride, ell_cols=ecols, ell_vals=evals,
+         y_ell=h.ell_spmv(b), slice_sets=sets, slice_lengths=lens,
+         sellp_cols=scols, sellp_vals=svals, y_sellp=h.sellp_spmv(b))
+
+    # --- the reference's own stencil generator (single domain + subdomains)
+    out = {}
+    for name, nd, dims, pos, tls, restricted in [
+            ("s3d_27pt_6", 3, [1, 1, 1], [0, 0, 0], 216, False),
+            ("s3d_7pt_5", 3, [1, 1, 1], [0, 0, 0], 125, True),
+            ("s2d_5pt_7", 2, [1, 1], [0, 0], 49, True),
+            ("s2d_9pt_6", 2, [1, 1], [0, 0], 36, False),
+            ("s3d_27pt_sub_2of3", 3, [3, 1, 1], [1, 0, 0], 72, False),
+            ("s3d_27pt_sub_221", 3, [2, 2, 1], [1, 0, 0], 54, False),
+            ("s2d_5pt_sub_1of2", 2, [2, 1], [1, 0], 32, True)]:
+        r, c, vv, ls = ref.stencil_subdomain(nd, dims, pos, tls, restricted)
+        out[name + "_rows"], out[name + "_cols"], out[name + "_vals"] = r, c, vv
+        out[name + "_meta"] = np.array([nd, *dims, *([1] * (3 - len(dims))),
+                                        *pos, *([0] * (3 - len(pos))), tls,
+                                        int(restricted), ls], dtype=np.int64)
+    save("stencil.npz", **out)
+
+    # --- block-Jacobi + CG on the 27-pt 10^3 Laplacian and a block matrix
+    from oracle import gko_oracle as o
+    rp, ci, v = o.stencil_csr(3, 10)
+    h = ref.CsrHandle("reference", rp, ci, v)
+    rhs = rng.uniform(-1, 1, 1000)
+    arrays = dict(row_ptrs=rp, cols=ci, vals=v, rhs=rhs)
+    for bs in (1, 4, 8, 13, 32):
+        if bs == 1:
+            x, it, rn = h.cg_solve(np.ones(1000), precond_block_size=1)
+        else:
+            nb, scheme, ptrs, blocks = h.jacobi_generate(bs)
+            arrays[f"jac{bs}_scheme"] = np.array(scheme)
+            arrays[f"jac{bs}_ptrs"] = ptrs
+            arrays[f"jac{bs}_blocks"] = blocks
+            arrays[f"jac{bs}_apply"] = h.jacobi_apply(rhs)
+            arrays[f"jac{bs}_apply_adv"] = h.jacobi_apply(rhs, 2.0, -1.0, np.ones(1000))
+            x, it, rn = h.cg_solve(np.ones(1000), precond_block_size=bs)
+        arrays[f"cg{bs}_x"] = x
+        arrays[f"cg{bs}_iters"] = np.array([it])
+        arrays[f"cg{bs}_resnorm"] = np.array([rn])
+    x, it, rn = h.cg_solve(np.ones(1000), precond_block_size=0)
+    arrays["cg0_x"], arrays["cg0_iters"], arrays["cg0_resnorm"] = x, np.array([it]), np.array([rn])
+    x, it, rn = h.cg_solve(rhs, x0=np.full(1000, 0.5), max_iters=9, reduction=1e-30,
+                           baseline="initial_resnorm", precond_block_size=8)
+    arrays["cg_lim_x"], arrays["cg_lim_iters"] = x, np.array([it])
+    save("krylov_27pt_10.npz", **arrays)
+
+    # --- block-Jacobi on a matrix with natural blocks of mixed size + pivoting
+    import scipy.sparse as sp
+    sizes = rng.integers(1, 7, 40)
+    blocks = []
+    for s in sizes:
+        m = rng.uniform(-1, 1, (s, s))
+        m[np.arange(s), np.arange(s)] = 0.01      # force row pivoting
+        blocks.append(m + np.eye(s)[::-1] * 3)
+    a = sp.block_diag(blocks).tocsr()
+    a.sort_indices()
+    rp, ci, v = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
+    h = ref.CsrHandle("reference", rp, ci, v)
+    arrays = dict(row_ptrs=rp, cols=ci, vals=v)
+    bvec = rng.uniform(-1, 1, (a.shape[0], 2))
+    arrays["b"] = bvec
+    for bs in (2, 6, 16):
+        nb, scheme, ptrs, blks = h.jacobi_generate(bs)
+        arrays[f"jac{bs}_scheme"] = np.array(scheme)
+        arrays[f"jac{bs}_ptrs"] = ptrs
+        arrays[f"jac{bs}_blocks"] = blks
+        arrays[f"jac{bs}_apply"] = h.jacobi_apply(bvec)
+    save("jacobi_blocks.npz", **arrays)
+
+    # --- dense reductions (sequential reference order)
+    x = rng.uniform(-1, 1, (5000, 3))
+    y = rng.uniform(-1, 1, (5000, 3))
+    save("dense.npz", x=x, y=y, dot=ref.dense_dot(x, y), norm2=ref.dense_norm2(x))
+
+
+if __name__ == "__main__":
+    main()

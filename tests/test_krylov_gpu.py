@@ -313,15 +313,29 @@ def test_cg_known_answers(gexec):
                           np.array([2., -1, -1, 2, -1, -1, 2]))
     s, x = _solve(g, gexec, a, np.array([-1., 3, 1]), np.zeros(3), 4, 1e-15)
     assert np.allclose(x, [1, 3, 2], rtol=1e-14)
-    # :407-424  6x6 dense SPD system
+    # :44-65 (mtx_big, cg_factory_big / big2), :407-462: dense 6x6 SPD systems,
+    # ResidualNorm and ImplicitResidualNorm criteria, tolerance r<double>*1e2
     import scipy.sparse as sp
-    m = np.array([[8828., 2673, 4150, -3139, 3829, 5856], [2673, 10765, 1805, 73, 1966, 3919],
-                  [4150, 1805, 6472, 2656, 2409, 3836], [-3139, 73, 2656, 6048, 665, -132],
-                  [3829, 1966, 2409, 665, 4240, 4004], [5856, 3919, 3836, -132, 4004, 5265]])
+    m = np.array([[8828.0, 2673.0, 4150.0, -3139.5, 3829.5, 5856.0],
+                  [2673.0, 10765.5, 1805.0, 73.0, 1966.0, 3919.5],
+                  [4150.0, 1805.0, 6472.5, 2656.0, 2409.5, 3836.5],
+                  [-3139.5, 73.0, 2656.0, 6048.0, 665.0, -132.0],
+                  [3829.5, 1966.0, 2409.5, 665.0, 4240.5, 4373.5],
+                  [5856.0, 3919.5, 3836.5, -132.0, 4373.5, 5678.0]])
     a = g.Csr.from_scipy(gexec, sp.csr_matrix(m))
-    b = np.array([1300083., 1018120, 906562, -42679, 846779, 1176858])
-    s, x = _solve(g, gexec, a, b, np.zeros(6), 100, 1e-15)
-    assert rel_frobenius(x, [81., 55, 45, 5, 85, -10]) < 1e-9
+    r_double = 10 * np.finfo(np.float64).eps      # core/test/utils.hpp:388-401
+    b1 = np.array([1300083.0, 1018120.5, 906410.0, -42679.5, 846779.5, 1176858.5])
+    s, x = _solve(g, gexec, a, b1, np.zeros(6), 100, r_double)
+    assert rel_frobenius(x, [81.0, 55.0, 45.0, 5.0, 85.0, -10.0]) < r_double * 1e2
+    b2 = np.array([886630.5, -172578.0, 684522.0, -65310.5, 455487.5, 607436.0])
+    s, x = _solve(g, gexec, a, b2, np.zeros(6), 100, r_double)
+    assert rel_frobenius(x, [33.0, -56.0, 81.0, -30.0, 21.0, 40.0]) < r_double * 1e2
+    f = g.Cg.build().with_criteria(
+        g.stop.Iteration.build().with_max_iters(100),
+        g.stop.ImplicitResidualNorm.build().with_reduction_factor(r_double))
+    xd = g.Dense.from_numpy(gexec, np.zeros(6))
+    f.on(gexec).generate(a).apply(g.Dense.from_numpy(gexec, b2), xd)
+    assert rel_frobenius(xd.to_numpy()[:, 0], [33.0, -56.0, 81.0, -30.0, 21.0, 40.0]) < r_double * 1e2
 
 
 @pytest.mark.parametrize("case", ["5pt-256", "27pt-24", "27pt-40"])

@@ -1,0 +1,308 @@
+"""Pins the oracle (oracle/gko_oracle.c) before anything is compared with it:
+
+ 1. known-answer vectors of the reference's own unit tests (cited inline);
+ 2. golden fixtures under tests/golden/*.npz, produced by the UNMODIFIED
+    reference (tests/golden/make_golden.py) - these also run on the GPU box;
+ 3. when oracle/_ref is built (this container), the live reference on further
+    random inputs, bit-for-bit.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import random_csr
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+# ------------------------------------------------- 1. known-answer vectors
+def test_csr_known_answers(oracle):
+    # reference/test/matrix/csr_kernels.cpp:84-108 fixture [[1,3,2],[0,5,0]]
+    rp = np.array([0, 3, 4], np.int32)
+    ci = np.array([0, 1, 2, 1], np.int32)
+    v = np.array([1., 3., 2., 5.])
+    x = np.array([2., 1., 4.])
+    assert oracle.csr_spmv(rp, ci, v, x).tolist() == [13.0, 5.0]               # :353-364
+    assert oracle.csr_spmv(rp, ci, v, x, -1.0, 2.0, np.array([1., 2.])).tolist() == [-11.0, -1.0]  # :505-518
+    nan = np.array([np.nan, np.nan])
+    assert oracle.csr_spmv(rp, ci, v, x, -1.0, 0.0, nan).tolist() == [-13.0, -5.0]   # :521-534
+    # :414-430 multiple right-hand sides
+    xm = np.array([[2., 3.], [1., -1.5], [4., 2.5]])
+    assert oracle.csr_spmv(rp, ci, v, xm).tolist() == [[13.0, 3.5], [5.0, -7.5]]
+    # ELL / SELL-P of the same matrix (reference/test/matrix/ell_kernels.cpp:78-88,
+    # sellp_kernels.cpp:56-66) give the same products
+    k, stride, ec, ev = oracle.csr_to_ell(rp, ci, v)
+    assert (k, stride) == (3, 2)
+    assert oracle.ell_spmv(2, k, stride, ec, ev, x).tolist() == [13.0, 5.0]
+    sets, lens, sc, sv = oracle.csr_to_sellp(rp, ci, v, slice_size=64)
+    assert lens.tolist() == [3] and sets.tolist() == [0, 3]
+    assert oracle.sellp_spmv(2, 64, sets, lens, sc, sv, x).tolist() == [13.0, 5.0]
+
+
+def test_cg_kernel_known_answers(oracle):
+    # reference/test/solver/cg_kernels.cpp:113-213 (initialize / step_1 / step_2
+    # incl. the division-by-zero conventions)
+    b = np.full((2, 2), 2.0)
+    r, z, p, q, prev_rho, rho, stop = oracle.cg_initialize(b)
+    assert np.all(r == 2) and np.all(z == 0) and np.all(p == 0) and np.all(q == 0)
+    assert np.all(prev_rho == 1) and np.all(rho == 0) and np.all(stop == 0)
+    # :140-160 step_1: p = z + rho/prev_rho * p ; prev_rho == 0 => p = z
+    p = np.array([[1., 2.], [3., 4.]])
+    z = np.array([[1., 1.], [1., 1.]])
+    out = oracle.cg_step_1(p, z, np.array([2., 3.]), np.array([8., 0.]), np.zeros(2, np.uint8))
+    assert out.tolist() == [[1.25, 1.0], [1.75, 1.0]]
+    # :176-213 step_2: beta == 0 => untouched
+    x, r = oracle.cg_step_2(np.ones((2, 2)), np.ones((2, 2)), p, np.full((2, 2), 2.0),
+                            np.array([8., 0.]), np.array([2., 3.]), np.zeros(2, np.uint8))
+    assert x.tolist() == [[1.25, 1.0], [1.75, 1.0]] and r.tolist() == [[0.5, 1.0], [0.5, 1.0]]
+    # a stopped column is never touched
+    out = oracle.cg_step_1(p, z, np.array([2., 3.]), np.array([8., 1.]), np.array([0, 0x81], np.uint8))
+    assert out[:, 1].tolist() == [2.0, 4.0]
+
+
+def test_cg_solver_known_answers(oracle):
+    # reference/test/solver/cg_kernels.cpp:215-226
+    rp = np.array([0, 2, 5, 7], np.int32)
+    ci = np.array([0, 1, 0, 1, 2, 1, 2], np.int32)
+    v = np.array([2., -1, -1, 2, -1, -1, 2])
+    x, it, _ = oracle.cg_solve(rp, ci, v, np.array([-1., 3, 1]), max_iters=4, reduction=1e-15)
+    assert np.allclose(x, [1, 3, 2], rtol=1e-14)
+    # :44-65, :407-446 dense 6 x 6 SPD systems, tolerance r<double> * 1e2
+    import scipy.sparse as sp
+    m = sp.csr_matrix(np.array([[8828.0, 2673.0, 4150.0, -3139.5, 3829.5, 5856.0],
+                                [2673.0, 10765.5, 1805.0, 73.0, 1966.0, 3919.5],
+                                [4150.0, 1805.0, 6472.5, 2656.0, 2409.5, 3836.5],
+                                [-3139.5, 73.0, 2656.0, 6048.0, 665.0, -132.0],
+                                [3829.5, 1966.0, 2409.5, 665.0, 4240.5, 4373.5],
+                                [5856.0, 3919.5, 3836.5, -132.0, 4373.5, 5678.0]]))
+    rp, ci, v = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    r_double = 10 * np.finfo(np.float64).eps
+    for b, sol in [([1300083.0, 1018120.5, 906410.0, -42679.5, 846779.5, 1176858.5],
+                    [81.0, 55.0, 45.0, 5.0, 85.0, -10.0]),
+                   ([886630.5, -172578.0, 684522.0, -65310.5, 455487.5, 607436.0],
+                    [33.0, -56.0, 81.0, -30.0, 21.0, 40.0])]:
+        x, it, _ = oracle.cg_solve(rp, ci, v, np.array(b), max_iters=100, reduction=r_double)
+        err = np.linalg.norm(x - sol) / np.linalg.norm(sol)
+        assert err < r_double * 1e2
+
+
+def test_jacobi_known_answers(oracle):
+    # reference/test/preconditioner/jacobi_kernels.cpp:129-260 style: natural
+    # blocks {2,1,2} agglomerated with max_block_size 3 -> [0,3,5]
+    import scipy.sparse as sp
+    a = sp.block_diag([np.array([[4., 1.], [2., 4.]]), np.array([[3.]]),
+                       np.array([[4., -2.], [-1., 4.]])]).tocsr()
+    a.sort_indices()
+    rp, ci, v = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, 3)
+    assert nb == 2 and ptrs[:3].tolist() == [0, 3, 5]
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, 2)
+    assert nb == 3 and ptrs[:4].tolist() == [0, 2, 3, 5]
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, 8)
+    assert nb == 1 and ptrs[:2].tolist() == [0, 5]
+    # inversion: [[4,-2],[-1,4]]^-1 = 1/14 [[4,2],[1,4]]
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, 2)
+    scheme = oracle.jacobi_storage_scheme(2)
+    assert scheme == (2, 128, 5)      # jacobi.hpp:589-627 with stride 64
+    blocks = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
+    bo, go, gp = scheme
+    stride = bo << gp
+    blk = blocks[2 * bo:]              # third block of group 0
+    inv = np.array([[blk[0], blk[stride]], [blk[1], blk[1 + stride]]])
+    assert np.allclose(inv, np.array([[4., 2.], [1., 4.]]) / 14.0, rtol=1e-15)
+    x = oracle.jacobi_apply(nb, scheme, ptrs, blocks, np.array([5., 6., 3., 2., 3.]))
+    assert np.allclose(a @ x, [5., 6., 3., 2., 3.], rtol=1e-14)
+    # scalar Jacobi: zero diagonal entries are replaced by one (:582-590)
+    assert oracle.jacobi_invert_diagonal(np.array([2., 0., -4.])).tolist() == [0.5, 1.0, -0.25]
+
+
+def test_stop_known_answers(oracle):
+    # reference/test/stop/residual_norm_kernels.cpp + stopping_status.hpp:85-121
+    allc, chg, st = oracle.residual_norm(np.array([1e-3, 2.0]), np.array([1.0, 1.0]), 1e-2, 3, True,
+                                         np.zeros(2, np.uint8))
+    assert (allc, chg) == (False, True) and st.tolist() == [0xC3, 0]
+    allc, chg, st = oracle.residual_norm(np.array([1e-3, 1e-5]), np.array([1.0, 1.0]), 1e-2, 3, False,
+                                         np.array([0, 0x45], np.uint8))
+    assert (allc, chg) == (True, True) and st.tolist() == [0x83, 0x45]
+    allc, chg, st = oracle.residual_norm(np.array([4e-4]), np.array([1.0]), 1e-2, 1, True,
+                                         np.zeros(1, np.uint8), implicit=True)
+    assert not allc            # sqrt(4e-4) = 2e-2 > 1e-2
+
+
+def test_dense_known_answers(oracle):
+    # reference/test/matrix/dense_kernels.cpp ComputesDot / ComputesNorm2 / Scales
+    x = np.array([[1., 0.], [2., 3.], [2., 4.]])
+    assert oracle.dense_dot(x, x).tolist() == [9.0, 25.0]
+    assert oracle.dense_norm2(x).tolist() == [3.0, 5.0]
+    assert oracle.dense_scale([2.0], x).tolist() == [[2., 0.], [4., 6.], [4., 8.]]
+    assert oracle.dense_scale([0.0], np.full((2, 2), np.nan)).tolist() == [[0., 0.], [0., 0.]]
+    assert oracle.dense_add_scaled([2.0, -1.0], x, np.ones((3, 2))).tolist() == [[3., 1.], [5., -2.], [5., -3.]]
+
+
+# ---------------------------------------------------- 2. golden fixtures
+def test_golden_spmv(oracle):
+    g = gold("spmv_532x231.npz")
+    rp, ci, v, b, c0 = g["row_ptrs"], g["cols"], g["vals"], g["b"], g["c0"]
+    assert np.array_equal(oracle.csr_spmv(rp, ci, v, b), g["y"])
+    assert np.array_equal(oracle.csr_spmv(rp, ci, v, b, 2.0, -1.0, c0), g["y_adv"])
+    k, stride, ec, ev = oracle.csr_to_ell(rp, ci, v)
+    assert (k, stride) == (int(g["ell_k"]), int(g["ell_stride"]))
+    assert np.array_equal(ec, g["ell_cols"]) and np.array_equal(ev, g["ell_vals"])
+    assert np.array_equal(oracle.ell_spmv(532, k, stride, ec, ev, b), g["y_ell"])
+    sets, lens, sc, sv = oracle.csr_to_sellp(rp, ci, v, 64, 1)
+    assert np.array_equal(sets, g["slice_sets"]) and np.array_equal(lens, g["slice_lengths"])
+    # rows past num_rows in the last slice are uninitialised in the reference
+    live = np.ones(len(sc), bool)
+    last = int(sets[-2]) * 64
+    for i in range(int(lens[-1])):
+        live[last + i * 64 + (532 - 512):last + (i + 1) * 64] = False
+    assert np.array_equal(sc[live], g["sellp_cols"][live])
+    assert np.array_equal(sv[live], g["sellp_vals"][live])
+    assert np.array_equal(oracle.sellp_spmv(532, 64, sets, lens, sc, sv, b), g["y_sellp"])
+
+
+def test_golden_stencil(oracle):
+    g = gold("stencil.npz")
+    names = sorted({k[:-5] for k in g.files if k.endswith("_meta")})
+    assert len(names) == 7
+    for name in names:
+        meta = g[name + "_meta"]
+        nd, dims, pos, tls, restricted, ls = int(meta[0]), meta[1:4], meta[4:7], int(meta[7]), int(meta[8]), int(meta[9])
+        nsub = int(np.prod(dims[:nd]))
+        grid = int(round((tls * nsub) ** (1.0 / nd)))
+        r, c, v, ls2 = oracle.stencil_subdomain(nd, dims[:nd], pos[:nd], grid, restricted)
+        assert ls2 == ls
+        assert np.array_equal(r, g[name + "_rows"]), name
+        assert np.array_equal(c, g[name + "_cols"]), name
+        assert np.array_equal(v, g[name + "_vals"]), name
+    # the direct CSR generator agrees with COO -> CSR of the subdomain generator
+    r, c, v, _ = oracle.stencil_subdomain(3, [1, 1, 1], [0, 0, 0], 6, False)
+    rp64, ci64, vv = oracle.coo_to_csr(r, c, v, 0, 216)
+    rp, ci, v2 = oracle.stencil_csr(3, 6)
+    assert np.array_equal(rp, rp64) and np.array_equal(ci, ci64) and np.array_equal(v2, vv)
+
+
+def test_golden_krylov(oracle):
+    g = gold("krylov_27pt_10.npz")
+    rp, ci, v, rhs = g["row_ptrs"], g["cols"], g["vals"], g["rhs"]
+    for bs in (4, 8, 13, 32):
+        nb, ptrs = oracle.jacobi_find_blocks(rp, ci, bs)
+        assert np.array_equal(ptrs[:nb + 1], g[f"jac{bs}_ptrs"])
+        scheme = oracle.jacobi_storage_scheme(bs)
+        assert scheme == tuple(int(s) for s in g[f"jac{bs}_scheme"])
+        blocks = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
+        ref_blocks = g[f"jac{bs}_blocks"]
+        # padding entries of the interleaved storage are uninitialised in the
+        # reference: compare the slots that belong to a block
+        mask = _block_mask(scheme, ptrs[:nb + 1], len(ref_blocks))
+        assert np.array_equal(blocks[mask], ref_blocks[mask])
+        assert np.array_equal(oracle.jacobi_apply(nb, scheme, ptrs, blocks, rhs), g[f"jac{bs}_apply"])
+        assert np.array_equal(oracle.jacobi_apply(nb, scheme, ptrs, blocks, rhs, 2.0, -1.0, np.ones(1000)),
+                              g[f"jac{bs}_apply_adv"])
+    for bs, pre in [(0, None), (1, "scalar"), (4, "block"), (8, "block"), (13, "block"), (32, "block")]:
+        x, it, rn = oracle.cg_solve(rp, ci, v, np.ones(1000), precond=pre, max_block_size=max(bs, 1))
+        assert it == int(g[f"cg{bs}_iters"][0]), bs
+        assert np.array_equal(x, g[f"cg{bs}_x"]), bs
+        assert rn == float(g[f"cg{bs}_resnorm"][0])
+    x, it, _ = oracle.cg_solve(rp, ci, v, rhs, x0=np.full(1000, 0.5), max_iters=9, reduction=1e-30,
+                               baseline="initial_resnorm", precond="block")
+    assert it == int(g["cg_lim_iters"][0]) == 9 and np.array_equal(x, g["cg_lim_x"])
+
+
+def _block_mask(scheme, ptrs, size):
+    bo, go, gp = scheme
+    stride = bo << gp
+    mask = np.zeros(size, bool)
+    for b in range(len(ptrs) - 1):
+        bs = int(ptrs[b + 1] - ptrs[b])
+        base = go * (b >> gp) + bo * (b & ((1 << gp) - 1))
+        for c in range(bs):
+            mask[base + c * stride:base + c * stride + bs] = True
+    return mask
+
+
+def test_golden_jacobi_blocks(oracle):
+    g = gold("jacobi_blocks.npz")
+    rp, ci, v, b = g["row_ptrs"], g["cols"], g["vals"], g["b"]
+    for bs in (2, 6, 16):
+        nb, ptrs = oracle.jacobi_find_blocks(rp, ci, bs)
+        assert np.array_equal(ptrs[:nb + 1], g[f"jac{bs}_ptrs"])
+        scheme = tuple(int(s) for s in g[f"jac{bs}_scheme"])
+        assert scheme == oracle.jacobi_storage_scheme(bs)
+        blocks = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
+        mask = _block_mask(scheme, ptrs[:nb + 1], len(blocks))
+        assert np.array_equal(blocks[mask], g[f"jac{bs}_blocks"][mask])
+        assert np.array_equal(oracle.jacobi_apply(nb, scheme, ptrs, blocks, b), g[f"jac{bs}_apply"])
+
+
+def test_golden_dense(oracle):
+    g = gold("dense.npz")
+    assert np.array_equal(oracle.dense_dot(g["x"], g["y"]), g["dot"])
+    assert np.array_equal(oracle.dense_norm2(g["x"]), g["norm2"])
+
+
+# ------------------------------------------------ 3. live reference (if built)
+def _ref():
+    from oracle import ref_shim
+    if not ref_shim.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    return ref_shim
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_live_reference_spmv(oracle, seed):
+    ref = _ref()
+    rng = np.random.default_rng(seed)
+    rows, cols = int(rng.integers(50, 400)), int(rng.integers(50, 400))
+    rp, ci, v = random_csr(rows, cols, 0.07, seed, unsorted=bool(seed % 2), empty_rows=(1,))
+    b = rng.uniform(-1, 1, (cols, 2))
+    c0 = rng.uniform(-1, 1, (rows, 2))
+    h = ref.CsrHandle("reference", rp, ci, v, n_cols=cols)
+    assert np.array_equal(oracle.csr_spmv(rp, ci, v, b), h.spmv(b))
+    assert np.array_equal(oracle.csr_spmv(rp, ci, v, b, 0.3, 1.7, c0), h.spmv(b, 0.3, 1.7, c0))
+    assert np.array_equal(oracle.csr_spmv(rp, ci, v, b, 0.3, 0.0, c0), h.spmv(b, 0.3, 0.0, c0))
+    # OmpExecutor agrees with the sequential reference to rounding
+    ho = ref.CsrHandle("omp", rp, ci, v, n_cols=cols)
+    assert np.allclose(ho.spmv(b), h.spmv(b), rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("case", [(2, 40, True, 1), (2, 24, False, 4), (3, 9, False, 8), (3, 8, True, 3)])
+def test_live_reference_cg_and_jacobi(oracle, case):
+    ref = _ref()
+    nd, grid, restricted, bs = case
+    rp, ci, v = oracle.stencil_csr(nd, grid, restricted)
+    n = grid ** nd
+    h = ref.CsrHandle("reference", rp, ci, v)
+    rhs = np.random.default_rng(bs).uniform(-1, 1, n)
+    pre = "scalar" if bs == 1 else "block"
+    xo, ito, rno = oracle.cg_solve(rp, ci, v, rhs, max_iters=300, reduction=1e-9, precond=pre, max_block_size=bs)
+    xr, itr, rnr = h.cg_solve(rhs, max_iters=300, reduction=1e-9, precond_block_size=bs)
+    assert ito == itr and rno == rnr and np.array_equal(xo, xr)
+    if bs > 1:
+        nb, scheme, ptrs, blocks = h.jacobi_generate(bs)
+        nbo, po = oracle.jacobi_find_blocks(rp, ci, bs)
+        assert nbo == nb and np.array_equal(po[:nb + 1], ptrs)
+        bo = oracle.jacobi_generate(rp, ci, v, nb, scheme, po)
+        mask = _block_mask(scheme, ptrs, len(blocks))
+        assert np.array_equal(bo[mask], blocks[mask])
+
+
+def test_live_reference_stencil_subdomains(oracle):
+    ref = _ref()
+    for nd, dims, grid, restricted in [(3, [2, 1, 1], 8, False), (3, [3, 1, 1], 7, False),
+                                       (2, [4, 1], 12, True), (3, [2, 2, 1], 6, True)]:
+        nsub = int(np.prod(dims))
+        for rank in range(nsub):
+            pos = [rank % dims[0], (rank // dims[0]) % dims[1]] + ([rank // (dims[0] * dims[1])] if nd == 3 else [])
+            tls = grid ** nd // nsub
+            assert round((tls * nsub) ** (1 / nd)) == grid
+            a = oracle.stencil_subdomain(nd, dims, pos, grid, restricted)
+            b = ref.stencil_subdomain(nd, dims, pos, tls, restricted)
+            assert a[3] == b[3]
+            for u, w in zip(a[:3], b[:3]):
+                assert np.array_equal(u, w)

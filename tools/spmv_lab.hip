@@ -13,7 +13,8 @@
 #include <cstring>
 #include <vector>
 
-#include "../ginkgo_amd/csrc/csr_spmv.hip"  // production kernel templates
+#include "../ginkgo_amd/csrc/csr_spmv.hip"  // production kernel + C ABI entry
+#include "lab_kernels.hpp"
 
 using namespace gkoc;
 
@@ -176,10 +177,13 @@ struct timer {
     }
 };
 
+
+
 int main(int argc, char** argv)
 {
     const int64_t g = argc > 1 ? atoll(argv[1]) : 256;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    const bool pmc_mode = argc > 3 && !strcmp(argv[3], "pmc");
     const int64_t n = g * g * g;
     int* row_ptrs;
     CK(hipMalloc(&row_ptrs, sizeof(int) * (n + 1)));
@@ -228,7 +232,7 @@ int main(int argc, char** argv)
     };
 
     // ceilings
-    {
+    if (!pmc_mode) {
         const int64_t n16 = nnz / 2, nb = nnz / 4;
         double ms = T.ms(reps, [&] {
             stream_read16_kernel<<<2048, 256>>>(n16, (const double2*)vals,
@@ -259,6 +263,11 @@ int main(int argc, char** argv)
     report("PRODUCTION gkoc_csr_spmv_f64_i32", ms, bytes);
     CK(hipMemcpy(href.data(), yref, sizeof(double) * n, hipMemcpyDeviceToHost));
 
+    if (pmc_mode) {
+        ms = T.ms(reps, [&] { stream_read_kernel<<<2048, 256>>>(nnz, vals, cols, y); });
+        report("ceiling: read val+col, 8B+4B loads", ms, double(nnz) * 12);
+        goto pmc_runs;
+    }
 #define RUN_WAVE(REMAP, U)                                                       \
     {                                                                            \
         ms = T.ms(reps, [&] {                                                    \
@@ -272,10 +281,6 @@ int main(int argc, char** argv)
     }
     RUN_WAVE(false, 9)
     RUN_WAVE(true, 9)
-    RUN_WAVE(true, 3)
-    RUN_WAVE(true, 5)
-    RUN_WAVE(true, 14)
-    RUN_WAVE(true, 27)
 
 #define RUN_STAGE(REMAP, U)                                                      \
     {                                                                            \
@@ -287,9 +292,7 @@ int main(int argc, char** argv)
                bytes);                                                           \
         check("stage " #REMAP " " #U, true);                                     \
     }
-    RUN_STAGE(true, 9)
     RUN_STAGE(false, 9)
-    RUN_STAGE(true, 14)
 
 #define RUN_CLASSICAL(SUB)                                                       \
     {                                                                            \
@@ -301,8 +304,72 @@ int main(int argc, char** argv)
         report("classical subwave=" #SUB, ms, bytes);                            \
         check("classical " #SUB, false);                                         \
     }
-    RUN_CLASSICAL(32)
-    RUN_CLASSICAL(16)
+
+#define RUN_PIPE(ROWS, E, U, RING, SPW, ABL)                                     \
+    {                                                                            \
+        const int64_t nsg = (n + ROWS - 1) / ROWS;                               \
+        const int64_t spw = SPW > 0 ? SPW : (nsg + (-SPW) * 256 - 1) / ((-SPW) * 256); \
+        const int64_t nw = (nsg + spw - 1) / spw;                                \
+        ms = T.ms(reps, [&] {                                                    \
+            csr_spmv_pipe_kernel<double, int, false, ROWS, E, U, RING, ABL>      \
+                <<<dim3(unsigned(nw)), dim3(64)>>>(n, nsg, spw, row_ptrs, cols,  \
+                                                   vals, x, 1, y, 1, 1, nullptr, \
+                                                   nullptr);                     \
+        });                                                                      \
+        report("pipe rows=" #ROWS " E=" #E " U=" #U " ring=" #RING " spw=" #SPW  \
+               " abl=" #ABL, ms, bytes);                                         \
+        if (!(ABL & 3)) check("pipe", true);                                    \
+    }
+    // SPW < 0: persistent, -SPW waves per CU
+    if (false) {
+    pmc_runs:
+        RUN_PIPE(32, 4, 1, 1024, 2, 0)
+        return 0;
+    }
+#define RUN_PIPE2(ROWS, E, U, RING, GB, SPW, ABL)                                \
+    {                                                                            \
+        const int64_t nsg = (n + ROWS - 1) / ROWS;                               \
+        const int64_t spw = SPW;                                                 \
+        const int64_t nw = (nsg + spw - 1) / spw;                                \
+        ms = T.ms(reps, [&] {                                                    \
+            csr_spmv_pipe2_kernel<double, int, false, ROWS, E, U, RING, GB, ABL> \
+                <<<dim3(unsigned(nw)), dim3(64)>>>(n, nsg, spw, row_ptrs, cols,  \
+                                                   vals, x, 1, y, 1, 1, nullptr, \
+                                                   nullptr);                     \
+        });                                                                      \
+        report("pipe2 rows=" #ROWS " E=" #E " U=" #U " ring=" #RING " gb=" #GB   \
+               " spw=" #SPW " abl=" #ABL, ms, bytes);                            \
+        if (!(ABL & 3)) check("pipe2", true);                                    \
+    }
+#define RUN_PIPE3(ROWS, E, U, RING, WPS, SPW, ABL)                               \
+    {                                                                            \
+        const int64_t nsg = (n + ROWS - 1) / ROWS;                               \
+        const int64_t spw = SPW;                                                 \
+        const int64_t nw = (nsg + spw - 1) / spw;                                \
+        ms = T.ms(reps, [&] {                                                    \
+            csr_spmv_pipe3_kernel<double, int, false, ROWS, E, U, RING, WPS, ABL> \
+                <<<dim3(unsigned(nw)), dim3(64)>>>(n, nsg, spw, row_ptrs, cols,  \
+                                                   vals, x, 1, y, 1, 1, nullptr, \
+                                                   nullptr);                     \
+        });                                                                      \
+        report("pipe3 rows=" #ROWS " E=" #E " U=" #U " ring=" #RING " wps=" #WPS \
+               " spw=" #SPW " abl=" #ABL, ms, bytes);                            \
+        if (!(ABL & 3)) check("pipe3", true);                                    \
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+    RUN_PIPE(32, 4, 1, 1024, 2, 0)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0)
+    RUN_PIPE3(32, 4, 1, 1024, 6, 2, 0)
+    RUN_PIPE3(32, 4, 1, 512, 8, 2, 0)
+    RUN_PIPE3(32, 4, 1, 512, 7, 2, 0)
+    RUN_PIPE3(32, 4, 1, 512, 6, 2, 0)
+    RUN_PIPE3(32, 2, 2, 512, 8, 2, 0)
+    RUN_PIPE3(32, 2, 1, 256, 8, 2, 0)
+    RUN_PIPE3(32, 4, 1, 512, 8, 4, 0)
+    RUN_PIPE3(32, 4, 1, 512, 8, 1, 0)
+    RUN_PIPE3(32, 4, 2, 1024, 4, 2, 0)
+    RUN_PIPE3(32, 4, 2, 1024, 5, 2, 0)
+    }
     RUN_CLASSICAL(8)
     return 0;
 }
