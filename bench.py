@@ -206,7 +206,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
-                         "kernel": "csr_spmv_wave_kernel<double,int>",
+                         "kernel": "csr_spmv_pipe3_kernel<double,int,...>",
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(per_gpu_bytes)},
         }
