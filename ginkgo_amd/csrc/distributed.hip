@@ -1,0 +1,262 @@
+// Row-partitioned (multi-GPU) support kernels.
+//
+// Device-side equivalents of what Ginkgo's experimental::distributed::Matrix
+// does when it is read (core/distributed/matrix.cpp:300-381:
+// distributed_matrix::separate_local_nonlocal + index_map) and applied
+// (matrix.cpp:450-509: local SpMV, halo gather, non-local SpMV):
+//
+//  * split: the rows a rank owns (CSR with GLOBAL column indices) are split into
+//    `local` (columns in the rank's own range [col_lo, col_hi), re-based to 0)
+//    and `non-local` (all other columns, compressed to a dense halo index space
+//    = rank of the column among the sorted distinct non-local columns, which is
+//    Ginkgo's index_map ordering for a contiguous partition).  The non-local
+//    part is stored as a ROW LIST (only rows that have non-local entries), so
+//    that applying it touches 2 boundary planes instead of re-reading and
+//    re-writing the whole local vector as csr::advanced_spmv(1, A_nl, x, 1, y)
+//    does in the stock path;
+//  * row-list SpMV: y[rows[i]] += sum_k vals[k] * halo[cols[k]], sequential in
+//    k starting from y (== advanced_spmv with alpha = beta = 1, bit-identical
+//    to the reference's distributed apply on the same partition).
+// Integer outputs are exact; everything runs on the caller's stream.
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace gkoc {
+namespace {
+
+template <typename I>
+__global__ __launch_bounds__(256) void dist_mark_count_kernel(
+    int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    int64_t col_lo, int64_t col_hi, I* __restrict__ col_map,
+    I* __restrict__ local_cnt, I* __restrict__ nl_cnt)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row > n_rows) return;
+    if (row == n_rows) {
+        local_cnt[row] = 0;
+        nl_cnt[row] = 0;
+        return;
+    }
+    I lc = 0, nc = 0;
+    for (int64_t k = row_ptrs[row]; k < row_ptrs[row + 1]; ++k) {
+        const int64_t c = cols[k];
+        if (c >= col_lo && c < col_hi) {
+            ++lc;
+        } else {
+            ++nc;
+            col_map[c] = 1;  // benign race: every writer stores 1
+        }
+    }
+    local_cnt[row] = lc;
+    nl_cnt[row] = nc;
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void dist_fill_kernel(
+    int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    const T* __restrict__ vals, int64_t col_lo, int64_t col_hi,
+    const I* __restrict__ col_map, const I* __restrict__ local_ptrs,
+    const I* __restrict__ nl_ptrs_full, I* __restrict__ local_cols,
+    T* __restrict__ local_vals, I* __restrict__ nl_cols, T* __restrict__ nl_vals)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    int64_t lp = local_ptrs[row], np = nl_ptrs_full[row];
+    for (int64_t k = row_ptrs[row]; k < row_ptrs[row + 1]; ++k) {
+        const int64_t c = cols[k];
+        if (c >= col_lo && c < col_hi) {
+            local_cols[lp] = I(c - col_lo);
+            local_vals[lp] = vals[k];
+            ++lp;
+        } else {
+            nl_cols[np] = col_map[c];
+            nl_vals[np] = vals[k];
+            ++np;
+        }
+    }
+}
+
+// recv_gidx[col_map[c]] = c for every marked column (col_map is the exclusive
+// scan of the marks, so marked <=> col_map[c+1] - col_map[c] == 1)
+template <typename I>
+__global__ __launch_bounds__(256) void dist_halo_list_kernel(
+    int64_t n_cols, const I* __restrict__ col_map, I* __restrict__ recv_gidx)
+{
+    const int64_t c = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (c >= n_cols) return;
+    if (col_map[c + 1] != col_map[c]) recv_gidx[int64_t(col_map[c])] = I(c);
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void dist_row_flag_kernel(
+    int64_t n_rows, const I* __restrict__ nl_ptrs_full, I* __restrict__ flag)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row > n_rows) return;
+    flag[row] = row < n_rows ? I(nl_ptrs_full[row + 1] != nl_ptrs_full[row]) : I(0);
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void dist_row_list_kernel(
+    int64_t n_rows, const I* __restrict__ nl_ptrs_full,
+    const I* __restrict__ pos, I* __restrict__ nl_rows, I* __restrict__ nl_ptrs)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row > n_rows) return;
+    if (row == n_rows) {
+        nl_ptrs[int64_t(pos[n_rows])] = nl_ptrs_full[n_rows];
+        return;
+    }
+    if (nl_ptrs_full[row + 1] != nl_ptrs_full[row]) {
+        nl_rows[int64_t(pos[row])] = I(row);
+        nl_ptrs[int64_t(pos[row])] = nl_ptrs_full[row];
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void csr_rowlist_add_kernel(
+    int64_t n_list, const I* __restrict__ rows, const I* __restrict__ ptrs,
+    const I* __restrict__ cols, const T* __restrict__ vals,
+    const T* __restrict__ halo, int64_t ld_halo, T* __restrict__ y, int64_t ldy,
+    int nrhs)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n_list) return;
+    const int64_t row = rows[i];
+    for (int j = 0; j < nrhs; ++j) {
+        T sum = y[row * ldy + j];
+        for (int64_t k = ptrs[i]; k < ptrs[i + 1]; ++k) {
+            sum += vals[k] * halo[int64_t(cols[k]) * ld_halo + j];
+        }
+        y[row * ldy + j] = sum;
+    }
+}
+
+inline dim3 grid_for(int64_t n) { return dim3(unsigned(ceildiv(n > 0 ? n : 1, 256))); }
+
+template <typename I>
+int split_count(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,
+                int64_t col_lo, int64_t col_hi, int64_t n_global_cols, I* col_map,
+                I* local_ptrs, I* nl_ptrs_full, int64_t* n_halo, int64_t* nnz_local,
+                int64_t* nnz_nl, int64_t* n_nl_rows)
+{
+    GKOC_REQUIRE(n_rows >= 0 && col_lo >= 0 && col_lo <= col_hi &&
+                     col_hi <= n_global_cols,
+                 GKOC_E_INVALID, "bad partition range");
+    GKOC_REQUIRE(col_map && local_ptrs && nl_ptrs_full && n_halo && nnz_local &&
+                     nnz_nl && n_nl_rows,
+                 GKOC_E_INVALID, "null output");
+    hipStream_t st = as_stream(s);
+    GKOC_HIP(hipMemsetAsync(col_map, 0, sizeof(I) * (n_global_cols + 1), st));
+    dist_mark_count_kernel<I><<<grid_for(n_rows + 1), dim3(256), 0, st>>>(
+        n_rows, row_ptrs, cols, col_lo, col_hi, col_map, local_ptrs, nl_ptrs_full);
+    GKOC_LAUNCH_OK();
+    int rc = device_exclusive_scan<I>(st, col_map, n_global_cols + 1);
+    if (rc) return rc;
+    rc = device_exclusive_scan<I>(st, local_ptrs, n_rows + 1);
+    if (rc) return rc;
+    // number of rows with non-local entries: scan of flags in a temporary
+    I* flag = nullptr;
+    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&flag), sizeof(I) * (n_rows + 1), st));
+    rc = device_exclusive_scan<I>(st, nl_ptrs_full, n_rows + 1);
+    if (rc) return rc;
+    dist_row_flag_kernel<I><<<grid_for(n_rows + 1), dim3(256), 0, st>>>(n_rows, nl_ptrs_full, flag);
+    GKOC_LAUNCH_OK();
+    rc = device_exclusive_scan<I>(st, flag, n_rows + 1);
+    if (rc) return rc;
+    I h[4] = {0, 0, 0, 0};
+    GKOC_HIP(hipMemcpyAsync(&h[0], col_map + n_global_cols, sizeof(I), hipMemcpyDeviceToHost, st));
+    GKOC_HIP(hipMemcpyAsync(&h[1], local_ptrs + n_rows, sizeof(I), hipMemcpyDeviceToHost, st));
+    GKOC_HIP(hipMemcpyAsync(&h[2], nl_ptrs_full + n_rows, sizeof(I), hipMemcpyDeviceToHost, st));
+    GKOC_HIP(hipMemcpyAsync(&h[3], flag + n_rows, sizeof(I), hipMemcpyDeviceToHost, st));
+    GKOC_HIP(hipStreamSynchronize(st));
+    GKOC_HIP(hipFreeAsync(flag, st));
+    *n_halo = int64_t(h[0]);
+    *nnz_local = int64_t(h[1]);
+    *nnz_nl = int64_t(h[2]);
+    *n_nl_rows = int64_t(h[3]);
+    return GKOC_OK;
+}
+
+template <typename T, typename I>
+int split_fill(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,
+               const T* vals, int64_t col_lo, int64_t col_hi, int64_t n_global_cols,
+               const I* col_map, const I* local_ptrs, const I* nl_ptrs_full,
+               I* local_cols, T* local_vals, I* nl_rows, I* nl_ptrs, I* nl_cols,
+               T* nl_vals, I* recv_gidx)
+{
+    hipStream_t st = as_stream(s);
+    if (n_rows > 0) {
+        dist_fill_kernel<T, I><<<grid_for(n_rows), dim3(256), 0, st>>>(
+            n_rows, row_ptrs, cols, vals, col_lo, col_hi, col_map, local_ptrs,
+            nl_ptrs_full, local_cols, local_vals, nl_cols, nl_vals);
+        GKOC_LAUNCH_OK();
+    }
+    dist_halo_list_kernel<I><<<grid_for(n_global_cols), dim3(256), 0, st>>>(
+        n_global_cols, col_map, recv_gidx);
+    GKOC_LAUNCH_OK();
+    I* pos = nullptr;
+    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&pos), sizeof(I) * (n_rows + 1), st));
+    dist_row_flag_kernel<I><<<grid_for(n_rows + 1), dim3(256), 0, st>>>(n_rows, nl_ptrs_full, pos);
+    GKOC_LAUNCH_OK();
+    int rc = device_exclusive_scan<I>(st, pos, n_rows + 1);
+    if (rc) return rc;
+    dist_row_list_kernel<I><<<grid_for(n_rows + 1), dim3(256), 0, st>>>(
+        n_rows, nl_ptrs_full, pos, nl_rows, nl_ptrs);
+    GKOC_LAUNCH_OK();
+    GKOC_HIP(hipFreeAsync(pos, st));
+    return GKOC_OK;
+}
+
+}  // namespace
+}  // namespace gkoc
+
+using namespace gkoc;
+
+#define GKOC_DEF_DIST_IDX(I, IN)                                               \
+    extern "C" int gkoc_dist_split_count_##IN(                                 \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,     \
+        int64_t col_lo, int64_t col_hi, int64_t n_global_cols, I* col_map,     \
+        I* local_row_ptrs, I* nl_row_ptrs_full, int64_t* n_halo_host,          \
+        int64_t* nnz_local_host, int64_t* nnz_nl_host,                         \
+        int64_t* n_nl_rows_host)                                               \
+    {                                                                          \
+        return split_count<I>(s, n_rows, row_ptrs, cols, col_lo, col_hi,       \
+                              n_global_cols, col_map, local_row_ptrs,          \
+                              nl_row_ptrs_full, n_halo_host, nnz_local_host,   \
+                              nnz_nl_host, n_nl_rows_host);                    \
+    }
+GKOC_DEF_DIST_IDX(int32_t, i32)
+GKOC_DEF_DIST_IDX(int64_t, i64)
+
+#define GKOC_DEF_DIST(T, TN, I, IN)                                            \
+    extern "C" int gkoc_dist_split_fill_##TN##_##IN(                           \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,     \
+        const T* vals, int64_t col_lo, int64_t col_hi, int64_t n_global_cols,  \
+        const I* col_map, const I* local_row_ptrs, const I* nl_row_ptrs_full,  \
+        I* local_cols, T* local_vals, I* nl_rows, I* nl_ptrs, I* nl_cols,      \
+        T* nl_vals, I* recv_gidx)                                              \
+    {                                                                          \
+        return split_fill<T, I>(s, n_rows, row_ptrs, cols, vals, col_lo,       \
+                                col_hi, n_global_cols, col_map,                \
+                                local_row_ptrs, nl_row_ptrs_full, local_cols,  \
+                                local_vals, nl_rows, nl_ptrs, nl_cols,         \
+                                nl_vals, recv_gidx);                           \
+    }                                                                          \
+    extern "C" int gkoc_csr_rowlist_spmv_add_##TN##_##IN(                      \
+        gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \
+        const I* cols, const T* vals, const T* halo, int64_t ld_halo, T* y,    \
+        int64_t ldy, int64_t nrhs)                                             \
+    {                                                                          \
+        if (n_list <= 0 || nrhs <= 0) return GKOC_OK;                          \
+        csr_rowlist_add_kernel<T, I>                                           \
+            <<<grid_for(n_list), dim3(256), 0, as_stream(s)>>>(                \
+                n_list, rows, ptrs, cols, vals, halo, ld_halo, y, ldy,         \
+                int(nrhs));                                                    \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }
+GKOC_DEF_DIST(double, f64, int32_t, i32)
+GKOC_DEF_DIST(double, f64, int64_t, i64)
+GKOC_DEF_DIST(float, f32, int32_t, i32)
+GKOC_DEF_DIST(float, f32, int64_t, i64)

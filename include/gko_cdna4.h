@@ -391,6 +391,46 @@ GKOC_DECL_STENCIL_FILL(double, f64, int64_t, i64)
 GKOC_DECL_STENCIL_FILL(float, f32, int32_t, i32)
 GKOC_DECL_STENCIL_FILL(float, f32, int64_t, i64)
 
+/* ------------------------------------------------ row-partitioned matrices
+ * What experimental::distributed::Matrix does on read and apply
+ * (core/distributed/matrix.cpp:300-381 read_distributed ->
+ * distributed_matrix::separate_local_nonlocal + index_map; :450-509 apply_impl).
+ * A rank owns rows with GLOBAL column indices and the column range
+ * [col_lo, col_hi).  split_count / split_fill produce
+ *   - the local matrix (columns re-based to col_lo), CSR,
+ *   - the non-local part as a ROW LIST: nl_rows[i] = local row, its entries
+ *     nl_ptrs[i]..nl_ptrs[i+1] with columns in the dense halo index space,
+ *   - recv_gidx[h] = global column of halo slot h (ascending), i.e. the rows
+ *     this rank must receive (index_map's ordering for contiguous partitions).
+ * col_map is caller-owned scratch of n_global_cols + 1 indices.  All integer
+ * outputs are exact.  rowlist_spmv_add: y[nl_rows[i]] += A_nl(i,:) * halo,
+ * accumulated in k order on top of y (== csr::advanced_spmv(1, A_nl, halo, 1, y),
+ * matrix.cpp:498-507, restricted to the rows that have non-local entries). */
+#define GKOC_DECL_DIST_IDX(I, IN)                                              \
+    int gkoc_dist_split_count_##IN(                                            \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,     \
+        int64_t col_lo, int64_t col_hi, int64_t n_global_cols, I* col_map,     \
+        I* local_row_ptrs, I* nl_row_ptrs_full, int64_t* n_halo_host,          \
+        int64_t* nnz_local_host, int64_t* nnz_nl_host,                         \
+        int64_t* n_nl_rows_host);
+GKOC_DECL_DIST_IDX(int32_t, i32)
+GKOC_DECL_DIST_IDX(int64_t, i64)
+#define GKOC_DECL_DIST(T, TN, I, IN)                                           \
+    int gkoc_dist_split_fill_##TN##_##IN(                                      \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,     \
+        const T* vals, int64_t col_lo, int64_t col_hi, int64_t n_global_cols,  \
+        const I* col_map, const I* local_row_ptrs, const I* nl_row_ptrs_full,  \
+        I* local_cols, T* local_vals, I* nl_rows, I* nl_ptrs, I* nl_cols,      \
+        T* nl_vals, I* recv_gidx);                                             \
+    int gkoc_csr_rowlist_spmv_add_##TN##_##IN(                                 \
+        gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \
+        const I* cols, const T* vals, const T* halo, int64_t ld_halo, T* y,    \
+        int64_t ldy, int64_t nrhs);
+GKOC_DECL_DIST(double, f64, int32_t, i32)
+GKOC_DECL_DIST(double, f64, int64_t, i64)
+GKOC_DECL_DIST(float, f32, int32_t, i32)
+GKOC_DECL_DIST(float, f32, int64_t, i64)
+
 #ifdef __cplusplus
 }
 #endif
