@@ -26,8 +26,12 @@ def _launch(mode, world, grid, timeout=600):
            "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(grid)]
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for attempt in range(2):       # one retry: the rendezvous port can race
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+        if p.returncode == 0:
+            break
+    assert p.returncode == 0, p.stdout[-3000:] + "\n--- stderr ---\n" + p.stderr[-12000:]
     assert "dist_worker OK" in p.stdout
 
 
