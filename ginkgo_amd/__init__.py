@@ -11,10 +11,10 @@ from ._lib import (DimensionMismatch, GkoError, NotCompiled, NotSupported,
 from .executor import Cdna4Executor
 from .matrix import Csr, Dense, Ell, Sellp, scalar, stencil_csr
 from .preconditioner import Jacobi, compute_storage_scheme
-from .solver import Cg, Identity
+from .solver import Cg, Gmres, Identity, ortho_method
 from . import stop
 
 __all__ = ["Cdna4Executor", "Csr", "Dense", "Ell", "Sellp", "scalar",
-           "stencil_csr", "Jacobi", "compute_storage_scheme", "Cg", "Identity",
+           "stencil_csr", "Jacobi", "compute_storage_scheme", "Cg", "Gmres", "ortho_method", "Identity",
            "stop", "GkoError", "NotCompiled", "NotSupported",
            "DimensionMismatch", "LIB_PATH"]

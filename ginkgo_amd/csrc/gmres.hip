@@ -1,0 +1,373 @@
+// GMRES inner-loop kernels for gfx950.
+//
+// Replaces gko::kernels::hip::gmres::{restart, multi_axpy, multi_dot} and
+// common_gmres::{initialize, hessenberg_qr, solve_krylov}
+// (decl core/solver/gmres_kernels.hpp:23-45, common_gmres_kernels.hpp:23-48;
+// semantics reference/solver/gmres_kernels.cpp:26-100,
+// reference/solver/common_gmres_kernels.cpp:28-193; stock GPU versions
+// common/unified/solver/gmres_kernels.cpp:25-122, common_gmres_kernels.cpp:25-160).
+//
+// The Krylov basis is one tall Dense ((krylov_dim+1)*n x nrhs); basis vector i
+// occupies rows [i*n, (i+1)*n).
+//  * multi_dot (classical Gram-Schmidt): every workgroup keeps its 1024-row
+//    chunk of next_krylov in registers and streams the matching chunk of each
+//    basis vector past it => next_krylov is read ONCE for all k+1 dots
+//    ((k+2)*n values of HBM traffic instead of 2(k+1)*n for k+1 separate
+//    dots); fixed two-level reduction tree, deterministic.
+//  * multi_axpy: one pass, each thread accumulates its row over the basis
+//    vectors in j order (bit-identical to the reference).
+//  * restart / initialize: element-wise.  hessenberg_qr / solve_krylov: one
+//    thread per right-hand side, same operation order as the reference
+//    (bit-identical: IEEE divide and sqrt, no FMA contraction).
+#include <cmath>
+
+#include "common.hpp"
+
+namespace gkoc {
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void gmres_restart_kernel(
+    int64_t rows, int64_t cols, const T* __restrict__ residual, int64_t ldr,
+    const T* __restrict__ residual_norm, T* __restrict__ rnc,
+    T* __restrict__ krylov, int64_t ldk, uint64_t* __restrict__ final_iter_nums)
+{
+    const int64_t total = rows * cols;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x; idx < total;
+         idx += stride) {
+        const int64_t i = cols == 1 ? idx : idx / cols;
+        const int64_t j = cols == 1 ? 0 : idx - i * cols;
+        krylov[i * ldk + j] = residual[i * ldr + j] / residual_norm[j];
+    }
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t < cols) {
+        rnc[t] = residual_norm[t];  // row 0 of residual_norm_collection
+        final_iter_nums[t] = 0;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gmres_init_kernel(
+    int64_t rows, int64_t cols, const T* __restrict__ b, int64_t ldb,
+    T* __restrict__ residual, int64_t ldr, T* __restrict__ gsin, int64_t lds,
+    T* __restrict__ gcos, int64_t ldc, int64_t krylov_dim,
+    uint8_t* __restrict__ stop)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    const int64_t tid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    for (int64_t idx = tid; idx < rows * cols; idx += stride) {
+        const int64_t i = cols == 1 ? idx : idx / cols;
+        const int64_t j = cols == 1 ? 0 : idx - i * cols;
+        residual[i * ldr + j] = b[i * ldb + j];
+    }
+    for (int64_t idx = tid; idx < krylov_dim * cols; idx += stride) {
+        const int64_t i = idx / cols;
+        const int64_t j = idx - i * cols;
+        gsin[i * lds + j] = T(0);
+        gcos[i * ldc + j] = T(0);
+    }
+    if (tid < cols) stop[tid] = 0;
+}
+
+// before_preconditioner(i,k) = sum_{j < final_iter_nums[k]} krylov(i + j*rows, k) * y(j,k)
+template <typename T>
+__global__ __launch_bounds__(256) void gmres_multi_axpy_kernel(
+    int64_t rows, int64_t cols, const T* __restrict__ krylov, int64_t ldk,
+    const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_t ldo,
+    const uint64_t* __restrict__ final_iter_nums,
+    const uint8_t* __restrict__ stop)
+{
+    const int64_t total = rows * cols;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x; idx < total;
+         idx += stride) {
+        const int64_t i = cols == 1 ? idx : idx / cols;
+        const int64_t k = cols == 1 ? 0 : idx - i * cols;
+        if (stop[k] & 0x40) continue;  // is_finalized
+        const int64_t nj = int64_t(final_iter_nums[k]);
+        T acc = T(0);
+        int64_t j = 0;
+        for (; j + 4 <= nj; j += 4) {
+            const T a0 = krylov[(i + j * rows) * ldk + k];
+            const T a1 = krylov[(i + (j + 1) * rows) * ldk + k];
+            const T a2 = krylov[(i + (j + 2) * rows) * ldk + k];
+            const T a3 = krylov[(i + (j + 3) * rows) * ldk + k];
+            acc += a0 * y[j * ldy + k];
+            acc += a1 * y[(j + 1) * ldy + k];
+            acc += a2 * y[(j + 2) * ldy + k];
+            acc += a3 * y[(j + 3) * ldy + k];
+        }
+        for (; j < nj; ++j) acc += krylov[(i + j * rows) * ldk + k] * y[j * ldy + k];
+        out[i * ldo + k] = acc;
+    }
+}
+
+// stop_status[k].finalize() for stopped, not yet finalized columns (runs after
+// the axpy kernel, which must still see the old flags)
+__global__ void gmres_finalize_kernel(int64_t cols, uint8_t* stop)
+{
+    const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k < cols) {
+        const uint8_t s = stop[k];
+        if (!(s & 0x40) && (s & 0x3f)) stop[k] = s | uint8_t(0x40);
+    }
+}
+
+// stage 1 of multi_dot for one rhs column: block = 1024-row chunk, loops the
+// basis vectors; partial[(d*cols + col) * nblocks + block]
+constexpr int md_items = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void gmres_multi_dot_stage1(
+    int64_t rows, int64_t cols, int num_dots, const T* __restrict__ krylov,
+    int64_t ldk, const T* __restrict__ next, int64_t ldn, T* __restrict__ partial)
+{
+    __shared__ T lds[4];
+    const int64_t col = blockIdx.y;
+    const int64_t base = int64_t(blockIdx.x) * (256 * md_items);
+    T nv[md_items];
+#pragma unroll
+    for (int u = 0; u < md_items; ++u) {
+        const int64_t r = base + u * 256 + threadIdx.x;
+        nv[u] = r < rows ? next[r * ldn + col] : T(0);
+    }
+    for (int d = 0; d < num_dots; ++d) {
+        T acc = T(0);
+#pragma unroll
+        for (int u = 0; u < md_items; ++u) {
+            const int64_t r = base + u * 256 + threadIdx.x;
+            const T kv = r < rows ? krylov[(int64_t(d) * rows + r) * ldk + col] : T(0);
+            acc += kv * nv[u];
+        }
+        const T s = block_sum<256>(acc, lds);
+        if (threadIdx.x == 0) {
+            partial[(int64_t(d) * cols + col) * gridDim.x + blockIdx.x] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// stage 2: one block per (dot, col): hessenberg_col(d, col) = sum of partials
+template <typename T>
+__global__ __launch_bounds__(256) void gmres_multi_dot_stage2(
+    int64_t nblocks, int64_t cols, const T* __restrict__ partial,
+    T* __restrict__ hcol, int64_t ldh)
+{
+    __shared__ T lds[4];
+    const int64_t d = blockIdx.x / cols, col = blockIdx.x % cols;
+    T acc = T(0);
+    for (int64_t i = threadIdx.x; i < nblocks; i += 256) {
+        acc += partial[int64_t(blockIdx.x) * nblocks + i];
+    }
+    const T s = block_sum<256>(acc, lds);
+    if (threadIdx.x == 0) hcol[d * ldh + col] = s;
+}
+
+template <typename T>
+__device__ __forceinline__ T dabs(T v)
+{
+    return v < T(0) ? -v : v;
+}
+
+// reference common_gmres_kernels.cpp:28-117 + hessenberg_qr :146-165
+template <typename T>
+__global__ __launch_bounds__(256) void gmres_hessenberg_qr_kernel(
+    int64_t cols, T* __restrict__ gsin, int64_t lds_, T* __restrict__ gcos,
+    int64_t ldc, T* __restrict__ residual_norm, T* __restrict__ rnc,
+    int64_t ldr, T* __restrict__ h, int64_t ldh, int64_t iter,
+    uint64_t* __restrict__ final_iter_nums, const uint8_t* __restrict__ stop)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= cols) return;
+    if (stop[i] & 0x3f) return;
+    final_iter_nums[i]++;
+    // givens_rotation
+    for (int64_t j = 0; j < iter; ++j) {
+        const T c = gcos[j * ldc + i], s = gsin[j * lds_ + i];
+        const T hj = h[j * ldh + i], hj1 = h[(j + 1) * ldh + i];
+        const T temp = c * hj + s * hj1;
+        h[(j + 1) * ldh + i] = -s * hj + c * hj1;
+        h[j * ldh + i] = temp;
+    }
+    // calculate_sin_and_cos
+    const T this_h = h[iter * ldh + i];
+    const T next_h = h[(iter + 1) * ldh + i];
+    T c, s;
+    if (this_h == T(0)) {
+        c = T(0);
+        s = T(1);
+    } else {
+        const T scale = dabs(this_h) + dabs(next_h);
+        const T hyp = scale * sqrt(dabs(this_h / scale) * dabs(this_h / scale) +
+                                   dabs(next_h / scale) * dabs(next_h / scale));
+        c = this_h / hyp;
+        s = next_h / hyp;
+    }
+    gcos[iter * ldc + i] = c;
+    gsin[iter * lds_ + i] = s;
+    h[iter * ldh + i] = c * this_h + s * next_h;
+    h[(iter + 1) * ldh + i] = T(0);
+    // calculate_next_residual_norm
+    const T r = rnc[iter * ldr + i];
+    const T rn = -s * r;
+    rnc[(iter + 1) * ldr + i] = rn;
+    rnc[iter * ldr + i] = c * r;
+    residual_norm[i] = dabs(rn);
+}
+
+// reference common_gmres_kernels.cpp:171-193: H(i, j) at hessenberg(j, i*cols + k)
+template <typename T>
+__global__ __launch_bounds__(256) void gmres_solve_krylov_kernel(
+    int64_t cols, const T* __restrict__ rnc, int64_t ldr,
+    const T* __restrict__ h, int64_t ldh, T* __restrict__ y, int64_t ldy,
+    const uint64_t* __restrict__ final_iter_nums,
+    const uint8_t* __restrict__ stop)
+{
+    const int64_t k = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (k >= cols) return;
+    if (stop[k] & 0x40) return;  // is_finalized
+    const int64_t m = int64_t(final_iter_nums[k]);
+    for (int64_t i = m - 1; i >= 0; --i) {
+        T temp = rnc[i * ldr + k];
+        for (int64_t j = i + 1; j < m; ++j) {
+            temp -= h[j * ldh + i * cols + k] * y[j * ldy + k];
+        }
+        y[i * ldy + k] = temp / h[i * ldh + i * cols + k];
+    }
+}
+
+inline unsigned stream_blocks(int64_t n)
+{
+    int64_t b = ceildiv(n > 0 ? n : 1, 256);
+    if (b > 4 * max_stream_blocks) b = 4 * max_stream_blocks;
+    return unsigned(b);
+}
+
+}  // namespace
+}  // namespace gkoc
+
+using namespace gkoc;
+
+extern "C" size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrhs,
+                                                       int64_t num_dots,
+                                                       size_t value_size)
+{
+    const int64_t nb = ceildiv(rows > 0 ? rows : 1, 256 * md_items);
+    return size_t(nb) * size_t(nrhs > 0 ? nrhs : 1) *
+           size_t(num_dots > 0 ? num_dots : 1) * value_size;
+}
+
+#define GKOC_DEF_GMRES(T, TN)                                                  \
+    extern "C" int gkoc_common_gmres_initialize_##TN(                          \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* b, int64_t ldb,  \
+        T* residual, int64_t ldr, T* givens_sin, int64_t ld_sin,               \
+        T* givens_cos, int64_t ld_cos, int64_t krylov_dim,                     \
+        uint8_t* stop_status)                                                  \
+    {                                                                          \
+        if (nrhs <= 0) return GKOC_OK;                                         \
+        const int64_t work = rows * nrhs > krylov_dim * nrhs ? rows * nrhs     \
+                                                             : krylov_dim * nrhs; \
+        gmres_init_kernel<T><<<dim3(stream_blocks(work > nrhs ? work : nrhs)), \
+                               dim3(256), 0, as_stream(s)>>>(                  \
+            rows, nrhs, b, ldb, residual, ldr, givens_sin, ld_sin, givens_cos, \
+            ld_cos, krylov_dim, stop_status);                                  \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_gmres_restart_##TN(                                    \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* residual,        \
+        int64_t ldr, const T* residual_norm, T* residual_norm_collection,      \
+        T* krylov_bases, int64_t ldk, uint64_t* final_iter_nums)               \
+    {                                                                          \
+        if (nrhs <= 0) return GKOC_OK;                                         \
+        gmres_restart_kernel<T>                                                \
+            <<<dim3(stream_blocks(rows * nrhs > nrhs ? rows * nrhs : nrhs)),   \
+               dim3(256), 0, as_stream(s)>>>(rows, nrhs, residual, ldr,        \
+                                             residual_norm,                    \
+                                             residual_norm_collection,         \
+                                             krylov_bases, ldk,                \
+                                             final_iter_nums);                 \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_gmres_multi_axpy_##TN(                                 \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* krylov_bases,    \
+        int64_t ldk, const T* y, int64_t ldy, T* before_preconditioner,        \
+        int64_t ldo, const uint64_t* final_iter_nums, uint8_t* stop_status)    \
+    {                                                                          \
+        if (nrhs <= 0) return GKOC_OK;                                         \
+        if (rows > 0) {                                                        \
+            gmres_multi_axpy_kernel<T>                                         \
+                <<<dim3(stream_blocks(rows * nrhs)), dim3(256), 0,             \
+                   as_stream(s)>>>(rows, nrhs, krylov_bases, ldk, y, ldy,      \
+                                   before_preconditioner, ldo,                 \
+                                   final_iter_nums, stop_status);              \
+            GKOC_LAUNCH_OK();                                                  \
+        }                                                                      \
+        gmres_finalize_kernel<<<dim3(unsigned(ceildiv(nrhs, 256))), dim3(256), \
+                                0, as_stream(s)>>>(nrhs, stop_status);         \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_gmres_multi_dot_##TN(                                  \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t num_dots,         \
+        const T* krylov_bases, int64_t ldk, const T* next_krylov, int64_t ldn, \
+        T* hessenberg_col, int64_t ldh, void* work, size_t work_bytes)         \
+    {                                                                          \
+        if (nrhs <= 0 || num_dots <= 0) return GKOC_OK;                        \
+        if (rows == 0) {                                                       \
+            for (int64_t d = 0; d < num_dots; ++d) {                           \
+                GKOC_HIP(hipMemsetAsync(hessenberg_col + d * ldh, 0,           \
+                                        sizeof(T) * nrhs, as_stream(s)));      \
+            }                                                                  \
+            return GKOC_OK;                                                    \
+        }                                                                      \
+        GKOC_REQUIRE(work_bytes >= gkoc_gmres_multi_dot_workspace_bytes(       \
+                                       rows, nrhs, num_dots, sizeof(T)),       \
+                     GKOC_E_WORKSPACE, "multi_dot workspace too small");       \
+        const int64_t nb = ceildiv(rows, 256 * md_items);                      \
+        gmres_multi_dot_stage1<T>                                              \
+            <<<dim3(unsigned(nb), unsigned(nrhs)), dim3(256), 0,               \
+               as_stream(s)>>>(rows, nrhs, int(num_dots), krylov_bases, ldk,   \
+                               next_krylov, ldn, static_cast<T*>(work));       \
+        GKOC_LAUNCH_OK();                                                      \
+        gmres_multi_dot_stage2<T>                                              \
+            <<<dim3(unsigned(num_dots * nrhs)), dim3(256), 0, as_stream(s)>>>( \
+                nb, nrhs, static_cast<const T*>(work), hessenberg_col, ldh);   \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_common_gmres_hessenberg_qr_##TN(                       \
+        gkoc_stream_t s, int64_t nrhs, T* givens_sin, int64_t ld_sin,          \
+        T* givens_cos, int64_t ld_cos, T* residual_norm,                       \
+        T* residual_norm_collection, int64_t ld_rnc, T* hessenberg_iter,       \
+        int64_t ld_h, int64_t iter, uint64_t* final_iter_nums,                 \
+        const uint8_t* stop_status)                                            \
+    {                                                                          \
+        if (nrhs <= 0) return GKOC_OK;                                         \
+        gmres_hessenberg_qr_kernel<T>                                          \
+            <<<dim3(unsigned(ceildiv(nrhs, 256))), dim3(256), 0,               \
+               as_stream(s)>>>(nrhs, givens_sin, ld_sin, givens_cos, ld_cos,   \
+                               residual_norm, residual_norm_collection,        \
+                               ld_rnc, hessenberg_iter, ld_h, iter,            \
+                               final_iter_nums, stop_status);                  \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_common_gmres_solve_krylov_##TN(                        \
+        gkoc_stream_t s, int64_t nrhs, const T* residual_norm_collection,      \
+        int64_t ld_rnc, const T* hessenberg, int64_t ld_h, T* y, int64_t ldy,  \
+        const uint64_t* final_iter_nums, const uint8_t* stop_status)           \
+    {                                                                          \
+        if (nrhs <= 0) return GKOC_OK;                                         \
+        gmres_solve_krylov_kernel<T>                                           \
+            <<<dim3(unsigned(ceildiv(nrhs, 256))), dim3(256), 0,               \
+               as_stream(s)>>>(nrhs, residual_norm_collection, ld_rnc,         \
+                               hessenberg, ld_h, y, ldy, final_iter_nums,      \
+                               stop_status);                                   \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }
+
+GKOC_DEF_GMRES(double, f64)
+GKOC_DEF_GMRES(float, f32)

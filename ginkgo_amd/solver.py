@@ -174,3 +174,148 @@ class Cg(_IterativeSolver):
         for c in crit.criteria:
             if getattr(c, "last_tau", None) is not None and not c.implicit:
                 self.residual_norm = c.last_tau.to_numpy()[0]
+
+
+class ortho_method:
+    """include/ginkgo/core/solver/gmres.hpp: gmres::ortho_method"""
+    mgs = "mgs"
+    cgs = "cgs"
+    cgs2 = "cgs2"
+
+
+class Gmres(_IterativeSolver):
+    """Restarted GMRES - mirror of include/ginkgo/core/solver/gmres.hpp and the
+    driver core/solver/gmres.cpp:321-621 (apply_dense_impl): same workspace
+    layout (Krylov basis = one tall Dense of (krylov_dim+1)*n rows, Hessenberg
+    stored row-per-iteration), same kernel sequence, MGS / CGS / CGS2
+    orthogonalisation (:157-300), Givens QR and restart logic.  Parameters:
+    with_krylov_dim (default 100), with_ortho_method, with_flexible."""
+
+    @staticmethod
+    def build():
+        return _SolverFactory(Gmres)
+
+    def apply_impl(self, b, x):
+        import ctypes as C
+        from . import _lib
+        ex = self.exec
+        a, m = self.system_matrix, self.preconditioner
+        suf = VT[b.dtype]
+        n, nrhs = b.size
+        kd = int(self.params.get("krylov_dim", 100)) or 100
+        ortho = self.params.get("ortho_method", ortho_method.mgs)
+        flexible = bool(self.params.get("flexible", False))
+        dt = b.dtype
+        D = lambda shape: Dense.create(ex, shape, dt)
+        residual, precv = self._vec("residual", b), self._vec("precv", b)
+        before, after = self._vec("before", b), self._vec("after", b)
+        key = ("gmres", n, nrhs, kd, dt, flexible)
+        if self._ws.get("gmres_key") != key:
+            self._ws["gmres_key"] = key
+            self._ws["krylov"] = D(((kd + 1) * n, nrhs))
+            self._ws["pkrylov"] = D(((kd + 1) * n, nrhs)) if flexible else None
+            self._ws["hess"] = D((kd, (kd + 1) * nrhs))
+            self._ws["haux"] = D((kd + 1, nrhs))
+            self._ws["gsin"], self._ws["gcos"] = D((kd, nrhs)), D((kd, nrhs))
+            self._ws["rnc"] = D((kd + 1, nrhs))
+            self._ws["rnorm"] = D((1, nrhs))
+            self._ws["y"] = D((kd, nrhs))
+            self._ws["final"] = ex.zeros((nrhs,), torch.int64)   # size_type
+            self._ws["gstop"] = ex.zeros((nrhs,), torch.uint8)
+            need = _lib.lib().gkoc_gmres_multi_dot_workspace_bytes
+            need.restype = C.c_size_t
+            self._ws["mdwork"] = ex.alloc(
+                (max(need(C.c_int64(n), C.c_int64(nrhs), C.c_int64(kd + 1),
+                          C.c_size_t(8 if dt == torch.float64 else 4)), 8),), torch.uint8)
+        w = self._ws
+        krylov, pkrylov, hess, haux = w["krylov"], w["pkrylov"], w["hess"], w["haux"]
+        gsin, gcos, rnc, rnorm, y = w["gsin"], w["gcos"], w["rnc"], w["rnorm"], w["y"]
+        final, stop_status, mdwork = w["final"], w["gstop"], w["mdwork"]
+        one = w.setdefault(("one", dt), scalar(ex, 1.0, dt))
+        neg_one = w.setdefault(("neg", dt), scalar(ex, -1.0, dt))
+
+        def basis(mat, i):
+            return mat.create_submatrix((n * i, n * (i + 1)), (0, nrhs))
+
+        def restart():
+            call("gkoc_gmres_restart_" + suf, ex.stream, n, nrhs, residual.values, residual.ld,
+                 rnorm.values, rnc.values, krylov.values, krylov.ld, final)
+
+        def multi_dot(next_k, num, target):
+            call("gkoc_gmres_multi_dot_" + suf, ex.stream, n, nrhs, num, krylov.values, krylov.ld,
+                 next_k.values, next_k.ld, target.values, target.ld, mdwork,
+                 C.c_size_t(mdwork.numel()))
+
+        call("gkoc_common_gmres_initialize_" + suf, ex.stream, n, nrhs, b.values, b.ld,
+             residual.values, residual.ld, gsin.values, gsin.ld, gcos.values, gcos.ld, kd,
+             stop_status)
+        a.apply(neg_one, x, one, residual)
+        residual.compute_norm2(rnorm)
+        restart()
+        crit = _stop.combine(self.criteria, a, b, x, residual)
+        total_iter, restart_iter = -1, 0
+        while True:
+            total_iter += 1
+            all_stopped, _ = crit.check(
+                1, False, stop_status,
+                {"num_iterations": total_iter, "residual": residual, "residual_norm": rnorm,
+                 "solution": x})
+            if all_stopped:
+                break
+            if restart_iter == kd:
+                call("gkoc_common_gmres_solve_krylov_" + suf, ex.stream, nrhs, rnc.values, rnc.ld,
+                     hess.values, hess.ld, y.values, y.ld, final, stop_status)
+                call("gkoc_gmres_multi_axpy_" + suf, ex.stream, n, nrhs, krylov.values, krylov.ld,
+                     y.values, y.ld, before.values, before.ld, final, stop_status)
+                m.apply(before, after)
+                x.add_scaled(one, after)
+                residual.copy_from(b)
+                a.apply(neg_one, x, one, residual)
+                residual.compute_norm2(rnorm)
+                restart()
+                restart_iter = 0
+            this_k, next_k = basis(krylov, restart_iter), basis(krylov, restart_iter + 1)
+            pre_k = basis(pkrylov, restart_iter) if flexible else precv
+            m.apply(this_k, pre_k)
+            # hessenberg_iter: (restart_iter + 2) x nrhs view into row restart_iter
+            hrow = hess.values[restart_iter, :(restart_iter + 2) * nrhs]
+            hiter = Dense(ex, hrow.view(restart_iter + 2, nrhs))
+            a.apply(pre_k, next_k)
+            if ortho == ortho_method.mgs:
+                for i in range(restart_iter + 1):
+                    h_i = hiter.create_submatrix((i, i + 1), (0, nrhs))
+                    basis(krylov, i).compute_conj_dot(next_k, h_i)
+                    next_k.sub_scaled(h_i, basis(krylov, i))
+            else:
+                multi_dot(next_k, restart_iter + 1, hiter)
+                for i in range(restart_iter + 1):
+                    next_k.sub_scaled(hiter.create_submatrix((i, i + 1), (0, nrhs)),
+                                      basis(krylov, i))
+                if ortho == ortho_method.cgs2:
+                    aux = haux.create_submatrix((0, restart_iter + 2), (0, nrhs))
+                    multi_dot(next_k, restart_iter + 1, aux)
+                    for i in range(restart_iter + 1):
+                        next_k.sub_scaled(haux.create_submatrix((i, i + 1), (0, nrhs)),
+                                          basis(krylov, i))
+                    hiter.add_scaled(one, aux)
+            h_norm = hiter.create_submatrix((restart_iter + 1, restart_iter + 2), (0, nrhs))
+            next_k.compute_norm2(h_norm)
+            next_k.inv_scale(h_norm)
+            call("gkoc_common_gmres_hessenberg_qr_" + suf, ex.stream, nrhs, gsin.values, gsin.ld,
+                 gcos.values, gcos.ld, rnorm.values, rnc.values, rnc.ld, hiter.values, hiter.ld,
+                 restart_iter, final, stop_status)
+            restart_iter += 1
+        call("gkoc_common_gmres_solve_krylov_" + suf, ex.stream, nrhs, rnc.values, rnc.ld,
+             hess.values, hess.ld, y.values, y.ld, final, stop_status)
+        if flexible:
+            call("gkoc_gmres_multi_axpy_" + suf, ex.stream, n, nrhs, pkrylov.values, pkrylov.ld,
+                 y.values, y.ld, after.values, after.ld, final, stop_status)
+        else:
+            call("gkoc_gmres_multi_axpy_" + suf, ex.stream, n, nrhs, krylov.values, krylov.ld,
+                 y.values, y.ld, before.values, before.ld, final, stop_status)
+            m.apply(before, after)
+        x.add_scaled(one, after)
+        self.num_iterations = total_iter
+        self.stop_status = stop_status
+        self.has_converged = bool(((stop_status.cpu() & 0x80) != 0).all().item())
+        self.residual_norm = rnorm.to_numpy()[0]

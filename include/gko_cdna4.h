@@ -284,6 +284,50 @@ GKOC_DECL_DENSE(float, f32)
 GKOC_DECL_CG(double, f64)
 GKOC_DECL_CG(float, f32)
 
+/* ----------------------------------------------------------------- GMRES
+ * gmres::{restart,multi_axpy,multi_dot}  core/solver/gmres_kernels.hpp:23-45,
+ * common_gmres::{initialize,hessenberg_qr,solve_krylov}
+ * core/solver/common_gmres_kernels.hpp:23-48; semantics
+ * reference/solver/gmres_kernels.cpp:26-100, common_gmres_kernels.cpp:28-193.
+ * krylov_bases: ((krylov_dim+1)*rows) x nrhs, basis i in rows [i*rows,(i+1)*rows);
+ * hessenberg entry H(i,j) of column k at hessenberg[j*ld_h + i*nrhs + k]
+ * (core/solver/gmres.cpp:352-363, :540-545); final_iter_nums is a size_type
+ * (uint64) array; residual_norm is 1 x nrhs.  multi_dot: hessenberg_col(d,k) =
+ * <basis_d(:,k), next_krylov(:,k)> for d < num_dots, deterministic tree
+ * (tolerance 1e-13); everything else is bit-identical to the reference. */
+size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrhs,
+                                            int64_t num_dots, size_t value_size);
+#define GKOC_DECL_GMRES(T, TN)                                                 \
+    int gkoc_common_gmres_initialize_##TN(                                     \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* b, int64_t ldb,  \
+        T* residual, int64_t ldr, T* givens_sin, int64_t ld_sin,               \
+        T* givens_cos, int64_t ld_cos, int64_t krylov_dim,                     \
+        uint8_t* stop_status);                                                 \
+    int gkoc_gmres_restart_##TN(                                               \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* residual,        \
+        int64_t ldr, const T* residual_norm, T* residual_norm_collection,      \
+        T* krylov_bases, int64_t ldk, uint64_t* final_iter_nums);              \
+    int gkoc_gmres_multi_axpy_##TN(                                            \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* krylov_bases,    \
+        int64_t ldk, const T* y, int64_t ldy, T* before_preconditioner,        \
+        int64_t ldo, const uint64_t* final_iter_nums, uint8_t* stop_status);   \
+    int gkoc_gmres_multi_dot_##TN(                                             \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t num_dots,         \
+        const T* krylov_bases, int64_t ldk, const T* next_krylov, int64_t ldn, \
+        T* hessenberg_col, int64_t ldh, void* work, size_t work_bytes);        \
+    int gkoc_common_gmres_hessenberg_qr_##TN(                                  \
+        gkoc_stream_t s, int64_t nrhs, T* givens_sin, int64_t ld_sin,          \
+        T* givens_cos, int64_t ld_cos, T* residual_norm,                       \
+        T* residual_norm_collection, int64_t ld_rnc, T* hessenberg_iter,       \
+        int64_t ld_h, int64_t iter, uint64_t* final_iter_nums,                 \
+        const uint8_t* stop_status);                                           \
+    int gkoc_common_gmres_solve_krylov_##TN(                                   \
+        gkoc_stream_t s, int64_t nrhs, const T* residual_norm_collection,      \
+        int64_t ld_rnc, const T* hessenberg, int64_t ld_h, T* y, int64_t ldy,  \
+        const uint64_t* final_iter_nums, const uint8_t* stop_status);
+GKOC_DECL_GMRES(double, f64)
+GKOC_DECL_GMRES(float, f32)
+
 /* ------------------------------------------------------- stopping criteria
  * residual_norm::residual_norm, implicit_residual_norm::implicit_residual_norm,
  * set_all_statuses  (core/stop/residual_norm_kernels.hpp,

@@ -361,3 +361,102 @@ int64_t oracle_cg_solve_f64_i32(int64_t n, const int32_t* row_ptrs,
     free(r);
     return iter;
 }
+
+/* ---- GMRES driver --------------------------------------------------------
+ * core/solver/gmres.cpp:321-621 (Gmres::apply_dense_impl), one right-hand
+ * side, non-flexible, f64 / int32; ortho: 0 = mgs (:157-177), 1 = cgs
+ * (:223-251), 2 = cgs2 (:254-300).  Criterion: Combined(Iteration,
+ * ResidualNorm(rhs_norm)) checked with the Givens residual-norm estimate
+ * (updater.residual_norm(residual_norm), gmres.cpp:452-458).  Returns the
+ * total iteration count. */
+int64_t oracle_gmres_solve_f64_i32(int64_t n, const int32_t* row_ptrs,
+                                   const int32_t* cols, const double* vals,
+                                   const oracle_precond* m, const double* b,
+                                   double* x, int64_t krylov_dim, int ortho,
+                                   int64_t max_iters, double reduction,
+                                   double* resnorm_out)
+{
+    const int64_t kd = krylov_dim;
+    double* residual = (double*)malloc(sizeof(double) * (size_t)n * 4);
+    double *precv = residual + n, *before = precv + n, *after = before + n;
+    double* krylov = (double*)malloc(sizeof(double) * (size_t)n * (size_t)(kd + 1));
+    double* hess = (double*)calloc((size_t)(kd * (kd + 1)), sizeof(double));
+    double* haux = (double*)calloc((size_t)(kd + 1), sizeof(double));
+    double* gsin = (double*)calloc((size_t)kd, sizeof(double));
+    double* gcos = (double*)calloc((size_t)kd, sizeof(double));
+    double* rnc = (double*)calloc((size_t)(kd + 1), sizeof(double));
+    double* y = (double*)calloc((size_t)kd, sizeof(double));
+    double residual_norm = 0, tau0 = 0;
+    uint64_t final_iter = 0;
+    uint8_t stop = 0;
+    const int64_t hld = kd + 1; /* row stride of hessenberg (nrhs = 1) */
+
+    oracle_gmres_initialize_f64(n, 1, b, 1, residual, 1, gsin, gcos, kd, &stop);
+    oracle_csr_advanced_spmv_f64_i32(n, -1.0, row_ptrs, cols, vals, x, 1, 1.0, residual, 1, 1);
+    oracle_dense_compute_norm2_f64(n, 1, residual, 1, &residual_norm, 0);
+    oracle_gmres_restart_f64(n, 1, residual, 1, &residual_norm, rnc, krylov, 1, &final_iter);
+    oracle_dense_compute_norm2_f64(n, 1, b, 1, &tau0, 0);
+
+    int64_t total_iter = -1, restart_iter = 0;
+    for (;;) {
+        ++total_iter;
+        int all_stopped = 0, one_changed = 0;
+        if (total_iter >= max_iters) {
+            if ((stop & 0x3f) == 0) stop |= 1; /* Iteration: id 1, setFinalized = false */
+            all_stopped = 1;
+        } else {
+            all_stopped = oracle_residual_norm_f64(1, &residual_norm, &tau0, reduction, 2, 0,
+                                                   &stop, 0, &one_changed);
+        }
+        if (all_stopped) break;
+        if (restart_iter == kd) {
+            oracle_gmres_solve_krylov_f64(1, rnc, hess, hld, y, &final_iter, &stop);
+            oracle_gmres_multi_axpy_f64(n, 1, krylov, 1, y, 1, before, 1, &final_iter, &stop);
+            apply_precond(m, n, before, after);
+            { const double one = 1.0; oracle_dense_add_scaled_f64(n, 1, &one, 1, after, 1, x, 1, 0); }
+            memcpy(residual, b, sizeof(double) * (size_t)n);
+            oracle_csr_advanced_spmv_f64_i32(n, -1.0, row_ptrs, cols, vals, x, 1, 1.0, residual, 1, 1);
+            oracle_dense_compute_norm2_f64(n, 1, residual, 1, &residual_norm, 0);
+            oracle_gmres_restart_f64(n, 1, residual, 1, &residual_norm, rnc, krylov, 1, &final_iter);
+            restart_iter = 0;
+        }
+        double* this_k = krylov + n * restart_iter;
+        double* next_k = krylov + n * (restart_iter + 1);
+        double* hiter = hess + restart_iter * hld; /* (restart_iter + 2) x 1 */
+        apply_precond(m, n, this_k, precv);
+        oracle_csr_spmv_f64_i32(n, row_ptrs, cols, vals, precv, 1, next_k, 1, 1);
+        if (ortho == 0) {
+            for (int64_t i = 0; i <= restart_iter; ++i) {
+                oracle_dense_compute_dot_f64(n, 1, krylov + n * i, 1, next_k, 1, &hiter[i]);
+                oracle_dense_add_scaled_f64(n, 1, &hiter[i], 1, krylov + n * i, 1, next_k, 1, 1);
+            }
+        } else {
+            oracle_gmres_multi_dot_f64(n, 1, restart_iter + 1, krylov, 1, next_k, 1, hiter, 1);
+            for (int64_t i = 0; i <= restart_iter; ++i) {
+                oracle_dense_add_scaled_f64(n, 1, &hiter[i], 1, krylov + n * i, 1, next_k, 1, 1);
+            }
+            if (ortho == 2) {
+                oracle_gmres_multi_dot_f64(n, 1, restart_iter + 1, krylov, 1, next_k, 1, haux, 1);
+                for (int64_t i = 0; i <= restart_iter; ++i) {
+                    oracle_dense_add_scaled_f64(n, 1, &haux[i], 1, krylov + n * i, 1, next_k, 1, 1);
+                }
+                /* hessenberg_iter->add_scaled(one, hessenberg_aux_iter): rows 0..restart_iter+1;
+                 * row restart_iter+1 of both still holds stale data that is overwritten by the
+                 * norm below, exactly as in the reference */
+                for (int64_t i = 0; i <= restart_iter + 1; ++i) hiter[i] += 1.0 * haux[i];
+            }
+        }
+        oracle_dense_compute_norm2_f64(n, 1, next_k, 1, &hiter[restart_iter + 1], 0);
+        oracle_dense_inv_scale_f64(n, 1, &hiter[restart_iter + 1], 1, next_k, 1);
+        oracle_gmres_hessenberg_qr_f64(1, gsin, gcos, &residual_norm, rnc, hiter, restart_iter,
+                                       &final_iter, &stop);
+        restart_iter++;
+    }
+    oracle_gmres_solve_krylov_f64(1, rnc, hess, hld, y, &final_iter, &stop);
+    oracle_gmres_multi_axpy_f64(n, 1, krylov, 1, y, 1, before, 1, &final_iter, &stop);
+    apply_precond(m, n, before, after);
+    { const double one = 1.0; oracle_dense_add_scaled_f64(n, 1, &one, 1, after, 1, x, 1, 0); }
+    if (resnorm_out) *resnorm_out = residual_norm;
+    free(residual); free(krylov); free(hess); free(haux); free(gsin); free(gcos); free(rnc); free(y);
+    return total_iter;
+}

@@ -416,3 +416,105 @@ def cg_solve(row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,
     if return_history:
         return x, int(iters), resnorm.value, hist[:iters + 1]
     return x, int(iters), resnorm.value
+
+
+def gmres_solve(row_ptrs, cols, vals, b, x0=None, krylov_dim=100, ortho="mgs",
+                max_iters=1000, reduction=1e-10, precond=None, max_block_size=8):
+    """Gmres(Combined(Iteration, ResidualNorm(rhs_norm))), non-flexible, one
+    right-hand side, f64 / int32 (core/solver/gmres.cpp:321-621)."""
+    n = len(row_ptrs) - 1
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64, copy=True)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    m = _Precond()
+    keep = []
+    if precond == "scalar":
+        inv = jacobi_invert_diagonal(csr_extract_diagonal(n, n, row_ptrs, cols, vals))
+        keep.append(inv)
+        m.precond, m.inv_diag = 1, inv.ctypes.data
+    elif precond == "block":
+        nb, ptrs = jacobi_find_blocks(row_ptrs, cols, max_block_size)
+        scheme = jacobi_storage_scheme(max_block_size)
+        blocks = jacobi_generate(row_ptrs, cols, vals, nb, scheme, ptrs)
+        keep += [ptrs, blocks]
+        m.precond, m.num_blocks = 2, nb
+        m.block_offset, m.group_offset, m.group_power = scheme
+        m.block_ptrs, m.blocks = ptrs.ctypes.data, blocks.ctypes.data
+    resnorm = C.c_double(0)
+    f = lib().oracle_gmres_solve_f64_i32
+    f.restype = C.c_int64
+    iters = f(_i64(n), _p(row_ptrs), _p(cols), _p(vals), C.byref(m), _p(b), _p(x),
+              _i64(krylov_dim), C.c_int({"mgs": 0, "cgs": 1, "cgs2": 2}[ortho]),
+              _i64(max_iters), C.c_double(reduction), C.byref(resnorm))
+    return x, int(iters), resnorm.value
+
+
+# ------------------------------------------------------------ GMRES kernels
+def gmres_initialize(b, krylov_dim):
+    b2 = np.ascontiguousarray(_as2d(b))
+    rows, cols = b2.shape
+    res = np.full_like(b2, np.nan)
+    gsin = np.full((krylov_dim, cols), np.nan, dtype=b2.dtype)
+    gcos = np.full((krylov_dim, cols), np.nan, dtype=b2.dtype)
+    stop = np.full(cols, 0xFF, dtype=np.uint8)
+    getattr(lib(), "oracle_gmres_initialize_" + _VT[b2.dtype])(
+        _i64(rows), _i64(cols), _p(b2), _i64(cols), _p(res), _i64(cols), _p(gsin),
+        _p(gcos), _i64(krylov_dim), _p(stop))
+    return res, gsin, gcos, stop
+
+
+def gmres_restart(residual, residual_norm, n_basis_rows):
+    r2 = np.ascontiguousarray(_as2d(residual))
+    rows, cols = r2.shape
+    rn = np.ascontiguousarray(residual_norm, dtype=r2.dtype)
+    rnc0 = np.zeros(cols, dtype=r2.dtype)
+    krylov = np.full((n_basis_rows, cols), np.nan, dtype=r2.dtype)
+    fin = np.full(cols, 99, dtype=np.uint64)
+    getattr(lib(), "oracle_gmres_restart_" + _VT[r2.dtype])(
+        _i64(rows), _i64(cols), _p(r2), _i64(cols), _p(rn), _p(rnc0), _p(krylov),
+        _i64(cols), _p(fin))
+    return rnc0, krylov, fin
+
+
+def gmres_multi_axpy(krylov, y, rows, final_iter_nums, stop):
+    k2 = np.ascontiguousarray(_as2d(krylov))
+    y2 = np.ascontiguousarray(_as2d(y))
+    cols = k2.shape[1]
+    out = np.full((rows, cols), np.nan, dtype=k2.dtype)
+    st = np.array(stop, dtype=np.uint8, copy=True)
+    getattr(lib(), "oracle_gmres_multi_axpy_" + _VT[k2.dtype])(
+        _i64(rows), _i64(cols), _p(k2), _i64(cols), _p(y2), _i64(cols), _p(out),
+        _i64(cols), _p(np.ascontiguousarray(final_iter_nums, dtype=np.uint64)), _p(st))
+    return out, st
+
+
+def gmres_multi_dot(krylov, next_krylov, num_dots):
+    k2 = np.ascontiguousarray(_as2d(krylov))
+    n2 = np.ascontiguousarray(_as2d(next_krylov))
+    rows, cols = n2.shape
+    h = np.zeros((num_dots, cols), dtype=k2.dtype)
+    getattr(lib(), "oracle_gmres_multi_dot_" + _VT[k2.dtype])(
+        _i64(rows), _i64(cols), _i64(num_dots), _p(k2), _i64(cols), _p(n2), _i64(cols),
+        _p(h), _i64(cols))
+    return h
+
+
+def gmres_hessenberg_qr(gsin, gcos, residual_norm, rnc, h, it, final_iter_nums, stop):
+    arrs = [np.array(a, order="C", copy=True) for a in (gsin, gcos, residual_norm, rnc, h)]
+    fin = np.array(final_iter_nums, dtype=np.uint64, copy=True)
+    cols = arrs[0].shape[1]
+    getattr(lib(), "oracle_gmres_hessenberg_qr_" + _VT[arrs[0].dtype])(
+        _i64(cols), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), _p(arrs[4]),
+        _i64(it), _p(fin), _p(np.ascontiguousarray(stop, dtype=np.uint8)))
+    return (*arrs, fin)
+
+
+def gmres_solve_krylov(rnc, hessenberg, final_iter_nums, stop):
+    r2 = np.ascontiguousarray(rnc)
+    h2 = np.ascontiguousarray(hessenberg)
+    cols = r2.shape[1]
+    y = np.full((h2.shape[0], cols), np.nan, dtype=r2.dtype)
+    getattr(lib(), "oracle_gmres_solve_krylov_" + _VT[r2.dtype])(
+        _i64(cols), _p(r2), _p(h2), _i64(h2.shape[1]), _p(y),
+        _p(np.ascontiguousarray(final_iter_nums, dtype=np.uint64)),
+        _p(np.ascontiguousarray(stop, dtype=np.uint8)))
+    return y

@@ -23,7 +23,7 @@ def lib():
         _LIB.ref_version.restype = C.c_char_p
         _LIB.ref_csr_create.restype = C.c_void_p
         for n in ("ref_to_ell", "ref_to_sellp", "ref_jacobi_generate",
-                  "ref_cg_solve", "ref_stencil_subdomain"):
+                  "ref_cg_solve", "ref_gmres_solve", "ref_stencil_subdomain"):
             getattr(_LIB, n).restype = C.c_int64
     return _LIB
 
@@ -133,6 +133,21 @@ class CsrHandle:
                                 _p(x), C.c_int64(max_iters), C.c_double(reduction),
                                 C.c_int(base), C.byref(rn))
         return x, int(it), rn.value
+
+
+def _gmres(self, b, x0=None, krylov_dim=100, ortho="mgs", max_iters=1000,
+           reduction=1e-10, precond_block_size=0):
+    x = np.zeros(self.n_rows) if x0 is None else np.array(x0, dtype=np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    rn = C.c_double(0)
+    om = {"mgs": 0, "cgs": 1, "cgs2": 2}[ortho]
+    it = lib().ref_gmres_solve(self.h, C.c_uint32(precond_block_size), _p(b), _p(x),
+                               C.c_int64(krylov_dim), C.c_int(om), C.c_int64(max_iters),
+                               C.c_double(reduction), C.byref(rn))
+    return x, int(it), rn.value
+
+
+CsrHandle.gmres_solve = _gmres
 
 
 def dense_dot(x, y, exec_kind="reference"):

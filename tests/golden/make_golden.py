@@ -87,6 +87,13 @@ def main():
     x, it, rn = h.cg_solve(rhs, x0=np.full(1000, 0.5), max_iters=9, reduction=1e-30,
                            baseline="initial_resnorm", precond_block_size=8)
     arrays["cg_lim_x"], arrays["cg_lim_iters"] = x, np.array([it])
+    for ortho in ("mgs", "cgs", "cgs2"):
+        for kd, bs in ((100, 0), (7, 8)):
+            xg, itg, rng_ = h.gmres_solve(rhs, krylov_dim=kd, ortho=ortho, max_iters=300,
+                                          reduction=1e-9, precond_block_size=bs)
+            arrays[f"gmres_{ortho}_{kd}_{bs}_x"] = xg
+            arrays[f"gmres_{ortho}_{kd}_{bs}_iters"] = np.array([itg])
+            arrays[f"gmres_{ortho}_{kd}_{bs}_resnorm"] = np.array([rng_])
     save("krylov_27pt_10.npz", **arrays)
 
     # --- block-Jacobi on a matrix with natural blocks of mixed size + pivoting

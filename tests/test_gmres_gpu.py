@@ -1,0 +1,170 @@
+"""GPU parity: GMRES kernels and the restarted-GMRES solve through the C ABI vs
+the oracle.  Mirrors test/solver/gmres_kernels.cpp (random 123 x 5 systems,
+stopped columns, krylov_dim 5..10) and reference/test/solver/gmres_kernels.cpp
+(known-answer solves).  Bars: restart / multi_axpy / initialize / hessenberg_qr
+/ solve_krylov bit-exact; multi_dot <= 1e-13 relative (reduction tree); full
+solves <= 1e-8 relative, iteration count +-1."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from util import rel_frobenius
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gmres_kernels_bit_exact(gexec, oracle):
+    import ginkgo_amd as g
+    from ginkgo_amd._lib import call, lib
+    ex = gexec
+    rng = np.random.default_rng(17)
+    n, nrhs, kd = 1234, 5, 7
+    D = lambda a, st=None: g.Dense.from_numpy(ex, a, st)
+    dv = lambda a: ex.to_device(a)
+    stop = np.zeros(nrhs, np.uint8)
+    stop[1] = 0x81        # converged, not finalized
+    stop[3] = 0xC2        # converged + finalized
+    # initialize
+    b = rng.uniform(-1, 1, (n, nrhs))
+    dres, dsin, dcos = D(b * 0 + 7), D(np.full((kd, nrhs), 3.0)), D(np.full((kd, nrhs), 3.0))
+    dstop = dv(np.full(nrhs, 0xFF, np.uint8))
+    call("gkoc_common_gmres_initialize_f64", ex.stream, n, nrhs, D(b, 6).values, 6, dres.values, dres.ld,
+         dsin.values, dsin.ld, dcos.values, dcos.ld, kd, dstop)
+    o = oracle.gmres_initialize(b, kd)
+    assert np.array_equal(dres.to_numpy(), o[0]) and np.array_equal(dsin.to_numpy(), o[1])
+    assert np.array_equal(dcos.to_numpy(), o[2]) and np.array_equal(dstop.cpu().numpy(), o[3])
+    # restart
+    rnorm = rng.uniform(0.5, 2, nrhs)
+    dk = D(np.full(((kd + 1) * n, nrhs), np.nan))
+    drnc = D(np.full((kd + 1, nrhs), np.nan))
+    dfin = dv(np.full(nrhs, 99, np.int64))
+    call("gkoc_gmres_restart_f64", ex.stream, n, nrhs, D(b).values, nrhs, dv(rnorm), drnc.values,
+         dk.values, dk.ld, dfin)
+    rnc0, kref, fin = oracle.gmres_restart(b, rnorm, (kd + 1) * n)
+    assert np.array_equal(dk.to_numpy()[:n], kref[:n]) and np.array_equal(drnc.to_numpy()[0], rnc0)
+    assert np.array_equal(dfin.cpu().numpy().view(np.uint64), fin)
+    # multi_axpy (+ finalize of stopped columns)
+    krylov = rng.uniform(-1, 1, ((kd + 1) * n, nrhs))
+    y = rng.uniform(-1, 1, (kd, nrhs))
+    fin = np.array([3, 7, 0, 5, 6], np.uint64)
+    dout = D(np.full((n, nrhs), 5.0), 8)
+    dstop = dv(stop)
+    call("gkoc_gmres_multi_axpy_f64", ex.stream, n, nrhs, D(krylov).values, nrhs, D(y).values, nrhs,
+         dout.values, dout.ld, dv(fin.view(np.int64)), dstop)
+    oout, ostop = oracle.gmres_multi_axpy(krylov, y, n, fin, stop)
+    got = dout.to_numpy()
+    live = [k for k in range(nrhs) if not (stop[k] & 0x40)]
+    assert np.array_equal(got[:, live], oout[:, live]) and np.all(got[:, 3] == 5.0)
+    assert np.array_equal(dstop.cpu().numpy(), ostop)
+    # multi_dot
+    nxt = rng.uniform(-1, 1, (n, nrhs))
+    need = lib().gkoc_gmres_multi_dot_workspace_bytes
+    need.restype = C.c_size_t
+    wb = need(C.c_int64(n), C.c_int64(nrhs), C.c_int64(kd), C.c_size_t(8))
+    work = ex.alloc((wb,), torch.uint8)
+    dh = D(np.full((kd + 1, nrhs), np.nan))
+    call("gkoc_gmres_multi_dot_f64", ex.stream, n, nrhs, kd, D(krylov).values, nrhs, D(nxt).values, nrhs,
+         dh.values, dh.ld, work, C.c_size_t(wb))
+    href = oracle.gmres_multi_dot(krylov, nxt, kd)
+    got = dh.to_numpy()[:kd]
+    scale = np.array([[np.sum(np.abs(krylov[i * n:(i + 1) * n, k] * nxt[:, k])) for k in range(nrhs)]
+                      for i in range(kd)])
+    assert np.all(np.abs(got - href) <= 1e-13 * scale)
+    # hessenberg_qr at several iterations, then solve_krylov
+    gsin, gcos = np.zeros((kd, nrhs)), np.zeros((kd, nrhs))
+    rn = rng.uniform(0.5, 2, (1, nrhs))
+    rnc = np.zeros((kd + 1, nrhs))
+    rnc[0] = rn[0]
+    fin = np.zeros(nrhs, np.uint64)
+    hess = np.zeros((kd, (kd + 1) * nrhs))
+    d = dict(gsin=D(gsin), gcos=D(gcos), rn=D(rn), rnc=D(rnc), hess=D(hess), fin=dv(fin.view(np.int64)))
+    qstop = np.zeros(nrhs, np.uint8)
+    qstop[2] = 0x81
+    for it in range(kd):
+        hcol = rng.uniform(-1, 1, (it + 2, nrhs))
+        if it == 2:
+            hcol[2, 0] = 0.0          # zero pivot branch of calculate_sin_and_cos
+        hess[it, :(it + 2) * nrhs] = hcol.reshape(-1)
+        d["hess"] = D(hess)
+        hv = d["hess"].values[it, :(it + 2) * nrhs].view(it + 2, nrhs)
+        call("gkoc_common_gmres_hessenberg_qr_f64", ex.stream, nrhs, d["gsin"].values, nrhs,
+             d["gcos"].values, nrhs, d["rn"].values, d["rnc"].values, nrhs, hv, nrhs, it, d["fin"],
+             dv(qstop))
+        gsin, gcos, rn, rnc, hnew, fin = oracle.gmres_hessenberg_qr(gsin, gcos, rn, rnc, hcol, it, fin, qstop)
+        hess[it, :(it + 2) * nrhs] = hnew.reshape(-1)
+        assert np.array_equal(d["gsin"].to_numpy(), gsin) and np.array_equal(d["gcos"].to_numpy(), gcos)
+        assert np.array_equal(d["rn"].to_numpy(), rn) and np.array_equal(d["rnc"].to_numpy(), rnc)
+        assert np.array_equal(d["hess"].to_numpy()[it], hess[it])
+        assert np.array_equal(d["fin"].cpu().numpy().view(np.uint64), fin)
+    dy = D(np.full((kd, nrhs), np.nan))
+    sstop = np.zeros(nrhs, np.uint8)
+    sstop[4] = 0xC1
+    call("gkoc_common_gmres_solve_krylov_f64", ex.stream, nrhs, d["rnc"].values, nrhs, d["hess"].values,
+         d["hess"].ld, dy.values, nrhs, d["fin"], dv(sstop))
+    yref = oracle.gmres_solve_krylov(rnc, hess, fin, sstop)
+    got = dy.to_numpy()
+    for k in range(nrhs):
+        m = int(fin[k])
+        if not (sstop[k] & 0x40):
+            assert np.array_equal(got[:m, k], yref[:m, k])
+
+
+def _gmres(g, ex, a, b, x0, kd, ortho, iters, red, bs=None, flexible=False):
+    f = (g.Gmres.build().with_krylov_dim(kd).with_ortho_method(ortho).with_flexible(flexible)
+         .with_criteria(g.stop.Iteration.build().with_max_iters(iters),
+                        g.stop.ResidualNorm.build().with_reduction_factor(red)))
+    if bs:
+        f = f.with_preconditioner(g.Jacobi.build().with_max_block_size(bs))
+    s = f.on(ex).generate(a)
+    x = g.Dense.from_numpy(ex, x0)
+    s.apply(g.Dense.from_numpy(ex, b), x)
+    return s, x.to_numpy()
+
+
+def test_gmres_known_answers(gexec):
+    import ginkgo_amd as g
+    import scipy.sparse as sp
+    # reference/test/solver/gmres_kernels.cpp: 3x3 system [[1,2,3],[3,2,-1],[0,-1,2]] x = (13,7,1)
+    m = sp.csr_matrix(np.array([[1.0, 2.0, 3.0], [3.0, 2.0, -1.0], [0.0, -1.0, 2.0]]))
+    a = g.Csr.from_scipy(gexec, m)
+    for ortho in ("mgs", "cgs", "cgs2"):
+        s, x = _gmres(g, gexec, a, np.array([13.0, 7.0, 1.0]), np.zeros(3), 100, ortho, 100, 1e-15)
+        assert np.allclose(x[:, 0], [1.0, 3.0, 2.0], rtol=1e-13)
+
+
+@pytest.mark.parametrize("ortho", ["mgs", "cgs", "cgs2"])
+@pytest.mark.parametrize("kd,bs", [(100, None), (7, 8), (3, 1)])
+def test_gmres_vs_oracle(gexec, oracle, ortho, kd, bs):
+    import ginkgo_amd as g
+    grid = 12
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    n = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    rhs = np.random.default_rng(5).uniform(-1, 1, n)
+    s, x = _gmres(g, gexec, a, rhs, np.zeros(n), kd, ortho, 400, 1e-9, bs)
+    pre = {None: None, 1: "scalar", 8: "block"}[bs]
+    xo, iters, rn = oracle.gmres_solve(rp, ci, v, rhs, krylov_dim=kd, ortho=ortho, max_iters=400,
+                                       reduction=1e-9, precond=pre, max_block_size=8)
+    assert s.has_converged and abs(s.num_iterations - iters) <= 1
+    assert rel_frobenius(x[:, 0], xo) < 1e-8
+    import scipy.sparse as sp
+    A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    assert np.linalg.norm(rhs - A @ x[:, 0]) <= 2e-9 * np.linalg.norm(rhs)
+
+
+def test_gmres_multiple_rhs_and_flexible(gexec, oracle):
+    import ginkgo_amd as g
+    rp, ci, v = oracle.stencil_csr(2, 24, True)
+    n = 576
+    a = g.stencil_csr(gexec, 2, 24, True)
+    rng = np.random.default_rng(2)
+    B = np.stack([np.ones(n), rng.uniform(-1, 1, n), 1e-3 * rng.uniform(-1, 1, n)], axis=1)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    for flexible in (False, True):
+        s, X = _gmres(g, gexec, a, B, np.zeros((n, 3)), 20, "mgs", 600, 1e-9, 4, flexible)
+        assert s.has_converged
+        for j in range(3):
+            assert np.linalg.norm(B[:, j] - A @ X[:, j]) <= 5e-9 * np.linalg.norm(B[:, j])

@@ -214,6 +214,24 @@ def test_golden_krylov(oracle):
     assert it == int(g["cg_lim_iters"][0]) == 9 and np.array_equal(x, g["cg_lim_x"])
 
 
+def test_golden_gmres(oracle):
+    """core/solver/gmres.cpp:321-621 driver + gmres / common_gmres kernels: the
+    oracle reproduces the reference's iterate, iteration count and Givens
+    residual-norm estimate bit-for-bit for MGS, CGS and CGS2, with and without
+    restarts / block-Jacobi."""
+    g = gold("krylov_27pt_10.npz")
+    rp, ci, v, rhs = g["row_ptrs"], g["cols"], g["vals"], g["rhs"]
+    for ortho in ("mgs", "cgs", "cgs2"):
+        for kd, bs in ((100, 0), (7, 8)):
+            x, it, rn = oracle.gmres_solve(rp, ci, v, rhs, krylov_dim=kd, ortho=ortho, max_iters=300,
+                                           reduction=1e-9, precond="block" if bs else None,
+                                           max_block_size=8)
+            key = f"gmres_{ortho}_{kd}_{bs}"
+            assert it == int(g[key + "_iters"][0]), key
+            assert rn == float(g[key + "_resnorm"][0]), key
+            assert np.array_equal(x, g[key + "_x"]), key
+
+
 def _block_mask(scheme, ptrs, size):
     bo, go, gp = scheme
     stride = bo << gp
@@ -290,6 +308,21 @@ def test_live_reference_cg_and_jacobi(oracle, case):
         bo = oracle.jacobi_generate(rp, ci, v, nb, scheme, po)
         mask = _block_mask(scheme, ptrs, len(blocks))
         assert np.array_equal(bo[mask], blocks[mask])
+
+
+@pytest.mark.parametrize("ortho", ["mgs", "cgs", "cgs2"])
+def test_live_reference_gmres(oracle, ortho):
+    ref = _ref()
+    rp, ci, v = oracle.stencil_csr(2, 20, False)
+    h = ref.CsrHandle("reference", rp, ci, v)
+    rhs = np.random.default_rng(11).uniform(-1, 1, 400)
+    for kd, bs in ((100, 0), (6, 4), (3, 1)):
+        xr, itr, rnr = h.gmres_solve(rhs, krylov_dim=kd, ortho=ortho, max_iters=150, reduction=1e-8,
+                                     precond_block_size=bs)
+        pre = None if bs == 0 else ("scalar" if bs == 1 else "block")
+        xo, ito, rno = oracle.gmres_solve(rp, ci, v, rhs, krylov_dim=kd, ortho=ortho, max_iters=150,
+                                          reduction=1e-8, precond=pre, max_block_size=max(bs, 1))
+        assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
 
 
 def test_live_reference_stencil_subdomains(oracle):
