@@ -444,3 +444,15 @@ extern "C" size_t gkoc_reduction_workspace_bytes(int64_t, int64_t nrhs,
 
 GKOC_DEF_DENSE(double, f64)
 GKOC_DEF_DENSE(float, f32)
+
+extern "C" int gkoc_fill_array_f64(gkoc_stream_t s, double* data, int64_t n,
+                                   double value)
+{
+    return gkoc_dense_fill_f64(s, n, 1, data, 1, value);
+}
+
+extern "C" int gkoc_fill_array_f32(gkoc_stream_t s, float* data, int64_t n,
+                                   float value)
+{
+    return gkoc_dense_fill_f32(s, n, 1, data, 1, value);
+}

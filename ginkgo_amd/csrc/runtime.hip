@@ -98,6 +98,56 @@ int gkoc_set_device(int device_id)
     return GKOC_OK;
 }
 
+int gkoc_get_device(int* device_id)
+{
+    GKOC_REQUIRE(device_id, GKOC_E_INVALID, "device_id == NULL");
+    GKOC_HIP(hipGetDevice(device_id));
+    return GKOC_OK;
+}
+
+int gkoc_event_create(gkoc_event_t* e)
+{
+    GKOC_REQUIRE(e, GKOC_E_INVALID, "e == NULL");
+    hipEvent_t ev;
+    GKOC_HIP(hipEventCreate(&ev));
+    *e = ev;
+    return GKOC_OK;
+}
+
+int gkoc_event_destroy(gkoc_event_t e)
+{
+    if (e) GKOC_HIP(hipEventDestroy(static_cast<hipEvent_t>(e)));
+    return GKOC_OK;
+}
+
+int gkoc_event_record(gkoc_event_t e, gkoc_stream_t s)
+{
+    GKOC_HIP(hipEventRecord(static_cast<hipEvent_t>(e), as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_event_synchronize(gkoc_event_t e)
+{
+    GKOC_HIP(hipEventSynchronize(static_cast<hipEvent_t>(e)));
+    return GKOC_OK;
+}
+
+int gkoc_event_elapsed_ns(gkoc_event_t start, gkoc_event_t stop, int64_t* ns)
+{
+    GKOC_REQUIRE(ns, GKOC_E_INVALID, "ns == NULL");
+    float ms = 0;
+    GKOC_HIP(hipEventElapsedTime(&ms, static_cast<hipEvent_t>(start),
+                                 static_cast<hipEvent_t>(stop)));
+    *ns = static_cast<int64_t>(double(ms) * 1e6);
+    return GKOC_OK;
+}
+
+int gkoc_stream_wait_event(gkoc_stream_t s, gkoc_event_t e)
+{
+    GKOC_HIP(hipStreamWaitEvent(as_stream(s), static_cast<hipEvent_t>(e), 0));
+    return GKOC_OK;
+}
+
 int gkoc_malloc(void** ptr, size_t bytes)
 {
     GKOC_REQUIRE(ptr, GKOC_E_INVALID, "ptr == NULL");

@@ -1,0 +1,818 @@
+// gko::kernels::hip::* hot-path kernels forwarded to the C ABI.
+//
+// Each function is an explicit specialisation of the kernel template that
+// Ginkgo core declares (core/**/*_kernels.hpp) for {double, float} x
+// {int32, int64}; every other instantiation (complex, half, mixed precision)
+// stays on Ginkgo's own weakened GKO_NOT_COMPILED stub.  See INTEGRATION.md.
+#include <ginkgo/core/matrix/csr.hpp>
+#include <ginkgo/core/matrix/diagonal.hpp>
+#include <ginkgo/core/matrix/ell.hpp>
+#include <ginkgo/core/matrix/sellp.hpp>
+#include <ginkgo/core/preconditioner/jacobi.hpp>
+
+#include "core/components/fill_array_kernels.hpp"
+#include "core/components/format_conversion_kernels.hpp"
+#include "core/components/prefix_sum_kernels.hpp"
+#include "core/matrix/csr_kernels.hpp"
+#include "core/matrix/dense_kernels.hpp"
+#include "core/matrix/ell_kernels.hpp"
+#include "core/matrix/sellp_kernels.hpp"
+#include "core/preconditioner/jacobi_kernels.hpp"
+#include "core/solver/cg_kernels.hpp"
+#include "core/solver/common_gmres_kernels.hpp"
+#include "core/solver/gmres_kernels.hpp"
+#include "core/stop/criterion_kernels.hpp"
+#include "core/stop/residual_norm_kernels.hpp"
+#include "shim_common.hpp"
+
+namespace gko {
+namespace kernels {
+namespace hip {
+
+using cdna4::cols;
+using cdna4::ld;
+using cdna4::raw;
+using cdna4::rows;
+using cdna4::stream_of;
+using exec_t = std::shared_ptr<const HipExecutor>;
+
+#define FOR_VT(M) M(double, f64) M(float, f32)
+#define FOR_VT_IT(M)                                                     \
+    M(double, f64, int32, i32) M(double, f64, int64, i64) M(float, f32, int32, i32) \
+        M(float, f32, int64, i64)
+#define FOR_IT(M) M(int32, i32) M(int64, i64)
+
+
+// ===================================================================== csr
+namespace csr {
+
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void spmv<T, T, T, I>(exec_t exec, const matrix::Csr<T, I>* a,              \
+                          const matrix::Dense<T>* b, matrix::Dense<T>* c)       \
+    {                                                                           \
+        GKOC_CALL(gkoc_csr_spmv_##TN##_##IN(                                    \
+            stream_of(exec), a->get_size()[0], a->get_size()[1],                \
+            a->get_const_row_ptrs(), a->get_const_col_idxs(),                   \
+            a->get_const_values(), b->get_const_values(), ld(b),                \
+            c->get_values(), ld(c), cols(c)));                                  \
+    }                                                                           \
+    template <>                                                                 \
+    void advanced_spmv<T, T, T, I>(                                             \
+        exec_t exec, const matrix::Dense<T>* alpha, const matrix::Csr<T, I>* a, \
+        const matrix::Dense<T>* b, const matrix::Dense<T>* beta,                \
+        matrix::Dense<T>* c)                                                    \
+    {                                                                           \
+        GKOC_CALL(gkoc_csr_advanced_spmv_##TN##_##IN(                           \
+            stream_of(exec), a->get_size()[0], a->get_size()[1],                \
+            alpha->get_const_values(), a->get_const_row_ptrs(),                 \
+            a->get_const_col_idxs(), a->get_const_values(),                     \
+            b->get_const_values(), ld(b), beta->get_const_values(),             \
+            c->get_values(), ld(c), cols(c)));                                  \
+    }                                                                           \
+    template <>                                                                 \
+    void extract_diagonal<T, I>(exec_t exec, const matrix::Csr<T, I>* orig,     \
+                                matrix::Diagonal<T>* diag)                      \
+    {                                                                           \
+        GKOC_CALL(gkoc_csr_extract_diagonal_##TN##_##IN(                        \
+            stream_of(exec), orig->get_size()[0], orig->get_size()[1],          \
+            orig->get_const_row_ptrs(), orig->get_const_col_idxs(),             \
+            orig->get_const_values(), diag->get_values()));                     \
+    }                                                                           \
+    template <>                                                                 \
+    void is_sorted_by_column_index<T, I>(exec_t exec,                           \
+                                         const matrix::Csr<T, I>* to_check,     \
+                                         bool* is_sorted)                       \
+    {                                                                           \
+        int flag = 1;                                                           \
+        GKOC_CALL(gkoc_csr_is_sorted_by_column_index_##TN##_##IN(               \
+            stream_of(exec), to_check->get_size()[0],                           \
+            to_check->get_const_row_ptrs(), to_check->get_const_col_idxs(),     \
+            &flag));                                                            \
+        *is_sorted = flag != 0;                                                 \
+    }                                                                           \
+    template <>                                                                 \
+    void sort_by_column_index<T, I>(exec_t exec, matrix::Csr<T, I>* to_sort)    \
+    {                                                                           \
+        GKOC_CALL(gkoc_csr_sort_by_column_index_##TN##_##IN(                    \
+            stream_of(exec), to_sort->get_size()[0],                            \
+            to_sort->get_const_row_ptrs(), to_sort->get_col_idxs(),             \
+            to_sort->get_values()));                                            \
+    }                                                                           \
+    template <>                                                                 \
+    void convert_to_ell<T, I>(exec_t exec, const matrix::Csr<T, I>* source,     \
+                              matrix::Ell<T, I>* result)                        \
+    {                                                                           \
+        GKOC_CALL(gkoc_csr_convert_to_ell_##TN##_##IN(                          \
+            stream_of(exec), source->get_size()[0],                             \
+            source->get_const_row_ptrs(), source->get_const_col_idxs(),         \
+            source->get_const_values(),                                         \
+            result->get_num_stored_elements_per_row(), result->get_stride(),    \
+            result->get_col_idxs(), result->get_values()));                     \
+    }                                                                           \
+    template <>                                                                 \
+    void convert_to_sellp<T, I>(exec_t exec, const matrix::Csr<T, I>* source,   \
+                                matrix::Sellp<T, I>* result)                    \
+    {                                                                           \
+        GKOC_CALL(gkoc_csr_convert_to_sellp_##TN##_##IN(                        \
+            stream_of(exec), source->get_size()[0], result->get_slice_size(),   \
+            source->get_const_row_ptrs(), source->get_const_col_idxs(),         \
+            source->get_const_values(),                                         \
+            reinterpret_cast<const uint64_t*>(result->get_const_slice_sets()),  \
+            result->get_col_idxs(), result->get_values()));                     \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace csr
+
+
+// ===================================================================== ell
+namespace ell {
+
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void spmv<T, T, T, I>(exec_t exec, const matrix::Ell<T, I>* a,              \
+                          const matrix::Dense<T>* b, matrix::Dense<T>* c)       \
+    {                                                                           \
+        GKOC_CALL(gkoc_ell_spmv_##TN##_##IN(                                    \
+            stream_of(exec), a->get_size()[0], a->get_size()[1],                \
+            a->get_num_stored_elements_per_row(), a->get_stride(),              \
+            a->get_const_col_idxs(), a->get_const_values(),                     \
+            b->get_const_values(), ld(b), c->get_values(), ld(c), cols(c)));    \
+    }                                                                           \
+    template <>                                                                 \
+    void advanced_spmv<T, T, T, I>(                                             \
+        exec_t exec, const matrix::Dense<T>* alpha, const matrix::Ell<T, I>* a, \
+        const matrix::Dense<T>* b, const matrix::Dense<T>* beta,                \
+        matrix::Dense<T>* c)                                                    \
+    {                                                                           \
+        GKOC_CALL(gkoc_ell_advanced_spmv_##TN##_##IN(                           \
+            stream_of(exec), a->get_size()[0], a->get_size()[1],                \
+            a->get_num_stored_elements_per_row(), a->get_stride(),              \
+            alpha->get_const_values(), a->get_const_col_idxs(),                 \
+            a->get_const_values(), b->get_const_values(), ld(b),                \
+            beta->get_const_values(), c->get_values(), ld(c), cols(c)));        \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+#define DEF(I, IN)                                                              \
+    template <>                                                                 \
+    void compute_max_row_nnz<I>(exec_t exec, const array<I>& row_ptrs,          \
+                                size_type& max_nnz)                             \
+    {                                                                           \
+        int64_t m = 0;                                                          \
+        GKOC_CALL(gkoc_compute_max_row_nnz_##IN(                                \
+            stream_of(exec), static_cast<int64_t>(row_ptrs.get_size()) - 1,     \
+            row_ptrs.get_const_data(), &m));                                    \
+        max_nnz = static_cast<size_type>(m);                                    \
+    }
+FOR_IT(DEF)
+#undef DEF
+
+}  // namespace ell
+
+
+// =================================================================== sellp
+namespace sellp {
+
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void spmv<T, I>(exec_t exec, const matrix::Sellp<T, I>* a,                  \
+                    const matrix::Dense<T>* b, matrix::Dense<T>* c)             \
+    {                                                                           \
+        GKOC_CALL(gkoc_sellp_spmv_##TN##_##IN(                                  \
+            stream_of(exec), a->get_size()[0], a->get_size()[1],                \
+            a->get_slice_size(),                                                \
+            reinterpret_cast<const uint64_t*>(a->get_const_slice_sets()),       \
+            reinterpret_cast<const uint64_t*>(a->get_const_slice_lengths()),    \
+            a->get_const_col_idxs(), a->get_const_values(),                     \
+            b->get_const_values(), ld(b), c->get_values(), ld(c), cols(c)));    \
+    }                                                                           \
+    template <>                                                                 \
+    void advanced_spmv<T, I>(exec_t exec, const matrix::Dense<T>* alpha,        \
+                             const matrix::Sellp<T, I>* a,                      \
+                             const matrix::Dense<T>* b,                         \
+                             const matrix::Dense<T>* beta, matrix::Dense<T>* c) \
+    {                                                                           \
+        GKOC_CALL(gkoc_sellp_advanced_spmv_##TN##_##IN(                         \
+            stream_of(exec), a->get_size()[0], a->get_size()[1],                \
+            a->get_slice_size(), alpha->get_const_values(),                     \
+            reinterpret_cast<const uint64_t*>(a->get_const_slice_sets()),       \
+            reinterpret_cast<const uint64_t*>(a->get_const_slice_lengths()),    \
+            a->get_const_col_idxs(), a->get_const_values(),                     \
+            b->get_const_values(), ld(b), beta->get_const_values(),             \
+            c->get_values(), ld(c), cols(c)));                                  \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+#define DEF(I, IN)                                                              \
+    template <>                                                                 \
+    void compute_slice_sets<I>(exec_t exec, const array<I>& row_ptrs,           \
+                               size_type slice_size, size_type stride_factor,   \
+                               size_type* slice_sets, size_type* slice_lengths) \
+    {                                                                           \
+        GKOC_CALL(gkoc_sellp_compute_slice_sets_##IN(                           \
+            stream_of(exec), static_cast<int64_t>(row_ptrs.get_size()) - 1,     \
+            slice_size, stride_factor, row_ptrs.get_const_data(),               \
+            reinterpret_cast<uint64_t*>(slice_sets),                            \
+            reinterpret_cast<uint64_t*>(slice_lengths)));                       \
+    }
+FOR_IT(DEF)
+#undef DEF
+
+}  // namespace sellp
+
+
+// =================================================================== dense
+namespace dense {
+
+template <typename T>
+inline void* scratch(array<char>& tmp, int64_t n, int64_t nrhs, size_t& bytes)
+{
+    bytes = gkoc_reduction_workspace_bytes(n, nrhs, sizeof(T));
+    if (tmp.get_size() < bytes) tmp.resize_and_reset(bytes);
+    return tmp.get_data();
+}
+
+#define DEF(T, TN)                                                              \
+    template <>                                                                 \
+    void fill<T>(exec_t exec, matrix::Dense<T>* mat, T value)                   \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_fill_##TN(stream_of(exec), rows(mat), cols(mat),   \
+                                       mat->get_values(), ld(mat), value));     \
+    }                                                                           \
+    template <>                                                                 \
+    void copy<T, T>(exec_t exec, const matrix::Dense<T>* input,                 \
+                    matrix::Dense<T>* output)                                   \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_copy_##TN(stream_of(exec), rows(input),            \
+                                       cols(input), input->get_const_values(),  \
+                                       ld(input), output->get_values(),         \
+                                       ld(output)));                            \
+    }                                                                           \
+    template <>                                                                 \
+    void scale<T, T>(exec_t exec, const matrix::Dense<T>* alpha,                \
+                     matrix::Dense<T>* x)                                       \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_scale_##TN(stream_of(exec), rows(x), cols(x),      \
+                                        alpha->get_const_values(), cols(alpha), \
+                                        x->get_values(), ld(x)));               \
+    }                                                                           \
+    template <>                                                                 \
+    void inv_scale<T, T>(exec_t exec, const matrix::Dense<T>* alpha,            \
+                         matrix::Dense<T>* x)                                   \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_inv_scale_##TN(                                    \
+            stream_of(exec), rows(x), cols(x), alpha->get_const_values(),       \
+            cols(alpha), x->get_values(), ld(x)));                              \
+    }                                                                           \
+    template <>                                                                 \
+    void add_scaled<T, T>(exec_t exec, const matrix::Dense<T>* alpha,           \
+                          const matrix::Dense<T>* x, matrix::Dense<T>* y)       \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_add_scaled_##TN(                                   \
+            stream_of(exec), rows(x), cols(x), alpha->get_const_values(),       \
+            cols(alpha), x->get_const_values(), ld(x), y->get_values(),         \
+            ld(y)));                                                            \
+    }                                                                           \
+    template <>                                                                 \
+    void sub_scaled<T, T>(exec_t exec, const matrix::Dense<T>* alpha,           \
+                          const matrix::Dense<T>* x, matrix::Dense<T>* y)       \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_sub_scaled_##TN(                                   \
+            stream_of(exec), rows(x), cols(x), alpha->get_const_values(),       \
+            cols(alpha), x->get_const_values(), ld(x), y->get_values(),         \
+            ld(y)));                                                            \
+    }                                                                           \
+    template <>                                                                 \
+    void compute_dot<T>(exec_t exec, const matrix::Dense<T>* x,                 \
+                        const matrix::Dense<T>* y, matrix::Dense<T>* result,    \
+                        array<char>& tmp)                                       \
+    {                                                                           \
+        size_t bytes = 0;                                                       \
+        void* w = scratch<T>(tmp, rows(x), cols(x), bytes);                     \
+        GKOC_CALL(gkoc_dense_compute_dot_##TN(                                  \
+            stream_of(exec), rows(x), cols(x), x->get_const_values(), ld(x),    \
+            y->get_const_values(), ld(y), result->get_values(), w, bytes));     \
+    }                                                                           \
+    template <>                                                                 \
+    void compute_dot_dispatch<T>(exec_t exec, const matrix::Dense<T>* x,        \
+                                 const matrix::Dense<T>* y,                     \
+                                 matrix::Dense<T>* result, array<char>& tmp)    \
+    {                                                                           \
+        compute_dot<T>(exec, x, y, result, tmp);                                \
+    }                                                                           \
+    template <>                                                                 \
+    void compute_conj_dot<T>(exec_t exec, const matrix::Dense<T>* x,            \
+                             const matrix::Dense<T>* y,                         \
+                             matrix::Dense<T>* result, array<char>& tmp)        \
+    {                                                                           \
+        compute_dot<T>(exec, x, y, result, tmp);                                \
+    }                                                                           \
+    template <>                                                                 \
+    void compute_conj_dot_dispatch<T>(exec_t exec, const matrix::Dense<T>* x,   \
+                                      const matrix::Dense<T>* y,                \
+                                      matrix::Dense<T>* result,                 \
+                                      array<char>& tmp)                         \
+    {                                                                           \
+        compute_dot<T>(exec, x, y, result, tmp);                                \
+    }                                                                           \
+    template <>                                                                 \
+    void compute_norm2<T>(exec_t exec, const matrix::Dense<T>* x,               \
+                          matrix::Dense<T>* result, array<char>& tmp)           \
+    {                                                                           \
+        size_t bytes = 0;                                                       \
+        void* w = scratch<T>(tmp, rows(x), cols(x), bytes);                     \
+        GKOC_CALL(gkoc_dense_compute_norm2_##TN(                                \
+            stream_of(exec), rows(x), cols(x), x->get_const_values(), ld(x),    \
+            result->get_values(), w, bytes));                                   \
+    }                                                                           \
+    template <>                                                                 \
+    void compute_norm2_dispatch<T>(exec_t exec, const matrix::Dense<T>* x,      \
+                                   matrix::Dense<T>* result, array<char>& tmp)  \
+    {                                                                           \
+        compute_norm2<T>(exec, x, result, tmp);                                 \
+    }                                                                           \
+    template <>                                                                 \
+    void compute_squared_norm2<T>(exec_t exec, const matrix::Dense<T>* x,       \
+                                  matrix::Dense<T>* result, array<char>& tmp)   \
+    {                                                                           \
+        size_t bytes = 0;                                                       \
+        void* w = scratch<T>(tmp, rows(x), cols(x), bytes);                     \
+        GKOC_CALL(gkoc_dense_compute_squared_norm2_##TN(                        \
+            stream_of(exec), rows(x), cols(x), x->get_const_values(), ld(x),    \
+            result->get_values(), w, bytes));                                   \
+    }                                                                           \
+    template <>                                                                 \
+    void compute_sqrt<T>(exec_t exec, matrix::Dense<T>* data)                   \
+    {                                                                           \
+        /* element-wise sqrt of a (1 x nrhs) row in Ginkgo's use */             \
+        for (int64_t r = 0; r < rows(data); ++r) {                              \
+            GKOC_CALL(gkoc_dense_compute_sqrt_##TN(                             \
+                stream_of(exec), cols(data), data->get_values() + r * ld(data))); \
+        }                                                                       \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void row_gather<T, T, I>(exec_t exec, const I* gather_indices,              \
+                             const matrix::Dense<T>* orig,                      \
+                             matrix::Dense<T>* row_collection)                  \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_row_gather_##TN##_##IN(                            \
+            stream_of(exec), rows(row_collection), cols(orig), gather_indices,  \
+            orig->get_const_values(), ld(orig), row_collection->get_values(),   \
+            ld(row_collection)));                                               \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace dense
+
+
+// ====================================================================== cg
+namespace cg {
+
+#define DEF(T, TN)                                                              \
+    template <>                                                                 \
+    void initialize<T>(exec_t exec, const matrix::Dense<T>* b,                  \
+                       matrix::Dense<T>* r, matrix::Dense<T>* z,                \
+                       matrix::Dense<T>* p, matrix::Dense<T>* q,                \
+                       matrix::Dense<T>* prev_rho, matrix::Dense<T>* rho,       \
+                       array<stopping_status>* stop_status)                     \
+    {                                                                           \
+        GKOC_CALL(gkoc_cg_initialize_##TN(                                      \
+            stream_of(exec), rows(b), cols(b), b->get_const_values(), ld(b),    \
+            r->get_values(), ld(r), z->get_values(), ld(z), p->get_values(),    \
+            ld(p), q->get_values(), ld(q), prev_rho->get_values(),              \
+            rho->get_values(), raw(stop_status)));                              \
+    }                                                                           \
+    template <>                                                                 \
+    void step_1<T>(exec_t exec, matrix::Dense<T>* p, const matrix::Dense<T>* z, \
+                   const matrix::Dense<T>* rho,                                 \
+                   const matrix::Dense<T>* prev_rho,                            \
+                   const array<stopping_status>* stop_status)                   \
+    {                                                                           \
+        GKOC_CALL(gkoc_cg_step_1_##TN(                                          \
+            stream_of(exec), rows(p), cols(p), p->get_values(), ld(p),          \
+            z->get_const_values(), ld(z), rho->get_const_values(),              \
+            prev_rho->get_const_values(), raw(stop_status)));                   \
+    }                                                                           \
+    template <>                                                                 \
+    void step_2<T>(exec_t exec, matrix::Dense<T>* x, matrix::Dense<T>* r,       \
+                   const matrix::Dense<T>* p, const matrix::Dense<T>* q,        \
+                   const matrix::Dense<T>* beta, const matrix::Dense<T>* rho,   \
+                   const array<stopping_status>* stop_status)                   \
+    {                                                                           \
+        GKOC_CALL(gkoc_cg_step_2_##TN(                                          \
+            stream_of(exec), rows(x), cols(x), x->get_values(), ld(x),          \
+            r->get_values(), ld(r), p->get_const_values(), ld(p),               \
+            q->get_const_values(), ld(q), beta->get_const_values(),             \
+            rho->get_const_values(), raw(stop_status)));                        \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+}  // namespace cg
+
+
+// =================================================================== gmres
+namespace gmres {
+
+#define DEF(T, TN)                                                              \
+    template <>                                                                 \
+    void restart<T>(exec_t exec, const matrix::Dense<T>* residual,              \
+                    const matrix::Dense<T>* residual_norm,                      \
+                    matrix::Dense<T>* residual_norm_collection,                 \
+                    matrix::Dense<T>* krylov_bases, size_type* final_iter_nums) \
+    {                                                                           \
+        GKOC_CALL(gkoc_gmres_restart_##TN(                                      \
+            stream_of(exec), rows(residual), cols(residual),                    \
+            residual->get_const_values(), ld(residual),                         \
+            residual_norm->get_const_values(),                                  \
+            residual_norm_collection->get_values(), krylov_bases->get_values(), \
+            ld(krylov_bases), reinterpret_cast<uint64_t*>(final_iter_nums)));   \
+    }                                                                           \
+    template <>                                                                 \
+    void multi_axpy<T>(exec_t exec, const matrix::Dense<T>* krylov_bases,       \
+                       const matrix::Dense<T>* y,                               \
+                       matrix::Dense<T>* before_preconditioner,                 \
+                       const size_type* final_iter_nums,                        \
+                       stopping_status* stop_status)                            \
+    {                                                                           \
+        GKOC_CALL(gkoc_gmres_multi_axpy_##TN(                                   \
+            stream_of(exec), rows(before_preconditioner),                       \
+            cols(before_preconditioner), krylov_bases->get_const_values(),      \
+            ld(krylov_bases), y->get_const_values(), ld(y),                     \
+            before_preconditioner->get_values(), ld(before_preconditioner),     \
+            reinterpret_cast<const uint64_t*>(final_iter_nums),                 \
+            raw(stop_status)));                                                 \
+    }                                                                           \
+    template <>                                                                 \
+    void multi_dot<T>(exec_t exec, const matrix::Dense<T>* krylov_bases,        \
+                      const matrix::Dense<T>* next_krylov,                      \
+                      matrix::Dense<T>* hessenberg_col)                         \
+    {                                                                           \
+        const int64_t n = rows(next_krylov), k = cols(next_krylov);             \
+        const int64_t dots = rows(hessenberg_col) - 1;                          \
+        const size_t bytes =                                                    \
+            gkoc_gmres_multi_dot_workspace_bytes(n, k, dots, sizeof(T));        \
+        array<char> tmp(exec, bytes);                                           \
+        GKOC_CALL(gkoc_gmres_multi_dot_##TN(                                    \
+            stream_of(exec), n, k, dots, krylov_bases->get_const_values(),      \
+            ld(krylov_bases), next_krylov->get_const_values(),                  \
+            ld(next_krylov), hessenberg_col->get_values(), ld(hessenberg_col),  \
+            tmp.get_data(), bytes));                                            \
+        exec->synchronize(); /* tmp is released on return */                    \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+}  // namespace gmres
+
+namespace common_gmres {
+
+#define DEF(T, TN)                                                              \
+    template <>                                                                 \
+    void initialize<T>(exec_t exec, const matrix::Dense<T>* b,                  \
+                       matrix::Dense<T>* residual, matrix::Dense<T>* givens_sin, \
+                       matrix::Dense<T>* givens_cos,                            \
+                       stopping_status* stop_status)                            \
+    {                                                                           \
+        GKOC_CALL(gkoc_common_gmres_initialize_##TN(                            \
+            stream_of(exec), rows(b), cols(b), b->get_const_values(), ld(b),    \
+            residual->get_values(), ld(residual), givens_sin->get_values(),     \
+            ld(givens_sin), givens_cos->get_values(), ld(givens_cos),           \
+            rows(givens_sin), raw(stop_status)));                               \
+    }                                                                           \
+    template <>                                                                 \
+    void hessenberg_qr<T>(exec_t exec, matrix::Dense<T>* givens_sin,            \
+                          matrix::Dense<T>* givens_cos,                         \
+                          matrix::Dense<T>* residual_norm,                      \
+                          matrix::Dense<T>* residual_norm_collection,           \
+                          matrix::Dense<T>* hessenberg_iter, size_type iter,    \
+                          size_type* final_iter_nums,                           \
+                          const stopping_status* stop_status)                   \
+    {                                                                           \
+        GKOC_CALL(gkoc_common_gmres_hessenberg_qr_##TN(                         \
+            stream_of(exec), cols(givens_sin), givens_sin->get_values(),        \
+            ld(givens_sin), givens_cos->get_values(), ld(givens_cos),           \
+            residual_norm->get_values(),                                        \
+            residual_norm_collection->get_values(),                             \
+            ld(residual_norm_collection), hessenberg_iter->get_values(),        \
+            ld(hessenberg_iter), iter,                                          \
+            reinterpret_cast<uint64_t*>(final_iter_nums), raw(stop_status)));   \
+    }                                                                           \
+    template <>                                                                 \
+    void solve_krylov<T>(exec_t exec,                                           \
+                         const matrix::Dense<T>* residual_norm_collection,      \
+                         const matrix::Dense<T>* hessenberg,                    \
+                         matrix::Dense<T>* y, const size_type* final_iter_nums, \
+                         const stopping_status* stop_status)                    \
+    {                                                                           \
+        GKOC_CALL(gkoc_common_gmres_solve_krylov_##TN(                          \
+            stream_of(exec), cols(residual_norm_collection),                    \
+            residual_norm_collection->get_const_values(),                       \
+            ld(residual_norm_collection), hessenberg->get_const_values(),       \
+            ld(hessenberg), y->get_values(), ld(y),                             \
+            reinterpret_cast<const uint64_t*>(final_iter_nums),                 \
+            raw(stop_status)));                                                 \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+}  // namespace common_gmres
+
+
+// ==================================================================== stop
+namespace residual_norm {
+
+#define DEF(T, TN)                                                              \
+    template <>                                                                 \
+    void residual_norm<T>(exec_t exec, const matrix::Dense<T>* tau,             \
+                          const matrix::Dense<T>* orig_tau,                     \
+                          T rel_residual_goal, uint8 stoppingId,                \
+                          bool setFinalized,                                    \
+                          array<stopping_status>* stop_status,                  \
+                          array<bool>* device_storage, bool* all_converged,     \
+                          bool* one_changed)                                    \
+    {                                                                           \
+        if (device_storage->get_size() < 2) device_storage->resize_and_reset(2); \
+        int allc = 0, chg = 0;                                                  \
+        GKOC_CALL(gkoc_residual_norm_##TN(                                      \
+            stream_of(exec), cols(tau), tau->get_const_values(),                \
+            orig_tau->get_const_values(), rel_residual_goal, stoppingId,        \
+            setFinalized ? 1 : 0, raw(stop_status),                             \
+            reinterpret_cast<uint8_t*>(device_storage->get_data()), &allc,      \
+            &chg));                                                             \
+        *all_converged = allc != 0;                                             \
+        *one_changed = chg != 0;                                                \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+}  // namespace residual_norm
+
+namespace implicit_residual_norm {
+
+#define DEF(T, TN)                                                              \
+    template <>                                                                 \
+    void implicit_residual_norm<T>(                                             \
+        exec_t exec, const matrix::Dense<T>* tau,                               \
+        const matrix::Dense<T>* orig_tau, T rel_residual_goal,                  \
+        uint8 stoppingId, bool setFinalized,                                    \
+        array<stopping_status>* stop_status, array<bool>* device_storage,       \
+        bool* all_converged, bool* one_changed)                                 \
+    {                                                                           \
+        if (device_storage->get_size() < 2) device_storage->resize_and_reset(2); \
+        int allc = 0, chg = 0;                                                  \
+        GKOC_CALL(gkoc_implicit_residual_norm_##TN(                             \
+            stream_of(exec), cols(tau), tau->get_const_values(),                \
+            orig_tau->get_const_values(), rel_residual_goal, stoppingId,        \
+            setFinalized ? 1 : 0, raw(stop_status),                             \
+            reinterpret_cast<uint8_t*>(device_storage->get_data()), &allc,      \
+            &chg));                                                             \
+        *all_converged = allc != 0;                                             \
+        *one_changed = chg != 0;                                                \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+}  // namespace implicit_residual_norm
+
+namespace set_all_statuses {
+
+void set_all_statuses(exec_t exec, uint8 stoppingId, bool setFinalized,
+                      array<stopping_status>* stop_status)
+{
+    GKOC_CALL(gkoc_set_all_statuses(stream_of(exec),
+                                    static_cast<int64_t>(stop_status->get_size()),
+                                    stoppingId, setFinalized ? 1 : 0,
+                                    raw(stop_status)));
+}
+
+}  // namespace set_all_statuses
+
+
+// ================================================================== jacobi
+namespace jacobi {
+
+template <typename I>
+inline gkoc_jacobi_scheme scheme_of(
+    const preconditioner::block_interleaved_storage_scheme<I>& s)
+{
+    return {static_cast<int64_t>(s.block_offset),
+            static_cast<int64_t>(s.group_offset), s.group_power};
+}
+
+inline void require_full_precision(const array<precision_reduction>& prec)
+{
+    // adaptive-precision storage is outside the hot path
+    if (prec.get_const_data() != nullptr) {
+        throw ::gko::NotSupported(
+            __FILE__, __LINE__, "jacobi",
+            "adaptive-precision block-Jacobi is not supported by gko-cdna4");
+    }
+}
+
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void find_blocks<T, I>(exec_t exec, const matrix::Csr<T, I>* system_matrix, \
+                           uint32 max_block_size, size_type& num_blocks,        \
+                           array<I>& block_pointers)                            \
+    {                                                                           \
+        int64_t nb = 0;                                                         \
+        GKOC_CALL(gkoc_jacobi_find_blocks_##TN##_##IN(                          \
+            stream_of(exec), system_matrix->get_size()[0],                      \
+            system_matrix->get_const_row_ptrs(),                                \
+            system_matrix->get_const_col_idxs(), max_block_size, &nb,           \
+            block_pointers.get_data()));                                        \
+        num_blocks = static_cast<size_type>(nb);                                \
+    }                                                                           \
+    template <>                                                                 \
+    void generate<T, I>(                                                        \
+        exec_t exec, const matrix::Csr<T, I>* system_matrix,                    \
+        size_type num_blocks, uint32 max_block_size, T,                         \
+        const preconditioner::block_interleaved_storage_scheme<I>&              \
+            storage_scheme,                                                     \
+        array<T>& conditioning, array<precision_reduction>& block_precisions,   \
+        const array<I>& block_pointers, array<T>& blocks)                       \
+    {                                                                           \
+        require_full_precision(block_precisions);                               \
+        GKOC_CALL(gkoc_jacobi_generate_##TN##_##IN(                             \
+            stream_of(exec), system_matrix->get_size()[0],                      \
+            system_matrix->get_const_row_ptrs(),                                \
+            system_matrix->get_const_col_idxs(),                                \
+            system_matrix->get_const_values(), num_blocks, max_block_size,      \
+            scheme_of(storage_scheme), block_pointers.get_const_data(),         \
+            blocks.get_data(), nullptr));                                       \
+    }                                                                           \
+    template <>                                                                 \
+    void simple_apply<T, I>(                                                    \
+        exec_t exec, size_type num_blocks, uint32 max_block_size,               \
+        const preconditioner::block_interleaved_storage_scheme<I>&              \
+            storage_scheme,                                                     \
+        const array<precision_reduction>& block_precisions,                     \
+        const array<I>& block_pointers, const array<T>& blocks,                 \
+        const matrix::Dense<T>* b, matrix::Dense<T>* x)                         \
+    {                                                                           \
+        require_full_precision(block_precisions);                               \
+        GKOC_CALL(gkoc_jacobi_simple_apply_##TN##_##IN(                         \
+            stream_of(exec), num_blocks, max_block_size,                        \
+            scheme_of(storage_scheme), block_pointers.get_const_data(),         \
+            blocks.get_const_data(), b->get_const_values(), ld(b),              \
+            x->get_values(), ld(x), cols(b)));                                  \
+    }                                                                           \
+    template <>                                                                 \
+    void apply<T, I>(                                                           \
+        exec_t exec, size_type num_blocks, uint32 max_block_size,               \
+        const preconditioner::block_interleaved_storage_scheme<I>&              \
+            storage_scheme,                                                     \
+        const array<precision_reduction>& block_precisions,                     \
+        const array<I>& block_pointers, const array<T>& blocks,                 \
+        const matrix::Dense<T>* alpha, const matrix::Dense<T>* b,               \
+        const matrix::Dense<T>* beta, matrix::Dense<T>* x)                      \
+    {                                                                           \
+        require_full_precision(block_precisions);                               \
+        GKOC_CALL(gkoc_jacobi_apply_##TN##_##IN(                                \
+            stream_of(exec), num_blocks, max_block_size,                        \
+            scheme_of(storage_scheme), block_pointers.get_const_data(),         \
+            blocks.get_const_data(), alpha->get_const_values(),                 \
+            b->get_const_values(), ld(b), beta->get_const_values(),             \
+            x->get_values(), ld(x), cols(b)));                                  \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+#define DEF(T, TN)                                                              \
+    template <>                                                                 \
+    void invert_diagonal<T>(exec_t exec, const array<T>& diag,                  \
+                            array<T>& inv_diag)                                 \
+    {                                                                           \
+        GKOC_CALL(gkoc_jacobi_invert_diagonal_##TN(                             \
+            stream_of(exec), static_cast<int64_t>(diag.get_size()),             \
+            diag.get_const_data(), inv_diag.get_data()));                       \
+    }                                                                           \
+    template <>                                                                 \
+    void simple_scalar_apply<T>(exec_t exec, const array<T>& diag,              \
+                                const matrix::Dense<T>* b, matrix::Dense<T>* x) \
+    {                                                                           \
+        GKOC_CALL(gkoc_jacobi_simple_scalar_apply_##TN(                         \
+            stream_of(exec), rows(x), cols(x), diag.get_const_data(),           \
+            b->get_const_values(), ld(b), x->get_values(), ld(x)));             \
+    }                                                                           \
+    template <>                                                                 \
+    void scalar_apply<T>(exec_t exec, const array<T>& diag,                     \
+                         const matrix::Dense<T>* alpha,                         \
+                         const matrix::Dense<T>* b,                             \
+                         const matrix::Dense<T>* beta, matrix::Dense<T>* x)     \
+    {                                                                           \
+        GKOC_CALL(gkoc_jacobi_scalar_apply_##TN(                                \
+            stream_of(exec), rows(x), cols(x), diag.get_const_data(),           \
+            alpha->get_const_values(), b->get_const_values(), ld(b),            \
+            beta->get_const_values(), x->get_values(), ld(x)));                 \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+}  // namespace jacobi
+
+
+// ============================================================== components
+namespace components {
+
+template <>
+void fill_array<double>(exec_t exec, double* data, size_type n, double val)
+{
+    GKOC_CALL(gkoc_fill_array_f64(stream_of(exec), data, n, val));
+}
+template <>
+void fill_array<float>(exec_t exec, float* data, size_type n, float val)
+{
+    GKOC_CALL(gkoc_fill_array_f32(stream_of(exec), data, n, val));
+}
+template <>
+void fill_array<int32>(exec_t exec, int32* data, size_type n, int32 val)
+{
+    GKOC_CALL(gkoc_fill_array_i32(stream_of(exec), data, n, val));
+}
+template <>
+void fill_array<int64>(exec_t exec, int64* data, size_type n, int64 val)
+{
+    GKOC_CALL(gkoc_fill_array_i64(stream_of(exec), data, n, val));
+}
+template <>
+void fill_array<size_type>(exec_t exec, size_type* data, size_type n,
+                           size_type val)
+{
+    GKOC_CALL(gkoc_fill_array_i64(stream_of(exec),
+                                  reinterpret_cast<int64_t*>(data), n,
+                                  static_cast<int64_t>(val)));
+}
+template <>
+void fill_seq_array<int32>(exec_t exec, int32* data, size_type n)
+{
+    GKOC_CALL(gkoc_fill_seq_array_i32(stream_of(exec), data, n));
+}
+template <>
+void fill_seq_array<int64>(exec_t exec, int64* data, size_type n)
+{
+    GKOC_CALL(gkoc_fill_seq_array_i64(stream_of(exec), data, n));
+}
+template <>
+void prefix_sum_nonnegative<int32>(exec_t exec, int32* counts, size_type n)
+{
+    GKOC_CALL(gkoc_prefix_sum_nonnegative_i32(stream_of(exec), counts, n));
+}
+template <>
+void prefix_sum_nonnegative<int64>(exec_t exec, int64* counts, size_type n)
+{
+    GKOC_CALL(gkoc_prefix_sum_nonnegative_i64(stream_of(exec), counts, n));
+}
+template <>
+void prefix_sum_nonnegative<size_type>(exec_t exec, size_type* counts,
+                                       size_type n)
+{
+    GKOC_CALL(gkoc_prefix_sum_nonnegative_u64(
+        stream_of(exec), reinterpret_cast<uint64_t*>(counts), n));
+}
+template <>
+void convert_ptrs_to_sizes<int32>(exec_t exec, const int32* ptrs,
+                                  size_type num_blocks, size_type* sizes)
+{
+    GKOC_CALL(gkoc_convert_ptrs_to_sizes_i32(
+        stream_of(exec), num_blocks, ptrs, reinterpret_cast<uint64_t*>(sizes)));
+}
+template <>
+void convert_ptrs_to_sizes<int64>(exec_t exec, const int64* ptrs,
+                                  size_type num_blocks, size_type* sizes)
+{
+    GKOC_CALL(gkoc_convert_ptrs_to_sizes_i64(
+        stream_of(exec), num_blocks, ptrs, reinterpret_cast<uint64_t*>(sizes)));
+}
+template <>
+void convert_idxs_to_ptrs<int32, int32>(exec_t exec, const int32* idxs,
+                                        size_type num_idxs,
+                                        size_type num_blocks, int32* ptrs)
+{
+    GKOC_CALL(gkoc_convert_idxs_to_ptrs_i32(stream_of(exec), num_idxs, idxs,
+                                            num_blocks, ptrs));
+}
+template <>
+void convert_idxs_to_ptrs<int64, int64>(exec_t exec, const int64* idxs,
+                                        size_type num_idxs,
+                                        size_type num_blocks, int64* ptrs)
+{
+    GKOC_CALL(gkoc_convert_idxs_to_ptrs_i64(stream_of(exec), num_idxs, idxs,
+                                            num_blocks, ptrs));
+}
+
+}  // namespace components
+}  // namespace hip
+}  // namespace kernels
+}  // namespace gko

@@ -1,0 +1,77 @@
+// Ginkgo-side binding of libgko_cdna4.so: shared helpers.
+//
+// This directory is the shim INTEGRATION.md describes: it is compiled against
+// the UNMODIFIED Ginkgo headers (public include/ + the core/**_kernels.hpp
+// declarations) and defines, with strong linkage, the `gko::HipExecutor`
+// runtime members and the hot-path `gko::kernels::hip::*` kernels by forwarding
+// to the C ABI (include/gko_cdna4.h).  Linked together with Ginkgo's own stub
+// object (core/device_hooks/hip_hooks.cpp, all symbols weakened) it forms a
+// link-compatible replacement for libginkgo_hip.so.  No device code and no HIP
+// headers are needed here: everything goes through the C ABI.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+
+#include <ginkgo/core/base/array.hpp>
+#include <ginkgo/core/base/exception.hpp>
+#include <ginkgo/core/base/executor.hpp>
+#include <ginkgo/core/base/types.hpp>
+#include <ginkgo/core/matrix/dense.hpp>
+#include <ginkgo/core/stop/stopping_status.hpp>
+
+#include "gko_cdna4.h"
+
+namespace gko {
+namespace cdna4 {
+
+// error convention of SURVEY.md 8(b): non-zero status -> gko::Error subclass
+inline void check(int status, const char* file, int line, const char* what)
+{
+    if (status == GKOC_OK) return;
+    const std::string msg = std::string(what) + ": " + gkoc_last_error();
+    if (status == GKOC_E_NOT_SUPPORTED) {
+        throw ::gko::NotSupported(file, line, what, gkoc_last_error());
+    }
+    throw ::gko::HipError(file, line, msg, status);
+}
+
+#define GKOC_CALL(expr) ::gko::cdna4::check((expr), __FILE__, __LINE__, #expr)
+
+inline gkoc_stream_t stream_of(const std::shared_ptr<const HipExecutor>& exec)
+{
+    return reinterpret_cast<gkoc_stream_t>(exec->get_stream());
+}
+
+template <typename T>
+inline int64_t rows(const matrix::Dense<T>* d)
+{
+    return static_cast<int64_t>(d->get_size()[0]);
+}
+template <typename T>
+inline int64_t cols(const matrix::Dense<T>* d)
+{
+    return static_cast<int64_t>(d->get_size()[1]);
+}
+template <typename T>
+inline int64_t ld(const matrix::Dense<T>* d)
+{
+    return static_cast<int64_t>(d->get_stride());
+}
+
+inline uint8_t* raw(array<stopping_status>* s)
+{
+    return reinterpret_cast<uint8_t*>(s->get_data());
+}
+inline const uint8_t* raw(const array<stopping_status>* s)
+{
+    return reinterpret_cast<const uint8_t*>(s->get_const_data());
+}
+inline uint8_t* raw(stopping_status* s) { return reinterpret_cast<uint8_t*>(s); }
+inline const uint8_t* raw(const stopping_status* s)
+{
+    return reinterpret_cast<const uint8_t*>(s);
+}
+
+}  // namespace cdna4
+}  // namespace gko

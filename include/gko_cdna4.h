@@ -69,6 +69,7 @@ int gkoc_version(void);
 int gkoc_get_num_devices(int* count);
 int gkoc_get_device_info(int device_id, gkoc_device_info* info);
 int gkoc_set_device(int device_id);
+int gkoc_get_device(int* device_id);
 int gkoc_malloc(void** ptr, size_t bytes);
 int gkoc_free(void* ptr);
 int gkoc_memcpy_h2d(void* dst, const void* src_host, size_t bytes, gkoc_stream_t s);
@@ -79,6 +80,14 @@ int gkoc_stream_create(gkoc_stream_t* s);
 int gkoc_stream_destroy(gkoc_stream_t s);
 int gkoc_stream_synchronize(gkoc_stream_t s);
 int gkoc_device_synchronize(void);
+/* events (HipTimer, hip/base/timer.hip.cpp; RowGatherer's event::record_event) */
+typedef void* gkoc_event_t;
+int gkoc_event_create(gkoc_event_t* e);
+int gkoc_event_destroy(gkoc_event_t e);
+int gkoc_event_record(gkoc_event_t e, gkoc_stream_t s);
+int gkoc_event_synchronize(gkoc_event_t e);
+int gkoc_event_elapsed_ns(gkoc_event_t start, gkoc_event_t stop, int64_t* ns);
+int gkoc_stream_wait_event(gkoc_stream_t s, gkoc_event_t e);
 
 /* --------------------------------------------------------------- CSR SpMV
  * csr::spmv            core/matrix/csr_kernels.hpp:29-34
@@ -203,6 +212,9 @@ GKOC_DECL_CONV(float, f32, int64_t, i64)
     int gkoc_fill_seq_array_##IN(gkoc_stream_t s, I* data, int64_t n);
 GKOC_DECL_IDX(int32_t, i32)
 GKOC_DECL_IDX(int64_t, i64)
+/* components::fill_array for value types (core/components/fill_array_kernels.hpp) */
+int gkoc_fill_array_f64(gkoc_stream_t s, double* data, int64_t n, double value);
+int gkoc_fill_array_f32(gkoc_stream_t s, float* data, int64_t n, float value);
 int gkoc_prefix_sum_nonnegative_u64(gkoc_stream_t s, uint64_t* counts,
                                     int64_t n);
 
