@@ -252,6 +252,39 @@ __global__ __launch_bounds__(256) void fill_idx_kernel(int64_t n, I* data,
     }
 }
 
+// Ginkgo's matrix_data_entry<T, I> (matrix_data.hpp:60): { I row; I column; T value; }
+template <typename T, typename I>
+struct md_entry {
+    I row;
+    I column;
+    T value;
+};
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void aos_to_soa_kernel(
+    int64_t nnz, const md_entry<T, I>* __restrict__ in, I* __restrict__ rows,
+    I* __restrict__ cols, T* __restrict__ vals)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < nnz; i += stride) {
+        const md_entry<T, I> e = in[i];
+        rows[i] = e.row;
+        cols[i] = e.column;
+        vals[i] = e.value;
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void fill_in_md_kernel(
+    int64_t nnz, const I* __restrict__ rows, const I* __restrict__ cols,
+    const T* __restrict__ vals, T* __restrict__ out, int64_t ld)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < nnz; i += stride) {
+        out[int64_t(rows[i]) * ld + cols[i]] = vals[i];
+    }
+}
+
 inline unsigned blocks_for(int64_t n)
 {
     return unsigned(ceildiv(n > 0 ? n : 1, 256));
@@ -364,6 +397,40 @@ using namespace gkoc;
         GKOC_LAUNCH_OK();                                                      \
         return GKOC_OK;                                                        \
     }
+
+#define GKOC_DEF_MD(T, TN, I, IN)                                              \
+    extern "C" int gkoc_aos_to_soa_##TN##_##IN(gkoc_stream_t s, int64_t nnz,   \
+                                               const void* entries,            \
+                                               I* row_idxs, I* col_idxs,       \
+                                               T* vals)                        \
+    {                                                                          \
+        if (nnz <= 0) return GKOC_OK;                                          \
+        int64_t nb = ceildiv(nnz, 256);                                        \
+        if (nb > max_stream_blocks) nb = max_stream_blocks;                    \
+        aos_to_soa_kernel<T, I>                                                \
+            <<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(              \
+                nnz, static_cast<const md_entry<T, I>*>(entries), row_idxs,    \
+                col_idxs, vals);                                               \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_dense_fill_in_matrix_data_##TN##_##IN(                 \
+        gkoc_stream_t s, int64_t nnz, const I* row_idxs, const I* col_idxs,    \
+        const T* vals, T* out, int64_t ld_out)                                 \
+    {                                                                          \
+        if (nnz <= 0) return GKOC_OK;                                          \
+        int64_t nb = ceildiv(nnz, 256);                                        \
+        if (nb > max_stream_blocks) nb = max_stream_blocks;                    \
+        fill_in_md_kernel<T, I>                                                \
+            <<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(              \
+                nnz, row_idxs, col_idxs, vals, out, ld_out);                   \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }
+GKOC_DEF_MD(double, f64, int32_t, i32)
+GKOC_DEF_MD(double, f64, int64_t, i64)
+GKOC_DEF_MD(float, f32, int32_t, i32)
+GKOC_DEF_MD(float, f32, int64_t, i64)
 
 GKOC_DEF_FMT(double, f64, int32_t, i32)
 GKOC_DEF_FMT(double, f64, int64_t, i64)

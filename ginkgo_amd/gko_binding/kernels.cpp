@@ -10,6 +10,10 @@
 #include <ginkgo/core/matrix/sellp.hpp>
 #include <ginkgo/core/preconditioner/jacobi.hpp>
 
+#include <ginkgo/core/base/device_matrix_data.hpp>
+#include <ginkgo/core/base/matrix_data.hpp>
+
+#include "core/base/device_matrix_data_kernels.hpp"
 #include "core/components/fill_array_kernels.hpp"
 #include "core/components/format_conversion_kernels.hpp"
 #include "core/components/prefix_sum_kernels.hpp"
@@ -359,6 +363,16 @@ FOR_VT(DEF)
 #undef DEF
 
 #define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void fill_in_matrix_data<T, I>(exec_t exec,                                 \
+                                   const device_matrix_data<T, I>& data,        \
+                                   matrix::Dense<T>* output)                    \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_fill_in_matrix_data_##TN##_##IN(                   \
+            stream_of(exec), data.get_num_stored_elements(),                    \
+            data.get_const_row_idxs(), data.get_const_col_idxs(),               \
+            data.get_const_values(), output->get_values(), ld(output)));        \
+    }                                                                           \
     template <>                                                                 \
     void row_gather<T, T, I>(exec_t exec, const I* gather_indices,              \
                              const matrix::Dense<T>* orig,                      \
@@ -811,6 +825,26 @@ void convert_idxs_to_ptrs<int64, int64>(exec_t exec, const int64* idxs,
     GKOC_CALL(gkoc_convert_idxs_to_ptrs_i64(stream_of(exec), num_idxs, idxs,
                                             num_blocks, ptrs));
 }
+
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void aos_to_soa<T, I>(exec_t exec,                                          \
+                          const array<matrix_data_entry<T, I>>& in,             \
+                          device_matrix_data<T, I>& out)                        \
+    {                                                                           \
+        static_assert(sizeof(matrix_data_entry<T, I>) ==                        \
+                          (sizeof(T) > sizeof(I) ? 2 * sizeof(T)                \
+                                                 : 3 * sizeof(I)) ||            \
+                          sizeof(matrix_data_entry<T, I>) ==                    \
+                              2 * sizeof(I) + sizeof(T),                        \
+                      "unexpected matrix_data_entry layout");                   \
+        GKOC_CALL(gkoc_aos_to_soa_##TN##_##IN(                                  \
+            stream_of(exec), static_cast<int64_t>(in.get_size()),               \
+            in.get_const_data(), out.get_row_idxs(), out.get_col_idxs(),        \
+            out.get_values()));                                                 \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
 
 }  // namespace components
 }  // namespace hip

@@ -191,6 +191,23 @@ GKOC_DECL_CONV(double, f64, int64_t, i64)
 GKOC_DECL_CONV(float, f32, int32_t, i32)
 GKOC_DECL_CONV(float, f32, int64_t, i64)
 
+/* components::aos_to_soa (core/base/device_matrix_data_kernels.hpp:27-30):
+ * entries is an array of Ginkgo matrix_data_entry<T,I> = struct { I row;
+ * I column; T value; } with natural alignment (include/ginkgo/core/base/
+ * matrix_data.hpp:60); dense::fill_in_matrix_data
+ * (core/matrix/dense_kernels.hpp:122-125): out(row, col) = value. */
+#define GKOC_DECL_MD(T, TN, I, IN)                                             \
+    int gkoc_aos_to_soa_##TN##_##IN(gkoc_stream_t s, int64_t nnz,              \
+                                    const void* entries, I* row_idxs,          \
+                                    I* col_idxs, T* vals);                     \
+    int gkoc_dense_fill_in_matrix_data_##TN##_##IN(                            \
+        gkoc_stream_t s, int64_t nnz, const I* row_idxs, const I* col_idxs,    \
+        const T* vals, T* out, int64_t ld_out);
+GKOC_DECL_MD(double, f64, int32_t, i32)
+GKOC_DECL_MD(double, f64, int64_t, i64)
+GKOC_DECL_MD(float, f32, int32_t, i32)
+GKOC_DECL_MD(float, f32, int64_t, i64)
+
 #define GKOC_DECL_IDX(I, IN)                                                   \
     /* ell::compute_max_row_nnz: *max_nnz is HOST memory */                    \
     int gkoc_compute_max_row_nnz_##IN(gkoc_stream_t s, int64_t n_rows,         \

@@ -1,0 +1,55 @@
+"""Drop-in acceptance on the GPU box: the UNMODIFIED Ginkgo core
+(oracle/_ref/lib/libginkgo.so) on gko::HipExecutor, with libginkgo_hip.so =
+ginkgo_amd/gko_binding (shim) + libgko_cdna4.so.  Runs tests/dropin/dropin_test.cpp
+and Ginkgo's own examples/preconditioned-solver (golden output
+examples/preconditioned-solver/doc/results.dox: residual 4.82005e-08).
+The binaries are built in the container by oracle/build_dropin.py."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROP = os.path.join(ROOT, "oracle", "_ref", "dropin")
+
+pytestmark = pytest.mark.gpu
+
+
+def _need(name):
+    path = os.path.join(DROP, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not built (run oracle/build_dropin.py where /root/reference exists)")
+    return path
+
+
+def test_dropin_program():
+    exe = _need("dropin_test")
+    p = subprocess.run([exe, "24"], capture_output=True, text=True, timeout=600, cwd=DROP)
+    print(p.stdout[-4000:])
+    assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
+    assert "DROPIN OK" in p.stdout
+    assert "bit-identical" in p.stdout and "FAILED" not in p.stdout
+
+
+def _numbers(block):
+    return [float(x) for x in re.findall(r"^[-+]?[0-9][-+0-9.eE]*$", block, re.M)]
+
+
+def test_ginkgo_example_preconditioned_solver():
+    exe = _need("preconditioned-solver")
+    out = {}
+    for ex in ("reference", "hip"):
+        p = subprocess.run([exe, ex], capture_output=True, text=True, timeout=600, cwd=DROP)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        out[ex] = p.stdout
+    # golden output (doc/results.dox): 19 solution values, then the residual norm 4.82005e-08
+    sol, res = {}, {}
+    for k, v in out.items():
+        head, tail = v.split("Residual norm")
+        sol[k] = _numbers(head)[-19:]
+        res[k] = _numbers(tail)[-1]
+    assert abs(res["reference"] - 4.82005e-08) < 1e-12
+    assert abs(res["hip"] - res["reference"]) < 1e-12
+    assert len(sol["hip"]) == len(sol["reference"]) == 19
+    assert max(abs(a - b) for a, b in zip(sol["hip"], sol["reference"])) < 1e-5
