@@ -530,3 +530,167 @@ __global__ __launch_bounds__(64) void csr_spmv_pipe2_kernel(
 
 
 }  // namespace gkoc
+
+namespace gkoc {
+
+// ---------------------------------------------------------------------------
+// Variant 4 (lab): producer / consumer wave pair.  Workgroup = 2 waves sharing
+// one LDS ring of (val, col): wave 0 only streams the matrix into the ring
+// (register sets, deep queue; its vmcnt queue holds nothing but stream loads),
+// wave 1 only does the row phase (lane = row, row-ordered b gather, k-ordered
+// sums; its vmcnt queue holds only gathers / row pointers / the c store).
+// Hand-off through two LDS words (produced / consumed offsets); a wave's LDS
+// operations execute in order, so flag-after-data needs no hardware fence.
+template <typename T, typename I, int ROWS, int E, int U, int NSETS, int RING,
+          int GB, int ABL = 0>
+__global__ __launch_bounds__(128) void csr_spmv_pair_kernel(
+    int64_t n_rows, int64_t n_segments, int64_t segs_per_wg,
+    const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    const T* __restrict__ vals, const T* __restrict__ b, T* __restrict__ c)
+{
+    static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
+    constexpr int G = 64 * E * U;
+    static_assert(RING >= 2 * G, "ring too small");
+    constexpr int MASK = RING - 1;
+    __shared__ __attribute__((aligned(16))) T ringv[RING];
+    __shared__ __attribute__((aligned(16))) I ringc[RING];
+    __shared__ volatile int sh_prod;
+    __shared__ volatile int sh_cons;
+
+    const int lane = threadIdx.x & 63;
+    const bool producer = threadIdx.x < 64;
+    const int64_t sb = int64_t(blockIdx.x) * segs_per_wg;
+    const int64_t se = sb + segs_per_wg < n_segments ? sb + segs_per_wg : n_segments;
+    if (sb >= se) return;
+    const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;
+    const int64_t K0 = row_ptrs[sb * ROWS];
+    const int64_t K1 = row_ptrs[row_e];
+    const int64_t NNZ = row_ptrs[n_rows];
+    const int64_t K0a = K0 & ~int64_t(E - 1);
+    const int k1o = int(K1 - K0a);
+    const int nnzo = (NNZ - K0a) > int64_t(0x7fffff00) ? 0x7fffff00 : int(NNZ - K0a);
+    const T* __restrict__ vals0 = vals + K0a;
+    const I* __restrict__ cols0 = cols + K0a;
+    if (threadIdx.x == 0) {
+        sh_prod = 0;
+        sh_cons = int(K0 - K0a);
+    }
+    __syncthreads();
+
+    using VT = vecT<T, E>;
+    using VI = vecT<I, E>;
+
+    if (producer) {
+        VT v[NSETS][U];
+        VI ci[NSETS][U];
+        auto load_group = [&](VT(&vv)[U], VI(&cc)[U], int p) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = p + (u * 64 + lane) * E;
+                if (k >= k1o) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        vv[u].v[e] = T(0);
+                        cc[u].v[e] = I(0);
+                    }
+                } else if (k + E <= nnzo) {
+                    vv[u] = *reinterpret_cast<const VT*>(vals0 + k);
+                    cc[u] = *reinterpret_cast<const VI*>(cols0 + k);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const bool in = k + e < nnzo;
+                        vv[u].v[e] = in ? vals0[k + e] : T(0);
+                        cc[u].v[e] = in ? cols0[k + e] : I(0);
+                    }
+                }
+            }
+        };
+        int p_load = 0;
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) {
+            load_group(v[s], ci[s], p_load);
+            p_load += G;
+        }
+        int produced = 0;
+        while (produced < k1o) {
+#pragma unroll
+            for (int s = 0; s < NSETS; ++s) {
+                if (produced < k1o) {
+                    // wait for ring space
+                    while (produced + G - sh_cons > RING) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int k = produced + (u * 64 + lane) * E;
+                        *reinterpret_cast<VT*>(&ringv[k & MASK]) = v[s][u];
+                        *reinterpret_cast<VI*>(&ringc[k & MASK]) = ci[s][u];
+                    }
+                    load_group(v[s], ci[s], p_load);
+                    p_load += G;
+                    produced += G;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    if (lane == 0) sh_prod = produced;
+                }
+            }
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------- consumer
+    int cons = int(K0 - K0a);
+    auto seg_rows = [&](int64_t s, int& rs, int& re, int& s_end) {
+        const int64_t row = s * ROWS + lane;
+        const int64_t last = (s + 1) * ROWS < n_rows ? (s + 1) * ROWS : n_rows;
+        const bool valid = lane < ROWS && row < n_rows;
+        rs = int(int64_t(row_ptrs[valid ? row : last]) - K0a);
+        re = int(int64_t(row_ptrs[valid ? row + 1 : last]) - K0a);
+        s_end = int(int64_t(row_ptrs[last]) - K0a);
+    };
+    int rs, re, seg_end, nrs = 0, nre = 0, nseg_end = 0;
+    int64_t seg = sb;
+    seg_rows(seg, rs, re, seg_end);
+    if (seg + 1 < se) seg_rows(seg + 1, nrs, nre, nseg_end);
+    T sum = T(0);
+    while (seg < se) {
+        int P = sh_prod;
+        while (!(P >= seg_end || P + G - cons > RING)) {
+            __builtin_amdgcn_s_sleep(1);
+            P = sh_prod;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int upto = P < seg_end ? P : seg_end;
+        int k = rs > cons ? rs : cons;
+        const int e_ = re < upto ? re : upto;
+        while (__any(k < e_)) {
+            T xv[GB];
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                I cc = ringc[(k + g) & MASK];
+                cc = (k + g < e_) ? cc : I(0);
+                xv[g] = (ABL & 1) ? T(cc) : b[cc];
+            }
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const T vv = ringv[(k + g) & MASK];
+                const T t = sum + vv * xv[g];
+                sum = (k + g < e_) ? t : sum;
+            }
+            k += GB;
+        }
+        cons = upto;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (lane == 0) sh_cons = cons;
+        if (cons >= seg_end) {
+            const int64_t row = seg * ROWS + lane;
+            if (lane < ROWS && row < n_rows) c[row] = sum;
+            ++seg;
+            rs = nrs;
+            re = nre;
+            seg_end = nseg_end;
+            if (seg + 1 < se) seg_rows(seg + 1, nrs, nre, nseg_end);
+            sum = T(0);
+        }
+    }
+}
+
+}  // namespace gkoc

@@ -356,19 +356,32 @@ int main(int argc, char** argv)
                " spw=" #SPW " abl=" #ABL, ms, bytes);                            \
         if (!(ABL & 3)) check("pipe3", true);                                    \
     }
+#define RUN_PAIR(ROWS, E, U, NSETS, RING, GB, SPW, ABL)                          \
+    {                                                                            \
+        const int64_t nsg = (n + ROWS - 1) / ROWS;                               \
+        const int64_t spw = SPW;                                                 \
+        const int64_t nw = (nsg + spw - 1) / spw;                                \
+        ms = T.ms(reps, [&] {                                                    \
+            csr_spmv_pair_kernel<double, int, ROWS, E, U, NSETS, RING, GB, ABL>  \
+                <<<dim3(unsigned(nw)), dim3(128)>>>(n, nsg, spw, row_ptrs, cols, \
+                                                    vals, x, y);                 \
+        });                                                                      \
+        report("pair rows=" #ROWS " E=" #E " U=" #U " sets=" #NSETS " ring=" #RING \
+               " gb=" #GB " spw=" #SPW " abl=" #ABL, ms, bytes);                 \
+        if (!(ABL & 3)) check("pair", true);                                     \
+    }
     for (int rep = 0; rep < 2; ++rep) {
-    RUN_PIPE(32, 4, 1, 1024, 2, 0)
     RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0)
-    RUN_PIPE3(32, 4, 1, 1024, 6, 2, 0)
-    RUN_PIPE3(32, 4, 1, 512, 8, 2, 0)
-    RUN_PIPE3(32, 4, 1, 512, 7, 2, 0)
-    RUN_PIPE3(32, 4, 1, 512, 6, 2, 0)
-    RUN_PIPE3(32, 2, 2, 512, 8, 2, 0)
-    RUN_PIPE3(32, 2, 1, 256, 8, 2, 0)
-    RUN_PIPE3(32, 4, 1, 512, 8, 4, 0)
-    RUN_PIPE3(32, 4, 1, 512, 8, 1, 0)
-    RUN_PIPE3(32, 4, 2, 1024, 4, 2, 0)
-    RUN_PIPE3(32, 4, 2, 1024, 5, 2, 0)
+    RUN_PAIR(64, 4, 1, 2, 4096, 28, 2, 0)
+    RUN_PAIR(64, 4, 1, 4, 4096, 28, 2, 0)
+    RUN_PAIR(64, 4, 1, 4, 4096, 28, 4, 0)
+    RUN_PAIR(64, 4, 1, 4, 4096, 14, 4, 0)
+    RUN_PAIR(64, 4, 1, 4, 2048, 28, 4, 0)
+    RUN_PAIR(32, 4, 1, 4, 2048, 28, 4, 0)
+    RUN_PAIR(32, 4, 1, 4, 2048, 28, 8, 0)
+    RUN_PAIR(32, 4, 1, 4, 1024, 28, 8, 0)
+    RUN_PAIR(64, 4, 2, 2, 4096, 28, 4, 0)
+    RUN_PAIR(64, 4, 1, 4, 4096, 28, 4, 1)
     }
     RUN_CLASSICAL(8)
     return 0;
