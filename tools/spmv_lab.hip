@@ -372,16 +372,39 @@ int main(int argc, char** argv)
     }
     for (int rep = 0; rep < 2; ++rep) {
     RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0)
-    RUN_PAIR(64, 4, 1, 2, 4096, 28, 2, 0)
-    RUN_PAIR(64, 4, 1, 4, 4096, 28, 2, 0)
-    RUN_PAIR(64, 4, 1, 4, 4096, 28, 4, 0)
-    RUN_PAIR(64, 4, 1, 4, 4096, 14, 4, 0)
     RUN_PAIR(64, 4, 1, 4, 2048, 28, 4, 0)
-    RUN_PAIR(32, 4, 1, 4, 2048, 28, 4, 0)
-    RUN_PAIR(32, 4, 1, 4, 2048, 28, 8, 0)
-    RUN_PAIR(32, 4, 1, 4, 1024, 28, 8, 0)
-    RUN_PAIR(64, 4, 2, 2, 4096, 28, 4, 0)
-    RUN_PAIR(64, 4, 1, 4, 4096, 28, 4, 1)
+    }
+    // ELL / SELL-P through the library entry points (formats built on device)
+    {
+        int64_t k = 0;
+        gkoc_compute_max_row_nnz_i32(nullptr, n, row_ptrs, &k);
+        int* ecols;
+        double* evals;
+        CK(hipMalloc(&ecols, sizeof(int) * k * n));
+        CK(hipMalloc(&evals, sizeof(double) * k * n));
+        gkoc_csr_convert_to_ell_f64_i32(nullptr, n, row_ptrs, cols, vals, k, n, ecols, evals);
+        ms = T.ms(reps, [&] { gkoc_ell_spmv_f64_i32(nullptr, n, n, k, n, ecols, evals, x, 1, y, 1, 1); });
+        report("ELL spmv (library), bytes = 12*k*n + 16n", ms, double(k) * n * 12 + 16.0 * n);
+        check("ell", true);
+        CK(hipFree(ecols));
+        CK(hipFree(evals));
+        const int64_t ns = (n + 63) / 64;
+        uint64_t *sets, *lens;
+        CK(hipMalloc(&sets, 8 * (ns + 1)));
+        CK(hipMalloc(&lens, 8 * ns));
+        gkoc_sellp_compute_slice_sets_i32(nullptr, n, 64, 1, row_ptrs, sets, lens);
+        uint64_t total = 0;
+        CK(hipMemcpy(&total, sets + ns, 8, hipMemcpyDeviceToHost));
+        int* scols;
+        double* svals;
+        CK(hipMalloc(&scols, sizeof(int) * total * 64));
+        CK(hipMalloc(&svals, sizeof(double) * total * 64));
+        gkoc_csr_convert_to_sellp_f64_i32(nullptr, n, 64, row_ptrs, cols, vals, sets, scols, svals);
+        ms = T.ms(reps, [&] {
+            gkoc_sellp_spmv_f64_i32(nullptr, n, n, 64, sets, lens, scols, svals, x, 1, y, 1, 1);
+        });
+        report("SELL-P spmv (library), bytes = 12*stored + 16n", ms, double(total) * 64 * 12 + 16.0 * n);
+        check("sellp", true);
     }
     RUN_CLASSICAL(8)
     return 0;
