@@ -56,7 +56,18 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     __shared__ __attribute__((aligned(16))) T ring[RING];
 
     const int lane = threadIdx.x;
-    const int64_t sb = int64_t(blockIdx.x) * segs_per_wave;
+    int64_t wave_id = blockIdx.x;
+    if (ABL >> 8) {
+        // measurement only: workgroup b runs on XCD b % 8; hand every XCD
+        // chunks of C consecutive waves instead of every 8th wave
+        constexpr int64_t C = int64_t(1) << ((ABL >> 8) & 15);
+        const int64_t nfull = (int64_t(gridDim.x) / (8 * C)) * (8 * C);
+        if (wave_id < nfull) {
+            const int64_t xcd = wave_id % 8, slot = wave_id / 8;
+            wave_id = ((slot / C) * 8 + xcd) * C + (slot % C);
+        }
+    }
+    const int64_t sb = wave_id * segs_per_wave;
     const int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
     if (sb >= se) return;
     const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;

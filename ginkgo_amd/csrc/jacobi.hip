@@ -359,6 +359,93 @@ __global__ __launch_bounds__(256) void jacobi_apply_kernel(
     }
 }
 
+// Fast path for the layout Ginkgo's compute_storage_scheme produces on a
+// 64-wide device: block_offset BO (power of two), BO << group_power == 64,
+// single right-hand side.  One wave handles GPW consecutive groups: per group
+// all BO matrix columns (coalesced 512 B / 256 B runs) and the lane's own b
+// value are requested before the first use; b[start + c] then comes from lane
+// (block, c) through ds_bpermute instead of BO more gathers.  Accumulation
+// order and rounding are those of the generic kernel (reference apply_block).
+template <typename T, typename I, bool ADV, int BO, int GPW>
+__global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
+    int64_t num_blocks, int64_t num_groups, int64_t group_offset,
+    const I* __restrict__ block_ptrs, const T* __restrict__ blocks,
+    const T* __restrict__ alpha_p, const T* __restrict__ b,
+    const T* __restrict__ beta_p, T* __restrict__ x)
+{
+    constexpr int LOG_BO = BO == 1 ? 0 : BO == 2 ? 1 : BO == 4 ? 2 : BO == 8 ? 3
+                         : BO == 16 ? 4 : BO == 32 ? 5 : 6;
+    constexpr int GP = 6 - LOG_BO;  // group_power
+    const int lane = threadIdx.x & 63;
+    const int r = lane & (BO - 1);
+    const int lane0 = lane - r;
+    const int64_t group0 =
+        (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * GPW;
+    T alpha = T(1), beta = T(0);
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    T m[GPW][BO];
+    T bv[GPW];
+    T xv[GPW];
+    int64_t row[GPW];
+    int bs[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int64_t group = group0 + g;
+        const int64_t blk = (group << GP) + (lane >> LOG_BO);
+        const bool have = group < num_groups && blk < num_blocks;
+        I start = 0, end = 0;
+        if (have) {
+            start = block_ptrs[blk];
+            end = block_ptrs[blk + 1];
+        }
+        bs[g] = have && r < int(end - start) ? int(end - start) : 0;
+        row[g] = int64_t(start) + r;
+    }
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const T* gp = blocks + group_offset * (group0 + g) + lane;
+        bv[g] = T(0);
+        xv[g] = T(0);
+        if (bs[g] > 0) {
+            bv[g] = b[row[g]];
+            if (ADV) xv[g] = x[row[g]];
+#pragma unroll
+            for (int c = 0; c < BO; ++c) m[g][c] = gp[c * 64];
+        } else {
+#pragma unroll
+            for (int c = 0; c < BO; ++c) m[g][c] = T(0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        T sum = T(0);
+        if (ADV && beta != T(0)) sum = xv[g] * beta;
+#pragma unroll
+        for (int c = 0; c < BO; ++c) {
+            const T bc = __shfl(bv[g], lane0 + c, 64);
+            const T t = ADV ? (alpha * m[g][c]) * bc : m[g][c] * bc;
+            sum = c < bs[g] ? sum + t : sum;
+        }
+        if (bs[g] > 0) x[row[g]] = sum;
+    }
+}
+
+template <typename T, typename I, bool ADV, int BO>
+void launch_apply_fixed(gkoc_stream_t s, int64_t num_blocks, int64_t groups,
+                        int64_t group_offset, const I* block_ptrs,
+                        const T* blocks, const T* alpha, const T* b,
+                        const T* beta, T* x)
+{
+    constexpr int GPW = (BO * sizeof(T) >= 128) ? 1 : 2;
+    jacobi_apply_fixed_kernel<T, I, ADV, BO, GPW>
+        <<<dim3(unsigned(ceildiv(groups, 4 * GPW))), dim3(256), 0,
+           as_stream(s)>>>(num_blocks, groups, group_offset, block_ptrs, blocks,
+                           alpha, b, beta, x);
+}
+
 template <typename T, typename I, bool ADV>
 int launch_apply(gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
                  gkoc_jacobi_scheme scheme, const I* block_ptrs,
@@ -374,6 +461,24 @@ int launch_apply(gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
                  "max_block_size exceeds block_offset");
     const int64_t gsize = int64_t(1) << scheme.group_power;
     const int64_t groups = ceildiv(num_blocks, gsize);
+    const int64_t bo = scheme.block_offset;
+    if (nrhs == 1 && ldb == 1 && ldx == 1 && (bo << scheme.group_power) == 64 &&
+        bo <= 16) {
+        const int64_t go = scheme.group_offset;
+#define GKOC_JAC_FIXED(BO)                                                     \
+    launch_apply_fixed<T, I, ADV, BO>(s, num_blocks, groups, go, block_ptrs,   \
+                                      blocks, alpha, b, beta, x)
+        switch (int(bo)) {
+        case 1: GKOC_JAC_FIXED(1); break;
+        case 2: GKOC_JAC_FIXED(2); break;
+        case 4: GKOC_JAC_FIXED(4); break;
+        case 8: GKOC_JAC_FIXED(8); break;
+        default: GKOC_JAC_FIXED(16); break;
+        }
+#undef GKOC_JAC_FIXED
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     jacobi_apply_kernel<T, I, ADV>
         <<<dim3(unsigned(ceildiv(groups, 4))), dim3(256), 0, as_stream(s)>>>(
             num_blocks, groups, scheme, block_ptrs, blocks, alpha, b, ldb, beta,

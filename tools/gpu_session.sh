@@ -10,6 +10,7 @@ for S in $STEPS; do
 case $S in
 info)
   echo "== rocminfo"; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|gfx9" | head -6
+  rocm-smi --showmemorypartition --showcomputepartition 2>/dev/null | grep -i "partition" | head -4
   echo "== nproc: $(nproc)"; grep -m1 "model name" /proc/cpuinfo ;;
 pytest)
   echo "== pytest -m gpu"

@@ -324,6 +324,9 @@ int main(int argc, char** argv)
     if (false) {
     pmc_runs:
         RUN_PIPE(32, 4, 1, 1024, 2, 0)
+        RUN_PIPE(32, 4, 1, 1024, 2, 4)
+        RUN_PIPE(32, 4, 1, 1024, 2, 8)
+        RUN_PIPE(32, 4, 1, 1024, 2, 12)
         return 0;
     }
 #define RUN_PIPE2(ROWS, E, U, RING, GB, SPW, ABL)                                \
@@ -354,7 +357,7 @@ int main(int argc, char** argv)
         });                                                                      \
         report("pipe3 rows=" #ROWS " E=" #E " U=" #U " ring=" #RING " wps=" #WPS \
                " spw=" #SPW " abl=" #ABL, ms, bytes);                            \
-        if (!(ABL & 3)) check("pipe3", true);                                    \
+        if (!((ABL) & 3)) check("pipe3", true);                                    \
     }
 #define RUN_PAIR(ROWS, E, U, NSETS, RING, GB, SPW, ABL)                          \
     {                                                                            \
@@ -372,7 +375,16 @@ int main(int argc, char** argv)
     }
     for (int rep = 0; rep < 2; ++rep) {
     RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0)
-    RUN_PAIR(64, 4, 1, 4, 2048, 28, 4, 0)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x100)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x200)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x300)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x400)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x500)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x600)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x700)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x800)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x900)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0xa00)
     }
     // ELL / SELL-P through the library entry points (formats built on device)
     {
