@@ -156,12 +156,16 @@ int launch_residual_norm(gkoc_stream_t s, int64_t cols, const T* tau,
                          int set_finalized, uint8_t* stop, uint8_t* flags,
                          int* all_converged, int* one_changed)
 {
-    GKOC_REQUIRE(all_converged && one_changed, GKOC_E_INVALID, "null result");
+    GKOC_REQUIRE((all_converged == nullptr) == (one_changed == nullptr),
+                 GKOC_E_INVALID, "pass both host results or neither");
     GKOC_REQUIRE(cols >= 0, GKOC_E_INVALID, "negative dimension");
     GKOC_REQUIRE(flags, GKOC_E_INVALID, "null flag storage");
     residual_norm_kernel<T, IMPLICIT><<<dim3(1), dim3(256), 0, as_stream(s)>>>(
         cols, tau, orig_tau, goal, id, set_finalized != 0, stop, flags);
     GKOC_LAUNCH_OK();
+    // asynchronous form: results stay in flags[0..1] on the device and the
+    // caller fetches them when it wants to (no host sync here)
+    if (!all_converged) return GKOC_OK;
     uint8_t host[2];
     GKOC_HIP(hipMemcpyAsync(host, flags, 2, hipMemcpyDeviceToHost, as_stream(s)));
     GKOC_HIP(hipStreamSynchronize(as_stream(s)));

@@ -217,6 +217,37 @@ class HipBackend:
     def stop_flags(self):
         return self.exec.zeros((2,), torch.uint8), self.exec.zeros((1,), torch.uint8)
 
+    def scalar_pair(self, dtype=torch.float64):
+        """two adjacent device scalars: (2-element tensor, view of [0], view of [1])"""
+        t = self.exec.zeros((2,), dtype)
+        return t, Dense(self.exec, t[0:1].view(1, 1)), Dense(self.exec, t[1:2].view(1, 1))
+
+    # asynchronous criterion check: the kernel and a 2-byte copy into pinned
+    # memory are enqueued, the host looks at the answer when the event is done
+    _NSLOT = 16
+
+    def check_begin(self, tau, tau0, factor, stop):
+        if not hasattr(self, "_chk_dev"):
+            self._chk_dev = self.exec.zeros((self._NSLOT, 2), torch.uint8)
+            self._chk_host = torch.zeros((self._NSLOT, 2), dtype=torch.uint8).pin_memory()
+            self._chk_next = 0
+        slot = self._chk_next
+        self._chk_next = (slot + 1) % self._NSLOT
+        call("gkoc_residual_norm_" + VT[tau.dtype], self.exec.stream, 1, tau.values, tau0.values,
+             C.c_double(factor) if tau.dtype == torch.float64 else C.c_float(factor),
+             C.c_uint8(2), C.c_int(1), stop, self._chk_dev[slot], None, None)
+        self._chk_host[slot].copy_(self._chk_dev[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return slot, ev
+
+    def check_done(self, token, block=True):
+        slot, ev = token
+        ev.synchronize()
+        return bool(self._chk_host[slot, 0].item())
+
+    max_check_lag = 6       # must stay below _NSLOT
+
     def residual_check(self, tau, tau0, factor, stop, flags):
         allc, chg = C.c_int(0), C.c_int(0)
         call("gkoc_residual_norm_" + VT[tau.dtype], self.exec.stream, 1, tau.values, tau0.values,
@@ -292,20 +323,33 @@ class DistributedMatrix:
 
 class DistributedCg:
     """Cg::apply_dense_impl (core/solver/cg.cpp:93-181) on distributed vectors:
-    every dot / norm is the local kernel + an all-reduce of one value that stays
-    on the device (distributed/vector.cpp:473-592)."""
+    every dot / norm is the local kernel + an all-reduce of values that stay on
+    the device (distributed/vector.cpp:473-592).
+
+    Two latency measures for strong scaling, neither changes a result:
+    * rho = <r,z> and ||r||^2 are reduced in ONE all-reduce of two values (the
+      reference issues two);
+    * the criterion check is asynchronous: its kernel marks stop_status on the
+      device, cg::step_1/step_2 are masked by stop_status (cg_kernels.hpp), so
+      the host enqueues `check_lag` further iterations before it reads the
+      answer of iteration k (always exactly that many, on every rank) - they
+      leave x, r, p untouched once the column has stopped.
+      check_lag = 0 is the reference's lock-step behaviour."""
 
     def __init__(self, backend, comm, matrix, max_iters, reduction_factor=1e-10,
-                 max_block_size=8):
+                 max_block_size=8, check_lag=None):
         self.be, self.comm, self.a = backend, comm, matrix
         self.max_iters, self.factor = int(max_iters), float(reduction_factor)
         self.m = backend.jacobi(matrix.local, max_block_size) if max_block_size else None
         self.num_iterations = 0
         self.residual_norm = None
+        self.check_lag = backend.max_check_lag if check_lag is None else int(check_lag)
         n, dt = matrix.n_local, matrix.dtype
         self.r, self.z, self.p, self.q = (backend.vector(n, dt) for _ in range(4))
-        self.beta, self.prev_rho, self.rho, self.tau, self.tau0 = (
-            backend.vector(1, dt) for _ in range(5))
+        self.beta, self.tau0 = backend.vector(1, dt), backend.vector(1, dt)
+        # [rho, ||r||^2] pairs; the two pairs swap roles as rho / prev_rho
+        self.pair_a = backend.scalar_pair(dt)
+        self.pair_b = backend.scalar_pair(dt)
         self.flags, self.stop = backend.stop_flags()
 
     def _dot(self, x, y, out):
@@ -317,34 +361,57 @@ class DistributedCg:
         self.comm.all_reduce_sum_(out.values.view(-1))
         self.be.sqrt_(out)
 
+    def _drain(self, pending, upto):
+        """read (blocking) the checks of iterations <= upto, oldest first; the
+        iteration that stopped, or None.  Which checks are read depends only on
+        the iteration number, never on timing, so every rank leaves the loop in
+        the same iteration and no collective is left unmatched."""
+        while pending and pending[0][0] <= upto:
+            it, token = pending.popleft()
+            if self.be.check_done(token, True):
+                return it
+        return None
+
     def apply(self, b, x):
+        from collections import deque
         be, a = self.be, self.a
         r, z, p, q = self.r, self.z, self.p, self.q
-        beta, prev_rho, rho = self.beta, self.prev_rho, self.rho
-        be.cg_initialize(b, r, z, p, q, prev_rho, rho, self.stop)
+        beta = self.beta
+        cur, prev = self.pair_a, self.pair_b
+        be.cg_initialize(b, r, z, p, q, prev[1], cur[1], self.stop)
         a.apply(x, q)                          # r = b - A x
         neg = be.scalar(-1.0, b.dtype)
         r.add_scaled(neg, q)
         q.fill(0.0)
         self._norm2(b, self.tau0)              # ResidualNorm(rhs_norm) baseline
+        pending = deque()
         it = -1
         while True:
             if self.m is not None:
                 self.m.apply(r, z)
             else:
                 z.copy_from(r)
-            self._dot(r, z, rho)
+            pair, rho, tau = cur
+            be.local_dot(r, z, rho)
+            be.local_sqnorm(r, tau)
+            self.comm.all_reduce_sum_(pair)    # one message: [<r,z>, ||r||^2]
             it += 1
             if it >= self.max_iters:
+                stopped = self._drain(pending, it)
+                if stopped is not None:
+                    it = stopped
                 break
-            self._norm2(r, self.tau)
-            if be.residual_check(self.tau, self.tau0, self.factor, self.stop, self.flags):
+            be.sqrt_(tau)
+            pending.append((it, be.check_begin(tau, self.tau0, self.factor, self.stop)))
+            stopped = self._drain(pending, it - self.check_lag)
+            if stopped is not None:
+                it = stopped
                 break
-            be.cg_step_1(p, z, rho, prev_rho, self.stop)
+            be.cg_step_1(p, z, rho, prev[1], self.stop)
             a.apply(p, q)
             self._dot(p, q, beta)
             be.cg_step_2(x, r, p, q, beta, rho, self.stop)
-            prev_rho, rho = rho, prev_rho
+            cur, prev = prev, cur
         self.num_iterations = it
         return x
 
@@ -387,19 +454,24 @@ class DistributedStencil:
     def apply(self, x, y):
         return self.matrix.apply(x, y)
 
-    def timed_cg(self, iters, barrier):
+    def prepare_cg(self, iters, barrier):
+        """set-up + one warm-up solve; returns the set-up time"""
         import time
         t0 = time.perf_counter()
-        solver = DistributedCg(self.backend, self.comm, self.matrix, iters, 1e-30, 8)
+        self._cg = DistributedCg(self.backend, self.comm, self.matrix, iters, 1e-30, 8)
         barrier()
         t_setup = time.perf_counter() - t0
-        rhs = Dense.create(self.exec, (self.n_local, 1)).fill(1.0)
-        x = self.zeros_vector()
-        solver.apply(rhs, x)
+        self._rhs = Dense.create(self.exec, (self.n_local, 1)).fill(1.0)
+        self._sol = self.zeros_vector()
+        self._cg.apply(self._rhs, self._sol)
         barrier()
-        x.fill(0.0)
+        return t_setup
+
+    def timed_cg(self, barrier):
+        import time
+        self._sol.fill(0.0)
         barrier()
         t1 = time.perf_counter()
-        solver.apply(rhs, x)
+        self._cg.apply(self._rhs, self._sol)
         barrier()
-        return solver.num_iterations, time.perf_counter() - t1, t_setup
+        return self._cg.num_iterations, time.perf_counter() - t1

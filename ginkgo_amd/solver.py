@@ -9,6 +9,8 @@ semantics.  Every step is a libgko_cdna4.so kernel; the host only drives.
 """
 import ctypes as C
 
+from collections import deque
+
 import torch
 
 from ._lib import DimensionMismatch, NotSupported, VT, call
@@ -148,16 +150,31 @@ class Cg(_IterativeSolver):
         # r = b - A x
         a.apply(neg_one, x, one, r)
         crit = _stop.combine(self.criteria, a, b, x, r)
+        # The criterion is evaluated every iteration as in cg.cpp:133-141, but
+        # its answer is read `check_lag` iterations later: the kernel marks
+        # stop_status on the device and step_1 / step_2 skip stopped columns, so
+        # the iterations enqueued in between leave x, r, p as they were at the
+        # stopping iteration.  with_check_lag(0) = lock-step like the reference.
+        lag = int(self.params.get("check_lag", 4))
+        pending = deque()
         it = -1
         while True:
             m.apply(r, z)
             r.compute_conj_dot(z, rho)
             it += 1
-            all_stopped, _ = crit.check(
+            tokens, decided = crit.check_begin(
                 1, True, stop_status,
                 {"num_iterations": it, "residual": r,
                  "implicit_sq_residual_norm": rho, "solution": x})
-            if all_stopped:
+            pending.append((it, tokens))
+            stopped = None
+            while pending and (decided or pending[0][0] <= it - lag):
+                pit, ptok = pending.popleft()
+                if crit.check_done(ptok)[0]:
+                    stopped = pit
+                    break
+            if stopped is not None:
+                it = stopped
                 break
             call("gkoc_cg_step_1_" + suf, ex.stream, rows, cols, p.values, p.ld,
                  z.values, z.ld, rho.values, prev_rho.values, stop_status)

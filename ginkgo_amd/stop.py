@@ -57,6 +57,13 @@ class Iteration:
                  C.c_int(int(set_finalized)), stop_status)
         return hit, hit
 
+    # deferred protocol (see Combined.check_begin): decided on the host at once
+    def check_begin(self, stopping_id, set_finalized, stop_status, upd):
+        return self.check(stopping_id, set_finalized, stop_status, upd)
+
+    def check_done(self, token):
+        return token
+
 
 class ResidualNorm:
     """core/stop/residual_norm.cpp:75-205"""
@@ -86,8 +93,7 @@ class ResidualNorm:
         self.u_dense_tau = Dense.create(ex, (1, cols), b.dtype)
         self.flags = ex.zeros((2,), torch.uint8)
 
-    def check(self, stopping_id, set_finalized, stop_status, upd):
-        ex = self.exec
+    def _select(self, upd):
         if self.implicit:
             tau = upd.get("implicit_sq_residual_norm")
             if tau is None:
@@ -102,13 +108,45 @@ class ResidualNorm:
             else:
                 raise NotSupported("ResidualNorm needs a residual")
             name = "gkoc_residual_norm_"
+        self.last_tau = tau
+        return name, tau
+
+    def check(self, stopping_id, set_finalized, stop_status, upd):
+        name, tau = self._select(upd)
         allc, chg = C.c_int(0), C.c_int(0)
-        call(name + VT[tau.dtype], ex.stream, tau.size[1], tau.values,
+        call(name + VT[tau.dtype], self.exec.stream, tau.size[1], tau.values,
              self.starting_tau.values, cval(tau.dtype, self.reduction_factor),
              C.c_uint8(stopping_id), C.c_int(int(set_finalized)), stop_status,
              self.flags, C.byref(allc), C.byref(chg))
-        self.last_tau = tau
         return bool(allc.value), bool(chg.value)
+
+    _NSLOT = 16
+
+    def check_begin(self, stopping_id, set_finalized, stop_status, upd):
+        """enqueue the criterion kernel and a 2-byte copy of its flags into
+        pinned host memory; nothing waits (gkoc_residual_norm_*, NULL host
+        results).  check_done(token) blocks on exactly that copy."""
+        name, tau = self._select(upd)
+        if not hasattr(self, "_ring_dev"):
+            self._ring_dev = self.exec.zeros((self._NSLOT, 2), torch.uint8)
+            self._ring_host = torch.zeros((self._NSLOT, 2), dtype=torch.uint8).pin_memory()
+            self._ring_next = 0
+        slot = self._ring_next
+        self._ring_next = (slot + 1) % self._NSLOT
+        call(name + VT[tau.dtype], self.exec.stream, tau.size[1], tau.values,
+             self.starting_tau.values, cval(tau.dtype, self.reduction_factor),
+             C.c_uint8(stopping_id), C.c_int(int(set_finalized)), stop_status,
+             self._ring_dev[slot], None, None)
+        self._ring_host[slot].copy_(self._ring_dev[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return slot, ev
+
+    def check_done(self, token):
+        slot, ev = token
+        ev.synchronize()
+        h = self._ring_host[slot]
+        return bool(h[0].item()), bool(h[1].item())
 
 
 class ImplicitResidualNorm(ResidualNorm):
@@ -131,6 +169,28 @@ class Combined:
         one_changed = False
         for i, c in enumerate(self.criteria):
             conv, chg = c.check(i + 1, set_finalized, stop_status, upd)
+            one_changed |= chg
+            if conv:
+                return True, one_changed
+        return False, one_changed
+
+    def check_begin(self, stopping_id, set_finalized, stop_status, upd):
+        """deferred form of check(): (tokens, decided).  Host-side criteria
+        (Iteration) answer at once; `decided` is True when one of them stopped
+        the solver, in which case later criteria are not evaluated (as in
+        check()).  Device-side criteria only enqueue work."""
+        tokens = []
+        for i, c in enumerate(self.criteria):
+            tok = c.check_begin(i + 1, set_finalized, stop_status, upd)
+            tokens.append((c, tok))
+            if isinstance(c, Iteration) and tok[0]:
+                return tokens, True
+        return tokens, False
+
+    def check_done(self, tokens):
+        one_changed = False
+        for c, tok in tokens:
+            conv, chg = c.check_done(tok)
             one_changed |= chg
             if conv:
                 return True, one_changed

@@ -363,7 +363,12 @@ GKOC_DECL_GMRES(float, f32)
  * core/stop/criterion_kernels.hpp; reference/stop/residual_norm_kernels.cpp:27-90).
  * flags_dev: 2 device bytes of scratch (Ginkgo's array<bool> device_storage);
  * *all_converged / *one_changed are HOST bools written after a stream sync
- * (this is the solver's one host sync point per iteration). */
+ * (this is the solver's one host sync point per iteration).  Passing NULL for
+ * BOTH host pointers selects the asynchronous form: the kernel is enqueued,
+ * flags_dev[0] = all_converged and flags_dev[1] = one_changed stay on the
+ * device and nothing is synchronised (the caller copies them when it wants
+ * to; the step kernels are masked by stop_status, so running ahead of the
+ * check does not change the result). */
 #define GKOC_DECL_STOP(T, TN)                                                  \
     int gkoc_residual_norm_##TN(gkoc_stream_t s, int64_t cols, const T* tau,   \
                                 const T* orig_tau, T rel_residual_goal,        \

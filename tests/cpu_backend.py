@@ -140,6 +140,24 @@ class OracleBackend:
     def stop_flags(self):
         return torch.zeros(2, dtype=torch.uint8), torch.zeros(1, dtype=torch.uint8)
 
+    max_check_lag = 3
+
+    def scalar_pair(self, dtype=torch.float64):
+        t = torch.zeros(2, dtype=torch.float64)
+        views = []
+        for k in (0, 1):
+            v = CpuVec.__new__(CpuVec)
+            v.values = t[k:k + 1].view(1, 1)
+            v.size, v.dtype, v.ld = (1, 1), torch.float64, 1
+            views.append(v)
+        return t, views[0], views[1]
+
+    def check_begin(self, tau, tau0, factor, stop):
+        return self.residual_check(tau, tau0, factor, stop, None)
+
+    def check_done(self, token, block):
+        return bool(token)
+
     def residual_check(self, tau, tau0, factor, stop, flags):
         allc, chg, st = o.residual_norm(tau.np().copy(), tau0.np().copy(), factor, 2, True,
                                         stop.numpy().copy())

@@ -63,6 +63,13 @@ def main():
     assert abs(solver.num_iterations - iters) <= 1, (solver.num_iterations, iters)
     e = np.linalg.norm(xs.to_numpy()[:, 0] - xo[lo:hi]) / np.linalg.norm(xo[lo:hi])
     assert e < 1e-8, f"rank {rank}: cg err {e}"
+    # --- the asynchronous criterion check (masked run-ahead) must not change anything
+    solver0 = gd.DistributedCg(be, comm, a, 500, 1e-10, 8, check_lag=0)
+    xs0 = be.vector(hi - lo)
+    solver0.apply(be.vector_from(np.ones(hi - lo)), xs0)
+    assert solver.check_lag > 0
+    assert solver0.num_iterations == solver.num_iterations
+    assert np.array_equal(xs0.to_numpy(), xs.to_numpy())
     dist.barrier()
     if rank == 0:
         print(f"dist_worker OK mode={mode} world={world} grid={grid} iters={solver.num_iterations}")

@@ -75,6 +75,7 @@ def test_distributed_single_rank_matches_plain(gexec, oracle):
     op.apply(x, y)
     xg = np.random.default_rng(42).uniform(-1, 1, grid ** 3)
     assert np.array_equal(y.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v, xg))
-    iters, t, _ = op.timed_cg(5, lambda: gexec.synchronize())
+    op.prepare_cg(5, lambda: gexec.synchronize())
+    iters, t = op.timed_cg(lambda: gexec.synchronize())
     assert iters == 5
     dist.destroy_process_group()

@@ -405,3 +405,60 @@ def test_cg_multiple_rhs(gexec, oracle):
     A = sp.csr_matrix((v, ci, rp), shape=(n, n))
     for j in range(3):
         assert np.linalg.norm(B[:, j] - A @ X[:, j]) <= 1.01e-10 * np.linalg.norm(B[:, j])
+
+
+def test_stop_kernel_async_form(gexec, oracle):
+    """NULL host results: flags stay on the device, nothing is synchronised"""
+    from ginkgo_amd._lib import call, GkoError
+    import ctypes as C
+    ex = gexec
+    cols = 300
+    rng = np.random.default_rng(8)
+    tau, orig = rng.uniform(0, 2, cols), rng.uniform(0.5, 1.5, cols)
+    stop = np.zeros(cols, np.uint8)
+    d_stop = ex.to_device(stop)
+    flags = ex.zeros((2,), torch.uint8)
+    call("gkoc_residual_norm_f64", ex.stream, cols, ex.to_device(tau), ex.to_device(orig),
+         C.c_double(0.9), C.c_uint8(2), C.c_int(1), d_stop, flags, None, None)
+    ra, rc, rs = oracle.residual_norm(tau, orig, 0.9, 2, True, stop, False)
+    assert flags.cpu().numpy().tolist() == [int(ra), int(rc)]
+    assert np.array_equal(d_stop.cpu().numpy(), rs)
+    allc = C.c_int(0)
+    with pytest.raises(GkoError):   # one host pointer without the other
+        call("gkoc_residual_norm_f64", ex.stream, cols, ex.to_device(tau), ex.to_device(orig),
+             C.c_double(0.9), C.c_uint8(2), C.c_int(1), d_stop, flags, C.byref(allc), None)
+
+
+@pytest.mark.parametrize("bs", [None, 8])
+def test_cg_deferred_check_changes_nothing(gexec, bs):
+    """reading the criterion `check_lag` iterations late (the step kernels are
+    masked by stop_status) gives bit-identical x, iteration count and status"""
+    import ginkgo_amd as g
+    grid = 24
+    n = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    rhs = np.random.default_rng(11).uniform(-1, 1, (n, 2))
+    res = []
+    for lag in (0, 1, 4, 7):
+        f = (g.Cg.build().with_check_lag(lag).with_criteria(
+            g.stop.ResidualNorm.build().with_reduction_factor(1e-9),
+            g.stop.Iteration.build().with_max_iters(300)))
+        if bs:
+            f = f.with_preconditioner(g.Jacobi.build().with_max_block_size(bs))
+        s = f.on(gexec).generate(a)
+        x = g.Dense.from_numpy(gexec, np.zeros((n, 2)))
+        s.apply(g.Dense.from_numpy(gexec, rhs), x)
+        res.append((s.num_iterations, s.has_converged, x.to_numpy(), s.stop_status.cpu().numpy()))
+    assert res[0][1]
+    for r in res[1:]:
+        assert r[0] == res[0][0] and r[1] == res[0][1]
+        assert np.array_equal(r[2], res[0][2]) and np.array_equal(r[3], res[0][3])
+    # iteration limit hit while checks are still pending
+    for lag in (0, 4):
+        f = (g.Cg.build().with_check_lag(lag).with_criteria(
+            g.stop.Iteration.build().with_max_iters(5),
+            g.stop.ResidualNorm.build().with_reduction_factor(1e-30)))
+        s = f.on(gexec).generate(a)
+        x = g.Dense.from_numpy(gexec, np.zeros((n, 2)))
+        s.apply(g.Dense.from_numpy(gexec, rhs), x)
+        assert s.num_iterations == 5 and not s.has_converged

@@ -68,6 +68,35 @@ __global__ __launch_bounds__(256) void copy16_kernel(int64_t n16,
     }
 }
 
+// every wave streams its own contiguous 1728-nonzero range (the access pattern
+// of the row-segment kernels) with all of its loads in flight at once
+template <int NPW>
+__global__ __launch_bounds__(64) void stream_private_kernel(
+    int64_t nnz, const double* __restrict__ vals, const int* __restrict__ cols,
+    double* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int64_t base = int64_t(blockIdx.x) * NPW;
+    constexpr int IT = (NPW + 255) / 256;
+    double2 v0[IT], v1[IT];
+    int4 c[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int64_t k = base + i * 256 + lane * 4;
+        const bool in = i * 256 + lane * 4 < NPW && k + 4 <= nnz;
+        const int64_t kk = in ? k : base;
+        v0[i] = *reinterpret_cast<const double2*>(vals + kk);
+        v1[i] = *reinterpret_cast<const double2*>(vals + kk + 2);
+        c[i] = *reinterpret_cast<const int4*>(cols + kk);
+    }
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        acc += v0[i].x + v0[i].y + v1[i].x + v1[i].y + double(c[i].x + c[i].y + c[i].z + c[i].w);
+    }
+    if (acc == 12345.678) out[0] = acc;
+}
+
 // ------------------------------------------------- classical (Ginkgo-like)
 // SUB lanes per row, shuffle reduction (common/cuda_hip csr classical idea)
 template <int SUB>
@@ -245,6 +274,18 @@ int main(int argc, char** argv)
             stream_read_kernel<<<8192, 256>>>(nnz, vals, cols, y);
         });
         report("ceiling: read val+col, 8B+4B, 8192 blocks", ms, double(nnz) * 12);
+        ms = T.ms(reps, [&] {
+            stream_private_kernel<1728><<<unsigned(nnz / 1728), 64>>>(nnz, vals, cols, y);
+        });
+        report("ceiling: per-wave private 1728-nnz ranges", ms, double(nnz) * 12);
+        ms = T.ms(reps, [&] {
+            stream_private_kernel<864><<<unsigned(nnz / 864), 64>>>(nnz, vals, cols, y);
+        });
+        report("ceiling: per-wave private 864-nnz ranges", ms, double(nnz) * 12);
+        ms = T.ms(reps, [&] {
+            stream_private_kernel<3456><<<unsigned(nnz / 3456), 64>>>(nnz, vals, cols, y);
+        });
+        report("ceiling: per-wave private 3456-nnz ranges", ms, double(nnz) * 12);
         const int64_t c16 = nnz / 4;  // copy half of vals into the other half
         ms = T.ms(reps, [&] {
             copy16_kernel<<<2048, 256>>>(c16, (const double2*)vals,
