@@ -50,6 +50,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.gkoc_last_error.restype = C.c_char_p
         _lib.gkoc_reduction_workspace_bytes.restype = C.c_size_t
+        _lib.gkoc_x_workspace_bytes.restype = C.c_size_t
     return _lib
 
 

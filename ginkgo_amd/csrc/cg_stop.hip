@@ -22,6 +22,7 @@
 
 #include "common.hpp"
 #include "elementwise.hpp"
+#include "fused.hpp"
 
 namespace gkoc {
 namespace {
@@ -102,6 +103,89 @@ struct op_cg_step2 {
         out[1] = in[1] - s.tmp * in[3];
     }
 };
+
+// ---------------------------------------------------- step_2 + ||r||_2 fused
+// one column, unit strides: x += t p, r -= t q (t = rho / beta, the masks of
+// op_cg_step2) and, from the registers that hold the new r, this block's part
+// of sum r^2.  x and r are bit-identical to cg::step_2.
+template <typename T>
+__global__ __launch_bounds__(256) void cg_step2_norm_kernel(
+    int64_t n, T* __restrict__ x, T* __restrict__ r, const T* __restrict__ p,
+    const T* __restrict__ q, const T* __restrict__ beta,
+    const T* __restrict__ rho, const uint8_t* __restrict__ stop,
+    T* __restrict__ partial, bool vec_ok)
+{
+    __shared__ T lds[4];
+    using V = vec16<T>;
+    constexpr int W = V::width;
+    const T bt = beta[0];
+    const bool noop = bt == T(0) || status_has_stopped(stop[0]);
+    const T tmp = noop ? T(0) : rho[0] / bt;
+    T acc = T(0);
+    const int64_t tid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t nthreads = int64_t(gridDim.x) * 256;
+    int64_t done = 0;
+    if (vec_ok) {
+        const int64_t n_vec = n / W;
+        for (int64_t i = tid; i < n_vec; i += nthreads) {
+            V rv = reinterpret_cast<const V*>(r)[i];
+            if (!noop) {
+                V xv = reinterpret_cast<const V*>(x)[i];
+                const V pv = reinterpret_cast<const V*>(p)[i];
+                const V qv = reinterpret_cast<const V*>(q)[i];
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    xv.v[e] = xv.v[e] + tmp * pv.v[e];
+                    rv.v[e] = rv.v[e] - tmp * qv.v[e];
+                }
+                reinterpret_cast<V*>(x)[i] = xv;
+                reinterpret_cast<V*>(r)[i] = rv;
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) acc += rv.v[e] * rv.v[e];
+        }
+        done = n_vec * W;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) {
+        T rv = r[i];
+        if (!noop) {
+            x[i] = x[i] + tmp * p[i];
+            rv = rv - tmp * q[i];
+            r[i] = rv;
+        }
+        acc += rv * rv;
+    }
+    const T s = block_sum<256>(acc, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+template <typename T>
+int launch_step2_norm(gkoc_stream_t s, int64_t n, T* x, T* r, const T* p,
+                      const T* q, const T* beta, const T* rho,
+                      const uint8_t* stop, T* norm_out, int take_sqrt,
+                      void* work, size_t work_bytes)
+{
+    GKOC_REQUIRE(n >= 0, GKOC_E_INVALID, "negative dimension");
+    GKOC_REQUIRE(norm_out, GKOC_E_INVALID, "null result");
+    if (n == 0) {
+        GKOC_HIP(hipMemsetAsync(norm_out, 0, sizeof(T), as_stream(s)));
+        return GKOC_OK;
+    }
+    GKOC_REQUIRE(x && r && p && q && beta && rho && stop && work, GKOC_E_INVALID,
+                 "null pointer");
+    GKOC_REQUIRE(work_bytes >= fused_workspace_bytes(n, sizeof(T)), GKOC_E_WORKSPACE,
+                 "workspace too small (gkoc_x_workspace_bytes)");
+    T* partial = static_cast<T*>(work);
+    T* scratch = partial + (fused_workspace_bytes(n, sizeof(T)) / sizeof(T) - fold_chunks);
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(r) |
+                         reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q)) % 16 == 0;
+    int64_t nb = ceildiv(n, int64_t(256) * vec16<T>::width * 2);
+    if (nb > 2048) nb = 2048;
+    cg_step2_norm_kernel<T><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(
+        n, x, r, p, q, beta, rho, stop, partial, vec_ok);
+    GKOC_LAUNCH_OK();
+    return fold_partials<T>(s, nb, partial, scratch, norm_out, take_sqrt != 0);
+}
 
 // ------------------------------------------------------------------ stop
 // flags[0] = all_converged, flags[1] = one_changed
@@ -283,6 +367,15 @@ using namespace gkoc;
         a.ld_out[1] = ldr;                                                     \
         return launch_elementwise<T, op_cg_step2<T>, 4, 2>(                    \
             s, rows, cols, a, op_cg_step2<T>{beta, rho, stop_status}, false);  \
+    }                                                                          \
+    extern "C" int gkoc_x_cg_step_2_norm_##TN(                                 \
+        gkoc_stream_t s, int64_t rows, T* x, T* r, const T* p, const T* q,     \
+        const T* beta, const T* rho, const uint8_t* stop_status, T* norm_out,  \
+        int take_sqrt, void* work, size_t work_bytes)                          \
+    {                                                                          \
+        return launch_step2_norm<T>(s, rows, x, r, p, q, beta, rho,            \
+                                    stop_status, norm_out, take_sqrt, work,    \
+                                    work_bytes);                               \
     }                                                                          \
     extern "C" int gkoc_residual_norm_##TN(                                    \
         gkoc_stream_t s, int64_t cols, const T* tau, const T* orig_tau,        \

@@ -22,6 +22,7 @@
 //                        + n_cols*sizeof(T) (b once) + n*sizeof(T) (c).
 #include "common.hpp"
 #include "csr_spmv_pipe.hpp"
+#include "fused.hpp"
 
 namespace gkoc {
 namespace {
@@ -66,6 +67,50 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     }
     GKOC_LAUNCH_OK();
     return GKOC_OK;
+}
+
+// c = A b and dot_out = <b, c> in one pass over the matrix (square A, one
+// right-hand side, unit strides): every wave also emits its part of the dot
+// product, a fixed two-level fold adds them up
+template <typename T, typename I>
+int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
+                   const I* col_idxs, const T* vals, const T* b, T* c,
+                   T* dot_out, void* work, size_t work_bytes)
+{
+    GKOC_REQUIRE(n >= 0, GKOC_E_INVALID, "negative dimension");
+    GKOC_REQUIRE(dot_out, GKOC_E_INVALID, "null result");
+    if (n == 0) {
+        GKOC_HIP(hipMemsetAsync(dot_out, 0, sizeof(T), as_stream(s)));
+        return GKOC_OK;
+    }
+    GKOC_REQUIRE(row_ptrs && b && c && work, GKOC_E_INVALID, "null pointer");
+    GKOC_REQUIRE(work_bytes >= fused_workspace_bytes(n, sizeof(T)), GKOC_E_WORKSPACE,
+                 "workspace too small (gkoc_x_workspace_bytes)");
+    constexpr int rows_per_seg = 32;
+    constexpr int segs_per_wave = 2;
+    const int64_t n_seg = ceildiv(n, rows_per_seg);
+    const int64_t n_waves = ceildiv(n_seg, segs_per_wave);
+    GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED,
+                 "more than 2^31 row segments");
+    T* partial = static_cast<T*>(work);
+    T* scratch = partial + (fused_workspace_bytes(n, sizeof(T)) / sizeof(T) - fold_chunks);
+    dim3 grid(static_cast<unsigned>(n_waves)), block(64);
+    const bool vec_ok =
+        reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
+        reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;
+    if (vec_ok) {
+        csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 4, 1, 1024, 1, 64>
+            <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs,
+                                               col_idxs, vals, b, 1, c, 1, 1,
+                                               nullptr, nullptr, partial);
+    } else {
+        csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 1, 4, 1024, 1, 64>
+            <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs,
+                                               col_idxs, vals, b, 1, c, 1, 1,
+                                               nullptr, nullptr, partial);
+    }
+    GKOC_LAUNCH_OK();
+    return fold_partials<T>(s, n_waves, partial, scratch, dot_out, false);
 }
 
 // ---- diagonal extraction / sortedness / per-row sort ---------------------
@@ -152,6 +197,14 @@ using namespace gkoc;
                                       col_idxs, vals, b, ldb, beta, c, ldc,    \
                                       nrhs);                                   \
     }                                                                          \
+    extern "C" int gkoc_x_csr_spmv_dot_##TN##_##IN(                            \
+        gkoc_stream_t s, int64_t n, const I* row_ptrs, const I* col_idxs,      \
+        const T* vals, const T* b, T* c, T* dot_out, void* work,               \
+        size_t work_bytes)                                                     \
+    {                                                                          \
+        return launch_csr_dot<T, I>(s, n, row_ptrs, col_idxs, vals, b, c,      \
+                                    dot_out, work, work_bytes);                \
+    }                                                                          \
     extern "C" int gkoc_csr_extract_diagonal_##TN##_##IN(                      \
         gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const I* row_ptrs,    \
         const I* col_idxs, const T* vals, T* diag)                             \
@@ -203,3 +256,8 @@ GKOC_DEF_CSR(double, f64, int32_t, i32)
 GKOC_DEF_CSR(double, f64, int64_t, i64)
 GKOC_DEF_CSR(float, f32, int32_t, i32)
 GKOC_DEF_CSR(float, f32, int64_t, i64)
+
+extern "C" size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size)
+{
+    return gkoc::fused_workspace_bytes(n < 0 ? 0 : n, value_size);
+}

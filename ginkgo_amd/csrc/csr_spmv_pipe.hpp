@@ -35,8 +35,10 @@ struct alignas(sizeof(T) * E) vecT {
 // All stream positions are 32-bit offsets from the wave's aligned stream start
 // K0a (keeps the address arithmetic in 32-bit registers: 72 VGPRs, 5 waves per
 // SIMD with the 8 KB ring).  WPS = minimum waves per SIMD the register
-// allocator must admit; ABL = measurement-only switches (1: skip the b gather,
-// 2: skip the LDS row sums) used by tools/spmv_lab.hip, 0 in the library.
+// allocator must admit; ABL = mode bits: 64 = also emit this wave's part of
+// <b, c> (square matrices, one right-hand side; used by gkoc_x_csr_spmv_dot);
+// the others are measurement-only switches of tools/spmv_lab.hip (1: skip the
+// b gather, 2: skip the LDS row sums, ...), 0 in the plain library kernel.
 // (Earlier generations of this kernel - 64-bit indexing, LDS-staged matrix
 // with row-ordered gather - are kept in tools/lab_kernels.hpp for A/B runs.)
 template <typename T, typename I, bool ADV, int ROWS, int E, int U, int RING,
@@ -46,16 +48,18 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     const I* __restrict__ row_ptrs, const I* __restrict__ cols,
     const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb,
     T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
-    const T* __restrict__ beta_p)
+    const T* __restrict__ beta_p, T* __restrict__ dot_partial = nullptr)
 {
     static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
     constexpr int G = 64 * E * U;
     static_assert(RING >= 2 * G, "ring too small for the group size");
     static_assert(ROWS == 32 || ROWS == 64, "ROWS must be 32 or 64");
     constexpr int MASK = RING - 1;
+    constexpr bool DOT = (ABL & 64) != 0;
     __shared__ __attribute__((aligned(16))) T ring[RING];
 
     const int lane = threadIdx.x;
+    T dot_acc = T(0);
     int64_t wave_id = blockIdx.x;
     if (ABL >> 8) {
         // measurement only: workgroup b runs on XCD b % 8; hand every XCD
@@ -69,7 +73,10 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     }
     const int64_t sb = wave_id * segs_per_wave;
     const int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
-    if (sb >= se) return;
+    if (sb >= se) {
+        if (DOT && lane == 0) dot_partial[blockIdx.x] = T(0);
+        return;
+    }
     const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;
     const int64_t K0 = row_ptrs[sb * ROWS];
     const int64_t K1 = row_ptrs[row_e];
@@ -209,7 +216,21 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                         if (lane == src) sum += part;
                     }
                     const int64_t row = seg * ROWS + lane;
-                    if (lane < ROWS && row < n_rows) c[row * ldc + j] = sum;
+                    if (DOT && lane < ROWS && row < n_rows) {
+                        dot_acc += bj[row * ldb] * sum;
+                    }
+                    if (lane < ROWS && row < n_rows) {
+                        if (ABL & 32) {
+                            __builtin_nontemporal_store(sum, &c[row * ldc + j]);
+                        } else {
+                            c[row * ldc + j] = sum;
+                        }
+                    }
+#ifdef GKOC_LAB_TIMESTAMPS
+                    if ((ABL & 16) && lane == 0 && seg + 1 == se) {
+                        gkoc_lab_ts[blockIdx.x] = wall_clock64();
+                    }
+#endif
                     ++seg;
                     rs = nrs;
                     re = nre;
@@ -234,6 +255,11 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
             produced += G;
             use_a = !use_a;
         }
+    }
+    if (DOT) {
+        // fixed butterfly: the partial of a wave does not depend on timing
+        dot_acc = wave_sum(dot_acc);
+        if (lane == 0) dot_partial[blockIdx.x] = dot_acc;
     }
 }
 

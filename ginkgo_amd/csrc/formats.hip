@@ -26,6 +26,65 @@ namespace {
 
 constexpr int fmt_unroll = 8;
 
+// One row of a column-major (ELL / SELL-P slice) layout: element i of the row
+// lives at first + i * step.  Software-pipelined: while the b entries of chunk
+// i are gathered, the val/col loads of chunk i+1 are already in flight; the
+// products are added in column order (bit-identical to the reference loop).
+template <typename T, typename I, bool ADV>
+__device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
+                                         int64_t step,
+                                         const I* __restrict__ cols,
+                                         const T* __restrict__ vals,
+                                         const T* __restrict__ b, int64_t ldb,
+                                         int j, T alpha)
+{
+    constexpr int U = fmt_unroll;
+    const int64_t full = len / U * U;
+    T v0[U], v1[U];
+    I c0[U], c1[U];
+    if (full > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v0[u] = vals[first + u * step];
+            c0[u] = cols[first + u * step];
+        }
+    }
+    int64_t i = 0;
+    while (i < full) {
+        T xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xv[u] = c0[u] >= 0 ? b[int64_t(c0[u]) * ldb + j] : T(0);
+        }
+        const int64_t nx = i + U < full ? i + U : i;  // last chunk: harmless reload
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v1[u] = vals[first + (nx + u) * step];
+            c1[u] = cols[first + (nx + u) * step];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const T t = ADV ? (alpha * v0[u]) * xv[u] : v0[u] * xv[u];
+            sum = c0[u] >= 0 ? sum + t : sum;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v0[u] = v1[u];
+            c0[u] = c1[u];
+        }
+        i += U;
+    }
+    for (; i < len; ++i) {
+        const I cc = cols[first + i * step];
+        if (cc >= 0) {
+            const T v = vals[first + i * step];
+            const T xv = b[int64_t(cc) * ldb + j];
+            sum += ADV ? (alpha * v) * xv : v * xv;
+        }
+    }
+    return sum;
+}
+
 template <typename T, typename I, bool ADV>
 __global__ __launch_bounds__(256) void ell_spmv_kernel(
     int64_t n_rows, int64_t k_per_row, int64_t stride,
@@ -43,35 +102,7 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(
     for (int j = 0; j < nrhs; ++j) {
         T sum = T(0);
         if (ADV && beta != T(0)) sum = beta * c[row * ldc + j];
-        int64_t i = 0;
-        for (; i + fmt_unroll <= k_per_row; i += fmt_unroll) {
-            T v[fmt_unroll];
-            I cc[fmt_unroll];
-#pragma unroll
-            for (int u = 0; u < fmt_unroll; ++u) {
-                v[u] = vals[row + (i + u) * stride];
-                cc[u] = cols[row + (i + u) * stride];
-            }
-            T xv[fmt_unroll];
-#pragma unroll
-            for (int u = 0; u < fmt_unroll; ++u) {
-                xv[u] = cc[u] >= 0 ? b[int64_t(cc[u]) * ldb + j] : T(0);
-            }
-#pragma unroll
-            for (int u = 0; u < fmt_unroll; ++u) {
-                if (cc[u] >= 0) {
-                    sum += ADV ? (alpha * v[u]) * xv[u] : v[u] * xv[u];
-                }
-            }
-        }
-        for (; i < k_per_row; ++i) {
-            const I cc = cols[row + i * stride];
-            if (cc >= 0) {
-                const T v = vals[row + i * stride];
-                const T xv = b[int64_t(cc) * ldb + j];
-                sum += ADV ? (alpha * v) * xv : v * xv;
-            }
-        }
+        sum = fmt_row_sum<T, I, ADV>(sum, k_per_row, row, stride, cols, vals, b, ldb, j, alpha);
         c[row * ldc + j] = sum;
     }
 }
@@ -99,35 +130,7 @@ __global__ __launch_bounds__(256) void sellp_spmv_kernel(
     for (int j = 0; j < nrhs; ++j) {
         T sum = T(0);
         if (ADV && beta != T(0)) sum = c[row * ldc + j] * beta;
-        int64_t i = 0;
-        for (; i + fmt_unroll <= len; i += fmt_unroll) {
-            T v[fmt_unroll];
-            I cc[fmt_unroll];
-#pragma unroll
-            for (int u = 0; u < fmt_unroll; ++u) {
-                v[u] = vals[base + (i + u) * slice_size];
-                cc[u] = cols[base + (i + u) * slice_size];
-            }
-            T xv[fmt_unroll];
-#pragma unroll
-            for (int u = 0; u < fmt_unroll; ++u) {
-                xv[u] = cc[u] >= 0 ? b[int64_t(cc[u]) * ldb + j] : T(0);
-            }
-#pragma unroll
-            for (int u = 0; u < fmt_unroll; ++u) {
-                if (cc[u] >= 0) {
-                    sum += ADV ? (alpha * v[u]) * xv[u] : v[u] * xv[u];
-                }
-            }
-        }
-        for (; i < len; ++i) {
-            const I cc = cols[base + i * slice_size];
-            if (cc >= 0) {
-                const T v = vals[base + i * slice_size];
-                const T xv = b[int64_t(cc) * ldb + j];
-                sum += ADV ? (alpha * v) * xv : v * xv;
-            }
-        }
+        sum = fmt_row_sum<T, I, ADV>(sum, len, base, slice_size, cols, vals, b, ldb, j, alpha);
         c[row * ldc + j] = sum;
     }
 }

@@ -28,6 +28,7 @@
 //    and operation order as in the reference => bit-identical inverse blocks.
 #include "common.hpp"
 #include "scan.hpp"
+#include "fused.hpp"
 
 namespace gkoc {
 namespace {
@@ -366,13 +367,16 @@ __global__ __launch_bounds__(256) void jacobi_apply_kernel(
 // value are requested before the first use; b[start + c] then comes from lane
 // (block, c) through ds_bpermute instead of BO more gathers.  Accumulation
 // order and rounding are those of the generic kernel (reference apply_block).
-template <typename T, typename I, bool ADV, int BO, int GPW>
+template <typename T, typename I, bool ADV, int BO, int GPW, bool DOT = false>
 __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
     int64_t num_blocks, int64_t num_groups, int64_t group_offset,
     const I* __restrict__ block_ptrs, const T* __restrict__ blocks,
     const T* __restrict__ alpha_p, const T* __restrict__ b,
-    const T* __restrict__ beta_p, T* __restrict__ x)
+    const T* __restrict__ beta_p, T* __restrict__ x,
+    T* __restrict__ dot_partial = nullptr)
 {
+    __shared__ T dot_lds[4];
+    T dot_acc = T(0);
     constexpr int LOG_BO = BO == 1 ? 0 : BO == 2 ? 1 : BO == 4 ? 2 : BO == 8 ? 3
                          : BO == 16 ? 4 : BO == 32 ? 5 : 6;
     constexpr int GP = 6 - LOG_BO;  // group_power
@@ -430,6 +434,11 @@ __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
             sum = c < bs[g] ? sum + t : sum;
         }
         if (bs[g] > 0) x[row[g]] = sum;
+        if (DOT && bs[g] > 0) dot_acc += bv[g] * sum;   // <b, x> for this row
+    }
+    if (DOT) {
+        const T r = block_sum<256>(dot_acc, dot_lds);
+        if (threadIdx.x == 0) dot_partial[blockIdx.x] = r;
     }
 }
 
@@ -444,6 +453,62 @@ void launch_apply_fixed(gkoc_stream_t s, int64_t num_blocks, int64_t groups,
         <<<dim3(unsigned(ceildiv(groups, 4 * GPW))), dim3(256), 0,
            as_stream(s)>>>(num_blocks, groups, group_offset, block_ptrs, blocks,
                            alpha, b, beta, x);
+}
+
+// x = M b and dot_out = <b, x> (fast-path layout only, one right-hand side)
+template <typename T, typename I, int BO>
+void launch_apply_dot_fixed(gkoc_stream_t s, int64_t num_blocks, int64_t groups,
+                            int64_t group_offset, const I* block_ptrs,
+                            const T* blocks, const T* b, T* x, T* partial,
+                            int64_t* n_partials)
+{
+    constexpr int GPW = (BO * sizeof(T) >= 128) ? 1 : 2;
+    const int64_t nb = ceildiv(groups, 4 * GPW);
+    *n_partials = nb;
+    jacobi_apply_fixed_kernel<T, I, false, BO, GPW, true>
+        <<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(
+            num_blocks, groups, group_offset, block_ptrs, blocks, nullptr, b,
+            nullptr, x, partial);
+}
+
+template <typename T, typename I>
+int launch_apply_dot(gkoc_stream_t s, int64_t num_blocks, int64_t n_rows,
+                     uint32_t max_bs, gkoc_jacobi_scheme scheme,
+                     const I* block_ptrs, const T* blocks, const T* b, T* x,
+                     T* dot_out, void* work, size_t work_bytes)
+{
+    GKOC_REQUIRE(dot_out, GKOC_E_INVALID, "null result");
+    if (num_blocks <= 0) {
+        GKOC_HIP(hipMemsetAsync(dot_out, 0, sizeof(T), as_stream(s)));
+        return GKOC_OK;
+    }
+    GKOC_REQUIRE(block_ptrs && blocks && b && x && work, GKOC_E_INVALID, "null pointer");
+    const int64_t bo = scheme.block_offset;
+    GKOC_REQUIRE(bo >= 1 && bo <= 16 && (bo << scheme.group_power) == 64 &&
+                     (bo & (bo - 1)) == 0,
+                 GKOC_E_NOT_SUPPORTED,
+                 "fused apply+dot needs block_offset in {1,2,4,8,16} and a 64-wide group");
+    GKOC_REQUIRE(max_bs <= uint64_t(bo), GKOC_E_INVALID,
+                 "max_block_size exceeds block_offset");
+    GKOC_REQUIRE(work_bytes >= fused_workspace_bytes(n_rows, sizeof(T)), GKOC_E_WORKSPACE,
+                 "workspace too small (gkoc_x_workspace_bytes)");
+    const int64_t gsize = int64_t(1) << scheme.group_power;
+    const int64_t groups = ceildiv(num_blocks, gsize);
+    GKOC_REQUIRE(ceildiv(groups, 4) <= (n_rows + 63) / 64 + 4096, GKOC_E_INVALID,
+                 "n_rows does not match the block count");
+    T* partial = static_cast<T*>(work);
+    T* scratch = partial + (fused_workspace_bytes(n_rows, sizeof(T)) / sizeof(T) - fold_chunks);
+    int64_t np = 0;
+    const int64_t go = scheme.group_offset;
+    switch (int(bo)) {
+    case 1: launch_apply_dot_fixed<T, I, 1>(s, num_blocks, groups, go, block_ptrs, blocks, b, x, partial, &np); break;
+    case 2: launch_apply_dot_fixed<T, I, 2>(s, num_blocks, groups, go, block_ptrs, blocks, b, x, partial, &np); break;
+    case 4: launch_apply_dot_fixed<T, I, 4>(s, num_blocks, groups, go, block_ptrs, blocks, b, x, partial, &np); break;
+    case 8: launch_apply_dot_fixed<T, I, 8>(s, num_blocks, groups, go, block_ptrs, blocks, b, x, partial, &np); break;
+    default: launch_apply_dot_fixed<T, I, 16>(s, num_blocks, groups, go, block_ptrs, blocks, b, x, partial, &np); break;
+    }
+    GKOC_LAUNCH_OK();
+    return fold_partials<T>(s, np, partial, scratch, dot_out, false);
 }
 
 template <typename T, typename I, bool ADV>
@@ -543,6 +608,16 @@ using namespace gkoc;
         return launch_apply<T, I, false>(s, num_blocks, max_block_size,        \
                                          scheme, block_ptrs, blocks, nullptr,  \
                                          b, ldb, nullptr, x, ldx, nrhs);       \
+    }                                                                          \
+    extern "C" int gkoc_x_jacobi_simple_apply_dot_##TN##_##IN(                 \
+        gkoc_stream_t s, int64_t num_blocks, int64_t n_rows,                   \
+        uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
+        const I* block_ptrs, const T* blocks, const T* b, T* x, T* dot_out,    \
+        void* work, size_t work_bytes)                                         \
+    {                                                                          \
+        return launch_apply_dot<T, I>(s, num_blocks, n_rows, max_block_size,   \
+                                      scheme, block_ptrs, blocks, b, x,        \
+                                      dot_out, work, work_bytes);              \
     }                                                                          \
     extern "C" int gkoc_jacobi_apply_##TN##_##IN(                              \
         gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,          \

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._lib import IT, VT, GkoError, call
+from ._lib import IT, VT, GkoError, call, lib
 from .matrix import Csr, Dense, scalar, stencil_csr
 from .preconditioner import Jacobi
 
@@ -208,6 +208,34 @@ class HipBackend:
     def local_dot(self, x, y, out):
         x.compute_dot(y, out)
 
+    # fused producer + local reduction (gkoc_x_*); vectors bit-identical
+    def _xwork(self, n, dtype):
+        w = getattr(self, "_xw", None)
+        nbytes = lib().gkoc_x_workspace_bytes(C.c_int64(n), C.c_size_t(torch.empty((), dtype=dtype).element_size()))
+        if w is None or w.numel() * w.element_size() < nbytes or w.dtype != dtype:
+            es = torch.empty((), dtype=dtype).element_size()
+            w = self._xw = self.exec.alloc(((nbytes + es - 1) // es,), dtype)
+        return w, C.c_size_t(w.numel() * w.element_size())
+
+    def jacobi_apply_dot(self, m, r, z, out):
+        """z = M r, out = local <r, z>; False if this preconditioner layout has
+        no fused kernel (caller uses apply + local_dot)"""
+        if not (hasattr(m, "can_fuse_dot") and m.can_fuse_dot(r) and z.ld == 1):
+            return False
+        w, _ = self._xwork(r.size[0], r.dtype)
+        m.apply_dot(r, z, out, w)
+        return True
+
+    def cg_step_2_sqnorm(self, x, r, p, q, beta, rho, stop, out):
+        """cg::step_2 and out = local ||r_new||^2"""
+        if not all(v.ld == 1 and v.size[1] == 1 for v in (x, r, p, q)):
+            return False
+        w, wb = self._xwork(x.size[0], x.dtype)
+        call("gkoc_x_cg_step_2_norm_" + VT[x.dtype], self.exec.stream, x.size[0], x.values,
+             r.values, p.values, q.values, beta.values, rho.values, stop, out.values,
+             C.c_int(0), w, wb)
+        return True
+
     def local_sqnorm(self, x, out):
         x.compute_squared_norm2(out)
 
@@ -337,13 +365,14 @@ class DistributedCg:
       check_lag = 0 is the reference's lock-step behaviour."""
 
     def __init__(self, backend, comm, matrix, max_iters, reduction_factor=1e-10,
-                 max_block_size=8, check_lag=None):
+                 max_block_size=8, check_lag=None, fused=True):
         self.be, self.comm, self.a = backend, comm, matrix
         self.max_iters, self.factor = int(max_iters), float(reduction_factor)
         self.m = backend.jacobi(matrix.local, max_block_size) if max_block_size else None
         self.num_iterations = 0
         self.residual_norm = None
         self.check_lag = backend.max_check_lag if check_lag is None else int(check_lag)
+        self.fused = bool(fused)
         n, dt = matrix.n_local, matrix.dtype
         self.r, self.z, self.p, self.q = (backend.vector(n, dt) for _ in range(4))
         self.beta, self.tau0 = backend.vector(1, dt), backend.vector(1, dt)
@@ -385,15 +414,19 @@ class DistributedCg:
         q.fill(0.0)
         self._norm2(b, self.tau0)              # ResidualNorm(rhs_norm) baseline
         pending = deque()
+        fused = self.fused and hasattr(be, "cg_step_2_sqnorm")
+        have_sq = False
         it = -1
         while True:
-            if self.m is not None:
-                self.m.apply(r, z)
-            else:
-                z.copy_from(r)
             pair, rho, tau = cur
-            be.local_dot(r, z, rho)
-            be.local_sqnorm(r, tau)
+            if not (self.m is not None and fused and be.jacobi_apply_dot(self.m, r, z, rho)):
+                if self.m is not None:
+                    self.m.apply(r, z)
+                else:
+                    z.copy_from(r)
+                be.local_dot(r, z, rho)
+            if not have_sq:
+                be.local_sqnorm(r, tau)
             self.comm.all_reduce_sum_(pair)    # one message: [<r,z>, ||r||^2]
             it += 1
             if it >= self.max_iters:
@@ -410,7 +443,10 @@ class DistributedCg:
             be.cg_step_1(p, z, rho, prev[1], self.stop)
             a.apply(p, q)
             self._dot(p, q, beta)
-            be.cg_step_2(x, r, p, q, beta, rho, self.stop)
+            # the pair that is `cur` in the next iteration receives ||r_new||^2
+            have_sq = fused and be.cg_step_2_sqnorm(x, r, p, q, beta, rho, self.stop, prev[2])
+            if not have_sq:
+                be.cg_step_2(x, r, p, q, beta, rho, self.stop)
             cur, prev = prev, cur
         self.num_iterations = it
         return x

@@ -241,6 +241,13 @@ class Csr(_SparseBase):
              self.size[0], self.size[1], alpha.values, self.row_ptrs,
              self.col_idxs, self.values, bv, ldb, beta.values, xv, ldx, nrhs)
 
+    def apply_dot(self, b, x, dot_out, work):
+        """x = A b and dot_out = <b, x> in one pass (gkoc_x_csr_spmv_dot_*):
+        square matrix, one right-hand side, unit strides"""
+        call("gkoc_x_csr_spmv_dot_" + self._suf(), self.exec.stream, self.size[0],
+             self.row_ptrs, self.col_idxs, self.values, b.values, x.values,
+             dot_out.values, work, C.c_size_t(work.numel() * work.element_size()))
+
     def extract_diagonal(self):
         n = min(self.size)
         d = self.exec.zeros((n,), self.dtype)

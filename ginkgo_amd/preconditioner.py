@@ -125,6 +125,21 @@ class Jacobi(LinOp):
              self.block_pointers, self.blocks, b.values, b.ld, x.values, x.ld,
              b.size[1])
 
+    def can_fuse_dot(self, b):
+        """x = M b together with <b, x> (gkoc_x_jacobi_simple_apply_dot_*): block
+        storage with a power-of-two block_offset <= 16 and 64-wide groups, one
+        right-hand side, unit stride"""
+        if self.max_block_size == 1 or b.size[1] != 1 or b.ld != 1:
+            return False
+        bo = self.scheme.block_offset
+        return bo <= 16 and (bo & (bo - 1)) == 0 and (bo << self.scheme.group_power) == 64
+
+    def apply_dot(self, b, x, dot_out, work):
+        call("gkoc_x_jacobi_simple_apply_dot_" + self._suf, self.exec.stream,
+             self.num_blocks, self.size[0], C.c_uint32(self.max_block_size), self.scheme,
+             self.block_pointers, self.blocks, b.values, x.values, dot_out.values,
+             work, C.c_size_t(work.numel() * work.element_size()))
+
     def apply_advanced_impl(self, alpha, b, beta, x):
         ex = self.exec
         if self.max_block_size == 1:

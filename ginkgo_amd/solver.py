@@ -13,7 +13,7 @@ from collections import deque
 
 import torch
 
-from ._lib import DimensionMismatch, NotSupported, VT, call
+from ._lib import DimensionMismatch, NotSupported, VT, call, lib
 from .base import LinOp
 from .matrix import Dense, scalar
 from . import stop as _stop
@@ -156,15 +156,41 @@ class Cg(_IterativeSolver):
         # the iterations enqueued in between leave x, r, p as they were at the
         # stopping iteration.  with_check_lag(0) = lock-step like the reference.
         lag = int(self.params.get("check_lag", 4))
+        # Fused producer+reduction kernels (include/gko_cdna4.h, gkoc_x_*): same
+        # vectors bit for bit, one pass less over r / z / p / q per pair.
+        # with_fused_kernels(False) = the reference's kernel sequence.
+        fuse = bool(self.params.get("fused_kernels", True)) and cols == 1 and \
+            all(v.ld == 1 for v in (b, x, r, z, p, q))
+        from .matrix import Csr
+        from .preconditioner import Jacobi
+        # (spmv + dot measured slower fused than unfused - the dot re-reads p, q
+        # from the memory-side cache -, so it is opt-in)
+        fuse_spmv = fuse and isinstance(a, Csr) and bool(self.params.get("fused_spmv_dot", False))
+        fuse_prec = fuse and isinstance(m, Jacobi) and m.can_fuse_dot(r)
+        fuse_norm = fuse and any(isinstance(c, _stop.ResidualNorm) and not c.implicit
+                                 for c in crit.criteria)
+        work = None
+        if fuse_spmv or fuse_prec or fuse_norm:
+            nbytes = lib().gkoc_x_workspace_bytes(C.c_int64(rows), C.c_size_t(b.values.element_size()))
+            work = self._ws.get("fused_work")
+            if work is None or work.numel() * work.element_size() < nbytes:
+                work = self._ws["fused_work"] = ex.alloc(
+                    ((nbytes + b.values.element_size() - 1) // b.values.element_size(),), b.dtype)
+        tau = self._scal("tau", b) if fuse_norm else None
+        have_tau = False
         pending = deque()
         it = -1
         while True:
-            m.apply(r, z)
-            r.compute_conj_dot(z, rho)
+            if fuse_prec:
+                m.apply_dot(r, z, rho, work)
+            else:
+                m.apply(r, z)
+                r.compute_conj_dot(z, rho)
             it += 1
             tokens, decided = crit.check_begin(
                 1, True, stop_status,
                 {"num_iterations": it, "residual": r,
+                 "residual_norm": tau if have_tau else None,
                  "implicit_sq_residual_norm": rho, "solution": x})
             pending.append((it, tokens))
             stopped = None
@@ -178,11 +204,20 @@ class Cg(_IterativeSolver):
                 break
             call("gkoc_cg_step_1_" + suf, ex.stream, rows, cols, p.values, p.ld,
                  z.values, z.ld, rho.values, prev_rho.values, stop_status)
-            a.apply(p, q)
-            p.compute_conj_dot(q, beta)
-            call("gkoc_cg_step_2_" + suf, ex.stream, rows, cols, x.values, x.ld,
-                 r.values, r.ld, p.values, p.ld, q.values, q.ld, beta.values,
-                 rho.values, stop_status)
+            if fuse_spmv:
+                a.apply_dot(p, q, beta, work)
+            else:
+                a.apply(p, q)
+                p.compute_conj_dot(q, beta)
+            if fuse_norm:
+                call("gkoc_x_cg_step_2_norm_" + suf, ex.stream, rows, x.values, r.values,
+                     p.values, q.values, beta.values, rho.values, stop_status, tau.values,
+                     C.c_int(1), work, C.c_size_t(work.numel() * work.element_size()))
+                have_tau = True
+            else:
+                call("gkoc_cg_step_2_" + suf, ex.stream, rows, cols, x.values, x.ld,
+                     r.values, r.ld, p.values, p.ld, q.values, q.ld, beta.values,
+                     rho.values, stop_status)
             prev_rho, rho = rho, prev_rho
         self.num_iterations = it
         self.stop_status = stop_status

@@ -509,6 +509,40 @@ GKOC_DECL_DIST(double, f64, int64_t, i64)
 GKOC_DECL_DIST(float, f32, int32_t, i32)
 GKOC_DECL_DIST(float, f32, int64_t, i64)
 
+/* ------------------------------------------------- extensions (gkoc_x_*)
+ * NOT part of Ginkgo's kernel set (the shim never calls them): producer
+ * kernels that also emit the reduction a Krylov loop needs next, so the
+ * vector is not read again and two launches disappear per fused pair.  They
+ * replace, inside this repository's own solver drivers, the pairs
+ *   csr::spmv + dense::compute_dot            (cg.cpp:160-163: q = A p, beta = p.q)
+ *   jacobi::simple_apply + dense::compute_dot (cg.cpp:133-136: z = M r, rho = r.z)
+ *   cg::step_2 + dense::compute_norm2         (cg.cpp:167-171 + stop/residual_norm.cpp:120)
+ * Vectors / c / x / r are bit-identical to the unfused kernels; the scalar is
+ * a deterministic tree sum (tolerance 1e-13 as for compute_dot).  One column,
+ * unit strides.  work: gkoc_x_workspace_bytes(n, sizeof(T)) device bytes. */
+size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size);
+#define GKOC_DECL_X(T, TN)                                                     \
+    int gkoc_x_cg_step_2_norm_##TN(                                            \
+        gkoc_stream_t s, int64_t rows, T* x, T* r, const T* p, const T* q,     \
+        const T* beta, const T* rho, const uint8_t* stop_status, T* norm_out,  \
+        int take_sqrt, void* work, size_t work_bytes);
+GKOC_DECL_X(double, f64)
+GKOC_DECL_X(float, f32)
+#define GKOC_DECL_XI(T, TN, I, IN)                                             \
+    int gkoc_x_csr_spmv_dot_##TN##_##IN(                                       \
+        gkoc_stream_t s, int64_t n, const I* row_ptrs, const I* col_idxs,      \
+        const T* vals, const T* b, T* c, T* dot_out, void* work,               \
+        size_t work_bytes);                                                    \
+    int gkoc_x_jacobi_simple_apply_dot_##TN##_##IN(                            \
+        gkoc_stream_t s, int64_t num_blocks, int64_t n_rows,                   \
+        uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
+        const I* block_ptrs, const T* blocks, const T* b, T* x, T* dot_out,    \
+        void* work, size_t work_bytes);
+GKOC_DECL_XI(double, f64, int32_t, i32)
+GKOC_DECL_XI(double, f64, int64_t, i64)
+GKOC_DECL_XI(float, f32, int32_t, i32)
+GKOC_DECL_XI(float, f32, int64_t, i64)
+
 #ifdef __cplusplus
 }
 #endif

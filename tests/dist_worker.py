@@ -70,6 +70,14 @@ def main():
     assert solver.check_lag > 0
     assert solver0.num_iterations == solver.num_iterations
     assert np.array_equal(xs0.to_numpy(), xs.to_numpy())
+    # --- fused producer+reduction kernels (HipBackend only) vs the plain sequence
+    if mode != "cpu":
+        solver1 = gd.DistributedCg(be, comm, a, 500, 1e-10, 8, fused=False)
+        xs1 = be.vector(hi - lo)
+        solver1.apply(be.vector_from(np.ones(hi - lo)), xs1)
+        assert abs(solver1.num_iterations - solver.num_iterations) <= 1
+        d = np.linalg.norm(xs1.to_numpy() - xs.to_numpy()) / np.linalg.norm(xs.to_numpy())
+        assert d < 1e-9, d
     dist.barrier()
     if rank == 0:
         print(f"dist_worker OK mode={mode} world={world} grid={grid} iters={solver.num_iterations}")

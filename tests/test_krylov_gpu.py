@@ -462,3 +462,111 @@ def test_cg_deferred_check_changes_nothing(gexec, bs):
         x = g.Dense.from_numpy(gexec, np.zeros((n, 2)))
         s.apply(g.Dense.from_numpy(gexec, rhs), x)
         assert s.num_iterations == 5 and not s.has_converged
+
+
+# ------------------------------------------------- fused extensions (gkoc_x_*)
+def _xwork(ex, n, dtype=torch.float64):
+    import ctypes as C
+    from ginkgo_amd._lib import lib
+    nbytes = lib().gkoc_x_workspace_bytes(C.c_int64(n), C.c_size_t(8))
+    return ex.alloc(((nbytes + 7) // 8,), dtype), nbytes
+
+
+@pytest.mark.parametrize("grid", [5, 17, 40])
+def test_fused_spmv_dot(gexec, grid):
+    """c bit-identical to csr::spmv, dot = <b, c> within the reduction tolerance"""
+    import ctypes as C
+    import ginkgo_amd as g
+    from ginkgo_amd._lib import call
+    n = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    bv = np.random.default_rng(grid).uniform(-1, 1, n)
+    b = g.Dense.from_numpy(gexec, bv)
+    c0, c1 = g.Dense.create(gexec, (n, 1)), g.Dense.create(gexec, (n, 1))
+    a.apply(b, c0)
+    work, nbytes = _xwork(gexec, n)
+    out = g.Dense.create(gexec, (1, 1))
+    a.apply_dot(b, c1, out, work)
+    assert np.array_equal(c0.to_numpy(), c1.to_numpy())
+    ref = float(np.dot(bv, c0.to_numpy()[:, 0]))
+    assert abs(out.to_numpy()[0, 0] - ref) <= 1e-13 * np.sum(np.abs(bv * c0.to_numpy()[:, 0]))
+    # deterministic
+    out2 = g.Dense.create(gexec, (1, 1))
+    a.apply_dot(b, c1, out2, work)
+    assert out.to_numpy()[0, 0] == out2.to_numpy()[0, 0]
+    # workspace check
+    from ginkgo_amd._lib import GkoError
+    with pytest.raises(GkoError):
+        call("gkoc_x_csr_spmv_dot_f64_i32", gexec.stream, n, a.row_ptrs, a.col_idxs, a.values,
+             b.values, c1.values, out.values, work, C.c_size_t(nbytes - 8))
+
+
+@pytest.mark.parametrize("max_bs", [2, 4, 8, 16])
+def test_fused_jacobi_apply_dot(gexec, max_bs):
+    import ginkgo_amd as g
+    grid = 24
+    n = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    m = g.Jacobi.build().with_max_block_size(max_bs).on(gexec).generate(a)
+    rv = np.random.default_rng(max_bs).uniform(-1, 1, n)
+    r = g.Dense.from_numpy(gexec, rv)
+    z0, z1 = g.Dense.create(gexec, (n, 1)), g.Dense.create(gexec, (n, 1))
+    m.apply(r, z0)
+    assert m.can_fuse_dot(r)
+    work, _ = _xwork(gexec, n)
+    out = g.Dense.create(gexec, (1, 1))
+    m.apply_dot(r, z1, out, work)
+    assert np.array_equal(z0.to_numpy(), z1.to_numpy())
+    zz = z0.to_numpy()[:, 0]
+    assert abs(out.to_numpy()[0, 0] - float(np.dot(rv, zz))) <= 1e-13 * np.sum(np.abs(rv * zz))
+    # layouts outside the fast path are refused, the caller keeps the two-kernel form
+    m13 = g.Jacobi.build().with_max_block_size(13).on(gexec).generate(a)
+    assert not m13.can_fuse_dot(r)
+
+
+@pytest.mark.parametrize("n", [1, 777, 100003, 1 << 20])
+def test_fused_step_2_norm(gexec, oracle, n):
+    import ctypes as C
+    from ginkgo_amd._lib import call
+    import ginkgo_amd as g
+    rng = np.random.default_rng(n)
+    x, r, p, q = (rng.uniform(-1, 1, n) for _ in range(4))
+    work, nbytes = _xwork(gexec, n)
+    for beta, stopped in ((0.37, 0), (0.0, 0), (0.37, 0x81)):
+        dx, dr = gexec.to_device(x), gexec.to_device(r)
+        stop = gexec.to_device(np.array([stopped], np.uint8))
+        out = g.Dense.create(gexec, (1, 1))
+        call("gkoc_x_cg_step_2_norm_f64", gexec.stream, n, dx, dr, gexec.to_device(p),
+             gexec.to_device(q), gexec.to_device(np.array([beta])), gexec.to_device(np.array([0.81])),
+             stop, out.values, C.c_int(1), work, C.c_size_t(nbytes))
+        ox, orr = oracle.cg_step_2(x.copy(), r.copy(), p.copy(), q.copy(), np.array([beta]),
+                                   np.array([0.81]), np.array([stopped], np.uint8))
+        assert np.array_equal(dx.cpu().numpy(), ox.reshape(-1))
+        assert np.array_equal(dr.cpu().numpy(), orr.reshape(-1))
+        nr = np.linalg.norm(orr)
+        assert abs(out.to_numpy()[0, 0] - nr) <= 1e-13 * max(nr, 1e-300)
+
+
+@pytest.mark.parametrize("bs", [None, 8, 13])
+def test_cg_fused_vs_unfused(gexec, bs):
+    """same iteration count and the same solution to rounding with and without
+    the fused kernels (vectors are bit-identical, scalars differ by the tree)"""
+    import ginkgo_amd as g
+    grid = 24
+    n = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    rhs = np.random.default_rng(21).uniform(-1, 1, n)
+    res = []
+    for fused in (False, True):
+        f = (g.Cg.build().with_fused_kernels(fused).with_criteria(
+            g.stop.Iteration.build().with_max_iters(300),
+            g.stop.ResidualNorm.build().with_reduction_factor(1e-10)))
+        if bs:
+            f = f.with_preconditioner(g.Jacobi.build().with_max_block_size(bs))
+        s = f.on(gexec).generate(a)
+        x = g.Dense.from_numpy(gexec, np.zeros(n))
+        s.apply(g.Dense.from_numpy(gexec, rhs), x)
+        res.append((s.num_iterations, s.has_converged, x.to_numpy()[:, 0], s.residual_norm))
+    assert res[0][1] and res[1][1]
+    assert abs(res[0][0] - res[1][0]) <= 1
+    assert rel_frobenius(res[1][2], res[0][2]) < 1e-9

@@ -30,18 +30,20 @@ def sync():
 
 rhs = g.Dense.from_numpy(ex, np.ones(n))
 sol = g.Dense.from_numpy(ex, np.zeros(n))
-solver = (g.Cg.build()
-          .with_criteria(g.stop.Iteration.build().with_max_iters(iters),
-                         g.stop.ResidualNorm.build().with_reduction_factor(1e-30))
-          .with_preconditioner(g.Jacobi.build().with_max_block_size(8))
-          .on(ex).generate(a))
-solver.apply(rhs, sol.fill(0.0))
-sync()
-t = time.perf_counter()
-solver.apply(rhs, sol.fill(0.0))
-sync()
-t = time.perf_counter() - t
-print(f"plain Cg           grid {grid}: {solver.num_iterations} its, {t*1e6/solver.num_iterations:8.1f} us/it, {solver.num_iterations/t:8.1f} it/s")
+jac_f = g.Jacobi.build().with_max_block_size(8).on(ex).generate(a)
+for fused in (False, True, False, True):
+    solver = (g.Cg.build().with_fused_kernels(fused)
+              .with_criteria(g.stop.Iteration.build().with_max_iters(iters),
+                             g.stop.ResidualNorm.build().with_reduction_factor(1e-30))
+              .with_generated_preconditioner(jac_f)
+              .on(ex).generate(a))
+    solver.apply(rhs, sol.fill(0.0))
+    sync()
+    t = time.perf_counter()
+    solver.apply(rhs, sol.fill(0.0))
+    sync()
+    t = time.perf_counter() - t
+    print(f"plain Cg fused={fused!s:5s} grid {grid}: {solver.num_iterations} its, {t*1e6/solver.num_iterations:8.1f} us/it, {solver.num_iterations/t:8.1f} it/s")
 
 part = gd.SlabPartition(grid, 1)
 op = gd.DistributedStencil(ex, part, 0)

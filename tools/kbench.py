@@ -71,3 +71,36 @@ timeit("cg step_1", lambda: call("gkoc_cg_step_1_f64", S(), n, 1, p.values, 1, z
                                  rho.values, prev.values, stop), 24 * n)
 timeit("cg step_2", lambda: call("gkoc_cg_step_2_f64", S(), n, 1, x.values, 1, r.values, 1,
                                  p.values, 1, q.values, 1, prev.values, rho.values, stop), 48 * n)
+
+# ---- fused extensions, A/B against the pairs they replace
+import ctypes as C  # noqa: E402
+from ginkgo_amd._lib import lib  # noqa: E402
+nbytes = lib().gkoc_x_workspace_bytes(C.c_int64(n), C.c_size_t(8))
+work = ex.alloc(((nbytes + 7) // 8,), torch.float64)
+wb = C.c_size_t(nbytes)
+
+
+def pair_spmv():
+    a.apply(p, q)
+    p.compute_dot(q, res)
+
+
+def pair_jac():
+    jac.apply(r, z)
+    r.compute_dot(z, res)
+
+
+def pair_step2():
+    call("gkoc_cg_step_2_f64", S(), n, 1, x.values, 1, r.values, 1, p.values, 1, q.values, 1,
+         prev.values, rho.values, stop)
+    r.compute_norm2(res)
+
+
+timeit("spmv + dot (2+1 launches)", pair_spmv, 12 * nnz + 4 * (n + 1) + 16 * n)
+timeit("x_csr_spmv_dot", lambda: a.apply_dot(p, q, res, work), 12 * nnz + 4 * (n + 1) + 16 * n)
+timeit("jacobi + dot", pair_jac, 64 * n + 4 * (n // 8 + 1) + 16 * n)
+timeit("x_jacobi_simple_apply_dot", lambda: jac.apply_dot(r, z, res, work), 64 * n + 4 * (n // 8 + 1) + 16 * n)
+timeit("step_2 + norm2", pair_step2, 48 * n)
+timeit("x_cg_step_2_norm", lambda: call("gkoc_x_cg_step_2_norm_f64", S(), n, x.values, r.values, p.values,
+                                        q.values, prev.values, rho.values, stop, res.values, C.c_int(1),
+                                        work, wb), 48 * n)

@@ -3,11 +3,14 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude \
 //     -Iginkgo_amd/csrc tools/place_lab.hip ginkgo_amd/csrc/runtime.hip \
 //     ginkgo_amd/csrc/stencil.hip -o tools/place_lab
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#define GKOC_LAB_TIMESTAMPS 1
+__device__ unsigned long long* gkoc_lab_ts;
 #include "../ginkgo_amd/csrc/csr_spmv.hip"
 
 using namespace gkoc;
@@ -69,6 +72,30 @@ __global__ void chain_walk_kernel(const int64_t* buf, int64_t n_steps, int64_t* 
     out[0] = idx;
 }
 
+// every lane touches one pseudo-random 4 KiB page of the buffer per step
+__global__ __launch_bounds__(256) void tlb_stress_kernel(const double* buf, int64_t n_pages,
+                                                         int steps, double* out)
+{
+    unsigned long long s = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+    double acc = 0;
+    for (int i = 0; i < steps; ++i) {
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        const int64_t page = int64_t((s >> 20) % (unsigned long long)n_pages);
+        acc += __builtin_nontemporal_load(buf + page * 512 + ((s >> 8) & 511));
+    }
+    if (acc == 1.2345e300) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void tlb_stress_write_kernel(double* buf, int64_t n_pages,
+                                                               int steps)
+{
+    unsigned long long s = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+    for (int i = 0; i < steps; ++i) {
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        const int64_t page = int64_t((s >> 20) % (unsigned long long)n_pages);
+        buf[page * 512 + ((s >> 8) & 511)] = double(i);
+    }
+}
+
 int main(int argc, char** argv)
 {
     const int64_t g = argc > 1 ? atoll(argv[1]) : 256;
@@ -101,6 +128,71 @@ int main(int argc, char** argv)
         }
         CK(hipMemcpy(b, hb.data(), sizeof(double) * n, hipMemcpyHostToDevice));
         printf("rp %p cols %p vals %p b %p\n", rp0, cols, vals, b);
+        if (argc > 5 && !strcmp(argv[5], "trace")) {
+            // progress of one launch in time: end time stamp of every wave
+            std::vector<double*> ys(nbuf);
+            std::vector<double> tms(nbuf);
+            for (int k = 0; k < nbuf; ++k) {
+                CK(hipMalloc(&ys[k], sizeof(double) * n));
+                tms[k] = T.ms(5, [&] {
+                    gkoc_csr_spmv_f64_i32(nullptr, n, n, rp0, cols, vals, b, 1, ys[k], 1, 1);
+                });
+            }
+            int kmin = 0, kmax = 0;
+            for (int k = 0; k < nbuf; ++k) {
+                if (tms[k] < tms[kmin]) kmin = k;
+                if (tms[k] > tms[kmax]) kmax = k;
+            }
+            for (int which = 0; which < 2; ++which) {
+                double* y = ys[which ? kmax : kmin];
+                const int64_t pages = int64_t(sizeof(double)) * n / 4096;
+                double tr = T.ms(3, [&] { tlb_stress_kernel<<<1024, 256>>>(y, pages, 64, ys[(kmin + 1) % nbuf]); });
+                double tw = T.ms(3, [&] { tlb_stress_write_kernel<<<1024, 256>>>(y, pages, 64); });
+                printf("%s y %p: random-page reads %.1f us, random-page writes %.1f us (16.8 M accesses each)\n",
+                       which ? "SLOWEST" : "FASTEST", (void*)y, tr * 1e3, tw * 1e3);
+            }
+            for (int k = 0; k < nbuf; ++k) printf("%.0f ", tms[k] * 1e3);
+            printf("\n");
+            const int64_t nseg = (n + 31) / 32, nw = (nseg + 1) / 2;
+            unsigned long long* ts;
+            CK(hipMalloc(&ts, 8 * nw));
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(gkoc_lab_ts), &ts, sizeof(ts)));
+            std::vector<unsigned long long> h(nw);
+            for (int which = 0; which < 2; ++which) {
+                double* y = ys[which ? kmax : kmin];
+                CK(hipMemset(ts, 0, 8 * nw));
+                for (int rep = 0; rep < 2; ++rep) {
+                    csr_spmv_pipe3_kernel<double, int, false, 32, 4, 1, 1024, 1, 16>
+                        <<<dim3(unsigned(nw)), dim3(64)>>>(n, nseg, 2, rp0, cols, vals, b, 1, y, 1,
+                                                           1, nullptr, nullptr);
+                    CK(hipDeviceSynchronize());
+                }
+                CK(hipMemcpy(h.data(), ts, 8 * nw, hipMemcpyDeviceToHost));
+                unsigned long long t0 = ~0ull, t1 = 0;
+                for (auto v : h) {
+                    if (v && v < t0) t0 = v;
+                    if (v > t1) t1 = v;
+                }
+                printf("%s y (%.1f us by events): span of wave end stamps %.1f us (100 MHz clock)\n",
+                       which ? "SLOWEST" : "FASTEST", (which ? tms[kmax] : tms[kmin]) * 1e3,
+                       (t1 - t0) / 100.0);
+                // time needed for each 1/32 of the waves (by median end stamp)
+                const int NC = 32;
+                std::vector<double> med(NC);
+                for (int cidx = 0; cidx < NC; ++cidx) {
+                    std::vector<unsigned long long> v(h.begin() + nw * cidx / NC,
+                                                      h.begin() + nw * (cidx + 1) / NC);
+                    std::sort(v.begin(), v.end());
+                    med[cidx] = (v[v.size() / 2] - t0) / 100.0;
+                }
+                printf("   median end time of each 1/32 of the rows [us]:");
+                for (int cidx = 0; cidx < NC; ++cidx) printf(" %.0f", med[cidx]);
+                printf("\n   increments [us]:");
+                for (int cidx = 1; cidx < NC; ++cidx) printf(" %.1f", med[cidx] - med[cidx - 1]);
+                printf("\n");
+            }
+            return 0;
+        }
         if (argc > 5 && !strcmp(argv[5], "factor")) {
             struct slot { int *r, *c; double *v, *b, *y; };
             std::vector<slot> S(nbuf);
