@@ -39,11 +39,14 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     GKOC_REQUIRE(ldc >= nrhs && (n_cols == 0 || ldb >= nrhs), GKOC_E_INVALID,
                  "stride smaller than nrhs");
     if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
-    // 32-row segments, 2 segments (64 rows) per wavefront; in-order dispatch
-    // keeps the set of resident waves on a compact window of rows, which is
-    // what lets the b-vector lines shared by neighbouring rows hit in L2
-    constexpr int rows_per_seg = 32;
+    // 64-row segments (lane = row in the row phase), 2 segments = 128 rows per
+    // wavefront, whose 1 KB of results is written in one burst at the end of
+    // the wave (mode 0x2000); in-order dispatch keeps the set of resident
+    // waves on a compact window of rows, which is what lets the b-vector lines
+    // shared by neighbouring rows hit in L2
+    constexpr int rows_per_seg = 64;
     constexpr int segs_per_wave = 2;
+    constexpr int mode = 0x2000;
     const int64_t n_seg = ceildiv(n_rows, rows_per_seg);
     const int64_t n_waves = ceildiv(n_seg, segs_per_wave);
     GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED,
@@ -55,12 +58,12 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
         reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;
     if (vec_ok) {
-        csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, 4, 1, 1024, 1>
+        csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, 4, 1, 1024, 1, mode>
             <<<grid, block, 0, as_stream(s)>>>(
                 n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb,
                 c, ldc, static_cast<int>(nrhs), alpha, beta);
     } else {
-        csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, 1, 4, 1024, 1>
+        csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, 1, 4, 1024, 1, mode>
             <<<grid, block, 0, as_stream(s)>>>(
                 n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb,
                 c, ldc, static_cast<int>(nrhs), alpha, beta);
@@ -86,7 +89,7 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
     GKOC_REQUIRE(row_ptrs && b && c && work, GKOC_E_INVALID, "null pointer");
     GKOC_REQUIRE(work_bytes >= fused_workspace_bytes(n, sizeof(T)), GKOC_E_WORKSPACE,
                  "workspace too small (gkoc_x_workspace_bytes)");
-    constexpr int rows_per_seg = 32;
+    constexpr int rows_per_seg = 64;
     constexpr int segs_per_wave = 2;
     const int64_t n_seg = ceildiv(n, rows_per_seg);
     const int64_t n_waves = ceildiv(n_seg, segs_per_wave);
@@ -99,12 +102,12 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
         reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
         reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;
     if (vec_ok) {
-        csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 4, 1, 1024, 1, 64>
+        csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 4, 1, 1024, 1, 0x2040>
             <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs,
                                                col_idxs, vals, b, 1, c, 1, 1,
                                                nullptr, nullptr, partial);
     } else {
-        csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 1, 4, 1024, 1, 64>
+        csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 1, 4, 1024, 1, 0x2040>
             <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs,
                                                col_idxs, vals, b, 1, c, 1, 1,
                                                nullptr, nullptr, partial);

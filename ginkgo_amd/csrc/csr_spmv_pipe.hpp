@@ -56,6 +56,12 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     static_assert(ROWS == 32 || ROWS == 64, "ROWS must be 32 or 64");
     constexpr int MASK = RING - 1;
     constexpr bool DOT = (ABL & 64) != 0;
+    // DEFER = n > 0: the wave keeps the results of its (at most n) row segments
+    // in registers and writes them in one burst at its end - >= 1 KB of
+    // contiguous output per wave instead of one 256 B piece per segment
+    // (sparse small writes between the read streams cost several times their
+    // byte share at the memory side)
+    constexpr int DEFER = (ABL >> 12) & 15;
     __shared__ __attribute__((aligned(16))) T ring[RING];
 
     const int lane = threadIdx.x;
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
         seg_rows(seg, rs, re, seg_end);
         if (seg + 1 < se) seg_rows(seg + 1, nrs, nre, nseg_end);
         T sum = T(0);
+        T ys[DEFER > 0 ? DEFER : 1];
         {
             const int64_t row = seg * ROWS + lane;
             if (ADV && beta != T(0) && lane < ROWS && row < n_rows) {
@@ -219,7 +226,11 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                     if (DOT && lane < ROWS && row < n_rows) {
                         dot_acc += bj[row * ldb] * sum;
                     }
-                    if (lane < ROWS && row < n_rows) {
+                    if (DEFER > 0) {
+                        const int kseg = int(seg - sb);
+#pragma unroll
+                        for (int t = 0; t < DEFER; ++t) ys[t] = t == kseg ? sum : ys[t];
+                    } else if (lane < ROWS && row < n_rows) {
                         if (ABL & 32) {
                             __builtin_nontemporal_store(sum, &c[row * ldc + j]);
                         } else {
@@ -254,6 +265,13 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
             p_load += G;
             produced += G;
             use_a = !use_a;
+        }
+        if (DEFER > 0) {
+#pragma unroll
+            for (int t = 0; t < DEFER; ++t) {
+                const int64_t row = (sb + t) * ROWS + lane;
+                if (sb + t < se && lane < ROWS && row < n_rows) c[row * ldc + j] = ys[t];
+            }
         }
     }
     if (DOT) {

@@ -97,6 +97,58 @@ __global__ __launch_bounds__(64) void stream_private_kernel(
     if (acc == 12345.678) out[0] = acc;
 }
 
+// same, plus the SpMV's output pattern: each wave stores 64 consecutive doubles
+template <int NPW, int MODE>
+__global__ __launch_bounds__(64) void stream_private_store_kernel(
+    int64_t nnz, const double* __restrict__ vals, const int* __restrict__ cols,
+    const double* __restrict__ bvec, const int* __restrict__ rp, double* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const int64_t base = int64_t(blockIdx.x) * NPW;
+    constexpr int IT = (NPW + 255) / 256;
+    double2 v0[IT], v1[IT];
+    int4 c[IT];
+    int rpv = 0;
+    if (MODE & 2) rpv = rp[int64_t(blockIdx.x) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int64_t k = base + i * 256 + lane * 4;
+        const bool in = i * 256 + lane * 4 < NPW && k + 4 <= nnz;
+        const int64_t kk = in ? k : 0;
+        v0[i] = *reinterpret_cast<const double2*>(vals + kk);
+        v1[i] = *reinterpret_cast<const double2*>(vals + kk + 2);
+        c[i] = *reinterpret_cast<const int4*>(cols + kk);
+    }
+    double acc = double(rpv);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        acc += v0[i].x + v0[i].y + v1[i].x + v1[i].y + double(c[i].x + c[i].y + c[i].z + c[i].w);
+    }
+    if (MODE & 4) acc += bvec[int64_t(blockIdx.x) * 64 + lane];
+    constexpr int FL = (MODE >> 4) & 15;   // store flavour
+    constexpr int CL = MODE >> 8;          // clustering: one wave in 2^CL stores 2^CL * 512 B
+    if (CL > 0) {
+        if (MODE & 1) {
+            if ((blockIdx.x & ((1 << CL) - 1)) == 0) {
+                double* d0 = out + int64_t(blockIdx.x) * 64;
+                for (int i = lane; i < (64 << CL); i += 64) d0[i] = acc;
+            }
+        } else if (acc == 12345.678) out[0] = acc;
+        return;
+    }
+    double* dst = out + int64_t(blockIdx.x) * 64 + lane;
+    if (MODE & 1) {
+        if (FL == 0) *dst = acc;
+        else if (FL == 1) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst), "v"(acc) : "memory");
+        else if (FL == 2) asm volatile("global_store_dwordx2 %0, %1, off sc0" ::"v"(dst), "v"(acc) : "memory");
+        else if (FL == 3) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(acc) : "memory");
+        else if (FL == 4) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(acc) : "memory");
+        else if (FL == 5) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(acc) : "memory");
+        else if (FL == 6) asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" ::"v"(dst), "v"(acc) : "memory");
+        else if (FL == 7) asm volatile("global_store_dwordx2 %0, %1, off sc0 nt" ::"v"(dst), "v"(acc) : "memory");
+    } else if (acc == 12345.678) out[0] = acc;
+}
+
 // ------------------------------------------------- classical (Ginkgo-like)
 // SUB lanes per row, shuffle reduction (common/cuda_hip csr classical idea)
 template <int SUB>
@@ -320,8 +372,40 @@ int main(int argc, char** argv)
             if (t > tmax) { tmax = t; y_slow = yc; }
         }
         printf("output-buffer candidates: fastest %.4f ms, slowest %.4f ms\n", tmin, tmax);
+        fflush(stdout);
     }
 
+    if (!pmc_mode) {
+        // minimal reproducer: private stream reads (+ row_ptrs, + b[row]) + the y store
+        const unsigned nwv = unsigned(n / 64);
+        for (int which = 0; which < 2; ++which) {
+            double* yy = which ? y_slow : y_fast;
+            const char* tag = which ? "Y-" : "Y+";
+            char nm[96];
+            ms = T.ms(reps, [&] { stream_private_store_kernel<1728, 0><<<nwv, 64>>>(nnz, vals, cols, x, row_ptrs, yy); });
+            snprintf(nm, 96, "repro %s: stream only", tag); report(nm, ms, double(nnz) * 12);
+            ms = T.ms(reps, [&] { stream_private_store_kernel<1728, 1><<<nwv, 64>>>(nnz, vals, cols, x, row_ptrs, yy); });
+            snprintf(nm, 96, "repro %s: stream + y store", tag); report(nm, ms, double(nnz) * 12 + 8.0 * n);
+            ms = T.ms(reps, [&] { stream_private_store_kernel<1728, 3><<<nwv, 64>>>(nnz, vals, cols, x, row_ptrs, yy); });
+            snprintf(nm, 96, "repro %s: stream + rp + y store", tag); report(nm, ms, double(nnz) * 12 + 12.0 * n);
+            ms = T.ms(reps, [&] { stream_private_store_kernel<1728, 7><<<nwv, 64>>>(nnz, vals, cols, x, row_ptrs, yy); });
+            snprintf(nm, 96, "repro %s: stream + rp + b[row] + y store", tag); report(nm, ms, double(nnz) * 12 + 20.0 * n);
+#define REPRO_FL(FL, NAME)                                                                  \
+    ms = T.ms(reps, [&] { stream_private_store_kernel<1728, 1 + 16 * FL><<<nwv, 64>>>(nnz, vals, cols, x, row_ptrs, yy); }); \
+    snprintf(nm, 96, "repro %s: stream + y store [" NAME "]", tag); report(nm, ms, double(nnz) * 12 + 8.0 * n);
+            REPRO_FL(1, "nt")
+            REPRO_FL(16, "1 wave in 2 stores 1 KB")
+            REPRO_FL(32, "1 in 4: 2 KB")
+            REPRO_FL(48, "1 in 8: 4 KB")
+            REPRO_FL(64, "1 in 16: 8 KB")
+            REPRO_FL(96, "1 in 64: 32 KB")
+            REPRO_FL(128, "1 in 256: 128 KB")
+            ms = T.ms(reps, [&] {
+                gkoc_csr_spmv_f64_i32(nullptr, n, n, row_ptrs, cols, vals, x, 1, yy, 1, 1);
+            });
+            snprintf(nm, 96, "repro %s: full SpMV", tag); report(nm, ms, bytes);
+        }
+    }
     if (pmc_mode) {
         ms = T.ms(reps, [&] { stream_read_kernel<<<2048, 256>>>(nnz, vals, cols, y); });
         report("ceiling: read val+col, 8B+4B loads", ms, double(nnz) * 12);
@@ -436,16 +520,13 @@ int main(int argc, char** argv)
     y = rep == 0 ? y_fast : y_slow;
     printf("--- variants on the %s output buffer\n", rep == 0 ? "FASTEST (Y+)" : "SLOWEST (Y-)");
     RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0)
-    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x300)
-    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x500)
-    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x700)
-    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 1)
-    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 2)
-    RUN_PIPE3(32, 1, 4, 1024, 1, 2, 0)
-    RUN_PIPE3(32, 2, 2, 1024, 1, 2, 0)
-    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 32)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 1, 0)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2000)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 3, 0x3000)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 4, 0x4000)
+    RUN_PIPE3(64, 4, 1, 2048, 1, 2, 0x2000)
     RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0)
-    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 32)
     }
     // ELL / SELL-P through the library entry points (formats built on device)
     {
