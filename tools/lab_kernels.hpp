@@ -693,4 +693,184 @@ __global__ __launch_bounds__(128) void csr_spmv_pair_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Variant 5 (lab): pipe3's structure with THREE register sets and hand-counted
+// waits.  hipcc guards the tail cases of pipe3's stream loads with branches,
+// and its s_waitcnt pass then falls back to vmcnt(0) before the gather - the
+// stream load issued one step earlier is waited for in full, every step
+// (ISA of pipe3: "s_waitcnt vmcnt(0)" ahead of the four gather loads).  Here
+// every VMEM operation of the steady state is an asm statement the compiler
+// does not count, issued in a fixed order per step
+//     gather(group i)  ->  stream load(group i+2)  ->  s_waitcnt vmcnt(3)
+// so that the only thing a step waits for is its own gather (and the stream
+// load issued a whole step earlier), while 6 KB of stream data stay in flight.
+// fp64 / int32, one right-hand side, unit strides, no long rows, and the padded
+// stream range of every wave must lie inside the arrays (lab only).
+typedef double lab_d2 __attribute__((ext_vector_type(2)));
+typedef int lab_i4 __attribute__((ext_vector_type(4)));
+
+struct lab_set {
+    lab_d2 v0, v1;
+    lab_i4 c;
+};
+
+template <int RING, int ABL = 0>
+__global__ __launch_bounds__(64) void csr_spmv_pipe5_kernel(
+    int64_t n_rows, int64_t n_segments, int64_t segs_per_wave,
+    const int* __restrict__ row_ptrs, const int* __restrict__ cols,
+    const double* __restrict__ vals, const double* __restrict__ b,
+    double* __restrict__ c)
+{
+    constexpr int ROWS = 64, E = 4, G = 256;
+    constexpr int MASK = RING - 1;
+    __shared__ __attribute__((aligned(16))) double ring[RING];
+    const int lane = threadIdx.x;
+    const int64_t sb = int64_t(blockIdx.x) * segs_per_wave;
+    const int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
+    if (sb >= se) return;
+    const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;
+    const int64_t K0 = row_ptrs[sb * ROWS];
+    const int64_t K1 = row_ptrs[row_e];
+    const int64_t NNZ = row_ptrs[n_rows];
+    const int64_t K0a = K0 & ~int64_t(E - 1);
+    const int k1o = int(K1 - K0a);
+    const int nnzo = (NNZ - K0a) > int64_t(0x7fffff00) ? 0x7fffff00 : int(NNZ - K0a);
+    const double* vals0 = vals + K0a;
+    const int* cols0 = cols + K0a;
+
+    // lane's stream position; lanes past the wave's range (or the arrays) keep
+    // re-reading the wave's first vector - branch-free and always in bounds
+    auto issue_load = [&](lab_set& S, int p) {
+        int k = p + lane * E;
+        k = (k < k1o && k + E <= nnzo) ? k : 0;
+        const double* pv = vals0 + k;
+        const int* pc = cols0 + k;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.v0) : "v"(pv) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(S.v1) : "v"(pv) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.c) : "v"(pc) : "memory");
+    };
+    double x0, x1, x2, x3;
+    auto issue_gather = [&](const lab_set& S) {
+        if (ABL & 1) {
+            x0 = S.c.x; x1 = S.c.y; x2 = S.c.z; x3 = S.c.w;
+            return;
+        }
+        const unsigned o0 = unsigned(S.c.x) * 8u, o1 = unsigned(S.c.y) * 8u,
+                       o2 = unsigned(S.c.z) * 8u, o3 = unsigned(S.c.w) * 8u;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(x0) : "v"(o0), "s"(b) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(x1) : "v"(o1), "s"(b) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(x2) : "v"(o2), "s"(b) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(x3) : "v"(o3), "s"(b) : "memory");
+    };
+    auto write_products = [&](const lab_set& S, int p) {
+        const int k = p + lane * E;
+        lab_d2 p0, p1;
+        p0.x = S.v0.x * x0;
+        p0.y = S.v0.y * x1;
+        p1.x = S.v1.x * x2;
+        p1.y = S.v1.y * x3;
+        *reinterpret_cast<lab_d2*>(&ring[k & MASK]) = p0;
+        *reinterpret_cast<lab_d2*>(&ring[(k + 2) & MASK]) = p1;
+    };
+
+    lab_set S0, S1, S2;
+    issue_load(S0, 0);
+    issue_load(S1, G);
+    // everything outstanding so far must land before the loop (row_ptrs too)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0.v0), "+v"(S0.v1), "+v"(S0.c), "+v"(S1.v0), "+v"(S1.v1), "+v"(S1.c)::"memory");
+    int p_load = 2 * G;
+    int produced = 0;
+    int cons = int(K0 - K0a);
+
+    int64_t seg = sb;
+    auto seg_rows = [&](int64_t s, int& rs, int& re, int& s_end) {
+        const int64_t row = s * ROWS + lane;
+        const int64_t last = (s + 1) * ROWS < n_rows ? (s + 1) * ROWS : n_rows;
+        const bool valid = row < n_rows;
+        rs = int(int64_t(row_ptrs[valid ? row : last]) - K0a);
+        re = int(int64_t(row_ptrs[valid ? row + 1 : last]) - K0a);
+        s_end = int(int64_t(row_ptrs[last]) - K0a);
+    };
+    int rs, re, seg_end, nrs = 0, nre = 0, nseg_end = 0;
+    seg_rows(seg, rs, re, seg_end);
+    if (seg + 1 < se) seg_rows(seg + 1, nrs, nre, nseg_end);
+    double sum = 0;
+    double ys0 = 0, ys1 = 0;
+
+    // one produce step: X = set to turn into products, Y = next set (its loads
+    // are older than X's gather), Z = free set that receives group i+2
+#define LAB_STEP(X, Y, Z)                                                          \
+    {                                                                              \
+        issue_gather(X);                                                           \
+        issue_load(Z, p_load);                                                     \
+        if (ABL & 1) {                                                             \
+            asm volatile("s_waitcnt vmcnt(3)"                                      \
+                         : "+v"(X.v0), "+v"(X.v1), "+v"(Y.v0), "+v"(Y.v1), "+v"(Y.c)::"memory"); \
+        } else {                                                                   \
+            asm volatile("s_waitcnt vmcnt(3)"                                      \
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(X.v0), "+v"(X.v1), \
+                           "+v"(Y.v0), "+v"(Y.v1), "+v"(Y.c)::"memory");           \
+        }                                                                          \
+        write_products(X, produced);                                               \
+        p_load += G;                                                               \
+        produced += G;                                                             \
+    }
+
+    // row phases until the next produce step is possible (or the wave is done)
+    auto row_phases = [&]() {
+        while (seg < se && (produced >= seg_end || produced + G - cons > RING)) {
+            const int upto = produced < seg_end ? produced : seg_end;
+            wave_lds_sync();
+            if (!(ABL & 2)) {
+                int k = rs > cons ? rs : cons;
+                const int e_ = re < upto ? re : upto;
+                for (; k + 4 <= e_; k += 4) {
+                    const double t0 = ring[k & MASK];
+                    const double t1 = ring[(k + 1) & MASK];
+                    const double t2 = ring[(k + 2) & MASK];
+                    const double t3 = ring[(k + 3) & MASK];
+                    sum += t0;
+                    sum += t1;
+                    sum += t2;
+                    sum += t3;
+                }
+                for (; k < e_; ++k) sum += ring[k & MASK];
+            }
+            wave_lds_sync();
+            cons = upto;
+            if (cons >= seg_end) {
+                if (seg == sb) ys0 = sum; else ys1 = sum;
+                ++seg;
+                rs = nrs;
+                re = nre;
+                seg_end = nseg_end;
+                if (seg + 1 < se) seg_rows(seg + 1, nrs, nre, nseg_end);
+                sum = 0;
+            }
+        }
+    };
+    // the three sets keep their registers: the rotation is unrolled, never
+    // expressed as data movement (a copy of a set with a load in flight would
+    // copy stale registers)
+    for (;;) {
+        row_phases();
+        if (seg >= se) break;
+        LAB_STEP(S0, S1, S2)
+        row_phases();
+        if (seg >= se) break;
+        LAB_STEP(S1, S2, S0)
+        row_phases();
+        if (seg >= se) break;
+        LAB_STEP(S2, S0, S1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        const int64_t r0 = sb * ROWS + lane, r1 = (sb + 1) * ROWS + lane;
+        if (r0 < n_rows) c[r0] = ys0;
+        if (sb + 1 < se && r1 < n_rows) c[r1] = ys1;
+    }
+#undef LAB_STEP
+}
+
 }  // namespace gkoc

@@ -516,17 +516,28 @@ int main(int argc, char** argv)
                " gb=" #GB " spw=" #SPW " abl=" #ABL, ms, bytes);                 \
         if (!(ABL & 3)) check("pair", true);                                     \
     }
+#define RUN_PIPE5(RING, ABL)                                                     \
+    {                                                                            \
+        const int64_t nsg = (n + 63) / 64;                                       \
+        const int64_t nw = (nsg + 1) / 2;                                        \
+        ms = T.ms(reps, [&] {                                                    \
+            csr_spmv_pipe5_kernel<RING, ABL>                                     \
+                <<<dim3(unsigned(nw)), dim3(64)>>>(n, nsg, 2, row_ptrs, cols,    \
+                                                   vals, x, y);                  \
+        });                                                                      \
+        report("pipe5 (3 sets, counted waits) ring=" #RING " abl=" #ABL, ms, bytes); \
+        if (!((ABL) & 3)) check("pipe5", true);                                  \
+    }
     for (int rep = 0; rep < 2; ++rep) {
     y = rep == 0 ? y_fast : y_slow;
     printf("--- variants on the %s output buffer\n", rep == 0 ? "FASTEST (Y+)" : "SLOWEST (Y-)");
-    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 1, 0)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0)
     RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2000)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 3, 0x3000)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 4, 0x4000)
-    RUN_PIPE3(64, 4, 1, 2048, 1, 2, 0x2000)
-    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0)
+    RUN_PIPE5(1024, 0)
+    RUN_PIPE5(2048, 0)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2001)
+    RUN_PIPE5(1024, 1)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2000)
+    RUN_PIPE5(1024, 0)
     }
     // ELL / SELL-P through the library entry points (formats built on device)
     {
