@@ -710,10 +710,20 @@ __global__ __launch_bounds__(128) void csr_spmv_pair_kernel(
 typedef double lab_d2 __attribute__((ext_vector_type(2)));
 typedef int lab_i4 __attribute__((ext_vector_type(4)));
 
+typedef int lab_i2 __attribute__((ext_vector_type(2)));
+// element t of a 256-nonzero group: v0/c0 = nonzeros 2*lane, 2*lane+1;
+// v1/c1 = nonzeros 128 + 2*lane, 129 + 2*lane  (every load instruction covers
+// whole cache lines exactly once: 1 KB / 1 KB / 512 B / 512 B)
 struct lab_set {
     lab_d2 v0, v1;
-    lab_i4 c;
+    lab_i2 c0, c1;
 };
+
+#define LAB_LD(MODSTR)                                                                        \
+    asm volatile("global_load_dwordx4 %0, %1, off" MODSTR : "=v"(S.v0) : "v"(pv) : "memory");   \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:1024" MODSTR : "=v"(S.v1) : "v"(pv) : "memory"); \
+    asm volatile("global_load_dwordx2 %0, %1, off" MODSTR : "=v"(S.c0) : "v"(pc) : "memory");   \
+    asm volatile("global_load_dwordx2 %0, %1, off offset:512" MODSTR : "=v"(S.c1) : "v"(pc) : "memory");
 
 template <int RING, int ABL = 0>
 __global__ __launch_bounds__(64) void csr_spmv_pipe5_kernel(
@@ -741,44 +751,49 @@ __global__ __launch_bounds__(64) void csr_spmv_pipe5_kernel(
 
     // lane's stream position; lanes past the wave's range (or the arrays) keep
     // re-reading the wave's first vector - branch-free and always in bounds
+    constexpr int MOD = (ABL >> 4) & 7;
     auto issue_load = [&](lab_set& S, int p) {
-        int k = p + lane * E;
-        k = (k < k1o && k + E <= nnzo) ? k : 0;
-        const double* pv = vals0 + k;
-        const int* pc = cols0 + k;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.v0) : "v"(pv) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(S.v1) : "v"(pv) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(S.c) : "v"(pc) : "memory");
+        // the whole 256-nonzero group must be inside the wave's padded range and
+        // the arrays; otherwise re-read the wave's first group (lab simplification)
+        const int pp = (p + G <= nnzo) ? p : 0;
+        const double* pv = vals0 + pp + 2 * lane;
+        const int* pc = cols0 + pp + 2 * lane;
+        if (MOD == 0) { LAB_LD("") }
+        else if (MOD == 1) { LAB_LD(" nt") }
+        else if (MOD == 2) { LAB_LD(" sc1") }
+        else if (MOD == 3) { LAB_LD(" sc0 sc1") }
+        else if (MOD == 4) { LAB_LD(" sc1 nt") }
+        else { LAB_LD(" sc0 sc1 nt") }
     };
     double x0, x1, x2, x3;
     auto issue_gather = [&](const lab_set& S) {
         if (ABL & 1) {
-            x0 = S.c.x; x1 = S.c.y; x2 = S.c.z; x3 = S.c.w;
+            x0 = S.c0.x; x1 = S.c0.y; x2 = S.c1.x; x3 = S.c1.y;
             return;
         }
-        const unsigned o0 = unsigned(S.c.x) * 8u, o1 = unsigned(S.c.y) * 8u,
-                       o2 = unsigned(S.c.z) * 8u, o3 = unsigned(S.c.w) * 8u;
+        const unsigned o0 = unsigned(S.c0.x) * 8u, o1 = unsigned(S.c0.y) * 8u,
+                       o2 = unsigned(S.c1.x) * 8u, o3 = unsigned(S.c1.y) * 8u;
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(x0) : "v"(o0), "s"(b) : "memory");
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(x1) : "v"(o1), "s"(b) : "memory");
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(x2) : "v"(o2), "s"(b) : "memory");
         asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(x3) : "v"(o3), "s"(b) : "memory");
     };
     auto write_products = [&](const lab_set& S, int p) {
-        const int k = p + lane * E;
+        const int k = p + 2 * lane;
         lab_d2 p0, p1;
         p0.x = S.v0.x * x0;
         p0.y = S.v0.y * x1;
         p1.x = S.v1.x * x2;
         p1.y = S.v1.y * x3;
         *reinterpret_cast<lab_d2*>(&ring[k & MASK]) = p0;
-        *reinterpret_cast<lab_d2*>(&ring[(k + 2) & MASK]) = p1;
+        *reinterpret_cast<lab_d2*>(&ring[(k + 128) & MASK]) = p1;
     };
 
     lab_set S0, S1, S2;
     issue_load(S0, 0);
     issue_load(S1, G);
     // everything outstanding so far must land before the loop (row_ptrs too)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0.v0), "+v"(S0.v1), "+v"(S0.c), "+v"(S1.v0), "+v"(S1.v1), "+v"(S1.c)::"memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0.v0), "+v"(S0.v1), "+v"(S0.c0), "+v"(S0.c1), "+v"(S1.v0), "+v"(S1.v1), "+v"(S1.c0), "+v"(S1.c1)::"memory");
     int p_load = 2 * G;
     int produced = 0;
     int cons = int(K0 - K0a);
@@ -805,12 +820,12 @@ __global__ __launch_bounds__(64) void csr_spmv_pipe5_kernel(
         issue_gather(X);                                                           \
         issue_load(Z, p_load);                                                     \
         if (ABL & 1) {                                                             \
-            asm volatile("s_waitcnt vmcnt(3)"                                      \
-                         : "+v"(X.v0), "+v"(X.v1), "+v"(Y.v0), "+v"(Y.v1), "+v"(Y.c)::"memory"); \
+            asm volatile("s_waitcnt vmcnt(4)"                                      \
+                         : "+v"(X.v0), "+v"(X.v1), "+v"(Y.v0), "+v"(Y.v1), "+v"(Y.c0), "+v"(Y.c1)::"memory"); \
         } else {                                                                   \
-            asm volatile("s_waitcnt vmcnt(3)"                                      \
+            asm volatile("s_waitcnt vmcnt(4)"                                      \
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(X.v0), "+v"(X.v1), \
-                           "+v"(Y.v0), "+v"(Y.v1), "+v"(Y.c)::"memory");           \
+                           "+v"(Y.v0), "+v"(Y.v1), "+v"(Y.c0), "+v"(Y.c1)::"memory"); \
         }                                                                          \
         write_products(X, produced);                                               \
         p_load += G;                                                               \

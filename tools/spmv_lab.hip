@@ -533,11 +533,15 @@ int main(int argc, char** argv)
     printf("--- variants on the %s output buffer\n", rep == 0 ? "FASTEST (Y+)" : "SLOWEST (Y-)");
     RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2000)
     RUN_PIPE5(1024, 0)
+    RUN_PIPE5(1024, 0x10)
+    RUN_PIPE5(1024, 0x20)
+    RUN_PIPE5(1024, 0x30)
+    RUN_PIPE5(1024, 0x40)
+    RUN_PIPE5(1024, 0x50)
     RUN_PIPE5(2048, 0)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2001)
-    RUN_PIPE5(1024, 1)
+    RUN_PIPE5(2048, 0x10)
+    RUN_PIPE5(2048, 0x40)
     RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2000)
-    RUN_PIPE5(1024, 0)
     }
     // ELL / SELL-P through the library entry points (formats built on device)
     {
