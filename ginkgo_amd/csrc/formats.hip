@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(
     int nrhs, const T* __restrict__ alpha_p, const T* __restrict__ beta_p)
 {
     const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (row >= n_rows) return;
+    const bool active = row < n_rows;
     T alpha = T(1), beta = T(0);
     if (ADV) {
         alpha = alpha_p[0];
@@ -101,9 +101,15 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(
     }
     for (int j = 0; j < nrhs; ++j) {
         T sum = T(0);
-        if (ADV && beta != T(0)) sum = beta * c[row * ldc + j];
-        sum = fmt_row_sum<T, I, ADV>(sum, k_per_row, row, stride, cols, vals, b, ldb, j, alpha);
-        c[row * ldc + j] = sum;
+        if (active) {
+            if (ADV && beta != T(0)) sum = beta * c[row * ldc + j];
+            sum = fmt_row_sum<T, I, ADV>(sum, k_per_row, row, stride, cols, vals, b, ldb, j, alpha);
+        }
+        // the block's four waves write their 2 KB of results together: sparse
+        // 512 B writes between the read streams cost a multiple of their
+        // byte share
+        __syncthreads();
+        if (active) c[row * ldc + j] = sum;
     }
 }
 
@@ -117,8 +123,8 @@ __global__ __launch_bounds__(256) void sellp_spmv_kernel(
     const T* __restrict__ beta_p)
 {
     const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (row >= n_rows) return;
-    const int64_t slice = row / slice_size;
+    const bool active = row < n_rows;
+    const int64_t slice = (active ? row : n_rows - 1) / slice_size;
     const int64_t local = row - slice * slice_size;
     const int64_t len = int64_t(slice_lengths[slice]);
     const int64_t base = int64_t(slice_sets[slice]) * slice_size + local;
@@ -129,9 +135,12 @@ __global__ __launch_bounds__(256) void sellp_spmv_kernel(
     }
     for (int j = 0; j < nrhs; ++j) {
         T sum = T(0);
-        if (ADV && beta != T(0)) sum = c[row * ldc + j] * beta;
-        sum = fmt_row_sum<T, I, ADV>(sum, len, base, slice_size, cols, vals, b, ldb, j, alpha);
-        c[row * ldc + j] = sum;
+        if (active) {
+            if (ADV && beta != T(0)) sum = c[row * ldc + j] * beta;
+            sum = fmt_row_sum<T, I, ADV>(sum, len, base, slice_size, cols, vals, b, ldb, j, alpha);
+        }
+        __syncthreads();   // one 2 KB output burst per block, see ell_spmv_kernel
+        if (active) c[row * ldc + j] = sum;
     }
 }
 
