@@ -104,3 +104,21 @@ timeit("step_2 + norm2", pair_step2, 48 * n)
 timeit("x_cg_step_2_norm", lambda: call("gkoc_x_cg_step_2_norm_f64", S(), n, x.values, r.values, p.values,
                                         q.values, prev.values, rho.values, stop, res.values, C.c_int(1),
                                         work, wb), 48 * n)
+
+# ---- GMRES(30) + block-Jacobi(8): time per iteration (fixed iteration count)
+import time  # noqa: E402
+for ortho in ("mgs", "cgs"):
+    gm = (g.Gmres.build().with_krylov_dim(30).with_ortho_method(ortho)
+          .with_criteria(g.stop.Iteration.build().with_max_iters(60),
+                         g.stop.ResidualNorm.build().with_reduction_factor(1e-30))
+          .with_generated_preconditioner(jac).on(ex).generate(a))
+    rhs = g.Dense.from_numpy(ex, np.ones(n))
+    sol = g.Dense.from_numpy(ex, np.zeros(n))
+    gm.apply(rhs, sol)
+    torch.cuda.synchronize()
+    sol.fill(0.0)
+    t0 = time.perf_counter()
+    gm.apply(rhs, sol)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"GMRES(30) {ortho:4s} + block-Jacobi(8): {gm.num_iterations} its, {dt*1e6/gm.num_iterations:9.1f} us/it")
