@@ -1,0 +1,141 @@
+"""Parity at BASELINE.json's full sizes (27-pt 256^3: n = 16 777 216, nnz = 449 455 096),
+where the CPU oracle is too slow to be the checker: size-independent properties
+with closed forms (exact in fp64 because all values are small integers),
+cross-format identity, symmetry / linearity, and a true-residual check of the
+CG + block-Jacobi(8) solve (configs[2])."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GRID = 256
+N = GRID ** 3
+
+
+@pytest.fixture(scope="module")
+def big(gexec):
+    import ginkgo_amd as g
+    a = g.stencil_csr(gexec, 3, GRID)
+    return g, a
+
+
+def _box3_zero_padded(x3):
+    """sum over the 3x3x3 neighbourhood inside the domain (zero outside)"""
+    out = x3.copy()
+    for ax in range(3):
+        s = out.copy()
+        lo = [slice(None)] * 3
+        hi = [slice(None)] * 3
+        lo[ax], hi[ax] = slice(1, None), slice(None, -1)
+        s[tuple(lo)] += out[tuple(hi)]
+        s[tuple(hi)] += out[tuple(lo)]
+        out = s
+    return out
+
+
+def test_structure_and_row_sums(gexec, big):
+    g, a = big
+    assert a.get_num_stored_elements() == (3 * GRID - 2) ** 3 == 449455096
+    rp = a.row_ptrs.cpu().numpy()
+    assert rp[0] == 0 and rp[-1] == 449455096
+    c = np.full(GRID, 3, np.int64)
+    c[0] = c[-1] = 2
+    cnt = (c[:, None, None] * c[None, :, None] * c[None, None, :]).reshape(-1)   # z, y, x
+    assert np.array_equal(np.diff(rp), cnt)
+    assert a.is_sorted_by_column_index()
+    ones = g.Dense.from_numpy(gexec, np.ones(N))
+    y = g.Dense.create(gexec, (N, 1))
+    a.apply(ones, y)
+    # diag 26, off-diagonals -1:  (A 1)_i = 26 - (#neighbours) = 27 - cnt_i, exact
+    assert np.array_equal(y.to_numpy()[:, 0], (27 - cnt).astype(np.float64))
+
+
+def test_linear_field_closed_form(gexec, big):
+    """x = i + 3 j + 7 k (integers): y = 27 x - box3(x) exactly; 0 in the interior"""
+    g, a = big
+    k, j, i = np.meshgrid(np.arange(GRID), np.arange(GRID), np.arange(GRID), indexing="ij")
+    x3 = (i + 3 * j + 7 * k).astype(np.float64)
+    expect = 27.0 * x3 - _box3_zero_padded(x3)
+    assert np.all(expect[1:-1, 1:-1, 1:-1] == 0)
+    y = g.Dense.create(gexec, (N, 1))
+    a.apply(g.Dense.from_numpy(gexec, x3.reshape(-1)), y)
+    assert np.array_equal(y.to_numpy()[:, 0], expect.reshape(-1))
+
+
+def test_formats_agree_bit_for_bit(gexec, big):
+    g, a = big
+    x = g.Dense.from_numpy(gexec, np.random.default_rng(42).uniform(-1, 1, N))
+    y0 = g.Dense.create(gexec, (N, 1))
+    a.apply(x, y0)
+    ref = y0.to_numpy()
+    for fmt in (a.convert_to_ell(), a.convert_to_sellp()):
+        y = g.Dense.create(gexec, (N, 1))
+        fmt.apply(x, y)
+        assert np.array_equal(y.to_numpy(), ref)
+        del fmt, y
+        torch.cuda.empty_cache()
+    # advanced apply: 2 A x - y0 = y0 up to the rounding of a different association
+    c = g.Dense.from_numpy(gexec, ref[:, 0])
+    a.apply(g.scalar(gexec, 2.0), x, g.scalar(gexec, -1.0), c)
+    d = np.abs(c.to_numpy() - ref)
+    assert d.max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_symmetry_and_reductions(gexec, big):
+    g, a = big
+    rng = np.random.default_rng(7)
+    u, v = rng.uniform(-1, 1, N), rng.uniform(-1, 1, N)
+    du, dv = g.Dense.from_numpy(gexec, u), g.Dense.from_numpy(gexec, v)
+    au, av = g.Dense.create(gexec, (N, 1)), g.Dense.create(gexec, (N, 1))
+    a.apply(du, au)
+    a.apply(dv, av)
+    s1, s2 = g.Dense.create(gexec, (1, 1)), g.Dense.create(gexec, (1, 1))
+    dv.compute_dot(au, s1)       # v' A u
+    du.compute_dot(av, s2)       # u' A v
+    a1, a2 = s1.to_numpy()[0, 0], s2.to_numpy()[0, 0]
+    assert abs(a1 - a2) <= 1e-12 * max(abs(a1), 1.0) * 27
+    # exactly representable reductions (any summation tree gives the same value)
+    ones = g.Dense.from_numpy(gexec, np.ones(N))
+    ones.compute_dot(ones, s1)
+    assert s1.to_numpy()[0, 0] == float(N)
+    ones.compute_norm2(s1)
+    assert s1.to_numpy()[0, 0] == 4096.0
+    # block-Jacobi(8): symmetric positive definite like the blocks it inverts
+    m = g.Jacobi.build().with_max_block_size(8).on(gexec).generate(a)
+    assert m.get_num_blocks() == N // 8
+    mu, mv = g.Dense.create(gexec, (N, 1)), g.Dense.create(gexec, (N, 1))
+    m.apply(du, mu)
+    m.apply(dv, mv)
+    dv.compute_dot(mu, s1)
+    du.compute_dot(mv, s2)
+    assert abs(s1.to_numpy()[0, 0] - s2.to_numpy()[0, 0]) <= 1e-12 * N ** 0.5
+    du.compute_dot(mu, s1)
+    assert s1.to_numpy()[0, 0] > 0
+
+
+def test_cg_block_jacobi_full_size(gexec, big):
+    """configs[2]: CG + block-Jacobi(8), ResidualNorm 1e-10 (rhs_norm), rhs = ones,
+    x0 = 0.  Checked by the TRUE residual through an independent kernel (ELL) and
+    by the mirror symmetry of the solution."""
+    g, a = big
+    rhs = g.Dense.from_numpy(gexec, np.ones(N))
+    x = g.Dense.from_numpy(gexec, np.zeros(N))
+    s = (g.Cg.build()
+         .with_criteria(g.stop.Iteration.build().with_max_iters(3000),
+                        g.stop.ResidualNorm.build().with_reduction_factor(1e-10))
+         .with_preconditioner(g.Jacobi.build().with_max_block_size(8))
+         .on(gexec).generate(a))
+    s.apply(rhs, x)
+    assert s.has_converged and 50 < s.num_iterations < 3000
+    ell = a.convert_to_ell()
+    r = g.Dense.from_numpy(gexec, np.ones(N))
+    ell.apply(g.scalar(gexec, -1.0), x, g.scalar(gexec, 1.0), r)   # r = b - A x
+    nr = g.Dense.create(gexec, (1, 1))
+    r.compute_norm2(nr)
+    assert nr.to_numpy()[0, 0] <= 1.05e-10 * 4096.0
+    x3 = x.to_numpy()[:, 0].reshape(GRID, GRID, GRID)
+    scale = np.abs(x3).max()
+    for ax in range(3):
+        assert np.abs(x3 - np.flip(x3, axis=ax)).max() <= 1e-7 * scale
+    assert np.abs(x3 - x3.transpose(2, 1, 0)).max() <= 1e-7 * scale
