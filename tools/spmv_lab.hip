@@ -131,7 +131,14 @@ __global__ __launch_bounds__(64) void stream_private_store_kernel(
         if (MODE & 1) {
             if ((blockIdx.x & ((1 << CL) - 1)) == 0) {
                 double* d0 = out + int64_t(blockIdx.x) * 64;
-                for (int i = lane; i < (64 << CL); i += 64) d0[i] = acc;
+                if (FL == 9) {
+                    // the same bytes with 16 B per lane (one 1 KB store instruction each)
+                    for (int i = 2 * lane; i < (64 << CL); i += 128) {
+                        *reinterpret_cast<double2*>(d0 + i) = make_double2(acc, acc);
+                    }
+                } else {
+                    for (int i = lane; i < (64 << CL); i += 64) d0[i] = acc;
+                }
             }
         } else if (acc == 12345.678) out[0] = acc;
         return;
@@ -395,6 +402,8 @@ int main(int argc, char** argv)
     snprintf(nm, 96, "repro %s: stream + y store [" NAME "]", tag); report(nm, ms, double(nnz) * 12 + 8.0 * n);
             REPRO_FL(1, "nt")
             REPRO_FL(16, "1 wave in 2 stores 1 KB")
+            REPRO_FL(25, "1 in 2: 1 KB, one dwordx4 store")
+            REPRO_FL(41, "1 in 4: 2 KB, two dwordx4 stores")
             REPRO_FL(32, "1 in 4: 2 KB")
             REPRO_FL(48, "1 in 8: 4 KB")
             REPRO_FL(64, "1 in 16: 8 KB")
