@@ -8,12 +8,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 # the bench line and the kernel-trace statistics come from ONE process (the
-# default bench command under rocprofv3 --kernel-trace --stats), so the kernel's
+# default bench command, minus the CPU baseline whose 256 OpenMP threads crawl
+# under the tracer, under rocprofv3 --kernel-trace --stats), so the kernel's
 # average duration in the trace and bench.py's own HIP-event figure describe
 # the same launches (different processes land on different placements, 3.2)
 echo "== default bench command under rocprofv3 --kernel-trace --stats"
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
-    python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 > $OUT/trace_run.txt 2>&1
+    python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu > $OUT/trace_run.txt 2>&1
 grep '^{"metric"' $OUT/trace_run.txt | tail -1 | tee $OUT/bench_line.json
 find $OUT/trace -name "*kernel_stats*" | head -1 | xargs -r head -12
 i=0
