@@ -157,6 +157,32 @@ int gkoc_malloc(void** ptr, size_t bytes)
     return GKOC_OK;
 }
 
+int gkoc_malloc_host(void** ptr, size_t bytes)
+{
+    GKOC_REQUIRE(ptr, GKOC_E_INVALID, "ptr == NULL");
+    *ptr = nullptr;
+    if (bytes == 0) return GKOC_OK;
+    GKOC_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return GKOC_OK;
+}
+
+int gkoc_free_host(void* ptr)
+{
+    if (ptr) GKOC_HIP(hipHostFree(ptr));
+    return GKOC_OK;
+}
+
+int gkoc_malloc_managed(void** ptr, size_t bytes, unsigned int flags)
+{
+    GKOC_REQUIRE(ptr, GKOC_E_INVALID, "ptr == NULL");
+    GKOC_REQUIRE(flags == hipMemAttachGlobal || flags == hipMemAttachHost,
+                 GKOC_E_INVALID, "flags must be 1 (attach global) or 2 (attach host)");
+    *ptr = nullptr;
+    if (bytes == 0) return GKOC_OK;
+    GKOC_HIP(hipMallocManaged(ptr, bytes, flags));
+    return GKOC_OK;
+}
+
 int gkoc_free(void* ptr)
 {
     if (ptr) GKOC_HIP(hipFree(ptr));

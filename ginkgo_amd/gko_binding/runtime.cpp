@@ -89,9 +89,14 @@ HipUnifiedAllocator::HipUnifiedAllocator(int device_id, unsigned int flags)
     : device_id_{device_id}, flags_{flags}
 {}
 
-void* HipUnifiedAllocator::allocate(size_type) GKO_NOT_SUPPORTED(this);
+void* HipUnifiedAllocator::allocate(size_type num_bytes)
+{
+    void* p = nullptr;
+    GKOC_CALL(gkoc_malloc_managed(&p, num_bytes, flags_));
+    return p;
+}
 
-void HipUnifiedAllocator::deallocate(void*) {}
+void HipUnifiedAllocator::deallocate(void* dev_ptr) { gkoc_free(dev_ptr); }
 
 bool HipUnifiedAllocator::check_environment(int device_id, GKO_HIP_STREAM_STRUCT*) const
 {
@@ -100,9 +105,14 @@ bool HipUnifiedAllocator::check_environment(int device_id, GKO_HIP_STREAM_STRUCT
 
 HipHostAllocator::HipHostAllocator(int device_id) : device_id_{device_id} {}
 
-void* HipHostAllocator::allocate(size_type) GKO_NOT_SUPPORTED(this);
+void* HipHostAllocator::allocate(size_type num_bytes)
+{
+    void* p = nullptr;
+    GKOC_CALL(gkoc_malloc_host(&p, num_bytes));
+    return p;
+}
 
-void HipHostAllocator::deallocate(void*) {}
+void HipHostAllocator::deallocate(void* ptr) { gkoc_free_host(ptr); }
 
 bool HipHostAllocator::check_environment(int device_id, GKO_HIP_STREAM_STRUCT*) const
 {

@@ -71,7 +71,13 @@ int gkoc_get_device_info(int device_id, gkoc_device_info* info);
 int gkoc_set_device(int device_id);
 int gkoc_get_device(int* device_id);
 int gkoc_malloc(void** ptr, size_t bytes);
-int gkoc_free(void* ptr);
+int gkoc_free(void* ptr);               /* device and managed memory */
+/* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,
+ * flags = hipMemAttachGlobal 1 / hipMemAttachHost 2): hip_hooks.cpp:60-100,
+ * hip/base/memory.hip.cpp */
+int gkoc_malloc_host(void** ptr, size_t bytes);
+int gkoc_free_host(void* ptr);
+int gkoc_malloc_managed(void** ptr, size_t bytes, unsigned int flags);
 int gkoc_memcpy_h2d(void* dst, const void* src_host, size_t bytes, gkoc_stream_t s);
 int gkoc_memcpy_d2h(void* dst_host, const void* src, size_t bytes, gkoc_stream_t s);
 int gkoc_memcpy_d2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s);
