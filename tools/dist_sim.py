@@ -1,0 +1,103 @@
+"""GPU-side cost of ONE rank of an N-rank z-slab run, on a single GPU: the
+communicator is replaced by device copies of the right sizes (the values that
+arrive are wrong, the kernels and their ordering are the real ones).  Gives the
+per-iteration device time of the distributed CG without RCCL latency.
+usage: python tools/dist_sim.py [grid=256] [world=8] [rank=3] [iters=200]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+
+import ginkgo_amd as g
+import ginkgo_amd.distributed as gd
+
+grid = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+rank = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+plane = grid * grid
+ex = g.Cdna4Executor.create(0)
+part = gd.SlabPartition(grid, world)
+lo, hi = part.range_of(rank)
+
+
+class FakeComm:
+    """every peer behaves like a translated copy of this rank"""
+    host_staging = False
+
+    def __init__(self):
+        self.rank, self.size = rank, world
+
+    def all_reduce_sum_(self, t):
+        return t
+
+    def all_to_all_counts(self, send_counts):
+        return list(send_counts)
+
+    def all_to_all_v(self, recv, send, recv_counts, send_counts, async_op=False):
+        if recv.dtype == torch.int64:
+            # peers ask for the planes next to the ones we ask them for
+            out, off = [], 0
+            for p, c in enumerate(recv_counts):
+                seg = send[off:off + c]
+                out.append(seg + plane if p < rank else seg - plane)
+                off += c
+            recv.copy_(torch.cat(out) if out else send)
+        else:
+            recv.copy_(send)
+        return None
+
+
+z0, z1 = part.plane_offsets[rank], part.plane_offsets[rank + 1]
+owned = g.stencil_csr(ex, 3, grid, z0=z0, nz=z1 - z0)
+be = gd.HipBackend(ex)
+a = gd.DistributedMatrix(be, FakeComm(), part, owned)
+print(f"rank {rank}/{world} of {grid}^3: {hi-lo} rows, halo {a.n_halo} values in, {a.n_send} out")
+x = be.vector_from(np.random.default_rng(1).uniform(-1, 1, hi - lo))
+y = be.vector(hi - lo)
+for _ in range(5):
+    a.apply(x, y)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50):
+    a.apply(x, y)
+e1.record()
+torch.cuda.synchronize()
+print(f"distributed SpMV (pack + copy-exchange on 2nd stream || local + boundary rows): {e0.elapsed_time(e1)*20:.1f} us")
+for fused in (False, True):
+    s = gd.DistributedCg(be, FakeComm(), a, iters, 1e-300, 8, fused=fused)
+    rhs = be.vector_from(np.ones(hi - lo))
+    xs = be.vector(hi - lo)
+    s.apply(rhs, xs)
+    torch.cuda.synchronize()
+    xs.fill(0.0)
+    t = time.perf_counter()
+    s.apply(rhs, xs)
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t
+    print(f"DistributedCg fused={fused!s:5s}: {s.num_iterations} its, {t*1e6/max(s.num_iterations,1):8.1f} us/it "
+          f"(device side, no RCCL latency) -> {max(s.num_iterations,1)/t:8.1f} it/s")
+
+# ---- pieces of the distributed SpMV
+def tm(name, fn, reps=100):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"   {name:46s} {e0.elapsed_time(e1)*1e3/reps:8.1f} us")
+
+
+tm("local SpMV only (local columns)", lambda: be.spmv(a.local, x, y))
+tm("pack (row_gather of the send planes)", lambda: be.gather(x, a.send_idx, a.send_buf))
+tm("boundary rows (rowlist += halo part)", lambda: be.rowlist_add(a.nl, a.recv_buf, y))
+tm("copy 'exchange' alone", lambda: a.recv_buf.values.copy_(a.send_buf.values))
+tm("whole distributed apply", lambda: a.apply(x, y))
