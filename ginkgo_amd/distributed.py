@@ -254,14 +254,18 @@ class HipBackend:
     # memory are enqueued, the host looks at the answer when the event is done
     _NSLOT = 16
 
-    def check_begin(self, tau, tau0, factor, stop):
+    def check_begin(self, tau, tau0, factor, stop, squared=False):
+        """squared: tau holds ||r||^2; the criterion kernel of ImplicitResidualNorm
+        (sqrt(|tau|) <= factor * tau0, residual_norm.cpp:209-230) then saves the
+        separate sqrt launch"""
         if not hasattr(self, "_chk_dev"):
             self._chk_dev = self.exec.zeros((self._NSLOT, 2), torch.uint8)
             self._chk_host = torch.zeros((self._NSLOT, 2), dtype=torch.uint8).pin_memory()
             self._chk_next = 0
         slot = self._chk_next
         self._chk_next = (slot + 1) % self._NSLOT
-        call("gkoc_residual_norm_" + VT[tau.dtype], self.exec.stream, 1, tau.values, tau0.values,
+        name = "gkoc_implicit_residual_norm_" if squared else "gkoc_residual_norm_"
+        call(name + VT[tau.dtype], self.exec.stream, 1, tau.values, tau0.values,
              C.c_double(factor) if tau.dtype == torch.float64 else C.c_float(factor),
              C.c_uint8(2), C.c_int(1), stop, self._chk_dev[slot], None, None)
         self._chk_host[slot].copy_(self._chk_dev[slot], non_blocking=True)
@@ -275,6 +279,7 @@ class HipBackend:
         return bool(self._chk_host[slot, 0].item())
 
     max_check_lag = 6       # must stay below _NSLOT
+    check_takes_squared_norm = True
 
     def residual_check(self, tau, tau0, factor, stop, flags):
         allc, chg = C.c_int(0), C.c_int(0)
@@ -434,8 +439,12 @@ class DistributedCg:
                 if stopped is not None:
                     it = stopped
                 break
-            be.sqrt_(tau)
-            pending.append((it, be.check_begin(tau, self.tau0, self.factor, self.stop)))
+            if getattr(be, "check_takes_squared_norm", False):
+                tok = be.check_begin(tau, self.tau0, self.factor, self.stop, squared=True)
+            else:
+                be.sqrt_(tau)
+                tok = be.check_begin(tau, self.tau0, self.factor, self.stop)
+            pending.append((it, tok))
             stopped = self._drain(pending, it - self.check_lag)
             if stopped is not None:
                 it = stopped
