@@ -39,15 +39,17 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     GKOC_REQUIRE(ldc >= nrhs && (n_cols == 0 || ldb >= nrhs), GKOC_E_INVALID,
                  "stride smaller than nrhs");
     if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
-    // 64-row segments (lane = row in the row phase), 2 segments = 128 rows per
-    // wavefront, whose 1 KB of results is written in one burst at the end of
-    // the wave (mode 0x2000); in-order dispatch keeps the set of resident
-    // waves on a compact window of rows, which is what lets the b-vector lines
-    // shared by neighbouring rows hit in L2
+    // 64-row segments (lane = row in the row phase).  Large matrices: 2 segments
+    // = 128 rows per wavefront, whose 1 KB of results is written in one burst at
+    // the end of the wave (mode 0x2000).  Below 65536 segments (4 M rows) the
+    // grid is only a few rounds of the 5120 resident waves deep and the tail
+    // dominates: one segment per wave then (+1 % at 2 M rows, +7 % at 0.9 M,
+    // +15 % at 0.26 M rows).  In-order dispatch keeps the set of resident waves
+    // on a compact window of rows, which is what lets the b-vector lines shared
+    // by neighbouring rows hit in L2.
     constexpr int rows_per_seg = 64;
-    constexpr int segs_per_wave = 2;
-    constexpr int mode = 0x2000;
     const int64_t n_seg = ceildiv(n_rows, rows_per_seg);
+    const int segs_per_wave = n_seg < 65536 ? 1 : 2;
     const int64_t n_waves = ceildiv(n_seg, segs_per_wave);
     GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED,
                  "more than 2^31 row segments");
@@ -57,17 +59,25 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     const bool vec_ok =
         reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
         reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;
+#define GKOC_LAUNCH_PIPE3(E_, U_, MODE_)                                       \
+    csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, E_, U_, 1024, 1, MODE_>     \
+        <<<grid, block, 0, as_stream(s)>>>(                                    \
+            n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, \
+            ldc, static_cast<int>(nrhs), alpha, beta)
     if (vec_ok) {
-        csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, 4, 1, 1024, 1, mode>
-            <<<grid, block, 0, as_stream(s)>>>(
-                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb,
-                c, ldc, static_cast<int>(nrhs), alpha, beta);
+        if (segs_per_wave == 2) {
+            GKOC_LAUNCH_PIPE3(4, 1, 0x2000);
+        } else {
+            GKOC_LAUNCH_PIPE3(4, 1, 0x1000);
+        }
     } else {
-        csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, 1, 4, 1024, 1, mode>
-            <<<grid, block, 0, as_stream(s)>>>(
-                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb,
-                c, ldc, static_cast<int>(nrhs), alpha, beta);
+        if (segs_per_wave == 2) {
+            GKOC_LAUNCH_PIPE3(1, 4, 0x2000);
+        } else {
+            GKOC_LAUNCH_PIPE3(1, 4, 0x1000);
+        }
     }
+#undef GKOC_LAUNCH_PIPE3
     GKOC_LAUNCH_OK();
     return GKOC_OK;
 }

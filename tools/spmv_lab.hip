@@ -541,11 +541,11 @@ int main(int argc, char** argv)
     y = rep == 0 ? y_fast : y_slow;
     printf("--- variants on the %s output buffer\n", rep == 0 ? "FASTEST (Y+)" : "SLOWEST (Y-)");
     RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2000)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2400)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2500)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2600)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2700)
-    RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2800)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 1, 0x1000)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 1, 0)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 2, 0x2000)
+    RUN_PIPE3(32, 4, 1, 1024, 1, 1, 0)
+    RUN_PIPE3(64, 4, 1, 1024, 1, 4, 0x4000)
     RUN_PIPE3(64, 4, 1, 1024, 1, 2, 0x2000)
     }
     // ELL / SELL-P through the library entry points (formats built on device)
