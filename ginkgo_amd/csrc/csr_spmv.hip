@@ -59,16 +59,19 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     const bool vec_ok =
         reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
         reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;
+    // 32 B of values per lane and load: 4 doubles or 8 floats (ring = 8 KB)
+    constexpr int EV = 32 / sizeof(T);
+    constexpr int RINGV = 8192 / sizeof(T);
 #define GKOC_LAUNCH_PIPE3(E_, U_, MODE_)                                       \
-    csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, E_, U_, 1024, 1, MODE_>     \
+    csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, E_, U_, RINGV, 1, MODE_>    \
         <<<grid, block, 0, as_stream(s)>>>(                                    \
             n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, \
             ldc, static_cast<int>(nrhs), alpha, beta)
     if (vec_ok) {
         if (segs_per_wave == 2) {
-            GKOC_LAUNCH_PIPE3(4, 1, 0x2000);
+            GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);
         } else {
-            GKOC_LAUNCH_PIPE3(4, 1, 0x1000);
+            GKOC_LAUNCH_PIPE3(EV, 1, 0x1000);
         }
     } else {
         if (segs_per_wave == 2) {
