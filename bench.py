@@ -32,28 +32,39 @@ def spmv_algorithmic_bytes(n_rows, n_cols, nnz, val_bytes=8, idx_bytes=4):
         n_cols * val_bytes + n_rows * val_bytes
 
 
-def cpu_baseline(grid, budget_s=12.0):
-    """Time the CPU reference on rank 0: 27-pt `grid`^3 CSR SpMV (fp64/int32).
+def cpu_baseline(grid, csr_host=None, budget_s=12.0):
+    """Time the CPU reference on rank 0 on the SAME matrix as the GPU run
+    (`csr_host` = (row_ptrs, cols, vals) copied back from the device; generated
+    by the oracle when absent): 27-pt `grid`^3 CSR SpMV (fp64/int32).
     kind = "reference": gko::OmpExecutor from the unmodified reference built
-    into oracle/_ref; kind = "port": the sequential plain-C oracle."""
+    into oracle/_ref (strategy classical); kind = "port": the sequential plain-C
+    oracle.  The vectors are allocated once; only `apply` calls are timed."""
+    import ctypes as C
     import numpy as np
     from oracle import gko_oracle as o
-    row_ptrs, cols, vals = o.stencil_csr(3, grid)
-    n, nnz = grid ** 3, len(vals)
-    b = np.random.default_rng(42).uniform(-1, 1, n)
+    own = csr_host is not None
+    if csr_host is None:
+        csr_host = o.stencil_csr(3, grid)
+    row_ptrs, cols, vals = csr_host
+    n, nnz = len(row_ptrs) - 1, len(vals)
+    b = np.random.default_rng(42).uniform(-1, 1, n).reshape(n, 1)
+    out = np.zeros((n, 1))
     nbytes = spmv_algorithmic_bytes(n, n, nnz)
-    kind, cores, fn = "port", 1, None
+    kind, cores, fn, keep = "port", 1, None, None
     try:
         from oracle import ref_shim
         if ref_shim.available():
             cores = os.cpu_count() or 1
-            h = ref_shim.CsrHandle("omp", row_ptrs, cols, vals)
-            fn = lambda: h.spmv(b)
+            keep = ref_shim.CsrHandle("omp", row_ptrs, cols, vals)
+            rl = ref_shim.lib()
+            pb, po = b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)
+            one = C.c_int64(1)
+            fn = lambda: rl.ref_csr_spmv(keep.h, pb, one, po, one, one)
             kind = "reference"
     except Exception:
         fn = None
     if fn is None:
-        fn = lambda: o.csr_spmv(row_ptrs, cols, vals, b)
+        fn = lambda: o.csr_spmv(row_ptrs, cols, vals, b[:, 0])
     fn()
     t0 = time.perf_counter()
     reps = 0
@@ -65,8 +76,9 @@ def cpu_baseline(grid, budget_s=12.0):
             break
     return {"value": round(nbytes * reps / el / 1e9, 3), "unit": "GB/s",
             "cores": cores, "kind": kind,
-            "sample": f"27-pt {grid}^3 CSR SpMV fp64/int32, {reps} reps in "
-                      f"{el:.1f} s"}
+            "sample": f"27-pt {grid}^3 CSR SpMV fp64/int32"
+                      f"{' (the matrix of the GPU run, copied to the host)' if own else ''}, "
+                      f"{reps} reps in {el:.1f} s"}
 
 
 def main():
@@ -77,7 +89,9 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--cg-iters", type=int, default=100,
                     help="fixed CG iterations timed for the iters/s figure")
-    ap.add_argument("--cpu-grid", type=int, default=128)
+    ap.add_argument("--cpu-grid", type=int, default=0,
+                    help="0 = time the CPU reference on the GPU run's own matrix; "
+                         "otherwise a separately generated grid^3 matrix")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--placement", type=int, default=6,
                     help="extra output allocations to re-time the kernel on (diagnostic)")
@@ -254,7 +268,11 @@ def main():
                 "frac_at_min": round(per_gpu_bytes / (min(alt) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "n": len(alt)}
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_grid)
+            if args.cpu_grid:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_grid)
+            else:
+                host = tuple(t.cpu().numpy() for t in (a.row_ptrs, a.col_idxs, a.values))
+                out["cpu_baseline"] = cpu_baseline(grid, host)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
