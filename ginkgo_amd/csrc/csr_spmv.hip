@@ -131,55 +131,129 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
 
 // ---- diagonal extraction / sortedness / per-row sort ---------------------
 
+// One wave per 64 rows: the rows' contiguous column-index (and value) range is
+// staged in LDS with coalesced loads, lane = row then works on its row there.
+// Segments longer than the stage fall back to walking global memory per lane.
+constexpr int row_stage_cap = 2048;
+
+template <typename I>
+struct row_segment {
+    int64_t row, rs, re, K0, K1;
+    bool valid;
+};
+
+template <typename I>
+__device__ __forceinline__ row_segment<I> load_row_segment(int64_t n_rows,
+                                                           const I* row_ptrs)
+{
+    row_segment<I> g;
+    const int64_t first = int64_t(blockIdx.x) * 64;
+    g.row = first + threadIdx.x;
+    g.valid = g.row < n_rows;
+    const int64_t last = first + 64 < n_rows ? first + 64 : n_rows;
+    g.rs = row_ptrs[g.valid ? g.row : last];
+    g.re = row_ptrs[g.valid ? g.row + 1 : last];
+    g.K0 = row_ptrs[first];
+    g.K1 = row_ptrs[last];
+    return g;
+}
+
 template <typename T, typename I>
-__global__ __launch_bounds__(256) void extract_diag_kernel(
+__global__ __launch_bounds__(64) void extract_diag_kernel(
     int64_t n_diag, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
     const T* __restrict__ vals, T* __restrict__ diag)
 {
-    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (row >= n_diag) return;
+    __shared__ I lc[row_stage_cap];
+    const row_segment<I> g = load_row_segment<I>(n_diag, row_ptrs);
+    const bool staged = g.K1 - g.K0 <= row_stage_cap;
+    if (staged) {
+        for (int i = threadIdx.x; i < int(g.K1 - g.K0); i += 64) lc[i] = cols[g.K0 + i];
+        wave_lds_sync();
+    }
+    if (!g.valid) return;
     T d = T(0);
-    for (int64_t k = row_ptrs[row]; k < row_ptrs[row + 1]; ++k) {
-        if (int64_t(cols[k]) == row) {
+    for (int64_t k = g.rs; k < g.re; ++k) {
+        const I c = staged ? lc[k - g.K0] : cols[k];
+        if (int64_t(c) == g.row) {
             d = vals[k];
             break;
         }
     }
-    diag[row] = d;
+    diag[g.row] = d;
 }
 
 template <typename I>
-__global__ __launch_bounds__(256) void is_sorted_kernel(
+__global__ __launch_bounds__(64) void is_sorted_kernel(
     int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
     int* __restrict__ flag)
 {
-    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (row >= n_rows) return;
+    __shared__ I lc[row_stage_cap];
+    const row_segment<I> g = load_row_segment<I>(n_rows, row_ptrs);
+    const bool staged = g.K1 - g.K0 <= row_stage_cap;
+    if (staged) {
+        for (int i = threadIdx.x; i < int(g.K1 - g.K0); i += 64) lc[i] = cols[g.K0 + i];
+        wave_lds_sync();
+    }
     bool ok = true;
-    for (int64_t k = row_ptrs[row] + 1; k < row_ptrs[row + 1]; ++k) {
-        if (cols[k - 1] > cols[k]) {
-            ok = false;
-            break;
+    if (g.valid) {
+        for (int64_t k = g.rs + 1; k < g.re; ++k) {
+            const I a = staged ? lc[k - 1 - g.K0] : cols[k - 1];
+            const I b = staged ? lc[k - g.K0] : cols[k];
+            if (a > b) {
+                ok = false;
+                break;
+            }
         }
     }
-    if (!ok) atomicAnd(flag, 0);
+    if (__any(!ok) && threadIdx.x == 0) atomicAnd(flag, 0);
 }
 
 // stable insertion sort per row (rows are short on this path; Ginkgo only
 // calls it when is_sorted_by_column_index returned false)
 template <typename T, typename I>
-__global__ __launch_bounds__(256) void sort_rows_kernel(
+__global__ __launch_bounds__(64) void sort_rows_kernel(
     int64_t n_rows, const I* __restrict__ row_ptrs, I* __restrict__ cols,
     T* __restrict__ vals)
 {
-    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (row >= n_rows) return;
-    const int64_t a = row_ptrs[row], e = row_ptrs[row + 1];
-    for (int64_t i = a + 1; i < e; ++i) {
+    __shared__ I lc[row_stage_cap];
+    __shared__ T lv[row_stage_cap];
+    const row_segment<I> g = load_row_segment<I>(n_rows, row_ptrs);
+    const bool staged = g.K1 - g.K0 <= row_stage_cap;
+    if (staged) {
+        const int seg = int(g.K1 - g.K0);
+        for (int i = threadIdx.x; i < seg; i += 64) {
+            lc[i] = cols[g.K0 + i];
+            lv[i] = vals[g.K0 + i];
+        }
+        wave_lds_sync();
+        if (g.valid) {
+            const int a = int(g.rs - g.K0), e = int(g.re - g.K0);
+            for (int i = a + 1; i < e; ++i) {
+                const I ci = lc[i];
+                const T vi = lv[i];
+                int k = i - 1;
+                while (k >= a && lc[k] > ci) {
+                    lc[k + 1] = lc[k];
+                    lv[k + 1] = lv[k];
+                    --k;
+                }
+                lc[k + 1] = ci;
+                lv[k + 1] = vi;
+            }
+        }
+        wave_lds_sync();
+        for (int i = threadIdx.x; i < seg; i += 64) {
+            cols[g.K0 + i] = lc[i];
+            vals[g.K0 + i] = lv[i];
+        }
+        return;
+    }
+    if (!g.valid) return;
+    for (int64_t i = g.rs + 1; i < g.re; ++i) {
         const I ci = cols[i];
         const T vi = vals[i];
         int64_t k = i - 1;
-        while (k >= a && cols[k] > ci) {
+        while (k >= g.rs && cols[k] > ci) {
             cols[k + 1] = cols[k];
             vals[k + 1] = vals[k];
             --k;
@@ -228,7 +302,7 @@ using namespace gkoc;
         const int64_t nd = n_rows < n_cols ? n_rows : n_cols;                  \
         if (nd <= 0) return GKOC_OK;                                           \
         extract_diag_kernel<T, I>                                              \
-            <<<dim3(unsigned(ceildiv(nd, 256))), dim3(256), 0, as_stream(s)>>>( \
+            <<<dim3(unsigned(ceildiv(nd, 64))), dim3(64), 0, as_stream(s)>>>(  \
                 nd, row_ptrs, col_idxs, vals, diag);                           \
         GKOC_LAUNCH_OK();                                                      \
         return GKOC_OK;                                                        \
@@ -247,7 +321,7 @@ using namespace gkoc;
         GKOC_HIP(hipMemcpyAsync(flag, &one, sizeof(int),                       \
                                 hipMemcpyHostToDevice, as_stream(s)));         \
         is_sorted_kernel<I>                                                    \
-            <<<dim3(unsigned(ceildiv(n_rows, 256))), dim3(256), 0,             \
+            <<<dim3(unsigned(ceildiv(n_rows, 64))), dim3(64), 0,               \
                as_stream(s)>>>(n_rows, row_ptrs, col_idxs, flag);              \
         GKOC_LAUNCH_OK();                                                      \
         GKOC_HIP(hipMemcpyAsync(is_sorted_host, flag, sizeof(int),             \
@@ -262,7 +336,7 @@ using namespace gkoc;
     {                                                                          \
         if (n_rows <= 0) return GKOC_OK;                                       \
         sort_rows_kernel<T, I>                                                 \
-            <<<dim3(unsigned(ceildiv(n_rows, 256))), dim3(256), 0,             \
+            <<<dim3(unsigned(ceildiv(n_rows, 64))), dim3(64), 0,               \
                as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals);              \
         GKOC_LAUNCH_OK();                                                      \
         return GKOC_OK;                                                        \

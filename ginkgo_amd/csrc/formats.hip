@@ -146,23 +146,6 @@ __global__ __launch_bounds__(256) void sellp_spmv_kernel(
 
 // ------------------------------------------------------------- conversions
 template <typename T, typename I>
-__global__ __launch_bounds__(256) void csr_to_ell_kernel(
-    int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
-    const T* __restrict__ vals, int64_t k_per_row, int64_t stride,
-    I* __restrict__ ell_cols, T* __restrict__ ell_vals)
-{
-    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (row >= n_rows) return;
-    const int64_t a = row_ptrs[row];
-    const int64_t len = row_ptrs[row + 1] - a;
-    for (int64_t i = 0; i < k_per_row; ++i) {
-        const bool in = i < len;
-        ell_vals[row + i * stride] = in ? vals[a + i] : T(0);
-        ell_cols[row + i * stride] = in ? cols[a + i] : I(-1);
-    }
-}
-
-template <typename T, typename I>
 __global__ __launch_bounds__(256) void csr_to_sellp_kernel(
     int64_t n_rows, int64_t slice_size, const I* __restrict__ row_ptrs,
     const I* __restrict__ cols, const T* __restrict__ vals,
@@ -182,6 +165,69 @@ __global__ __launch_bounds__(256) void csr_to_sellp_kernel(
         const bool in = i < len;
         s_vals[base + i * slice_size] = in ? vals[a + i] : T(0);
         s_cols[base + i * slice_size] = in ? cols[a + i] : I(-1);
+    }
+}
+
+// Staged conversion of 64 consecutive rows per wave: the rows' contiguous CSR
+// range goes through LDS with coalesced loads, then lane = row emits column j
+// of all 64 rows per step, i.e. one contiguous 512 B / 256 B run per store -
+// both sides of the copy are coalesced (the lane-walks-its-row kernels above
+// reach 0.7 TB/s).  SELLP = false: ELL, element (row, j) at row + j * stride;
+// SELLP = true (slice_size 64): (slice_sets[g] + j) * 64 + lane.  Segments with
+// more than conv_stage_cap stored elements fall back to the direct loop.
+constexpr int conv_stage_cap = 2048;
+
+template <typename T, typename I, bool SELLP>
+__global__ __launch_bounds__(64) void csr_to_colmajor_staged_kernel(
+    int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    const T* __restrict__ vals, int64_t k_per_row, int64_t stride,
+    const uint64_t* __restrict__ slice_sets, I* __restrict__ out_cols,
+    T* __restrict__ out_vals)
+{
+    __shared__ T lv[conv_stage_cap];
+    __shared__ I lc[conv_stage_cap];
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;
+    const int64_t row = g * 64 + lane;
+    const bool valid = row < n_rows;
+    const int64_t last = (g + 1) * 64 < n_rows ? (g + 1) * 64 : n_rows;
+    const int64_t rs = row_ptrs[valid ? row : last];
+    const int64_t re = row_ptrs[valid ? row + 1 : last];
+    const int64_t K0 = row_ptrs[g * 64];
+    const int64_t K1 = row_ptrs[last];
+    int64_t ncols, base, cstride;
+    if (SELLP) {
+        const int64_t s0 = int64_t(slice_sets[g]);
+        ncols = int64_t(slice_sets[g + 1]) - s0;
+        base = s0 * 64 + lane;
+        cstride = 64;
+    } else {
+        ncols = k_per_row;
+        base = row;
+        cstride = stride;
+    }
+    const int64_t len = re - rs;
+    if (K1 - K0 <= conv_stage_cap) {
+        const int seg = int(K1 - K0);
+        for (int i = lane; i < seg; i += 64) {
+            lv[i] = vals[K0 + i];
+            lc[i] = cols[K0 + i];
+        }
+        wave_lds_sync();
+        const int off = int(rs - K0);
+        if (valid) {
+            for (int64_t j = 0; j < ncols; ++j) {
+                const bool in = j < len;
+                out_vals[base + j * cstride] = in ? lv[off + int(j)] : T(0);
+                out_cols[base + j * cstride] = in ? lc[off + int(j)] : I(-1);
+            }
+        }
+    } else if (valid) {
+        for (int64_t j = 0; j < ncols; ++j) {
+            const bool in = j < len;
+            out_vals[base + j * cstride] = in ? vals[rs + j] : T(0);
+            out_cols[base + j * cstride] = in ? cols[rs + j] : I(-1);
+        }
     }
 }
 
@@ -390,9 +436,10 @@ using namespace gkoc;
         const T* vals, int64_t k, int64_t stride, I* ell_cols, T* ell_vals)    \
     {                                                                          \
         if (n_rows <= 0) return GKOC_OK;                                       \
-        csr_to_ell_kernel<T, I>                                                \
-            <<<dim3(blocks_for(n_rows)), dim3(256), 0, as_stream(s)>>>(        \
-                n_rows, row_ptrs, cols, vals, k, stride, ell_cols, ell_vals);  \
+        csr_to_colmajor_staged_kernel<T, I, false>                             \
+            <<<dim3(unsigned(ceildiv(n_rows, 64))), dim3(64), 0,               \
+               as_stream(s)>>>(n_rows, row_ptrs, cols, vals, k, stride,        \
+                               nullptr, ell_cols, ell_vals);                   \
         GKOC_LAUNCH_OK();                                                      \
         return GKOC_OK;                                                        \
     }                                                                          \
@@ -402,6 +449,14 @@ using namespace gkoc;
         const uint64_t* slice_sets, I* s_cols, T* s_vals)                      \
     {                                                                          \
         if (n_rows <= 0) return GKOC_OK;                                       \
+        if (slice_size == 64) {                                                \
+            csr_to_colmajor_staged_kernel<T, I, true>                          \
+                <<<dim3(unsigned(ceildiv(n_rows, 64))), dim3(64), 0,           \
+                   as_stream(s)>>>(n_rows, row_ptrs, cols, vals, 0, 0,         \
+                                   slice_sets, s_cols, s_vals);                \
+            GKOC_LAUNCH_OK();                                                  \
+            return GKOC_OK;                                                    \
+        }                                                                      \
         csr_to_sellp_kernel<T, I>                                              \
             <<<dim3(blocks_for(n_rows)), dim3(256), 0, as_stream(s)>>>(        \
                 n_rows, slice_size, row_ptrs, cols, vals, slice_sets, s_cols,  \

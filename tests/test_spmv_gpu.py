@@ -218,3 +218,30 @@ def test_sellp_bit_exact(gexec, oracle, nrhs, slice_size, stride_factor):
     assert np.array_equal(
         y.to_numpy(), oracle.sellp_spmv(532, slice_size, sets, lens, sc, sv, b,
                                         alpha=2.0, beta=-1.0, c=c0))
+
+
+@pytest.mark.parametrize("density,rows", [(0.3, 200), (0.02, 1000)])
+def test_setup_kernels_staged_and_fallback(gexec, oracle, density, rows):
+    """conversions, sortedness, sort and diagonal extraction go through an LDS stage
+    of 2048 elements per 64 rows; density 0.3 x 500 columns (~150 / row) exceeds it
+    and takes the direct path, density 0.02 stays inside.  Index-exact / bit-exact."""
+    import ginkgo_amd as g
+    rp, ci, v = random_csr(rows, 500, density, 17, unsorted=True, empty_rows=(3, 64))
+    a = dev_csr(g, gexec, rp, ci.copy(), v.copy(), (rows, 500))
+    assert not a.is_sorted_by_column_index()
+    a.sort_by_column_index()
+    assert a.is_sorted_by_column_index()
+    import scipy.sparse as sp
+    ref = sp.csr_matrix((v, ci, rp), shape=(rows, 500))
+    ref.sort_indices()
+    assert np.array_equal(a.col_idxs.cpu().numpy(), ref.indices)
+    assert np.array_equal(a.values.cpu().numpy(), ref.data)
+    rs, cs, vs = ref.indptr.astype(np.int32), ref.indices.astype(np.int32), ref.data
+    d = a.extract_diagonal().cpu().numpy()
+    assert np.array_equal(d, oracle.csr_extract_diagonal(rows, 500, rs, cs, vs))
+    e = a.convert_to_ell()
+    k, stride, ec, ev = oracle.csr_to_ell(rs, cs, vs)
+    assert np.array_equal(e.col_idxs.cpu().numpy(), ec) and np.array_equal(e.values.cpu().numpy(), ev)
+    sl = a.convert_to_sellp()
+    sets, lens, sc, sv = oracle.csr_to_sellp(rs, cs, vs, 64, 1)
+    assert np.array_equal(sl.col_idxs.cpu().numpy(), sc) and np.array_equal(sl.values.cpu().numpy(), sv)
