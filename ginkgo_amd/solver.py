@@ -180,7 +180,58 @@ class Cg(_IterativeSolver):
         have_tau = False
         pending = deque()
         it = -1
+
+        def precond_and_rho(rho_):
+            if fuse_prec:
+                m.apply_dot(r, z, rho_, work)
+            else:
+                m.apply(r, z)
+                r.compute_conj_dot(z, rho_)
+
+        def update(rho_, prev_rho_):
+            call("gkoc_cg_step_1_" + suf, ex.stream, rows, cols, p.values, p.ld,
+                 z.values, z.ld, rho_.values, prev_rho_.values, stop_status)
+            if fuse_spmv:
+                a.apply_dot(p, q, beta, work)
+            else:
+                a.apply(p, q)
+                p.compute_conj_dot(q, beta)
+            if fuse_norm:
+                call("gkoc_x_cg_step_2_norm_" + suf, ex.stream, rows, x.values, r.values,
+                     p.values, q.values, beta.values, rho_.values, stop_status, tau.values,
+                     C.c_int(1), work, C.c_size_t(work.numel() * work.element_size()))
+            else:
+                call("gkoc_cg_step_2_" + suf, ex.stream, rows, cols, x.values, x.ld,
+                     r.values, r.ld, p.values, p.ld, q.values, q.ld, beta.values,
+                     rho_.values, stop_status)
+
+        # hipGraph mode (with_hip_graph(True), or "auto" = systems below 2^21 rows,
+        # where the loop is bound by host launch cost): two consecutive
+        # iterations - the rho / prev_rho roles swap back after two - are captured
+        # once and replayed; the criterion kernels inside the graph leave their
+        # flags in two device slots that are copied to pinned memory after each
+        # replay and read `check_lag` iterations later, exactly like the eager path.
+        self._graph_x_ptr = x.values.data_ptr()
+        graph = self._graph_setup(crit, fuse_norm, lag, rows, cols) if fuse_norm else None
         while True:
+            if graph is not None and have_tau and it + 2 < graph["max_iters"]:
+                graph["exec"] = self._graph_capture(
+                    graph, lambda rho_, prev_rho_: precond_and_rho(rho_),
+                    update, rho, prev_rho, tau, stop_status)
+                graph["exec"].replay()
+                stopped = None
+                for k in (0, 1):
+                    it += 1
+                    pending.append((it, [(graph["reader"], graph["reader"].adopt(graph["flags"][k]))]))
+                while pending and pending[0][0] <= it - lag:
+                    pit, ptok = pending.popleft()
+                    if crit.check_done(ptok)[0]:
+                        stopped = pit
+                        break
+                if stopped is not None:
+                    it = stopped
+                    break
+                continue
             if fuse_prec:
                 m.apply_dot(r, z, rho, work)
             else:
@@ -202,22 +253,8 @@ class Cg(_IterativeSolver):
             if stopped is not None:
                 it = stopped
                 break
-            call("gkoc_cg_step_1_" + suf, ex.stream, rows, cols, p.values, p.ld,
-                 z.values, z.ld, rho.values, prev_rho.values, stop_status)
-            if fuse_spmv:
-                a.apply_dot(p, q, beta, work)
-            else:
-                a.apply(p, q)
-                p.compute_conj_dot(q, beta)
-            if fuse_norm:
-                call("gkoc_x_cg_step_2_norm_" + suf, ex.stream, rows, x.values, r.values,
-                     p.values, q.values, beta.values, rho.values, stop_status, tau.values,
-                     C.c_int(1), work, C.c_size_t(work.numel() * work.element_size()))
-                have_tau = True
-            else:
-                call("gkoc_cg_step_2_" + suf, ex.stream, rows, cols, x.values, x.ld,
-                     r.values, r.ld, p.values, p.ld, q.values, q.ld, beta.values,
-                     rho.values, stop_status)
+            update(rho, prev_rho)
+            have_tau = fuse_norm
             prev_rho, rho = rho, prev_rho
         self.num_iterations = it
         self.stop_status = stop_status
@@ -226,6 +263,80 @@ class Cg(_IterativeSolver):
         for c in crit.criteria:
             if getattr(c, "last_tau", None) is not None and not c.implicit:
                 self.residual_norm = c.last_tau.to_numpy()[0]
+
+
+    # ------------------------------------------------------------ hipGraph
+    class _GraphFlags:
+        """reads the flags a captured criterion kernel left on the device: same
+        token protocol as stop.ResidualNorm.check_begin / check_done"""
+        _NSLOT = 32
+
+        def __init__(self, exec_):
+            self.host = torch.zeros((self._NSLOT, 2), dtype=torch.uint8).pin_memory()
+            self.next = 0
+
+        def adopt(self, dev_flags):
+            slot = self.next
+            self.next = (slot + 1) % self._NSLOT
+            self.host[slot].copy_(dev_flags, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return slot, ev
+
+        def check_done(self, token):
+            slot, ev = token
+            ev.synchronize()
+            return bool(self.host[slot, 0].item()), bool(self.host[slot, 1].item())
+
+    def _graph_setup(self, crit, fuse_norm, lag, rows, cols):
+        """None unless graph mode applies: one right-hand side, fused norm, criteria
+        made of Iteration and one ResidualNorm, lag >= 1"""
+        mode = self.params.get("hip_graph", "auto")
+        if mode is False or not fuse_norm or lag < 1 or cols != 1:
+            return None
+        if mode == "auto" and rows >= (1 << 21):
+            return None
+        rn, max_iters, rn_id = None, float("inf"), 0
+        for i, c in enumerate(crit.criteria):
+            if isinstance(c, _stop.Iteration):
+                max_iters = min(max_iters, c.max_iters)
+            elif type(c) is _stop.ResidualNorm and rn is None:
+                rn, rn_id = c, i + 1
+            else:
+                return None
+        if rn is None:
+            return None
+        g_ = self._ws.get("graph")
+        if g_ is None:
+            g_ = self._ws["graph"] = {
+                "flags": self.exec.zeros((2, 2), torch.uint8),
+                "tau0": Dense.create(self.exec, (1, 1), rn.starting_tau.dtype),
+                "reader": Cg._GraphFlags(self.exec), "exec": None, "key": None}
+        g_["tau0"].copy_from(rn.starting_tau)      # criteria are rebuilt per apply
+        g_.update(max_iters=max_iters, rn_id=rn_id, factor=rn.reduction_factor)
+        return g_
+
+    def _graph_capture(self, g_, precond_and_rho, update, rho, prev_rho, tau, stop_status):
+        key = (rho.values.data_ptr(), prev_rho.values.data_ptr(), tau.values.data_ptr(),
+               stop_status.data_ptr(), g_["rn_id"], g_["factor"],
+               tuple(v.values.data_ptr() for v in (self._ws["r"], self._ws["z"], self._ws["p"],
+                                                   self._ws["q"])), self._graph_x_ptr)
+        if g_["key"] == key and g_["exec"] is not None:
+            return g_["exec"]
+        ex = self.exec
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=ex.device)
+        side.wait_stream(torch.cuda.current_stream(ex.device))
+        with torch.cuda.graph(graph, stream=side):
+            for k, (rk, pk) in enumerate(((rho, prev_rho), (prev_rho, rho))):
+                precond_and_rho(rk, pk)
+                call("gkoc_residual_norm_" + VT[tau.dtype], ex.stream, 1, tau.values,
+                     g_["tau0"].values, _stop.cval(tau.dtype, g_["factor"]),
+                     C.c_uint8(g_["rn_id"]), C.c_int(1), stop_status, g_["flags"][k], None, None)
+                update(rk, pk)
+        torch.cuda.current_stream(ex.device).wait_stream(side)
+        g_["key"] = key
+        return graph
 
 
 class ortho_method:

@@ -570,3 +570,34 @@ def test_cg_fused_vs_unfused(gexec, bs):
     assert res[0][1] and res[1][1]
     assert abs(res[0][0] - res[1][0]) <= 1
     assert rel_frobenius(res[1][2], res[0][2]) < 1e-9
+
+
+@pytest.mark.parametrize("bs", [None, 8])
+def test_cg_hip_graph_changes_nothing(gexec, bs):
+    """two iterations captured in a hipGraph and replayed: bit-identical x,
+    iteration count and stop status vs the eager loop; reusable across applies"""
+    import ginkgo_amd as g
+    grid = 20
+    n = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    rhs = np.random.default_rng(4).uniform(-1, 1, n)
+    res = {}
+    for mode in (False, True):
+        for max_it in (1000, 7, 8):
+            f = (g.Cg.build().with_hip_graph(mode).with_criteria(
+                g.stop.Iteration.build().with_max_iters(max_it),
+                g.stop.ResidualNorm.build().with_reduction_factor(1e-10)))
+            if bs:
+                f = f.with_preconditioner(g.Jacobi.build().with_max_block_size(bs))
+            s = f.on(gexec).generate(a)
+            x = g.Dense.from_numpy(gexec, np.zeros(n))
+            for _ in range(2):                       # second apply reuses the captured graph
+                x.fill(0.0)
+                s.apply(g.Dense.from_numpy(gexec, rhs), x)
+            res[(mode, max_it)] = (s.num_iterations, s.has_converged, x.to_numpy(),
+                                   s.stop_status.cpu().numpy())
+    for max_it in (1000, 7, 8):
+        e, h = res[(False, max_it)], res[(True, max_it)]
+        assert e[0] == h[0] and e[1] == h[1]
+        assert np.array_equal(e[2], h[2]) and np.array_equal(e[3], h[3])
+    assert res[(True, 1000)][1] and res[(True, 7)][0] == 7 and not res[(True, 7)][1]
