@@ -6,11 +6,13 @@
 //   * the fused producer+reduction kernels and the asynchronous criterion check
 //     (mode "fused", default): the criterion kernel of iteration k is read
 //     `lag` iterations later from pinned memory; cg::step_1/step_2 are masked by
-//     stop_status, so the result is bit-identical to lag 0.
+//     stop_status, so the result is bit-identical to lag 0;
+//   * the same with two consecutive iterations captured as a hipGraph and
+//     replayed (mode "graph"): for launch-bound system sizes.
 // Build (g++ is enough, the device code lives in libgko_cdna4.so):
 //   g++ -O2 -std=c++17 -Iinclude examples/native_cg.cpp -Lginkgo_amd/lib \
 //       -lgko_cdna4 -Wl,-rpath,'$ORIGIN/../ginkgo_amd/lib' -o examples/native_cg
-// Run:  examples/native_cg [grid=64] [max_iters=1000] [reduction=1e-10] [plain|fused] [lag=4]
+// Run:  examples/native_cg [grid=64] [max_iters=1000] [reduction=1e-10] [plain|fused|graph] [lag=4]
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -75,10 +77,13 @@ try {
     const int64_t max_iters = argc > 2 ? atoll(argv[2]) : 1000;
     const double reduction = argc > 3 ? atof(argv[3]) : 1e-10;
     const bool fused = !(argc > 4 && !strcmp(argv[4], "plain"));
-    const int lag = fused ? (argc > 5 ? atoi(argv[5]) : 4) : 0;
+    const bool use_graph = argc > 4 && !strcmp(argv[4], "graph");
+    int lag = fused ? (argc > 5 ? atoi(argv[5]) : 4) : 0;
+    if (use_graph && lag < 1) lag = 1;
     const uint32_t bs = 8;
     const int64_t n = grid * grid * grid;
-    gkoc_stream_t s = nullptr;   // default stream
+    gkoc_stream_t s = nullptr;   // default stream; graph capture needs an explicit one
+    if (use_graph) CK(gkoc_stream_create(&s));
 
     // ---- system matrix (benchmark/utils/stencil_matrix.hpp semantics), on the device
     dev_array<int32_t> row_ptrs(n + 1);
@@ -140,23 +145,74 @@ try {
         CK(gkoc_event_synchronize(events[c.slot]));
         return flags_host[2 * c.slot] != 0;
     };
-    for (;;) {
+    auto precond_and_rho = [&](double* rho_) {
         if (fused) {
             CK(gkoc_x_jacobi_simple_apply_dot_f64_i32(s, num_blocks, n, bs, scheme, block_ptrs.p, blocks.p,
-                                                      r.p, z.p, rho, x_ws.p, x_bytes));
+                                                      r.p, z.p, rho_, x_ws.p, x_bytes));
         } else {
             CK(gkoc_jacobi_simple_apply_f64_i32(s, num_blocks, bs, scheme, block_ptrs.p, blocks.p, r.p, 1, z.p, 1, 1));
-            CK(gkoc_dense_compute_dot_f64(s, n, 1, r.p, 1, z.p, 1, rho, red_ws.p, red_bytes));
+            CK(gkoc_dense_compute_dot_f64(s, n, 1, r.p, 1, z.p, 1, rho_, red_ws.p, red_bytes));
         }
+    };
+    auto update = [&](double* rho_, double* prev_rho_) {
+        CK(gkoc_cg_step_1_f64(s, n, 1, p.p, 1, z.p, 1, rho_, prev_rho_, stop.p));
+        CK(gkoc_csr_spmv_f64_i32(s, n, n, row_ptrs.p, cols.p, vals.p, p.p, 1, q.p, 1, 1));
+        CK(gkoc_dense_compute_dot_f64(s, n, 1, p.p, 1, q.p, 1, beta, red_ws.p, red_bytes));
+        if (fused) {
+            CK(gkoc_x_cg_step_2_norm_f64(s, n, x.p, r.p, p.p, q.p, beta, rho_, stop.p, tau, 1, x_ws.p, x_bytes));
+        } else {
+            CK(gkoc_cg_step_2_f64(s, n, 1, x.p, 1, r.p, 1, p.p, 1, q.p, 1, beta, rho_, stop.p));
+        }
+    };
+    // enqueue the copy of a criterion kernel's flags into pinned memory + its event
+    auto publish = [&](int64_t iteration, const uint8_t* dev_flags) {
+        const int slot = next_slot;
+        next_slot = (next_slot + 1) % NSLOT;
+        CK(gkoc_memcpy_d2h(flags_host + 2 * slot, dev_flags, 2, s));
+        CK(gkoc_event_record(events[slot], s));
+        pending.push_back({iteration, slot});
+    };
+    auto drain = [&](int64_t upto, int64_t& stop_it) {
+        while (!pending.empty() && pending.front().it <= upto) {
+            const pending_check c = pending.front();
+            pending.pop_front();
+            if (check_done(c)) { stop_it = c.it; return true; }
+        }
+        return false;
+    };
+    gkoc_graph_t graph = nullptr;
+    dev_array<uint8_t> gflags(4);    // flags of the two captured iterations
+    for (;;) {
+        if (use_graph && have_tau && it + 2 < max_iters) {
+            if (!graph) {
+                // two iterations: the roles of rho / prev_rho are back after two swaps
+                CK(gkoc_stream_begin_capture(s));
+                double *rk = rho, *pk = prev_rho;
+                for (int k = 0; k < 2; ++k) {
+                    precond_and_rho(rk);
+                    CK(gkoc_residual_norm_f64(s, 1, tau, tau0, reduction, 2, 1, stop.p, gflags.p + 2 * k,
+                                              nullptr, nullptr));
+                    update(rk, pk);
+                    std::swap(rk, pk);
+                }
+                CK(gkoc_stream_end_capture(s, &graph));
+            }
+            CK(gkoc_graph_launch(graph, s));
+            publish(it + 1, gflags.p);
+            publish(it + 2, gflags.p + 2);
+            it += 2;
+            int64_t stop_it = it;
+            if (drain(it - lag, stop_it)) { it = stop_it; break; }
+            continue;
+        }
+        precond_and_rho(rho);
         ++it;
         bool stopped = false;
         int64_t stop_it = it;
         if (it >= max_iters) {                                  // stop::Iteration
-            for (auto& c : pending) {
-                if (check_done(c)) { stop_it = c.it; break; }
-            }
-            pending.clear();
             stopped = true;
+            drain(it, stop_it);
+            pending.clear();
         } else {
             if (!have_tau) CK(gkoc_dense_compute_norm2_f64(s, n, 1, r.p, 1, tau, red_ws.p, red_bytes));
             if (lag == 0) {                                     // lock step, as the reference
@@ -164,32 +220,18 @@ try {
                 CK(gkoc_residual_norm_f64(s, 1, tau, tau0, reduction, 2, 1, stop.p, flags_dev.p, &allc, &chg));
                 stopped = allc != 0;
             } else {                                            // stop::ResidualNorm, read `lag` iterations later
-                const int slot = next_slot;
-                next_slot = (next_slot + 1) % NSLOT;
-                CK(gkoc_residual_norm_f64(s, 1, tau, tau0, reduction, 2, 1, stop.p, flags_dev.p + 2 * slot,
-                                          nullptr, nullptr));
-                CK(gkoc_memcpy_d2h(flags_host + 2 * slot, flags_dev.p + 2 * slot, 2, s));
-                CK(gkoc_event_record(events[slot], s));
-                pending.push_back({it, slot});
-                while (!pending.empty() && pending.front().it <= it - lag) {
-                    const pending_check c = pending.front();
-                    pending.pop_front();
-                    if (check_done(c)) { stop_it = c.it; stopped = true; break; }
-                }
+                uint8_t* df = flags_dev.p + 2 * next_slot;
+                CK(gkoc_residual_norm_f64(s, 1, tau, tau0, reduction, 2, 1, stop.p, df, nullptr, nullptr));
+                publish(it, df);
+                stopped = drain(it - lag, stop_it);
             }
         }
         if (stopped) { it = stop_it; break; }
-        CK(gkoc_cg_step_1_f64(s, n, 1, p.p, 1, z.p, 1, rho, prev_rho, stop.p));
-        CK(gkoc_csr_spmv_f64_i32(s, n, n, row_ptrs.p, cols.p, vals.p, p.p, 1, q.p, 1, 1));
-        CK(gkoc_dense_compute_dot_f64(s, n, 1, p.p, 1, q.p, 1, beta, red_ws.p, red_bytes));
-        if (fused) {
-            CK(gkoc_x_cg_step_2_norm_f64(s, n, x.p, r.p, p.p, q.p, beta, rho, stop.p, tau, 1, x_ws.p, x_bytes));
-            have_tau = true;
-        } else {
-            CK(gkoc_cg_step_2_f64(s, n, 1, x.p, 1, r.p, 1, p.p, 1, q.p, 1, beta, rho, stop.p));
-        }
+        update(rho, prev_rho);
+        have_tau = fused;
         std::swap(rho, prev_rho);
     }
+    if (graph) CK(gkoc_graph_destroy(graph));
     CK(gkoc_device_synchronize());
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 
@@ -197,6 +239,7 @@ try {
     CK(gkoc_dense_copy_f64(s, n, 1, b.p, 1, r.p, 1));
     CK(gkoc_csr_advanced_spmv_f64_i32(s, n, n, neg_one, row_ptrs.p, cols.p, vals.p, x.p, 1, one, r.p, 1, 1));
     CK(gkoc_dense_compute_norm2_f64(s, n, 1, r.p, 1, tau, red_ws.p, red_bytes));
+    CK(gkoc_device_synchronize());   // the downloads below use the NULL stream
     const std::vector<double> hs = sc.download();
     const double tr = hs[tau - sc.p], bn = hs[tau0 - sc.p];
     const std::vector<uint8_t> hstop = stop.download();
@@ -207,7 +250,7 @@ try {
     }
     printf("{\"grid\": %lld, \"n\": %lld, \"nnz\": %lld, \"mode\": \"%s\", \"lag\": %d, \"iterations\": %lld, "
            "\"converged\": %s, \"true_rel_residual\": %.6e, \"x_sum\": %.17g, \"us_per_iteration\": %.2f}\n",
-           (long long)grid, (long long)n, (long long)nnz, fused ? "fused" : "plain", lag, (long long)it,
+           (long long)grid, (long long)n, (long long)nnz, use_graph ? "graph" : (fused ? "fused" : "plain"), lag, (long long)it,
            (hstop[0] & 0x80) ? "true" : "false", tr / bn, xsum, seconds * 1e6 / double(it > 0 ? it : 1));
     for (auto& e : events) gkoc_event_destroy(e);
     gkoc_free_host(flags_host);

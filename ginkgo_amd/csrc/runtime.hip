@@ -148,6 +148,42 @@ int gkoc_stream_wait_event(gkoc_stream_t s, gkoc_event_t e)
     return GKOC_OK;
 }
 
+// ---- hipGraph: capture what is enqueued on a stream, replay it
+int gkoc_stream_begin_capture(gkoc_stream_t s)
+{
+    GKOC_REQUIRE(s != nullptr, GKOC_E_INVALID,
+                 "capture needs an explicit stream (not the NULL stream)");
+    GKOC_HIP(hipStreamBeginCapture(as_stream(s), hipStreamCaptureModeThreadLocal));
+    return GKOC_OK;
+}
+
+int gkoc_stream_end_capture(gkoc_stream_t s, gkoc_graph_t* graph)
+{
+    GKOC_REQUIRE(graph, GKOC_E_INVALID, "graph == NULL");
+    *graph = nullptr;
+    hipGraph_t g = nullptr;
+    GKOC_HIP(hipStreamEndCapture(as_stream(s), &g));
+    hipGraphExec_t e = nullptr;
+    const hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    GKOC_HIP(err);
+    *graph = e;
+    return GKOC_OK;
+}
+
+int gkoc_graph_launch(gkoc_graph_t graph, gkoc_stream_t s)
+{
+    GKOC_REQUIRE(graph, GKOC_E_INVALID, "graph == NULL");
+    GKOC_HIP(hipGraphLaunch(static_cast<hipGraphExec_t>(graph), as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_graph_destroy(gkoc_graph_t graph)
+{
+    if (graph) GKOC_HIP(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph)));
+    return GKOC_OK;
+}
+
 int gkoc_malloc(void** ptr, size_t bytes)
 {
     GKOC_REQUIRE(ptr, GKOC_E_INVALID, "ptr == NULL");

@@ -94,6 +94,15 @@ int gkoc_event_record(gkoc_event_t e, gkoc_stream_t s);
 int gkoc_event_synchronize(gkoc_event_t e);
 int gkoc_event_elapsed_ns(gkoc_event_t start, gkoc_event_t stop, int64_t* ns);
 int gkoc_stream_wait_event(gkoc_stream_t s, gkoc_event_t e);
+/* hipGraph: everything enqueued on `s` between begin and end (any gkoc_* kernel
+ * call without a host result, async copies) becomes one replayable graph.  No
+ * counterpart in Ginkgo (its solvers re-issue every kernel per iteration); used
+ * by this repository's own CG drivers for launch-bound system sizes. */
+typedef void* gkoc_graph_t;
+int gkoc_stream_begin_capture(gkoc_stream_t s);
+int gkoc_stream_end_capture(gkoc_stream_t s, gkoc_graph_t* graph);
+int gkoc_graph_launch(gkoc_graph_t graph, gkoc_stream_t s);
+int gkoc_graph_destroy(gkoc_graph_t graph);
 
 /* --------------------------------------------------------------- CSR SpMV
  * csr::spmv            core/matrix/csr_kernels.hpp:29-34

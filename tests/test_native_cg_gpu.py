@@ -27,7 +27,7 @@ def test_native_cg_matches_oracle(oracle):
     xo, iters, _ = oracle.cg_solve(rp, ci, v, np.ones(n), max_iters=1000, reduction=1e-10,
                                    precond="block", max_block_size=8)
     res = {}
-    for mode, lag in (("plain", 0), ("fused", 0), ("fused", 4), ("fused", 7)):
+    for mode, lag in (("plain", 0), ("fused", 0), ("fused", 4), ("fused", 7), ("graph", 4)):
         r = _run(grid, 1000, 1e-10, mode, lag)
         assert r["converged"] and abs(r["iterations"] - iters) <= 1
         assert r["true_rel_residual"] <= 1.01e-10
@@ -36,6 +36,11 @@ def test_native_cg_matches_oracle(oracle):
     # reading the criterion late changes nothing, bit for bit
     assert res[("fused", 0)]["x_sum"] == res[("fused", 4)]["x_sum"] == res[("fused", 7)]["x_sum"]
     assert res[("fused", 0)]["iterations"] == res[("fused", 4)]["iterations"]
+    # ... and so does replaying two captured iterations as a hipGraph
+    assert res[("graph", 4)]["x_sum"] == res[("fused", 0)]["x_sum"]
+    assert res[("graph", 4)]["iterations"] == res[("fused", 0)]["iterations"]
     # iteration limit
-    r = _run(grid, 5, 1e-30, "fused", 4)
-    assert r["iterations"] == 5 and not r["converged"]
+    for mode in ("fused", "graph"):
+        for cap in (5, 6):
+            r = _run(grid, cap, 1e-30, mode, 4)
+            assert r["iterations"] == cap and not r["converged"]
