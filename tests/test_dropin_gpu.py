@@ -53,3 +53,15 @@ def test_ginkgo_example_preconditioned_solver():
     assert abs(res["hip"] - res["reference"]) < 1e-12
     assert len(sol["hip"]) == len(sol["reference"]) == 19
     assert max(abs(a - b) for a, b in zip(sol["hip"], sol["reference"])) < 1e-5
+
+
+def test_ginkgo_api_benchmark_program_runs():
+    """tests/dropin/dropin_bench.cpp: Csr / Ell / Sellp apply and Cg + Jacobi(8) of the
+    unmodified core, timed with gko::Timer (small grid here; 256^3 numbers in
+    profiles/r01_ginkgo_api_bench_on_this_backend.txt)"""
+    exe = _need("dropin_bench")
+    p = subprocess.run([exe, "48", "5", "20"], capture_output=True, text=True, timeout=600, cwd=DROP)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    for key in ("gko::matrix::Csr::apply", "gko::matrix::Ell::apply", "gko::matrix::Sellp::apply",
+                "gko::solver::Cg + Jacobi(8)  20 iterations"):
+        assert key in p.stdout, p.stdout
