@@ -601,3 +601,28 @@ def test_cg_hip_graph_changes_nothing(gexec, bs):
         assert e[0] == h[0] and e[1] == h[1]
         assert np.array_equal(e[2], h[2]) and np.array_equal(e[3], h[3])
     assert res[(True, 1000)][1] and res[(True, 7)][0] == 7 and not res[(True, 7)][1]
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_cg_float32_fused_paths(gexec, graph):
+    """the f32 instantiations of the fused kernels / hipGraph loop: CG + block-Jacobi(8)
+    in single precision reaches the single-precision residual level and agrees
+    with the double-precision solution to ~1e-4"""
+    import ginkgo_amd as g
+    grid = 16
+    n = grid ** 3
+    rhs = np.random.default_rng(2).uniform(-1, 1, n)
+    sols = {}
+    for dt, tol in ((torch.float64, 1e-10), (torch.float32, 1e-5)):
+        a = g.stencil_csr(gexec, 3, grid, dtype=dt)
+        npdt = np.float64 if dt == torch.float64 else np.float32
+        s = (g.Cg.build().with_hip_graph(graph)
+             .with_criteria(g.stop.Iteration.build().with_max_iters(500),
+                            g.stop.ResidualNorm.build().with_reduction_factor(tol))
+             .with_preconditioner(g.Jacobi.build().with_max_block_size(8))
+             .on(gexec).generate(a))
+        x = g.Dense.from_numpy(gexec, np.zeros(n, npdt))
+        s.apply(g.Dense.from_numpy(gexec, rhs.astype(npdt)), x)
+        assert s.has_converged
+        sols[dt] = x.to_numpy()[:, 0].astype(np.float64)
+    assert rel_frobenius(sols[torch.float32], sols[torch.float64]) < 2e-4
