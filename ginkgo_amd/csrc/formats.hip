@@ -85,6 +85,12 @@ __device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
     return sum;
 }
 
+// ELL / SELL-P SpMV: lane = row, and every lane owns TWO rows, 64 apart, of the
+// 128 consecutive rows of its wave, so that the wave ends with two back-to-back
+// 512 B stores = one contiguous 1 KB burst.  (Sparse small writes between the
+// read streams cost several times their byte share at the memory side, and
+// only a burst of >= 1 KB issued by ONE wave avoids it - a barrier that lines
+// up the 512 B stores of four waves does not)
 template <typename T, typename I, bool ADV>
 __global__ __launch_bounds__(256) void ell_spmv_kernel(
     int64_t n_rows, int64_t k_per_row, int64_t stride,
@@ -92,24 +98,26 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(
     const T* __restrict__ b, int64_t ldb, T* __restrict__ c, int64_t ldc,
     int nrhs, const T* __restrict__ alpha_p, const T* __restrict__ beta_p)
 {
-    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    const bool active = row < n_rows;
+    const int64_t wave = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int64_t row0 = wave * 128 + (threadIdx.x & 63);
+    const int64_t row1 = row0 + 64;
     T alpha = T(1), beta = T(0);
     if (ADV) {
         alpha = alpha_p[0];
         beta = beta_p[0];
     }
     for (int j = 0; j < nrhs; ++j) {
-        T sum = T(0);
-        if (active) {
-            if (ADV && beta != T(0)) sum = beta * c[row * ldc + j];
-            sum = fmt_row_sum<T, I, ADV>(sum, k_per_row, row, stride, cols, vals, b, ldb, j, alpha);
+        T s0 = T(0), s1 = T(0);
+        if (row0 < n_rows) {
+            if (ADV && beta != T(0)) s0 = beta * c[row0 * ldc + j];
+            s0 = fmt_row_sum<T, I, ADV>(s0, k_per_row, row0, stride, cols, vals, b, ldb, j, alpha);
         }
-        // the block's four waves write their 2 KB of results together: sparse
-        // 512 B writes between the read streams cost a multiple of their
-        // byte share
-        __syncthreads();
-        if (active) c[row * ldc + j] = sum;
+        if (row1 < n_rows) {
+            if (ADV && beta != T(0)) s1 = beta * c[row1 * ldc + j];
+            s1 = fmt_row_sum<T, I, ADV>(s1, k_per_row, row1, stride, cols, vals, b, ldb, j, alpha);
+        }
+        if (row0 < n_rows) c[row0 * ldc + j] = s0;
+        if (row1 < n_rows) c[row1 * ldc + j] = s1;
     }
 }
 
@@ -122,25 +130,32 @@ __global__ __launch_bounds__(256) void sellp_spmv_kernel(
     T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
     const T* __restrict__ beta_p)
 {
-    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    const bool active = row < n_rows;
-    const int64_t slice = (active ? row : n_rows - 1) / slice_size;
-    const int64_t local = row - slice * slice_size;
-    const int64_t len = int64_t(slice_lengths[slice]);
-    const int64_t base = int64_t(slice_sets[slice]) * slice_size + local;
+    const int64_t wave = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int64_t rows[2] = {wave * 128 + (threadIdx.x & 63), wave * 128 + 64 + (threadIdx.x & 63)};
     T alpha = T(1), beta = T(0);
     if (ADV) {
         alpha = alpha_p[0];
         beta = beta_p[0];
     }
     for (int j = 0; j < nrhs; ++j) {
-        T sum = T(0);
-        if (active) {
-            if (ADV && beta != T(0)) sum = c[row * ldc + j] * beta;
-            sum = fmt_row_sum<T, I, ADV>(sum, len, base, slice_size, cols, vals, b, ldb, j, alpha);
+        T sum[2] = {T(0), T(0)};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t row = rows[t];
+            if (row < n_rows) {
+                const int64_t slice = row / slice_size;
+                const int64_t local = row - slice * slice_size;
+                const int64_t len = int64_t(slice_lengths[slice]);
+                const int64_t base = int64_t(slice_sets[slice]) * slice_size + local;
+                if (ADV && beta != T(0)) sum[t] = c[row * ldc + j] * beta;
+                sum[t] = fmt_row_sum<T, I, ADV>(sum[t], len, base, slice_size, cols, vals, b,
+                                                ldb, j, alpha);
+            }
         }
-        __syncthreads();   // one 2 KB output burst per block, see ell_spmv_kernel
-        if (active) c[row * ldc + j] = sum;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (rows[t] < n_rows) c[rows[t] * ldc + j] = sum[t];
+        }
     }
 }
 
@@ -359,7 +374,7 @@ int launch_ell(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t k,
                  GKOC_E_INVALID, "bad ELL dimensions");
     if (n_rows == 0 || nrhs == 0) return GKOC_OK;
     if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
-    ell_spmv_kernel<T, I, ADV><<<dim3(blocks_for(n_rows)), dim3(256), 0, as_stream(s)>>>(
+    ell_spmv_kernel<T, I, ADV><<<dim3(unsigned(ceildiv(n_rows, 512))), dim3(256), 0, as_stream(s)>>>(
         n_rows, k, stride, cols, vals, b, ldb, c, ldc, int(nrhs), alpha, beta);
     GKOC_LAUNCH_OK();
     return GKOC_OK;
@@ -378,7 +393,7 @@ int launch_sellp(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,
     if (n_rows == 0 || nrhs == 0) return GKOC_OK;
     if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
     sellp_spmv_kernel<T, I, ADV>
-        <<<dim3(blocks_for(n_rows)), dim3(256), 0, as_stream(s)>>>(
+        <<<dim3(unsigned(ceildiv(n_rows, 512))), dim3(256), 0, as_stream(s)>>>(
             n_rows, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c,
             ldc, int(nrhs), alpha, beta);
     GKOC_LAUNCH_OK();

@@ -156,6 +156,37 @@ __global__ __launch_bounds__(64) void stream_private_store_kernel(
     } else if (acc == 12345.678) out[0] = acc;
 }
 
+// four waves per block, each streams its own range; with SYNC the four 512 B
+// stores of a block are issued together after a barrier (2 KB contiguous)
+template <int NPW, bool SYNC>
+__global__ __launch_bounds__(256) void stream_private_store_block4_kernel(
+    int64_t nnz, const double* __restrict__ vals, const int* __restrict__ cols,
+    double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    const int64_t base = wave * NPW;
+    constexpr int IT = (NPW + 255) / 256;
+    double2 v0[IT], v1[IT];
+    int4 c[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int64_t k = base + i * 256 + lane * 4;
+        const bool in = i * 256 + lane * 4 < NPW && k + 4 <= nnz;
+        const int64_t kk = in ? k : 0;
+        v0[i] = *reinterpret_cast<const double2*>(vals + kk);
+        v1[i] = *reinterpret_cast<const double2*>(vals + kk + 2);
+        c[i] = *reinterpret_cast<const int4*>(cols + kk);
+    }
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        acc += v0[i].x + v0[i].y + v1[i].x + v1[i].y + double(c[i].x + c[i].y + c[i].z + c[i].w);
+    }
+    if (SYNC) __syncthreads();
+    out[wave * 64 + lane] = acc;
+}
+
 // ------------------------------------------------- classical (Ginkgo-like)
 // SUB lanes per row, shuffle reduction (common/cuda_hip csr classical idea)
 template <int SUB>
@@ -401,6 +432,10 @@ int main(int argc, char** argv)
     ms = T.ms(reps, [&] { stream_private_store_kernel<1728, 1 + 16 * FL><<<nwv, 64>>>(nnz, vals, cols, x, row_ptrs, yy); }); \
     snprintf(nm, 96, "repro %s: stream + y store [" NAME "]", tag); report(nm, ms, double(nnz) * 12 + 8.0 * n);
             REPRO_FL(1, "nt")
+            ms = T.ms(reps, [&] { stream_private_store_block4_kernel<1728, false><<<nwv / 4, 256>>>(nnz, vals, cols, yy); });
+            snprintf(nm, 96, "repro %s: 4 waves/block, 512 B each, no barrier", tag); report(nm, ms, double(nnz) * 12 + 8.0 * n);
+            ms = T.ms(reps, [&] { stream_private_store_block4_kernel<1728, true><<<nwv / 4, 256>>>(nnz, vals, cols, yy); });
+            snprintf(nm, 96, "repro %s: 4 waves/block, barrier, 2 KB together", tag); report(nm, ms, double(nnz) * 12 + 8.0 * n);
             REPRO_FL(16, "1 wave in 2 stores 1 KB")
             REPRO_FL(25, "1 in 2: 1 KB, one dwordx4 store")
             REPRO_FL(41, "1 in 4: 2 KB, two dwordx4 stores")
