@@ -103,6 +103,48 @@ __global__ __launch_bounds__(256) void gmres_multi_axpy_kernel(
     }
 }
 
+// next_krylov(i,k) -= sum_{d < num} h(d,k) * basis_d(i,k), one term after the
+// other in d order with the roundings of dense::sub_scaled (t = h*v; w = w - t;
+// a single zero h skips its term) => bit-identical to the num sub_scaled calls
+// of the classical Gram-Schmidt step (gmres.cpp:222-236), but next_krylov is
+// read and written once instead of num times.
+template <typename T>
+__global__ __launch_bounds__(256) void gmres_multi_sub_scaled_kernel(
+    int64_t rows, int64_t cols, int num, const T* __restrict__ krylov,
+    int64_t ldk, const T* __restrict__ h, int64_t ldh, T* __restrict__ w,
+    int64_t ldw)
+{
+    const int64_t total = rows * cols;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x; idx < total;
+         idx += stride) {
+        const int64_t i = cols == 1 ? idx : idx / cols;
+        const int64_t k = cols == 1 ? 0 : idx - i * cols;
+        T acc = w[i * ldw + k];
+        int d = 0;
+        for (; d + 4 <= num; d += 4) {
+            const T v0 = krylov[(i + int64_t(d) * rows) * ldk + k];
+            const T v1 = krylov[(i + int64_t(d + 1) * rows) * ldk + k];
+            const T v2 = krylov[(i + int64_t(d + 2) * rows) * ldk + k];
+            const T v3 = krylov[(i + int64_t(d + 3) * rows) * ldk + k];
+            const T a0 = h[d * ldh + k], a1 = h[(d + 1) * ldh + k];
+            const T a2 = h[(d + 2) * ldh + k], a3 = h[(d + 3) * ldh + k];
+            const bool one = cols == 1;
+            const T t0 = a0 * v0, t1 = a1 * v1, t2 = a2 * v2, t3 = a3 * v3;
+            acc = (one && a0 == T(0)) ? acc : acc - t0;
+            acc = (one && a1 == T(0)) ? acc : acc - t1;
+            acc = (one && a2 == T(0)) ? acc : acc - t2;
+            acc = (one && a3 == T(0)) ? acc : acc - t3;
+        }
+        for (; d < num; ++d) {
+            const T a = h[d * ldh + k];
+            const T t = a * krylov[(i + int64_t(d) * rows) * ldk + k];
+            acc = (cols == 1 && a == T(0)) ? acc : acc - t;
+        }
+        w[i * ldw + k] = acc;
+    }
+}
+
 // stop_status[k].finalize() for stopped, not yet finalized columns (runs after
 // the axpy kernel, which must still see the old flags)
 __global__ void gmres_finalize_kernel(int64_t cols, uint8_t* stop)
@@ -306,6 +348,21 @@ extern "C" size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrh
         }                                                                      \
         gmres_finalize_kernel<<<dim3(unsigned(ceildiv(nrhs, 256))), dim3(256), \
                                 0, as_stream(s)>>>(nrhs, stop_status);         \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_x_gmres_multi_sub_scaled_##TN(                         \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t num,              \
+        const T* krylov_bases, int64_t ldk, const T* h, int64_t ldh,           \
+        T* next_krylov, int64_t ldn)                                           \
+    {                                                                          \
+        if (rows <= 0 || nrhs <= 0 || num <= 0) return GKOC_OK;                \
+        GKOC_REQUIRE(krylov_bases && h && next_krylov, GKOC_E_INVALID,         \
+                     "null pointer");                                          \
+        gmres_multi_sub_scaled_kernel<T>                                       \
+            <<<dim3(stream_blocks(rows * nrhs)), dim3(256), 0, as_stream(s)>>>( \
+                rows, nrhs, int(num), krylov_bases, ldk, h, ldh, next_krylov,  \
+                ldn);                                                          \
         GKOC_LAUNCH_OK();                                                      \
         return GKOC_OK;                                                        \
     }                                                                          \

@@ -450,16 +450,25 @@ class Gmres(_IterativeSolver):
                     basis(krylov, i).compute_conj_dot(next_k, h_i)
                     next_k.sub_scaled(h_i, basis(krylov, i))
             else:
+                fused = bool(self.params.get("fused_kernels", True))
+
+                def subtract(hm):
+                    # next_k -= sum_i hm(i,:) * basis_i: one pass (bit-identical to
+                    # the restart_iter + 1 sub_scaled calls of the reference)
+                    if fused:
+                        call("gkoc_x_gmres_multi_sub_scaled_" + suf, ex.stream, n, nrhs,
+                             restart_iter + 1, krylov.values, krylov.ld, hm.values, hm.ld,
+                             next_k.values, next_k.ld)
+                    else:
+                        for i in range(restart_iter + 1):
+                            next_k.sub_scaled(hm.create_submatrix((i, i + 1), (0, nrhs)),
+                                              basis(krylov, i))
                 multi_dot(next_k, restart_iter + 1, hiter)
-                for i in range(restart_iter + 1):
-                    next_k.sub_scaled(hiter.create_submatrix((i, i + 1), (0, nrhs)),
-                                      basis(krylov, i))
+                subtract(hiter)
                 if ortho == ortho_method.cgs2:
                     aux = haux.create_submatrix((0, restart_iter + 2), (0, nrhs))
                     multi_dot(next_k, restart_iter + 1, aux)
-                    for i in range(restart_iter + 1):
-                        next_k.sub_scaled(haux.create_submatrix((i, i + 1), (0, nrhs)),
-                                          basis(krylov, i))
+                    subtract(aux)
                     hiter.add_scaled(one, aux)
             h_norm = hiter.create_submatrix((restart_iter + 1, restart_iter + 2), (0, nrhs))
             next_k.compute_norm2(h_norm)

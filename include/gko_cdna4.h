@@ -536,7 +536,14 @@ GKOC_DECL_DIST(float, f32, int64_t, i64)
  * a deterministic tree sum (tolerance 1e-13 as for compute_dot).  One column,
  * unit strides.  work: gkoc_x_workspace_bytes(n, sizeof(T)) device bytes. */
 size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size);
+/* gkoc_x_gmres_multi_sub_scaled: next_krylov -= sum_{d<num} h(d,:) * basis_d, the
+ * num dense::sub_scaled calls of the classical Gram-Schmidt update
+ * (gmres.cpp:222-236) in one pass, term by term in d order => bit-identical. */
 #define GKOC_DECL_X(T, TN)                                                     \
+    int gkoc_x_gmres_multi_sub_scaled_##TN(                                    \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t num,              \
+        const T* krylov_bases, int64_t ldk, const T* h, int64_t ldh,           \
+        T* next_krylov, int64_t ldn);                                          \
     int gkoc_x_cg_step_2_norm_##TN(                                            \
         gkoc_stream_t s, int64_t rows, T* x, T* r, const T* p, const T* q,     \
         const T* beta, const T* rho, const uint8_t* stop_status, T* norm_out,  \

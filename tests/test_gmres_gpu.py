@@ -170,3 +170,27 @@ def test_gmres_multiple_rhs_and_flexible(gexec, oracle):
             # the criterion sees the Givens estimate of the residual norm; the true
             # residual of a restarted multi-column solve agrees to ~1e-7
             assert np.linalg.norm(B[:, j] - A @ X[:, j]) <= 1e-7 * np.linalg.norm(B[:, j])
+
+
+@pytest.mark.parametrize("ortho", ["cgs", "cgs2"])
+@pytest.mark.parametrize("nrhs", [1, 2])
+def test_gmres_fused_cgs_update_bit_identical(gexec, ortho, nrhs):
+    """gkoc_x_gmres_multi_sub_scaled (one pass) vs the k+1 dense::sub_scaled calls
+    of the reference's classical Gram-Schmidt update: same iterates, bit for bit"""
+    import ginkgo_amd as g
+    grid = 14
+    n = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    rhs = np.random.default_rng(6).uniform(-1, 1, (n, nrhs))
+    res = []
+    for fused in (False, True):
+        s = (g.Gmres.build().with_krylov_dim(12).with_ortho_method(ortho).with_fused_kernels(fused)
+             .with_criteria(g.stop.Iteration.build().with_max_iters(200),
+                            g.stop.ResidualNorm.build().with_reduction_factor(1e-9))
+             .with_preconditioner(g.Jacobi.build().with_max_block_size(4))
+             .on(gexec).generate(a))
+        x = g.Dense.from_numpy(gexec, np.zeros((n, nrhs)))
+        s.apply(g.Dense.from_numpy(gexec, rhs), x)
+        res.append((s.num_iterations, x.to_numpy()))
+    assert res[0][0] == res[1][0] and res[0][0] < 200
+    assert np.array_equal(res[0][1], res[1][1])
