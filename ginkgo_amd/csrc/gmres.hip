@@ -22,6 +22,8 @@
 #include <cmath>
 
 #include "common.hpp"
+#include "elementwise.hpp"
+#include "fused.hpp"
 
 namespace gkoc {
 namespace {
@@ -143,6 +145,57 @@ __global__ __launch_bounds__(256) void gmres_multi_sub_scaled_kernel(
         }
         w[i * ldw + k] = acc;
     }
+}
+
+// One modified Gram-Schmidt step fused with the next dot (one column, unit
+// strides): w -= h_cur * v_cur with the roundings of dense::sub_scaled (a zero
+// h_cur skips the update), and from the registers that hold the new w this
+// block's part of <v_next, w>.  w is bit-identical to the unfused step.
+template <typename T>
+__global__ __launch_bounds__(256) void gmres_mgs_step_kernel(
+    int64_t n, T* __restrict__ w, const T* __restrict__ v_cur,
+    const T* __restrict__ h_cur, const T* __restrict__ v_next,
+    T* __restrict__ partial, bool vec_ok)
+{
+    __shared__ T lds[4];
+    using V = vec16<T>;
+    constexpr int W = V::width;
+    const T a = h_cur[0];
+    const bool noop = a == T(0);
+    T acc = T(0);
+    const int64_t tid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    int64_t done = 0;
+    if (vec_ok) {
+        const int64_t n_vec = n / W;
+        for (int64_t i = tid; i < n_vec; i += stride) {
+            V wv = reinterpret_cast<const V*>(w)[i];
+            const V nv = reinterpret_cast<const V*>(v_next)[i];
+            if (!noop) {
+                const V cv = reinterpret_cast<const V*>(v_cur)[i];
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    const T t = a * cv.v[e];
+                    wv.v[e] = wv.v[e] - t;
+                }
+                reinterpret_cast<V*>(w)[i] = wv;
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) acc += nv.v[e] * wv.v[e];
+        }
+        done = n_vec * W;
+    }
+    for (int64_t i = done + tid; i < n; i += stride) {
+        T wv = w[i];
+        if (!noop) {
+            const T t = a * v_cur[i];
+            wv = wv - t;
+            w[i] = wv;
+        }
+        acc += v_next[i] * wv;
+    }
+    const T r = block_sum<256>(acc, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
 // stop_status[k].finalize() for stopped, not yet finalized columns (runs after
@@ -350,6 +403,35 @@ extern "C" size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrh
                                 0, as_stream(s)>>>(nrhs, stop_status);         \
         GKOC_LAUNCH_OK();                                                      \
         return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_x_gmres_mgs_step_##TN(                                 \
+        gkoc_stream_t s, int64_t rows, T* next_krylov, const T* basis_cur,     \
+        const T* h_cur, const T* basis_next, T* h_next, void* work,            \
+        size_t work_bytes)                                                     \
+    {                                                                          \
+        GKOC_REQUIRE(rows >= 0 && h_next, GKOC_E_INVALID, "bad argument");     \
+        if (rows == 0) {                                                       \
+            GKOC_HIP(hipMemsetAsync(h_next, 0, sizeof(T), as_stream(s)));      \
+            return GKOC_OK;                                                    \
+        }                                                                      \
+        GKOC_REQUIRE(next_krylov && basis_cur && h_cur && basis_next && work,  \
+                     GKOC_E_INVALID, "null pointer");                          \
+        GKOC_REQUIRE(work_bytes >= fused_workspace_bytes(rows, sizeof(T)),     \
+                     GKOC_E_WORKSPACE,                                         \
+                     "workspace too small (gkoc_x_workspace_bytes)");          \
+        int64_t nb = ceildiv(rows, int64_t(256) * 8);                          \
+        if (nb > 2048) nb = 2048;                                              \
+        T* partial = static_cast<T*>(work);                                    \
+        T* scratch = partial + (fused_workspace_bytes(rows, sizeof(T)) /       \
+                                    sizeof(T) - fold_chunks);                  \
+        gmres_mgs_step_kernel<T>                                               \
+            <<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(              \
+                rows, next_krylov, basis_cur, h_cur, basis_next, partial,      \
+                (reinterpret_cast<uintptr_t>(next_krylov) |                    \
+                 reinterpret_cast<uintptr_t>(basis_cur) |                      \
+                 reinterpret_cast<uintptr_t>(basis_next)) % 16 == 0);          \
+        GKOC_LAUNCH_OK();                                                      \
+        return fold_partials<T>(s, nb, partial, scratch, h_next, false);       \
     }                                                                          \
     extern "C" int gkoc_x_gmres_multi_sub_scaled_##TN(                         \
         gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t num,              \

@@ -445,10 +445,31 @@ class Gmres(_IterativeSolver):
             hiter = Dense(ex, hrow.view(restart_iter + 2, nrhs))
             a.apply(pre_k, next_k)
             if ortho == ortho_method.mgs:
-                for i in range(restart_iter + 1):
-                    h_i = hiter.create_submatrix((i, i + 1), (0, nrhs))
-                    basis(krylov, i).compute_conj_dot(next_k, h_i)
-                    next_k.sub_scaled(h_i, basis(krylov, i))
+                mgs_fused = bool(self.params.get("fused_kernels", True)) and nrhs == 1 and \
+                    krylov.ld == 1
+                if mgs_fused:
+                    # h_0 = <v_0, w>; then each step w -= h_i v_i together with
+                    # h_{i+1} = <v_{i+1}, w>: one pass over w less per step
+                    xw = self._ws.get("x_work")
+                    need = _lib.lib().gkoc_x_workspace_bytes(C.c_int64(n), C.c_size_t(b.values.element_size()))
+                    if xw is None or xw.numel() * xw.element_size() < need:
+                        es = b.values.element_size()
+                        xw = self._ws["x_work"] = ex.alloc(((need + es - 1) // es,), b.dtype)
+                    h0 = hiter.create_submatrix((0, 1), (0, 1))
+                    basis(krylov, 0).compute_conj_dot(next_k, h0)
+                    for i in range(restart_iter):
+                        call("gkoc_x_gmres_mgs_step_" + suf, ex.stream, n, next_k.values,
+                             basis(krylov, i).values, hiter.values[i:i + 1],
+                             basis(krylov, i + 1).values, hiter.values[i + 1:i + 2], xw,
+                             C.c_size_t(xw.numel() * xw.element_size()))
+                    last = restart_iter
+                    next_k.sub_scaled(hiter.create_submatrix((last, last + 1), (0, 1)),
+                                      basis(krylov, last))
+                else:
+                    for i in range(restart_iter + 1):
+                        h_i = hiter.create_submatrix((i, i + 1), (0, nrhs))
+                        basis(krylov, i).compute_conj_dot(next_k, h_i)
+                        next_k.sub_scaled(h_i, basis(krylov, i))
             else:
                 fused = bool(self.params.get("fused_kernels", True))
 

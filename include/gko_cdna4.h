@@ -539,7 +539,14 @@ size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size);
 /* gkoc_x_gmres_multi_sub_scaled: next_krylov -= sum_{d<num} h(d,:) * basis_d, the
  * num dense::sub_scaled calls of the classical Gram-Schmidt update
  * (gmres.cpp:222-236) in one pass, term by term in d order => bit-identical. */
+/* gkoc_x_gmres_mgs_step: one modified Gram-Schmidt step fused with the next dot
+ * (gmres.cpp:176-190): next_krylov -= h_cur * basis_cur (bit-identical to
+ * dense::sub_scaled), h_next = <basis_next, next_krylov> (tree sum). */
 #define GKOC_DECL_X(T, TN)                                                     \
+    int gkoc_x_gmres_mgs_step_##TN(                                            \
+        gkoc_stream_t s, int64_t rows, T* next_krylov, const T* basis_cur,     \
+        const T* h_cur, const T* basis_next, T* h_next, void* work,            \
+        size_t work_bytes);                                                    \
     int gkoc_x_gmres_multi_sub_scaled_##TN(                                    \
         gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t num,              \
         const T* krylov_bases, int64_t ldk, const T* h, int64_t ldh,           \

@@ -194,3 +194,44 @@ def test_gmres_fused_cgs_update_bit_identical(gexec, ortho, nrhs):
         res.append((s.num_iterations, x.to_numpy()))
     assert res[0][0] == res[1][0] and res[0][0] < 200
     assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_gmres_fused_mgs_step(gexec):
+    """gkoc_x_gmres_mgs_step (w -= h_i v_i fused with h_{i+1} = <v_{i+1}, w>): the
+    vector update is bit-identical, the dot uses another summation tree, so the
+    solves agree to rounding"""
+    import ctypes as C
+    import ginkgo_amd as g
+    from ginkgo_amd._lib import call, lib
+    n = 100003
+    rng = np.random.default_rng(12)
+    w, v0, v1 = (rng.uniform(-1, 1, n) for _ in range(3))
+    for h in (0.37, 0.0):
+        dw = g.Dense.from_numpy(gexec, w)
+        dv0, dv1 = g.Dense.from_numpy(gexec, v0), g.Dense.from_numpy(gexec, v1)
+        dh, out = g.scalar(gexec, h), g.Dense.create(gexec, (1, 1))
+        nbytes = lib().gkoc_x_workspace_bytes(C.c_int64(n), C.c_size_t(8))
+        work = gexec.alloc(((nbytes + 7) // 8,), torch.float64)
+        call("gkoc_x_gmres_mgs_step_f64", gexec.stream, n, dw.values, dv0.values, dh.values,
+             dv1.values, out.values, work, C.c_size_t(nbytes))
+        ref = g.Dense.from_numpy(gexec, w)
+        ref.sub_scaled(dh, dv0)
+        assert np.array_equal(dw.to_numpy(), ref.to_numpy())
+        d = float(np.dot(v1, ref.to_numpy()[:, 0]))
+        assert abs(out.to_numpy()[0, 0] - d) <= 1e-13 * np.sum(np.abs(v1 * ref.to_numpy()[:, 0]))
+    grid = 14
+    nn = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    rhs = rng.uniform(-1, 1, nn)
+    res = []
+    for fused in (False, True):
+        s = (g.Gmres.build().with_krylov_dim(12).with_ortho_method("mgs").with_fused_kernels(fused)
+             .with_criteria(g.stop.Iteration.build().with_max_iters(300),
+                            g.stop.ResidualNorm.build().with_reduction_factor(1e-9))
+             .with_preconditioner(g.Jacobi.build().with_max_block_size(8))
+             .on(gexec).generate(a))
+        x = g.Dense.from_numpy(gexec, np.zeros(nn))
+        s.apply(g.Dense.from_numpy(gexec, rhs), x)
+        res.append((s.num_iterations, s.has_converged, x.to_numpy()[:, 0]))
+    assert res[0][1] and res[1][1] and abs(res[0][0] - res[1][0]) <= 1
+    assert rel_frobenius(res[0][2], res[1][2]) < 1e-8
