@@ -78,10 +78,53 @@ def main():
         assert abs(solver1.num_iterations - solver.num_iterations) <= 1
         d = np.linalg.norm(xs1.to_numpy() - xs.to_numpy()) / np.linalg.norm(xs.to_numpy())
         assert d < 1e-9, d
+    # --- a general row partition: irregular symmetric positive definite matrix whose
+    #     rows reach into EVERY other rank (halo from several peers, scattered
+    #     indices, uneven part sizes) - nothing slab-specific may be assumed
+    irregular_case(mode, o, gd, be, comm, rank, world)
     dist.barrier()
     if rank == 0:
         print(f"dist_worker OK mode={mode} world={world} grid={grid} iters={solver.num_iterations}")
     dist.destroy_process_group()
+
+
+def irregular_case(mode, o, gd, be, comm, rank, world):
+    import scipy.sparse as sp
+    n = 613
+    rng = np.random.default_rng(77)           # same matrix on every rank
+    m = sp.random(n, n, density=0.02, random_state=rng, format="csr",
+                  data_rvs=lambda k: rng.uniform(-1, 1, k))
+    m = m + m.T
+    m = (m + sp.diags(np.asarray(abs(m).sum(axis=1)).ravel() + 1.0)).tocsr()
+    m.sort_indices()
+    rp, ci, v = m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data
+    part = gd.Partition.build_from_global_size_uniform(world, n)     # 205 / 204 / 204 for 3 ranks
+    lo, hi = part.range_of(rank)
+    lrp = (rp[lo:hi + 1] - rp[lo]).astype(np.int32)
+    lci, lv = ci[rp[lo]:rp[hi]], v[rp[lo]:rp[hi]]
+    if mode == "cpu":
+        from cpu_backend import CpuCsr
+        owned = CpuCsr(hi - lo, n, lrp, lci, lv)
+    else:
+        import ginkgo_amd as g
+        owned = g.Csr.from_arrays(be.exec, (hi - lo, n), lrp, lci, lv)
+    a = gd.DistributedMatrix(be, comm, part, owned)
+    if world > 2:
+        assert sum(1 for c in a.recv_counts if c > 0) >= 2, a.recv_counts   # several peers
+    xg = rng.uniform(-1, 1, n)
+    x, y = be.vector_from(xg[lo:hi]), be.vector(hi - lo)
+    a.apply(x, y)
+    ref = o.csr_spmv(rp, ci, v, xg)[lo:hi]
+    err = np.max(np.abs(y.to_numpy()[:, 0] - ref)) / np.max(np.abs(ref))
+    assert err < 1e-14, f"rank {rank}: irregular spmv err {err}"
+    solver = gd.DistributedCg(be, comm, a, 300, 1e-10, 0)          # unpreconditioned
+    xs = be.vector(hi - lo)
+    rhs = np.sin(np.arange(n))
+    solver.apply(be.vector_from(rhs[lo:hi]), xs)
+    xo, iters, _ = o.cg_solve(rp, ci, v, rhs, max_iters=300, reduction=1e-10)
+    assert abs(solver.num_iterations - iters) <= 1, (solver.num_iterations, iters)
+    e = np.linalg.norm(xs.to_numpy()[:, 0] - xo[lo:hi]) / np.linalg.norm(xo[lo:hi])
+    assert e < 1e-8, f"rank {rank}: irregular cg err {e}"
 
 
 if __name__ == "__main__":
