@@ -113,20 +113,57 @@ __global__ __launch_bounds__(256) void dist_row_list_kernel(
     }
 }
 
+// One wave per 64 list rows: their contiguous cols / vals range is staged in LDS
+// with coalesced loads (up to rl_stage_cap entries), lane = list row then adds
+// its products in k order; the y rows of a stencil halo are consecutive, so the
+// read-modify-write of y is coalesced as well.
+constexpr int rl_stage_cap = 2048;
+
 template <typename T, typename I>
-__global__ __launch_bounds__(256) void csr_rowlist_add_kernel(
+__global__ __launch_bounds__(64) void csr_rowlist_add_kernel(
     int64_t n_list, const I* __restrict__ rows, const I* __restrict__ ptrs,
     const I* __restrict__ cols, const T* __restrict__ vals,
     const T* __restrict__ halo, int64_t ld_halo, T* __restrict__ y, int64_t ldy,
     int nrhs)
 {
-    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= n_list) return;
+    __shared__ T lv[rl_stage_cap];
+    __shared__ I lc[rl_stage_cap];
+    const int lane = threadIdx.x;
+    const int64_t first = int64_t(blockIdx.x) * 64;
+    const int64_t i = first + lane;
+    const bool valid = i < n_list;
+    const int64_t last = first + 64 < n_list ? first + 64 : n_list;
+    const int64_t K0 = ptrs[first], K1 = ptrs[last];
+    const int64_t ks = ptrs[valid ? i : last], ke = ptrs[valid ? i + 1 : last];
+    const bool staged = K1 - K0 <= rl_stage_cap;
+    if (staged) {
+        for (int t = lane; t < int(K1 - K0); t += 64) {
+            lv[t] = vals[K0 + t];
+            lc[t] = cols[K0 + t];
+        }
+        wave_lds_sync();
+    }
+    if (!valid) return;
     const int64_t row = rows[i];
     for (int j = 0; j < nrhs; ++j) {
         T sum = y[row * ldy + j];
-        for (int64_t k = ptrs[i]; k < ptrs[i + 1]; ++k) {
-            sum += vals[k] * halo[int64_t(cols[k]) * ld_halo + j];
+        int64_t k = ks;
+        // eight gathers in flight, products added in k order
+        for (; k + 8 <= ke; k += 8) {
+            T v[8], h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = staged ? lv[k + u - K0] : vals[k + u];
+                const I c = staged ? lc[k + u - K0] : cols[k + u];
+                h[u] = halo[int64_t(c) * ld_halo + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u] * h[u];
+        }
+        for (; k < ke; ++k) {
+            const T v = staged ? lv[k - K0] : vals[k];
+            const I c = staged ? lc[k - K0] : cols[k];
+            sum += v * halo[int64_t(c) * ld_halo + j];
         }
         y[row * ldy + j] = sum;
     }
@@ -250,7 +287,8 @@ GKOC_DEF_DIST_IDX(int64_t, i64)
     {                                                                          \
         if (n_list <= 0 || nrhs <= 0) return GKOC_OK;                          \
         csr_rowlist_add_kernel<T, I>                                           \
-            <<<grid_for(n_list), dim3(256), 0, as_stream(s)>>>(                \
+            <<<dim3(unsigned(ceildiv(n_list, 64))), dim3(64), 0,               \
+               as_stream(s)>>>(                                                \
                 n_list, rows, ptrs, cols, vals, halo, ld_halo, y, ldy,         \
                 int(nrhs));                                                    \
         GKOC_LAUNCH_OK();                                                      \
