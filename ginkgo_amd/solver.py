@@ -358,6 +358,34 @@ class Gmres(_IterativeSolver):
     def build():
         return _SolverFactory(Gmres)
 
+    # ---- reduction hooks: identity on one GPU; distributed.DistributedGmres
+    # all-reduces the device-resident values over the row partition
+    _comm = None
+
+    def _reduce(self, t):
+        if self._comm is not None:
+            self._comm.all_reduce_sum_(t)
+
+    def _norm2(self, v, out):
+        if self._comm is None:
+            v.compute_norm2(out)
+        else:
+            v.compute_squared_norm2(out)
+            self._reduce(out.values.view(-1))
+            call("gkoc_dense_compute_sqrt_" + VT[out.dtype], self.exec.stream, out.size[1], out.values)
+
+    def _dot(self, v, w, out):
+        v.compute_conj_dot(w, out)
+        self._reduce(out.values.view(-1))
+
+    def _residual(self, a, b_like_residual, x, one, neg_one, scratch):
+        """residual (holding b) -= A x"""
+        if self._comm is None:
+            a.apply(neg_one, x, one, b_like_residual)
+        else:
+            a.apply(x, scratch)
+            b_like_residual.sub_scaled(one, scratch)
+
     def apply_impl(self, b, x):
         import ctypes as C
         from . import _lib
@@ -408,14 +436,19 @@ class Gmres(_IterativeSolver):
             call("gkoc_gmres_multi_dot_" + suf, ex.stream, n, nrhs, num, krylov.values, krylov.ld,
                  next_k.values, next_k.ld, target.values, target.ld, mdwork,
                  C.c_size_t(mdwork.numel()))
+            self._reduce(target.values[:num])
 
         call("gkoc_common_gmres_initialize_" + suf, ex.stream, n, nrhs, b.values, b.ld,
              residual.values, residual.ld, gsin.values, gsin.ld, gcos.values, gcos.ld, kd,
              stop_status)
-        a.apply(neg_one, x, one, residual)
-        residual.compute_norm2(rnorm)
+        self._residual(a, residual, x, one, neg_one, before)
+        self._norm2(residual, rnorm)
         restart()
         crit = _stop.combine(self.criteria, a, b, x, residual)
+        if self._comm is not None:
+            for c in crit.criteria:           # baselines are norms of distributed vectors
+                if isinstance(c, _stop.ResidualNorm) and c.baseline != _stop.mode.absolute:
+                    self._norm2(b if c.baseline == _stop.mode.rhs_norm else residual, c.starting_tau)
         total_iter, restart_iter = -1, 0
         while True:
             total_iter += 1
@@ -433,8 +466,8 @@ class Gmres(_IterativeSolver):
                 m.apply(before, after)
                 x.add_scaled(one, after)
                 residual.copy_from(b)
-                a.apply(neg_one, x, one, residual)
-                residual.compute_norm2(rnorm)
+                self._residual(a, residual, x, one, neg_one, before)
+                self._norm2(residual, rnorm)
                 restart()
                 restart_iter = 0
             this_k, next_k = basis(krylov, restart_iter), basis(krylov, restart_iter + 1)
@@ -456,19 +489,20 @@ class Gmres(_IterativeSolver):
                         es = b.values.element_size()
                         xw = self._ws["x_work"] = ex.alloc(((need + es - 1) // es,), b.dtype)
                     h0 = hiter.create_submatrix((0, 1), (0, 1))
-                    basis(krylov, 0).compute_conj_dot(next_k, h0)
+                    self._dot(basis(krylov, 0), next_k, h0)
                     for i in range(restart_iter):
                         call("gkoc_x_gmres_mgs_step_" + suf, ex.stream, n, next_k.values,
                              basis(krylov, i).values, hiter.values[i:i + 1],
                              basis(krylov, i + 1).values, hiter.values[i + 1:i + 2], xw,
                              C.c_size_t(xw.numel() * xw.element_size()))
+                        self._reduce(hiter.values[i + 1:i + 2].view(-1))
                     last = restart_iter
                     next_k.sub_scaled(hiter.create_submatrix((last, last + 1), (0, 1)),
                                       basis(krylov, last))
                 else:
                     for i in range(restart_iter + 1):
                         h_i = hiter.create_submatrix((i, i + 1), (0, nrhs))
-                        basis(krylov, i).compute_conj_dot(next_k, h_i)
+                        self._dot(basis(krylov, i), next_k, h_i)
                         next_k.sub_scaled(h_i, basis(krylov, i))
             else:
                 fused = bool(self.params.get("fused_kernels", True))
@@ -492,7 +526,7 @@ class Gmres(_IterativeSolver):
                     subtract(aux)
                     hiter.add_scaled(one, aux)
             h_norm = hiter.create_submatrix((restart_iter + 1, restart_iter + 2), (0, nrhs))
-            next_k.compute_norm2(h_norm)
+            self._norm2(next_k, h_norm)
             next_k.inv_scale(h_norm)
             call("gkoc_common_gmres_hessenberg_qr_" + suf, ex.stream, nrhs, gsin.values, gsin.ld,
                  gcos.values, gcos.ld, rnorm.values, rnc.values, rnc.ld, hiter.values, hiter.ld,

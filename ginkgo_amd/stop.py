@@ -77,7 +77,7 @@ class ResidualNorm:
     def __init__(self, factory, a, b, x, r):
         ex = self.exec = b.exec
         self.reduction_factor = float(factory.params["reduction_factor"])
-        baseline = factory.params["baseline"]
+        baseline = self.baseline = factory.params["baseline"]
         cols = b.size[1]
         self.starting_tau = Dense.create(ex, (1, cols), b.dtype)
         if baseline == mode.rhs_norm:

@@ -78,6 +78,17 @@ def main():
         assert abs(solver1.num_iterations - solver.num_iterations) <= 1
         d = np.linalg.norm(xs1.to_numpy() - xs.to_numpy()) / np.linalg.norm(xs.to_numpy())
         assert d < 1e-9, d
+    # --- restarted GMRES on the distributed matrix (HIP kernels only)
+    if mode != "cpu":
+        for ortho in ("mgs", "cgs"):
+            gm = gd.DistributedGmres(be, comm, a, 400, 1e-9, 8, krylov_dim=10, ortho_method=ortho)
+            xg_ = be.vector(hi - lo)
+            gm.apply(be.vector_from(np.ones(hi - lo)), xg_)
+            xo_, it_, _ = o.gmres_solve(rp, ci, v, np.ones(n), krylov_dim=10, ortho=ortho, max_iters=400,
+                                        reduction=1e-9, precond="block", max_block_size=8)
+            assert gm.has_converged and abs(gm.num_iterations - it_) <= 1, (gm.num_iterations, it_)
+            e = np.linalg.norm(xg_.to_numpy()[:, 0] - xo_[lo:hi]) / np.linalg.norm(xo_[lo:hi])
+            assert e < 1e-7, f"rank {rank}: gmres({ortho}) err {e}"
     # --- a general row partition: irregular symmetric positive definite matrix whose
     #     rows reach into EVERY other rank (halo from several peers, scattered
     #     indices, uneven part sizes) - nothing slab-specific may be assumed

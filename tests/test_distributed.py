@@ -138,3 +138,11 @@ def test_overlap_branch_with_mirror_comm(gexec, oracle):
     assert abs(solver.num_iterations - iters) <= 1
     e = np.linalg.norm(xs.to_numpy()[:, 0] - xo[lo:hi]) / np.linalg.norm(xo[lo:hi])
     assert e < 1e-8
+    # restarted GMRES through the same communicator
+    gm = gd.DistributedGmres(be, MirrorComm(), a, 400, 1e-9, 8, krylov_dim=12, ortho_method="cgs")
+    xg_ = be.vector(hi - lo)
+    gm.apply(be.vector_from(np.ones(hi - lo)), xg_)
+    xo2, it2, _ = oracle.gmres_solve(rp, ci, v, np.ones(n), krylov_dim=12, ortho="cgs", max_iters=400,
+                                     reduction=1e-9, precond="block", max_block_size=8)
+    assert gm.has_converged and abs(gm.num_iterations - it2) <= 1
+    assert np.linalg.norm(xg_.to_numpy()[:, 0] - xo2[lo:hi]) / np.linalg.norm(xo2[lo:hi]) < 1e-7
