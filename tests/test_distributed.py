@@ -146,3 +146,15 @@ def test_overlap_branch_with_mirror_comm(gexec, oracle):
                                      reduction=1e-9, precond="block", max_block_size=8)
     assert gm.has_converged and abs(gm.num_iterations - it2) <= 1
     assert np.linalg.norm(xg_.to_numpy()[:, 0] - xo2[lo:hi]) / np.linalg.norm(xo2[lo:hi]) < 1e-7
+
+
+@pytest.mark.gpu
+def test_collectives_through_rccl_one_rank():
+    """the same mirror construction with every collective issued through backend
+    "nccl" (RCCL) on the device: tests/rccl_mirror_worker.py"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_mirror_worker.py"), "16"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n--- stderr ---\n" + p.stderr[-12000:]
+    assert "rccl_mirror OK" in p.stdout
