@@ -97,6 +97,13 @@ def main():
                     help="extra output allocations to re-time the kernel on (diagnostic)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON result: everything else written to
+    # file descriptor 1 by this process (RCCL prints a version banner there from C
+    # stdio, flushed at exit, i.e. AFTER the result) is sent to stderr instead
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import ginkgo_amd as g
@@ -114,8 +121,13 @@ def main():
     dev_id = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_id)
     ex = g.Cdna4Executor.create(dev_id)
-    if world > 1:
+    # GKO_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, barriers,
+    # max-over-ranks, DistributedStencil) with a single rank - checks the RCCL calls
+    # of this script on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("GKO_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", dev_id))
@@ -126,7 +138,7 @@ def main():
     n_global = grid ** 3
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -135,7 +147,7 @@ def main():
     # next to the matrix measured up to 15 % slower for the same kernel.
     solver = None
     t_setup = 0.0
-    if world == 1:
+    if not use_dist:
         a = g.stencil_csr(ex, 3, grid)
         n_local = n_global
         nnz_global = a.get_num_stored_elements()
@@ -185,7 +197,7 @@ def main():
     wall = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
     t = torch.tensor([wall], dtype=torch.float64, device=ex.device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall = float(t.item())
     ms_per_step = wall * 1e3 / args.steps
@@ -195,7 +207,7 @@ def main():
     cg = {}
     if args.cg_iters > 0:
         import numpy as np
-        if world == 1:
+        if not use_dist:
             t1 = time.perf_counter()
             solver.apply(rhs, sol.fill(0.0))
             barrier()
@@ -204,7 +216,7 @@ def main():
         else:
             iters, t_cg = op.timed_cg(barrier)
         tt = torch.tensor([t_cg], dtype=torch.float64, device=ex.device)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_cg = float(tt.item())
         n, nnz = n_global, nnz_global
@@ -219,7 +231,7 @@ def main():
         achieved = per_gpu_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "spmv_pmc_latest.json")
-        if world == 1 and grid == 256 and os.path.exists(prof):
+        if not use_dist and grid == 256 and os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
             except Exception:
@@ -239,14 +251,14 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic,
-                         "kernel": ("csr_spmv_pipe3_kernel<double,int,...>" if world == 1 else
+                         "kernel": ("csr_spmv_pipe3_kernel<double,int,...>" if not use_dist else
                                     "per-rank distributed apply: halo pack + exchange || local "
                                     "csr_spmv_pipe3_kernel, then boundary rows"),
                          "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(per_gpu_bytes)},
         }
         out.update(cg)
-        if world == 1 and args.placement > 0:
+        if not use_dist and args.placement > 0:
             # the same kernel on other output allocations, so a
             # slow draw of device-memory placement can be told from a slow kernel
             alt, keep = [], []
@@ -267,14 +279,15 @@ def main():
                 "kernel_ms_min": round(min(alt), 4), "kernel_ms_max": round(max(alt), 4),
                 "frac_at_min": round(per_gpu_bytes / (min(alt) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "n": len(alt)}
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and not use_dist:
             if args.cpu_grid:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_grid)
             else:
                 host = tuple(t.cpu().numpy() for t in (a.row_ptrs, a.col_idxs, a.values))
                 out["cpu_baseline"] = cpu_baseline(grid, host)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,248 @@
+// Device-buffer communicator of the distributed path on RCCL (xGMI inside a node).
+// It stands where experimental::mpi::communicator stands in the reference
+// (include/ginkgo/core/base/mpi.hpp:419; all_reduce :838, i_all_to_all_v :1441),
+// restricted to what distributed::Vector reductions (vector.cpp:473-592) and the
+// RowGatherer exchange (row_gatherer.cpp:67-190) need.
+//
+// Why not go through a host framework's process group: every collective of a CG
+// iteration is a 16-byte all-reduce or a 1-2 plane neighbour exchange; at 8 GPUs
+// the device side of an iteration is ~250 us, and a framework call costs 20-45 us
+// of host time each plus cross-stream event hops on the device.  Here a collective
+// is ONE enqueue on the caller's stream.
+//
+// RCCL is bound with dlopen/dlsym at run time: libgko_cdna4.so keeps no link
+// dependency on it and loads on machines without RCCL.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+// the part of the RCCL/NCCL ABI used here (rccl.h): opaque communicator, 128-byte
+// id passed by value, enums as ints
+struct nccl_unique_id {
+    char internal[GKOC_COMM_ID_BYTES];
+};
+using nccl_comm = void*;
+constexpr int nccl_success = 0;
+constexpr int nccl_float32 = 7, nccl_float64 = 8, nccl_uint8 = 1;
+constexpr int nccl_sum = 0;
+
+struct rccl_api {
+    void* handle = nullptr;
+    int (*GetUniqueId)(nccl_unique_id*) = nullptr;
+    int (*CommInitRank)(nccl_comm*, int, nccl_unique_id, int) = nullptr;
+    int (*CommDestroy)(nccl_comm) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+
+rccl_api g_rccl;
+std::mutex g_rccl_mtx;
+
+int load_rccl(const char* path)
+{
+    std::lock_guard<std::mutex> g(g_rccl_mtx);
+    if (g_rccl.ok) return GKOC_OK;
+    const char* candidates[] = {path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* c : candidates) {
+        if (c == nullptr || *c == 0) continue;
+        h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) {
+        gkoc::set_last_error("gkoc_comm_load_rccl: librccl not found (%s)", dlerror());
+        return GKOC_E_COMM;
+    }
+    rccl_api a;
+    a.handle = h;
+    bool all = true;
+    auto sym = [&](const char* name) {
+        void* p = dlsym(h, name);
+        if (!p) {
+            gkoc::set_last_error("gkoc_comm_load_rccl: symbol %s missing", name);
+            all = false;
+        }
+        return p;
+    };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!all) return GKOC_E_COMM;
+    a.ok = true;
+    g_rccl = a;
+    return GKOC_OK;
+}
+
+int rccl_fail(int e, const char* what, int line)
+{
+    gkoc::set_last_error("comm.hip:%d: %s failed: %s (%d)", line, what,
+                         g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?", e);
+    return GKOC_E_COMM;
+}
+
+#define GKOC_RCCL(call)                                        \
+    do {                                                       \
+        int gkoc_r_ = (call);                                  \
+        if (gkoc_r_ != nccl_success) {                         \
+            return rccl_fail(gkoc_r_, #call, __LINE__);        \
+        }                                                      \
+    } while (0)
+
+}  // namespace
+
+struct gkoc_comm_s {
+    nccl_comm comm = nullptr;
+    int n_ranks = 0, rank = 0;
+    hipEvent_t packed = nullptr;   // main -> side: the send buffer is ready
+    hipEvent_t arrived = nullptr;  // side -> main: the halo is in recv_buf
+    bool pending_side = false;
+};
+
+using namespace gkoc;
+
+extern "C" {
+
+int gkoc_comm_load_rccl(const char* librccl_path) { return load_rccl(librccl_path); }
+
+int gkoc_comm_unique_id(void* id_out)
+{
+    GKOC_REQUIRE(id_out, GKOC_E_INVALID, "id_out == NULL");
+    int rc = load_rccl(nullptr);
+    if (rc != GKOC_OK) return rc;
+    nccl_unique_id id;
+    GKOC_RCCL(g_rccl.GetUniqueId(&id));
+    std::memcpy(id_out, id.internal, GKOC_COMM_ID_BYTES);
+    return GKOC_OK;
+}
+
+int gkoc_comm_create(gkoc_comm_t* comm, int n_ranks, int rank, const void* id)
+{
+    GKOC_REQUIRE(comm && id, GKOC_E_INVALID, "comm or id == NULL");
+    GKOC_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, GKOC_E_INVALID, "bad rank / n_ranks");
+    int rc = load_rccl(nullptr);
+    if (rc != GKOC_OK) return rc;
+    nccl_unique_id uid;
+    std::memcpy(uid.internal, id, GKOC_COMM_ID_BYTES);
+    auto* c = new gkoc_comm_s;
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    int e = g_rccl.CommInitRank(&c->comm, n_ranks, uid, rank);
+    if (e != nccl_success) {
+        delete c;
+        return rccl_fail(e, "ncclCommInitRank", __LINE__);
+    }
+    if (hipEventCreateWithFlags(&c->packed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->arrived, hipEventDisableTiming) != hipSuccess) {
+        g_rccl.CommDestroy(c->comm);
+        delete c;
+        set_last_error("gkoc_comm_create: hipEventCreate failed");
+        return GKOC_E_COMM;
+    }
+    *comm = c;
+    return GKOC_OK;
+}
+
+int gkoc_comm_destroy(gkoc_comm_t comm)
+{
+    if (!comm) return GKOC_OK;
+    if (comm->packed) (void)hipEventDestroy(comm->packed);
+    if (comm->arrived) (void)hipEventDestroy(comm->arrived);
+    int e = comm->comm ? g_rccl.CommDestroy(comm->comm) : nccl_success;
+    delete comm;
+    if (e != nccl_success) return rccl_fail(e, "ncclCommDestroy", __LINE__);
+    return GKOC_OK;
+}
+
+int gkoc_comm_size(gkoc_comm_t comm, int* n_ranks, int* rank)
+{
+    GKOC_REQUIRE(comm, GKOC_E_INVALID, "comm == NULL");
+    if (n_ranks) *n_ranks = comm->n_ranks;
+    if (rank) *rank = comm->rank;
+    return GKOC_OK;
+}
+
+int gkoc_comm_all_reduce_sum(gkoc_comm_t comm, gkoc_stream_t s, void* buf, int64_t n,
+                             size_t value_size)
+{
+    GKOC_REQUIRE(comm && buf && n >= 0, GKOC_E_INVALID, "bad argument");
+    GKOC_REQUIRE(value_size == 8 || value_size == 4, GKOC_E_NOT_SUPPORTED, "value_size must be 4 or 8");
+    if (n == 0) return GKOC_OK;
+    GKOC_RCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n),
+                               value_size == 8 ? nccl_float64 : nccl_float32, nccl_sum, comm->comm,
+                               as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_stream_t side,
+                             const void* send_buf, const int64_t* send_counts, void* recv_buf,
+                             const int64_t* recv_counts, size_t value_size)
+{
+    GKOC_REQUIRE(comm && send_counts && recv_counts, GKOC_E_INVALID, "bad argument");
+    GKOC_REQUIRE(value_size > 0, GKOC_E_INVALID, "value_size == 0");
+    GKOC_REQUIRE(!comm->pending_side, GKOC_E_INVALID,
+                 "gkoc_comm_exchange_begin: previous exchange not ended");
+    hipStream_t ms = as_stream(main_stream);
+    const bool overlapped = side != nullptr && side != main_stream;
+    hipStream_t xs = overlapped ? as_stream(side) : ms;
+    int64_t n_msgs = 0;
+    for (int p = 0; p < comm->n_ranks; ++p) {
+        GKOC_REQUIRE(send_counts[p] >= 0 && recv_counts[p] >= 0, GKOC_E_INVALID, "negative count");
+        n_msgs += (send_counts[p] > 0) + (recv_counts[p] > 0);
+    }
+    if (n_msgs == 0) return GKOC_OK;
+    GKOC_REQUIRE(send_buf && recv_buf, GKOC_E_INVALID, "NULL buffer with non-zero counts");
+    if (overlapped) {
+        GKOC_HIP(hipEventRecord(comm->packed, ms));
+        GKOC_HIP(hipStreamWaitEvent(xs, comm->packed, 0));
+    }
+    const char* sp = static_cast<const char*>(send_buf);
+    char* rp = static_cast<char*>(recv_buf);
+    GKOC_RCCL(g_rccl.GroupStart());
+    int e = nccl_success;
+    for (int p = 0; p < comm->n_ranks && e == nccl_success; ++p) {
+        // bytes as uint8: any value type travels unchanged
+        const size_t sb = static_cast<size_t>(send_counts[p]) * value_size;
+        const size_t rb = static_cast<size_t>(recv_counts[p]) * value_size;
+        if (sb) e = g_rccl.Send(sp, sb, nccl_uint8, p, comm->comm, xs);
+        if (rb && e == nccl_success) e = g_rccl.Recv(rp, rb, nccl_uint8, p, comm->comm, xs);
+        sp += sb;
+        rp += rb;
+    }
+    int e2 = g_rccl.GroupEnd();
+    if (e != nccl_success) return rccl_fail(e, "ncclSend/ncclRecv", __LINE__);
+    if (e2 != nccl_success) return rccl_fail(e2, "ncclGroupEnd", __LINE__);
+    if (overlapped) {
+        GKOC_HIP(hipEventRecord(comm->arrived, xs));
+        comm->pending_side = true;
+    }
+    return GKOC_OK;
+}
+
+int gkoc_comm_exchange_end(gkoc_comm_t comm, gkoc_stream_t main_stream)
+{
+    GKOC_REQUIRE(comm, GKOC_E_INVALID, "comm == NULL");
+    if (comm->pending_side) {
+        GKOC_HIP(hipStreamWaitEvent(as_stream(main_stream), comm->arrived, 0));
+        comm->pending_side = false;
+    }
+    return GKOC_OK;
+}
+
+}  // extern "C"

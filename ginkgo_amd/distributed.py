@@ -120,6 +120,73 @@ class TorchComm:
                                       group=self.group, async_op=async_op)
 
 
+class RcclComm(TorchComm):
+    """The data path straight on RCCL through the C ABI (gkoc_comm_*,
+    csrc/comm.hip): an all-reduce or a halo exchange is one enqueue on the
+    executor's stream - no process-group bookkeeping (20-45 us of host time per
+    call through torch.distributed, tools/dist_host_cost.py) and no cross-stream
+    event hops on the device.  torch.distributed (whatever backend is up) is used
+    only to hand rank 0's communicator id to the other ranks and for the integer
+    set-up exchanges.  Device buffers only."""
+
+    direct = True
+
+    def __init__(self, exec_, group=None):
+        super().__init__(group)
+        self.exec = exec_
+        import os
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        call("gkoc_comm_load_rccl", C.c_char_p(path.encode()) if os.path.exists(path) else None)
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            call("gkoc_comm_unique_id", ident)
+        if self.size > 1:
+            dev = torch.device("cpu") if self.host_staging else exec_.device
+            t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                           group=group)
+            ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        self._handle = C.c_void_p(0)
+        call("gkoc_comm_create", C.byref(self._handle), C.c_int(self.size), C.c_int(self.rank), ident)
+        self._cnt = {}
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            call("gkoc_comm_destroy", self._handle)
+            self._handle = C.c_void_p(0)
+
+    def all_reduce_sum_(self, t):
+        if self.size == 1:
+            return t
+        call("gkoc_comm_all_reduce_sum", self._handle, self.exec.stream, t, t.numel(),
+             C.c_size_t(t.element_size()))
+        return t
+
+    def _counts(self, counts):
+        key = tuple(counts)
+        arr = self._cnt.get(key)
+        if arr is None:
+            arr = self._cnt[key] = (C.c_int64 * len(key))(*key)
+        return arr
+
+    def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None):
+        """halo exchange of float buffers; kernels enqueued on the executor's stream
+        before exchange_end overlap the transfer when side_stream is given"""
+        side = C.c_void_p(side_stream.cuda_stream) if side_stream is not None else None
+        call("gkoc_comm_exchange_begin", self._handle, self.exec.stream, side, send,
+             self._counts(send_counts), recv, self._counts(recv_counts),
+             C.c_size_t(send.element_size()))
+
+    def exchange_end(self):
+        call("gkoc_comm_exchange_end", self._handle, self.exec.stream)
+
+    def all_to_all_v(self, recv, send, recv_counts, send_counts, async_op=False):
+        if self.size == 1 or not send.is_cuda or not send.dtype.is_floating_point:
+            return super().all_to_all_v(recv, send, recv_counts, send_counts, async_op)
+        self.exchange_begin(recv, send, recv_counts, send_counts)
+        return None
+
+
 class HipBackend:
     """numerical kernels of the distributed path on the Cdna4Executor"""
 
@@ -333,8 +400,15 @@ class DistributedMatrix:
         be, comm = self.backend, self.comm
         # 1. pack the rows the neighbours need (RowGatherer::apply_prepare)
         be.gather(x, self.send_idx, self.send_buf)
-        if comm.size > 1 and self._side is not None and not comm.host_staging:
-            # 2. exchange on a second stream, overlapped with 3.
+        if comm.size > 1 and self._side is not None and getattr(comm, "direct", False):
+            # 2. exchange on a second stream (ordering by events inside the library),
+            # overlapped with 3.
+            comm.exchange_begin(self.recv_buf.values, self.send_buf.values, self.recv_counts,
+                                self.send_counts, self._side)
+            be.spmv(self.local, x, y)                      # 3. local part
+            comm.exchange_end()
+        elif comm.size > 1 and self._side is not None and not comm.host_staging:
+            # the same through torch.distributed
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self._side):

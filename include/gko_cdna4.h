@@ -572,6 +572,42 @@ GKOC_DECL_XI(double, f64, int64_t, i64)
 GKOC_DECL_XI(float, f32, int32_t, i32)
 GKOC_DECL_XI(float, f32, int64_t, i64)
 
+/* ------------------------------------------------- communicator (RCCL over xGMI)
+ * Replaces, for device buffers, what the distributed path asks of
+ * experimental::mpi::communicator (include/ginkgo/core/base/mpi.hpp):
+ *   all_reduce (:838, in place, sum)          -> gkoc_comm_all_reduce_sum
+ *   i_all_to_all_v (:1441) + request::wait    -> gkoc_comm_exchange_begin / _end
+ * as used by distributed::Vector::compute_dot/norm2 (vector.cpp:473-592) and the
+ * RowGatherer (row_gatherer.cpp:67-190).  One communicator per process (= per
+ * GPU); the 128-byte id is created on rank 0 and handed to the other ranks by
+ * whatever the host program already has (MPI_Bcast, a key-value store).
+ * RCCL is bound at run time (gkoc_comm_load_rccl: path of the librccl the process
+ * should use, NULL = default search), so this library loads on machines without it.
+ * Every call enqueues on the given stream and returns; nothing synchronises. */
+typedef struct gkoc_comm_s* gkoc_comm_t;
+#define GKOC_COMM_ID_BYTES 128
+int gkoc_comm_load_rccl(const char* librccl_path);
+int gkoc_comm_unique_id(void* id_out /* GKOC_COMM_ID_BYTES */);
+int gkoc_comm_create(gkoc_comm_t* comm, int n_ranks, int rank, const void* id);
+int gkoc_comm_destroy(gkoc_comm_t comm);
+int gkoc_comm_size(gkoc_comm_t comm, int* n_ranks, int* rank);
+/* buf[0..n) <- sum over ranks, in place; value_size 8 (double) or 4 (float).
+ * Every rank receives the same bits (one reduction order for all). */
+int gkoc_comm_all_reduce_sum(gkoc_comm_t comm, gkoc_stream_t s, void* buf,
+                             int64_t n, size_t value_size);
+/* Sparse all-to-all of contiguous segments: send_counts[p] values leave
+ * send_buf (segments ordered by p) for rank p, recv_counts[p] values arrive
+ * into recv_buf from rank p; ranks with both counts 0 are not contacted.
+ * begin: `side` waits for what `main` has enqueued so far (the pack kernel),
+ * then carries the grouped send/recv, so kernels enqueued on `main` after
+ * begin overlap the transfer.  end: `main` waits for the transfer.
+ * side == main (or NULL): plain in-order exchange on main, end is a no-op. */
+int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream,
+                             gkoc_stream_t side, const void* send_buf,
+                             const int64_t* send_counts, void* recv_buf,
+                             const int64_t* recv_counts, size_t value_size);
+int gkoc_comm_exchange_end(gkoc_comm_t comm, gkoc_stream_t main_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,20 +16,43 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def mirror_problem(grid, direct=False):
+    """rank 0 of a 2-slab run whose peer is its own mirror image; collectives via RCCL:
+    through torch.distributed (TorchComm) or, direct=True, through the C ABI (RcclComm)"""
+    import ctypes as C
     import ginkgo_amd as g
     import ginkgo_amd.distributed as gd
-    from oracle import gko_oracle as oracle
+    from ginkgo_amd._lib import call
 
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    grid = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    plane, n = grid * grid, grid ** 3
+    plane = grid * grid
     calls = {"ar": 0, "a2a": 0}
+    ex = g.Cdna4Executor.create(0)
+
+    class DirectMirrorComm(gd.RcclComm):
+        def __init__(self):
+            super().__init__(ex)               # a real 1-rank RCCL communicator
+            self.rank, self.size = 0, 2
+
+        def all_reduce_sum_(self, t):
+            call("gkoc_comm_all_reduce_sum", self._handle, self.exec.stream, t, t.numel(),
+                 C.c_size_t(t.element_size()))
+            calls["ar"] += 1
+            return t.mul_(2)
+
+        def all_to_all_counts(self, send_counts):
+            return list(send_counts)
+
+        def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None):
+            assert list(recv_counts) == [0, plane] and list(send_counts) == [0, plane]
+            calls["a2a"] += 1
+            super().exchange_begin(recv, send, [plane], [plane], side_stream)   # to ourselves
+
+        def all_to_all_v(self, recv, send, recv_counts, send_counts, async_op=False):
+            assert recv.dtype == torch.int64   # set-up only; floats go through exchange_begin
+            recv.copy_(send - plane)
+            return None
 
     class RcclMirrorComm(gd.TorchComm):
-        """rank 0 of 2; the peer's messages are our own (mirror symmetry), moved by RCCL"""
-
         def __init__(self):
             super().__init__(None)
             assert not self.host_staging
@@ -51,15 +74,33 @@ def main():
                 recv.sub_(plane)
             return None
 
-    ex = g.Cdna4Executor.create(0)
-    rp, ci, v = oracle.stencil_csr(3, grid)
     part = gd.SlabPartition(grid, 2)
-    lo, hi = part.range_of(0)
     owned = g.stencil_csr(ex, 3, grid, z0=0, nz=grid // 2)
     be = gd.HipBackend(ex)
-    comm = RcclMirrorComm()
+    comm = DirectMirrorComm() if direct else RcclMirrorComm()
     a = gd.DistributedMatrix(be, comm, part, owned)
     assert a._side is not None and a.n_halo == plane
+    return be, comm, a, part, calls
+
+
+def init_rccl_single():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29655")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+
+def main():
+    import ginkgo_amd.distributed as gd
+    from oracle import gko_oracle as oracle
+
+    init_rccl_single()
+    grid = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    direct = len(sys.argv) > 2 and sys.argv[2] == "direct"
+    plane, n = grid * grid, grid ** 3
+    be, comm, a, part, calls = mirror_problem(grid, direct)
+    lo, hi = part.range_of(0)
+    rp, ci, v = oracle.stencil_csr(3, grid)
     half = np.random.default_rng(9).uniform(-1, 1, n // 2)
     xg = np.concatenate([half, half.reshape(grid // 2, plane)[::-1].reshape(-1)])
     x, y = be.vector_from(xg[lo:hi]), be.vector(hi - lo)
@@ -91,18 +132,17 @@ def main():
         a.apply(x, y)
     torch.cuda.synchronize()
     t_apply = (time.perf_counter() - t0) / 50
-    s2 = be.scalar_pair(torch.float64) if hasattr(be, "scalar_pair") else None
     t0 = time.perf_counter()
     for _ in range(50):
-        dist.all_reduce(y.values[:2].view(-1))
+        comm.all_reduce_sum_(y.values[:2].view(-1))
     torch.cuda.synchronize()
     t_ar = (time.perf_counter() - t0) / 50
-    print(f"rccl_mirror OK grid={grid} cg_iters={solver.num_iterations} all_reduce_calls={calls['ar']} "
+    print(f"rccl_mirror OK {'direct' if direct else 'torch'} grid={grid} cg_iters={solver.num_iterations} all_reduce_calls={calls['ar']} "
           f"a2a_calls={calls['a2a']} apply_us={t_apply * 1e6:.1f} all_reduce_us={t_ar * 1e6:.1f}")
+    if direct:
+        comm.close()
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29655")
     main()

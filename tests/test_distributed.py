@@ -149,12 +149,14 @@ def test_overlap_branch_with_mirror_comm(gexec, oracle):
 
 
 @pytest.mark.gpu
-def test_collectives_through_rccl_one_rank():
-    """the same mirror construction with every collective issued through backend
-    "nccl" (RCCL) on the device: tests/rccl_mirror_worker.py"""
+@pytest.mark.parametrize("how", ["torch", "direct"])
+def test_collectives_through_rccl_one_rank(how):
+    """the same mirror construction with every collective issued through RCCL on the
+    device - via torch.distributed backend "nccl", and via the library's own
+    communicator (gkoc_comm_*, RcclComm): tests/rccl_mirror_worker.py"""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(_free_port()))
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_mirror_worker.py"), "16"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_mirror_worker.py"), "16", how],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + "\n--- stderr ---\n" + p.stderr[-12000:]
     assert "rccl_mirror OK" in p.stdout
