@@ -246,6 +246,7 @@ def main():
             "config": {"workload": f"27-pt 3D Laplacian {grid}^3 CSR SpMV fp64 "
                                    f"(BASELINE configs[1]); n={n_global}, nnz={nnz_global}",
                        "index_type": "int32", "partition": f"{world} z-slab(s)",
+                       **({"communicator": type(op.comm).__name__} if use_dist else {}),
                        "pct_hbm_peak": round(100 * gbs / (HBM_PEAK_GBS * world), 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",

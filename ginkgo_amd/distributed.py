@@ -24,6 +24,7 @@ import torch
 import torch.distributed as dist
 
 from ._lib import IT, VT, GkoError, call, lib
+from ._lib import record as _record
 from .matrix import Csr, Dense, scalar, stencil_csr
 from .preconditioner import Jacobi
 
@@ -78,6 +79,12 @@ class TorchComm:
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.host_staging = dist.get_backend(group) == "gloo"
+
+    @property
+    def tapeable(self):
+        """collectives issued through call() alone (here: none at all) - _lib.Tape
+        may replay the code around them"""
+        return self.size == 1
 
     def _h(self, t):
         return t.cpu() if (self.host_staging and t.is_cuda) else t
@@ -135,20 +142,35 @@ class RcclComm(TorchComm):
         super().__init__(group)
         self.exec = exec_
         import os
+        dev = torch.device("cpu") if self.host_staging else exec_.device
+
+        def agree(ok, what):
+            """every rank learns whether the step worked everywhere, so that a local
+            failure raises on ALL ranks instead of leaving the others in a collective"""
+            if self.size > 1:
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok = bool(flag.item())
+            if not ok:
+                raise GkoError(f"RcclComm: {what} failed on at least one rank: "
+                               + lib().gkoc_last_error().decode(errors="replace"))
+
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        call("gkoc_comm_load_rccl", C.c_char_p(path.encode()) if os.path.exists(path) else None)
+        path = C.c_char_p(path.encode()) if os.path.exists(path) else None
+        agree(lib().gkoc_comm_load_rccl(path) == 0, "binding librccl")
         ident = (C.c_uint8 * 128)()
-        if self.rank == 0:
-            call("gkoc_comm_unique_id", ident)
+        agree(self.rank != 0 or lib().gkoc_comm_unique_id(ident) == 0, "ncclGetUniqueId")
         if self.size > 1:
-            dev = torch.device("cpu") if self.host_staging else exec_.device
             t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0,
                            group=group)
             ident = (C.c_uint8 * 128)(*t.cpu().tolist())
         self._handle = C.c_void_p(0)
-        call("gkoc_comm_create", C.byref(self._handle), C.c_int(self.size), C.c_int(self.rank), ident)
+        agree(lib().gkoc_comm_create(C.byref(self._handle), C.c_int(self.size), C.c_int(self.rank),
+                                     ident) == 0, "ncclCommInitRank")
         self._cnt = {}
+
+    tapeable = True
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -158,6 +180,8 @@ class RcclComm(TorchComm):
     def all_reduce_sum_(self, t):
         if self.size == 1:
             return t
+        if not (t.is_cuda and t.dtype.is_floating_point):
+            return super().all_reduce_sum_(t)      # set-up integers
         call("gkoc_comm_all_reduce_sum", self._handle, self.exec.stream, t, t.numel(),
              C.c_size_t(t.element_size()))
         return t
@@ -187,8 +211,42 @@ class RcclComm(TorchComm):
         return None
 
 
+def default_comm(exec_, group=None):
+    """The communicator of the product path: RcclComm when the process group runs
+    on RCCL and the library's own communicator comes up and passes a known-answer
+    all-reduce on every rank; otherwise (gloo, one rank, GKO_COMM=torch, or any
+    failure - reported on stderr) torch.distributed itself."""
+    import os
+    import sys
+    base = TorchComm(group)
+    if base.size == 1 or base.host_staging or os.environ.get("GKO_COMM", "") == "torch":
+        return base
+    ok, comm = True, None
+    try:
+        comm = RcclComm(exec_, group)
+        t = torch.full((2,), float(comm.rank + 1), dtype=torch.float64, device=exec_.device)
+        comm.all_reduce_sum_(t)
+        want = comm.size * (comm.size + 1) / 2
+        ok = bool((t == want).all().item())
+    except Exception as e:        # noqa: BLE001 - any failure means "use torch.distributed"
+        print(f"[ginkgo_amd] RcclComm unavailable, using torch.distributed: {e}", file=sys.stderr)
+        ok = False
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=exec_.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if bool(flag.item()):
+        return comm
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:          # noqa: BLE001
+            pass
+    return base
+
+
 class HipBackend:
     """numerical kernels of the distributed path on the Cdna4Executor"""
+
+    tapeable = True        # every kernel method below is a plain call()
 
     def __init__(self, exec_):
         self.exec = exec_
@@ -319,33 +377,42 @@ class HipBackend:
         t = self.exec.zeros((2,), dtype)
         return t, Dense(self.exec, t[0:1].view(1, 1)), Dense(self.exec, t[1:2].view(1, 1))
 
-    # asynchronous criterion check: the kernel and a 2-byte copy into pinned
-    # memory are enqueued, the host looks at the answer when the event is done
+    # asynchronous criterion check: the kernel writes its two flags straight into
+    # pinned host memory (one slot per in-flight check), an event marks it done;
+    # the host looks at the answer when it wants to
     _NSLOT = 16
 
     def check_begin(self, tau, tau0, factor, stop, squared=False):
         """squared: tau holds ||r||^2; the criterion kernel of ImplicitResidualNorm
         (sqrt(|tau|) <= factor * tau0, residual_norm.cpp:209-230) then saves the
         separate sqrt launch"""
-        if not hasattr(self, "_chk_dev"):
-            self._chk_dev = self.exec.zeros((self._NSLOT, 2), torch.uint8)
+        if not hasattr(self, "_chk_host"):
             self._chk_host = torch.zeros((self._NSLOT, 2), dtype=torch.uint8).pin_memory()
+            self._chk_np = self._chk_host.numpy()
+            self._chk_ev = [torch.cuda.Event() for _ in range(self._NSLOT)]
             self._chk_next = 0
+            self._chk_tapes = {}
         slot = self._chk_next
         self._chk_next = (slot + 1) % self._NSLOT
-        name = "gkoc_implicit_residual_norm_" if squared else "gkoc_residual_norm_"
-        call(name + VT[tau.dtype], self.exec.stream, 1, tau.values, tau0.values,
-             C.c_double(factor) if tau.dtype == torch.float64 else C.c_float(factor),
-             C.c_uint8(2), C.c_int(1), stop, self._chk_dev[slot], None, None)
-        self._chk_host[slot].copy_(self._chk_dev[slot], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        return slot, ev
+        key = (tau.values.data_ptr(), tau0.values.data_ptr(), stop.data_ptr(), factor, slot, squared)
+        tape = self._chk_tapes.get(key)
+        if tape is None:
+            if len(self._chk_tapes) > 4 * self._NSLOT:
+                self._chk_tapes.clear()
+            name = "gkoc_implicit_residual_norm_" if squared else "gkoc_residual_norm_"
+            with _record() as tape:
+                call(name + VT[tau.dtype], self.exec.stream, 1, tau.values, tau0.values,
+                     C.c_double(factor) if tau.dtype == torch.float64 else C.c_float(factor),
+                     C.c_uint8(2), C.c_int(1), stop, self._chk_host[slot], None, None)
+            self._chk_tapes[key] = tape
+        else:
+            tape.replay()
+        self._chk_ev[slot].record()
+        return slot
 
     def check_done(self, token, block=True):
-        slot, ev = token
-        ev.synchronize()
-        return bool(self._chk_host[slot, 0].item())
+        self._chk_ev[token].synchronize()
+        return bool(self._chk_np[token, 0])
 
     max_check_lag = 6       # must stay below _NSLOT
     check_takes_squared_norm = True
@@ -446,8 +513,9 @@ class DistributedCg:
       check_lag = 0 is the reference's lock-step behaviour."""
 
     def __init__(self, backend, comm, matrix, max_iters, reduction_factor=1e-10,
-                 max_block_size=8, check_lag=None, fused=True):
+                 max_block_size=8, check_lag=None, fused=True, taped=True):
         self.be, self.comm, self.a = backend, comm, matrix
+        self.taped = bool(taped)
         self.max_iters, self.factor = int(max_iters), float(reduction_factor)
         self.m = backend.jacobi(matrix.local, max_block_size) if max_block_size else None
         self.num_iterations = 0
@@ -496,9 +564,8 @@ class DistributedCg:
         self._norm2(b, self.tau0)              # ResidualNorm(rhs_norm) baseline
         pending = deque()
         fused = self.fused and hasattr(be, "cg_step_2_sqnorm")
-        have_sq = False
-        it = -1
-        while True:
+
+        def seg_a(cur, have_sq):
             pair, rho, tau = cur
             if not (self.m is not None and fused and be.jacobi_apply_dot(self.m, r, z, rho)):
                 if self.m is not None:
@@ -509,6 +576,40 @@ class DistributedCg:
             if not have_sq:
                 be.local_sqnorm(r, tau)
             self.comm.all_reduce_sum_(pair)    # one message: [<r,z>, ||r||^2]
+
+        def seg_b(cur, prev):
+            be.cg_step_1(p, z, cur[1], prev[1], self.stop)
+            a.apply(p, q)
+            self._dot(p, q, beta)
+            # the pair that is `cur` in the next iteration receives ||r_new||^2
+            hs = fused and be.cg_step_2_sqnorm(x, r, p, q, beta, cur[1], self.stop, prev[2])
+            if not hs:
+                be.cg_step_2(x, r, p, q, beta, cur[1], self.stop)
+            return hs
+
+        # The two halves of an iteration touch the same buffers every second
+        # iteration (the [rho, tau] pairs alternate): each variant is recorded the
+        # first time it runs and replayed afterwards (_lib.Tape).
+        taped = self.taped and getattr(be, "tapeable", False) and getattr(self.comm, "tapeable", False)
+        tapes = {}
+
+        def run(key, fn, *args):
+            if not taped:
+                return fn(*args)
+            t = tapes.get(key)
+            if t is not None:
+                return t.replay()
+            with _record() as t:
+                t.result = fn(*args)
+            tapes[key] = t
+            return t.result
+
+        have_sq = False
+        it = -1
+        while True:
+            parity = (it + 1) & 1
+            run(("a", parity, have_sq), seg_a, cur, have_sq)
+            tau = cur[2]
             it += 1
             if it >= self.max_iters:
                 stopped = self._drain(pending, it)
@@ -525,13 +626,7 @@ class DistributedCg:
             if stopped is not None:
                 it = stopped
                 break
-            be.cg_step_1(p, z, rho, prev[1], self.stop)
-            a.apply(p, q)
-            self._dot(p, q, beta)
-            # the pair that is `cur` in the next iteration receives ||r_new||^2
-            have_sq = fused and be.cg_step_2_sqnorm(x, r, p, q, beta, rho, self.stop, prev[2])
-            if not have_sq:
-                be.cg_step_2(x, r, p, q, beta, rho, self.stop)
+            have_sq = run(("b", parity), seg_b, cur, prev)
             cur, prev = prev, cur
         self.num_iterations = it
         return x
@@ -591,7 +686,7 @@ class DistributedStencil:
 
     def __init__(self, exec_, part, rank, comm=None):
         self.exec, self.part, self.rank = exec_, part, rank
-        self.comm = comm or TorchComm()
+        self.comm = comm or default_comm(exec_)
         z0, z1 = part.plane_offsets[rank], part.plane_offsets[rank + 1]
         owned = stencil_csr(exec_, 3, part.grid, z0=z0, nz=z1 - z0)
         self.backend = HipBackend(exec_)

@@ -32,12 +32,17 @@ def mirror_problem(grid, direct=False):
         def __init__(self):
             super().__init__(ex)               # a real 1-rank RCCL communicator
             self.rank, self.size = 0, 2
+            self.two = g.scalar(ex, 2.0, torch.float64)
 
         def all_reduce_sum_(self, t):
+            # the peer's contribution equals ours: sum = 2 x.  Everything through call()
+            # so that the solver's call tape (_lib.Tape) replays it.
+            assert t.is_cuda and t.dtype == torch.float64
             call("gkoc_comm_all_reduce_sum", self._handle, self.exec.stream, t, t.numel(),
                  C.c_size_t(t.element_size()))
+            call("gkoc_dense_scale_f64", self.exec.stream, t.numel(), 1, self.two.values, 1, t, 1)
             calls["ar"] += 1
-            return t.mul_(2)
+            return t
 
         def all_to_all_counts(self, send_counts):
             return list(send_counts)
@@ -123,7 +128,16 @@ def main():
                                      reduction=1e-9, precond="block", max_block_size=8)
     # restarted GMRES counts drift with rounding on long runs: exact only on the small grid
     assert gm.has_converged and abs(gm.num_iterations - it2) <= max(1, it2 // 10), (gm.num_iterations, it2)
-    assert calls["ar"] > 2 * iters and calls["a2a"] > iters
+    if direct:
+        # the recorded-call loop (Tape) against the plain loop: same bits
+        assert solver.taped and comm.tapeable and calls["ar"] > 4
+        plain = gd.DistributedCg(be, comm, a, 500, 1e-10, 8, taped=False)
+        xp = be.vector(hi - lo)
+        plain.apply(be.vector_from(np.ones(hi - lo)), xp)
+        assert plain.num_iterations == solver.num_iterations
+        assert np.array_equal(xp.to_numpy(), xs.to_numpy())
+    else:
+        assert calls["ar"] > 2 * iters and calls["a2a"] > iters
     # timing of the pieces under RCCL (informational)
     torch.cuda.synchronize()
     import time
