@@ -191,7 +191,8 @@ int gkoc_comm_all_reduce_sum(gkoc_comm_t comm, gkoc_stream_t s, void* buf, int64
 }
 
 int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_stream_t side,
-                             const void* send_buf, const int64_t* send_counts, void* recv_buf,
+                             const void* send_buf, const int64_t* send_counts,
+                             const int64_t* send_displs, void* recv_buf,
                              const int64_t* recv_counts, size_t value_size)
 {
     GKOC_REQUIRE(comm && send_counts && recv_counts, GKOC_E_INVALID, "bad argument");
@@ -204,6 +205,7 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
     int64_t n_msgs = 0;
     for (int p = 0; p < comm->n_ranks; ++p) {
         GKOC_REQUIRE(send_counts[p] >= 0 && recv_counts[p] >= 0, GKOC_E_INVALID, "negative count");
+        GKOC_REQUIRE(!send_displs || send_displs[p] >= 0, GKOC_E_INVALID, "negative displacement");
         n_msgs += (send_counts[p] > 0) + (recv_counts[p] > 0);
     }
     if (n_msgs == 0) return GKOC_OK;
@@ -220,6 +222,9 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
         // bytes as uint8: any value type travels unchanged
         const size_t sb = static_cast<size_t>(send_counts[p]) * value_size;
         const size_t rb = static_cast<size_t>(recv_counts[p]) * value_size;
+        if (send_displs) {
+            sp = static_cast<const char*>(send_buf) + static_cast<size_t>(send_displs[p]) * value_size;
+        }
         if (sb) e = g_rccl.Send(sp, sb, nccl_uint8, p, comm->comm, xs);
         if (rb && e == nccl_success) e = g_rccl.Recv(rp, rb, nccl_uint8, p, comm->comm, xs);
         sp += sb;

@@ -193,13 +193,17 @@ class RcclComm(TorchComm):
             arr = self._cnt[key] = (C.c_int64 * len(key))(*key)
         return arr
 
-    def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None):
+    def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None,
+                       send_displs=None):
         """halo exchange of float buffers; kernels enqueued on the executor's stream
-        before exchange_end overlap the transfer when side_stream is given"""
+        before exchange_end overlap the transfer when side_stream is given.
+        send_displs: per-peer offsets into `send` (then `send` is the vector itself
+        and no pack kernel ran); None: `send` is packed in rank order."""
         side = C.c_void_p(side_stream.cuda_stream) if side_stream is not None else None
         call("gkoc_comm_exchange_begin", self._handle, self.exec.stream, side, send,
-             self._counts(send_counts), recv, self._counts(recv_counts),
-             C.c_size_t(send.element_size()))
+             self._counts(send_counts),
+             self._counts(send_displs) if send_displs is not None else None, recv,
+             self._counts(recv_counts), C.c_size_t(send.element_size()))
 
     def exchange_end(self):
         call("gkoc_comm_exchange_end", self._handle, self.exec.stream)
@@ -456,6 +460,17 @@ class DistributedMatrix:
         want = backend.index_tensor(gidx, torch.int64)
         comm.all_to_all_v(send_gidx, want, self.send_counts, self.recv_counts)
         self.send_idx = (send_gidx - lo).to(idt)
+        # peers that want one contiguous row range each (slab partitions): the
+        # vector itself can be the send buffer (send_offsets of i_all_to_all_v)
+        sidx = backend.to_host(self.send_idx).astype(np.int64)
+        self.send_displs, pos = [], 0
+        for c in self.send_counts:
+            seg = sidx[pos:pos + c]
+            if c and not np.array_equal(seg, np.arange(seg[0], seg[0] + c)):
+                self.send_displs = None
+                break
+            self.send_displs.append(int(seg[0]) if c else 0)
+            pos += c
         self.n_halo, self.n_send = len(gidx), sum(self.send_counts)
         self.send_buf = backend.vector(self.n_send, self.dtype)
         self.recv_buf = backend.vector(self.n_halo, self.dtype)
@@ -465,13 +480,20 @@ class DistributedMatrix:
     def apply(self, x, y):
         """y_local = A[owned rows, :] x   (x, y: local parts, n_local x 1)"""
         be, comm = self.backend, self.comm
+        direct = comm.size > 1 and self._side is not None and getattr(comm, "direct", False)
+        zero_copy = direct and self.send_displs is not None and x.ld == 1 and x.size[1] == 1
         # 1. pack the rows the neighbours need (RowGatherer::apply_prepare)
-        be.gather(x, self.send_idx, self.send_buf)
-        if comm.size > 1 and self._side is not None and getattr(comm, "direct", False):
+        if not zero_copy:
+            be.gather(x, self.send_idx, self.send_buf)
+        if direct:
             # 2. exchange on a second stream (ordering by events inside the library),
             # overlapped with 3.
-            comm.exchange_begin(self.recv_buf.values, self.send_buf.values, self.recv_counts,
-                                self.send_counts, self._side)
+            if zero_copy:
+                comm.exchange_begin(self.recv_buf.values, x.values, self.recv_counts,
+                                    self.send_counts, self._side, self.send_displs)
+            else:
+                comm.exchange_begin(self.recv_buf.values, self.send_buf.values, self.recv_counts,
+                                    self.send_counts, self._side)
             be.spmv(self.local, x, y)                      # 3. local part
             comm.exchange_end()
         elif comm.size > 1 and self._side is not None and not comm.host_staging:

@@ -596,15 +596,20 @@ int gkoc_comm_size(gkoc_comm_t comm, int* n_ranks, int* rank);
 int gkoc_comm_all_reduce_sum(gkoc_comm_t comm, gkoc_stream_t s, void* buf,
                              int64_t n, size_t value_size);
 /* Sparse all-to-all of contiguous segments: send_counts[p] values leave
- * send_buf (segments ordered by p) for rank p, recv_counts[p] values arrive
- * into recv_buf from rank p; ranks with both counts 0 are not contacted.
+ * send_buf for rank p - from offset send_displs[p] (in values; the send_offsets
+ * of mpi.hpp:1441), or packed in rank order when send_displs == NULL -,
+ * recv_counts[p] values arrive into recv_buf from rank p, packed in rank order;
+ * ranks with both counts 0 are not contacted.  With displacements a rank whose
+ * peers want contiguous row ranges (slab partitions) sends straight out of the
+ * vector, without a pack kernel.
  * begin: `side` waits for what `main` has enqueued so far (the pack kernel),
  * then carries the grouped send/recv, so kernels enqueued on `main` after
  * begin overlap the transfer.  end: `main` waits for the transfer.
  * side == main (or NULL): plain in-order exchange on main, end is a no-op. */
 int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream,
                              gkoc_stream_t side, const void* send_buf,
-                             const int64_t* send_counts, void* recv_buf,
+                             const int64_t* send_counts,
+                             const int64_t* send_displs, void* recv_buf,
                              const int64_t* recv_counts, size_t value_size);
 int gkoc_comm_exchange_end(gkoc_comm_t comm, gkoc_stream_t main_stream);
 

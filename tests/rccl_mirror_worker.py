@@ -47,10 +47,13 @@ def mirror_problem(grid, direct=False):
         def all_to_all_counts(self, send_counts):
             return list(send_counts)
 
-        def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None):
+        def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None,
+                           send_displs=None):
             assert list(recv_counts) == [0, plane] and list(send_counts) == [0, plane]
             calls["a2a"] += 1
-            super().exchange_begin(recv, send, [plane], [plane], side_stream)   # to ourselves
+            calls["zero_copy"] = calls.get("zero_copy", 0) + (send_displs is not None)
+            super().exchange_begin(recv, send, [plane], [plane], side_stream,     # to ourselves
+                                   None if send_displs is None else [send_displs[1]])
 
         def all_to_all_v(self, recv, send, recv_counts, send_counts, async_op=False):
             assert recv.dtype == torch.int64   # set-up only; floats go through exchange_begin
@@ -131,6 +134,7 @@ def main():
     if direct:
         # the recorded-call loop (Tape) against the plain loop: same bits
         assert solver.taped and comm.tapeable and calls["ar"] > 4
+        assert calls["zero_copy"] > 0 and a.send_displs == [0, (grid // 2 - 1) * plane]
         plain = gd.DistributedCg(be, comm, a, 500, 1e-10, 8, taped=False)
         xp = be.vector(hi - lo)
         plain.apply(be.vector_from(np.ones(hi - lo)), xp)
