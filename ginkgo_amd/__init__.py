@@ -12,9 +12,10 @@ from .executor import Cdna4Executor
 from .matrix import Csr, Dense, Ell, Sellp, scalar, stencil_csr
 from .preconditioner import Jacobi, compute_storage_scheme
 from .solver import Cg, Gmres, Identity, ortho_method
+from .krylov import Bicgstab, Cgs, Fcg, PipeCg
 from . import stop
 
-__all__ = ["Cdna4Executor", "Csr", "Dense", "Ell", "Sellp", "scalar",
+__all__ = ["Bicgstab", "Cgs", "Fcg", "PipeCg", "Cdna4Executor", "Csr", "Dense", "Ell", "Sellp", "scalar",
            "stencil_csr", "Jacobi", "compute_storage_scheme", "Cg", "Gmres", "ortho_method", "Identity",
            "stop", "GkoError", "NotCompiled", "NotSupported",
            "DimensionMismatch", "LIB_PATH"]

@@ -14,6 +14,11 @@
 //    __device__ scalars load(int64_t col) const;          read device scalars
 //    __device__ bool skip(const scalars&) const;          whole column no-op
 //    __device__ void apply(const scalars&, const T* in, T* out) const;
+// and optionally
+//    __device__ void store(int64_t col, const scalars&) const;   write back a
+//        per-column scalar computed in load(); called by ONE thread per column
+//        that is not skipped.  load() must not depend on what store() writes
+//        (or the written value must equal the value read).
 // Outputs may alias inputs at the same element index only.
 #pragma once
 #include "common.hpp"
@@ -36,6 +41,16 @@ struct vec16 {
     T v[16 / sizeof(T)];
 } __attribute__((aligned(16)));
 
+template <typename OP, typename S>
+__device__ __forceinline__ auto ew_store(const OP& op, int64_t col, const S& sc, int)
+    -> decltype(op.store(col, sc), void())
+{
+    op.store(col, sc);
+}
+template <typename OP, typename S>
+__device__ __forceinline__ void ew_store(const OP&, int64_t, const S&, long)
+{}
+
 template <typename T, typename OP, int NIN, int NOUT>
 __global__ __launch_bounds__(256) void ew_flat_vec_kernel(
     int64_t n, ew_operands<T, NIN, NOUT> a, OP op)
@@ -44,6 +59,7 @@ __global__ __launch_bounds__(256) void ew_flat_vec_kernel(
     constexpr int W = V::width;
     const auto sc = op.load(0);
     if (op.skip(sc)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ew_store(op, 0, sc, 0);
     const int64_t n_vec = n / W;
     const int64_t stride = int64_t(gridDim.x) * 256;
     for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n_vec;
@@ -93,6 +109,7 @@ __global__ __launch_bounds__(256) void ew_general_kernel(
         const int64_t col = idx - row * cols;
         const auto sc = op.load(col);
         if (op.skip(sc)) continue;
+        if (row == 0) ew_store(op, col, sc, 0);
         T ie[NIN > 0 ? NIN : 1], oe[NOUT];
 #pragma unroll
         for (int k = 0; k < NIN; ++k) ie[k] = a.in[k][row * a.ld_in[k] + col];

@@ -1,0 +1,612 @@
+// Fused vector updates of the other Krylov solvers:
+//   bicgstab::{initialize, step_1, step_2, step_3, finalize}
+//     (decl core/solver/bicgstab_kernels.hpp; reference/solver/bicgstab_kernels.cpp:24-180;
+//      stock GPU version common/unified/solver/bicgstab_kernels.cpp)
+//   cgs::{initialize, step_1, step_2, step_3}       (reference/solver/cgs_kernels.cpp:24-146)
+//   fcg::{initialize, step_1, step_2}               (reference/solver/fcg_kernels.cpp:24-106)
+//   pipe_cg::{initialize_1, initialize_2, step_1, step_2}
+//                                                   (reference/solver/pipe_cg_kernels.cpp:24-164)
+// All of them are "per column: a few scalars; per element: a short update that
+// is skipped when the column has stopped" - the shape of elementwise.hpp: 16-byte
+// loads, every operand of an element group in flight before the first store.
+// Each result element is computed with the reference's expression (separate
+// multiplies, adds and divides, -ffp-contract=off) => bit-identical.
+// The scalars some kernels update (alpha, beta, omega) are written by one thread
+// per column (OP::store); every thread derives the value it needs from the
+// kernel's read-only inputs, so no thread depends on that write.
+// Algorithmic HBM traffic per element (values): bicgstab step_1 4, step_2 3,
+// step_3 8; cgs step_1 5, step_2 4, step_3 6; fcg step_1 3, step_2 7;
+// pipe_cg step_1 14, step_2 12.
+#include <cmath>
+
+#include "common.hpp"
+#include "elementwise.hpp"
+
+namespace gkoc {
+namespace {
+
+template <typename T, int NIN, int NOUT>
+struct operand_list {
+    ew_operands<T, NIN, NOUT> a{};
+    int ni = 0, no = 0;
+    operand_list& in(const T* p, int64_t ld)
+    {
+        a.in[ni] = p;
+        a.ld_in[ni++] = ld;
+        return *this;
+    }
+    operand_list& out(T* p, int64_t ld)
+    {
+        a.out[no] = p;
+        a.ld_out[no++] = ld;
+        return *this;
+    }
+};
+
+// scalars of the initialize kernels: value list per column, stop reset
+template <typename T, int N>
+struct scalar_init {
+    T* ptr[N];
+    T value[N];
+};
+
+template <typename T, int N>
+__global__ void init_scalars_kernel(int64_t cols, scalar_init<T, N> s, uint8_t* stop)
+{
+    const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j < cols) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) s.ptr[k][j] = s.value[k];
+        if (stop) stop[j] = 0;
+    }
+}
+
+template <typename T, int N>
+int launch_init_scalars(gkoc_stream_t s, int64_t cols, const scalar_init<T, N>& si, uint8_t* stop)
+{
+    if (cols <= 0) return GKOC_OK;
+    init_scalars_kernel<T, N><<<dim3(unsigned(ceildiv(cols, 256))), dim3(256), 0, as_stream(s)>>>(
+        cols, si, stop);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+// out[0] = in[0], out[1..NOUT) = 0   (and NCOPY leading outputs all copy in[0])
+template <typename T, int NCOPY, int NOUT>
+struct op_copy_and_zero {
+    struct scalars {};
+    __device__ scalars load(int64_t) const { return {}; }
+    __device__ bool skip(const scalars&) const { return false; }
+    __device__ void apply(const scalars&, const T* in, T* out) const
+    {
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) out[k] = k < NCOPY ? in[0] : T(0);
+    }
+};
+
+// ---------------------------------------------------------------- bicgstab
+// p = r + tmp (p - omega v), tmp = rho / prev_rho * alpha / omega ; p = r if
+// prev_rho * omega == 0.   in = {r, p, v}, out = {p}
+template <typename T>
+struct op_bicgstab_step1 {
+    const T *rho, *prev_rho, *alpha, *omega;
+    const uint8_t* stop;
+    struct scalars {
+        T tmp, omega;
+        bool plain, stopped;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T pr = prev_rho[c], om = omega[c];
+        const bool nz = pr * om != T(0);
+        return {nz ? rho[c] / pr * alpha[c] / om : T(0), om, !nz, status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = s.plain ? in[0] : in[0] + s.tmp * (in[1] - s.omega * in[2]);
+    }
+};
+
+// alpha = rho / beta ; s = r - alpha v   (alpha = 0, s = r if beta == 0)
+// in = {r, v}, out = {s}
+template <typename T>
+struct op_bicgstab_step2 {
+    const T *rho, *beta;
+    T* alpha;
+    const uint8_t* stop;
+    struct scalars {
+        T alpha;
+        bool plain, stopped;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T bt = beta[c];
+        const bool nz = bt != T(0);
+        return {nz ? rho[c] / bt : T(0), !nz, status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    __device__ void store(int64_t c, const scalars& s) const { alpha[c] = s.alpha; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = s.plain ? in[0] : in[0] - s.alpha * in[1];
+    }
+};
+
+// omega = gamma / beta (0 if beta == 0) ; x += alpha y + omega z ; r = s - omega t
+// in = {x, s, t, y, z}, out = {x, r}
+template <typename T>
+struct op_bicgstab_step3 {
+    const T *alpha, *beta, *gamma;
+    T* omega;
+    const uint8_t* stop;
+    struct scalars {
+        T alpha, omega;
+        bool stopped;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T bt = beta[c];
+        return {alpha[c], bt != T(0) ? gamma[c] / bt : T(0), status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    __device__ void store(int64_t c, const scalars& s) const { omega[c] = s.omega; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = in[0] + (s.alpha * in[3] + s.omega * in[4]);
+        out[1] = in[1] - s.omega * in[2];
+    }
+};
+
+// x += alpha y for columns that stopped but are not finalized.  in = {x, y}, out = {x}
+template <typename T>
+struct op_bicgstab_finalize {
+    const T* alpha;
+    const uint8_t* stop;
+    struct scalars {
+        T alpha;
+        bool skip;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const uint8_t st = stop[c];
+        return {alpha[c], !(status_has_stopped(st) && !(st & 0x40))};
+    }
+    __device__ bool skip(const scalars& s) const { return s.skip; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = in[0] + s.alpha * in[1];
+    }
+};
+
+// after the update: stopped columns become finalized (stopping_status::finalize).
+// A separate launch: the update kernel reads the flag this one sets.
+__global__ void finalize_status_kernel(int64_t cols, uint8_t* stop)
+{
+    const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j < cols && status_has_stopped(stop[j])) stop[j] |= uint8_t(0x40);
+}
+
+// --------------------------------------------------------------------- cgs
+// beta = rho / rho_prev (kept if rho_prev == 0) ; u = r + beta q ;
+// p = u + beta (q + beta p).   in = {r, q, p}, out = {u, p}
+template <typename T>
+struct op_cgs_step1 {
+    const T *rho, *rho_prev;
+    T* beta;
+    const uint8_t* stop;
+    struct scalars {
+        T beta;
+        bool stopped;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T pr = rho_prev[c];
+        // rho_prev == 0: the old beta is used and written back unchanged
+        return {pr != T(0) ? rho[c] / pr : beta[c], status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    __device__ void store(int64_t c, const scalars& s) const { beta[c] = s.beta; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        const T u = in[0] + s.beta * in[1];
+        out[0] = u;
+        out[1] = u + s.beta * (in[1] + s.beta * in[2]);
+    }
+};
+
+// alpha = rho / gamma (kept if gamma == 0) ; q = u - alpha v_hat ; t = u + q
+// in = {u, v_hat}, out = {q, t}
+template <typename T>
+struct op_cgs_step2 {
+    const T *rho, *gamma;
+    T* alpha;
+    const uint8_t* stop;
+    struct scalars {
+        T alpha;
+        bool stopped;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T g = gamma[c];
+        return {g != T(0) ? rho[c] / g : alpha[c], status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    __device__ void store(int64_t c, const scalars& s) const { alpha[c] = s.alpha; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        const T q = in[0] - s.alpha * in[1];
+        out[0] = q;
+        out[1] = in[0] + q;
+    }
+};
+
+// x += alpha u_hat ; r -= alpha t.   in = {x, u_hat, r, t}, out = {x, r}
+template <typename T>
+struct op_cgs_step3 {
+    const T* alpha;
+    const uint8_t* stop;
+    struct scalars {
+        T alpha;
+        bool stopped;
+    };
+    __device__ scalars load(int64_t c) const { return {alpha[c], status_has_stopped(stop[c])}; }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = in[0] + s.alpha * in[1];
+        out[1] = in[2] - s.alpha * in[3];
+    }
+};
+
+// --------------------------------------------------------------------- fcg
+// p = z + (rho_t / prev_rho) p ; p = z if prev_rho == 0.   in = {z, p}, out = {p}
+template <typename T>
+struct op_fcg_step1 {
+    const T *rho_t, *prev_rho;
+    const uint8_t* stop;
+    struct scalars {
+        T tmp;
+        bool plain, stopped;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T pr = prev_rho[c];
+        const bool z = pr == T(0);
+        return {z ? T(0) : rho_t[c] / pr, z, status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = s.plain ? in[0] : in[0] + s.tmp * in[1];
+    }
+};
+
+// tmp = rho / beta ; x += tmp p ; r_new = r - tmp q ; t = r_new - r  (beta != 0)
+// in = {x, r, p, q}, out = {x, r, t}
+template <typename T>
+struct op_fcg_step2 {
+    const T *beta, *rho;
+    const uint8_t* stop;
+    struct scalars {
+        T tmp;
+        bool noop;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T bt = beta[c];
+        const bool nz = bt != T(0);
+        return {nz ? rho[c] / bt : T(0), !nz || status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.noop; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        const T rn = in[1] - s.tmp * in[3];
+        out[0] = in[0] + s.tmp * in[2];
+        out[1] = rn;
+        out[2] = rn - in[1];
+    }
+};
+
+// ----------------------------------------------------------------- pipe_cg
+// p = z, q = w, f = m, g = n.   in = {z, w, m, n}, out = {p, q, f, g}
+template <typename T>
+struct op_copy4 {
+    struct scalars {};
+    __device__ scalars load(int64_t) const { return {}; }
+    __device__ bool skip(const scalars&) const { return false; }
+    __device__ void apply(const scalars&, const T* in, T* out) const
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = in[k];
+    }
+};
+
+template <typename T>
+__global__ void copy_scalars_kernel(int64_t cols, T* dst, const T* src)
+{
+    const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j < cols) dst[j] = src[j];
+}
+
+// tmp = rho / beta ; x += tmp p ; r -= tmp q ; z1 -= tmp f ; z2 = z1 ; w -= tmp g
+// in = {x, r, z1, w, p, q, f, g}, out = {x, r, z1, z2, w}
+template <typename T>
+struct op_pipe_cg_step1 {
+    const T *rho, *beta;
+    const uint8_t* stop;
+    struct scalars {
+        T tmp;
+        bool noop;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T bt = beta[c];
+        const bool nz = bt != T(0);
+        return {nz ? rho[c] / bt : T(0), !nz || status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.noop; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        const T z = in[2] - s.tmp * in[6];
+        out[0] = in[0] + s.tmp * in[4];
+        out[1] = in[1] - s.tmp * in[5];
+        out[2] = z;
+        out[3] = z;
+        out[4] = in[3] - s.tmp * in[7];
+    }
+};
+
+// tmp = rho / prev_rho ; beta = delta - |tmp|^2 beta (delta if that is 0) ;
+// p = z + tmp p ; q = w + tmp q ; f = m + tmp f ; g = n + tmp g
+// prev_rho == 0: beta = delta and plain copies.
+// in = {z, w, m, n, p, q, f, g}, out = {p, q, f, g}
+template <typename T>
+struct op_pipe_cg_step2 {
+    const T *prev_rho, *rho, *delta;
+    T* beta;
+    const uint8_t* stop;
+    struct scalars {
+        T tmp;
+        bool plain, stopped;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T pr = prev_rho[c];
+        const bool nz = pr != T(0);
+        return {nz ? rho[c] / pr : T(0), !nz, status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    // the only reader and writer of beta is this one thread
+    __device__ void store(int64_t c, const scalars& s) const
+    {
+        if (s.plain) {
+            beta[c] = delta[c];
+        } else {
+            const T a = fabs(s.tmp);
+            T b = delta[c] - a * a * beta[c];
+            if (b == T(0)) b = delta[c];
+            beta[c] = b;
+        }
+    }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = s.plain ? in[k] : in[k] + s.tmp * in[4 + k];
+    }
+};
+
+}  // namespace
+}  // namespace gkoc
+
+using namespace gkoc;
+
+#define GKOC_DEF_KRYLOV(T, TN)                                                            \
+    /* ------------------------------------------------------------ bicgstab */           \
+    extern "C" int gkoc_bicgstab_initialize_##TN(                                         \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* b, int64_t ldb, T* r,       \
+        int64_t ldr, T* rr, int64_t ldrr, T* y, int64_t ldy, T* sv, int64_t lds, T* t,    \
+        int64_t ldt, T* z, int64_t ldz, T* v, int64_t ldv, T* p, int64_t ldp,             \
+        T* prev_rho, T* rho, T* alpha, T* beta, T* gamma, T* omega, uint8_t* stop_status) \
+    {                                                                                     \
+        scalar_init<T, 6> si{{prev_rho, rho, alpha, beta, gamma, omega},                  \
+                             {T(1), T(1), T(1), T(1), T(1), T(1)}};                       \
+        int rc = launch_init_scalars<T, 6>(s, cols, si, stop_status);                     \
+        if (rc != GKOC_OK) return rc;                                                     \
+        operand_list<T, 1, 8> o;                                                          \
+        o.in(b, ldb).out(r, ldr).out(rr, ldrr).out(y, ldy).out(sv, lds).out(t, ldt)       \
+            .out(z, ldz).out(v, ldv).out(p, ldp);                                         \
+        return launch_elementwise<T, op_copy_and_zero<T, 1, 8>, 1, 8>(                    \
+            s, rows, cols, o.a, op_copy_and_zero<T, 1, 8>{}, true);                       \
+    }                                                                                     \
+    extern "C" int gkoc_bicgstab_step_1_##TN(                                             \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* r, int64_t ldr, T* p,       \
+        int64_t ldp, const T* v, int64_t ldv, const T* rho, const T* prev_rho,            \
+        const T* alpha, const T* omega, const uint8_t* stop_status)                       \
+    {                                                                                     \
+        operand_list<T, 3, 1> o;                                                          \
+        o.in(r, ldr).in(p, ldp).in(v, ldv).out(p, ldp);                                   \
+        return launch_elementwise<T, op_bicgstab_step1<T>, 3, 1>(                         \
+            s, rows, cols, o.a,                                                           \
+            op_bicgstab_step1<T>{rho, prev_rho, alpha, omega, stop_status}, false);       \
+    }                                                                                     \
+    extern "C" int gkoc_bicgstab_step_2_##TN(                                             \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* r, int64_t ldr, T* sv,      \
+        int64_t lds, const T* v, int64_t ldv, const T* rho, T* alpha, const T* beta,      \
+        const uint8_t* stop_status)                                                       \
+    {                                                                                     \
+        operand_list<T, 2, 1> o;                                                          \
+        o.in(r, ldr).in(v, ldv).out(sv, lds);                                             \
+        return launch_elementwise<T, op_bicgstab_step2<T>, 2, 1>(                         \
+            s, rows, cols, o.a, op_bicgstab_step2<T>{rho, beta, alpha, stop_status},      \
+            false);                                                                       \
+    }                                                                                     \
+    extern "C" int gkoc_bicgstab_step_3_##TN(                                             \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* r,             \
+        int64_t ldr, const T* sv, int64_t lds, const T* t, int64_t ldt, const T* y,       \
+        int64_t ldy, const T* z, int64_t ldz, const T* alpha, const T* beta,              \
+        const T* gamma, T* omega, const uint8_t* stop_status)                             \
+    {                                                                                     \
+        operand_list<T, 5, 2> o;                                                          \
+        o.in(x, ldx).in(sv, lds).in(t, ldt).in(y, ldy).in(z, ldz).out(x, ldx)             \
+            .out(r, ldr);                                                                 \
+        return launch_elementwise<T, op_bicgstab_step3<T>, 5, 2>(                         \
+            s, rows, cols, o.a,                                                           \
+            op_bicgstab_step3<T>{alpha, beta, gamma, omega, stop_status}, false);         \
+    }                                                                                     \
+    extern "C" int gkoc_bicgstab_finalize_##TN(                                           \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, const T* y,       \
+        int64_t ldy, const T* alpha, uint8_t* stop_status)                                \
+    {                                                                                     \
+        operand_list<T, 2, 1> o;                                                          \
+        o.in(x, ldx).in(y, ldy).out(x, ldx);                                              \
+        int rc = launch_elementwise<T, op_bicgstab_finalize<T>, 2, 1>(                    \
+            s, rows, cols, o.a, op_bicgstab_finalize<T>{alpha, stop_status}, false);      \
+        if (rc != GKOC_OK || cols <= 0 || rows <= 0) return rc;                           \
+        finalize_status_kernel<<<dim3(unsigned(ceildiv(cols, 256))), dim3(256), 0,        \
+                                 as_stream(s)>>>(cols, stop_status);                      \
+        GKOC_LAUNCH_OK();                                                                 \
+        return GKOC_OK;                                                                   \
+    }                                                                                     \
+    /* ----------------------------------------------------------------- cgs */           \
+    extern "C" int gkoc_cgs_initialize_##TN(                                              \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* b, int64_t ldb, T* r,       \
+        int64_t ldr, T* r_tld, int64_t ldrt, T* p, int64_t ldp, T* q, int64_t ldq, T* u,  \
+        int64_t ldu, T* u_hat, int64_t lduh, T* v_hat, int64_t ldvh, T* t, int64_t ldt,   \
+        T* alpha, T* beta, T* gamma, T* rho_prev, T* rho, uint8_t* stop_status)           \
+    {                                                                                     \
+        scalar_init<T, 5> si{{rho, rho_prev, alpha, beta, gamma},                         \
+                             {T(0), T(1), T(1), T(1), T(1)}};                             \
+        int rc = launch_init_scalars<T, 5>(s, cols, si, stop_status);                     \
+        if (rc != GKOC_OK) return rc;                                                     \
+        operand_list<T, 1, 8> o;                                                          \
+        o.in(b, ldb).out(r, ldr).out(r_tld, ldrt).out(p, ldp).out(q, ldq).out(u, ldu)     \
+            .out(u_hat, lduh).out(v_hat, ldvh).out(t, ldt);                               \
+        return launch_elementwise<T, op_copy_and_zero<T, 2, 8>, 1, 8>(                    \
+            s, rows, cols, o.a, op_copy_and_zero<T, 2, 8>{}, true);                       \
+    }                                                                                     \
+    extern "C" int gkoc_cgs_step_1_##TN(                                                  \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* r, int64_t ldr, T* u,       \
+        int64_t ldu, T* p, int64_t ldp, const T* q, int64_t ldq, T* beta, const T* rho,   \
+        const T* rho_prev, const uint8_t* stop_status)                                    \
+    {                                                                                     \
+        operand_list<T, 3, 2> o;                                                          \
+        o.in(r, ldr).in(q, ldq).in(p, ldp).out(u, ldu).out(p, ldp);                       \
+        return launch_elementwise<T, op_cgs_step1<T>, 3, 2>(                              \
+            s, rows, cols, o.a, op_cgs_step1<T>{rho, rho_prev, beta, stop_status},        \
+            false);                                                                       \
+    }                                                                                     \
+    extern "C" int gkoc_cgs_step_2_##TN(                                                  \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* u, int64_t ldu,             \
+        const T* v_hat, int64_t ldvh, T* q, int64_t ldq, T* t, int64_t ldt, T* alpha,     \
+        const T* rho, const T* gamma, const uint8_t* stop_status)                         \
+    {                                                                                     \
+        operand_list<T, 2, 2> o;                                                          \
+        o.in(u, ldu).in(v_hat, ldvh).out(q, ldq).out(t, ldt);                             \
+        return launch_elementwise<T, op_cgs_step2<T>, 2, 2>(                              \
+            s, rows, cols, o.a, op_cgs_step2<T>{rho, gamma, alpha, stop_status}, false);  \
+    }                                                                                     \
+    extern "C" int gkoc_cgs_step_3_##TN(                                                  \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* t, int64_t ldt,             \
+        const T* u_hat, int64_t lduh, T* r, int64_t ldr, T* x, int64_t ldx,               \
+        const T* alpha, const uint8_t* stop_status)                                       \
+    {                                                                                     \
+        operand_list<T, 4, 2> o;                                                          \
+        o.in(x, ldx).in(u_hat, lduh).in(r, ldr).in(t, ldt).out(x, ldx).out(r, ldr);       \
+        return launch_elementwise<T, op_cgs_step3<T>, 4, 2>(                              \
+            s, rows, cols, o.a, op_cgs_step3<T>{alpha, stop_status}, false);              \
+    }                                                                                     \
+    /* ----------------------------------------------------------------- fcg */           \
+    extern "C" int gkoc_fcg_initialize_##TN(                                              \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* b, int64_t ldb, T* r,       \
+        int64_t ldr, T* z, int64_t ldz, T* p, int64_t ldp, T* q, int64_t ldq, T* t,       \
+        int64_t ldt, T* prev_rho, T* rho, T* rho_t, uint8_t* stop_status)                 \
+    {                                                                                     \
+        scalar_init<T, 3> si{{rho, prev_rho, rho_t}, {T(0), T(1), T(1)}};                 \
+        int rc = launch_init_scalars<T, 3>(s, cols, si, stop_status);                     \
+        if (rc != GKOC_OK) return rc;                                                     \
+        operand_list<T, 1, 5> o;                                                          \
+        o.in(b, ldb).out(r, ldr).out(t, ldt).out(z, ldz).out(p, ldp).out(q, ldq);         \
+        return launch_elementwise<T, op_copy_and_zero<T, 2, 5>, 1, 5>(                    \
+            s, rows, cols, o.a, op_copy_and_zero<T, 2, 5>{}, true);                       \
+    }                                                                                     \
+    extern "C" int gkoc_fcg_step_1_##TN(                                                  \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* p, int64_t ldp, const T* z,       \
+        int64_t ldz, const T* rho_t, const T* prev_rho, const uint8_t* stop_status)       \
+    {                                                                                     \
+        operand_list<T, 2, 1> o;                                                          \
+        o.in(z, ldz).in(p, ldp).out(p, ldp);                                              \
+        return launch_elementwise<T, op_fcg_step1<T>, 2, 1>(                              \
+            s, rows, cols, o.a, op_fcg_step1<T>{rho_t, prev_rho, stop_status}, false);    \
+    }                                                                                     \
+    extern "C" int gkoc_fcg_step_2_##TN(                                                  \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* r,             \
+        int64_t ldr, T* t, int64_t ldt, const T* p, int64_t ldp, const T* q,              \
+        int64_t ldq, const T* beta, const T* rho, const uint8_t* stop_status)             \
+    {                                                                                     \
+        operand_list<T, 4, 3> o;                                                          \
+        o.in(x, ldx).in(r, ldr).in(p, ldp).in(q, ldq).out(x, ldx).out(r, ldr)             \
+            .out(t, ldt);                                                                 \
+        return launch_elementwise<T, op_fcg_step2<T>, 4, 3>(                              \
+            s, rows, cols, o.a, op_fcg_step2<T>{beta, rho, stop_status}, false);          \
+    }                                                                                     \
+    /* ------------------------------------------------------------- pipe_cg */           \
+    extern "C" int gkoc_pipe_cg_initialize_1_##TN(                                        \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* b, int64_t ldb, T* r,       \
+        int64_t ldr, T* prev_rho, uint8_t* stop_status)                                   \
+    {                                                                                     \
+        scalar_init<T, 1> si{{prev_rho}, {T(1)}};                                         \
+        int rc = launch_init_scalars<T, 1>(s, cols, si, stop_status);                     \
+        if (rc != GKOC_OK) return rc;                                                     \
+        operand_list<T, 1, 1> o;                                                          \
+        o.in(b, ldb).out(r, ldr);                                                         \
+        return launch_elementwise<T, op_copy_and_zero<T, 1, 1>, 1, 1>(                    \
+            s, rows, cols, o.a, op_copy_and_zero<T, 1, 1>{}, true);                       \
+    }                                                                                     \
+    extern "C" int gkoc_pipe_cg_initialize_2_##TN(                                        \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* p, int64_t ldp, T* q,             \
+        int64_t ldq, T* f, int64_t ldf, T* g, int64_t ldg, T* beta, const T* z,           \
+        int64_t ldz, const T* w, int64_t ldw, const T* m, int64_t ldm, const T* n,        \
+        int64_t ldn, const T* delta)                                                      \
+    {                                                                                     \
+        if (cols > 0) {                                                                   \
+            copy_scalars_kernel<T><<<dim3(unsigned(ceildiv(cols, 256))), dim3(256), 0,    \
+                                     as_stream(s)>>>(cols, beta, delta);                  \
+            GKOC_LAUNCH_OK();                                                             \
+        }                                                                                 \
+        operand_list<T, 4, 4> o;                                                          \
+        o.in(z, ldz).in(w, ldw).in(m, ldm).in(n, ldn).out(p, ldp).out(q, ldq)             \
+            .out(f, ldf).out(g, ldg);                                                     \
+        return launch_elementwise<T, op_copy4<T>, 4, 4>(s, rows, cols, o.a,               \
+                                                        op_copy4<T>{}, true);             \
+    }                                                                                     \
+    extern "C" int gkoc_pipe_cg_step_1_##TN(                                              \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* r,             \
+        int64_t ldr, T* z1, int64_t ldz1, T* z2, int64_t ldz2, T* w, int64_t ldw,         \
+        const T* p, int64_t ldp, const T* q, int64_t ldq, const T* f, int64_t ldf,        \
+        const T* g, int64_t ldg, const T* rho, const T* beta,                             \
+        const uint8_t* stop_status)                                                       \
+    {                                                                                     \
+        operand_list<T, 8, 5> o;                                                          \
+        o.in(x, ldx).in(r, ldr).in(z1, ldz1).in(w, ldw).in(p, ldp).in(q, ldq)             \
+            .in(f, ldf).in(g, ldg).out(x, ldx).out(r, ldr).out(z1, ldz1).out(z2, ldz2)    \
+            .out(w, ldw);                                                                 \
+        return launch_elementwise<T, op_pipe_cg_step1<T>, 8, 5>(                          \
+            s, rows, cols, o.a, op_pipe_cg_step1<T>{rho, beta, stop_status}, false);      \
+    }                                                                                     \
+    extern "C" int gkoc_pipe_cg_step_2_##TN(                                              \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* beta, T* p, int64_t ldp, T* q,    \
+        int64_t ldq, T* f, int64_t ldf, T* g, int64_t ldg, const T* z, int64_t ldz,       \
+        const T* w, int64_t ldw, const T* m, int64_t ldm, const T* n, int64_t ldn,        \
+        const T* prev_rho, const T* rho, const T* delta, const uint8_t* stop_status)      \
+    {                                                                                     \
+        operand_list<T, 8, 4> o;                                                          \
+        o.in(z, ldz).in(w, ldw).in(m, ldm).in(n, ldn).in(p, ldp).in(q, ldq).in(f, ldf)    \
+            .in(g, ldg).out(p, ldp).out(q, ldq).out(f, ldf).out(g, ldg);                  \
+        return launch_elementwise<T, op_pipe_cg_step2<T>, 8, 4>(                          \
+            s, rows, cols, o.a,                                                           \
+            op_pipe_cg_step2<T>{prev_rho, rho, delta, beta, stop_status}, false);         \
+    }
+
+GKOC_DEF_KRYLOV(double, f64)
+GKOC_DEF_KRYLOV(float, f32)

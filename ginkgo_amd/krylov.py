@@ -1,0 +1,246 @@
+"""Bicgstab, Cgs, Fcg and PipeCg on the Cdna4Executor.
+
+Each class is the driver of the reference with the same kernel sequence -
+  Bicgstab  core/solver/bicgstab.cpp:95-236
+  Cgs       core/solver/cgs.cpp:96-201
+  Fcg       core/solver/fcg.cpp:94-183
+  PipeCg    core/solver/pipe_cg.cpp:95-297
+- issuing the fused vector updates of csrc/krylov_steps.hip (gkoc_bicgstab_*,
+gkoc_cgs_*, gkoc_fcg_*, gkoc_pipe_cg_*) between the SpMV / preconditioner
+applications and the reductions.  The criterion is checked where the reference
+checks it (lock-step: these loops have two SpMVs per iteration, the host
+round-trip of a check is small against them).
+"""
+import torch
+
+from . import stop as _stop
+from ._lib import VT, call
+from .matrix import scalar
+from .solver import _IterativeSolver, _SolverFactory
+
+
+class _Krylov(_IterativeSolver):
+    def _common(self, b):
+        ex = self.exec
+        one = self._ws.setdefault(("one", b.dtype), scalar(ex, 1.0, b.dtype))
+        neg_one = self._ws.setdefault(("neg", b.dtype), scalar(ex, -1.0, b.dtype))
+        cols = b.size[1]
+        stop_status = self._ws.get("stop")
+        if stop_status is None or stop_status.numel() != cols:
+            stop_status = self._ws["stop"] = ex.zeros((cols,), torch.uint8)
+        return ex, one, neg_one, stop_status
+
+    def _check(self, crit, it, set_finalized, stop_status, residual, rho, x):
+        upd = {"num_iterations": it, "residual": residual, "implicit_sq_residual_norm": rho}
+        if x is not None:
+            upd["solution"] = x
+        return crit.check(1, set_finalized, stop_status, upd)
+
+    def _finish(self, it, stop_status, r):
+        self.num_iterations = it
+        self.stop_status = stop_status
+        self.has_converged = bool(((stop_status.cpu() & 0x80) != 0).all().item())
+        tau = self._scal("report_norm", r)
+        r.compute_norm2(tau)            # what log::Convergence reports
+        self.residual_norm = tau.to_numpy()[0]
+
+
+class Bicgstab(_Krylov):
+    @staticmethod
+    def build():
+        return _SolverFactory(Bicgstab)
+
+    def apply_impl(self, b, x):
+        a, m = self.system_matrix, self.preconditioner
+        ex, one, neg_one, stop = self._common(b)
+        suf = VT[b.dtype]
+        rows, cols = b.size
+        r, z, y, v, s, t, p, rr = (self._vec(n, b) for n in ("r", "z", "y", "v", "s", "t", "p", "rr"))
+        alpha, beta, gamma, prev_rho, rho, omega = (
+            self._scal(n, b) for n in ("alpha", "beta", "gamma", "prev_rho", "rho", "omega"))
+        st = lambda: ex.stream
+        # r = b ; prev_rho = rho = omega = alpha = beta = gamma = 1 ; rr = v = s = t = z = y = p = 0
+        call("gkoc_bicgstab_initialize_" + suf, st(), rows, cols, b.values, b.ld, r.values, r.ld,
+             rr.values, rr.ld, y.values, y.ld, s.values, s.ld, t.values, t.ld, z.values, z.ld,
+             v.values, v.ld, p.values, p.ld, prev_rho.values, rho.values, alpha.values,
+             beta.values, gamma.values, omega.values, stop)
+        a.apply(neg_one, x, one, r)                       # r = b - A x
+        crit = _stop.combine(self.criteria, a, b, x, r)
+        rr.copy_from(r)
+        it = -1
+        while True:
+            it += 1
+            rr.compute_conj_dot(r, rho)
+            if self._check(crit, it, True, stop, r, rho, x)[0]:
+                break
+            # p = r + (rho / prev_rho * alpha / omega) (p - omega v)
+            call("gkoc_bicgstab_step_1_" + suf, st(), rows, cols, r.values, r.ld, p.values, p.ld,
+                 v.values, v.ld, rho.values, prev_rho.values, alpha.values, omega.values, stop)
+            m.apply(p, y)
+            a.apply(y, v)
+            rr.compute_conj_dot(v, beta)
+            # alpha = rho / beta ; s = r - alpha v
+            call("gkoc_bicgstab_step_2_" + suf, st(), rows, cols, r.values, r.ld, s.values, s.ld,
+                 v.values, v.ld, rho.values, alpha.values, beta.values, stop)
+            all_stopped, one_changed = self._check(crit, it, False, stop, s, rho, None)
+            if one_changed:
+                # x += alpha y for the columns that just stopped
+                call("gkoc_bicgstab_finalize_" + suf, st(), rows, cols, x.values, x.ld, y.values,
+                     y.ld, alpha.values, stop)
+            if all_stopped:
+                break
+            m.apply(s, z)
+            a.apply(z, t)
+            s.compute_conj_dot(t, gamma)
+            t.compute_conj_dot(t, beta)
+            # omega = gamma / beta ; x += alpha y + omega z ; r = s - omega t
+            call("gkoc_bicgstab_step_3_" + suf, st(), rows, cols, x.values, x.ld, r.values, r.ld,
+                 s.values, s.ld, t.values, t.ld, y.values, y.ld, z.values, z.ld, alpha.values,
+                 beta.values, gamma.values, omega.values, stop)
+            prev_rho, rho = rho, prev_rho
+        self._finish(it, stop, r)
+
+
+class Cgs(_Krylov):
+    @staticmethod
+    def build():
+        return _SolverFactory(Cgs)
+
+    def apply_impl(self, b, x):
+        a, m = self.system_matrix, self.preconditioner
+        ex, one, neg_one, stop = self._common(b)
+        suf = VT[b.dtype]
+        rows, cols = b.size
+        r, r_tld, p, q, u, u_hat, v_hat, t = (
+            self._vec(n, b) for n in ("r", "r_tld", "p", "q", "u", "u_hat", "v_hat", "t"))
+        alpha, beta, gamma, prev_rho, rho = (
+            self._scal(n, b) for n in ("alpha", "beta", "gamma", "prev_rho", "rho"))
+        st = lambda: ex.stream
+        call("gkoc_cgs_initialize_" + suf, st(), rows, cols, b.values, b.ld, r.values, r.ld,
+             r_tld.values, r_tld.ld, p.values, p.ld, q.values, q.ld, u.values, u.ld,
+             u_hat.values, u_hat.ld, v_hat.values, v_hat.ld, t.values, t.ld, alpha.values,
+             beta.values, gamma.values, prev_rho.values, rho.values, stop)
+        a.apply(neg_one, x, one, r)
+        crit = _stop.combine(self.criteria, a, b, x, r)
+        r_tld.copy_from(r)
+        it = -1
+        while True:
+            r.compute_conj_dot(r_tld, rho)
+            it += 1
+            if self._check(crit, it, True, stop, r, rho, x)[0]:
+                break
+            # beta = rho / prev_rho ; u = r + beta q ; p = u + beta (q + beta p)
+            call("gkoc_cgs_step_1_" + suf, st(), rows, cols, r.values, r.ld, u.values, u.ld,
+                 p.values, p.ld, q.values, q.ld, beta.values, rho.values, prev_rho.values, stop)
+            m.apply(p, t)
+            a.apply(t, v_hat)
+            r_tld.compute_conj_dot(v_hat, gamma)
+            # alpha = rho / gamma ; q = u - alpha v_hat ; t = u + q
+            call("gkoc_cgs_step_2_" + suf, st(), rows, cols, u.values, u.ld, v_hat.values,
+                 v_hat.ld, q.values, q.ld, t.values, t.ld, alpha.values, rho.values,
+                 gamma.values, stop)
+            m.apply(t, u_hat)
+            a.apply(u_hat, t)
+            # r -= alpha t ; x += alpha u_hat
+            call("gkoc_cgs_step_3_" + suf, st(), rows, cols, t.values, t.ld, u_hat.values,
+                 u_hat.ld, r.values, r.ld, x.values, x.ld, alpha.values, stop)
+            prev_rho, rho = rho, prev_rho
+        self._finish(it, stop, r)
+
+
+class Fcg(_Krylov):
+    @staticmethod
+    def build():
+        return _SolverFactory(Fcg)
+
+    def apply_impl(self, b, x):
+        a, m = self.system_matrix, self.preconditioner
+        ex, one, neg_one, stop = self._common(b)
+        suf = VT[b.dtype]
+        rows, cols = b.size
+        r, z, p, q, t = (self._vec(n, b) for n in ("r", "z", "p", "q", "t"))
+        beta, prev_rho, rho, rho_t = (self._scal(n, b) for n in ("beta", "prev_rho", "rho", "rho_t"))
+        st = lambda: ex.stream
+        # r = t = b ; rho = 0 ; prev_rho = rho_t = 1 ; z = p = q = 0
+        call("gkoc_fcg_initialize_" + suf, st(), rows, cols, b.values, b.ld, r.values, r.ld,
+             z.values, z.ld, p.values, p.ld, q.values, q.ld, t.values, t.ld, prev_rho.values,
+             rho.values, rho_t.values, stop)
+        a.apply(neg_one, x, one, r)
+        crit = _stop.combine(self.criteria, a, b, x, r)
+        it = -1
+        while True:
+            m.apply(r, z)
+            r.compute_conj_dot(z, rho)
+            t.compute_conj_dot(z, rho_t)
+            it += 1
+            if self._check(crit, it, True, stop, r, rho, x)[0]:
+                break
+            # p = z + (rho_t / prev_rho) p
+            call("gkoc_fcg_step_1_" + suf, st(), rows, cols, p.values, p.ld, z.values, z.ld,
+                 rho_t.values, prev_rho.values, stop)
+            a.apply(p, q)
+            p.compute_conj_dot(q, beta)
+            # x += (rho / beta) p ; r -= (rho / beta) q ; t = r_new - r_old
+            call("gkoc_fcg_step_2_" + suf, st(), rows, cols, x.values, x.ld, r.values, r.ld,
+                 t.values, t.ld, p.values, p.ld, q.values, q.ld, beta.values, rho.values, stop)
+            prev_rho, rho = rho, prev_rho
+        self._finish(it, stop, r)
+
+
+class PipeCg(_Krylov):
+    """The reference interleaves (r, w) and (z1, z2) as the two columns of one
+    matrix so that rho = <r, z> and delta = <w, z> come out of one 2-column dot
+    (pipe_cg.cpp:106-160).  Here r, w, z are separate unit-stride vectors - the
+    layout the SpMV and the preconditioner are fastest on - and z2 is z1 itself;
+    the two dots are two reductions of the same values."""
+
+    @staticmethod
+    def build():
+        return _SolverFactory(PipeCg)
+
+    def apply_impl(self, b, x):
+        a, m_op = self.system_matrix, self.preconditioner
+        ex, one, neg_one, stop = self._common(b)
+        suf = VT[b.dtype]
+        rows, cols = b.size
+        r, w, z, p, m, n, q, f, g = (
+            self._vec(k, b) for k in ("r", "w", "z", "p", "m", "n", "q", "f", "g"))
+        rho, delta, beta, prev_rho = (self._scal(k, b) for k in ("rho", "delta", "beta", "prev_rho"))
+        st = lambda: ex.stream
+        # r = b ; prev_rho = 1
+        call("gkoc_pipe_cg_initialize_1_" + suf, st(), rows, cols, b.values, b.ld, r.values, r.ld,
+             prev_rho.values, stop)
+        a.apply(neg_one, x, one, r)
+        m_op.apply(r, z)
+        a.apply(z, w)
+        m_op.apply(w, m)
+        a.apply(m, n)
+        r.compute_conj_dot(z, rho)
+        w.compute_conj_dot(z, delta)
+        crit = _stop.combine(self.criteria, a, b, x, r)
+        it = 0
+        if not self._check(crit, it, True, stop, r, rho, x)[0]:
+            # beta = delta ; p = z ; q = w ; f = m ; g = n
+            call("gkoc_pipe_cg_initialize_2_" + suf, st(), rows, cols, p.values, p.ld, q.values,
+                 q.ld, f.values, f.ld, g.values, g.ld, beta.values, z.values, z.ld, w.values,
+                 w.ld, m.values, m.ld, n.values, n.ld, delta.values)
+            while True:
+                # x += t p ; r -= t q ; z -= t f ; w -= t g   (t = rho / beta)
+                call("gkoc_pipe_cg_step_1_" + suf, st(), rows, cols, x.values, x.ld, r.values,
+                     r.ld, z.values, z.ld, z.values, z.ld, w.values, w.ld, p.values, p.ld,
+                     q.values, q.ld, f.values, f.ld, g.values, g.ld, rho.values, beta.values,
+                     stop)
+                m_op.apply(w, m)
+                a.apply(m, n)
+                prev_rho.copy_from(rho)
+                r.compute_conj_dot(z, rho)
+                w.compute_conj_dot(z, delta)
+                it += 1
+                if self._check(crit, it, True, stop, r, rho, x)[0]:
+                    break
+                # beta = delta - |rho / prev_rho|^2 beta ; p = z + t p ; q = w + t q ; ...
+                call("gkoc_pipe_cg_step_2_" + suf, st(), rows, cols, beta.values, p.values, p.ld,
+                     q.values, q.ld, f.values, f.ld, g.values, g.ld, z.values, z.ld, w.values,
+                     w.ld, m.values, m.ld, n.values, n.ld, prev_rho.values, rho.values,
+                     delta.values, stop)
+        self._finish(it, stop, r)

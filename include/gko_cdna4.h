@@ -572,6 +572,92 @@ GKOC_DECL_XI(double, f64, int64_t, i64)
 GKOC_DECL_XI(float, f32, int32_t, i32)
 GKOC_DECL_XI(float, f32, int64_t, i64)
 
+/* ------------------------------------------------- other Krylov solvers
+ * The fused vector updates of Bicgstab, Cgs, Fcg and PipeCg - the kernels
+ * core/solver/{bicgstab,cgs,fcg,pipe_cg}.cpp issue through exec->run:
+ *   bicgstab::{initialize, step_1, step_2, step_3, finalize}
+ *       (core/solver/bicgstab_kernels.hpp:23-75; reference/solver/bicgstab_kernels.cpp:24-180)
+ *   cgs::{initialize, step_1, step_2, step_3}
+ *       (core/solver/cgs_kernels.hpp; reference/solver/cgs_kernels.cpp:24-146)
+ *   fcg::{initialize, step_1, step_2}
+ *       (core/solver/fcg_kernels.hpp; reference/solver/fcg_kernels.cpp:24-106)
+ *   pipe_cg::{initialize_1, initialize_2, step_1, step_2}
+ *       (core/solver/pipe_cg_kernels.hpp; reference/solver/pipe_cg_kernels.cpp:24-164)
+ * Argument order = the reference kernel's, every rows x cols operand followed by
+ * its leading dimension; scalars are device arrays of `cols` values; columns whose
+ * stop_status has stopped are left untouched.  Results bit-identical to the
+ * reference (same expressions, no contraction). */
+#define GKOC_DECL_KRYLOV(T, TN) \
+    int gkoc_bicgstab_initialize_##TN(gkoc_stream_t s, int64_t rows, int64_t \
+        cols, const T* b, int64_t ldb, T* r, int64_t ldr, T* rr, int64_t \
+        ldrr, T* y, int64_t ldy, T* sv, int64_t lds, T* t, int64_t ldt, T* \
+        z, int64_t ldz, T* v, int64_t ldv, T* p, int64_t ldp, T* prev_rho, \
+        T* rho, T* alpha, T* beta, T* gamma, T* omega, uint8_t* \
+        stop_status); \
+    int gkoc_bicgstab_step_1_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, \
+        const T* r, int64_t ldr, T* p, int64_t ldp, const T* v, int64_t ldv, \
+        const T* rho, const T* prev_rho, const T* alpha, const T* omega, \
+        const uint8_t* stop_status); \
+    int gkoc_bicgstab_step_2_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, \
+        const T* r, int64_t ldr, T* sv, int64_t lds, const T* v, int64_t \
+        ldv, const T* rho, T* alpha, const T* beta, const uint8_t* \
+        stop_status); \
+    int gkoc_bicgstab_step_3_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, \
+        T* x, int64_t ldx, T* r, int64_t ldr, const T* sv, int64_t lds, \
+        const T* t, int64_t ldt, const T* y, int64_t ldy, const T* z, \
+        int64_t ldz, const T* alpha, const T* beta, const T* gamma, T* \
+        omega, const uint8_t* stop_status); \
+    int gkoc_bicgstab_finalize_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, \
+        T* x, int64_t ldx, const T* y, int64_t ldy, const T* alpha, uint8_t* \
+        stop_status); \
+    int gkoc_cgs_initialize_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, \
+        const T* b, int64_t ldb, T* r, int64_t ldr, T* r_tld, int64_t ldrt, \
+        T* p, int64_t ldp, T* q, int64_t ldq, T* u, int64_t ldu, T* u_hat, \
+        int64_t lduh, T* v_hat, int64_t ldvh, T* t, int64_t ldt, T* alpha, \
+        T* beta, T* gamma, T* rho_prev, T* rho, uint8_t* stop_status); \
+    int gkoc_cgs_step_1_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const \
+        T* r, int64_t ldr, T* u, int64_t ldu, T* p, int64_t ldp, const T* q, \
+        int64_t ldq, T* beta, const T* rho, const T* rho_prev, const \
+        uint8_t* stop_status); \
+    int gkoc_cgs_step_2_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const \
+        T* u, int64_t ldu, const T* v_hat, int64_t ldvh, T* q, int64_t ldq, \
+        T* t, int64_t ldt, T* alpha, const T* rho, const T* gamma, const \
+        uint8_t* stop_status); \
+    int gkoc_cgs_step_3_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const \
+        T* t, int64_t ldt, const T* u_hat, int64_t lduh, T* r, int64_t ldr, \
+        T* x, int64_t ldx, const T* alpha, const uint8_t* stop_status); \
+    int gkoc_fcg_initialize_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, \
+        const T* b, int64_t ldb, T* r, int64_t ldr, T* z, int64_t ldz, T* p, \
+        int64_t ldp, T* q, int64_t ldq, T* t, int64_t ldt, T* prev_rho, T* \
+        rho, T* rho_t, uint8_t* stop_status); \
+    int gkoc_fcg_step_1_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, T* p, \
+        int64_t ldp, const T* z, int64_t ldz, const T* rho_t, const T* \
+        prev_rho, const uint8_t* stop_status); \
+    int gkoc_fcg_step_2_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, T* x, \
+        int64_t ldx, T* r, int64_t ldr, T* t, int64_t ldt, const T* p, \
+        int64_t ldp, const T* q, int64_t ldq, const T* beta, const T* rho, \
+        const uint8_t* stop_status); \
+    int gkoc_pipe_cg_initialize_1_##TN(gkoc_stream_t s, int64_t rows, int64_t \
+        cols, const T* b, int64_t ldb, T* r, int64_t ldr, T* prev_rho, \
+        uint8_t* stop_status); \
+    int gkoc_pipe_cg_initialize_2_##TN(gkoc_stream_t s, int64_t rows, int64_t \
+        cols, T* p, int64_t ldp, T* q, int64_t ldq, T* f, int64_t ldf, T* g, \
+        int64_t ldg, T* beta, const T* z, int64_t ldz, const T* w, int64_t \
+        ldw, const T* m, int64_t ldm, const T* n, int64_t ldn, const T* \
+        delta); \
+    int gkoc_pipe_cg_step_1_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, T* \
+        x, int64_t ldx, T* r, int64_t ldr, T* z1, int64_t ldz1, T* z2, \
+        int64_t ldz2, T* w, int64_t ldw, const T* p, int64_t ldp, const T* \
+        q, int64_t ldq, const T* f, int64_t ldf, const T* g, int64_t ldg, \
+        const T* rho, const T* beta, const uint8_t* stop_status); \
+    int gkoc_pipe_cg_step_2_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, T* \
+        beta, T* p, int64_t ldp, T* q, int64_t ldq, T* f, int64_t ldf, T* g, \
+        int64_t ldg, const T* z, int64_t ldz, const T* w, int64_t ldw, const \
+        T* m, int64_t ldm, const T* n, int64_t ldn, const T* prev_rho, const \
+        T* rho, const T* delta, const uint8_t* stop_status);
+GKOC_DECL_KRYLOV(double, f64)
+GKOC_DECL_KRYLOV(float, f32)
+
 /* ------------------------------------------------- communicator (RCCL over xGMI)
  * Replaces, for device buffers, what the distributed path asks of
  * experimental::mpi::communicator (include/ginkgo/core/base/mpi.hpp):

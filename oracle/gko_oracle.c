@@ -362,6 +362,173 @@ int64_t oracle_cg_solve_f64_i32(int64_t n, const int32_t* row_ptrs,
     return iter;
 }
 
+/* ---- the other Krylov drivers ------------------------------------------
+ * One right-hand side, f64 / int32, same preconditioner and criterion
+ * conventions as oracle_cg_solve (Combined(Iteration, ResidualNorm(baseline)),
+ * ids 1 and 2).  kind:
+ *   1 Bicgstab  core/solver/bicgstab.cpp:95-236
+ *   2 Cgs       core/solver/cgs.cpp:96-201
+ *   3 Fcg       core/solver/fcg.cpp:94-183
+ *   4 PipeCg    core/solver/pipe_cg.cpp:95-297 (the reference interleaves r/w and
+ *               z1/z2 as two columns to merge the two dots; the values are the
+ *               same with separate vectors, which is what is restated here)
+ * Returns the iteration count at exit; *resnorm_out = ||r||_2 as the reference's
+ * Convergence logger reports it. */
+static int krylov_check(int64_t iter, int64_t max_iters, int64_t n,
+                        const double* res, double tau0, double reduction,
+                        int set_finalized, uint8_t* stop, int* one_changed,
+                        double* tau)
+{
+    *one_changed = 0;
+    /* (the logger computes this norm itself when the Iteration criterion ends the loop) */
+    oracle_dense_compute_norm2_f64(n, 1, res, 1, tau, 0);
+    if (iter >= max_iters) { /* stop::Iteration, id 1 (iteration.cpp:15-26) */
+        if ((*stop & 0x3f) == 0) *stop |= (uint8_t)1 | (set_finalized ? 0x40 : 0);
+        *one_changed = 1;
+        return 1;
+    }
+    return oracle_residual_norm_f64(1, tau, &tau0, reduction, 2, set_finalized, stop,
+                                    0, one_changed);
+}
+
+int64_t oracle_krylov_solve_f64_i32(int kind, int64_t n, const int32_t* row_ptrs,
+                                    const int32_t* cols, const double* vals,
+                                    const oracle_precond* m, const double* b,
+                                    double* x, int64_t max_iters, double reduction,
+                                    int baseline, double* resnorm_out)
+{
+    const size_t N = (size_t)n;
+    double* w = (double*)calloc(N * 12, sizeof(double));
+    double* V[12];
+    for (int k = 0; k < 12; ++k) V[k] = w + N * (size_t)k;
+    double tau = 0.0, tau0 = 1.0;
+    uint8_t stop = 0;
+    int one_changed = 0;
+    int64_t iter = -1;
+#define SPMV(in, out) oracle_csr_spmv_f64_i32(n, row_ptrs, cols, vals, in, 1, out, 1, 1)
+#define RESID(r) oracle_csr_advanced_spmv_f64_i32(n, -1.0, row_ptrs, cols, vals, x, 1, 1.0, r, 1, 1)
+#define DOT(a, c, out) oracle_dense_compute_dot_f64(n, 1, a, 1, c, 1, out)
+#define BASELINE(r)                                                     \
+    do {                                                                \
+        if (baseline == 0) oracle_dense_compute_norm2_f64(n, 1, b, 1, &tau0, 0); \
+        else if (baseline == 1) oracle_dense_compute_norm2_f64(n, 1, r, 1, &tau0, 0); \
+        else tau0 = 1.0;                                                \
+    } while (0)
+    if (kind == 1) {
+        double *r = V[0], *z = V[1], *y = V[2], *v = V[3], *s = V[4], *t = V[5], *p = V[6],
+               *rr = V[7];
+        double alpha, beta, gamma, prev_rho, rho, omega;
+        oracle_bicgstab_initialize_f64(n, 1, 1, b, r, rr, y, s, t, z, v, p, &prev_rho, &rho,
+                                       &alpha, &beta, &gamma, &omega, &stop);
+        RESID(r);
+        BASELINE(r);
+        memcpy(rr, r, sizeof(double) * N);
+        for (;;) {
+            ++iter;
+            DOT(rr, r, &rho);
+            if (krylov_check(iter, max_iters, n, r, tau0, reduction, 1, &stop, &one_changed, &tau)) break;
+            oracle_bicgstab_step_1_f64(n, 1, 1, r, p, v, &rho, &prev_rho, &alpha, &omega, &stop);
+            apply_precond(m, n, p, y);
+            SPMV(y, v);
+            DOT(rr, v, &beta);
+            oracle_bicgstab_step_2_f64(n, 1, 1, r, s, v, &rho, &alpha, &beta, &stop);
+            /* the Convergence logger is handed r, not s, after this check
+             * (bicgstab.cpp:183-185): the reported norm stays ||r|| */
+            double tau_s = 0.0;
+            const int all = krylov_check(iter, max_iters, n, s, tau0, reduction, 0, &stop,
+                                         &one_changed, &tau_s);
+            if (one_changed) oracle_bicgstab_finalize_f64(n, 1, 1, x, y, &alpha, &stop);
+            if (all) break;
+            apply_precond(m, n, s, z);
+            SPMV(z, t);
+            DOT(s, t, &gamma);
+            DOT(t, t, &beta);
+            oracle_bicgstab_step_3_f64(n, 1, 1, x, r, s, t, y, z, &alpha, &beta, &gamma, &omega, &stop);
+            { const double tmp = prev_rho; prev_rho = rho; rho = tmp; }
+        }
+    } else if (kind == 2) {
+        double *r = V[0], *r_tld = V[1], *p = V[2], *q = V[3], *u = V[4], *u_hat = V[5],
+               *v_hat = V[6], *t = V[7];
+        double alpha, beta, gamma, prev_rho, rho;
+        oracle_cgs_initialize_f64(n, 1, 1, b, r, r_tld, p, q, u, u_hat, v_hat, t, &alpha, &beta,
+                                  &gamma, &prev_rho, &rho, &stop);
+        RESID(r);
+        BASELINE(r);
+        memcpy(r_tld, r, sizeof(double) * N);
+        for (;;) {
+            DOT(r, r_tld, &rho);
+            ++iter;
+            if (krylov_check(iter, max_iters, n, r, tau0, reduction, 1, &stop, &one_changed, &tau)) break;
+            oracle_cgs_step_1_f64(n, 1, 1, r, u, p, q, &beta, &rho, &prev_rho, &stop);
+            apply_precond(m, n, p, t);
+            SPMV(t, v_hat);
+            DOT(r_tld, v_hat, &gamma);
+            oracle_cgs_step_2_f64(n, 1, 1, u, v_hat, q, t, &alpha, &rho, &gamma, &stop);
+            apply_precond(m, n, t, u_hat);
+            SPMV(u_hat, t);
+            oracle_cgs_step_3_f64(n, 1, 1, t, u_hat, r, x, &alpha, &stop);
+            { const double tmp = prev_rho; prev_rho = rho; rho = tmp; }
+        }
+    } else if (kind == 3) {
+        double *r = V[0], *z = V[1], *p = V[2], *q = V[3], *t = V[4];
+        double beta, prev_rho, rho, rho_t;
+        oracle_fcg_initialize_f64(n, 1, 1, b, r, z, p, q, t, &prev_rho, &rho, &rho_t, &stop);
+        RESID(r);
+        BASELINE(r);
+        for (;;) {
+            apply_precond(m, n, r, z);
+            DOT(r, z, &rho);
+            DOT(t, z, &rho_t);
+            ++iter;
+            if (krylov_check(iter, max_iters, n, r, tau0, reduction, 1, &stop, &one_changed, &tau)) break;
+            oracle_fcg_step_1_f64(n, 1, 1, p, z, &rho_t, &prev_rho, &stop);
+            SPMV(p, q);
+            DOT(p, q, &beta);
+            oracle_fcg_step_2_f64(n, 1, 1, x, r, t, p, q, &beta, &rho, &stop);
+            { const double tmp = prev_rho; prev_rho = rho; rho = tmp; }
+        }
+    } else if (kind == 4) {
+        double *r = V[0], *wv = V[1], *z1 = V[2], *z2 = V[3], *p = V[4], *mm = V[5], *nn = V[6],
+               *q = V[7], *f = V[8], *g = V[9];
+        double rho, delta, beta, prev_rho;
+        oracle_pipe_cg_initialize_1_f64(n, 1, 1, b, r, &prev_rho, &stop);
+        RESID(r);
+        BASELINE(r);
+        apply_precond(m, n, r, z1);
+        memcpy(z2, z1, sizeof(double) * N);
+        SPMV(z1, wv);
+        apply_precond(m, n, wv, mm);
+        SPMV(mm, nn);
+        DOT(r, z1, &rho);
+        DOT(wv, z2, &delta);
+        iter = 0;
+        if (!krylov_check(iter, max_iters, n, r, tau0, reduction, 1, &stop, &one_changed, &tau)) {
+            oracle_pipe_cg_initialize_2_f64(n, 1, 1, p, q, f, g, &beta, z1, wv, mm, nn, &delta);
+            for (;;) {
+                oracle_pipe_cg_step_1_f64(n, 1, 1, x, r, z1, z2, wv, p, q, f, g, &rho, &beta, &stop);
+                apply_precond(m, n, wv, mm);
+                SPMV(mm, nn);
+                prev_rho = rho;
+                DOT(r, z1, &rho);
+                DOT(wv, z2, &delta);
+                ++iter;
+                if (krylov_check(iter, max_iters, n, r, tau0, reduction, 1, &stop, &one_changed, &tau)) break;
+                oracle_pipe_cg_step_2_f64(n, 1, 1, &beta, p, q, f, g, z1, wv, mm, nn, &prev_rho, &rho,
+                                          &delta, &stop);
+            }
+        }
+    } else {
+        iter = -2;
+    }
+#undef SPMV
+#undef RESID
+#undef DOT
+#undef BASELINE
+    if (resnorm_out) *resnorm_out = tau;
+    free(w);
+    return iter;
+}
+
 /* ---- GMRES driver --------------------------------------------------------
  * core/solver/gmres.cpp:321-621 (Gmres::apply_dense_impl), one right-hand
  * side, non-flexible, f64 / int32; ortho: 0 = mgs (:157-177), 1 = cgs

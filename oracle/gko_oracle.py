@@ -379,15 +379,9 @@ class _Precond(C.Structure):
                 ("block_ptrs", C.c_void_p), ("blocks", C.c_void_p)]
 
 
-def cg_solve(row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,
-             baseline="rhs_norm", precond=None, max_block_size=8,
-             return_history=False):
-    """Cg(Combined(Iteration, ResidualNorm)) with precond in
-    {None, 'scalar', 'block'}; f64 / int32, one right-hand side."""
+def _make_precond(row_ptrs, cols, vals, precond, max_block_size):
+    """oracle_precond for precond in {None, 'scalar', 'block'} + the arrays it points to"""
     n = len(row_ptrs) - 1
-    assert vals.dtype == np.float64 and cols.dtype == np.int32
-    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64, copy=True)
-    b = np.ascontiguousarray(b, dtype=np.float64)
     m = _Precond()
     keep = []
     if precond == "scalar":
@@ -405,6 +399,53 @@ def cg_solve(row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,
         m.block_ptrs, m.blocks = ptrs.ctypes.data, blocks.ctypes.data
     else:
         m.precond = 0
+    return m, keep
+
+
+KRYLOV_KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4}
+
+
+def krylov_solve(kind, row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,
+                 baseline="rhs_norm", precond=None, max_block_size=8):
+    """Bicgstab / Cgs / Fcg / PipeCg (oracle_krylov_solve_f64_i32) with
+    Combined(Iteration, ResidualNorm); f64 / int32, one right-hand side."""
+    n = len(row_ptrs) - 1
+    assert vals.dtype == np.float64 and cols.dtype == np.int32
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64, copy=True)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    m, keep = _make_precond(row_ptrs, cols, vals, precond, max_block_size)
+    base = {"rhs_norm": 0, "initial_resnorm": 1, "absolute": 2}[baseline]
+    resnorm = C.c_double(0)
+    f = lib().oracle_krylov_solve_f64_i32
+    f.restype = C.c_int64
+    iters = f(C.c_int(KRYLOV_KINDS[kind]), _i64(n), _p(row_ptrs), _p(cols), _p(vals), C.byref(m),
+              _p(b), _p(x), _i64(max_iters), C.c_double(reduction), C.c_int(base),
+              C.byref(resnorm))
+    del keep
+    return x, int(iters), resnorm.value
+
+
+def krylov_step(name, rows, cols, *arrays):
+    """oracle_<name>_<f64|f32>(rows, cols, ld = cols, arrays...): the step kernels of
+    bicgstab / cgs / fcg / pipe_cg, operands in the order of the reference kernel's
+    signature; the arrays (C-contiguous numpy) are updated in place."""
+    vt = next(a.dtype for a in arrays if a.dtype != np.uint8)
+    for a in arrays:
+        assert a.flags.c_contiguous and a.dtype in (vt, np.uint8), "mixed value types"
+    getattr(lib(), f"oracle_{name}_{_VT[np.dtype(vt)]}")(
+        _i64(rows), _i64(cols), _i64(cols), *[_p(a) for a in arrays])
+
+
+def cg_solve(row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,
+             baseline="rhs_norm", precond=None, max_block_size=8,
+             return_history=False):
+    """Cg(Combined(Iteration, ResidualNorm)) with precond in
+    {None, 'scalar', 'block'}; f64 / int32, one right-hand side."""
+    n = len(row_ptrs) - 1
+    assert vals.dtype == np.float64 and cols.dtype == np.int32
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64, copy=True)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    m, keep = _make_precond(row_ptrs, cols, vals, precond, max_block_size)
     base = {"rhs_norm": 0, "initial_resnorm": 1, "absolute": 2}[baseline]
     resnorm = C.c_double(0)
     hist = np.full(max_iters + 1, np.nan) if return_history else None

@@ -134,6 +134,21 @@ class CsrHandle:
                                 C.c_int(base), C.byref(rn))
         return x, int(it), rn.value
 
+    KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4}
+
+    def krylov_solve(self, kind, b, x0=None, max_iters=1000, reduction=1e-10,
+                     baseline="rhs_norm", precond_block_size=0):
+        """Bicgstab / Cgs / Fcg / PipeCg of the reference"""
+        x = np.zeros(self.n_rows) if x0 is None else np.array(x0, dtype=np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        rn = C.c_double(0)
+        base = {"rhs_norm": 0, "initial_resnorm": 1, "absolute": 2}[baseline]
+        f = lib().ref_krylov_solve
+        f.restype = C.c_int64
+        it = f(self.h, C.c_int(self.KINDS[kind]), C.c_uint32(precond_block_size), _p(b), _p(x),
+               C.c_int64(max_iters), C.c_double(reduction), C.c_int(base), C.byref(rn))
+        return x, int(it), rn.value
+
 
 def _gmres(self, b, x0=None, krylov_dim=100, ortho="mgs", max_iters=1000,
            reduction=1e-10, precond_block_size=0):

@@ -19,7 +19,11 @@
 #include <ginkgo/core/matrix/ell.hpp>
 #include <ginkgo/core/matrix/sellp.hpp>
 #include <ginkgo/core/preconditioner/jacobi.hpp>
+#include <ginkgo/core/solver/bicgstab.hpp>
 #include <ginkgo/core/solver/cg.hpp>
+#include <ginkgo/core/solver/cgs.hpp>
+#include <ginkgo/core/solver/fcg.hpp>
+#include <ginkgo/core/solver/pipe_cg.hpp>
 #include <ginkgo/core/solver/gmres.hpp>
 #include <ginkgo/core/stop/combined.hpp>
 #include <ginkgo/core/stop/iteration.hpp>
@@ -33,6 +37,11 @@ using Csr = gko::matrix::Csr<vt, it>;
 using Dense = gko::matrix::Dense<vt>;
 
 static int failures = 0;
+template <typename T>
+struct type_tag {
+    using type = T;
+};
+
 #define CHECK(cond, msg)                                                   \
     do {                                                                   \
         if (!(cond)) {                                                     \
@@ -176,6 +185,43 @@ int main(int argc, char** argv)
         std::cout << "GMRES(30)+Jacobi(8): iterations reference " << it_ref << ", hip " << it_hip << std::endl;
         CHECK(std::abs(it_ref - it_hip) <= 1, "GMRES iteration count matches reference");
         CHECK(rel_err(x_hip2.get(), x_ref2.get()) < 1e-8, "GMRES solution matches reference");
+    }
+
+    // --- Ginkgo's own Bicgstab / Cgs / Fcg / PipeCg drivers on this backend
+    {
+        auto family = [&](auto tag, auto exec, auto a, int& iters) {
+            using Solver = typename decltype(tag)::type;
+            auto rhs = Dense::create(exec, gko::dim<2>{n, 1});
+            rhs->fill(1.0);
+            auto x = Dense::create(exec, gko::dim<2>{n, 1});
+            x->fill(0.0);
+            auto logger = gko::share(gko::log::Convergence<vt>::create());
+            auto solver =
+                Solver::build()
+                    .with_criteria(gko::stop::Iteration::build().with_max_iters(500u),
+                                   gko::stop::ResidualNorm<vt>::build().with_reduction_factor(1e-10))
+                    .with_preconditioner(
+                        gko::preconditioner::Jacobi<vt, it>::build().with_max_block_size(8u))
+                    .on(exec)
+                    ->generate(a);
+            solver->add_logger(logger);
+            solver->apply(rhs, x);
+            iters = static_cast<int>(logger->get_num_iterations());
+            return gko::clone(exec->get_master(), x);
+        };
+        auto run = [&](auto tag, const char* name) {
+            int it_ref = 0, it_hip = 0;
+            auto x_ref = family(tag, ref, a_ref, it_ref);
+            auto x_hip = family(tag, hip, a_hip, it_hip);
+            std::cout << name << "+Jacobi(8): iterations reference " << it_ref << ", hip " << it_hip
+                      << std::endl;
+            CHECK(std::abs(it_ref - it_hip) <= 1, (std::string(name) + " iteration count matches reference").c_str());
+            CHECK(rel_err(x_hip.get(), x_ref.get()) < 1e-8, (std::string(name) + " solution matches reference").c_str());
+        };
+        run(type_tag<gko::solver::Bicgstab<vt>>{}, "Bicgstab");
+        run(type_tag<gko::solver::Cgs<vt>>{}, "Cgs");
+        run(type_tag<gko::solver::Fcg<vt>>{}, "Fcg");
+        run(type_tag<gko::solver::PipeCg<vt>>{}, "PipeCg");
     }
 
     // --- timer (HipTimer through the C ABI events)

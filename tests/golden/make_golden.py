@@ -27,7 +27,46 @@ def save(name, **arrays):
     print("wrote", name, {k: getattr(v, "shape", v) for k, v in arrays.items()})
 
 
+def nonsymmetric_5pt(o, grid):
+    """5-pt stencil with the upper couplings scaled by 0.6 and the lower by 1.3
+    (an upwinded convection-diffusion pattern): non-symmetric, diagonally dominant"""
+    rp, ci, v = o.stencil_csr(2, grid, True)
+    v = v.copy()
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    v[ci > rows] *= 0.6
+    v[ci < rows] *= 1.3
+    return rp, ci, v
+
+
+def krylov_family():
+    """Bicgstab / Cgs / Fcg / PipeCg of the reference"""
+    from oracle import gko_oracle as o
+    rng = np.random.default_rng(2024)
+    arrays = {}
+    mats = {"sym": o.stencil_csr(3, 10), "nonsym": nonsymmetric_5pt(o, 32)}
+    for mname, (rp, ci, v) in mats.items():
+        n = len(rp) - 1
+        h = ref.CsrHandle("reference", rp, ci, v)
+        rhs = rng.uniform(-1, 1, n)
+        arrays[f"{mname}_row_ptrs"], arrays[f"{mname}_cols"] = rp, ci
+        arrays[f"{mname}_vals"], arrays[f"{mname}_rhs"] = v, rhs
+        kinds = ("bicgstab", "cgs", "fcg", "pipe_cg") if mname == "sym" else ("bicgstab", "cgs")
+        for kind in kinds:
+            for bs in (0, 1, 8):
+                x, it, rn = h.krylov_solve(kind, rhs, max_iters=400, reduction=1e-9,
+                                           precond_block_size=bs)
+                arrays[f"{mname}_{kind}_{bs}_x"] = x
+                arrays[f"{mname}_{kind}_{bs}_it_rn"] = np.array([it, rn])
+            x, it, rn = h.krylov_solve(kind, rhs, x0=np.full(n, 0.5), max_iters=6, reduction=1e-30,
+                                       baseline="initial_resnorm", precond_block_size=8)
+            arrays[f"{mname}_{kind}_lim_x"] = x
+            arrays[f"{mname}_{kind}_lim_it_rn"] = np.array([it, rn])
+    save("krylov_family.npz", **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "krylov_family":
+        return krylov_family()
     assert ref.available(), "build oracle/_ref first (python oracle/build_ref.py; build_shim.py)"
     print("reference version", ref.version())
     rng = np.random.default_rng(2024)
@@ -127,3 +166,5 @@ def main():
 
 if __name__ == "__main__":
     main()
+    if len(sys.argv) == 1:
+        krylov_family()

@@ -339,3 +339,57 @@ def test_live_reference_stencil_subdomains(oracle):
             assert a[3] == b[3]
             for u, w in zip(a[:3], b[:3]):
                 assert np.array_equal(u, w)
+
+
+# ----------------------------------------------------------------------------
+# Bicgstab / Cgs / Fcg / PipeCg
+def test_krylov_family_known_answers(oracle):
+    import krylov_family_cases as kc
+    for solver, kernel, inp, stop, exp in kc.CASES:
+        for dt in (np.float64, np.float32):
+            arr = kc.materialise(solver, kernel, inp, stop, dt)
+            oracle.krylov_step(f"{solver}_{kernel}", 2, 2, *arr.values())
+            kc.check(arr, exp)
+
+
+def _family_cases(g):
+    for mname, kinds in (("sym", ("bicgstab", "cgs", "fcg", "pipe_cg")), ("nonsym", ("bicgstab", "cgs"))):
+        mat = tuple(g[f"{mname}_{k}"] for k in ("row_ptrs", "cols", "vals"))
+        for kind in kinds:
+            yield mname, mat, g[f"{mname}_rhs"], kind
+
+
+def test_golden_krylov_family(oracle):
+    g = gold("krylov_family.npz")
+    for mname, (rp, ci, v), rhs, kind in _family_cases(g):
+        n = len(rp) - 1
+        for bs, pre in ((0, None), (1, "scalar"), (8, "block")):
+            x, it, rn = oracle.krylov_solve(kind, rp, ci, v, rhs, max_iters=400, reduction=1e-9,
+                                            precond=pre, max_block_size=max(bs, 1))
+            it_ref, rn_ref = g[f"{mname}_{kind}_{bs}_it_rn"]
+            assert (it, rn) == (int(it_ref), float(rn_ref)), (mname, kind, bs)
+            assert np.array_equal(x, g[f"{mname}_{kind}_{bs}_x"]), (mname, kind, bs)
+        x, it, rn = oracle.krylov_solve(kind, rp, ci, v, rhs, x0=np.full(n, 0.5), max_iters=6,
+                                        reduction=1e-30, baseline="initial_resnorm", precond="block")
+        it_ref, rn_ref = g[f"{mname}_{kind}_lim_it_rn"]
+        assert (it, rn) == (int(it_ref), float(rn_ref)) and it == 6
+        assert np.array_equal(x, g[f"{mname}_{kind}_lim_x"])
+
+
+@pytest.mark.parametrize("kind", ["bicgstab", "cgs", "fcg", "pipe_cg"])
+def test_live_reference_krylov_family(oracle, kind):
+    ref = _ref()
+    rp, ci, v = oracle.stencil_csr(3, 7)
+    if kind in ("bicgstab", "cgs"):                    # also a non-symmetric operator
+        rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+        v = v.copy()
+        v[ci > rows] *= 0.7
+    n = len(rp) - 1
+    h = ref.CsrHandle("reference", rp, ci, v)
+    rhs = np.random.default_rng(5).uniform(-1, 1, n)
+    for bs in (0, 1, 4):
+        pre = None if bs == 0 else ("scalar" if bs == 1 else "block")
+        xo, ito, rno = oracle.krylov_solve(kind, rp, ci, v, rhs, max_iters=200, reduction=1e-10,
+                                           precond=pre, max_block_size=max(bs, 1))
+        xr, itr, rnr = h.krylov_solve(kind, rhs, max_iters=200, reduction=1e-10, precond_block_size=bs)
+        assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
