@@ -51,6 +51,7 @@ def lib():
         _lib.gkoc_last_error.restype = C.c_char_p
         _lib.gkoc_reduction_workspace_bytes.restype = C.c_size_t
         _lib.gkoc_x_workspace_bytes.restype = C.c_size_t
+        _lib.gkoc_coo_workspace_bytes.restype = C.c_size_t
     return _lib
 
 

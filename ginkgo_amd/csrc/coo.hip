@@ -1,0 +1,363 @@
+// COO SpMV and the CSR -> Hybrid conversion:
+//   coo::{spmv, advanced_spmv, spmv2, advanced_spmv2}
+//     (decl core/matrix/coo_kernels.hpp; reference/matrix/coo_kernels.cpp:33-100;
+//      stock GPU version common/cuda_hip/matrix/coo_kernels.cpp: f64 atomics on c)
+//   hybrid::compute_coo_row_ptrs (reference/matrix/hybrid_kernels.cpp:30-43),
+//   csr::convert_to_hybrid      (reference/matrix/csr_kernels.cpp:911-955)
+//
+// COO in Ginkgo is row-major sorted (Coo::read sorts; conversions emit rows in
+// order).  For such input the reference's entry-by-entry accumulation
+//   c(row) = (...((c0 + p1) + p2) + ...)         c0 = 0, c, beta*c
+// is the CSR row sum of the same entries started from c0 - exactly what
+// csr::advanced_spmv computes (sum = beta*c, then += (alpha*val)*b in k order), and
+// multiplying by a literal 1 is exact.  So:
+//   pass 1: row_idxs -> row_ptrs into the workspace (one read of row_idxs, 4 B/nnz;
+//           the same kernel notes whether the rows really are non-decreasing);
+//   pass 2: the production CSR kernel (12 B/nnz) with (alpha, beta) in
+//           {(-, -), (alpha, beta), (1, 1), (alpha, 1)}.
+// 16 B/nnz in total - the algorithmic traffic of COO - no atomics, results
+// bit-identical to the reference.  Input whose rows are NOT sorted takes the
+// reference's semantics through a fallback: pass 1 raises a device flag, the row
+// pointers are cleared (the CSR pass then only applies beta), and an atomic kernel
+// adds the products (sum order then differs: tolerance instead of bit-identity).
+// Both extra kernels return at once when the flag is not set; no host round trip.
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace gkoc {
+namespace {
+
+inline unsigned grid_for(int64_t n, int cap = 4 * max_stream_blocks)
+{
+    int64_t b = ceildiv(n > 0 ? n : 1, 256);
+    if (b > cap) b = cap;
+    return unsigned(b);
+}
+
+// workspace: [row_ptrs (n_rows + 1) of I | pad to 16 | flag int32, pad | one T]
+template <typename T, typename I>
+struct coo_work {
+    I* ptrs;
+    int* flag;
+    T* one;
+    static size_t bytes(int64_t n_rows)
+    {
+        const size_t p = (size_t(n_rows + 1) * sizeof(I) + 15) / 16 * 16;
+        return p + 16 + 16;
+    }
+    coo_work(void* w, int64_t n_rows)
+    {
+        char* c = static_cast<char*>(w);
+        const size_t p = (size_t(n_rows + 1) * sizeof(I) + 15) / 16 * 16;
+        ptrs = reinterpret_cast<I*>(c);
+        flag = reinterpret_cast<int*>(c + p);
+        one = reinterpret_cast<T*>(c + p + 16);
+    }
+};
+
+template <typename T>
+__global__ void coo_init_kernel(int* flag, T* one)
+{
+    *flag = 0;
+    *one = T(1);
+}
+
+// ptrs[r] = first position whose row index is >= r (rows sorted); flag = 1 if some
+// row index is smaller than its predecessor or out of range
+template <typename I>
+__global__ __launch_bounds__(256) void coo_rows_to_ptrs_kernel(
+    int64_t nnz, const I* __restrict__ rows, int64_t n_rows, I* __restrict__ ptrs,
+    int* __restrict__ flag)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i > nnz) return;
+    const int64_t prev = i == 0 ? -1 : int64_t(rows[i - 1]);
+    const int64_t cur = i == nnz ? n_rows : int64_t(rows[i]);
+    if (cur < prev || cur < 0 || cur > n_rows || (i < nnz && cur == n_rows)) {
+        *flag = 1;
+        return;
+    }
+    for (int64_t r = prev + 1; r <= cur; ++r) ptrs[r] = I(i);
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void coo_clear_ptrs_if_unsorted_kernel(
+    int64_t n, I* __restrict__ ptrs, const int* __restrict__ flag)
+{
+    if (*flag == 0) return;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) ptrs[i] = I(0);
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void coo_atomic_if_unsorted_kernel(
+    int64_t nnz, const I* __restrict__ rows, const I* __restrict__ cols,
+    const T* __restrict__ vals, const T* __restrict__ alpha, const T* __restrict__ b,
+    int64_t ldb, T* __restrict__ c, int64_t ldc, int64_t nrhs, int64_t n_rows,
+    const int* __restrict__ flag)
+{
+    if (*flag == 0) return;
+    const T a = alpha ? alpha[0] : T(1);
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < nnz; i += stride) {
+        const int64_t r = rows[i];
+        if (r < 0 || r >= n_rows) continue;
+        const T v = alpha ? a * vals[i] : vals[i];
+        for (int64_t j = 0; j < nrhs; ++j) {
+            atomicAdd(&c[r * ldc + j], v * b[int64_t(cols[i]) * ldb + j]);
+        }
+    }
+}
+
+template <typename T, typename I>
+int csr_call(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha, const I* ptrs,
+             const I* cols, const T* vals, const T* b, int64_t ldb, const T* beta, T* c,
+             int64_t ldc, int64_t nrhs);
+
+#define GKOC_COO_CSR(T, TN, I, IN)                                                          \
+    template <>                                                                             \
+    int csr_call<T, I>(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,     \
+                       const I* ptrs, const I* cols, const T* vals, const T* b,             \
+                       int64_t ldb, const T* beta, T* c, int64_t ldc, int64_t nrhs)         \
+    {                                                                                       \
+        if (alpha == nullptr) {                                                             \
+            return gkoc_csr_spmv_##TN##_##IN(s, n_rows, n_cols, ptrs, cols, vals, b, ldb,   \
+                                             c, ldc, nrhs);                                 \
+        }                                                                                   \
+        return gkoc_csr_advanced_spmv_##TN##_##IN(s, n_rows, n_cols, alpha, ptrs, cols,     \
+                                                  vals, b, ldb, beta, c, ldc, nrhs);        \
+    }
+GKOC_COO_CSR(double, f64, int32_t, i32)
+GKOC_COO_CSR(double, f64, int64_t, i64)
+GKOC_COO_CSR(float, f32, int32_t, i32)
+GKOC_COO_CSR(float, f32, int64_t, i64)
+
+// mode: 0 spmv, 1 advanced_spmv(alpha, beta), 2 spmv2, 3 advanced_spmv2(alpha)
+template <typename T, typename I>
+int launch_coo(gkoc_stream_t s, int mode, int64_t n_rows, int64_t n_cols, int64_t nnz,
+               const T* alpha, const I* rows, const I* cols, const T* vals, const T* b,
+               int64_t ldb, const T* beta, T* c, int64_t ldc, int64_t nrhs, void* work,
+               size_t work_bytes)
+{
+    GKOC_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && nrhs >= 0, GKOC_E_INVALID,
+                 "negative dimension");
+    if (n_rows == 0 || nrhs == 0) return GKOC_OK;
+    const size_t need = coo_work<T, I>::bytes(n_rows);
+    GKOC_REQUIRE(work && work_bytes >= need, GKOC_E_WORKSPACE,
+                 "workspace too small (gkoc_coo_workspace_bytes)");
+    GKOC_REQUIRE(nnz == 0 || (rows && cols && vals), GKOC_E_INVALID, "null pointer");
+    if (mode == 1) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha / beta");
+    if (mode == 3) GKOC_REQUIRE(alpha, GKOC_E_INVALID, "null alpha");
+    coo_work<T, I> w(work, n_rows);
+    hipStream_t st = as_stream(s);
+    coo_init_kernel<T><<<dim3(1), dim3(1), 0, st>>>(w.flag, w.one);
+    GKOC_LAUNCH_OK();
+    coo_rows_to_ptrs_kernel<I><<<dim3(unsigned(ceildiv(nnz + 1, 256))), dim3(256), 0, st>>>(
+        nnz, rows, n_rows, w.ptrs, w.flag);
+    GKOC_LAUNCH_OK();
+    coo_clear_ptrs_if_unsorted_kernel<I><<<dim3(grid_for(n_rows + 1)), dim3(256), 0, st>>>(
+        n_rows + 1, w.ptrs, w.flag);
+    GKOC_LAUNCH_OK();
+    const T* a = mode == 0 ? nullptr : (mode == 2 ? w.one : alpha);
+    const T* bt = mode == 1 ? beta : w.one;
+    int rc = csr_call<T, I>(s, n_rows, n_cols, a, w.ptrs, cols, vals, b, ldb, bt, c, ldc, nrhs);
+    if (rc != GKOC_OK) return rc;
+    if (nnz > 0) {
+        coo_atomic_if_unsorted_kernel<T, I><<<dim3(grid_for(nnz)), dim3(256), 0, st>>>(
+            nnz, rows, cols, vals, (mode == 1 || mode == 3) ? alpha : nullptr, b, ldb, c, ldc,
+            nrhs, n_rows, w.flag);
+        GKOC_LAUNCH_OK();
+    }
+    return GKOC_OK;
+}
+
+// row_ptrs -> row index per stored entry (components::convert_ptrs_to_idxs,
+// reference/components/format_conversion_kernels.cpp): one wavefront per 64 rows, the
+// 65 pointers in LDS, lanes stride over the segment's entries (coalesced stores) and
+// find their row by bisection.
+template <typename I>
+__global__ __launch_bounds__(64) void ptrs_to_idxs_kernel(int64_t n_rows,
+                                                          const I* __restrict__ ptrs,
+                                                          I* __restrict__ idxs)
+{
+    __shared__ int64_t lp[65];
+    const int lane = threadIdx.x;
+    const int64_t r0 = int64_t(blockIdx.x) * 64;
+    const int64_t nr = n_rows - r0 < 64 ? n_rows - r0 : 64;
+    if (lane < nr) lp[lane] = ptrs[r0 + lane];
+    if (lane == 0) {
+        for (int64_t k = nr; k <= 64; ++k) lp[k] = ptrs[r0 + nr];
+    }
+    __syncthreads();
+    const int64_t K0 = lp[0], K1 = lp[nr];
+    for (int64_t k = K0 + lane; k < K1; k += 64) {
+        int lo = 0, hi = int(nr);          // largest r with lp[r] <= k
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (lp[mid] <= k) {
+                lo = mid;
+            } else {
+                hi = mid;
+            }
+        }
+        idxs[k] = I(r0 + lo);
+    }
+}
+
+// ell::copy (reference/matrix/ell_kernels.cpp:195-206): same entries, other stride
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void ell_copy_kernel(int64_t n_rows, int64_t k,
+                                                       int64_t src_stride,
+                                                       const I* __restrict__ src_cols,
+                                                       const T* __restrict__ src_vals,
+                                                       int64_t dst_stride, I* __restrict__ dst_cols,
+                                                       T* __restrict__ dst_vals)
+{
+    const int64_t total = n_rows * k;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t i = t / n_rows, row = t - i * n_rows;
+        dst_cols[row + i * dst_stride] = src_cols[row + i * src_stride];
+        dst_vals[row + i * dst_stride] = src_vals[row + i * src_stride];
+    }
+}
+
+// ------------------------------------------------------------------ hybrid
+__global__ __launch_bounds__(256) void hybrid_overflow_counts_kernel(
+    int64_t n_rows, const uint64_t* __restrict__ row_nnz, uint64_t ell_lim,
+    int64_t* __restrict__ out)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i <= n_rows; i += stride) {
+        out[i] = (i < n_rows && row_nnz[i] > ell_lim) ? int64_t(row_nnz[i] - ell_lim) : 0;
+    }
+}
+
+// the entries of a row beyond the first ell_lim go to COO, in order
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void hybrid_overflow_kernel(
+    int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    const T* __restrict__ vals, int64_t ell_lim, const int64_t* __restrict__ coo_row_ptrs,
+    I* __restrict__ coo_rows, I* __restrict__ coo_cols, T* __restrict__ coo_vals)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x; row < n_rows; row += stride) {
+        const int64_t rs = row_ptrs[row], re = row_ptrs[row + 1];
+        int64_t pos = coo_row_ptrs[row];
+        for (int64_t k = rs + ell_lim; k < re; ++k, ++pos) {
+            coo_vals[pos] = vals[k];
+            coo_cols[pos] = cols[k];
+            coo_rows[pos] = I(row);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace gkoc
+
+using namespace gkoc;
+
+extern "C" size_t gkoc_coo_workspace_bytes(int64_t n_rows, size_t index_size, size_t value_size)
+{
+    (void)value_size;
+    if (n_rows < 0) n_rows = 0;
+    return (size_t(n_rows + 1) * index_size + 15) / 16 * 16 + 32;
+}
+
+extern "C" int gkoc_hybrid_compute_coo_row_ptrs(gkoc_stream_t s, int64_t n_rows,
+                                                const uint64_t* row_nnz, uint64_t ell_lim,
+                                                int64_t* coo_row_ptrs)
+{
+    GKOC_REQUIRE(n_rows >= 0 && coo_row_ptrs && (n_rows == 0 || row_nnz), GKOC_E_INVALID,
+                 "bad argument");
+    hybrid_overflow_counts_kernel<<<dim3(grid_for(n_rows + 1)), dim3(256), 0, as_stream(s)>>>(
+        n_rows, row_nnz, ell_lim, coo_row_ptrs);
+    GKOC_LAUNCH_OK();
+    return device_exclusive_scan<int64_t>(as_stream(s), coo_row_ptrs, n_rows + 1);
+}
+
+#define GKOC_DEF_P2I(I, IN)                                                                 \
+    extern "C" int gkoc_convert_ptrs_to_idxs_##IN(gkoc_stream_t s, const I* ptrs,           \
+                                                  int64_t n_rows, I* idxs)                  \
+    {                                                                                       \
+        GKOC_REQUIRE(n_rows >= 0, GKOC_E_INVALID, "negative size");                         \
+        if (n_rows == 0) return GKOC_OK;                                                    \
+        ptrs_to_idxs_kernel<I><<<dim3(unsigned(ceildiv(n_rows, 64))), dim3(64), 0,          \
+                                 as_stream(s)>>>(n_rows, ptrs, idxs);                       \
+        GKOC_LAUNCH_OK();                                                                   \
+        return GKOC_OK;                                                                     \
+    }
+GKOC_DEF_P2I(int32_t, i32)
+GKOC_DEF_P2I(int64_t, i64)
+
+#define GKOC_DEF_COO(T, TN, I, IN)                                                          \
+    extern "C" int gkoc_coo_spmv_##TN##_##IN(                                               \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t nnz, const I* row_idxs,    \
+        const I* col_idxs, const T* vals, const T* b, int64_t ldb, T* c, int64_t ldc,       \
+        int64_t nrhs, void* work, size_t work_bytes)                                        \
+    {                                                                                       \
+        return launch_coo<T, I>(s, 0, n_rows, n_cols, nnz, nullptr, row_idxs, col_idxs,     \
+                                vals, b, ldb, nullptr, c, ldc, nrhs, work, work_bytes);     \
+    }                                                                                       \
+    extern "C" int gkoc_coo_advanced_spmv_##TN##_##IN(                                      \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t nnz, const T* alpha,       \
+        const I* row_idxs, const I* col_idxs, const T* vals, const T* b, int64_t ldb,       \
+        const T* beta, T* c, int64_t ldc, int64_t nrhs, void* work, size_t work_bytes)      \
+    {                                                                                       \
+        return launch_coo<T, I>(s, 1, n_rows, n_cols, nnz, alpha, row_idxs, col_idxs, vals, \
+                                b, ldb, beta, c, ldc, nrhs, work, work_bytes);              \
+    }                                                                                       \
+    extern "C" int gkoc_coo_spmv2_##TN##_##IN(                                              \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t nnz, const I* row_idxs,    \
+        const I* col_idxs, const T* vals, const T* b, int64_t ldb, T* c, int64_t ldc,       \
+        int64_t nrhs, void* work, size_t work_bytes)                                        \
+    {                                                                                       \
+        return launch_coo<T, I>(s, 2, n_rows, n_cols, nnz, nullptr, row_idxs, col_idxs,     \
+                                vals, b, ldb, nullptr, c, ldc, nrhs, work, work_bytes);     \
+    }                                                                                       \
+    extern "C" int gkoc_coo_advanced_spmv2_##TN##_##IN(                                     \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t nnz, const T* alpha,       \
+        const I* row_idxs, const I* col_idxs, const T* vals, const T* b, int64_t ldb, T* c, \
+        int64_t ldc, int64_t nrhs, void* work, size_t work_bytes)                           \
+    {                                                                                       \
+        return launch_coo<T, I>(s, 3, n_rows, n_cols, nnz, alpha, row_idxs, col_idxs, vals, \
+                                b, ldb, nullptr, c, ldc, nrhs, work, work_bytes);           \
+    }                                                                                       \
+    extern "C" int gkoc_ell_copy_##TN##_##IN(                                               \
+        gkoc_stream_t s, int64_t n_rows, int64_t k, int64_t src_stride, const I* src_cols,  \
+        const T* src_vals, int64_t dst_stride, I* dst_cols, T* dst_vals)                    \
+    {                                                                                       \
+        GKOC_REQUIRE(n_rows >= 0 && k >= 0 && src_stride >= n_rows && dst_stride >= n_rows, \
+                     GKOC_E_INVALID, "bad dimensions");                                     \
+        if (n_rows == 0 || k == 0) return GKOC_OK;                                          \
+        ell_copy_kernel<T, I><<<dim3(grid_for(n_rows * k)), dim3(256), 0, as_stream(s)>>>(  \
+            n_rows, k, src_stride, src_cols, src_vals, dst_stride, dst_cols, dst_vals);     \
+        GKOC_LAUNCH_OK();                                                                   \
+        return GKOC_OK;                                                                     \
+    }                                                                                       \
+    extern "C" int gkoc_csr_convert_to_hybrid_##TN##_##IN(                                  \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs,              \
+        const T* vals, int64_t ell_lim, int64_t ell_stride, I* ell_cols, T* ell_vals,       \
+        const int64_t* coo_row_ptrs, I* coo_rows, I* coo_cols, T* coo_vals)                 \
+    {                                                                                       \
+        GKOC_REQUIRE(n_rows >= 0 && ell_lim >= 0, GKOC_E_INVALID, "negative dimension");    \
+        if (n_rows == 0) return GKOC_OK;                                                    \
+        if (ell_lim > 0) {                                                                  \
+            int rc = gkoc_csr_convert_to_ell_##TN##_##IN(s, n_rows, row_ptrs, col_idxs,     \
+                                                         vals, ell_lim, ell_stride,         \
+                                                         ell_cols, ell_vals);               \
+            if (rc != GKOC_OK) return rc;                                                   \
+        }                                                                                   \
+        GKOC_REQUIRE(coo_row_ptrs, GKOC_E_INVALID, "null coo_row_ptrs");                    \
+        hybrid_overflow_kernel<T, I>                                                        \
+            <<<dim3(grid_for(n_rows)), dim3(256), 0, as_stream(s)>>>(                       \
+                n_rows, row_ptrs, col_idxs, vals, ell_lim, coo_row_ptrs, coo_rows,          \
+                coo_cols, coo_vals);                                                        \
+        GKOC_LAUNCH_OK();                                                                   \
+        return GKOC_OK;                                                                     \
+    }
+
+GKOC_DEF_COO(double, f64, int32_t, i32)
+GKOC_DEF_COO(double, f64, int64_t, i64)
+GKOC_DEF_COO(float, f32, int32_t, i32)
+GKOC_DEF_COO(float, f32, int64_t, i64)

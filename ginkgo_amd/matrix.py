@@ -286,6 +286,45 @@ class Csr(_SparseBase):
              num_stored_per_row, stride, cols, vals)
         return Ell(self.exec, self.size, vals, cols, num_stored_per_row, stride)
 
+    def convert_to_coo(self):
+        rows = self.exec.alloc((self.col_idxs.numel(),), self.col_idxs.dtype)
+        call("gkoc_convert_ptrs_to_idxs_" + IT[self.col_idxs.dtype], self.exec.stream,
+             self.row_ptrs, self.size[0], rows)
+        return Coo(self.exec, self.size, self.values, self.col_idxs, rows)
+
+    def convert_to_hybrid(self, column_limit=None, imbalance_percent=0.8):
+        """Csr::convert_to(Hybrid) (core/matrix/csr.cpp:417-441).  The split is the
+        strategy's: column_limit(k) keeps k entries per row in the Ell part;
+        otherwise imbalance_limit(percent) = the row length at that quantile of the
+        sorted row lengths (hybrid.hpp:231-252; decided on the host like there)."""
+        ex, n = self.exec, self.size[0]
+        it = IT[self.col_idxs.dtype]
+        sizes = ex.alloc((max(n, 1),), torch.int64)[:n]      # uint64 bits
+        call("gkoc_convert_ptrs_to_sizes_" + it, ex.stream, n, self.row_ptrs, sizes)
+        if column_limit is None:
+            if n == 0:
+                ell_lim = 0
+            else:
+                srt = torch.sort(sizes).values
+                p = min(max(float(imbalance_percent), 0.0), 1.0)
+                ell_lim = int(srt[int(n * p)].item()) if p < 1 else int(srt[-1].item())
+        else:
+            ell_lim = int(column_limit)
+        ell_lim = min(ell_lim, self.size[1])
+        crp = ex.alloc((n + 1,), torch.int64)
+        call("gkoc_hybrid_compute_coo_row_ptrs", ex.stream, n, sizes, C.c_uint64(ell_lim), crp)
+        coo_nnz = int(crp[-1].item())
+        idt, vdt = self.col_idxs.dtype, self.dtype
+        ec, ev = ex.alloc((ell_lim * n,), idt), ex.alloc((ell_lim * n,), vdt)
+        cr, cc = ex.alloc((coo_nnz,), idt), ex.alloc((coo_nnz,), idt)
+        cv = ex.alloc((coo_nnz,), vdt)
+        call("gkoc_csr_convert_to_hybrid_" + self._suf(), ex.stream, n, self.row_ptrs,
+             self.col_idxs, self.values, ell_lim, n, ec, ev, crp, cr, cc, cv)
+        hyb = Hybrid(ex, self.size, Ell(ex, self.size, ev, ec, ell_lim, n),
+                     Coo(ex, self.size, cv, cc, cr))
+        hyb.coo_row_ptrs = crp
+        return hyb
+
     def convert_to_sellp(self, slice_size=64, stride_factor=1):
         it = IT[self.col_idxs.dtype]
         n_slices = (self.size[0] + slice_size - 1) // slice_size
@@ -305,6 +344,78 @@ class Csr(_SparseBase):
              self.values, sets, cols, vals)
         return Sellp(self.exec, self.size, vals, cols, sets, lens, slice_size,
                      stride_factor)
+
+
+class Coo(_SparseBase):
+    """coo.hpp: (row, column, value) triplets, rows ascending.  apply = c = A b;
+    apply2 = c += A b (Coo::apply2, coo.hpp) as Hybrid uses it."""
+
+    def __init__(self, exec_, size, values, col_idxs, row_idxs):
+        super().__init__(exec_, size)
+        self.values, self.col_idxs, self.row_idxs = values, col_idxs, row_idxs
+        need = _lib.lib().gkoc_coo_workspace_bytes(C.c_int64(size[0]),
+                                                   C.c_size_t(col_idxs.element_size()),
+                                                   C.c_size_t(values.element_size()))
+        self._work = exec_.alloc((int(need),), torch.uint8)
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    def _suf(self):
+        return f"{VT[self.values.dtype]}_{IT[self.col_idxs.dtype]}"
+
+    def get_num_stored_elements(self):
+        return int(self.values.numel())
+
+    def _run(self, name, alpha, b, beta, x):
+        bv, ldb, xv, ldx, nrhs = self._operands(b, x)
+        args = [self.exec.stream, self.size[0], self.size[1], self.values.numel()]
+        if alpha is not None:
+            args.append(alpha.values)
+        args += [self.row_idxs, self.col_idxs, self.values, bv, ldb]
+        if beta is not None:
+            args.append(beta.values)
+        args += [xv, ldx, nrhs, self._work, C.c_size_t(self._work.numel())]
+        call(name + self._suf(), *args)
+
+    def apply_impl(self, b, x):
+        self._run("gkoc_coo_spmv_", None, b, None, x)
+
+    def apply_advanced_impl(self, alpha, b, beta, x):
+        self._run("gkoc_coo_advanced_spmv_", alpha, b, beta, x)
+
+    def apply2(self, *args):
+        """apply2(b, x): x += A b ; apply2(alpha, b, x): x += alpha A b"""
+        if len(args) == 2:
+            self._run("gkoc_coo_spmv2_", None, args[0], None, args[1])
+        else:
+            self._run("gkoc_coo_advanced_spmv2_", args[0], args[1], None, args[2])
+        return args[-1]
+
+
+class Hybrid(_SparseBase):
+    """hybrid.hpp: an Ell part holding the first ell_lim entries of every row and a
+    Coo part with the rest; apply = ell.apply then coo.apply2 (core/matrix/hybrid.cpp)."""
+
+    def __init__(self, exec_, size, ell, coo):
+        super().__init__(exec_, size)
+        self.ell, self.coo = ell, coo
+
+    @property
+    def dtype(self):
+        return self.ell.dtype
+
+    def get_num_stored_elements(self):
+        return int(self.ell.values.numel()) + self.coo.get_num_stored_elements()
+
+    def apply_impl(self, b, x):
+        self.ell.apply(b, x)
+        self.coo.apply2(b, x)
+
+    def apply_advanced_impl(self, alpha, b, beta, x):
+        self.ell.apply(alpha, b, beta, x)
+        self.coo.apply2(alpha, b, x)
 
 
 class Ell(_SparseBase):

@@ -572,6 +572,67 @@ GKOC_DECL_XI(double, f64, int64_t, i64)
 GKOC_DECL_XI(float, f32, int32_t, i32)
 GKOC_DECL_XI(float, f32, int64_t, i64)
 
+/* ------------------------------------------------- COO SpMV, CSR -> Hybrid
+ * coo::{spmv, advanced_spmv, spmv2, advanced_spmv2} (core/matrix/coo_kernels.hpp:24-58;
+ * reference/matrix/coo_kernels.cpp:33-100): c = A b, c = alpha A b + beta c,
+ * c += A b, c += alpha A b for a COO matrix.  Row indices sorted ascending (what
+ * Ginkgo's Coo holds): bit-identical to the reference's entry-by-entry
+ * accumulation, 16 B per stored entry of traffic, no atomics (csrc/coo.hip);
+ * unsorted rows are detected on the device and handled with atomics (tolerance).
+ * work: gkoc_coo_workspace_bytes(n_rows, sizeof(I), sizeof(T)) device bytes.
+ * Hybrid needs nothing else for apply (ell::spmv then coo::spmv2, hybrid.cpp).
+ * hybrid::compute_coo_row_ptrs (reference/matrix/hybrid_kernels.cpp:30-43) and
+ * csr::convert_to_hybrid (reference/matrix/csr_kernels.cpp:911-955): the first
+ * ell_lim entries of each row go to the ELL part (padding: value 0, column -1),
+ * the rest to COO at coo_row_ptrs[row]...; index arrays bit-exact. */
+size_t gkoc_coo_workspace_bytes(int64_t n_rows, size_t index_size,
+                                size_t value_size);
+/* components::convert_ptrs_to_idxs (core/components/format_conversion_kernels.hpp):
+ * idxs[k] = row for ptrs[row] <= k < ptrs[row + 1] (Csr -> Coo) */
+int gkoc_convert_ptrs_to_idxs_i32(gkoc_stream_t s, const int32_t* ptrs,
+                                  int64_t n_rows, int32_t* idxs);
+int gkoc_convert_ptrs_to_idxs_i64(gkoc_stream_t s, const int64_t* ptrs,
+                                  int64_t n_rows, int64_t* idxs);
+int gkoc_hybrid_compute_coo_row_ptrs(gkoc_stream_t s, int64_t n_rows,
+                                     const uint64_t* row_nnz, uint64_t ell_lim,
+                                     int64_t* coo_row_ptrs /* n_rows + 1 */);
+#define GKOC_DECL_COO(T, TN, I, IN)                                            \
+    int gkoc_coo_spmv_##TN##_##IN(                                             \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t nnz,          \
+        const I* row_idxs, const I* col_idxs, const T* vals, const T* b,       \
+        int64_t ldb, T* c, int64_t ldc, int64_t nrhs, void* work,              \
+        size_t work_bytes);                                                    \
+    int gkoc_coo_advanced_spmv_##TN##_##IN(                                    \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t nnz,          \
+        const T* alpha, const I* row_idxs, const I* col_idxs, const T* vals,   \
+        const T* b, int64_t ldb, const T* beta, T* c, int64_t ldc,             \
+        int64_t nrhs, void* work, size_t work_bytes);                          \
+    int gkoc_coo_spmv2_##TN##_##IN(                                            \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t nnz,          \
+        const I* row_idxs, const I* col_idxs, const T* vals, const T* b,       \
+        int64_t ldb, T* c, int64_t ldc, int64_t nrhs, void* work,              \
+        size_t work_bytes);                                                    \
+    int gkoc_coo_advanced_spmv2_##TN##_##IN(                                   \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t nnz,          \
+        const T* alpha, const I* row_idxs, const I* col_idxs, const T* vals,   \
+        const T* b, int64_t ldb, T* c, int64_t ldc, int64_t nrhs, void* work,  \
+        size_t work_bytes);                                                    \
+    /* ell::copy (core/matrix/ell_kernels.hpp:53-56): the stored entries of an \
+     * Ell into one with another stride (Ell / Hybrid assignment, resize) */   \
+    int gkoc_ell_copy_##TN##_##IN(                                             \
+        gkoc_stream_t s, int64_t n_rows, int64_t k, int64_t src_stride,        \
+        const I* src_cols, const T* src_vals, int64_t dst_stride,              \
+        I* dst_cols, T* dst_vals);                                             \
+    int gkoc_csr_convert_to_hybrid_##TN##_##IN(                                \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs, \
+        const T* vals, int64_t ell_lim, int64_t ell_stride, I* ell_cols,       \
+        T* ell_vals, const int64_t* coo_row_ptrs, I* coo_rows, I* coo_cols,    \
+        T* coo_vals);
+GKOC_DECL_COO(double, f64, int32_t, i32)
+GKOC_DECL_COO(double, f64, int64_t, i64)
+GKOC_DECL_COO(float, f32, int32_t, i32)
+GKOC_DECL_COO(float, f32, int64_t, i64)
+
 /* ------------------------------------------------- other Krylov solvers
  * The fused vector updates of Bicgstab, Cgs, Fcg and PipeCg - the kernels
  * core/solver/{bicgstab,cgs,fcg,pipe_cg}.cpp issue through exec->run:

@@ -76,6 +76,43 @@ def csr_spmv(row_ptrs, cols, vals, b, alpha=None, beta=None, c=None):
     return out if np.asarray(b).ndim == 2 else out[:, 0]
 
 
+def coo_apply(mode, n_rows, rows, cols, vals, b, alpha=1.0, beta=0.0, c=None):
+    """coo::spmv (mode 'spmv'), advanced_spmv, spmv2, advanced_spmv2 of the reference,
+    entry by entry in storage order; c is the input/output for the modes that read it"""
+    m = {"spmv": 0, "advanced_spmv": 1, "spmv2": 2, "advanced_spmv2": 3}[mode]
+    b2 = np.ascontiguousarray(_as2d(b))
+    nrhs = b2.shape[1]
+    out = np.zeros((n_rows, nrhs), dtype=vals.dtype) if c is None else \
+        np.array(_as2d(c), dtype=vals.dtype, order="C", copy=True)
+    getattr(lib(), "oracle_coo_apply_" + _suf(vals, cols))(
+        C.c_int(m), _i64(n_rows), _i64(len(vals)), _val(vals.dtype, alpha),
+        _p(np.ascontiguousarray(rows)), _p(np.ascontiguousarray(cols)),
+        _p(np.ascontiguousarray(vals)), _p(b2), _i64(nrhs), _val(vals.dtype, beta), _p(out),
+        _i64(nrhs), _i64(nrhs))
+    return out if np.ndim(b) == 2 else out[:, 0]
+
+
+def csr_to_hybrid(row_ptrs, cols, vals, ell_lim, ell_stride=None):
+    """hybrid::compute_coo_row_ptrs + csr::convert_to_hybrid.  Returns
+    (ell_cols, ell_vals, coo_row_ptrs, coo_rows, coo_cols, coo_vals); the ELL part is
+    column-major with leading dimension ell_stride (default n_rows)."""
+    n = len(row_ptrs) - 1
+    stride = n if ell_stride is None else ell_stride
+    f = getattr(lib(), "oracle_csr_convert_to_hybrid_" + _suf(vals, cols))
+    f.restype = C.c_int64
+    crp = np.zeros(n + 1, dtype=np.int64)
+    total = f(_i64(n), _p(row_ptrs), _p(cols), _p(vals), _i64(ell_lim), _i64(stride), None, None,
+              _p(crp), None, None, None)
+    ec = np.full(stride * ell_lim, -7, dtype=cols.dtype)
+    ev = np.full(stride * ell_lim, np.nan, dtype=vals.dtype)
+    cr = np.full(total, -7, dtype=cols.dtype)
+    cc = np.full(total, -7, dtype=cols.dtype)
+    cv = np.full(total, np.nan, dtype=vals.dtype)
+    f(_i64(n), _p(row_ptrs), _p(cols), _p(vals), _i64(ell_lim), _i64(stride), _p(ec), _p(ev),
+      _p(crp), _p(cr), _p(cc), _p(cv))
+    return ec, ev, crp, cr, cc, cv
+
+
 def ell_spmv(n_rows, k, stride, cols, vals, b, alpha=None, beta=None, c=None):
     b2 = np.ascontiguousarray(_as2d(b))
     nrhs = b2.shape[1]

@@ -134,6 +134,25 @@ class CsrHandle:
                                 C.c_int(base), C.byref(rn))
         return x, int(it), rn.value
 
+    def to_hybrid(self, ell_lim):
+        """Csr -> Hybrid(column_limit(ell_lim)); (ell_k, ell_stride, ell_cols, ell_vals,
+        coo_rows, coo_cols, coo_vals)"""
+        k, st = C.c_int64(0), C.c_int64(0)
+        f = lib().ref_to_hybrid
+        f.restype = C.c_int64
+        nc = f(self.h, C.c_int64(ell_lim), C.byref(k), C.byref(st))
+        ne = k.value * st.value
+        ec, ev = np.zeros(ne, np.int32), np.zeros(ne)
+        cr, cc, cv = np.zeros(nc, np.int32), np.zeros(nc, np.int32), np.zeros(nc)
+        lib().ref_hybrid_get(self.h, _p(ec), _p(ev), _p(cr), _p(cc), _p(cv))
+        return k.value, st.value, ec, ev, cr, cc, cv
+
+    def hybrid_spmv(self, b):
+        b2 = np.ascontiguousarray(b.reshape(len(b), -1), np.float64)
+        out = np.zeros((self.n_rows, b2.shape[1]))
+        lib().ref_hybrid_spmv(self.h, _p(b2), _p(out), C.c_int64(b2.shape[1]))
+        return out if np.ndim(b) == 2 else out[:, 0]
+
     KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4}
 
     def krylov_solve(self, kind, b, x0=None, max_iters=1000, reduction=1e-10,
@@ -195,3 +214,18 @@ def stencil_subdomain(nd, dims, pos, target_local_size, restricted):
     f(C.c_int(nd), _p(dims), _p(pos), C.c_int64(target_local_size),
       C.c_int(int(restricted)), _p(rows), _p(cols), _p(vals), C.byref(ls))
     return rows, cols, vals, int(ls.value)
+
+
+def coo_apply(mode, n_rows, n_cols, rows, cols, vals, b, alpha=1.0, beta=0.0, c=None, exec_kind="reference"):
+    """Coo::apply / apply2 of the reference on the given index arrays"""
+    m = {"spmv": 0, "advanced_spmv": 1, "spmv2": 2, "advanced_spmv2": 3}[mode]
+    b2 = np.ascontiguousarray(np.asarray(b, np.float64).reshape(n_cols, -1))
+    nrhs = b2.shape[1]
+    out = np.zeros((n_rows, nrhs)) if c is None else \
+        np.array(np.asarray(c, np.float64).reshape(n_rows, -1), order="C", copy=True)
+    lib().ref_coo_apply(exec_kind.encode(), C.c_int(m), C.c_int64(n_rows), C.c_int64(n_cols),
+                        C.c_int64(len(vals)), _p(np.ascontiguousarray(rows, np.int32)),
+                        _p(np.ascontiguousarray(cols, np.int32)),
+                        _p(np.ascontiguousarray(vals, np.float64)), C.c_double(alpha),
+                        C.c_double(beta), _p(b2), _p(out), C.c_int64(nrhs))
+    return out if np.ndim(b) == 2 else out[:, 0]

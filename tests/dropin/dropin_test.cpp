@@ -14,7 +14,9 @@
 #include <ginkgo/core/base/matrix_data.hpp>
 #include <ginkgo/core/base/timer.hpp>
 #include <ginkgo/core/log/convergence.hpp>
+#include <ginkgo/core/matrix/coo.hpp>
 #include <ginkgo/core/matrix/csr.hpp>
+#include <ginkgo/core/matrix/hybrid.hpp>
 #include <ginkgo/core/matrix/dense.hpp>
 #include <ginkgo/core/matrix/ell.hpp>
 #include <ginkgo/core/matrix/sellp.hpp>
@@ -138,6 +140,56 @@ int main(int argc, char** argv)
         x_ref->compute_norm2(d_ref);
         x_hip->compute_norm2(d_hip);
         CHECK(rel_err(gko::clone(ref, d_hip).get(), d_ref.get()) < 1e-13, "dense compute_norm2");
+    }
+
+    // --- Ginkgo's own Coo and Hybrid (Ell + Coo): device conversions and apply
+    {
+        using Coo = gko::matrix::Coo<vt, it>;
+        using Hybrid = gko::matrix::Hybrid<vt, it>;
+        auto y_ref = Dense::create(ref, gko::dim<2>{n, 3});
+        auto y_hip = Dense::create(hip, gko::dim<2>{n, 3});
+        auto coo_ref = Coo::create(ref);
+        auto coo_hip = Coo::create(hip);
+        a_ref->convert_to(coo_ref);
+        a_hip->convert_to(coo_hip);      // components::convert_ptrs_to_idxs on the device
+        auto coo_back = gko::clone(ref, coo_hip);
+        bool same_idx = coo_back->get_num_stored_elements() == coo_ref->get_num_stored_elements();
+        for (gko::size_type k = 0; same_idx && k < coo_ref->get_num_stored_elements(); ++k)
+            same_idx = coo_back->get_const_row_idxs()[k] == coo_ref->get_const_row_idxs()[k];
+        CHECK(same_idx, "csr->coo conversion on hip: row indices identical");
+        coo_ref->apply(b_ref, y_ref);
+        coo_hip->apply(b_hip, y_hip);
+        CHECK(identical(gko::clone(ref, y_hip).get(), y_ref.get()), "coo::spmv bit-identical to reference");
+        auto alpha = gko::initialize<Dense>({2.0}, ref), beta = gko::initialize<Dense>({-1.0}, ref);
+        coo_ref->apply(alpha, b_ref, beta, y_ref);
+        coo_hip->apply(gko::clone(hip, alpha), b_hip, gko::clone(hip, beta), y_hip);
+        CHECK(identical(gko::clone(ref, y_hip).get(), y_ref.get()), "coo::advanced_spmv bit-identical");
+        coo_ref->apply2(b_ref, y_ref);
+        coo_hip->apply2(b_hip, y_hip);
+        CHECK(identical(gko::clone(ref, y_hip).get(), y_ref.get()), "coo::spmv2 (c += A b) bit-identical");
+        coo_ref->apply2(alpha, b_ref, y_ref);
+        coo_hip->apply2(gko::clone(hip, alpha), b_hip, y_hip);
+        CHECK(identical(gko::clone(ref, y_hip).get(), y_ref.get()), "coo::advanced_spmv2 bit-identical");
+        for (gko::size_type lim : {gko::size_type{9}, gko::size_type{20}}) {
+            auto hyb_ref = Hybrid::create(ref, std::make_shared<Hybrid::column_limit>(lim));
+            auto hyb_hip = Hybrid::create(hip, std::make_shared<Hybrid::column_limit>(lim));
+            a_ref->convert_to(hyb_ref);
+            a_hip->convert_to(hyb_hip);  // hybrid::compute_coo_row_ptrs + csr::convert_to_hybrid
+            auto back = gko::clone(ref, hyb_hip);
+            bool same = back->get_coo_num_stored_elements() == hyb_ref->get_coo_num_stored_elements() &&
+                        back->get_ell_num_stored_elements() == hyb_ref->get_ell_num_stored_elements();
+            for (gko::size_type k = 0; same && k < hyb_ref->get_coo_num_stored_elements(); ++k)
+                same = back->get_const_coo_row_idxs()[k] == hyb_ref->get_const_coo_row_idxs()[k] &&
+                       back->get_const_coo_col_idxs()[k] == hyb_ref->get_const_coo_col_idxs()[k] &&
+                       back->get_const_coo_values()[k] == hyb_ref->get_const_coo_values()[k];
+            for (gko::size_type k = 0; same && k < hyb_ref->get_ell_num_stored_elements(); ++k)
+                same = back->get_const_ell_col_idxs()[k] == hyb_ref->get_const_ell_col_idxs()[k] &&
+                       back->get_const_ell_values()[k] == hyb_ref->get_const_ell_values()[k];
+            CHECK(same, "csr->hybrid conversion on hip: Ell and Coo parts identical to reference");
+            hyb_ref->apply(b_ref, y_ref);
+            hyb_hip->apply(b_hip, y_hip);
+            CHECK(identical(gko::clone(ref, y_hip).get(), y_ref.get()), "Hybrid apply (ell::spmv + coo::spmv2) bit-identical");
+        }
     }
 
     // --- CG + block-Jacobi(8) (examples/preconditioned-solver configuration)

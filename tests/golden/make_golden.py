@@ -64,9 +64,35 @@ def krylov_family():
     save("krylov_family.npz", **arrays)
 
 
+def coo_hybrid():
+    """Coo apply / apply2 and Csr -> Hybrid of the reference"""
+    rng = np.random.default_rng(77)
+    rp, ci, v = random_csr(532, 231, 0.03, seed=5)       # the size of test/matrix/csr_kernels2.cpp
+    rows = np.repeat(np.arange(532, dtype=np.int32), np.diff(rp))
+    b = rng.uniform(-1, 1, (231, 3))
+    c0 = rng.uniform(-1, 1, (532, 3))
+    perm = rng.permutation(len(v))
+    arrays = dict(row_ptrs=rp, rows=rows, cols=ci, vals=v, b=b, c0=c0, perm=perm)
+    for mode in ("spmv", "advanced_spmv", "spmv2", "advanced_spmv2"):
+        arrays[mode] = ref.coo_apply(mode, 532, 231, rows, ci, v, b, 2.0, -1.0, c0)
+        arrays[mode + "_shuffled"] = ref.coo_apply(mode, 532, 231, rows[perm], ci[perm], v[perm], b,
+                                                   2.0, -1.0, c0)
+    h = ref.CsrHandle("reference", rp, ci, v, n_cols=231)
+    for lim in (0, 4, 9, 1000):
+        k, st, ec, ev, cr, cc, cv = h.to_hybrid(lim)
+        arrays[f"hyb{lim}_shape"] = np.array([k, st])
+        arrays[f"hyb{lim}_ell_cols"], arrays[f"hyb{lim}_ell_vals"] = ec, ev
+        arrays[f"hyb{lim}_coo_rows"], arrays[f"hyb{lim}_coo_cols"] = cr, cc
+        arrays[f"hyb{lim}_coo_vals"] = cv
+        arrays[f"hyb{lim}_apply"] = h.hybrid_spmv(b)
+    save("coo_hybrid.npz", **arrays)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "krylov_family":
         return krylov_family()
+    if len(sys.argv) > 1 and sys.argv[1] == "coo_hybrid":
+        return coo_hybrid()
     assert ref.available(), "build oracle/_ref first (python oracle/build_ref.py; build_shim.py)"
     print("reference version", ref.version())
     rng = np.random.default_rng(2024)
@@ -168,3 +194,4 @@ if __name__ == "__main__":
     main()
     if len(sys.argv) == 1:
         krylov_family()
+        coo_hybrid()

@@ -393,3 +393,60 @@ def test_live_reference_krylov_family(oracle, kind):
                                            precond=pre, max_block_size=max(bs, 1))
         xr, itr, rnr = h.krylov_solve(kind, rhs, max_iters=200, reduction=1e-10, precond_block_size=bs)
         assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
+
+
+# ----------------------------------------------------------------------------
+# Coo / Hybrid
+def test_coo_known_answers(oracle):
+    """reference/test/matrix/coo_kernels.cpp: the 2 x 3 matrix [[1,3,2],[0,5,0]]
+    (AppliesToDenseVector :311-320, AppliesLinearCombinationToDenseVector :406-417,
+    AppliesAddToDenseVector :509-518, AppliesLinearCombinationAddToDenseVector :557-567)"""
+    rows = np.array([0, 0, 0, 1], np.int32)
+    cols = np.array([0, 1, 2, 1], np.int32)
+    vals = np.array([1.0, 3.0, 2.0, 5.0])
+    x = np.array([2.0, 1.0, 4.0])
+    assert np.array_equal(oracle.coo_apply("spmv", 2, rows, cols, vals, x), [13.0, 5.0])
+    assert np.array_equal(oracle.coo_apply("advanced_spmv", 2, rows, cols, vals, x,
+                                           -1.0, 2.0, np.array([1.0, 2.0])), [-11.0, -1.0])
+    assert np.array_equal(oracle.coo_apply("spmv2", 2, rows, cols, vals, x, c=np.array([2.0, 1.0])), [15.0, 6.0])
+    assert np.array_equal(oracle.coo_apply("advanced_spmv2", 2, rows, cols, vals, x,
+                                           -1.0, c=np.array([1.0, 2.0])), [-12.0, -3.0])
+
+
+def test_golden_coo_hybrid(oracle):
+    g = gold("coo_hybrid.npz")
+    rp, rows, cols, vals, b, c0, perm = (g[k] for k in ("row_ptrs", "rows", "cols", "vals", "b", "c0", "perm"))
+    for mode in ("spmv", "advanced_spmv", "spmv2", "advanced_spmv2"):
+        assert np.array_equal(oracle.coo_apply(mode, 532, rows, cols, vals, b, 2.0, -1.0, c0), g[mode])
+        assert np.array_equal(oracle.coo_apply(mode, 532, rows[perm], cols[perm], vals[perm], b, 2.0, -1.0, c0),
+                              g[mode + "_shuffled"])
+    # sorted COO = CSR row sums started from c (what the device path relies on)
+    assert np.array_equal(g["spmv"], oracle.csr_spmv(rp, cols, vals, b))
+    assert np.array_equal(g["spmv2"], oracle.csr_spmv(rp, cols, vals, b, alpha=1.0, beta=1.0, c=c0))
+    assert np.array_equal(g["advanced_spmv2"], oracle.csr_spmv(rp, cols, vals, b, alpha=2.0, beta=1.0, c=c0))
+    for lim in (0, 4, 9, 1000):
+        k, st = (int(t) for t in g[f"hyb{lim}_shape"])
+        ec, ev, crp, cr, cc, cv = oracle.csr_to_hybrid(rp, cols, vals, k, st)
+        for got, name in ((ec, "ell_cols"), (ev, "ell_vals"), (cr, "coo_rows"), (cc, "coo_cols"), (cv, "coo_vals")):
+            assert np.array_equal(got, g[f"hyb{lim}_{name}"]), (lim, name)
+        y = oracle.ell_spmv(532, k, st, ec, ev, b) if k else np.zeros((532, 3))
+        y = oracle.coo_apply("spmv2", 532, cr, cc, cv, b, c=y)
+        assert np.array_equal(y, g[f"hyb{lim}_apply"])
+
+
+def test_live_reference_coo_hybrid(oracle):
+    ref = _ref()
+    rng = np.random.default_rng(8)
+    rp, ci, v = random_csr(97, 64, 0.15, seed=9)
+    rows = np.repeat(np.arange(97, dtype=np.int32), np.diff(rp))
+    b, c0 = rng.uniform(-1, 1, (64, 2)), rng.uniform(-1, 1, (97, 2))
+    for mode in ("spmv", "advanced_spmv", "spmv2", "advanced_spmv2"):
+        for p in (np.arange(len(v)), rng.permutation(len(v))):
+            assert np.array_equal(oracle.coo_apply(mode, 97, rows[p], ci[p], v[p], b, 0.7, 1.3, c0),
+                                  ref.coo_apply(mode, 97, 64, rows[p], ci[p], v[p], b, 0.7, 1.3, c0))
+    h = ref.CsrHandle("reference", rp, ci, v, n_cols=64)
+    for lim in (0, 2, 11):
+        k, st, ec, ev, cr, cc, cv = h.to_hybrid(lim)
+        got = oracle.csr_to_hybrid(rp, ci, v, k, st)
+        for a_, b_ in zip((got[0], got[1], got[3], got[4], got[5]), (ec, ev, cr, cc, cv)):
+            assert np.array_equal(a_, b_)
