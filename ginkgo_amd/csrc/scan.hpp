@@ -90,6 +90,37 @@ int device_exclusive_scan(hipStream_t st, T* data, int64_t n)
     return GKOC_OK;
 }
 
+// the same with caller-provided scratch (no allocation on the stream):
+// scratch holds scan_scratch_count(n) values
+inline int64_t scan_scratch_count(int64_t n)
+{
+    int64_t total = 0;
+    for (int64_t t = ceildiv(n > 0 ? n : 1, int64_t(scan_tile)); t > 1;
+         t = ceildiv(t, int64_t(scan_tile))) {
+        total += t;
+    }
+    return total + 1;
+}
+
+template <typename T>
+int device_exclusive_scan(hipStream_t st, T* data, int64_t n, T* scratch)
+{
+    if (n <= 0) return GKOC_OK;
+    const int64_t tiles = ceildiv(n, scan_tile);
+    if (tiles == 1) {
+        scan_tiles<T><<<dim3(1), dim3(scan_block), 0, st>>>(n, data, nullptr);
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
+    scan_tile_sums<T><<<dim3(unsigned(tiles)), dim3(scan_block), 0, st>>>(n, data, scratch);
+    GKOC_LAUNCH_OK();
+    int rc = device_exclusive_scan<T>(st, scratch, tiles, scratch + tiles);
+    if (rc != GKOC_OK) return rc;
+    scan_tiles<T><<<dim3(unsigned(tiles)), dim3(scan_block), 0, st>>>(n, data, scratch);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
 #endif
 
 }  // namespace gkoc
