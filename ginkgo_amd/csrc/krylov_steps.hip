@@ -6,6 +6,8 @@
 //   fcg::{initialize, step_1, step_2}               (reference/solver/fcg_kernels.cpp:24-106)
 //   pipe_cg::{initialize_1, initialize_2, step_1, step_2}
 //                                                   (reference/solver/pipe_cg_kernels.cpp:24-164)
+//   chebyshev::{init_update, update}                (reference/solver/chebyshev_kernels.cpp:20-66)
+//   ir::initialize                                  (reference/solver/ir_kernels.cpp:20-27)
 // All of them are "per column: a few scalars; per element: a short update that
 // is skipped when the column has stopped" - the shape of elementwise.hpp: 16-byte
 // loads, every operand of an element group in flight before the first store.
@@ -396,10 +398,63 @@ struct op_pipe_cg_step2 {
     }
 };
 
+// --------------------------------------------------------------- chebyshev
+// coefficients are host scalars of the highest precision (solver::detail::coeff_type
+// = double); every element is widened, updated and narrowed back like the reference
+// (reference/solver/chebyshev_kernels.cpp:20-66).
+// init_update: update = inner ; output += alpha inner.   in = {inner, output}, out = {update, output}
+template <typename T>
+struct op_cheb_init {
+    double alpha;
+    struct scalars {};
+    __device__ scalars load(int64_t) const { return {}; }
+    __device__ bool skip(const scalars&) const { return false; }
+    __device__ void apply(const scalars&, const T* in, T* out) const
+    {
+        const double v = static_cast<double>(in[0]);
+        out[0] = static_cast<T>(v);
+        out[1] = static_cast<T>(static_cast<double>(in[1]) + alpha * v);
+    }
+};
+
+// val = inner + beta update ; inner = update = val ; output += alpha val
+// in = {inner, update, output}, out = {inner, update, output}
+template <typename T>
+struct op_cheb_update {
+    double alpha, beta;
+    struct scalars {};
+    __device__ scalars load(int64_t) const { return {}; }
+    __device__ bool skip(const scalars&) const { return false; }
+    __device__ void apply(const scalars&, const T* in, T* out) const
+    {
+        const double v = static_cast<double>(in[0]) + beta * static_cast<double>(in[1]);
+        out[0] = static_cast<T>(v);
+        out[1] = static_cast<T>(v);
+        out[2] = static_cast<T>(static_cast<double>(in[2]) + alpha * v);
+    }
+};
+
+__global__ void reset_status_kernel(int64_t cols, uint8_t* stop)
+{
+    const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j < cols) stop[j] = 0;
+}
+
 }  // namespace
 }  // namespace gkoc
 
 using namespace gkoc;
+
+// ir::initialize (reference/solver/ir_kernels.cpp:20-27): stop_status.reset()
+extern "C" int gkoc_ir_initialize(gkoc_stream_t s, int64_t cols, uint8_t* stop_status)
+{
+    GKOC_REQUIRE(cols >= 0 && (cols == 0 || stop_status), GKOC_E_INVALID, "bad argument");
+    if (cols == 0) return GKOC_OK;
+    reset_status_kernel<<<dim3(unsigned(ceildiv(cols, 256))), dim3(256), 0, as_stream(s)>>>(
+        cols, stop_status);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
 
 #define GKOC_DEF_KRYLOV(T, TN)                                                            \
     /* ------------------------------------------------------------ bicgstab */           \
@@ -610,3 +665,26 @@ using namespace gkoc;
 
 GKOC_DEF_KRYLOV(double, f64)
 GKOC_DEF_KRYLOV(float, f32)
+
+#define GKOC_DEF_CHEB(T, TN)                                                              \
+    extern "C" int gkoc_chebyshev_init_update_##TN(                                       \
+        gkoc_stream_t s, int64_t rows, int64_t cols, double alpha, const T* inner_sol,    \
+        int64_t ldi, T* update_sol, int64_t ldu, T* output, int64_t ldo)                  \
+    {                                                                                     \
+        operand_list<T, 2, 2> o;                                                          \
+        o.in(inner_sol, ldi).in(output, ldo).out(update_sol, ldu).out(output, ldo);       \
+        return launch_elementwise<T, op_cheb_init<T>, 2, 2>(s, rows, cols, o.a,           \
+                                                            op_cheb_init<T>{alpha}, true); \
+    }                                                                                     \
+    extern "C" int gkoc_chebyshev_update_##TN(                                            \
+        gkoc_stream_t s, int64_t rows, int64_t cols, double alpha, double beta,           \
+        T* inner_sol, int64_t ldi, T* update_sol, int64_t ldu, T* output, int64_t ldo)    \
+    {                                                                                     \
+        operand_list<T, 3, 3> o;                                                          \
+        o.in(inner_sol, ldi).in(update_sol, ldu).in(output, ldo).out(inner_sol, ldi)      \
+            .out(update_sol, ldu).out(output, ldo);                                       \
+        return launch_elementwise<T, op_cheb_update<T>, 3, 3>(                            \
+            s, rows, cols, o.a, op_cheb_update<T>{alpha, beta}, true);                    \
+    }
+GKOC_DEF_CHEB(double, f64)
+GKOC_DEF_CHEB(float, f32)

@@ -1,10 +1,12 @@
-"""Bicgstab, Cgs, Fcg and PipeCg on the Cdna4Executor.
+"""Bicgstab, Cgs, Fcg, PipeCg, Ir and Chebyshev on the Cdna4Executor.
 
 Each class is the driver of the reference with the same kernel sequence -
   Bicgstab  core/solver/bicgstab.cpp:95-236
   Cgs       core/solver/cgs.cpp:96-201
   Fcg       core/solver/fcg.cpp:94-183
   PipeCg    core/solver/pipe_cg.cpp:95-297
+  Ir        core/solver/ir.cpp:189-255         (with core/solver/update_residual.hpp)
+  Chebyshev core/solver/chebyshev.cpp:203-296  (likewise)
 - issuing the fused vector updates of csrc/krylov_steps.hip (gkoc_bicgstab_*,
 gkoc_cgs_*, gkoc_fcg_*, gkoc_pipe_cg_*) between the SpMV / preconditioner
 applications and the reductions.  The criterion is checked where the reference
@@ -244,3 +246,96 @@ class PipeCg(_Krylov):
                      w.ld, m.values, m.ld, n.values, n.ld, prev_rho.values, rho.values,
                      delta.values, stop)
         self._finish(it, stop, r)
+
+
+class _Stationary(_Krylov):
+    """residual handling shared by Ir and Chebyshev (core/solver/update_residual.hpp:25-75):
+    iteration 0 checks the initial residual; later iterations first ask the criteria that
+    need no residual, then recompute r = b - A x and check it.  The initial guess is x."""
+
+    def _update_residual(self, crit, it, a, b, x, r, one, neg_one, stop):
+        if it == 0:
+            return crit.check(1, True, stop, {"num_iterations": it, "residual": r, "solution": x})[0]
+        if crit.check(1, False, stop, {"num_iterations": it, "solution": x,
+                                       "ignore_residual_check": True})[0]:
+            return True
+        r.copy_from(b)
+        a.apply(neg_one, x, one, r)
+        return crit.check(1, True, stop, {"num_iterations": it, "residual": r, "solution": x})[0]
+
+    def _finish_stationary(self, it, stop, a, b, x, r, one, neg_one):
+        # what log::Convergence reports: the residual of the final x
+        r.copy_from(b)
+        a.apply(neg_one, x, one, r)
+        self._finish(it, stop, r)
+
+
+class Ir(_Stationary):
+    """x += relaxation_factor * S (b - A x) with inner solver S (with_solver /
+    with_preconditioner, Identity if none): Richardson iteration / iterative refinement"""
+
+    @staticmethod
+    def build():
+        return _SolverFactory(Ir)
+
+    def apply_impl(self, b, x):
+        a, inner = self.system_matrix, self.preconditioner
+        ex, one, neg_one, stop = self._common(b)
+        r = self._vec("r", b)
+        relax = scalar(ex, float(self.params.get("relaxation_factor", 1.0)), b.dtype)
+        call("gkoc_ir_initialize", ex.stream, b.size[1], stop)
+        r.copy_from(b)
+        a.apply(neg_one, x, one, r)
+        crit = _stop.combine(self.criteria, a, b, x, r)
+        it = -1
+        while True:
+            it += 1
+            if self._update_residual(crit, it, a, b, x, r, one, neg_one, stop):
+                break
+            inner.apply(relax, r, one, x)          # x = relaxation * S r + x
+        self._finish_stationary(it, stop, a, b, x, r, one, neg_one)
+
+
+class Chebyshev(_Stationary):
+    """Chebyshev iteration for a preconditioned operator whose spectrum lies between the
+    foci (with_foci((lower, upper)))"""
+
+    @staticmethod
+    def build():
+        return _SolverFactory(Chebyshev)
+
+    def apply_impl(self, b, x):
+        import ctypes as C
+        a, m = self.system_matrix, self.preconditioner
+        ex, one, neg_one, stop = self._common(b)
+        suf = VT[b.dtype]
+        rows, cols = b.size
+        r, inner, update = (self._vec(n, b) for n in ("r", "inner_solution", "update_solution"))
+        lo, hi = self.params.get("foci", (0.0, 1.0))
+        center, direction = (lo + hi) / 2.0, (hi - lo) / 2.0
+        if center == 0:
+            raise ValueError("Chebyshev: the centre of the foci must not be zero")
+        alpha = 1.0 / center
+        beta = 0.5 * (direction * alpha) * (direction * alpha)
+        call("gkoc_ir_initialize", ex.stream, cols, stop)
+        r.copy_from(b)
+        a.apply(neg_one, x, one, r)
+        crit = _stop.combine(self.criteria, a, b, x, r)
+        it = -1
+        while True:
+            it += 1
+            if self._update_residual(crit, it, a, b, x, r, one, neg_one, stop):
+                break
+            m.apply(r, inner)
+            if it == 0:
+                # update = inner ; x += alpha inner
+                call("gkoc_chebyshev_init_update_" + suf, ex.stream, rows, cols, C.c_double(alpha),
+                     inner.values, inner.ld, update.values, update.ld, x.values, x.ld)
+                continue
+            if it > 1:
+                beta = (direction * alpha / 2.0) * (direction * alpha / 2.0)
+            alpha = 1.0 / (center - beta / alpha)
+            # inner = update = inner + beta update ; x += alpha inner
+            call("gkoc_chebyshev_update_" + suf, ex.stream, rows, cols, C.c_double(alpha),
+                 C.c_double(beta), inner.values, inner.ld, update.values, update.ld, x.values, x.ld)
+        self._finish_stationary(it, stop, a, b, x, r, one, neg_one)

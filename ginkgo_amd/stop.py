@@ -94,6 +94,8 @@ class ResidualNorm:
         self.flags = ex.zeros((2,), torch.uint8)
 
     def _select(self, upd):
+        if upd.get("ignore_residual_check"):
+            return None, None            # criterion::updater::ignore_residual_check
         if self.implicit:
             tau = upd.get("implicit_sq_residual_norm")
             if tau is None:
@@ -113,6 +115,8 @@ class ResidualNorm:
 
     def check(self, stopping_id, set_finalized, stop_status, upd):
         name, tau = self._select(upd)
+        if name is None:
+            return False, False
         allc, chg = C.c_int(0), C.c_int(0)
         call(name + VT[tau.dtype], self.exec.stream, tau.size[1], tau.values,
              self.starting_tau.values, cval(tau.dtype, self.reduction_factor),

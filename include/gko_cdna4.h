@@ -719,6 +719,26 @@ GKOC_DECL_COO(float, f32, int64_t, i64)
 GKOC_DECL_KRYLOV(double, f64)
 GKOC_DECL_KRYLOV(float, f32)
 
+/* ir::initialize (core/solver/ir_kernels.hpp:19-21; reference/solver/ir_kernels.cpp:20-27):
+ * reset the stopping status; used by Ir and Chebyshev.
+ * chebyshev::{init_update, update} (core/solver/chebyshev_kernels.hpp:21-40;
+ * reference/solver/chebyshev_kernels.cpp:20-66): alpha, beta are host scalars of
+ * solver::detail::coeff_type (double); elements are widened to double, updated,
+ * narrowed back.  init_update: update = inner, output += alpha inner.
+ * update: val = inner + beta update; inner = update = val; output += alpha val. */
+int gkoc_ir_initialize(gkoc_stream_t s, int64_t cols, uint8_t* stop_status);
+#define GKOC_DECL_CHEB(T, TN)                                                  \
+    int gkoc_chebyshev_init_update_##TN(                                       \
+        gkoc_stream_t s, int64_t rows, int64_t cols, double alpha,             \
+        const T* inner_sol, int64_t ldi, T* update_sol, int64_t ldu,           \
+        T* output, int64_t ldo);                                               \
+    int gkoc_chebyshev_update_##TN(                                            \
+        gkoc_stream_t s, int64_t rows, int64_t cols, double alpha,             \
+        double beta, T* inner_sol, int64_t ldi, T* update_sol, int64_t ldu,    \
+        T* output, int64_t ldo);
+GKOC_DECL_CHEB(double, f64)
+GKOC_DECL_CHEB(float, f32)
+
 /* ------------------------------------------------- communicator (RCCL over xGMI)
  * Replaces, for device buffers, what the distributed path asks of
  * experimental::mpi::communicator (include/ginkgo/core/base/mpi.hpp):

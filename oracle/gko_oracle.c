@@ -391,12 +391,23 @@ static int krylov_check(int64_t iter, int64_t max_iters, int64_t n,
                                     0, one_changed);
 }
 
+static int64_t oracle_stationary_solve(int kind, int64_t n, const int32_t* row_ptrs,
+                                       const int32_t* cols, const double* vals,
+                                       const oracle_precond* m, const double* b, double* x,
+                                       int64_t max_iters, double reduction, int baseline,
+                                       double p0, double p1, double* resnorm_out);
+
 int64_t oracle_krylov_solve_f64_i32(int kind, int64_t n, const int32_t* row_ptrs,
                                     const int32_t* cols, const double* vals,
                                     const oracle_precond* m, const double* b,
                                     double* x, int64_t max_iters, double reduction,
-                                    int baseline, double* resnorm_out)
+                                    int baseline, double p0, double p1,
+                                    double* resnorm_out)
 {
+    if (kind == 5 || kind == 6) {
+        return oracle_stationary_solve(kind, n, row_ptrs, cols, vals, m, b, x, max_iters,
+                                       reduction, baseline, p0, p1, resnorm_out);
+    }
     const size_t N = (size_t)n;
     double* w = (double*)calloc(N * 12, sizeof(double));
     double* V[12];
@@ -524,6 +535,81 @@ int64_t oracle_krylov_solve_f64_i32(int kind, int64_t n, const int32_t* row_ptrs
 #undef RESID
 #undef DOT
 #undef BASELINE
+    if (resnorm_out) *resnorm_out = tau;
+    free(w);
+    return iter;
+}
+
+/* Ir (kind 5; core/solver/ir.cpp:189-255, inner solver = the preconditioner argument,
+ * Identity if none, p0 = relaxation factor) and Chebyshev (kind 6;
+ * core/solver/chebyshev.cpp:203-296, p0 / p1 = the foci) with the residual handling of
+ * core/solver/update_residual.hpp:25-75: iteration 0 checks the initial residual; later
+ * iterations first ask the criteria that need no residual (Iteration), then recompute
+ * r = b - A x and check it.  The initial guess is the given x. */
+static int64_t oracle_stationary_solve(int kind, int64_t n, const int32_t* row_ptrs,
+                                       const int32_t* cols, const double* vals,
+                                       const oracle_precond* m, const double* b, double* x,
+                                       int64_t max_iters, double reduction, int baseline,
+                                       double p0, double p1, double* resnorm_out)
+{
+    const size_t N = (size_t)n;
+    double* w = (double*)calloc(N * 3, sizeof(double));
+    double *r = w, *inner = w + N, *upd = w + 2 * N;
+    double tau = 0.0, tau0 = 1.0;
+    uint8_t stop = 0;
+    int one_changed = 0;
+    const double center = (p0 + p1) / 2.0, foci_direction = (p1 - p0) / 2.0;
+    double alpha = 1.0 / center;
+    double beta = 0.5 * (foci_direction * alpha) * (foci_direction * alpha);
+    memcpy(r, b, sizeof(double) * N);
+    oracle_csr_advanced_spmv_f64_i32(n, -1.0, row_ptrs, cols, vals, x, 1, 1.0, r, 1, 1);
+    if (baseline == 0) {
+        oracle_dense_compute_norm2_f64(n, 1, b, 1, &tau0, 0);
+    } else if (baseline == 1) {
+        oracle_dense_compute_norm2_f64(n, 1, r, 1, &tau0, 0);
+    }
+    int64_t iter = -1;
+    for (;;) {
+        ++iter;
+        if (iter > 0) {
+            if (iter >= max_iters) { /* Iteration, residual check ignored; not finalized */
+                if ((stop & 0x3f) == 0) stop |= (uint8_t)1;
+                /* the Convergence logger gets no residual here and computes
+                 * ||b - A x|| itself (core/log/convergence.cpp) */
+                memcpy(r, b, sizeof(double) * N);
+                oracle_csr_advanced_spmv_f64_i32(n, -1.0, row_ptrs, cols, vals, x, 1, 1.0, r, 1, 1);
+                oracle_dense_compute_norm2_f64(n, 1, r, 1, &tau, 0);
+                break;
+            }
+            memcpy(r, b, sizeof(double) * N);
+            oracle_csr_advanced_spmv_f64_i32(n, -1.0, row_ptrs, cols, vals, x, 1, 1.0, r, 1, 1);
+        }
+        if (krylov_check(iter, max_iters, n, r, tau0, reduction, 1, &stop, &one_changed, &tau)) break;
+        if (kind == 5) {
+            /* solver_->apply(relaxation, r, one, x): the ADVANCED apply of the inner
+             * operator, in its own operation order (ir.cpp:252-253) */
+            if (m->precond == 1) {
+                oracle_jacobi_scalar_apply_f64(n, 1, m->inv_diag, 1, p0, r, 1, 1.0, x, 1);
+            } else if (m->precond == 2) {
+                oracle_jacobi_apply_f64_i32(m->num_blocks, m->block_offset, m->group_offset,
+                                            m->group_power, m->block_ptrs, m->blocks, p0, r, 1,
+                                            1.0, x, 1, 1);
+            } else { /* Identity: x->scale(one); x->add_scaled(relaxation, r) */
+                for (int64_t i = 0; i < n; ++i) x[i] = x[i] * 1.0 + p0 * r[i];
+            }
+        } else {
+            apply_precond(m, n, r, inner);
+            if (iter == 0) {
+                oracle_chebyshev_init_update_f64(n, 1, 1, alpha, inner, upd, x);
+                continue;
+            }
+            if (iter > 1) {
+                beta = (foci_direction * alpha / 2.0) * (foci_direction * alpha / 2.0);
+            }
+            alpha = 1.0 / (center - beta / alpha);
+            oracle_chebyshev_update_f64(n, 1, 1, alpha, beta, inner, upd, x);
+        }
+    }
     if (resnorm_out) *resnorm_out = tau;
     free(w);
     return iter;

@@ -439,13 +439,14 @@ def _make_precond(row_ptrs, cols, vals, precond, max_block_size):
     return m, keep
 
 
-KRYLOV_KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4}
+KRYLOV_KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4, "ir": 5, "chebyshev": 6}
 
 
 def krylov_solve(kind, row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,
-                 baseline="rhs_norm", precond=None, max_block_size=8):
-    """Bicgstab / Cgs / Fcg / PipeCg (oracle_krylov_solve_f64_i32) with
-    Combined(Iteration, ResidualNorm); f64 / int32, one right-hand side."""
+                 baseline="rhs_norm", precond=None, max_block_size=8, relaxation=1.0,
+                 foci=(0.0, 1.0)):
+    """Bicgstab / Cgs / Fcg / PipeCg / Ir (relaxation; inner solver = precond) /
+    Chebyshev (foci) with Combined(Iteration, ResidualNorm); f64 / int32, one rhs."""
     n = len(row_ptrs) - 1
     assert vals.dtype == np.float64 and cols.dtype == np.int32
     x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64, copy=True)
@@ -457,6 +458,7 @@ def krylov_solve(kind, row_ptrs, cols, vals, b, x0=None, max_iters=1000, reducti
     f.restype = C.c_int64
     iters = f(C.c_int(KRYLOV_KINDS[kind]), _i64(n), _p(row_ptrs), _p(cols), _p(vals), C.byref(m),
               _p(b), _p(x), _i64(max_iters), C.c_double(reduction), C.c_int(base),
+              C.c_double(relaxation if kind == "ir" else foci[0]), C.c_double(foci[1]),
               C.byref(resnorm))
     del keep
     return x, int(iters), resnorm.value

@@ -153,6 +153,21 @@ class CsrHandle:
         lib().ref_hybrid_spmv(self.h, _p(b2), _p(out), C.c_int64(b2.shape[1]))
         return out if np.ndim(b) == 2 else out[:, 0]
 
+    def stationary_solve(self, kind, b, x0=None, max_iters=1000, reduction=1e-10,
+                         baseline="rhs_norm", precond_block_size=0, relaxation=1.0, foci=(0.0, 1.0)):
+        """Ir (inner solver Jacobi / Identity) and Chebyshev of the reference"""
+        x = np.zeros(self.n_rows) if x0 is None else np.array(x0, dtype=np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        rn = C.c_double(0)
+        base = {"rhs_norm": 0, "initial_resnorm": 1, "absolute": 2}[baseline]
+        f = lib().ref_stationary_solve
+        f.restype = C.c_int64
+        k = {"ir": 5, "chebyshev": 6}[kind]
+        it = f(self.h, C.c_int(k), C.c_uint32(precond_block_size), _p(b), _p(x), C.c_int64(max_iters),
+               C.c_double(reduction), C.c_int(base), C.c_double(relaxation if kind == "ir" else foci[0]),
+               C.c_double(foci[1]), C.byref(rn))
+        return x, int(it), rn.value
+
     KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4}
 
     def krylov_solve(self, kind, b, x0=None, max_iters=1000, reduction=1e-10,

@@ -24,6 +24,8 @@
 #include <ginkgo/core/solver/bicgstab.hpp>
 #include <ginkgo/core/solver/cg.hpp>
 #include <ginkgo/core/solver/cgs.hpp>
+#include <ginkgo/core/solver/chebyshev.hpp>
+#include <ginkgo/core/solver/ir.hpp>
 #include <ginkgo/core/solver/fcg.hpp>
 #include <ginkgo/core/solver/pipe_cg.hpp>
 #include <ginkgo/core/solver/gmres.hpp>
@@ -274,6 +276,39 @@ int main(int argc, char** argv)
         run(type_tag<gko::solver::Cgs<vt>>{}, "Cgs");
         run(type_tag<gko::solver::Fcg<vt>>{}, "Fcg");
         run(type_tag<gko::solver::PipeCg<vt>>{}, "PipeCg");
+        // Ir (Richardson with a Jacobi inner solver) and Chebyshev: no reduction enters the
+        // iterates, so a fixed number of iterations must reproduce the reference's bits
+        auto stationary = [&](auto exec, auto a, bool cheb) {
+            auto rhs = Dense::create(exec, gko::dim<2>{n, 1});
+            rhs->fill(1.0);
+            auto x = Dense::create(exec, gko::dim<2>{n, 1});
+            x->fill(0.25);
+            auto crit = gko::share(gko::stop::Iteration::build().with_max_iters(9u).on(exec));
+            auto jac = gko::share(
+                gko::preconditioner::Jacobi<vt, it>::build().with_max_block_size(8u).on(exec));
+            std::shared_ptr<gko::LinOp> solver;
+            if (cheb) {
+                solver = gko::solver::Chebyshev<vt>::build()
+                             .with_criteria(crit)
+                             .with_preconditioner(jac)
+                             .with_foci(std::pair<double, double>{0.02, 2.0})
+                             .on(exec)
+                             ->generate(a);
+            } else {
+                solver = gko::solver::Ir<vt>::build()
+                             .with_criteria(crit)
+                             .with_solver(jac)
+                             .with_relaxation_factor(0.9)
+                             .on(exec)
+                             ->generate(a);
+            }
+            solver->apply(rhs, x);
+            return gko::clone(exec->get_master(), x);
+        };
+        CHECK(identical(stationary(hip, a_hip, false).get(), stationary(ref, a_ref, false).get()),
+              "Ir + Jacobi(8), 9 iterations: bit-identical to reference");
+        CHECK(identical(stationary(hip, a_hip, true).get(), stationary(ref, a_ref, true).get()),
+              "Chebyshev + Jacobi(8), 9 iterations: bit-identical to reference");
     }
 
     // --- timer (HipTimer through the C ABI events)

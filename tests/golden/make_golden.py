@@ -88,7 +88,34 @@ def coo_hybrid():
     save("coo_hybrid.npz", **arrays)
 
 
+def stationary():
+    """Ir and Chebyshev of the reference"""
+    from oracle import gko_oracle as o
+    rng = np.random.default_rng(31)
+    rp, ci, v = o.stencil_csr(3, 10)
+    n = len(rp) - 1
+    h = ref.CsrHandle("reference", rp, ci, v)
+    rhs = rng.uniform(-1, 1, n)
+    arrays = dict(row_ptrs=rp, cols=ci, vals=v, rhs=rhs)
+    # spectrum of the 27-pt operator: (0, 52); Jacobi-preconditioned: (0, 2)
+    for bs, relax, foci in ((0, 0.035, (0.5, 52.0)), (1, 0.9, (0.02, 2.0)), (8, 0.9, (0.02, 2.0))):
+        x, it, rn = h.stationary_solve("ir", rhs, max_iters=400, reduction=1e-6, precond_block_size=bs,
+                                       relaxation=relax)
+        arrays[f"ir_{bs}_x"], arrays[f"ir_{bs}_it_rn"] = x, np.array([it, rn, relax])
+        x, it, rn = h.stationary_solve("chebyshev", rhs, x0=np.full(n, 0.1), max_iters=400, reduction=1e-6,
+                                       precond_block_size=bs, foci=foci)
+        arrays[f"chebyshev_{bs}_x"] = x
+        arrays[f"chebyshev_{bs}_it_rn"] = np.array([it, rn, *foci])
+    for kind, kw in (("ir", dict(relaxation=0.9)), ("chebyshev", dict(foci=(0.02, 2.0)))):
+        x, it, rn = h.stationary_solve(kind, rhs, x0=np.full(n, 0.5), max_iters=7, reduction=1e-30,
+                                       baseline="initial_resnorm", precond_block_size=8, **kw)
+        arrays[f"{kind}_lim_x"], arrays[f"{kind}_lim_it_rn"] = x, np.array([it, rn])
+    save("stationary.npz", **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "stationary":
+        return stationary()
     if len(sys.argv) > 1 and sys.argv[1] == "krylov_family":
         return krylov_family()
     if len(sys.argv) > 1 and sys.argv[1] == "coo_hybrid":
@@ -195,3 +222,4 @@ if __name__ == "__main__":
     if len(sys.argv) == 1:
         krylov_family()
         coo_hybrid()
+        stationary()

@@ -108,3 +108,22 @@ def random_case(solver, kernel, rows, cols, dtype, seed, zero_col=None, stopped_
                 st[stopped_col] = STOPPED
             arrays[name] = st
     return arrays
+
+
+# reference/test/solver/chebyshev_kernels.cpp:41-52 (fixture: alpha 0.5, beta 0.25) and
+# :66-81 (KernelInitUpdate), :84-108 (KernelUpdate); all values are exact in binary
+CHEB_INNER = [[0.5, 0.125, -0.125], [0.25, 0.5, -1.0], [1.5, -0.25, 1.5]]
+CHEB_UPDATE = [[1.0, 0.0, -0.5], [0.5, 1.0, -1.0], [-1.5, -0.5, 1.0]]
+CHEB_OUTPUT = [[-1.0, 0.5, -0.0], [0.75, 0.25, -1.25], [1.0, -1.25, 3.0]]
+
+
+def check_chebyshev(kernel, inner, update, output):
+    if kernel == "init_update":
+        assert np.array_equal(update, np.array(CHEB_INNER, dtype=update.dtype))
+        want = [[-0.75, 0.5625, -0.0625], [0.875, 0.5, -1.75], [1.75, -1.375, 3.75]]
+    else:
+        val = [[0.75, 0.125, -0.25], [0.375, 0.75, -1.25], [1.125, -0.375, 1.75]]
+        assert np.array_equal(inner, np.array(val, dtype=inner.dtype))
+        assert np.array_equal(update, inner)
+        want = [[-0.625, 0.5625, -0.125], [0.9375, 0.625, -1.875], [1.5625, -1.4375, 3.875]]
+    assert np.array_equal(output, np.array(want, dtype=output.dtype))

@@ -175,3 +175,72 @@ def test_f32_and_multiple_rhs(gexec, oracle):
         s.apply(g.Dense.from_numpy(gexec, rhs[:, :1].astype(np.float32)), x)
         r = rhs[:, 0] - oracle.csr_spmv(rp, ci, v, x.to_numpy()[:, 0].astype(np.float64))
         assert s.has_converged and np.linalg.norm(r) <= 1e-3 * np.linalg.norm(rhs[:, 0])
+
+
+# ------------------------------------------------------------ Ir / Chebyshev
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_chebyshev_kernels(gexec, oracle, dtype):
+    """known answers of reference/test/solver/chebyshev_kernels.cpp, then seeded operands
+    with strides against the oracle, bit-exact"""
+    import ginkgo_amd as g
+    from ginkgo_amd._lib import VT, call
+    suf = "f64" if dtype == np.float64 else "f32"
+    for kernel in ("init_update", "update"):
+        inner, upd, out = (g.Dense.from_numpy(gexec, np.array(m, dtype=dtype))
+                           for m in (kc.CHEB_INNER, kc.CHEB_UPDATE, kc.CHEB_OUTPUT))
+        coeffs = [C.c_double(0.5)] + ([C.c_double(0.25)] if kernel == "update" else [])
+        call(f"gkoc_chebyshev_{kernel}_{suf}", gexec.stream, 3, 3, *coeffs, inner.values, inner.ld,
+             upd.values, upd.ld, out.values, out.ld)
+        kc.check_chebyshev(kernel, inner.to_numpy(), upd.to_numpy(), out.to_numpy())
+    rng = np.random.default_rng(3)
+    for rows, cols, lds in ((100003, 1, (1, 1, 1)), (597, 3, (4, 3, 5))):
+        for kernel in ("init_update", "update"):
+            host = [rng.uniform(-1, 1, (rows, cols)).astype(dtype) for _ in range(3)]
+            dev = [g.Dense.from_numpy(gexec, h, ld) for h, ld in zip(host, lds)]
+            coeffs = [0.37] + ([-0.61] if kernel == "update" else [])
+            f = getattr(oracle.lib(), f"oracle_chebyshev_{kernel}_{suf}")
+            f(C.c_int64(rows), C.c_int64(cols), C.c_int64(cols), *map(C.c_double, coeffs),
+              *[oracle._p(h) for h in host])
+            call(f"gkoc_chebyshev_{kernel}_{suf}", gexec.stream, rows, cols, *map(C.c_double, coeffs),
+                 *[t for d in dev for t in (d.values, d.ld)])
+            for h, d in zip(host, dev):
+                assert np.array_equal(d.to_numpy(), h), (kernel, rows)
+
+
+def test_ir_chebyshev_match_reference_golden(gexec, oracle):
+    import ginkgo_amd as g
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "stationary.npz"))
+    rp, ci, v, rhs = (gold[k] for k in ("row_ptrs", "cols", "vals", "rhs"))
+    n = len(rp) - 1
+    a = g.Csr.from_arrays(gexec, (n, n), rp, ci, v)
+
+    def solve(cls, bs, x0, max_iters, reduction, baseline=None, **params):
+        rn = g.stop.ResidualNorm.build().with_reduction_factor(reduction)
+        if baseline is not None:
+            rn = rn.with_baseline(baseline)
+        f = cls.build().with_criteria(g.stop.Iteration.build().with_max_iters(max_iters), rn)
+        for k, val in params.items():
+            f = getattr(f, "with_" + k)(val)
+        if bs:
+            f = f.with_preconditioner(g.Jacobi.build().with_max_block_size(bs))
+        s = f.on(gexec).generate(a)
+        x = g.Dense.from_numpy(gexec, x0)
+        s.apply(g.Dense.from_numpy(gexec, rhs), x)
+        return x.to_numpy()[:, 0], s
+
+    for bs in (0, 1, 8):
+        it_ref, rn_ref, relax = gold[f"ir_{bs}_it_rn"]
+        x, s = solve(g.Ir, bs, np.zeros(n), 400, 1e-6, relaxation_factor=float(relax))
+        assert s.has_converged and abs(s.num_iterations - int(it_ref)) <= 1, ("ir", bs, s.num_iterations, it_ref)
+        assert np.linalg.norm(x - gold[f"ir_{bs}_x"]) <= 1e-9 * np.linalg.norm(x)
+        it_ref, rn_ref, f0, f1 = gold[f"chebyshev_{bs}_it_rn"]
+        x, s = solve(g.Chebyshev, bs, np.full(n, 0.1), 400, 1e-6, foci=(float(f0), float(f1)))
+        assert s.has_converged and abs(s.num_iterations - int(it_ref)) <= 1, ("chebyshev", bs)
+        assert np.linalg.norm(x - gold[f"chebyshev_{bs}_x"]) <= 1e-9 * np.linalg.norm(x)
+    # fixed iteration count: no reduction order is involved in the iterates (SpMV,
+    # Jacobi and the updates are all bit-exact) => identical bits
+    for cls, kind, kw in ((g.Ir, "ir", dict(relaxation_factor=0.9)), (g.Chebyshev, "chebyshev", dict(foci=(0.02, 2.0)))):
+        x, s = solve(cls, 8, np.full(n, 0.5), 7, 1e-30, baseline=g.stop.mode.initial_resnorm, **kw)
+        assert s.num_iterations == 7 and not s.has_converged
+        assert np.array_equal(x, gold[f"{kind}_lim_x"]), kind
+        assert abs(s.residual_norm - gold[f"{kind}_lim_it_rn"][1]) <= 1e-12 * s.residual_norm

@@ -450,3 +450,59 @@ def test_live_reference_coo_hybrid(oracle):
         got = oracle.csr_to_hybrid(rp, ci, v, k, st)
         for a_, b_ in zip((got[0], got[1], got[3], got[4], got[5]), (ec, ev, cr, cc, cv)):
             assert np.array_equal(a_, b_)
+
+
+# ----------------------------------------------------------------------------
+# Ir / Chebyshev
+def test_chebyshev_kernel_known_answers(oracle):
+    import ctypes as C
+    import krylov_family_cases as kc
+    for dt, suf in ((np.float64, "f64"), (np.float32, "f32")):
+        for kernel in ("init_update", "update"):
+            inner, upd, out = (np.array(m, dtype=dt) for m in (kc.CHEB_INNER, kc.CHEB_UPDATE, kc.CHEB_OUTPUT))
+            f = getattr(oracle.lib(), f"oracle_chebyshev_{kernel}_{suf}")
+            coeffs = [C.c_double(0.5)] + ([C.c_double(0.25)] if kernel == "update" else [])
+            f(C.c_int64(3), C.c_int64(3), C.c_int64(3), *coeffs, oracle._p(inner), oracle._p(upd),
+              oracle._p(out))
+            kc.check_chebyshev(kernel, inner, upd, out)
+
+
+def test_golden_stationary(oracle):
+    g = gold("stationary.npz")
+    rp, ci, v, rhs = g["row_ptrs"], g["cols"], g["vals"], g["rhs"]
+    n = len(rp) - 1
+    for bs, pre in ((0, None), (1, "scalar"), (8, "block")):
+        it_ref, rn_ref, relax = g[f"ir_{bs}_it_rn"]
+        x, it, rn = oracle.krylov_solve("ir", rp, ci, v, rhs, max_iters=400, reduction=1e-6, precond=pre,
+                                        max_block_size=max(bs, 1), relaxation=float(relax))
+        assert (it, rn) == (int(it_ref), float(rn_ref)) and np.array_equal(x, g[f"ir_{bs}_x"])
+        it_ref, rn_ref, f0, f1 = g[f"chebyshev_{bs}_it_rn"]
+        x, it, rn = oracle.krylov_solve("chebyshev", rp, ci, v, rhs, x0=np.full(n, 0.1), max_iters=400,
+                                        reduction=1e-6, precond=pre, max_block_size=max(bs, 1),
+                                        foci=(float(f0), float(f1)))
+        assert (it, rn) == (int(it_ref), float(rn_ref)) and np.array_equal(x, g[f"chebyshev_{bs}_x"])
+    for kind, kw in (("ir", dict(relaxation=0.9)), ("chebyshev", dict(foci=(0.02, 2.0)))):
+        x, it, rn = oracle.krylov_solve(kind, rp, ci, v, rhs, x0=np.full(n, 0.5), max_iters=7, reduction=1e-30,
+                                        baseline="initial_resnorm", precond="block", **kw)
+        it_ref, rn_ref = g[f"{kind}_lim_it_rn"]
+        assert (it, rn) == (int(it_ref), float(rn_ref)) and np.array_equal(x, g[f"{kind}_lim_x"])
+
+
+def test_live_reference_stationary(oracle):
+    ref = _ref()
+    rp, ci, v = oracle.stencil_csr(2, 14, True)
+    n = len(rp) - 1
+    h = ref.CsrHandle("reference", rp, ci, v)
+    rhs = np.random.default_rng(6).uniform(-1, 1, n)
+    for bs, pre in ((0, None), (1, "scalar"), (4, "block")):
+        relax, foci = (0.2, (0.05, 8.0)) if bs == 0 else (0.8, (0.02, 2.0))
+        xo, ito, rno = oracle.krylov_solve("ir", rp, ci, v, rhs, max_iters=300, reduction=1e-5, precond=pre,
+                                           max_block_size=max(bs, 1), relaxation=relax)
+        xr, itr, rnr = h.stationary_solve("ir", rhs, max_iters=300, reduction=1e-5, precond_block_size=bs,
+                                          relaxation=relax)
+        assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
+        xo, ito, rno = oracle.krylov_solve("chebyshev", rp, ci, v, rhs, max_iters=300, reduction=1e-5,
+                                           precond=pre, max_block_size=max(bs, 1), foci=foci)
+        xr, itr, rnr = h.stationary_solve("chebyshev", rhs, max_iters=300, reduction=1e-5,
+                                          precond_block_size=bs, foci=foci)
+        assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
