@@ -148,6 +148,36 @@ namespace csr {
 FOR_VT_IT(DEF)
 #undef DEF
 
+// transpose / conj_transpose (real value types: the same operation)
+#define DEF(T, TN, I, IN)                                                                 \
+    static void transpose_impl_##TN##_##IN(exec_t exec, const matrix::Csr<T, I>* orig,    \
+                                           matrix::Csr<T, I>* trans)                      \
+    {                                                                                     \
+        const int64_t nnz = orig->get_num_stored_elements();                              \
+        array<char> work(exec, gkoc_csr_transpose_workspace_bytes(                        \
+                                   nnz, orig->get_size()[1], sizeof(I)));                 \
+        GKOC_CALL(gkoc_csr_transpose_##TN##_##IN(                                         \
+            stream_of(exec), orig->get_size()[0], orig->get_size()[1],                    \
+            orig->get_const_row_ptrs(), orig->get_const_col_idxs(),                       \
+            orig->get_const_values(), nnz, trans->get_row_ptrs(), trans->get_col_idxs(),  \
+            trans->get_values(), work.get_data(), work.get_size()));                      \
+        exec->synchronize(); /* work is released on return */                             \
+    }                                                                                     \
+    template <>                                                                           \
+    void transpose<T, I>(exec_t exec, const matrix::Csr<T, I>* orig,                      \
+                         matrix::Csr<T, I>* trans)                                        \
+    {                                                                                     \
+        transpose_impl_##TN##_##IN(exec, orig, trans);                                    \
+    }                                                                                     \
+    template <>                                                                           \
+    void conj_transpose<T, I>(exec_t exec, const matrix::Csr<T, I>* orig,                 \
+                              matrix::Csr<T, I>* trans)                                   \
+    {                                                                                     \
+        transpose_impl_##TN##_##IN(exec, orig, trans);                                    \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
 }  // namespace csr
 
 

@@ -286,6 +286,23 @@ class Csr(_SparseBase):
              num_stored_per_row, stride, cols, vals)
         return Ell(self.exec, self.size, vals, cols, num_stored_per_row, stride)
 
+    def transpose(self):
+        """Csr::transpose (core/matrix/csr.cpp, csr::transpose kernel)"""
+        ex = self.exec
+        nnz = int(self.col_idxs.numel())
+        idt = self.col_idxs.dtype
+        t_ptrs = ex.alloc((self.size[1] + 1,), idt)
+        t_cols, t_vals = ex.alloc((nnz,), idt), ex.alloc((nnz,), self.dtype)
+        f = _lib.lib().gkoc_csr_transpose_workspace_bytes
+        f.restype = C.c_size_t
+        need = f(C.c_int64(nnz), C.c_int64(self.size[1]), C.c_size_t(self.col_idxs.element_size()))
+        work = ex.alloc((int(need),), torch.uint8)
+        call("gkoc_csr_transpose_" + self._suf(), ex.stream, self.size[0], self.size[1],
+             self.row_ptrs, self.col_idxs, self.values, nnz, t_ptrs, t_cols, t_vals, work,
+             C.c_size_t(work.numel()))
+        ex.synchronize()        # `work` is released on return
+        return Csr(ex, (self.size[1], self.size[0]), t_vals, t_cols, t_ptrs)
+
     def convert_to_coo(self):
         rows = self.exec.alloc((self.col_idxs.numel(),), self.col_idxs.dtype)
         call("gkoc_convert_ptrs_to_idxs_" + IT[self.col_idxs.dtype], self.exec.stream,

@@ -633,6 +633,23 @@ GKOC_DECL_COO(double, f64, int64_t, i64)
 GKOC_DECL_COO(float, f32, int32_t, i32)
 GKOC_DECL_COO(float, f32, int64_t, i64)
 
+/* csr::transpose / conj_transpose (real types) (core/matrix/csr_kernels.hpp,
+ * GKO_DECLARE_CSR_TRANSPOSE_KERNEL; reference/matrix/csr_kernels.cpp:693-731): the
+ * transposed matrix in CSR, entries of a row ordered as the reference orders them
+ * (stable by original row, then storage order) - index arrays and values
+ * bit-identical.  work: gkoc_csr_transpose_workspace_bytes(nnz, n_cols, sizeof(I)). */
+size_t gkoc_csr_transpose_workspace_bytes(int64_t nnz, int64_t n_cols,
+                                          size_t index_size);
+#define GKOC_DECL_TRANSPOSE(T, TN, I, IN)                                      \
+    int gkoc_csr_transpose_##TN##_##IN(                                        \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const I* row_ptrs,    \
+        const I* col_idxs, const T* vals, int64_t nnz, I* t_row_ptrs,          \
+        I* t_col_idxs, T* t_vals, void* work, size_t work_bytes);
+GKOC_DECL_TRANSPOSE(double, f64, int32_t, i32)
+GKOC_DECL_TRANSPOSE(double, f64, int64_t, i64)
+GKOC_DECL_TRANSPOSE(float, f32, int32_t, i32)
+GKOC_DECL_TRANSPOSE(float, f32, int64_t, i64)
+
 /* ------------------------------------------------- other Krylov solvers
  * The fused vector updates of Bicgstab, Cgs, Fcg and PipeCg - the kernels
  * core/solver/{bicgstab,cgs,fcg,pipe_cg}.cpp issue through exec->run:

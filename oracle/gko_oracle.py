@@ -113,6 +113,17 @@ def csr_to_hybrid(row_ptrs, cols, vals, ell_lim, ell_stride=None):
     return ec, ev, crp, cr, cc, cv
 
 
+def csr_transpose(n_rows, n_cols, row_ptrs, cols, vals):
+    """csr::transpose of the reference: (t_row_ptrs, t_cols, t_vals)"""
+    trp = np.zeros(n_cols + 1, dtype=cols.dtype)
+    tc = np.full(len(vals), -7, dtype=cols.dtype)
+    tv = np.full(len(vals), np.nan, dtype=vals.dtype)
+    getattr(lib(), "oracle_csr_transpose_" + _suf(vals, cols))(
+        _i64(n_rows), _i64(n_cols), _p(np.ascontiguousarray(row_ptrs)), _p(np.ascontiguousarray(cols)),
+        _p(np.ascontiguousarray(vals)), _p(trp), _p(tc), _p(tv))
+    return trp, tc, tv
+
+
 def ell_spmv(n_rows, k, stride, cols, vals, b, alpha=None, beta=None, c=None):
     b2 = np.ascontiguousarray(_as2d(b))
     nrhs = b2.shape[1]

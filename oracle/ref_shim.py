@@ -134,6 +134,13 @@ class CsrHandle:
                                 C.c_int(base), C.byref(rn))
         return x, int(it), rn.value
 
+    def transpose(self):
+        trp = np.zeros(self.n_cols + 1, np.int32)
+        nnz = len(self._keep[2])
+        tc, tv = np.zeros(nnz, np.int32), np.zeros(nnz)
+        lib().ref_csr_transpose(self.h, _p(trp), _p(tc), _p(tv))
+        return trp, tc, tv
+
     def to_hybrid(self, ell_lim):
         """Csr -> Hybrid(column_limit(ell_lim)); (ell_k, ell_stride, ell_cols, ell_vals,
         coo_rows, coo_cols, coo_vals)"""

@@ -19,6 +19,7 @@
 #include <ginkgo/core/matrix/hybrid.hpp>
 #include <ginkgo/core/matrix/dense.hpp>
 #include <ginkgo/core/matrix/ell.hpp>
+#include <ginkgo/core/matrix/fbcsr.hpp>
 #include <ginkgo/core/matrix/sellp.hpp>
 #include <ginkgo/core/preconditioner/jacobi.hpp>
 #include <ginkgo/core/solver/bicgstab.hpp>
@@ -328,11 +329,24 @@ int main(int argc, char** argv)
     {
         bool threw = false;
         try {
-            auto t = gko::as<Csr>(a_hip->transpose());
+            auto f = gko::matrix::Fbcsr<vt, it>::create(hip, 2);
+            a_hip->convert_to(f);
         } catch (const gko::NotCompiled&) {
             threw = true;
         }
-        CHECK(threw, "out-of-scope kernel (csr::transpose) reports gko::NotCompiled");
+        CHECK(threw, "out-of-scope kernel (csr::convert_to_fbcsr) reports gko::NotCompiled");
+    }
+    // --- Csr::transpose on the device (stable sort by column)
+    {
+        auto t_ref = gko::as<Csr>(a_ref->transpose());
+        auto t_hip = gko::clone(ref, gko::as<Csr>(a_hip->transpose()));
+        bool same = t_ref->get_num_stored_elements() == t_hip->get_num_stored_elements();
+        for (gko::size_type k = 0; same && k < t_ref->get_num_stored_elements(); ++k)
+            same = t_ref->get_const_col_idxs()[k] == t_hip->get_const_col_idxs()[k] &&
+                   t_ref->get_const_values()[k] == t_hip->get_const_values()[k];
+        for (gko::size_type r = 0; same && r <= t_ref->get_size()[0]; ++r)
+            same = t_ref->get_const_row_ptrs()[r] == t_hip->get_const_row_ptrs()[r];
+        CHECK(same, "Csr::transpose on hip identical to reference");
     }
     std::cout << (failures == 0 ? "DROPIN OK" : "DROPIN FAILED") << std::endl;
     return failures == 0 ? 0 : 1;

@@ -134,3 +134,37 @@ def test_27pt_full_formats_agree(gexec, oracle):
     a.convert_to_hybrid(column_limit=18).apply(x, y2)
     assert np.array_equal(y0.to_numpy(), y1.to_numpy())
     assert np.array_equal(y0.to_numpy(), y2.to_numpy())
+
+
+@pytest.mark.parametrize("dtype,itype", [(np.float64, np.int32), (np.float64, np.int64), (np.float32, np.int32)])
+def test_transpose(gexec, oracle, dtype, itype):
+    """csr::transpose: the reference's result is the stable sort of the entries by column;
+    index arrays and values bit-exact, incl. unsorted / duplicate columns inside a row,
+    empty rows and columns, rectangular shapes"""
+    import ginkgo_amd as g
+    for n_rows, n_cols, dens, seed in ((532, 231, 0.03, 1), (3, 4000, 0.2, 2), (4000, 3, 0.4, 3),
+                                       (50, 50, 0.0, 4), (1000, 1000, 0.01, 5)):
+        rp, ci, v = random_csr(n_rows, n_cols, dens, seed=seed)
+        rng = np.random.default_rng(seed)
+        ci = ci.copy()
+        for r in range(0, n_rows, 3):                 # unsorted and duplicated columns
+            seg = slice(rp[r], rp[r + 1])
+            if rp[r + 1] - rp[r] > 1:
+                ci[seg] = rng.permutation(ci[seg])
+                ci[rp[r]] = ci[rp[r] + 1]
+        rp, ci, v = rp.astype(itype), ci.astype(itype), v.astype(dtype)
+        a = g.Csr.from_arrays(gexec, (n_rows, n_cols), rp, ci, v)
+        t = a.transpose()
+        trp, tc, tv = oracle.csr_transpose(n_rows, n_cols, rp, ci, v)
+        assert t.size == (n_cols, n_rows)
+        assert np.array_equal(t.row_ptrs.cpu().numpy(), trp)
+        assert np.array_equal(t.col_idxs.cpu().numpy(), tc)
+        assert np.array_equal(t.values.cpu().numpy(), tv)
+    # 27-pt Laplacian is symmetric: A^T x and A x agree bit for bit (same entries per row,
+    # same order since columns are sorted)
+    a = g.stencil_csr(gexec, 3, 40)
+    x = g.Dense.from_numpy(gexec, np.random.default_rng(0).uniform(-1, 1, 40 ** 3))
+    y0, y1 = g.Dense.create(gexec, (40 ** 3, 1)), g.Dense.create(gexec, (40 ** 3, 1))
+    a.apply(x, y0)
+    a.transpose().apply(x, y1)
+    assert np.array_equal(y0.to_numpy(), y1.to_numpy())

@@ -506,3 +506,24 @@ def test_live_reference_stationary(oracle):
         xr, itr, rnr = h.stationary_solve("chebyshev", rhs, max_iters=300, reduction=1e-5,
                                           precond_block_size=bs, foci=foci)
         assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
+
+
+def test_live_reference_transpose(oracle):
+    ref = _ref()
+    for nr, nc, d, seed in ((60, 45, 0.2, 3), (5, 300, 0.1, 4), (200, 3, 0.5, 5), (40, 40, 0.0, 6)):
+        rp, ci, v = random_csr(nr, nc, d, seed=seed)
+        h = ref.CsrHandle("reference", rp, ci, v, n_cols=nc)
+        for got, want in zip(oracle.csr_transpose(nr, nc, rp, ci, v), h.transpose()):
+            assert np.array_equal(got, want)
+
+
+def test_transpose_known_answer(oracle):
+    """reference/test/matrix/csr_kernels.cpp:1612-1632 (SquareMtxIsTransposable)"""
+    rp = np.array([0, 3, 4, 6], np.int32)
+    ci = np.array([0, 1, 2, 1, 1, 2], np.int32)
+    v = np.array([1.0, 3.0, 2.0, 5.0, 1.5, 2.0])
+    trp, tc, tv = oracle.csr_transpose(3, 3, rp, ci, v)
+    dense = np.zeros((3, 3))
+    for r in range(3):
+        dense[r, tc[trp[r]:trp[r + 1]]] = tv[trp[r]:trp[r + 1]]
+    assert np.array_equal(dense, [[1.0, 0.0, 0.0], [3.0, 5.0, 1.5], [2.0, 0.0, 2.0]])
