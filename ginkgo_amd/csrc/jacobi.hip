@@ -367,7 +367,92 @@ __global__ __launch_bounds__(256) void jacobi_apply_kernel(
 // value are requested before the first use; b[start + c] then comes from lane
 // (block, c) through ds_bpermute instead of BO more gathers.  Accumulation
 // order and rounding are those of the generic kernel (reference apply_block).
-template <typename T, typename I, bool ADV, int BO, int GPW, bool DOT = false>
+// ---- reduced-precision block storage (adaptive block-Jacobi with a fixed
+// storage_optimization; include/ginkgo/core/preconditioner/jacobi.hpp, the types of
+// core/preconditioner/jacobi_utils.hpp:15-37 for ValueType = double).  The stored
+// blocks are widened to double on load and the product runs in double, exactly like
+// reference apply_block with its default_converter.  PREC = the precision_reduction
+// byte (preserving << 4 | nonpreserving):
+//   0x01 float (round to nearest)            0x02 half (via float, round to nearest
+//   0x10 upper 32 bits of the double              even; values below the smallest
+//   0x11 upper 16 bits of the float               normal half become signed zero,
+//   0x20 upper 16 bits of the double              like gko::half, half.hpp:405-433)
+// A group keeps its place (group_offset is in doubles); its reduced entries sit at
+// the same element index of the narrower type, i.e. in the first part of the group.
+template <int PREC>
+struct stored;
+template <>
+struct stored<0x01> {
+    using type = float;
+    __device__ static double load(type v) { return double(v); }
+    __device__ static type store(double v) { return float(v); }
+};
+template <>
+struct stored<0x10> {
+    using type = uint32_t;
+    __device__ static double load(type v) { return __longlong_as_double((long long)(uint64_t(v) << 32)); }
+    __device__ static type store(double v) { return uint32_t(uint64_t(__double_as_longlong(v)) >> 32); }
+};
+template <>
+struct stored<0x20> {
+    using type = uint16_t;
+    __device__ static double load(type v) { return __longlong_as_double((long long)(uint64_t(v) << 48)); }
+    __device__ static type store(double v) { return uint16_t(uint64_t(__double_as_longlong(v)) >> 48); }
+};
+template <>
+struct stored<0x11> {
+    using type = uint16_t;
+    __device__ static double load(type v) { return double(__uint_as_float(uint32_t(v) << 16)); }
+    __device__ static type store(double v) { return uint16_t(__float_as_uint(float(v)) >> 16); }
+};
+template <>
+struct stored<0x02> {
+    using type = uint16_t;
+    __device__ static double load(type h)
+    {
+        // the hardware conversion, except that subnormal halves read as signed zero
+        // (gko::half does not decode them, half.hpp:444-446)
+        _Float16 hv;
+        __builtin_memcpy(&hv, &h, 2);
+        const float f = (h & 0x7c00u) == 0 ? __uint_as_float(uint32_t(h & 0x8000u) << 16) : float(hv);
+        return double(f);
+    }
+    __device__ static type store(double v)
+    {
+        const uint32_t f = __float_as_uint(float(v));
+        const uint16_t sign = uint16_t((f >> 16) & 0x8000u);
+        const uint32_t e = (f >> 23) & 0xffu, m = f & 0x007fffffu;
+        if (e == 0xffu) return uint16_t(sign | 0x7c00u | (m ? 0x03ffu : 0u));
+        if (e <= 112u) return sign;                      // below the normal half range
+        if (e - 112u >= 31u) return uint16_t(sign | 0x7c00u);
+        const uint16_t res = uint16_t(sign | ((e - 112u) << 10) | (m >> 13));
+        const uint32_t tail = m & 0x1fffu;
+        return uint16_t(res + ((tail > 0x1000u || (tail == 0x1000u && (res & 1u))) ? 1u : 0u));
+    }
+};
+
+// in place: the group's double entries become PREC entries at the same element index
+template <int PREC, int BO>
+__global__ __launch_bounds__(64) void jacobi_convert_storage_kernel(int64_t num_groups,
+                                                                    int64_t group_offset,
+                                                                    double* blocks)
+{
+    using S = typename stored<PREC>::type;
+    const int64_t group = blockIdx.x;
+    if (group >= num_groups) return;
+    double* gp = blocks + group_offset * group;
+    double v[BO];
+#pragma unroll
+    for (int c = 0; c < BO; ++c) v[c] = gp[c * 64 + threadIdx.x];
+    // every lane has its loads back before any narrow entry is written
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    S* sp = reinterpret_cast<S*>(gp);
+#pragma unroll
+    for (int c = 0; c < BO; ++c) sp[c * 64 + threadIdx.x] = stored<PREC>::store(v[c]);
+}
+
+template <typename T, typename I, bool ADV, int BO, int GPW, bool DOT = false, int PREC = 0>
 __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
     int64_t num_blocks, int64_t num_groups, int64_t group_offset,
     const I* __restrict__ block_ptrs, const T* __restrict__ blocks,
@@ -416,8 +501,15 @@ __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
         if (bs[g] > 0) {
             bv[g] = b[row[g]];
             if (ADV) xv[g] = x[row[g]];
+            if constexpr (PREC == 0) {
 #pragma unroll
-            for (int c = 0; c < BO; ++c) m[g][c] = gp[c * 64];
+                for (int c = 0; c < BO; ++c) m[g][c] = gp[c * 64];
+            } else {
+                using S = typename stored<PREC>::type;
+                const S* sp = reinterpret_cast<const S*>(blocks + group_offset * (group0 + g)) + lane;
+#pragma unroll
+                for (int c = 0; c < BO; ++c) m[g][c] = T(stored<PREC>::load(sp[c * 64]));
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < BO; ++c) m[g][c] = T(0);
@@ -552,6 +644,103 @@ int launch_apply(gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
     return GKOC_OK;
 }
 
+template <typename I, bool ADV, int BO, int PREC>
+void launch_apply_stored_fixed(gkoc_stream_t s, int64_t num_blocks, int64_t groups,
+                               int64_t group_offset, const I* block_ptrs, const double* blocks,
+                               const double* alpha, const double* b, const double* beta, double* x)
+{
+    constexpr int GPW = 2;
+    jacobi_apply_fixed_kernel<double, I, ADV, BO, GPW, false, PREC>
+        <<<dim3(unsigned(ceildiv(groups, 4 * GPW))), dim3(256), 0, as_stream(s)>>>(
+            num_blocks, groups, group_offset, block_ptrs, blocks, alpha, b, beta, x);
+}
+
+inline bool known_precision(int prec)
+{
+    return prec == 0x01 || prec == 0x02 || prec == 0x10 || prec == 0x11 || prec == 0x20;
+}
+
+#define GKOC_FOR_PREC(M, ...)                 \
+    switch (prec) {                           \
+    case 0x01: M(0x01, __VA_ARGS__); break;   \
+    case 0x02: M(0x02, __VA_ARGS__); break;   \
+    case 0x10: M(0x10, __VA_ARGS__); break;   \
+    case 0x11: M(0x11, __VA_ARGS__); break;   \
+    default: M(0x20, __VA_ARGS__); break;     \
+    }
+
+template <typename I, bool ADV>
+int launch_apply_stored(gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
+                        gkoc_jacobi_scheme scheme, const I* block_ptrs, const double* blocks,
+                        int prec, const double* alpha, const double* b, int64_t ldb,
+                        const double* beta, double* x, int64_t ldx, int64_t nrhs)
+{
+    if (prec == 0) {
+        return launch_apply<double, I, ADV>(s, num_blocks, max_bs, scheme, block_ptrs, blocks,
+                                            alpha, b, ldb, beta, x, ldx, nrhs);
+    }
+    if (num_blocks <= 0 || nrhs <= 0) return GKOC_OK;
+    GKOC_REQUIRE(known_precision(prec), GKOC_E_NOT_SUPPORTED, "unknown storage precision");
+    GKOC_REQUIRE(block_ptrs && blocks && b && x, GKOC_E_INVALID, "null pointer");
+    const int64_t bo = scheme.block_offset;
+    GKOC_REQUIRE(bo >= 1 && bo <= 16 && (bo & (bo - 1)) == 0 && (bo << scheme.group_power) == 64,
+                 GKOC_E_NOT_SUPPORTED,
+                 "reduced-precision storage needs block_offset in {1,2,4,8,16}, 64-wide groups");
+    GKOC_REQUIRE(max_bs <= uint64_t(bo), GKOC_E_INVALID, "max_block_size exceeds block_offset");
+    const int64_t groups = ceildiv(num_blocks, int64_t(1) << scheme.group_power);
+    const int64_t go = scheme.group_offset;
+    // one right-hand side per launch (reference: one apply_block per column as well)
+    for (int64_t j = 0; j < nrhs; ++j) {
+        GKOC_REQUIRE(ldb == 1 && ldx == 1, GKOC_E_NOT_SUPPORTED,
+                     "reduced-precision storage: one right-hand side with unit strides");
+#define GKOC_JAC_ST(PREC_, BO_)                                                                 \
+    launch_apply_stored_fixed<I, ADV, BO_, PREC_>(s, num_blocks, groups, go, block_ptrs, blocks, \
+                                                  alpha, b + j, beta, x + j)
+#define GKOC_JAC_ST_BO(PREC_, dummy)            \
+    switch (int(bo)) {                          \
+    case 1: GKOC_JAC_ST(PREC_, 1); break;       \
+    case 2: GKOC_JAC_ST(PREC_, 2); break;       \
+    case 4: GKOC_JAC_ST(PREC_, 4); break;       \
+    case 8: GKOC_JAC_ST(PREC_, 8); break;       \
+    default: GKOC_JAC_ST(PREC_, 16); break;     \
+    }
+        GKOC_FOR_PREC(GKOC_JAC_ST_BO, 0)
+#undef GKOC_JAC_ST_BO
+#undef GKOC_JAC_ST
+        GKOC_LAUNCH_OK();
+    }
+    return GKOC_OK;
+}
+
+int launch_convert_storage(gkoc_stream_t s, int64_t num_blocks, gkoc_jacobi_scheme scheme,
+                           double* blocks, int prec)
+{
+    if (prec == 0 || num_blocks <= 0) return GKOC_OK;
+    GKOC_REQUIRE(known_precision(prec), GKOC_E_NOT_SUPPORTED, "unknown storage precision");
+    GKOC_REQUIRE(blocks, GKOC_E_INVALID, "null pointer");
+    const int64_t bo = scheme.block_offset;
+    GKOC_REQUIRE(bo >= 1 && bo <= 16 && (bo & (bo - 1)) == 0 && (bo << scheme.group_power) == 64,
+                 GKOC_E_NOT_SUPPORTED,
+                 "reduced-precision storage needs block_offset in {1,2,4,8,16}, 64-wide groups");
+    const int64_t groups = ceildiv(num_blocks, int64_t(1) << scheme.group_power);
+#define GKOC_JAC_CV(PREC_, BO_)                                                        \
+    jacobi_convert_storage_kernel<PREC_, BO_>                                          \
+        <<<dim3(unsigned(groups)), dim3(64), 0, as_stream(s)>>>(groups, scheme.group_offset, blocks)
+#define GKOC_JAC_CV_BO(PREC_, dummy)            \
+    switch (int(bo)) {                          \
+    case 1: GKOC_JAC_CV(PREC_, 1); break;       \
+    case 2: GKOC_JAC_CV(PREC_, 2); break;       \
+    case 4: GKOC_JAC_CV(PREC_, 4); break;       \
+    case 8: GKOC_JAC_CV(PREC_, 8); break;       \
+    default: GKOC_JAC_CV(PREC_, 16); break;     \
+    }
+    GKOC_FOR_PREC(GKOC_JAC_CV_BO, 0)
+#undef GKOC_JAC_CV_BO
+#undef GKOC_JAC_CV
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
 template <typename T, typename I>
 int launch_generate(gkoc_stream_t s, const I* row_ptrs, const I* cols,
                     const T* vals, int64_t num_blocks, uint32_t max_bs,
@@ -630,6 +819,64 @@ using namespace gkoc;
                                         block_ptrs, blocks, alpha, b, ldb,     \
                                         beta, x, ldx, nrhs);                   \
     }
+
+namespace gkoc {
+namespace {
+__global__ void tile_bytes_kernel(int64_t n, const uint8_t* __restrict__ src, int64_t src_n,
+                                  uint8_t* __restrict__ dst)
+{
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+        dst[i] = src[i % src_n];
+    }
+}
+}  // namespace
+}  // namespace gkoc
+
+// jacobi::initialize_precisions (reference/preconditioner/jacobi_kernels.cpp:454-462)
+extern "C" int gkoc_jacobi_initialize_precisions(gkoc_stream_t s, const uint8_t* source,
+                                                 int64_t source_size, uint8_t* precisions,
+                                                 int64_t n)
+{
+    GKOC_REQUIRE(n >= 0 && source_size >= 0, GKOC_E_INVALID, "negative size");
+    if (n == 0) return GKOC_OK;
+    GKOC_REQUIRE(source && precisions && source_size > 0, GKOC_E_INVALID, "bad argument");
+    int64_t nb = ceildiv(n, 256);
+    if (nb > max_stream_blocks) nb = max_stream_blocks;
+    tile_bytes_kernel<<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(n, source, source_size,
+                                                                         precisions);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+// reduced-precision storage: value type double only
+extern "C" int gkoc_jacobi_convert_storage_f64(gkoc_stream_t s, int64_t num_blocks,
+                                               gkoc_jacobi_scheme scheme, double* blocks,
+                                               uint8_t precision)
+{
+    return launch_convert_storage(s, num_blocks, scheme, blocks, int(precision));
+}
+
+#define GKOC_DEF_JACOBI_STORED(I, IN)                                                        \
+    extern "C" int gkoc_jacobi_apply_stored_f64_##IN(                                        \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,                        \
+        gkoc_jacobi_scheme scheme, const I* block_ptrs, const double* blocks,                \
+        uint8_t precision, const double* alpha, const double* b, int64_t ldb,                \
+        const double* beta, double* x, int64_t ldx, int64_t nrhs)                            \
+    {                                                                                        \
+        GKOC_REQUIRE((alpha == nullptr) == (beta == nullptr), GKOC_E_INVALID,                \
+                     "pass alpha and beta, or neither");                                     \
+        if (alpha) {                                                                         \
+            return launch_apply_stored<I, true>(s, num_blocks, max_block_size, scheme,       \
+                                                block_ptrs, blocks, int(precision), alpha,   \
+                                                b, ldb, beta, x, ldx, nrhs);                 \
+        }                                                                                    \
+        return launch_apply_stored<I, false>(s, num_blocks, max_block_size, scheme,          \
+                                             block_ptrs, blocks, int(precision), nullptr, b, \
+                                             ldb, nullptr, x, ldx, nrhs);                    \
+    }
+GKOC_DEF_JACOBI_STORED(int32_t, i32)
+GKOC_DEF_JACOBI_STORED(int64_t, i64)
 
 GKOC_DEF_JACOBI(double, f64, int32_t, i32)
 GKOC_DEF_JACOBI(double, f64, int64_t, i64)

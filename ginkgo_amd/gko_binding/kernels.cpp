@@ -624,14 +624,61 @@ inline gkoc_jacobi_scheme scheme_of(
             static_cast<int64_t>(s.group_offset), s.group_power};
 }
 
-inline void require_full_precision(const array<precision_reduction>& prec)
+// The storage precision of the blocks: 0 when no precisions are attached; the common
+// value when Jacobi was built with a fixed storage_optimization (core fills the array
+// with it); autodetect (a per-block choice from condition numbers) is not supported.
+template <typename T>
+inline uint8 stored_precision(exec_t exec, const array<precision_reduction>& prec)
 {
-    // adaptive-precision storage is outside the hot path
-    if (prec.get_const_data() != nullptr) {
+    if (prec.get_const_data() == nullptr || prec.get_size() == 0) {
+        return 0;
+    }
+    const auto first = static_cast<uint8>(
+        exec->copy_val_to_host(reinterpret_cast<const uint8*>(prec.get_const_data())));
+    if (first == static_cast<uint8>(precision_reduction::autodetect())) {
         throw ::gko::NotSupported(
             __FILE__, __LINE__, "jacobi",
-            "adaptive-precision block-Jacobi is not supported by gko-cdna4");
+            "block-Jacobi storage_optimization autodetect is not supported by gko-cdna4");
     }
+    if (first != 0 && !std::is_same<T, double>::value) {
+        throw ::gko::NotSupported(__FILE__, __LINE__, "jacobi",
+                                  "reduced block storage is implemented for double only");
+    }
+    return first;
+}
+
+void initialize_precisions(exec_t exec, const array<precision_reduction>& source,
+                           array<precision_reduction>& precisions)
+{
+    GKOC_CALL(gkoc_jacobi_initialize_precisions(
+        stream_of(exec), reinterpret_cast<const uint8_t*>(source.get_const_data()),
+        static_cast<int64_t>(source.get_size()),
+        reinterpret_cast<uint8_t*>(precisions.get_data()),
+        static_cast<int64_t>(precisions.get_size())));
+}
+
+template <typename I>
+inline int apply_stored(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jacobi_scheme sc,
+                        const I* ptrs, const double* blocks, uint8 prec, const double* alpha,
+                        const double* b, int64_t ldb, const double* beta, double* x, int64_t ldx,
+                        int64_t nrhs);
+template <>
+inline int apply_stored<int32>(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jacobi_scheme sc,
+                               const int32* ptrs, const double* blocks, uint8 prec,
+                               const double* alpha, const double* b, int64_t ldb,
+                               const double* beta, double* x, int64_t ldx, int64_t nrhs)
+{
+    return gkoc_jacobi_apply_stored_f64_i32(s, nb, mbs, sc, ptrs, blocks, prec, alpha, b, ldb, beta,
+                                            x, ldx, nrhs);
+}
+template <>
+inline int apply_stored<int64>(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jacobi_scheme sc,
+                               const int64* ptrs, const double* blocks, uint8 prec,
+                               const double* alpha, const double* b, int64_t ldb,
+                               const double* beta, double* x, int64_t ldx, int64_t nrhs)
+{
+    return gkoc_jacobi_apply_stored_f64_i64(s, nb, mbs, sc, ptrs, blocks, prec, alpha, b, ldb, beta,
+                                            x, ldx, nrhs);
 }
 
 #define DEF(T, TN, I, IN)                                                       \
@@ -657,7 +704,7 @@ inline void require_full_precision(const array<precision_reduction>& prec)
         array<T>& conditioning, array<precision_reduction>& block_precisions,   \
         const array<I>& block_pointers, array<T>& blocks)                       \
     {                                                                           \
-        require_full_precision(block_precisions);                               \
+        const uint8 prec = stored_precision<T>(exec, block_precisions);         \
         GKOC_CALL(gkoc_jacobi_generate_##TN##_##IN(                             \
             stream_of(exec), system_matrix->get_size()[0],                      \
             system_matrix->get_const_row_ptrs(),                                \
@@ -665,6 +712,11 @@ inline void require_full_precision(const array<precision_reduction>& prec)
             system_matrix->get_const_values(), num_blocks, max_block_size,      \
             scheme_of(storage_scheme), block_pointers.get_const_data(),         \
             blocks.get_data(), nullptr));                                       \
+        if (prec != 0) {                                                        \
+            GKOC_CALL(gkoc_jacobi_convert_storage_f64(                          \
+                stream_of(exec), num_blocks, scheme_of(storage_scheme),         \
+                reinterpret_cast<double*>(blocks.get_data()), prec));           \
+        }                                                                       \
     }                                                                           \
     template <>                                                                 \
     void simple_apply<T, I>(                                                    \
@@ -675,7 +727,17 @@ inline void require_full_precision(const array<precision_reduction>& prec)
         const array<I>& block_pointers, const array<T>& blocks,                 \
         const matrix::Dense<T>* b, matrix::Dense<T>* x)                         \
     {                                                                           \
-        require_full_precision(block_precisions);                               \
+        const uint8 prec = stored_precision<T>(exec, block_precisions);         \
+        if (prec != 0) {                                                        \
+            GKOC_CALL(apply_stored<I>(                                          \
+                stream_of(exec), num_blocks, max_block_size,                    \
+                scheme_of(storage_scheme), block_pointers.get_const_data(),     \
+                reinterpret_cast<const double*>(blocks.get_const_data()), prec, \
+                nullptr, reinterpret_cast<const double*>(b->get_const_values()), \
+                ld(b), nullptr, reinterpret_cast<double*>(x->get_values()),     \
+                ld(x), cols(b)));                                               \
+            return;                                                             \
+        }                                                                       \
         GKOC_CALL(gkoc_jacobi_simple_apply_##TN##_##IN(                         \
             stream_of(exec), num_blocks, max_block_size,                        \
             scheme_of(storage_scheme), block_pointers.get_const_data(),         \
@@ -692,7 +754,18 @@ inline void require_full_precision(const array<precision_reduction>& prec)
         const matrix::Dense<T>* alpha, const matrix::Dense<T>* b,               \
         const matrix::Dense<T>* beta, matrix::Dense<T>* x)                      \
     {                                                                           \
-        require_full_precision(block_precisions);                               \
+        const uint8 prec = stored_precision<T>(exec, block_precisions);         \
+        if (prec != 0) {                                                        \
+            GKOC_CALL(apply_stored<I>(                                          \
+                stream_of(exec), num_blocks, max_block_size,                    \
+                scheme_of(storage_scheme), block_pointers.get_const_data(),     \
+                reinterpret_cast<const double*>(blocks.get_const_data()), prec, \
+                reinterpret_cast<const double*>(alpha->get_const_values()),     \
+                reinterpret_cast<const double*>(b->get_const_values()), ld(b),  \
+                reinterpret_cast<const double*>(beta->get_const_values()),      \
+                reinterpret_cast<double*>(x->get_values()), ld(x), cols(b)));   \
+            return;                                                             \
+        }                                                                       \
         GKOC_CALL(gkoc_jacobi_apply_##TN##_##IN(                                \
             stream_of(exec), num_blocks, max_block_size,                        \
             scheme_of(storage_scheme), block_pointers.get_const_data(),         \

@@ -36,6 +36,7 @@ class JacobiFactory:
         self.max_block_size = 32
         self.skip_sorting = False
         self.block_pointers = None
+        self.storage_precision = 0
         self.exec = None
 
     def with_max_block_size(self, v):
@@ -50,8 +51,21 @@ class JacobiFactory:
         self.block_pointers = ptrs
         return self
 
-    def with_storage_optimization(self, *_):
-        raise NotSupported("adaptive-precision block-Jacobi is not supported")
+    def with_storage_optimization(self, preserving, nonpreserving=None):
+        """precision_reduction(preserving, nonpreserving) for every block (jacobi.hpp,
+        storage_optimization): (0,1) float, (0,2) half, (1,0) / (2,0) upper 32 / 16 bits
+        of the double, (1,1) upper 16 bits of the float, (0,0) full precision.
+        precision_reduction::autodetect() (per-block choice from condition numbers) is
+        not supported."""
+        if nonpreserving is None:
+            if preserving in ("autodetect", "auto"):
+                raise NotSupported("block-Jacobi: storage_optimization autodetect is not supported")
+            preserving, nonpreserving = preserving
+        self.storage_precision = (int(preserving) << 4) | int(nonpreserving)
+        if self.storage_precision not in (0x00, 0x01, 0x02, 0x10, 0x11, 0x20):
+            raise NotSupported(f"block-Jacobi: no storage type for precision_reduction"
+                               f"({preserving}, {nonpreserving})")
+        return self
 
     def on(self, exec_):
         self.exec = exec_
@@ -76,6 +90,11 @@ class Jacobi(LinOp):
         ex = self.exec
         self.max_block_size = factory.max_block_size
         self.dtype = a.dtype
+        self.storage_precision = factory.storage_precision
+        if self.storage_precision and (a.dtype != torch.float64
+                                       or self.max_block_size not in (2, 4, 8, 16)):
+            raise NotSupported("block-Jacobi: reduced storage precision needs fp64 values and "
+                               "max_block_size in {2, 4, 8, 16} (64-wide storage groups)")
         self._suf = f"{VT[a.dtype]}_{IT[a.col_idxs.dtype]}"
         n = a.size[0]
         if not factory.skip_sorting and not a.is_sorted_by_column_index():
@@ -109,6 +128,16 @@ class Jacobi(LinOp):
              a.col_idxs, a.values, self.num_blocks,
              C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
              self.blocks, None)
+        if self.storage_precision:
+            call("gkoc_jacobi_convert_storage_f64", ex.stream, self.num_blocks, self.scheme,
+                 self.blocks, C.c_uint8(self.storage_precision))
+
+    def _apply_stored(self, alpha, b, beta, x):
+        call("gkoc_jacobi_apply_stored_f64_" + IT[self.block_pointers.dtype], self.exec.stream,
+             self.num_blocks, C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
+             self.blocks, C.c_uint8(self.storage_precision),
+             None if alpha is None else alpha.values, b.values, b.ld,
+             None if beta is None else beta.values, x.values, x.ld, b.size[1])
 
     def get_num_blocks(self):
         return self.num_blocks
@@ -120,6 +149,8 @@ class Jacobi(LinOp):
                  self.size[0], b.size[1], self.inv_diag, b.values, b.ld,
                  x.values, x.ld)
             return
+        if self.storage_precision:
+            return self._apply_stored(None, b, None, x)
         call("gkoc_jacobi_simple_apply_" + self._suf, ex.stream,
              self.num_blocks, C.c_uint32(self.max_block_size), self.scheme,
              self.block_pointers, self.blocks, b.values, b.ld, x.values, x.ld,
@@ -129,7 +160,7 @@ class Jacobi(LinOp):
         """x = M b together with <b, x> (gkoc_x_jacobi_simple_apply_dot_*): block
         storage with a power-of-two block_offset <= 16 and 64-wide groups, one
         right-hand side, unit stride"""
-        if self.max_block_size == 1 or b.size[1] != 1 or b.ld != 1:
+        if self.max_block_size == 1 or b.size[1] != 1 or b.ld != 1 or self.storage_precision:
             return False
         bo = self.scheme.block_offset
         return bo <= 16 and (bo & (bo - 1)) == 0 and (bo << self.scheme.group_power) == 64
@@ -147,6 +178,8 @@ class Jacobi(LinOp):
                  self.size[0], b.size[1], self.inv_diag, alpha.values, b.values,
                  b.ld, beta.values, x.values, x.ld)
             return
+        if self.storage_precision:
+            return self._apply_stored(alpha, b, beta, x)
         call("gkoc_jacobi_apply_" + self._suf, ex.stream, self.num_blocks,
              C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
              self.blocks, alpha.values, b.values, b.ld, beta.values, x.values,

@@ -445,6 +445,37 @@ GKOC_DECL_JACOBI(double, f64, int64_t, i64)
 GKOC_DECL_JACOBI(float, f32, int32_t, i32)
 GKOC_DECL_JACOBI(float, f32, int64_t, i64)
 
+/* Block-Jacobi with a fixed reduced storage precision (Jacobi::storage_optimization
+ * other than autodetect; include/ginkgo/core/preconditioner/jacobi.hpp, storage types
+ * of core/preconditioner/jacobi_utils.hpp:15-37), value type double.  `precision` is
+ * the precision_reduction byte (preserving << 4 | nonpreserving): 0x01 float,
+ * 0x02 half, 0x10 / 0x20 upper 32 / 16 bits of the double, 0x11 upper 16 bits of the
+ * float, 0 = full precision.  gkoc_jacobi_convert_storage narrows, in place, the
+ * blocks gkoc_jacobi_generate produced (the reference converts while it stores,
+ * reference/preconditioner/jacobi_kernels.cpp:393-408: same values); apply_stored
+ * widens each entry on load and multiplies in double (apply_block with its
+ * default_converter, :413-470).  alpha = beta = NULL: x = M b, else
+ * x = alpha M b + beta x.  Bit-identical to the reference.  Layouts with 64-wide
+ * groups (max_block_size <= 16), one right-hand side, unit strides. */
+/* jacobi::initialize_precisions (core/preconditioner/jacobi_kernels.hpp:120-123):
+ * precisions[i] = source[i % source_size], one precision_reduction byte per block */
+int gkoc_jacobi_initialize_precisions(gkoc_stream_t s, const uint8_t* source,
+                                      int64_t source_size, uint8_t* precisions,
+                                      int64_t n);
+int gkoc_jacobi_convert_storage_f64(gkoc_stream_t s, int64_t num_blocks,
+                                    gkoc_jacobi_scheme scheme, double* blocks,
+                                    uint8_t precision);
+int gkoc_jacobi_apply_stored_f64_i32(
+    gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,
+    gkoc_jacobi_scheme scheme, const int32_t* block_ptrs, const double* blocks,
+    uint8_t precision, const double* alpha, const double* b, int64_t ldb,
+    const double* beta, double* x, int64_t ldx, int64_t nrhs);
+int gkoc_jacobi_apply_stored_f64_i64(
+    gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,
+    gkoc_jacobi_scheme scheme, const int64_t* block_ptrs, const double* blocks,
+    uint8_t precision, const double* alpha, const double* b, int64_t ldb,
+    const double* beta, double* x, int64_t ldx, int64_t nrhs);
+
 #define GKOC_DECL_JACOBI_SCALAR(T, TN)                                         \
     /* inv_diag[i] = 1 / diag[i] */                                            \
     int gkoc_jacobi_invert_diagonal_##TN(gkoc_stream_t s, int64_t n,           \

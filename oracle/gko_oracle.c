@@ -274,6 +274,149 @@ int64_t oracle_stencil_csr_i32(int nd, int64_t g, int restricted,
     return count;
 }
 
+/* ---- block-Jacobi with a fixed reduced storage precision, value type double --------
+ * Storage types of core/preconditioner/jacobi_utils.hpp:15-37; conversions of
+ * include/ginkgo/core/base/half.hpp:405-450 (half: via float, round to nearest even,
+ * exponents below the normal half range give signed zero, above give infinity) and
+ * core/base/extended_float.hpp:52-104 (truncated<>: the upper bits of the float /
+ * double).  prec = precision_reduction byte (preserving << 4 | nonpreserving). */
+static uint16_t oracle_float_to_half(float v)
+{
+    uint32_t f;
+    memcpy(&f, &v, 4);
+    const uint16_t sign = (uint16_t)((f >> 16) & 0x8000u);
+    const uint32_t e = (f >> 23) & 0xffu, m = f & 0x007fffffu;
+    if (e == 0xffu) return (uint16_t)(sign | 0x7c00u | (m ? 0x03ffu : 0u));
+    if (e <= 112u) return sign;
+    if (e - 112u >= 31u) return (uint16_t)(sign | 0x7c00u);
+    const uint16_t res = (uint16_t)(sign | ((e - 112u) << 10) | (m >> 13));
+    const uint32_t tail = m & 0x1fffu;
+    return (uint16_t)(res + ((tail > 0x1000u || (tail == 0x1000u && (res & 1u))) ? 1u : 0u));
+}
+
+static float oracle_half_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t bits;
+    if (e == 0x1fu) {
+        bits = sign | 0x7f800000u | (m ? 0x007fffffu : 0u);
+    } else if (e == 0) {
+        bits = sign;
+    } else {
+        bits = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float out;
+    memcpy(&out, &bits, 4);
+    return out;
+}
+
+static int oracle_prec_bytes(int prec)
+{
+    return prec == 0x01 || prec == 0x10 ? 4 : (prec == 0 ? 8 : 2);
+}
+
+static void oracle_store_reduced(int prec, void* base, int64_t idx, double v)
+{
+    uint64_t d;
+    uint32_t f;
+    const float vf = (float)v;
+    memcpy(&d, &v, 8);
+    memcpy(&f, &vf, 4);
+    switch (prec) {
+    case 0x01: ((float*)base)[idx] = vf; break;
+    case 0x02: ((uint16_t*)base)[idx] = oracle_float_to_half(vf); break;
+    case 0x10: ((uint32_t*)base)[idx] = (uint32_t)(d >> 32); break;
+    case 0x11: ((uint16_t*)base)[idx] = (uint16_t)(f >> 16); break;
+    case 0x20: ((uint16_t*)base)[idx] = (uint16_t)(d >> 48); break;
+    default: ((double*)base)[idx] = v; break;
+    }
+}
+
+static double oracle_load_reduced(int prec, const void* base, int64_t idx)
+{
+    uint64_t d;
+    uint32_t f;
+    double out;
+    float fo;
+    switch (prec) {
+    case 0x01: return (double)((const float*)base)[idx];
+    case 0x02: return (double)oracle_half_to_float(((const uint16_t*)base)[idx]);
+    case 0x10:
+        d = (uint64_t)((const uint32_t*)base)[idx] << 32;
+        memcpy(&out, &d, 8);
+        return out;
+    case 0x11:
+        f = (uint32_t)((const uint16_t*)base)[idx] << 16;
+        memcpy(&fo, &f, 4);
+        return (double)fo;
+    case 0x20:
+        d = (uint64_t)((const uint16_t*)base)[idx] << 48;
+        memcpy(&out, &d, 8);
+        return out;
+    default: return ((const double*)base)[idx];
+    }
+}
+
+/* narrow full-precision block storage (as oracle_jacobi_generate wrote it) in place:
+ * group by group, entry (r, c) of block b goes to element index
+ * block_offset (b & mask) + r + c stride of the narrower type
+ * (reference/preconditioner/jacobi_kernels.cpp:393-408) */
+void oracle_jacobi_convert_storage_f64(int64_t num_blocks, int64_t block_offset,
+                                       int64_t group_offset, uint32_t group_power,
+                                       double* blocks, int prec)
+{
+    if (prec == 0) return;
+    const int64_t gsize = (int64_t)1 << group_power;
+    const int64_t groups = (num_blocks + gsize - 1) / gsize;
+    double* tmp = (double*)malloc(sizeof(double) * (size_t)group_offset);
+    for (int64_t g = 0; g < groups; ++g) {
+        double* gp = blocks + group_offset * g;
+        memcpy(tmp, gp, sizeof(double) * (size_t)group_offset);
+        for (int64_t i = 0; i < group_offset; ++i) oracle_store_reduced(prec, gp, i, tmp[i]);
+    }
+    free(tmp);
+    (void)block_offset;
+}
+
+/* reference/preconditioner/jacobi_kernels.cpp:413-531 (apply_block with a
+ * BlockValueType and its default_converter; apply / simple_apply) */
+void oracle_jacobi_apply_stored_f64_i32(int64_t num_blocks, int64_t block_offset,
+                                        int64_t group_offset, uint32_t group_power,
+                                        const int32_t* block_ptrs, const double* blocks,
+                                        int prec, double alpha, const double* b, int64_t ldb,
+                                        double beta, double* x, int64_t ldx, int64_t nrhs)
+{
+    const int64_t stride = block_offset << group_power;
+    const int64_t gmask = ((int64_t)1 << group_power) - 1;
+    for (int64_t blk = 0; blk < num_blocks; ++blk) {
+        const void* group = blocks + group_offset * (blk >> group_power);
+        const int64_t off = block_offset * (blk & gmask);
+        const int64_t start = block_ptrs[blk];
+        const int64_t bs = block_ptrs[blk + 1] - start;
+        const double* bb = b + ldb * start;
+        double* bx = x + ldx * start;
+        for (int64_t row = 0; row < bs; ++row) {
+            for (int64_t col = 0; col < nrhs; ++col) {
+                if (beta != 0.0) {
+                    bx[row * ldx + col] *= beta;
+                } else {
+                    bx[row * ldx + col] = 0.0;
+                }
+            }
+        }
+        for (int64_t inner = 0; inner < bs; ++inner) {
+            for (int64_t row = 0; row < bs; ++row) {
+                for (int64_t col = 0; col < nrhs; ++col) {
+                    bx[row * ldx + col] += alpha * oracle_load_reduced(prec, group, off + row + inner * stride) *
+                                           bb[inner * ldb + col];
+                }
+            }
+        }
+    }
+    (void)oracle_prec_bytes;
+}
+
 /* ---- CG driver ---------------------------------------------------------
  * core/solver/cg.cpp:93-181 (Cg::apply_dense_impl) with
  *   - preconditioner: 0 = Identity (z = r), 1 = scalar Jacobi, 2 = block Jacobi

@@ -262,6 +262,28 @@ def jacobi_apply(num_blocks, scheme, block_ptrs, blocks, b, alpha=1.0, beta=0.0,
     return out if np.asarray(b).ndim == 2 else out[:, 0]
 
 
+def jacobi_convert_storage(num_blocks, scheme, blocks, prec):
+    """blocks (float64, as jacobi_generate returns them) narrowed in place to the storage
+    type of precision_reduction byte `prec`; returns the same buffer"""
+    bo, go, gp = scheme
+    out = np.array(blocks, dtype=np.float64, copy=True)
+    lib().oracle_jacobi_convert_storage_f64(_i64(num_blocks), _i64(bo), _i64(go), C.c_uint32(gp),
+                                            _p(out), C.c_int(prec))
+    return out
+
+
+def jacobi_apply_stored(num_blocks, scheme, block_ptrs, blocks, prec, b, alpha=1.0, beta=0.0, x=None):
+    bo, go, gp = scheme
+    b2 = np.ascontiguousarray(_as2d(b), dtype=np.float64)
+    nrhs = b2.shape[1]
+    out = np.zeros_like(b2) if x is None else np.array(_as2d(x), dtype=np.float64, order="C", copy=True)
+    lib().oracle_jacobi_apply_stored_f64_i32(
+        _i64(num_blocks), _i64(bo), _i64(go), C.c_uint32(gp), _p(np.ascontiguousarray(block_ptrs, np.int32)),
+        _p(blocks), C.c_int(prec), C.c_double(alpha), _p(b2), _i64(nrhs), C.c_double(beta), _p(out),
+        _i64(nrhs), _i64(nrhs))
+    return out if np.asarray(b).ndim == 2 else out[:, 0]
+
+
 def jacobi_invert_diagonal(diag):
     inv = np.empty_like(diag)
     getattr(lib(), "oracle_jacobi_invert_diagonal_" + _VT[diag.dtype])(

@@ -110,6 +110,18 @@ class CsrHandle:
         lib().ref_jacobi_get(self.h, _p(ptrs), _p(blocks))
         return nb, tuple(int(s) for s in scheme), ptrs, blocks
 
+    def jacobi_generate_prec(self, max_block_size, preserving, nonpreserving):
+        """Jacobi with storage_optimization = precision_reduction(preserving, nonpreserving);
+        blocks = the raw storage (as float64 words) the reference holds"""
+        scheme = np.zeros(3, np.int64)
+        storage = C.c_int64(0)
+        nb = lib().ref_jacobi_generate_prec(self.h, C.c_uint32(max_block_size), C.c_int(preserving),
+                                            C.c_int(nonpreserving), _p(scheme), C.byref(storage))
+        ptrs = np.empty(nb + 1, np.int32)
+        blocks = np.empty(storage.value, np.float64)
+        lib().ref_jacobi_get(self.h, _p(ptrs), _p(blocks))
+        return nb, tuple(int(s) for s in scheme), ptrs, blocks
+
     def jacobi_apply(self, b, alpha=None, beta=None, x=None):
         b2 = np.ascontiguousarray(np.reshape(b, (len(b), -1)))
         if alpha is None:

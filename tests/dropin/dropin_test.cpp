@@ -242,6 +242,30 @@ int main(int argc, char** argv)
         CHECK(rel_err(x_hip2.get(), x_ref2.get()) < 1e-8, "GMRES solution matches reference");
     }
 
+    // --- Ginkgo's block-Jacobi with a fixed reduced storage precision
+    {
+        auto x_in = Dense::create(ref, gko::dim<2>{n, 1});
+        for (gko::size_type i = 0; i < n; ++i) x_in->at(i, 0) = std::cos(0.11 * i);
+        for (auto prec : {gko::precision_reduction(0, 1), gko::precision_reduction(0, 2),
+                          gko::precision_reduction(1, 0), gko::precision_reduction(2, 0)}) {
+            auto jac = [&](auto exec, auto a) {
+                return gko::preconditioner::Jacobi<vt, it>::build()
+                    .with_max_block_size(8u)
+                    .with_storage_optimization(prec)
+                    .on(exec)
+                    ->generate(a);
+            };
+            auto j_ref = jac(ref, a_ref);
+            auto j_hip = jac(hip, a_hip);
+            auto y_ref = Dense::create(ref, gko::dim<2>{n, 1});
+            auto y_hip = Dense::create(hip, gko::dim<2>{n, 1});
+            j_ref->apply(x_in, y_ref);
+            j_hip->apply(gko::clone(hip, x_in), y_hip);
+            CHECK(identical(gko::clone(ref, y_hip).get(), y_ref.get()),
+                  "Jacobi(8) with reduced storage precision: apply bit-identical to reference");
+        }
+    }
+
     // --- Ginkgo's own Bicgstab / Cgs / Fcg / PipeCg drivers on this backend
     {
         auto family = [&](auto tag, auto exec, auto a, int& iters) {

@@ -113,7 +113,28 @@ def stationary():
     save("stationary.npz", **arrays)
 
 
+def jacobi_storage():
+    """block-Jacobi with a fixed storage_optimization: the reference's apply results"""
+    from oracle import gko_oracle as o
+    rng = np.random.default_rng(12)
+    rp, ci, v = o.stencil_csr(3, 9)
+    v = v * rng.uniform(0.5, 2.0, len(v))        # blocks of varied magnitude
+    n = len(rp) - 1
+    h = ref.CsrHandle("reference", rp, ci, v)
+    b, x0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    arrays = dict(row_ptrs=rp, cols=ci, vals=v, b=b, x0=x0)
+    for bs in (4, 8, 16):
+        for p_, n_ in ((0, 1), (0, 2), (1, 0), (1, 1), (2, 0)):
+            nb, scheme, ptrs, blocks = h.jacobi_generate_prec(bs, p_, n_)
+            key = f"bs{bs}_p{p_}n{n_}"
+            arrays[key + "_apply"] = h.jacobi_apply(b)
+            arrays[key + "_apply_adv"] = h.jacobi_apply(b, 0.7, -1.1, x0)
+    save("jacobi_storage.npz", **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "jacobi_storage":
+        return jacobi_storage()
     if len(sys.argv) > 1 and sys.argv[1] == "stationary":
         return stationary()
     if len(sys.argv) > 1 and sys.argv[1] == "krylov_family":
@@ -223,3 +244,4 @@ if __name__ == "__main__":
         krylov_family()
         coo_hybrid()
         stationary()
+        jacobi_storage()

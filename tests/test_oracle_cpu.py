@@ -527,3 +527,73 @@ def test_transpose_known_answer(oracle):
     for r in range(3):
         dense[r, tc[trp[r]:trp[r + 1]]] = tv[trp[r]:trp[r + 1]]
     assert np.array_equal(dense, [[1.0, 0.0, 0.0], [3.0, 5.0, 1.5], [2.0, 0.0, 2.0]])
+
+
+# ----------------------------------------------------------------------------
+# block-Jacobi with reduced storage precision (fixed storage_optimization)
+PRECS = ((0, 1), (0, 2), (1, 0), (1, 1), (2, 0))
+
+
+def test_reduced_storage_conversions(oracle):
+    """half: round to nearest even, exponents below the normal range give signed zero,
+    above give infinity (include/ginkgo/core/base/half.hpp:405-433); truncated types keep
+    the upper bits (core/base/extended_float.hpp:72-89)"""
+    scheme = (1, 64, 6)                 # one 1 x 1 block per lane: 64 values = one group
+    vals = np.array([1.0, -1.0, 0.1, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 65504.0, 65520.0, 1e5, 6e-5,
+                     6.2e-5, -5e-8, 3.14159265358979, 2.0 ** -14, 1e-300, -0.0] + [0.0] * 49)
+    def roundtrip(prec):
+        st = oracle.jacobi_convert_storage(64, scheme, vals, prec)
+        ptrs = np.arange(65, dtype=np.int32)
+        return oracle.jacobi_apply_stored(64, scheme, ptrs, st, prec, np.ones(64))
+    h = roundtrip(0x02)
+    assert h[0] == 1.0 and h[1] == -1.0
+    assert h[2] == float(np.float16(np.float32(0.1)))
+    assert h[3] == 1.0                           # tie -> even
+    assert h[4] == 1.0 + 2.0 ** -9               # tie -> even (upwards)
+    assert h[5] == 65504.0 and np.isinf(h[6]) and np.isinf(h[7])
+    assert h[8] == 0.0 and h[9] == float(np.float16(6.2e-5))      # 6e-5 < 2^-14: flushed
+    assert h[10] == 0.0                          # -5e-8: flushed (the sign is lost in 0 + -0)
+    assert h[12] == 2.0 ** -14 and h[13] == 0.0
+    f = roundtrip(0x01)
+    assert np.array_equal(f[:15], vals[:15].astype(np.float32).astype(np.float64))
+    t32 = roundtrip(0x10)
+    want = (vals.view(np.uint64) & np.uint64(0xFFFFFFFF00000000)).view(np.float64)
+    assert np.array_equal(t32, want)
+    t16 = roundtrip(0x20)
+    assert np.array_equal(t16, (vals.view(np.uint64) & np.uint64(0xFFFF000000000000)).view(np.float64))
+    b16 = roundtrip(0x11)
+    wf = (vals.astype(np.float32).view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    assert np.array_equal(b16, wf.astype(np.float64))
+
+
+def test_golden_jacobi_storage(oracle):
+    g = gold("jacobi_storage.npz")
+    rp, ci, v, b, x0 = (g[k] for k in ("row_ptrs", "cols", "vals", "b", "x0"))
+    for bs in (4, 8, 16):
+        nb, ptrs = oracle.jacobi_find_blocks(rp, ci, bs)
+        scheme = oracle.jacobi_storage_scheme(bs)
+        full = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
+        for p_, n_ in PRECS:
+            prec = (p_ << 4) | n_
+            st = oracle.jacobi_convert_storage(nb, scheme, full, prec)
+            key = f"bs{bs}_p{p_}n{n_}"
+            assert np.array_equal(oracle.jacobi_apply_stored(nb, scheme, ptrs, st, prec, b), g[key + "_apply"]), key
+            assert np.array_equal(oracle.jacobi_apply_stored(nb, scheme, ptrs, st, prec, b, 0.7, -1.1, x0),
+                                  g[key + "_apply_adv"]), key
+
+
+def test_live_reference_jacobi_storage(oracle):
+    ref = _ref()
+    rng = np.random.default_rng(4)
+    rp, ci, v = oracle.stencil_csr(2, 17, True)
+    v = v * rng.uniform(0.1, 10.0, len(v))
+    n = len(rp) - 1
+    h = ref.CsrHandle("reference", rp, ci, v)
+    b = rng.uniform(-1, 1, n)
+    for bs in (3, 8):
+        for p_, n_ in PRECS:
+            nb, scheme, ptrs, _ = h.jacobi_generate_prec(bs, p_, n_)
+            nbo, po = oracle.jacobi_find_blocks(rp, ci, bs)
+            full = oracle.jacobi_generate(rp, ci, v, nb, scheme, po)
+            st = oracle.jacobi_convert_storage(nb, scheme, full, (p_ << 4) | n_)
+            assert np.array_equal(oracle.jacobi_apply_stored(nb, scheme, po, st, (p_ << 4) | n_, b), h.jacobi_apply(b))
