@@ -217,41 +217,17 @@ __device__ __forceinline__ T gabs(T v)
     return v < T(0) ? -v : v;
 }
 
-// one wave per 64/SUB blocks; dynamic LDS: (64/SUB) * SUB * (SUB+1) values
-template <typename T, typename I>
-__global__ __launch_bounds__(64) void jacobi_generate_kernel(
-    const I* __restrict__ row_ptrs, const I* __restrict__ cols,
-    const T* __restrict__ vals, int64_t num_blocks, int sub,
-    gkoc_jacobi_scheme scheme, const I* __restrict__ block_ptrs,
-    T* __restrict__ blocks)
+// In-place Gauss-Jordan inversion with column pivoting of the bs x bs block held
+// row-major (leading dimension ld) in LDS, one SUB-lane sub-wavefront per block, lane =
+// row r; operation order of reference invert_block (:175-240) => bit-identical.  perm is
+// the lane's entry of the row permutation.  Returns false when a pivot was zero (the
+// reference stops transforming the block there).  All lanes of the wave must call it
+// together (max_bs = the largest block size in the wave).
+template <typename T>
+__device__ __forceinline__ bool gauss_jordan_lds(T* Bm, int ld, int bs, int r, int g, int sub,
+                                                 int max_bs, int& perm)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    T* lds = reinterpret_cast<T*>(lds_raw);
-    const int lane = threadIdx.x;
-    const int per_wave = 64 / sub;
-    const int g = lane / sub;
-    const int r = lane % sub;
-    const int ld = sub + 1;
-    T* Bm = lds + int64_t(g) * sub * ld;
-    const int64_t blk = int64_t(blockIdx.x) * per_wave + g;
-    int64_t start = 0;
-    int bs = 0;
-    if (blk < num_blocks) {
-        start = block_ptrs[blk];
-        bs = int(block_ptrs[blk + 1] - start);
-    }
-    // extract the dense diagonal block (reference extract_block, :125-147)
-    if (r < bs) {
-        for (int j = 0; j < bs; ++j) Bm[r * ld + j] = T(0);
-        const int64_t a = row_ptrs[start + r], e = row_ptrs[start + r + 1];
-        for (int64_t k = a; k < e; ++k) {
-            const int64_t c = int64_t(cols[k]) - start;
-            if (c >= 0 && c < bs) Bm[r * ld + c] = vals[k];
-        }
-    }
-    int perm = r;
-    bool dead = false;  // zero pivot: reference stops transforming the block
-    const int max_bs = wave_max(bs);
+    bool dead = false;
     wave_lds_sync();
     for (int k = 0; k < max_bs; ++k) {
         const bool act = k < bs && !dead;
@@ -304,6 +280,44 @@ __global__ __launch_bounds__(64) void jacobi_generate_kernel(
         }
         wave_lds_sync();
     }
+    return !dead;
+}
+
+// one wave per 64/SUB blocks; dynamic LDS: (64/SUB) * SUB * (SUB+1) values
+template <typename T, typename I>
+__global__ __launch_bounds__(64) void jacobi_generate_kernel(
+    const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    const T* __restrict__ vals, int64_t num_blocks, int sub,
+    gkoc_jacobi_scheme scheme, const I* __restrict__ block_ptrs,
+    T* __restrict__ blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+    const int lane = threadIdx.x;
+    const int per_wave = 64 / sub;
+    const int g = lane / sub;
+    const int r = lane % sub;
+    const int ld = sub + 1;
+    T* Bm = lds + int64_t(g) * sub * ld;
+    const int64_t blk = int64_t(blockIdx.x) * per_wave + g;
+    int64_t start = 0;
+    int bs = 0;
+    if (blk < num_blocks) {
+        start = block_ptrs[blk];
+        bs = int(block_ptrs[blk + 1] - start);
+    }
+    // extract the dense diagonal block (reference extract_block, :125-147)
+    if (r < bs) {
+        for (int j = 0; j < bs; ++j) Bm[r * ld + j] = T(0);
+        const int64_t a = row_ptrs[start + r], e = row_ptrs[start + r + 1];
+        for (int64_t k = a; k < e; ++k) {
+            const int64_t c = int64_t(cols[k]) - start;
+            if (c >= 0 && c < bs) Bm[r * ld + c] = vals[k];
+        }
+    }
+    int perm = r;
+    const int max_bs = wave_max(bs);
+    gauss_jordan_lds<T>(Bm, ld, bs, r, g, sub, max_bs, perm);
     // store inverse, column-permuted, into the interleaved scheme
     // (reference permute_and_transpose_block, :242-258)
     const int64_t gsize = int64_t(1) << scheme.group_power;
@@ -431,6 +445,157 @@ struct stored<0x02> {
     }
 };
 
+// runtime-selected storage type (one precision per storage group)
+__device__ __forceinline__ double load_stored(int prec, const double* group, int64_t idx)
+{
+    switch (prec) {
+    case 0x01: return stored<0x01>::load(reinterpret_cast<const float*>(group)[idx]);
+    case 0x02: return stored<0x02>::load(reinterpret_cast<const uint16_t*>(group)[idx]);
+    case 0x10: return stored<0x10>::load(reinterpret_cast<const uint32_t*>(group)[idx]);
+    case 0x11: return stored<0x11>::load(reinterpret_cast<const uint16_t*>(group)[idx]);
+    case 0x20: return stored<0x20>::load(reinterpret_cast<const uint16_t*>(group)[idx]);
+    default: return group[idx];
+    }
+}
+
+__device__ __forceinline__ void store_stored(int prec, double* group, int64_t idx, double v)
+{
+    switch (prec) {
+    case 0x01: reinterpret_cast<float*>(group)[idx] = stored<0x01>::store(v); break;
+    case 0x02: reinterpret_cast<uint16_t*>(group)[idx] = stored<0x02>::store(v); break;
+    case 0x10: reinterpret_cast<uint32_t*>(group)[idx] = stored<0x10>::store(v); break;
+    case 0x11: reinterpret_cast<uint16_t*>(group)[idx] = stored<0x11>::store(v); break;
+    case 0x20: reinterpret_cast<uint16_t*>(group)[idx] = stored<0x20>::store(v); break;
+    default: group[idx] = v; break;
+    }
+}
+
+// reference compute_inf_norm (reference/components/matrix_operations.hpp:22-37) applied to
+// the ROW-major block as the reference applies it (element i + j * bs = row j, column i):
+// lane r sums |B(j, r)| over j in order, the maximum over the lanes is order-free
+__device__ __forceinline__ double block_norm_lds(const double* Bm, int ld, int bs, int r, int sub)
+{
+    double t = 0.0;
+    if (r < bs) {
+        for (int j = 0; j < bs; ++j) t += fabs(Bm[j * ld + r]);
+    }
+    for (int off = 1; off < sub; off <<= 1) {
+        const double o = __shfl_xor(t, off, 64);
+        t = o > t ? o : t;
+    }
+    return t;
+}
+
+// validate_precision_reduction_feasibility<ReducedType> (reference :280-307): round the
+// inverse to the reduced type, invert that in double, condition number must be >= 1 and
+// * eps(double) < 1e-3.  PREC 0x01 = float, 0x02 = half.  Tm: scratch block in LDS.
+template <int PREC>
+__device__ __forceinline__ bool feasible_lds(const double* Bm, double* Tm, int ld, int bs, int r,
+                                             int g, int sub, int max_bs)
+{
+    if (r < bs) {
+        for (int j = 0; j < bs; ++j) {
+            Tm[r * ld + j] = stored<PREC>::load(stored<PREC>::store(Bm[r * ld + j]));
+        }
+    }
+    wave_lds_sync();
+    double cond = block_norm_lds(Tm, ld, bs, r, sub);
+    int perm = r;
+    const bool ok = gauss_jordan_lds<double>(Tm, ld, bs, r, g, sub, max_bs, perm);
+    cond *= block_norm_lds(Tm, ld, bs, r, sub);
+    wave_lds_sync();
+    return ok && cond >= 1.0 && cond * (1.0 / 9007199254740992.0) < 1e-3;
+}
+
+// adaptive generate (reference/preconditioner/jacobi_kernels.cpp:313-411), value type
+// double, one wave per storage group (64-wide groups: 64/SUB blocks).
+// precisions[blk] in: requested precision_reduction byte (0xff = autodetect); out: the
+// precision of the group = get_optimal_storage_reduction of the AND of the blocks'
+// descriptors (core/preconditioner/jacobi_utils.hpp:104-176).  conditioning[blk] =
+// norm(block) * norm(inverse).  dynamic LDS: 2 * (64/SUB) * SUB * (SUB+1) doubles.
+template <typename I>
+__global__ __launch_bounds__(64) void jacobi_generate_adaptive_kernel(
+    const I* __restrict__ row_ptrs, const I* __restrict__ cols, const double* __restrict__ vals,
+    int64_t num_blocks, int sub, gkoc_jacobi_scheme scheme, const I* __restrict__ block_ptrs,
+    double accuracy, uint8_t* __restrict__ precisions, double* __restrict__ conditioning,
+    double* __restrict__ blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double* lds = reinterpret_cast<double*>(lds_raw);
+    const int lane = threadIdx.x;
+    const int per_wave = 64 / sub;
+    const int g = lane / sub;
+    const int r = lane % sub;
+    const int ld = sub + 1;
+    double* Bm = lds + int64_t(g) * sub * ld;
+    double* Tm = lds + int64_t(per_wave) * sub * ld + int64_t(g) * sub * ld;
+    const int64_t blk = int64_t(blockIdx.x) * per_wave + g;
+    int64_t start = 0;
+    int bs = 0;
+    if (blk < num_blocks) {
+        start = block_ptrs[blk];
+        bs = int(block_ptrs[blk + 1] - start);
+    }
+    if (r < bs) {
+        for (int j = 0; j < bs; ++j) Bm[r * ld + j] = 0.0;
+        const int64_t a = row_ptrs[start + r], e = row_ptrs[start + r + 1];
+        for (int64_t k = a; k < e; ++k) {
+            const int64_t c = int64_t(cols[k]) - start;
+            if (c >= 0 && c < bs) Bm[r * ld + c] = vals[k];
+        }
+    }
+    const int max_bs = wave_max(bs);
+    wave_lds_sync();
+    double cond = block_norm_lds(Bm, ld, bs, r, sub);
+    int perm = r;
+    gauss_jordan_lds<double>(Bm, ld, bs, r, g, sub, max_bs, perm);
+    cond *= block_norm_lds(Bm, ld, bs, r, sub);
+    const int request = blk < num_blocks ? int(precisions[blk]) : -1;
+    uint32_t desc = 0xffffffffu;           // blocks past the end do not restrict the group
+    const bool any_auto = __ballot(request == 0xff) != 0;
+    bool v1 = false, v2 = false;
+    if (any_auto) {                        // wave-uniform: the inversions run in lock step
+        v1 = feasible_lds<0x01>(Bm, Tm, ld, bs, r, g, sub, max_bs);
+        v2 = feasible_lds<0x02>(Bm, Tm, ld, bs, r, g, sub, max_bs);
+    }
+    if (request == 0xff) {
+        // get_supported_storage_reductions: eps of truncated<double,4>, truncated<float,2>,
+        // half, truncated<double,2>, float; verificators are pure, so evaluating them
+        // eagerly and replaying the short-circuit logic gives the same set
+        int verified1 = 2;
+        desc = 0;
+        if (cond * (1.0 / 16) < accuracy) desc |= 0x04;
+        if (cond * (1.0 / 128) < accuracy) {
+            verified1 = v1 ? 1 : 0;
+            if (v1) desc |= 0x02;
+        }
+        if (cond * (1.0 / 2048) < accuracy && verified1 != 0 && v2) desc |= 0x01;
+        if (cond * (1.0 / 1048576) < accuracy) desc |= 0x10;
+        if (cond * (1.0 / 16777216) < accuracy) {
+            if (verified1 == 2) verified1 = v1 ? 1 : 0;
+            if (verified1 == 1) desc |= 0x08;
+        }
+    } else if (request >= 0) {
+        desc = request == 0x01 ? 0x08u : request == 0x02 ? 0x01u : request == 0x10 ? 0x10u
+             : request == 0x11 ? 0x02u : request == 0x20 ? 0x04u : 0u;
+    }
+    for (int off = 1; off < 64; off <<= 1) desc &= __shfl_xor(desc, off, 64);
+    const int p = (desc & 0x01) ? 0x02 : (desc & 0x02) ? 0x11 : (desc & 0x04) ? 0x20
+                : (desc & 0x08) ? 0x01 : (desc & 0x10) ? 0x10 : 0x00;
+    if (blk < num_blocks && r == 0) {
+        precisions[blk] = uint8_t(p);
+        if (conditioning) conditioning[blk] = cond;
+    }
+    const int64_t gsize = int64_t(1) << scheme.group_power;
+    const int64_t stride = scheme.block_offset << scheme.group_power;
+    double* group = blocks + scheme.group_offset * (blk >> scheme.group_power);
+    const int64_t boff = scheme.block_offset * (blk & (gsize - 1));
+    for (int j = 0; j < max_bs; ++j) {
+        const int pj = __shfl(perm, g * sub + j, 64);
+        if (r < bs && j < bs) store_stored(p, group, boff + r + int64_t(pj) * stride, Bm[r * ld + j]);
+    }
+}
+
 // in place: the group's double entries become PREC entries at the same element index
 template <int PREC, int BO>
 __global__ __launch_bounds__(64) void jacobi_convert_storage_kernel(int64_t num_groups,
@@ -458,7 +623,7 @@ __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
     const I* __restrict__ block_ptrs, const T* __restrict__ blocks,
     const T* __restrict__ alpha_p, const T* __restrict__ b,
     const T* __restrict__ beta_p, T* __restrict__ x,
-    T* __restrict__ dot_partial = nullptr)
+    T* __restrict__ dot_partial = nullptr, const uint8_t* __restrict__ precs = nullptr)
 {
     __shared__ T dot_lds[4];
     T dot_acc = T(0);
@@ -504,6 +669,32 @@ __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
             if constexpr (PREC == 0) {
 #pragma unroll
                 for (int c = 0; c < BO; ++c) m[g][c] = gp[c * 64];
+            } else if constexpr (PREC == -1) {
+                // one precision per group (adaptive block-Jacobi)
+                const int64_t first = (group0 + g) << GP;
+                const int pg = int(precs[first < num_blocks ? first : 0]);
+                const double* gd = reinterpret_cast<const double*>(blocks + group_offset * (group0 + g));
+                // the type is a property of the group: decide once, then BO typed loads
+#define GKOC_LOAD_GROUP(P_)                                                             \
+    {                                                                                   \
+        const typename stored<P_>::type* sp =                                           \
+            reinterpret_cast<const typename stored<P_>::type*>(gd) + lane;              \
+        typename stored<P_>::type raw[BO];                                              \
+        _Pragma("unroll") for (int c = 0; c < BO; ++c) raw[c] = sp[c * 64];             \
+        _Pragma("unroll") for (int c = 0; c < BO; ++c) m[g][c] = T(stored<P_>::load(raw[c])); \
+    }
+                switch (pg) {
+                case 0x01: GKOC_LOAD_GROUP(0x01) break;
+                case 0x02: GKOC_LOAD_GROUP(0x02) break;
+                case 0x10: GKOC_LOAD_GROUP(0x10) break;
+                case 0x11: GKOC_LOAD_GROUP(0x11) break;
+                case 0x20: GKOC_LOAD_GROUP(0x20) break;
+                default:
+#pragma unroll
+                    for (int c = 0; c < BO; ++c) m[g][c] = T(gd[lane + c * 64]);
+                    break;
+                }
+#undef GKOC_LOAD_GROUP
             } else {
                 using S = typename stored<PREC>::type;
                 const S* sp = reinterpret_cast<const S*>(blocks + group_offset * (group0 + g)) + lane;
@@ -848,6 +1039,116 @@ extern "C" int gkoc_jacobi_initialize_precisions(gkoc_stream_t s, const uint8_t*
     GKOC_LAUNCH_OK();
     return GKOC_OK;
 }
+
+namespace gkoc {
+namespace {
+
+inline bool wide_group_layout(const gkoc_jacobi_scheme& sc)
+{
+    const int64_t bo = sc.block_offset;
+    return bo >= 1 && bo <= 16 && (bo & (bo - 1)) == 0 && (bo << sc.group_power) == 64;
+}
+
+template <typename I>
+int launch_generate_adaptive(gkoc_stream_t s, const I* row_ptrs, const I* cols, const double* vals,
+                             int64_t num_blocks, uint32_t max_bs, gkoc_jacobi_scheme scheme,
+                             const I* block_ptrs, double accuracy, uint8_t* precisions,
+                             double* conditioning, double* blocks)
+{
+    if (num_blocks <= 0) return GKOC_OK;
+    GKOC_REQUIRE(row_ptrs && cols && vals && block_ptrs && precisions && blocks, GKOC_E_INVALID,
+                 "null pointer");
+    GKOC_REQUIRE(wide_group_layout(scheme) && max_bs >= 1 && max_bs <= uint64_t(scheme.block_offset),
+                 GKOC_E_NOT_SUPPORTED,
+                 "adaptive block-Jacobi needs max_block_size in {1,2,4,8,16} (64-wide groups)");
+    const int sub = int(scheme.block_offset);
+    const int per_wave = 64 / sub;
+    const size_t lds = 2 * size_t(per_wave) * sub * (sub + 1) * sizeof(double);
+    jacobi_generate_adaptive_kernel<I>
+        <<<dim3(unsigned(ceildiv(num_blocks, per_wave))), dim3(64), lds, as_stream(s)>>>(
+            row_ptrs, cols, vals, num_blocks, sub, scheme, block_ptrs, accuracy, precisions,
+            conditioning, blocks);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+template <typename I, bool ADV, int BO>
+void launch_apply_adaptive_fixed(gkoc_stream_t s, int64_t num_blocks, int64_t groups,
+                                 int64_t group_offset, const I* block_ptrs, const double* blocks,
+                                 const uint8_t* precisions, const double* alpha, const double* b,
+                                 const double* beta, double* x)
+{
+    constexpr int GPW = 2;
+    jacobi_apply_fixed_kernel<double, I, ADV, BO, GPW, false, -1>
+        <<<dim3(unsigned(ceildiv(groups, 4 * GPW))), dim3(256), 0, as_stream(s)>>>(
+            num_blocks, groups, group_offset, block_ptrs, blocks, alpha, b, beta, x, nullptr,
+            precisions);
+}
+
+template <typename I, bool ADV>
+int launch_apply_adaptive(gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
+                          gkoc_jacobi_scheme scheme, const I* block_ptrs, const double* blocks,
+                          const uint8_t* precisions, const double* alpha, const double* b,
+                          int64_t ldb, const double* beta, double* x, int64_t ldx, int64_t nrhs)
+{
+    if (num_blocks <= 0 || nrhs <= 0) return GKOC_OK;
+    GKOC_REQUIRE(block_ptrs && blocks && precisions && b && x, GKOC_E_INVALID, "null pointer");
+    GKOC_REQUIRE(wide_group_layout(scheme) && max_bs <= uint64_t(scheme.block_offset),
+                 GKOC_E_NOT_SUPPORTED,
+                 "adaptive block-Jacobi needs max_block_size in {1,2,4,8,16} (64-wide groups)");
+    GKOC_REQUIRE(nrhs == 1 && ldb == 1 && ldx == 1, GKOC_E_NOT_SUPPORTED,
+                 "adaptive block-Jacobi: one right-hand side with unit strides");
+    const int64_t groups = ceildiv(num_blocks, int64_t(1) << scheme.group_power);
+    const int64_t go = scheme.group_offset;
+#define GKOC_JAC_AD(BO_)                                                                    \
+    launch_apply_adaptive_fixed<I, ADV, BO_>(s, num_blocks, groups, go, block_ptrs, blocks, \
+                                             precisions, alpha, b, beta, x)
+    switch (int(scheme.block_offset)) {
+    case 1: GKOC_JAC_AD(1); break;
+    case 2: GKOC_JAC_AD(2); break;
+    case 4: GKOC_JAC_AD(4); break;
+    case 8: GKOC_JAC_AD(8); break;
+    default: GKOC_JAC_AD(16); break;
+    }
+#undef GKOC_JAC_AD
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+}  // namespace
+}  // namespace gkoc
+
+#define GKOC_DEF_JACOBI_ADAPTIVE(I, IN)                                                      \
+    extern "C" int gkoc_jacobi_generate_adaptive_f64_##IN(                                   \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs,               \
+        const double* vals, int64_t num_blocks, uint32_t max_block_size,                     \
+        gkoc_jacobi_scheme scheme, const I* block_ptrs, double accuracy,                     \
+        uint8_t* precisions, double* conditioning, double* blocks)                           \
+    {                                                                                        \
+        (void)n_rows;                                                                        \
+        return launch_generate_adaptive<I>(s, row_ptrs, col_idxs, vals, num_blocks,          \
+                                           max_block_size, scheme, block_ptrs, accuracy,     \
+                                           precisions, conditioning, blocks);                \
+    }                                                                                        \
+    extern "C" int gkoc_jacobi_apply_adaptive_f64_##IN(                                      \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,                        \
+        gkoc_jacobi_scheme scheme, const I* block_ptrs, const double* blocks,                \
+        const uint8_t* precisions, const double* alpha, const double* b, int64_t ldb,        \
+        const double* beta, double* x, int64_t ldx, int64_t nrhs)                            \
+    {                                                                                        \
+        GKOC_REQUIRE((alpha == nullptr) == (beta == nullptr), GKOC_E_INVALID,                \
+                     "pass alpha and beta, or neither");                                     \
+        if (alpha) {                                                                         \
+            return launch_apply_adaptive<I, true>(s, num_blocks, max_block_size, scheme,     \
+                                                  block_ptrs, blocks, precisions, alpha, b,  \
+                                                  ldb, beta, x, ldx, nrhs);                  \
+        }                                                                                    \
+        return launch_apply_adaptive<I, false>(s, num_blocks, max_block_size, scheme,        \
+                                               block_ptrs, blocks, precisions, nullptr, b,   \
+                                               ldb, nullptr, x, ldx, nrhs);                  \
+    }
+GKOC_DEF_JACOBI_ADAPTIVE(int32_t, i32)
+GKOC_DEF_JACOBI_ADAPTIVE(int64_t, i64)
 
 // reduced-precision storage: value type double only
 extern "C" int gkoc_jacobi_convert_storage_f64(gkoc_stream_t s, int64_t num_blocks,

@@ -624,28 +624,34 @@ inline gkoc_jacobi_scheme scheme_of(
             static_cast<int64_t>(s.group_offset), s.group_power};
 }
 
-// The storage precision of the blocks: 0 when no precisions are attached; the common
-// value when Jacobi was built with a fixed storage_optimization (core fills the array
-// with it); autodetect (a per-block choice from condition numbers) is not supported.
+// Precisions attached to the blocks (Jacobi::storage_optimization other than full
+// precision): the adaptive entry points of the C ABI handle fixed, block-wise and
+// autodetect requests alike; implemented for value type double.
 template <typename T>
-inline uint8 stored_precision(exec_t exec, const array<precision_reduction>& prec)
+inline bool has_precisions(const array<precision_reduction>& prec)
 {
     if (prec.get_const_data() == nullptr || prec.get_size() == 0) {
-        return 0;
+        return false;
     }
-    const auto first = static_cast<uint8>(
-        exec->copy_val_to_host(reinterpret_cast<const uint8*>(prec.get_const_data())));
-    if (first == static_cast<uint8>(precision_reduction::autodetect())) {
-        throw ::gko::NotSupported(
-            __FILE__, __LINE__, "jacobi",
-            "block-Jacobi storage_optimization autodetect is not supported by gko-cdna4");
-    }
-    if (first != 0 && !std::is_same<T, double>::value) {
+    if (!std::is_same<T, double>::value) {
         throw ::gko::NotSupported(__FILE__, __LINE__, "jacobi",
                                   "reduced block storage is implemented for double only");
     }
-    return first;
+    return true;
 }
+
+template <typename I>
+struct adaptive_abi;
+template <>
+struct adaptive_abi<int32> {
+    static constexpr auto generate = gkoc_jacobi_generate_adaptive_f64_i32;
+    static constexpr auto apply = gkoc_jacobi_apply_adaptive_f64_i32;
+};
+template <>
+struct adaptive_abi<int64> {
+    static constexpr auto generate = gkoc_jacobi_generate_adaptive_f64_i64;
+    static constexpr auto apply = gkoc_jacobi_apply_adaptive_f64_i64;
+};
 
 void initialize_precisions(exec_t exec, const array<precision_reduction>& source,
                            array<precision_reduction>& precisions)
@@ -655,30 +661,6 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
         static_cast<int64_t>(source.get_size()),
         reinterpret_cast<uint8_t*>(precisions.get_data()),
         static_cast<int64_t>(precisions.get_size())));
-}
-
-template <typename I>
-inline int apply_stored(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jacobi_scheme sc,
-                        const I* ptrs, const double* blocks, uint8 prec, const double* alpha,
-                        const double* b, int64_t ldb, const double* beta, double* x, int64_t ldx,
-                        int64_t nrhs);
-template <>
-inline int apply_stored<int32>(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jacobi_scheme sc,
-                               const int32* ptrs, const double* blocks, uint8 prec,
-                               const double* alpha, const double* b, int64_t ldb,
-                               const double* beta, double* x, int64_t ldx, int64_t nrhs)
-{
-    return gkoc_jacobi_apply_stored_f64_i32(s, nb, mbs, sc, ptrs, blocks, prec, alpha, b, ldb, beta,
-                                            x, ldx, nrhs);
-}
-template <>
-inline int apply_stored<int64>(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jacobi_scheme sc,
-                               const int64* ptrs, const double* blocks, uint8 prec,
-                               const double* alpha, const double* b, int64_t ldb,
-                               const double* beta, double* x, int64_t ldx, int64_t nrhs)
-{
-    return gkoc_jacobi_apply_stored_f64_i64(s, nb, mbs, sc, ptrs, blocks, prec, alpha, b, ldb, beta,
-                                            x, ldx, nrhs);
 }
 
 #define DEF(T, TN, I, IN)                                                       \
@@ -698,13 +680,26 @@ inline int apply_stored<int64>(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jac
     template <>                                                                 \
     void generate<T, I>(                                                        \
         exec_t exec, const matrix::Csr<T, I>* system_matrix,                    \
-        size_type num_blocks, uint32 max_block_size, T,                         \
+        size_type num_blocks, uint32 max_block_size, T accuracy,                \
         const preconditioner::block_interleaved_storage_scheme<I>&              \
             storage_scheme,                                                     \
         array<T>& conditioning, array<precision_reduction>& block_precisions,   \
         const array<I>& block_pointers, array<T>& blocks)                       \
     {                                                                           \
-        const uint8 prec = stored_precision<T>(exec, block_precisions);         \
+        if (has_precisions<T>(block_precisions)) {                              \
+            GKOC_CALL(adaptive_abi<I>::generate(                                \
+                stream_of(exec), system_matrix->get_size()[0],                  \
+                system_matrix->get_const_row_ptrs(),                            \
+                system_matrix->get_const_col_idxs(),                            \
+                reinterpret_cast<const double*>(                                \
+                    system_matrix->get_const_values()),                         \
+                num_blocks, max_block_size, scheme_of(storage_scheme),          \
+                block_pointers.get_const_data(), static_cast<double>(accuracy), \
+                reinterpret_cast<uint8_t*>(block_precisions.get_data()),        \
+                reinterpret_cast<double*>(conditioning.get_data()),             \
+                reinterpret_cast<double*>(blocks.get_data())));                 \
+            return;                                                             \
+        }                                                                       \
         GKOC_CALL(gkoc_jacobi_generate_##TN##_##IN(                             \
             stream_of(exec), system_matrix->get_size()[0],                      \
             system_matrix->get_const_row_ptrs(),                                \
@@ -712,11 +707,6 @@ inline int apply_stored<int64>(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jac
             system_matrix->get_const_values(), num_blocks, max_block_size,      \
             scheme_of(storage_scheme), block_pointers.get_const_data(),         \
             blocks.get_data(), nullptr));                                       \
-        if (prec != 0) {                                                        \
-            GKOC_CALL(gkoc_jacobi_convert_storage_f64(                          \
-                stream_of(exec), num_blocks, scheme_of(storage_scheme),         \
-                reinterpret_cast<double*>(blocks.get_data()), prec));           \
-        }                                                                       \
     }                                                                           \
     template <>                                                                 \
     void simple_apply<T, I>(                                                    \
@@ -727,12 +717,13 @@ inline int apply_stored<int64>(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jac
         const array<I>& block_pointers, const array<T>& blocks,                 \
         const matrix::Dense<T>* b, matrix::Dense<T>* x)                         \
     {                                                                           \
-        const uint8 prec = stored_precision<T>(exec, block_precisions);         \
-        if (prec != 0) {                                                        \
-            GKOC_CALL(apply_stored<I>(                                          \
+        if (has_precisions<T>(block_precisions)) {                              \
+            GKOC_CALL(adaptive_abi<I>::apply(                                   \
                 stream_of(exec), num_blocks, max_block_size,                    \
                 scheme_of(storage_scheme), block_pointers.get_const_data(),     \
-                reinterpret_cast<const double*>(blocks.get_const_data()), prec, \
+                reinterpret_cast<const double*>(blocks.get_const_data()),       \
+                reinterpret_cast<const uint8_t*>(                               \
+                    block_precisions.get_const_data()),                         \
                 nullptr, reinterpret_cast<const double*>(b->get_const_values()), \
                 ld(b), nullptr, reinterpret_cast<double*>(x->get_values()),     \
                 ld(x), cols(b)));                                               \
@@ -754,12 +745,13 @@ inline int apply_stored<int64>(gkoc_stream_t s, int64_t nb, uint32 mbs, gkoc_jac
         const matrix::Dense<T>* alpha, const matrix::Dense<T>* b,               \
         const matrix::Dense<T>* beta, matrix::Dense<T>* x)                      \
     {                                                                           \
-        const uint8 prec = stored_precision<T>(exec, block_precisions);         \
-        if (prec != 0) {                                                        \
-            GKOC_CALL(apply_stored<I>(                                          \
+        if (has_precisions<T>(block_precisions)) {                              \
+            GKOC_CALL(adaptive_abi<I>::apply(                                   \
                 stream_of(exec), num_blocks, max_block_size,                    \
                 scheme_of(storage_scheme), block_pointers.get_const_data(),     \
-                reinterpret_cast<const double*>(blocks.get_const_data()), prec, \
+                reinterpret_cast<const double*>(blocks.get_const_data()),       \
+                reinterpret_cast<const uint8_t*>(                               \
+                    block_precisions.get_const_data()),                         \
                 reinterpret_cast<const double*>(alpha->get_const_values()),     \
                 reinterpret_cast<const double*>(b->get_const_values()), ld(b),  \
                 reinterpret_cast<const double*>(beta->get_const_values()),      \

@@ -11,6 +11,7 @@ invert_diagonal + simple_scalar_apply).  Adaptive precision
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from ._lib import IT, VT, JacobiScheme, NotSupported, call
@@ -37,6 +38,8 @@ class JacobiFactory:
         self.skip_sorting = False
         self.block_pointers = None
         self.storage_precision = 0
+        self.block_wise = None
+        self.accuracy = 1e-1
         self.exec = None
 
     def with_max_block_size(self, v):
@@ -52,19 +55,37 @@ class JacobiFactory:
         return self
 
     def with_storage_optimization(self, preserving, nonpreserving=None):
-        """precision_reduction(preserving, nonpreserving) for every block (jacobi.hpp,
-        storage_optimization): (0,1) float, (0,2) half, (1,0) / (2,0) upper 32 / 16 bits
-        of the double, (1,1) upper 16 bits of the float, (0,0) full precision.
-        precision_reduction::autodetect() (per-block choice from condition numbers) is
-        not supported."""
-        if nonpreserving is None:
-            if preserving in ("autodetect", "auto"):
-                raise NotSupported("block-Jacobi: storage_optimization autodetect is not supported")
-            preserving, nonpreserving = preserving
-        self.storage_precision = (int(preserving) << 4) | int(nonpreserving)
-        if self.storage_precision not in (0x00, 0x01, 0x02, 0x10, 0x11, 0x20):
-            raise NotSupported(f"block-Jacobi: no storage type for precision_reduction"
-                               f"({preserving}, {nonpreserving})")
+        """Jacobi's storage_optimization (jacobi.hpp:389-484):
+        with_storage_optimization(p, n)      precision_reduction(p, n) for every block -
+            (0,1) float, (0,2) half, (1,0) / (2,0) upper 32 / 16 bits of the double,
+            (1,1) upper 16 bits of the float, (0,0) full precision;
+        with_storage_optimization("autodetect")   per storage group, the smallest type
+            whose unit round-off times the block condition number stays below
+            with_accuracy (default 0.1);
+        with_storage_optimization([...])     block-wise requests: (p, n) pairs or
+            "autodetect", replicated over the blocks."""
+        def byte(v):
+            if v in ("autodetect", "auto"):
+                return 0xff
+            p_, n_ = v
+            code = (int(p_) << 4) | int(n_)
+            if code not in (0x00, 0x01, 0x02, 0x10, 0x11, 0x20):
+                raise NotSupported(f"block-Jacobi: no storage type for precision_reduction({p_}, {n_})")
+            return code
+        self.storage_precision, self.block_wise = 0, None
+        if nonpreserving is not None:
+            self.storage_precision = byte((preserving, nonpreserving))
+        elif preserving in ("autodetect", "auto"):
+            self.block_wise = [0xff]
+        elif isinstance(preserving, (list, tuple)) and preserving and \
+                isinstance(preserving[0], (list, tuple, str)):
+            self.block_wise = [byte(v) for v in preserving]
+        else:
+            self.storage_precision = byte(preserving)
+        return self
+
+    def with_accuracy(self, v):
+        self.accuracy = float(v)
         return self
 
     def on(self, exec_):
@@ -91,7 +112,9 @@ class Jacobi(LinOp):
         self.max_block_size = factory.max_block_size
         self.dtype = a.dtype
         self.storage_precision = factory.storage_precision
-        if self.storage_precision and (a.dtype != torch.float64
+        self.precisions = self.conditioning = None
+        adaptive = factory.block_wise is not None
+        if (self.storage_precision or adaptive) and (a.dtype != torch.float64
                                        or self.max_block_size not in (2, 4, 8, 16)):
             raise NotSupported("block-Jacobi: reduced storage precision needs fp64 values and "
                                "max_block_size in {2, 4, 8, 16} (64-wide storage groups)")
@@ -124,6 +147,15 @@ class Jacobi(LinOp):
         gs = 1 << self.scheme.group_power
         storage = ((self.num_blocks + gs - 1) // gs) * self.scheme.group_offset
         self.blocks = ex.zeros((storage,), a.dtype)
+        if adaptive:
+            req = np.resize(np.asarray(factory.block_wise, np.uint8), self.num_blocks)
+            self.precisions = ex.to_device(req)
+            self.conditioning = ex.alloc((self.num_blocks,), torch.float64)
+            call("gkoc_jacobi_generate_adaptive_f64_" + IT[a.col_idxs.dtype], ex.stream, n,
+                 a.row_ptrs, a.col_idxs, a.values, self.num_blocks, C.c_uint32(self.max_block_size),
+                 self.scheme, self.block_pointers, C.c_double(factory.accuracy), self.precisions,
+                 self.conditioning, self.blocks)
+            return
         call("gkoc_jacobi_generate_" + self._suf, ex.stream, n, a.row_ptrs,
              a.col_idxs, a.values, self.num_blocks,
              C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
@@ -133,6 +165,12 @@ class Jacobi(LinOp):
                  self.blocks, C.c_uint8(self.storage_precision))
 
     def _apply_stored(self, alpha, b, beta, x):
+        if self.precisions is not None:
+            call("gkoc_jacobi_apply_adaptive_f64_" + IT[self.block_pointers.dtype], self.exec.stream,
+                 self.num_blocks, C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
+                 self.blocks, self.precisions, None if alpha is None else alpha.values, b.values,
+                 b.ld, None if beta is None else beta.values, x.values, x.ld, b.size[1])
+            return
         call("gkoc_jacobi_apply_stored_f64_" + IT[self.block_pointers.dtype], self.exec.stream,
              self.num_blocks, C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
              self.blocks, C.c_uint8(self.storage_precision),
@@ -149,7 +187,7 @@ class Jacobi(LinOp):
                  self.size[0], b.size[1], self.inv_diag, b.values, b.ld,
                  x.values, x.ld)
             return
-        if self.storage_precision:
+        if self.storage_precision or self.precisions is not None:
             return self._apply_stored(None, b, None, x)
         call("gkoc_jacobi_simple_apply_" + self._suf, ex.stream,
              self.num_blocks, C.c_uint32(self.max_block_size), self.scheme,
@@ -160,7 +198,8 @@ class Jacobi(LinOp):
         """x = M b together with <b, x> (gkoc_x_jacobi_simple_apply_dot_*): block
         storage with a power-of-two block_offset <= 16 and 64-wide groups, one
         right-hand side, unit stride"""
-        if self.max_block_size == 1 or b.size[1] != 1 or b.ld != 1 or self.storage_precision:
+        if self.max_block_size == 1 or b.size[1] != 1 or b.ld != 1 or self.storage_precision \
+                or self.precisions is not None:
             return False
         bo = self.scheme.block_offset
         return bo <= 16 and (bo & (bo - 1)) == 0 and (bo << self.scheme.group_power) == 64
@@ -178,7 +217,7 @@ class Jacobi(LinOp):
                  self.size[0], b.size[1], self.inv_diag, alpha.values, b.values,
                  b.ld, beta.values, x.values, x.ld)
             return
-        if self.storage_precision:
+        if self.storage_precision or self.precisions is not None:
             return self._apply_stored(alpha, b, beta, x)
         call("gkoc_jacobi_apply_" + self._suf, ex.stream, self.num_blocks,
              C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,

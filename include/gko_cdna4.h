@@ -476,6 +476,36 @@ int gkoc_jacobi_apply_stored_f64_i64(
     uint8_t precision, const double* alpha, const double* b, int64_t ldb,
     const double* beta, double* x, int64_t ldx, int64_t nrhs);
 
+/* Adaptive block-Jacobi (Jacobi::storage_optimization block-wise or autodetect),
+ * value type double: jacobi::generate with a precision array
+ * (core/preconditioner/jacobi_kernels.hpp:30-47; reference/preconditioner/
+ * jacobi_kernels.cpp:313-411).  precisions[b] in: the requested precision_reduction
+ * byte of block b, 0xff = autodetect (condition number x unit round-off of the
+ * storage type < accuracy, and - for float / half - the rounded inverse must still be
+ * invertible with a sane condition number, :280-307); out: the precision of its storage
+ * group (all blocks of a group share one: the best one every block supports,
+ * core/preconditioner/jacobi_utils.hpp:104-176).  conditioning[b] (may be NULL) =
+ * norm(block) * norm(inverse) as the reference computes it.  The blocks are stored in
+ * the chosen types; apply_adaptive widens on load (alpha = beta = NULL: x = M b).
+ * Decisions, condition numbers, stored blocks and apply results are bit-identical to
+ * the reference.  64-wide storage groups (max_block_size in {1,2,4,8,16}), one
+ * right-hand side with unit strides. */
+#define GKOC_DECL_JACOBI_ADAPTIVE(I, IN)                                       \
+    int gkoc_jacobi_generate_adaptive_f64_##IN(                                \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,                    \
+        const I* col_idxs, const double* vals, int64_t num_blocks,             \
+        uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
+        const I* block_ptrs, double accuracy, uint8_t* precisions,             \
+        double* conditioning, double* blocks);                                 \
+    int gkoc_jacobi_apply_adaptive_f64_##IN(                                   \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,          \
+        gkoc_jacobi_scheme scheme, const I* block_ptrs, const double* blocks,  \
+        const uint8_t* precisions, const double* alpha, const double* b,       \
+        int64_t ldb, const double* beta, double* x, int64_t ldx,               \
+        int64_t nrhs);
+GKOC_DECL_JACOBI_ADAPTIVE(int32_t, i32)
+GKOC_DECL_JACOBI_ADAPTIVE(int64_t, i64)
+
 #define GKOC_DECL_JACOBI_SCALAR(T, TN)                                         \
     /* inv_diag[i] = 1 / diag[i] */                                            \
     int gkoc_jacobi_invert_diagonal_##TN(gkoc_stream_t s, int64_t n,           \

@@ -417,6 +417,190 @@ void oracle_jacobi_apply_stored_f64_i32(int64_t num_blocks, int64_t block_offset
     (void)oracle_prec_bytes;
 }
 
+/* ---- adaptive block-Jacobi: generate with per-block storage precisions ----------
+ * reference/preconditioner/jacobi_kernels.cpp:313-411 (generate), :280-307
+ * (validate_precision_reduction_feasibility), reference/components/
+ * matrix_operations.hpp:22-37 (compute_inf_norm, indexes the row-major block as
+ * i + j * stride), core/preconditioner/jacobi_utils.hpp:104-176
+ * (get_supported_storage_reductions, get_optimal_storage_reduction).
+ * prec[b] in: the requested precision_reduction byte of block b (0xff = autodetect);
+ * out: the precision of its group.  cond[b] = ||B||.||B^-1|| as computed there. */
+static double oracle_block_norm(int bs, const double* m, int stride)
+{
+    double result = 0.0;
+    for (int i = 0; i < bs; ++i) {
+        double tmp = 0.0;
+        for (int j = 0; j < bs; ++j) tmp += fabs(m[i + j * stride]);
+        result = result > tmp ? result : tmp;
+    }
+    return result;
+}
+
+static double oracle_round_to(int prec, double v)
+{
+    double buf[1];
+    oracle_store_reduced(prec, buf, 0, v);
+    return oracle_load_reduced(prec, buf, 0);
+}
+
+static int oracle_feasible(int prec, int bs, const double* block)
+{
+    double tmp[64 * 64];
+    int32_t perm[64];
+    for (int i = 0; i < bs; ++i) {
+        perm[i] = i;
+        for (int j = 0; j < bs; ++j) tmp[i * bs + j] = oracle_round_to(prec, block[i * bs + j]);
+    }
+    double cond = oracle_block_norm(bs, tmp, bs);
+    if (!oracle_invert_block_f64_i32(bs, perm, tmp, bs)) return 0;
+    cond *= oracle_block_norm(bs, tmp, bs);
+    return cond >= 1.0 && cond * (1.0 / 9007199254740992.0) < 1e-3; /* eps(double) = 2^-53 */
+}
+
+enum { PRD_P0N2 = 0x01, PRD_P1N1 = 0x02, PRD_P2N0 = 0x04, PRD_P0N1 = 0x08, PRD_P1N0 = 0x10 };
+
+static uint32_t oracle_singleton(uint8_t pr)
+{
+    switch (pr) {
+    case 0x01: return PRD_P0N1;
+    case 0x02: return PRD_P0N2;
+    case 0x10: return PRD_P1N0;
+    case 0x11: return PRD_P1N1;
+    case 0x20: return PRD_P2N0;
+    default: return 0;
+    }
+}
+
+static uint32_t oracle_supported_reductions(double accuracy, double cond, int bs,
+                                            const double* block)
+{
+    /* eps of truncated<double,4>, truncated<float,2>, half, truncated<double,2>, float */
+    const double e_p2n0 = 1.0 / 16, e_p1n1 = 1.0 / 128, e_p0n2 = 1.0 / 2048,
+                 e_p1n0 = 1.0 / 1048576, e_p0n1 = 1.0 / 16777216;
+    int verified1 = 2;
+    uint32_t supported = 0;
+    if (cond * e_p2n0 < accuracy) supported |= PRD_P2N0;
+    if (cond * e_p1n1 < accuracy && (verified1 = oracle_feasible(0x01, bs, block))) {
+        supported |= PRD_P1N1;
+    }
+    if (cond * e_p0n2 < accuracy && verified1 != 0 && oracle_feasible(0x02, bs, block)) {
+        supported |= PRD_P0N2;
+    }
+    if (cond * e_p1n0 < accuracy) supported |= PRD_P1N0;
+    if (cond * e_p0n1 < accuracy &&
+        (verified1 == 1 || (verified1 == 2 && (verified1 = oracle_feasible(0x01, bs, block))))) {
+        supported |= PRD_P0N1;
+    }
+    return supported;
+}
+
+static uint8_t oracle_optimal_reduction(uint32_t supported)
+{
+    if (supported & PRD_P0N2) return 0x02;
+    if (supported & PRD_P1N1) return 0x11;
+    if (supported & PRD_P2N0) return 0x20;
+    if (supported & PRD_P0N1) return 0x01;
+    if (supported & PRD_P1N0) return 0x10;
+    return 0x00;
+}
+
+void oracle_jacobi_generate_adaptive_f64_i32(const int32_t* row_ptrs, const int32_t* cols,
+                                             const double* vals, int64_t num_blocks,
+                                             int64_t block_offset, int64_t group_offset,
+                                             uint32_t group_power, const int32_t* block_ptrs,
+                                             double accuracy, uint8_t* prec, double* cond,
+                                             double* blocks)
+{
+    const int64_t gsize = (int64_t)1 << group_power;
+    const int64_t stride = block_offset << group_power;
+    double* blk = (double*)malloc(sizeof(double) * 64 * 64 * (size_t)gsize);
+    int32_t* perm = (int32_t*)malloc(sizeof(int32_t) * 64 * (size_t)gsize);
+    for (int64_t g = 0; g < num_blocks; g += gsize) {
+        uint32_t all = 0xffffffffu;
+        for (int64_t b = 0; b < gsize && g + b < num_blocks; ++b) {
+            double* block = blk + 64 * 64 * b;
+            int32_t* pm = perm + 64 * b;
+            const int64_t start = block_ptrs[g + b];
+            const int bs = (int)(block_ptrs[g + b + 1] - start);
+            for (int i = 0; i < bs; ++i) {
+                pm[i] = i;
+                for (int j = 0; j < bs; ++j) block[i * bs + j] = 0.0;
+            }
+            for (int row = 0; row < bs; ++row) {
+                for (int64_t k = row_ptrs[start + row]; k < row_ptrs[start + row + 1]; ++k) {
+                    const int64_t col = (int64_t)cols[k] - start;
+                    if (0 <= col && col < bs) block[row * bs + col] = vals[k];
+                }
+            }
+            cond[g + b] = oracle_block_norm(bs, block, bs);
+            oracle_invert_block_f64_i32(bs, pm, block, bs);
+            cond[g + b] *= oracle_block_norm(bs, block, bs);
+            uint32_t d;
+            if (prec[g + b] == 0xff) {
+                d = oracle_supported_reductions(accuracy, cond[g + b], bs, block);
+            } else {
+                d = oracle_singleton(prec[g + b]);
+            }
+            all &= d;
+        }
+        const uint8_t p = oracle_optimal_reduction(all);
+        for (int64_t b = 0; b < gsize && g + b < num_blocks; ++b) {
+            const double* block = blk + 64 * 64 * b;
+            const int32_t* pm = perm + 64 * b;
+            const int bs = (int)(block_ptrs[g + b + 1] - block_ptrs[g + b]);
+            prec[g + b] = p;
+            void* group = blocks + group_offset * ((g + b) >> group_power);
+            const int64_t off = block_offset * b;
+            for (int i = 0; i < bs; ++i) {
+                for (int j = 0; j < bs; ++j) {
+                    oracle_store_reduced(p, group, off + i + (int64_t)pm[j] * stride, block[i * bs + j]);
+                }
+            }
+        }
+    }
+    free(blk);
+    free(perm);
+}
+
+/* apply with the per-block precisions the adaptive generate chose */
+void oracle_jacobi_apply_adaptive_f64_i32(int64_t num_blocks, int64_t block_offset,
+                                          int64_t group_offset, uint32_t group_power,
+                                          const int32_t* block_ptrs, const double* blocks,
+                                          const uint8_t* prec, double alpha, const double* b,
+                                          int64_t ldb, double beta, double* x, int64_t ldx,
+                                          int64_t nrhs)
+{
+    for (int64_t blk = 0; blk < num_blocks; ++blk) {
+        /* one block at a time through the fixed-precision routine */
+        const int64_t gmask = ((int64_t)1 << group_power) - 1;
+        const int64_t stride = block_offset << group_power;
+        const void* group = blocks + group_offset * (blk >> group_power);
+        const int64_t off = block_offset * (blk & gmask);
+        const int64_t start = block_ptrs[blk];
+        const int64_t bs = block_ptrs[blk + 1] - start;
+        const double* bb = b + ldb * start;
+        double* bx = x + ldx * start;
+        for (int64_t row = 0; row < bs; ++row) {
+            for (int64_t col = 0; col < nrhs; ++col) {
+                if (beta != 0.0) {
+                    bx[row * ldx + col] *= beta;
+                } else {
+                    bx[row * ldx + col] = 0.0;
+                }
+            }
+        }
+        for (int64_t inner = 0; inner < bs; ++inner) {
+            for (int64_t row = 0; row < bs; ++row) {
+                for (int64_t col = 0; col < nrhs; ++col) {
+                    bx[row * ldx + col] +=
+                        alpha * oracle_load_reduced(prec[blk], group, off + row + inner * stride) *
+                        bb[inner * ldb + col];
+                }
+            }
+        }
+    }
+}
+
 /* ---- CG driver ---------------------------------------------------------
  * core/solver/cg.cpp:93-181 (Cg::apply_dense_impl) with
  *   - preconditioner: 0 = Identity (z = r), 1 = scalar Jacobi, 2 = block Jacobi

@@ -284,6 +284,36 @@ def jacobi_apply_stored(num_blocks, scheme, block_ptrs, blocks, prec, b, alpha=1
     return out if np.asarray(b).ndim == 2 else out[:, 0]
 
 
+def jacobi_generate_adaptive(row_ptrs, cols, vals, num_blocks, scheme, block_ptrs, accuracy=1e-1,
+                             requested=None):
+    """adaptive generate: (raw blocks as float64 words, chosen precision per block, conditioning).
+    requested: per-block precision_reduction bytes (0xff = autodetect), default all autodetect"""
+    bo, go, gp = scheme
+    gs = 1 << gp
+    storage = ((num_blocks + gs - 1) // gs) * go
+    blocks = np.zeros(storage)
+    prec = np.full(num_blocks, 0xff, np.uint8) if requested is None else \
+        np.resize(np.asarray(requested, np.uint8), num_blocks).copy()
+    cond = np.zeros(num_blocks)
+    lib().oracle_jacobi_generate_adaptive_f64_i32(
+        _p(np.ascontiguousarray(row_ptrs, np.int32)), _p(np.ascontiguousarray(cols, np.int32)),
+        _p(np.ascontiguousarray(vals, np.float64)), _i64(num_blocks), _i64(bo), _i64(go), C.c_uint32(gp),
+        _p(np.ascontiguousarray(block_ptrs, np.int32)), C.c_double(accuracy), _p(prec), _p(cond), _p(blocks))
+    return blocks, prec, cond
+
+
+def jacobi_apply_adaptive(num_blocks, scheme, block_ptrs, blocks, prec, b, alpha=1.0, beta=0.0, x=None):
+    bo, go, gp = scheme
+    b2 = np.ascontiguousarray(_as2d(b), dtype=np.float64)
+    nrhs = b2.shape[1]
+    out = np.zeros_like(b2) if x is None else np.array(_as2d(x), dtype=np.float64, order="C", copy=True)
+    lib().oracle_jacobi_apply_adaptive_f64_i32(
+        _i64(num_blocks), _i64(bo), _i64(go), C.c_uint32(gp), _p(np.ascontiguousarray(block_ptrs, np.int32)),
+        _p(blocks), _p(np.ascontiguousarray(prec, np.uint8)), C.c_double(alpha), _p(b2), _i64(nrhs),
+        C.c_double(beta), _p(out), _i64(nrhs), _i64(nrhs))
+    return out if np.asarray(b).ndim == 2 else out[:, 0]
+
+
 def jacobi_invert_diagonal(diag):
     inv = np.empty_like(diag)
     getattr(lib(), "oracle_jacobi_invert_diagonal_" + _VT[diag.dtype])(

@@ -122,6 +122,23 @@ class CsrHandle:
         lib().ref_jacobi_get(self.h, _p(ptrs), _p(blocks))
         return nb, tuple(int(s) for s in scheme), ptrs, blocks
 
+    def jacobi_generate_adaptive(self, max_block_size, accuracy=1e-1, requested=None):
+        """adaptive Jacobi (autodetect, or the given per-block requests replicated over the
+        blocks): (num_blocks, scheme, block_ptrs, raw blocks, chosen precisions, conditioning)"""
+        scheme = np.zeros(3, np.int64)
+        storage = C.c_int64(0)
+        req = None if requested is None else np.ascontiguousarray(requested, np.uint8)
+        f = lib().ref_jacobi_generate_adaptive
+        f.restype = C.c_int64
+        nb = f(self.h, C.c_uint32(max_block_size), C.c_double(accuracy), _p(req),
+               C.c_int64(0 if req is None else len(req)), _p(scheme), C.byref(storage))
+        ptrs = np.empty(nb + 1, np.int32)
+        blocks = np.empty(storage.value, np.float64)
+        lib().ref_jacobi_get(self.h, _p(ptrs), _p(blocks))
+        prec, cond = np.zeros(nb, np.uint8), np.zeros(nb)
+        lib().ref_jacobi_get_adaptive(self.h, _p(prec), _p(cond))
+        return nb, tuple(int(s) for s in scheme), ptrs, blocks, prec, cond
+
     def jacobi_apply(self, b, alpha=None, beta=None, x=None):
         b2 = np.ascontiguousarray(np.reshape(b, (len(b), -1)))
         if alpha is None:

@@ -247,7 +247,8 @@ int main(int argc, char** argv)
         auto x_in = Dense::create(ref, gko::dim<2>{n, 1});
         for (gko::size_type i = 0; i < n; ++i) x_in->at(i, 0) = std::cos(0.11 * i);
         for (auto prec : {gko::precision_reduction(0, 1), gko::precision_reduction(0, 2),
-                          gko::precision_reduction(1, 0), gko::precision_reduction(2, 0)}) {
+                          gko::precision_reduction(1, 0), gko::precision_reduction(2, 0),
+                          gko::precision_reduction::autodetect()}) {
             auto jac = [&](auto exec, auto a) {
                 return gko::preconditioner::Jacobi<vt, it>::build()
                     .with_max_block_size(8u)
@@ -262,7 +263,13 @@ int main(int argc, char** argv)
             j_ref->apply(x_in, y_ref);
             j_hip->apply(gko::clone(hip, x_in), y_hip);
             CHECK(identical(gko::clone(ref, y_hip).get(), y_ref.get()),
-                  "Jacobi(8) with reduced storage precision: apply bit-identical to reference");
+                  "Jacobi(8) with reduced / adaptive storage precision: apply bit-identical to reference");
+            bool same_cond = true;
+            gko::array<double> c_hip(ref, j_hip->get_num_blocks());
+            ref->copy_from(hip, j_hip->get_num_blocks(), j_hip->get_conditioning(), c_hip.get_data());
+            for (gko::size_type k = 0; k < j_ref->get_num_blocks(); ++k)
+                same_cond = same_cond && c_hip.get_const_data()[k] == j_ref->get_conditioning()[k];
+            CHECK(same_cond, "Jacobi block condition numbers identical to reference");
         }
     }
 

@@ -719,7 +719,79 @@ def test_jacobi_reduced_storage_golden_and_cg(gexec, oracle):
         assert np.linalg.norm(r) <= 2e-10 * np.linalg.norm(rhs)
         sols.append((x.to_numpy()[:, 0], s.num_iterations))
     assert abs(sols[1][1] - sols[0][1]) <= 2 and abs(sols[2][1] - sols[0][1]) <= 3
-    with pytest.raises(g.NotSupported):
-        g.Jacobi.build().with_storage_optimization("autodetect")
     with pytest.raises(g.NotSupported):      # 13 x 13 blocks are not stored in 64-wide groups
         g.Jacobi.build().with_max_block_size(13).with_storage_optimization(0, 1).on(gexec).generate(a)
+
+
+@pytest.mark.parametrize("bs", [2, 4, 8, 16])
+def test_jacobi_adaptive_precision_bit_exact(gexec, oracle, bs):
+    """storage_optimization autodetect and block-wise requests: the chosen precision per
+    block, the condition numbers, the stored bytes and both applies against the oracle
+    (pinned to the reference in tests/test_oracle_cpu.py) - all bit-exact"""
+    import ginkgo_amd as g
+    from adaptive_cases import graded_block_matrix
+    rp, ci, v = graded_block_matrix(24, bs, bs)
+    n = len(rp) - 1
+    a = g.Csr.from_arrays(gexec, (n, n), rp, ci, v)
+    rng = np.random.default_rng(bs)
+    b, x0 = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, bs)
+    scheme = oracle.jacobi_storage_scheme(bs)
+    seen = set()
+    for acc, req in ((1e-1, None), (1e-3, None), (1e-2, [0x01, 0xff, 0x20, 0x00, 0x11, 0xff, 0x02, 0x10]),
+                     (1e-1, [0x20] * 3 + [0xff] * 5)):
+        f = g.Jacobi.build().with_max_block_size(bs).with_accuracy(acc)
+        if req is None:
+            f = f.with_storage_optimization("autodetect")
+        else:
+            f = f.with_storage_optimization([("autodetect" if q == 0xff else (q >> 4, q & 15)) for q in req])
+        m = f.on(gexec).generate(a)
+        assert m.num_blocks == nb
+        blocks_o, prec_o, cond_o = oracle.jacobi_generate_adaptive(rp, ci, v, nb, scheme, ptrs[:nb + 1], acc, req)
+        prec_d = m.precisions.cpu().numpy()
+        assert np.array_equal(prec_d, prec_o), (bs, acc)
+        assert np.array_equal(m.conditioning.cpu().numpy(), cond_o), (bs, acc)
+        seen |= set(int(p) for p in prec_o)
+        # stored bytes, group by group, in the width of the group's type
+        go, gp = scheme[1], scheme[2]
+        dev = m.blocks.cpu().numpy().view(np.uint8).reshape(-1, go * 8)
+        ref = blocks_o.view(np.uint8).reshape(-1, go * 8)
+        for grp in range(dev.shape[0]):
+            width = {0x00: 8, 0x01: 4, 0x02: 2, 0x10: 4, 0x11: 2, 0x20: 2}[int(prec_o[grp << gp])]
+            sub_ptrs = ptrs[grp << gp:min(((grp + 1) << gp), nb) + 1]
+            mask = _block_byte_mask(scheme, sub_ptrs, width)[0]
+            assert np.array_equal(dev[grp, :go * width][mask], ref[grp, :go * width][mask]), (bs, acc, grp)
+        x = g.Dense.create(gexec, (n, 1))
+        m.apply(g.Dense.from_numpy(gexec, b), x)
+        assert np.array_equal(x.to_numpy()[:, 0],
+                              oracle.jacobi_apply_adaptive(nb, scheme, ptrs[:nb + 1], blocks_o, prec_o, b))
+        x = g.Dense.from_numpy(gexec, x0)
+        m.apply(g.scalar(gexec, 0.7), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.1), x)
+        assert np.array_equal(x.to_numpy()[:, 0],
+                              oracle.jacobi_apply_adaptive(nb, scheme, ptrs[:nb + 1], blocks_o, prec_o, b, 0.7, -1.1, x0))
+    assert {0x00, 0x01, 0x02} <= seen and (len(seen) >= 4 or bs == 16)
+
+
+def test_jacobi_adaptive_cg(gexec, oracle):
+    """CG with the autodetected storage: same solution, within a few iterations"""
+    import ginkgo_amd as g
+    grid = 20
+    a = g.stencil_csr(gexec, 3, grid)
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    rhs = np.ones(grid ** 3)
+    its = []
+    for adaptive in (False, True):
+        pf = g.Jacobi.build().with_max_block_size(8)
+        if adaptive:
+            pf = pf.with_storage_optimization("autodetect")
+        s = (g.Cg.build().with_criteria(g.stop.Iteration.build().with_max_iters(300),
+                                        g.stop.ResidualNorm.build().with_reduction_factor(1e-10))
+             .with_preconditioner(pf).on(gexec).generate(a))
+        x = g.Dense.from_numpy(gexec, np.zeros(grid ** 3))
+        s.apply(g.Dense.from_numpy(gexec, rhs), x)
+        r = rhs - oracle.csr_spmv(rp, ci, v, x.to_numpy()[:, 0])
+        assert s.has_converged and np.linalg.norm(r) <= 2e-10 * np.linalg.norm(rhs)
+        its.append(s.num_iterations)
+        if adaptive:     # well-conditioned 8 x 8 blocks: half storage everywhere
+            assert set(s.preconditioner.precisions.cpu().numpy().tolist()) == {0x02}
+    assert abs(its[0] - its[1]) <= 3

@@ -597,3 +597,25 @@ def test_live_reference_jacobi_storage(oracle):
             full = oracle.jacobi_generate(rp, ci, v, nb, scheme, po)
             st = oracle.jacobi_convert_storage(nb, scheme, full, (p_ << 4) | n_)
             assert np.array_equal(oracle.jacobi_apply_stored(nb, scheme, po, st, (p_ << 4) | n_, b), h.jacobi_apply(b))
+
+
+@pytest.mark.parametrize("bs", [2, 4, 8, 16])
+def test_live_reference_jacobi_adaptive(oracle, bs):
+    """autodetect and block-wise storage_optimization: chosen precisions, condition numbers
+    and apply results of the oracle restatement equal the reference's, bit for bit"""
+    ref = _ref()
+    from adaptive_cases import graded_block_matrix
+    rp, ci, v = graded_block_matrix(24, bs, bs)
+    n = len(rp) - 1
+    h = ref.CsrHandle("reference", rp, ci, v)
+    b = np.random.default_rng(1).uniform(-1, 1, n)
+    seen = set()
+    for acc, req in ((1e-1, None), (1e-3, None), (1e-2, [0x01, 0xff, 0x20, 0x00, 0x11, 0xff, 0x02, 0x10]),
+                     (1e-1, [0x20] * 3 + [0xff] * 5)):
+        nb, scheme, ptrs, _, prec_r, cond_r = h.jacobi_generate_adaptive(bs, acc, req)
+        y_r = h.jacobi_apply(b)
+        blocks_o, prec_o, cond_o = oracle.jacobi_generate_adaptive(rp, ci, v, nb, scheme, ptrs, acc, req)
+        assert np.array_equal(prec_r, prec_o) and np.array_equal(cond_r, cond_o)
+        assert np.array_equal(oracle.jacobi_apply_adaptive(nb, scheme, ptrs, blocks_o, prec_o, b), y_r)
+        seen |= set(int(p) for p in prec_o)
+    assert {0x00, 0x01, 0x02} <= seen and (len(seen) >= 4 or bs == 16)

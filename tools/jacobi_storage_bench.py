@@ -20,12 +20,24 @@ x = g.Dense.create(ex, (n, 1))
 print(f"27-pt {grid}^3, block-Jacobi(8): {n // 8} blocks; apply = 20 launches (HIP events); CG = 60 fixed iterations")
 CASES = (("double (0,0)", None, 8), ("float (0,1)", (0, 1), 4), ("half (0,2)", (0, 2), 2),
          ("upper 32 bits of the double (1,0)", (1, 0), 4), ("upper 16 bits of the float (1,1)", (1, 1), 2),
-         ("upper 16 bits of the double (2,0)", (2, 0), 2))
+         ("upper 16 bits of the double (2,0)", (2, 0), 2),
+         ("autodetect, accuracy 1e-1", "autodetect", None))
 for name, prec, width in CASES:
     f = g.Jacobi.build().with_max_block_size(8)
-    if prec:
+    if prec == "autodetect":
+        f = f.with_storage_optimization("autodetect")
+    elif prec:
         f = f.with_storage_optimization(*prec)
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
     m = f.on(ex).generate(a)
+    torch.cuda.synchronize()
+    tg = time.perf_counter() - tg
+    if width is None:
+        chosen = torch.unique(m.precisions, return_counts=True)
+        width = sum({0: 8, 1: 4, 2: 2, 0x10: 4, 0x11: 2, 0x20: 2}[int(p)] * int(c)
+                    for p, c in zip(*chosen)) / m.num_blocks
+        name += " -> " + ", ".join(f"{int(c)} x {int(p):#04x}" for p, c in zip(*chosen))
     for _ in range(3):
         m.apply(b, x)
     torch.cuda.synchronize()
@@ -48,5 +60,6 @@ for name, prec, width in CASES:
     s.apply(rhs, sol)
     torch.cuda.synchronize()
     print(f"  blocks stored as {name:36s}: apply {ms * 1e3:6.1f} us, {nbytes / 1e9:5.3f} GB, "
-          f"{nbytes / ms / 1e6:6.1f} GB/s; CG {60 / (time.perf_counter() - t0):6.1f} it/s", flush=True)
+          f"{nbytes / ms / 1e6:6.1f} GB/s; CG {60 / (time.perf_counter() - t0):6.1f} it/s; "
+          f"generate (incl. find_blocks) {tg * 1e3:6.1f} ms", flush=True)
     del m, s
