@@ -1024,6 +1024,68 @@ __global__ void tile_bytes_kernel(int64_t n, const uint8_t* __restrict__ src, in
 }  // namespace
 }  // namespace gkoc
 
+namespace gkoc {
+namespace {
+// jacobi::transpose_jacobi / conj_transpose_jacobi for real types
+// (reference/preconditioner/jacobi_kernels.cpp:597-627): every stored block is
+// transposed in place of its group, in its own storage type (the entries are moved as
+// raw words of the type's width, so no rounding takes place).
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void jacobi_transpose_kernel(
+    int64_t num_blocks, gkoc_jacobi_scheme scheme, const I* __restrict__ block_ptrs,
+    const T* __restrict__ blocks, const uint8_t* __restrict__ precs, T* __restrict__ out)
+{
+    const int64_t bo = scheme.block_offset;
+    const int64_t stride = bo << scheme.group_power;
+    const int64_t gmask = (int64_t(1) << scheme.group_power) - 1;
+    const int64_t total = num_blocks * bo;
+    const int64_t step = int64_t(gridDim.x) * 256;
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < total; t += step) {
+        const int64_t blk = t / bo;
+        const int r = int(t - blk * bo);
+        const int bs = int(block_ptrs[blk + 1] - block_ptrs[blk]);
+        if (r >= bs) continue;
+        const int64_t goff = scheme.group_offset * (blk >> scheme.group_power);
+        const int64_t boff = bo * (blk & gmask);
+        const int prec = precs ? int(precs[blk]) : 0;
+        const int width = prec == 0 ? int(sizeof(T)) : (prec == 0x01 || prec == 0x10) ? 4 : 2;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(blocks + goff);
+        unsigned char* dst = reinterpret_cast<unsigned char*>(out + goff);
+        for (int c = 0; c < bs; ++c) {
+            // out(r, c) = in(c, r)
+            const int64_t from = (boff + c + int64_t(r) * stride) * width;
+            const int64_t to = (boff + r + int64_t(c) * stride) * width;
+            for (int k = 0; k < width; ++k) dst[to + k] = src[from + k];
+        }
+    }
+}
+}  // namespace
+}  // namespace gkoc
+
+#define GKOC_DEF_JACOBI_TRANSPOSE(T, TN, I, IN)                                             \
+    extern "C" int gkoc_jacobi_transpose_##TN##_##IN(                                       \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,                       \
+        gkoc_jacobi_scheme scheme, const I* block_ptrs, const T* blocks,                    \
+        const uint8_t* precisions, T* out_blocks)                                           \
+    {                                                                                       \
+        (void)max_block_size;                                                               \
+        if (num_blocks <= 0) return GKOC_OK;                                                \
+        GKOC_REQUIRE(block_ptrs && blocks && out_blocks, GKOC_E_INVALID, "null pointer");   \
+        GKOC_REQUIRE(scheme.block_offset >= 1, GKOC_E_INVALID, "bad storage scheme");       \
+        GKOC_REQUIRE(precisions == nullptr || sizeof(T) == 8, GKOC_E_NOT_SUPPORTED,         \
+                     "reduced block storage is implemented for double only");               \
+        int64_t nb = ceildiv(num_blocks * scheme.block_offset, 256);                        \
+        if (nb > 4 * max_stream_blocks) nb = 4 * max_stream_blocks;                         \
+        jacobi_transpose_kernel<T, I><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(  \
+            num_blocks, scheme, block_ptrs, blocks, precisions, out_blocks);                \
+        GKOC_LAUNCH_OK();                                                                   \
+        return GKOC_OK;                                                                     \
+    }
+GKOC_DEF_JACOBI_TRANSPOSE(double, f64, int32_t, i32)
+GKOC_DEF_JACOBI_TRANSPOSE(double, f64, int64_t, i64)
+GKOC_DEF_JACOBI_TRANSPOSE(float, f32, int32_t, i32)
+GKOC_DEF_JACOBI_TRANSPOSE(float, f32, int64_t, i64)
+
 // jacobi::initialize_precisions (reference/preconditioner/jacobi_kernels.cpp:454-462)
 extern "C" int gkoc_jacobi_initialize_precisions(gkoc_stream_t s, const uint8_t* source,
                                                  int64_t source_size, uint8_t* precisions,

@@ -6,6 +6,7 @@
 //   fcg::{initialize, step_1, step_2}               (reference/solver/fcg_kernels.cpp:24-106)
 //   pipe_cg::{initialize_1, initialize_2, step_1, step_2}
 //                                                   (reference/solver/pipe_cg_kernels.cpp:24-164)
+//   bicg::{initialize, step_1, step_2}              (reference/solver/bicg_kernels.cpp:24-110)
 //   chebyshev::{init_update, update}                (reference/solver/chebyshev_kernels.cpp:20-66)
 //   ir::initialize                                  (reference/solver/ir_kernels.cpp:20-27)
 // All of them are "per column: a few scalars; per element: a short update that
@@ -398,6 +399,57 @@ struct op_pipe_cg_step2 {
     }
 };
 
+// -------------------------------------------------------------------- bicg
+// reference/solver/bicg_kernels.cpp:24-110.
+// step_1: p = z + t p ; p2 = z2 + t p2 (t = rho / prev_rho; plain copies if prev_rho == 0)
+// in = {z, p, z2, p2}, out = {p, p2}
+template <typename T>
+struct op_bicg_step1 {
+    const T *rho, *prev_rho;
+    const uint8_t* stop;
+    struct scalars {
+        T tmp;
+        bool plain, stopped;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T pr = prev_rho[c];
+        const bool z = pr == T(0);
+        return {z ? T(0) : rho[c] / pr, z, status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = s.plain ? in[0] : in[0] + s.tmp * in[1];
+        out[1] = s.plain ? in[2] : in[2] + s.tmp * in[3];
+    }
+};
+
+// step_2: t = rho / beta ; x += t p ; r -= t q ; r2 -= t q2   (beta != 0)
+// in = {x, r, r2, p, q, q2}, out = {x, r, r2}
+template <typename T>
+struct op_bicg_step2 {
+    const T *beta, *rho;
+    const uint8_t* stop;
+    struct scalars {
+        T tmp;
+        bool noop;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T bt = beta[c];
+        const bool nz = bt != T(0);
+        return {nz ? rho[c] / bt : T(0), !nz || status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.noop; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = in[0] + s.tmp * in[3];
+        out[1] = in[1] - s.tmp * in[4];
+        out[2] = in[2] - s.tmp * in[5];
+    }
+};
+
 // --------------------------------------------------------------- chebyshev
 // coefficients are host scalars of the highest precision (solver::detail::coeff_type
 // = double); every element is widened, updated and narrowed back like the reference
@@ -665,6 +717,47 @@ extern "C" int gkoc_ir_initialize(gkoc_stream_t s, int64_t cols, uint8_t* stop_s
 
 GKOC_DEF_KRYLOV(double, f64)
 GKOC_DEF_KRYLOV(float, f32)
+
+#define GKOC_DEF_BICG(T, TN)                                                              \
+    extern "C" int gkoc_bicg_initialize_##TN(                                             \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* b, int64_t ldb, T* r,       \
+        int64_t ldr, T* z, int64_t ldz, T* p, int64_t ldp, T* q, int64_t ldq,             \
+        T* prev_rho, T* rho, T* r2, int64_t ldr2, T* z2, int64_t ldz2, T* p2,             \
+        int64_t ldp2, T* q2, int64_t ldq2, uint8_t* stop_status)                          \
+    {                                                                                     \
+        scalar_init<T, 2> si{{rho, prev_rho}, {T(0), T(1)}};                              \
+        int rc = launch_init_scalars<T, 2>(s, cols, si, stop_status);                     \
+        if (rc != GKOC_OK) return rc;                                                     \
+        operand_list<T, 1, 8> o;                                                          \
+        o.in(b, ldb).out(r, ldr).out(r2, ldr2).out(z, ldz).out(p, ldp).out(q, ldq)        \
+            .out(z2, ldz2).out(p2, ldp2).out(q2, ldq2);                                   \
+        return launch_elementwise<T, op_copy_and_zero<T, 2, 8>, 1, 8>(                    \
+            s, rows, cols, o.a, op_copy_and_zero<T, 2, 8>{}, true);                       \
+    }                                                                                     \
+    extern "C" int gkoc_bicg_step_1_##TN(                                                 \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* p, int64_t ldp, const T* z,       \
+        int64_t ldz, T* p2, int64_t ldp2, const T* z2, int64_t ldz2, const T* rho,        \
+        const T* prev_rho, const uint8_t* stop_status)                                    \
+    {                                                                                     \
+        operand_list<T, 4, 2> o;                                                          \
+        o.in(z, ldz).in(p, ldp).in(z2, ldz2).in(p2, ldp2).out(p, ldp).out(p2, ldp2);      \
+        return launch_elementwise<T, op_bicg_step1<T>, 4, 2>(                             \
+            s, rows, cols, o.a, op_bicg_step1<T>{rho, prev_rho, stop_status}, false);     \
+    }                                                                                     \
+    extern "C" int gkoc_bicg_step_2_##TN(                                                 \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* r,             \
+        int64_t ldr, T* r2, int64_t ldr2, const T* p, int64_t ldp, const T* q,            \
+        int64_t ldq, const T* q2, int64_t ldq2, const T* beta, const T* rho,              \
+        const uint8_t* stop_status)                                                       \
+    {                                                                                     \
+        operand_list<T, 6, 3> o;                                                          \
+        o.in(x, ldx).in(r, ldr).in(r2, ldr2).in(p, ldp).in(q, ldq).in(q2, ldq2)           \
+            .out(x, ldx).out(r, ldr).out(r2, ldr2);                                       \
+        return launch_elementwise<T, op_bicg_step2<T>, 6, 3>(                             \
+            s, rows, cols, o.a, op_bicg_step2<T>{beta, rho, stop_status}, false);         \
+    }
+GKOC_DEF_BICG(double, f64)
+GKOC_DEF_BICG(float, f32)
 
 #define GKOC_DEF_CHEB(T, TN)                                                              \
     extern "C" int gkoc_chebyshev_init_update_##TN(                                       \

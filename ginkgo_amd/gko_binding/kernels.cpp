@@ -768,6 +768,50 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
 FOR_VT_IT(DEF)
 #undef DEF
 
+#define DEF(T, TN, I, IN)                                                       \
+    static void transpose_blocks_##TN##_##IN(                                   \
+        exec_t exec, size_type num_blocks, uint32 max_block_size,               \
+        const array<precision_reduction>& block_precisions,                     \
+        const array<I>& block_pointers, const array<T>& blocks,                 \
+        const preconditioner::block_interleaved_storage_scheme<I>& scheme,      \
+        array<T>& out_blocks)                                                   \
+    {                                                                           \
+        GKOC_CALL(gkoc_jacobi_transpose_##TN##_##IN(                            \
+            stream_of(exec), num_blocks, max_block_size, scheme_of(scheme),     \
+            block_pointers.get_const_data(), blocks.get_const_data(),           \
+            has_precisions<T>(block_precisions)                                 \
+                ? reinterpret_cast<const uint8_t*>(                             \
+                      block_precisions.get_const_data())                        \
+                : nullptr,                                                      \
+            out_blocks.get_data()));                                            \
+    }                                                                           \
+    template <>                                                                 \
+    void transpose_jacobi<T, I>(                                                \
+        exec_t exec, size_type num_blocks, uint32 max_block_size,               \
+        const array<precision_reduction>& block_precisions,                     \
+        const array<I>& block_pointers, const array<T>& blocks,                 \
+        const preconditioner::block_interleaved_storage_scheme<I>& scheme,      \
+        array<T>& out_blocks)                                                   \
+    {                                                                           \
+        transpose_blocks_##TN##_##IN(exec, num_blocks, max_block_size,          \
+                                     block_precisions, block_pointers, blocks,  \
+                                     scheme, out_blocks);                       \
+    }                                                                           \
+    template <>                                                                 \
+    void conj_transpose_jacobi<T, I>(                                           \
+        exec_t exec, size_type num_blocks, uint32 max_block_size,               \
+        const array<precision_reduction>& block_precisions,                     \
+        const array<I>& block_pointers, const array<T>& blocks,                 \
+        const preconditioner::block_interleaved_storage_scheme<I>& scheme,      \
+        array<T>& out_blocks)                                                   \
+    {                                                                           \
+        transpose_blocks_##TN##_##IN(exec, num_blocks, max_block_size,          \
+                                     block_precisions, block_pointers, blocks,  \
+                                     scheme, out_blocks);                       \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
 #define DEF(T, TN)                                                              \
     template <>                                                                 \
     void invert_diagonal<T>(exec_t exec, const array<T>& diag,                  \

@@ -5,6 +5,7 @@ Each class is the driver of the reference with the same kernel sequence -
   Cgs       core/solver/cgs.cpp:96-201
   Fcg       core/solver/fcg.cpp:94-183
   PipeCg    core/solver/pipe_cg.cpp:95-297
+  Bicg      core/solver/bicg.cpp:106-230
   Ir        core/solver/ir.cpp:189-255         (with core/solver/update_residual.hpp)
   Chebyshev core/solver/chebyshev.cpp:203-296  (likewise)
 - issuing the fused vector updates of csrc/krylov_steps.hip (gkoc_bicgstab_*,
@@ -245,6 +246,52 @@ class PipeCg(_Krylov):
                      q.values, q.ld, f.values, f.ld, g.values, g.ld, z.values, z.ld, w.values,
                      w.ld, m.values, m.ld, n.values, n.ld, prev_rho.values, rho.values,
                      delta.values, stop)
+        self._finish(it, stop, r)
+
+
+class Bicg(_Krylov):
+    """Biconjugate gradients (core/solver/bicg.cpp:106-230): the system and its transposed
+    shadow advance together; A^T and M^T come from Csr.transpose / Jacobi.transpose, built
+    at every apply like in the reference."""
+
+    @staticmethod
+    def build():
+        return _SolverFactory(Bicg)
+
+    def apply_impl(self, b, x):
+        a, m = self.system_matrix, self.preconditioner
+        ex, one, neg_one, stop = self._common(b)
+        suf = VT[b.dtype]
+        rows, cols = b.size
+        r, z, p, q, r2, z2, p2, q2 = (self._vec(n, b) for n in ("r", "z", "p", "q", "r2", "z2", "p2", "q2"))
+        beta, prev_rho, rho = (self._scal(n, b) for n in ("beta", "prev_rho", "rho"))
+        st = lambda: ex.stream
+        call("gkoc_bicg_initialize_" + suf, st(), rows, cols, b.values, b.ld, r.values, r.ld,
+             z.values, z.ld, p.values, p.ld, q.values, q.ld, prev_rho.values, rho.values,
+             r2.values, r2.ld, z2.values, z2.ld, p2.values, p2.ld, q2.values, q2.ld, stop)
+        at, mt = a.transpose(), m.transpose()
+        a.apply(neg_one, x, one, r)
+        r2.copy_from(r)
+        crit = _stop.combine(self.criteria, a, b, x, r)
+        it = -1
+        while True:
+            m.apply(r, z)
+            mt.apply(r2, z2)
+            z.compute_conj_dot(r2, rho)
+            it += 1
+            if self._check(crit, it, True, stop, r, rho, x)[0]:
+                break
+            # p = z + (rho / prev_rho) p ; p2 = z2 + (rho / prev_rho) p2
+            call("gkoc_bicg_step_1_" + suf, st(), rows, cols, p.values, p.ld, z.values, z.ld,
+                 p2.values, p2.ld, z2.values, z2.ld, rho.values, prev_rho.values, stop)
+            a.apply(p, q)
+            at.apply(p2, q2)
+            p2.compute_conj_dot(q, beta)
+            # x += t p ; r -= t q ; r2 -= t q2   (t = rho / beta)
+            call("gkoc_bicg_step_2_" + suf, st(), rows, cols, x.values, x.ld, r.values, r.ld,
+                 r2.values, r2.ld, p.values, p.ld, q.values, q.ld, q2.values, q2.ld, beta.values,
+                 rho.values, stop)
+            prev_rho, rho = rho, prev_rho
         self._finish(it, stop, r)
 
 

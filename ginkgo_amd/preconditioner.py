@@ -177,6 +177,24 @@ class Jacobi(LinOp):
              None if alpha is None else alpha.values, b.values, b.ld,
              None if beta is None else beta.values, x.values, x.ld, b.size[1])
 
+    def transpose(self):
+        """Jacobi::transpose / conj_transpose (real types): every inverse block transposed,
+        same storage scheme and precisions (jacobi::transpose_jacobi)"""
+        import copy
+        t = copy.copy(self)
+        if self.max_block_size == 1:
+            return t
+        t.blocks = self.exec.zeros((self.blocks.numel(),), self.blocks.dtype)
+        prec = self.precisions
+        if prec is None and self.storage_precision:
+            prec = self.exec.to_device(np.full(self.num_blocks, self.storage_precision, np.uint8))
+        call("gkoc_jacobi_transpose_" + self._suf, self.exec.stream, self.num_blocks,
+             C.c_uint32(self.max_block_size), self.scheme, self.block_pointers, self.blocks, prec,
+             t.blocks)
+        return t
+
+    conj_transpose = transpose
+
     def get_num_blocks(self):
         return self.num_blocks
 

@@ -32,6 +32,11 @@ class Identity(LinOp):
         x.scale(beta)
         x.add_scaled(alpha, b)
 
+    def transpose(self):
+        return self
+
+    conj_transpose = transpose
+
 
 class _SolverFactory:
     def __init__(self, cls):

@@ -444,6 +444,20 @@ GKOC_DECL_JACOBI(double, f64, int32_t, i32)
 GKOC_DECL_JACOBI(double, f64, int64_t, i64)
 GKOC_DECL_JACOBI(float, f32, int32_t, i32)
 GKOC_DECL_JACOBI(float, f32, int64_t, i64)
+/* jacobi::transpose_jacobi and conj_transpose_jacobi for real value types
+ * (core/preconditioner/jacobi_kernels.hpp; reference/preconditioner/
+ * jacobi_kernels.cpp:597-627): every block transposed into out_blocks (same storage
+ * scheme; precisions may be NULL = full precision, else one byte per block and the
+ * entries keep their storage type).  Needed by Jacobi::transpose(), i.e. by Bicg. */
+#define GKOC_DECL_JACOBI_TRANSPOSE(T, TN, I, IN)                               \
+    int gkoc_jacobi_transpose_##TN##_##IN(                                     \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,          \
+        gkoc_jacobi_scheme scheme, const I* block_ptrs, const T* blocks,       \
+        const uint8_t* precisions, T* out_blocks);
+GKOC_DECL_JACOBI_TRANSPOSE(double, f64, int32_t, i32)
+GKOC_DECL_JACOBI_TRANSPOSE(double, f64, int64_t, i64)
+GKOC_DECL_JACOBI_TRANSPOSE(float, f32, int32_t, i32)
+GKOC_DECL_JACOBI_TRANSPOSE(float, f32, int64_t, i64)
 
 /* Block-Jacobi with a fixed reduced storage precision (Jacobi::storage_optimization
  * other than autodetect; include/ginkgo/core/preconditioner/jacobi.hpp, storage types
@@ -796,6 +810,31 @@ GKOC_DECL_TRANSPOSE(float, f32, int64_t, i64)
         T* rho, const T* delta, const uint8_t* stop_status);
 GKOC_DECL_KRYLOV(double, f64)
 GKOC_DECL_KRYLOV(float, f32)
+
+/* bicg::{initialize, step_1, step_2} (core/solver/bicg_kernels.hpp;
+ * reference/solver/bicg_kernels.cpp:24-110): the updates of the biconjugate gradient
+ * method, for the system and its transposed shadow at once.  Same conventions as the
+ * kernels above.  (core/solver/bicg.cpp applies A^T and M^T through
+ * csr::conj_transpose and jacobi::transpose_jacobi.) */
+#define GKOC_DECL_BICG(T, TN)                                                  \
+    int gkoc_bicg_initialize_##TN(                                             \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* b, int64_t ldb,  \
+        T* r, int64_t ldr, T* z, int64_t ldz, T* p, int64_t ldp, T* q,         \
+        int64_t ldq, T* prev_rho, T* rho, T* r2, int64_t ldr2, T* z2,          \
+        int64_t ldz2, T* p2, int64_t ldp2, T* q2, int64_t ldq2,                \
+        uint8_t* stop_status);                                                 \
+    int gkoc_bicg_step_1_##TN(                                                 \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* p, int64_t ldp,        \
+        const T* z, int64_t ldz, T* p2, int64_t ldp2, const T* z2,             \
+        int64_t ldz2, const T* rho, const T* prev_rho,                         \
+        const uint8_t* stop_status);                                           \
+    int gkoc_bicg_step_2_##TN(                                                 \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* r,  \
+        int64_t ldr, T* r2, int64_t ldr2, const T* p, int64_t ldp, const T* q, \
+        int64_t ldq, const T* q2, int64_t ldq2, const T* beta, const T* rho,   \
+        const uint8_t* stop_status);
+GKOC_DECL_BICG(double, f64)
+GKOC_DECL_BICG(float, f32)
 
 /* ir::initialize (core/solver/ir_kernels.hpp:19-21; reference/solver/ir_kernels.cpp:20-27):
  * reset the stopping status; used by Ir and Chebyshev.

@@ -701,6 +701,29 @@ int64_t oracle_cg_solve_f64_i32(int64_t n, const int32_t* row_ptrs,
  *               same with separate vectors, which is what is restated here)
  * Returns the iteration count at exit; *resnorm_out = ||r||_2 as the reference's
  * Convergence logger reports it. */
+/* Jacobi::transpose (core/preconditioner/jacobi.cpp; jacobi::transpose_jacobi,
+ * reference/preconditioner/jacobi_kernels.cpp:597-627): the same scheme with every block
+ * transposed; scalar Jacobi and Identity are their own transposes.  Full precision. */
+static double* transposed_blocks(const oracle_precond* m)
+{
+    if (m->precond != 2) return NULL;
+    const int64_t gsize = (int64_t)1 << m->group_power;
+    const int64_t groups = (m->num_blocks + gsize - 1) / gsize;
+    const int64_t stride = m->block_offset << m->group_power;
+    double* out = (double*)calloc((size_t)(groups * m->group_offset), sizeof(double));
+    for (int64_t blk = 0; blk < m->num_blocks; ++blk) {
+        const int64_t base = m->group_offset * (blk >> m->group_power) +
+                             m->block_offset * (blk & (gsize - 1));
+        const int64_t bs = m->block_ptrs[blk + 1] - m->block_ptrs[blk];
+        for (int64_t r = 0; r < bs; ++r) {
+            for (int64_t c = 0; c < bs; ++c) {
+                out[base + r + c * stride] = m->blocks[base + c + r * stride];
+            }
+        }
+    }
+    return out;
+}
+
 static int krylov_check(int64_t iter, int64_t max_iters, int64_t n,
                         const double* res, double tau0, double reduction,
                         int set_finalized, uint8_t* stop, int* one_changed,
@@ -855,6 +878,39 @@ int64_t oracle_krylov_solve_f64_i32(int kind, int64_t n, const int32_t* row_ptrs
                                           &delta, &stop);
             }
         }
+    } else if (kind == 7) { /* Bicg, core/solver/bicg.cpp:106-230 */
+        double *r = V[0], *z = V[1], *p = V[2], *q = V[3], *r2 = V[4], *z2 = V[5], *p2 = V[6],
+               *q2 = V[7];
+        double beta, prev_rho, rho;
+        /* A^T through csr::conj_transpose, M^T through Jacobi::conj_transpose */
+        int32_t* t_ptrs = (int32_t*)malloc(sizeof(int32_t) * (N + 1));
+        int32_t* t_cols = (int32_t*)malloc(sizeof(int32_t) * (size_t)row_ptrs[n]);
+        double* t_vals = (double*)malloc(sizeof(double) * (size_t)row_ptrs[n]);
+        oracle_csr_transpose_f64_i32(n, n, row_ptrs, cols, vals, t_ptrs, t_cols, t_vals);
+        oracle_precond mt = *m;
+        double* tb = transposed_blocks(m);
+        if (tb) mt.blocks = tb;
+        oracle_bicg_initialize_f64(n, 1, 1, b, r, z, p, q, &prev_rho, &rho, r2, z2, p2, q2, &stop);
+        RESID(r);
+        BASELINE(r);
+        memcpy(r2, r, sizeof(double) * N);
+        for (;;) {
+            apply_precond(m, n, r, z);
+            apply_precond(&mt, n, r2, z2);
+            DOT(z, r2, &rho);
+            ++iter;
+            if (krylov_check(iter, max_iters, n, r, tau0, reduction, 1, &stop, &one_changed, &tau)) break;
+            oracle_bicg_step_1_f64(n, 1, 1, p, z, p2, z2, &rho, &prev_rho, &stop);
+            SPMV(p, q);
+            oracle_csr_spmv_f64_i32(n, t_ptrs, t_cols, t_vals, p2, 1, q2, 1, 1);
+            DOT(p2, q, &beta);
+            oracle_bicg_step_2_f64(n, 1, 1, x, r, r2, p, q, q2, &beta, &rho, &stop);
+            { const double tmp = prev_rho; prev_rho = rho; rho = tmp; }
+        }
+        free(t_ptrs);
+        free(t_cols);
+        free(t_vals);
+        free(tb);
     } else {
         iter = -2;
     }

@@ -502,7 +502,7 @@ def _make_precond(row_ptrs, cols, vals, precond, max_block_size):
     return m, keep
 
 
-KRYLOV_KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4, "ir": 5, "chebyshev": 6}
+KRYLOV_KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4, "ir": 5, "chebyshev": 6, "bicg": 7}
 
 
 def krylov_solve(kind, row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,

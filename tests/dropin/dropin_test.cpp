@@ -22,6 +22,7 @@
 #include <ginkgo/core/matrix/fbcsr.hpp>
 #include <ginkgo/core/matrix/sellp.hpp>
 #include <ginkgo/core/preconditioner/jacobi.hpp>
+#include <ginkgo/core/solver/bicg.hpp>
 #include <ginkgo/core/solver/bicgstab.hpp>
 #include <ginkgo/core/solver/cg.hpp>
 #include <ginkgo/core/solver/cgs.hpp>
@@ -308,6 +309,7 @@ int main(int argc, char** argv)
         run(type_tag<gko::solver::Cgs<vt>>{}, "Cgs");
         run(type_tag<gko::solver::Fcg<vt>>{}, "Fcg");
         run(type_tag<gko::solver::PipeCg<vt>>{}, "PipeCg");
+        run(type_tag<gko::solver::Bicg<vt>>{}, "Bicg");     // csr + Jacobi transposes on the device
         // Ir (Richardson with a Jacobi inner solver) and Chebyshev: no reduction enters the
         // iterates, so a fixed number of iterations must reproduce the reference's bits
         auto stationary = [&](auto exec, auto a, bool cheb) {

@@ -132,7 +132,29 @@ def jacobi_storage():
     save("jacobi_storage.npz", **arrays)
 
 
+def bicg():
+    """Bicg of the reference (needs A^T and M^T) on a non-symmetric operator"""
+    from oracle import gko_oracle as o
+    rng = np.random.default_rng(99)
+    rp, ci, v = nonsymmetric_5pt(o, 32)
+    n = len(rp) - 1
+    h = ref.CsrHandle("reference", rp, ci, v)
+    rhs = rng.uniform(-1, 1, n)
+    arrays = dict(row_ptrs=rp, cols=ci, vals=v, rhs=rhs)
+    for bs in (0, 1, 8):
+        x, it, rn = h.krylov_solve("bicg", rhs, max_iters=400, reduction=1e-9, precond_block_size=bs)
+        arrays[f"bicg_{bs}_x"], arrays[f"bicg_{bs}_it_rn"] = x, np.array([it, rn])
+    x, it, rn = h.krylov_solve("bicg", rhs, x0=np.full(n, 0.5), max_iters=6, reduction=1e-30,
+                               baseline="initial_resnorm", precond_block_size=8)
+    arrays["bicg_lim_x"], arrays["bicg_lim_it_rn"] = x, np.array([it, rn])
+    trp, tc, tv = h.transpose()
+    arrays["t_row_ptrs"], arrays["t_cols"], arrays["t_vals"] = trp, tc, tv
+    save("bicg.npz", **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "bicg":
+        return bicg()
     if len(sys.argv) > 1 and sys.argv[1] == "jacobi_storage":
         return jacobi_storage()
     if len(sys.argv) > 1 and sys.argv[1] == "stationary":
@@ -245,3 +267,4 @@ if __name__ == "__main__":
         coo_hybrid()
         stationary()
         jacobi_storage()
+        bicg()

@@ -1,6 +1,7 @@
 """Known-answer cases of the Bicgstab / Cgs / Fcg / PipeCg step kernels, restated from
 the reference's own unit tests (2 x 2 operands filled with one value, scalar rows of
 two values, column 1 stopped where the test stops it):
+  reference/test/solver/bicg_kernels.cpp (KernelStep1 / Step1DivByZero / Step2 / Step2DivByZero)
   reference/test/solver/bicgstab_kernels.cpp:174-368
   reference/test/solver/cgs_kernels.cpp:170-279
   reference/test/solver/fcg_kernels.cpp:151-225
@@ -32,6 +33,15 @@ CASES = [
      [RUN, RUN], dict(x=[[9.0, -3.0], [9.0, -3.0]], omega=[0.0, 0.0])),
     ("bicgstab", "finalize", dict(x=5, y=4, alpha=[1, -2]), [STOPPED, FINAL],
      dict(x=[[9.0, 5.0], [9.0, 5.0]], stop_status=[FINAL, FINAL])),
+    ("bicg", "step_1", dict(p=3, z=-2, p2=3, z2=-2, rho=[2, 3], prev_rho=[8, 3]),
+     [RUN, STOPPED], dict(p=[[-1.25, 3.0], [-1.25, 3.0]], p2=[[-1.25, 3.0], [-1.25, 3.0]])),
+    ("bicg", "step_1", dict(p=3, z=-2, p2=3, z2=-2, rho=[1, 1], prev_rho=[0, 0]),
+     [RUN, RUN], dict(p=-2.0, p2=-2.0)),
+    ("bicg", "step_2", dict(x=-2, p=3, r=4, q=-5, r2=4, q2=-5, rho=[2, 3], beta=[8, 3]),
+     [RUN, STOPPED], dict(x=[[-1.25, -2.0], [-1.25, -2.0]], r=[[5.25, 4.0], [5.25, 4.0]],
+                          r2=[[5.25, 4.0], [5.25, 4.0]])),
+    ("bicg", "step_2", dict(x=-2, p=3, r=4, q=-5, r2=4, q2=-5, rho=[1, 1], beta=[0, 0]),
+     [RUN, RUN], dict(x=-2.0, r=4.0, r2=4.0)),
     ("cgs", "step_1", dict(r=1, p=-2, q=3, u=-4, beta=[2, 2], rho_prev=[2, 3], rho=[-4, 4]),
      [RUN, STOPPED], dict(u=[[-5.0, -4.0], [-5.0, -4.0]], p=[[-19.0, -2.0], [-19.0, -2.0]], beta=[-2.0, 2.0])),
     ("cgs", "step_1", dict(r=1, p=-2, q=3, u=-4, beta=[2, 2], rho_prev=[0, 0], rho=[3, 3]),

@@ -244,3 +244,60 @@ def test_ir_chebyshev_match_reference_golden(gexec, oracle):
         assert s.num_iterations == 7 and not s.has_converged
         assert np.array_equal(x, gold[f"{kind}_lim_x"]), kind
         assert abs(s.residual_norm - gold[f"{kind}_lim_it_rn"][1]) <= 1e-12 * s.residual_norm
+
+
+# -------------------------------------------------------------------- Bicg
+def test_bicg_matches_reference_golden(gexec, oracle):
+    """Bicg drives A^T (csr transpose) and M^T (Jacobi transpose) next to A and M"""
+    import ginkgo_amd as g
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "bicg.npz"))
+    rp, ci, v, rhs = (gold[k] for k in ("row_ptrs", "cols", "vals", "rhs"))
+    n = len(rp) - 1
+    a = g.Csr.from_arrays(gexec, (n, n), rp, ci, v)
+    for bs in (0, 1, 8):
+        x, s = _solve_kind(g, gexec, g.Bicg, a, rhs, 400, 1e-9, bs)
+        it_ref, _ = gold[f"bicg_{bs}_it_rn"]
+        assert s.has_converged and abs(s.num_iterations - int(it_ref)) <= 1, (bs, s.num_iterations, it_ref)
+        assert np.linalg.norm(x - gold[f"bicg_{bs}_x"]) <= 1e-8 * np.linalg.norm(x)
+    x, s = _solve_kind(g, gexec, g.Bicg, a, rhs, 6, 1e-30, 8, x0=np.full(n, 0.5),
+                       baseline=g.stop.mode.initial_resnorm)
+    assert s.num_iterations == 6
+    assert np.linalg.norm(x - gold["bicg_lim_x"]) <= 1e-10 * np.linalg.norm(x)
+    # the transposed block-Jacobi: M^T b against the oracle (transposed blocks), bit-exact,
+    # also for reduced and adaptive storage
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, 8)
+    scheme = oracle.jacobi_storage_scheme(8)
+    full = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
+    bo, go, gp = scheme
+    stride = bo << gp
+    tr = full.copy()
+    for blk in range(nb):
+        base = go * (blk >> gp) + bo * (blk & ((1 << gp) - 1))
+        bsz = int(ptrs[blk + 1] - ptrs[blk])
+        for r in range(bsz):
+            for c in range(bsz):
+                tr[base + r + c * stride] = full[base + c + r * stride]
+    b = np.random.default_rng(2).uniform(-1, 1, n)
+    m = g.Jacobi.build().with_max_block_size(8).on(gexec).generate(a)
+    y = g.Dense.create(gexec, (n, 1))
+    m.transpose().apply(g.Dense.from_numpy(gexec, b), y)
+    assert np.array_equal(y.to_numpy()[:, 0], oracle.jacobi_apply(nb, scheme, ptrs, tr, b))
+    for prec in ((0, 1), (0, 2), (2, 0)):
+        code = (prec[0] << 4) | prec[1]
+        mp = g.Jacobi.build().with_max_block_size(8).with_storage_optimization(*prec).on(gexec).generate(a)
+        mp.transpose().apply(g.Dense.from_numpy(gexec, b), y)
+        want = oracle.jacobi_apply_stored(nb, scheme, ptrs, oracle.jacobi_convert_storage(nb, scheme, tr, code), code, b)
+        assert np.array_equal(y.to_numpy()[:, 0], want), prec
+
+
+def _solve_kind(g, gexec, cls, a, rhs, max_iters, reduction, bs, x0=None, baseline=None):
+    rn = g.stop.ResidualNorm.build().with_reduction_factor(reduction)
+    if baseline is not None:
+        rn = rn.with_baseline(baseline)
+    f = cls.build().with_criteria(g.stop.Iteration.build().with_max_iters(max_iters), rn)
+    if bs:
+        f = f.with_preconditioner(g.Jacobi.build().with_max_block_size(bs))
+    s = f.on(gexec).generate(a)
+    x = g.Dense.from_numpy(gexec, np.zeros(len(rhs)) if x0 is None else x0)
+    s.apply(g.Dense.from_numpy(gexec, rhs), x)
+    return x.to_numpy()[:, 0], s

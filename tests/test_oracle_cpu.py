@@ -619,3 +619,37 @@ def test_live_reference_jacobi_adaptive(oracle, bs):
         assert np.array_equal(oracle.jacobi_apply_adaptive(nb, scheme, ptrs, blocks_o, prec_o, b), y_r)
         seen |= set(int(p) for p in prec_o)
     assert {0x00, 0x01, 0x02} <= seen and (len(seen) >= 4 or bs == 16)
+
+
+# ----------------------------------------------------------------------------
+# Bicg - needs csr::conj_transpose and Jacobi::conj_transpose
+def test_golden_bicg(oracle):
+    g = gold("bicg.npz")
+    rp, ci, v, rhs = g["row_ptrs"], g["cols"], g["vals"], g["rhs"]
+    n = len(rp) - 1
+    for got, want in zip(oracle.csr_transpose(n, n, rp, ci, v), (g["t_row_ptrs"], g["t_cols"], g["t_vals"])):
+        assert np.array_equal(got, want)
+    for bs, pre in ((0, None), (1, "scalar"), (8, "block")):
+        x, it, rn = oracle.krylov_solve("bicg", rp, ci, v, rhs, max_iters=400, reduction=1e-9, precond=pre,
+                                        max_block_size=max(bs, 1))
+        it_ref, rn_ref = g[f"bicg_{bs}_it_rn"]
+        assert (it, rn) == (int(it_ref), float(rn_ref)) and np.array_equal(x, g[f"bicg_{bs}_x"])
+    x, it, rn = oracle.krylov_solve("bicg", rp, ci, v, rhs, x0=np.full(n, 0.5), max_iters=6, reduction=1e-30,
+                                    baseline="initial_resnorm", precond="block")
+    assert (it, rn) == tuple(g["bicg_lim_it_rn"]) and np.array_equal(x, g["bicg_lim_x"])
+
+
+def test_live_reference_bicg(oracle):
+    ref = _ref()
+    rp, ci, v = oracle.stencil_csr(3, 7)
+    rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+    v = v.copy()
+    v[ci > rows] *= 0.7
+    h = ref.CsrHandle("reference", rp, ci, v)
+    rhs = np.random.default_rng(5).uniform(-1, 1, len(rp) - 1)
+    for bs in (0, 1, 4, 8):
+        pre = None if bs == 0 else ("scalar" if bs == 1 else "block")
+        xo, ito, rno = oracle.krylov_solve("bicg", rp, ci, v, rhs, max_iters=200, reduction=1e-10, precond=pre,
+                                           max_block_size=max(bs, 1))
+        xr, itr, rnr = h.krylov_solve("bicg", rhs, max_iters=200, reduction=1e-10, precond_block_size=bs)
+        assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
