@@ -7,6 +7,7 @@
 //   pipe_cg::{initialize_1, initialize_2, step_1, step_2}
 //                                                   (reference/solver/pipe_cg_kernels.cpp:24-164)
 //   bicg::{initialize, step_1, step_2}              (reference/solver/bicg_kernels.cpp:24-110)
+//   gcr::{initialize, restart, step_1}              (reference/solver/gcr_kernels.cpp:24-88)
 //   chebyshev::{init_update, update}                (reference/solver/chebyshev_kernels.cpp:20-66)
 //   ir::initialize                                  (reference/solver/ir_kernels.cpp:20-27)
 // All of them are "per column: a few scalars; per element: a short update that
@@ -450,6 +451,51 @@ struct op_bicg_step2 {
     }
 };
 
+// --------------------------------------------------------------------- gcr
+// reference/solver/gcr_kernels.cpp:24-88.
+// step_1: t = rAp / Ap_norm ; x += t p ; residual -= t Ap   (Ap_norm != 0)
+// in = {x, residual, p, Ap}, out = {x, residual}
+template <typename T>
+struct op_gcr_step1 {
+    const T *ap_norm, *rap;
+    const uint8_t* stop;
+    struct scalars {
+        T tmp;
+        bool noop;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        const T nrm = ap_norm[c];
+        const bool nz = nrm != T(0);
+        return {nz ? rap[c] / nrm : T(0), !nz || status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.noop; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = in[0] + s.tmp * in[2];
+        out[1] = in[1] - s.tmp * in[3];
+    }
+};
+
+// p_bases(0:rows) = residual ; Ap_bases(0:rows) = A_residual.  in = {res, Ares}, out = {p, Ap}
+template <typename T>
+struct op_copy2 {
+    struct scalars {};
+    __device__ scalars load(int64_t) const { return {}; }
+    __device__ bool skip(const scalars&) const { return false; }
+    __device__ void apply(const scalars&, const T* in, T* out) const
+    {
+        out[0] = in[0];
+        out[1] = in[1];
+    }
+};
+
+__global__ void zero_u64_kernel(int64_t n, uint64_t* data)
+{
+    const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j < n) data[j] = 0;
+}
+
 // --------------------------------------------------------------- chebyshev
 // coefficients are host scalars of the highest precision (solver::detail::coeff_type
 // = double); every element is widened, updated and narrowed back like the reference
@@ -758,6 +804,47 @@ GKOC_DEF_KRYLOV(float, f32)
     }
 GKOC_DEF_BICG(double, f64)
 GKOC_DEF_BICG(float, f32)
+
+#define GKOC_DEF_GCR(T, TN)                                                               \
+    extern "C" int gkoc_gcr_initialize_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,   \
+                                            const T* b, int64_t ldb, T* residual,         \
+                                            int64_t ldr, uint8_t* stop_status)            \
+    {                                                                                     \
+        int rc = gkoc_ir_initialize(s, cols, stop_status);                                \
+        if (rc != GKOC_OK) return rc;                                                     \
+        operand_list<T, 1, 1> o;                                                          \
+        o.in(b, ldb).out(residual, ldr);                                                  \
+        return launch_elementwise<T, op_copy_and_zero<T, 1, 1>, 1, 1>(                    \
+            s, rows, cols, o.a, op_copy_and_zero<T, 1, 1>{}, true);                       \
+    }                                                                                     \
+    extern "C" int gkoc_gcr_restart_##TN(                                                 \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* residual, int64_t ldr,      \
+        const T* a_residual, int64_t ldar, T* p_bases, int64_t ldp, T* ap_bases,          \
+        int64_t ldap, uint64_t* final_iter_nums)                                          \
+    {                                                                                     \
+        if (cols > 0) {                                                                   \
+            zero_u64_kernel<<<dim3(unsigned(ceildiv(cols, 256))), dim3(256), 0,           \
+                              as_stream(s)>>>(cols, final_iter_nums);                     \
+            GKOC_LAUNCH_OK();                                                             \
+        }                                                                                 \
+        operand_list<T, 2, 2> o;                                                          \
+        o.in(residual, ldr).in(a_residual, ldar).out(p_bases, ldp).out(ap_bases, ldap);   \
+        return launch_elementwise<T, op_copy2<T>, 2, 2>(s, rows, cols, o.a, op_copy2<T>{}, \
+                                                        true);                            \
+    }                                                                                     \
+    extern "C" int gkoc_gcr_step_1_##TN(                                                  \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* residual,      \
+        int64_t ldr, const T* p, int64_t ldp, const T* ap, int64_t ldap,                  \
+        const T* ap_norm, const T* rap, const uint8_t* stop_status)                       \
+    {                                                                                     \
+        operand_list<T, 4, 2> o;                                                          \
+        o.in(x, ldx).in(residual, ldr).in(p, ldp).in(ap, ldap).out(x, ldx)                \
+            .out(residual, ldr);                                                          \
+        return launch_elementwise<T, op_gcr_step1<T>, 4, 2>(                              \
+            s, rows, cols, o.a, op_gcr_step1<T>{ap_norm, rap, stop_status}, false);       \
+    }
+GKOC_DEF_GCR(double, f64)
+GKOC_DEF_GCR(float, f32)
 
 #define GKOC_DEF_CHEB(T, TN)                                                              \
     extern "C" int gkoc_chebyshev_init_update_##TN(                                       \

@@ -6,6 +6,7 @@ Each class is the driver of the reference with the same kernel sequence -
   Fcg       core/solver/fcg.cpp:94-183
   PipeCg    core/solver/pipe_cg.cpp:95-297
   Bicg      core/solver/bicg.cpp:106-230
+  Gcr       core/solver/gcr.cpp:95-320
   Ir        core/solver/ir.cpp:189-255         (with core/solver/update_residual.hpp)
   Chebyshev core/solver/chebyshev.cpp:203-296  (likewise)
 - issuing the fused vector updates of csrc/krylov_steps.hip (gkoc_bicgstab_*,
@@ -292,6 +293,77 @@ class Bicg(_Krylov):
                  r2.values, r2.ld, p.values, p.ld, q.values, q.ld, q2.values, q2.ld, beta.values,
                  rho.values, stop)
             prev_rho, rho = rho, prev_rho
+        self._finish(it, stop, r)
+
+
+class Gcr(_Krylov):
+    """Restarted generalised conjugate residual method (core/solver/gcr.cpp:95-320):
+    search directions p_k and A p_k kept in two tall matrices of krylov_dim + 1 slots,
+    A p_k orthogonalised against the earlier ones with modified Gram-Schmidt."""
+
+    @staticmethod
+    def build():
+        return _SolverFactory(Gcr)
+
+    def apply_impl(self, b, x):
+        from .matrix import Dense
+        a, m = self.system_matrix, self.preconditioner
+        ex, one, neg_one, stop = self._common(b)
+        suf = VT[b.dtype]
+        n, cols = b.size
+        kd = int(self.params.get("krylov_dim", 100)) or 100
+        r, pr, apr = (self._vec(k, b) for k in ("residual", "precon_residual", "A_precon_residual"))
+        key = ("gcr", n, cols, kd, b.dtype)
+        if self._ws.get("gcr_key") != key:
+            self._ws["gcr_key"] = key
+            self._ws["P"] = Dense.create(ex, ((kd + 1) * n, cols), b.dtype)
+            self._ws["AP"] = Dense.create(ex, ((kd + 1) * n, cols), b.dtype)
+            self._ws["ap_norms"] = Dense.create(ex, (kd + 1, cols), b.dtype)
+            self._ws["final"] = ex.zeros((cols,), torch.int64)
+        P, AP, ap_norms, final = (self._ws[k] for k in ("P", "AP", "ap_norms", "final"))
+        rap, minus_beta, rnorm = (self._scal(k, b) for k in ("rAp", "minus_beta", "residual_norm"))
+        slot = lambda mat, i: mat.create_submatrix((n * i, n * (i + 1)), (0, cols))
+        st = lambda: ex.stream
+
+        def restart():
+            call("gkoc_gcr_restart_" + suf, st(), n, cols, pr.values, pr.ld, apr.values, apr.ld,
+                 P.values, P.ld, AP.values, AP.ld, final)
+
+        call("gkoc_gcr_initialize_" + suf, st(), n, cols, b.values, b.ld, r.values, r.ld, stop)
+        a.apply(neg_one, x, one, r)
+        m.apply(r, pr)
+        a.apply(pr, apr)
+        restart()
+        crit = _stop.combine(self.criteria, a, b, x, r)
+        it, restart_iter = -1, 0
+        while True:
+            it += 1
+            r.compute_norm2(rnorm)
+            if crit.check(1, True, stop, {"num_iterations": it, "residual": r, "residual_norm": rnorm,
+                                          "solution": x})[0]:
+                break
+            if restart_iter == kd:
+                restart()
+                restart_iter = 0
+            Ap, p = slot(AP, restart_iter), slot(P, restart_iter)
+            r.compute_conj_dot(Ap, rap)
+            ap_norm = ap_norms.create_submatrix((restart_iter, restart_iter + 1), (0, cols))
+            Ap.compute_squared_norm2(ap_norm)
+            # x += t p ; r -= t Ap   (t = <r, Ap> / ||Ap||^2)
+            call("gkoc_gcr_step_1_" + suf, st(), n, cols, x.values, x.ld, r.values, r.ld, p.values,
+                 p.ld, Ap.values, Ap.ld, ap_norm.values, rap.values, stop)
+            m.apply(r, pr)
+            a.apply(pr, apr)
+            next_Ap, next_p = slot(AP, restart_iter + 1), slot(P, restart_iter + 1)
+            next_Ap.copy_from(apr)
+            next_p.copy_from(pr)
+            for i in range(restart_iter + 1):
+                Ap_i, p_i = slot(AP, i), slot(P, i)
+                apr.compute_conj_dot(Ap_i, minus_beta)
+                minus_beta.inv_scale(ap_norms.create_submatrix((i, i + 1), (0, cols)))
+                next_Ap.sub_scaled(minus_beta, Ap_i)
+                next_p.sub_scaled(minus_beta, p_i)
+            restart_iter += 1
         self._finish(it, stop, r)
 
 

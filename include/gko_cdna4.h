@@ -836,6 +836,27 @@ GKOC_DECL_KRYLOV(float, f32)
 GKOC_DECL_BICG(double, f64)
 GKOC_DECL_BICG(float, f32)
 
+/* gcr::{initialize, restart, step_1} (core/solver/gcr_kernels.hpp;
+ * reference/solver/gcr_kernels.cpp:24-88): the restarted generalised conjugate
+ * residual method keeps its search directions p and A p in two tall Dense matrices of
+ * (krylov_dim + 1) x rows rows; restart copies the preconditioned residual and its
+ * image into the first slot, step_1 is the update with t = <r, Ap> / ||Ap||^2. */
+#define GKOC_DECL_GCR(T, TN)                                                   \
+    int gkoc_gcr_initialize_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,  \
+                                 const T* b, int64_t ldb, T* residual,         \
+                                 int64_t ldr, uint8_t* stop_status);           \
+    int gkoc_gcr_restart_##TN(                                                 \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* residual,        \
+        int64_t ldr, const T* a_residual, int64_t ldar, T* p_bases,            \
+        int64_t ldp, T* ap_bases, int64_t ldap, uint64_t* final_iter_nums);    \
+    int gkoc_gcr_step_1_##TN(                                                  \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx,        \
+        T* residual, int64_t ldr, const T* p, int64_t ldp, const T* ap,        \
+        int64_t ldap, const T* ap_norm, const T* rap,                          \
+        const uint8_t* stop_status);
+GKOC_DECL_GCR(double, f64)
+GKOC_DECL_GCR(float, f32)
+
 /* ir::initialize (core/solver/ir_kernels.hpp:19-21; reference/solver/ir_kernels.cpp:20-27):
  * reset the stopping status; used by Ir and Chebyshev.
  * chebyshev::{init_update, update} (core/solver/chebyshev_kernels.hpp:21-40;

@@ -911,6 +911,73 @@ int64_t oracle_krylov_solve_f64_i32(int kind, int64_t n, const int32_t* row_ptrs
         free(t_cols);
         free(t_vals);
         free(tb);
+    } else if (kind == 8) { /* Gcr, core/solver/gcr.cpp:95-320; p0 = krylov_dim */
+        const int64_t kd = (int64_t)p0 > 0 ? (int64_t)p0 : 100;
+        double* base = (double*)calloc(N * (size_t)(2 * (kd + 1) + 3), sizeof(double));
+        double *r = base, *pr = base + N, *apr = base + 2 * N;
+        double* P = base + 3 * N;
+        double* AP = P + N * (size_t)(kd + 1);
+        double* ap_norms = (double*)calloc((size_t)kd + 1, sizeof(double));
+        double rap, minus_beta, rnorm;
+        int64_t restart_iter = 0;
+        memcpy(r, b, sizeof(double) * N); /* gcr::initialize */
+        stop = 0;
+        RESID(r);
+        BASELINE(r);
+        apply_precond(m, n, r, pr);
+        SPMV(pr, apr);
+        memcpy(P, pr, sizeof(double) * N); /* gcr::restart */
+        memcpy(AP, apr, sizeof(double) * N);
+        for (;;) {
+            ++iter;
+            oracle_dense_compute_norm2_f64(n, 1, r, 1, &rnorm, 0);
+            tau = rnorm;
+            one_changed = 0;
+            {
+                int all = 0;
+                if (iter >= max_iters) {
+                    if ((stop & 0x3f) == 0) stop |= (uint8_t)1 | 0x40;
+                    all = 1;
+                } else {
+                    all = oracle_residual_norm_f64(1, &rnorm, &tau0, reduction, 2, 1, &stop, 0,
+                                                   &one_changed);
+                }
+                if (all) break;
+            }
+            if (restart_iter == kd) {
+                memcpy(P, pr, sizeof(double) * N);
+                memcpy(AP, apr, sizeof(double) * N);
+                restart_iter = 0;
+            }
+            double* Ap = AP + N * (size_t)restart_iter;
+            double* pp = P + N * (size_t)restart_iter;
+            DOT(r, Ap, &rap);
+            oracle_dense_compute_norm2_f64(n, 1, Ap, 1, &ap_norms[restart_iter], 1);
+            if (!(stop & 0x3f) && ap_norms[restart_iter] != 0.0) { /* gcr::step_1 */
+                const double t = rap / ap_norms[restart_iter];
+                for (int64_t i = 0; i < n; ++i) {
+                    x[i] += t * pp[i];
+                    r[i] -= t * Ap[i];
+                }
+            }
+            apply_precond(m, n, r, pr);
+            SPMV(pr, apr);
+            double* next_Ap = AP + N * (size_t)(restart_iter + 1);
+            double* next_p = P + N * (size_t)(restart_iter + 1);
+            memcpy(next_Ap, apr, sizeof(double) * N);
+            memcpy(next_p, pr, sizeof(double) * N);
+            for (int64_t k = 0; k <= restart_iter; ++k) {
+                const double* Apk = AP + N * (size_t)k;
+                const double* pk = P + N * (size_t)k;
+                DOT(apr, Apk, &minus_beta);
+                minus_beta = minus_beta / ap_norms[k]; /* dense::inv_scale */
+                for (int64_t i = 0; i < n; ++i) next_Ap[i] -= minus_beta * Apk[i];
+                for (int64_t i = 0; i < n; ++i) next_p[i] -= minus_beta * pk[i];
+            }
+            ++restart_iter;
+        }
+        free(base);
+        free(ap_norms);
     } else {
         iter = -2;
     }

@@ -502,12 +502,12 @@ def _make_precond(row_ptrs, cols, vals, precond, max_block_size):
     return m, keep
 
 
-KRYLOV_KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4, "ir": 5, "chebyshev": 6, "bicg": 7}
+KRYLOV_KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4, "ir": 5, "chebyshev": 6, "bicg": 7, "gcr": 8}
 
 
 def krylov_solve(kind, row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,
                  baseline="rhs_norm", precond=None, max_block_size=8, relaxation=1.0,
-                 foci=(0.0, 1.0)):
+                 foci=(0.0, 1.0), krylov_dim=100):
     """Bicgstab / Cgs / Fcg / PipeCg / Ir (relaxation; inner solver = precond) /
     Chebyshev (foci) with Combined(Iteration, ResidualNorm); f64 / int32, one rhs."""
     n = len(row_ptrs) - 1
@@ -521,7 +521,8 @@ def krylov_solve(kind, row_ptrs, cols, vals, b, x0=None, max_iters=1000, reducti
     f.restype = C.c_int64
     iters = f(C.c_int(KRYLOV_KINDS[kind]), _i64(n), _p(row_ptrs), _p(cols), _p(vals), C.byref(m),
               _p(b), _p(x), _i64(max_iters), C.c_double(reduction), C.c_int(base),
-              C.c_double(relaxation if kind == "ir" else foci[0]), C.c_double(foci[1]),
+              C.c_double(relaxation if kind == "ir" else (krylov_dim if kind == "gcr" else foci[0])),
+              C.c_double(foci[1]),
               C.byref(resnorm))
     del keep
     return x, int(iters), resnorm.value
@@ -531,9 +532,9 @@ def krylov_step(name, rows, cols, *arrays):
     """oracle_<name>_<f64|f32>(rows, cols, ld = cols, arrays...): the step kernels of
     bicgstab / cgs / fcg / pipe_cg, operands in the order of the reference kernel's
     signature; the arrays (C-contiguous numpy) are updated in place."""
-    vt = next(a.dtype for a in arrays if a.dtype != np.uint8)
+    vt = next(a.dtype for a in arrays if a.dtype not in (np.uint8, np.uint64))
     for a in arrays:
-        assert a.flags.c_contiguous and a.dtype in (vt, np.uint8), "mixed value types"
+        assert a.flags.c_contiguous and a.dtype in (vt, np.uint8, np.uint64), "mixed value types"
     getattr(lib(), f"oracle_{name}_{_VT[np.dtype(vt)]}")(
         _i64(rows), _i64(cols), _i64(cols), *[_p(a) for a in arrays])
 

@@ -189,6 +189,16 @@ class CsrHandle:
         lib().ref_hybrid_spmv(self.h, _p(b2), _p(out), C.c_int64(b2.shape[1]))
         return out if np.ndim(b) == 2 else out[:, 0]
 
+    def gcr_solve(self, b, x0=None, krylov_dim=100, max_iters=1000, reduction=1e-10, precond_block_size=0):
+        x = np.zeros(self.n_rows) if x0 is None else np.array(x0, dtype=np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        rn = C.c_double(0)
+        f = lib().ref_gcr_solve
+        f.restype = C.c_int64
+        it = f(self.h, C.c_uint32(precond_block_size), _p(b), _p(x), C.c_int64(krylov_dim),
+               C.c_int64(max_iters), C.c_double(reduction), C.byref(rn))
+        return x, int(it), rn.value
+
     def stationary_solve(self, kind, b, x0=None, max_iters=1000, reduction=1e-10,
                          baseline="rhs_norm", precond_block_size=0, relaxation=1.0, foci=(0.0, 1.0)):
         """Ir (inner solver Jacobi / Identity) and Chebyshev of the reference"""

@@ -149,6 +149,10 @@ def bicg():
     arrays["bicg_lim_x"], arrays["bicg_lim_it_rn"] = x, np.array([it, rn])
     trp, tc, tv = h.transpose()
     arrays["t_row_ptrs"], arrays["t_cols"], arrays["t_vals"] = trp, tc, tv
+    for kd in (100, 6):
+        for bs in (0, 8):
+            x, it, rn = h.gcr_solve(rhs, krylov_dim=kd, max_iters=400, reduction=1e-9, precond_block_size=bs)
+            arrays[f"gcr_{kd}_{bs}_x"], arrays[f"gcr_{kd}_{bs}_it_rn"] = x, np.array([it, rn])
     save("bicg.npz", **arrays)
 
 

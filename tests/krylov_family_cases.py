@@ -42,6 +42,8 @@ CASES = [
                           r2=[[5.25, 4.0], [5.25, 4.0]])),
     ("bicg", "step_2", dict(x=-2, p=3, r=4, q=-5, r2=4, q2=-5, rho=[1, 1], beta=[0, 0]),
      [RUN, RUN], dict(x=-2.0, r=4.0, r2=4.0)),
+    ("gcr", "step_1", dict(x=1, residual=2, p=3, Ap=4, Ap_norm=[8, 0], rAp=[2, 5]),
+     [RUN, RUN], dict(x=[[1.75, 1.0], [1.75, 1.0]], residual=[[1.0, 2.0], [1.0, 2.0]])),
     ("cgs", "step_1", dict(r=1, p=-2, q=3, u=-4, beta=[2, 2], rho_prev=[2, 3], rho=[-4, 4]),
      [RUN, STOPPED], dict(u=[[-5.0, -4.0], [-5.0, -4.0]], p=[[-19.0, -2.0], [-19.0, -2.0]], beta=[-2.0, 2.0])),
     ("cgs", "step_1", dict(r=1, p=-2, q=3, u=-4, beta=[2, 2], rho_prev=[0, 0], rho=[3, 3]),
@@ -88,6 +90,8 @@ def materialise(solver, kernel, inputs, stop, dtype=np.float64, rows=2, cols=2):
             arrays[name] = np.full((rows, cols), float(inputs.get(name, 0.0)), dtype=dtype)
         elif kind in "Ss":
             arrays[name] = np.array(inputs.get(name, [0.0] * cols), dtype=dtype)
+        elif kind == "U":
+            arrays[name] = np.full(cols, 7, dtype=np.uint64)
         else:
             arrays[name] = np.array(stop, dtype=np.uint8)
     return arrays
@@ -112,6 +116,8 @@ def random_case(solver, kernel, rows, cols, dtype, seed, zero_col=None, stopped_
             arrays[name] = (rng.uniform(0.5, 2.0, cols) * rng.choice([-1, 1], cols)).astype(dtype)
             if zero_col is not None and zero_col < cols:
                 arrays[name][zero_col] = 0
+        elif kind == "U":
+            arrays[name] = np.full(cols, 7, dtype=np.uint64)
         else:
             st = np.zeros(cols, dtype=np.uint8)
             if stopped_col is not None and stopped_col < cols:

@@ -46,7 +46,7 @@ def run_device(gexec, solver, kernel, arrays, strides=None):
          gexec.stream, rows, cols, *args)
     gexec.synchronize()
     for name, kind in spec:
-        if kind in "vst":
+        if kind in "vstpU":
             d = dev[name]
             arrays[name][...] = d.to_numpy() if kind == "v" else d.cpu().numpy()
 
@@ -301,3 +301,27 @@ def _solve_kind(g, gexec, cls, a, rhs, max_iters, reduction, bs, x0=None, baseli
     x = g.Dense.from_numpy(gexec, np.zeros(len(rhs)) if x0 is None else x0)
     s.apply(g.Dense.from_numpy(gexec, rhs), x)
     return x.to_numpy()[:, 0], s
+
+
+def test_gcr_matches_reference_golden(gexec, oracle):
+    import ginkgo_amd as g
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "bicg.npz"))
+    rp, ci, v, rhs = (gold[k] for k in ("row_ptrs", "cols", "vals", "rhs"))
+    n = len(rp) - 1
+    a = g.Csr.from_arrays(gexec, (n, n), rp, ci, v)
+    for kd in (100, 6):
+        for bs in (0, 8):
+            f = g.Gcr.build().with_krylov_dim(kd).with_criteria(
+                g.stop.Iteration.build().with_max_iters(400),
+                g.stop.ResidualNorm.build().with_reduction_factor(1e-9))
+            if bs:
+                f = f.with_preconditioner(g.Jacobi.build().with_max_block_size(bs))
+            s = f.on(gexec).generate(a)
+            x = g.Dense.from_numpy(gexec, np.zeros(n))
+            s.apply(g.Dense.from_numpy(gexec, rhs), x)
+            it_ref, _ = gold[f"gcr_{kd}_{bs}_it_rn"]
+            assert s.has_converged and abs(s.num_iterations - int(it_ref)) <= 1, (kd, bs, s.num_iterations, it_ref)
+            xr = gold[f"gcr_{kd}_{bs}_x"]
+            assert np.linalg.norm(x.to_numpy()[:, 0] - xr) <= 1e-7 * np.linalg.norm(xr)
+            r = rhs - oracle.csr_spmv(rp, ci, v, x.to_numpy()[:, 0])
+            assert np.linalg.norm(r) <= 2e-9 * np.linalg.norm(rhs)

@@ -653,3 +653,24 @@ def test_live_reference_bicg(oracle):
                                            max_block_size=max(bs, 1))
         xr, itr, rnr = h.krylov_solve("bicg", rhs, max_iters=200, reduction=1e-10, precond_block_size=bs)
         assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
+
+
+def test_golden_and_live_gcr(oracle):
+    g = gold("bicg.npz")
+    rp, ci, v, rhs = g["row_ptrs"], g["cols"], g["vals"], g["rhs"]
+    for kd in (100, 6):
+        for bs, pre in ((0, None), (8, "block")):
+            x, it, rn = oracle.krylov_solve("gcr", rp, ci, v, rhs, max_iters=400, reduction=1e-9, precond=pre,
+                                            max_block_size=max(bs, 1), krylov_dim=kd)
+            assert (it, rn) == tuple(g[f"gcr_{kd}_{bs}_it_rn"]) and np.array_equal(x, g[f"gcr_{kd}_{bs}_x"])
+    if os.path.exists(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libgko_ref_shim.so")):
+        ref = _ref()
+        rp, ci, v = oracle.stencil_csr(3, 6)
+        h = ref.CsrHandle("reference", rp, ci, v)
+        b = np.random.default_rng(3).uniform(-1, 1, len(rp) - 1)
+        for kd, bs in ((100, 1), (4, 4)):
+            pre = "scalar" if bs == 1 else "block"
+            xo, ito, rno = oracle.krylov_solve("gcr", rp, ci, v, b, max_iters=200, reduction=1e-10, precond=pre,
+                                               max_block_size=bs, krylov_dim=kd)
+            xr, itr, rnr = h.gcr_solve(b, krylov_dim=kd, max_iters=200, reduction=1e-10, precond_block_size=bs)
+            assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
