@@ -12,10 +12,10 @@ from .executor import Cdna4Executor
 from .matrix import Coo, Csr, Dense, Ell, Hybrid, Sellp, scalar, stencil_csr
 from .preconditioner import Jacobi, compute_storage_scheme
 from .solver import Cg, Gmres, Identity, ortho_method
-from .krylov import Bicg, Bicgstab, Cgs, Chebyshev, Fcg, Gcr, Ir, PipeCg
+from .krylov import Bicg, Bicgstab, Cgs, Chebyshev, Fcg, Gcr, Ir, Minres, PipeCg
 from . import stop
 
-__all__ = ["Coo", "Hybrid", "Bicg", "Bicgstab", "Chebyshev", "Gcr", "Ir", "Cgs", "Fcg", "PipeCg", "Cdna4Executor", "Csr", "Dense", "Ell", "Sellp", "scalar",
+__all__ = ["Coo", "Hybrid", "Bicg", "Bicgstab", "Chebyshev", "Gcr", "Ir", "Minres", "Cgs", "Fcg", "PipeCg", "Cdna4Executor", "Csr", "Dense", "Ell", "Sellp", "scalar",
            "stencil_csr", "Jacobi", "compute_storage_scheme", "Cg", "Gmres", "ortho_method", "Identity",
            "stop", "GkoError", "NotCompiled", "NotSupported",
            "DimensionMismatch", "LIB_PATH"]

@@ -8,6 +8,7 @@
 //                                                   (reference/solver/pipe_cg_kernels.cpp:24-164)
 //   bicg::{initialize, step_1, step_2}              (reference/solver/bicg_kernels.cpp:24-110)
 //   gcr::{initialize, restart, step_1}              (reference/solver/gcr_kernels.cpp:24-88)
+//   minres::{initialize, step_1, step_2}            (reference/solver/minres_kernels.cpp:24-150)
 //   chebyshev::{init_update, update}                (reference/solver/chebyshev_kernels.cpp:20-66)
 //   ir::initialize                                  (reference/solver/ir_kernels.cpp:20-27)
 // All of them are "per column: a few scalars; per element: a short update that
@@ -451,6 +452,114 @@ struct op_bicg_step2 {
     }
 };
 
+// ------------------------------------------------------------------ minres
+// reference/solver/minres_kernels.cpp:24-150.  safe_divide(a, b) = b == 0 ? 0 : a / b.
+template <typename T>
+__device__ __forceinline__ T safe_div(T a, T b)
+{
+    return b == T(0) ? T(0) : a / b;
+}
+
+// scalars of initialize: beta = sqrt(<r, z>) etc.  One thread per column; runs before
+// the vector kernel, which reads the new beta.
+template <typename T>
+__global__ void minres_init_scalars_kernel(int64_t cols, T* beta, T* gamma, T* delta,
+                                           T* cos_prev, T* cosv, T* sin_prev, T* sinv,
+                                           T* eta_next, T* eta, uint8_t* stop)
+{
+    const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    delta[j] = gamma[j] = cos_prev[j] = sin_prev[j] = sinv[j] = T(0);
+    cosv[j] = T(1);
+    const T b = sqrt(beta[j]);
+    eta_next[j] = eta[j] = beta[j] = b;
+    stop[j] = 0;
+}
+
+// q = r / beta ; z = z / beta ; p = p_prev = q_prev = q_tilde = 0
+// in = {r, z}, out = {q, z, p, p_prev, q_prev, q_tilde}
+template <typename T>
+struct op_minres_init {
+    const T* beta;
+    struct scalars {
+        T beta;
+    };
+    __device__ scalars load(int64_t c) const { return {beta[c]}; }
+    __device__ bool skip(const scalars&) const { return false; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        out[0] = safe_div(in[0], s.beta);
+        out[1] = safe_div(in[1], s.beta);
+        out[2] = out[3] = out[4] = out[5] = T(0);
+    }
+};
+
+// the Givens update of step_1: all scalars, one thread per column
+template <typename T>
+__global__ void minres_step1_kernel(int64_t cols, T* alpha, T* beta, T* gamma, T* delta,
+                                    T* cos_prev, T* cosv, T* sin_prev, T* sinv, T* eta,
+                                    T* eta_next, T* tau, const uint8_t* stop)
+{
+    const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (j >= cols || status_has_stopped(stop[j])) return;
+    const T bt = sqrt(beta[j]);
+    beta[j] = bt;
+    delta[j] = sin_prev[j] * gamma[j];
+    const T tmp_d = gamma[j], tmp_a = alpha[j];
+    const T c_old = cosv[j], s_old = sinv[j], cp_old = cos_prev[j];
+    gamma[j] = cp_old * c_old * tmp_d + s_old * tmp_a;
+    T a = -s_old * cp_old * tmp_d + c_old * tmp_a;
+    cos_prev[j] = c_old;                      // swap(cos, cos_prev), swap(sin, sin_prev)
+    sin_prev[j] = s_old;
+    T c, sn;
+    if (a == T(0)) {
+        c = T(0);
+        sn = T(1);
+    } else {
+        const T scale = fabs(a) + fabs(bt);
+        const T as = fabs(a / scale), bs = fabs(bt / scale);
+        const T hyp = scale * sqrt(as * as + bs * bs);
+        c = a / hyp;
+        sn = bt / hyp;
+    }
+    a = c * a + sn * bt;
+    alpha[j] = a;
+    cosv[j] = c;
+    sinv[j] = sn;
+    tau[j] = sn * sn * tau[j];
+    const T e = eta_next[j];
+    eta[j] = e;
+    eta_next[j] = -sn * e;
+}
+
+// p = (z - gamma p_prev - delta p) / alpha ; x += cos eta p ; q_prev = v ;
+// q_new = v / beta ; v = q_old beta ; z = z_tilde / beta
+// in = {x, p, p_prev, z, z_tilde, q, v}, out = {x, p, z, q, q_prev, v}
+template <typename T>
+struct op_minres_step2 {
+    const T *alpha, *beta, *gamma, *delta, *cosv, *eta;
+    const uint8_t* stop;
+    struct scalars {
+        T alpha, beta, gamma, delta, cos, eta;
+        bool stopped;
+    };
+    __device__ scalars load(int64_t c) const
+    {
+        return {alpha[c], beta[c], gamma[c], delta[c], cosv[c], eta[c], status_has_stopped(stop[c])};
+    }
+    __device__ bool skip(const scalars& s) const { return s.stopped; }
+    __device__ void apply(const scalars& s, const T* in, T* out) const
+    {
+        const T p = safe_div(in[3] - s.gamma * in[2] - s.delta * in[1], s.alpha);
+        out[0] = in[0] + s.cos * s.eta * p;
+        out[1] = p;
+        out[2] = safe_div(in[4], s.beta);
+        out[3] = safe_div(in[6], s.beta);
+        out[4] = in[6];
+        out[5] = in[5] * s.beta;
+    }
+};
+
 // --------------------------------------------------------------------- gcr
 // reference/solver/gcr_kernels.cpp:24-88.
 // step_1: t = rAp / Ap_norm ; x += t p ; residual -= t Ap   (Ap_norm != 0)
@@ -804,6 +913,60 @@ GKOC_DEF_KRYLOV(float, f32)
     }
 GKOC_DEF_BICG(double, f64)
 GKOC_DEF_BICG(float, f32)
+
+#define GKOC_DEF_MINRES(T, TN)                                                            \
+    extern "C" int gkoc_minres_initialize_##TN(                                           \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* r, int64_t ldr, T* z,       \
+        int64_t ldz, T* p, int64_t ldp, T* p_prev, int64_t ldpp, T* q, int64_t ldq,       \
+        T* q_prev, int64_t ldqp, T* q_tilde, int64_t ldqt, T* beta, T* gamma, T* delta,   \
+        T* cos_prev, T* cosv, T* sin_prev, T* sinv, T* eta_next, T* eta,                  \
+        uint8_t* stop_status)                                                             \
+    {                                                                                     \
+        if (cols > 0) {                                                                   \
+            minres_init_scalars_kernel<T>                                                 \
+                <<<dim3(unsigned(ceildiv(cols, 256))), dim3(256), 0, as_stream(s)>>>(     \
+                    cols, beta, gamma, delta, cos_prev, cosv, sin_prev, sinv, eta_next,   \
+                    eta, stop_status);                                                    \
+            GKOC_LAUNCH_OK();                                                             \
+        }                                                                                 \
+        operand_list<T, 2, 6> o;                                                          \
+        o.in(r, ldr).in(z, ldz).out(q, ldq).out(z, ldz).out(p, ldp).out(p_prev, ldpp)     \
+            .out(q_prev, ldqp).out(q_tilde, ldqt);                                        \
+        return launch_elementwise<T, op_minres_init<T>, 2, 6>(s, rows, cols, o.a,         \
+                                                              op_minres_init<T>{beta},    \
+                                                              false);                     \
+    }                                                                                     \
+    extern "C" int gkoc_minres_step_1_##TN(                                               \
+        gkoc_stream_t s, int64_t cols, T* alpha, T* beta, T* gamma, T* delta,             \
+        T* cos_prev, T* cosv, T* sin_prev, T* sinv, T* eta, T* eta_next, T* tau,          \
+        const uint8_t* stop_status)                                                       \
+    {                                                                                     \
+        if (cols <= 0) return GKOC_OK;                                                    \
+        minres_step1_kernel<T><<<dim3(unsigned(ceildiv(cols, 256))), dim3(256), 0,        \
+                                 as_stream(s)>>>(cols, alpha, beta, gamma, delta,         \
+                                                 cos_prev, cosv, sin_prev, sinv, eta,     \
+                                                 eta_next, tau, stop_status);             \
+        GKOC_LAUNCH_OK();                                                                 \
+        return GKOC_OK;                                                                   \
+    }                                                                                     \
+    extern "C" int gkoc_minres_step_2_##TN(                                               \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* p,             \
+        int64_t ldp, const T* p_prev, int64_t ldpp, T* z, int64_t ldz, const T* z_tilde,  \
+        int64_t ldzt, T* q, int64_t ldq, T* q_prev, int64_t ldqp, T* v, int64_t ldv,      \
+        const T* alpha, const T* beta, const T* gamma, const T* delta, const T* cosv,     \
+        const T* eta, const uint8_t* stop_status)                                         \
+    {                                                                                     \
+        operand_list<T, 7, 6> o;                                                          \
+        o.in(x, ldx).in(p, ldp).in(p_prev, ldpp).in(z, ldz).in(z_tilde, ldzt).in(q, ldq)  \
+            .in(v, ldv).out(x, ldx).out(p, ldp).out(z, ldz).out(q, ldq)                   \
+            .out(q_prev, ldqp).out(v, ldv);                                               \
+        return launch_elementwise<T, op_minres_step2<T>, 7, 6>(                           \
+            s, rows, cols, o.a,                                                           \
+            op_minres_step2<T>{alpha, beta, gamma, delta, cosv, eta, stop_status},        \
+            false);                                                                       \
+    }
+GKOC_DEF_MINRES(double, f64)
+GKOC_DEF_MINRES(float, f32)
 
 #define GKOC_DEF_GCR(T, TN)                                                               \
     extern "C" int gkoc_gcr_initialize_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,   \

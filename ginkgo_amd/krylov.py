@@ -7,6 +7,7 @@ Each class is the driver of the reference with the same kernel sequence -
   PipeCg    core/solver/pipe_cg.cpp:95-297
   Bicg      core/solver/bicg.cpp:106-230
   Gcr       core/solver/gcr.cpp:95-320
+  Minres    core/solver/minres.cpp:110-230
   Ir        core/solver/ir.cpp:189-255         (with core/solver/update_residual.hpp)
   Chebyshev core/solver/chebyshev.cpp:203-296  (likewise)
 - issuing the fused vector updates of csrc/krylov_steps.hip (gkoc_bicgstab_*,
@@ -294,6 +295,61 @@ class Bicg(_Krylov):
                  rho.values, stop)
             prev_rho, rho = rho, prev_rho
         self._finish(it, stop, r)
+
+
+class Minres(_Krylov):
+    """MINRES for symmetric, possibly indefinite systems (core/solver/minres.cpp:110-230):
+    preconditioned Lanczos recurrence + Givens rotations.  The driver hands no residual to
+    the criterion, only tau = ||z||^2 (ImplicitResidualNorm uses it; a plain ResidualNorm
+    recomputes b - A x, as in the reference)."""
+
+    @staticmethod
+    def build():
+        return _SolverFactory(Minres)
+
+    def apply_impl(self, b, x):
+        a, m = self.system_matrix, self.preconditioner
+        ex, one, neg_one, stop = self._common(b)
+        suf = VT[b.dtype]
+        rows, cols = b.size
+        r, z, p, q, v, z_tilde, p_prev, q_prev = (
+            self._vec(k, b) for k in ("r", "z", "p", "q", "v", "z_tilde", "p_prev", "q_prev"))
+        (alpha, beta, gamma, delta, eta_next, eta, tau, cos_prev, cos, sin_prev, sin) = (
+            self._scal(k, b) for k in ("alpha", "beta", "gamma", "delta", "eta_next", "eta", "tau",
+                                       "cos_prev", "cos", "sin_prev", "sin"))
+        st = lambda: ex.stream
+        r.copy_from(b)
+        a.apply(neg_one, x, one, r)
+        crit = _stop.combine(self.criteria, a, b, x, r)
+        m.apply(r, z)
+        r.compute_conj_dot(z, beta)
+        z.compute_conj_dot(z, tau)
+        # (v takes the place of q_tilde, minres.cpp:169-178)
+        call("gkoc_minres_initialize_" + suf, st(), rows, cols, r.values, r.ld, z.values, z.ld,
+             p.values, p.ld, p_prev.values, p_prev.ld, q.values, q.ld, q_prev.values, q_prev.ld,
+             v.values, v.ld, beta.values, gamma.values, delta.values, cos_prev.values, cos.values,
+             sin_prev.values, sin.values, eta_next.values, eta.values, stop)
+        it = -1
+        while True:
+            it += 1
+            if crit.check(1, True, stop, {"num_iterations": it, "implicit_sq_residual_norm": tau,
+                                          "solution": x})[0]:
+                break
+            a.apply(one, z, neg_one, v)                   # v = A z - v
+            v.compute_conj_dot(z, alpha)
+            v.sub_scaled(alpha, q)
+            m.apply(v, z_tilde)
+            v.compute_conj_dot(z_tilde, beta)
+            call("gkoc_minres_step_1_" + suf, st(), cols, alpha.values, beta.values, gamma.values,
+                 delta.values, cos_prev.values, cos.values, sin_prev.values, sin.values, eta.values,
+                 eta_next.values, tau.values, stop)
+            p, p_prev = p_prev, p
+            call("gkoc_minres_step_2_" + suf, st(), rows, cols, x.values, x.ld, p.values, p.ld,
+                 p_prev.values, p_prev.ld, z.values, z.ld, z_tilde.values, z_tilde.ld, q.values,
+                 q.ld, q_prev.values, q_prev.ld, v.values, v.ld, alpha.values, beta.values,
+                 gamma.values, delta.values, cos.values, eta.values, stop)
+            gamma, beta = beta, gamma
+        self._finish(it, stop, r)      # (r is the initial residual, as the logger sees it)
 
 
 class Gcr(_Krylov):

@@ -92,6 +92,8 @@ class ResidualNorm:
             raise NotSupported(f"unknown baseline {baseline}")
         self.u_dense_tau = Dense.create(ex, (1, cols), b.dtype)
         self.flags = ex.zeros((2,), torch.uint8)
+        self.system = (a, b) if a is not None else None
+        self._scratch = None
 
     def _select(self, upd):
         if upd.get("ignore_residual_check"):
@@ -106,6 +108,18 @@ class ResidualNorm:
                 tau = upd["residual_norm"]
             elif upd.get("residual") is not None:
                 upd["residual"].compute_norm2(self.u_dense_tau)
+                tau = self.u_dense_tau
+            elif upd.get("solution") is not None and self.system is not None:
+                # no residual at hand: b - A x is computed (residual_norm.cpp:139-160)
+                a, b = self.system
+                if self._scratch is None or self._scratch.size != b.size:
+                    from .matrix import Dense, scalar
+                    self._scratch = Dense.create(self.exec, b.size, b.dtype)
+                    self._one = scalar(self.exec, 1.0, b.dtype)
+                    self._neg = scalar(self.exec, -1.0, b.dtype)
+                self._scratch.copy_from(b)
+                a.apply(self._neg, upd["solution"], self._one, self._scratch)
+                self._scratch.compute_norm2(self.u_dense_tau)
                 tau = self.u_dense_tau
             else:
                 raise NotSupported("ResidualNorm needs a residual")

@@ -857,6 +857,33 @@ GKOC_DECL_BICG(float, f32)
 GKOC_DECL_GCR(double, f64)
 GKOC_DECL_GCR(float, f32)
 
+/* minres::{initialize, step_1, step_2} (core/solver/minres_kernels.hpp;
+ * reference/solver/minres_kernels.cpp:24-150): MINRES for symmetric (indefinite)
+ * systems.  initialize: beta (holding <r, z>) becomes its square root, q = r / beta,
+ * z /= beta, the other vectors and the rotation scalars are reset.  step_1: the Givens
+ * update of the tridiagonal recurrence, scalars only.  step_2: the update of the search
+ * direction p, the solution x and the Lanczos vectors. */
+#define GKOC_DECL_MINRES(T, TN)                                                \
+    int gkoc_minres_initialize_##TN(                                           \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* r, int64_t ldr,  \
+        T* z, int64_t ldz, T* p, int64_t ldp, T* p_prev, int64_t ldpp, T* q,   \
+        int64_t ldq, T* q_prev, int64_t ldqp, T* q_tilde, int64_t ldqt,        \
+        T* beta, T* gamma, T* delta, T* cos_prev, T* cosv, T* sin_prev,        \
+        T* sinv, T* eta_next, T* eta, uint8_t* stop_status);                   \
+    int gkoc_minres_step_1_##TN(                                               \
+        gkoc_stream_t s, int64_t cols, T* alpha, T* beta, T* gamma, T* delta,  \
+        T* cos_prev, T* cosv, T* sin_prev, T* sinv, T* eta, T* eta_next,       \
+        T* tau, const uint8_t* stop_status);                                   \
+    int gkoc_minres_step_2_##TN(                                               \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* p,  \
+        int64_t ldp, const T* p_prev, int64_t ldpp, T* z, int64_t ldz,         \
+        const T* z_tilde, int64_t ldzt, T* q, int64_t ldq, T* q_prev,          \
+        int64_t ldqp, T* v, int64_t ldv, const T* alpha, const T* beta,        \
+        const T* gamma, const T* delta, const T* cosv, const T* eta,           \
+        const uint8_t* stop_status);
+GKOC_DECL_MINRES(double, f64)
+GKOC_DECL_MINRES(float, f32)
+
 /* ir::initialize (core/solver/ir_kernels.hpp:19-21; reference/solver/ir_kernels.cpp:20-27):
  * reset the stopping status; used by Ir and Chebyshev.
  * chebyshev::{init_update, update} (core/solver/chebyshev_kernels.hpp:21-40;

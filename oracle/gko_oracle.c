@@ -978,6 +978,40 @@ int64_t oracle_krylov_solve_f64_i32(int kind, int64_t n, const int32_t* row_ptrs
         }
         free(base);
         free(ap_norms);
+    } else if (kind == 9) { /* Minres, core/solver/minres.cpp:110-230 */
+        double *r = V[0], *z = V[1], *p = V[2], *q = V[3], *v = V[4], *z_tilde = V[5],
+               *p_prev = V[6], *q_prev = V[7], *rt = V[8];
+        double alpha = 0, beta, gamma, delta, eta_next, eta, tau_sq, cos_prev, cosv, sin_prev, sinv;
+        memcpy(r, b, sizeof(double) * N);
+        RESID(r);
+        BASELINE(r);
+        apply_precond(m, n, r, z);
+        DOT(r, z, &beta);
+        DOT(z, z, &tau_sq);
+        /* the driver hands v as q_tilde to initialize (minres.cpp:169-178) */
+        oracle_minres_initialize_f64(n, 1, 1, r, z, p, p_prev, q, q_prev, v, &beta, &gamma, &delta,
+                                     &cos_prev, &cosv, &sin_prev, &sinv, &eta_next, &eta, &stop);
+        for (;;) {
+            ++iter;
+            /* ResidualNorm without a residual computes b - A x (residual_norm.cpp:120-160) */
+            memcpy(rt, b, sizeof(double) * N);
+            RESID(rt);
+            if (krylov_check(iter, max_iters, n, rt, tau0, reduction, 1, &stop, &one_changed, &tau)) break;
+            oracle_csr_advanced_spmv_f64_i32(n, 1.0, row_ptrs, cols, vals, z, 1, -1.0, v, 1, 1);
+            DOT(v, z, &alpha);
+            for (int64_t i = 0; i < n; ++i) v[i] -= alpha * q[i];
+            apply_precond(m, n, v, z_tilde);
+            DOT(v, z_tilde, &beta);
+            oracle_minres_step_1_f64(1, &alpha, &beta, &gamma, &delta, &cos_prev, &cosv, &sin_prev,
+                                     &sinv, &eta, &eta_next, &tau_sq, &stop);
+            { double* t_ = p; p = p_prev; p_prev = t_; }
+            oracle_minres_step_2_f64(n, 1, 1, x, p, p_prev, z, z_tilde, q, q_prev, v, &alpha, &beta,
+                                     &gamma, &delta, &cosv, &eta, &stop);
+            { const double t_ = gamma; gamma = beta; beta = t_; }
+        }
+        /* the Convergence logger is handed r, which Minres never updates: it reports the
+         * norm of the INITIAL residual (minres.cpp:196-198) */
+        oracle_dense_compute_norm2_f64(n, 1, r, 1, &tau, 0);
     } else {
         iter = -2;
     }

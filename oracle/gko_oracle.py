@@ -502,7 +502,7 @@ def _make_precond(row_ptrs, cols, vals, precond, max_block_size):
     return m, keep
 
 
-KRYLOV_KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4, "ir": 5, "chebyshev": 6, "bicg": 7, "gcr": 8}
+KRYLOV_KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4, "ir": 5, "chebyshev": 6, "bicg": 7, "gcr": 8, "minres": 9}
 
 
 def krylov_solve(kind, row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,
@@ -535,8 +535,8 @@ def krylov_step(name, rows, cols, *arrays):
     vt = next(a.dtype for a in arrays if a.dtype not in (np.uint8, np.uint64))
     for a in arrays:
         assert a.flags.c_contiguous and a.dtype in (vt, np.uint8, np.uint64), "mixed value types"
-    getattr(lib(), f"oracle_{name}_{_VT[np.dtype(vt)]}")(
-        _i64(rows), _i64(cols), _i64(cols), *[_p(a) for a in arrays])
+    dims = [_i64(cols)] if all(a.ndim == 1 for a in arrays) else [_i64(rows), _i64(cols), _i64(cols)]
+    getattr(lib(), f"oracle_{name}_{_VT[np.dtype(vt)]}")(*dims, *[_p(a) for a in arrays])
 
 
 def cg_solve(row_ptrs, cols, vals, b, x0=None, max_iters=1000, reduction=1e-10,

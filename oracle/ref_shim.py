@@ -214,7 +214,7 @@ class CsrHandle:
                C.c_double(foci[1]), C.byref(rn))
         return x, int(it), rn.value
 
-    KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4, "bicg": 7}
+    KINDS = {"bicgstab": 1, "cgs": 2, "fcg": 3, "pipe_cg": 4, "bicg": 7, "minres": 9}
 
     def krylov_solve(self, kind, b, x0=None, max_iters=1000, reduction=1e-10,
                      baseline="rhs_norm", precond_block_size=0):

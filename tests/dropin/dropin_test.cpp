@@ -28,6 +28,7 @@
 #include <ginkgo/core/solver/cgs.hpp>
 #include <ginkgo/core/solver/chebyshev.hpp>
 #include <ginkgo/core/solver/ir.hpp>
+#include <ginkgo/core/solver/minres.hpp>
 #include <ginkgo/core/solver/fcg.hpp>
 #include <ginkgo/core/solver/gcr.hpp>
 #include <ginkgo/core/solver/pipe_cg.hpp>
@@ -312,6 +313,7 @@ int main(int argc, char** argv)
         run(type_tag<gko::solver::PipeCg<vt>>{}, "PipeCg");
         run(type_tag<gko::solver::Bicg<vt>>{}, "Bicg");     // csr + Jacobi transposes on the device
         run(type_tag<gko::solver::Gcr<vt>>{}, "Gcr");
+        run(type_tag<gko::solver::Minres<vt>>{}, "Minres");
         // Ir (Richardson with a Jacobi inner solver) and Chebyshev: no reduction enters the
         // iterates, so a fixed number of iterations must reproduce the reference's bits
         auto stationary = [&](auto exec, auto a, bool cheb) {

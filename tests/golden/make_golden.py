@@ -153,6 +153,20 @@ def bicg():
         for bs in (0, 8):
             x, it, rn = h.gcr_solve(rhs, krylov_dim=kd, max_iters=400, reduction=1e-9, precond_block_size=bs)
             arrays[f"gcr_{kd}_{bs}_x"], arrays[f"gcr_{kd}_{bs}_it_rn"] = x, np.array([it, rn])
+    # Minres on a symmetric indefinite operator (27-pt Laplacian with a shifted diagonal)
+    rp2, ci2, v2 = o.stencil_csr(3, 8)
+    rows2 = np.repeat(np.arange(len(rp2) - 1), np.diff(rp2))
+    v2 = v2.copy()
+    v2[rows2 == ci2] -= 20.0
+    h2 = ref.CsrHandle("reference", rp2, ci2, v2)
+    rhs2 = rng.uniform(-1, 1, len(rp2) - 1)
+    arrays.update(m_row_ptrs=rp2, m_cols=ci2, m_vals=v2, m_rhs=rhs2)
+    for bs in (0, 1):
+        x, it, rn = h2.krylov_solve("minres", rhs2, max_iters=400, reduction=1e-9, precond_block_size=bs)
+        arrays[f"minres_{bs}_x"], arrays[f"minres_{bs}_it_rn"] = x, np.array([it, rn])
+    x, it, rn = h2.krylov_solve("minres", rhs2, x0=np.full(len(rhs2), 0.5), max_iters=7, reduction=1e-30,
+                                baseline="initial_resnorm")
+    arrays["minres_lim_x"], arrays["minres_lim_it_rn"] = x, np.array([it, rn])
     save("bicg.npz", **arrays)
 
 

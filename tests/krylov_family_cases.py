@@ -114,6 +114,8 @@ def random_case(solver, kernel, rows, cols, dtype, seed, zero_col=None, stopped_
             arrays[name] = rng.uniform(-1, 1, (rows, cols)).astype(dtype)
         elif kind in "Ss":
             arrays[name] = (rng.uniform(0.5, 2.0, cols) * rng.choice([-1, 1], cols)).astype(dtype)
+            if solver == "minres" and name == "beta":
+                arrays[name] = np.abs(arrays[name])          # its square root is taken
             if zero_col is not None and zero_col < cols:
                 arrays[name][zero_col] = 0
         elif kind == "U":

@@ -28,8 +28,11 @@ def run_device(gexec, solver, kernel, arrays, strides=None):
     from ginkgo_amd._lib import VT, call
     import ginkgo_amd as g
     spec = KERNELS[solver][kernel]
-    shape = next(arrays[n] for n, k in spec if k in "Vv")
-    rows, cols = shape.shape
+    shape = next((arrays[n] for n, k in spec if k in "Vv"), None)
+    if shape is None:                      # scalars only: (stream, cols, ...)
+        rows, cols = None, len(next(arrays[n] for n, k in spec if k in "Ss"))
+    else:
+        rows, cols = shape.shape
     dev, args = {}, []
     for name, kind in spec:
         a = arrays[name]
@@ -42,8 +45,9 @@ def run_device(gexec, solver, kernel, arrays, strides=None):
             t = gexec.to_device(a)
             dev[name] = t
             args.append(t)
-    call(f"gkoc_{solver}_{kernel}_" + VT[dev[next(n for n, k in spec if k in 'Vv')].dtype],
-         gexec.stream, rows, cols, *args)
+    vt = VT[next(d.dtype for (n, k), d in zip(spec, dev.values()) if k in "VvSs")]
+    dims = [cols] if rows is None else [rows, cols]
+    call(f"gkoc_{solver}_{kernel}_" + vt, gexec.stream, *dims, *args)
     gexec.synchronize()
     for name, kind in spec:
         if kind in "vstpU":
@@ -325,3 +329,30 @@ def test_gcr_matches_reference_golden(gexec, oracle):
             assert np.linalg.norm(x.to_numpy()[:, 0] - xr) <= 1e-7 * np.linalg.norm(xr)
             r = rhs - oracle.csr_spmv(rp, ci, v, x.to_numpy()[:, 0])
             assert np.linalg.norm(r) <= 2e-9 * np.linalg.norm(rhs)
+
+
+def test_minres_matches_reference_golden(gexec, oracle):
+    """symmetric indefinite operator; ResidualNorm recomputes b - A x (no residual handed over),
+    ImplicitResidualNorm uses tau"""
+    import ginkgo_amd as g
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "bicg.npz"))
+    rp, ci, v, rhs = (gold[k] for k in ("m_row_ptrs", "m_cols", "m_vals", "m_rhs"))
+    n = len(rp) - 1
+    a = g.Csr.from_arrays(gexec, (n, n), rp, ci, v)
+    for bs in (0, 1):
+        x, s = _solve_kind(g, gexec, g.Minres, a, rhs, 400, 1e-9, bs)
+        it_ref, _ = gold[f"minres_{bs}_it_rn"]
+        assert s.has_converged and abs(s.num_iterations - int(it_ref)) <= 1, (bs, s.num_iterations, it_ref)
+        xr = gold[f"minres_{bs}_x"]
+        assert np.linalg.norm(x - xr) <= 1e-7 * np.linalg.norm(xr)
+    x, s = _solve_kind(g, gexec, g.Minres, a, rhs, 7, 1e-30, 0, x0=np.full(n, 0.5),
+                       baseline=g.stop.mode.initial_resnorm)
+    assert s.num_iterations == 7
+    assert np.linalg.norm(x - gold["minres_lim_x"]) <= 1e-10 * np.linalg.norm(x)
+    f = g.Minres.build().with_criteria(g.stop.Iteration.build().with_max_iters(400),
+                                       g.stop.ImplicitResidualNorm.build().with_reduction_factor(1e-9))
+    s = f.on(gexec).generate(a)
+    x = g.Dense.from_numpy(gexec, np.zeros(n))
+    s.apply(g.Dense.from_numpy(gexec, rhs), x)
+    r = rhs - oracle.csr_spmv(rp, ci, v, x.to_numpy()[:, 0])
+    assert s.has_converged and np.linalg.norm(r) <= 1e-6 * np.linalg.norm(rhs)

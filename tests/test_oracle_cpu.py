@@ -674,3 +674,25 @@ def test_golden_and_live_gcr(oracle):
                                                max_block_size=bs, krylov_dim=kd)
             xr, itr, rnr = h.gcr_solve(b, krylov_dim=kd, max_iters=200, reduction=1e-10, precond_block_size=bs)
             assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
+
+
+def test_golden_and_live_minres(oracle):
+    g = gold("bicg.npz")
+    rp, ci, v, rhs = g["m_row_ptrs"], g["m_cols"], g["m_vals"], g["m_rhs"]
+    for bs, pre in ((0, None), (1, "scalar")):
+        x, it, rn = oracle.krylov_solve("minres", rp, ci, v, rhs, max_iters=400, reduction=1e-9, precond=pre)
+        assert (it, rn) == tuple(g[f"minres_{bs}_it_rn"]) and np.array_equal(x, g[f"minres_{bs}_x"])
+    x, it, rn = oracle.krylov_solve("minres", rp, ci, v, rhs, x0=np.full(len(rhs), 0.5), max_iters=7,
+                                    reduction=1e-30, baseline="initial_resnorm")
+    assert (it, rn) == tuple(g["minres_lim_it_rn"]) and np.array_equal(x, g["minres_lim_x"])
+    if os.path.exists(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libgko_ref_shim.so")):
+        ref = _ref()
+        rp, ci, v = oracle.stencil_csr(3, 6)
+        h = ref.CsrHandle("reference", rp, ci, v)
+        b = np.random.default_rng(3).uniform(-1, 1, len(rp) - 1)
+        for bs in (0, 1, 8):
+            pre = None if bs == 0 else ("scalar" if bs == 1 else "block")
+            xo, ito, rno = oracle.krylov_solve("minres", rp, ci, v, b, max_iters=200, reduction=1e-10,
+                                               precond=pre, max_block_size=max(bs, 1))
+            xr, itr, rnr = h.krylov_solve("minres", b, max_iters=200, reduction=1e-10, precond_block_size=bs)
+            assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
