@@ -1,5 +1,5 @@
-"""Step kernels and whole iterations of Bicgstab / Cgs / Fcg / PipeCg (and Cg for
-scale) on the 27-pt grid^3 Laplacian with block-Jacobi(8): per-kernel time and
+"""Step kernels of Bicgstab / Cgs / Fcg / PipeCg / Bicg / Gcr / Minres and whole iterations of every
+solver of ginkgo_amd (Cg for scale) on the 27-pt grid^3 Laplacian with block-Jacobi(8): per-kernel time and
 fraction of 8 TB/s (algorithmic bytes = values read + written per element, header of
 csrc/krylov_steps.hip), then iterations/s over a fixed iteration count.
   python tools/family_bench.py [grid=256] [iters=60]"""
@@ -25,6 +25,18 @@ a = g.stencil_csr(ex, 3, grid)
 rng = np.random.default_rng(1)
 print(f"grid {grid}^3, n = {n}")
 vecs = {}
+# values read + written per element (vector operands; in-place operands count twice)
+TRAFFIC = {
+    ("bicgstab", "initialize"): (1, 8), ("bicgstab", "step_1"): (3, 1), ("bicgstab", "step_2"): (2, 1),
+    ("bicgstab", "step_3"): (5, 2),
+    ("bicg", "initialize"): (1, 8), ("bicg", "step_1"): (4, 2), ("bicg", "step_2"): (6, 3),
+    ("gcr", "initialize"): (1, 1), ("gcr", "restart"): (2, 2), ("gcr", "step_1"): (4, 2),
+    ("minres", "initialize"): (2, 6), ("minres", "step_2"): (7, 6),
+    ("cgs", "initialize"): (1, 8), ("cgs", "step_1"): (3, 2), ("cgs", "step_2"): (2, 2), ("cgs", "step_3"): (4, 2),
+    ("fcg", "initialize"): (1, 5), ("fcg", "step_1"): (2, 1), ("fcg", "step_2"): (4, 3),
+    ("pipe_cg", "initialize_1"): (1, 1), ("pipe_cg", "initialize_2"): (4, 4), ("pipe_cg", "step_1"): (8, 5),
+    ("pipe_cg", "step_2"): (8, 4),
+}
 
 
 def vec(name):
@@ -46,21 +58,10 @@ for solver, kernels in KERNELS.items():
             elif kind in "Ss":
                 args.append(g.scalar(ex, 0.7).values)
             else:
-                args.append(ex.zeros((1,), torch.uint8))
-        # in-place operands are read and written
-        reads = sum(1 for nme, k in spec if k == "V") + \
-            (0 if kernel.startswith("initialize") else sum(1 for nme, k in spec if k == "v"))
-        if solver == "pipe_cg" and kernel == "step_1":
-            reads -= 1          # z2 is written only
-        if kernel in ("step_2",) and solver in ("bicgstab", "cgs"):
-            reads = sum(1 for nme, k in spec if k == "V")      # s / q, t are outputs only
-        if solver == "cgs" and kernel == "step_1":
-            reads = 3           # r, q, p ; u is written only
-        if solver == "fcg" and kernel == "step_2":
-            reads = 4           # x, r, p, q ; t written only
-        if solver == "bicgstab" and kernel == "step_3":
-            reads = 5           # x, s, t, y, z ; r written only
-        writes = sum(1 for nme, k in spec if k == "v")
+                args.append(ex.zeros((8,), torch.uint8))      # stop byte / uint64 counter
+        if (solver, kernel) not in TRAFFIC:
+            continue            # scalar-only kernels (minres::step_1)
+        reads, writes = TRAFFIC[(solver, kernel)]
         fn = lambda: call(f"gkoc_{solver}_{kernel}_f64", ex.stream, n, 1, *args)
         for _ in range(3):
             fn()
@@ -79,10 +80,18 @@ for solver, kernels in KERNELS.items():
 vecs.clear()
 torch.cuda.empty_cache()
 rhs = g.Dense.from_numpy(ex, np.ones(n))
-for name, cls in (("Cg", g.Cg), ("Fcg", g.Fcg), ("PipeCg", g.PipeCg), ("Bicgstab", g.Bicgstab), ("Cgs", g.Cgs)):
-    s = (cls.build().with_criteria(g.stop.Iteration.build().with_max_iters(iters),
-                                   g.stop.ResidualNorm.build().with_reduction_factor(1e-30))
-         .with_preconditioner(g.Jacobi.build().with_max_block_size(8)).on(ex).generate(a))
+SOLVERS = (("Cg", g.Cg, {}, 1), ("Fcg", g.Fcg, {}, 1), ("PipeCg", g.PipeCg, {}, 1),
+           ("Minres", g.Minres, {}, 1), ("Bicgstab", g.Bicgstab, {}, 2), ("Cgs", g.Cgs, {}, 2),
+           ("Bicg", g.Bicg, {}, 2), ("Gcr(10)", g.Gcr, {"krylov_dim": 10}, 1),
+           ("Ir(0.9)", g.Ir, {"relaxation_factor": 0.9}, 1), ("Chebyshev", g.Chebyshev, {"foci": (0.02, 2.0)}, 1))
+for name, cls, params, spmv in SOLVERS:
+    f = cls.build().with_criteria(g.stop.Iteration.build().with_max_iters(iters),
+                                  g.stop.ImplicitResidualNorm.build().with_reduction_factor(1e-30)
+                                  if name == "Minres" else
+                                  g.stop.ResidualNorm.build().with_reduction_factor(1e-30))
+    for k, val in params.items():
+        f = getattr(f, "with_" + k)(val)
+    s = f.with_preconditioner(g.Jacobi.build().with_max_block_size(8)).on(ex).generate(a)
     x = g.Dense.from_numpy(ex, np.zeros(n))
     s.apply(rhs, x)                       # warm-up (workspace)
     x.fill(0.0)
@@ -91,8 +100,7 @@ for name, cls in (("Cg", g.Cg), ("Fcg", g.Fcg), ("PipeCg", g.PipeCg), ("Bicgstab
     s.apply(rhs, x)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    spmv = 2 if name in ("Bicgstab", "Cgs") else 1
-    print(f"{name:9s} {s.num_iterations:4d} iterations  {dt / s.num_iterations * 1e3:7.3f} ms/it  "
-          f"{s.num_iterations / dt:7.1f} it/s   ({spmv} SpMV + {spmv} block-Jacobi per iteration)", flush=True)
+    print(f"{name:10s} {s.num_iterations:4d} iterations  {dt / s.num_iterations * 1e3:7.3f} ms/it  "
+          f"{s.num_iterations / dt:7.1f} it/s   ({spmv} SpMV per iteration)", flush=True)
     del s, x
     torch.cuda.empty_cache()
