@@ -165,7 +165,7 @@ int gkoc_stream_end_capture(gkoc_stream_t s, gkoc_graph_t* graph)
     GKOC_HIP(hipStreamEndCapture(as_stream(s), &g));
     hipGraphExec_t e = nullptr;
     const hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     GKOC_HIP(err);
     *graph = e;
     return GKOC_OK;
