@@ -9,13 +9,14 @@ Cdna4Executor does, and there is no CPU fallback.
 from ._lib import (DimensionMismatch, GkoError, NotCompiled, NotSupported,
                    LIB_PATH)
 from .executor import Cdna4Executor
-from .matrix import Coo, Csr, Dense, Ell, Hybrid, Sellp, scalar, stencil_csr
+from .matrix import (Coo, Csr, Dense, DeviceMatrixData, Ell, Hybrid, Sellp, entry_dtype, scalar,
+                     stencil_csr)
 from .preconditioner import Jacobi, compute_storage_scheme
 from .solver import Cg, Gmres, Identity, ortho_method
 from .krylov import Bicg, Bicgstab, Cgs, Chebyshev, Fcg, Gcr, Ir, Minres, PipeCg
 from . import stop
 
-__all__ = ["Coo", "Hybrid", "Bicg", "Bicgstab", "Chebyshev", "Gcr", "Ir", "Minres", "Cgs", "Fcg", "PipeCg", "Cdna4Executor", "Csr", "Dense", "Ell", "Sellp", "scalar",
+__all__ = ["Coo", "DeviceMatrixData", "entry_dtype", "Hybrid", "Bicg", "Bicgstab", "Chebyshev", "Gcr", "Ir", "Minres", "Cgs", "Fcg", "PipeCg", "Cdna4Executor", "Csr", "Dense", "Ell", "Sellp", "scalar",
            "stencil_csr", "Jacobi", "compute_storage_scheme", "Cg", "Gmres", "ortho_method", "Identity",
            "stop", "GkoError", "NotCompiled", "NotSupported",
            "DimensionMismatch", "LIB_PATH"]

@@ -955,6 +955,94 @@ void convert_idxs_to_ptrs<int64, int64>(exec_t exec, const int64* idxs,
 FOR_VT_IT(DEF)
 #undef DEF
 
+
+// device-side assembly (core/base/device_matrix_data.cpp:106-129): the workspace lives
+// until the stream has drained; remove_zeros / sum_duplicates replace the arrays only
+// if entries go away, like the reference (test/base/device_matrix_data_kernels.cpp:
+// "no reallocation")
+struct assembly_scratch {
+    exec_t exec;
+    array<char> buf;
+    assembly_scratch(exec_t e, size_t bytes) : exec{e}, buf{e, bytes} {}
+    ~assembly_scratch() { exec->synchronize(); }
+};
+
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void soa_to_aos<T, I>(exec_t exec, const device_matrix_data<T, I>& in,      \
+                          array<matrix_data_entry<T, I>>& out)                  \
+    {                                                                           \
+        GKOC_CALL(gkoc_soa_to_aos_##TN##_##IN(                                  \
+            stream_of(exec),                                                    \
+            static_cast<int64_t>(in.get_num_stored_elements()),                 \
+            in.get_const_row_idxs(), in.get_const_col_idxs(),                   \
+            in.get_const_values(), out.get_data()));                            \
+    }                                                                           \
+    template <>                                                                 \
+    void sort_row_major<T, I>(exec_t exec, size_type num_elems, I* row_idxs,    \
+                              I* col_idxs, T* values)                           \
+    {                                                                           \
+        const auto nnz = static_cast<int64_t>(num_elems);                       \
+        assembly_scratch w(exec, gkoc_sort_row_major_workspace_bytes(           \
+                                     nnz, sizeof(T), sizeof(I)));               \
+        GKOC_CALL(gkoc_sort_row_major_##TN##_##IN(                              \
+            stream_of(exec), nnz, row_idxs, col_idxs, values,                   \
+            w.buf.get_data(), w.buf.get_size()));                               \
+    }                                                                           \
+    template <>                                                                 \
+    void remove_zeros<T, I>(exec_t exec, array<T>& values,                      \
+                            array<I>& row_idxs, array<I>& col_idxs)             \
+    {                                                                           \
+        const auto nnz = static_cast<int64_t>(values.get_size());               \
+        assembly_scratch w(exec, gkoc_compact_workspace_bytes(nnz));            \
+        int64_t kept = 0;                                                       \
+        GKOC_CALL(gkoc_remove_zeros_count_##TN(                                 \
+            stream_of(exec), nnz, values.get_const_data(), w.buf.get_data(),    \
+            w.buf.get_size(), &kept));                                          \
+        if (kept < nnz) {                                                       \
+            array<T> new_values{exec, static_cast<size_type>(kept)};            \
+            array<I> new_row_idxs{exec, static_cast<size_type>(kept)};          \
+            array<I> new_col_idxs{exec, static_cast<size_type>(kept)};          \
+            GKOC_CALL(gkoc_remove_zeros_fill_##TN##_##IN(                       \
+                stream_of(exec), nnz, row_idxs.get_const_data(),                \
+                col_idxs.get_const_data(), values.get_const_data(),             \
+                w.buf.get_const_data(), new_row_idxs.get_data(),                \
+                new_col_idxs.get_data(), new_values.get_data()));               \
+            exec->synchronize();                                                \
+            values = std::move(new_values);                                     \
+            row_idxs = std::move(new_row_idxs);                                 \
+            col_idxs = std::move(new_col_idxs);                                 \
+        }                                                                       \
+    }                                                                           \
+    template <>                                                                 \
+    void sum_duplicates<T, I>(exec_t exec, size_type, array<T>& values,         \
+                              array<I>& row_idxs, array<I>& col_idxs)           \
+    {                                                                           \
+        const auto nnz = static_cast<int64_t>(values.get_size());               \
+        assembly_scratch w(exec, gkoc_compact_workspace_bytes(nnz));            \
+        int64_t kept = 0;                                                       \
+        GKOC_CALL(gkoc_sum_duplicates_count_##IN(                               \
+            stream_of(exec), nnz, row_idxs.get_const_data(),                    \
+            col_idxs.get_const_data(), w.buf.get_data(), w.buf.get_size(),      \
+            &kept));                                                            \
+        if (kept < nnz) {                                                       \
+            array<T> new_values{exec, static_cast<size_type>(kept)};            \
+            array<I> new_row_idxs{exec, static_cast<size_type>(kept)};          \
+            array<I> new_col_idxs{exec, static_cast<size_type>(kept)};          \
+            GKOC_CALL(gkoc_sum_duplicates_fill_##TN##_##IN(                     \
+                stream_of(exec), nnz, row_idxs.get_const_data(),                \
+                col_idxs.get_const_data(), values.get_const_data(),             \
+                w.buf.get_const_data(), new_row_idxs.get_data(),                \
+                new_col_idxs.get_data(), new_values.get_data()));               \
+            exec->synchronize();                                                \
+            values = std::move(new_values);                                     \
+            row_idxs = std::move(new_row_idxs);                                 \
+            col_idxs = std::move(new_col_idxs);                                 \
+        }                                                                       \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
 }  // namespace components
 }  // namespace hip
 }  // namespace kernels

@@ -213,6 +213,17 @@ class Csr(_SparseBase):
                    exec_.to_device(a.indptr.astype(index_dtype)), strategy)
 
     @staticmethod
+    def read(data, strategy="automatical"):
+        """Csr::read(const device_matrix_data&) (core/matrix/csr.cpp:583-606): the entries
+        must be sorted row-major; values and column indices are taken as they are, the
+        row pointers come from components::convert_idxs_to_ptrs on the device"""
+        ex, n = data.exec, data.size[0]
+        ptrs = ex.alloc((n + 1,), data.row_idxs.dtype)
+        call("gkoc_convert_idxs_to_ptrs_" + IT[data.row_idxs.dtype], ex.stream,
+             data.get_num_stored_elements(), data.row_idxs, n, ptrs)
+        return Csr(ex, data.size, data.values, data.col_idxs, ptrs, strategy)
+
+    @staticmethod
     def from_arrays(exec_, size, row_ptrs, col_idxs, values,
                     strategy="automatical"):
         return Csr(exec_, size, exec_.to_device(values),
@@ -375,6 +386,11 @@ class Coo(_SparseBase):
                                                    C.c_size_t(values.element_size()))
         self._work = exec_.alloc((int(need),), torch.uint8)
 
+    @staticmethod
+    def read(data):
+        """Coo::read(const device_matrix_data&) (core/matrix/coo.cpp): the arrays as they are"""
+        return Coo(data.exec, data.size, data.values, data.col_idxs, data.row_idxs)
+
     @property
     def dtype(self):
         return self.values.dtype
@@ -409,6 +425,106 @@ class Coo(_SparseBase):
         else:
             self._run("gkoc_coo_advanced_spmv2_", args[0], args[1], None, args[2])
         return args[-1]
+
+
+def entry_dtype(value_dtype, index_dtype):
+    """numpy layout of gko::matrix_data_entry<V, I> = struct { I row; I column; V value; }
+    with natural alignment (include/ginkgo/core/base/matrix_data.hpp:60)"""
+    return np.dtype([("row", index_dtype), ("column", index_dtype), ("value", value_dtype)],
+                    align=True)
+
+
+class DeviceMatrixData:
+    """gko::device_matrix_data<V, I> (include/ginkgo/core/base/device_matrix_data.hpp:36;
+    core/base/device_matrix_data.cpp): the structure-of-arrays triplets a matrix is
+    assembled from ON THE DEVICE - sort_row_major, remove_zeros and sum_duplicates run
+    there, and Csr.read(data) / Coo.read(data) take the arrays over without a host trip."""
+
+    def __init__(self, exec_, size, row_idxs, col_idxs, values):
+        if not (row_idxs.numel() == col_idxs.numel() == values.numel()):
+            raise GkoError("device_matrix_data: arrays differ in length")
+        if row_idxs.dtype != col_idxs.dtype:
+            raise GkoError("device_matrix_data: index arrays must share one type")
+        self.exec, self.size = exec_, (int(size[0]), int(size[1]))
+        self.row_idxs, self.col_idxs, self.values = row_idxs, col_idxs, values
+
+    @staticmethod
+    def create_from_host(exec_, size, entries):
+        """device_matrix_data::create_from_host (device_matrix_data.cpp:60-72): `entries`
+        is a structured array of entry_dtype (the nonzeros of a gko::matrix_data); they
+        are copied to the device as they are and split there (components::aos_to_soa)"""
+        entries = np.ascontiguousarray(entries)
+        vdt, idt = entries.dtype["value"], entries.dtype["row"]
+        if entries.dtype != entry_dtype(vdt, idt):
+            raise GkoError("create_from_host: entries are not laid out like matrix_data_entry")
+        nnz = len(entries)
+        raw = exec_.to_device(entries.view(np.uint8))
+        tv = torch.from_numpy(np.empty(0, vdt)).dtype
+        ti = torch.from_numpy(np.empty(0, idt)).dtype
+        rows, cols, vals = exec_.alloc((nnz,), ti), exec_.alloc((nnz,), ti), exec_.alloc((nnz,), tv)
+        call(f"gkoc_aos_to_soa_{VT[tv]}_{IT[ti]}", exec_.stream, nnz, raw, rows, cols, vals)
+        exec_.synchronize()     # `raw` is released on return
+        return DeviceMatrixData(exec_, size, rows, cols, vals)
+
+    def _suf(self):
+        return f"{VT[self.values.dtype]}_{IT[self.col_idxs.dtype]}"
+
+    def get_num_stored_elements(self):
+        return int(self.values.numel())
+
+    def copy_to_host(self):
+        """device_matrix_data::copy_to_host (components::soa_to_aos): the entries as a
+        structured array of entry_dtype"""
+        nnz = self.get_num_stored_elements()
+        dt = entry_dtype(_np_dtype(self.values.dtype), _np_dtype(self.col_idxs.dtype))
+        raw = self.exec.alloc((nnz * dt.itemsize,), torch.uint8)
+        call("gkoc_soa_to_aos_" + self._suf(), self.exec.stream, nnz, self.row_idxs,
+             self.col_idxs, self.values, raw)
+        self.exec.synchronize()
+        return raw.cpu().numpy().view(dt)
+
+    def sort_row_major(self):
+        """stable by (row, column), in place (device_matrix_data.cpp:106-112)"""
+        nnz = self.get_num_stored_elements()
+        f = _lib.lib().gkoc_sort_row_major_workspace_bytes
+        f.restype = C.c_size_t
+        need = f(C.c_int64(nnz), C.c_size_t(self.values.element_size()),
+                 C.c_size_t(self.col_idxs.element_size()))
+        work = self.exec.alloc((int(need),), torch.uint8)
+        call("gkoc_sort_row_major_" + self._suf(), self.exec.stream, nnz, self.row_idxs,
+             self.col_idxs, self.values, work, C.c_size_t(work.numel()))
+        self.exec.synchronize()     # `work` is released on return
+        return self
+
+    def _compact(self, count_name, count_args, fill_name):
+        nnz = self.get_num_stored_elements()
+        f = _lib.lib().gkoc_compact_workspace_bytes
+        f.restype = C.c_size_t
+        work = self.exec.alloc((int(f(C.c_int64(nnz))),), torch.uint8)
+        kept = C.c_int64(0)
+        call(count_name, self.exec.stream, nnz, *count_args, work, C.c_size_t(work.numel()),
+             C.byref(kept))
+        if kept.value < nnz:        # otherwise the arrays stay as they are, like the reference's
+            ex, n = self.exec, kept.value
+            rows, cols = ex.alloc((n,), self.row_idxs.dtype), ex.alloc((n,), self.col_idxs.dtype)
+            vals = ex.alloc((n,), self.values.dtype)
+            call(fill_name + self._suf(), ex.stream, nnz, self.row_idxs, self.col_idxs,
+                 self.values, work, rows, cols, vals)
+            ex.synchronize()        # `work` and the old arrays are released
+            self.row_idxs, self.col_idxs, self.values = rows, cols, vals
+        return self
+
+    def remove_zeros(self):
+        """drops the entries whose value == 0 (device_matrix_data.cpp:115-120)"""
+        return self._compact("gkoc_remove_zeros_count_" + VT[self.values.dtype], (self.values,),
+                             "gkoc_remove_zeros_fill_")
+
+    def sum_duplicates(self):
+        """sort_row_major, then one entry per (row, column) whose value is the sum of the
+        run in storage order (device_matrix_data.cpp:123-129)"""
+        self.sort_row_major()
+        return self._compact("gkoc_sum_duplicates_count_" + IT[self.col_idxs.dtype],
+                             (self.row_idxs, self.col_idxs), "gkoc_sum_duplicates_fill_")
 
 
 class Hybrid(_SparseBase):

@@ -223,6 +223,57 @@ GKOC_DECL_MD(double, f64, int64_t, i64)
 GKOC_DECL_MD(float, f32, int32_t, i32)
 GKOC_DECL_MD(float, f32, int64_t, i64)
 
+/* Device-side assembly of device_matrix_data
+ * (core/base/device_matrix_data_kernels.hpp:23-51; reference/base/
+ * device_matrix_data_kernels.cpp:24-143), all bit-identical to the reference:
+ *   components::soa_to_aos      entries[i] = {row, column, value}
+ *   components::sort_row_major  in place, stable by (row, column); needs
+ *       gkoc_sort_row_major_workspace_bytes(nnz, sizeof value, sizeof index)
+ *   components::remove_zeros    = count + fill: count marks value != 0, scans the
+ *       marks into the workspace (gkoc_compact_workspace_bytes(nnz)) and returns
+ *       the number of kept entries in HOST memory; the caller allocates the
+ *       compacted arrays (as the reference does, and only if count < nnz) and
+ *       fill scatters the kept entries through the SAME workspace
+ *   components::sum_duplicates  = count + fill on row-major sorted input: count
+ *       marks the first entry of every (row, column) run; fill writes one entry
+ *       per run whose value is 0 + v0 + v1 + ... in storage order. */
+size_t gkoc_sort_row_major_workspace_bytes(int64_t nnz, size_t value_size,
+                                           size_t index_size);
+size_t gkoc_compact_workspace_bytes(int64_t nnz);
+int gkoc_remove_zeros_count_f64(gkoc_stream_t s, int64_t nnz,
+                                const double* vals, void* work,
+                                size_t work_bytes, int64_t* count_host);
+int gkoc_remove_zeros_count_f32(gkoc_stream_t s, int64_t nnz,
+                                const float* vals, void* work,
+                                size_t work_bytes, int64_t* count_host);
+int gkoc_sum_duplicates_count_i32(gkoc_stream_t s, int64_t nnz,
+                                  const int32_t* row_idxs,
+                                  const int32_t* col_idxs, void* work,
+                                  size_t work_bytes, int64_t* count_host);
+int gkoc_sum_duplicates_count_i64(gkoc_stream_t s, int64_t nnz,
+                                  const int64_t* row_idxs,
+                                  const int64_t* col_idxs, void* work,
+                                  size_t work_bytes, int64_t* count_host);
+#define GKOC_DECL_ASSEMBLY(T, TN, I, IN)                                       \
+    int gkoc_soa_to_aos_##TN##_##IN(gkoc_stream_t s, int64_t nnz,              \
+                                    const I* row_idxs, const I* col_idxs,      \
+                                    const T* vals, void* entries);             \
+    int gkoc_sort_row_major_##TN##_##IN(gkoc_stream_t s, int64_t nnz,          \
+                                        I* row_idxs, I* col_idxs, T* vals,     \
+                                        void* work, size_t work_bytes);        \
+    int gkoc_remove_zeros_fill_##TN##_##IN(                                    \
+        gkoc_stream_t s, int64_t nnz, const I* row_idxs, const I* col_idxs,    \
+        const T* vals, const void* work, I* out_rows, I* out_cols,             \
+        T* out_vals);                                                          \
+    int gkoc_sum_duplicates_fill_##TN##_##IN(                                  \
+        gkoc_stream_t s, int64_t nnz, const I* row_idxs, const I* col_idxs,    \
+        const T* vals, const void* work, I* out_rows, I* out_cols,             \
+        T* out_vals);
+GKOC_DECL_ASSEMBLY(double, f64, int32_t, i32)
+GKOC_DECL_ASSEMBLY(double, f64, int64_t, i64)
+GKOC_DECL_ASSEMBLY(float, f32, int32_t, i32)
+GKOC_DECL_ASSEMBLY(float, f32, int64_t, i64)
+
 #define GKOC_DECL_IDX(I, IN)                                                   \
     /* ell::compute_max_row_nnz: *max_nnz is HOST memory */                    \
     int gkoc_compute_max_row_nnz_##IN(gkoc_stream_t s, int64_t n_rows,         \

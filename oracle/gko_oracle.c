@@ -47,6 +47,14 @@
 #undef I
 #undef SUF
 
+#define T float
+#define I int64_t
+#define SUF f32_i64
+#include "gko_oracle_impl.inc"
+#undef T
+#undef I
+#undef SUF
+
 #define T double
 #define SUF f64
 #include "gko_oracle_val.inc"

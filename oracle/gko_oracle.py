@@ -124,6 +124,32 @@ def csr_transpose(n_rows, n_cols, row_ptrs, cols, vals):
     return trp, tc, tv
 
 
+def md_sort_row_major(rows, cols, vals):
+    """components::sort_row_major of the reference: sorted copies (rows, cols, vals)"""
+    r, c, v = (np.array(a, copy=True, order="C") for a in (rows, cols, vals))
+    getattr(lib(), "oracle_md_sort_row_major_" + _suf(v, c))(_i64(len(v)), _p(r), _p(c), _p(v))
+    return r, c, v
+
+
+def _md_compact(name, rows, cols, vals):
+    r, c, v = (np.ascontiguousarray(a) for a in (rows, cols, vals))
+    orow, ocol, oval = np.empty_like(r), np.empty_like(c), np.empty_like(v)
+    fn = getattr(lib(), name + _suf(v, c))
+    fn.restype = C.c_int64
+    n = fn(_i64(len(v)), _p(r), _p(c), _p(v), _p(orow), _p(ocol), _p(oval))
+    return orow[:n].copy(), ocol[:n].copy(), oval[:n].copy()
+
+
+def md_remove_zeros(rows, cols, vals):
+    """components::remove_zeros of the reference: the kept entries, in order"""
+    return _md_compact("oracle_md_remove_zeros_", rows, cols, vals)
+
+
+def md_sum_duplicates(rows, cols, vals):
+    """components::sum_duplicates of the reference on row-major sorted input"""
+    return _md_compact("oracle_md_sum_duplicates_", rows, cols, vals)
+
+
 def ell_spmv(n_rows, k, stride, cols, vals, b, alpha=None, beta=None, c=None):
     b2 = np.ascontiguousarray(_as2d(b))
     nrhs = b2.shape[1]

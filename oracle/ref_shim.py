@@ -277,6 +277,23 @@ def stencil_subdomain(nd, dims, pos, target_local_size, restricted):
     return rows, cols, vals, int(ls.value)
 
 
+def md_assemble(op, n_rows, n_cols, rows, cols, vals):
+    """device_matrix_data::{sort_row_major, remove_zeros, sum_duplicates} of the reference, or
+    op = "csr": Csr::read(device_matrix_data) after sort_row_major -> (row_ptrs, cols, vals)"""
+    code = {"sort_row_major": 0, "remove_zeros": 1, "sum_duplicates": 2, "csr": 3}[op]
+    nnz = len(vals)
+    r = np.zeros(max(nnz, n_rows + 1), np.int32)
+    r[:nnz] = rows
+    c = np.array(cols, np.int32, copy=True)
+    v = np.array(vals, np.float64, copy=True)
+    f = lib().ref_md_assemble
+    f.restype = C.c_int64
+    n = f(C.c_int(code), C.c_int64(n_rows), C.c_int64(n_cols), C.c_int64(nnz), _p(r), _p(c), _p(v))
+    if code == 3:
+        return r[:n_rows + 1].copy(), c, v
+    return r[:n].copy(), c[:n].copy(), v[:n].copy()
+
+
 def coo_apply(mode, n_rows, n_cols, rows, cols, vals, b, alpha=1.0, beta=0.0, c=None, exec_kind="reference"):
     """Coo::apply / apply2 of the reference on the given index arrays"""
     m = {"spmv": 0, "advanced_spmv": 1, "spmv2": 2, "advanced_spmv2": 3}[mode]

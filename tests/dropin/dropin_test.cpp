@@ -10,6 +10,7 @@
 #include <iostream>
 #include <string>
 
+#include <ginkgo/core/base/device_matrix_data.hpp>
 #include <ginkgo/core/base/executor.hpp>
 #include <ginkgo/core/base/matrix_data.hpp>
 #include <ginkgo/core/base/timer.hpp>
@@ -384,6 +385,49 @@ int main(int argc, char** argv)
         for (gko::size_type r = 0; same && r <= t_ref->get_size()[0]; ++r)
             same = t_ref->get_const_row_ptrs()[r] == t_hip->get_const_row_ptrs()[r];
         CHECK(same, "Csr::transpose on hip identical to reference");
+    }
+    // --- device_matrix_data assembled on the device: the stencil's entries reversed,
+    // each split into two parts, plus one explicit zero per row; sum_duplicates +
+    // remove_zeros on hip and on the reference executor, then Csr::read(device data)
+    {
+        gko::matrix_data<vt, it> md{a_ref->get_size()};
+        const auto& nz = data.first.nonzeros;
+        for (auto e = nz.rbegin(); e != nz.rend(); ++e) {
+            md.nonzeros.emplace_back(e->row, e->column, 0.3 * e->value);
+            md.nonzeros.emplace_back(e->row, e->column, 0.7 * e->value);
+        }
+        for (gko::size_type r = 0; r < n; ++r) md.nonzeros.emplace_back(r, (r * 7 + 3) % n, 0.0);
+        auto d_ref = gko::device_matrix_data<vt, it>::create_from_host(ref, md);
+        auto d_hip = gko::device_matrix_data<vt, it>::create_from_host(hip, md);
+        d_ref.sum_duplicates();
+        d_hip.sum_duplicates();
+        d_ref.remove_zeros();
+        d_hip.remove_zeros();
+        const auto h_ref = d_ref.copy_to_host();
+        const auto h_hip = d_hip.copy_to_host();      // components::soa_to_aos on hip
+        bool same = h_ref.nonzeros.size() == h_hip.nonzeros.size();
+        for (gko::size_type k = 0; same && k < h_ref.nonzeros.size(); ++k)
+            same = h_ref.nonzeros[k].row == h_hip.nonzeros[k].row &&
+                   h_ref.nonzeros[k].column == h_hip.nonzeros[k].column &&
+                   std::memcmp(&h_ref.nonzeros[k].value, &h_hip.nonzeros[k].value, sizeof(vt)) == 0;
+        CHECK(same, "device_matrix_data::sum_duplicates + remove_zeros on hip identical to reference");
+        CHECK(h_hip.nonzeros.size() <= a_ref->get_num_stored_elements() + n &&
+                  h_hip.nonzeros.size() >= a_ref->get_num_stored_elements(),
+              "duplicates merged, explicit zeros removed");
+        const auto p1 = d_hip.get_const_values();
+        d_hip.sum_duplicates();
+        d_hip.remove_zeros();
+        CHECK(p1 == d_hip.get_const_values(), "nothing to merge / remove: no reallocation");
+        auto c_ref = Csr::create(ref);
+        auto c_hip = Csr::create(hip);
+        c_ref->read(d_ref);
+        c_hip->read(d_hip);
+        auto y_ref = Dense::create(ref, gko::dim<2>{n, 3});
+        auto y_hip = Dense::create(hip, gko::dim<2>{n, 3});
+        c_ref->apply(b_ref, y_ref);
+        c_hip->apply(b_hip, y_hip);
+        CHECK(identical(gko::clone(ref, y_hip).get(), y_ref.get()),
+              "Csr::read(device_matrix_data) on hip + apply bit-identical");
     }
     std::cout << (failures == 0 ? "DROPIN OK" : "DROPIN FAILED") << std::endl;
     return failures == 0 ? 0 : 1;

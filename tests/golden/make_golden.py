@@ -88,6 +88,23 @@ def coo_hybrid():
     save("coo_hybrid.npz", **arrays)
 
 
+def assembly():
+    """device_matrix_data::{sort_row_major, remove_zeros, sum_duplicates} and
+    Csr::read(device_matrix_data) of the reference (SURVEY 8(f) rank 1)"""
+    rng = np.random.default_rng(2024)
+    nnz, n_rows, n_cols = 6000, 532, 231
+    rows = rng.integers(0, n_rows, nnz).astype(np.int32)
+    cols = rng.integers(0, 40, nnz).astype(np.int32)          # few columns: many duplicates
+    vals = rng.uniform(-1, 1, nnz)
+    vals[rng.random(nnz) < 0.15] = 0.0
+    vals[rng.random(nnz) < 0.05] = -0.0
+    arrays = dict(shape=np.array([n_rows, n_cols]), rows=rows, cols=cols, vals=vals)
+    for op in ("sort_row_major", "remove_zeros", "sum_duplicates", "csr"):
+        r, c, v = ref.md_assemble(op, n_rows, n_cols, rows, cols, vals)
+        arrays[op + "_rows"], arrays[op + "_cols"], arrays[op + "_vals"] = r, c, v
+    save("assembly.npz", **arrays)
+
+
 def stationary():
     """Ir and Chebyshev of the reference"""
     from oracle import gko_oracle as o
@@ -177,6 +194,8 @@ def main():
         return jacobi_storage()
     if len(sys.argv) > 1 and sys.argv[1] == "stationary":
         return stationary()
+    if len(sys.argv) > 1 and sys.argv[1] == "assembly":
+        return assembly()
     if len(sys.argv) > 1 and sys.argv[1] == "krylov_family":
         return krylov_family()
     if len(sys.argv) > 1 and sys.argv[1] == "coo_hybrid":
@@ -286,3 +305,4 @@ if __name__ == "__main__":
         stationary()
         jacobi_storage()
         bicg()
+        assembly()

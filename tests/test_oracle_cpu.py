@@ -696,3 +696,60 @@ def test_golden_and_live_minres(oracle):
                                                precond=pre, max_block_size=max(bs, 1))
             xr, itr, rnr = h.krylov_solve("minres", b, max_iters=200, reduction=1e-10, precond_block_size=bs)
             assert (ito, rno) == (itr, rnr) and np.array_equal(xo, xr)
+
+
+# ------------------------------------------------- device_matrix_data assembly
+def test_golden_assembly(oracle):
+    g = gold("assembly.npz")
+    rows, cols, vals = g["rows"], g["cols"], g["vals"]
+    s = oracle.md_sort_row_major(rows, cols, vals)
+    for got, name in zip(s, ("rows", "cols", "vals")):
+        assert got.tobytes() == g["sort_row_major_" + name].tobytes()
+    for got, name in zip(oracle.md_remove_zeros(rows, cols, vals), ("rows", "cols", "vals")):
+        assert got.tobytes() == g["remove_zeros_" + name].tobytes()
+    for got, name in zip(oracle.md_sum_duplicates(*s), ("rows", "cols", "vals")):
+        assert got.tobytes() == g["sum_duplicates_" + name].tobytes()
+    # Csr::read(device_matrix_data) = the sorted arrays + convert_idxs_to_ptrs
+    n_rows = int(g["shape"][0])
+    assert np.array_equal(g["csr_rows"], np.concatenate(([0], np.cumsum(np.bincount(s[0], minlength=n_rows)))))
+    assert g["csr_cols"].tobytes() == s[1].tobytes() and g["csr_vals"].tobytes() == s[2].tobytes()
+
+
+def test_assembly_known_properties(oracle):
+    # stable: equal (row, column) keep their input order (std::stable_sort,
+    # reference/base/device_matrix_data_kernels.cpp:135-143)
+    rows = np.array([1, 0, 1, 0, 1], np.int32)
+    cols = np.array([2, 5, 2, 5, 0], np.int32)
+    vals = np.array([1., 2., 3., 4., 5.])
+    r, c, v = oracle.md_sort_row_major(rows, cols, vals)
+    assert (r.tolist(), c.tolist(), v.tolist()) == ([0, 0, 1, 1, 1], [5, 5, 0, 2, 2], [2., 4., 5., 1., 3.])
+    r, c, v = oracle.md_sum_duplicates(r, c, v)
+    assert (r.tolist(), c.tolist(), v.tolist()) == ([0, 1, 1], [5, 0, 2], [6., 5., 4.])
+    # a run is summed from 0: -0 alone becomes +0 once ANY run is merged, stays -0 otherwise
+    r, c, v = oracle.md_sum_duplicates(np.array([0, 1, 1], np.int32), np.array([0, 1, 1], np.int32),
+                                       np.array([-0.0, 1.0, 2.0]))
+    assert not np.signbit(v[0]) and v[1] == 3.0
+    _, _, v = oracle.md_sum_duplicates(np.array([0, 1], np.int32), np.array([0, 1], np.int32), np.array([-0.0, 1.0]))
+    assert np.signbit(v[0])
+    # remove_zeros: -0 == 0 goes, NaN stays
+    _, _, v = oracle.md_remove_zeros(np.arange(4, dtype=np.int32), np.arange(4, dtype=np.int32),
+                                     np.array([0.0, -0.0, np.nan, 3.0]))
+    assert len(v) == 2 and np.isnan(v[0]) and v[1] == 3.0
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_live_reference_assembly(oracle, seed):
+    ref = _ref()
+    rng = np.random.default_rng(seed)
+    nnz = 3000
+    rows = rng.integers(0, 100, nnz).astype(np.int32)
+    cols = rng.integers(0, 30 * seed, nnz).astype(np.int32)
+    vals = rng.uniform(1, 2, nnz)
+    vals[rng.random(nnz) < 0.3] = 0.0
+    s = oracle.md_sort_row_major(rows, cols, vals)
+    for a, b in zip(s, ref.md_assemble("sort_row_major", 100, 200, rows, cols, vals)):
+        assert a.tobytes() == b.tobytes()
+    for a, b in zip(oracle.md_remove_zeros(rows, cols, vals), ref.md_assemble("remove_zeros", 100, 200, rows, cols, vals)):
+        assert a.tobytes() == b.tobytes()
+    for a, b in zip(oracle.md_sum_duplicates(*s), ref.md_assemble("sum_duplicates", 100, 200, rows, cols, vals)):
+        assert a.tobytes() == b.tobytes()
