@@ -21,6 +21,7 @@
 // Algorithmic HBM bytes: nnz*(sizeof(T)+sizeof(I)) + (n+1)*sizeof(I)
 //                        + n_cols*sizeof(T) (b once) + n*sizeof(T) (c).
 #include "common.hpp"
+#include "csr_spmv_multi.hpp"
 #include "csr_spmv_pipe.hpp"
 #include "fused.hpp"
 
@@ -62,6 +63,23 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     // 32 B of values per lane and load: 4 doubles or 8 floats (ring = 8 KB)
     constexpr int EV = 32 / sizeof(T);
     constexpr int RINGV = 8192 / sizeof(T);
+    if (nrhs >= 2 && vec_ok) {
+        // several right-hand sides: one pass over the matrix per chunk of 2 or 4
+        // columns (csr_spmv_multi.hpp); b is read as pairs of columns when its
+        // rows allow 2-element vector loads; 16 KB of LDS per wave in both cases
+        const int b_vec_ok = reinterpret_cast<uintptr_t>(b) % (2 * sizeof(T)) == 0 && ldb % 2 == 0;
+        if (nrhs == 2) {
+            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV, 2><<<grid, block, 0, as_stream(s)>>>(
+                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
+                static_cast<int>(nrhs), alpha, beta, b_vec_ok);
+        } else {
+            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 4><<<grid, block, 0, as_stream(s)>>>(
+                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
+                static_cast<int>(nrhs), alpha, beta, b_vec_ok);
+        }
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
 #define GKOC_LAUNCH_PIPE3(E_, U_, MODE_)                                       \
     csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, E_, U_, RINGV, 1, MODE_>    \
         <<<grid, block, 0, as_stream(s)>>>(                                    \
