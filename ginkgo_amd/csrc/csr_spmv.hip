@@ -72,8 +72,13 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
             csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV, 2><<<grid, block, 0, as_stream(s)>>>(
                 n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
                 static_cast<int>(nrhs), alpha, beta, b_vec_ok);
-        } else {
+        } else if (nrhs <= 4) {
             csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 4><<<grid, block, 0, as_stream(s)>>>(
+                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
+                static_cast<int>(nrhs), alpha, beta, b_vec_ok);
+        } else {
+            // 8 columns per pass (32 KB ring): every gathered b line is used in full
+            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 8><<<grid, block, 0, as_stream(s)>>>(
                 n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
                 static_cast<int>(nrhs), alpha, beta, b_vec_ok);
         }

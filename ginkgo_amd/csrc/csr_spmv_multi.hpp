@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void csr_spmv_multi_kernel(
     const T* __restrict__ beta_p, int b_vec_ok)
 {
     static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
-    static_assert(NR == 2 || NR == 4, "chunks of 2 or 4 columns");
+    static_assert(NR == 2 || NR == 4 || NR == 8, "chunks of 2, 4 or 8 columns");
     constexpr int ROWS = 64;
     constexpr int G = 64 * E * U;
     static_assert(RING >= 2 * G, "ring too small for the group size");

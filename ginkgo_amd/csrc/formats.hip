@@ -85,6 +85,116 @@ __device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
     return sum;
 }
 
+// The same for a chunk of NR right-hand sides: the row's entries are read ONCE, the NR
+// values b[col, jcol[0..NR)) of an entry are neighbours in the row-major b (one cache
+// line), and NR sums are carried; per column the products are added in column order,
+// so every column is bit-identical to fmt_row_sum.  jcol = column behind slot jj
+// (slots past nrhs repeat the last column and are not stored).
+template <typename T, typename I, bool ADV, int NR>
+__device__ __forceinline__ void fmt_row_sum_multi(T (&sum)[NR], int64_t len, int64_t first,
+                                                  int64_t step, const I* __restrict__ cols,
+                                                  const T* __restrict__ vals,
+                                                  const T* __restrict__ b, int64_t ldb,
+                                                  const int (&jcol)[NR], T alpha)
+{
+    constexpr int U = 4;
+    const int64_t full = len / U * U;
+    T v0[U], v1[U];
+    I c0[U], c1[U];
+    if (full > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v0[u] = vals[first + u * step];
+            c0[u] = cols[first + u * step];
+        }
+    }
+    int64_t i = 0;
+    while (i < full) {
+        T xv[U][NR];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const T* __restrict__ brow = b + int64_t(c0[u] >= 0 ? c0[u] : I(0)) * ldb;
+#pragma unroll
+            for (int jj = 0; jj < NR; ++jj) xv[u][jj] = c0[u] >= 0 ? brow[jcol[jj]] : T(0);
+        }
+        const int64_t nx = i + U < full ? i + U : i;  // last chunk: harmless reload
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v1[u] = vals[first + (nx + u) * step];
+            c1[u] = cols[first + (nx + u) * step];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int jj = 0; jj < NR; ++jj) {
+                const T t = ADV ? (alpha * v0[u]) * xv[u][jj] : v0[u] * xv[u][jj];
+                sum[jj] = c0[u] >= 0 ? sum[jj] + t : sum[jj];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v0[u] = v1[u];
+            c0[u] = c1[u];
+        }
+        i += U;
+    }
+    for (; i < len; ++i) {
+        const I cc = cols[first + i * step];
+        if (cc >= 0) {
+            const T v = vals[first + i * step];
+            const T* __restrict__ brow = b + int64_t(cc) * ldb;
+#pragma unroll
+            for (int jj = 0; jj < NR; ++jj) {
+                const T xv = brow[jcol[jj]];
+                sum[jj] += ADV ? (alpha * v) * xv : v * xv;
+            }
+        }
+    }
+}
+
+// ELL / SELL-P SpMV with several right-hand sides: lane = row, one pass over the
+// row's entries per chunk of NR columns (SELL: slice_sets != nullptr)
+template <typename T, typename I, bool ADV, int NR, bool SELL>
+__global__ __launch_bounds__(256) void fmt_spmv_multi_kernel(
+    int64_t n_rows, int64_t k_per_row, int64_t stride, int64_t slice_size,
+    const uint64_t* __restrict__ slice_sets, const uint64_t* __restrict__ slice_lengths,
+    const I* __restrict__ cols, const T* __restrict__ vals, const T* __restrict__ b,
+    int64_t ldb, T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
+    const T* __restrict__ beta_p)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    T alpha = T(1), beta = T(0);
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    int64_t len = k_per_row, first = row, step = stride;
+    if (SELL) {
+        const int64_t slice = row / slice_size;
+        len = int64_t(slice_lengths[slice]);
+        first = int64_t(slice_sets[slice]) * slice_size + (row - slice * slice_size);
+        step = slice_size;
+    }
+    for (int j0 = 0; j0 < nrhs; j0 += NR) {
+        int jcol[NR];
+        T sum[NR];
+#pragma unroll
+        for (int jj = 0; jj < NR; ++jj) {
+            jcol[jj] = j0 + jj < nrhs ? j0 + jj : nrhs - 1;
+            sum[jj] = T(0);
+            if (ADV && beta != T(0)) {
+                sum[jj] = SELL ? c[row * ldc + jcol[jj]] * beta : beta * c[row * ldc + jcol[jj]];
+            }
+        }
+        fmt_row_sum_multi<T, I, ADV, NR>(sum, len, first, step, cols, vals, b, ldb, jcol, alpha);
+#pragma unroll
+        for (int jj = 0; jj < NR; ++jj) {
+            if (j0 + jj < nrhs) c[row * ldc + j0 + jj] = sum[jj];
+        }
+    }
+}
+
 // ELL / SELL-P SpMV: lane = row, and every lane owns TWO rows, 64 apart, of the
 // 128 consecutive rows of its wave, so that the wave ends with two back-to-back
 // 512 B stores = one contiguous 1 KB burst.  (Sparse small writes between the
@@ -374,6 +484,25 @@ int launch_ell(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t k,
                  GKOC_E_INVALID, "bad ELL dimensions");
     if (n_rows == 0 || nrhs == 0) return GKOC_OK;
     if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
+    if (nrhs >= 2) {
+        const dim3 grid(unsigned(ceildiv(n_rows, 256)));
+        if (nrhs == 2) {
+            fmt_spmv_multi_kernel<T, I, ADV, 2, false><<<grid, dim3(256), 0, as_stream(s)>>>(
+                n_rows, k, stride, 0, nullptr, nullptr, cols, vals, b, ldb, c, ldc, int(nrhs),
+                alpha, beta);
+        } else if (nrhs <= 4) {
+            fmt_spmv_multi_kernel<T, I, ADV, 4, false><<<grid, dim3(256), 0, as_stream(s)>>>(
+                n_rows, k, stride, 0, nullptr, nullptr, cols, vals, b, ldb, c, ldc, int(nrhs),
+                alpha, beta);
+        } else {
+            // wider blocks: 8 columns per pass use every gathered b line in full
+            fmt_spmv_multi_kernel<T, I, ADV, 8, false><<<grid, dim3(256), 0, as_stream(s)>>>(
+                n_rows, k, stride, 0, nullptr, nullptr, cols, vals, b, ldb, c, ldc, int(nrhs),
+                alpha, beta);
+        }
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     ell_spmv_kernel<T, I, ADV><<<dim3(unsigned(ceildiv(n_rows, 512))), dim3(256), 0, as_stream(s)>>>(
         n_rows, k, stride, cols, vals, b, ldb, c, ldc, int(nrhs), alpha, beta);
     GKOC_LAUNCH_OK();
@@ -392,6 +521,24 @@ int launch_sellp(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,
                  "bad SELL-P dimensions");
     if (n_rows == 0 || nrhs == 0) return GKOC_OK;
     if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
+    if (nrhs >= 2) {
+        const dim3 grid(unsigned(ceildiv(n_rows, 256)));
+        if (nrhs == 2) {
+            fmt_spmv_multi_kernel<T, I, ADV, 2, true><<<grid, dim3(256), 0, as_stream(s)>>>(
+                n_rows, 0, 0, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c, ldc,
+                int(nrhs), alpha, beta);
+        } else if (nrhs <= 4) {
+            fmt_spmv_multi_kernel<T, I, ADV, 4, true><<<grid, dim3(256), 0, as_stream(s)>>>(
+                n_rows, 0, 0, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c, ldc,
+                int(nrhs), alpha, beta);
+        } else {
+            fmt_spmv_multi_kernel<T, I, ADV, 8, true><<<grid, dim3(256), 0, as_stream(s)>>>(
+                n_rows, 0, 0, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c, ldc,
+                int(nrhs), alpha, beta);
+        }
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     sellp_spmv_kernel<T, I, ADV>
         <<<dim3(unsigned(ceildiv(n_rows, 512))), dim3(256), 0, as_stream(s)>>>(
             n_rows, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c,

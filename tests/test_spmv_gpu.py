@@ -169,7 +169,7 @@ def test_dimension_mismatch(gexec):
         a.apply(g.Dense.create(gexec, (2, 2)), g.Dense.create(gexec, (2, 1)))
 
 
-@pytest.mark.parametrize("nrhs", [1, 3])
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 5, 11])
 @pytest.mark.parametrize("idx", [np.int32, np.int64])
 def test_ell_bit_exact(gexec, oracle, nrhs, idx):
     import ginkgo_amd as g
@@ -194,7 +194,7 @@ def test_ell_bit_exact(gexec, oracle, nrhs, idx):
                               oracle.ell_spmv(532, k, st, ec, ev, b, alpha=2.0, beta=-1.0, c=c0))
 
 
-@pytest.mark.parametrize("nrhs", [1, 3])
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 5, 11])
 @pytest.mark.parametrize("slice_size,stride_factor", [(64, 1), (32, 2), (2, 2)])
 def test_sellp_bit_exact(gexec, oracle, nrhs, slice_size, stride_factor):
     import ginkgo_amd as g

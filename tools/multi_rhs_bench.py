@@ -1,21 +1,43 @@
-"""CSR SpMV on the 27-pt 256^3 Laplacian with 1, 2, 3, 4, 8 right-hand sides (fp64 / int32,
-HIP events, 10 launches): the one-pass kernel of csrc/csr_spmv_multi.hpp against one
-pass per column.
-  python tools/multi_rhs_bench.py"""
-import sys, os
-sys.path.insert(0, os.getcwd())
-import numpy as np, torch
+"""CSR / ELL / SELL-P SpMV on the 27-pt 256^3 Laplacian with 1, 2, 3, 4, 8 right-hand sides
+(fp64 / int32, HIP events, 10 launches): the one-pass kernels (csrc/csr_spmv_multi.hpp,
+fmt_spmv_multi_kernel in csrc/formats.hip); every column is checked bitwise against the
+single-column product.
+  python tools/multi_rhs_bench.py [grid=256]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+
 import ginkgo_amd as g
+
+grid = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ex = g.Cdna4Executor.create(0)
-a = g.stencil_csr(ex, 3, 256)
+a = g.stencil_csr(ex, 3, grid)
 n = a.size[0]
-for k in (1, 2, 3, 4, 8):
-    x = g.Dense.from_numpy(ex, np.random.default_rng(1).uniform(-1, 1, (n, k)))
-    y = g.Dense.create(ex, (n, k))
-    for _ in range(3): a.apply(x, y)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10): a.apply(x, y)
-    e1.record(); torch.cuda.synchronize()
-    print(f"nrhs {k}: {e0.elapsed_time(e1)/10:.3f} ms", flush=True)
+xs = np.random.default_rng(1).uniform(-1, 1, (n, 8))
+single = g.Dense.create(ex, (n, 8))
+for j in range(8):
+    a.apply(g.Dense.from_numpy(ex, xs[:, j].copy()), single.create_submatrix((0, n), (j, j + 1)))
+print(f"27-pt {grid}^3, n = {n}, nnz = {a.get_num_stored_elements()}")
+for name, make in (("csr", lambda: a), ("ell", a.convert_to_ell), ("sellp", a.convert_to_sellp)):
+    op = make()
+    for k in (1, 2, 3, 4, 8):
+        x = g.Dense.from_numpy(ex, xs[:, :k].copy())
+        y = g.Dense.create(ex, (n, k))
+        for _ in range(3):
+            op.apply(x, y)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(y.values, single.values[:, :k]))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            op.apply(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print(f"  {name:6s} nrhs {k}: {ms:7.3f} ms  ({ms / k:6.3f} ms per column)  columns == single-column bits: {same}",
+              flush=True)
+    del op
+    torch.cuda.empty_cache()
