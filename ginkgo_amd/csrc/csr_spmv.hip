@@ -63,6 +63,19 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     // 32 B of values per lane and load: 4 doubles or 8 floats (ring = 8 KB)
     constexpr int EV = 32 / sizeof(T);
     constexpr int RINGV = 8192 / sizeof(T);
+    if (nrhs >= 5 && n_seg < (int64_t(1) << 31)) {
+        // 5+ right-hand sides: row-ordered gather from an LDS-staged segment, 8 columns per
+        // pass (L256, 8 columns: 5.0 ms against 6.8 ms for the ring kernel; for 2-4 columns
+        // the ring kernel below is faster, 1.7-2.8 ms against 3.4-3.6 ms)
+        const dim3 g64(static_cast<unsigned>(n_seg));
+#define GKOC_LAUNCH_ROWMULTI(NR_)                                                        \
+    csr_spmv_rowmulti_kernel<T, I, ADV, NR_><<<g64, block, 0, as_stream(s)>>>(           \
+        n_rows, row_ptrs, col_idxs, vals, b, ldb, c, ldc, static_cast<int>(nrhs), alpha, beta)
+        GKOC_LAUNCH_ROWMULTI(8);
+#undef GKOC_LAUNCH_ROWMULTI
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     if (nrhs >= 2 && vec_ok) {
         // several right-hand sides: one pass over the matrix per chunk of 2 or 4
         // columns (csr_spmv_multi.hpp); b is read as pairs of columns when its
@@ -72,13 +85,8 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
             csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV, 2><<<grid, block, 0, as_stream(s)>>>(
                 n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
                 static_cast<int>(nrhs), alpha, beta, b_vec_ok);
-        } else if (nrhs <= 4) {
-            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 4><<<grid, block, 0, as_stream(s)>>>(
-                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
-                static_cast<int>(nrhs), alpha, beta, b_vec_ok);
         } else {
-            // 8 columns per pass (32 KB ring): every gathered b line is used in full
-            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 8><<<grid, block, 0, as_stream(s)>>>(
+            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 4><<<grid, block, 0, as_stream(s)>>>(
                 n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
                 static_cast<int>(nrhs), alpha, beta, b_vec_ok);
         }

@@ -17,6 +17,9 @@
 //     single-column kernel;
 //   * the results of a segment leave as 64 runs of NR contiguous values
 //     (one contiguous block when ldc == NR).
+// That kernel (csr_spmv_multi_kernel) serves 2-4 columns; for 5 and more,
+// csr_spmv_rowmulti_kernel below stages the segment in LDS and gathers in ROW order,
+// 8 columns per pass (the launcher in csr_spmv.hip holds the measured crossover).
 // Columns beyond nrhs in the last chunk are computed on a clamped column index
 // and not stored.  Rows longer than GKOC_CSR_LONG_ROW take the cooperative wave
 // path of the single-column kernel (tolerance-compared, include/gko_cdna4.h).
@@ -28,6 +31,134 @@ namespace gkoc {
 
 #ifdef __HIPCC__
 
+// The same for a chunk of NR right-hand sides: the row's entries are read ONCE, the NR
+// values b[col, jcol[0..NR)) of an entry are neighbours in the row-major b (one cache
+// line), and NR sums are carried; per column the products are added in column order,
+// so every column is bit-identical to the single-column kernels.  jcol = column behind slot jj
+// (slots past nrhs repeat the last column and are not stored).
+template <typename T, typename I, bool ADV, int NR>
+__device__ __forceinline__ void fmt_row_sum_multi(T (&sum)[NR], int64_t len, int64_t first,
+                                                  int64_t step, const I* __restrict__ cols,
+                                                  const T* __restrict__ vals,
+                                                  const T* __restrict__ b, int64_t ldb,
+                                                  const int (&jcol)[NR], T alpha)
+{
+    constexpr int U = 4;
+    const int64_t full = len / U * U;
+    T v0[U], v1[U];
+    I c0[U], c1[U];
+    if (full > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v0[u] = vals[first + u * step];
+            c0[u] = cols[first + u * step];
+        }
+    }
+    int64_t i = 0;
+    while (i < full) {
+        T xv[U][NR];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const T* __restrict__ brow = b + int64_t(c0[u] >= 0 ? c0[u] : I(0)) * ldb;
+#pragma unroll
+            for (int jj = 0; jj < NR; ++jj) xv[u][jj] = c0[u] >= 0 ? brow[jcol[jj]] : T(0);
+        }
+        const int64_t nx = i + U < full ? i + U : i;  // last chunk: harmless reload
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v1[u] = vals[first + (nx + u) * step];
+            c1[u] = cols[first + (nx + u) * step];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int jj = 0; jj < NR; ++jj) {
+                const T t = ADV ? (alpha * v0[u]) * xv[u][jj] : v0[u] * xv[u][jj];
+                sum[jj] = c0[u] >= 0 ? sum[jj] + t : sum[jj];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v0[u] = v1[u];
+            c0[u] = c1[u];
+        }
+        i += U;
+    }
+    for (; i < len; ++i) {
+        const I cc = cols[first + i * step];
+        if (cc >= 0) {
+            const T v = vals[first + i * step];
+            const T* __restrict__ brow = b + int64_t(cc) * ldb;
+#pragma unroll
+            for (int jj = 0; jj < NR; ++jj) {
+                const T xv = brow[jcol[jj]];
+                sum[jj] += ADV ? (alpha * v) * xv : v * xv;
+            }
+        }
+    }
+}
+
+// CSR, several right-hand sides, ROW-ORDERED gather: the wave's 64 rows own one
+// contiguous val / col range, which is staged in LDS with coalesced loads; then
+// lane = row walks its entries in k order (fmt_row_sum_multi on the staged copy) with
+// NR sums in registers.  The 64 lanes of a gather instruction then read the b rows
+// of entry i of 64 consecutive matrix rows - for banded / stencil matrices one
+// contiguous run of b - instead of the scattered neighbours of a few rows.
+// Segments above multi_stage_cap entries walk global memory directly (still exact).
+constexpr int multi_stage_cap = 2048;
+
+template <typename T, typename I, bool ADV, int NR>
+__global__ __launch_bounds__(64) void csr_spmv_rowmulti_kernel(
+    int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb, T* __restrict__ c,
+    int64_t ldc, int nrhs, const T* __restrict__ alpha_p, const T* __restrict__ beta_p)
+{
+    __shared__ __attribute__((aligned(16))) T lv[multi_stage_cap];
+    __shared__ __attribute__((aligned(16))) I lc[multi_stage_cap];
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;
+    const int64_t row = g * 64 + lane;
+    const bool valid = row < n_rows;
+    const int64_t last = (g + 1) * 64 < n_rows ? (g + 1) * 64 : n_rows;
+    const int64_t rs = row_ptrs[valid ? row : last];
+    const int64_t re = row_ptrs[valid ? row + 1 : last];
+    const int64_t K0 = row_ptrs[g * 64];
+    const int64_t K1 = row_ptrs[last];
+    T alpha = T(1), beta = T(0);
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    const bool staged = K1 - K0 <= multi_stage_cap;
+    if (staged) {
+        const int seg = int(K1 - K0);
+        for (int i = lane; i < seg; i += 64) {
+            lv[i] = vals[K0 + i];
+            lc[i] = cols[K0 + i];
+        }
+        wave_lds_sync();
+    }
+    const T* pv = staged ? lv : vals + K0;
+    const I* pc = staged ? lc : cols + K0;
+    for (int j0 = 0; j0 < nrhs; j0 += NR) {
+        int jcol[NR];
+        T sum[NR];
+#pragma unroll
+        for (int jj = 0; jj < NR; ++jj) {
+            jcol[jj] = j0 + jj < nrhs ? j0 + jj : nrhs - 1;
+            sum[jj] = T(0);
+            if (ADV && beta != T(0) && valid) sum[jj] = c[row * ldc + jcol[jj]] * beta;
+        }
+        if (valid) {
+            fmt_row_sum_multi<T, I, ADV, NR>(sum, re - rs, rs - K0, 1, pc, pv, b, ldb, jcol, alpha);
+#pragma unroll
+            for (int jj = 0; jj < NR; ++jj) {
+                if (j0 + jj < nrhs) c[row * ldc + j0 + jj] = sum[jj];
+            }
+        }
+    }
+}
+
 template <typename T, typename I, bool ADV, int E, int U, int RING, int NR>
 __global__ __launch_bounds__(64) void csr_spmv_multi_kernel(
     int64_t n_rows, int64_t n_segments, int64_t segs_per_wave,
@@ -37,7 +168,7 @@ __global__ __launch_bounds__(64) void csr_spmv_multi_kernel(
     const T* __restrict__ beta_p, int b_vec_ok)
 {
     static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
-    static_assert(NR == 2 || NR == 4 || NR == 8, "chunks of 2, 4 or 8 columns");
+    static_assert(NR == 2 || NR == 4, "chunks of 2 or 4 columns");
     constexpr int ROWS = 64;
     constexpr int G = 64 * E * U;
     static_assert(RING >= 2 * G, "ring too small for the group size");

@@ -19,6 +19,7 @@
 // reference's sequential summation order => bit-identical results.
 // Algorithmic HBM bytes: stored_elements*(sizeof(T)+sizeof(I)) + 2 n sizeof(T).
 #include "common.hpp"
+#include "csr_spmv_multi.hpp"
 #include "scan.hpp"
 
 namespace gkoc {
@@ -83,73 +84,6 @@ __device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
         }
     }
     return sum;
-}
-
-// The same for a chunk of NR right-hand sides: the row's entries are read ONCE, the NR
-// values b[col, jcol[0..NR)) of an entry are neighbours in the row-major b (one cache
-// line), and NR sums are carried; per column the products are added in column order,
-// so every column is bit-identical to fmt_row_sum.  jcol = column behind slot jj
-// (slots past nrhs repeat the last column and are not stored).
-template <typename T, typename I, bool ADV, int NR>
-__device__ __forceinline__ void fmt_row_sum_multi(T (&sum)[NR], int64_t len, int64_t first,
-                                                  int64_t step, const I* __restrict__ cols,
-                                                  const T* __restrict__ vals,
-                                                  const T* __restrict__ b, int64_t ldb,
-                                                  const int (&jcol)[NR], T alpha)
-{
-    constexpr int U = 4;
-    const int64_t full = len / U * U;
-    T v0[U], v1[U];
-    I c0[U], c1[U];
-    if (full > 0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            v0[u] = vals[first + u * step];
-            c0[u] = cols[first + u * step];
-        }
-    }
-    int64_t i = 0;
-    while (i < full) {
-        T xv[U][NR];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const T* __restrict__ brow = b + int64_t(c0[u] >= 0 ? c0[u] : I(0)) * ldb;
-#pragma unroll
-            for (int jj = 0; jj < NR; ++jj) xv[u][jj] = c0[u] >= 0 ? brow[jcol[jj]] : T(0);
-        }
-        const int64_t nx = i + U < full ? i + U : i;  // last chunk: harmless reload
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            v1[u] = vals[first + (nx + u) * step];
-            c1[u] = cols[first + (nx + u) * step];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int jj = 0; jj < NR; ++jj) {
-                const T t = ADV ? (alpha * v0[u]) * xv[u][jj] : v0[u] * xv[u][jj];
-                sum[jj] = c0[u] >= 0 ? sum[jj] + t : sum[jj];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            v0[u] = v1[u];
-            c0[u] = c1[u];
-        }
-        i += U;
-    }
-    for (; i < len; ++i) {
-        const I cc = cols[first + i * step];
-        if (cc >= 0) {
-            const T v = vals[first + i * step];
-            const T* __restrict__ brow = b + int64_t(cc) * ldb;
-#pragma unroll
-            for (int jj = 0; jj < NR; ++jj) {
-                const T xv = brow[jcol[jj]];
-                sum[jj] += ADV ? (alpha * v) * xv : v * xv;
-            }
-        }
-    }
 }
 
 // ELL / SELL-P SpMV with several right-hand sides: lane = row, one pass over the
