@@ -297,6 +297,56 @@ class Csr(_SparseBase):
              num_stored_per_row, stride, cols, vals)
         return Ell(self.exec, self.size, vals, cols, num_stored_per_row, stride)
 
+    def _time_apply(self, x, y, reps):
+        self.apply(x, y)
+        torch.cuda.synchronize(self.exec.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self.apply(x, y)
+        e1.record()
+        torch.cuda.synchronize(self.exec.device)
+        return e0.elapsed_time(e1) / reps
+
+    def tune_placement(self, x=None, y=None, trials=4, reps=3):
+        """Set-up step of this backend (the role Ginkgo's `automatical` strategy plays at
+        generate time, csr.hpp:519-697): on MI355X the SpMV time depends on WHICH device
+        allocations hold col_idxs / values / the output (0.99-1.20 ms for
+        the same kernel and data).  Copies col_idxs, then values, into `trials` fresh
+        allocations each, times the apply on every copy and keeps the fastest; the
+        others are released.  Contents are untouched.  Call it before generating solvers
+        or preconditioners on this matrix (they may capture the arrays).  Returns the
+        timings (ms)."""
+        ex = self.exec
+        x = x if x is not None else Dense.create(ex, (self.size[1], 1), self.dtype).fill(1.0)
+        y = y if y is not None else Dense.create(ex, (self.size[0], 1), self.dtype)
+        log = {"before_ms": self._time_apply(x, y, reps)}
+        for name in ("col_idxs", "values"):
+            cands = [getattr(self, name)]
+            times = [log["before_ms"] if name == "col_idxs" else log["col_idxs_ms"][log["col_idxs_pick"]]]
+            for _ in range(trials):
+                cands.append(cands[0].clone())
+                setattr(self, name, cands[-1])
+                times.append(self._time_apply(x, y, reps))
+            best = min(range(len(times)), key=times.__getitem__)
+            setattr(self, name, cands[best])
+            log[name + "_ms"], log[name + "_pick"] = [round(t, 4) for t in times], best
+            del cands
+        log["after_ms"] = self._time_apply(x, y, reps)
+        torch.cuda.empty_cache()
+        return log
+
+    def tuned_output(self, x, trials=4, reps=3):
+        """an output vector for apply(x, .) in the fastest of `trials` fresh allocations
+        (same reason as tune_placement); returns (vector, timings in ms)"""
+        cands = [Dense.create(self.exec, (self.size[0], x.size[1]), self.dtype) for _ in range(max(trials, 1))]
+        times = [self._time_apply(x, c, reps) for c in cands]
+        best = min(range(len(times)), key=times.__getitem__)
+        y = cands[best]
+        del cands
+        torch.cuda.empty_cache()
+        return y, [round(t, 4) for t in times]
+
     def transpose(self):
         """Csr::transpose (core/matrix/csr.cpp, csr::transpose kernel)"""
         ex = self.exec
