@@ -298,6 +298,9 @@ class HipBackend:
              col_lo, col_hi, n_global, col_map, local_ptrs, nl_full, local_cols, local_vals,
              nl_rows, nl_ptrs, nl_cols, nl_vals, recv_gidx)
         local = Csr(ex, (n, col_hi - col_lo), local_vals, local_cols, local_ptrs)
+        # set-up: home the local block's arrays in the fastest of a few fresh allocations
+        # (Csr.tune_placement); nothing has captured them yet
+        self.placement_log = local.tune_placement(trials=4) if nnz_l > 0 else None
         nl = dict(rows=nl_rows, ptrs=nl_ptrs, cols=nl_cols, vals=nl_vals, n=n_nl_rows,
                   suffix=f"{vt}_{it}")
         return local, nl, recv_gidx
