@@ -292,3 +292,24 @@ def test_csr_multi_rhs_full_size_columns_match_single(gexec):
             y = g.Dense.create(gexec, (n, k), dtype)
             m.apply(g.Dense(gexec, x[:, :k].contiguous()), y)
             assert torch.equal(y.values[:, :k], single.values[:, :k]), (dtype, k)
+
+
+def test_tune_placement_moves_arrays_only(gexec):
+    """Csr.tune_placement / tuned_output re-home the arrays: contents and
+    results are bit-identical, every candidate is timed, the fastest is kept"""
+    import ginkgo_amd as g
+    a = g.stencil_csr(gexec, 3, 64)
+    n = a.size[0]
+    x = g.Dense.from_numpy(gexec, np.random.default_rng(0).uniform(-1, 1, n))
+    y0 = g.Dense.create(gexec, (n, 1))
+    a.apply(x, y0)
+    cols, vals = a.col_idxs.clone(), a.values.clone()
+    log = a.tune_placement(x, trials=3)
+    assert len(log["col_idxs_ms"]) == 4 and len(log["values_ms"]) == 4
+    assert log["col_idxs_ms"][log["col_idxs_pick"]] == min(log["col_idxs_ms"])
+    assert log["values_ms"][log["values_pick"]] == min(log["values_ms"])
+    assert torch.equal(a.col_idxs, cols) and torch.equal(a.values, vals)
+    y1, times = a.tuned_output(x, trials=3)
+    assert len(times) == 3 and y1.size == (n, 1)
+    a.apply(x, y1)
+    assert torch.equal(y1.values, y0.values)
