@@ -32,6 +32,38 @@ def spmv_algorithmic_bytes(n_rows, n_cols, nnz, val_bytes=8, idx_bytes=4):
         n_cols * val_bytes + n_rows * val_bytes
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _interleave_host_memory(on):
+    """The reference's arrays are first touched by ONE thread (the copy into the
+    executor), i.e. they would all sit on one NUMA node while OpenMP threads of every
+    socket read them.  set_mempolicy(MPOL_INTERLEAVE) over all nodes for the
+    allocations of the baseline spreads the pages instead.  Returns what was done."""
+    import ctypes as C
+    try:
+        nodes = [d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]
+        n = len(nodes)
+        if n < 2:
+            return f"{max(n, 1)} NUMA node"
+        libc = C.CDLL(None, use_errno=True)
+        mask = C.c_ulong((1 << n) - 1 if on else 0)
+        mode = 3 if on else 0          # MPOL_INTERLEAVE / MPOL_DEFAULT
+        rc = libc.syscall(238, C.c_int(mode), C.byref(mask), C.c_ulong(64))   # SYS_set_mempolicy, x86-64
+        if rc != 0:
+            return f"{n} NUMA nodes, first touch by one thread (set_mempolicy refused)"
+        return f"pages interleaved over {n} NUMA nodes"
+    except Exception:
+        return "unknown"
+
+
 def cpu_baseline(grid, csr_host=None, budget_s=12.0):
     """Time the CPU reference on rank 0 on the SAME matrix as the GPU run
     (`csr_host` = (row_ptrs, cols, vals) copied back from the device; generated
@@ -42,6 +74,7 @@ def cpu_baseline(grid, csr_host=None, budget_s=12.0):
     import ctypes as C
     import numpy as np
     from oracle import gko_oracle as o
+    numa = _interleave_host_memory(True)
     own = csr_host is not None
     if csr_host is None:
         csr_host = o.stencil_csr(3, grid)
@@ -74,8 +107,9 @@ def cpu_baseline(grid, csr_host=None, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or reps >= 200:
             break
+    _interleave_host_memory(False)
     return {"value": round(nbytes * reps / el / 1e9, 3), "unit": "GB/s",
-            "cores": cores, "kind": kind,
+            "cores": cores, "kind": kind, "cpu": _cpu_model(), "numa": numa,
             "sample": f"27-pt {grid}^3 CSR SpMV fp64/int32"
                       f"{' (the matrix of the GPU run, copied to the host)' if own else ''}, "
                       f"{reps} reps in {el:.1f} s"}
@@ -93,9 +127,12 @@ def main():
                     help="0 = time the CPU reference on the GPU run's own matrix; "
                          "otherwise a separately generated grid^3 matrix")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--placement", type=int, default=6,
-                    help="candidate device allocations per array in the untimed placement set-up (0 = off)")
+    ap.add_argument("--arena", type=int, default=None,
+                    help="GKOC_ARENA mode of the library's allocator: 2 = memory-class regions "
+                         "(default), 1 = plain chunks, 0 = one hipMalloc per array (DESIGN.md 3.2)")
     args = ap.parse_args()
+    if args.arena is not None:
+        os.environ["GKOC_ARENA"] = str(args.arena)
 
     # stdout carries exactly one line, the JSON result: everything else written to
     # file descriptor 1 by this process (RCCL prints a version banner there from C
@@ -142,9 +179,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Order of allocation: matrix, then the solver (block-Jacobi storage, Krylov
-    # workspace), then the SpMV vectors.  DESIGN.md 3.2: vectors allocated right
-    # next to the matrix measured up to 15 % slower for the same kernel.
+    # Placement is the allocator's job (csrc/arena.hip): matrix values,
+    # index arrays and vectors come from three different memory classes of the device;
+    # nothing is tuned or re-homed here.
     solver = None
     t_setup = 0.0
     if not use_dist:
@@ -153,12 +190,6 @@ def main():
         nnz_global = a.get_num_stored_elements()
         x = g.Dense.from_numpy(
             ex, __import__("numpy").random.default_rng(42).uniform(-1, 1, n_global))
-        # set-up, untimed, before anything captures the arrays: DESIGN.md 3.2 - the same
-        # kernel on the same data takes 0.99-1.20 ms depending on which device
-        # allocations hold the arrays, so the backend re-homes col_idxs / values and
-        # picks the output vector among a few fresh allocations (Csr.tune_placement /
-        # tuned_output); contents unchanged
-        tuned = a.tune_placement(x, trials=args.placement) if args.placement > 0 else None
         if args.cg_iters > 0:
             t_setup = time.perf_counter()
             solver = (g.Cg.build()
@@ -173,10 +204,7 @@ def main():
             sol = g.Dense.from_numpy(ex, np.zeros(n_local))
             solver.apply(rhs, sol.fill(0.0))       # warm-up solve (allocates the workspace)
             barrier()
-        if tuned is not None:
-            y, tuned["output_ms"] = a.tuned_output(x, trials=args.placement)
-        else:
-            y = g.Dense.create(ex, (n_local, 1))
+        y = g.Dense.create(ex, (n_local, 1))
         step = lambda: a.apply(x, y)
         op = a
     else:
@@ -238,11 +266,15 @@ def main():
     if rank == 0:
         per_gpu_bytes = total_bytes / world
         achieved = per_gpu_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this
+        # kernel (counters cannot be read from inside the process): the committed
+        # summary of the last such run, NOT a measurement of this run
+        traffic, traffic_source = None, None
         prof = os.path.join(ROOT, "profiles", "spmv_pmc_latest.json")
         if not use_dist and grid == 256 and os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/spmv_pmc_latest.json (separate rocprofv3 --pmc run)"
             except Exception:
                 traffic = None
         out = {
@@ -260,7 +292,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ("csr_spmv_pipe3_kernel<double,int,...>" if not use_dist else
                                     "per-rank distributed apply: halo pack + exchange || local "
                                     "csr_spmv_pipe3_kernel, then boundary rows"),
@@ -268,17 +300,32 @@ def main():
                          "algorithmic_bytes_per_launch": int(per_gpu_bytes)},
         }
         out.update(cg)
-        if not use_dist and tuned is not None:
-            # what the set-up step saw (ms per launch): the arrays as first allocated, every
-            # candidate allocation of col_idxs / values / output, and the choice made
+        if not use_dist:
+            import ctypes as C
+            from ginkgo_amd import _lib
+
+            class ArenaInfo(C.Structure):
+                _fields_ = [("mode", C.c_int32), ("num_classes", C.c_int32),
+                            ("chunk_bytes", C.c_int64), ("num_chunks", C.c_int64),
+                            ("reserved_bytes", C.c_int64), ("used_bytes", C.c_int64),
+                            ("num_allocations", C.c_int64), ("probes", C.c_int64),
+                            ("granules_walked", C.c_int64), ("spare_bytes", C.c_int64),
+                            ("class_reserved_bytes", C.c_int64 * 3),
+                            ("class_used_bytes", C.c_int64 * 3)]
+            info = ArenaInfo()
+            _lib.call("gkoc_arena_stats", C.byref(info))
             out["placement"] = {
-                "note": "untimed set-up: col_idxs, values and the output vector re-homed to the "
-                        "fastest of N fresh device allocations (same data, same kernel; DESIGN.md 3.2)",
-                "kernel_ms_untuned": round(tuned["before_ms"], 4),
-                "kernel_ms_tuned": round(min(tuned["output_ms"]), 4),
-                "frac_untuned": round(per_gpu_bytes / (tuned["before_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "col_idxs_ms": tuned["col_idxs_ms"], "values_ms": tuned["values_ms"],
-                "output_ms": tuned["output_ms"], "n": args.placement}
+                "note": "device allocator of the library (csrc/arena.hip): one region per memory "
+                        "class of the MI355X, class of every 1 GiB granule measured by a probe; "
+                        "nothing tuned per run",
+                "arena_mode": info.mode, "memory_classes_found": info.num_classes,
+                "class_of": {"values": ex.memory_class(a.values), "col_idxs": ex.memory_class(a.col_idxs),
+                             "row_ptrs": ex.memory_class(a.row_ptrs), "x": ex.memory_class(x.values),
+                             "y": ex.memory_class(y.values)},
+                "reserved_gib": round(info.reserved_bytes / 2 ** 30, 2),
+                "used_gib": round(info.used_bytes / 2 ** 30, 2),
+                "spare_gib": round(info.spare_bytes / 2 ** 30, 2),
+                "granules_walked": info.granules_walked, "probe_launches": info.probes}
         if not args.no_cpu and not use_dist:
             if args.cpu_grid:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_grid)

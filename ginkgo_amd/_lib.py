@@ -30,6 +30,10 @@ class DimensionMismatch(GkoError):
     pass
 
 
+class BadDimension(GkoError):
+    """gko::BadDimension"""
+
+
 class JacobiScheme(C.Structure):
     """gkoc_jacobi_scheme == gko block_interleaved_storage_scheme."""
     _fields_ = [("block_offset", C.c_int64), ("group_offset", C.c_int64),

@@ -1,0 +1,719 @@
+// Device-memory arena of libgko_cdna4: the policy behind gkoc_malloc / gkoc_free,
+// i.e. behind HipExecutor::raw_alloc / raw_free and HipAllocator::allocate /
+// deallocate of the Ginkgo binding (reference: hip/base/memory.hip.cpp,
+// hip/base/executor.hip.cpp:95-112 - one hipMalloc / hipFree per request).
+//
+// Why the backend places memory itself (measurements: DESIGN.md 3.2,
+// profiles/r02_placement/).  The 288 GiB of an MI355X consist of three MEMORY
+// CLASSES of 96 GiB (in all likelihood the three ranks of the 12-high HBM3E
+// stacks; the free-block sizes of the driver's allocator say they are the three
+// contiguous thirds of the physical address space).  A kernel whose
+// read streams and written stream live in the SAME class is about 11 % slower than
+// one whose output lives in another class (CSR SpMV on the 27-pt 256^3 Laplacian:
+// 1.127 ms against 1.005 ms; values and column indices in two different classes as
+// well: 0.985 ms; block-Jacobi apply 246 against 226 us).  With one hipMalloc per
+// array the class of every array is an accident of the allocation history - the
+// "allocation lottery" of round 1.  The arena removes the accident:
+//   * it owns three REGIONS, one per class: a virtual address range backed by
+//     1 GiB physical granules (hipMemCreate + hipMemMap) of that class only;
+//   * the class of a fresh granule is MEASURED with a 0.2 ms probe (every wavefront
+//     streams a private piece of a region's first granule and writes a short piece
+//     of the new one: same class = 10 % slower; the reference is the same launch
+//     writing into a reserved 32 MiB target of the region itself).  A fresh device
+//     hands out all three classes within the first few GiB; granules of a class
+//     nobody asked for yet wait in a pool (GKOC_ARENA_SPARE_MB, default 16384);
+//   * requests are placed by role: matrix values -> class 0, index arrays ->
+//     class 1, vectors (everything a kernel writes) -> class 2.  gkoc_malloc has no
+//     role argument (Ginkgo's raw_alloc has none): it takes requests of at least a
+//     quarter of the largest live request for matrix arrays (values / indices by
+//     load) and smaller ones for vectors; gkoc_malloc_role states the role.
+// Requests below 1 MiB come from plain 64 MiB chunks (they live in the caches).
+//
+// Modes (gkoc_arena_configure or the environment variable GKOC_ARENA):
+//   0  off: hipMalloc / hipFree per request (the reference's behaviour)
+//   1  plain chunks from hipMalloc, first fit, no classes
+//   2  class regions as described (default)
+// Chunk size of mode 1: GKOC_ARENA_CHUNK_MB (default 8192); granule size of mode 2:
+// GKOC_ARENA_GRANULE_MB (default and minimum 1024, power of two).  Fresh device
+// memory costs about 30 ms per GiB whoever asks for it (the driver clears it).
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace gkoc {
+namespace {
+
+constexpr size_t MiB = size_t(1) << 20, GiB = size_t(1) << 30;
+constexpr size_t small_limit = MiB;          // below: small pool
+constexpr size_t small_chunk = 64 * MiB;
+constexpr int max_classes = 3;
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- a range of device memory with a first-fit free list --------------------
+struct span {
+    char* base = nullptr;
+    size_t size = 0;                          // usable bytes from base
+    std::map<size_t, size_t> free_list;       // offset -> size
+    std::map<size_t, size_t> used;            // offset -> size
+    size_t in_use = 0;
+
+    void* take(size_t bytes, size_t align)
+    {
+        for (auto it = free_list.begin(); it != free_list.end(); ++it) {
+            const size_t off = it->first, sz = it->second;
+            const size_t a = round_up(reinterpret_cast<uintptr_t>(base) + off, align) -
+                             reinterpret_cast<uintptr_t>(base);
+            if (a + bytes > off + sz) continue;
+            free_list.erase(it);
+            if (a > off) free_list[off] = a - off;
+            if (a + bytes < off + sz) free_list[a + bytes] = off + sz - (a + bytes);
+            used[a] = bytes;
+            in_use += bytes;
+            return base + a;
+        }
+        return nullptr;
+    }
+    bool owns(const void* p) const
+    {
+        return static_cast<const char*>(p) >= base && static_cast<const char*>(p) < base + size;
+    }
+    // false if p is not the start of an allocation
+    bool give(void* p)
+    {
+        const size_t off = size_t(static_cast<char*>(p) - base);
+        auto u = used.find(off);
+        if (u == used.end()) return false;
+        size_t sz = u->second;
+        used.erase(u);
+        in_use -= sz;
+        add_free(off, sz);
+        return true;
+    }
+    void add_free(size_t off, size_t sz)
+    {
+        auto nxt = free_list.lower_bound(off);
+        if (nxt != free_list.end() && off + sz == nxt->first) {
+            sz += nxt->second;
+            nxt = free_list.erase(nxt);
+        }
+        if (nxt != free_list.begin()) {
+            auto prv = std::prev(nxt);
+            if (prv->first + prv->second == off) {
+                prv->second += sz;
+                return;
+            }
+        }
+        free_list[off] = sz;
+    }
+    // bytes of the free block that ends at `size` (0 if the end is in use)
+    size_t free_tail() const
+    {
+        if (free_list.empty()) return 0;
+        auto last = std::prev(free_list.end());
+        return last->first + last->second == size ? last->second : 0;
+    }
+};
+
+struct region : span {
+    size_t reserved = 0;                                    // bytes of virtual address space
+    std::vector<hipMemGenericAllocationHandle_t> granules;  // mapped back to back from base
+};
+
+struct device_arena {
+    std::vector<span*> small;     // hipMalloc'ed 64 MiB chunks (modes 1, 2)
+    std::vector<span*> plain;     // mode 1 chunks
+    // mode 2
+    bool ready = false, no_more_classes = false, failed = false;
+    int n_cls = 0;
+    region reg[max_classes];
+    // Virtual addresses for classifying candidates.  Every address is used for ONE
+    // mapping only: on this system (ROCm 7.2) a kernel that accesses an address which
+    // was unmapped and mapped to another physical handle still reaches the OLD memory
+    // (stale translation; tools/vmm_tlb.hip, profiles/r02_placement/vmm_remap_stale_translation.txt)
+    char* scratch = nullptr;      // next unused address of the current window
+    size_t scratch_left = 0;
+    hipStream_t stream = nullptr;
+    std::vector<hipMemGenericAllocationHandle_t> spare[max_classes];   // classified, unmapped
+    size_t max_large = 0;         // largest live large request (role heuristic)
+    int64_t probes = 0, walked = 0;
+};
+
+std::mutex g_mtx;
+int g_mode = -1;            // -1: read the environment on first use
+size_t g_chunk_bytes = 0;
+size_t g_granule_bytes = 0, g_spare_bytes = 0;
+int g_sync_free = 1;
+int g_verbose = 0;
+device_arena g_arena[64];
+
+void read_env_locked()
+{
+    if (g_mode >= 0) return;
+    const char* m = std::getenv("GKOC_ARENA");
+    g_mode = m ? std::atoi(m) : 2;
+    if (g_mode < 0 || g_mode > 2) g_mode = 2;
+    const char* c = std::getenv("GKOC_ARENA_CHUNK_MB");
+    const long long mb = c ? std::atoll(c) : 8192;
+    g_chunk_bytes = size_t(mb > 2 ? mb : 2) * MiB;
+    const char* gm = std::getenv("GKOC_ARENA_GRANULE_MB");
+    g_granule_bytes = GiB;
+    while (gm && g_granule_bytes < size_t(std::atoll(gm)) * MiB) g_granule_bytes *= 2;
+    const char* sp = std::getenv("GKOC_ARENA_SPARE_MB");
+    g_spare_bytes = size_t(sp ? std::atoll(sp) : 16384) * MiB;
+    const char* sf = std::getenv("GKOC_ARENA_SYNC_FREE");
+    g_sync_free = sf ? std::atoi(sf) : 1;
+    const char* v = std::getenv("GKOC_ARENA_VERBOSE");
+    g_verbose = v ? std::atoi(v) : 0;
+}
+
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return dev;
+}
+
+size_t granule_bytes() { return g_granule_bytes; }
+
+// the first probe_target bytes of every region are never handed out: the probe
+// writes there to get the "same class" reference time
+constexpr size_t probe_target = 32 * MiB;
+
+// ---- memory-class probe ----------------------------------------------------
+// The access pattern that shows the classes, reduced to its essentials: every
+// wavefront streams a private contiguous piece of `x` (read only, any content) and
+// then stores a short contiguous piece of `y`.  x must be well beyond the 256 MiB
+// memory-side cache (2 GiB: 0.40 ms same class, 0.36 ms different classes).
+__global__ __launch_bounds__(64) void arena_probe_kernel(const uint4* __restrict__ x,
+                                                         int loads_per_wave,
+                                                         uint4* __restrict__ y,
+                                                         int stores_per_wave)
+{
+    const int lane = threadIdx.x;
+    const uint4* xp = x + (size_t(blockIdx.x) * loads_per_wave) * 64 + lane;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    int i = 0;
+    for (; i + 4 <= loads_per_wave; i += 4) {
+        const uint4 a = xp[(i + 0) * 64];
+        const uint4 b = xp[(i + 1) * 64];
+        const uint4 c = xp[(i + 2) * 64];
+        const uint4 d = xp[(i + 3) * 64];
+        acc.x += a.x ^ b.x ^ c.x ^ d.x;
+        acc.y += a.y ^ b.y ^ c.y ^ d.y;
+        acc.z += a.z ^ b.z ^ c.z ^ d.z;
+        acc.w += a.w ^ b.w ^ c.w ^ d.w;
+    }
+    for (; i < loads_per_wave; ++i) {
+        const uint4 a = xp[i * 64];
+        acc.x += a.x;
+        acc.y += a.y;
+        acc.z += a.z;
+        acc.w += a.w;
+    }
+    uint4* yp = y + (size_t(blockIdx.x) * stores_per_wave) * 64 + lane;
+    for (int k = 0; k < stores_per_wave; ++k) yp[k * 64] = acc;
+}
+
+// time of one probe launch in ns (best of `reps`), on `st`
+int probe_ns(hipStream_t st, const void* x, size_t x_bytes, void* y, int read_kb, int write_b,
+             int reps, int64_t* ns)
+{
+    const int loads = read_kb;   // 64 lanes * 16 B = 1 KiB per wave load
+    const int stores = write_b / 1024 > 0 ? write_b / 1024 : 1;
+    const size_t waves = x_bytes / (size_t(read_kb) * 1024);
+    GKOC_REQUIRE(waves > 0 && waves < (size_t(1) << 31), GKOC_E_INVALID, "probe range");
+    hipEvent_t a, b;
+    GKOC_HIP(hipEventCreate(&a));
+    GKOC_HIP(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int r = 0; r <= reps; ++r) {
+        GKOC_HIP(hipEventRecord(a, st));
+        arena_probe_kernel<<<dim3(unsigned(waves)), dim3(64), 0, st>>>(
+            static_cast<const uint4*>(x), loads, static_cast<uint4*>(y), stores);
+        GKOC_HIP(hipEventRecord(b, st));
+        GKOC_HIP(hipEventSynchronize(b));
+        float ms = 0;
+        GKOC_HIP(hipEventElapsedTime(&ms, a, b));
+        if (r > 0 && ms < best) best = ms;   // launch 0 warms up
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ns = int64_t(double(best) * 1e6);
+    return GKOC_OK;
+}
+
+constexpr int probe_read_kb = 32, probe_write_b = 1024;
+// read the first granule of a region behind its probe target (992 MiB at 1 GiB
+// granules: 0.21 ms same class, 0.19 ms different); writes 31 MiB
+constexpr size_t probe_x_bytes = GiB - probe_target;
+
+// ---- physical granules -------------------------------------------------------
+hipMemAllocationProp granule_prop(int dev)
+{
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    return prop;
+}
+
+hipError_t map_granule(char* va, size_t bytes, hipMemGenericAllocationHandle_t h, int dev)
+{
+    hipError_t e = hipMemMap(va, bytes, 0, h, 0);
+    if (e != hipSuccess) return e;
+    hipMemAccessDesc acc{};
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = dev;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    e = hipMemSetAccess(va, bytes, &acc, 1);
+    if (e != hipSuccess) (void)hipMemUnmap(va, bytes);
+    return e;
+}
+
+// class of the granule mapped at `cand`: an existing class id, A.n_cls for "none of
+// the known classes", -1 if the probe failed
+int classify_at(device_arena& A, char* cand)
+{
+    for (int k = 0; k < A.n_cls; ++k) {
+        const char* x = A.reg[k].base + probe_target;
+        int64_t t_ref = 0, t_new = 0;
+        if (probe_ns(A.stream, x, probe_x_bytes, A.reg[k].base, probe_read_kb, probe_write_b, 2, &t_ref) ||
+            probe_ns(A.stream, x, probe_x_bytes, cand, probe_read_kb, probe_write_b, 2, &t_new)) {
+            return -1;
+        }
+        A.probes += 2;
+        if (g_verbose > 1) {
+            fprintf(stderr, "[gkoc arena]   probe vs class %d: %.0f us, reference %.0f us\n", k,
+                    t_new / 1e3, t_ref / 1e3);
+        }
+        if (double(t_new) > 0.95 * double(t_ref)) return k;
+    }
+    return A.n_cls;
+}
+
+// region of the next class = [probe target | free space] on granule h
+bool start_class(device_arena& A, int dev, hipMemGenericAllocationHandle_t h)
+{
+    const size_t gr = granule_bytes();
+    region& R = A.reg[A.n_cls];
+    if (map_granule(R.base, gr, h, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    R.granules.push_back(h);
+    R.add_free(probe_target, gr - probe_target);
+    R.size = gr;
+    ++A.n_cls;
+    return true;
+}
+
+// a granule of class `want` (want == A.n_cls: of a class not seen yet), from the pool
+// or from the driver.  Granules of other classes met on the way go to the pool of
+// their class; nothing is released during a search (the driver would hand the same
+// block out again), afterwards the pools are cut back to GKOC_ARENA_SPARE_MB.
+hipError_t acquire_granule(device_arena& A, int dev, int want, hipMemGenericAllocationHandle_t* out)
+{
+    const size_t gr = granule_bytes();
+    if (want < max_classes && !A.spare[want].empty()) {
+        *out = A.spare[want].front();
+        A.spare[want].erase(A.spare[want].begin());
+        return hipSuccess;
+    }
+    const hipMemAllocationProp prop = granule_prop(dev);
+    std::vector<hipMemGenericAllocationHandle_t> unknown;
+    hipError_t result = hipErrorOutOfMemory;
+    const char* lim = std::getenv("GKOC_ARENA_MAX_WALK");
+    const int max_walk = lim ? std::atoi(lim) : 256;
+    for (int step = 0; step < max_walk; ++step) {
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, gr, &prop, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            result = e;
+            break;
+        }
+        ++A.walked;
+        int cls = 0;
+        if (A.n_cls > 0) {
+            if (A.scratch_left < gr) {
+                // a fresh window of never-used addresses (1024 candidates)
+                void* va = nullptr;
+                e = hipMemAddressReserve(&va, 1024 * gr, gr, nullptr, 0);
+                if (e != hipSuccess) {
+                    (void)hipMemRelease(h);
+                    result = e;
+                    break;
+                }
+                A.scratch = static_cast<char*>(va);
+                A.scratch_left = 1024 * gr;
+            }
+            char* cand = A.scratch;
+            A.scratch += gr;
+            A.scratch_left -= gr;
+            e = map_granule(cand, gr, h, dev);
+            if (e != hipSuccess) {
+                (void)hipMemRelease(h);
+                result = e;
+                break;
+            }
+            cls = classify_at(A, cand);
+            (void)hipMemUnmap(cand, gr);
+        }
+        if (g_verbose) {
+            fprintf(stderr, "[gkoc arena] granule %lld: class %d (want %d)\n", (long long)A.walked, cls,
+                    want);
+        }
+        if (cls == want) {
+            *out = h;
+            result = hipSuccess;
+            break;
+        }
+        if (cls >= 0 && cls < A.n_cls) {
+            A.spare[cls].push_back(h);
+        } else if (cls == A.n_cls && cls < max_classes && start_class(A, dev, h)) {
+            // a class nobody has asked for yet: its region starts with this granule
+        } else {
+            unknown.push_back(h);   // failed probe
+        }
+    }
+    for (auto h : unknown) (void)hipMemRelease(h);
+    // cut the pools back, largest first
+    for (;;) {
+        size_t total = 0;
+        int big = 0;
+        for (int k = 0; k < max_classes; ++k) {
+            total += A.spare[k].size() * gr;
+            if (A.spare[k].size() > A.spare[big].size()) big = k;
+        }
+        if (total <= g_spare_bytes || A.spare[big].empty()) break;
+        (void)hipMemRelease(A.spare[big].back());
+        A.spare[big].pop_back();
+    }
+    return result;
+}
+
+// map `count` more granules of its class at the end of region `cls`
+hipError_t extend_region(device_arena& A, int dev, int cls, size_t count)
+{
+    const size_t gr = granule_bytes();
+    region& R = A.reg[cls];
+    for (size_t i = 0; i < count; ++i) {
+        if (R.size + gr > R.reserved) return hipErrorOutOfMemory;
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = acquire_granule(A, dev, cls, &h);
+        if (e != hipSuccess) return e;
+        e = map_granule(R.base + R.size, gr, h, dev);
+        if (e != hipSuccess) {
+            (void)hipMemRelease(h);
+            return e;
+        }
+        R.granules.push_back(h);
+        R.add_free(R.size, gr);
+        R.size += gr;
+    }
+    return hipSuccess;
+}
+
+hipError_t classes_init(device_arena& A, int dev)
+{
+    const size_t gr = granule_bytes();
+    hipError_t e = hipStreamCreateWithFlags(&A.stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+    void* va = nullptr;
+    size_t total = 0, free_b = 0;
+    (void)hipMemGetInfo(&free_b, &total);
+    const size_t reserve = round_up(total ? total : size_t(288) * GiB, gr);
+    for (int k = 0; k < max_classes; ++k) {
+        e = hipMemAddressReserve(&va, reserve, gr, nullptr, 0);
+        if (e != hipSuccess) return e;
+        A.reg[k].base = static_cast<char*>(va);
+        A.reg[k].reserved = reserve;
+        A.reg[k].size = 0;
+    }
+    A.ready = true;
+    return hipSuccess;
+}
+
+// make class `cls` exist (classes are discovered in order); false if it cannot
+bool ensure_class(device_arena& A, int dev, int cls)
+{
+    while (A.n_cls <= cls && !A.no_more_classes) {
+        hipMemGenericAllocationHandle_t h;
+        if (acquire_granule(A, dev, A.n_cls, &h) != hipSuccess || !start_class(A, dev, h)) {
+            A.no_more_classes = true;
+        }
+    }
+    return A.n_cls > cls;
+}
+
+int class_for_role(const device_arena& A, int role, size_t bytes)
+{
+    if (role == GKOC_MEM_AUTO) {
+        // matrix arrays are the largest requests of a solve: at least a quarter of the
+        // largest live one counts as a matrix array, anything smaller as a vector
+        if (bytes * 4 >= A.max_large) {
+            role = A.reg[0].in_use <= A.reg[1].in_use ? GKOC_MEM_VALUES : GKOC_MEM_INDICES;
+        } else {
+            role = GKOC_MEM_VECTOR;
+        }
+    }
+    return role == GKOC_MEM_VALUES ? 0 : role == GKOC_MEM_INDICES ? 1 : 2;
+}
+
+int span_list_malloc(std::vector<span*>& list, size_t chunk_bytes, void** ptr, size_t need,
+                     size_t align)
+{
+    for (span* c : list) {
+        if (c->size - c->in_use < need) continue;
+        if (void* p = c->take(need, align)) {
+            *ptr = p;
+            return GKOC_OK;
+        }
+    }
+    span* c = new span;
+    const size_t want = need > chunk_bytes ? round_up(need, 2 * MiB) : chunk_bytes;
+    void* base = nullptr;
+    hipError_t e = hipMalloc(&base, want);
+    size_t got = want;
+    if (e != hipSuccess && want > round_up(need, 2 * MiB)) {
+        (void)hipGetLastError();
+        got = round_up(need, 2 * MiB);
+        e = hipMalloc(&base, got);
+    }
+    if (e != hipSuccess) {
+        delete c;
+        return hip_fail(e, "arena chunk allocation", __FILE__, __LINE__);
+    }
+    c->base = static_cast<char*>(base);
+    c->size = got;
+    c->free_list[0] = got;
+    list.push_back(c);
+    *ptr = c->take(need, align);
+    return *ptr ? GKOC_OK : GKOC_E_INVALID;
+}
+
+// 1 = freed, 0 = not ours, <0 = error
+int span_list_free(std::vector<span*>& list, void* ptr, size_t regular_size, bool release_empty_odd)
+{
+    for (size_t i = 0; i < list.size(); ++i) {
+        span* c = list[i];
+        if (!c->owns(ptr)) continue;
+        if (!c->give(ptr)) return GKOC_E_INVALID;
+        if (release_empty_odd && c->in_use == 0 && c->size != regular_size) {
+            (void)hipFree(c->base);
+            delete c;
+            list.erase(list.begin() + i);
+        }
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+int arena_malloc(void** ptr, size_t bytes, int role)
+{
+    *ptr = nullptr;
+    if (bytes == 0) return GKOC_OK;
+    std::lock_guard<std::mutex> g(g_mtx);
+    read_env_locked();
+    if (g_mode == 0) {
+        GKOC_HIP(hipMalloc(ptr, bytes));
+        return GKOC_OK;
+    }
+    const int dev = current_device();
+    device_arena& A = g_arena[dev];
+    const size_t need = round_up(bytes, 256);
+    if (bytes < small_limit) return span_list_malloc(A.small, small_chunk, ptr, need, 256);
+    const size_t align = 2 * MiB;
+    if (g_mode == 1 || A.failed) {
+        return span_list_malloc(A.plain, g_chunk_bytes, ptr, need, align);
+    }
+    if (!A.ready) {
+        const hipError_t e = classes_init(A, dev);
+        if (e != hipSuccess) {
+            // no virtual-memory API on this system: plain chunks
+            (void)hipGetLastError();
+            A.failed = true;
+            return span_list_malloc(A.plain, g_chunk_bytes, ptr, need, align);
+        }
+    }
+    int cls = class_for_role(A, role, bytes);
+    if (!ensure_class(A, dev, cls)) {
+        if (A.n_cls == 0) {
+            A.failed = true;
+            return span_list_malloc(A.plain, g_chunk_bytes, ptr, need, align);
+        }
+        // fewer classes than roles: vectors keep a class of their own as long as
+        // there are two
+        cls = (cls == 2 && A.n_cls == 2) ? 1 : 0;
+    }
+    const size_t gr = granule_bytes();
+    for (int attempt = 0; attempt < max_classes; ++attempt) {
+        region& R = A.reg[cls];
+        if (void* p = R.take(need, align)) {
+            *ptr = p;
+            if (need > A.max_large) A.max_large = need;
+            return GKOC_OK;
+        }
+        const size_t tail = R.free_tail();
+        const size_t count = tail >= need + 2 * MiB ? 1 : (need + 2 * MiB - tail + gr - 1) / gr;
+        if (extend_region(A, dev, cls, count) == hipSuccess) {
+            if (void* p = R.take(need, align)) {
+                *ptr = p;
+                if (need > A.max_large) A.max_large = need;
+                return GKOC_OK;
+            }
+        }
+        (void)hipGetLastError();
+        // this class is exhausted: any other class is better than failing
+        cls = (cls + 1) % A.n_cls;
+    }
+    set_last_error("arena: out of device memory for a request of %zu bytes", bytes);
+    return static_cast<int>(hipErrorOutOfMemory);
+}
+
+int arena_free(void* ptr)
+{
+    if (!ptr) return GKOC_OK;
+    {
+        std::unique_lock<std::mutex> g(g_mtx);
+        for (int dev = 0; dev < 64; ++dev) {
+            device_arena& A = g_arena[dev];
+            bool ours = false;
+            for (span* c : A.small) ours = ours || c->owns(ptr);
+            for (span* c : A.plain) ours = ours || c->owns(ptr);
+            for (int k = 0; k < A.n_cls; ++k) ours = ours || A.reg[k].owns(ptr);
+            if (!ours) continue;
+            if (g_sync_free) {
+                // hipFree semantics: nothing enqueued earlier still uses the block
+                g.unlock();
+                GKOC_HIP(hipDeviceSynchronize());
+                g.lock();
+            }
+            int r = span_list_free(A.small, ptr, small_chunk, false);
+            if (r == 0) r = span_list_free(A.plain, ptr, g_chunk_bytes, true);
+            for (int k = 0; r == 0 && k < A.n_cls; ++k) {
+                if (A.reg[k].owns(ptr)) r = A.reg[k].give(ptr) ? 1 : GKOC_E_INVALID;
+            }
+            if (r < 0) {
+                set_last_error("gkoc_free: %p is inside the arena but not the start of an "
+                               "allocation", ptr);
+                return r;
+            }
+            return GKOC_OK;
+        }
+    }
+    GKOC_HIP(hipFree(ptr));
+    return GKOC_OK;
+}
+
+}  // namespace gkoc
+
+using namespace gkoc;
+
+extern "C" {
+
+int gkoc_malloc_role(void** ptr, size_t bytes, int role)
+{
+    GKOC_REQUIRE(ptr, GKOC_E_INVALID, "ptr == NULL");
+    GKOC_REQUIRE(role >= GKOC_MEM_AUTO && role <= GKOC_MEM_VECTOR, GKOC_E_INVALID, "unknown role");
+    return arena_malloc(ptr, bytes, role);
+}
+
+int gkoc_arena_configure(int mode, size_t chunk_bytes, int sync_on_free)
+{
+    GKOC_REQUIRE(mode >= 0 && mode <= 2, GKOC_E_INVALID, "arena mode must be 0..2");
+    std::lock_guard<std::mutex> g(g_mtx);
+    read_env_locked();
+    g_mode = mode;
+    if (chunk_bytes) g_chunk_bytes = round_up(chunk_bytes, 2 * MiB);
+    g_sync_free = sync_on_free ? 1 : 0;
+    return GKOC_OK;
+}
+
+int gkoc_arena_stats(gkoc_arena_info* info)
+{
+    GKOC_REQUIRE(info, GKOC_E_INVALID, "info == NULL");
+    std::lock_guard<std::mutex> g(g_mtx);
+    read_env_locked();
+    const device_arena& A = g_arena[current_device()];
+    *info = gkoc_arena_info{};
+    info->mode = g_mode;
+    info->chunk_bytes = int64_t(g_mode == 2 ? granule_bytes() : g_chunk_bytes);
+    for (int k = 0; k < max_classes; ++k) info->spare_bytes += int64_t(A.spare[k].size() * granule_bytes());
+    info->num_classes = A.n_cls;
+    info->probes = A.probes;
+    info->granules_walked = A.walked;
+    auto add = [&](const span* c) {
+        info->num_chunks += 1;
+        info->reserved_bytes += int64_t(c->size);
+        info->used_bytes += int64_t(c->in_use);
+        info->num_allocations += int64_t(c->used.size());
+    };
+    for (const span* c : A.small) add(c);
+    for (const span* c : A.plain) add(c);
+    for (int k = 0; k < A.n_cls; ++k) {
+        const region& R = A.reg[k];
+        info->num_chunks += int64_t(R.granules.size());
+        info->reserved_bytes += int64_t(R.size);
+        info->used_bytes += int64_t(R.in_use);
+        info->num_allocations += int64_t(R.used.size());
+        info->class_reserved_bytes[k] = int64_t(R.size);
+        info->class_used_bytes[k] = int64_t(R.in_use);
+    }
+    return GKOC_OK;
+}
+
+int gkoc_arena_class_of(const void* ptr, int* cls)
+{
+    GKOC_REQUIRE(cls, GKOC_E_INVALID, "cls == NULL");
+    std::lock_guard<std::mutex> g(g_mtx);
+    const device_arena& A = g_arena[current_device()];
+    *cls = -1;
+    for (int k = 0; k < A.n_cls; ++k) {
+        if (A.reg[k].owns(ptr)) *cls = k;
+    }
+    return GKOC_OK;
+}
+
+int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wave,
+                     int write_bytes_per_wave, int reps, int64_t* ns)
+{
+    GKOC_REQUIRE(x && y && ns && read_kb_per_wave > 0 && write_bytes_per_wave >= 1024 && reps > 0,
+                 GKOC_E_INVALID, "bad probe arguments");
+    return probe_ns(nullptr, x, x_bytes, y, read_kb_per_wave, write_bytes_per_wave, reps, ns);
+}
+
+int gkoc_arena_trim(void)
+{
+    std::lock_guard<std::mutex> g(g_mtx);
+    const int dev = current_device();
+    device_arena& A = g_arena[dev];
+    for (auto* list : {&A.small, &A.plain}) {
+        for (size_t i = 0; i < list->size();) {
+            span* c = (*list)[i];
+            if (c->in_use == 0) {
+                (void)hipFree(c->base);
+                delete c;
+                list->erase(list->begin() + i);
+            } else {
+                ++i;
+            }
+        }
+    }
+    for (int k = 0; k < max_classes; ++k) {
+        for (auto h : A.spare[k]) (void)hipMemRelease(h);
+        A.spare[k].clear();
+    }
+    // the granules mapped into the regions stay: their addresses could not be used
+    // for other memory again (stale translations, see device_arena::scratch)
+    return GKOC_OK;
+}
+
+}  // extern "C"

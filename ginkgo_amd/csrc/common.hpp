@@ -49,6 +49,14 @@ struct device_props {
 // cached per-device query (hipGetDeviceProperties is slow)
 const device_props& current_device_props();
 
+// gkoc_malloc / gkoc_free go through the arena (arena.hip)
+int arena_malloc(void** ptr, size_t bytes, int role);
+int arena_free(void* ptr);
+
+// tuning switches (runtime.hip; keys = GKOC_TUNE_* of gko_cdna4.h)
+constexpr int tune_num_keys = 2;
+int64_t tune_value(int key);
+
 #ifdef __HIPCC__
 
 // ---- wave / block reductions (64-lane) ---------------------------------

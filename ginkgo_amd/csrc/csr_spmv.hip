@@ -55,14 +55,15 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED,
                  "more than 2^31 row segments");
     dim3 grid(static_cast<unsigned>(n_waves)), block(64);
-    // 4-element vector loads need 4*sizeof(T) / 4*sizeof(I) alignment of the
-    // array bases (true for whole allocations; sub-views fall back to scalars)
-    const bool vec_ok =
-        reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
-        reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;
     // 32 B of values per lane and load: 4 doubles or 8 floats (ring = 8 KB)
     constexpr int EV = 32 / sizeof(T);
     constexpr int RINGV = 8192 / sizeof(T);
+    // EV-element vector loads need the array bases aligned like the vector types
+    // (vecT<T,EV> / vecT<I,EV>: true for whole allocations; sub-views that are not
+    // take the scalar-load instantiation E = 1)
+    const bool vec_ok =
+        reinterpret_cast<uintptr_t>(vals) % (EV * sizeof(T)) == 0 &&
+        reinterpret_cast<uintptr_t>(col_idxs) % (EV * sizeof(I)) == 0;
     if (nrhs >= 5 && n_seg < (int64_t(1) << 31)) {
         // 5+ right-hand sides: row-ordered gather from an LDS-staged segment, 8 columns per
         // pass (L256, 8 columns: 5.0 ms against 6.8 ms for the ring kernel; for 2-4 columns
@@ -97,7 +98,10 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, E_, U_, RINGV, 1, MODE_>    \
         <<<grid, block, 0, as_stream(s)>>>(                                    \
             n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, \
-            ldc, static_cast<int>(nrhs), alpha, beta)
+            ldc, static_cast<int>(nrhs), alpha, beta, nullptr, xcd_map)
+    // XCD-contiguous wave order needs enough waves per XCD to keep the in-order
+    // window argument valid; below that the plain order is used
+    const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
     if (vec_ok) {
         if (segs_per_wave == 2) {
             GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);
@@ -144,17 +148,18 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
     dim3 grid(static_cast<unsigned>(n_waves)), block(64);
     const bool vec_ok =
         reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
-        reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;
+        reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;  // E = 4 below
+    const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
     if (vec_ok) {
         csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 4, 1, 1024, 1, 0x2040>
             <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs,
                                                col_idxs, vals, b, 1, c, 1, 1,
-                                               nullptr, nullptr, partial);
+                                               nullptr, nullptr, partial, xcd_map);
     } else {
         csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 1, 4, 1024, 1, 0x2040>
             <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs,
                                                col_idxs, vals, b, 1, c, 1, 1,
-                                               nullptr, nullptr, partial);
+                                               nullptr, nullptr, partial, xcd_map);
     }
     GKOC_LAUNCH_OK();
     return fold_partials<T>(s, n_waves, partial, scratch, dot_out, false);

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     const I* __restrict__ row_ptrs, const I* __restrict__ cols,
     const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb,
     T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
-    const T* __restrict__ beta_p, T* __restrict__ dot_partial = nullptr)
+    const T* __restrict__ beta_p, T* __restrict__ dot_partial = nullptr,
+    int xcd_map = 0)
 {
     static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
     constexpr int G = 64 * E * U;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     // (sparse small writes between the read streams cost several times their
     // byte share at the memory side)
     constexpr int DEFER = (ABL >> 12) & 15;
-    __shared__ __attribute__((aligned(16))) T ring[RING];
+    __shared__ __attribute__((aligned(64))) T ring[RING];
 
     const int lane = threadIdx.x;
     T dot_acc = T(0);
@@ -77,10 +78,20 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
             wave_id = ((slot / C) * 8 + xcd) * C + (slot % C);
         }
     }
+    if (xcd_map) {
+        // Workgroup b runs on XCD b % 8 (observed dispatch rule; a wrong guess
+        // costs speed, never correctness - the map is a bijection).  Give each
+        // XCD ONE contiguous eighth of the waves, walked in order: the b lines
+        // shared by neighbouring rows are then fetched by one L2 instead of by
+        // all eight, and a CU only ever translates addresses of its own eighth.
+        const int64_t nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int64_t xcd = wave_id & 7, slot = wave_id >> 3;
+        wave_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
     const int64_t sb = wave_id * segs_per_wave;
     const int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
     if (sb >= se) {
-        if (DOT && lane == 0) dot_partial[blockIdx.x] = T(0);
+        if (DOT && lane == 0) dot_partial[wave_id] = T(0);
         return;
     }
     const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;
@@ -88,8 +99,9 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     const int64_t K1 = row_ptrs[row_e];
     const int64_t NNZ = row_ptrs[n_rows];
     const int64_t K0a = K0 & ~int64_t(E - 1);
-    // wave-relative 32-bit offsets (a wave's range is far below 2^31 entries;
-    // the launcher falls back to variant 1 otherwise)
+    // wave-relative 32-bit offsets (a wave owns at most two 64-row segments, whose
+    // entries beyond GKOC_CSR_LONG_ROW per row are summed by the whole wave; the
+    // launcher refuses more than 2^31 segments)
     const int k1o = int(K1 - K0a);
     const int nnzo = (NNZ - K0a) > int64_t(0x7fffff00) ? 0x7fffff00 : int(NNZ - K0a);
     const T* __restrict__ vals0 = vals + K0a;
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     if (DOT) {
         // fixed butterfly: the partial of a wave does not depend on timing
         dot_acc = wave_sum(dot_acc);
-        if (lane == 0) dot_partial[blockIdx.x] = dot_acc;
+        if (lane == 0) dot_partial[wave_id] = dot_acc;
     }
 }
 

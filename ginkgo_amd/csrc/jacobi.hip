@@ -623,7 +623,8 @@ __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
     const I* __restrict__ block_ptrs, const T* __restrict__ blocks,
     const T* __restrict__ alpha_p, const T* __restrict__ b,
     const T* __restrict__ beta_p, T* __restrict__ x,
-    T* __restrict__ dot_partial = nullptr, const uint8_t* __restrict__ precs = nullptr)
+    T* __restrict__ dot_partial = nullptr, const uint8_t* __restrict__ precs = nullptr,
+    int xcd_map = 0)
 {
     __shared__ T dot_lds[4];
     T dot_acc = T(0);
@@ -633,8 +634,15 @@ __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
     const int lane = threadIdx.x & 63;
     const int r = lane & (BO - 1);
     const int lane0 = lane - r;
-    const int64_t group0 =
-        (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * GPW;
+    int64_t wg = blockIdx.x;
+    if (xcd_map) {
+        // workgroup b runs on XCD b % 8: one contiguous eighth of the groups per
+        // XCD (a CU then translates addresses of its own eighth only); bijective
+        const int64_t nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7;
+        const int64_t xcd = wg & 7, slot = wg >> 3;
+        wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+    }
+    const int64_t group0 = (wg * 4 + (threadIdx.x >> 6)) * GPW;
     T alpha = T(1), beta = T(0);
     if (ADV) {
         alpha = alpha_p[0];
@@ -721,8 +729,13 @@ __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
     }
     if (DOT) {
         const T r = block_sum<256>(dot_acc, dot_lds);
-        if (threadIdx.x == 0) dot_partial[blockIdx.x] = r;
+        if (threadIdx.x == 0) dot_partial[wg] = r;
     }
+}
+
+inline int jacobi_xcd_map(int64_t n_workgroups)
+{
+    return (tune_value(GKOC_TUNE_JACOBI_XCD_MAP) != 0 && n_workgroups >= 8 * 256) ? 1 : 0;
 }
 
 template <typename T, typename I, bool ADV, int BO>
@@ -735,7 +748,8 @@ void launch_apply_fixed(gkoc_stream_t s, int64_t num_blocks, int64_t groups,
     jacobi_apply_fixed_kernel<T, I, ADV, BO, GPW>
         <<<dim3(unsigned(ceildiv(groups, 4 * GPW))), dim3(256), 0,
            as_stream(s)>>>(num_blocks, groups, group_offset, block_ptrs, blocks,
-                           alpha, b, beta, x);
+                           alpha, b, beta, x, nullptr, nullptr,
+                           jacobi_xcd_map(ceildiv(groups, 4 * GPW)));
 }
 
 // x = M b and dot_out = <b, x> (fast-path layout only, one right-hand side)
@@ -751,7 +765,7 @@ void launch_apply_dot_fixed(gkoc_stream_t s, int64_t num_blocks, int64_t groups,
     jacobi_apply_fixed_kernel<T, I, false, BO, GPW, true>
         <<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(
             num_blocks, groups, group_offset, block_ptrs, blocks, nullptr, b,
-            nullptr, x, partial);
+            nullptr, x, partial, nullptr, jacobi_xcd_map(nb));
 }
 
 template <typename T, typename I>
@@ -843,7 +857,8 @@ void launch_apply_stored_fixed(gkoc_stream_t s, int64_t num_blocks, int64_t grou
     constexpr int GPW = 2;
     jacobi_apply_fixed_kernel<double, I, ADV, BO, GPW, false, PREC>
         <<<dim3(unsigned(ceildiv(groups, 4 * GPW))), dim3(256), 0, as_stream(s)>>>(
-            num_blocks, groups, group_offset, block_ptrs, blocks, alpha, b, beta, x);
+            num_blocks, groups, group_offset, block_ptrs, blocks, alpha, b, beta, x, nullptr,
+            nullptr, jacobi_xcd_map(ceildiv(groups, 4 * GPW)));
 }
 
 inline bool known_precision(int prec)
@@ -1144,7 +1159,7 @@ void launch_apply_adaptive_fixed(gkoc_stream_t s, int64_t num_blocks, int64_t gr
     jacobi_apply_fixed_kernel<double, I, ADV, BO, GPW, false, -1>
         <<<dim3(unsigned(ceildiv(groups, 4 * GPW))), dim3(256), 0, as_stream(s)>>>(
             num_blocks, groups, group_offset, block_ptrs, blocks, alpha, b, beta, x, nullptr,
-            precisions);
+            precisions, jacobi_xcd_map(ceildiv(groups, 4 * GPW)));
 }
 
 template <typename I, bool ADV>

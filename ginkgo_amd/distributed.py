@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 from ._lib import IT, VT, GkoError, call, lib
 from ._lib import record as _record
+from .executor import MEM_INDICES, MEM_VALUES
 from .matrix import Csr, Dense, scalar, stencil_csr
 from .preconditioner import Jacobi
 
@@ -284,13 +285,13 @@ class HipBackend:
         n = a.size[0]
         idt = a.col_idxs.dtype
         col_map = ex.alloc((n_global + 1,), idt)
-        local_ptrs = ex.alloc((n + 1,), idt)
+        local_ptrs = ex.alloc((n + 1,), idt, MEM_INDICES)
         nl_full = ex.alloc((n + 1,), idt)
         cnt = [C.c_int64(0) for _ in range(4)]
         call("gkoc_dist_split_count_" + it, ex.stream, n, a.row_ptrs, a.col_idxs, col_lo,
              col_hi, n_global, col_map, local_ptrs, nl_full, *[C.byref(c) for c in cnt])
         n_halo, nnz_l, nnz_nl, n_nl_rows = (c.value for c in cnt)
-        local_cols, local_vals = ex.alloc((nnz_l,), idt), ex.alloc((nnz_l,), a.dtype)
+        local_cols, local_vals = ex.alloc((nnz_l,), idt, MEM_INDICES), ex.alloc((nnz_l,), a.dtype, MEM_VALUES)
         nl_rows, nl_ptrs = ex.alloc((n_nl_rows,), idt), ex.alloc((n_nl_rows + 1,), idt)
         nl_cols, nl_vals = ex.alloc((nnz_nl,), idt), ex.alloc((nnz_nl,), a.dtype)
         recv_gidx = ex.alloc((n_halo,), idt)
@@ -298,9 +299,9 @@ class HipBackend:
              col_lo, col_hi, n_global, col_map, local_ptrs, nl_full, local_cols, local_vals,
              nl_rows, nl_ptrs, nl_cols, nl_vals, recv_gidx)
         local = Csr(ex, (n, col_hi - col_lo), local_vals, local_cols, local_ptrs)
-        # set-up: home the local block's arrays in the fastest of a few fresh allocations
-        # (Csr.tune_placement); nothing has captured them yet
-        self.placement_log = local.tune_placement(trials=4) if nnz_l > 0 else None
+        # the arena has put values / indices / vectors into different memory classes
+        # (DESIGN.md 3.2); kept for the bench line
+        self.placement_log = local.memory_classes() if nnz_l > 0 else None
         nl = dict(rows=nl_rows, ptrs=nl_ptrs, cols=nl_cols, vals=nl_vals, n=n_nl_rows,
                   suffix=f"{vt}_{it}")
         return local, nl, recv_gidx

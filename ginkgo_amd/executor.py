@@ -2,8 +2,12 @@
 
 Reference interface: include/ginkgo/core/base/executor.hpp:1785-1990
 (HipExecutor::create / synchronize / get_num_devices / get_stream, exec_info
-fields num_computing_units / max_subgroup_size).  Device memory and streams
-are torch's (plumbing); all numerical work goes through libgko_cdna4.so.
+fields num_computing_units / max_subgroup_size).  Streams are torch's
+(plumbing); device memory of 1 MiB and more comes from the library's arena
+(`gkoc_malloc_role`, csrc/arena.hip - the counterpart of HipExecutor::raw_alloc)
+and is handed to torch as a tensor over that memory, so that matrix values, index
+arrays and vectors live in different memory classes of the MI355X (DESIGN.md 3.2);
+all numerical work goes through libgko_cdna4.so.
 """
 import ctypes as C
 
@@ -19,6 +23,34 @@ class DeviceInfo(C.Structure):
                 ("max_threads_per_block", C.c_int32), ("major", C.c_int32),
                 ("minor", C.c_int32), ("lds_bytes_per_cu", C.c_int32),
                 ("hbm_bytes", C.c_int64), ("arch", C.c_char * 64)]
+
+
+# roles of gkoc_malloc_role (include/gko_cdna4.h)
+MEM_AUTO, MEM_VALUES, MEM_INDICES, MEM_VECTOR = 0, 1, 2, 3
+_ARENA_MIN_BYTES = 1 << 20
+_TYPESTR = {torch.float64: "<f8", torch.float32: "<f4", torch.float16: "<f2",
+            torch.int64: "<i8", torch.int32: "<i4", torch.int16: "<i2", torch.int8: "|i1",
+            torch.uint8: "|u1", torch.bool: "|b1"}
+
+
+class _ArenaBlock:
+    """Owner of one gkoc_malloc_role allocation; torch keeps it alive through the
+    CUDA array interface and gkoc_free runs when the last tensor over it is gone."""
+
+    def __init__(self, nbytes, role, shape, typestr):
+        p = C.c_void_p()
+        _lib.call("gkoc_malloc_role", C.byref(p), C.c_size_t(nbytes), C.c_int(role))
+        self.ptr = p.value
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
+                                         "data": (self.ptr, False), "version": 2}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            try:
+                _lib.lib().gkoc_free(C.c_void_p(ptr))
+            except Exception:   # interpreter shutdown
+                pass
 
 
 class Cdna4Executor:
@@ -69,13 +101,47 @@ class Cdna4Executor:
         _lib.call("gkoc_stream_synchronize", self.stream)
 
     # --- memory
-    def alloc(self, shape, dtype):
-        return torch.empty(shape, dtype=dtype, device=self.device)
+    _arena_ok = True
 
-    def zeros(self, shape, dtype):
-        return torch.zeros(shape, dtype=dtype, device=self.device)
+    def alloc(self, shape, dtype, role=MEM_VECTOR):
+        """uninitialised device array; `role` places it (MEM_VALUES / MEM_INDICES for
+        the big read-only arrays of a matrix, MEM_VECTOR for everything kernels write)"""
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        n = 1
+        for v in shape:
+            n *= v
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        if nbytes < _ARENA_MIN_BYTES or dtype not in _TYPESTR or not Cdna4Executor._arena_ok:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            block = _ArenaBlock(nbytes, role, shape, _TYPESTR[dtype])
+            try:
+                t = torch.as_tensor(block, device=self.device)
+            except Exception as e:   # torch cannot wrap foreign device memory here
+                import warnings
+                warnings.warn(f"gko-cdna4: arena memory not usable from torch ({e}); "
+                              "falling back to torch's allocator")
+                Cdna4Executor._arena_ok = False
+                return torch.empty(shape, dtype=dtype, device=self.device)
+        assert t.data_ptr() == block.ptr and t.dtype == dtype
+        return t
 
-    def to_device(self, array):
+    def zeros(self, shape, dtype, role=MEM_VECTOR):
+        return self.alloc(shape, dtype, role).zero_()
+
+    def to_device(self, array, role=MEM_VECTOR):
         if isinstance(array, torch.Tensor):
-            return array.to(self.device)
-        return torch.from_numpy(np.ascontiguousarray(array)).to(self.device)
+            src = array
+        else:
+            src = torch.from_numpy(np.ascontiguousarray(array))
+        if src.device == self.device and src.is_contiguous():
+            return src
+        out = self.alloc(tuple(src.shape), src.dtype, role)
+        out.copy_(src)
+        return out
+
+    def memory_class(self, tensor):
+        """memory class (0..2) of a tensor inside the arena's class regions, else -1"""
+        c = C.c_int(-1)
+        _lib.call("gkoc_arena_class_of", C.c_void_p(tensor.data_ptr()), C.byref(c))
+        return c.value

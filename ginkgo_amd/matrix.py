@@ -12,6 +12,7 @@ import torch
 from . import _lib
 from ._lib import DimensionMismatch, GkoError, IT, VT, call, cval
 from .base import LinOp
+from .executor import MEM_INDICES, MEM_VALUES
 
 
 def _np_dtype(t):
@@ -208,9 +209,9 @@ class Csr(_SparseBase):
     @staticmethod
     def from_scipy(exec_, a, index_dtype=np.int32, strategy="automatical"):
         a = a.tocsr()
-        return Csr(exec_, a.shape, exec_.to_device(np.asarray(a.data)),
-                   exec_.to_device(a.indices.astype(index_dtype)),
-                   exec_.to_device(a.indptr.astype(index_dtype)), strategy)
+        return Csr(exec_, a.shape, exec_.to_device(np.asarray(a.data), MEM_VALUES),
+                   exec_.to_device(a.indices.astype(index_dtype), MEM_INDICES),
+                   exec_.to_device(a.indptr.astype(index_dtype), MEM_INDICES), strategy)
 
     @staticmethod
     def read(data, strategy="automatical"):
@@ -218,7 +219,7 @@ class Csr(_SparseBase):
         must be sorted row-major; values and column indices are taken as they are, the
         row pointers come from components::convert_idxs_to_ptrs on the device"""
         ex, n = data.exec, data.size[0]
-        ptrs = ex.alloc((n + 1,), data.row_idxs.dtype)
+        ptrs = ex.alloc((n + 1,), data.row_idxs.dtype, MEM_INDICES)
         call("gkoc_convert_idxs_to_ptrs_" + IT[data.row_idxs.dtype], ex.stream,
              data.get_num_stored_elements(), data.row_idxs, n, ptrs)
         return Csr(ex, data.size, data.values, data.col_idxs, ptrs, strategy)
@@ -226,9 +227,9 @@ class Csr(_SparseBase):
     @staticmethod
     def from_arrays(exec_, size, row_ptrs, col_idxs, values,
                     strategy="automatical"):
-        return Csr(exec_, size, exec_.to_device(values),
-                   exec_.to_device(col_idxs), exec_.to_device(row_ptrs),
-                   strategy)
+        return Csr(exec_, size, exec_.to_device(values, MEM_VALUES),
+                   exec_.to_device(col_idxs, MEM_INDICES),
+                   exec_.to_device(row_ptrs, MEM_INDICES), strategy)
 
     @property
     def dtype(self):
@@ -287,8 +288,8 @@ class Csr(_SparseBase):
                  self.size[0], self.row_ptrs, C.byref(m))
             num_stored_per_row = m.value
         stride = self.size[0] if stride is None else stride
-        cols = self.exec.alloc((num_stored_per_row * stride,), self.col_idxs.dtype)
-        vals = self.exec.alloc((num_stored_per_row * stride,), self.dtype)
+        cols = self.exec.alloc((num_stored_per_row * stride,), self.col_idxs.dtype, MEM_INDICES)
+        vals = self.exec.alloc((num_stored_per_row * stride,), self.dtype, MEM_VALUES)
         if stride > self.size[0]:
             cols.fill_(-1)
             vals.zero_()
@@ -308,52 +309,20 @@ class Csr(_SparseBase):
         torch.cuda.synchronize(self.exec.device)
         return e0.elapsed_time(e1) / reps
 
-    def tune_placement(self, x=None, y=None, trials=4, reps=3):
-        """Set-up step of this backend (the role Ginkgo's `automatical` strategy plays at
-        generate time, csr.hpp:519-697): on MI355X the SpMV time depends on WHICH device
-        allocations hold col_idxs / values / the output (0.99-1.20 ms for
-        the same kernel and data).  Copies col_idxs, then values, into `trials` fresh
-        allocations each, times the apply on every copy and keeps the fastest; the
-        others are released.  Contents are untouched.  Call it before generating solvers
-        or preconditioners on this matrix (they may capture the arrays).  Returns the
-        timings (ms)."""
+    def memory_classes(self):
+        """memory class (arena) of values / col_idxs / row_ptrs; the SpMV is
+        fastest when the output vector's class differs from those of values and col_idxs"""
         ex = self.exec
-        x = x if x is not None else Dense.create(ex, (self.size[1], 1), self.dtype).fill(1.0)
-        y = y if y is not None else Dense.create(ex, (self.size[0], 1), self.dtype)
-        log = {"before_ms": self._time_apply(x, y, reps)}
-        for name in ("col_idxs", "values"):
-            cands = [getattr(self, name)]
-            times = [log["before_ms"] if name == "col_idxs" else log["col_idxs_ms"][log["col_idxs_pick"]]]
-            for _ in range(trials):
-                cands.append(cands[0].clone())
-                setattr(self, name, cands[-1])
-                times.append(self._time_apply(x, y, reps))
-            best = min(range(len(times)), key=times.__getitem__)
-            setattr(self, name, cands[best])
-            log[name + "_ms"], log[name + "_pick"] = [round(t, 4) for t in times], best
-            del cands
-        log["after_ms"] = self._time_apply(x, y, reps)
-        torch.cuda.empty_cache()
-        return log
-
-    def tuned_output(self, x, trials=4, reps=3):
-        """an output vector for apply(x, .) in the fastest of `trials` fresh allocations
-        (same reason as tune_placement); returns (vector, timings in ms)"""
-        cands = [Dense.create(self.exec, (self.size[0], x.size[1]), self.dtype) for _ in range(max(trials, 1))]
-        times = [self._time_apply(x, c, reps) for c in cands]
-        best = min(range(len(times)), key=times.__getitem__)
-        y = cands[best]
-        del cands
-        torch.cuda.empty_cache()
-        return y, [round(t, 4) for t in times]
+        return {"values": ex.memory_class(self.values), "col_idxs": ex.memory_class(self.col_idxs),
+                "row_ptrs": ex.memory_class(self.row_ptrs)}
 
     def transpose(self):
         """Csr::transpose (core/matrix/csr.cpp, csr::transpose kernel)"""
         ex = self.exec
         nnz = int(self.col_idxs.numel())
         idt = self.col_idxs.dtype
-        t_ptrs = ex.alloc((self.size[1] + 1,), idt)
-        t_cols, t_vals = ex.alloc((nnz,), idt), ex.alloc((nnz,), self.dtype)
+        t_ptrs = ex.alloc((self.size[1] + 1,), idt, MEM_INDICES)
+        t_cols, t_vals = ex.alloc((nnz,), idt, MEM_INDICES), ex.alloc((nnz,), self.dtype, MEM_VALUES)
         f = _lib.lib().gkoc_csr_transpose_workspace_bytes
         f.restype = C.c_size_t
         need = f(C.c_int64(nnz), C.c_int64(self.size[1]), C.c_size_t(self.col_idxs.element_size()))
@@ -365,7 +334,7 @@ class Csr(_SparseBase):
         return Csr(ex, (self.size[1], self.size[0]), t_vals, t_cols, t_ptrs)
 
     def convert_to_coo(self):
-        rows = self.exec.alloc((self.col_idxs.numel(),), self.col_idxs.dtype)
+        rows = self.exec.alloc((self.col_idxs.numel(),), self.col_idxs.dtype, MEM_INDICES)
         call("gkoc_convert_ptrs_to_idxs_" + IT[self.col_idxs.dtype], self.exec.stream,
              self.row_ptrs, self.size[0], rows)
         return Coo(self.exec, self.size, self.values, self.col_idxs, rows)
@@ -393,9 +362,9 @@ class Csr(_SparseBase):
         call("gkoc_hybrid_compute_coo_row_ptrs", ex.stream, n, sizes, C.c_uint64(ell_lim), crp)
         coo_nnz = int(crp[-1].item())
         idt, vdt = self.col_idxs.dtype, self.dtype
-        ec, ev = ex.alloc((ell_lim * n,), idt), ex.alloc((ell_lim * n,), vdt)
-        cr, cc = ex.alloc((coo_nnz,), idt), ex.alloc((coo_nnz,), idt)
-        cv = ex.alloc((coo_nnz,), vdt)
+        ec, ev = ex.alloc((ell_lim * n,), idt, MEM_INDICES), ex.alloc((ell_lim * n,), vdt, MEM_VALUES)
+        cr, cc = ex.alloc((coo_nnz,), idt, MEM_INDICES), ex.alloc((coo_nnz,), idt, MEM_INDICES)
+        cv = ex.alloc((coo_nnz,), vdt, MEM_VALUES)
         call("gkoc_csr_convert_to_hybrid_" + self._suf(), ex.stream, n, self.row_ptrs,
              self.col_idxs, self.values, ell_lim, n, ec, ev, crp, cr, cc, cv)
         hyb = Hybrid(ex, self.size, Ell(ex, self.size, ev, ec, ell_lim, n),
@@ -412,8 +381,8 @@ class Csr(_SparseBase):
         call("gkoc_sellp_compute_slice_sets_" + it, self.exec.stream,
              self.size[0], slice_size, stride_factor, self.row_ptrs, sets, lens)
         total = int(sets[-1].item()) * slice_size
-        cols = self.exec.alloc((total,), self.col_idxs.dtype)
-        vals = self.exec.alloc((total,), self.dtype)
+        cols = self.exec.alloc((total,), self.col_idxs.dtype, MEM_INDICES)
+        vals = self.exec.alloc((total,), self.dtype, MEM_VALUES)
         if total:
             cols.fill_(-1)   # rows past num_rows in the last slice stay padding
             vals.zero_()
@@ -671,14 +640,14 @@ def stencil_csr(exec_, nd, g, restricted=False, dtype=torch.float64,
     n_local = nz * (g * g if nd == 3 else g)
     n_global = g ** nd
     it, vt = IT[index_dtype], VT[dtype]
-    row_ptrs = exec_.alloc((n_local + 1,), index_dtype)
+    row_ptrs = exec_.alloc((n_local + 1,), index_dtype, MEM_INDICES)
     nnz = C.c_int64(0)
     call("gkoc_stencil_row_ptrs_" + it, exec_.stream, C.c_int(nd), g,
          C.c_int(int(restricted)), z0, nz, row_ptrs, C.byref(nnz))
     if index_dtype == torch.int32 and nnz.value >= 2 ** 31:
         raise GkoError("stencil_csr: nnz overflows int32")
-    cols = exec_.alloc((nnz.value,), index_dtype)
-    vals = exec_.alloc((nnz.value,), dtype)
+    cols = exec_.alloc((nnz.value,), index_dtype, MEM_INDICES)
+    vals = exec_.alloc((nnz.value,), dtype, MEM_VALUES)
     call(f"gkoc_stencil_fill_{vt}_{it}", exec_.stream, C.c_int(nd), g,
          C.c_int(int(restricted)), z0, nz, row_ptrs, cols, vals)
     return Csr(exec_, (n_local, n_global), vals, cols, row_ptrs)

@@ -7,7 +7,8 @@ blocks (jacobi::find_blocks), inverts them (jacobi::generate) and applies them
 (jacobi::simple_apply / apply), all on the device through libgko_cdna4.so.
 max_block_size == 1 takes Ginkgo's scalar path (extract_diagonal +
 invert_diagonal + simple_scalar_apply).  Adaptive precision
-(storage_optimization) is not supported and raises NotSupported.
+(`with_storage_optimization`: fixed, block-wise and autodetect) is supported
+for fp64 values and max_block_size in {2, 4, 8, 16}.
 """
 import ctypes as C
 
@@ -16,6 +17,7 @@ import torch
 
 from ._lib import IT, VT, JacobiScheme, NotSupported, call
 from .base import LinOp
+from .executor import MEM_INDICES
 from .matrix import Csr
 
 
@@ -134,7 +136,22 @@ class Jacobi(LinOp):
         self.scheme = compute_storage_scheme(self.max_block_size,
                                              ex.get_warp_size())
         if factory.block_pointers is not None:
-            self.block_pointers = ex.to_device(factory.block_pointers)
+            # user-supplied blocks (jacobi.hpp:377-387): the kernels are selected by the
+            # matrix' index type, so the array is converted to it; checked like
+            # jacobi.cpp:358-363 expects them (ascending, covering all rows, <= max size)
+            if isinstance(factory.block_pointers, torch.Tensor):
+                hp = factory.block_pointers.detach().cpu().numpy()
+            else:
+                hp = np.asarray(factory.block_pointers)
+            hp = hp.astype(np.int64).reshape(-1)
+            sizes = np.diff(hp)
+            if (hp.size < 1 or hp[0] != 0 or hp[-1] != n or (sizes < 0).any()
+                    or (sizes > self.max_block_size).any()):
+                from ._lib import BadDimension
+                raise BadDimension("block_pointers must start at 0, end at the number of rows, "
+                                   "ascend, and describe blocks of at most max_block_size rows")
+            np_idx = np.int32 if a.row_ptrs.dtype == torch.int32 else np.int64
+            self.block_pointers = ex.to_device(hp.astype(np_idx))
             self.num_blocks = self.block_pointers.numel() - 1
         else:
             self.block_pointers = ex.alloc((n + 1,), a.row_ptrs.dtype)
@@ -146,7 +163,8 @@ class Jacobi(LinOp):
             self.block_pointers = self.block_pointers[:self.num_blocks + 1]
         gs = 1 << self.scheme.group_power
         storage = ((self.num_blocks + gs - 1) // gs) * self.scheme.group_offset
-        self.blocks = ex.zeros((storage,), a.dtype)
+        # the inverse blocks are the apply's one large read stream: not with the vectors
+        self.blocks = ex.zeros((storage,), a.dtype, MEM_INDICES)
         if adaptive:
             req = np.resize(np.asarray(factory.block_wise, np.uint8), self.num_blocks)
             self.precisions = ex.to_device(req)

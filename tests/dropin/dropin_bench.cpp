@@ -78,6 +78,16 @@ int main(int argc, char** argv)
     auto b = gko::clone(hip, b_host);
     auto x = Dense::create(hip, gko::dim<2>{n, 1});
 
+    {
+        // where the backend's allocator (HipAllocator -> csrc/arena.hip) put Ginkgo's arrays
+        int cv = -1, cc = -1, cr = -1, cb = -1, cx = -1;
+        gkoc_arena_class_of(a->get_const_values(), &cv);
+        gkoc_arena_class_of(a->get_const_col_idxs(), &cc);
+        gkoc_arena_class_of(a->get_const_row_ptrs(), &cr);
+        gkoc_arena_class_of(b->get_const_values(), &cb);
+        gkoc_arena_class_of(x->get_const_values(), &cx);
+        std::printf("memory classes: values %d, col_idxs %d, row_ptrs %d, b %d, x %d\n", cv, cc, cr, cb, cx);
+    }
     const double bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     double ms = time_ms(hip, reps, [&] { a->apply(b, x); });
     std::printf("gko::matrix::Csr::apply      %8.4f ms  %8.1f GB/s  (%.1f %% of 8 TB/s)\n", ms,

@@ -241,6 +241,40 @@ def test_jacobi_blocks_generate_apply_bit_exact(gexec, oracle, max_bs):
     assert np.array_equal(x.to_numpy(), oracle.jacobi_apply(nb, scheme, ptrs, blocks, b, 2.0, -1.0, x0))
 
 
+@pytest.mark.parametrize("ptr_kind", ["list", "int64", "int32", "tensor"])
+def test_jacobi_with_block_pointers(gexec, oracle, ptr_kind):
+    """Jacobi.with_block_pointers (jacobi.hpp:377-387): user-supplied blocks, given in any
+    integer type, are converted to the matrix' index type; generate / apply == oracle"""
+    import ginkgo_amd as g
+    import torch
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(1, 9, 40)
+    a = _block_matrix(8, sizes)
+    n = a.shape[0]
+    rp, ci, v = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
+    # blocks different from the natural ones: pairs of rows, last block whatever is left
+    ptrs = np.arange(0, n + 1, 2)
+    if ptrs[-1] != n:
+        ptrs = np.append(ptrs, n)
+    given = {"list": [int(p) for p in ptrs], "int64": ptrs.astype(np.int64),
+             "int32": ptrs.astype(np.int32), "tensor": torch.tensor(ptrs, dtype=torch.int64)}[ptr_kind]
+    da = g.Csr.from_arrays(gexec, (n, n), rp, ci, v)
+    jac = g.Jacobi.build().with_max_block_size(8).with_block_pointers(given).on(gexec).generate(da)
+    nb = len(ptrs) - 1
+    assert jac.num_blocks == nb and jac.block_pointers.dtype == torch.int32
+    scheme = oracle.jacobi_storage_scheme(8)
+    p32 = ptrs.astype(np.int32)
+    blocks = oracle.jacobi_generate(rp, ci, v, nb, scheme, p32)
+    assert np.array_equal(jac.blocks.cpu().numpy(), blocks)
+    b = rng.uniform(-1, 1, (n, 2))
+    x = g.Dense.create(gexec, (n, 2))
+    jac.apply(g.Dense.from_numpy(gexec, b), x)
+    assert np.array_equal(x.to_numpy(), oracle.jacobi_apply(nb, scheme, p32, blocks, b))
+    for bad in ([1, n], [0, n - 1], [0, 3, 2, n], [0, 9, n]):
+        with pytest.raises(g.GkoError):
+            g.Jacobi.build().with_max_block_size(8).with_block_pointers(bad).on(gexec).generate(da)
+
+
 def test_jacobi_pivoting_and_unsorted(gexec, oracle):
     """blocks that need row pivoting (zero / small diagonal) and an unsorted
     input matrix (Jacobi sorts a copy, jacobi.cpp:331-336)"""

@@ -294,22 +294,72 @@ def test_csr_multi_rhs_full_size_columns_match_single(gexec):
             assert torch.equal(y.values[:, :k], single.values[:, :k]), (dtype, k)
 
 
-def test_tune_placement_moves_arrays_only(gexec):
-    """Csr.tune_placement / tuned_output re-home the arrays: contents and
-    results are bit-identical, every candidate is timed, the fastest is kept"""
+def test_arena_places_by_role(gexec):
+    """The library's device allocator (csrc/arena.hip) behind gkoc_malloc /
+    HipExecutor::raw_alloc: matrix values, index arrays and vectors of >= 1 MiB come from
+    regions of different memory classes; contents and results do not depend on it."""
+    import ctypes as C
     import ginkgo_amd as g
-    a = g.stencil_csr(gexec, 3, 64)
+    from ginkgo_amd import _lib
+    a = g.stencil_csr(gexec, 3, 96)                    # values 170 MB, col_idxs 85 MB
     n = a.size[0]
-    x = g.Dense.from_numpy(gexec, np.random.default_rng(0).uniform(-1, 1, n))
-    y0 = g.Dense.create(gexec, (n, 1))
-    a.apply(x, y0)
-    cols, vals = a.col_idxs.clone(), a.values.clone()
-    log = a.tune_placement(x, trials=3)
-    assert len(log["col_idxs_ms"]) == 4 and len(log["values_ms"]) == 4
-    assert log["col_idxs_ms"][log["col_idxs_pick"]] == min(log["col_idxs_ms"])
-    assert log["values_ms"][log["values_pick"]] == min(log["values_ms"])
-    assert torch.equal(a.col_idxs, cols) and torch.equal(a.values, vals)
-    y1, times = a.tuned_output(x, trials=3)
-    assert len(times) == 3 and y1.size == (n, 1)
-    a.apply(x, y1)
-    assert torch.equal(y1.values, y0.values)
+    xh = np.random.default_rng(0).uniform(-1, 1, n)
+    x = g.Dense.from_numpy(gexec, xh)
+    y = g.Dense.create(gexec, (n, 1))
+    a.apply(x, y)
+    mode = C.c_int64(0)
+    cls = a.memory_classes()
+    cy = gexec.memory_class(y.values)
+    if cls["values"] >= 0:                              # class regions in use (default)
+        assert cls["col_idxs"] >= 0 and cy >= 0
+        found = len({cls["values"], cls["col_idxs"], cy})
+        assert found >= 2, (cls, cy)                    # at least: output not with the matrix
+        assert cy != cls["values"]
+    # same numbers as with torch's own allocator
+    a2 = g.Csr(gexec, a.size, a.values.clone(), a.col_idxs.clone(), a.row_ptrs.clone())
+    y2 = g.Dense(gexec, torch.empty((n, 1), dtype=torch.float64, device=gexec.device))
+    a2.apply(g.Dense(gexec, x.values.clone()), y2)
+    assert torch.equal(y.values, y2.values)
+
+
+def test_arena_c_abi(gexec):
+    """gkoc_malloc / gkoc_malloc_role / gkoc_free: alignment, no overlap, reuse after
+    free, interior pointers refused, gkoc_arena_class_of / gkoc_arena_stats"""
+    import ctypes as C
+    from ginkgo_amd import _lib
+    L = _lib.lib()
+    sizes = [100, 4096, 1 << 20, (1 << 20) + 12345, 3 << 20, 64 << 20, 5, 200 << 20]
+    roles = [0, 1, 2, 3, 0, 1, 2, 3]
+    ptrs = []
+    for sz, role in zip(sizes, roles):
+        p = C.c_void_p()
+        _lib.call("gkoc_malloc_role", C.byref(p), C.c_size_t(sz), C.c_int(role))
+        assert p.value and p.value % 256 == 0
+        if sz >= (1 << 20):
+            assert p.value % (2 << 20) == 0
+        ptrs.append((p.value, sz))
+    spans = sorted(ptrs)
+    for (p0, s0), (p1, _) in zip(spans, spans[1:]):
+        assert p0 + s0 <= p1, "allocations overlap"
+    # the memory is usable
+    t = torch.empty(1)  # noqa: F841 (torch initialised)
+    for p, sz in ptrs:
+        _lib.call("gkoc_memset", C.c_void_p(p), C.c_int(0x5a), C.c_size_t(sz), gexec.stream)
+    gexec.synchronize()
+    host = (C.c_uint8 * 100)()
+    _lib.call("gkoc_memcpy_d2h", host, C.c_void_p(ptrs[0][0]), C.c_size_t(100), gexec.stream)
+    assert bytes(host) == b"\x5a" * 100
+    # an interior pointer is not an allocation
+    assert L.gkoc_free(C.c_void_p(ptrs[5][0] + 4096)) != 0
+    # free and get the same block back
+    big = ptrs[5]
+    _lib.call("gkoc_free", C.c_void_p(big[0]))
+    p = C.c_void_p()
+    _lib.call("gkoc_malloc_role", C.byref(p), C.c_size_t(big[1]), C.c_int(1))
+    assert p.value == big[0]
+    c = C.c_int(-2)
+    _lib.call("gkoc_arena_class_of", p, C.byref(c))
+    assert -1 <= c.value <= 2
+    for q, _ in ptrs:
+        _lib.call("gkoc_free", C.c_void_p(q))
+    assert L.gkoc_malloc_role(C.byref(p), C.c_size_t(10), C.c_int(7)) != 0      # unknown role
