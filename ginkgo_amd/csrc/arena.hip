@@ -578,7 +578,7 @@ int arena_malloc(void** ptr, size_t bytes, int role)
     return static_cast<int>(hipErrorOutOfMemory);
 }
 
-int arena_free(void* ptr)
+static int arena_free_impl(void* ptr, bool sync)
 {
     if (!ptr) return GKOC_OK;
     {
@@ -590,7 +590,7 @@ int arena_free(void* ptr)
             for (span* c : A.plain) ours = ours || c->owns(ptr);
             for (int k = 0; k < A.n_cls; ++k) ours = ours || A.reg[k].owns(ptr);
             if (!ours) continue;
-            if (g_sync_free) {
+            if (sync && g_sync_free) {
                 // hipFree semantics: nothing enqueued earlier still uses the block
                 g.unlock();
                 GKOC_HIP(hipDeviceSynchronize());
@@ -610,6 +610,64 @@ int arena_free(void* ptr)
         }
     }
     GKOC_HIP(hipFree(ptr));
+    return GKOC_OK;
+}
+
+int arena_free(void* ptr) { return arena_free_impl(ptr, true); }
+
+// ---- stream-ordered scratch ---------------------------------------------------
+namespace {
+struct pending_free {
+    void* ptr;
+    hipEvent_t done;
+};
+std::mutex g_scratch_mtx;
+std::vector<pending_free> g_pending;
+
+void reclaim_scratch(bool wait)
+{
+    std::vector<pending_free> ready;
+    {
+        std::lock_guard<std::mutex> g(g_scratch_mtx);
+        for (size_t i = 0; i < g_pending.size();) {
+            const hipError_t e = wait ? hipEventSynchronize(g_pending[i].done)
+                                      : hipEventQuery(g_pending[i].done);
+            if (e == hipSuccess) {
+                ready.push_back(g_pending[i]);
+                g_pending.erase(g_pending.begin() + i);
+            } else {
+                (void)hipGetLastError();
+                ++i;
+            }
+        }
+    }
+    for (auto& p : ready) {
+        (void)hipEventDestroy(p.done);
+        (void)arena_free_impl(p.ptr, false);
+    }
+}
+}  // namespace
+
+int scratch_malloc(hipStream_t, void** ptr, size_t bytes)
+{
+    reclaim_scratch(false);
+    int rc = arena_malloc(ptr, bytes ? bytes : 1, GKOC_MEM_VECTOR);
+    if (rc != GKOC_OK) {
+        // memory may be held by scratch whose stream has not caught up yet
+        reclaim_scratch(true);
+        rc = arena_malloc(ptr, bytes ? bytes : 1, GKOC_MEM_VECTOR);
+    }
+    return rc;
+}
+
+int scratch_free(hipStream_t st, void* ptr)
+{
+    if (!ptr) return GKOC_OK;
+    hipEvent_t ev;
+    GKOC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GKOC_HIP(hipEventRecord(ev, st));
+    std::lock_guard<std::mutex> g(g_scratch_mtx);
+    g_pending.push_back({ptr, ev});
     return GKOC_OK;
 }
 

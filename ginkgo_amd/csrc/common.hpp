@@ -52,6 +52,20 @@ const device_props& current_device_props();
 // gkoc_malloc / gkoc_free go through the arena (arena.hip)
 int arena_malloc(void** ptr, size_t bytes, int role);
 int arena_free(void* ptr);
+// Stream-ordered scratch for the library's own temporaries (flags, scan partials,
+// find_blocks work arrays): taken from the arena, handed back once `st` has passed the
+// point of scratch_free.  NOT hipMallocAsync / hipFreeAsync: their pool unmaps and
+// re-maps virtual addresses, and on this system a kernel can still reach the OLD
+// physical memory through a re-mapped address (tools/vmm_tlb.hip) - observed as
+// sporadically wrong flags and scan offsets in Ginkgo's own test-suite.
+int scratch_malloc(hipStream_t st, void** ptr, size_t bytes);
+int scratch_free(hipStream_t st, void* ptr);
+
+#define GKOC_TRY(call)                              \
+    do {                                            \
+        int gkoc_rc_ = (call);                      \
+        if (gkoc_rc_ != GKOC_OK) return gkoc_rc_;   \
+    } while (0)
 
 // tuning switches (runtime.hip; keys = GKOC_TUNE_* of gko_cdna4.h)
 constexpr int tune_num_keys = 2;

@@ -351,11 +351,11 @@ using namespace gkoc;
         *is_sorted_host = 1;                                                   \
         if (n_rows <= 0) return GKOC_OK;                                       \
         int* flag = nullptr;                                                   \
-        GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&flag), sizeof(int),  \
-                                as_stream(s)));                                \
-        int one = 1;                                                           \
-        GKOC_HIP(hipMemcpyAsync(flag, &one, sizeof(int),                       \
-                                hipMemcpyHostToDevice, as_stream(s)));         \
+        GKOC_TRY(scratch_malloc(as_stream(s), reinterpret_cast<void**>(&flag), \
+                                sizeof(int)));                                 \
+        /* any non-zero pattern = sorted; set on the device (an asynchronous */ \
+        /* copy from pageable host memory is not ordered with the kernel)    */ \
+        GKOC_HIP(hipMemsetAsync(flag, 1, sizeof(int), as_stream(s)));          \
         is_sorted_kernel<I>                                                    \
             <<<dim3(unsigned(ceildiv(n_rows, 64))), dim3(64), 0,               \
                as_stream(s)>>>(n_rows, row_ptrs, col_idxs, flag);              \
@@ -363,7 +363,8 @@ using namespace gkoc;
         GKOC_HIP(hipMemcpyAsync(is_sorted_host, flag, sizeof(int),             \
                                 hipMemcpyDeviceToHost, as_stream(s)));         \
         GKOC_HIP(hipStreamSynchronize(as_stream(s)));                          \
-        GKOC_HIP(hipFreeAsync(flag, as_stream(s)));                            \
+        GKOC_TRY(scratch_free(as_stream(s), flag));                            \
+        *is_sorted_host = *is_sorted_host != 0;                                \
         return GKOC_OK;                                                        \
     }                                                                          \
     extern "C" int gkoc_csr_sort_by_column_index_##TN##_##IN(                  \

@@ -194,7 +194,7 @@ int split_count(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col
     if (rc) return rc;
     // number of rows with non-local entries: scan of flags in a temporary
     I* flag = nullptr;
-    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&flag), sizeof(I) * (n_rows + 1), st));
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&flag), sizeof(I) * (n_rows + 1)));
     rc = device_exclusive_scan<I>(st, nl_ptrs_full, n_rows + 1);
     if (rc) return rc;
     dist_row_flag_kernel<I><<<grid_for(n_rows + 1), dim3(256), 0, st>>>(n_rows, nl_ptrs_full, flag);
@@ -207,7 +207,7 @@ int split_count(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col
     GKOC_HIP(hipMemcpyAsync(&h[2], nl_ptrs_full + n_rows, sizeof(I), hipMemcpyDeviceToHost, st));
     GKOC_HIP(hipMemcpyAsync(&h[3], flag + n_rows, sizeof(I), hipMemcpyDeviceToHost, st));
     GKOC_HIP(hipStreamSynchronize(st));
-    GKOC_HIP(hipFreeAsync(flag, st));
+    GKOC_TRY(scratch_free(st, flag));
     *n_halo = int64_t(h[0]);
     *nnz_local = int64_t(h[1]);
     *nnz_nl = int64_t(h[2]);
@@ -233,7 +233,7 @@ int split_fill(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols
         n_global_cols, col_map, recv_gidx);
     GKOC_LAUNCH_OK();
     I* pos = nullptr;
-    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&pos), sizeof(I) * (n_rows + 1), st));
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&pos), sizeof(I) * (n_rows + 1)));
     dist_row_flag_kernel<I><<<grid_for(n_rows + 1), dim3(256), 0, st>>>(n_rows, nl_ptrs_full, pos);
     GKOC_LAUNCH_OK();
     int rc = device_exclusive_scan<I>(st, pos, n_rows + 1);
@@ -241,7 +241,7 @@ int split_fill(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols
     dist_row_list_kernel<I><<<grid_for(n_rows + 1), dim3(256), 0, st>>>(
         n_rows, nl_ptrs_full, pos, nl_rows, nl_ptrs);
     GKOC_LAUNCH_OK();
-    GKOC_HIP(hipFreeAsync(pos, st));
+    GKOC_TRY(scratch_free(st, pos));
     return GKOC_OK;
 }
 

@@ -18,6 +18,8 @@
 // issued UNROLL columns ahead of the in-order accumulation, which keeps the
 // reference's sequential summation order => bit-identical results.
 // Algorithmic HBM bytes: stored_elements*(sizeof(T)+sizeof(I)) + 2 n sizeof(T).
+#include <limits>
+
 #include "common.hpp"
 #include "csr_spmv_multi.hpp"
 #include "scan.hpp"
@@ -608,7 +610,7 @@ GKOC_DEF_FMT(float, f32, int64_t, i64)
         *max_host = 0;                                                         \
         if (n_rows <= 0) return GKOC_OK;                                       \
         unsigned long long* d = nullptr;                                       \
-        GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&d), 8, as_stream(s))); \
+        GKOC_TRY(scratch_malloc(as_stream(s), reinterpret_cast<void**>(&d), 8)); \
         GKOC_HIP(hipMemsetAsync(d, 0, 8, as_stream(s)));                       \
         int64_t nb = ceildiv(n_rows, 256);                                     \
         if (nb > max_stream_blocks) nb = max_stream_blocks;                    \
@@ -618,7 +620,7 @@ GKOC_DEF_FMT(float, f32, int64_t, i64)
         unsigned long long h = 0;                                              \
         GKOC_HIP(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, as_stream(s))); \
         GKOC_HIP(hipStreamSynchronize(as_stream(s)));                          \
-        GKOC_HIP(hipFreeAsync(d, as_stream(s)));                               \
+        GKOC_TRY(scratch_free(as_stream(s), d));                               \
         *max_host = int64_t(h);                                                \
         return GKOC_OK;                                                        \
     }                                                                          \
@@ -671,6 +673,17 @@ GKOC_DEF_FMT(float, f32, int64_t, i64)
     {                                                                          \
         return device_exclusive_scan<I>(as_stream(s), counts, n);              \
     }                                                                          \
+    extern "C" int gkoc_prefix_sum_nonnegative_checked_##IN(                   \
+        gkoc_stream_t s, I* counts, int64_t n)                                 \
+    {                                                                          \
+        int over = 0;                                                          \
+        const int rc = scan_overflows(as_stream(s), counts, n - 1, sizeof(I),  \
+                                      (unsigned long long)(std::numeric_limits<I>::max()), \
+                                      &over);                                  \
+        if (rc != GKOC_OK) return rc;                                          \
+        GKOC_REQUIRE(!over, GKOC_E_OVERFLOW, "prefix sum overflows " #I);      \
+        return device_exclusive_scan<I>(as_stream(s), counts, n);              \
+    }                                                                          \
     extern "C" int gkoc_fill_array_##IN(gkoc_stream_t s, I* data, int64_t n,   \
                                         I value)                               \
     {                                                                          \
@@ -696,6 +709,17 @@ GKOC_DEF_FMT(float, f32, int64_t, i64)
 
 GKOC_DEF_IDX(int32_t, i32)
 GKOC_DEF_IDX(int64_t, i64)
+
+extern "C" int gkoc_prefix_sum_nonnegative_checked_u64(gkoc_stream_t s, uint64_t* counts,
+                                                       int64_t n)
+{
+    int over = 0;
+    const int rc = scan_overflows(as_stream(s), counts, n - 1, 8, ~0ull, &over);
+    if (rc != GKOC_OK) return rc;
+    GKOC_REQUIRE(!over, GKOC_E_OVERFLOW, "prefix sum overflows uint64_t");
+    return device_exclusive_scan<unsigned long long>(
+        as_stream(s), reinterpret_cast<unsigned long long*>(counts), n);
+}
 
 extern "C" int gkoc_prefix_sum_nonnegative_u64(gkoc_stream_t s, uint64_t* counts,
                                                int64_t n)

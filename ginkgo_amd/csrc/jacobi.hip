@@ -116,8 +116,7 @@ template <typename I>
 int mark_chain(hipStream_t st, int64_t n, I* next, I* scratch, uint8_t* marked)
 {
     GKOC_HIP(hipMemsetAsync(marked, 0, n, st));
-    const uint8_t one = 1;
-    GKOC_HIP(hipMemcpyAsync(marked, &one, 1, hipMemcpyHostToDevice, st));
+    GKOC_HIP(hipMemsetAsync(marked, 1, 1, st));   // row 0 starts the chain
     const dim3 grid(unsigned(ceildiv(n + 1, 256))), block(256);
     I* a = next;
     I* b = scratch;
@@ -173,10 +172,10 @@ int find_blocks_impl(gkoc_stream_t s, int64_t n, const I* row_ptrs,
     }
     uint8_t *same = nullptr, *marked = nullptr;
     I *next = nullptr, *scratch = nullptr;
-    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&same), n, st));
-    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&marked), n, st));
-    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&next), sizeof(I) * (n + 1), st));
-    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(I) * (n + 1), st));
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&same), n));
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&marked), n));
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&next), sizeof(I) * (n + 1)));
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&scratch), sizeof(I) * (n + 1)));
     const dim3 grid(unsigned(ceildiv(n + 1, 256))), block(256);
     same_pattern_kernel<I><<<grid, block, 0, st>>>(n, row_ptrs, cols, same);
     GKOC_LAUNCH_OK();
@@ -203,10 +202,10 @@ int find_blocks_impl(gkoc_stream_t s, int64_t n, const I* row_ptrs,
     GKOC_HIP(hipMemcpyAsync(&nb, next + n, sizeof(I), hipMemcpyDeviceToHost, st));
     GKOC_HIP(hipStreamSynchronize(st));
     *num_blocks_host = int64_t(nb);
-    GKOC_HIP(hipFreeAsync(same, st));
-    GKOC_HIP(hipFreeAsync(marked, st));
-    GKOC_HIP(hipFreeAsync(next, st));
-    GKOC_HIP(hipFreeAsync(scratch, st));
+    GKOC_TRY(scratch_free(st, same));
+    GKOC_TRY(scratch_free(st, marked));
+    GKOC_TRY(scratch_free(st, next));
+    GKOC_TRY(scratch_free(st, scratch));
     return GKOC_OK;
 }
 

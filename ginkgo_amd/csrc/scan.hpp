@@ -79,14 +79,66 @@ int device_exclusive_scan(hipStream_t st, T* data, int64_t n)
         return GKOC_OK;
     }
     T* sums = nullptr;
-    GKOC_HIP(hipMallocAsync(reinterpret_cast<void**>(&sums), sizeof(T) * tiles, st));
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&sums), sizeof(T) * tiles));
     scan_tile_sums<T><<<dim3(unsigned(tiles)), dim3(scan_block), 0, st>>>(n, data, sums);
     GKOC_LAUNCH_OK();
     int rc = device_exclusive_scan<T>(st, sums, tiles);
     if (rc != GKOC_OK) return rc;
     scan_tiles<T><<<dim3(unsigned(tiles)), dim3(scan_block), 0, st>>>(n, data, sums);
     GKOC_LAUNCH_OK();
-    GKOC_HIP(hipFreeAsync(sums, st));
+    GKOC_TRY(scratch_free(st, sums));
+    return GKOC_OK;
+}
+
+// ---- overflow check of Ginkgo's prefix_sum_nonnegative contract -----------
+// (reference/components/prefix_sum_kernels.cpp:15-33: OverflowError as soon as a
+// partial sum of the first n-1 non-negative entries exceeds the type's maximum).
+// The 128-bit total is computed BEFORE the in-place scan; a total above `max` means
+// some partial sum overflowed (the entries are non-negative).
+static __global__ __launch_bounds__(256) void scan_total128_kernel(
+    int64_t n, const void* __restrict__ data, int elem_bytes, unsigned long long* __restrict__ hi_lo)
+{
+    unsigned long long lo = 0, hi = 0;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+        const unsigned long long v =
+            elem_bytes == 4 ? (unsigned long long)(static_cast<const unsigned int*>(data)[i])
+                            : static_cast<const unsigned long long*>(data)[i];
+        lo += v;
+        hi += lo < v ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long olo = __shfl_xor(lo, off, 64);
+        const unsigned long long ohi = __shfl_xor(hi, off, 64);
+        lo += olo;
+        hi += ohi + (lo < olo ? 1 : 0);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long old = atomicAdd(&hi_lo[1], lo);
+        if (old + lo < old) atomicAdd(&hi_lo[0], 1ull);
+        if (hi) atomicAdd(&hi_lo[0], hi);
+    }
+}
+
+// 0 = fits, 1 = overflow, <0 = error; synchronises the stream
+inline int scan_overflows(hipStream_t st, const void* data, int64_t n_summed, int elem_bytes,
+                          unsigned long long max_value, int* overflow)
+{
+    *overflow = 0;
+    if (n_summed <= 0) return GKOC_OK;
+    unsigned long long* acc = nullptr;
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&acc), 16));
+    GKOC_HIP(hipMemsetAsync(acc, 0, 16, st));
+    int64_t nb = ceildiv(n_summed, 256);
+    if (nb > max_stream_blocks) nb = max_stream_blocks;
+    scan_total128_kernel<<<dim3(unsigned(nb)), dim3(256), 0, st>>>(n_summed, data, elem_bytes, acc);
+    GKOC_LAUNCH_OK();
+    unsigned long long h[2] = {0, 0};
+    GKOC_HIP(hipMemcpyAsync(h, acc, 16, hipMemcpyDeviceToHost, st));
+    GKOC_HIP(hipStreamSynchronize(st));
+    GKOC_TRY(scratch_free(st, acc));
+    *overflow = (h[0] != 0 || h[1] > max_value) ? 1 : 0;
     return GKOC_OK;
 }
 

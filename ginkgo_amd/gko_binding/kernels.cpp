@@ -27,6 +27,8 @@
 #include "core/solver/gmres_kernels.hpp"
 #include "core/stop/criterion_kernels.hpp"
 #include "core/stop/residual_norm_kernels.hpp"
+#include <complex>
+
 #include "shim_common.hpp"
 
 namespace gko {
@@ -258,6 +260,25 @@ inline void* scratch(array<char>& tmp, int64_t n, int64_t nrhs, size_t& bytes)
                                        ld(output)));                            \
     }                                                                           \
     template <>                                                                 \
+    void simple_apply<T>(exec_t exec, const matrix::Dense<T>* a,                \
+                         const matrix::Dense<T>* b, matrix::Dense<T>* c)        \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_simple_apply_##TN(                                 \
+            stream_of(exec), rows(c), cols(c), cols(a), a->get_const_values(),  \
+            ld(a), b->get_const_values(), ld(b), c->get_values(), ld(c)));      \
+    }                                                                           \
+    template <>                                                                 \
+    void apply<T>(exec_t exec, const matrix::Dense<T>* alpha,                   \
+                  const matrix::Dense<T>* a, const matrix::Dense<T>* b,         \
+                  const matrix::Dense<T>* beta, matrix::Dense<T>* c)            \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_apply_##TN(                                        \
+            stream_of(exec), rows(c), cols(c), cols(a),                         \
+            alpha->get_const_values(), a->get_const_values(), ld(a),            \
+            b->get_const_values(), ld(b), beta->get_const_values(),             \
+            c->get_values(), ld(c)));                                           \
+    }                                                                           \
+    template <>                                                                 \
     void scale<T, T>(exec_t exec, const matrix::Dense<T>* alpha,                \
                      matrix::Dense<T>* x)                                       \
     {                                                                           \
@@ -384,6 +405,41 @@ FOR_VT(DEF)
             ld(row_collection)));                                               \
     }
 FOR_VT_IT(DEF)
+#undef DEF
+
+// dense::copy between the two real precisions (Dense::convert_to, mixed-precision applies)
+template <>
+void copy<double, float>(exec_t exec, const matrix::Dense<double>* input,
+                         matrix::Dense<float>* output)
+{
+    GKOC_CALL(gkoc_dense_convert_f64_f32(stream_of(exec), rows(input), cols(input),
+                                         input->get_const_values(), ld(input),
+                                         output->get_values(), ld(output)));
+}
+template <>
+void copy<float, double>(exec_t exec, const matrix::Dense<float>* input,
+                         matrix::Dense<double>* output)
+{
+    GKOC_CALL(gkoc_dense_convert_f32_f64(stream_of(exec), rows(input), cols(input),
+                                         input->get_const_values(), ld(input),
+                                         output->get_values(), ld(output)));
+}
+
+// complex Dense copies: a complex row-major matrix is a real one with twice the columns and
+// twice the stride (the only complex kernels of this backend; they keep Dense::convert_to /
+// clone of complex vectors working, e.g. for Ginkgo's cross-executor tests)
+#define DEF(CI, RI, CO, RO, FN)                                                                  \
+    template <>                                                                                  \
+    void copy<CI, CO>(exec_t exec, const matrix::Dense<CI>* input, matrix::Dense<CO>* output)    \
+    {                                                                                            \
+        GKOC_CALL(FN(stream_of(exec), rows(input), 2 * cols(input),                              \
+                     reinterpret_cast<const RI*>(input->get_const_values()), 2 * ld(input),      \
+                     reinterpret_cast<RO*>(output->get_values()), 2 * ld(output)));              \
+    }
+DEF(std::complex<double>, double, std::complex<double>, double, gkoc_dense_copy_f64)
+DEF(std::complex<float>, float, std::complex<float>, float, gkoc_dense_copy_f32)
+DEF(std::complex<double>, double, std::complex<float>, float, gkoc_dense_convert_f64_f32)
+DEF(std::complex<float>, float, std::complex<double>, double, gkoc_dense_convert_f32_f64)
 #undef DEF
 
 }  // namespace dense
@@ -890,18 +946,18 @@ void fill_seq_array<int64>(exec_t exec, int64* data, size_type n)
 template <>
 void prefix_sum_nonnegative<int32>(exec_t exec, int32* counts, size_type n)
 {
-    GKOC_CALL(gkoc_prefix_sum_nonnegative_i32(stream_of(exec), counts, n));
+    GKOC_CALL(gkoc_prefix_sum_nonnegative_checked_i32(stream_of(exec), counts, n));
 }
 template <>
 void prefix_sum_nonnegative<int64>(exec_t exec, int64* counts, size_type n)
 {
-    GKOC_CALL(gkoc_prefix_sum_nonnegative_i64(stream_of(exec), counts, n));
+    GKOC_CALL(gkoc_prefix_sum_nonnegative_checked_i64(stream_of(exec), counts, n));
 }
 template <>
 void prefix_sum_nonnegative<size_type>(exec_t exec, size_type* counts,
                                        size_type n)
 {
-    GKOC_CALL(gkoc_prefix_sum_nonnegative_u64(
+    GKOC_CALL(gkoc_prefix_sum_nonnegative_checked_u64(
         stream_of(exec), reinterpret_cast<uint64_t*>(counts), n));
 }
 template <>

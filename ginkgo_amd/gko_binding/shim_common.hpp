@@ -33,6 +33,9 @@ inline void check(int status, const char* file, int line, const char* what)
     if (status == GKOC_E_NOT_SUPPORTED) {
         throw ::gko::NotSupported(file, line, what, gkoc_last_error());
     }
+    if (status == GKOC_E_OVERFLOW) {
+        throw ::gko::OverflowError(file, line, gkoc_last_error());
+    }
     throw ::gko::HipError(file, line, msg, status);
 }
 

@@ -45,6 +45,7 @@ extern "C" {
 #define GKOC_E_WORKSPACE (-3)     /* workspace too small                */
 #define GKOC_E_NO_DEVICE (-4)     /* no gfx950 device / HIP unavailable */
 #define GKOC_E_COMM (-5)          /* RCCL failure                       */
+#define GKOC_E_OVERFLOW (-6)      /* index computation overflows (gko::OverflowError) */
 
 typedef void* gkoc_stream_t;
 
@@ -342,6 +343,10 @@ GKOC_DECL_ASSEMBLY(float, f32, int64_t, i64)
     /* in-place exclusive scan over n entries (last entry = total) */          \
     int gkoc_prefix_sum_nonnegative_##IN(gkoc_stream_t s, I* counts,           \
                                          int64_t n);                           \
+    /* the same with the reference's overflow check (GKOC_E_OVERFLOW when a */ \
+    /* partial sum exceeds the type; synchronises the stream)              */ \
+    int gkoc_prefix_sum_nonnegative_checked_##IN(gkoc_stream_t s, I* counts,   \
+                                                 int64_t n);                   \
     int gkoc_fill_array_##IN(gkoc_stream_t s, I* data, int64_t n, I value);    \
     int gkoc_fill_seq_array_##IN(gkoc_stream_t s, I* data, int64_t n);
 GKOC_DECL_IDX(int32_t, i32)
@@ -351,6 +356,28 @@ int gkoc_fill_array_f64(gkoc_stream_t s, double* data, int64_t n, double value);
 int gkoc_fill_array_f32(gkoc_stream_t s, float* data, int64_t n, float value);
 int gkoc_prefix_sum_nonnegative_u64(gkoc_stream_t s, uint64_t* counts,
                                     int64_t n);
+int gkoc_prefix_sum_nonnegative_checked_u64(gkoc_stream_t s, uint64_t* counts,
+                                            int64_t n);
+
+/* --------------------------------------------- Dense x Dense, precision conversion
+ * dense::simple_apply / apply (core/matrix/dense_kernels.hpp:23-32, reference/matrix/
+ * dense_kernels.cpp:38-92): C (m x n) = A (m x k) B (k x n) resp. alpha A B + beta C, row-major
+ * with row strides; every entry is the reference's in-order sum (bit-identical).  dense::copy
+ * between precisions (:95-106) = gkoc_dense_convert_<from>_<to>.  Off the hot path. */
+#define GKOC_DECL_GEMM(T, TN)                                                   \
+    int gkoc_dense_simple_apply_##TN(gkoc_stream_t s, int64_t m, int64_t n,     \
+                                     int64_t k, const T* a, int64_t lda,        \
+                                     const T* b, int64_t ldb, T* c, int64_t ldc); \
+    int gkoc_dense_apply_##TN(gkoc_stream_t s, int64_t m, int64_t n, int64_t k,  \
+                              const T* alpha, const T* a, int64_t lda,          \
+                              const T* b, int64_t ldb, const T* beta, T* c,     \
+                              int64_t ldc);
+GKOC_DECL_GEMM(double, f64)
+GKOC_DECL_GEMM(float, f32)
+int gkoc_dense_convert_f64_f32(gkoc_stream_t s, int64_t rows, int64_t cols,
+                               const double* x, int64_t ldx, float* y, int64_t ldy);
+int gkoc_dense_convert_f32_f64(gkoc_stream_t s, int64_t rows, int64_t cols,
+                               const float* x, int64_t ldx, double* y, int64_t ldy);
 
 /* ------------------------------------------------------------ Dense BLAS-1
  * dense::{fill,copy,scale,inv_scale,add_scaled,sub_scaled}
