@@ -2,6 +2,8 @@
 // stream management.  These are the C-ABI equivalents of the HipExecutor
 // member functions that Ginkgo stubs in core/device_hooks/hip_hooks.cpp:21-252
 // and implements for its own backend in hip/base/executor.hip.cpp.
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -309,5 +311,54 @@ int gkoc_device_synchronize(void)
     GKOC_HIP(hipDeviceSynchronize());
     return GKOC_OK;
 }
+
+// ---- ROCTX ranges (gko::log::begin_roctx / end_roctx, hip/base/roctx.hip.cpp:30-36): bound at
+// run time, so that the library has no link dependency on a profiler.  rocprofiler-sdk's roctx
+// is tried first (rocprofv3 --marker-trace), then the roctracer one.
+}  // extern "C"
+
+namespace {
+using roctx_push_t = int (*)(const char*);
+using roctx_pop_t = int (*)();
+struct roctx_api {
+    roctx_push_t push = nullptr;
+    roctx_pop_t pop = nullptr;
+    roctx_api()
+    {
+        for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so",
+                                 "libroctx64.so.4", "libroctx64.so"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<roctx_push_t>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<roctx_pop_t>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+const roctx_api& roctx()
+{
+    static roctx_api api;
+    return api;
+}
+}  // namespace
+
+extern "C" {
+
+int gkoc_range_push(const char* name)
+{
+    GKOC_REQUIRE(name, GKOC_E_INVALID, "name == NULL");
+    if (roctx().push) roctx().push(name);
+    return GKOC_OK;
+}
+
+int gkoc_range_pop(void)
+{
+    if (roctx().pop) roctx().pop();
+    return GKOC_OK;
+}
+
+int gkoc_range_available(void) { return roctx().push != nullptr; }
 
 }  // extern "C"

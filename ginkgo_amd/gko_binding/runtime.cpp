@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstring>
 
+#include <ginkgo/core/base/event.hpp>
 #include <ginkgo/core/base/memory.hpp>
 #include <ginkgo/core/base/scoped_device_id_guard.hpp>
 #include <ginkgo/core/base/stream.hpp>
@@ -355,15 +356,61 @@ void reset_device(int) {}
 
 void destroy_event(GKO_HIP_EVENT_STRUCT* event) { gkoc_event_destroy(event); }
 
+std::string get_device_name(int device_id)
+{
+    gkoc_device_info info;
+    GKOC_CALL(gkoc_get_device_info(device_id, &info));
+    return info.arch;
+}
+
+namespace event {
+
+namespace {
+// an event on the executor's stream: recorded at construction (core/base/event_kernels.hpp;
+// used by distributed::RowGatherer / Matrix to order the halo exchange after the pack kernel)
+class stream_event : public ::gko::detail::Event {
+public:
+    explicit stream_event(std::shared_ptr<const HipExecutor> exec) : exec_{std::move(exec)}
+    {
+        cdna4::device_guard g(exec_->get_device_id());
+        GKOC_CALL(gkoc_event_create(&ev_));
+        GKOC_CALL(gkoc_event_record(ev_, reinterpret_cast<gkoc_stream_t>(exec_->get_stream())));
+    }
+    ~stream_event()
+    {
+        cdna4::device_guard g(exec_->get_device_id());
+        gkoc_event_destroy(ev_);
+    }
+    void synchronize() const override
+    {
+        cdna4::device_guard g(exec_->get_device_id());
+        GKOC_CALL(gkoc_event_synchronize(ev_));
+    }
+
+private:
+    std::shared_ptr<const HipExecutor> exec_;
+    gkoc_event_t ev_{};
+};
+}  // namespace
+
+void record_event(std::shared_ptr<const HipExecutor> exec,
+                  std::shared_ptr<const ::gko::detail::Event>& event)
+{
+    event = std::make_shared<stream_event>(std::move(exec));
+}
+
+}  // namespace event
+
 }  // namespace hip
 }  // namespace kernels
 
 
 namespace log {
 
-// ROCTX ranges are optional instrumentation; without libroctx they are no-ops
-void begin_roctx(const char*, profile_event_category) {}
-void end_roctx(const char*, profile_event_category) {}
+// ROCTX ranges: bound at run time by the library (gkoc_range_push / pop), no-ops without a
+// roctx library on the system
+void begin_roctx(const char* name, profile_event_category) { gkoc_range_push(name); }
+void end_roctx(const char*, profile_event_category) { gkoc_range_pop(); }
 
 }  // namespace log
 }  // namespace gko

@@ -138,6 +138,12 @@ int gkoc_stream_create(gkoc_stream_t* s);
 int gkoc_stream_destroy(gkoc_stream_t s);
 int gkoc_stream_synchronize(gkoc_stream_t s);
 int gkoc_device_synchronize(void);
+/* ROCTX ranges (log::begin_roctx / end_roctx, hip/base/roctx.hip.cpp:30-36; ProfilerHook::
+ * create_roctx): librocprofiler-sdk-roctx / libroctx64 bound with dlopen at first use, no-ops
+ * when neither is there.  `rocprofv3 --marker-trace` then shows Ginkgo's operation ranges. */
+int gkoc_range_push(const char* name);
+int gkoc_range_pop(void);
+int gkoc_range_available(void);   /* 1 if a roctx library was found */
 /* events (HipTimer, hip/base/timer.hip.cpp; RowGatherer's event::record_event) */
 typedef void* gkoc_event_t;
 int gkoc_event_create(gkoc_event_t* e);

@@ -1,0 +1,211 @@
+// TEST INFRASTRUCTURE.  Ginkgo's OWN distributed classes (unmodified core built with
+// GINKGO_BUILD_MPI=1, oracle/build_ref_mpi.py) on this backend, launched with
+// `mpiexec -n <ranks>`; all ranks share GPU 0 of the test box.  Restates the equivalence checks of
+// test/mpi/distributed/matrix.cpp (apply / advanced apply vs ReferenceExecutor),
+// test/mpi/distributed/vector.cpp (compute_dot / compute_norm2 / compute_squared_norm2, add_scaled,
+// scale) and test/mpi/solver/solver.cpp (distributed Cg with a Schwarz(block-Jacobi)
+// preconditioner) for gko::experimental::distributed::{Matrix, Vector}<double, int32, int64>:
+//   core/distributed/matrix.cpp:450-509 (apply_impl: local SpMV || halo exchange, non-local SpMV),
+//   core/distributed/vector.cpp:473-592 (reductions + all_reduce).
+// Every comparison is HipExecutor (gko-cdna4 kernels) against ReferenceExecutor on the SAME
+// partitioned data; MPICH is not GPU-aware, so Ginkgo stages the halo through the host itself.
+//   mpiexec -n 2 mpi_dist_test [grid=24]
+#include <mpi.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <random>
+#include <vector>
+
+#include <ginkgo/ginkgo.hpp>
+
+using vt = double;
+using lit = gko::int32;
+using git = gko::int64;
+using dist_mtx = gko::experimental::distributed::Matrix<vt, lit, git>;
+using dist_vec = gko::experimental::distributed::Vector<vt>;
+using part_type = gko::experimental::distributed::Partition<lit, git>;
+using dense = gko::matrix::Dense<vt>;
+
+static int failures = 0;
+static int g_rank = 0;
+
+static void check(bool ok, const char* what, double value = 0)
+{
+    int all_ok = ok ? 1 : 0;
+    MPI_Allreduce(MPI_IN_PLACE, &all_ok, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+    if (g_rank == 0) std::printf("%-68s %s  (%.3e)\n", what, all_ok ? "PASSED" : "FAILED", value);
+    if (!all_ok) ++failures;
+}
+
+// max |a - b| / max |b| over the LOCAL parts of two distributed vectors (b on the host)
+static double local_rel_diff(const dist_vec* on_device, const dist_vec* on_host)
+{
+    auto ref = gko::ReferenceExecutor::create();
+    auto d = gko::clone(ref, on_device->get_local_vector());
+    auto h = on_host->get_local_vector();
+    double diff = 0, scale = 0;
+    for (gko::size_type i = 0; i < h->get_size()[0]; ++i) {
+        for (gko::size_type j = 0; j < h->get_size()[1]; ++j) {
+            diff = std::max(diff, std::abs(d->at(i, j) - h->at(i, j)));
+            scale = std::max(scale, std::abs(h->at(i, j)));
+        }
+    }
+    double both[2] = {diff, scale};
+    MPI_Allreduce(MPI_IN_PLACE, both, 2, MPI_DOUBLE, MPI_MAX, MPI_COMM_WORLD);
+    return both[1] > 0 ? both[0] / both[1] : both[0];
+}
+
+int main(int argc, char** argv)
+{
+    const gko::experimental::mpi::environment env(argc, argv);
+    const gko::experimental::mpi::communicator comm(MPI_COMM_WORLD);
+    g_rank = comm.rank();
+    const int grid = argc > 1 ? std::atoi(argv[1]) : 24;
+    const git n = git(grid) * grid * grid;
+    auto ref = gko::ReferenceExecutor::create();
+    auto hip = gko::HipExecutor::create(0, ref);
+    if (g_rank == 0) {
+        std::cout << comm.size() << " ranks, " << hip->get_description() << ", 27-pt " << grid
+                  << "^3, GPU-aware MPI: " << gko::experimental::mpi::is_gpu_aware() << std::endl;
+    }
+
+    // rows by contiguous ranges (z-slabs), 27-point stencil with global column indices:
+    // benchmark/utils/stencil_matrix.hpp:264-453 (diag 26, off-diagonals -1)
+    auto partition = gko::share(part_type::build_from_global_size_uniform(ref, comm.size(), n));
+    const auto lo = partition->get_range_bounds()[g_rank], hi = partition->get_range_bounds()[g_rank + 1];
+    gko::matrix_data<vt, git> a_data{gko::dim<2>(n, n)};
+    gko::matrix_data<vt, git> b_data{gko::dim<2>(n, 2)}, x_data{gko::dim<2>(n, 2)};
+    std::mt19937_64 rng(42);
+    std::uniform_real_distribution<double> dist(-1.0, 1.0);
+    std::vector<double> bvals(2 * n), xvals(2 * n);
+    for (auto& v : bvals) v = dist(rng);   // same sequence on every rank
+    for (auto& v : xvals) v = dist(rng);
+    for (git row = lo; row < hi; ++row) {
+        const git ix = row % grid, iy = (row / grid) % grid, iz = row / (git(grid) * grid);
+        for (int dz = -1; dz <= 1; ++dz) {
+            for (int dy = -1; dy <= 1; ++dy) {
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const git x = ix + dx, y = iy + dy, z = iz + dz;
+                    if (x < 0 || y < 0 || z < 0 || x >= grid || y >= grid || z >= grid) continue;
+                    const git col = (z * grid + y) * grid + x;
+                    a_data.nonzeros.emplace_back(row, col, col == row ? 26.0 : -1.0);
+                }
+            }
+        }
+        for (int j = 0; j < 2; ++j) {
+            b_data.nonzeros.emplace_back(row, j, bvals[2 * row + j]);
+            x_data.nonzeros.emplace_back(row, j, xvals[2 * row + j]);
+        }
+    }
+    auto a_host = gko::share(dist_mtx::create(ref, comm));
+    auto b_host = gko::share(dist_vec::create(ref, comm));
+    auto x_host = gko::share(dist_vec::create(ref, comm));
+    a_host->read_distributed(a_data, partition);
+    b_host->read_distributed(b_data, partition);
+    x_host->read_distributed(x_data, partition);
+    auto a = gko::share(dist_mtx::create(hip, comm));
+    auto b = gko::share(dist_vec::create(hip, comm));
+    auto x = gko::share(dist_vec::create(hip, comm));
+    a->copy_from(a_host);
+    b->copy_from(b_host);
+    x->copy_from(x_host);
+    {
+        auto nl = gko::as<gko::matrix::Csr<vt, lit>>(a->get_non_local_matrix());
+        long cols = nl->get_size()[1], total = 0;
+        MPI_Allreduce(&cols, &total, 1, MPI_LONG, MPI_SUM, MPI_COMM_WORLD);
+        check(comm.size() == 1 || total > 0, "the non-local blocks have halo columns", double(total));
+    }
+
+    // ---- Matrix::apply / advanced apply (test/mpi/distributed/matrix.cpp)
+    a_host->apply(b_host, x_host);
+    a->apply(b, x);
+    double d = local_rel_diff(x.get(), x_host.get());
+    check(d <= 1e-14, "distributed::Matrix::apply, 2 right-hand sides: hip vs reference", d);
+    auto alpha = gko::initialize<dense>({2.0}, ref), beta = gko::initialize<dense>({-0.5}, ref);
+    auto dalpha = gko::clone(hip, alpha), dbeta = gko::clone(hip, beta);
+    a_host->apply(alpha, b_host, beta, x_host);
+    a->apply(dalpha, b, dbeta, x);
+    d = local_rel_diff(x.get(), x_host.get());
+    check(d <= 1e-14, "distributed::Matrix::apply(alpha, b, beta, x): hip vs reference", d);
+
+    // ---- Vector reductions and updates (test/mpi/distributed/vector.cpp)
+    auto res_h = dense::create(ref, gko::dim<2>{1, 2}), res_d = dense::create(hip, gko::dim<2>{1, 2});
+    auto rel = [&](const dense* dev, const dense* host) {
+        auto c = gko::clone(ref, dev);
+        double m = 0;
+        for (int j = 0; j < 2; ++j) {
+            m = std::max(m, std::abs(c->at(0, j) - host->at(0, j)) / std::max(std::abs(host->at(0, j)), 1e-300));
+        }
+        return m;
+    };
+    b_host->compute_dot(x_host, res_h);
+    b->compute_dot(x, res_d);
+    check(rel(res_d.get(), res_h.get()) <= 1e-13, "distributed::Vector::compute_dot (all-reduced)", rel(res_d.get(), res_h.get()));
+    b_host->compute_norm2(res_h);
+    b->compute_norm2(res_d);
+    check(rel(res_d.get(), res_h.get()) <= 1e-13, "distributed::Vector::compute_norm2", rel(res_d.get(), res_h.get()));
+    b_host->compute_squared_norm2(res_h);
+    b->compute_squared_norm2(res_d);
+    check(rel(res_d.get(), res_h.get()) <= 1e-13, "distributed::Vector::compute_squared_norm2", rel(res_d.get(), res_h.get()));
+    x_host->add_scaled(alpha, b_host);
+    x->add_scaled(dalpha, b);
+    x_host->scale(beta);
+    x->scale(dbeta);
+    d = local_rel_diff(x.get(), x_host.get());
+    check(d == 0.0, "distributed::Vector::add_scaled + scale: bit-identical local parts", d);
+
+    // ---- distributed Cg + Schwarz(block-Jacobi(8)) (test/mpi/solver/solver.cpp, examples/distributed-solver)
+    auto solve = [&](std::shared_ptr<const gko::Executor> exec, std::shared_ptr<dist_mtx> mat,
+                     const dist_vec* rhs, dist_vec* sol) {
+        using schwarz = gko::experimental::distributed::preconditioner::Schwarz<vt, lit, git>;
+        auto logger = gko::share(gko::log::Convergence<vt>::create());
+        auto solver =
+            gko::solver::Cg<vt>::build()
+                .with_preconditioner(
+                    schwarz::build()
+                        .with_local_solver(gko::preconditioner::Jacobi<vt, lit>::build().with_max_block_size(8u))
+                        .on(exec))
+                .with_criteria(gko::stop::Iteration::build().with_max_iters(500u),
+                               gko::stop::ResidualNorm<vt>::build().with_reduction_factor(1e-10))
+                .on(exec)
+                ->generate(mat);
+        solver->add_logger(logger);
+        solver->apply(rhs, sol);
+        return int(logger->get_num_iterations());
+    };
+    gko::matrix_data<vt, git> ones_data{gko::dim<2>(n, 1)}, zero_data{gko::dim<2>(n, 1)};
+    for (git row = lo; row < hi; ++row) {
+        ones_data.nonzeros.emplace_back(row, 0, 1.0);
+        zero_data.nonzeros.emplace_back(row, 0, 0.0);
+    }
+    auto rhs_host = dist_vec::create(ref, comm), sol_host = dist_vec::create(ref, comm);
+    rhs_host->read_distributed(ones_data, partition);
+    sol_host->read_distributed(zero_data, partition);
+    auto rhs = dist_vec::create(hip, comm), sol = dist_vec::create(hip, comm);
+    rhs->copy_from(rhs_host);
+    sol->copy_from(sol_host);
+    const int it_host = solve(ref, a_host, rhs_host.get(), sol_host.get());
+    const int it_dev = solve(hip, a, rhs.get(), sol.get());
+    check(std::abs(it_host - it_dev) <= 1, "distributed Cg + Schwarz(Jacobi(8)): iteration count hip vs reference",
+          double(it_dev - it_host));
+    d = local_rel_diff(sol.get(), sol_host.get());
+    check(d <= 1e-8, "distributed Cg solution: hip vs reference", d);
+    // true residual through the distributed operator on the device
+    auto one = gko::initialize<dense>({1.0}, hip), neg = gko::initialize<dense>({-1.0}, hip);
+    auto r = dist_vec::create(hip, comm);
+    r->copy_from(rhs);
+    a->apply(neg, sol, one, r);
+    auto rn = dense::create(hip, gko::dim<2>{1, 1});
+    r->compute_norm2(rn);
+    const double resn = gko::clone(ref, rn)->at(0, 0) / std::sqrt(double(n));
+    check(resn <= 1e-9, "distributed Cg: relative true residual on the device", resn);
+
+    if (g_rank == 0) {
+        std::printf("%s: %d iterations on hip, %d on reference\n", failures ? "FAILED" : "ALL PASSED", it_dev,
+                    it_host);
+    }
+    return failures ? 1 : 0;
+}
