@@ -21,6 +21,8 @@
 
 #include <ginkgo/ginkgo.hpp>
 
+#include "rccl_communicator.hpp"
+
 using vt = double;
 using lit = gko::int32;
 using git = gko::int64;
@@ -130,6 +132,41 @@ int main(int argc, char** argv)
     a->apply(dalpha, b, dbeta, x);
     d = local_rel_diff(x.get(), x_host.get());
     check(d <= 1e-14, "distributed::Matrix::apply(alpha, b, beta, x): hip vs reference", d);
+
+    // ---- this backend's CollectiveCommunicator (ginkgo_amd/gko_binding/rccl_communicator.hpp) inside
+    // Ginkgo's RowGatherer (test/mpi/distributed/row_gatherer.cpp): gather the halo planes of b.
+    // RCCL carries device buffers when every rank has its own GPU; on this box the ranks share one
+    // and Ginkgo hands over host-staged buffers, which take the class's MPI path.
+    {
+        using gatherer = gko::experimental::distributed::RowGatherer<lit>;
+        using imap_t = gko::experimental::distributed::index_map<lit, git>;
+        const git plane = git(grid) * grid;
+        std::vector<git> halo;
+        for (git gi = std::max<git>(lo - plane, 0); gi < lo; ++gi) halo.push_back(gi);
+        for (git gi = hi; gi < std::min<git>(hi + plane, n); ++gi) halo.push_back(gi);
+        gko::array<git> halo_arr(ref, halo.begin(), halo.end());
+        imap_t imap(ref, partition, g_rank, halo_arr);
+        std::shared_ptr<const gko::experimental::mpi::CollectiveCommunicator> templ =
+            std::make_shared<gko::cdna4::RcclCommunicator>(comm, 0);
+        const bool rccl = static_cast<const gko::cdna4::RcclCommunicator*>(templ.get())->uses_rccl();
+        auto mpi_exec = gko::experimental::mpi::requires_host_buffer(hip, comm)
+                            ? std::shared_ptr<const gko::Executor>(ref)
+                            : std::shared_ptr<const gko::Executor>(hip);
+        auto rg = gatherer::create(hip, templ->create_with_same_type(comm, &imap), imap);
+        auto out = dist_vec::create(mpi_exec, comm, gko::dim<2>{rg->get_size()[0], 2},
+                                    gko::dim<2>{halo.size(), 2});
+        rg->apply_async(b, out).wait();
+        hip->synchronize();
+        auto got = gko::clone(ref, out->get_local_vector());
+        double worst = 0;
+        // remote indices come sorted by owning rank, then by global index = the order of `halo`
+        for (gko::size_type i = 0; i < halo.size(); ++i) {
+            for (int j = 0; j < 2; ++j) worst = std::max(worst, std::abs(got->at(i, j) - bvals[2 * halo[i] + j]));
+        }
+        check(worst == 0.0, rccl ? "RowGatherer with RcclCommunicator (RCCL transport): halo of b"
+                                 : "RowGatherer with RcclCommunicator (MPI path: ranks share the GPU)",
+              worst);
+    }
 
     // ---- Vector reductions and updates (test/mpi/distributed/vector.cpp)
     auto res_h = dense::create(ref, gko::dim<2>{1, 2}), res_d = dense::create(hip, gko::dim<2>{1, 2});

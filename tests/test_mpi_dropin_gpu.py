@@ -30,7 +30,7 @@ def test_distributed_matrix_vector_cg_vs_reference(ranks, grid):
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "ALL PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
-    assert p.stdout.count("PASSED") >= 11, p.stdout
+    assert p.stdout.count("PASSED") >= 12, p.stdout
     # the apply is bit-identical to the ReferenceExecutor's (same local / non-local split)
     m = re.search(r"distributed::Matrix::apply, 2 right-hand sides.*\(([\d.e+-]+)\)", p.stdout)
     assert m and float(m.group(1)) == 0.0, p.stdout
