@@ -546,7 +546,9 @@ class DistributedCg:
         self.m = backend.jacobi(matrix.local, max_block_size) if max_block_size else None
         self.num_iterations = 0
         self.residual_norm = None
-        self.check_lag = backend.max_check_lag if check_lag is None else int(check_lag)
+        # never more checks in flight than the flag ring has slots
+        self.check_lag = backend.max_check_lag if check_lag is None else \
+            max(0, min(int(check_lag), 16 - 2))
         self.fused = bool(fused)
         n, dt = matrix.n_local, matrix.dtype
         self.r, self.z, self.p, self.q = (backend.vector(n, dt) for _ in range(4))

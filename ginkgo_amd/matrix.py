@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import DimensionMismatch, GkoError, IT, VT, call, cval
 from .base import LinOp
-from .executor import MEM_INDICES, MEM_VALUES
+from .executor import MEM_INDICES, MEM_VALUES, MEM_VECTOR
 
 
 def _np_dtype(t):
@@ -35,12 +35,12 @@ class Dense(LinOp):
 
     # -- construction
     @staticmethod
-    def create(exec_, size, dtype=torch.float64, stride=None):
+    def create(exec_, size, dtype=torch.float64, stride=None, role=MEM_VECTOR):
         rows, cols = size
         stride = cols if stride is None else stride
         if stride < cols:
             raise GkoError("Dense: stride smaller than number of columns")
-        store = exec_.alloc((rows, max(stride, 1)), dtype)
+        store = exec_.alloc((rows, max(stride, 1)), dtype, role)
         return Dense(exec_, store[:, :cols])
 
     @staticmethod

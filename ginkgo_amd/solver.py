@@ -8,6 +8,7 @@ criterion check, step_1, SpMV, conj_dot, step_2, swap), same stopping
 semantics.  Every step is a libgko_cdna4.so kernel; the host only drives.
 """
 import ctypes as C
+import os
 
 from collections import deque
 
@@ -15,6 +16,7 @@ import torch
 
 from ._lib import DimensionMismatch, NotSupported, VT, call, lib
 from .base import LinOp
+from .executor import MEM_VALUES, MEM_VECTOR
 from .matrix import Dense, scalar
 from . import stop as _stop
 
@@ -111,7 +113,13 @@ class _IterativeSolver(LinOp):
     def _vec(self, name, like):
         v = self._ws.get(name)
         if v is None or v.size != like.size or v.dtype != like.dtype:
-            v = Dense.create(self.exec, like.size, like.dtype)
+            # Memory class of a workspace vector (arena): a kernel's output should
+            # not share a class with its large inputs.  z is written by the preconditioner, whose
+            # inputs are the Jacobi blocks (index class) and r (vector class): z goes to the
+            # third class, where the matrix values live (no kernel touches values and z).
+            role = MEM_VALUES if name == "z" and os.environ.get("GKO_CG_Z_ROLE", "1") == "1" \
+                else MEM_VECTOR
+            v = Dense.create(self.exec, like.size, like.dtype, role=role)
             self._ws[name] = v
         return v
 
@@ -161,6 +169,9 @@ class Cg(_IterativeSolver):
         # the iterations enqueued in between leave x, r, p as they were at the
         # stopping iteration.  with_check_lag(0) = lock-step like the reference.
         lag = int(self.params.get("check_lag", 4))
+        # the criterion's flag ring holds _NSLOT checks in flight: a larger lag would overwrite
+        # slots that have not been read yet
+        lag = max(0, min(lag, _stop.ResidualNorm._NSLOT - 2))
         # Fused producer+reduction kernels (include/gko_cdna4.h, gkoc_x_*): same
         # vectors bit for bit, one pass less over r / z / p / q per pair.
         # with_fused_kernels(False) = the reference's kernel sequence.
@@ -168,9 +179,10 @@ class Cg(_IterativeSolver):
             all(v.ld == 1 for v in (b, x, r, z, p, q))
         from .matrix import Csr
         from .preconditioner import Jacobi
-        # (spmv + dot measured slower fused than unfused - the dot re-reads p, q
-        # from the memory-side cache -, so it is opt-in)
-        fuse_spmv = fuse and isinstance(a, Csr) and bool(self.params.get("fused_spmv_dot", False))
+        # spmv + <p, q> in one pass: 1034 against 1050 us on L256 once the operands sit in
+        # different memory classes (round 1, without the arena: slower fused); with_fused_spmv_dot(False)
+        # turns it off
+        fuse_spmv = fuse and isinstance(a, Csr) and bool(self.params.get("fused_spmv_dot", True))
         fuse_prec = fuse and isinstance(m, Jacobi) and m.can_fuse_dot(r)
         fuse_norm = fuse and any(isinstance(c, _stop.ResidualNorm) and not c.implicit
                                  for c in crit.criteria)
