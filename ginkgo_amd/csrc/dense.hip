@@ -47,6 +47,19 @@ struct op_copy {
     }
 };
 
+// dense::inplace_absolute_dense / outplace_absolute_dense (real types),
+// reference/matrix/dense_kernels.cpp:1178-1202
+template <typename T>
+struct op_abs {
+    struct scalars {};
+    __device__ scalars load(int64_t) const { return {}; }
+    __device__ bool skip(const scalars&) const { return false; }
+    __device__ void apply(const scalars&, const T* in, T* out) const
+    {
+        out[0] = in[0] < T(0) ? -in[0] : in[0];
+    }
+};
+
 // reference/matrix/dense_kernels.cpp:126-148: single alpha == 0 => x = 0
 template <typename T>
 struct op_scale {
@@ -330,6 +343,18 @@ extern "C" size_t gkoc_reduction_workspace_bytes(int64_t, int64_t nrhs,
         a.ld_out[0] = ldy;                                                     \
         return launch_elementwise<T, op_copy<T>, 1, 1>(s, rows, cols, a,       \
                                                        op_copy<T>{}, true);    \
+    }                                                                          \
+    extern "C" int gkoc_dense_absolute_##TN(gkoc_stream_t s, int64_t rows,      \
+                                            int64_t cols, const T* x,          \
+                                            int64_t ldx, T* y, int64_t ldy)    \
+    {                                                                          \
+        ew_operands<T, 1, 1> a{};                                              \
+        a.in[0] = x;                                                           \
+        a.ld_in[0] = ldx;                                                      \
+        a.out[0] = y;                                                          \
+        a.ld_out[0] = ldy;                                                     \
+        return launch_elementwise<T, op_abs<T>, 1, 1>(s, rows, cols, a,        \
+                                                      op_abs<T>{}, true);      \
     }                                                                          \
     extern "C" int gkoc_dense_scale_##TN(gkoc_stream_t s, int64_t rows,        \
                                          int64_t cols, const T* alpha,         \

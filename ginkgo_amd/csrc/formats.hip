@@ -349,16 +349,16 @@ __global__ __launch_bounds__(256) void ptrs_to_sizes_kernel(
 
 // idxs sorted ascending; ptrs[r] = first position with idxs[pos] >= r
 // (reference convert_idxs_to_ptrs, reference/components/format_conversion.hpp)
-template <typename I>
+template <typename I, typename P = I>
 __global__ __launch_bounds__(256) void idxs_to_ptrs_kernel(
     int64_t num_idxs, const I* __restrict__ idxs, int64_t n,
-    I* __restrict__ ptrs)
+    P* __restrict__ ptrs)
 {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (i > num_idxs) return;
     const int64_t lo = i == 0 ? 0 : int64_t(idxs[i - 1]) + 1;
     const int64_t hi = i == num_idxs ? n : int64_t(idxs[i]);
-    for (int64_t r = lo; r <= hi && r <= n; ++r) ptrs[r] = I(i);
+    for (int64_t r = lo; r <= hi && r <= n; ++r) ptrs[r] = P(i);
 }
 
 template <typename I>
@@ -709,6 +709,49 @@ GKOC_DEF_FMT(float, f32, int64_t, i64)
 
 GKOC_DEF_IDX(int32_t, i32)
 GKOC_DEF_IDX(int64_t, i64)
+
+// 64-bit row pointers (device_matrix_data readers) narrowed for matrices with 32-bit indices
+__global__ __launch_bounds__(256) void narrow_i64_kernel(int64_t n, const int64_t* __restrict__ in,
+                                                         int32_t* __restrict__ out)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+        out[i] = int32_t(in[i]);
+    }
+}
+
+extern "C" int gkoc_narrow_i64_to_i32(gkoc_stream_t s, int64_t n, const int64_t* in, int32_t* out)
+{
+    if (n <= 0) return GKOC_OK;
+    GKOC_REQUIRE(in && out, GKOC_E_INVALID, "null pointer");
+    int64_t nb = ceildiv(n, 256);
+    if (nb > max_stream_blocks) nb = max_stream_blocks;
+    narrow_i64_kernel<<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(n, in, out);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+// row pointers of another width than the indices (Ell / Sellp / Hybrid read their
+// device_matrix_data with 64-bit row pointers: GKO_DECLARE_CONVERT_IDXS_TO_PTRS64)
+extern "C" int gkoc_convert_idxs_to_ptrs_i32_i64(gkoc_stream_t s, int64_t num_idxs,
+                                                 const int32_t* idxs, int64_t n, int64_t* ptrs)
+{
+    GKOC_REQUIRE(num_idxs >= 0 && n >= 0, GKOC_E_INVALID, "negative size");
+    idxs_to_ptrs_kernel<int32_t, int64_t>
+        <<<dim3(blocks_for(num_idxs + 1)), dim3(256), 0, as_stream(s)>>>(num_idxs, idxs, n, ptrs);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+extern "C" int gkoc_convert_idxs_to_ptrs_i64_i32(gkoc_stream_t s, int64_t num_idxs,
+                                                 const int64_t* idxs, int64_t n, int32_t* ptrs)
+{
+    GKOC_REQUIRE(num_idxs >= 0 && n >= 0, GKOC_E_INVALID, "negative size");
+    idxs_to_ptrs_kernel<int64_t, int32_t>
+        <<<dim3(blocks_for(num_idxs + 1)), dim3(256), 0, as_stream(s)>>>(num_idxs, idxs, n, ptrs);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
 
 extern "C" int gkoc_prefix_sum_nonnegative_checked_u64(gkoc_stream_t s, uint64_t* counts,
                                                        int64_t n)

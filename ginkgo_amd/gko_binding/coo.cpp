@@ -3,6 +3,7 @@
 // components::convert_ptrs_to_idxs forwarded to the C ABI (csrc/coo.hip).
 // With these, Ginkgo's own Coo and Hybrid (Ell + Coo) matrices apply on this
 // backend, and Csr -> Coo / Hybrid conversions run on the device.
+#include <ginkgo/core/base/device_matrix_data.hpp>
 #include <ginkgo/core/matrix/coo.hpp>
 #include <ginkgo/core/matrix/csr.hpp>
 #include <ginkgo/core/matrix/ell.hpp>
@@ -126,6 +127,42 @@ void compute_coo_row_ptrs(exec_t exec, const array<size_type>& row_nnz, size_typ
         stream_of(exec), static_cast<int64_t>(row_nnz.get_size()),
         reinterpret_cast<const uint64_t*>(row_nnz.get_const_data()), ell_lim, coo_row_ptrs));
 }
+
+void compute_row_nnz(exec_t exec, const array<int64>& row_ptrs, size_type* row_nnzs)
+{
+    GKOC_CALL(gkoc_convert_ptrs_to_sizes_i64(
+        stream_of(exec), static_cast<int64_t>(row_ptrs.get_size()) - 1, row_ptrs.get_const_data(),
+        reinterpret_cast<uint64_t*>(row_nnzs)));
+}
+
+#define DEF(T, TN, I, IN)                                                                 \
+    template <>                                                                           \
+    void fill_in_matrix_data<T, I>(exec_t exec, const device_matrix_data<T, I>& data,     \
+                                   const int64* row_ptrs, const int64* coo_row_ptrs,      \
+                                   matrix::Hybrid<T, I>* result)                          \
+    {                                                                                     \
+        const auto n = result->get_size()[0];                                             \
+        array<I> narrowed(exec);                                                          \
+        const I* ptrs = nullptr;                                                          \
+        if (sizeof(I) == sizeof(int64)) {                                                 \
+            ptrs = reinterpret_cast<const I*>(row_ptrs);                                  \
+        } else {                                                                          \
+            narrowed.resize_and_reset(n + 1);                                             \
+            GKOC_CALL(gkoc_narrow_i64_to_i32(stream_of(exec), static_cast<int64_t>(n + 1), \
+                                             row_ptrs,                                    \
+                                             reinterpret_cast<int32_t*>(narrowed.get_data()))); \
+            ptrs = narrowed.get_const_data();                                             \
+        }                                                                                 \
+        GKOC_CALL(gkoc_csr_convert_to_hybrid_##TN##_##IN(                                 \
+            stream_of(exec), n, ptrs, data.get_const_col_idxs(), data.get_const_values(), \
+            result->get_ell_num_stored_elements_per_row(), result->get_ell_stride(),      \
+            result->get_ell_col_idxs(), result->get_ell_values(), coo_row_ptrs,           \
+            result->get_coo_row_idxs(), result->get_coo_col_idxs(),                       \
+            result->get_coo_values()));                                                   \
+        exec->synchronize();                                                              \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
 
 }  // namespace hybrid
 

@@ -49,6 +49,31 @@ using exec_t = std::shared_ptr<const HipExecutor>;
 #define FOR_IT(M) M(int32, i32) M(int64, i64)
 
 
+// Ell / Sellp / Hybrid::read(device_matrix_data) hand over 64-bit row pointers; the
+// converters take the matrix' own index type: narrowed into a temporary for int32 matrices
+template <typename I>
+struct ptrs_as {
+    ptrs_as(exec_t exec, const int64* ptrs, size_type n);
+    const I* get() const;
+};
+template <>
+struct ptrs_as<int64> {
+    ptrs_as(exec_t, const int64* ptrs, size_type) : p_{ptrs} {}
+    const int64* get() const { return p_; }
+    const int64* p_;
+};
+template <>
+struct ptrs_as<int32> {
+    ptrs_as(exec_t exec, const int64* ptrs, size_type n) : tmp_{exec, n}
+    {
+        GKOC_CALL(gkoc_narrow_i64_to_i32(stream_of(exec), static_cast<int64_t>(n), ptrs,
+                                         tmp_.get_data()));
+    }
+    const int32* get() const { return tmp_.get_const_data(); }
+    array<int32> tmp_;
+};
+
+
 // ===================================================================== csr
 namespace csr {
 
@@ -177,6 +202,25 @@ FOR_VT_IT(DEF)
 FOR_IT(DEF)
 #undef DEF
 
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void fill_in_matrix_data<T, I>(exec_t exec,                                 \
+                                   const device_matrix_data<T, I>& data,        \
+                                   const int64* row_ptrs,                       \
+                                   matrix::Ell<T, I>* output)                   \
+    {                                                                           \
+        const auto n = output->get_size()[0];                                   \
+        ptrs_as<I> ptrs(exec, row_ptrs, n + 1);                                 \
+        GKOC_CALL(gkoc_csr_convert_to_ell_##TN##_##IN(                          \
+            stream_of(exec), n, ptrs.get(), data.get_const_col_idxs(),          \
+            data.get_const_values(),                                            \
+            output->get_num_stored_elements_per_row(), output->get_stride(),    \
+            output->get_col_idxs(), output->get_values()));                     \
+        exec->synchronize(); /* the temporary row pointers die here */          \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
 }  // namespace ell
 
 
@@ -229,6 +273,25 @@ FOR_VT_IT(DEF)
 FOR_IT(DEF)
 #undef DEF
 
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void fill_in_matrix_data<T, I>(exec_t exec,                                 \
+                                   const device_matrix_data<T, I>& data,        \
+                                   const int64* row_ptrs,                       \
+                                   matrix::Sellp<T, I>* output)                 \
+    {                                                                           \
+        const auto n = output->get_size()[0];                                   \
+        ptrs_as<I> ptrs(exec, row_ptrs, n + 1);                                 \
+        GKOC_CALL(gkoc_csr_convert_to_sellp_##TN##_##IN(                        \
+            stream_of(exec), n, output->get_slice_size(), ptrs.get(),           \
+            data.get_const_col_idxs(), data.get_const_values(),                 \
+            reinterpret_cast<const uint64_t*>(output->get_const_slice_sets()),  \
+            output->get_col_idxs(), output->get_values()));                     \
+        exec->synchronize();                                                    \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
 }  // namespace sellp
 
 
@@ -258,6 +321,23 @@ inline void* scratch(array<char>& tmp, int64_t n, int64_t nrhs, size_t& bytes)
                                        cols(input), input->get_const_values(),  \
                                        ld(input), output->get_values(),         \
                                        ld(output)));                            \
+    }                                                                           \
+    template <>                                                                 \
+    void inplace_absolute_dense<T>(exec_t exec, matrix::Dense<T>* source)       \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_absolute_##TN(                                     \
+            stream_of(exec), rows(source), cols(source),                        \
+            source->get_const_values(), ld(source), source->get_values(),       \
+            ld(source)));                                                       \
+    }                                                                           \
+    template <>                                                                 \
+    void outplace_absolute_dense<T>(exec_t exec, const matrix::Dense<T>* source, \
+                                    matrix::Dense<T>* result)                   \
+    {                                                                           \
+        GKOC_CALL(gkoc_dense_absolute_##TN(                                     \
+            stream_of(exec), rows(source), cols(source),                        \
+            source->get_const_values(), ld(source), result->get_values(),       \
+            ld(result)));                                                       \
     }                                                                           \
     template <>                                                                 \
     void simple_apply<T>(exec_t exec, const matrix::Dense<T>* a,                \
@@ -989,6 +1069,19 @@ void convert_idxs_to_ptrs<int64, int64>(exec_t exec, const int64* idxs,
 {
     GKOC_CALL(gkoc_convert_idxs_to_ptrs_i64(stream_of(exec), num_idxs, idxs,
                                             num_blocks, ptrs));
+}
+
+template <>
+void convert_idxs_to_ptrs<int32, int64>(exec_t exec, const int32* idxs, size_type num_idxs,
+                                        size_type num_blocks, int64* ptrs)
+{
+    GKOC_CALL(gkoc_convert_idxs_to_ptrs_i32_i64(stream_of(exec), num_idxs, idxs, num_blocks, ptrs));
+}
+template <>
+void convert_idxs_to_ptrs<int64, int32>(exec_t exec, const int64* idxs, size_type num_idxs,
+                                        size_type num_blocks, int32* ptrs)
+{
+    GKOC_CALL(gkoc_convert_idxs_to_ptrs_i64_i32(stream_of(exec), num_idxs, idxs, num_blocks, ptrs));
 }
 
 #define DEF(T, TN, I, IN)                                                       \

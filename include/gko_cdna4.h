@@ -364,6 +364,15 @@ int gkoc_prefix_sum_nonnegative_u64(gkoc_stream_t s, uint64_t* counts,
                                     int64_t n);
 int gkoc_prefix_sum_nonnegative_checked_u64(gkoc_stream_t s, uint64_t* counts,
                                             int64_t n);
+/* out[i] = (int32) in[i]: the 64-bit row pointers Ell / Sellp / Hybrid::read compute for
+ * device_matrix_data, narrowed for the converters of matrices with 32-bit indices */
+int gkoc_narrow_i64_to_i32(gkoc_stream_t s, int64_t n, const int64_t* in, int32_t* out);
+/* convert_idxs_to_ptrs with row pointers of the other width
+ * (core/components/format_conversion_kernels.hpp:31-38) */
+int gkoc_convert_idxs_to_ptrs_i32_i64(gkoc_stream_t s, int64_t num_idxs,
+                                      const int32_t* idxs, int64_t n, int64_t* ptrs);
+int gkoc_convert_idxs_to_ptrs_i64_i32(gkoc_stream_t s, int64_t num_idxs,
+                                      const int64_t* idxs, int64_t n, int32_t* ptrs);
 
 /* --------------------------------------------- Dense x Dense, precision conversion
  * dense::simple_apply / apply (core/matrix/dense_kernels.hpp:23-32, reference/matrix/
@@ -404,6 +413,9 @@ size_t gkoc_reduction_workspace_bytes(int64_t n_rows, int64_t nrhs,
                              T* x, int64_t ldx, T value);                      \
     int gkoc_dense_copy_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,      \
                              const T* x, int64_t ldx, T* y, int64_t ldy);      \
+    /* y = |x| (dense::outplace_absolute_dense; x == y: inplace_absolute_dense) */ \
+    int gkoc_dense_absolute_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,  \
+                                 const T* x, int64_t ldx, T* y, int64_t ldy);  \
     int gkoc_dense_scale_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,     \
                               const T* alpha, int64_t alpha_cols, T* x,        \
                               int64_t ldx);                                    \
