@@ -519,6 +519,41 @@ size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrhs,
 GKOC_DECL_GMRES(double, f64)
 GKOC_DECL_GMRES(float, f32)
 
+/* ---------------------------------------------------------------- IDR(s)
+ * idr::{initialize, step_1, step_2, step_3, compute_omega}  core/solver/idr_kernels.hpp:22-72,
+ * reference/solver/idr_kernels.cpp:27-290 (driver core/solver/idr.cpp:150-300).  Row-major, row
+ * strides ld*: p = subspace_vectors s x n (P^H), m  s x (s nrhs), f / c  s x nrhs,
+ * g / u  n x (s nrhs), g_k / v / residual / x  n x nrhs.  Updates in the reference's term order;
+ * the dots <p_j, g_k> use a fixed two-level tree.  deterministic == 0: shadow vectors drawn on the
+ * host from N(0,1) with a random seed, like the reference. */
+#define GKOC_DECL_IDR(T, TN)                                                    \
+    int gkoc_idr_initialize_##TN(gkoc_stream_t s, int64_t nrhs,                 \
+                                 int64_t subspace_dim, T* m, int64_t ldm,       \
+                                 int64_t n, T* subspace_vectors, int64_t ldp,   \
+                                 int deterministic, uint8_t* stop_status);      \
+    int gkoc_idr_step_1_##TN(gkoc_stream_t s, int64_t n, int64_t nrhs,          \
+                             int64_t subspace_dim, int64_t k, const T* m,       \
+                             int64_t ldm, const T* f, int64_t ldf,              \
+                             const T* residual, int64_t ldr, const T* g,        \
+                             int64_t ldg, T* c, int64_t ldc, T* v, int64_t ldv, \
+                             const uint8_t* stop_status);                       \
+    int gkoc_idr_step_2_##TN(gkoc_stream_t s, int64_t n, int64_t nrhs,          \
+                             int64_t subspace_dim, int64_t k, const T* omega,   \
+                             const T* preconditioned_vector, int64_t ldpv,      \
+                             const T* c, int64_t ldc, T* u, int64_t ldu,        \
+                             const uint8_t* stop_status);                       \
+    int gkoc_idr_step_3_##TN(gkoc_stream_t s, int64_t n, int64_t nrhs,          \
+                             int64_t subspace_dim, int64_t k, const T* p,       \
+                             int64_t ldp, T* g, int64_t ldg, T* g_k,            \
+                             int64_t ldgk, T* u, int64_t ldu, T* m, int64_t ldm, \
+                             T* f, int64_t ldf, T* residual, int64_t ldr, T* x, \
+                             int64_t ldx, const uint8_t* stop_status);          \
+    int gkoc_idr_compute_omega_##TN(gkoc_stream_t s, int64_t nrhs, T kappa,     \
+                                    const T* tht, const T* residual_norm,       \
+                                    T* omega, const uint8_t* stop_status);
+GKOC_DECL_IDR(double, f64)
+GKOC_DECL_IDR(float, f32)
+
 /* ------------------------------------------------------- stopping criteria
  * residual_norm::residual_norm, implicit_residual_norm::implicit_residual_norm,
  * set_all_statuses  (core/stop/residual_norm_kernels.hpp,
