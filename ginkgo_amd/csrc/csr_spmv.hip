@@ -102,7 +102,34 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     // XCD-contiguous wave order needs enough waves per XCD to keep the in-order
     // window argument valid; below that the plain order is used
     const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
-    if (vec_ok) {
+    // Long rows: the ring holds only a few rows at a time (1024 / 81 = 12 for the 81-nonzero
+    // rows of a 3-dof 27-point problem), so each hand-over to the row phase keeps only that many
+    // lanes busy for a whole row length.  Bigger rings (16 / 32 KB per wave, fewer resident
+    // waves, more loads in flight per wave) cut the number of hand-overs.  Chosen with
+    // GKOC_TUNE_CSR_RING; results are bit-identical for every value.
+    const int ring_variant = vec_ok ? int(tune_value(GKOC_TUNE_CSR_RING)) : 0;
+#define GKOC_LAUNCH_PIPE3R(U_, RMUL_, MODE_)                                         \
+    csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, EV, U_, RINGV * RMUL_, 1, MODE_>  \
+        <<<grid, block, 0, as_stream(s)>>>(                                          \
+            n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,  \
+            static_cast<int>(nrhs), alpha, beta, nullptr, xcd_map)
+#define GKOC_LAUNCH_RING_VARIANT(U_, RMUL_)           \
+    do {                                              \
+        if (segs_per_wave == 2) {                     \
+            GKOC_LAUNCH_PIPE3R(U_, RMUL_, 0x2000);    \
+        } else {                                      \
+            GKOC_LAUNCH_PIPE3R(U_, RMUL_, 0x1000);    \
+        }                                             \
+    } while (0)
+    if (ring_variant == 1) {
+        GKOC_LAUNCH_RING_VARIANT(2, 2);
+    } else if (ring_variant == 2) {
+        GKOC_LAUNCH_RING_VARIANT(2, 4);
+    } else if (ring_variant == 3) {
+        GKOC_LAUNCH_RING_VARIANT(4, 4);
+    } else if (ring_variant == 4) {
+        GKOC_LAUNCH_RING_VARIANT(1, 2);
+    } else if (vec_ok) {
         if (segs_per_wave == 2) {
             GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);
         } else {
@@ -116,6 +143,8 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         }
     }
 #undef GKOC_LAUNCH_PIPE3
+#undef GKOC_LAUNCH_PIPE3R
+#undef GKOC_LAUNCH_RING_VARIANT
     GKOC_LAUNCH_OK();
     return GKOC_OK;
 }

@@ -122,6 +122,8 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
  * depend on them. */
 #define GKOC_TUNE_CSR_XCD_MAP 0    /* 1: each XCD walks one contiguous eighth of the rows (default 0) */
 #define GKOC_TUNE_JACOBI_XCD_MAP 1 /* same for the block-Jacobi apply                     */
+#define GKOC_TUNE_CSR_RING 2       /* CSR SpMV product ring per wave: 0 = 8 KB (default), 1 = 16 KB / 2 load
+                                      groups, 2 = 32 KB / 2, 3 = 32 KB / 4, 4 = 16 KB / 1 (long rows) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,
@@ -553,6 +555,49 @@ GKOC_DECL_GMRES(float, f32)
                                     T* omega, const uint8_t* stop_status);
 GKOC_DECL_IDR(double, f64)
 GKOC_DECL_IDR(float, f32)
+
+/* ------------------------------------------------------------- CB-GMRES
+ * cb_gmres::{restart, arnoldi, solve_krylov}  core/solver/cb_gmres_kernels.hpp:101-142,
+ * reference/solver/cb_gmres_kernels.cpp:31-420 (driver core/solver/cb_gmres.cpp:205-480);
+ * cb_gmres::initialize is gkoc_common_gmres_initialize.  The Krylov basis is the 3-d accessor range
+ * (krylov_dim+1) x rows x nrhs of accessor/reduced_row_major.hpp / scaled_reduced_row_major.hpp:
+ * element (k, r, c) at bases[k*st0 + r*st1 + c] in the storage type named by storage_kind,
+ * GKOC_CB_KEEP (= value type), GKOC_CB_F32 (f64 only), GKOC_CB_F16 (gko::half), or an integer type
+ * GKOC_CB_I64 (f64 only) / I32 / I16 times scalars[k*sst + c] (value = storage * scalar, storage =
+ * trunc(value / scalar)).  arnoldi_norm is 3 x nrhs (row 0: eta * old norm, 1: norm, 2: inf-norm).
+ * arnoldi runs classical Gram-Schmidt with up to two re-orthogonalisation rounds; the decision is
+ * taken on the device per column (no host synchronisation); buffer_iter may be NULL. */
+#define GKOC_CB_KEEP 0
+#define GKOC_CB_F32 1
+#define GKOC_CB_F16 2
+#define GKOC_CB_I64 3
+#define GKOC_CB_I32 4
+#define GKOC_CB_I16 5
+#define GKOC_DECL_CB_GMRES(T, TN)                                                \
+    int gkoc_cb_gmres_restart_##TN(                                              \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t krylov_dim,         \
+        const T* residual, int64_t ldr, T* residual_norm,                        \
+        T* residual_norm_collection, int64_t ld_rnc, T* arnoldi_norm,            \
+        int64_t ld_an, int storage_kind, void* bases, int64_t st0, int64_t st1,  \
+        T* scalars, int64_t sst, T* next_krylov, int64_t ldn,                    \
+        uint64_t* final_iter_nums);                                              \
+    int gkoc_cb_gmres_arnoldi_##TN(                                              \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t iter,               \
+        T* next_krylov, int64_t ldn, T* givens_sin, int64_t ld_sin,              \
+        T* givens_cos, int64_t ld_cos, T* residual_norm,                         \
+        T* residual_norm_collection, int64_t ld_rnc, int storage_kind,           \
+        void* bases, int64_t st0, int64_t st1, T* scalars, int64_t sst,          \
+        T* hessenberg_iter, int64_t ld_h, T* buffer_iter, int64_t ld_buf,        \
+        T* arnoldi_norm, int64_t ld_an, uint64_t* final_iter_nums,               \
+        const uint8_t* stop_status);                                             \
+    int gkoc_cb_gmres_solve_krylov_##TN(                                         \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs,                             \
+        const T* residual_norm_collection, int64_t ld_rnc, int storage_kind,     \
+        const void* bases, int64_t st0, int64_t st1, const T* scalars,           \
+        int64_t sst, const T* hessenberg, int64_t ld_h, T* y, int64_t ldy,       \
+        T* before_preconditioner, int64_t ldo, const uint64_t* final_iter_nums);
+GKOC_DECL_CB_GMRES(double, f64)
+GKOC_DECL_CB_GMRES(float, f32)
 
 /* ------------------------------------------------------- stopping criteria
  * residual_norm::residual_norm, implicit_residual_norm::implicit_residual_norm,

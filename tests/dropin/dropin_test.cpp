@@ -25,6 +25,7 @@
 #include <ginkgo/core/preconditioner/jacobi.hpp>
 #include <ginkgo/core/solver/bicg.hpp>
 #include <ginkgo/core/solver/bicgstab.hpp>
+#include <ginkgo/core/solver/cb_gmres.hpp>
 #include <ginkgo/core/solver/cg.hpp>
 #include <ginkgo/core/solver/cgs.hpp>
 #include <ginkgo/core/solver/chebyshev.hpp>
@@ -244,6 +245,59 @@ int main(int argc, char** argv)
         std::cout << "GMRES(30)+Jacobi(8): iterations reference " << it_ref << ", hip " << it_hip << std::endl;
         CHECK(std::abs(it_ref - it_hip) <= 1, "GMRES iteration count matches reference");
         CHECK(rel_err(x_hip2.get(), x_ref2.get()) < 1e-8, "GMRES solution matches reference");
+    }
+
+    // --- Ginkgo's own CbGmres (compressed Krylov basis) on this backend, every storage precision
+    {
+        using gko::solver::cb_gmres::storage_precision;
+        auto cb = [&](auto exec, auto a, storage_precision prec, int& iters) {
+            auto rhs = Dense::create(exec, gko::dim<2>{n, 1});
+            rhs->fill(1.0);
+            auto x = Dense::create(exec, gko::dim<2>{n, 1});
+            x->fill(0.0);
+            auto logger = gko::share(gko::log::Convergence<vt>::create());
+            auto solver =
+                gko::solver::CbGmres<vt>::build()
+                    .with_krylov_dim(30u)
+                    .with_storage_precision(prec)
+                    .with_criteria(gko::stop::Iteration::build().with_max_iters(500u),
+                                   gko::stop::ResidualNorm<vt>::build().with_reduction_factor(1e-10))
+                    .with_preconditioner(
+                        gko::preconditioner::Jacobi<vt, it>::build().with_max_block_size(8u))
+                    .on(exec)
+                    ->generate(a);
+            solver->add_logger(logger);
+            solver->apply(rhs, x);
+            iters = static_cast<int>(logger->get_num_iterations());
+            return gko::clone(exec->get_master(), x);
+        };
+        const char* names[] = {"keep", "reduce1", "reduce2", "integer", "ireduce1", "ireduce2"};
+        int idx = 0;
+        for (auto prec : {storage_precision::keep, storage_precision::reduce1, storage_precision::reduce2,
+                          storage_precision::integer, storage_precision::ireduce1,
+                          storage_precision::ireduce2}) {
+            int it_ref = 0, it_hip = 0;
+            auto x_ref = cb(ref, a_ref, prec, it_ref);
+            auto x_hip = cb(hip, a_hip, prec, it_hip);
+            // true residual of the device solution on the reference executor
+            auto r = Dense::create(ref, gko::dim<2>{n, 1});
+            r->fill(1.0);
+            auto one = gko::initialize<Dense>({1.0}, ref);
+            auto neg = gko::initialize<Dense>({-1.0}, ref);
+            a_ref->apply(neg, x_hip, one, r);
+            auto nrm = gko::matrix::Dense<vt>::create(ref, gko::dim<2>{1, 1});
+            r->compute_norm2(nrm);
+            const double res = nrm->at(0, 0) / std::sqrt(double(n));
+            std::cout << "CbGmres(30, " << names[idx] << ")+Jacobi(8): iterations reference " << it_ref
+                      << ", hip " << it_hip << ", relative residual " << res << ", x vs reference "
+                      << rel_err(x_hip.get(), x_ref.get()) << std::endl;
+            // the compressed basis makes the iteration count sensitive to rounding: allow 10 %
+            CHECK(std::abs(it_ref - it_hip) <= std::max(2, it_ref / 10),
+                  "CbGmres iteration count close to the reference's");
+            CHECK(res < 1e-8, "CbGmres reaches the residual reduction on hip");
+            CHECK(rel_err(x_hip.get(), x_ref.get()) < 1e-7, "CbGmres solution matches reference");
+            ++idx;
+        }
     }
 
     // --- Ginkgo's block-Jacobi with a fixed reduced storage precision
