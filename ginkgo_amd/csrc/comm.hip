@@ -112,7 +112,11 @@ struct gkoc_comm_s {
     int n_ranks = 0, rank = 0;
     hipEvent_t packed = nullptr;   // main -> side: the send buffer is ready
     hipEvent_t arrived = nullptr;  // side -> main: the halo is in recv_buf
+    hipEvent_t reduce_in = nullptr;   // main -> side: the values to reduce are written
+    hipEvent_t reduce_out = nullptr;  // side -> main: the reduced values are there
     bool pending_side = false;
+    bool pending_reduce = false;
+    hipStream_t side_in_use = nullptr;  // the stream that carries the pending operations
 };
 
 using namespace gkoc;
@@ -149,7 +153,9 @@ int gkoc_comm_create(gkoc_comm_t* comm, int n_ranks, int rank, const void* id)
         return rccl_fail(e, "ncclCommInitRank", __LINE__);
     }
     if (hipEventCreateWithFlags(&c->packed, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->arrived, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->arrived, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->reduce_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->reduce_out, hipEventDisableTiming) != hipSuccess) {
         g_rccl.CommDestroy(c->comm);
         delete c;
         set_last_error("gkoc_comm_create: hipEventCreate failed");
@@ -164,6 +170,8 @@ int gkoc_comm_destroy(gkoc_comm_t comm)
     if (!comm) return GKOC_OK;
     if (comm->packed) (void)hipEventDestroy(comm->packed);
     if (comm->arrived) (void)hipEventDestroy(comm->arrived);
+    if (comm->reduce_in) (void)hipEventDestroy(comm->reduce_in);
+    if (comm->reduce_out) (void)hipEventDestroy(comm->reduce_out);
     int e = comm->comm ? g_rccl.CommDestroy(comm->comm) : nccl_success;
     delete comm;
     if (e != nccl_success) return rccl_fail(e, "ncclCommDestroy", __LINE__);
@@ -184,9 +192,54 @@ int gkoc_comm_all_reduce_sum(gkoc_comm_t comm, gkoc_stream_t s, void* buf, int64
     GKOC_REQUIRE(comm && buf && n >= 0, GKOC_E_INVALID, "bad argument");
     GKOC_REQUIRE(value_size == 8 || value_size == 4, GKOC_E_NOT_SUPPORTED, "value_size must be 4 or 8");
     if (n == 0) return GKOC_OK;
+    // One communicator, one order of operations on every rank: while an overlapped operation is
+    // pending on the side stream, a collective on ANOTHER stream would reach RCCL in an order
+    // that depends on timing (a hang, not a wrong number) - refuse it.
+    GKOC_REQUIRE(!(comm->pending_side || comm->pending_reduce) || as_stream(s) == comm->side_in_use,
+                 GKOC_E_INVALID,
+                 "gkoc_comm_all_reduce_sum on another stream while an overlapped exchange / "
+                 "all-reduce is pending (end it first)");
     GKOC_RCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n),
                                value_size == 8 ? nccl_float64 : nccl_float32, nccl_sum, comm->comm,
                                as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_comm_all_reduce_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_stream_t side,
+                               void* buf, int64_t n, size_t value_size)
+{
+    GKOC_REQUIRE(comm && buf && n >= 0, GKOC_E_INVALID, "bad argument");
+    GKOC_REQUIRE(value_size == 8 || value_size == 4, GKOC_E_NOT_SUPPORTED, "value_size must be 4 or 8");
+    GKOC_REQUIRE(!comm->pending_reduce, GKOC_E_INVALID,
+                 "gkoc_comm_all_reduce_begin: previous all-reduce not ended");
+    if (n == 0) return GKOC_OK;
+    hipStream_t ms = as_stream(main_stream);
+    const bool overlapped = side != nullptr && side != main_stream;
+    hipStream_t xs = overlapped ? as_stream(side) : ms;
+    GKOC_REQUIRE(!comm->pending_side || xs == comm->side_in_use, GKOC_E_INVALID,
+                 "gkoc_comm_all_reduce_begin: an exchange is pending on another stream");
+    if (overlapped) {
+        GKOC_HIP(hipEventRecord(comm->reduce_in, ms));
+        GKOC_HIP(hipStreamWaitEvent(xs, comm->reduce_in, 0));
+    }
+    GKOC_RCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n),
+                               value_size == 8 ? nccl_float64 : nccl_float32, nccl_sum, comm->comm,
+                               xs));
+    if (overlapped) {
+        GKOC_HIP(hipEventRecord(comm->reduce_out, xs));
+        comm->pending_reduce = true;
+        comm->side_in_use = xs;
+    }
+    return GKOC_OK;
+}
+
+int gkoc_comm_all_reduce_end(gkoc_comm_t comm, gkoc_stream_t main_stream)
+{
+    GKOC_REQUIRE(comm, GKOC_E_INVALID, "comm == NULL");
+    if (comm->pending_reduce) {
+        GKOC_HIP(hipStreamWaitEvent(as_stream(main_stream), comm->reduce_out, 0));
+        comm->pending_reduce = false;
+    }
     return GKOC_OK;
 }
 
@@ -210,6 +263,8 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
     }
     if (n_msgs == 0) return GKOC_OK;
     GKOC_REQUIRE(send_buf && recv_buf, GKOC_E_INVALID, "NULL buffer with non-zero counts");
+    GKOC_REQUIRE(!comm->pending_reduce || xs == comm->side_in_use, GKOC_E_INVALID,
+                 "gkoc_comm_exchange_begin: an all-reduce is pending on another stream");
     if (overlapped) {
         GKOC_HIP(hipEventRecord(comm->packed, ms));
         GKOC_HIP(hipStreamWaitEvent(xs, comm->packed, 0));
@@ -236,6 +291,7 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
     if (overlapped) {
         GKOC_HIP(hipEventRecord(comm->arrived, xs));
         comm->pending_side = true;
+        comm->side_in_use = xs;
     }
     return GKOC_OK;
 }

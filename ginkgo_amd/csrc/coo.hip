@@ -11,9 +11,9 @@
 // is the CSR row sum of the same entries started from c0 - exactly what
 // csr::advanced_spmv computes (sum = beta*c, then += (alpha*val)*b in k order), and
 // multiplying by a literal 1 is exact.  So:
-//   pass 1: row_idxs -> row lengths -> (scan) row_ptrs in the workspace: one read of
-//           row_idxs, 4 B/nnz; the same kernel notes whether the rows really are
-//           non-decreasing;
+//   pass 1: row_idxs -> row_ptrs in the workspace, one kernel: one read of row_idxs
+//           (4 B/nnz), every pointer written once by the entry that starts its run; the
+//           same kernel notes whether the rows really are non-decreasing;
 //   pass 2: the production CSR kernel (12 B/nnz) with (alpha, beta) in
 //           {(-, -), (alpha, beta), (1, 1), (alpha, 1)}.
 // 16 B/nnz in total - the algorithmic traffic of COO - no atomics, results
@@ -36,7 +36,7 @@ inline unsigned grid_for(int64_t n, int cap = 4 * max_stream_blocks)
 }
 
 // workspace: [row_ptrs (n_rows + 1) of I | pad to 16 | flag int32, pad | one T, pad |
-//             run ends (n_rows + 1) of I | pad | scratch of the scan]
+//             reserve of the same size (earlier versions kept run ends and scan partials)]
 inline size_t coo_ptr_bytes(int64_t n_rows, size_t index_size)
 {
     return (size_t(n_rows + 1) * index_size + 15) / 16 * 16;
@@ -75,34 +75,38 @@ __global__ void coo_init_kernel(int* flag, T* one)
     *one = T(1);
 }
 
-// Row lengths of a row-sorted COO without touching the gaps between rows: the entry
-// that starts a run of equal row indices stores its position in start[row], the entry
-// that ends it stores position + 1 in end[row] (plain stores, one pair per NON-EMPTY
-// row, nothing for empty rows - a COO part with a few long rows, as in a Hybrid, costs
-// nothing extra; device-scope atomics on one counter array were measured 2.7x slower:
-// 1.0 ms for the 449 M entries of L256).  end - start = row length; an exclusive scan
-// of the lengths gives row_ptrs.  flag = 1 if a row index is smaller than its
-// predecessor or out of range.  Four entries per thread.
+// Row pointers of a row-sorted COO in ONE pass over row_idxs, no scan and no clearing pass:
+// the entry k that starts a run of equal row indices knows the pointer of its own row and
+// of every empty row in front of it,
+//     row_ptrs[r] = k   for  row_idxs[k-1] < r <= row_idxs[k],
+// the first entry additionally covers rows 0 .. row_idxs[0] and the last one the rows behind
+// row_idxs[nnz-1] (pointer nnz).  Every pointer is written exactly once (plain stores, no
+// atomics - device-scope atomics on a counter array were measured 2.7x slower).  Gaps of up
+// to 8 empty rows are filled by the lane that found them, longer ones by the whole wave (a
+// COO part with a few long rows, as in a Hybrid, has one long gap per stored row).  flag = 1
+// if a row index is smaller than its predecessor or out of range (the pointers are then
+// cleared and the atomic fallback adds the products).  Four entries per thread: one 16-byte
+// (int32) / 32-byte (int64) load per lane, the neighbours' boundary entries come through
+// wave shuffles (six scalar loads per lane, 16 bytes apart, kept the pipeline at 2 TB/s).
 template <typename I>
 struct alignas(16) idx4 {
     I v[4];
 };
 
-// One 16-byte (int32) / 32-byte (int64) load per lane for its four entries; the
-// neighbours' boundary entries come through wave shuffles (six scalar loads per lane,
-// 16 bytes apart, kept the memory pipeline at 2 TB/s).
 template <typename I>
-__global__ __launch_bounds__(256) void coo_row_runs_kernel(
-    int64_t nnz, const I* __restrict__ rows, int64_t n_rows, I* __restrict__ start,
-    I* __restrict__ end, int* __restrict__ flag)
+__global__ __launch_bounds__(256) void coo_row_ptrs_kernel(int64_t nnz,
+                                                           const I* __restrict__ rows,
+                                                           int64_t n_rows, I* __restrict__ ptrs,
+                                                           int* __restrict__ flag)
 {
+    constexpr int64_t inline_gap = 8;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t(blockIdx.x) * 256 + threadIdx.x) >> 6;
     const int64_t n_waves = (int64_t(gridDim.x) * 256) >> 6;
     const bool aligned = reinterpret_cast<uintptr_t>(rows) % 16 == 0;
     for (int64_t base = wave * 256; base < nnz; base += n_waves * 256) {
         const int64_t i0 = base + lane * 4;
-        int64_t r[6];
+        int64_t r[5];
         if (aligned && i0 + 4 <= nnz) {
             const idx4<I> q = *reinterpret_cast<const idx4<I>*>(rows + i0);
 #pragma unroll
@@ -112,35 +116,56 @@ __global__ __launch_bounds__(256) void coo_row_runs_kernel(
             for (int e = 0; e < 4; ++e) r[e + 1] = i0 + e < nnz ? int64_t(rows[i0 + e]) : -2;
         }
         int64_t prev = __shfl_up(r[4], 1, 64);
-        int64_t next = __shfl_down(r[1], 1, 64);
         if (lane == 0) prev = base > 0 ? int64_t(rows[base - 1]) : -1;
-        if (lane == 63) next = base + 256 < nnz ? int64_t(rows[base + 256]) : -2;
         r[0] = prev;
-        r[5] = next;
         bool bad = false;
+        // the (at most one per entry) range of pointers this lane has to write: (lo, hi] <- val;
+        // long ranges are kept for the wave
+        int64_t big_lo = 0, big_hi = -1, big_val = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t i = i0 + e;
             if (i >= nnz) break;
-            const int64_t cur = r[e + 1], pv = r[e], nx = r[e + 2];
+            const int64_t cur = r[e + 1], pv = r[e];
             if (cur < 0 || cur >= n_rows || (i > 0 && cur < pv)) {
                 bad = true;
                 continue;
             }
-            if (i == 0 || cur != pv) start[cur] = I(i);
-            if (i == nnz - 1 || cur != nx) end[cur] = I(i + 1);
+            if (i == 0 || cur != pv) {
+                const int64_t lo = i == 0 ? -1 : pv;
+                if (cur - lo <= inline_gap || big_hi >= big_lo + 1) {
+                    for (int64_t t = lo + 1; t <= cur; ++t) ptrs[t] = I(i);
+                } else {
+                    big_lo = lo;
+                    big_hi = cur;
+                    big_val = i;
+                }
+            }
+            if (i == nnz - 1) {
+                for (int64_t t = cur + 1; t <= n_rows; ++t) {
+                    if (t - cur > inline_gap) {
+                        // the trailing rows: keep the rest for the wave unless a range is kept
+                        if (big_hi < big_lo + 1) {
+                            big_lo = t - 1;
+                            big_hi = n_rows;
+                            big_val = nnz;
+                            break;
+                        }
+                    }
+                    ptrs[t] = I(nnz);
+                }
+            }
         }
         if (bad) *flag = 1;
-    }
-}
-
-template <typename I>
-__global__ __launch_bounds__(256) void coo_run_lengths_kernel(int64_t n, I* __restrict__ start,
-                                                              const I* __restrict__ end)
-{
-    const int64_t stride = int64_t(gridDim.x) * 256;
-    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
-        start[i] = end[i] - start[i];
+        unsigned long long m = __ballot(big_hi >= big_lo + 1);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t lo = __shfl(big_lo, src, 64);
+            const int64_t hi = __shfl(big_hi, src, 64);
+            const int64_t val = __shfl(big_val, src, 64);
+            for (int64_t t = lo + 1 + lane; t <= hi; t += 64) ptrs[t] = I(val);
+        }
     }
 }
 
@@ -217,19 +242,12 @@ int launch_coo(gkoc_stream_t s, int mode, int64_t n_rows, int64_t n_cols, int64_
     hipStream_t st = as_stream(s);
     coo_init_kernel<T><<<dim3(1), dim3(1), 0, st>>>(w.flag, w.one);
     GKOC_LAUNCH_OK();
-    GKOC_HIP(hipMemsetAsync(w.ptrs, 0, size_t(n_rows + 1) * sizeof(I), st));
     if (nnz > 0) {
-        GKOC_HIP(hipMemsetAsync(w.ends, 0, size_t(n_rows + 1) * sizeof(I), st));
-        coo_row_runs_kernel<I><<<dim3(grid_for(ceildiv(nnz, 4), 8 * max_stream_blocks)),
-                                 dim3(256), 0, st>>>(nnz, rows, n_rows, w.ptrs, w.ends, w.flag);
+        coo_row_ptrs_kernel<I><<<dim3(grid_for(ceildiv(nnz, 4), 8 * max_stream_blocks)), dim3(256),
+                                 0, st>>>(nnz, rows, n_rows, w.ptrs, w.flag);
         GKOC_LAUNCH_OK();
-        coo_run_lengths_kernel<I><<<dim3(grid_for(n_rows)), dim3(256), 0, st>>>(n_rows, w.ptrs,
-                                                                                w.ends);
-        GKOC_LAUNCH_OK();
-    }
-    {
-        int rc = device_exclusive_scan<I>(st, w.ptrs, n_rows + 1, w.scan_scratch);
-        if (rc != GKOC_OK) return rc;
+    } else {
+        GKOC_HIP(hipMemsetAsync(w.ptrs, 0, size_t(n_rows + 1) * sizeof(I), st));
     }
     coo_clear_ptrs_if_unsorted_kernel<I><<<dim3(grid_for(n_rows + 1)), dim3(256), 0, st>>>(
         n_rows + 1, w.ptrs, w.flag);

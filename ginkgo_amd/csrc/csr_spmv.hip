@@ -129,6 +129,24 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         GKOC_LAUNCH_RING_VARIANT(4, 4);
     } else if (ring_variant == 4) {
         GKOC_LAUNCH_RING_VARIANT(1, 2);
+    } else if (ring_variant == 6) {
+        GKOC_LAUNCH_RING_VARIANT(2, 1);   // 8 KB ring, two load groups of 256 entries each in flight twice
+    } else if (ring_variant == 5 || ring_variant == 7) {
+        // 32-row segments, one per wave: half the work per wave, i.e. half the tail when the
+        // grid is only a few rounds of resident waves deep and the rows are long
+        const int64_t n_seg32 = ceildiv(n_rows, 32);
+        const dim3 grid32(static_cast<unsigned>(n_seg32));
+        if (ring_variant == 5) {
+            csr_spmv_pipe3_kernel<T, I, ADV, 32, EV, 1, RINGV, 1, 0x1000>
+                <<<grid32, block, 0, as_stream(s)>>>(n_rows, n_seg32, 1, row_ptrs, col_idxs, vals, b,
+                                                     ldb, c, ldc, static_cast<int>(nrhs), alpha, beta,
+                                                     nullptr, 0);
+        } else {
+            csr_spmv_pipe3_kernel<T, I, ADV, 32, EV, 2, RINGV, 1, 0x1000>
+                <<<grid32, block, 0, as_stream(s)>>>(n_rows, n_seg32, 1, row_ptrs, col_idxs, vals, b,
+                                                     ldb, c, ldc, static_cast<int>(nrhs), alpha, beta,
+                                                     nullptr, 0);
+        }
     } else if (vec_ok) {
         if (segs_per_wave == 2) {
             GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);

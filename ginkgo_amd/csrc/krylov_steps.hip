@@ -663,6 +663,133 @@ extern "C" int gkoc_ir_initialize(gkoc_stream_t s, int64_t cols, uint8_t* stop_s
     return GKOC_OK;
 }
 
+// pipe_cg::step_1 fused with the three reductions that follow it in a distributed PipeCg
+// iteration (one column, unit strides): x += t p ; r -= t q ; z -= t f ; w -= t g with
+// t = rho / beta (vectors bit-identical to op_pipe_cg_step1), and from the registers that hold
+// the new r, z, w this block's parts of <r, z>, <w, z> and <r, r>.  The eight vectors are read
+// once (step_1 + two dots + a norm: 136 B per row, fused: 96 B) and the whole iteration needs
+// ONE all-reduce, of the three values this kernel's fold leaves next to each other.
+template <typename T>
+__global__ __launch_bounds__(256) void pipe_cg_step1_dots_kernel(
+    int64_t n, T* __restrict__ x, T* __restrict__ r, T* __restrict__ z, T* __restrict__ w,
+    const T* __restrict__ p, const T* __restrict__ q, const T* __restrict__ f,
+    const T* __restrict__ g, const T* __restrict__ rho, const T* __restrict__ beta,
+    const uint8_t* __restrict__ stop, T* __restrict__ partial, int64_t pstride, bool vec_ok)
+{
+    __shared__ T lds[4];
+    using V = vec16<T>;
+    constexpr int W = V::width;
+    const T bt = beta[0];
+    const bool noop = bt == T(0) || status_has_stopped(stop[0]);
+    const T tmp = noop ? T(0) : rho[0] / bt;
+    T a_rz = T(0), a_wz = T(0), a_rr = T(0);
+    const int64_t tid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t nthreads = int64_t(gridDim.x) * 256;
+    int64_t done = 0;
+    if (vec_ok) {
+        const int64_t n_vec = n / W;
+        for (int64_t i = tid; i < n_vec; i += nthreads) {
+            V rv = reinterpret_cast<const V*>(r)[i];
+            V zv = reinterpret_cast<const V*>(z)[i];
+            V wv = reinterpret_cast<const V*>(w)[i];
+            if (!noop) {
+                V xv = reinterpret_cast<const V*>(x)[i];
+                const V pv = reinterpret_cast<const V*>(p)[i];
+                const V qv = reinterpret_cast<const V*>(q)[i];
+                const V fv = reinterpret_cast<const V*>(f)[i];
+                const V gv = reinterpret_cast<const V*>(g)[i];
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    xv.v[e] = xv.v[e] + tmp * pv.v[e];
+                    rv.v[e] = rv.v[e] - tmp * qv.v[e];
+                    zv.v[e] = zv.v[e] - tmp * fv.v[e];
+                    wv.v[e] = wv.v[e] - tmp * gv.v[e];
+                }
+                reinterpret_cast<V*>(x)[i] = xv;
+                reinterpret_cast<V*>(r)[i] = rv;
+                reinterpret_cast<V*>(z)[i] = zv;
+                reinterpret_cast<V*>(w)[i] = wv;
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                a_rz += rv.v[e] * zv.v[e];
+                a_wz += wv.v[e] * zv.v[e];
+                a_rr += rv.v[e] * rv.v[e];
+            }
+        }
+        done = n_vec * W;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) {
+        T rv = r[i], zv = z[i], wv = w[i];
+        if (!noop) {
+            x[i] = x[i] + tmp * p[i];
+            rv = rv - tmp * q[i];
+            zv = zv - tmp * f[i];
+            wv = wv - tmp * g[i];
+            r[i] = rv;
+            z[i] = zv;
+            w[i] = wv;
+        }
+        a_rz += rv * zv;
+        a_wz += wv * zv;
+        a_rr += rv * rv;
+    }
+    const T s0 = block_sum<256>(a_rz, lds);
+    __syncthreads();
+    const T s1 = block_sum<256>(a_wz, lds);
+    __syncthreads();
+    const T s2 = block_sum<256>(a_rr, lds);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s0;
+        partial[pstride + blockIdx.x] = s1;
+        partial[2 * pstride + blockIdx.x] = s2;
+    }
+}
+
+// out[k] = sum of partial[k * pstride .. + count), k = blockIdx.x (fixed tree)
+template <typename T>
+__global__ __launch_bounds__(1024) void fold_rows_kernel(int64_t count, int64_t pstride,
+                                                          const T* __restrict__ partial,
+                                                          T* __restrict__ out)
+{
+    __shared__ T lds[1024 / 64];
+    T acc = T(0);
+    const T* p = partial + int64_t(blockIdx.x) * pstride;
+    for (int64_t i = threadIdx.x; i < count; i += 1024) acc += p[i];
+    const T r = block_sum<1024>(acc, lds);
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
+template <typename T>
+int launch_pipe_cg_step1_dots(gkoc_stream_t s, int64_t n, T* x, T* r, T* z, T* w, const T* p,
+                              const T* q, const T* f, const T* g, const T* rho, const T* beta,
+                              const uint8_t* stop, T* out3, void* work, size_t work_bytes)
+{
+    GKOC_REQUIRE(n >= 0 && out3, GKOC_E_INVALID, "bad argument");
+    if (n == 0) {
+        GKOC_HIP(hipMemsetAsync(out3, 0, 3 * sizeof(T), as_stream(s)));
+        return GKOC_OK;
+    }
+    GKOC_REQUIRE(x && r && z && w && p && q && f && g && rho && beta && stop && work,
+                 GKOC_E_INVALID, "null pointer");
+    constexpr int64_t max_blocks = 1024;
+    GKOC_REQUIRE(work_bytes >= size_t(3 * max_blocks) * sizeof(T), GKOC_E_WORKSPACE,
+                 "workspace too small (gkoc_x_workspace_bytes)");
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(r) |
+                           reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(w) |
+                           reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q) |
+                           reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g);
+    int64_t nb = ceildiv(n, int64_t(256) * vec16<T>::width * 2);
+    if (nb > max_blocks) nb = max_blocks;
+    T* partial = static_cast<T*>(work);
+    pipe_cg_step1_dots_kernel<T><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(
+        n, x, r, z, w, p, q, f, g, rho, beta, stop, partial, max_blocks, bits % 16 == 0);
+    GKOC_LAUNCH_OK();
+    fold_rows_kernel<T><<<dim3(3), dim3(1024), 0, as_stream(s)>>>(nb, max_blocks, partial, out3);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
 #define GKOC_DEF_KRYLOV(T, TN)                                                            \
     /* ------------------------------------------------------------ bicgstab */           \
     extern "C" int gkoc_bicgstab_initialize_##TN(                                         \
@@ -868,6 +995,14 @@ extern "C" int gkoc_ir_initialize(gkoc_stream_t s, int64_t cols, uint8_t* stop_s
         return launch_elementwise<T, op_pipe_cg_step2<T>, 8, 4>(                          \
             s, rows, cols, o.a,                                                           \
             op_pipe_cg_step2<T>{prev_rho, rho, delta, beta, stop_status}, false);         \
+    }                                                                                     \
+    extern "C" int gkoc_x_pipe_cg_step_1_dots_##TN(                                       \
+        gkoc_stream_t s, int64_t rows, T* x, T* r, T* z, T* w, const T* p, const T* q,    \
+        const T* f, const T* g, const T* rho, const T* beta, const uint8_t* stop_status,  \
+        T* out3, void* work, size_t work_bytes)                                           \
+    {                                                                                     \
+        return launch_pipe_cg_step1_dots<T>(s, rows, x, r, z, w, p, q, f, g, rho, beta,   \
+                                            stop_status, out3, work, work_bytes);         \
     }
 
 GKOC_DEF_KRYLOV(double, f64)

@@ -101,6 +101,14 @@ class TorchComm:
             dist.all_reduce(t, group=self.group)
         return t
 
+    def all_reduce_begin(self, t, side_stream=None):
+        """start an all-reduce whose result is needed only after all_reduce_end();
+        torch.distributed: nothing to overlap with, the reduction happens here"""
+        return self.all_reduce_sum_(t)
+
+    def all_reduce_end(self):
+        pass
+
     def all_to_all_counts(self, send_counts):
         """exchange one integer with every peer (setup only)"""
         if self.size == 1:
@@ -186,6 +194,20 @@ class RcclComm(TorchComm):
         call("gkoc_comm_all_reduce_sum", self._handle, self.exec.stream, t, t.numel(),
              C.c_size_t(t.element_size()))
         return t
+
+    def all_reduce_begin(self, t, side_stream=None):
+        """the all-reduce travels on side_stream; kernels enqueued on the executor's
+        stream before all_reduce_end() overlap it (gkoc_comm_all_reduce_begin)"""
+        if self.size == 1:
+            return t
+        side = C.c_void_p(side_stream.cuda_stream) if side_stream is not None else None
+        call("gkoc_comm_all_reduce_begin", self._handle, self.exec.stream, side, t, t.numel(),
+             C.c_size_t(t.element_size()))
+        return t
+
+    def all_reduce_end(self):
+        if self.size > 1:
+            call("gkoc_comm_all_reduce_end", self._handle, self.exec.stream)
 
     def _counts(self, counts):
         key = tuple(counts)
@@ -342,6 +364,42 @@ class HipBackend:
 
     def local_dot(self, x, y, out):
         x.compute_dot(y, out)
+
+    def pipe_cg_initialize_1(self, b, r, prev_rho, stop):
+        call("gkoc_pipe_cg_initialize_1_" + VT[b.dtype], self.exec.stream, b.size[0], 1, b.values,
+             b.ld, r.values, r.ld, prev_rho.values, stop)
+
+    def pipe_cg_initialize_2(self, p, q, f, g, beta, z, w, m, n, delta):
+        call("gkoc_pipe_cg_initialize_2_" + VT[p.dtype], self.exec.stream, p.size[0], 1, p.values,
+             p.ld, q.values, q.ld, f.values, f.ld, g.values, g.ld, beta.values, z.values, z.ld,
+             w.values, w.ld, m.values, m.ld, n.values, n.ld, delta.values)
+
+    def pipe_cg_step_1(self, x, r, z, w, p, q, f, g, rho, beta, stop):
+        call("gkoc_pipe_cg_step_1_" + VT[x.dtype], self.exec.stream, x.size[0], 1, x.values, x.ld,
+             r.values, r.ld, z.values, z.ld, z.values, z.ld, w.values, w.ld, p.values, p.ld,
+             q.values, q.ld, f.values, f.ld, g.values, g.ld, rho.values, beta.values, stop)
+
+    def pipe_cg_step_1_dots(self, x, r, z, w, p, q, f, g, rho, beta, stop, out3):
+        """pipe_cg::step_1 and out3 = local {<r,z>, <w,z>, <r,r>} in one pass; False if the
+        layout has no fused kernel"""
+        if not all(v.ld == 1 and v.size[1] == 1 for v in (x, r, z, w, p, q, f, g)):
+            return False
+        wk, wb = self._xwork(x.size[0], x.dtype)
+        call("gkoc_x_pipe_cg_step_1_dots_" + VT[x.dtype], self.exec.stream, x.size[0], x.values,
+             r.values, z.values, w.values, p.values, q.values, f.values, g.values, rho.values,
+             beta.values, stop, out3, wk, wb)
+        return True
+
+    def pipe_cg_step_2(self, beta, p, q, f, g, z, w, m, n, prev_rho, rho, delta, stop):
+        call("gkoc_pipe_cg_step_2_" + VT[p.dtype], self.exec.stream, p.size[0], 1, beta.values,
+             p.values, p.ld, q.values, q.ld, f.values, f.ld, g.values, g.ld, z.values, z.ld,
+             w.values, w.ld, m.values, m.ld, n.values, n.ld, prev_rho.values, rho.values,
+             delta.values, stop)
+
+    def scalar_tuple(self, k, dtype=torch.float64):
+        """k adjacent device scalars: (k-element tensor, [view of [0], ..., view of [k-1]])"""
+        t = self.exec.zeros((k,), dtype)
+        return t, [Dense(self.exec, t[i:i + 1].view(1, 1)) for i in range(k)]
 
     # fused producer + local reduction (gkoc_x_*); vectors bit-identical
     def _xwork(self, n, dtype):
@@ -656,6 +714,149 @@ class DistributedCg:
                 break
             have_sq = run(("b", parity), seg_b, cur, prev)
             cur, prev = prev, cur
+        self.num_iterations = it
+        return x
+
+
+class DistributedPipeCg:
+    """PipeCg::apply_dense_impl (core/solver/pipe_cg.cpp:95-297) on distributed vectors: the
+    pipelined CG whose iteration needs ONE global reduction - the fit for a latency-bound
+    strong-scaling run over xGMI.
+
+    Per iteration (kernel sequence of the reference, same values):
+      step_1:  x += t p, r -= t q, z -= t f, w -= t g          (t = rho / beta)
+      dots:    rho = <r,z>, delta = <w,z>, ||r||^2   - ONE all-reduce of three values
+      m = M^-1 w ; n = A m                            - runs WHILE the all-reduce travels
+      check ; step_2: beta, p = z + s p, q = w + s q, f = m + s f, g = n + s g
+    The reference computes the dots after n = A m; they only read r, z, w, which step_1
+    finished, so here they are taken first (fused into step_1's pass on the device) and
+    reduced on the side stream that also carries the halo exchange of n = A m, both in the
+    same order on every rank.  rho / prev_rho alternate between two triples instead of being
+    copied.  The criterion is ResidualNorm(rhs_norm) on ||r|| like DistributedCg's (its square
+    rides in the same message), checked asynchronously with `check_lag` exactly as there:
+    pipe_cg::step_1 / step_2 are masked by stop_status (pipe_cg_kernels.cpp:79-164)."""
+
+    def __init__(self, backend, comm, matrix, max_iters, reduction_factor=1e-10,
+                 max_block_size=8, check_lag=None, fused=True, taped=True):
+        self.be, self.comm, self.a = backend, comm, matrix
+        self.taped = bool(taped)
+        self.max_iters, self.factor = int(max_iters), float(reduction_factor)
+        self.m_op = backend.jacobi(matrix.local, max_block_size) if max_block_size else None
+        self.num_iterations = 0
+        self.check_lag = backend.max_check_lag if check_lag is None else \
+            max(0, min(int(check_lag), 16 - 2))
+        self.fused = bool(fused)
+        n, dt = matrix.n_local, matrix.dtype
+        (self.r, self.w, self.z, self.p, self.m, self.n, self.q, self.f, self.g) = (
+            backend.vector(n, dt) for _ in range(9))
+        self.beta, self.tau0 = backend.vector(1, dt), backend.vector(1, dt)
+        # [rho, delta, ||r||^2]; the two triples swap roles as (rho, prev_rho)
+        self.trip_a = backend.scalar_tuple(3, dt)
+        self.trip_b = backend.scalar_tuple(3, dt)
+        self.flags, self.stop = backend.stop_flags()
+        self._side = matrix._side
+
+    def _precond(self, src, dst):
+        if self.m_op is not None:
+            self.m_op.apply(src, dst)
+        else:
+            dst.copy_from(src)
+
+    def _drain(self, pending, upto):
+        while pending and pending[0][0] <= upto:
+            it, token = pending.popleft()
+            if self.be.check_done(token, True):
+                return it
+        return None
+
+    def _check_begin(self, tau):
+        be = self.be
+        if getattr(be, "check_takes_squared_norm", False):
+            return be.check_begin(tau, self.tau0, self.factor, self.stop, squared=True)
+        be.sqrt_(tau)
+        return be.check_begin(tau, self.tau0, self.factor, self.stop)
+
+    def apply(self, b, x):
+        from collections import deque
+        be, a, comm = self.be, self.a, self.comm
+        r, w, z, p, m, n, q, f, g = (self.r, self.w, self.z, self.p, self.m, self.n, self.q,
+                                     self.f, self.g)
+        beta = self.beta
+        cur, prev = self.trip_a, self.trip_b
+        fused = self.fused and hasattr(be, "pipe_cg_step_1_dots")
+        be.pipe_cg_initialize_1(b, r, prev[1][0], self.stop)   # r = b ; prev_rho = 1
+        a.apply(x, q)                                           # r = b - A x
+        r.add_scaled(be.scalar(-1.0, b.dtype), q)
+        self._precond(r, z)
+        a.apply(z, w)
+        self._precond(w, m)
+        a.apply(m, n)
+        # ResidualNorm(rhs_norm) baseline
+        be.local_sqnorm(b, self.tau0)
+        comm.all_reduce_sum_(self.tau0.values.view(-1))
+        be.sqrt_(self.tau0)
+        be.local_dot(r, z, cur[1][0])
+        be.local_dot(w, z, cur[1][1])
+        be.local_sqnorm(r, cur[1][2])
+        comm.all_reduce_sum_(cur[0])
+        pending = deque()
+        it = 0
+        pending.append((it, self._check_begin(cur[1][2])))
+        if self._drain(pending, it) is not None:
+            self.num_iterations = 0
+            return x
+        be.pipe_cg_initialize_2(p, q, f, g, beta, z, w, m, n, cur[1][1])
+
+        def seg(cur, prev):
+            """one iteration up to the all-reduced scalars; `prev` receives the new triple"""
+            out, (rho_new, delta_new, tau_new) = prev
+            rho = cur[1][0]
+            if not (fused and be.pipe_cg_step_1_dots(x, r, z, w, p, q, f, g, rho, beta, self.stop,
+                                                     out)):
+                be.pipe_cg_step_1(x, r, z, w, p, q, f, g, rho, beta, self.stop)
+                be.local_dot(r, z, rho_new)
+                be.local_dot(w, z, delta_new)
+                be.local_sqnorm(r, tau_new)
+            comm.all_reduce_begin(out, self._side)      # one message: [rho, delta, ||r||^2]
+            self._precond(w, m)
+            a.apply(m, n)
+            comm.all_reduce_end()
+
+        def seg_step2(cur, prev):
+            # cur = the new triple, prev = the old one (prev_rho)
+            be.pipe_cg_step_2(beta, p, q, f, g, z, w, m, n, prev[1][0], cur[1][0], cur[1][1],
+                              self.stop)
+
+        taped = self.taped and getattr(be, "tapeable", False) and getattr(comm, "tapeable", False)
+        tapes = {}
+
+        def run(key, fn, *args):
+            if not taped:
+                return fn(*args)
+            t = tapes.get(key)
+            if t is not None:
+                return t.replay()
+            with _record() as t:
+                t.result = fn(*args)
+            tapes[key] = t
+            return t.result
+
+        while True:
+            parity = it & 1
+            run(("s", parity), seg, cur, prev)
+            cur, prev = prev, cur
+            it += 1
+            if it >= self.max_iters:
+                stopped = self._drain(pending, it)
+                if stopped is not None:
+                    it = stopped
+                break
+            pending.append((it, self._check_begin(cur[1][2])))
+            stopped = self._drain(pending, it - self.check_lag)
+            if stopped is not None:
+                it = stopped
+                break
+            run(("t", parity), seg_step2, cur, prev)
         self.num_iterations = it
         return x
 

@@ -856,7 +856,14 @@ size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size);
     int gkoc_x_cg_step_2_norm_##TN(                                            \
         gkoc_stream_t s, int64_t rows, T* x, T* r, const T* p, const T* q,     \
         const T* beta, const T* rho, const uint8_t* stop_status, T* norm_out,  \
-        int take_sqrt, void* work, size_t work_bytes);
+        int take_sqrt, void* work, size_t work_bytes);                         \
+    /* pipe_cg::step_1 (one column, unit strides; vectors bit-identical) and     \
+     * out3 = {<r,z>, <w,z>, <r,r>} of the updated vectors: the three values a   \
+     * distributed PipeCg iteration all-reduces in one message */              \
+    int gkoc_x_pipe_cg_step_1_dots_##TN(                                       \
+        gkoc_stream_t s, int64_t rows, T* x, T* r, T* z, T* w, const T* p,     \
+        const T* q, const T* f, const T* g, const T* rho, const T* beta,       \
+        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes);
 GKOC_DECL_X(double, f64)
 GKOC_DECL_X(float, f32)
 #define GKOC_DECL_XI(T, TN, I, IN)                                             \
@@ -1154,6 +1161,18 @@ int gkoc_comm_size(gkoc_comm_t comm, int* n_ranks, int* rank);
  * Every rank receives the same bits (one reduction order for all). */
 int gkoc_comm_all_reduce_sum(gkoc_comm_t comm, gkoc_stream_t s, void* buf,
                              int64_t n, size_t value_size);
+/* The same all-reduce travelling on `side` while kernels enqueued on `main` after begin run
+ * (pipelined Krylov methods: PipeCg reduces its three scalars while the preconditioner and
+ * the SpMV of the same iteration run, core/solver/pipe_cg.cpp:244-256).  begin: `side` waits
+ * for what `main` has enqueued (the kernels that wrote buf); end: `main` waits for the
+ * result.  An exchange started between begin and end must use the same `side` stream: the
+ * communicator sees one order of operations on every rank (anything else is refused with
+ * GKOC_E_INVALID, as is gkoc_comm_all_reduce_sum on another stream while something is
+ * pending).  side == main (or NULL): plain all-reduce on main, end is a no-op. */
+int gkoc_comm_all_reduce_begin(gkoc_comm_t comm, gkoc_stream_t main_stream,
+                               gkoc_stream_t side, void* buf, int64_t n,
+                               size_t value_size);
+int gkoc_comm_all_reduce_end(gkoc_comm_t comm, gkoc_stream_t main_stream);
 /* Sparse all-to-all of contiguous segments: send_counts[p] values leave
  * send_buf for rank p - from offset send_displs[p] (in values; the send_offsets
  * of mpi.hpp:1441), or packed in rank order when send_displs == NULL -,

@@ -131,6 +131,40 @@ class OracleBackend:
     def local_dot(self, x, y, out):
         out.values[0, 0] = float(o.dense_dot(x.np().copy(), y.np().copy())[0])
 
+    # pipe_cg step kernels: the oracle's restatement of reference/solver/pipe_cg_kernels.cpp,
+    # working in place on the vectors' memory
+    @staticmethod
+    def _a(v):
+        return v.values.numpy()
+
+    def pipe_cg_initialize_1(self, b, r, prev_rho, stop):
+        o.krylov_step("pipe_cg_initialize_1", b.size[0], 1, self._a(b), self._a(r), self._a(prev_rho),
+                      stop.numpy())
+
+    def pipe_cg_initialize_2(self, p, q, f, g, beta, z, w, m, n, delta):
+        o.krylov_step("pipe_cg_initialize_2", p.size[0], 1, *(self._a(v) for v in
+                                                              (p, q, f, g, beta, z, w, m, n, delta)))
+
+    def pipe_cg_step_1(self, x, r, z, w, p, q, f, g, rho, beta, stop):
+        o.krylov_step("pipe_cg_step_1", x.size[0], 1, *(self._a(v) for v in
+                                                        (x, r, z, z, w, p, q, f, g, rho, beta)),
+                      stop.numpy())
+
+    def pipe_cg_step_2(self, beta, p, q, f, g, z, w, m, n, prev_rho, rho, delta, stop):
+        o.krylov_step("pipe_cg_step_2", p.size[0], 1, *(self._a(v) for v in
+                                                        (beta, p, q, f, g, z, w, m, n, prev_rho, rho,
+                                                         delta)), stop.numpy())
+
+    def scalar_tuple(self, k, dtype=torch.float64):
+        t = torch.zeros(k, dtype=torch.float64)
+        views = []
+        for i in range(k):
+            v = CpuVec.__new__(CpuVec)
+            v.values = t[i:i + 1].view(1, 1)
+            v.size, v.dtype, v.ld = (1, 1), torch.float64, 1
+            views.append(v)
+        return t, views
+
     def local_sqnorm(self, x, out):
         out.values[0, 0] = float(o.dense_norm2(x.np().copy(), squared=True)[0])
 

@@ -70,6 +70,26 @@ def main():
     assert solver.check_lag > 0
     assert solver0.num_iterations == solver.num_iterations
     assert np.array_equal(xs0.to_numpy(), xs.to_numpy())
+    # --- distributed PipeCg (one all-reduce per iteration) vs the single-process oracle PipeCg
+    pipe = gd.DistributedPipeCg(be, comm, a, 500, 1e-10, 8)
+    xp = be.vector(hi - lo)
+    pipe.apply(be.vector_from(np.ones(hi - lo)), xp)
+    xo_p, it_p, _ = o.krylov_solve("pipe_cg", rp, ci, v, np.ones(n), max_iters=500, reduction=1e-10,
+                                   precond="block")
+    assert abs(pipe.num_iterations - it_p) <= 1, (pipe.num_iterations, it_p)
+    e = np.linalg.norm(xp.to_numpy()[:, 0] - xo_p[lo:hi]) / np.linalg.norm(xo_p[lo:hi])
+    assert e < 1e-8, f"rank {rank}: pipe_cg err {e}"
+    pipe0 = gd.DistributedPipeCg(be, comm, a, 500, 1e-10, 8, check_lag=0, fused=False, taped=False)
+    xp0 = be.vector(hi - lo)
+    pipe0.apply(be.vector_from(np.ones(hi - lo)), xp0)
+    assert pipe0.num_iterations == pipe.num_iterations, (pipe0.num_iterations, pipe.num_iterations)
+    if mode == "cpu":
+        # same kernels, only the run-ahead differs: identical bits
+        assert np.array_equal(xp0.to_numpy(), xp.to_numpy())
+    else:
+        # fused step_1 + dots uses another reduction tree than the three separate reductions
+        d = np.linalg.norm(xp0.to_numpy() - xp.to_numpy()) / np.linalg.norm(xp.to_numpy())
+        assert d < 1e-9, d
     # --- fused producer+reduction kernels (HipBackend only) vs the plain sequence
     if mode != "cpu":
         solver1 = gd.DistributedCg(be, comm, a, 500, 1e-10, 8, fused=False)

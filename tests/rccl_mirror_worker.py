@@ -44,6 +44,21 @@ def mirror_problem(grid, direct=False):
             calls["ar"] += 1
             return t
 
+        def all_reduce_begin(self, t, side_stream=None):
+            # the overlapped form (PipeCg): the real RCCL all-reduce on the side stream ...
+            side = C.c_void_p(side_stream.cuda_stream) if side_stream is not None else None
+            call("gkoc_comm_all_reduce_begin", self._handle, self.exec.stream, side, t, t.numel(),
+                 C.c_size_t(t.element_size()))
+            self._pending = t
+            calls["ar_overlapped"] = calls.get("ar_overlapped", 0) + 1
+            return t
+
+        def all_reduce_end(self):
+            # ... and the peer's equal contribution once the main stream has the result
+            call("gkoc_comm_all_reduce_end", self._handle, self.exec.stream)
+            t = self._pending
+            call("gkoc_dense_scale_f64", self.exec.stream, t.numel(), 1, self.two.values, 1, t, 1)
+
         def all_to_all_counts(self, send_counts):
             return list(send_counts)
 
@@ -91,6 +106,29 @@ def mirror_problem(grid, direct=False):
     return be, comm, a, part, calls
 
 
+def ex_stream(be):
+    return be.exec.stream
+
+
+def C_void(stream):
+    import ctypes as C
+    return C.c_void_p(stream.cuda_stream)
+
+
+def C_size(v):
+    import ctypes as C
+    return C.c_size_t(v)
+
+
+def raw_all_reduce(handle, stream, t):
+    """gkoc_comm_all_reduce_sum without the raising wrapper: the return code"""
+    import ctypes as C
+    from ginkgo_amd._lib import lib
+    f = lib().gkoc_comm_all_reduce_sum
+    f.restype = C.c_int
+    return f(handle, stream, C.c_void_p(t.data_ptr()), C.c_int64(t.numel()), C.c_size_t(t.element_size()))
+
+
 def init_rccl_single():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29655")
@@ -131,6 +169,29 @@ def main():
                                      reduction=1e-9, precond="block", max_block_size=8)
     # restarted GMRES counts drift with rounding on long runs: exact only on the small grid
     assert gm.has_converged and abs(gm.num_iterations - it2) <= max(1, it2 // 10), (gm.num_iterations, it2)
+    # distributed PipeCg: one (overlapped) all-reduce per iteration
+    pipe = gd.DistributedPipeCg(be, comm, a, 500, 1e-10, 8)
+    xq = be.vector(hi - lo)
+    pipe.apply(be.vector_from(np.ones(hi - lo)), xq)
+    xo3, it3, _ = oracle.krylov_solve("pipe_cg", rp, ci, v, np.ones(n), max_iters=500, reduction=1e-10,
+                                      precond="block")
+    assert abs(pipe.num_iterations - it3) <= 1, (pipe.num_iterations, it3)
+    e = np.linalg.norm(xq.to_numpy()[:, 0] - xo3[lo:hi]) / np.linalg.norm(xo3[lo:hi])
+    assert e < 1e-8, e
+    if direct:
+        assert pipe.taped and calls.get("ar_overlapped", 0) >= 2
+        plain_pipe = gd.DistributedPipeCg(be, comm, a, 500, 1e-10, 8, taped=False, check_lag=0)
+        xq0 = be.vector(hi - lo)
+        plain_pipe.apply(be.vector_from(np.ones(hi - lo)), xq0)
+        assert plain_pipe.num_iterations == pipe.num_iterations
+        assert np.array_equal(xq0.to_numpy(), xq.to_numpy())
+        # an all-reduce on the main stream while an overlapped one is pending must be refused
+        t2 = torch.ones(2, dtype=torch.float64, device="cuda")
+        comm_h = comm._handle
+        call("gkoc_comm_all_reduce_begin", comm_h, ex_stream(be), C_void(a._side), t2, 2, C_size(8))
+        rc = raw_all_reduce(comm_h, ex_stream(be), t2)
+        call("gkoc_comm_all_reduce_end", comm_h, ex_stream(be))
+        assert rc != 0, "all-reduce on another stream while one is pending was accepted"
     if direct:
         # the recorded-call loop (Tape) against the plain loop: same bits
         assert solver.taped and comm.tapeable and calls["ar"] > 4

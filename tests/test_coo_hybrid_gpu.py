@@ -168,3 +168,34 @@ def test_transpose(gexec, oracle, dtype, itype):
     a.apply(x, y0)
     a.transpose().apply(x, y1)
     assert np.array_equal(y0.to_numpy(), y1.to_numpy())
+
+
+@pytest.mark.parametrize("itype", [np.int32, np.int64])
+def test_row_pointer_pass_with_gaps(gexec, oracle, itype):
+    """pass 1 (row_idxs -> row pointers in one kernel): runs of empty rows of every length around
+    the lane-fills-it (8) and wave-fills-it thresholds, in front of the first and behind the last
+    stored row, several long gaps inside one lane's four entries, a single stored entry"""
+    import ginkgo_amd as g
+    rng = np.random.default_rng(5)
+    cases = []
+    # (n_rows, stored rows)
+    cases.append((5000, np.array([4999])))                       # one entry, 4999 empty rows in front
+    cases.append((5000, np.array([0])))                          # ... behind
+    cases.append((9000, np.array([700, 701, 1500, 1509, 1510, 1519, 8000])))
+    gaps = np.array([1, 2, 7, 8, 9, 10, 63, 64, 65, 66, 127, 128, 129, 300, 5, 1000, 3, 2000])
+    cases.append((int(gaps.sum()) + 500, np.cumsum(gaps)))
+    dense_rows = np.sort(rng.choice(20000, 6000, replace=False))
+    cases.append((20011, dense_rows))
+    for n_rows, stored in cases:
+        n_cols = 37
+        counts = rng.integers(1, 4, len(stored))
+        rows = np.repeat(stored, counts).astype(itype)
+        cols = rng.integers(0, n_cols, len(rows)).astype(itype)
+        vals = rng.uniform(-1, 1, len(rows))
+        b = rng.uniform(-1, 1, (n_cols, 1))
+        c0 = rng.uniform(-1, 1, (n_rows, 1))
+        a = _coo(g, gexec, n_rows, n_cols, rows, cols, vals)
+        for mode in MODES:
+            want = oracle.coo_apply(mode, n_rows, rows, cols, vals, b, 0.7, -1.3, c0)
+            got = _apply(g, gexec, a, mode, b, 0.7, -1.3, c0)
+            assert np.array_equal(got, want.reshape(got.shape)), (mode, n_rows)

@@ -218,3 +218,72 @@ def test_int64_indices_beyond_2_31_nonzeros(gexec):
     assert m.get_num_blocks() == n // 8
     del a, m, y
     torch.cuda.empty_cache()
+
+
+def test_config3_rank_local_slab_of_512_cubed(gexec):
+    """configs[3] (27-pt 512^3 row-partitioned over 8 ranks) as ONE rank sees it: rank 3 of 8 owns
+    planes 192..255 (16 777 216 rows, global row indices up to 134 M), its halo is one plane from
+    each z-neighbour.  The peers are played by a communicator that hands over exactly the planes a
+    linear field x = i + 3 j + 7 k has there, so y = A x over the local rows has the closed form of
+    test_linear_field_closed_form (0 wherever the 27 neighbours exist, exact in fp64) - the whole
+    distributed apply of the bench (device-side split into local / non-local part, halo index map,
+    send plan, boundary rows) at the full per-rank size of config 3."""
+    import ginkgo_amd as g
+    import ginkgo_amd.distributed as gd
+
+    grid, world, rank = 512, 8, 3
+    plane = grid * grid
+    part = gd.SlabPartition(grid, world)
+    z0, z1 = part.plane_offsets[rank], part.plane_offsets[rank + 1]
+    assert (z0, z1) == (192, 256)
+    lo, hi = part.range_of(rank)
+    assert (lo, hi) == (z0 * plane, z1 * plane)
+
+    def field(zs):
+        k, j, i = np.meshgrid(np.asarray(zs), np.arange(grid), np.arange(grid), indexing="ij")
+        return (i + 3 * j + 7 * k).astype(np.float64)
+
+    below, above = field([z0 - 1]).reshape(-1), field([z1]).reshape(-1)
+
+    class PeerPlanes:
+        """ranks 2 and 4 as this rank sees them"""
+        rank, size, host_staging = 3, world, False
+
+        def all_reduce_sum_(self, t):
+            return t
+
+        def all_to_all_counts(self, send_counts):
+            # what we need from a peer is what it needs from us (symmetric stencil)
+            return list(send_counts)
+
+        def all_to_all_v(self, recv, send, recv_counts, send_counts, async_op=False):
+            want = [0] * world
+            want[rank - 1] = want[rank + 1] = plane
+            assert list(recv_counts) == want and list(send_counts) == want
+            if recv.dtype == torch.int64:
+                # set-up: the global rows the peers want from us = our first and last plane
+                recv[:plane].copy_(torch.arange(lo, lo + plane, device=recv.device))
+                recv[plane:].copy_(torch.arange(hi - plane, hi, device=recv.device))
+            else:
+                recv[:plane].copy_(torch.from_numpy(below).to(recv.device))
+                recv[plane:].copy_(torch.from_numpy(above).to(recv.device))
+            return None
+
+    owned = g.stencil_csr(gexec, 3, grid, z0=z0, nz=z1 - z0)
+    be = gd.HipBackend(gexec)
+    a = gd.DistributedMatrix(be, PeerPlanes(), part, owned)
+    assert a.n_local == (z1 - z0) * plane == 16777216
+    assert a.n_halo == 2 * plane and a.n_send == 2 * plane
+    x3 = field(range(z0, z1))
+    x = be.vector_from(x3.reshape(-1))
+    y = be.vector(a.n_local)
+    a.apply(x, y)
+    got = y.to_numpy()[:, 0].reshape(z1 - z0, grid, grid)
+    # closed form: 27 x - (sum over the 3x3x3 box inside the GLOBAL domain); all 64 local planes
+    # have both z-neighbours, so only the x / y faces of the domain are non-zero
+    full = field(range(z0 - 1, z1 + 1))
+    # (the box sum pads with zeros in z as well, but only in the two extra planes cut off here)
+    expect = (27.0 * full - _box3_zero_padded(full))[1:-1]
+    assert np.all(expect[:, 1:-1, 1:-1] == 0)
+    assert np.array_equal(got, expect)
+
