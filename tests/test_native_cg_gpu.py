@@ -44,3 +44,57 @@ def test_native_cg_matches_oracle(oracle):
         for cap in (5, 6):
             r = _run(grid, cap, 1e-30, mode, 4)
             assert r["iterations"] == cap and not r["converged"]
+
+
+DEXE = os.path.join(ROOT, "examples", "native_dist_cg")
+
+
+def _run_dist(*args, env=None):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update(env or {})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PMI_RANK", "PMI_SIZE"):
+        e.pop(k, None)
+    out = subprocess.run([DEXE, *map(str, args)], capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.skipif(not os.path.exists(DEXE), reason="examples/native_dist_cg not built (run build())")
+@pytest.mark.parametrize("solver", ["cg", "pipe_cg"])
+def test_native_distributed_driver_matches_oracle(oracle, solver, tmp_path):
+    """examples/native_dist_cg.cpp: the row-partitioned CG / PipeCg loop in C++ over gkoc_comm_*.
+    One process plays rank 0 of a 2-slab run of the z-mirror-symmetric problem (`mirror`: halo
+    exchange and all-reduces go through a real RCCL communicator, the peer's data are its own by
+    symmetry) and, as a single rank, the whole problem; both against the single-process oracle."""
+    grid = 16
+    n, plane = grid ** 3, grid * grid
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    if solver == "cg":
+        xo, iters, _ = oracle.cg_solve(rp, ci, v, np.ones(n), max_iters=1000, reduction=1e-10,
+                                       precond="block", max_block_size=8)
+    else:
+        xo, iters, _ = oracle.krylov_solve("pipe_cg", rp, ci, v, np.ones(n), max_iters=1000,
+                                           reduction=1e-10, precond="block")
+    got = {}
+    for lag in (0, 4):
+        dump = str(tmp_path / f"x_{solver}_{lag}")
+        r = _run_dist(grid, 1000, 1e-10, solver, lag, "mirror", "dump=" + dump)
+        assert r["world"] == 2 and r["mirror"] and r["n_local"] == n // 2
+        assert r["converged"] and abs(r["iterations"] - iters) <= 1, (r, iters)
+        assert r["true_rel_residual"] <= 2e-10
+        x = np.fromfile(dump + ".0", dtype=np.float64)
+        assert x.shape == (n // 2,)
+        assert np.linalg.norm(x - xo[:n // 2]) <= 1e-8 * np.linalg.norm(xo[:n // 2])
+        got[lag] = (r["iterations"], x)
+    # reading the criterion late changes nothing, bit for bit
+    assert got[0][0] == got[4][0] and np.array_equal(got[0][1], got[4][1])
+    # one real rank = the whole domain, no communication
+    dump = str(tmp_path / f"x_{solver}_single")
+    r = _run_dist(grid, 1000, 1e-10, solver, 4, "dump=" + dump)
+    assert r["world"] == 1 and r["converged"] and abs(r["iterations"] - iters) <= 1
+    x = np.fromfile(dump + ".0", dtype=np.float64)
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+    # iteration limit
+    r = _run_dist(grid, 7, 1e-30, solver, 4, "mirror")
+    assert r["iterations"] == 7 and not r["converged"]
