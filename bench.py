@@ -127,6 +127,9 @@ def main():
                     help="0 = time the CPU reference on the GPU run's own matrix; "
                          "otherwise a separately generated grid^3 matrix")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pipe-cg", action="store_true",
+                    help="distributed runs: also time PipeCg + block-Jacobi(8) (one all-reduce per "
+                         "iteration) and report pipe_cg_iters_per_s next to cg_iters_per_s")
     ap.add_argument("--arena", type=int, default=None,
                     help="GKOC_ARENA mode of the library's allocator: 2 = memory-class regions "
                          "(default), 1 = plain chunks, 0 = one hipMalloc per array (DESIGN.md 3.2)")
@@ -262,6 +265,13 @@ def main():
               "cg_ms_per_iter": round(t_cg * 1e3 / iters, 4),
               "cg_model_gbs": round(cg_bytes * iters / t_cg / 1e9, 1),
               "cg_precond": "block-Jacobi(8)", "cg_setup_s": round(t_setup, 3)}
+        if use_dist and args.pipe_cg:
+            op.prepare_pipe_cg(args.cg_iters, barrier)
+            p_iters, t_p = op.timed_pipe_cg(barrier)
+            tp = torch.tensor([t_p], dtype=torch.float64, device=ex.device)
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            cg["pipe_cg_iters_per_s"] = round(p_iters / float(tp.item()), 2)
+            cg["pipe_cg_iterations"] = p_iters
 
     if rank == 0:
         per_gpu_bytes = total_bytes / world

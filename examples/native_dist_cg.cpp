@@ -236,7 +236,9 @@ try {
                                     scheme, block_ptrs.p, blocks.p, nullptr));
 
     // ---- vectors, scalars, workspaces
-    dev_array<double> b(n), x(n), r(n), z(n), p(n), q(n);
+    // z, the preconditioner's output, in another memory class than its inputs (blocks: class of
+    // the indices, r: class of the vectors)
+    dev_array<double> b(n), x(n), r(n), z(n, GKOC_MEM_VALUES), p(n), q(n);
     std::unique_ptr<dev_array<double>> w, m, nn, f, g;
     if (pipe) {
         for (auto* v : {&w, &m, &nn, &f, &g}) v->reset(new dev_array<double>(n));
@@ -252,7 +254,6 @@ try {
     const size_t x_bytes = gkoc_x_workspace_bytes(n, sizeof(double));
     dev_array<char> red_ws(red_bytes), x_ws(x_bytes);
     constexpr int NSLOT = 16;
-    dev_array<uint8_t> flags_dev(2 * NSLOT);
     uint8_t* flags_host = nullptr;
     {
         void* q_ = nullptr;
@@ -264,9 +265,18 @@ try {
     CK(gkoc_fill_array_f64(s, b.p, n, 1.0));
     CK(gkoc_fill_array_f64(s, x.p, n, 0.0));
 
+    // where the host's time goes (printed with GKOC_EXAMPLE_TRACE=1)
+    enum { T_ALLREDUCE, T_EXCHANGE, T_CHECK, T_COUNT };
+    double spent[T_COUNT] = {};
+    struct scoped {
+        double& acc;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~scoped() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    };
     // ---- the distributed pieces
     auto all_reduce = [&](double* buf, int64_t cnt) {
         if (world == 1) return;
+        scoped t{spent[T_ALLREDUCE]};
         CK(gkoc_comm_all_reduce_sum(comm, s, buf, cnt, sizeof(double)));
         if (mirror) CK(gkoc_dense_scale_f64(s, 1, cnt, two, 1, buf, cnt));
     };
@@ -274,23 +284,27 @@ try {
     int64_t pending_cnt = 0;
     auto all_reduce_begin = [&](double* buf, int64_t cnt) {
         if (world == 1) return;
+        scoped t{spent[T_ALLREDUCE]};
         CK(gkoc_comm_all_reduce_begin(comm, s, side, buf, cnt, sizeof(double)));
         pending_reduce = buf;
         pending_cnt = cnt;
     };
     auto all_reduce_end = [&]() {
         if (world == 1) return;
+        scoped t{spent[T_ALLREDUCE]};
         CK(gkoc_comm_all_reduce_end(comm, s));
         if (mirror) CK(gkoc_dense_scale_f64(s, 1, pending_cnt, two, 1, pending_reduce, pending_cnt));
     };
     // y = A[owned rows, :] v   (distributed::Matrix::apply_impl, matrix.cpp:450-509)
     auto dist_apply = [&](const double* v, double* y) {
         if (world > 1) {
+            scoped t{spent[T_EXCHANGE]};
             CK(gkoc_comm_exchange_begin(comm, s, side, v, send_counts.data(), send_displs.data(),
                                         halo.p, recv_counts.data(), sizeof(double)));
         }
         CK(gkoc_csr_spmv_f64_i32(s, n, n, local_ptrs.p, local_cols->p, local_vals->p, v, 1, y, 1, 1));
         if (world > 1) {
+            scoped t{spent[T_EXCHANGE]};
             CK(gkoc_comm_exchange_end(comm, s));
             CK(gkoc_csr_rowlist_spmv_add_f64_i32(s, n_nl_rows, nl_rows->p, nl_ptrs->p, nl_cols->p,
                                                  nl_vals->p, halo.p, 1, y, 1, 1));
@@ -311,26 +325,30 @@ try {
     int next_slot = 0;
     // criterion on the SQUARED norm (ImplicitResidualNorm's kernel: sqrt(tau) <= factor * tau0)
     auto check_begin = [&](int64_t iteration, const double* tau_sq) {
+        scoped t{spent[T_CHECK]};
         const int slot = next_slot;
         next_slot = (next_slot + 1) % NSLOT;
-        uint8_t* df = flags_dev.p + 2 * slot;
+        // the kernel writes its two flags straight into pinned host memory
+        uint8_t* df = flags_host + 2 * slot;
         CK(gkoc_implicit_residual_norm_f64(s, 1, tau_sq, tau0, reduction, 2, 1, stop.p, df, nullptr, nullptr));
-        CK(gkoc_memcpy_d2h(flags_host + 2 * slot, df, 2, s));
         CK(gkoc_event_record(events[slot], s));
         pending.push_back({iteration, slot});
     };
+    double wait_seconds = 0;   // time the host spent WAITING for criterion flags (not enqueueing)
     auto drain = [&](int64_t upto, int64_t& stop_it) {
         while (!pending.empty() && pending.front().it <= upto) {
             const pending_check c = pending.front();
             pending.pop_front();
+            const auto t0 = std::chrono::steady_clock::now();
             CK(gkoc_event_synchronize(events[c.slot]));
+            wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (flags_host[2 * c.slot] != 0) { stop_it = c.it; return true; }
         }
         return false;
     };
 
     CK(gkoc_device_synchronize());
-    double host_seconds = 0;   // time spent enqueueing (excludes the final synchronisation)
+    double host_seconds = 0;   // time spent enqueueing (excludes waiting for flags and the final sync)
     const auto t_start = std::chrono::steady_clock::now();
     // baseline: ||b|| (ResidualNorm with rhs_norm)
     local_sqnorm(b.p, tau0);
@@ -411,7 +429,8 @@ try {
             }
         }
     }
-    host_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    host_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() -
+                   wait_seconds;
     CK(gkoc_device_synchronize());
     const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
 
@@ -442,6 +461,13 @@ try {
            rank, world, mirror ? "true" : "false", (long long)grid, (long long)n, pipe ? "pipe_cg" : "cg", lag,
            (long long)it, (hstop[0] & 0x80) ? "true" : "false", tr / bn, xsum,
            seconds * 1e6 / double(it > 0 ? it : 1), host_seconds * 1e6 / double(it > 0 ? it : 1));
+    if (getenv("GKOC_EXAMPLE_TRACE")) {
+        const double per = 1e6 / double(it > 0 ? it : 1);
+        fprintf(stderr, "host us / iteration: all-reduce calls %.1f, exchange calls %.1f, criterion + flag copy %.1f, "
+                "waiting for flags %.1f, everything else (kernel launches) %.1f\n",
+                spent[T_ALLREDUCE] * per, spent[T_EXCHANGE] * per, spent[T_CHECK] * per, wait_seconds * per,
+                (host_seconds - spent[T_ALLREDUCE] - spent[T_EXCHANGE] - spent[T_CHECK]) * per);
+    }
     for (auto& e : events) gkoc_event_destroy(e);
     gkoc_free_host(flags_host);
     if (comm) gkoc_comm_destroy(comm);

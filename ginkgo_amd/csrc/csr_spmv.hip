@@ -129,6 +129,26 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         GKOC_LAUNCH_RING_VARIANT(4, 4);
     } else if (ring_variant == 4) {
         GKOC_LAUNCH_RING_VARIANT(1, 2);
+    } else if (ring_variant == 8 || ring_variant == 9) {
+        // lane = ONE entry per batch (8: E = 1, U = 4) or two (9: E = 2, U = 2): neighbouring
+        // lanes then gather neighbouring entries of a row, whose columns are runs of consecutive
+        // indices in block-structured matrices - the texture addresser merges them into one
+        // cache access per quad instead of one per lane (PMC on the Flan-like matrix: 1.0 L1
+        // accesses per nonzero and the addresser stalled by the cache 23 % of the time with
+        // E = 4).  val / col loads become 8 / 4-byte-per-lane loads (still contiguous runs).
+        if (ring_variant == 8) {
+            if (segs_per_wave == 2) {
+                GKOC_LAUNCH_PIPE3(1, 4, 0x2000);
+            } else {
+                GKOC_LAUNCH_PIPE3(1, 4, 0x1000);
+            }
+        } else {
+            if (segs_per_wave == 2) {
+                GKOC_LAUNCH_PIPE3(2, 2, 0x2000);
+            } else {
+                GKOC_LAUNCH_PIPE3(2, 2, 0x1000);
+            }
+        }
     } else if (ring_variant == 6) {
         GKOC_LAUNCH_RING_VARIANT(2, 1);   // 8 KB ring, two load groups of 256 entries each in flight twice
     } else if (ring_variant == 5 || ring_variant == 7) {

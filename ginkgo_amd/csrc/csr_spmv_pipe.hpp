@@ -140,16 +140,30 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
         }
     };
 
+    // b with unit row stride (every vector of a Krylov solver): the gather address is
+    // base + 8 col; a run-time stride costs a 64-bit multiply per nonzero (three quarter-rate
+    // integer multiplies in the ISA), more than the product itself
+    const bool unit_b = ldb == 1;
     for (int j = 0; j < nrhs; ++j) {
         const T* __restrict__ bj = b + j;
         auto produce = [&](VT(&v)[U], VI(&ci)[U], int p) {
             VT xv[U];
+            if (unit_b) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+                for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    xv[u].v[e] = (ABL & 1) ? T(ci[u].v[e])
-                                           : bj[int64_t(ci[u].v[e]) * ldb];
+                    for (int e = 0; e < E; ++e) {
+                        xv[u].v[e] = (ABL & 1) ? T(ci[u].v[e]) : bj[int64_t(ci[u].v[e])];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        xv[u].v[e] = (ABL & 1) ? T(ci[u].v[e])
+                                               : bj[int64_t(ci[u].v[e]) * ldb];
+                    }
                 }
             }
 #pragma unroll
@@ -205,17 +219,64 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                 if (!is_long && !(ABL & 2)) {
                     int k = rs > cons ? rs : cons;
                     const int e_ = re < upto ? re : upto;
-                    for (; k + 4 <= e_; k += 4) {
-                        const T t0 = ring[k & MASK];
-                        const T t1 = ring[(k + 1) & MASK];
-                        const T t2 = ring[(k + 2) & MASK];
-                        const T t3 = ring[(k + 3) & MASK];
-                        sum += t0;
-                        sum += t1;
-                        sum += t2;
-                        sum += t3;
+                    // Four products per step, added in k order.  The range [k, e_) is at most
+                    // one ring long, so it wraps at most once: split there and both pieces are
+                    // contiguous in LDS - one pointer increment per step, the other three
+                    // addresses are immediate offsets, and the loads of step i+1 are issued
+                    // before the adds of step i.  With 81-nonzero rows this loop was 2/3 of the
+                    // kernel's vector instructions (rocprofv3 SQ_INSTS_VALU, Flan-like matrix).
+                    auto run = [&](int lo_, int hi_) {
+                        const T* q4 = ring + (lo_ & MASK);
+                        int n4 = (hi_ - lo_) >> 2;
+                        if (n4 > 0) {
+                            // two register sets, alternating: no copies between the steps
+                            T a0 = q4[0], a1 = q4[1], a2 = q4[2], a3 = q4[3];
+                            q4 += 4;
+                            --n4;
+                            while (n4 >= 2) {
+                                const T b0 = q4[0], b1 = q4[1], b2 = q4[2], b3 = q4[3];
+                                sum += a0;
+                                sum += a1;
+                                sum += a2;
+                                sum += a3;
+                                a0 = q4[4];
+                                a1 = q4[5];
+                                a2 = q4[6];
+                                a3 = q4[7];
+                                q4 += 8;
+                                n4 -= 2;
+                                sum += b0;
+                                sum += b1;
+                                sum += b2;
+                                sum += b3;
+                            }
+                            sum += a0;
+                            sum += a1;
+                            sum += a2;
+                            sum += a3;
+                            if (n4 == 1) {
+                                const T b0 = q4[0], b1 = q4[1], b2 = q4[2], b3 = q4[3];
+                                q4 += 4;
+                                sum += b0;
+                                sum += b1;
+                                sum += b2;
+                                sum += b3;
+                            }
+                        }
+                        const int rem = (hi_ - lo_) & 3;
+                        if (rem > 0) sum += q4[0];
+                        if (rem > 1) sum += q4[1];
+                        if (rem > 2) sum += q4[2];
+                    };
+                    if (k < e_) {
+                        const int wrap = (k | MASK) + 1;   // first index behind k that maps to ring[0]
+                        if (wrap < e_) {
+                            run(k, wrap);
+                            run(wrap, e_);
+                        } else {
+                            run(k, e_);
+                        }
                     }
-                    for (; k < e_; ++k) sum += ring[k & MASK];
                 }
                 wave_lds_sync();
                 cons = upto;

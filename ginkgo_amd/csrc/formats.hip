@@ -33,7 +33,9 @@ constexpr int fmt_unroll = 8;
 // lives at first + i * step.  Software-pipelined: while the b entries of chunk
 // i are gathered, the val/col loads of chunk i+1 are already in flight; the
 // products are added in column order (bit-identical to the reference loop).
-template <typename T, typename I, bool ADV>
+// UNITB: b has unit row stride and j == 0 (the gather address is base + 8 col instead of a
+// 64-bit multiply per entry)
+template <typename T, typename I, bool ADV, bool UNITB = false>
 __device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
                                          int64_t step,
                                          const I* __restrict__ cols,
@@ -57,7 +59,7 @@ __device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
         T xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            xv[u] = c0[u] >= 0 ? b[int64_t(c0[u]) * ldb + j] : T(0);
+            xv[u] = c0[u] >= 0 ? (UNITB ? b[int64_t(c0[u])] : b[int64_t(c0[u]) * ldb + j]) : T(0);
         }
         const int64_t nx = i + U < full ? i + U : i;  // last chunk: harmless reload
 #pragma unroll
@@ -81,7 +83,7 @@ __device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
         const I cc = cols[first + i * step];
         if (cc >= 0) {
             const T v = vals[first + i * step];
-            const T xv = b[int64_t(cc) * ldb + j];
+            const T xv = UNITB ? b[int64_t(cc)] : b[int64_t(cc) * ldb + j];
             sum += ADV ? (alpha * v) * xv : v * xv;
         }
     }
@@ -153,14 +155,17 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(
         beta = beta_p[0];
     }
     for (int j = 0; j < nrhs; ++j) {
+        const bool unit_b = ldb == 1 && j == 0;   // uniform: one of the two instances runs
         T s0 = T(0), s1 = T(0);
         if (row0 < n_rows) {
             if (ADV && beta != T(0)) s0 = beta * c[row0 * ldc + j];
-            s0 = fmt_row_sum<T, I, ADV>(s0, k_per_row, row0, stride, cols, vals, b, ldb, j, alpha);
+            s0 = unit_b ? fmt_row_sum<T, I, ADV, true>(s0, k_per_row, row0, stride, cols, vals, b, ldb, j, alpha)
+                        : fmt_row_sum<T, I, ADV>(s0, k_per_row, row0, stride, cols, vals, b, ldb, j, alpha);
         }
         if (row1 < n_rows) {
             if (ADV && beta != T(0)) s1 = beta * c[row1 * ldc + j];
-            s1 = fmt_row_sum<T, I, ADV>(s1, k_per_row, row1, stride, cols, vals, b, ldb, j, alpha);
+            s1 = unit_b ? fmt_row_sum<T, I, ADV, true>(s1, k_per_row, row1, stride, cols, vals, b, ldb, j, alpha)
+                        : fmt_row_sum<T, I, ADV>(s1, k_per_row, row1, stride, cols, vals, b, ldb, j, alpha);
         }
         if (row0 < n_rows) c[row0 * ldc + j] = s0;
         if (row1 < n_rows) c[row1 * ldc + j] = s1;
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256) void sellp_spmv_kernel(
         beta = beta_p[0];
     }
     for (int j = 0; j < nrhs; ++j) {
+        const bool unit_b = ldb == 1 && j == 0;   // uniform: one of the two instances runs
         T sum[2] = {T(0), T(0)};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -194,8 +200,10 @@ __global__ __launch_bounds__(256) void sellp_spmv_kernel(
                 const int64_t len = int64_t(slice_lengths[slice]);
                 const int64_t base = int64_t(slice_sets[slice]) * slice_size + local;
                 if (ADV && beta != T(0)) sum[t] = c[row * ldc + j] * beta;
-                sum[t] = fmt_row_sum<T, I, ADV>(sum[t], len, base, slice_size, cols, vals, b,
-                                                ldb, j, alpha);
+                sum[t] = unit_b ? fmt_row_sum<T, I, ADV, true>(sum[t], len, base, slice_size, cols, vals,
+                                                               b, ldb, j, alpha)
+                                : fmt_row_sum<T, I, ADV>(sum[t], len, base, slice_size, cols, vals, b,
+                                                         ldb, j, alpha);
             }
         }
 #pragma unroll

@@ -950,6 +950,21 @@ class DistributedStencil:
         barrier()
         return t_setup
 
+    def prepare_pipe_cg(self, iters, barrier):
+        """the same for the pipelined CG (one all-reduce per iteration)"""
+        self._pcg = DistributedPipeCg(self.backend, self.comm, self.matrix, iters, 1e-30, 8)
+        self._pcg.apply(self._rhs, self._sol.fill(0.0))
+        barrier()
+
+    def timed_pipe_cg(self, barrier):
+        import time
+        self._sol.fill(0.0)
+        barrier()
+        t1 = time.perf_counter()
+        self._pcg.apply(self._rhs, self._sol)
+        barrier()
+        return self._pcg.num_iterations, time.perf_counter() - t1
+
     def timed_cg(self, barrier):
         import time
         self._sol.fill(0.0)

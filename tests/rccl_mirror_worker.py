@@ -179,6 +179,8 @@ def main():
     e = np.linalg.norm(xq.to_numpy()[:, 0] - xo3[lo:hi]) / np.linalg.norm(xo3[lo:hi])
     assert e < 1e-8, e
     if direct:
+        import ctypes as C  # noqa: F401
+        from ginkgo_amd._lib import call
         assert pipe.taped and calls.get("ar_overlapped", 0) >= 2
         plain_pipe = gd.DistributedPipeCg(be, comm, a, 500, 1e-10, 8, taped=False, check_lag=0)
         xq0 = be.vector(hi - lo)
