@@ -373,6 +373,96 @@ __global__ __launch_bounds__(256) void jacobi_apply_kernel(
     }
 }
 
+// Several right-hand sides on the matrix cores (f64, block_offset 8, 64-wide groups):
+// X_blk (8 x nrhs) = Inv_blk (8 x 8) * B_blk (8 x nrhs) is the one GEMM-shaped piece of the Krylov
+// hot path.  One wave per storage group (8 blocks).  v_mfma_f64_16x16x4_f64 computes
+// D(16x16) += A(16x4) B(4x16); two blocks form a block-diagonal 16 x 16 operand (half of A is
+// zero - the flops are free here, the kernel is bound by the b / x traffic), 16 right-hand
+// sides are the 16 columns of B and D, four instructions walk the 16 inner indices.  What the
+// matrix cores buy is the DATA LAYOUT: a lane of the B / D fragments holds column j of a row, so
+// every b / x access is a run of 16 consecutive values of the row-major multi-vector, where the
+// lane = row kernel above reads one value per row per instruction with a stride of ldb.
+// The group's inverse blocks are read once (coalesced, masked to the block size) into LDS and
+// re-read from there in fragment order for every chunk of 16 columns.
+// Sums are fused multiply-adds in the unit's order: NOT bit-identical to the reference's
+// separate multiply and add (relative difference ~5e-16), which everything else in this file
+// is.  Used from four right-hand sides on (GKOC_TUNE_JACOBI_MFMA: 0 never, 1 from two, 2 = default).
+// Fragment maps (cdna_hip_programming.md, f64 MFMA): A[i][k]: i = lane & 15, k = lane >> 4;
+// B[k][j]: k = lane >> 4, j = lane & 15; D[i][j]: j = lane & 15, i = (lane >> 4) + 4 * reg.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+template <typename I, bool ADV>
+__global__ __launch_bounds__(256) void jacobi_apply_mfma_kernel(
+    int64_t num_blocks, int64_t num_groups, int64_t group_offset,
+    const I* __restrict__ block_ptrs, const double* __restrict__ blocks,
+    const double* __restrict__ alpha_p, const double* __restrict__ b, int64_t ldb,
+    const double* __restrict__ beta_p, double* __restrict__ x, int64_t ldx, int nrhs)
+{
+    __shared__ double inv[4][8 * 64];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t group = int64_t(blockIdx.x) * 4 + w;
+    if (group >= num_groups) return;   // no block-wide barrier below
+    double alpha = 1.0, beta = 0.0;
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    // block pointers of the group's 8 blocks (+ end) in lanes 0..8
+    const int64_t blk0 = group << 3;
+    int64_t pv = 0;
+    {
+        const int64_t bi = blk0 + lane < num_blocks ? blk0 + lane : num_blocks;
+        if (lane <= 8) pv = block_ptrs[bi];
+    }
+    // stage the inverse blocks: lane = (block, row), masked to the block's size
+    {
+        const int bl = lane >> 3, r = lane & 7;
+        const int64_t st = __shfl(pv, bl, 64), en = __shfl(pv, bl + 1, 64);
+        const int bs = blk0 + bl < num_blocks ? int(en - st) : 0;
+        const double* gp = blocks + group_offset * group + lane;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            inv[w][c * 64 + lane] = (r < bs && c < bs) ? gp[c * 64] : 0.0;
+        }
+    }
+    wave_lds_sync();
+    const int i16 = lane & 15, q = lane >> 4;
+    for (int j0 = 0; j0 < nrhs; j0 += 16) {
+        const int j = j0 + i16;
+        const bool jok = j < nrhs;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                // A: row i16 of the block pair, inner index k = 4 kk + q
+                const int k = 4 * kk + q;
+                const int ca = k - 8 * (i16 >> 3);      // column inside the row's own block
+                const double av = (ca >= 0 && ca < 8) ? inv[w][ca * 64 + 16 * p + i16] : 0.0;
+                // B: inner index k -> block 2p + (k >> 3), row k & 7 of that block
+                const int bl = 2 * p + (k >> 3), rb = k & 7;
+                const int64_t st = __shfl(pv, bl, 64), en = __shfl(pv, bl + 1, 64);
+                const bool rok = blk0 + bl < num_blocks && rb < int(en - st);
+                const double bvv = (rok && jok) ? b[(st + rb) * ldb + j] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bvv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int i = q + 4 * reg;
+                const int bl = 2 * p + (i >> 3), rd = i & 7;
+                const int64_t st = __shfl(pv, bl, 64), en = __shfl(pv, bl + 1, 64);
+                if (blk0 + bl < num_blocks && rd < int(en - st) && jok) {
+                    double* xp = x + (st + rd) * ldx + j;
+                    double v = acc[reg];
+                    if (ADV) v = beta != 0.0 ? alpha * v + beta * xp[0] : alpha * v;
+                    xp[0] = v;
+                }
+            }
+        }
+    }
+}
+
 // Fast path for the layout Ginkgo's compute_storage_scheme produces on a
 // 64-wide device: block_offset BO (power of two), BO << group_power == 64,
 // single right-hand side.  One wave handles GPW consecutive groups: per group
@@ -839,6 +929,21 @@ int launch_apply(gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
 #undef GKOC_JAC_FIXED
         GKOC_LAUNCH_OK();
         return GKOC_OK;
+    }
+    if constexpr (sizeof(T) == 8) {
+        // matrix-core path (fused multiply-adds: ~5e-16 off the reference's bits).  Measured on
+        // L256 (profiles/r02_jacobi_mfma_256.txt): 2 columns 603 us against 530 us for the lane =
+        // row kernel, 4: 654 / 1251, 8: 778 / 3779, 16: 987 / 9680 -> from four columns on.
+        const int64_t mode = tune_value(GKOC_TUNE_JACOBI_MFMA);
+        if (mode != 0 && nrhs >= (mode == 1 ? 2 : 4) && bo == 8 && scheme.group_power == 3 &&
+            b != x) {
+            jacobi_apply_mfma_kernel<I, ADV>
+                <<<dim3(unsigned(ceildiv(groups, 4))), dim3(256), 0, as_stream(s)>>>(
+                    num_blocks, groups, scheme.group_offset, block_ptrs, blocks, alpha, b, ldb,
+                    beta, x, ldx, int(nrhs));
+            GKOC_LAUNCH_OK();
+            return GKOC_OK;
+        }
     }
     jacobi_apply_kernel<T, I, ADV>
         <<<dim3(unsigned(ceildiv(groups, 4))), dim3(256), 0, as_stream(s)>>>(
