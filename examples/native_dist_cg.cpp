@@ -165,7 +165,7 @@ try {
     if (n < 2 * plane && world > 1) throw std::runtime_error("fewer than two planes per rank");
 
     gkoc_stream_t s = nullptr, side = nullptr;
-    CK(gkoc_stream_create(&s));
+    if (!getenv("GKOC_EXAMPLE_NULL_STREAM")) CK(gkoc_stream_create(&s));   // else: the NULL stream
     CK(gkoc_stream_create(&side));
 
     // ---- communicator (RCCL), id through a file

@@ -53,7 +53,7 @@ def test_hot_path_suites_are_fully_green():
     for suite in ("solver_cg_kernels_hip", "solver_gmres_kernels_hip", "solver_fcg_kernels_hip",
                   "solver_pipe_cg_kernels_hip", "solver_bicgstab_kernels_hip",
                   "solver_cgs_kernels_hip", "solver_gcr_kernels_hip", "solver_ir_kernels_hip",
-                  "solver_chebyshev_kernels_hip", "components_prefix_sum_kernels_hip",
+                  "solver_chebyshev_kernels_hip", "solver_cb_gmres_kernels_hip", "components_prefix_sum_kernels_hip",
                   "components_format_conversion_kernels_hip", "stop_criterion_kernels_hip",
                   "stop_combined_kernels_hip", "base_executor_hip", "base_timer_hip"):
         assert EXPECTED[suite]["known_failures"] == {}, suite
