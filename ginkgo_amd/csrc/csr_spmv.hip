@@ -102,72 +102,12 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     // XCD-contiguous wave order needs enough waves per XCD to keep the in-order
     // window argument valid; below that the plain order is used
     const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
-    // Long rows: the ring holds only a few rows at a time (1024 / 81 = 12 for the 81-nonzero
-    // rows of a 3-dof 27-point problem), so each hand-over to the row phase keeps only that many
-    // lanes busy for a whole row length.  Bigger rings (16 / 32 KB per wave, fewer resident
-    // waves, more loads in flight per wave) cut the number of hand-overs.  Chosen with
-    // GKOC_TUNE_CSR_RING; results are bit-identical for every value.
-    const int ring_variant = vec_ok ? int(tune_value(GKOC_TUNE_CSR_RING)) : 0;
-#define GKOC_LAUNCH_PIPE3R(U_, RMUL_, MODE_)                                         \
-    csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, EV, U_, RINGV * RMUL_, 1, MODE_>  \
-        <<<grid, block, 0, as_stream(s)>>>(                                          \
-            n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,  \
-            static_cast<int>(nrhs), alpha, beta, nullptr, xcd_map)
-#define GKOC_LAUNCH_RING_VARIANT(U_, RMUL_)           \
-    do {                                              \
-        if (segs_per_wave == 2) {                     \
-            GKOC_LAUNCH_PIPE3R(U_, RMUL_, 0x2000);    \
-        } else {                                      \
-            GKOC_LAUNCH_PIPE3R(U_, RMUL_, 0x1000);    \
-        }                                             \
-    } while (0)
-    if (ring_variant == 1) {
-        GKOC_LAUNCH_RING_VARIANT(2, 2);
-    } else if (ring_variant == 2) {
-        GKOC_LAUNCH_RING_VARIANT(2, 4);
-    } else if (ring_variant == 3) {
-        GKOC_LAUNCH_RING_VARIANT(4, 4);
-    } else if (ring_variant == 4) {
-        GKOC_LAUNCH_RING_VARIANT(1, 2);
-    } else if (ring_variant == 8 || ring_variant == 9) {
-        // lane = ONE entry per batch (8: E = 1, U = 4) or two (9: E = 2, U = 2): neighbouring
-        // lanes then gather neighbouring entries of a row, whose columns are runs of consecutive
-        // indices in block-structured matrices - the texture addresser merges them into one
-        // cache access per quad instead of one per lane (PMC on the Flan-like matrix: 1.0 L1
-        // accesses per nonzero and the addresser stalled by the cache 23 % of the time with
-        // E = 4).  val / col loads become 8 / 4-byte-per-lane loads (still contiguous runs).
-        if (ring_variant == 8) {
-            if (segs_per_wave == 2) {
-                GKOC_LAUNCH_PIPE3(1, 4, 0x2000);
-            } else {
-                GKOC_LAUNCH_PIPE3(1, 4, 0x1000);
-            }
-        } else {
-            if (segs_per_wave == 2) {
-                GKOC_LAUNCH_PIPE3(2, 2, 0x2000);
-            } else {
-                GKOC_LAUNCH_PIPE3(2, 2, 0x1000);
-            }
-        }
-    } else if (ring_variant == 6) {
-        GKOC_LAUNCH_RING_VARIANT(2, 1);   // 8 KB ring, two load groups of 256 entries each in flight twice
-    } else if (ring_variant == 5 || ring_variant == 7) {
-        // 32-row segments, one per wave: half the work per wave, i.e. half the tail when the
-        // grid is only a few rounds of resident waves deep and the rows are long
-        const int64_t n_seg32 = ceildiv(n_rows, 32);
-        const dim3 grid32(static_cast<unsigned>(n_seg32));
-        if (ring_variant == 5) {
-            csr_spmv_pipe3_kernel<T, I, ADV, 32, EV, 1, RINGV, 1, 0x1000>
-                <<<grid32, block, 0, as_stream(s)>>>(n_rows, n_seg32, 1, row_ptrs, col_idxs, vals, b,
-                                                     ldb, c, ldc, static_cast<int>(nrhs), alpha, beta,
-                                                     nullptr, 0);
-        } else {
-            csr_spmv_pipe3_kernel<T, I, ADV, 32, EV, 2, RINGV, 1, 0x1000>
-                <<<grid32, block, 0, as_stream(s)>>>(n_rows, n_seg32, 1, row_ptrs, col_idxs, vals, b,
-                                                     ldb, c, ldc, static_cast<int>(nrhs), alpha, beta,
-                                                     nullptr, 0);
-        }
-    } else if (vec_ok) {
+    // Measured and rejected on the Flan-like matrix and on L256 (profiles/r02_experiments,
+    // profiles/r02_flan_pmc): 16 / 32 KB rings with 2-4 load groups (fewer resident waves: 299-475 us
+    // against 288), 32-row segments (294), one or two entries per lane and load so that neighbouring
+    // lanes gather neighbouring columns (301-305).  What helped was the row-phase loop
+    // (csr_spmv_pipe.hpp): 295 -> 277 us.
+    if (vec_ok) {
         if (segs_per_wave == 2) {
             GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);
         } else {
@@ -181,8 +121,6 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         }
     }
 #undef GKOC_LAUNCH_PIPE3
-#undef GKOC_LAUNCH_PIPE3R
-#undef GKOC_LAUNCH_RING_VARIANT
     GKOC_LAUNCH_OK();
     return GKOC_OK;
 }

@@ -125,8 +125,7 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
 #define GKOC_TUNE_JACOBI_MFMA 3     /* block-Jacobi(8) apply, several right-hand sides, on the f64 matrix cores
                                       (fused multiply-adds: ~5e-16 off the reference's bits): 0 never,
                                       1 from two columns, 2 (default) from four columns on */
-#define GKOC_TUNE_CSR_RING 2       /* CSR SpMV product ring per wave: 0 = 8 KB (default), 1 = 16 KB / 2 load
-                                      groups, 2 = 32 KB / 2, 3 = 32 KB / 4, 4 = 16 KB / 1 (long rows) */
+/* key 2: reserved (round-2 experiments with the CSR kernel's ring size / lane layout, all rejected) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,
