@@ -362,13 +362,15 @@ try {
         dist_apply(x.p, q.p);                                   // r = b - A x
         CK(gkoc_dense_add_scaled_f64(s, n, 1, neg_one, 1, q.p, 1, r.p, 1));
         CK(gkoc_fill_array_f64(s, q.p, n, 0.0));
-        bool have_sq = false;
+        bool have_next = false;   // z, <r,z> and ||r||^2 of the coming iteration are already there
         it = -1;
         for (;;) {
-            // z = M^-1 r, rho = <r,z> (one kernel), ||r||^2 from step_2 of the last iteration
-            CK(gkoc_x_jacobi_simple_apply_dot_f64_i32(s, num_blocks, n, bs, scheme, block_ptrs.p, blocks.p,
-                                                      r.p, z.p, cur, x_ws.p, x_bytes));
-            if (!have_sq) local_sqnorm(r.p, cur + 1);
+            if (!have_next) {
+                // z = M^-1 r, rho = <r,z> (one kernel) and ||r||^2
+                CK(gkoc_x_jacobi_simple_apply_dot_f64_i32(s, num_blocks, n, bs, scheme, block_ptrs.p, blocks.p,
+                                                          r.p, z.p, cur, x_ws.p, x_bytes));
+                local_sqnorm(r.p, cur + 1);
+            }
             all_reduce(cur, 2);                                 // one message: [<r,z>, ||r||^2]
             ++it;
             int64_t stop_it = it;
@@ -383,9 +385,12 @@ try {
             dist_apply(p.p, q.p);
             local_dot(p.p, q.p, beta);
             all_reduce(beta, 1);
-            // x += t p, r -= t q, and ||r_new||^2 into the group that is `cur` next
-            CK(gkoc_x_cg_step_2_norm_f64(s, n, x.p, r.p, p.p, q.p, beta, cur, stop.p, prev + 1, 0, x_ws.p, x_bytes));
-            have_sq = true;
+            // x += t p, r -= t q, z = M^-1 r_new in ONE kernel; <r,z> and ||r||^2 of the new
+            // vectors go into the group that is `cur` next
+            CK(gkoc_x_cg_step_2_jacobi_apply_f64_i32(s, num_blocks, n, bs, scheme, block_ptrs.p, blocks.p, x.p, r.p,
+                                                     p.p, q.p, beta, cur, stop.p, z.p, prev, prev + 1, 0, x_ws.p,
+                                                     x_bytes));
+            have_next = true;
             std::swap(cur, prev);
         }
     } else {

@@ -822,6 +822,150 @@ __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
     }
 }
 
+// cg::step_2 fused with the preconditioner application that follows it in the next iteration
+// (cg.cpp:167-171, then :133-136; one column, unit strides, fast-path layout):
+//   t = rho / beta ;  x += t p ;  r -= t q ;  z = M r ;  partials of <r, z> and <r, r>.
+// The new residual goes from the registers that computed it straight into the block
+// product - r is not read again, and one launch (plus one fold) disappears from the iteration.
+// x, r, z are bit-identical to step_2 followed by simple_apply (same operations per element:
+// separate multiply and add, the block row sum in column order).  A stopped column leaves x
+// and r alone and recomputes the same z, as the two separate kernels do.
+template <typename T, typename I, int BO, int GPW>
+__global__ __launch_bounds__(256) void jacobi_step2_apply_kernel(
+    int64_t num_blocks, int64_t num_groups, int64_t group_offset,
+    const I* __restrict__ block_ptrs, const T* __restrict__ blocks, T* __restrict__ x,
+    T* __restrict__ r, const T* __restrict__ p, const T* __restrict__ q,
+    const T* __restrict__ beta_p, const T* __restrict__ rho_p, const uint8_t* __restrict__ stop,
+    T* __restrict__ z, T* __restrict__ partial, int64_t pstride)
+{
+    __shared__ T lds[4];
+    constexpr int LOG_BO = BO == 1 ? 0 : BO == 2 ? 1 : BO == 4 ? 2 : BO == 8 ? 3 : 4;
+    constexpr int GP = 6 - LOG_BO;
+    const int lane = threadIdx.x & 63;
+    const int rr = lane & (BO - 1);
+    const int lane0 = lane - rr;
+    const int64_t wg = blockIdx.x;
+    const int64_t group0 = (wg * 4 + (threadIdx.x >> 6)) * GPW;
+    const T bt = beta_p[0];
+    const bool noop = bt == T(0) || status_has_stopped(stop[0]);
+    const T tmp = noop ? T(0) : rho_p[0] / bt;
+    T m[GPW][BO];
+    T rv[GPW], xv[GPW], pv[GPW], qv[GPW];
+    int64_t row[GPW];
+    int bs[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int64_t group = group0 + g;
+        const int64_t blk = (group << GP) + (lane >> LOG_BO);
+        const bool have = group < num_groups && blk < num_blocks;
+        I start = 0, end = 0;
+        if (have) {
+            start = block_ptrs[blk];
+            end = block_ptrs[blk + 1];
+        }
+        bs[g] = have && rr < int(end - start) ? int(end - start) : 0;
+        row[g] = int64_t(start) + rr;
+    }
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const T* gp = blocks + group_offset * (group0 + g) + lane;
+        rv[g] = xv[g] = pv[g] = qv[g] = T(0);
+        if (bs[g] > 0) {
+            rv[g] = r[row[g]];
+            if (!noop) {
+                xv[g] = x[row[g]];
+                pv[g] = p[row[g]];
+                qv[g] = q[row[g]];
+            }
+#pragma unroll
+            for (int c = 0; c < BO; ++c) m[g][c] = gp[c * 64];
+        } else {
+#pragma unroll
+            for (int c = 0; c < BO; ++c) m[g][c] = T(0);
+        }
+    }
+    T dot_acc = T(0), nrm_acc = T(0);
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        if (!noop && bs[g] > 0) {
+            const T tx = tmp * pv[g];
+            const T tr = tmp * qv[g];
+            xv[g] = xv[g] + tx;
+            rv[g] = rv[g] - tr;
+            x[row[g]] = xv[g];
+            r[row[g]] = rv[g];
+        }
+        T sum = T(0);
+#pragma unroll
+        for (int c = 0; c < BO; ++c) {
+            const T bc = __shfl(rv[g], lane0 + c, 64);
+            const T t = m[g][c] * bc;
+            sum = c < bs[g] ? sum + t : sum;
+        }
+        if (bs[g] > 0) {
+            z[row[g]] = sum;
+            dot_acc += rv[g] * sum;
+            nrm_acc += rv[g] * rv[g];
+        }
+    }
+    const T s0 = block_sum<256>(dot_acc, lds);
+    __syncthreads();
+    const T s1 = block_sum<256>(nrm_acc, lds);
+    if (threadIdx.x == 0) {
+        partial[wg] = s0;
+        partial[pstride + wg] = s1;
+    }
+}
+
+template <typename T, typename I>
+int launch_step2_apply(gkoc_stream_t s, int64_t num_blocks, int64_t n_rows, uint32_t max_bs,
+                       gkoc_jacobi_scheme scheme, const I* block_ptrs, const T* blocks, T* x, T* r,
+                       const T* p, const T* q, const T* beta, const T* rho, const uint8_t* stop,
+                       T* z, T* rho_out, T* norm_out, int take_sqrt, void* work, size_t work_bytes)
+{
+    GKOC_REQUIRE(rho_out && norm_out, GKOC_E_INVALID, "null result");
+    GKOC_REQUIRE(num_blocks > 0 && n_rows > 0, GKOC_E_INVALID, "empty system");
+    GKOC_REQUIRE(block_ptrs && blocks && x && r && p && q && beta && rho && stop && z && work,
+                 GKOC_E_INVALID, "null pointer");
+    const int64_t bo = scheme.block_offset;
+    GKOC_REQUIRE(bo >= 1 && bo <= 16 && (bo << scheme.group_power) == 64 && (bo & (bo - 1)) == 0,
+                 GKOC_E_NOT_SUPPORTED,
+                 "fused step_2 + apply needs block_offset in {1,2,4,8,16} and a 64-wide group");
+    GKOC_REQUIRE(max_bs <= uint64_t(bo), GKOC_E_INVALID, "max_block_size exceeds block_offset");
+    GKOC_REQUIRE(work_bytes >= fused_workspace_bytes(n_rows, sizeof(T)), GKOC_E_WORKSPACE,
+                 "workspace too small (gkoc_x_workspace_bytes)");
+    const int64_t groups = ceildiv(num_blocks, int64_t(1) << scheme.group_power);
+    // groups per wave as in the plain fused apply + dot: the partial sums then group the same
+    // rows, and <r, z> comes out with the same bits
+    const int gpw = (bo * int64_t(sizeof(T)) >= 128) ? 1 : 2;
+    const int64_t nb = ceildiv(groups, 4 * gpw);
+    // workspace of gkoc_x_workspace_bytes: [two rows of partials | 2 * fold_chunks of scratch]:
+    // (n + 63) / 64 + 4096 + fold_chunks values; a row needs n / 64 at most (one partial per 8
+    // groups of 8+ rows)
+    const int64_t total = int64_t(fused_workspace_bytes(n_rows, sizeof(T)) / sizeof(T));
+    const int64_t pstride = (total - 2 * fold_chunks) / 2;
+    GKOC_REQUIRE(nb <= pstride, GKOC_E_INVALID, "n_rows does not match the block count");
+    T* partial = static_cast<T*>(work);
+    T* scratch = partial + 2 * pstride;
+    const int64_t go = scheme.group_offset;
+#define GKOC_JAC_S2(BO_)                                                                          \
+    jacobi_step2_apply_kernel<T, I, BO_, ((BO_ * sizeof(T) >= 128) ? 1 : 2)>                        \
+        <<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(num_blocks, groups, go, block_ptrs,     \
+                                                             blocks, x, r, p, q, beta, rho, stop, z, \
+                                                             partial, pstride)
+    switch (int(bo)) {
+    case 1: GKOC_JAC_S2(1); break;
+    case 2: GKOC_JAC_S2(2); break;
+    case 4: GKOC_JAC_S2(4); break;
+    case 8: GKOC_JAC_S2(8); break;
+    default: GKOC_JAC_S2(16); break;
+    }
+#undef GKOC_JAC_S2
+    GKOC_LAUNCH_OK();
+    // <r, z> through the tree of gkoc_x_jacobi_simple_apply_dot: the same bits as the unfused pair
+    return fold_partials2<T>(s, nb, pstride, partial, scratch, rho_out, norm_out, take_sqrt ? 1 : -1);
+}
+
 inline int jacobi_xcd_map(int64_t n_workgroups)
 {
     return (tune_value(GKOC_TUNE_JACOBI_XCD_MAP) != 0 && n_workgroups >= 8 * 256) ? 1 : 0;
@@ -1117,6 +1261,19 @@ using namespace gkoc;
         return launch_apply_dot<T, I>(s, num_blocks, n_rows, max_block_size,   \
                                       scheme, block_ptrs, blocks, b, x,        \
                                       dot_out, work, work_bytes);              \
+    }                                                                          \
+    extern "C" int gkoc_x_cg_step_2_jacobi_apply_##TN##_##IN(                  \
+        gkoc_stream_t s, int64_t num_blocks, int64_t n_rows,                   \
+        uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
+        const I* block_ptrs, const T* blocks, T* x, T* r, const T* p,          \
+        const T* q, const T* beta, const T* rho, const uint8_t* stop_status,   \
+        T* z, T* rho_out, T* norm_out, int take_sqrt, void* work,              \
+        size_t work_bytes)                                                     \
+    {                                                                          \
+        return launch_step2_apply<T, I>(s, num_blocks, n_rows, max_block_size, \
+                                        scheme, block_ptrs, blocks, x, r, p,   \
+                                        q, beta, rho, stop_status, z, rho_out, \
+                                        norm_out, take_sqrt, work, work_bytes); \
     }                                                                          \
     extern "C" int gkoc_jacobi_apply_##TN##_##IN(                              \
         gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,          \

@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "elementwise.hpp"
+#include "fused.hpp"
 
 namespace gkoc {
 namespace {
@@ -744,20 +745,6 @@ __global__ __launch_bounds__(256) void pipe_cg_step1_dots_kernel(
         partial[pstride + blockIdx.x] = s1;
         partial[2 * pstride + blockIdx.x] = s2;
     }
-}
-
-// out[k] = sum of partial[k * pstride .. + count), k = blockIdx.x (fixed tree)
-template <typename T>
-__global__ __launch_bounds__(1024) void fold_rows_kernel(int64_t count, int64_t pstride,
-                                                          const T* __restrict__ partial,
-                                                          T* __restrict__ out)
-{
-    __shared__ T lds[1024 / 64];
-    T acc = T(0);
-    const T* p = partial + int64_t(blockIdx.x) * pstride;
-    for (int64_t i = threadIdx.x; i < count; i += 1024) acc += p[i];
-    const T r = block_sum<1024>(acc, lds);
-    if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
 template <typename T>

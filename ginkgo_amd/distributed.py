@@ -429,6 +429,16 @@ class HipBackend:
              C.c_int(0), w, wb)
         return True
 
+    def cg_step_2_jacobi(self, m, x, r, p, q, beta, rho, stop, z, rho_out, sq_out):
+        """cg::step_2, z = M r_new, rho_out = local <r,z>, sq_out = local ||r||^2 in one kernel
+        (gkoc_x_cg_step_2_jacobi_apply_*); False if this preconditioner layout has no such kernel"""
+        if not (hasattr(m, "can_fuse_step_2") and m.can_fuse_step_2(r) and
+                all(v.ld == 1 and v.size[1] == 1 for v in (x, r, p, q, z))):
+            return False
+        w, _ = self._xwork(x.size[0], x.dtype)
+        m.step_2_apply_dot(x, r, p, q, beta, rho, stop, z, rho_out, sq_out, False, w)
+        return True
+
     def local_sqnorm(self, x, out):
         x.compute_squared_norm2(out)
 
@@ -597,9 +607,10 @@ class DistributedCg:
       check_lag = 0 is the reference's lock-step behaviour."""
 
     def __init__(self, backend, comm, matrix, max_iters, reduction_factor=1e-10,
-                 max_block_size=8, check_lag=None, fused=True, taped=True):
+                 max_block_size=8, check_lag=None, fused=True, taped=True, fused_step_2=True):
         self.be, self.comm, self.a = backend, comm, matrix
         self.taped = bool(taped)
+        self.fused_step_2 = bool(fused_step_2)
         self.max_iters, self.factor = int(max_iters), float(reduction_factor)
         self.m = backend.jacobi(matrix.local, max_block_size) if max_block_size else None
         self.num_iterations = 0
@@ -651,27 +662,35 @@ class DistributedCg:
         pending = deque()
         fused = self.fused and hasattr(be, "cg_step_2_sqnorm")
 
+        # have_sq: 0 nothing of the coming iteration exists yet, 1 ||r||^2 does (step_2 + norm),
+        # 2 z, <r,z> and ||r||^2 do (step_2 + preconditioner in one kernel)
         def seg_a(cur, have_sq):
             pair, rho, tau = cur
-            if not (self.m is not None and fused and be.jacobi_apply_dot(self.m, r, z, rho)):
-                if self.m is not None:
-                    self.m.apply(r, z)
-                else:
-                    z.copy_from(r)
-                be.local_dot(r, z, rho)
-            if not have_sq:
-                be.local_sqnorm(r, tau)
+            if have_sq < 2:
+                if not (self.m is not None and fused and be.jacobi_apply_dot(self.m, r, z, rho)):
+                    if self.m is not None:
+                        self.m.apply(r, z)
+                    else:
+                        z.copy_from(r)
+                    be.local_dot(r, z, rho)
+                if not have_sq:
+                    be.local_sqnorm(r, tau)
             self.comm.all_reduce_sum_(pair)    # one message: [<r,z>, ||r||^2]
+
+        fused_s2 = fused and self.m is not None and hasattr(be, "cg_step_2_jacobi") and self.fused_step_2
 
         def seg_b(cur, prev):
             be.cg_step_1(p, z, cur[1], prev[1], self.stop)
             a.apply(p, q)
             self._dot(p, q, beta)
-            # the pair that is `cur` in the next iteration receives ||r_new||^2
+            # the pair that is `cur` in the next iteration receives <r_new, z_new> and ||r_new||^2
+            if fused_s2 and be.cg_step_2_jacobi(self.m, x, r, p, q, beta, cur[1], self.stop, z,
+                                                prev[1], prev[2]):
+                return 2
             hs = fused and be.cg_step_2_sqnorm(x, r, p, q, beta, cur[1], self.stop, prev[2])
             if not hs:
                 be.cg_step_2(x, r, p, q, beta, cur[1], self.stop)
-            return hs
+            return 1 if hs else 0
 
         # The two halves of an iteration touch the same buffers every second
         # iteration (the [rho, tau] pairs alternate): each variant is recorded the
@@ -690,7 +709,7 @@ class DistributedCg:
             tapes[key] = t
             return t.result
 
-        have_sq = False
+        have_sq = 0
         it = -1
         while True:
             parity = (it + 1) & 1

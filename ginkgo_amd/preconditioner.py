@@ -246,6 +246,27 @@ class Jacobi(LinOp):
              self.block_pointers, self.blocks, b.values, x.values, dot_out.values,
              work, C.c_size_t(work.numel() * work.element_size()))
 
+    def can_fuse_step_2(self, b):
+        """the fused step_2 + apply keeps two rows of per-workgroup partial sums in the workspace of
+        gkoc_x_workspace_bytes: enough unless the blocks are tiny (< 2 rows on average)"""
+        if not self.can_fuse_dot(b) or self.max_block_size == 1:
+            return False
+        groups = -(-self.num_blocks // (1 << self.scheme.group_power))
+        per_wave = 1 if self.scheme.block_offset * b.values.element_size() >= 128 else 2
+        n_partials = -(-groups // (4 * per_wave))
+        return n_partials <= ((self.size[0] + 63) // 64 + 4096 - 1024) // 2
+
+    def step_2_apply_dot(self, x, r, p, q, beta, rho, stop_status, z, rho_out, norm_out, take_sqrt,
+                         work):
+        """cg::step_2 (x += t p, r -= t q, t = rho / beta) and z = M r in one kernel, with
+        rho_out = <r, z> and norm_out = ||r||^2 (||r|| with take_sqrt); same layouts as apply_dot
+        (gkoc_x_cg_step_2_jacobi_apply_*).  x, r, z as from step_2 followed by apply, bit for bit."""
+        call("gkoc_x_cg_step_2_jacobi_apply_" + self._suf, self.exec.stream, self.num_blocks,
+             self.size[0], C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
+             self.blocks, x.values, r.values, p.values, q.values, beta.values, rho.values,
+             stop_status, z.values, rho_out.values, norm_out.values, C.c_int(1 if take_sqrt else 0),
+             work, C.c_size_t(work.numel() * work.element_size()))
+
     def apply_advanced_impl(self, alpha, b, beta, x):
         ex = self.exec
         if self.max_block_size == 1:

@@ -197,6 +197,13 @@ class Cg(_IterativeSolver):
         have_tau = False
         pending = deque()
         it = -1
+        # step_2 of iteration k and the preconditioner application of iteration k+1 in ONE kernel
+        # (gkoc_x_cg_step_2_jacobi_apply_*): the new residual goes from the registers that computed
+        # it into the block product; x, r, z, the iteration count and the stop status are those of
+        # the separate kernels bit for bit.  with_fused_step_2_apply(False) turns it off.
+        fuse_s2 = fuse_prec and fuse_norm and m.can_fuse_step_2(r) and \
+            bool(self.params.get("fused_step_2_apply", True))
+        have_z = False     # z and rho of the coming iteration are already there
 
         def precond_and_rho(rho_):
             if fuse_prec:
@@ -213,7 +220,11 @@ class Cg(_IterativeSolver):
             else:
                 a.apply(p, q)
                 p.compute_conj_dot(q, beta)
-            if fuse_norm:
+            if fuse_s2 and not in_graph[0]:
+                # also z = M r_new and the NEXT iteration's rho, written over prev_rho
+                # (step_1 above was its last reader)
+                m.step_2_apply_dot(x, r, p, q, beta, rho_, stop_status, z, prev_rho_, tau, True, work)
+            elif fuse_norm:
                 call("gkoc_x_cg_step_2_norm_" + suf, ex.stream, rows, x.values, r.values,
                      p.values, q.values, beta.values, rho_.values, stop_status, tau.values,
                      C.c_int(1), work, C.c_size_t(work.numel() * work.element_size()))
@@ -230,6 +241,9 @@ class Cg(_IterativeSolver):
         # replay and read `check_lag` iterations later, exactly like the eager path.
         self._graph_x_ptr = x.values.data_ptr()
         graph = self._graph_setup(crit, fuse_norm, lag, rows, cols) if fuse_norm else None
+        in_graph = [graph is not None]     # the captured iterations keep the two-kernel sequence
+        if graph is not None:
+            fuse_s2 = False
         while True:
             if graph is not None and have_tau and it + 2 < graph["max_iters"]:
                 graph["exec"] = self._graph_capture(
@@ -249,7 +263,9 @@ class Cg(_IterativeSolver):
                     it = stopped
                     break
                 continue
-            if fuse_prec:
+            if have_z:
+                pass                                   # the fused step_2 left z and rho
+            elif fuse_prec:
                 m.apply_dot(r, z, rho, work)
             else:
                 m.apply(r, z)
@@ -272,6 +288,7 @@ class Cg(_IterativeSolver):
                 break
             update(rho, prev_rho)
             have_tau = fuse_norm
+            have_z = fuse_s2
             prev_rho, rho = rho, prev_rho
         self.num_iterations = it
         self.stop_status = stop_status

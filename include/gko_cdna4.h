@@ -877,7 +877,19 @@ GKOC_DECL_X(float, f32)
         gkoc_stream_t s, int64_t num_blocks, int64_t n_rows,                   \
         uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
         const I* block_ptrs, const T* blocks, const T* b, T* x, T* dot_out,    \
-        void* work, size_t work_bytes);
+        void* work, size_t work_bytes);                                        \
+    /* cg::step_2 and the preconditioner application of the NEXT iteration in    \
+     * one kernel (cg.cpp:167-171 + :133-136): t = rho / beta, x += t p,          \
+     * r -= t q, z = M r, rho_out = <r, z>, norm_out = ||r||^2 (or ||r|| with     \
+     * take_sqrt).  x, r, z bit-identical to step_2 followed by simple_apply;     \
+     * rho_out must not alias rho.  Fast-path block layout, one column. */        \
+    int gkoc_x_cg_step_2_jacobi_apply_##TN##_##IN(                             \
+        gkoc_stream_t s, int64_t num_blocks, int64_t n_rows,                   \
+        uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
+        const I* block_ptrs, const T* blocks, T* x, T* r, const T* p,          \
+        const T* q, const T* beta, const T* rho, const uint8_t* stop_status,   \
+        T* z, T* rho_out, T* norm_out, int take_sqrt, void* work,              \
+        size_t work_bytes);
 GKOC_DECL_XI(double, f64, int32_t, i32)
 GKOC_DECL_XI(double, f64, int64_t, i64)
 GKOC_DECL_XI(float, f32, int32_t, i32)

@@ -829,3 +829,72 @@ def test_jacobi_adaptive_cg(gexec, oracle):
         if adaptive:     # well-conditioned 8 x 8 blocks: half storage everywhere
             assert set(s.preconditioner.precisions.cpu().numpy().tolist()) == {0x02}
     assert abs(its[0] - its[1]) <= 3
+
+
+@pytest.mark.parametrize("max_bs", [2, 4, 8, 16])
+def test_fused_step_2_jacobi_apply(gexec, oracle, max_bs):
+    """gkoc_x_cg_step_2_jacobi_apply: x, r as cg::step_2 (oracle), z as jacobi::simple_apply of the
+    new r (oracle), bit for bit; <r,z> with the bits of the unfused apply + dot; ||r||; a zero beta
+    and a stopped column leave x and r alone and still produce z"""
+    import ctypes as C
+    from ginkgo_amd._lib import call
+    import ginkgo_amd as g
+    rng = np.random.default_rng(max_bs)
+    sizes = rng.integers(1, max_bs + 1, 3000)
+    a = _block_matrix(max_bs, sizes)
+    n = a.shape[0]
+    rp, ci, v = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
+    jac = g.Jacobi.build().with_max_block_size(max_bs).on(gexec).generate(
+        g.Csr.from_arrays(gexec, (n, n), rp, ci, v))
+    nb, ptrs = oracle.jacobi_find_blocks(rp, ci, max_bs)
+    scheme = oracle.jacobi_storage_scheme(max_bs)
+    blocks = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
+    x0, r0, p, q = (rng.uniform(-1, 1, n) for _ in range(4))
+    work, nbytes = _xwork(gexec, n)
+    assert jac.can_fuse_step_2(g.Dense.from_numpy(gexec, r0))
+    for beta, stopped in ((0.37, 0), (0.0, 0), (0.37, 0x81)):
+        x, r = g.Dense.from_numpy(gexec, x0), g.Dense.from_numpy(gexec, r0)
+        z = g.Dense.from_numpy(gexec, np.full(n, np.nan))
+        rho_out, nrm = g.Dense.create(gexec, (1, 1)), g.Dense.create(gexec, (1, 1))
+        stop = gexec.to_device(np.array([stopped], np.uint8))
+        jac.step_2_apply_dot(x, r, g.Dense.from_numpy(gexec, p), g.Dense.from_numpy(gexec, q),
+                             g.scalar(gexec, beta), g.scalar(gexec, 0.81), stop, z, rho_out, nrm, True, work)
+        ox, orr = oracle.cg_step_2(x0.copy(), r0.copy(), p.copy(), q.copy(), np.array([beta]),
+                                   np.array([0.81]), np.array([stopped], np.uint8))
+        assert np.array_equal(x.to_numpy()[:, 0], ox.reshape(-1))
+        assert np.array_equal(r.to_numpy()[:, 0], orr.reshape(-1))
+        oz = oracle.jacobi_apply(nb, scheme, ptrs, blocks, orr.reshape(-1, 1))[:, 0]
+        assert np.array_equal(z.to_numpy()[:, 0], oz)
+        # the unfused pair on the same r: identical <r,z> bits, ||r|| to the tree's tolerance
+        z2, rho2 = g.Dense.create(gexec, (n, 1)), g.Dense.create(gexec, (1, 1))
+        jac.apply_dot(r, z2, rho2, work)
+        assert np.array_equal(rho_out.to_numpy(), rho2.to_numpy())
+        nr = np.linalg.norm(orr)
+        assert abs(nrm.to_numpy()[0, 0] - nr) <= 1e-13 * nr
+
+
+@pytest.mark.parametrize("bs", [4, 8])
+def test_cg_fused_step_2_apply_changes_nothing(gexec, bs):
+    """CG with step_2 and the next preconditioner application in one kernel against the
+    two-kernel sequence: x bit-identical, same iteration count and stop status"""
+    import ginkgo_amd as g
+    grid = 22
+    n = grid ** 3
+    a = g.stencil_csr(gexec, 3, grid)
+    rhs = np.random.default_rng(8).uniform(-1, 1, n)
+    res = {}
+    for fused in (False, True):
+        for max_it in (1000, 9):
+            s = (g.Cg.build().with_fused_step_2_apply(fused).with_hip_graph(False).with_criteria(
+                g.stop.Iteration.build().with_max_iters(max_it),
+                g.stop.ResidualNorm.build().with_reduction_factor(1e-10))
+                .with_preconditioner(g.Jacobi.build().with_max_block_size(bs)).on(gexec).generate(a))
+            x = g.Dense.from_numpy(gexec, np.zeros(n))
+            s.apply(g.Dense.from_numpy(gexec, rhs), x)
+            res[(fused, max_it)] = (s.num_iterations, s.has_converged, x.to_numpy(),
+                                    s.stop_status.cpu().numpy())
+    for max_it in (1000, 9):
+        e, f = res[(False, max_it)], res[(True, max_it)]
+        assert e[0] == f[0] and e[1] == f[1]
+        assert np.array_equal(e[2], f[2]) and np.array_equal(e[3], f[3])
+    assert res[(True, 1000)][1] and res[(True, 9)][0] == 9
