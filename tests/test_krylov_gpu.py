@@ -831,8 +831,9 @@ def test_jacobi_adaptive_cg(gexec, oracle):
     assert abs(its[0] - its[1]) <= 3
 
 
+@pytest.mark.parametrize("itype", [np.int32, np.int64])
 @pytest.mark.parametrize("max_bs", [2, 4, 8, 16])
-def test_fused_step_2_jacobi_apply(gexec, oracle, max_bs):
+def test_fused_step_2_jacobi_apply(gexec, oracle, max_bs, itype):
     """gkoc_x_cg_step_2_jacobi_apply: x, r as cg::step_2 (oracle), z as jacobi::simple_apply of the
     new r (oracle), bit for bit; <r,z> with the bits of the unfused apply + dot; ||r||; a zero beta
     and a stopped column leave x and r alone and still produce z"""
@@ -845,7 +846,7 @@ def test_fused_step_2_jacobi_apply(gexec, oracle, max_bs):
     n = a.shape[0]
     rp, ci, v = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
     jac = g.Jacobi.build().with_max_block_size(max_bs).on(gexec).generate(
-        g.Csr.from_arrays(gexec, (n, n), rp, ci, v))
+        g.Csr.from_arrays(gexec, (n, n), rp.astype(itype), ci.astype(itype), v))
     nb, ptrs = oracle.jacobi_find_blocks(rp, ci, max_bs)
     scheme = oracle.jacobi_storage_scheme(max_bs)
     blocks = oracle.jacobi_generate(rp, ci, v, nb, scheme, ptrs)
