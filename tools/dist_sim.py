@@ -34,6 +34,12 @@ class FakeComm:
     def all_reduce_sum_(self, t):
         return t
 
+    def all_reduce_begin(self, t, side_stream=None):
+        return t
+
+    def all_reduce_end(self):
+        pass
+
     def all_to_all_counts(self, send_counts):
         return list(send_counts)
 
@@ -68,8 +74,10 @@ for _ in range(50):
 e1.record()
 torch.cuda.synchronize()
 print(f"distributed SpMV (pack + copy-exchange on 2nd stream || local + boundary rows): {e0.elapsed_time(e1)*20:.1f} us")
-for fused in (False, True):
-    s = gd.DistributedCg(be, FakeComm(), a, iters, 1e-300, 8, fused=fused)
+for fused, s2, cls in ((False, False, gd.DistributedCg), (True, False, gd.DistributedCg),
+                       (True, True, gd.DistributedCg), (True, True, gd.DistributedPipeCg)):
+    kw = dict(fused_step_2=s2) if cls is gd.DistributedCg else {}
+    s = cls(be, FakeComm(), a, iters, 1e-300, 8, fused=fused, **kw)
     rhs = be.vector_from(np.ones(hi - lo))
     xs = be.vector(hi - lo)
     s.apply(rhs, xs)
@@ -79,7 +87,7 @@ for fused in (False, True):
     s.apply(rhs, xs)
     torch.cuda.synchronize()
     t = time.perf_counter() - t
-    print(f"DistributedCg fused={fused!s:5s}: {s.num_iterations} its, {t*1e6/max(s.num_iterations,1):8.1f} us/it "
+    print(f"{cls.__name__:18s} fused={fused!s:5s} step_2+jacobi={s2!s:5s}: {s.num_iterations} its, {t*1e6/max(s.num_iterations,1):8.1f} us/it "
           f"(device side, no RCCL latency) -> {max(s.num_iterations,1)/t:8.1f} it/s")
 
 # ---- pieces of the distributed SpMV
