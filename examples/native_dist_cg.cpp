@@ -296,18 +296,34 @@ try {
         if (mirror) CK(gkoc_dense_scale_f64(s, 1, pending_cnt, two, 1, pending_reduce, pending_cnt));
     };
     // y = A[owned rows, :] v   (distributed::Matrix::apply_impl, matrix.cpp:450-509)
-    auto dist_apply = [&](const double* v, double* y) {
+    // dot != nullptr: also the LOCAL part of <v, y> (fused into the local SpMV, the boundary rows'
+    // share next to their update)
+    dev_array<double> nl_dot_ws(size_t((n_nl_rows + 63) / 64 + 1));
+    auto dist_apply = [&](const double* v, double* y, double* dot = nullptr) {
         if (world > 1) {
             scoped t{spent[T_EXCHANGE]};
             CK(gkoc_comm_exchange_begin(comm, s, side, v, send_counts.data(), send_displs.data(),
                                         halo.p, recv_counts.data(), sizeof(double)));
         }
-        CK(gkoc_csr_spmv_f64_i32(s, n, n, local_ptrs.p, local_cols->p, local_vals->p, v, 1, y, 1, 1));
+        if (dot) {
+            CK(gkoc_x_csr_spmv_dot_f64_i32(s, n, local_ptrs.p, local_cols->p, local_vals->p, v, y, dot, x_ws.p,
+                                           x_bytes));
+        } else {
+            CK(gkoc_csr_spmv_f64_i32(s, n, n, local_ptrs.p, local_cols->p, local_vals->p, v, 1, y, 1, 1));
+        }
         if (world > 1) {
-            scoped t{spent[T_EXCHANGE]};
-            CK(gkoc_comm_exchange_end(comm, s));
-            CK(gkoc_csr_rowlist_spmv_add_f64_i32(s, n_nl_rows, nl_rows->p, nl_ptrs->p, nl_cols->p,
-                                                 nl_vals->p, halo.p, 1, y, 1, 1));
+            {
+                scoped t{spent[T_EXCHANGE]};
+                CK(gkoc_comm_exchange_end(comm, s));
+            }
+            if (dot) {
+                CK(gkoc_x_csr_rowlist_spmv_add_dot_f64_i32(s, n_nl_rows, nl_rows->p, nl_ptrs->p, nl_cols->p,
+                                                           nl_vals->p, halo.p, y, v, dot, nl_dot_ws.p,
+                                                           sizeof(double) * nl_dot_ws.n));
+            } else {
+                CK(gkoc_csr_rowlist_spmv_add_f64_i32(s, n_nl_rows, nl_rows->p, nl_ptrs->p, nl_cols->p,
+                                                     nl_vals->p, halo.p, 1, y, 1, 1));
+            }
         }
     };
     auto precond = [&](const double* src, double* dst) {
@@ -382,8 +398,13 @@ try {
             check_begin(it, cur + 1);
             if (drain(it - lag, stop_it)) { it = stop_it; break; }
             CK(gkoc_cg_step_1_f64(s, n, 1, p.p, 1, z.p, 1, cur, prev, stop.p));
-            dist_apply(p.p, q.p);
-            local_dot(p.p, q.p, beta);
+            if (n >= (int64_t(1) << 22)) {
+                dist_apply(p.p, q.p, beta);                     // q = A p and the local <p, q>
+            } else {
+                // small local parts: the plain SpMV and a separate dot are faster
+                dist_apply(p.p, q.p);
+                local_dot(p.p, q.p, beta);
+            }
             all_reduce(beta, 1);
             // x += t p, r -= t q, z = M^-1 r_new in ONE kernel; <r,z> and ||r||^2 of the new
             // vectors go into the group that is `cur` next

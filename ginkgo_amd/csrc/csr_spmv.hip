@@ -143,8 +143,10 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
     GKOC_REQUIRE(work_bytes >= fused_workspace_bytes(n, sizeof(T)), GKOC_E_WORKSPACE,
                  "workspace too small (gkoc_x_workspace_bytes)");
     constexpr int rows_per_seg = 64;
-    constexpr int segs_per_wave = 2;
     const int64_t n_seg = ceildiv(n, rows_per_seg);
+    // one segment per wave below 4 M rows, as in the plain kernel (a rank's share of a
+    // strong-scaling run is that small: 2.1 M rows at 8 ranks, 255 -> 24x us per CG iteration)
+    const int segs_per_wave = n_seg < 65536 ? 1 : 2;
     const int64_t n_waves = ceildiv(n_seg, segs_per_wave);
     GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED,
                  "more than 2^31 row segments");
@@ -155,17 +157,25 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
         reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
         reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;  // E = 4 below
     const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
+#define GKOC_LAUNCH_DOT(E_, U_, MODE_)                                               \
+    csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, E_, U_, 1024, 1, MODE_>         \
+        <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs, col_idxs, \
+                                           vals, b, 1, c, 1, 1, nullptr, nullptr,    \
+                                           partial, xcd_map)
     if (vec_ok) {
-        csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 4, 1, 1024, 1, 0x2040>
-            <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs,
-                                               col_idxs, vals, b, 1, c, 1, 1,
-                                               nullptr, nullptr, partial, xcd_map);
+        if (segs_per_wave == 2) {
+            GKOC_LAUNCH_DOT(4, 1, 0x2040);
+        } else {
+            GKOC_LAUNCH_DOT(4, 1, 0x1040);
+        }
     } else {
-        csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, 1, 4, 1024, 1, 0x2040>
-            <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs,
-                                               col_idxs, vals, b, 1, c, 1, 1,
-                                               nullptr, nullptr, partial, xcd_map);
+        if (segs_per_wave == 2) {
+            GKOC_LAUNCH_DOT(1, 4, 0x2040);
+        } else {
+            GKOC_LAUNCH_DOT(1, 4, 0x1040);
+        }
     }
+#undef GKOC_LAUNCH_DOT
     GKOC_LAUNCH_OK();
     return fold_partials<T>(s, n_waves, partial, scratch, dot_out, false);
 }

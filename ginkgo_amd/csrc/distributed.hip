@@ -119,12 +119,14 @@ __global__ __launch_bounds__(256) void dist_row_list_kernel(
 // read-modify-write of y is coalesced as well.
 constexpr int rl_stage_cap = 2048;
 
-template <typename T, typename I>
+// DOT: one column; additionally partial[block] = sum over the block's rows of xdot[row] * (what
+// was added to y[row]) - the non-local part of <x, A x> next to the fused local SpMV + dot
+template <typename T, typename I, bool DOT = false>
 __global__ __launch_bounds__(64) void csr_rowlist_add_kernel(
     int64_t n_list, const I* __restrict__ rows, const I* __restrict__ ptrs,
     const I* __restrict__ cols, const T* __restrict__ vals,
     const T* __restrict__ halo, int64_t ld_halo, T* __restrict__ y, int64_t ldy,
-    int nrhs)
+    int nrhs, const T* __restrict__ xdot = nullptr, T* __restrict__ partial = nullptr)
 {
     __shared__ T lv[rl_stage_cap];
     __shared__ I lc[rl_stage_cap];
@@ -143,10 +145,12 @@ __global__ __launch_bounds__(64) void csr_rowlist_add_kernel(
         }
         wave_lds_sync();
     }
-    if (!valid) return;
-    const int64_t row = rows[i];
-    for (int j = 0; j < nrhs; ++j) {
-        T sum = y[row * ldy + j];
+    T dot_acc = T(0);
+    if (!valid && !DOT) return;
+    const int64_t row = valid ? int64_t(rows[i]) : 0;
+    for (int j = 0; valid && j < nrhs; ++j) {
+        const T y0 = y[row * ldy + j];
+        T sum = y0;
         int64_t k = ks;
         // eight gathers in flight, products added in k order
         for (; k + 8 <= ke; k += 8) {
@@ -166,7 +170,24 @@ __global__ __launch_bounds__(64) void csr_rowlist_add_kernel(
             sum += v * halo[int64_t(c) * ld_halo + j];
         }
         y[row * ldy + j] = sum;
+        if (DOT) dot_acc += xdot[row] * (sum - y0);
     }
+    if (DOT) {
+        dot_acc = wave_sum(dot_acc);
+        if (lane == 0) partial[blockIdx.x] = dot_acc;
+    }
+}
+
+// inout[0] += sum of partial[0 .. count) (fixed tree)
+template <typename T>
+__global__ __launch_bounds__(1024) void add_partials_kernel(int64_t count, const T* __restrict__ partial,
+                                                            T* __restrict__ inout)
+{
+    __shared__ T lds[1024 / 64];
+    T acc = T(0);
+    for (int64_t t = threadIdx.x; t < count; t += 1024) acc += partial[t];
+    const T r = block_sum<1024>(acc, lds);
+    if (threadIdx.x == 0) inout[0] += r;
 }
 
 inline dim3 grid_for(int64_t n) { return dim3(unsigned(ceildiv(n > 0 ? n : 1, 256))); }
@@ -279,6 +300,27 @@ GKOC_DEF_DIST_IDX(int64_t, i64)
                                 local_row_ptrs, nl_row_ptrs_full, local_cols,  \
                                 local_vals, nl_rows, nl_ptrs, nl_cols,         \
                                 nl_vals, recv_gidx);                           \
+    }                                                                          \
+    extern "C" int gkoc_x_csr_rowlist_spmv_add_dot_##TN##_##IN(                \
+        gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \
+        const I* cols, const T* vals, const T* halo, T* y, const T* x,         \
+        T* dot_inout, void* work, size_t work_bytes)                           \
+    {                                                                          \
+        if (n_list <= 0) return GKOC_OK;                                       \
+        GKOC_REQUIRE(rows && ptrs && halo && y && x && dot_inout && work,      \
+                     GKOC_E_INVALID, "null pointer");                          \
+        const int64_t nb = ceildiv(n_list, 64);                                \
+        GKOC_REQUIRE(work_bytes >= size_t(nb) * sizeof(T), GKOC_E_WORKSPACE,   \
+                     "workspace too small (one value per 64 listed rows)");    \
+        csr_rowlist_add_kernel<T, I, true>                                     \
+            <<<dim3(unsigned(nb)), dim3(64), 0, as_stream(s)>>>(               \
+                n_list, rows, ptrs, cols, vals, halo, 1, y, 1, 1, x,           \
+                static_cast<T*>(work));                                        \
+        GKOC_LAUNCH_OK();                                                      \
+        add_partials_kernel<T><<<dim3(1), dim3(1024), 0, as_stream(s)>>>(      \
+            nb, static_cast<const T*>(work), dot_inout);                       \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
     }                                                                          \
     extern "C" int gkoc_csr_rowlist_spmv_add_##TN##_##IN(                      \
         gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \

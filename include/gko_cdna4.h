@@ -822,7 +822,14 @@ GKOC_DECL_DIST_IDX(int64_t, i64)
     int gkoc_csr_rowlist_spmv_add_##TN##_##IN(                                 \
         gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \
         const I* cols, const T* vals, const T* halo, int64_t ld_halo, T* y,    \
-        int64_t ldy, int64_t nrhs);
+        int64_t ldy, int64_t nrhs);                                            \
+    /* the same for one column, plus dot_inout += sum_rows x[row] * (what was    \
+     * added to y[row]): the non-local part of <x, A x>, to go with              \
+     * gkoc_x_csr_spmv_dot on the local block.  work: 8 bytes per 64 listed rows */ \
+    int gkoc_x_csr_rowlist_spmv_add_dot_##TN##_##IN(                           \
+        gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \
+        const I* cols, const T* vals, const T* halo, T* y, const T* x,         \
+        T* dot_inout, void* work, size_t work_bytes);
 GKOC_DECL_DIST(double, f64, int32_t, i32)
 GKOC_DECL_DIST(double, f64, int64_t, i64)
 GKOC_DECL_DIST(float, f32, int32_t, i32)

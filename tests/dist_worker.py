@@ -98,6 +98,17 @@ def main():
         assert abs(solver1.num_iterations - solver.num_iterations) <= 1
         d = np.linalg.norm(xs1.to_numpy() - xs.to_numpy()) / np.linalg.norm(xs.to_numpy())
         assert d < 1e-9, d
+    # --- <p,q> fused into the local SpMV + the boundary rows' share next to their update (the
+    #     default only for large local parts): same iterations, same solution to rounding
+    if mode != "cpu":
+        a.fused_dot_min_rows = 0
+        solver2 = gd.DistributedCg(be, comm, a, 500, 1e-10, 8)
+        xs2 = be.vector(hi - lo)
+        solver2.apply(be.vector_from(np.ones(hi - lo)), xs2)
+        a.fused_dot_min_rows = 1 << 22
+        assert abs(solver2.num_iterations - solver.num_iterations) <= 1
+        d = np.linalg.norm(xs2.to_numpy() - xs.to_numpy()) / np.linalg.norm(xs.to_numpy())
+        assert d < 1e-9, d
     # --- restarted GMRES on the distributed matrix (HIP kernels only)
     if mode != "cpu":
         for ortho in ("mgs", "cgs"):

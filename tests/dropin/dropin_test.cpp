@@ -300,6 +300,56 @@ int main(int argc, char** argv)
         }
     }
 
+    // --- the single-precision instantiations of the same kernels: CbGmres<float> with the basis
+    //     kept in float, half, int32 and int16 (cb_gmres_kernels.hpp:61-74)
+    {
+        using gko::solver::cb_gmres::storage_precision;
+        using DenseF = gko::matrix::Dense<float>;
+        using CsrF = gko::matrix::Csr<float, it>;
+        auto af_ref = gko::share(CsrF::create(ref));
+        a_ref->convert_to(af_ref);
+        auto af_hip = gko::share(gko::clone(hip, af_ref));
+        auto cbf = [&](auto exec, auto a, storage_precision prec, int& iters) {
+            auto rhs = DenseF::create(exec, gko::dim<2>{n, 1});
+            rhs->fill(1.0f);
+            auto x = DenseF::create(exec, gko::dim<2>{n, 1});
+            x->fill(0.0f);
+            auto logger = gko::share(gko::log::Convergence<float>::create());
+            auto solver =
+                gko::solver::CbGmres<float>::build()
+                    .with_krylov_dim(20u)
+                    .with_storage_precision(prec)
+                    .with_criteria(gko::stop::Iteration::build().with_max_iters(300u),
+                                   gko::stop::ResidualNorm<float>::build().with_reduction_factor(1e-4f))
+                    .on(exec)
+                    ->generate(a);
+            solver->add_logger(logger);
+            solver->apply(rhs, x);
+            iters = static_cast<int>(logger->get_num_iterations());
+            return gko::clone(exec->get_master(), x);
+        };
+        const char* names[] = {"keep", "reduce1", "integer", "ireduce1"};
+        int idx = 0;
+        for (auto prec : {storage_precision::keep, storage_precision::reduce1, storage_precision::integer,
+                          storage_precision::ireduce1}) {
+            int it_ref = 0, it_hip = 0;
+            auto x_ref = cbf(ref, af_ref, prec, it_ref);
+            auto x_hip = cbf(hip, af_hip, prec, it_hip);
+            double num = 0, den = 0;
+            for (gko::size_type i = 0; i < n; ++i) {
+                const double d = double(x_hip->at(i, 0)) - double(x_ref->at(i, 0));
+                num += d * d;
+                den += double(x_ref->at(i, 0)) * double(x_ref->at(i, 0));
+            }
+            std::cout << "CbGmres<float>(20, " << names[idx] << "): iterations reference " << it_ref << ", hip "
+                      << it_hip << ", x vs reference " << std::sqrt(num / den) << std::endl;
+            CHECK(std::abs(it_ref - it_hip) <= std::max(2, it_ref / 5),
+                  "CbGmres<float> iteration count close to the reference's");
+            CHECK(std::sqrt(num / den) < 2e-3, "CbGmres<float> solution matches reference");
+            ++idx;
+        }
+    }
+
     // --- Ginkgo's block-Jacobi with a fixed reduced storage precision
     {
         auto x_in = Dense::create(ref, gko::dim<2>{n, 1});
