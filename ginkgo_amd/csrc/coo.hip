@@ -11,11 +11,16 @@
 // is the CSR row sum of the same entries started from c0 - exactly what
 // csr::advanced_spmv computes (sum = beta*c, then += (alpha*val)*b in k order), and
 // multiplying by a literal 1 is exact.  So:
+//   c = A b, one column: ONE pass - the CSR kernel in its COO mode (csr_spmv_pipe.hpp) reads
+//           values, columns and rows together, finds each wave's piece of the entry stream
+//           through a pointer per 64-row segment (bisection of row_idxs) and derives the row
+//           pointers in LDS while it streams; it also proves that the input is sorted;
+//   the operations that read c (advanced_spmv, spmv2, advanced_spmv2) and several columns:
 //   pass 1: row_idxs -> row_ptrs in the workspace, one kernel: one read of row_idxs
 //           (4 B/nnz), every pointer written once by the entry that starts its run; the
 //           same kernel notes whether the rows really are non-decreasing;
 //   pass 2: the production CSR kernel (12 B/nnz) with (alpha, beta) in
-//           {(-, -), (alpha, beta), (1, 1), (alpha, 1)}.
+//           {(alpha, beta), (1, 1), (alpha, 1)}.
 // 16 B/nnz in total - the algorithmic traffic of COO - no atomics, results
 // bit-identical to the reference.  Input whose rows are NOT sorted takes the
 // reference's semantics through a fallback: pass 1 raises a device flag, the row
@@ -23,6 +28,7 @@
 // adds the products (sum order then differs: tolerance instead of bit-identity).
 // Both extra kernels return at once when the flag is not set; no host round trip.
 #include "common.hpp"
+#include "csr_spmv_pipe.hpp"
 #include "scan.hpp"
 
 namespace gkoc {
@@ -169,6 +175,38 @@ __global__ __launch_bounds__(256) void coo_row_ptrs_kernel(int64_t nnz,
     }
 }
 
+// seg_ptrs[s] = first entry whose row index is >= 64 s (bisection of the sorted row_idxs; on
+// unsorted input: some index in [0, nnz], which the product kernel then detects), s = 0 .. n_seg
+template <typename I>
+__global__ __launch_bounds__(256) void coo_segment_ptrs_kernel(int64_t nnz,
+                                                               const I* __restrict__ rows,
+                                                               int64_t n_seg, I* __restrict__ seg_ptrs)
+{
+    const int64_t sgm = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (sgm > n_seg) return;
+    const int64_t want = sgm * 64;
+    int64_t lo = 0, hi = nnz;   // first k in [0, nnz] with rows[k] >= want
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if (int64_t(rows[mid]) < want) {
+            lo = mid + 1;
+        } else {
+            hi = mid;
+        }
+    }
+    seg_ptrs[sgm] = sgm == n_seg ? I(nnz) : I(lo);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void coo_zero_if_unsorted_kernel(int64_t rows, T* __restrict__ c,
+                                                                   int64_t ldc,
+                                                                   const int* __restrict__ flag)
+{
+    if (*flag == 0) return;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < rows; i += stride) c[i * ldc] = T(0);
+}
+
 template <typename I>
 __global__ __launch_bounds__(256) void coo_clear_ptrs_if_unsorted_kernel(
     int64_t n, I* __restrict__ ptrs, const int* __restrict__ flag)
@@ -242,6 +280,46 @@ int launch_coo(gkoc_stream_t s, int mode, int64_t n_rows, int64_t n_cols, int64_
     hipStream_t st = as_stream(s);
     coo_init_kernel<T><<<dim3(1), dim3(1), 0, st>>>(w.flag, w.one);
     GKOC_LAUNCH_OK();
+    {
+        // c = A b, one right-hand side: ONE pass over values, columns and rows (16 B per entry):
+        // the CSR kernel in its COO mode (csr_spmv_pipe.hpp) finds each wave's piece of the entry
+        // stream through a pointer per 64-row segment (bisection: n / 64 searches) and derives the
+        // row pointers while it streams.  The other three operations read c, which the detection
+        // of unsorted input inside the product kernel would have destroyed by the time it is
+        // known: they keep the two passes below.
+        constexpr int EV = 32 / sizeof(T);
+        constexpr int RINGV = 8192 / sizeof(T);
+        const bool vec_ok = reinterpret_cast<uintptr_t>(vals) % (EV * sizeof(T)) == 0 &&
+                            reinterpret_cast<uintptr_t>(cols) % (EV * sizeof(I)) == 0 &&
+                            reinterpret_cast<uintptr_t>(rows) % (EV * sizeof(I)) == 0;
+        const int64_t n_seg = ceildiv(n_rows, 64);
+        if (mode == 0 && nrhs == 1 && nnz > 0 && vec_ok && n_seg < (int64_t(1) << 31) &&
+            tune_value(GKOC_TUNE_COO_FUSED) != 0) {
+            coo_segment_ptrs_kernel<I><<<dim3(unsigned(ceildiv(n_seg + 1, 256))), dim3(256), 0, st>>>(
+                nnz, rows, n_seg, w.ptrs);
+            GKOC_LAUNCH_OK();
+            const int segs_per_wave = n_seg < 65536 ? 1 : 2;
+            const dim3 grid(static_cast<unsigned>(ceildiv(n_seg, segs_per_wave))), block(64);
+            if (segs_per_wave == 2) {
+                csr_spmv_pipe3_kernel<T, I, false, 64, EV, 1, RINGV, 1, 0x2000 | 128>
+                    <<<grid, block, 0, st>>>(n_rows, n_seg, segs_per_wave, w.ptrs, cols, vals, b, ldb, c,
+                                             ldc, 1, nullptr, nullptr, nullptr, 0, rows, w.flag);
+            } else {
+                csr_spmv_pipe3_kernel<T, I, false, 64, EV, 1, RINGV, 1, 0x1000 | 128>
+                    <<<grid, block, 0, st>>>(n_rows, n_seg, segs_per_wave, w.ptrs, cols, vals, b, ldb, c,
+                                             ldc, 1, nullptr, nullptr, nullptr, 0, rows, w.flag);
+            }
+            GKOC_LAUNCH_OK();
+            // unsorted input (never produced by Ginkgo's own Coo): start again with atomics
+            coo_zero_if_unsorted_kernel<T><<<dim3(grid_for(n_rows)), dim3(256), 0, st>>>(n_rows, c, ldc,
+                                                                                        w.flag);
+            GKOC_LAUNCH_OK();
+            coo_atomic_if_unsorted_kernel<T, I><<<dim3(grid_for(nnz)), dim3(256), 0, st>>>(
+                nnz, rows, cols, vals, nullptr, b, ldb, c, ldc, 1, n_rows, w.flag);
+            GKOC_LAUNCH_OK();
+            return GKOC_OK;
+        }
+    }
     if (nnz > 0) {
         coo_row_ptrs_kernel<I><<<dim3(grid_for(ceildiv(nnz, 4), 8 * max_stream_blocks)), dim3(256),
                                  0, st>>>(nnz, rows, n_rows, w.ptrs, w.flag);

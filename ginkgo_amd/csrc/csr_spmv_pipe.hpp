@@ -49,7 +49,8 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb,
     T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
     const T* __restrict__ beta_p, T* __restrict__ dot_partial = nullptr,
-    int xcd_map = 0)
+    int xcd_map = 0, const I* __restrict__ row_idxs = nullptr,
+    int* __restrict__ unsorted_flag = nullptr)
 {
     static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
     constexpr int G = 64 * E * U;
@@ -63,7 +64,20 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     // (sparse small writes between the read streams cost several times their
     // byte share at the memory side)
     constexpr int DEFER = (ABL >> 12) & 15;
+    // COO = ABL & 128: the matrix is row-sorted COO (coo.hip).  `row_ptrs` then holds ONE pointer
+    // per ROWS-row segment (n_segments + 1 entries, found by bisection of row_idxs); the row index
+    // of every entry travels with its value and column through the same loads, and the entry that
+    // starts a run of equal row indices notes, in an LDS table, where its row (and the empty rows
+    // in front of it) begins - the pointers the row phase needs appear while the products are
+    // written, no pass over row_idxs of its own, no row-pointer array in memory.  The same walk
+    // proves that the wave's piece is sorted and belongs to its rows; otherwise unsorted_flag is
+    // raised (the launcher then redoes the product with atomics).  Long rows are summed by their
+    // lane like all others (the cooperative path needs the row length in advance).
+    constexpr bool COO = (ABL & 128) != 0;
+    constexpr int MAXSEG = DEFER > 0 ? DEFER : 2;
+    constexpr int TAB_NONE = 0x7fffffff;
     __shared__ __attribute__((aligned(64))) T ring[RING];
+    __shared__ int tab[COO ? ROWS * MAXSEG + 1 : 1];
 
     const int lane = threadIdx.x;
     T dot_acc = T(0);
@@ -95,10 +109,21 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
         return;
     }
     const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;
-    const int64_t K0 = row_ptrs[sb * ROWS];
-    const int64_t K1 = row_ptrs[row_e];
-    const int64_t NNZ = row_ptrs[n_rows];
+    const int64_t K0 = COO ? row_ptrs[sb] : row_ptrs[sb * ROWS];
+    const int64_t K1r = COO ? row_ptrs[se] : row_ptrs[row_e];
+    const int64_t NNZ = COO ? row_ptrs[n_segments] : row_ptrs[n_rows];
+    bool coo_bad = COO && K1r < K0;
+    const int64_t K1 = coo_bad ? K0 : K1r;
     const int64_t K0a = K0 & ~int64_t(E - 1);
+    const int64_t R0 = sb * ROWS;              // COO: first row of the wave
+    const int nrw = int(row_e - R0);           //      its number of rows
+    const int k0o = int(K0 - K0a);
+    int carry_rel = -1;                        //      (row - R0) of the entry in front of the group
+    const I* __restrict__ rows0 = COO ? row_idxs + K0a : nullptr;
+    if constexpr (COO) {
+        for (int t = lane; t <= nrw; t += 64) tab[t] = K0 == K1 ? k0o : TAB_NONE;
+        wave_lds_sync();
+    }
     // wave-relative 32-bit offsets (a wave owns at most two 64-row segments, whose
     // entries beyond GKOC_CSR_LONG_ROW per row are summed by the whole wave; the
     // launcher refuses more than 2^31 segments)
@@ -116,7 +141,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     using VT = vecT<T, E>;
     using VI = vecT<I, E>;
 
-    auto load_group = [&](VT(&v)[U], VI(&ci)[U], int p) {
+    auto load_group = [&](VT(&v)[U], VI(&ci)[U], VI(&ri)[COO ? U : 1], int p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = p + (u * 64 + lane) * E;
@@ -125,16 +150,19 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                 for (int e = 0; e < E; ++e) {
                     v[u].v[e] = T(0);
                     ci[u].v[e] = I(0);
+                    if constexpr (COO) ri[u].v[e] = I(0);
                 }
             } else if (k + E <= nnzo) {
                 v[u] = *reinterpret_cast<const VT*>(vals0 + k);
                 ci[u] = *reinterpret_cast<const VI*>(cols0 + k);
+                if constexpr (COO) ri[u] = *reinterpret_cast<const VI*>(rows0 + k);
             } else {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const bool in = k + e < nnzo;
                     v[u].v[e] = in ? vals0[k + e] : T(0);
                     ci[u].v[e] = in ? cols0[k + e] : I(0);
+                    if constexpr (COO) ri[u].v[e] = in ? rows0[k + e] : I(0);
                 }
             }
         }
@@ -146,7 +174,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     const bool unit_b = ldb == 1;
     for (int j = 0; j < nrhs; ++j) {
         const T* __restrict__ bj = b + j;
-        auto produce = [&](VT(&v)[U], VI(&ci)[U], int p) {
+        auto produce = [&](VT(&v)[U], VI(&ci)[U], VI(&ri)[COO ? U : 1], int p) {
             VT xv[U];
             if (unit_b) {
 #pragma unroll
@@ -177,14 +205,54 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                 const int k = p + (u * 64 + lane) * E;
                 *reinterpret_cast<VT*>(&ring[k & MASK]) = pr;
             }
+            if constexpr (COO) {
+                // rows relative to the wave's first row, in 32 bits (the range check is done on
+                // the full index)
+                auto rel = [&](I row) {
+                    const int64_t d = int64_t(row) - R0;
+                    return (d < -1 || d > int64_t(nrw)) ? (d < 0 ? -2 : nrw + 1) : int(d);
+                };
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kb = p + (u * 64 + lane) * E;
+                    // the entry in front of a lane's first one: in the lane to its left, in lane
+                    // 63 of the load before, or in the group before
+                    const int last_rel = rel(ri[u].v[E - 1]);
+                    const int left = __shfl_up(last_rel, 1, 64);
+                    const int before = u > 0 ? __shfl(rel(ri[u > 0 ? u - 1 : 0].v[E - 1]), 63, 64) : carry_rel;
+                    int pv = lane == 0 ? before : left;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int k = kb + e;
+                        const int cur = rel(ri[u].v[e]);
+                        if (k < k0o || k >= k1o) {
+                            pv = cur;
+                            continue;
+                        }
+                        if (k == k0o) pv = -1;
+                        if (cur < 0 || cur >= nrw || cur < pv) {
+                            coo_bad = true;
+                            pv = cur;
+                            continue;
+                        }
+                        for (int t = pv + 1; t <= cur; ++t) tab[t] = k;
+                        if (k == k1o - 1) {
+                            for (int t = cur + 1; t <= nrw; ++t) tab[t] = k1o;
+                        }
+                        pv = cur;
+                    }
+                    if (u == U - 1) carry_rel = __shfl(last_rel, 63, 64);
+                }
+            }
         };
 
         VT vA[U], vB[U];
         VI cA[U], cB[U];
+        VI rA[COO ? U : 1], rB[COO ? U : 1];
         int p_load = 0;
-        load_group(vA, cA, p_load);
+        load_group(vA, cA, rA, p_load);
         p_load += G;
-        load_group(vB, cB, p_load);
+        load_group(vB, cB, rB, p_load);
         p_load += G;
         int produced = 0;          // offsets relative to K0a
         int cons = int(K0 - K0a);
@@ -195,9 +263,31 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
             const int64_t row = s * ROWS + lane;
             const int64_t last = (s + 1) * ROWS < n_rows ? (s + 1) * ROWS : n_rows;
             const bool valid = lane < ROWS && row < n_rows;
-            rs = int(int64_t(row_ptrs[valid ? row : last]) - K0a);
-            re = int(int64_t(row_ptrs[valid ? row + 1 : last]) - K0a);
-            s_end = int(int64_t(row_ptrs[last]) - K0a);
+            if constexpr (COO) {
+                // read from the table at every hand-over (coo_rows below); nothing to prefetch
+                rs = re = s_end = TAB_NONE;
+            } else {
+                rs = int(int64_t(row_ptrs[valid ? row : last]) - K0a);
+                re = int(int64_t(row_ptrs[valid ? row + 1 : last]) - K0a);
+                s_end = int(int64_t(row_ptrs[last]) - K0a);
+            }
+        };
+        // COO: what the table knows about segment s after `produced` entries: a row whose first
+        // entry has not been seen yet (or that is empty) starts where the next known row starts;
+        // TAB_NONE = not known yet = behind everything produced so far
+        auto coo_rows = [&](int64_t s, int& rs, int& re, int& s_end, int produced_) {
+            const int64_t row = s * ROWS + lane;
+            const int64_t last = (s + 1) * ROWS < n_rows ? (s + 1) * ROWS : n_rows;
+            const bool valid = lane < ROWS && row < n_rows;
+            rs = tab[int((valid ? row : last) - R0)];
+            re = tab[int((valid ? row + 1 : last) - R0)];
+            s_end = tab[int(last - R0)];
+            if (produced_ >= k1o) {
+                // the whole piece has been seen: whatever is still unknown lies behind it
+                rs = rs < k1o ? rs : k1o;
+                re = re < k1o ? re : k1o;
+                s_end = s_end < k1o ? s_end : k1o;
+            }
         };
         int rs, re, seg_end, nrs = 0, nre = 0, nseg_end = 0;
         seg_rows(seg, rs, re, seg_end);
@@ -212,10 +302,18 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
         }
 
         while (seg < se) {
+            if constexpr (COO) {
+                wave_lds_sync();
+                coo_rows(seg, rs, re, seg_end, produced);
+            }
             if (produced >= seg_end || produced + G - cons > RING) {
                 const int upto = produced < seg_end ? produced : seg_end;
                 wave_lds_sync();
-                const bool is_long = (re - rs) > GKOC_CSR_LONG_ROW;
+                if constexpr (COO) {
+                    rs = rs < upto ? rs : upto;
+                    re = re < upto ? re : upto;
+                }
+                const bool is_long = !COO && (re - rs) > GKOC_CSR_LONG_ROW;
                 if (!is_long && !(ABL & 2)) {
                     int k = rs > cons ? rs : cons;
                     const int e_ = re < upto ? re : upto;
@@ -329,11 +427,11 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                 continue;
             }
             if (use_a) {
-                produce(vA, cA, produced);
-                load_group(vA, cA, p_load);
+                produce(vA, cA, rA, produced);
+                load_group(vA, cA, rA, p_load);
             } else {
-                produce(vB, cB, produced);
-                load_group(vB, cB, p_load);
+                produce(vB, cB, rB, produced);
+                load_group(vB, cB, rB, p_load);
             }
             p_load += G;
             produced += G;
@@ -346,6 +444,9 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                 if (sb + t < se && lane < ROWS && row < n_rows) c[row * ldc + j] = ys[t];
             }
         }
+    }
+    if constexpr (COO) {
+        if (__ballot(coo_bad) && lane == 0) *unsorted_flag = 1;
     }
     if (DOT) {
         // fixed butterfly: the partial of a wave does not depend on timing

@@ -125,6 +125,9 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
 #define GKOC_TUNE_JACOBI_MFMA 3     /* block-Jacobi(8) apply, several right-hand sides, on the f64 matrix cores
                                       (fused multiply-adds: ~5e-16 off the reference's bits): 0 never,
                                       1 from two columns, 2 (default) from four columns on */
+#define GKOC_TUNE_COO_FUSED 4       /* coo::spmv, one column: one pass over values, columns and rows with the row
+                                      pointers derived while streaming (default 1); 0: row pointers in a pass of
+                                      their own, then the CSR kernel */
 /* key 2: reserved (round-2 experiments with the CSR kernel's ring size / lane layout, all rejected) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
