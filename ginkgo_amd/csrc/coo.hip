@@ -42,16 +42,16 @@ inline unsigned grid_for(int64_t n, int cap = 4 * max_stream_blocks)
 }
 
 // workspace: [row_ptrs (n_rows + 1) of I | pad to 16 | flag int32, pad | one T, pad |
-//             reserve of the same size (earlier versions kept run ends and scan partials)]
+//             n_rows values: the copy of c that the one-pass forms of the operations reading c
+//             keep until the input is known to be sorted]
 inline size_t coo_ptr_bytes(int64_t n_rows, size_t index_size)
 {
     return (size_t(n_rows + 1) * index_size + 15) / 16 * 16;
 }
 
-inline size_t coo_work_bytes(int64_t n_rows, size_t index_size)
+inline size_t coo_work_bytes(int64_t n_rows, size_t index_size, size_t value_size)
 {
-    return 2 * coo_ptr_bytes(n_rows, index_size) + 32 +
-           size_t(scan_scratch_count(n_rows + 1)) * index_size;
+    return coo_ptr_bytes(n_rows, index_size) + 32 + (size_t(n_rows) * value_size + 15) / 16 * 16;
 }
 
 template <typename T, typename I>
@@ -59,9 +59,8 @@ struct coo_work {
     I* ptrs;
     int* flag;
     T* one;
-    I* ends;
-    I* scan_scratch;
-    static size_t bytes(int64_t n_rows) { return coo_work_bytes(n_rows, sizeof(I)); }
+    T* saved_c;
+    static size_t bytes(int64_t n_rows) { return coo_work_bytes(n_rows, sizeof(I), sizeof(T)); }
     coo_work(void* w, int64_t n_rows)
     {
         char* c = static_cast<char*>(w);
@@ -69,8 +68,7 @@ struct coo_work {
         ptrs = reinterpret_cast<I*>(c);
         flag = reinterpret_cast<int*>(c + p);
         one = reinterpret_cast<T*>(c + p + 16);
-        ends = reinterpret_cast<I*>(c + p + 32);
-        scan_scratch = reinterpret_cast<I*>(c + 2 * p + 32);
+        saved_c = reinterpret_cast<T*>(c + p + 32);
     }
 };
 
@@ -198,6 +196,30 @@ __global__ __launch_bounds__(256) void coo_segment_ptrs_kernel(int64_t nnz,
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void coo_save_kernel(int64_t rows, const T* __restrict__ c,
+                                                       int64_t ldc, T* __restrict__ saved)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < rows; i += stride) saved[i] = c[i * ldc];
+}
+
+// unsorted input: c = beta * (what it was), ready for the atomic additions (beta == NULL: 1)
+template <typename T>
+__global__ __launch_bounds__(256) void coo_restore_if_unsorted_kernel(int64_t rows, T* __restrict__ c,
+                                                                      int64_t ldc,
+                                                                      const T* __restrict__ saved,
+                                                                      const T* __restrict__ beta,
+                                                                      const int* __restrict__ flag)
+{
+    if (*flag == 0) return;
+    const T bt = beta ? beta[0] : T(1);
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < rows; i += stride) {
+        c[i * ldc] = bt == T(0) ? T(0) : (beta ? bt * saved[i] : saved[i]);
+    }
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void coo_zero_if_unsorted_kernel(int64_t rows, T* __restrict__ c,
                                                                    int64_t ldc,
                                                                    const int* __restrict__ flag)
@@ -281,41 +303,68 @@ int launch_coo(gkoc_stream_t s, int mode, int64_t n_rows, int64_t n_cols, int64_
     coo_init_kernel<T><<<dim3(1), dim3(1), 0, st>>>(w.flag, w.one);
     GKOC_LAUNCH_OK();
     {
-        // c = A b, one right-hand side: ONE pass over values, columns and rows (16 B per entry):
-        // the CSR kernel in its COO mode (csr_spmv_pipe.hpp) finds each wave's piece of the entry
-        // stream through a pointer per 64-row segment (bisection: n / 64 searches) and derives the
-        // row pointers while it streams.  The other three operations read c, which the detection
-        // of unsorted input inside the product kernel would have destroyed by the time it is
-        // known: they keep the two passes below.
+        // One right-hand side: ONE pass over values, columns and rows (16 B per entry): the CSR
+        // kernel in its COO mode (csr_spmv_pipe.hpp) finds each wave's piece of the entry stream
+        // through a pointer per 64-row segment (bisection: n / 64 searches) and derives the row
+        // pointers while it streams.  That the input is sorted is only known when the kernel has
+        // run, i.e. when c has been overwritten: the operations that read c keep a copy of it in
+        // the workspace (2 x 8 n bytes of traffic) for the atomic fallback to start from.
         constexpr int EV = 32 / sizeof(T);
         constexpr int RINGV = 8192 / sizeof(T);
         const bool vec_ok = reinterpret_cast<uintptr_t>(vals) % (EV * sizeof(T)) == 0 &&
                             reinterpret_cast<uintptr_t>(cols) % (EV * sizeof(I)) == 0 &&
                             reinterpret_cast<uintptr_t>(rows) % (EV * sizeof(I)) == 0;
         const int64_t n_seg = ceildiv(n_rows, 64);
-        if (mode == 0 && nrhs == 1 && nnz > 0 && vec_ok && n_seg < (int64_t(1) << 31) &&
+        // the copy of c costs 16 B per row, the pointer pass it replaces 4 B per entry, and short
+        // rows run the one-pass kernel below its streaming rate: measured on the COO part of the
+        // 256^3 Hybrid (8.8 per row) 1.327 ms against 1.303 ms in two passes
+        const bool pays = mode == 0 || nnz >= 16 * n_rows;
+        if (nrhs == 1 && nnz > 0 && vec_ok && pays && n_seg < (int64_t(1) << 31) &&
             tune_value(GKOC_TUNE_COO_FUSED) != 0) {
             coo_segment_ptrs_kernel<I><<<dim3(unsigned(ceildiv(n_seg + 1, 256))), dim3(256), 0, st>>>(
                 nnz, rows, n_seg, w.ptrs);
             GKOC_LAUNCH_OK();
+            if (mode != 0) {
+                coo_save_kernel<T><<<dim3(grid_for(n_rows)), dim3(256), 0, st>>>(n_rows, c, ldc, w.saved_c);
+                GKOC_LAUNCH_OK();
+            }
             const int segs_per_wave = n_seg < 65536 ? 1 : 2;
             const dim3 grid(static_cast<unsigned>(ceildiv(n_seg, segs_per_wave))), block(64);
-            if (segs_per_wave == 2) {
-                csr_spmv_pipe3_kernel<T, I, false, 64, EV, 1, RINGV, 1, 0x2000 | 128>
-                    <<<grid, block, 0, st>>>(n_rows, n_seg, segs_per_wave, w.ptrs, cols, vals, b, ldb, c,
-                                             ldc, 1, nullptr, nullptr, nullptr, 0, rows, w.flag);
+            // (alpha, beta) of the CSR kernel: spmv -, advanced (alpha, beta), spmv2 (1, 1),
+            // advanced_spmv2 (alpha, 1); a literal 1 multiplies exactly
+            const T* ka = mode == 0 ? nullptr : (mode == 2 ? w.one : alpha);
+            const T* kb = mode == 1 ? beta : w.one;
+#define GKOC_LAUNCH_COO(ADV_, MODE_)                                                                    \
+    csr_spmv_pipe3_kernel<T, I, ADV_, 64, EV, 1, RINGV, 1, MODE_ | 128><<<grid, block, 0, st>>>(          \
+        n_rows, n_seg, segs_per_wave, w.ptrs, cols, vals, b, ldb, c, ldc, 1, ka, kb, nullptr, 0, rows,  \
+        w.flag)
+            if (mode == 0) {
+                if (segs_per_wave == 2) {
+                    GKOC_LAUNCH_COO(false, 0x2000);
+                } else {
+                    GKOC_LAUNCH_COO(false, 0x1000);
+                }
             } else {
-                csr_spmv_pipe3_kernel<T, I, false, 64, EV, 1, RINGV, 1, 0x1000 | 128>
-                    <<<grid, block, 0, st>>>(n_rows, n_seg, segs_per_wave, w.ptrs, cols, vals, b, ldb, c,
-                                             ldc, 1, nullptr, nullptr, nullptr, 0, rows, w.flag);
+                if (segs_per_wave == 2) {
+                    GKOC_LAUNCH_COO(true, 0x2000);
+                } else {
+                    GKOC_LAUNCH_COO(true, 0x1000);
+                }
             }
+#undef GKOC_LAUNCH_COO
             GKOC_LAUNCH_OK();
             // unsorted input (never produced by Ginkgo's own Coo): start again with atomics
-            coo_zero_if_unsorted_kernel<T><<<dim3(grid_for(n_rows)), dim3(256), 0, st>>>(n_rows, c, ldc,
-                                                                                        w.flag);
+            if (mode == 0) {
+                coo_zero_if_unsorted_kernel<T><<<dim3(grid_for(n_rows)), dim3(256), 0, st>>>(n_rows, c, ldc,
+                                                                                            w.flag);
+            } else {
+                coo_restore_if_unsorted_kernel<T><<<dim3(grid_for(n_rows)), dim3(256), 0, st>>>(
+                    n_rows, c, ldc, w.saved_c, mode == 1 ? beta : nullptr, w.flag);
+            }
             GKOC_LAUNCH_OK();
             coo_atomic_if_unsorted_kernel<T, I><<<dim3(grid_for(nnz)), dim3(256), 0, st>>>(
-                nnz, rows, cols, vals, nullptr, b, ldb, c, ldc, 1, n_rows, w.flag);
+                nnz, rows, cols, vals, (mode == 1 || mode == 3) ? alpha : nullptr, b, ldb, c, ldc, 1, n_rows,
+                w.flag);
             GKOC_LAUNCH_OK();
             return GKOC_OK;
         }
@@ -431,9 +480,8 @@ using namespace gkoc;
 
 extern "C" size_t gkoc_coo_workspace_bytes(int64_t n_rows, size_t index_size, size_t value_size)
 {
-    (void)value_size;
     if (n_rows < 0) n_rows = 0;
-    return coo_work_bytes(n_rows, index_size);
+    return coo_work_bytes(n_rows, index_size, value_size ? value_size : 8);
 }
 
 extern "C" int gkoc_hybrid_compute_coo_row_ptrs(gkoc_stream_t s, int64_t n_rows,

@@ -121,6 +121,48 @@ def test_equivalence_types_and_shapes(gexec, oracle, dtype, itype, nrhs):
                 assert np.array_equal(got_.cpu().numpy(), want_), (n_rows, lim)
 
 
+@pytest.mark.parametrize("dtype,itype", [(np.float64, np.int32), (np.float64, np.int64), (np.float32, np.int32)])
+def test_one_pass_operations_that_read_c(gexec, oracle, dtype, itype):
+    """From 16 entries per row on, the operations that read c also run in one pass and keep a
+    copy of c for the atomic fallback: sorted input bit-exact for every (alpha, beta), unsorted
+    input (the kernel has overwritten c by the time it knows) restored and redone with atomics,
+    empty leading / trailing rows, and both toggles of the switch give the same bits"""
+    import ginkgo_amd as g
+    import ctypes as C
+    from ginkgo_amd import _lib
+    rng = np.random.default_rng(11)
+    for n_rows, n_cols, dens in ((700, 90, 0.4), (9000, 64, 0.5), (65, 2000, 0.05)):
+        rp, ci, v = random_csr(n_rows, n_cols, dens, seed=n_rows)
+        keep = np.ones(len(ci), bool)
+        for r in list(range(0, 70)) + list(range(n_rows - 3, n_rows)):
+            if n_rows > 100:
+                keep[rp[r]:rp[r + 1]] = False            # 70 empty rows in front, 3 at the end
+        rows = np.repeat(np.arange(n_rows, dtype=itype), np.diff(rp))[keep]
+        ci, v = ci[keep].astype(itype), v[keep].astype(dtype)
+        assert len(ci) >= 16 * n_rows
+        b = rng.uniform(-1, 1, (n_cols, 1)).astype(dtype)
+        c0 = rng.uniform(-1, 1, (n_rows, 1)).astype(dtype)
+        a = _coo(g, gexec, n_rows, n_cols, rows, ci, v)
+        perm = rng.permutation(len(ci))
+        ash = _coo(g, gexec, n_rows, n_cols, rows[perm], ci[perm], v[perm])
+        for mode in MODES:
+            for alpha, beta in ((0.7, -1.3), (2.0, 0.0), (1.0, 1.0)):
+                want = oracle.coo_apply(mode, n_rows, rows, ci, v, b, alpha, beta, c0)
+                got = _apply(g, gexec, a, mode, b, alpha, beta, c0)
+                assert np.array_equal(got, want.reshape(got.shape)), (mode, n_rows, alpha, beta)
+                _lib.call("gkoc_tune_set", C.c_int(4), C.c_int64(0))
+                try:
+                    two_pass = _apply(g, gexec, a, mode, b, alpha, beta, c0)
+                finally:
+                    _lib.call("gkoc_tune_set", C.c_int(4), C.c_int64(1))
+                assert np.array_equal(got, two_pass), (mode, n_rows, alpha, beta)
+                got = _apply(g, gexec, ash, mode, b, alpha, beta, c0)
+                tol = (1e-13 if dtype == np.float64 else 1e-5) * np.max(np.abs(want))
+                assert np.max(np.abs(got - want.reshape(got.shape))) <= tol, (mode, n_rows, alpha, beta)
+        got = _apply(g, gexec, a, "advanced_spmv", b, 1.5, 0.0, np.full((n_rows, 1), np.nan, dtype=dtype))
+        assert not np.isnan(got).any()
+
+
 def test_27pt_full_formats_agree(gexec, oracle):
     """Coo and Hybrid of the 27-pt Laplacian give the bits of the Csr product"""
     import ginkgo_amd as g
