@@ -397,6 +397,14 @@ inline void* scratch(array<char>& tmp, int64_t n, int64_t nrhs, size_t& bytes)
                         const matrix::Dense<T>* y, matrix::Dense<T>* result,    \
                         array<char>& tmp)                                       \
     {                                                                           \
+        if (cols(x) == 1 && ld(x) == 1 && ld(y) == 1 &&                         \
+            cdna4::fused_dot(cdna4::vt_of<T>(),                                 \
+                             cdna4::stream_keeping_deferred(exec), rows(x),     \
+                             x->get_const_values(), y->get_const_values(),      \
+                             result->get_values(), tmp)) {                      \
+            return; /* step_2 + block-Jacobi + this dot in one launch */        \
+        }                                                                       \
+        cdna4::launch_deferred();                                               \
         size_t bytes = 0;                                                       \
         void* w = scratch<T>(tmp, rows(x), cols(x), bytes);                     \
         GKOC_CALL(gkoc_dense_compute_dot_##TN(                                  \
@@ -429,6 +437,13 @@ inline void* scratch(array<char>& tmp, int64_t n, int64_t nrhs, size_t& bytes)
     void compute_norm2<T>(exec_t exec, const matrix::Dense<T>* x,               \
                           matrix::Dense<T>* result, array<char>& tmp)           \
     {                                                                           \
+        if (cols(x) == 1 &&                                                     \
+            cdna4::cached_norm2(cdna4::vt_of<T>(),                              \
+                                cdna4::stream_keeping_deferred(exec), rows(x),  \
+                                x->get_const_values(), result->get_values())) { \
+            return; /* computed by the fused launch that produced x */          \
+        }                                                                       \
+        cdna4::launch_deferred();                                               \
         size_t bytes = 0;                                                       \
         void* w = scratch<T>(tmp, rows(x), cols(x), bytes);                     \
         GKOC_CALL(gkoc_dense_compute_norm2_##TN(                                \
@@ -559,6 +574,15 @@ namespace cg {
                    const matrix::Dense<T>* beta, const matrix::Dense<T>* rho,   \
                    const array<stopping_status>* stop_status)                   \
     {                                                                           \
+        if (cols(x) == 1 && ld(x) == 1 && ld(r) == 1 && ld(p) == 1 &&           \
+            ld(q) == 1 &&                                                       \
+            cdna4::hold_step_2(cdna4::vt_of<T>(), stream_of(exec), rows(x),     \
+                               x->get_values(), r->get_values(),                \
+                               p->get_const_values(), q->get_const_values(),    \
+                               beta->get_const_values(),                        \
+                               rho->get_const_values(), raw(stop_status))) {    \
+            return; /* launched by the next call into the backend */           \
+        }                                                                       \
         GKOC_CALL(gkoc_cg_step_2_##TN(                                          \
             stream_of(exec), rows(x), cols(x), x->get_values(), ld(x),          \
             r->get_values(), ld(r), p->get_const_values(), ld(p),               \
@@ -853,6 +877,16 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
         const array<I>& block_pointers, const array<T>& blocks,                 \
         const matrix::Dense<T>* b, matrix::Dense<T>* x)                         \
     {                                                                           \
+        if (!has_precisions<T>(block_precisions) && cols(b) == 1 &&             \
+            ld(b) == 1 && ld(x) == 1 &&                                         \
+            cdna4::hold_jacobi_apply(                                           \
+                cdna4::vt_of<T>(), cdna4::it_of<I>(),                           \
+                cdna4::stream_keeping_deferred(exec), num_blocks,               \
+                max_block_size, scheme_of(storage_scheme),                      \
+                block_pointers.get_const_data(), blocks.get_const_data(),       \
+                b->get_const_values(), rows(b), x->get_values())) {             \
+            return; /* follows a held cg::step_2: see fusion.cpp */             \
+        }                                                                       \
         if (has_precisions<T>(block_precisions)) {                              \
             GKOC_CALL(adaptive_abi<I>::apply(                                   \
                 stream_of(exec), num_blocks, max_block_size,                    \

@@ -29,6 +29,9 @@
 
 #include "gko_cdna4.h"
 
+// libginkgo_hip.so of this backend (gko_binding/fusion.cpp): launches kernels the binding holds back
+extern "C" void gko_cdna4_launch_deferred();
+
 namespace gko {
 namespace cdna4 {
 
@@ -128,6 +131,7 @@ protected:
             std::vector<int64_t> sc(send_sizes_.begin(), send_sizes_.end());
             std::vector<int64_t> sd(send_offsets_.begin(), send_offsets_.end() - 1);
             std::vector<int64_t> rc(recv_sizes_.begin(), recv_sizes_.end());
+            gko_cdna4_launch_deferred();
             auto stream = reinterpret_cast<gkoc_stream_t>(hip->get_stream());
             const int status = gkoc_comm_exchange_begin(state_->comm, stream, nullptr, send_buffer, sc.data(),
                                                         sd.data(), recv_buffer, rc.data(),

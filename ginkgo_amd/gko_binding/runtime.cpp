@@ -206,6 +206,7 @@ void HipExecutor::raw_free(void* ptr) const noexcept
 {
     try {
         cdna4::device_guard g(this->get_device_id());
+        cdna4::launch_deferred();   // a held kernel may still have to read or write ptr
         alloc_->deallocate(ptr);
     } catch (...) {
     }
@@ -216,6 +217,7 @@ void OmpExecutor::raw_copy_to(const HipExecutor* dest, size_type num_bytes,
 {
     if (num_bytes > 0) {
         cdna4::device_guard g(dest->get_device_id());
+        cdna4::launch_deferred();
         auto s = reinterpret_cast<gkoc_stream_t>(dest->get_stream());
         GKOC_CALL(gkoc_memcpy_h2d(dest_ptr, src_ptr, num_bytes, s));
         GKOC_CALL(gkoc_stream_synchronize(s));
@@ -227,6 +229,7 @@ void HipExecutor::raw_copy_to(const OmpExecutor*, size_type num_bytes,
 {
     if (num_bytes > 0) {
         cdna4::device_guard g(this->get_device_id());
+        cdna4::launch_deferred();
         GKOC_CALL(gkoc_memcpy_d2h(dest_ptr, src_ptr, num_bytes,
                                   reinterpret_cast<gkoc_stream_t>(this->get_stream())));
     }
@@ -237,6 +240,7 @@ void HipExecutor::raw_copy_to(const HipExecutor*, size_type num_bytes,
 {
     if (num_bytes > 0) {
         cdna4::device_guard g(this->get_device_id());
+        cdna4::launch_deferred();
         auto s = reinterpret_cast<gkoc_stream_t>(this->get_stream());
         GKOC_CALL(gkoc_memcpy_d2d(dest_ptr, src_ptr, num_bytes, s));
         GKOC_CALL(gkoc_stream_synchronize(s));
@@ -252,6 +256,7 @@ void HipExecutor::raw_copy_to(const DpcppExecutor* dest, size_type, const void*,
 void HipExecutor::synchronize() const
 {
     cdna4::device_guard g(this->get_device_id());
+    cdna4::launch_deferred();
     GKOC_CALL(gkoc_stream_synchronize(
         reinterpret_cast<gkoc_stream_t>(this->get_stream())));
 }
@@ -328,6 +333,7 @@ void HipTimer::init_time_point(time_point& time)
 void HipTimer::record(time_point& time)
 {
     cdna4::device_guard g(device_id_);
+    cdna4::launch_deferred();
     GKOC_CALL(gkoc_event_record(time.data_.hip_event,
                                 reinterpret_cast<gkoc_stream_t>(stream_)));
 }
@@ -374,6 +380,7 @@ public:
     {
         cdna4::device_guard g(exec_->get_device_id());
         GKOC_CALL(gkoc_event_create(&ev_));
+        cdna4::launch_deferred();
         GKOC_CALL(gkoc_event_record(ev_, reinterpret_cast<gkoc_stream_t>(exec_->get_stream())));
     }
     ~stream_event()

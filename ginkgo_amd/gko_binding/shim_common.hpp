@@ -9,6 +9,7 @@
 // link-compatible replacement for libginkgo_hip.so.  No device code and no HIP
 // headers are needed here: everything goes through the C ABI.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -41,9 +42,44 @@ inline void check(int status, const char* file, int line, const char* what)
 
 #define GKOC_CALL(expr) ::gko::cdna4::check((expr), __FILE__, __LINE__, #expr)
 
+// Fusion across calls (fusion.cpp): cg::step_2 and the block-Jacobi application that follows it
+// are held back until the next call shows whether one kernel can do them together with the dot
+// product.  Everything that enters the backend goes through launch_deferred() first.
+extern std::atomic<int> deferred_state;   // != 0: something is held or a norm is cached
+void flush_deferred();
+inline void launch_deferred()
+{
+    if (deferred_state.load(std::memory_order_acquire) != 0) flush_deferred();
+}
+bool hold_step_2(int vt, gkoc_stream_t s, int64_t n, void* x, void* r, const void* p, const void* q,
+                 const void* beta, const void* rho, const uint8_t* stop);
+bool hold_jacobi_apply(int vt, int it, gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
+                       gkoc_jacobi_scheme scheme, const void* block_ptrs, const void* blocks,
+                       const void* b, int64_t n, void* z);
+bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y, void* result,
+               array<char>& tmp);
+bool cached_norm2(int vt, gkoc_stream_t s, int64_t n, const void* x, void* result);
+
+// the stream of a kernel launch: what was held back is launched first
 inline gkoc_stream_t stream_of(const std::shared_ptr<const HipExecutor>& exec)
 {
+    launch_deferred();
     return reinterpret_cast<gkoc_stream_t>(exec->get_stream());
+}
+// ... for the calls that take part in the fusion themselves
+inline gkoc_stream_t stream_keeping_deferred(const std::shared_ptr<const HipExecutor>& exec)
+{
+    return reinterpret_cast<gkoc_stream_t>(exec->get_stream());
+}
+template <typename T>
+constexpr int vt_of()
+{
+    return sizeof(T) == 8 ? 0 : 1;
+}
+template <typename I>
+constexpr int it_of()
+{
+    return sizeof(I) == 4 ? 0 : 1;
 }
 
 template <typename T>

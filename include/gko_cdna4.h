@@ -128,6 +128,10 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
 #define GKOC_TUNE_COO_FUSED 4       /* coo::spmv, one column: one pass over values, columns and rows with the row
                                       pointers derived while streaming (default 1); 0: row pointers in a pass of
                                       their own, then the CSR kernel */
+#define GKOC_TUNE_DEFERRED_FUSION 5 /* binding for the unmodified Ginkgo core (gko_binding/fusion.cpp): cg::step_2 and
+                                      the block-Jacobi application after it are held until the next call and run
+                                      as one kernel with the dot product that follows (default 1); 0: every call
+                                      launches its own kernel */
 /* key 2: reserved (round-2 experiments with the CSR kernel's ring size / lane layout, all rejected) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);

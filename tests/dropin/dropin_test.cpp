@@ -38,8 +38,11 @@
 #include <ginkgo/core/stop/combined.hpp>
 #include <ginkgo/core/stop/iteration.hpp>
 #include <ginkgo/core/stop/residual_norm.hpp>
+#include <vector>
+#include <ginkgo/core/log/logger.hpp>
 
 #include "benchmark/utils/stencil_matrix.hpp"
+#include "gko_cdna4.h"
 
 using vt = double;
 using it = gko::int32;
@@ -240,6 +243,81 @@ int main(int argc, char** argv)
         std::cout << "CG+Jacobi(8): iterations reference " << it_ref << ", hip " << it_hip << std::endl;
         CHECK(std::abs(it_ref - it_hip) <= 1, "CG iteration count matches reference");
         CHECK(rel_err(x_hip.get(), x_ref.get()) < 1e-9, "CG solution matches reference");
+        // Fusion across calls (gko_binding/fusion.cpp): cg::step_2, the block-Jacobi application and
+        // the two reductions that follow run as one kernel; x, r, z are bit-identical to the separate
+        // kernels, rho and ||r|| come from a different summation tree.  A logger reads r and x from the
+        // device after every iteration: same history with the mechanism on and off.
+        {
+            struct history : gko::log::Logger {
+                mutable std::vector<double> rnorm, xnorm, rho;
+                void on_iteration_complete(const gko::LinOp*, const gko::LinOp*, const gko::LinOp* x,
+                                           const gko::size_type&, const gko::LinOp* r, const gko::LinOp*,
+                                           const gko::LinOp* implicit_tau_sq,
+                                           const gko::array<gko::stopping_status>*, bool) const override
+                {
+                    auto host = r->get_executor()->get_master();
+                    auto rh = gko::clone(host, gko::as<Dense>(r));
+                    auto xh = gko::clone(host, gko::as<Dense>(x));
+                    double sr = 0, sx = 0;
+                    for (gko::size_type i = 0; i < rh->get_size()[0]; ++i) {
+                        sr += rh->at(i, 0) * rh->at(i, 0);
+                        sx += xh->at(i, 0) * xh->at(i, 0);
+                    }
+                    rnorm.push_back(std::sqrt(sr));
+                    xnorm.push_back(std::sqrt(sx));
+                    rho.push_back(gko::clone(host, gko::as<Dense>(implicit_tau_sq))->at(0, 0));
+                }
+                history() : gko::log::Logger(gko::log::Logger::iteration_complete_mask) {}
+            };
+            auto run = [&](int fused, std::shared_ptr<history> h, int& iters) {
+                gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, fused);
+                auto rhs = Dense::create(hip, gko::dim<2>{n, 1});
+                rhs->fill(1.0);
+                auto x = Dense::create(hip, gko::dim<2>{n, 1});
+                x->fill(0.0);
+                auto conv = gko::share(gko::log::Convergence<vt>::create());
+                auto solver =
+                    gko::solver::Cg<vt>::build()
+                        .with_criteria(gko::stop::Iteration::build().with_max_iters(500u),
+                                       gko::stop::ResidualNorm<vt>::build().with_reduction_factor(1e-10))
+                        .with_preconditioner(
+                            gko::preconditioner::Jacobi<vt, it>::build().with_max_block_size(8u))
+                        .on(hip)
+                        ->generate(a_hip);
+                solver->add_logger(conv);
+                if (h) solver->add_logger(h);
+                solver->apply(rhs, x);
+                iters = static_cast<int>(conv->get_num_iterations());
+                gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 1);
+                // the criterion's own ||r|| (with the mechanism on: the value the fused kernel left behind)
+                const double tau = gko::clone(ref, gko::as<Dense>(conv->get_residual_norm()))->at(0, 0);
+                return std::make_pair(gko::clone(ref, x), tau);
+            };
+            auto h_on = std::make_shared<history>(), h_off = std::make_shared<history>();
+            int it_on = 0, it_off = 0, it_plain = 0;
+            auto on = run(1, h_on, it_on);
+            auto off = run(0, h_off, it_off);
+            auto plain = run(1, nullptr, it_plain);   // no logger in between: every iteration fuses
+            CHECK(it_on == it_off && it_on == it_plain && it_on == it_hip,
+                  "CG with fusion across calls: same iteration count as without");
+            CHECK(rel_err(on.first.get(), off.first.get()) < 1e-12 &&
+                      rel_err(plain.first.get(), off.first.get()) < 1e-12,
+                  "CG with fusion across calls: same solution");
+            bool same = h_on->rnorm.size() == h_off->rnorm.size() && !h_on->rnorm.empty();
+            double worst = 0;
+            for (size_t i = 0; same && i < h_on->rnorm.size(); ++i) {
+                worst = std::max(worst, std::abs(h_on->rnorm[i] - h_off->rnorm[i]) / h_off->rnorm[i]);
+                worst = std::max(worst, std::abs(h_on->xnorm[i] - h_off->xnorm[i]) /
+                                            std::max(h_off->xnorm[i], 1e-300));
+                worst = std::max(worst, std::abs(h_on->rho[i] - h_off->rho[i]) / std::abs(h_off->rho[i]));
+            }
+            std::cout << "  " << h_on->rnorm.size() << " iterations, worst relative difference of ||r||, ||x||, rho "
+                      << worst << std::endl;
+            CHECK(same && worst < 1e-9, "CG with fusion across calls: same ||r||, ||x||, rho after every iteration");
+            CHECK(std::abs(on.second - h_on->rnorm.back()) <= 1e-13 * h_on->rnorm.back() &&
+                      std::abs(plain.second - off.second) <= 1e-10 * off.second,
+                  "criterion's ||r|| (left behind by the fused kernel) is the norm of r on the device");
+        }
         auto x_ref2 = solve(ref, a_ref, true, it_ref);
         auto x_hip2 = solve(hip, a_hip, true, it_hip);
         std::cout << "GMRES(30)+Jacobi(8): iterations reference " << it_ref << ", hip " << it_hip << std::endl;
