@@ -331,15 +331,20 @@ __global__ __launch_bounds__(64) void jacobi_generate_kernel(
     }
 }
 
+// entry idx of a storage group held in reduced precision (defined with the storage types below)
+__device__ double load_stored_any(int prec, const double* group, int64_t idx);
+__device__ inline float load_stored_any(int, const float* group, int64_t idx) { return group[idx]; }
+
 // ------------------------------------------------------------------- apply
 // one wave per storage group; lane l < stride: block = l / block_offset,
 // row = l % block_offset
-template <typename T, typename I, bool ADV>
+template <typename T, typename I, bool ADV, bool STORED = false>
 __global__ __launch_bounds__(256) void jacobi_apply_kernel(
     int64_t num_blocks, int64_t num_groups, gkoc_jacobi_scheme scheme,
     const I* __restrict__ block_ptrs, const T* __restrict__ blocks,
     const T* __restrict__ alpha_p, const T* __restrict__ b, int64_t ldb,
-    const T* __restrict__ beta_p, T* __restrict__ x, int64_t ldx, int nrhs)
+    const T* __restrict__ beta_p, T* __restrict__ x, int64_t ldx, int nrhs,
+    const uint8_t* __restrict__ precisions = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int64_t group = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -365,7 +370,14 @@ __global__ __launch_bounds__(256) void jacobi_apply_kernel(
         T sum = T(0);
         if (ADV && beta != T(0)) sum = x[(start + r) * ldx + j] * beta;
         for (int c = 0; c < bs; ++c) {
-            const T m = gp[c * stride];
+            T m;
+            if constexpr (STORED) {
+                // block stored in the precision of its group (any layout; T = double)
+                m = load_stored_any(int(precisions[blk]), blocks + scheme.group_offset * group,
+                                    lane + c * stride);
+            } else {
+                m = gp[c * stride];
+            }
             const T bv = b[(start + c) * ldb + j];
             sum += ADV ? (alpha * m) * bv : m * bv;
         }
@@ -545,6 +557,11 @@ __device__ __forceinline__ double load_stored(int prec, const double* group, int
     case 0x20: return stored<0x20>::load(reinterpret_cast<const uint16_t*>(group)[idx]);
     default: return group[idx];
     }
+}
+
+__device__ double load_stored_any(int prec, const double* group, int64_t idx)
+{
+    return load_stored(prec, group, idx);
 }
 
 __device__ __forceinline__ void store_stored(int prec, double* group, int64_t idx, double v)
@@ -1387,6 +1404,22 @@ inline bool wide_group_layout(const gkoc_jacobi_scheme& sc)
     return bo >= 1 && bo <= 16 && (bo & (bo - 1)) == 0 && (bo << sc.group_power) == 64;
 }
 
+// lanes per block = the power of two at or above block_offset
+// (Jacobi::compute_storage_scheme, include/ginkgo/core/preconditioner/jacobi.hpp: a group holds
+// max_block_stride / that power blocks; max_block_stride = 64 on this device)
+inline int subwarp_of(const gkoc_jacobi_scheme& sc)
+{
+    int sub = 1;
+    while (sub < sc.block_offset) sub <<= 1;
+    return sub;
+}
+
+inline bool wave_group_layout(const gkoc_jacobi_scheme& sc)
+{
+    return sc.block_offset >= 1 && sc.block_offset <= 32 &&
+           (int64_t(subwarp_of(sc)) << sc.group_power) == 64;
+}
+
 template <typename I>
 int launch_generate_adaptive(gkoc_stream_t s, const I* row_ptrs, const I* cols, const double* vals,
                              int64_t num_blocks, uint32_t max_bs, gkoc_jacobi_scheme scheme,
@@ -1396,10 +1429,11 @@ int launch_generate_adaptive(gkoc_stream_t s, const I* row_ptrs, const I* cols, 
     if (num_blocks <= 0) return GKOC_OK;
     GKOC_REQUIRE(row_ptrs && cols && vals && block_ptrs && precisions && blocks, GKOC_E_INVALID,
                  "null pointer");
-    GKOC_REQUIRE(wide_group_layout(scheme) && max_bs >= 1 && max_bs <= uint64_t(scheme.block_offset),
+    GKOC_REQUIRE(wave_group_layout(scheme) && max_bs >= 1 && max_bs <= uint64_t(scheme.block_offset),
                  GKOC_E_NOT_SUPPORTED,
-                 "adaptive block-Jacobi needs max_block_size in {1,2,4,8,16} (64-wide groups)");
-    const int sub = int(scheme.block_offset);
+                 "adaptive block-Jacobi needs max_block_size <= 32 and groups that fill a wavefront "
+                 "(max_block_stride 64)");
+    const int sub = subwarp_of(scheme);
     const int per_wave = 64 / sub;
     const size_t lds = 2 * size_t(per_wave) * sub * (sub + 1) * sizeof(double);
     jacobi_generate_adaptive_kernel<I>
@@ -1431,12 +1465,20 @@ int launch_apply_adaptive(gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
 {
     if (num_blocks <= 0 || nrhs <= 0) return GKOC_OK;
     GKOC_REQUIRE(block_ptrs && blocks && precisions && b && x, GKOC_E_INVALID, "null pointer");
-    GKOC_REQUIRE(wide_group_layout(scheme) && max_bs <= uint64_t(scheme.block_offset),
-                 GKOC_E_NOT_SUPPORTED,
-                 "adaptive block-Jacobi needs max_block_size in {1,2,4,8,16} (64-wide groups)");
-    GKOC_REQUIRE(nrhs == 1 && ldb == 1 && ldx == 1, GKOC_E_NOT_SUPPORTED,
-                 "adaptive block-Jacobi: one right-hand side with unit strides");
+    GKOC_REQUIRE(scheme.block_offset >= 1 && (scheme.block_offset << scheme.group_power) <= 64 &&
+                     max_bs <= uint64_t(scheme.block_offset),
+                 GKOC_E_NOT_SUPPORTED, "storage stride must be <= 64 (wave size)");
     const int64_t groups = ceildiv(num_blocks, int64_t(1) << scheme.group_power);
+    if (!(wide_group_layout(scheme) && nrhs == 1 && ldb == 1 && ldx == 1)) {
+        // any other layout (block_offset not a power of two, e.g. max_block_size 13), several
+        // right-hand sides, strides: lane = row of a block, entries converted as they are read
+        jacobi_apply_kernel<double, I, ADV, true>
+            <<<dim3(unsigned(ceildiv(groups, 4))), dim3(256), 0, as_stream(s)>>>(
+                num_blocks, groups, scheme, block_ptrs, blocks, alpha, b, ldb, beta, x, ldx, int(nrhs),
+                precisions);
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     const int64_t go = scheme.group_offset;
 #define GKOC_JAC_AD(BO_)                                                                    \
     launch_apply_adaptive_fixed<I, ADV, BO_>(s, num_blocks, groups, go, block_ptrs, blocks, \
