@@ -1,0 +1,769 @@
+// Format conversions and small matrix utilities on either side of the SpMV hot path
+// ("callers and data formats"): everything Ginkgo's Dense / Csr / Coo / Ell /
+// Sellp / Hybrid classes ask the device for when a matrix moves between formats, plus the
+// diagonal / absolute / transpose helpers.  Restated from the reference kernels cited per function
+// (reference/matrix/{dense,csr,coo,ell,sellp,hybrid}_kernels.cpp); all of it is copy / index work,
+// reproduced entry for entry (output order = the reference's row-by-row walk).  None of this is on
+// the iteration path: kernels are one thread per row (or per entry), grid-stride.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace gkoc {
+namespace {
+
+inline unsigned cv_grid(int64_t n)
+{
+    int64_t b = ceildiv(n, 256);
+    if (b > 4 * max_stream_blocks) b = 4 * max_stream_blocks;
+    return unsigned(b < 1 ? 1 : b);
+}
+
+#define GKOC_FOR_EACH(i, n) \
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < (n); i += int64_t(gridDim.x) * 256)
+
+template <typename T>
+__device__ __forceinline__ bool nonzero(T v)
+{
+    return v != T(0);   // is_nonzero (include/ginkgo/core/base/math.hpp): NaN counts, -0 does not
+}
+
+// ------------------------------------------------------------------ arrays
+template <typename T>
+__global__ __launch_bounds__(256) void fill_seq_kernel(int64_t n, T* data)
+{
+    GKOC_FOR_EACH(i, n) data[i] = T(i);
+}
+
+// ------------------------------------------------------------------- dense
+template <typename T>
+__global__ __launch_bounds__(256) void dense_transpose_kernel(int64_t rows, int64_t cols,
+                                                              const T* __restrict__ in, int64_t ldi,
+                                                              T* __restrict__ out, int64_t ldo)
+{
+    // one 16 x 16 tile per 256 threads through LDS would coalesce both sides; the matrices that
+    // come here are right-hand-side blocks and test fixtures
+    GKOC_FOR_EACH(t, rows * cols)
+    {
+        const int64_t i = t / cols, j = t - i * cols;
+        out[j * ldo + i] = in[i * ldi + j];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dense_extract_diagonal_kernel(int64_t n, const T* __restrict__ in,
+                                                                     int64_t ld, T* __restrict__ diag)
+{
+    GKOC_FOR_EACH(i, n) diag[i] = in[i * ld + i];
+}
+
+// reference/matrix/dense_kernels.cpp add_scaled_identity: m *= beta, diagonal += alpha
+template <typename T>
+__global__ __launch_bounds__(256) void dense_add_scaled_identity_kernel(int64_t rows, int64_t cols,
+                                                                        const T* __restrict__ alpha,
+                                                                        const T* __restrict__ beta,
+                                                                        T* __restrict__ m, int64_t ld)
+{
+    const T a = alpha[0], b = beta[0];
+    GKOC_FOR_EACH(t, rows * cols)
+    {
+        const int64_t i = t / cols, j = t - i * cols;
+        T v = m[i * ld + j] * b;
+        if (i == j) v += a;
+        m[i * ld + j] = v;
+    }
+}
+
+// add_scaled_diag / sub_scaled_diag (:229-257): nothing happens for alpha == 0
+template <typename T, bool SUB>
+__global__ __launch_bounds__(256) void dense_scaled_diag_kernel(int64_t n, const T* __restrict__ alpha,
+                                                                const T* __restrict__ diag,
+                                                                T* __restrict__ y, int64_t ld)
+{
+    const T a = alpha[0];
+    if (!nonzero(a)) return;
+    GKOC_FOR_EACH(i, n)
+    {
+        const T p = a * diag[i];
+        y[i * ld + i] = SUB ? y[i * ld + i] - p : y[i * ld + i] + p;
+    }
+}
+
+template <typename T, typename O>
+__global__ __launch_bounds__(256) void dense_count_nnz_kernel(int64_t rows, int64_t cols,
+                                                              const T* __restrict__ in, int64_t ld,
+                                                              O* __restrict__ out)
+{
+    GKOC_FOR_EACH(r, rows)
+    {
+        O c = 0;
+        for (int64_t j = 0; j < cols; ++j) c += nonzero(in[r * ld + j]) ? O(1) : O(0);
+        out[r] = c;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dense_max_nnz_kernel(int64_t rows, int64_t cols,
+                                                            const T* __restrict__ in, int64_t ld,
+                                                            unsigned long long* __restrict__ out)
+{
+    GKOC_FOR_EACH(r, rows)
+    {
+        unsigned long long c = 0;
+        for (int64_t j = 0; j < cols; ++j) c += nonzero(in[r * ld + j]) ? 1 : 0;
+        atomicMax(out, c);
+    }
+}
+
+// compute_slice_sets (:733-758): slice length = max over the slice's rows of the row count
+// rounded up to stride_factor
+template <typename T>
+__global__ __launch_bounds__(256) void dense_slice_lengths_kernel(int64_t rows, int64_t cols,
+                                                                  const T* __restrict__ in, int64_t ld,
+                                                                  int64_t slice_size, int64_t stride_factor,
+                                                                  int64_t num_slices,
+                                                                  uint64_t* __restrict__ lengths,
+                                                                  uint64_t* __restrict__ sets)
+{
+    GKOC_FOR_EACH(sl, num_slices + 1)
+    {
+        uint64_t len = 0;
+        if (sl < num_slices) {
+            for (int64_t lr = 0; lr < slice_size; ++lr) {
+                const int64_t r = sl * slice_size + lr;
+                if (r >= rows) break;
+                uint64_t c = 0;
+                for (int64_t j = 0; j < cols; ++j) c += nonzero(in[r * ld + j]) ? 1 : 0;
+                const uint64_t up = (c + stride_factor - 1) / stride_factor * stride_factor;
+                len = up > len ? up : len;
+            }
+            lengths[sl] = len;
+        }
+        sets[sl] = len;   // scanned in place afterwards; the entry past the end starts at 0
+    }
+}
+
+// Dense -> Csr / SparsityCsr (vals == NULL) / Coo (rows_out != NULL): row pointers come from the
+// caller (count + prefix sum, as core/matrix/dense.cpp does), entries in column order
+template <typename T, typename I, typename P>
+__global__ __launch_bounds__(256) void dense_to_rows_kernel(int64_t rows, int64_t cols,
+                                                            const T* __restrict__ in, int64_t ld,
+                                                            const P* __restrict__ row_ptrs,
+                                                            I* __restrict__ rows_out,
+                                                            I* __restrict__ cols_out,
+                                                            T* __restrict__ vals_out)
+{
+    GKOC_FOR_EACH(r, rows)
+    {
+        int64_t k = int64_t(row_ptrs[r]);
+        for (int64_t j = 0; j < cols; ++j) {
+            const T v = in[r * ld + j];
+            if (nonzero(v)) {
+                if (rows_out) rows_out[k] = I(r);
+                cols_out[k] = I(j);
+                if (vals_out) vals_out[k] = v;
+                ++k;
+            }
+        }
+    }
+}
+
+// Dense -> Ell (:518-543) and the Ell part of Dense -> Hybrid (:597-639, coo_* != NULL): the first
+// ell_lim non-zeros of a row, the padding (0, invalid_index = -1) over the whole stride; the rest
+// goes to Coo at coo_row_ptrs[row]
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void dense_to_ell_kernel(int64_t rows, int64_t cols,
+                                                           const T* __restrict__ in, int64_t ld,
+                                                           int64_t ell_k, int64_t ell_lim, int64_t stride,
+                                                           I* __restrict__ ell_cols,
+                                                           T* __restrict__ ell_vals,
+                                                           const int64_t* __restrict__ coo_row_ptrs,
+                                                           I* __restrict__ coo_rows,
+                                                           I* __restrict__ coo_cols,
+                                                           T* __restrict__ coo_vals)
+{
+    GKOC_FOR_EACH(r, stride)
+    {
+        int64_t k = 0;
+        int64_t c = coo_row_ptrs ? coo_row_ptrs[r < rows ? r : rows] : 0;
+        if (r < rows) {
+            for (int64_t j = 0; j < cols; ++j) {
+                const T v = in[r * ld + j];
+                if (!nonzero(v)) continue;
+                if (k < ell_lim) {
+                    ell_cols[r + k * stride] = I(j);
+                    ell_vals[r + k * stride] = v;
+                    ++k;
+                } else if (coo_row_ptrs) {
+                    coo_rows[c] = I(r);
+                    coo_cols[c] = I(j);
+                    coo_vals[c] = v;
+                    ++c;
+                }
+            }
+        }
+        for (; k < ell_k; ++k) {
+            ell_cols[r + k * stride] = I(-1);
+            ell_vals[r + k * stride] = T(0);
+        }
+    }
+}
+
+// Dense -> Sellp (:646-675)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void dense_to_sellp_kernel(int64_t rows, int64_t cols,
+                                                             const T* __restrict__ in, int64_t ld,
+                                                             int64_t slice_size,
+                                                             const uint64_t* __restrict__ slice_sets,
+                                                             I* __restrict__ cols_out,
+                                                             T* __restrict__ vals_out)
+{
+    GKOC_FOR_EACH(r, rows)
+    {
+        const int64_t sl = r / slice_size, lr = r - sl * slice_size;
+        int64_t at = int64_t(slice_sets[sl]) * slice_size + lr;
+        const int64_t end = int64_t(slice_sets[sl + 1]) * slice_size + lr;
+        for (int64_t j = 0; j < cols; ++j) {
+            const T v = in[r * ld + j];
+            if (nonzero(v)) {
+                cols_out[at] = I(j);
+                vals_out[at] = v;
+                at += slice_size;
+            }
+        }
+        for (; at < end; at += slice_size) {
+            cols_out[at] = I(-1);
+            vals_out[at] = T(0);
+        }
+    }
+}
+
+// --------------------------------------------------------- sparse -> dense
+// fill_in_dense: the caller has zeroed the result (core/matrix/*.cpp convert_to(Dense))
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void csr_fill_in_dense_kernel(int64_t n_rows,
+                                                                const I* __restrict__ row_ptrs,
+                                                                const I* __restrict__ cols,
+                                                                const T* __restrict__ vals,
+                                                                T* __restrict__ out, int64_t ld)
+{
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        for (int64_t k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) out[r * ld + cols[k]] = vals[k];
+    }
+}
+
+// coo (reference/matrix/coo_kernels.cpp:104-114): +=, so duplicates add up
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void coo_fill_in_dense_kernel(int64_t nnz, const I* __restrict__ rows,
+                                                                const I* __restrict__ cols,
+                                                                const T* __restrict__ vals,
+                                                                T* __restrict__ out, int64_t ld)
+{
+    GKOC_FOR_EACH(k, nnz) atomicAdd(&out[int64_t(rows[k]) * ld + cols[k]], vals[k]);
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void ell_fill_in_dense_kernel(int64_t n_rows, int64_t ell_k,
+                                                                int64_t stride,
+                                                                const I* __restrict__ cols,
+                                                                const T* __restrict__ vals,
+                                                                T* __restrict__ out, int64_t ld)
+{
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        for (int64_t k = 0; k < ell_k; ++k) {
+            const I c = cols[r + k * stride];
+            if (c != I(-1)) out[r * ld + c] = vals[r + k * stride];
+        }
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void sellp_fill_in_dense_kernel(int64_t n_rows, int64_t slice_size,
+                                                                  const uint64_t* __restrict__ slice_sets,
+                                                                  const I* __restrict__ cols,
+                                                                  const T* __restrict__ vals,
+                                                                  T* __restrict__ out, int64_t ld)
+{
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        const int64_t sl = r / slice_size, lr = r - sl * slice_size;
+        for (int64_t i = int64_t(slice_sets[sl]); i < int64_t(slice_sets[sl + 1]); ++i) {
+            const I c = cols[lr + i * slice_size];
+            if (c != I(-1)) out[r * ld + c] = vals[lr + i * slice_size];
+        }
+    }
+}
+
+// ------------------------------------------------------------ diagonals
+// extract_diagonal: the first entry of row r with column r (ell / sellp: the reference breaks at
+// the first match; csr: csr_spmv.hip); coo: every entry with row == column (one per row in a valid
+// matrix)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void ell_extract_diagonal_kernel(int64_t n, int64_t ell_k, int64_t stride,
+                                                                   const I* __restrict__ cols,
+                                                                   const T* __restrict__ vals,
+                                                                   T* __restrict__ diag)
+{
+    GKOC_FOR_EACH(r, n)
+    {
+        for (int64_t k = 0; k < ell_k; ++k) {
+            if (int64_t(cols[r + k * stride]) == r) {
+                diag[r] = vals[r + k * stride];
+                break;
+            }
+        }
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void sellp_extract_diagonal_kernel(
+    int64_t n, int64_t slice_size, const uint64_t* __restrict__ slice_sets, const I* __restrict__ cols,
+    const T* __restrict__ vals, T* __restrict__ diag)
+{
+    GKOC_FOR_EACH(r, n)
+    {
+        const int64_t sl = r / slice_size, lr = r - sl * slice_size;
+        for (int64_t i = int64_t(slice_sets[sl]); i < int64_t(slice_sets[sl + 1]); ++i) {
+            if (int64_t(cols[lr + i * slice_size]) == r) {
+                diag[r] = vals[lr + i * slice_size];
+                break;
+            }
+        }
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void coo_extract_diagonal_kernel(int64_t nnz, const I* __restrict__ rows,
+                                                                   const I* __restrict__ cols,
+                                                                   const T* __restrict__ vals,
+                                                                   T* __restrict__ diag)
+{
+    GKOC_FOR_EACH(k, nnz)
+    {
+        if (rows[k] == cols[k]) diag[rows[k]] = vals[k];
+    }
+}
+
+// check_diagonal_entries_exist (reference/matrix/csr_kernels.cpp:1375-1395): *missing != 0 if a row
+// below min(rows, cols) has no entry on the diagonal
+template <typename I>
+__global__ __launch_bounds__(256) void csr_missing_diagonal_kernel(int64_t n, const I* __restrict__ row_ptrs,
+                                                                   const I* __restrict__ cols,
+                                                                   int* __restrict__ missing)
+{
+    GKOC_FOR_EACH(r, n)
+    {
+        bool found = false;
+        for (int64_t k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) found |= int64_t(cols[k]) == r;
+        if (!found) *missing = 1;
+    }
+}
+
+// csr::add_scaled_identity (:1402-1418): every stored value *= beta, the diagonal ones += alpha
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void csr_add_scaled_identity_kernel(int64_t n_rows,
+                                                                      const I* __restrict__ row_ptrs,
+                                                                      const I* __restrict__ cols,
+                                                                      T* __restrict__ vals,
+                                                                      const T* __restrict__ alpha,
+                                                                      const T* __restrict__ beta)
+{
+    const T a = alpha[0], b = beta[0];
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        for (int64_t k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+            T v = vals[k] * b;
+            if (int64_t(cols[k]) == r) v += a;
+            vals[k] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------- Ell / Sellp / Hybrid -> Csr
+template <typename I>
+__global__ __launch_bounds__(256) void ell_count_kernel(int64_t n_rows, int64_t ell_k, int64_t stride,
+                                                        const I* __restrict__ cols, I* __restrict__ out)
+{
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        I c = 0;
+        for (int64_t k = 0; k < ell_k; ++k) c += cols[r + k * stride] != I(-1) ? I(1) : I(0);
+        out[r] = c;
+    }
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void sellp_count_kernel(int64_t n_rows, int64_t slice_size,
+                                                          const uint64_t* __restrict__ slice_sets,
+                                                          const I* __restrict__ cols, I* __restrict__ out)
+{
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        const int64_t sl = r / slice_size, lr = r - sl * slice_size;
+        I c = 0;
+        for (int64_t i = int64_t(slice_sets[sl]); i < int64_t(slice_sets[sl + 1]); ++i) {
+            c += cols[lr + i * slice_size] != I(-1) ? I(1) : I(0);
+        }
+        out[r] = c;
+    }
+}
+
+// the stored entries of a row in storage order, padding skipped wherever it sits
+// (reference/matrix/ell_kernels.cpp:212-237, sellp_kernels.cpp:246-285)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void ell_to_csr_kernel(int64_t n_rows, int64_t ell_k, int64_t stride,
+                                                         const I* __restrict__ cols,
+                                                         const T* __restrict__ vals,
+                                                         const I* __restrict__ row_ptrs,
+                                                         I* __restrict__ out_cols,
+                                                         T* __restrict__ out_vals)
+{
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        int64_t at = row_ptrs[r];
+        for (int64_t k = 0; k < ell_k; ++k) {
+            const I c = cols[r + k * stride];
+            if (c != I(-1)) {
+                out_cols[at] = c;
+                out_vals[at] = vals[r + k * stride];
+                ++at;
+            }
+        }
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void sellp_to_csr_kernel(int64_t n_rows, int64_t slice_size,
+                                                           const uint64_t* __restrict__ slice_sets,
+                                                           const I* __restrict__ cols,
+                                                           const T* __restrict__ vals,
+                                                           const I* __restrict__ row_ptrs,
+                                                           I* __restrict__ out_cols,
+                                                           T* __restrict__ out_vals)
+{
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        const int64_t sl = r / slice_size, lr = r - sl * slice_size;
+        int64_t at = row_ptrs[r];
+        for (int64_t i = int64_t(slice_sets[sl]); i < int64_t(slice_sets[sl + 1]); ++i) {
+            const I c = cols[lr + i * slice_size];
+            if (c != I(-1)) {
+                out_cols[at] = c;
+                out_vals[at] = vals[lr + i * slice_size];
+                ++at;
+            }
+        }
+    }
+}
+
+// hybrid::convert_to_csr (reference/matrix/hybrid_kernels.cpp:94-131): a row's Ell entries, then
+// its Coo entries; ell_row_ptrs / coo_row_ptrs are the exclusive sums core/matrix/hybrid.cpp:300-308
+// computes, out_row_ptrs = their sum
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void hybrid_to_csr_kernel(
+    int64_t n_rows, int64_t ell_k, int64_t stride, const I* __restrict__ ell_cols,
+    const T* __restrict__ ell_vals, const I* __restrict__ coo_cols, const T* __restrict__ coo_vals,
+    const I* __restrict__ ell_row_ptrs, const I* __restrict__ coo_row_ptrs, I* __restrict__ out_row_ptrs,
+    I* __restrict__ out_cols, T* __restrict__ out_vals)
+{
+    GKOC_FOR_EACH(r, n_rows + 1)
+    {
+        int64_t at = int64_t(ell_row_ptrs[r]) + int64_t(coo_row_ptrs[r]);
+        out_row_ptrs[r] = I(at);
+        if (r == n_rows) continue;
+        for (int64_t k = 0; k < ell_k; ++k) {
+            const I c = ell_cols[r + k * stride];
+            if (c != I(-1)) {
+                out_cols[at] = c;
+                out_vals[at] = ell_vals[r + k * stride];
+                ++at;
+            }
+        }
+        for (int64_t k = coo_row_ptrs[r]; k < coo_row_ptrs[r + 1]; ++k) {
+            out_cols[at] = coo_cols[k];
+            out_vals[at] = coo_vals[k];
+            ++at;
+        }
+    }
+}
+
+#define CV_LAUNCH(kernel, n, ...)                                                     \
+    do {                                                                              \
+        if ((n) > 0) {                                                                \
+            kernel<<<dim3(cv_grid(n)), dim3(256), 0, as_stream(s)>>>(__VA_ARGS__);    \
+            GKOC_LAUNCH_OK();                                                         \
+        }                                                                             \
+    } while (0)
+
+}  // namespace
+}  // namespace gkoc
+
+using namespace gkoc;
+
+#define GKOC_DEF_FILL_SEQ(T, TN)                                                  \
+    extern "C" int gkoc_fill_seq_array_##TN(gkoc_stream_t s, T* data, int64_t n)  \
+    {                                                                             \
+        GKOC_REQUIRE(n >= 0 && (n == 0 || data), GKOC_E_INVALID, "bad argument"); \
+        CV_LAUNCH(fill_seq_kernel<T>, n, n, data);                                \
+        return GKOC_OK;                                                           \
+    }
+GKOC_DEF_FILL_SEQ(double, f64)
+GKOC_DEF_FILL_SEQ(float, f32)
+GKOC_DEF_FILL_SEQ(uint64_t, u64)
+
+#define GKOC_DEF_CV_DENSE(T, TN)                                                                       \
+    extern "C" int gkoc_dense_transpose_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in, \
+                                             int64_t ldi, T* out, int64_t ldo)                         \
+    {                                                                                                  \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0, GKOC_E_INVALID, "negative dimension");                    \
+        GKOC_REQUIRE(rows * cols == 0 || (in && out && in != out), GKOC_E_INVALID, "bad operand");     \
+        CV_LAUNCH(dense_transpose_kernel<T>, rows* cols, rows, cols, in, ldi, out, ldo);               \
+        return GKOC_OK;                                                                                \
+    }                                                                                                  \
+    extern "C" int gkoc_dense_extract_diagonal_##TN(gkoc_stream_t s, int64_t n, const T* in,           \
+                                                    int64_t ld, T* diag)                               \
+    {                                                                                                  \
+        GKOC_REQUIRE(n >= 0 && (n == 0 || (in && diag)), GKOC_E_INVALID, "bad argument");              \
+        CV_LAUNCH(dense_extract_diagonal_kernel<T>, n, n, in, ld, diag);                               \
+        return GKOC_OK;                                                                                \
+    }                                                                                                  \
+    extern "C" int gkoc_dense_add_scaled_identity_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,    \
+                                                       const T* alpha, const T* beta, T* m,            \
+                                                       int64_t ld)                                     \
+    {                                                                                                  \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0 && alpha && beta, GKOC_E_INVALID, "bad argument");         \
+        CV_LAUNCH(dense_add_scaled_identity_kernel<T>, rows* cols, rows, cols, alpha, beta, m, ld);    \
+        return GKOC_OK;                                                                                \
+    }                                                                                                  \
+    extern "C" int gkoc_dense_add_scaled_diag_##TN(gkoc_stream_t s, int64_t n, const T* alpha,         \
+                                                   const T* diag, T* y, int64_t ldy, int subtract)     \
+    {                                                                                                  \
+        GKOC_REQUIRE(n >= 0 && alpha && (n == 0 || (diag && y)), GKOC_E_INVALID, "bad argument");      \
+        if (subtract) {                                                                                \
+            CV_LAUNCH((dense_scaled_diag_kernel<T, true>), n, n, alpha, diag, y, ldy);                 \
+        } else {                                                                                       \
+            CV_LAUNCH((dense_scaled_diag_kernel<T, false>), n, n, alpha, diag, y, ldy);                \
+        }                                                                                              \
+        return GKOC_OK;                                                                                \
+    }                                                                                                  \
+    extern "C" int gkoc_dense_count_nonzeros_per_row_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, \
+                                                          const T* in, int64_t ld, void* out,          \
+                                                          int out_bytes)                               \
+    {                                                                                                  \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0 && (out_bytes == 4 || out_bytes == 8), GKOC_E_INVALID,     \
+                     "bad argument");                                                                  \
+        if (out_bytes == 4) {                                                                          \
+            CV_LAUNCH((dense_count_nnz_kernel<T, int32_t>), rows, rows, cols, in, ld,                  \
+                      static_cast<int32_t*>(out));                                                     \
+        } else {                                                                                       \
+            CV_LAUNCH((dense_count_nnz_kernel<T, int64_t>), rows, rows, cols, in, ld,                  \
+                      static_cast<int64_t*>(out));                                                     \
+        }                                                                                              \
+        return GKOC_OK;                                                                                \
+    }                                                                                                  \
+    extern "C" int gkoc_dense_max_nnz_per_row_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,        \
+                                                   const T* in, int64_t ld, uint64_t* result_host)     \
+    {                                                                                                  \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0 && result_host, GKOC_E_INVALID, "bad argument");           \
+        *result_host = 0;                                                                              \
+        if (rows == 0 || cols == 0) return GKOC_OK;                                                    \
+        void* d = nullptr;                                                                             \
+        GKOC_TRY(scratch_malloc(as_stream(s), &d, 8));                                                 \
+        GKOC_HIP(hipMemsetAsync(d, 0, 8, as_stream(s)));                                               \
+        CV_LAUNCH(dense_max_nnz_kernel<T>, rows, rows, cols, in, ld,                                   \
+                  static_cast<unsigned long long*>(d));                                                \
+        GKOC_HIP(hipMemcpyAsync(result_host, d, 8, hipMemcpyDeviceToHost, as_stream(s)));              \
+        GKOC_HIP(hipStreamSynchronize(as_stream(s)));                                                  \
+        return scratch_free(as_stream(s), d);                                                          \
+    }                                                                                                  \
+    extern "C" int gkoc_dense_compute_slice_sets_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,     \
+                                                      const T* in, int64_t ld, int64_t slice_size,     \
+                                                      int64_t stride_factor, uint64_t* slice_sets,     \
+                                                      uint64_t* slice_lengths)                         \
+    {                                                                                                  \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0 && slice_size > 0 && stride_factor > 0 && slice_sets,      \
+                     GKOC_E_INVALID, "bad argument");                                                  \
+        const int64_t ns = ceildiv(rows, slice_size);                                                  \
+        GKOC_REQUIRE(ns == 0 || slice_lengths, GKOC_E_INVALID, "null slice_lengths");                  \
+        CV_LAUNCH(dense_slice_lengths_kernel<T>, ns + 1, rows, cols, in, ld, slice_size,               \
+                  stride_factor, ns, slice_lengths, slice_sets);                                       \
+        return device_exclusive_scan<uint64_t>(as_stream(s), slice_sets, ns + 1);                      \
+    }
+GKOC_DEF_CV_DENSE(double, f64)
+GKOC_DEF_CV_DENSE(float, f32)
+
+#define GKOC_DEF_CV(T, TN, I, IN)                                                                       \
+    extern "C" int gkoc_dense_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols,           \
+                                                 const T* in, int64_t ld, const I* row_ptrs,            \
+                                                 I* out_cols, T* out_vals)                              \
+    {                                                                                                   \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0 && (rows == 0 || row_ptrs), GKOC_E_INVALID, "bad argument"); \
+        CV_LAUNCH((dense_to_rows_kernel<T, I, I>), rows, rows, cols, in, ld, row_ptrs,                  \
+                  static_cast<I*>(nullptr), out_cols, out_vals);                                        \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_dense_to_coo_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols,           \
+                                                 const T* in, int64_t ld, const int64_t* row_ptrs,      \
+                                                 I* out_rows, I* out_cols, T* out_vals)                 \
+    {                                                                                                   \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0 && (rows == 0 || row_ptrs), GKOC_E_INVALID, "bad argument"); \
+        CV_LAUNCH((dense_to_rows_kernel<T, I, int64_t>), rows, rows, cols, in, ld, row_ptrs, out_rows,  \
+                  out_cols, out_vals);                                                                  \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_dense_to_ell_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols,           \
+                                                 const T* in, int64_t ld, int64_t ell_k,                \
+                                                 int64_t ell_lim, int64_t stride, I* ell_cols,          \
+                                                 T* ell_vals, const int64_t* coo_row_ptrs,              \
+                                                 I* coo_rows, I* coo_cols, T* coo_vals)                 \
+    {                                                                                                   \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0 && ell_k >= 0 && stride >= rows, GKOC_E_INVALID,            \
+                     "bad argument");                                                                   \
+        CV_LAUNCH((dense_to_ell_kernel<T, I>), stride, rows, cols, in, ld, ell_k, ell_lim, stride,      \
+                  ell_cols, ell_vals, coo_row_ptrs, coo_rows, coo_cols, coo_vals);                      \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_dense_to_sellp_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols,         \
+                                                   const T* in, int64_t ld, int64_t slice_size,         \
+                                                   const uint64_t* slice_sets, I* out_cols,             \
+                                                   T* out_vals)                                         \
+    {                                                                                                   \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0 && slice_size > 0, GKOC_E_INVALID, "bad argument");         \
+        CV_LAUNCH((dense_to_sellp_kernel<T, I>), rows, rows, cols, in, ld, slice_size, slice_sets,      \
+                  out_cols, out_vals);                                                                  \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_csr_fill_in_dense_##TN##_##IN(gkoc_stream_t s, int64_t n_rows,                  \
+                                                      const I* row_ptrs, const I* cols,                 \
+                                                      const T* vals, T* out, int64_t ld)                \
+    {                                                                                                   \
+        CV_LAUNCH((csr_fill_in_dense_kernel<T, I>), n_rows, n_rows, row_ptrs, cols, vals, out, ld);     \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_coo_fill_in_dense_##TN##_##IN(gkoc_stream_t s, int64_t nnz, const I* rows,      \
+                                                      const I* cols, const T* vals, T* out,             \
+                                                      int64_t ld)                                       \
+    {                                                                                                   \
+        CV_LAUNCH((coo_fill_in_dense_kernel<T, I>), nnz, nnz, rows, cols, vals, out, ld);               \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_ell_fill_in_dense_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t ell_k,   \
+                                                      int64_t stride, const I* cols, const T* vals,     \
+                                                      T* out, int64_t ld)                               \
+    {                                                                                                   \
+        CV_LAUNCH((ell_fill_in_dense_kernel<T, I>), n_rows, n_rows, ell_k, stride, cols, vals, out, ld); \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_sellp_fill_in_dense_##TN##_##IN(gkoc_stream_t s, int64_t n_rows,                \
+                                                        int64_t slice_size,                             \
+                                                        const uint64_t* slice_sets, const I* cols,      \
+                                                        const T* vals, T* out, int64_t ld)              \
+    {                                                                                                   \
+        GKOC_REQUIRE(slice_size > 0, GKOC_E_INVALID, "bad slice size");                                 \
+        CV_LAUNCH((sellp_fill_in_dense_kernel<T, I>), n_rows, n_rows, slice_size, slice_sets, cols,     \
+                  vals, out, ld);                                                                       \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_ell_extract_diagonal_##TN##_##IN(gkoc_stream_t s, int64_t n, int64_t ell_k,     \
+                                                         int64_t stride, const I* cols,                 \
+                                                         const T* vals, T* diag)                        \
+    {                                                                                                   \
+        CV_LAUNCH((ell_extract_diagonal_kernel<T, I>), n, n, ell_k, stride, cols, vals, diag);          \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_sellp_extract_diagonal_##TN##_##IN(gkoc_stream_t s, int64_t n,                  \
+                                                           int64_t slice_size,                          \
+                                                           const uint64_t* slice_sets, const I* cols,   \
+                                                           const T* vals, T* diag)                      \
+    {                                                                                                   \
+        GKOC_REQUIRE(slice_size > 0, GKOC_E_INVALID, "bad slice size");                                 \
+        CV_LAUNCH((sellp_extract_diagonal_kernel<T, I>), n, n, slice_size, slice_sets, cols, vals,      \
+                  diag);                                                                                \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_coo_extract_diagonal_##TN##_##IN(gkoc_stream_t s, int64_t nnz, const I* rows,   \
+                                                         const I* cols, const T* vals, T* diag)         \
+    {                                                                                                   \
+        CV_LAUNCH((coo_extract_diagonal_kernel<T, I>), nnz, nnz, rows, cols, vals, diag);               \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_csr_add_scaled_identity_##TN##_##IN(gkoc_stream_t s, int64_t n_rows,            \
+                                                            const I* row_ptrs, const I* cols, T* vals,  \
+                                                            const T* alpha, const T* beta)              \
+    {                                                                                                   \
+        GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null scalar");                                     \
+        CV_LAUNCH((csr_add_scaled_identity_kernel<T, I>), n_rows, n_rows, row_ptrs, cols, vals, alpha,  \
+                  beta);                                                                                \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_ell_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t ell_k,          \
+                                               int64_t stride, const I* cols, const T* vals,            \
+                                               const I* row_ptrs, I* out_cols, T* out_vals)             \
+    {                                                                                                   \
+        CV_LAUNCH((ell_to_csr_kernel<T, I>), n_rows, n_rows, ell_k, stride, cols, vals, row_ptrs,       \
+                  out_cols, out_vals);                                                                  \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_sellp_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t slice_size,   \
+                                                 const uint64_t* slice_sets, const I* cols,             \
+                                                 const T* vals, const I* row_ptrs, I* out_cols,         \
+                                                 T* out_vals)                                           \
+    {                                                                                                   \
+        GKOC_REQUIRE(slice_size > 0, GKOC_E_INVALID, "bad slice size");                                 \
+        CV_LAUNCH((sellp_to_csr_kernel<T, I>), n_rows, n_rows, slice_size, slice_sets, cols, vals,      \
+                  row_ptrs, out_cols, out_vals);                                                        \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_hybrid_to_csr_##TN##_##IN(                                                      \
+        gkoc_stream_t s, int64_t n_rows, int64_t ell_k, int64_t stride, const I* ell_cols,              \
+        const T* ell_vals, const I* coo_cols, const T* coo_vals, const I* ell_row_ptrs,                 \
+        const I* coo_row_ptrs, I* out_row_ptrs, I* out_cols, T* out_vals)                               \
+    {                                                                                                   \
+        GKOC_REQUIRE(n_rows >= 0 && ell_row_ptrs && coo_row_ptrs && out_row_ptrs, GKOC_E_INVALID,       \
+                     "bad argument");                                                                   \
+        CV_LAUNCH((hybrid_to_csr_kernel<T, I>), n_rows + 1, n_rows, ell_k, stride, ell_cols, ell_vals,  \
+                  coo_cols, coo_vals, ell_row_ptrs, coo_row_ptrs, out_row_ptrs, out_cols, out_vals);    \
+        return GKOC_OK;                                                                                 \
+    }
+GKOC_DEF_CV(double, f64, int32_t, i32)
+GKOC_DEF_CV(double, f64, int64_t, i64)
+GKOC_DEF_CV(float, f32, int32_t, i32)
+GKOC_DEF_CV(float, f32, int64_t, i64)
+
+#define GKOC_DEF_CV_INDEX(I, IN)                                                                        \
+    extern "C" int gkoc_ell_count_nonzeros_per_row_##IN(gkoc_stream_t s, int64_t n_rows,                \
+                                                        int64_t ell_k, int64_t stride, const I* cols,   \
+                                                        I* out)                                         \
+    {                                                                                                   \
+        CV_LAUNCH(ell_count_kernel<I>, n_rows, n_rows, ell_k, stride, cols, out);                       \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_sellp_count_nonzeros_per_row_##IN(gkoc_stream_t s, int64_t n_rows,              \
+                                                          int64_t slice_size,                           \
+                                                          const uint64_t* slice_sets, const I* cols,    \
+                                                          I* out)                                       \
+    {                                                                                                   \
+        GKOC_REQUIRE(slice_size > 0, GKOC_E_INVALID, "bad slice size");                                 \
+        CV_LAUNCH(sellp_count_kernel<I>, n_rows, n_rows, slice_size, slice_sets, cols, out);            \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    /* *missing_host = 1 if some row r < n has no entry (r, r) */                                       \
+    extern "C" int gkoc_csr_missing_diagonal_##IN(gkoc_stream_t s, int64_t n, const I* row_ptrs,        \
+                                                  const I* cols, int* missing_host)                     \
+    {                                                                                                   \
+        GKOC_REQUIRE(n >= 0 && missing_host, GKOC_E_INVALID, "bad argument");                           \
+        *missing_host = 0;                                                                              \
+        if (n == 0) return GKOC_OK;                                                                     \
+        void* d = nullptr;                                                                              \
+        GKOC_TRY(scratch_malloc(as_stream(s), &d, 4));                                                  \
+        GKOC_HIP(hipMemsetAsync(d, 0, 4, as_stream(s)));                                                \
+        CV_LAUNCH(csr_missing_diagonal_kernel<I>, n, n, row_ptrs, cols, static_cast<int*>(d));          \
+        GKOC_HIP(hipMemcpyAsync(missing_host, d, 4, hipMemcpyDeviceToHost, as_stream(s)));              \
+        GKOC_HIP(hipStreamSynchronize(as_stream(s)));                                                   \
+        return scratch_free(as_stream(s), d);                                                           \
+    }
+GKOC_DEF_CV_INDEX(int32_t, i32)
+GKOC_DEF_CV_INDEX(int64_t, i64)

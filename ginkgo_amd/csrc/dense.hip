@@ -126,14 +126,15 @@ struct op_axpy {
 constexpr int red_block = 256;
 constexpr int max_partials = 1024;
 
-template <typename T, bool SQUARE>
+template <typename T, int SQUARE>
 __device__ __forceinline__ T red_term(T x, T y)
 {
-    return SQUARE ? x * x : x * y;
+    // SQUARE: 0 x y (dot), 1 x x (squared norm), 2 |x| (1-norm)
+    return SQUARE == 2 ? (x < T(0) ? -x : x) : SQUARE ? x * x : x * y;
 }
 
 // flat (ld == 1, one column) stage 1
-template <typename T, bool SQUARE>
+template <typename T, int SQUARE>
 __global__ __launch_bounds__(red_block) void reduce_flat_stage1(
     int64_t n, const T* __restrict__ x, const T* __restrict__ y,
     T* __restrict__ partial, bool vec_ok)
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(red_block) void reduce_flat_stage1(
 }
 
 // general (strided, multi-column) stage 1: grid = (blocks_x, cols)
-template <typename T, bool SQUARE>
+template <typename T, int SQUARE>
 __global__ __launch_bounds__(red_block) void reduce_cols_stage1(
     int64_t rows, const T* __restrict__ x, int64_t ldx,
     const T* __restrict__ y, int64_t ldy, T* __restrict__ partial)
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(red_block) void reduce_stage2(
     if (threadIdx.x == 0) result[col] = SQRT ? sqrt(r) : r;
 }
 
-template <typename T, bool SQUARE, bool SQRT>
+template <typename T, int SQUARE, bool SQRT>
 int launch_reduce(gkoc_stream_t s, int64_t rows, int64_t cols, const T* x,
                   int64_t ldx, const T* y, int64_t ldy, T* result, void* work,
                   size_t work_bytes)
@@ -435,6 +436,13 @@ extern "C" size_t gkoc_reduction_workspace_bytes(int64_t, int64_t nrhs,
     {                                                                          \
         return launch_reduce<T, true, true>(s, rows, cols, x, ldx, nullptr, 0, \
                                             result, work, work_bytes);         \
+    }                                                                          \
+    extern "C" int gkoc_dense_compute_norm1_##TN(                              \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const T* x, int64_t ldx,  \
+        T* result, void* work, size_t work_bytes)                              \
+    {                                                                          \
+        return launch_reduce<T, 2, false>(s, rows, cols, x, ldx, nullptr, 0,   \
+                                          result, work, work_bytes);           \
     }                                                                          \
     extern "C" int gkoc_dense_compute_squared_norm2_##TN(                      \
         gkoc_stream_t s, int64_t rows, int64_t cols, const T* x, int64_t ldx,  \

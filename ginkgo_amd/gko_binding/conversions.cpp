@@ -1,0 +1,425 @@
+// gko::kernels::hip: the conversions between Dense / Csr / Coo / Ell / Sellp / Hybrid that Ginkgo's
+// matrix classes run on the device, and the diagonal / transpose / 1-norm helpers, forwarded to the
+// C ABI (csrc/conversions.hip).  Real value types; complex stays with Ginkgo's NotCompiled stubs.
+#include <ginkgo/core/matrix/coo.hpp>
+#include <ginkgo/core/matrix/csr.hpp>
+#include <ginkgo/core/matrix/dense.hpp>
+#include <ginkgo/core/matrix/diagonal.hpp>
+#include <ginkgo/core/matrix/ell.hpp>
+#include <ginkgo/core/matrix/hybrid.hpp>
+#include <ginkgo/core/matrix/sellp.hpp>
+#include <ginkgo/core/matrix/sparsity_csr.hpp>
+
+#include "core/components/absolute_array_kernels.hpp"
+#include "core/components/fill_array_kernels.hpp"
+#include "core/matrix/coo_kernels.hpp"
+#include "core/matrix/csr_kernels.hpp"
+#include "core/matrix/dense_kernels.hpp"
+#include "core/matrix/ell_kernels.hpp"
+#include "core/matrix/hybrid_kernels.hpp"
+#include "core/matrix/sellp_kernels.hpp"
+#include "shim_common.hpp"
+
+namespace gko {
+namespace kernels {
+namespace hip {
+
+using cdna4::cols;
+using cdna4::ld;
+using cdna4::rows;
+using cdna4::stream_of;
+using exec_t = std::shared_ptr<const HipExecutor>;
+
+#define FOR_VT(M) M(double, f64) M(float, f32)
+#define FOR_VT_IT(M)                                                                \
+    M(double, f64, int32, i32) M(double, f64, int64, i64) M(float, f32, int32, i32) \
+        M(float, f32, int64, i64)
+
+inline const uint64_t* u64(const size_type* p) { return reinterpret_cast<const uint64_t*>(p); }
+inline uint64_t* u64(size_type* p) { return reinterpret_cast<uint64_t*>(p); }
+
+
+namespace components {
+
+#define DEF(T, TN)                                                                              \
+    template <>                                                                                 \
+    void inplace_absolute_array<T>(exec_t exec, T* data, size_type n)                           \
+    {                                                                                           \
+        GKOC_CALL(gkoc_dense_absolute_##TN(stream_of(exec), static_cast<int64_t>(n), 1, data, 1, \
+                                           data, 1));                                           \
+    }                                                                                           \
+    template <>                                                                                 \
+    void outplace_absolute_array<T>(exec_t exec, const T* in, size_type n, T* out)              \
+    {                                                                                           \
+        GKOC_CALL(gkoc_dense_absolute_##TN(stream_of(exec), static_cast<int64_t>(n), 1, in, 1,   \
+                                           out, 1));                                            \
+    }                                                                                           \
+    template <>                                                                                 \
+    void fill_seq_array<T>(exec_t exec, T* data, size_type n)                                   \
+    {                                                                                           \
+        GKOC_CALL(gkoc_fill_seq_array_##TN(stream_of(exec), data, static_cast<int64_t>(n)));    \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+template <>
+void fill_seq_array<size_type>(exec_t exec, size_type* data, size_type n)
+{
+    GKOC_CALL(gkoc_fill_seq_array_u64(stream_of(exec), u64(data), static_cast<int64_t>(n)));
+}
+
+}  // namespace components
+
+
+namespace dense {
+
+#define DEF(T, TN)                                                                                  \
+    template <>                                                                                     \
+    void compute_norm1<T>(exec_t exec, const matrix::Dense<T>* x, matrix::Dense<T>* result,         \
+                          array<char>& tmp)                                                         \
+    {                                                                                               \
+        const auto s = stream_of(exec);                                                             \
+        const size_t bytes = gkoc_reduction_workspace_bytes(rows(x), cols(x), sizeof(T));           \
+        if (tmp.get_size() < bytes) tmp.resize_and_reset(bytes);                                    \
+        GKOC_CALL(gkoc_dense_compute_norm1_##TN(s, rows(x), cols(x), x->get_const_values(), ld(x),  \
+                                                result->get_values(), tmp.get_data(), bytes));      \
+    }                                                                                               \
+    template <>                                                                                     \
+    void transpose<T>(exec_t exec, const matrix::Dense<T>* orig, matrix::Dense<T>* trans)           \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_transpose_##TN(stream_of(exec), rows(orig), cols(orig),                \
+                                            orig->get_const_values(), ld(orig),                     \
+                                            trans->get_values(), ld(trans)));                       \
+    }                                                                                               \
+    template <>                                                                                     \
+    void conj_transpose<T>(exec_t exec, const matrix::Dense<T>* orig, matrix::Dense<T>* trans)      \
+    {                                                                                               \
+        transpose<T>(exec, orig, trans);                                                            \
+    }                                                                                               \
+    template <>                                                                                     \
+    void extract_diagonal<T>(exec_t exec, const matrix::Dense<T>* orig,                             \
+                             matrix::Diagonal<T>* diag)                                             \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_extract_diagonal_##TN(                                                 \
+            stream_of(exec), static_cast<int64_t>(diag->get_size()[0]), orig->get_const_values(),   \
+            ld(orig), diag->get_values()));                                                         \
+    }                                                                                               \
+    template <>                                                                                     \
+    void add_scaled_identity<T, T>(exec_t exec, const matrix::Dense<T>* alpha,                      \
+                                   const matrix::Dense<T>* beta, matrix::Dense<T>* mtx)             \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_add_scaled_identity_##TN(                                              \
+            stream_of(exec), rows(mtx), cols(mtx), alpha->get_const_values(),                       \
+            beta->get_const_values(), mtx->get_values(), ld(mtx)));                                 \
+    }                                                                                               \
+    template <>                                                                                     \
+    void add_scaled_diag<T>(exec_t exec, const matrix::Dense<T>* alpha,                             \
+                            const matrix::Diagonal<T>* x, matrix::Dense<T>* y)                      \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_add_scaled_diag_##TN(                                                  \
+            stream_of(exec), static_cast<int64_t>(x->get_size()[0]), alpha->get_const_values(),     \
+            x->get_const_values(), y->get_values(), ld(y), 0));                                     \
+    }                                                                                               \
+    template <>                                                                                     \
+    void sub_scaled_diag<T>(exec_t exec, const matrix::Dense<T>* alpha,                             \
+                            const matrix::Diagonal<T>* x, matrix::Dense<T>* y)                      \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_add_scaled_diag_##TN(                                                  \
+            stream_of(exec), static_cast<int64_t>(x->get_size()[0]), alpha->get_const_values(),     \
+            x->get_const_values(), y->get_values(), ld(y), 1));                                     \
+    }                                                                                               \
+    template <>                                                                                     \
+    void count_nonzeros_per_row<T, int32>(exec_t exec, const matrix::Dense<T>* source,              \
+                                          int32* result)                                            \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_count_nonzeros_per_row_##TN(stream_of(exec), rows(source),             \
+                                                         cols(source), source->get_const_values(),  \
+                                                         ld(source), result, 4));                   \
+    }                                                                                               \
+    template <>                                                                                     \
+    void count_nonzeros_per_row<T, int64>(exec_t exec, const matrix::Dense<T>* source,              \
+                                          int64* result)                                            \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_count_nonzeros_per_row_##TN(stream_of(exec), rows(source),             \
+                                                         cols(source), source->get_const_values(),  \
+                                                         ld(source), result, 8));                   \
+    }                                                                                               \
+    template <>                                                                                     \
+    void count_nonzeros_per_row<T, size_type>(exec_t exec, const matrix::Dense<T>* source,          \
+                                              size_type* result)                                    \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_count_nonzeros_per_row_##TN(stream_of(exec), rows(source),             \
+                                                         cols(source), source->get_const_values(),  \
+                                                         ld(source), result, 8));                   \
+    }                                                                                               \
+    template <>                                                                                     \
+    void compute_max_nnz_per_row<T>(exec_t exec, const matrix::Dense<T>* source,                    \
+                                    size_type& result)                                              \
+    {                                                                                               \
+        uint64_t r = 0;                                                                             \
+        GKOC_CALL(gkoc_dense_max_nnz_per_row_##TN(stream_of(exec), rows(source), cols(source),      \
+                                                  source->get_const_values(), ld(source), &r));     \
+        result = static_cast<size_type>(r);                                                         \
+    }                                                                                               \
+    template <>                                                                                     \
+    void compute_slice_sets<T>(exec_t exec, const matrix::Dense<T>* source, size_type slice_size,   \
+                               size_type stride_factor, size_type* slice_sets,                      \
+                               size_type* slice_lengths)                                            \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_compute_slice_sets_##TN(                                               \
+            stream_of(exec), rows(source), cols(source), source->get_const_values(), ld(source),    \
+            static_cast<int64_t>(slice_size), static_cast<int64_t>(stride_factor),                  \
+            u64(slice_sets), u64(slice_lengths)));                                                  \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void convert_to_csr<T, I>(exec_t exec, const matrix::Dense<T>* source,                          \
+                              matrix::Csr<T, I>* result)                                            \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_to_csr_##TN##_##IN(                                                    \
+            stream_of(exec), rows(source), cols(source), source->get_const_values(), ld(source),    \
+            result->get_const_row_ptrs(), result->get_col_idxs(), result->get_values()));           \
+    }                                                                                               \
+    template <>                                                                                     \
+    void convert_to_sparsity_csr<T, I>(exec_t exec, const matrix::Dense<T>* source,                 \
+                                       matrix::SparsityCsr<T, I>* result)                           \
+    {                                                                                               \
+        const auto s = stream_of(exec);                                                             \
+        GKOC_CALL(gkoc_dense_to_csr_##TN##_##IN(s, rows(source), cols(source),                      \
+                                                source->get_const_values(), ld(source),             \
+                                                result->get_const_row_ptrs(),                       \
+                                                result->get_col_idxs(), nullptr));                  \
+        GKOC_CALL(gkoc_fill_array_##TN(s, result->get_value(), 1, T(1)));                           \
+    }                                                                                               \
+    template <>                                                                                     \
+    void convert_to_coo<T, I>(exec_t exec, const matrix::Dense<T>* source, const int64* row_ptrs,   \
+                              matrix::Coo<T, I>* result)                                            \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_to_coo_##TN##_##IN(                                                    \
+            stream_of(exec), rows(source), cols(source), source->get_const_values(), ld(source),    \
+            row_ptrs, result->get_row_idxs(), result->get_col_idxs(), result->get_values()));       \
+    }                                                                                               \
+    template <>                                                                                     \
+    void convert_to_ell<T, I>(exec_t exec, const matrix::Dense<T>* source,                          \
+                              matrix::Ell<T, I>* result)                                            \
+    {                                                                                               \
+        const int64_t k = static_cast<int64_t>(result->get_num_stored_elements_per_row());          \
+        GKOC_CALL(gkoc_dense_to_ell_##TN##_##IN(                                                    \
+            stream_of(exec), rows(source), cols(source), source->get_const_values(), ld(source), k, \
+            k, static_cast<int64_t>(result->get_stride()), result->get_col_idxs(),                  \
+            result->get_values(), nullptr, nullptr, nullptr, nullptr));                             \
+    }                                                                                               \
+    template <>                                                                                     \
+    void convert_to_hybrid<T, I>(exec_t exec, const matrix::Dense<T>* source,                       \
+                                 const int64* coo_row_ptrs, matrix::Hybrid<T, I>* result)           \
+    {                                                                                               \
+        const int64_t k = static_cast<int64_t>(result->get_ell_num_stored_elements_per_row());      \
+        GKOC_CALL(gkoc_dense_to_ell_##TN##_##IN(                                                    \
+            stream_of(exec), rows(source), cols(source), source->get_const_values(), ld(source), k, \
+            k, static_cast<int64_t>(result->get_ell_stride()), result->get_ell_col_idxs(),          \
+            result->get_ell_values(), coo_row_ptrs, result->get_coo_row_idxs(),                     \
+            result->get_coo_col_idxs(), result->get_coo_values()));                                 \
+    }                                                                                               \
+    template <>                                                                                     \
+    void convert_to_sellp<T, I>(exec_t exec, const matrix::Dense<T>* source,                        \
+                                matrix::Sellp<T, I>* result)                                        \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_to_sellp_##TN##_##IN(                                                  \
+            stream_of(exec), rows(source), cols(source), source->get_const_values(), ld(source),    \
+            static_cast<int64_t>(result->get_slice_size()), u64(result->get_const_slice_sets()),    \
+            result->get_col_idxs(), result->get_values()));                                         \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace dense
+
+
+namespace csr {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void fill_in_dense<T, I>(exec_t exec, const matrix::Csr<T, I>* source,                          \
+                             matrix::Dense<T>* result)                                              \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_fill_in_dense_##TN##_##IN(                                               \
+            stream_of(exec), static_cast<int64_t>(source->get_size()[0]),                           \
+            source->get_const_row_ptrs(), source->get_const_col_idxs(), source->get_const_values(), \
+            result->get_values(), ld(result)));                                                     \
+    }                                                                                               \
+    template <>                                                                                     \
+    void check_diagonal_entries_exist<T, I>(exec_t exec, const matrix::Csr<T, I>* mtx,              \
+                                            bool& has_all_diags)                                    \
+    {                                                                                               \
+        int missing = 0;                                                                            \
+        const auto n = std::min(mtx->get_size()[0], mtx->get_size()[1]);                            \
+        GKOC_CALL(gkoc_csr_missing_diagonal_##IN(stream_of(exec), static_cast<int64_t>(n),          \
+                                                 mtx->get_const_row_ptrs(),                         \
+                                                 mtx->get_const_col_idxs(), &missing));             \
+        has_all_diags = missing == 0;                                                               \
+    }                                                                                               \
+    template <>                                                                                     \
+    void add_scaled_identity<T, I>(exec_t exec, const matrix::Dense<T>* alpha,                      \
+                                   const matrix::Dense<T>* beta, matrix::Csr<T, I>* mtx)            \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_add_scaled_identity_##TN##_##IN(                                         \
+            stream_of(exec), static_cast<int64_t>(mtx->get_size()[0]), mtx->get_const_row_ptrs(),   \
+            mtx->get_const_col_idxs(), mtx->get_values(), alpha->get_const_values(),                \
+            beta->get_const_values()));                                                             \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace csr
+
+
+namespace coo {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void fill_in_dense<T, I>(exec_t exec, const matrix::Coo<T, I>* source,                          \
+                             matrix::Dense<T>* result)                                              \
+    {                                                                                               \
+        GKOC_CALL(gkoc_coo_fill_in_dense_##TN##_##IN(                                               \
+            stream_of(exec), static_cast<int64_t>(source->get_num_stored_elements()),               \
+            source->get_const_row_idxs(), source->get_const_col_idxs(), source->get_const_values(), \
+            result->get_values(), ld(result)));                                                     \
+    }                                                                                               \
+    template <>                                                                                     \
+    void extract_diagonal<T, I>(exec_t exec, const matrix::Coo<T, I>* orig,                         \
+                                matrix::Diagonal<T>* diag)                                          \
+    {                                                                                               \
+        GKOC_CALL(gkoc_coo_extract_diagonal_##TN##_##IN(                                            \
+            stream_of(exec), static_cast<int64_t>(orig->get_num_stored_elements()),                 \
+            orig->get_const_row_idxs(), orig->get_const_col_idxs(), orig->get_const_values(),       \
+            diag->get_values()));                                                                   \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace coo
+
+
+namespace ell {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void fill_in_dense<T, I>(exec_t exec, const matrix::Ell<T, I>* source,                          \
+                             matrix::Dense<T>* result)                                              \
+    {                                                                                               \
+        GKOC_CALL(gkoc_ell_fill_in_dense_##TN##_##IN(                                               \
+            stream_of(exec), static_cast<int64_t>(source->get_size()[0]),                           \
+            static_cast<int64_t>(source->get_num_stored_elements_per_row()),                        \
+            static_cast<int64_t>(source->get_stride()), source->get_const_col_idxs(),               \
+            source->get_const_values(), result->get_values(), ld(result)));                         \
+    }                                                                                               \
+    template <>                                                                                     \
+    void extract_diagonal<T, I>(exec_t exec, const matrix::Ell<T, I>* orig,                         \
+                                matrix::Diagonal<T>* diag)                                          \
+    {                                                                                               \
+        GKOC_CALL(gkoc_ell_extract_diagonal_##TN##_##IN(                                            \
+            stream_of(exec), static_cast<int64_t>(diag->get_size()[0]),                             \
+            static_cast<int64_t>(orig->get_num_stored_elements_per_row()),                          \
+            static_cast<int64_t>(orig->get_stride()), orig->get_const_col_idxs(),                   \
+            orig->get_const_values(), diag->get_values()));                                         \
+    }                                                                                               \
+    template <>                                                                                     \
+    void count_nonzeros_per_row<T, I>(exec_t exec, const matrix::Ell<T, I>* source, I* result)      \
+    {                                                                                               \
+        GKOC_CALL(gkoc_ell_count_nonzeros_per_row_##IN(                                             \
+            stream_of(exec), static_cast<int64_t>(source->get_size()[0]),                           \
+            static_cast<int64_t>(source->get_num_stored_elements_per_row()),                        \
+            static_cast<int64_t>(source->get_stride()), source->get_const_col_idxs(), result));     \
+    }                                                                                               \
+    template <>                                                                                     \
+    void convert_to_csr<T, I>(exec_t exec, const matrix::Ell<T, I>* source,                         \
+                              matrix::Csr<T, I>* result)                                            \
+    {                                                                                               \
+        GKOC_CALL(gkoc_ell_to_csr_##TN##_##IN(                                                      \
+            stream_of(exec), static_cast<int64_t>(source->get_size()[0]),                           \
+            static_cast<int64_t>(source->get_num_stored_elements_per_row()),                        \
+            static_cast<int64_t>(source->get_stride()), source->get_const_col_idxs(),               \
+            source->get_const_values(), result->get_const_row_ptrs(), result->get_col_idxs(),       \
+            result->get_values()));                                                                 \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace ell
+
+
+namespace sellp {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void fill_in_dense<T, I>(exec_t exec, const matrix::Sellp<T, I>* source,                        \
+                             matrix::Dense<T>* result)                                              \
+    {                                                                                               \
+        GKOC_CALL(gkoc_sellp_fill_in_dense_##TN##_##IN(                                             \
+            stream_of(exec), static_cast<int64_t>(source->get_size()[0]),                           \
+            static_cast<int64_t>(source->get_slice_size()), u64(source->get_const_slice_sets()),    \
+            source->get_const_col_idxs(), source->get_const_values(), result->get_values(),         \
+            ld(result)));                                                                           \
+    }                                                                                               \
+    template <>                                                                                     \
+    void extract_diagonal<T, I>(exec_t exec, const matrix::Sellp<T, I>* orig,                       \
+                                matrix::Diagonal<T>* diag)                                          \
+    {                                                                                               \
+        GKOC_CALL(gkoc_sellp_extract_diagonal_##TN##_##IN(                                          \
+            stream_of(exec), static_cast<int64_t>(diag->get_size()[0]),                             \
+            static_cast<int64_t>(orig->get_slice_size()), u64(orig->get_const_slice_sets()),        \
+            orig->get_const_col_idxs(), orig->get_const_values(), diag->get_values()));             \
+    }                                                                                               \
+    template <>                                                                                     \
+    void count_nonzeros_per_row<T, I>(exec_t exec, const matrix::Sellp<T, I>* source, I* result)    \
+    {                                                                                               \
+        GKOC_CALL(gkoc_sellp_count_nonzeros_per_row_##IN(                                           \
+            stream_of(exec), static_cast<int64_t>(source->get_size()[0]),                           \
+            static_cast<int64_t>(source->get_slice_size()), u64(source->get_const_slice_sets()),    \
+            source->get_const_col_idxs(), result));                                                 \
+    }                                                                                               \
+    template <>                                                                                     \
+    void convert_to_csr<T, I>(exec_t exec, const matrix::Sellp<T, I>* source,                       \
+                              matrix::Csr<T, I>* result)                                            \
+    {                                                                                               \
+        GKOC_CALL(gkoc_sellp_to_csr_##TN##_##IN(                                                    \
+            stream_of(exec), static_cast<int64_t>(source->get_size()[0]),                           \
+            static_cast<int64_t>(source->get_slice_size()), u64(source->get_const_slice_sets()),    \
+            source->get_const_col_idxs(), source->get_const_values(),                               \
+            result->get_const_row_ptrs(), result->get_col_idxs(), result->get_values()));           \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace sellp
+
+
+namespace hybrid {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void convert_to_csr<T, I>(exec_t exec, const matrix::Hybrid<T, I>* source,                      \
+                              const I* ell_row_ptrs, const I* coo_row_ptrs,                         \
+                              matrix::Csr<T, I>* result)                                            \
+    {                                                                                               \
+        const auto ell = source->get_ell();                                                         \
+        GKOC_CALL(gkoc_hybrid_to_csr_##TN##_##IN(                                                   \
+            stream_of(exec), static_cast<int64_t>(source->get_size()[0]),                           \
+            static_cast<int64_t>(ell->get_num_stored_elements_per_row()),                           \
+            static_cast<int64_t>(ell->get_stride()), ell->get_const_col_idxs(),                     \
+            ell->get_const_values(), source->get_const_coo_col_idxs(),                              \
+            source->get_const_coo_values(), ell_row_ptrs, coo_row_ptrs, result->get_row_ptrs(),     \
+            result->get_col_idxs(), result->get_values()));                                         \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace hybrid
+
+
+}  // namespace hip
+}  // namespace kernels
+}  // namespace gko

@@ -909,6 +909,107 @@ GKOC_DECL_XI(double, f64, int64_t, i64)
 GKOC_DECL_XI(float, f32, int32_t, i32)
 GKOC_DECL_XI(float, f32, int64_t, i64)
 
+/* ------------------------------------------- conversions and matrix utilities
+ * Everything Ginkgo's matrix classes ask the device for when a matrix moves between formats, and the
+ * diagonal / transpose / 1-norm helpers (csrc/conversions.hip; reference/matrix/{dense,csr,coo,ell,
+ * sellp,hybrid}_kernels.cpp, cited per kernel there).  Entry order of every output = the
+ * reference's.  Padding of Ell / Sellp: value 0, column -1 (invalid_index).  slice_sets are
+ * Ginkgo's size_type (uint64_t).  Row pointers of the *_to_csr / dense_to_* functions are inputs:
+ * the caller counts and scans first, as core/matrix/*.cpp does. */
+#define GKOC_DECL_CV_DENSE(T, TN)                                                                     \
+    int gkoc_fill_seq_array_##TN(gkoc_stream_t s, T* data, int64_t n);                                \
+    int gkoc_dense_compute_norm1_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* x,        \
+                                      int64_t ldx, T* result, void* work, size_t work_bytes);         \
+    int gkoc_dense_transpose_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,           \
+                                  int64_t ldi, T* out, int64_t ldo);                                  \
+    int gkoc_dense_extract_diagonal_##TN(gkoc_stream_t s, int64_t n, const T* in, int64_t ld,         \
+                                         T* diag);                                                    \
+    /* m = beta m + alpha I */                                                                        \
+    int gkoc_dense_add_scaled_identity_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,              \
+                                            const T* alpha, const T* beta, T* m, int64_t ld);         \
+    /* y(i,i) += alpha diag[i] (subtract != 0: -=); nothing for alpha == 0 */                         \
+    int gkoc_dense_add_scaled_diag_##TN(gkoc_stream_t s, int64_t n, const T* alpha, const T* diag,    \
+                                        T* y, int64_t ldy, int subtract);                             \
+    /* out: int32 / int64 / uint64 counts (out_bytes 4 or 8) */                                       \
+    int gkoc_dense_count_nonzeros_per_row_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,           \
+                                               const T* in, int64_t ld, void* out, int out_bytes);    \
+    int gkoc_dense_max_nnz_per_row_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,     \
+                                        int64_t ld, uint64_t* result_host);                           \
+    int gkoc_dense_compute_slice_sets_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,  \
+                                           int64_t ld, int64_t slice_size, int64_t stride_factor,     \
+                                           uint64_t* slice_sets, uint64_t* slice_lengths);
+GKOC_DECL_CV_DENSE(double, f64)
+GKOC_DECL_CV_DENSE(float, f32)
+int gkoc_fill_seq_array_u64(gkoc_stream_t s, uint64_t* data, int64_t n);
+#define GKOC_DECL_CV(T, TN, I, IN)                                                                    \
+    /* out_vals == NULL: pattern only (SparsityCsr) */                                                \
+    int gkoc_dense_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,       \
+                                      int64_t ld, const I* row_ptrs, I* out_cols, T* out_vals);       \
+    int gkoc_dense_to_coo_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,       \
+                                      int64_t ld, const int64_t* row_ptrs, I* out_rows,               \
+                                      I* out_cols, T* out_vals);                                      \
+    /* the first ell_lim non-zeros of a row go to Ell (ell_k columns of storage, padded over the      \
+     * whole stride), the rest - Hybrid, coo_row_ptrs != NULL - to Coo */                             \
+    int gkoc_dense_to_ell_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,       \
+                                      int64_t ld, int64_t ell_k, int64_t ell_lim, int64_t stride,     \
+                                      I* ell_cols, T* ell_vals, const int64_t* coo_row_ptrs,          \
+                                      I* coo_rows, I* coo_cols, T* coo_vals);                         \
+    int gkoc_dense_to_sellp_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,     \
+                                        int64_t ld, int64_t slice_size, const uint64_t* slice_sets,   \
+                                        I* out_cols, T* out_vals);                                    \
+    /* fill_in_dense: out is zero on entry; Coo adds (duplicates sum up) */                           \
+    int gkoc_csr_fill_in_dense_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,        \
+                                           const I* cols, const T* vals, T* out, int64_t ld);         \
+    int gkoc_coo_fill_in_dense_##TN##_##IN(gkoc_stream_t s, int64_t nnz, const I* rows,               \
+                                           const I* cols, const T* vals, T* out, int64_t ld);         \
+    int gkoc_ell_fill_in_dense_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t ell_k,            \
+                                           int64_t stride, const I* cols, const T* vals, T* out,      \
+                                           int64_t ld);                                               \
+    int gkoc_sellp_fill_in_dense_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t slice_size,     \
+                                             const uint64_t* slice_sets, const I* cols,               \
+                                             const T* vals, T* out, int64_t ld);                      \
+    /* diag[r] = first stored (r, r) for r < n; rows without one keep what diag held */               \
+    int gkoc_ell_extract_diagonal_##TN##_##IN(gkoc_stream_t s, int64_t n, int64_t ell_k,              \
+                                              int64_t stride, const I* cols, const T* vals,           \
+                                              T* diag);                                               \
+    int gkoc_sellp_extract_diagonal_##TN##_##IN(gkoc_stream_t s, int64_t n, int64_t slice_size,       \
+                                                const uint64_t* slice_sets, const I* cols,            \
+                                                const T* vals, T* diag);                              \
+    int gkoc_coo_extract_diagonal_##TN##_##IN(gkoc_stream_t s, int64_t nnz, const I* rows,            \
+                                              const I* cols, const T* vals, T* diag);                 \
+    /* vals = beta vals, diagonal entries += alpha */                                                 \
+    int gkoc_csr_add_scaled_identity_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,  \
+                                                 const I* cols, T* vals, const T* alpha,              \
+                                                 const T* beta);                                      \
+    int gkoc_ell_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t ell_k, int64_t stride,   \
+                                    const I* cols, const T* vals, const I* row_ptrs, I* out_cols,     \
+                                    T* out_vals);                                                     \
+    int gkoc_sellp_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t slice_size,            \
+                                      const uint64_t* slice_sets, const I* cols, const T* vals,       \
+                                      const I* row_ptrs, I* out_cols, T* out_vals);                   \
+    /* a row's Ell entries, then its Coo entries; *_row_ptrs: exclusive sums of the two parts'        \
+     * row counts (n_rows + 1 each), out_row_ptrs = their sum */                                      \
+    int gkoc_hybrid_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t ell_k,                \
+                                       int64_t stride, const I* ell_cols, const T* ell_vals,          \
+                                       const I* coo_cols, const T* coo_vals, const I* ell_row_ptrs,   \
+                                       const I* coo_row_ptrs, I* out_row_ptrs, I* out_cols,           \
+                                       T* out_vals);
+GKOC_DECL_CV(double, f64, int32_t, i32)
+GKOC_DECL_CV(double, f64, int64_t, i64)
+GKOC_DECL_CV(float, f32, int32_t, i32)
+GKOC_DECL_CV(float, f32, int64_t, i64)
+#define GKOC_DECL_CV_INDEX(I, IN)                                                                     \
+    int gkoc_ell_count_nonzeros_per_row_##IN(gkoc_stream_t s, int64_t n_rows, int64_t ell_k,          \
+                                             int64_t stride, const I* cols, I* out);                  \
+    int gkoc_sellp_count_nonzeros_per_row_##IN(gkoc_stream_t s, int64_t n_rows, int64_t slice_size,   \
+                                               const uint64_t* slice_sets, const I* cols, I* out);    \
+    /* csr::check_diagonal_entries_exist: *missing_host = 1 if a row r < n has no entry (r, r).       \
+     * Synchronises the stream. */                                                                    \
+    int gkoc_csr_missing_diagonal_##IN(gkoc_stream_t s, int64_t n, const I* row_ptrs, const I* cols,  \
+                                       int* missing_host);
+GKOC_DECL_CV_INDEX(int32_t, i32)
+GKOC_DECL_CV_INDEX(int64_t, i64)
+
 /* ------------------------------------------------- COO SpMV, CSR -> Hybrid
  * coo::{spmv, advanced_spmv, spmv2, advanced_spmv2} (core/matrix/coo_kernels.hpp:24-58;
  * reference/matrix/coo_kernels.cpp:33-100): c = A b, c = alpha A b + beta c,

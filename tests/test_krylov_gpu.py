@@ -757,11 +757,12 @@ def test_jacobi_reduced_storage_golden_and_cg(gexec, oracle):
         g.Jacobi.build().with_max_block_size(13).with_storage_optimization(0, 1).on(gexec).generate(a)
 
 
-@pytest.mark.parametrize("bs", [2, 4, 8, 16])
+@pytest.mark.parametrize("bs", [2, 4, 8, 16, 5, 13, 32])
 def test_jacobi_adaptive_precision_bit_exact(gexec, oracle, bs):
     """storage_optimization autodetect and block-wise requests: the chosen precision per
     block, the condition numbers, the stored bytes and both applies against the oracle
-    (pinned to the reference in tests/test_oracle_cpu.py) - all bit-exact"""
+    (pinned to the reference in tests/test_oracle_cpu.py) - all bit-exact; block sizes that are
+    not a power of two (block_offset 5, 13: what Ginkgo's own jacobi tests use) as well"""
     import ginkgo_amd as g
     from adaptive_cases import graded_block_matrix
     rp, ci, v = graded_block_matrix(24, bs, bs)
@@ -803,7 +804,7 @@ def test_jacobi_adaptive_precision_bit_exact(gexec, oracle, bs):
         m.apply(g.scalar(gexec, 0.7), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.1), x)
         assert np.array_equal(x.to_numpy()[:, 0],
                               oracle.jacobi_apply_adaptive(nb, scheme, ptrs[:nb + 1], blocks_o, prec_o, b, 0.7, -1.1, x0))
-    assert {0x00, 0x01, 0x02} <= seen and (len(seen) >= 4 or bs == 16)
+    assert {0x00, 0x01, 0x02} <= seen and (len(seen) >= 4 or bs >= 13)
 
 
 def test_jacobi_adaptive_cg(gexec, oracle):

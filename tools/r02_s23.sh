@@ -1,8 +1,6 @@
 #!/bin/bash
-OUT=gpurun_out/r02s23; mkdir -p $OUT
-cd oracle/_ref/dropin/reftests
-for s in preconditioner_jacobi_kernels_hip matrix_dense_kernels_hip matrix_csr_kernels2_hip matrix_ell_kernels_hip matrix_sellp_kernels_hip matrix_hybrid_kernels_hip matrix_coo_kernels_hip components_fill_array_kernels_hip base_device_matrix_data_kernels_hip solver_idr_kernels_hip solver_bicg_kernels_hip solver_minres_kernels_hip; do
-  timeout 300 ./$s > ../../../../$OUT/$s.txt 2>&1
-  echo "$s rc=$?"; grep -c "^\[  FAILED  \]" ../../../../$OUT/$s.txt
-done
+OUT=gpurun_out/r02s23; rm -rf $OUT; mkdir -p $OUT
+bash tools/run_reftests.sh $OUT > /dev/null 2>&1
+cat $OUT/summary.txt
+timeout 300 python -m pytest tests/test_krylov_gpu.py -q -m gpu -x -k "adaptive or reduced" 2>&1 | tail -4
 exit 0
