@@ -490,6 +490,166 @@ __global__ __launch_bounds__(256) void hybrid_to_csr_kernel(
     }
 }
 
+// ------------------------------------------------------------ permutations
+// Dense (reference/matrix/dense_kernels.cpp:838-1160): with si = row_perm[i] (or i), sj = col_perm[j]
+// (or j): forward out(i, j) = scale * in(si, sj), inverse out(si, sj) = in(i, j) / scale, where scale
+// = row_scale[si] * col_scale[sj], or the one of the two that is given, or nothing.
+template <typename T, typename I, bool INVERSE>
+__global__ __launch_bounds__(256) void dense_permute_kernel(int64_t rows, int64_t cols,
+                                                            const T* __restrict__ in, int64_t ldi,
+                                                            T* __restrict__ out, int64_t ldo,
+                                                            const I* __restrict__ row_perm,
+                                                            const I* __restrict__ col_perm,
+                                                            const T* __restrict__ row_scale,
+                                                            const T* __restrict__ col_scale)
+{
+    GKOC_FOR_EACH(t, rows * cols)
+    {
+        const int64_t i = t / cols, j = t - i * cols;
+        const int64_t si = row_perm ? int64_t(row_perm[i]) : i;
+        const int64_t sj = col_perm ? int64_t(col_perm[j]) : j;
+        T v = INVERSE ? in[i * ldi + j] : in[si * ldi + sj];
+        if (row_scale && col_scale) {
+            const T sc = row_scale[si] * col_scale[sj];
+            v = INVERSE ? v / sc : sc * v;
+        } else if (row_scale || col_scale) {
+            const T sc = row_scale ? row_scale[si] : col_scale[sj];
+            v = INVERSE ? v / sc : sc * v;
+        }
+        if (INVERSE) {
+            out[si * ldo + sj] = v;
+        } else {
+            out[i * ldo + j] = v;
+        }
+    }
+}
+
+// advanced_row_gather (:932-950): out(i, :) = alpha in(rows[i], :) + beta out(i, :)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void dense_advanced_row_gather_kernel(
+    int64_t n_gather, int64_t cols, const T* __restrict__ alpha, const I* __restrict__ rows_idx,
+    const T* __restrict__ in, int64_t ldi, const T* __restrict__ beta, T* __restrict__ out, int64_t ldo)
+{
+    const T a = alpha[0], b = beta[0];
+    GKOC_FOR_EACH(t, n_gather * cols)
+    {
+        const int64_t i = t / cols, j = t - i * cols;
+        out[i * ldo + j] = a * in[int64_t(rows_idx[i]) * ldi + j] + b * out[i * ldo + j];
+    }
+}
+
+// Csr (reference/matrix/csr_kernels.cpp:962-1262).  Rows: forward (row_permute) out row i = in row
+// perm[i]; inverse out row perm[i] = in row i.  Columns only ever inverse: new column =
+// col_perm[old column] (entries keep their place; the caller sorts afterwards).
+template <typename I>
+__global__ __launch_bounds__(256) void csr_permute_lengths_kernel(int64_t n_rows,
+                                                                  const I* __restrict__ in_rp,
+                                                                  const I* __restrict__ row_perm,
+                                                                  bool row_inverse, I* __restrict__ out_rp)
+{
+    GKOC_FOR_EACH(r, n_rows + 1)
+    {
+        if (r == n_rows) {
+            out_rp[n_rows] = 0;
+            continue;
+        }
+        const int64_t src = (row_perm && !row_inverse) ? int64_t(row_perm[r]) : r;
+        const int64_t dst = (row_perm && row_inverse) ? int64_t(row_perm[r]) : r;
+        out_rp[dst] = in_rp[src + 1] - in_rp[src];
+    }
+}
+
+// scale_mode 1: value * row_scale[source row] (row_scale_permute); 2: value / (row_scale[new row] *
+// col_scale[new column]), absent factors left out (the inv_*_scale_permute family)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void csr_permute_fill_kernel(
+    int64_t n_rows, const I* __restrict__ in_rp, const I* __restrict__ in_ci, const T* __restrict__ in_v,
+    const I* __restrict__ row_perm, bool row_inverse, const I* __restrict__ col_perm,
+    const T* __restrict__ row_scale, const T* __restrict__ col_scale, int scale_mode,
+    const I* __restrict__ out_rp, I* __restrict__ out_ci, T* __restrict__ out_v)
+{
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        const int64_t src = (row_perm && !row_inverse) ? int64_t(row_perm[r]) : r;
+        const int64_t dst = (row_perm && row_inverse) ? int64_t(row_perm[r]) : r;
+        const int64_t sb = in_rp[src], len = in_rp[src + 1] - sb, db = out_rp[dst];
+        for (int64_t k = 0; k < len; ++k) {
+            const I c = col_perm ? col_perm[in_ci[sb + k]] : in_ci[sb + k];
+            T v = in_v[sb + k];
+            if (scale_mode == 1) {
+                v = v * row_scale[src];
+            } else if (scale_mode == 2) {
+                if (row_scale && col_scale) {
+                    v = v / (row_scale[dst] * col_scale[c]);
+                } else {
+                    v = v / (row_scale ? row_scale[dst] : col_scale[c]);
+                }
+            }
+            out_ci[db + k] = c;
+            out_v[db + k] = v;
+        }
+    }
+}
+
+// permutation::invert / compose, scaled_permutation::invert / compose
+// (reference/matrix/permutation_kernels.cpp, scaled_permutation_kernels.cpp)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void permutation_invert_kernel(int64_t n, const T* __restrict__ in_scale,
+                                                                 const I* __restrict__ perm,
+                                                                 T* __restrict__ out_scale,
+                                                                 I* __restrict__ out_perm)
+{
+    GKOC_FOR_EACH(i, n)
+    {
+        const I ip = perm[i];
+        out_perm[ip] = I(i);
+        if (in_scale) out_scale[i] = T(1) / in_scale[ip];
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void permutation_compose_kernel(
+    int64_t n, const T* __restrict__ first_scale, const I* __restrict__ first,
+    const T* __restrict__ second_scale, const I* __restrict__ second, T* __restrict__ out_scale,
+    I* __restrict__ out_perm)
+{
+    GKOC_FOR_EACH(i, n)
+    {
+        const I sp = second[i];
+        const I cp = first[sp];
+        out_perm[i] = cp;
+        if (first_scale) out_scale[cp] = first_scale[cp] * second_scale[sp];
+    }
+}
+
+// csr::calculate_nonzeros_per_row_in_span / compute_submatrix (:1468-1530): the entries of rows
+// [row0, row0 + n) with columns in [col0, col1), in storage order, columns shifted by col0
+template <typename T, typename I, bool FILL>
+__global__ __launch_bounds__(256) void csr_span_kernel(int64_t n, int64_t row0, int64_t col0, int64_t col1,
+                                                       const I* __restrict__ in_rp,
+                                                       const I* __restrict__ in_ci,
+                                                       const T* __restrict__ in_v, I* __restrict__ counts,
+                                                       const I* __restrict__ out_rp,
+                                                       I* __restrict__ out_ci, T* __restrict__ out_v)
+{
+    GKOC_FOR_EACH(r, n)
+    {
+        int64_t at = FILL ? int64_t(out_rp[r]) : 0;
+        for (int64_t k = in_rp[row0 + r]; k < in_rp[row0 + r + 1]; ++k) {
+            const int64_t c = in_ci[k];
+            if (c >= col0 && c < col1) {
+                if (FILL) {
+                    out_ci[at] = I(c - col0);
+                    out_v[at] = in_v[k];
+                }
+                ++at;
+            }
+        }
+        if (!FILL) counts[r] = I(at);
+    }
+}
+
+
 #define CV_LAUNCH(kernel, n, ...)                                                     \
     do {                                                                              \
         if ((n) > 0) {                                                                \
@@ -767,3 +927,110 @@ GKOC_DEF_CV(float, f32, int64_t, i64)
     }
 GKOC_DEF_CV_INDEX(int32_t, i32)
 GKOC_DEF_CV_INDEX(int64_t, i64)
+
+#define GKOC_DEF_PERMUTE(T, TN, I, IN)                                                                  \
+    extern "C" int gkoc_dense_permute_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols,          \
+                                                  const T* in, int64_t ldi, T* out, int64_t ldo,        \
+                                                  const I* row_perm, const I* col_perm,                 \
+                                                  const T* row_scale, const T* col_scale, int inverse)  \
+    {                                                                                                   \
+        GKOC_REQUIRE(rows >= 0 && cols >= 0 && (rows * cols == 0 || (in && out && in != out)),          \
+                     GKOC_E_INVALID, "bad argument");                                                   \
+        GKOC_REQUIRE((!row_scale || row_perm) && (!col_scale || col_perm), GKOC_E_INVALID,              \
+                     "a scale needs its permutation");                                                  \
+        if (inverse) {                                                                                  \
+            CV_LAUNCH((dense_permute_kernel<T, I, true>), rows* cols, rows, cols, in, ldi, out, ldo,    \
+                      row_perm, col_perm, row_scale, col_scale);                                        \
+        } else {                                                                                        \
+            CV_LAUNCH((dense_permute_kernel<T, I, false>), rows* cols, rows, cols, in, ldi, out, ldo,   \
+                      row_perm, col_perm, row_scale, col_scale);                                        \
+        }                                                                                               \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_dense_advanced_row_gather_##TN##_##IN(                                          \
+        gkoc_stream_t s, int64_t n_gather, int64_t cols, const T* alpha, const I* rows_idx,             \
+        const T* in, int64_t ldi, const T* beta, T* out, int64_t ldo)                                   \
+    {                                                                                                   \
+        GKOC_REQUIRE(n_gather >= 0 && cols >= 0 && alpha && beta, GKOC_E_INVALID, "bad argument");      \
+        CV_LAUNCH((dense_advanced_row_gather_kernel<T, I>), n_gather* cols, n_gather, cols, alpha,      \
+                  rows_idx, in, ldi, beta, out, ldo);                                                   \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_csr_permute_##TN##_##IN(                                                        \
+        gkoc_stream_t s, int64_t n_rows, const I* in_rp, const I* in_ci, const T* in_v,                 \
+        const I* row_perm, int row_inverse, const I* col_perm, const T* row_scale, const T* col_scale,  \
+        int scale_mode, I* out_rp, I* out_ci, T* out_v)                                                 \
+    {                                                                                                   \
+        GKOC_REQUIRE(n_rows >= 0 && in_rp && out_rp, GKOC_E_INVALID, "bad argument");                   \
+        GKOC_REQUIRE(scale_mode >= 0 && scale_mode <= 2 && (scale_mode != 1 || row_scale) &&            \
+                         (scale_mode != 2 || row_scale || col_scale),                                   \
+                     GKOC_E_INVALID, "bad scale arguments");                                            \
+        CV_LAUNCH(csr_permute_lengths_kernel<I>, n_rows + 1, n_rows, in_rp, row_perm, row_inverse != 0, \
+                  out_rp);                                                                              \
+        GKOC_TRY(device_exclusive_scan<I>(as_stream(s), out_rp, n_rows + 1));                           \
+        CV_LAUNCH((csr_permute_fill_kernel<T, I>), n_rows, n_rows, in_rp, in_ci, in_v, row_perm,        \
+                  row_inverse != 0, col_perm, row_scale, col_scale, scale_mode, out_rp, out_ci, out_v); \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_scaled_permutation_invert_##TN##_##IN(gkoc_stream_t s, int64_t n,               \
+                                                              const T* in_scale, const I* perm,         \
+                                                              T* out_scale, I* out_perm)                \
+    {                                                                                                   \
+        GKOC_REQUIRE(n >= 0 && (n == 0 || (in_scale && perm && out_scale && out_perm)), GKOC_E_INVALID, \
+                     "bad argument");                                                                   \
+        CV_LAUNCH((permutation_invert_kernel<T, I>), n, n, in_scale, perm, out_scale, out_perm);        \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_scaled_permutation_compose_##TN##_##IN(                                         \
+        gkoc_stream_t s, int64_t n, const T* first_scale, const I* first, const T* second_scale,        \
+        const I* second, T* out_scale, I* out_perm)                                                     \
+    {                                                                                                   \
+        GKOC_REQUIRE(n >= 0 && (n == 0 || (first_scale && first && second_scale && second &&            \
+                                           out_scale && out_perm)),                                     \
+                     GKOC_E_INVALID, "bad argument");                                                   \
+        CV_LAUNCH((permutation_compose_kernel<T, I>), n, n, first_scale, first, second_scale, second,   \
+                  out_scale, out_perm);                                                                 \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_csr_count_in_span_##TN##_##IN(gkoc_stream_t s, int64_t n, int64_t row0,         \
+                                                      int64_t col0, int64_t col1, const I* in_rp,       \
+                                                      const I* in_ci, I* counts)                        \
+    {                                                                                                   \
+        CV_LAUNCH((csr_span_kernel<T, I, false>), n, n, row0, col0, col1, in_rp, in_ci,                 \
+                  static_cast<const T*>(nullptr), counts, static_cast<const I*>(nullptr),               \
+                  static_cast<I*>(nullptr), static_cast<T*>(nullptr));                                  \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_csr_submatrix_##TN##_##IN(gkoc_stream_t s, int64_t n, int64_t row0,             \
+                                                  int64_t col0, int64_t col1, const I* in_rp,           \
+                                                  const I* in_ci, const T* in_v, const I* out_rp,       \
+                                                  I* out_ci, T* out_v)                                  \
+    {                                                                                                   \
+        CV_LAUNCH((csr_span_kernel<T, I, true>), n, n, row0, col0, col1, in_rp, in_ci, in_v,            \
+                  static_cast<I*>(nullptr), out_rp, out_ci, out_v);                                     \
+        return GKOC_OK;                                                                                 \
+    }
+GKOC_DEF_PERMUTE(double, f64, int32_t, i32)
+GKOC_DEF_PERMUTE(double, f64, int64_t, i64)
+GKOC_DEF_PERMUTE(float, f32, int32_t, i32)
+GKOC_DEF_PERMUTE(float, f32, int64_t, i64)
+
+#define GKOC_DEF_PERMUTATION(I, IN)                                                                     \
+    extern "C" int gkoc_permutation_invert_##IN(gkoc_stream_t s, int64_t n, const I* perm, I* out)      \
+    {                                                                                                   \
+        GKOC_REQUIRE(n >= 0 && (n == 0 || (perm && out)), GKOC_E_INVALID, "bad argument");              \
+        CV_LAUNCH((permutation_invert_kernel<double, I>), n, n, static_cast<const double*>(nullptr),    \
+                  perm, static_cast<double*>(nullptr), out);                                            \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_permutation_compose_##IN(gkoc_stream_t s, int64_t n, const I* first,            \
+                                                 const I* second, I* out)                               \
+    {                                                                                                   \
+        GKOC_REQUIRE(n >= 0 && (n == 0 || (first && second && out)), GKOC_E_INVALID, "bad argument");   \
+        CV_LAUNCH((permutation_compose_kernel<double, I>), n, n, static_cast<const double*>(nullptr),   \
+                  first, static_cast<const double*>(nullptr), second, static_cast<double*>(nullptr),    \
+                  out);                                                                                 \
+        return GKOC_OK;                                                                                 \
+    }
+GKOC_DEF_PERMUTATION(int32_t, i32)
+GKOC_DEF_PERMUTATION(int64_t, i64)

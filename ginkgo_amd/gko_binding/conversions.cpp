@@ -17,6 +17,8 @@
 #include "core/matrix/dense_kernels.hpp"
 #include "core/matrix/ell_kernels.hpp"
 #include "core/matrix/hybrid_kernels.hpp"
+#include "core/matrix/permutation_kernels.hpp"
+#include "core/matrix/scaled_permutation_kernels.hpp"
 #include "core/matrix/sellp_kernels.hpp"
 #include "shim_common.hpp"
 
@@ -418,6 +420,304 @@ FOR_VT_IT(DEF)
 #undef DEF
 
 }  // namespace hybrid
+
+
+
+// ------------------------------------------------------------ permutations
+namespace dense {
+
+// one C entry point does all sixteen: (row_perm, col_perm, row_scale, col_scale, inverse)
+#define PERMUTE(TN, IN, rp, cp, rs, cs, inv)                                                        \
+    GKOC_CALL(gkoc_dense_permute_##TN##_##IN(stream_of(exec), rows(orig), cols(orig),               \
+                                             orig->get_const_values(), ld(orig),                    \
+                                             permuted->get_values(), ld(permuted), rp, cp, rs, cs,  \
+                                             inv))
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void symm_permute<T, I>(exec_t exec, const I* perm, const matrix::Dense<T>* orig,               \
+                            matrix::Dense<T>* permuted)                                             \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, perm, nullptr, nullptr, 0);                                           \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_symm_permute<T, I>(exec_t exec, const I* perm, const matrix::Dense<T>* orig,           \
+                                matrix::Dense<T>* permuted)                                         \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, perm, nullptr, nullptr, 1);                                           \
+    }                                                                                               \
+    template <>                                                                                     \
+    void nonsymm_permute<T, I>(exec_t exec, const I* rp, const I* cp,                               \
+                               const matrix::Dense<T>* orig, matrix::Dense<T>* permuted)            \
+    {                                                                                               \
+        PERMUTE(TN, IN, rp, cp, nullptr, nullptr, 0);                                               \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_nonsymm_permute<T, I>(exec_t exec, const I* rp, const I* cp,                           \
+                                   const matrix::Dense<T>* orig, matrix::Dense<T>* permuted)        \
+    {                                                                                               \
+        PERMUTE(TN, IN, rp, cp, nullptr, nullptr, 1);                                               \
+    }                                                                                               \
+    template <>                                                                                     \
+    void col_permute<T, I>(exec_t exec, const I* perm, const matrix::Dense<T>* orig,                \
+                           matrix::Dense<T>* permuted)                                              \
+    {                                                                                               \
+        PERMUTE(TN, IN, nullptr, perm, nullptr, nullptr, 0);                                        \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_row_permute<T, I>(exec_t exec, const I* perm, const matrix::Dense<T>* orig,            \
+                               matrix::Dense<T>* permuted)                                          \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, nullptr, nullptr, nullptr, 1);                                        \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_col_permute<T, I>(exec_t exec, const I* perm, const matrix::Dense<T>* orig,            \
+                               matrix::Dense<T>* permuted)                                          \
+    {                                                                                               \
+        PERMUTE(TN, IN, nullptr, perm, nullptr, nullptr, 1);                                        \
+    }                                                                                               \
+    template <>                                                                                     \
+    void symm_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                       \
+                                  const matrix::Dense<T>* orig, matrix::Dense<T>* permuted)         \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, perm, scale, scale, 0);                                               \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_symm_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                   \
+                                      const matrix::Dense<T>* orig, matrix::Dense<T>* permuted)     \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, perm, scale, scale, 1);                                               \
+    }                                                                                               \
+    template <>                                                                                     \
+    void nonsymm_scale_permute<T, I>(exec_t exec, const T* rs, const I* rp, const T* cs,            \
+                                     const I* cp, const matrix::Dense<T>* orig,                     \
+                                     matrix::Dense<T>* permuted)                                    \
+    {                                                                                               \
+        PERMUTE(TN, IN, rp, cp, rs, cs, 0);                                                         \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_nonsymm_scale_permute<T, I>(exec_t exec, const T* rs, const I* rp, const T* cs,        \
+                                         const I* cp, const matrix::Dense<T>* orig,                 \
+                                         matrix::Dense<T>* permuted)                                \
+    {                                                                                               \
+        PERMUTE(TN, IN, rp, cp, rs, cs, 1);                                                         \
+    }                                                                                               \
+    template <>                                                                                     \
+    void row_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                        \
+                                 const matrix::Dense<T>* orig, matrix::Dense<T>* permuted)          \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, nullptr, scale, nullptr, 0);                                          \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_row_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                    \
+                                     const matrix::Dense<T>* orig, matrix::Dense<T>* permuted)      \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, nullptr, scale, nullptr, 1);                                          \
+    }                                                                                               \
+    template <>                                                                                     \
+    void col_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                        \
+                                 const matrix::Dense<T>* orig, matrix::Dense<T>* permuted)          \
+    {                                                                                               \
+        PERMUTE(TN, IN, nullptr, perm, nullptr, scale, 0);                                          \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_col_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                    \
+                                     const matrix::Dense<T>* orig, matrix::Dense<T>* permuted)      \
+    {                                                                                               \
+        PERMUTE(TN, IN, nullptr, perm, nullptr, scale, 1);                                          \
+    }                                                                                               \
+    template <>                                                                                     \
+    void advanced_row_gather<T, T, I>(exec_t exec, const matrix::Dense<T>* alpha,                   \
+                                      const I* gather_indices, const matrix::Dense<T>* orig,        \
+                                      const matrix::Dense<T>* beta,                                 \
+                                      matrix::Dense<T>* row_collection)                             \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_advanced_row_gather_##TN##_##IN(                                       \
+            stream_of(exec), rows(row_collection), cols(orig), alpha->get_const_values(),           \
+            gather_indices, orig->get_const_values(), ld(orig), beta->get_const_values(),           \
+            row_collection->get_values(), ld(row_collection)));                                     \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+#undef PERMUTE
+
+// real value types: the real part is the matrix, the imaginary part is zero
+#define DEF(T, TN)                                                                                  \
+    template <>                                                                                     \
+    void get_real<T>(exec_t exec, const matrix::Dense<T>* source, matrix::Dense<T>* result)         \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_copy_##TN(stream_of(exec), rows(source), cols(source),                 \
+                                       source->get_const_values(), ld(source),                      \
+                                       result->get_values(), ld(result)));                          \
+    }                                                                                               \
+    template <>                                                                                     \
+    void get_imag<T>(exec_t exec, const matrix::Dense<T>* source, matrix::Dense<T>* result)         \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_fill_##TN(stream_of(exec), rows(result), cols(result),                 \
+                                       result->get_values(), ld(result), T(0)));                    \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+}  // namespace dense
+
+
+namespace csr {
+
+#define PERMUTE(TN, IN, rp, rinv, cp, rs, cs, mode)                                                 \
+    GKOC_CALL(gkoc_csr_permute_##TN##_##IN(                                                         \
+        stream_of(exec), static_cast<int64_t>(orig->get_size()[0]), orig->get_const_row_ptrs(),     \
+        orig->get_const_col_idxs(), orig->get_const_values(), rp, rinv, cp, rs, cs, mode,           \
+        permuted->get_row_ptrs(), permuted->get_col_idxs(), permuted->get_values()))
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void inv_symm_permute<T, I>(exec_t exec, const I* perm, const matrix::Csr<T, I>* orig,          \
+                                matrix::Csr<T, I>* permuted)                                        \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, 1, perm, nullptr, nullptr, 0);                                        \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_nonsymm_permute<T, I>(exec_t exec, const I* rp, const I* cp,                           \
+                                   const matrix::Csr<T, I>* orig, matrix::Csr<T, I>* permuted)      \
+    {                                                                                               \
+        PERMUTE(TN, IN, rp, 1, cp, nullptr, nullptr, 0);                                            \
+    }                                                                                               \
+    template <>                                                                                     \
+    void row_permute<T, I>(exec_t exec, const I* perm, const matrix::Csr<T, I>* orig,               \
+                           matrix::Csr<T, I>* permuted)                                             \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, 0, nullptr, nullptr, nullptr, 0);                                     \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_row_permute<T, I>(exec_t exec, const I* perm, const matrix::Csr<T, I>* orig,           \
+                               matrix::Csr<T, I>* permuted)                                         \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, 1, nullptr, nullptr, nullptr, 0);                                     \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_col_permute<T, I>(exec_t exec, const I* perm, const matrix::Csr<T, I>* orig,           \
+                               matrix::Csr<T, I>* permuted)                                         \
+    {                                                                                               \
+        PERMUTE(TN, IN, nullptr, 0, perm, nullptr, nullptr, 0);                                     \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_symm_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                   \
+                                      const matrix::Csr<T, I>* orig, matrix::Csr<T, I>* permuted)   \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, 1, perm, scale, scale, 2);                                            \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_nonsymm_scale_permute<T, I>(exec_t exec, const T* rs, const I* rp, const T* cs,        \
+                                         const I* cp, const matrix::Csr<T, I>* orig,                \
+                                         matrix::Csr<T, I>* permuted)                               \
+    {                                                                                               \
+        PERMUTE(TN, IN, rp, 1, cp, rs, cs, 2);                                                      \
+    }                                                                                               \
+    template <>                                                                                     \
+    void row_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                        \
+                                 const matrix::Csr<T, I>* orig, matrix::Csr<T, I>* permuted)        \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, 0, nullptr, scale, nullptr, 1);                                       \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_row_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                    \
+                                     const matrix::Csr<T, I>* orig, matrix::Csr<T, I>* permuted)    \
+    {                                                                                               \
+        PERMUTE(TN, IN, perm, 1, nullptr, scale, nullptr, 2);                                       \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_col_scale_permute<T, I>(exec_t exec, const T* scale, const I* perm,                    \
+                                     const matrix::Csr<T, I>* orig, matrix::Csr<T, I>* permuted)    \
+    {                                                                                               \
+        PERMUTE(TN, IN, nullptr, 0, perm, nullptr, scale, 2);                                       \
+    }                                                                                               \
+    template <>                                                                                     \
+    void calculate_nonzeros_per_row_in_span<T, I>(exec_t exec, const matrix::Csr<T, I>* source,     \
+                                                  const span& row_span, const span& col_span,       \
+                                                  array<I>* row_nnz)                                \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_count_in_span_##TN##_##IN(                                               \
+            stream_of(exec), static_cast<int64_t>(row_span.length()),                               \
+            static_cast<int64_t>(row_span.begin), static_cast<int64_t>(col_span.begin),             \
+            static_cast<int64_t>(col_span.end), source->get_const_row_ptrs(),                       \
+            source->get_const_col_idxs(), row_nnz->get_data()));                                    \
+    }                                                                                               \
+    template <>                                                                                     \
+    void compute_submatrix<T, I>(exec_t exec, const matrix::Csr<T, I>* source, gko::span row_span,  \
+                                 gko::span col_span, matrix::Csr<T, I>* result)                     \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_submatrix_##TN##_##IN(                                                   \
+            stream_of(exec), static_cast<int64_t>(row_span.length()),                               \
+            static_cast<int64_t>(row_span.begin), static_cast<int64_t>(col_span.begin),             \
+            static_cast<int64_t>(col_span.end), source->get_const_row_ptrs(),                       \
+            source->get_const_col_idxs(), source->get_const_values(), result->get_const_row_ptrs(), \
+            result->get_col_idxs(), result->get_values()));                                         \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+#undef PERMUTE
+
+}  // namespace csr
+
+
+namespace coo {
+
+// conj_array for real value types: nothing to do
+#define DEF(T, TN)                                                    \
+    template <>                                                       \
+    void conj_array<T>(exec_t exec, size_type, T*)                    \
+    {                                                                 \
+        cdna4::launch_deferred();                                     \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+}  // namespace coo
+
+
+namespace permutation {
+
+#define DEF(I, IN)                                                                                  \
+    template <>                                                                                     \
+    void invert<I>(exec_t exec, const I* perm, size_type size, I* out)                              \
+    {                                                                                               \
+        GKOC_CALL(gkoc_permutation_invert_##IN(stream_of(exec), static_cast<int64_t>(size), perm,   \
+                                               out));                                               \
+    }                                                                                               \
+    template <>                                                                                     \
+    void compose<I>(exec_t exec, const I* first, const I* second, size_type size, I* out)           \
+    {                                                                                               \
+        GKOC_CALL(gkoc_permutation_compose_##IN(stream_of(exec), static_cast<int64_t>(size), first, \
+                                                second, out));                                      \
+    }
+DEF(int32, i32)
+DEF(int64, i64)
+#undef DEF
+
+}  // namespace permutation
+
+
+namespace scaled_permutation {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void invert<T, I>(exec_t exec, const T* in_scale, const I* in_perm, size_type size,             \
+                      T* out_scale, I* out_perm)                                                    \
+    {                                                                                               \
+        GKOC_CALL(gkoc_scaled_permutation_invert_##TN##_##IN(                                       \
+            stream_of(exec), static_cast<int64_t>(size), in_scale, in_perm, out_scale, out_perm));  \
+    }                                                                                               \
+    template <>                                                                                     \
+    void compose<T, I>(exec_t exec, const T* first_scale, const I* first, const T* second_scale,    \
+                       const I* second, size_type size, T* out_scale, I* out_perm)                  \
+    {                                                                                               \
+        GKOC_CALL(gkoc_scaled_permutation_compose_##TN##_##IN(                                      \
+            stream_of(exec), static_cast<int64_t>(size), first_scale, first, second_scale, second,  \
+            out_scale, out_perm));                                                                  \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace scaled_permutation
 
 
 }  // namespace hip

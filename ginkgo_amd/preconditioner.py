@@ -116,10 +116,15 @@ class Jacobi(LinOp):
         self.storage_precision = factory.storage_precision
         self.precisions = self.conditioning = None
         adaptive = factory.block_wise is not None
-        if (self.storage_precision or adaptive) and (a.dtype != torch.float64
-                                       or self.max_block_size not in (2, 4, 8, 16)):
-            raise NotSupported("block-Jacobi: reduced storage precision needs fp64 values and "
+        if (self.storage_precision or adaptive) and a.dtype != torch.float64:
+            raise NotSupported("block-Jacobi: reduced storage precision needs fp64 values")
+        if self.storage_precision and self.max_block_size not in (2, 4, 8, 16):
+            # the in-place conversion of ONE precision for all blocks works on 64-wide groups;
+            # block-wise / autodetected precisions take any max_block_size <= 32
+            raise NotSupported("block-Jacobi: one reduced storage precision for all blocks needs "
                                "max_block_size in {2, 4, 8, 16} (64-wide storage groups)")
+        if adaptive and not 2 <= self.max_block_size <= 32:
+            raise NotSupported("block-Jacobi: adaptive precision needs 2 <= max_block_size <= 32")
         self._suf = f"{VT[a.dtype]}_{IT[a.col_idxs.dtype]}"
         n = a.size[0]
         if not factory.skip_sorting and not a.is_sorted_by_column_index():

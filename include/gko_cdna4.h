@@ -1010,6 +1010,50 @@ GKOC_DECL_CV(float, f32, int64_t, i64)
 GKOC_DECL_CV_INDEX(int32_t, i32)
 GKOC_DECL_CV_INDEX(int64_t, i64)
 
+/* Permutations (Dense / Csr ::permute, ::scale_permute, Permutation / ScaledPermutation).
+ * dense_permute: si = row_perm[i] (NULL: i), sj = col_perm[j] (NULL: j); forward out(i, j) =
+ * scale * in(si, sj), inverse out(si, sj) = in(i, j) / scale with scale = row_scale[si] * col_scale[sj]
+ * or whichever of the two is given.  csr_permute: row_inverse 0: out row i = in row row_perm[i],
+ * 1: out row row_perm[i] = in row i; new column = col_perm[old column] (not re-sorted);
+ * scale_mode 0 none, 1 value * row_scale[source row], 2 value / (row_scale[new row] * col_scale[new
+ * column]) with absent factors left out. */
+#define GKOC_DECL_PERMUTE(T, TN, I, IN)                                                               \
+    int gkoc_dense_permute_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,      \
+                                       int64_t ldi, T* out, int64_t ldo, const I* row_perm,           \
+                                       const I* col_perm, const T* row_scale, const T* col_scale,     \
+                                       int inverse);                                                  \
+    /* out(i, :) = alpha in(rows_idx[i], :) + beta out(i, :) */                                       \
+    int gkoc_dense_advanced_row_gather_##TN##_##IN(gkoc_stream_t s, int64_t n_gather, int64_t cols,   \
+                                                   const T* alpha, const I* rows_idx, const T* in,    \
+                                                   int64_t ldi, const T* beta, T* out, int64_t ldo);  \
+    int gkoc_csr_permute_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* in_rp, const I* in_ci, \
+                                     const T* in_v, const I* row_perm, int row_inverse,               \
+                                     const I* col_perm, const T* row_scale, const T* col_scale,       \
+                                     int scale_mode, I* out_rp, I* out_ci, T* out_v);                 \
+    int gkoc_scaled_permutation_invert_##TN##_##IN(gkoc_stream_t s, int64_t n, const T* in_scale,     \
+                                                   const I* perm, T* out_scale, I* out_perm);         \
+    int gkoc_scaled_permutation_compose_##TN##_##IN(gkoc_stream_t s, int64_t n, const T* first_scale, \
+                                                    const I* first, const T* second_scale,            \
+                                                    const I* second, T* out_scale, I* out_perm);      \
+    /* csr::calculate_nonzeros_per_row_in_span / compute_submatrix: rows [row0, row0 + n), columns    \
+     * [col0, col1); out_rp = exclusive sums of counts (the caller scans) */                          \
+    int gkoc_csr_count_in_span_##TN##_##IN(gkoc_stream_t s, int64_t n, int64_t row0, int64_t col0,    \
+                                           int64_t col1, const I* in_rp, const I* in_ci, I* counts);  \
+    int gkoc_csr_submatrix_##TN##_##IN(gkoc_stream_t s, int64_t n, int64_t row0, int64_t col0,        \
+                                       int64_t col1, const I* in_rp, const I* in_ci, const T* in_v,   \
+                                       const I* out_rp, I* out_ci, T* out_v);
+GKOC_DECL_PERMUTE(double, f64, int32_t, i32)
+GKOC_DECL_PERMUTE(double, f64, int64_t, i64)
+GKOC_DECL_PERMUTE(float, f32, int32_t, i32)
+GKOC_DECL_PERMUTE(float, f32, int64_t, i64)
+#define GKOC_DECL_PERMUTATION(I, IN)                                                                  \
+    /* out[perm[i]] = i;  out[i] = first[second[i]] */                                                \
+    int gkoc_permutation_invert_##IN(gkoc_stream_t s, int64_t n, const I* perm, I* out);              \
+    int gkoc_permutation_compose_##IN(gkoc_stream_t s, int64_t n, const I* first, const I* second,    \
+                                      I* out);
+GKOC_DECL_PERMUTATION(int32_t, i32)
+GKOC_DECL_PERMUTATION(int64_t, i64)
+
 /* ------------------------------------------------- COO SpMV, CSR -> Hybrid
  * coo::{spmv, advanced_spmv, spmv2, advanced_spmv2} (core/matrix/coo_kernels.hpp:24-58;
  * reference/matrix/coo_kernels.cpp:33-100): c = A b, c = alpha A b + beta c,
