@@ -7,8 +7,9 @@ blocks (jacobi::find_blocks), inverts them (jacobi::generate) and applies them
 (jacobi::simple_apply / apply), all on the device through libgko_cdna4.so.
 max_block_size == 1 takes Ginkgo's scalar path (extract_diagonal +
 invert_diagonal + simple_scalar_apply).  Adaptive precision
-(`with_storage_optimization`: fixed, block-wise and autodetect) is supported
-for fp64 values and max_block_size in {2, 4, 8, 16}.
+(`with_storage_optimization`) is supported for fp64 values: block-wise and
+autodetected precisions for any max_block_size <= 32, one fixed reduced
+precision for all blocks for max_block_size in {2, 4, 8, 16}.
 """
 import ctypes as C
 
