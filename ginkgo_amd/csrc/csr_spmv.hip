@@ -125,6 +125,53 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     return GKOC_OK;
 }
 
+// Mixed precision: values stored as V (float), vectors and arithmetic T (double).  8 instead of
+// 12 bytes per stored entry; the result has the bits of the T kernel on the widened values.
+// Columns one after the other (the matrix is streamed once per column).
+template <typename T, typename V, typename I, bool ADV>
+int launch_csr_mixed(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
+                     const I* row_ptrs, const I* col_idxs, const V* vals, const T* b, int64_t ldb,
+                     const T* beta, T* c, int64_t ldc, int64_t nrhs)
+{
+    GKOC_REQUIRE(n_rows >= 0 && n_cols >= 0 && nrhs >= 0, GKOC_E_INVALID, "negative dimension");
+    if (n_rows == 0 || nrhs == 0) return GKOC_OK;
+    GKOC_REQUIRE(row_ptrs && c, GKOC_E_INVALID, "null pointer");
+    GKOC_REQUIRE(ldc >= nrhs && (n_cols == 0 || ldb >= nrhs), GKOC_E_INVALID,
+                 "stride smaller than nrhs");
+    if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
+    const int64_t n_seg = ceildiv(n_rows, 64);
+    const int segs_per_wave = n_seg < 65536 ? 1 : 2;
+    const int64_t n_waves = ceildiv(n_seg, segs_per_wave);
+    GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 row segments");
+    const dim3 grid(static_cast<unsigned>(n_waves)), block(64);
+    // four entries per lane and load (16 B of values, 16 B of columns); eight need 129 VGPRs
+    // (three waves per SIMD)
+    constexpr int EV = 32 / sizeof(T);
+    constexpr int RINGV = 8192 / sizeof(T);
+    const bool vec_ok = reinterpret_cast<uintptr_t>(vals) % (EV * sizeof(V)) == 0 &&
+                        reinterpret_cast<uintptr_t>(col_idxs) % (EV * sizeof(I)) == 0;
+#define GKOC_LAUNCH_MIXED(E_, U_, MODE_)                                                        \
+    csr_spmv_pipe3_kernel<T, I, ADV, 64, E_, U_, RINGV, 1, MODE_, V><<<grid, block, 0, as_stream(s)>>>( \
+        n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc, static_cast<int>(nrhs), \
+        alpha, beta, nullptr, 0)
+    if (vec_ok) {
+        if (segs_per_wave == 2) {
+            GKOC_LAUNCH_MIXED(EV, 1, 0x2000);
+        } else {
+            GKOC_LAUNCH_MIXED(EV, 1, 0x1000);
+        }
+    } else {
+        if (segs_per_wave == 2) {
+            GKOC_LAUNCH_MIXED(1, 4, 0x2000);
+        } else {
+            GKOC_LAUNCH_MIXED(1, 4, 0x1000);
+        }
+    }
+#undef GKOC_LAUNCH_MIXED
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
 // c = A b and dot_out = <b, c> in one pass over the matrix (square A, one
 // right-hand side, unit strides): every wave also emits its part of the dot
 // product, a fixed two-level fold adds them up
@@ -398,6 +445,28 @@ GKOC_DEF_CSR(double, f64, int32_t, i32)
 GKOC_DEF_CSR(double, f64, int64_t, i64)
 GKOC_DEF_CSR(float, f32, int32_t, i32)
 GKOC_DEF_CSR(float, f32, int64_t, i64)
+
+#define GKOC_DEF_CSR_MIXED(I, IN)                                                                  \
+    extern "C" int gkoc_csr_spmv_f32_f64_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,     \
+                                              const I* row_ptrs, const I* col_idxs,                \
+                                              const float* vals, const double* b, int64_t ldb,     \
+                                              double* c, int64_t ldc, int64_t nrhs)                \
+    {                                                                                              \
+        return launch_csr_mixed<double, float, I, false>(s, n_rows, n_cols, nullptr, row_ptrs,     \
+                                                         col_idxs, vals, b, ldb, nullptr, c, ldc,  \
+                                                         nrhs);                                    \
+    }                                                                                              \
+    extern "C" int gkoc_csr_advanced_spmv_f32_f64_##IN(                                            \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const double* alpha, const I* row_ptrs,   \
+        const I* col_idxs, const float* vals, const double* b, int64_t ldb, const double* beta,    \
+        double* c, int64_t ldc, int64_t nrhs)                                                      \
+    {                                                                                              \
+        return launch_csr_mixed<double, float, I, true>(s, n_rows, n_cols, alpha, row_ptrs,        \
+                                                        col_idxs, vals, b, ldb, beta, c, ldc,      \
+                                                        nrhs);                                     \
+    }
+GKOC_DEF_CSR_MIXED(int32_t, i32)
+GKOC_DEF_CSR_MIXED(int64_t, i64)
 
 extern "C" size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size)
 {

@@ -41,12 +41,16 @@ struct alignas(sizeof(T) * E) vecT {
 // b gather, 2: skip the LDS row sums, ...), 0 in the plain library kernel.
 // (Earlier generations of this kernel - 64-bit indexing, LDS-staged matrix
 // with row-ordered gather - are kept in tools/lab_kernels.hpp for A/B runs.)
+// V = type the matrix values are STORED in (mixed precision: float values, double vectors and
+// arithmetic - csr::spmv<MatrixValueType, InputValueType, OutputValueType> with
+// arithmetic_type = highest_precision, common/cuda_hip/matrix/csr_kernels.template.cpp); every
+// value is widened as it is loaded, nothing else changes.
 template <typename T, typename I, bool ADV, int ROWS, int E, int U, int RING,
-          int WPS, int ABL = 0>
+          int WPS, int ABL = 0, typename V = T>
 __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     int64_t n_rows, int64_t n_segments, int64_t segs_per_wave,
     const I* __restrict__ row_ptrs, const I* __restrict__ cols,
-    const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb,
+    const V* __restrict__ vals, const T* __restrict__ b, int64_t ldb,
     T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
     const T* __restrict__ beta_p, T* __restrict__ dot_partial = nullptr,
     int xcd_map = 0, const I* __restrict__ row_idxs = nullptr,
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     // launcher refuses more than 2^31 segments)
     const int k1o = int(K1 - K0a);
     const int nnzo = (NNZ - K0a) > int64_t(0x7fffff00) ? 0x7fffff00 : int(NNZ - K0a);
-    const T* __restrict__ vals0 = vals + K0a;
+    const V* __restrict__ vals0 = vals + K0a;
     const I* __restrict__ cols0 = cols + K0a;
 
     T alpha = T(1), beta = T(0);
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     }
 
     using VT = vecT<T, E>;
+    using VV = vecT<V, E>;
     using VI = vecT<I, E>;
 
     auto load_group = [&](VT(&v)[U], VI(&ci)[U], VI(&ri)[COO ? U : 1], int p) {
@@ -153,14 +158,20 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                     if constexpr (COO) ri[u].v[e] = I(0);
                 }
             } else if (k + E <= nnzo) {
-                v[u] = *reinterpret_cast<const VT*>(vals0 + k);
+                if constexpr (sizeof(V) == sizeof(T)) {
+                    v[u] = *reinterpret_cast<const VT*>(vals0 + k);
+                } else {
+                    const VV raw = *reinterpret_cast<const VV*>(vals0 + k);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) v[u].v[e] = T(raw.v[e]);
+                }
                 ci[u] = *reinterpret_cast<const VI*>(cols0 + k);
                 if constexpr (COO) ri[u] = *reinterpret_cast<const VI*>(rows0 + k);
             } else {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const bool in = k + e < nnzo;
-                    v[u].v[e] = in ? vals0[k + e] : T(0);
+                    v[u].v[e] = in ? T(vals0[k + e]) : T(0);
                     ci[u].v[e] = in ? cols0[k + e] : I(0);
                     if constexpr (COO) ri[u].v[e] = in ? rows0[k + e] : I(0);
                 }
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                         T part = T(0);
                         for (int k = lrs + lane; k < lre; k += 64) {
                             const T xb = bj[int64_t(cols0[k]) * ldb];
-                            part += ADV ? (alpha * vals0[k]) * xb : vals0[k] * xb;
+                            part += ADV ? (alpha * T(vals0[k])) * xb : T(vals0[k]) * xb;
                         }
                         part = wave_sum(part);
                         if (lane == src) sum += part;

@@ -35,17 +35,18 @@ constexpr int fmt_unroll = 8;
 // products are added in column order (bit-identical to the reference loop).
 // UNITB: b has unit row stride and j == 0 (the gather address is base + 8 col instead of a
 // 64-bit multiply per entry)
-template <typename T, typename I, bool ADV, bool UNITB = false>
+// V: the type the matrix values are stored in (mixed precision: widened to T as they are used)
+template <typename T, typename I, bool ADV, bool UNITB = false, typename V = T>
 __device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
                                          int64_t step,
                                          const I* __restrict__ cols,
-                                         const T* __restrict__ vals,
+                                         const V* __restrict__ vals,
                                          const T* __restrict__ b, int64_t ldb,
                                          int j, T alpha)
 {
     constexpr int U = fmt_unroll;
     const int64_t full = len / U * U;
-    T v0[U], v1[U];
+    V v0[U], v1[U];
     I c0[U], c1[U];
     if (full > 0) {
 #pragma unroll
@@ -69,7 +70,7 @@ __device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const T t = ADV ? (alpha * v0[u]) * xv[u] : v0[u] * xv[u];
+            const T t = ADV ? (alpha * T(v0[u])) * xv[u] : T(v0[u]) * xv[u];
             sum = c0[u] >= 0 ? sum + t : sum;
         }
 #pragma unroll
@@ -82,7 +83,7 @@ __device__ __forceinline__ T fmt_row_sum(T sum, int64_t len, int64_t first,
     for (; i < len; ++i) {
         const I cc = cols[first + i * step];
         if (cc >= 0) {
-            const T v = vals[first + i * step];
+            const T v = T(vals[first + i * step]);
             const T xv = UNITB ? b[int64_t(cc)] : b[int64_t(cc) * ldb + j];
             sum += ADV ? (alpha * v) * xv : v * xv;
         }
@@ -139,10 +140,10 @@ __global__ __launch_bounds__(256) void fmt_spmv_multi_kernel(
 // read streams cost several times their byte share at the memory side, and
 // only a burst of >= 1 KB issued by ONE wave avoids it - a barrier that lines
 // up the 512 B stores of four waves does not)
-template <typename T, typename I, bool ADV>
+template <typename T, typename I, bool ADV, typename V = T>
 __global__ __launch_bounds__(256) void ell_spmv_kernel(
     int64_t n_rows, int64_t k_per_row, int64_t stride,
-    const I* __restrict__ cols, const T* __restrict__ vals,
+    const I* __restrict__ cols, const V* __restrict__ vals,
     const T* __restrict__ b, int64_t ldb, T* __restrict__ c, int64_t ldc,
     int nrhs, const T* __restrict__ alpha_p, const T* __restrict__ beta_p)
 {
@@ -159,13 +160,13 @@ __global__ __launch_bounds__(256) void ell_spmv_kernel(
         T s0 = T(0), s1 = T(0);
         if (row0 < n_rows) {
             if (ADV && beta != T(0)) s0 = beta * c[row0 * ldc + j];
-            s0 = unit_b ? fmt_row_sum<T, I, ADV, true>(s0, k_per_row, row0, stride, cols, vals, b, ldb, j, alpha)
-                        : fmt_row_sum<T, I, ADV>(s0, k_per_row, row0, stride, cols, vals, b, ldb, j, alpha);
+            s0 = unit_b ? fmt_row_sum<T, I, ADV, true, V>(s0, k_per_row, row0, stride, cols, vals, b, ldb, j, alpha)
+                        : fmt_row_sum<T, I, ADV, false, V>(s0, k_per_row, row0, stride, cols, vals, b, ldb, j, alpha);
         }
         if (row1 < n_rows) {
             if (ADV && beta != T(0)) s1 = beta * c[row1 * ldc + j];
-            s1 = unit_b ? fmt_row_sum<T, I, ADV, true>(s1, k_per_row, row1, stride, cols, vals, b, ldb, j, alpha)
-                        : fmt_row_sum<T, I, ADV>(s1, k_per_row, row1, stride, cols, vals, b, ldb, j, alpha);
+            s1 = unit_b ? fmt_row_sum<T, I, ADV, true, V>(s1, k_per_row, row1, stride, cols, vals, b, ldb, j, alpha)
+                        : fmt_row_sum<T, I, ADV, false, V>(s1, k_per_row, row1, stride, cols, vals, b, ldb, j, alpha);
         }
         if (row0 < n_rows) c[row0 * ldc + j] = s0;
         if (row1 < n_rows) c[row1 * ldc + j] = s1;
@@ -453,6 +454,22 @@ int launch_ell(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t k,
     return GKOC_OK;
 }
 
+// mixed precision (values float, vectors and arithmetic double): the one-column kernel, column by column
+template <typename T, typename V, typename I, bool ADV>
+int launch_ell_mixed(gkoc_stream_t s, int64_t n_rows, int64_t k, int64_t stride, const T* alpha,
+                     const I* cols, const V* vals, const T* b, int64_t ldb, const T* beta, T* c,
+                     int64_t ldc, int64_t nrhs)
+{
+    GKOC_REQUIRE(n_rows >= 0 && k >= 0 && nrhs >= 0 && stride >= n_rows, GKOC_E_INVALID,
+                 "bad ELL dimensions");
+    if (n_rows == 0 || nrhs == 0) return GKOC_OK;
+    if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
+    ell_spmv_kernel<T, I, ADV, V><<<dim3(unsigned(ceildiv(n_rows, 512))), dim3(256), 0, as_stream(s)>>>(
+        n_rows, k, stride, cols, vals, b, ldb, c, ldc, int(nrhs), alpha, beta);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
 template <typename T, typename I, bool ADV>
 int launch_sellp(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,
                  int64_t slice_size, const T* alpha, const uint64_t* slice_sets,
@@ -495,6 +512,28 @@ int launch_sellp(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,
 }  // namespace gkoc
 
 using namespace gkoc;
+
+#define GKOC_DEF_ELL_MIXED(I, IN)                                                                  \
+    extern "C" int gkoc_ell_spmv_f32_f64_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,     \
+                                              int64_t k, int64_t stride, const I* cols,            \
+                                              const float* vals, const double* b, int64_t ldb,     \
+                                              double* c, int64_t ldc, int64_t nrhs)                \
+    {                                                                                              \
+        (void)n_cols;                                                                              \
+        return launch_ell_mixed<double, float, I, false>(s, n_rows, k, stride, nullptr, cols,      \
+                                                         vals, b, ldb, nullptr, c, ldc, nrhs);     \
+    }                                                                                              \
+    extern "C" int gkoc_ell_advanced_spmv_f32_f64_##IN(                                            \
+        gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t k, int64_t stride,                \
+        const double* alpha, const I* cols, const float* vals, const double* b, int64_t ldb,       \
+        const double* beta, double* c, int64_t ldc, int64_t nrhs)                                  \
+    {                                                                                              \
+        (void)n_cols;                                                                              \
+        return launch_ell_mixed<double, float, I, true>(s, n_rows, k, stride, alpha, cols, vals,   \
+                                                        b, ldb, beta, c, ldc, nrhs);               \
+    }
+GKOC_DEF_ELL_MIXED(int32_t, i32)
+GKOC_DEF_ELL_MIXED(int64_t, i64)
 
 #define GKOC_DEF_FMT(T, TN, I, IN)                                             \
     extern "C" int gkoc_ell_spmv_##TN##_##IN(                                  \

@@ -185,8 +185,15 @@ def scalar(exec_, value, dtype=torch.float64):
 class _SparseBase(LinOp):
     def _operands(self, b, x):
         if b.dtype != self.dtype or x.dtype != self.dtype:
-            raise _lib.NotSupported("mixed-precision apply is not supported")
+            raise _lib.NotSupported("mixed-precision apply: only float32 Csr / Ell values with float64 "
+                                    "vectors (arithmetic in float64)")
         return b.values, b.ld, x.values, x.ld, b.size[1]
+
+    def _mixed(self, b, x, *scalars):
+        """float32 values applied to float64 vectors (csr::spmv<float, double, double>, arithmetic
+        in the highest precision): the kernels take the values as stored, 8 B per entry"""
+        return (self.dtype == torch.float32 and b.dtype == torch.float64 and x.dtype == torch.float64
+                and all(t.dtype == torch.float64 for t in scalars))
 
 
 class Csr(_SparseBase):
@@ -242,12 +249,22 @@ class Csr(_SparseBase):
         return self.values.numel()
 
     def apply_impl(self, b, x):
+        if self._mixed(b, x):
+            call("gkoc_csr_spmv_f32_f64_" + IT[self.col_idxs.dtype], self.exec.stream, self.size[0],
+                 self.size[1], self.row_ptrs, self.col_idxs, self.values, b.values, b.ld, x.values,
+                 x.ld, b.size[1])
+            return
         bv, ldb, xv, ldx, nrhs = self._operands(b, x)
         call("gkoc_csr_spmv_" + self._suf(), self.exec.stream, self.size[0],
              self.size[1], self.row_ptrs, self.col_idxs, self.values, bv, ldb,
              xv, ldx, nrhs)
 
     def apply_advanced_impl(self, alpha, b, beta, x):
+        if self._mixed(b, x, alpha, beta):
+            call("gkoc_csr_advanced_spmv_f32_f64_" + IT[self.col_idxs.dtype], self.exec.stream,
+                 self.size[0], self.size[1], alpha.values, self.row_ptrs, self.col_idxs, self.values,
+                 b.values, b.ld, beta.values, x.values, x.ld, b.size[1])
+            return
         bv, ldb, xv, ldx, nrhs = self._operands(b, x)
         call("gkoc_csr_advanced_spmv_" + self._suf(), self.exec.stream,
              self.size[0], self.size[1], alpha.values, self.row_ptrs,
@@ -587,12 +604,22 @@ class Ell(_SparseBase):
         return f"{VT[self.values.dtype]}_{IT[self.col_idxs.dtype]}"
 
     def apply_impl(self, b, x):
+        if self._mixed(b, x):
+            call("gkoc_ell_spmv_f32_f64_" + IT[self.col_idxs.dtype], self.exec.stream, self.size[0],
+                 self.size[1], self.num_stored_per_row, self.stride, self.col_idxs, self.values,
+                 b.values, b.ld, x.values, x.ld, b.size[1])
+            return
         bv, ldb, xv, ldx, nrhs = self._operands(b, x)
         call("gkoc_ell_spmv_" + self._suf(), self.exec.stream, self.size[0],
              self.size[1], self.num_stored_per_row, self.stride, self.col_idxs,
              self.values, bv, ldb, xv, ldx, nrhs)
 
     def apply_advanced_impl(self, alpha, b, beta, x):
+        if self._mixed(b, x, alpha, beta):
+            call("gkoc_ell_advanced_spmv_f32_f64_" + IT[self.col_idxs.dtype], self.exec.stream,
+                 self.size[0], self.size[1], self.num_stored_per_row, self.stride, alpha.values,
+                 self.col_idxs, self.values, b.values, b.ld, beta.values, x.values, x.ld, b.size[1])
+            return
         bv, ldb, xv, ldx, nrhs = self._operands(b, x)
         call("gkoc_ell_advanced_spmv_" + self._suf(), self.exec.stream,
              self.size[0], self.size[1], self.num_stored_per_row, self.stride,

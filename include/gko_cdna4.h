@@ -909,13 +909,40 @@ GKOC_DECL_XI(double, f64, int64_t, i64)
 GKOC_DECL_XI(float, f32, int32_t, i32)
 GKOC_DECL_XI(float, f32, int64_t, i64)
 
+/* ---------------------------------------------------- mixed-precision SpMV
+ * csr::spmv / ell::spmv<MatrixValueType = float, InputValueType = OutputValueType = double>
+ * (core/matrix/csr_kernels.hpp:34-52, ell_kernels.hpp:24-41; arithmetic_type = highest_precision =
+ * double): the matrix values are STORED in float and widened as they are loaded, vectors, scalars
+ * and every product and sum are double - 8 instead of 12 bytes per stored entry.  The result has the
+ * bits of the double kernel applied to the widened values.  Several columns: one after the other. */
+#define GKOC_DECL_MIXED(I, IN)                                                                        \
+    int gkoc_csr_spmv_f32_f64_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const I* row_ptrs, \
+                                   const I* col_idxs, const float* vals, const double* b,             \
+                                   int64_t ldb, double* c, int64_t ldc, int64_t nrhs);                \
+    int gkoc_csr_advanced_spmv_f32_f64_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,          \
+                                            const double* alpha, const I* row_ptrs,                   \
+                                            const I* col_idxs, const float* vals, const double* b,    \
+                                            int64_t ldb, const double* beta, double* c, int64_t ldc,  \
+                                            int64_t nrhs);                                            \
+    int gkoc_ell_spmv_f32_f64_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t k,        \
+                                   int64_t stride, const I* cols, const float* vals,                  \
+                                   const double* b, int64_t ldb, double* c, int64_t ldc,              \
+                                   int64_t nrhs);                                                     \
+    int gkoc_ell_advanced_spmv_f32_f64_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,          \
+                                            int64_t k, int64_t stride, const double* alpha,           \
+                                            const I* cols, const float* vals, const double* b,        \
+                                            int64_t ldb, const double* beta, double* c, int64_t ldc,  \
+                                            int64_t nrhs);
+GKOC_DECL_MIXED(int32_t, i32)
+GKOC_DECL_MIXED(int64_t, i64)
+
 /* ------------------------------------------- conversions and matrix utilities
  * Everything Ginkgo's matrix classes ask the device for when a matrix moves between formats, and the
  * diagonal / transpose / 1-norm helpers (csrc/conversions.hip; reference/matrix/{dense,csr,coo,ell,
  * sellp,hybrid}_kernels.cpp, cited per kernel there).  Entry order of every output = the
  * reference's.  Padding of Ell / Sellp: value 0, column -1 (invalid_index).  slice_sets are
  * Ginkgo's size_type (uint64_t).  Row pointers of the *_to_csr / dense_to_* functions are inputs:
- * the caller counts and scans first, as core/matrix/*.cpp does. */
+ * the caller counts and scans first, as the classes in core/matrix do. */
 #define GKOC_DECL_CV_DENSE(T, TN)                                                                     \
     int gkoc_fill_seq_array_##TN(gkoc_stream_t s, T* data, int64_t n);                                \
     int gkoc_dense_compute_norm1_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* x,        \

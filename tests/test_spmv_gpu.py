@@ -82,6 +82,59 @@ def test_csr_f32(gexec, oracle):
     assert np.array_equal(dc.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v, b))
 
 
+@pytest.mark.parametrize("idx", [np.int32, np.int64])
+def test_mixed_precision_f32_values_f64_vectors(gexec, oracle, idx):
+    """csr::spmv / ell::spmv<float, double, double> (arithmetic_type = highest precision): the
+    values are stored in float, widened on load, every product and sum is double - the bits of
+    the double oracle on the widened values; plain and advanced, several columns, strided
+    operands, unsorted columns, rows up to the long-row threshold, empty rows, unaligned views"""
+    import ginkgo_amd as g
+    rng = np.random.default_rng(17)
+    for n_rows, n_cols, dens in ((532, 231, 0.05), (1, 5, 1.0), (300, 300, 0.0), (65, 3000, 0.4), (4100, 70, 0.3)):
+        rp, ci, v = random_csr(n_rows, n_cols, dens, n_rows, idx, empty_rows=(0,) if n_rows > 1 else ())
+        v32 = v.astype(np.float32)
+        wide = v32.astype(np.float64)
+        a = dev_csr(g, gexec, rp, ci, v32, (n_rows, n_cols))
+        assert a.dtype == torch.float32
+        for nrhs in (1, 3):
+            b = rng.uniform(-1, 1, (n_cols, nrhs))
+            c0 = rng.uniform(-1, 1, (n_rows, nrhs))
+            y = g.Dense.from_numpy(gexec, np.full((n_rows, nrhs), np.nan), stride=nrhs + 2)
+            a.apply(g.Dense.from_numpy(gexec, b, stride=nrhs + 1), y)
+            assert np.array_equal(y.to_numpy(), oracle.csr_spmv(rp, ci, wide, b).reshape(n_rows, nrhs))
+            y = g.Dense.from_numpy(gexec, c0)
+            a.apply(g.scalar(gexec, 0.7), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.3), y)
+            want = oracle.csr_spmv(rp, ci, wide, b, alpha=0.7, beta=-1.3, c=c0).reshape(n_rows, nrhs)
+            assert np.array_equal(y.to_numpy(), want)
+            if n_rows * n_cols == 0 or len(ci) == 0:
+                continue
+            ell = a.convert_to_ell()
+            assert ell.dtype == torch.float32
+            y = g.Dense.create(gexec, (n_rows, nrhs))
+            ell.apply(g.Dense.from_numpy(gexec, b), y)
+            assert np.array_equal(y.to_numpy(), oracle.csr_spmv(rp, ci, wide, b).reshape(n_rows, nrhs))
+            y = g.Dense.from_numpy(gexec, c0)
+            ell.apply(g.scalar(gexec, 0.7), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.3), y)
+            assert np.array_equal(y.to_numpy(), want)
+    # an unaligned view of the arrays takes the scalar-load instance
+    rp, ci, v = random_csr(700, 700, 0.05, 3, idx)
+    v32 = v.astype(np.float32)
+    vals = gexec.to_device(np.concatenate([[0.0], v32]).astype(np.float32))[1:]
+    cols = gexec.to_device(np.concatenate([[0], ci]).astype(idx))[1:]
+    a = g.Csr(gexec, (700, 700), vals, cols, gexec.to_device(rp))
+    b = rng.uniform(-1, 1, 700)
+    y = g.Dense.create(gexec, (700, 1))
+    a.apply(g.Dense.from_numpy(gexec, b), y)
+    assert np.array_equal(y.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v32.astype(np.float64), b))
+    # the other mixed combinations are refused, not silently converted
+    with pytest.raises(g.NotSupported):
+        a.apply(g.Dense.from_numpy(gexec, b.astype(np.float32)), y)
+    a64 = dev_csr(g, gexec, rp, ci, v, (700, 700))
+    with pytest.raises(g.NotSupported):
+        a64.apply(g.Dense.from_numpy(gexec, b.astype(np.float32)),
+                  g.Dense.create(gexec, (700, 1), torch.float32))
+
+
 def test_csr_edge_shapes(gexec, oracle):
     import ginkgo_amd as g
     # 0 x 0, all-empty rows, one row, non-multiple-of-64 rows

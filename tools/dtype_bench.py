@@ -35,3 +35,30 @@ for vt, it in ((torch.float64, torch.int32), (torch.float64, torch.int64),
         del op
     del a, x, y
     torch.cuda.empty_cache()
+
+# mixed precision: float32 values, float64 vectors and arithmetic (csr / ell ::spmv<float, double,
+# double>): 8 B per stored entry; compared with the all-double product of the same (widened) matrix
+for it in (torch.int32,):
+    a32 = g.stencil_csr(ex, 3, grid, dtype=torch.float32, index_dtype=it)
+    nnz = a32.get_num_stored_elements()
+    x = g.Dense.from_numpy(ex, np.random.default_rng(1).uniform(-1, 1, n))
+    y = g.Dense.create(ex, (n, 1))
+    nbytes = nnz * (4 + 4) + (n + 1) * 4 + 2 * n * 8
+    a64 = g.stencil_csr(ex, 3, grid, index_dtype=it)   # the 27-pt entries are exact in float
+    ref = g.Dense.create(ex, (n, 1))
+    a64.apply(x, ref)
+    del a64
+    for name, op in (("csr", a32), ("ell", a32.convert_to_ell())):
+        for _ in range(25):
+            op.apply(x, y)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(y.values, ref.values))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            op.apply(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print(f"f32 values x f64 vectors  {str(it):12s} {name:6s} {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s "
+              f"({100*nbytes/ms/1e6/8000:5.1f} % of 8 TB/s)  bits == all-double product: {same}", flush=True)
