@@ -650,6 +650,76 @@ __global__ __launch_bounds__(256) void csr_span_kernel(int64_t n, int64_t row0, 
 }
 
 
+// ------------------------------------------------------- SpGEMM / SpGEAM as triplets
+// C = alpha A B + beta D (csr::spgemm / advanced_spgemm, reference/matrix/csr_kernels.cpp:156-300)
+// and C = alpha A + beta B (csr::spgeam, :425-468) accumulate a row's contributions in a map by
+// column: value = 0 + contributions in the order they are met (D's entries first, then the products
+// a_ik b_kj in storage order), pattern = union, columns ascending.  Here: every contribution of row
+// i is written as a triplet (i, column, value) at offsets[i] ..., then the library's own
+// sort_row_major (stable) and sum_duplicates (assembly.hip: 0 + v0 + v1 + ... in storage order) give
+// exactly that.  B == NULL (b_rp): A's entries themselves are the contributions (SpGEAM).
+template <typename I>
+__global__ __launch_bounds__(256) void spgemm_count_kernel(int64_t n_rows, const I* __restrict__ a_rp,
+                                                           const I* __restrict__ a_ci,
+                                                           const I* __restrict__ b_rp,
+                                                           const I* __restrict__ d_rp,
+                                                           int64_t* __restrict__ offsets)
+{
+    GKOC_FOR_EACH(r, n_rows + 1)
+    {
+        int64_t c = 0;
+        if (r < n_rows) {
+            if (d_rp) c += d_rp[r + 1] - d_rp[r];
+            if (b_rp) {
+                for (int64_t k = a_rp[r]; k < a_rp[r + 1]; ++k) c += b_rp[a_ci[k] + 1] - b_rp[a_ci[k]];
+            } else {
+                c += a_rp[r + 1] - a_rp[r];
+            }
+        }
+        offsets[r] = c;
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void spgemm_expand_kernel(
+    int64_t n_rows, const T* __restrict__ alpha_p, const I* __restrict__ a_rp, const I* __restrict__ a_ci,
+    const T* __restrict__ a_v, const I* __restrict__ b_rp, const I* __restrict__ b_ci,
+    const T* __restrict__ b_v, const T* __restrict__ beta_p, const I* __restrict__ d_rp,
+    const I* __restrict__ d_ci, const T* __restrict__ d_v, const int64_t* __restrict__ offsets,
+    I* __restrict__ t_rows, I* __restrict__ t_cols, T* __restrict__ t_vals)
+{
+    const T alpha = alpha_p ? alpha_p[0] : T(1);
+    const T beta = beta_p ? beta_p[0] : T(1);
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        int64_t at = offsets[r];
+        if (d_rp) {
+            for (int64_t k = d_rp[r]; k < d_rp[r + 1]; ++k, ++at) {
+                t_rows[at] = I(r);
+                t_cols[at] = d_ci[k];
+                t_vals[at] = beta * d_v[k];
+            }
+        }
+        for (int64_t k = a_rp[r]; k < a_rp[r + 1]; ++k) {
+            const T sa = alpha * a_v[k];
+            if (!b_rp) {
+                t_rows[at] = I(r);
+                t_cols[at] = a_ci[k];
+                t_vals[at] = sa;
+                ++at;
+                continue;
+            }
+            const int64_t br = a_ci[k];
+            for (int64_t l = b_rp[br]; l < b_rp[br + 1]; ++l, ++at) {
+                t_rows[at] = I(r);
+                t_cols[at] = b_ci[l];
+                t_vals[at] = sa * b_v[l];
+            }
+        }
+    }
+}
+
+
 #define CV_LAUNCH(kernel, n, ...)                                                     \
     do {                                                                              \
         if ((n) > 0) {                                                                \
@@ -1034,3 +1104,35 @@ GKOC_DEF_PERMUTE(float, f32, int64_t, i64)
     }
 GKOC_DEF_PERMUTATION(int32_t, i32)
 GKOC_DEF_PERMUTATION(int64_t, i64)
+
+// offsets[r] = where row r's contributions start (n_rows + 1 entries, int64); *total_host = their number
+#define GKOC_DEF_SPGEMM_COUNT(I, IN)                                                                    \
+    extern "C" int gkoc_csr_spgemm_count_##IN(gkoc_stream_t s, int64_t n_rows, const I* a_rp,           \
+                                              const I* a_ci, const I* b_rp, const I* d_rp,              \
+                                              int64_t* offsets, int64_t* total_host)                    \
+    {                                                                                                   \
+        GKOC_REQUIRE(n_rows >= 0 && a_rp && offsets && total_host, GKOC_E_INVALID, "bad argument");     \
+        CV_LAUNCH(spgemm_count_kernel<I>, n_rows + 1, n_rows, a_rp, a_ci, b_rp, d_rp, offsets);         \
+        GKOC_TRY(device_exclusive_scan<int64_t>(as_stream(s), offsets, n_rows + 1));                    \
+        GKOC_HIP(hipMemcpyAsync(total_host, offsets + n_rows, 8, hipMemcpyDeviceToHost, as_stream(s))); \
+        GKOC_HIP(hipStreamSynchronize(as_stream(s)));                                                   \
+        return GKOC_OK;                                                                                 \
+    }
+GKOC_DEF_SPGEMM_COUNT(int32_t, i32)
+GKOC_DEF_SPGEMM_COUNT(int64_t, i64)
+
+#define GKOC_DEF_SPGEMM(T, TN, I, IN)                                                                   \
+    extern "C" int gkoc_csr_spgemm_expand_##TN##_##IN(                                                  \
+        gkoc_stream_t s, int64_t n_rows, const T* alpha, const I* a_rp, const I* a_ci, const T* a_v,    \
+        const I* b_rp, const I* b_ci, const T* b_v, const T* beta, const I* d_rp, const I* d_ci,        \
+        const T* d_v, const int64_t* offsets, I* t_rows, I* t_cols, T* t_vals)                          \
+    {                                                                                                   \
+        GKOC_REQUIRE(n_rows >= 0 && a_rp && offsets, GKOC_E_INVALID, "bad argument");                   \
+        CV_LAUNCH((spgemm_expand_kernel<T, I>), n_rows, n_rows, alpha, a_rp, a_ci, a_v, b_rp, b_ci,     \
+                  b_v, beta, d_rp, d_ci, d_v, offsets, t_rows, t_cols, t_vals);                         \
+        return GKOC_OK;                                                                                 \
+    }
+GKOC_DEF_SPGEMM(double, f64, int32_t, i32)
+GKOC_DEF_SPGEMM(double, f64, int64_t, i64)
+GKOC_DEF_SPGEMM(float, f32, int32_t, i32)
+GKOC_DEF_SPGEMM(float, f32, int64_t, i64)

@@ -12,6 +12,7 @@
 
 #include "core/components/absolute_array_kernels.hpp"
 #include "core/components/fill_array_kernels.hpp"
+#include "core/matrix/csr_builder.hpp"
 #include "core/matrix/coo_kernels.hpp"
 #include "core/matrix/csr_kernels.hpp"
 #include "core/matrix/dense_kernels.hpp"
@@ -655,6 +656,99 @@ namespace csr {
 FOR_VT_IT(DEF)
 #undef DEF
 #undef PERMUTE
+
+}  // namespace csr
+
+
+namespace csr {
+
+// C = alpha A B + beta D and C = alpha A + beta B through triplets (csrc/conversions.hip): expand the
+// contributions row by row, sort them (stable) by (row, column), add up the runs, rows -> pointers
+#define DEF(T, TN, I, IN)                                                                           \
+    static void from_contributions_##TN##_##IN(                                                     \
+        exec_t exec, const T* alpha, const matrix::Csr<T, I>* a, const matrix::Csr<T, I>* b,        \
+        const T* beta, const matrix::Csr<T, I>* d, matrix::Csr<T, I>* c)                            \
+    {                                                                                               \
+        const auto s = stream_of(exec);                                                             \
+        const auto n = static_cast<int64_t>(a->get_size()[0]);                                      \
+        array<int64> offsets{exec, static_cast<size_type>(n + 1)};                                  \
+        int64_t total = 0;                                                                          \
+        GKOC_CALL(gkoc_csr_spgemm_count_##IN(s, n, a->get_const_row_ptrs(), a->get_const_col_idxs(), \
+                                             b ? b->get_const_row_ptrs() : nullptr,                 \
+                                             d ? d->get_const_row_ptrs() : nullptr,                 \
+                                             offsets.get_data(), &total));                          \
+        const auto nt = static_cast<size_type>(total);                                              \
+        array<I> t_rows{exec, nt}, t_cols{exec, nt};                                                \
+        array<T> t_vals{exec, nt};                                                                  \
+        GKOC_CALL(gkoc_csr_spgemm_expand_##TN##_##IN(                                               \
+            s, n, alpha, a->get_const_row_ptrs(), a->get_const_col_idxs(), a->get_const_values(),   \
+            b ? b->get_const_row_ptrs() : nullptr, b ? b->get_const_col_idxs() : nullptr,           \
+            b ? b->get_const_values() : nullptr, beta, d ? d->get_const_row_ptrs() : nullptr,       \
+            d ? d->get_const_col_idxs() : nullptr, d ? d->get_const_values() : nullptr,             \
+            offsets.get_const_data(), t_rows.get_data(), t_cols.get_data(), t_vals.get_data()));    \
+        array<char> sort_work{exec, gkoc_sort_row_major_workspace_bytes(total, sizeof(T), sizeof(I))}; \
+        GKOC_CALL(gkoc_sort_row_major_##TN##_##IN(s, total, t_rows.get_data(), t_cols.get_data(),   \
+                                                  t_vals.get_data(), sort_work.get_data(),          \
+                                                  sort_work.get_size()));                           \
+        array<char> work{exec, gkoc_compact_workspace_bytes(total)};                                \
+        int64_t kept = 0;                                                                           \
+        GKOC_CALL(gkoc_sum_duplicates_count_##IN(s, total, t_rows.get_const_data(),                 \
+                                                 t_cols.get_const_data(), work.get_data(),          \
+                                                 work.get_size(), &kept));                          \
+        matrix::CsrBuilder<T, I> builder{c};                                                        \
+        builder.get_col_idx_array().resize_and_reset(static_cast<size_type>(kept));                 \
+        builder.get_value_array().resize_and_reset(static_cast<size_type>(kept));                   \
+        array<I> c_rows{exec, static_cast<size_type>(kept)};                                        \
+        GKOC_CALL(gkoc_sum_duplicates_fill_##TN##_##IN(                                             \
+            s, total, t_rows.get_const_data(), t_cols.get_const_data(), t_vals.get_const_data(),    \
+            work.get_const_data(), c_rows.get_data(), builder.get_col_idx_array().get_data(),       \
+            builder.get_value_array().get_data()));                                                 \
+        GKOC_CALL(gkoc_convert_idxs_to_ptrs_##IN(s, kept, c_rows.get_const_data(), n,               \
+                                                 c->get_row_ptrs()));                               \
+        exec->synchronize(); /* the temporaries are released on return */                           \
+    }                                                                                               \
+    /* csr::scale / inv_scale (reference/matrix/csr_kernels.cpp:1342-1370): every stored value */   \
+    template <>                                                                                     \
+    void scale<T, I>(exec_t exec, const matrix::Dense<T>* alpha, matrix::Csr<T, I>* to_scale)       \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_scale_##TN(stream_of(exec),                                            \
+                                        static_cast<int64_t>(to_scale->get_num_stored_elements()),  \
+                                        1, alpha->get_const_values(), 1, to_scale->get_values(),    \
+                                        1));                                                        \
+    }                                                                                               \
+    template <>                                                                                     \
+    void inv_scale<T, I>(exec_t exec, const matrix::Dense<T>* alpha, matrix::Csr<T, I>* to_scale)   \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_inv_scale_##TN(                                                        \
+            stream_of(exec), static_cast<int64_t>(to_scale->get_num_stored_elements()), 1,          \
+            alpha->get_const_values(), 1, to_scale->get_values(), 1));                              \
+    }                                                                                               \
+    template <>                                                                                     \
+    void spgemm<T, I>(exec_t exec, const matrix::Csr<T, I>* a, const matrix::Csr<T, I>* b,          \
+                      matrix::Csr<T, I>* c)                                                         \
+    {                                                                                               \
+        from_contributions_##TN##_##IN(exec, nullptr, a, b, nullptr, nullptr, c);                   \
+    }                                                                                               \
+    template <>                                                                                     \
+    void advanced_spgemm<T, I>(exec_t exec, const matrix::Dense<T>* alpha,                          \
+                               const matrix::Csr<T, I>* a, const matrix::Csr<T, I>* b,              \
+                               const matrix::Dense<T>* beta, const matrix::Csr<T, I>* d,            \
+                               matrix::Csr<T, I>* c)                                                \
+    {                                                                                               \
+        from_contributions_##TN##_##IN(exec, alpha->get_const_values(), a, b,                       \
+                                       beta->get_const_values(), d, c);                             \
+    }                                                                                               \
+    template <>                                                                                     \
+    void spgeam<T, I>(exec_t exec, const matrix::Dense<T>* alpha, const matrix::Csr<T, I>* a,       \
+                      const matrix::Dense<T>* beta, const matrix::Csr<T, I>* b,                     \
+                      matrix::Csr<T, I>* c)                                                         \
+    {                                                                                               \
+        /* alpha A's entries come first ("D"), then beta B's: 0 + alpha a + beta b */               \
+        from_contributions_##TN##_##IN(exec, beta->get_const_values(), b, nullptr,                  \
+                                       alpha->get_const_values(), a, c);                            \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
 
 }  // namespace csr
 

@@ -18,14 +18,12 @@
 // device pointers of a solver's INTERNAL vectors and reads them with its own launches between two
 // backend calls - GKOC_TUNE_DEFERRED_FUSION = 0 (gkoc_tune_set / env GKOC_TUNE_5) switches the
 // mechanism off.
-#include <mutex>
-
 #include "shim_common.hpp"
 
 namespace gko {
 namespace cdna4 {
 
-std::atomic<int> deferred_state{0};
+thread_local int deferred_state = 0;
 
 namespace {
 
@@ -50,8 +48,11 @@ struct held_ops {
     gkoc_stream_t norm_s = nullptr;
 };
 
-held_ops held;
-std::mutex held_mutex;
+// Per thread: the calls that take part arrive back to back on the thread that runs the solver, and
+// what a thread holds never outlives the solver's apply (the loop ends with the dot product and the
+// criterion check).  Another thread - possibly working on another device - neither sees nor has to
+// launch it.
+thread_local held_ops held;
 
 int enabled()
 {
@@ -60,7 +61,7 @@ int enabled()
     return v != 0;
 }
 
-void publish() { deferred_state.store(held.stage | (held.norm_of ? 4 : 0), std::memory_order_release); }
+void publish() { deferred_state = held.stage | (held.norm_of ? 4 : 0); }
 
 void launch_step_2(const held_ops& h)
 {
@@ -98,7 +99,6 @@ void launch_apply(const held_ops& h)
 
 void flush_deferred()
 {
-    std::lock_guard<std::mutex> guard(held_mutex);
     const held_ops h = held;
     held.stage = 0;
     held.norm_of = nullptr;
@@ -112,7 +112,6 @@ bool hold_step_2(int vt, gkoc_stream_t s, int64_t n, void* x, void* r, const voi
 {
     // (the caller has been through stream_of(): nothing is held at this point)
     if (n <= 0 || !enabled()) return false;
-    std::lock_guard<std::mutex> guard(held_mutex);
     held.stage = 1;
     held.vt = vt;
     held.s = s;
@@ -132,7 +131,6 @@ bool hold_jacobi_apply(int vt, int it, gkoc_stream_t s, int64_t num_blocks, uint
                        gkoc_jacobi_scheme scheme, const void* block_ptrs, const void* blocks,
                        const void* b, int64_t n, void* z)
 {
-    std::lock_guard<std::mutex> guard(held_mutex);
     const int64_t bo = scheme.block_offset;
     const bool fast_layout = bo >= 1 && bo <= 16 && (bo & (bo - 1)) == 0 &&
                              (bo << scheme.group_power) == 64 && int64_t(max_bs) <= bo;
@@ -157,8 +155,7 @@ bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y,
 {
     held_ops h;
     {
-        std::lock_guard<std::mutex> guard(held_mutex);
-        if (held.stage != 2 || held.vt != vt || held.s != s || held.n != n || held.r != x || held.z != y ||
+            if (held.stage != 2 || held.vt != vt || held.s != s || held.n != n || held.r != x || held.z != y ||
             result == held.rho || result == held.beta) {
             return false;
         }
@@ -193,7 +190,6 @@ bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y,
     }
     GKOC_FUSION_TYPES(CASE)
 #undef CASE
-    std::lock_guard<std::mutex> guard(held_mutex);
     held.norm_of = h.r;
     held.norm_at = norm_at;
     held.norm_vt = vt;
@@ -207,8 +203,7 @@ bool cached_norm2(int vt, gkoc_stream_t s, int64_t n, const void* x, void* resul
 {
     const void* src = nullptr;
     {
-        std::lock_guard<std::mutex> guard(held_mutex);
-        if (held.stage == 0 && held.norm_of && held.norm_of == x && held.norm_vt == vt && held.norm_n == n &&
+            if (held.stage == 0 && held.norm_of && held.norm_of == x && held.norm_vt == vt && held.norm_n == n &&
             held.norm_s == s) {
             src = held.norm_at;
         }

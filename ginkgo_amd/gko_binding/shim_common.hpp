@@ -9,7 +9,6 @@
 // link-compatible replacement for libginkgo_hip.so.  No device code and no HIP
 // headers are needed here: everything goes through the C ABI.
 #pragma once
-#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -45,11 +44,11 @@ inline void check(int status, const char* file, int line, const char* what)
 // Fusion across calls (fusion.cpp): cg::step_2 and the block-Jacobi application that follows it
 // are held back until the next call shows whether one kernel can do them together with the dot
 // product.  Everything that enters the backend goes through launch_deferred() first.
-extern std::atomic<int> deferred_state;   // != 0: something is held or a norm is cached
+extern thread_local int deferred_state;   // != 0: this thread holds something or caches a norm
 void flush_deferred();
 inline void launch_deferred()
 {
-    if (deferred_state.load(std::memory_order_acquire) != 0) flush_deferred();
+    if (deferred_state != 0) flush_deferred();
 }
 bool hold_step_2(int vt, gkoc_stream_t s, int64_t n, void* x, void* r, const void* p, const void* q,
                  const void* beta, const void* rho, const uint8_t* stop);

@@ -1081,6 +1081,31 @@ GKOC_DECL_PERMUTE(float, f32, int64_t, i64)
 GKOC_DECL_PERMUTATION(int32_t, i32)
 GKOC_DECL_PERMUTATION(int64_t, i64)
 
+/* SpGEMM / SpGEAM (csr::spgemm, advanced_spgemm, spgeam; reference/matrix/csr_kernels.cpp:156-300,
+ * 425-468) as triplets: count gives where each row's contributions start (offsets: n_rows + 1
+ * int64 on the device) and their number on the host; expand writes them as (row, column, value) -
+ * first beta * D's entries (d_rp != NULL), then (alpha * a_ik) * b_kj in storage order, or, with
+ * b_rp == NULL, alpha * a_ik themselves (SpGEAM: A's entries are "D", the second matrix is "A").
+ * gkoc_sort_row_major + gkoc_sum_duplicates_* + gkoc_convert_idxs_to_ptrs turn the triplets into the
+ * result: the reference's values (0 + contributions in the order they are met), pattern and order.
+ * alpha / beta NULL: 1. */
+int gkoc_csr_spgemm_count_i32(gkoc_stream_t s, int64_t n_rows, const int32_t* a_rp, const int32_t* a_ci,
+                              const int32_t* b_rp, const int32_t* d_rp, int64_t* offsets,
+                              int64_t* total_host);
+int gkoc_csr_spgemm_count_i64(gkoc_stream_t s, int64_t n_rows, const int64_t* a_rp, const int64_t* a_ci,
+                              const int64_t* b_rp, const int64_t* d_rp, int64_t* offsets,
+                              int64_t* total_host);
+#define GKOC_DECL_SPGEMM(T, TN, I, IN)                                                                \
+    int gkoc_csr_spgemm_expand_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const T* alpha,           \
+                                           const I* a_rp, const I* a_ci, const T* a_v, const I* b_rp, \
+                                           const I* b_ci, const T* b_v, const T* beta, const I* d_rp, \
+                                           const I* d_ci, const T* d_v, const int64_t* offsets,       \
+                                           I* t_rows, I* t_cols, T* t_vals);
+GKOC_DECL_SPGEMM(double, f64, int32_t, i32)
+GKOC_DECL_SPGEMM(double, f64, int64_t, i64)
+GKOC_DECL_SPGEMM(float, f32, int32_t, i32)
+GKOC_DECL_SPGEMM(float, f32, int64_t, i64)
+
 /* ------------------------------------------------- COO SpMV, CSR -> Hybrid
  * coo::{spmv, advanced_spmv, spmv2, advanced_spmv2} (core/matrix/coo_kernels.hpp:24-58;
  * reference/matrix/coo_kernels.cpp:33-100): c = A b, c = alpha A b + beta c,
