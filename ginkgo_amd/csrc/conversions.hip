@@ -720,6 +720,108 @@ __global__ __launch_bounds__(256) void spgemm_expand_kernel(
 }
 
 
+// ------------------------------------------------------------ L1 block-Jacobi
+// jacobi::scalar_l1 / block_l1 (reference/preconditioner/jacobi_kernels.cpp:728-780): the diagonal
+// entry of every row grows by the sum of |a_ij| over the entries OUTSIDE its diagonal block (scalar:
+// j != i), added in storage order.  factorization::add_diagonal_elements
+// (reference/factorization/factorization_kernels.cpp:55-128) makes sure every row has one: a missing
+// diagonal is inserted as an explicit zero before the first larger column (at the end of the row if
+// there is none).
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void jacobi_scalar_l1_kernel(int64_t n_rows, const I* __restrict__ rp,
+                                                               const I* __restrict__ ci,
+                                                               const T* __restrict__ v, T* __restrict__ diag)
+{
+    GKOC_FOR_EACH(r, n_rows)
+    {
+        T off = T(0);
+        for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+            if (int64_t(ci[k]) != r) off += v[k] < T(0) ? -v[k] : v[k];
+        }
+        diag[r] += off;
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void jacobi_block_l1_kernel(int64_t num_blocks,
+                                                              const I* __restrict__ block_ptrs,
+                                                              const I* __restrict__ rp,
+                                                              const I* __restrict__ ci, T* __restrict__ v)
+{
+    GKOC_FOR_EACH(b, num_blocks)
+    {
+        const int64_t start = block_ptrs[b], end = block_ptrs[b + 1];
+        for (int64_t r = start; r < end; ++r) {
+            T off = T(0);
+            int64_t diag_at = -1;
+            for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+                const int64_t c = ci[k];
+                if (c >= start && c < end) {
+                    if (c == r) diag_at = k;
+                    continue;
+                }
+                off += v[k] < T(0) ? -v[k] : v[k];
+            }
+            if (diag_at >= 0) v[diag_at] += off;
+        }
+    }
+}
+
+template <typename I>
+__global__ __launch_bounds__(256) void missing_diagonal_count_kernel(int64_t n_rows, int64_t n_cols,
+                                                                     const I* __restrict__ rp,
+                                                                     const I* __restrict__ ci,
+                                                                     I* __restrict__ shift)
+{
+    GKOC_FOR_EACH(r, n_rows + 1)
+    {
+        I miss = 0;
+        if (r < n_rows && r < n_cols) {
+            miss = 1;
+            for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+                if (int64_t(ci[k]) == r) miss = 0;
+            }
+        }
+        shift[r] = miss;
+    }
+}
+
+// shift = exclusive sums of the per-row counts: row r moves to old start + shift[r]
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void add_diagonal_fill_kernel(int64_t n_rows, const I* __restrict__ rp,
+                                                                const I* __restrict__ ci,
+                                                                const T* __restrict__ v,
+                                                                const I* __restrict__ shift,
+                                                                I* __restrict__ new_rp,
+                                                                I* __restrict__ new_ci,
+                                                                T* __restrict__ new_v)
+{
+    GKOC_FOR_EACH(r, n_rows + 1)
+    {
+        new_rp[r] = rp[r] + shift[r];
+        if (r == n_rows) continue;
+        const bool missing = shift[r + 1] != shift[r];
+        int64_t at = int64_t(rp[r]) + shift[r];
+        bool placed = !missing;
+        for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
+            if (!placed && int64_t(ci[k]) > r) {
+                new_ci[at] = I(r);
+                new_v[at] = T(0);
+                ++at;
+                placed = true;
+            }
+            new_ci[at] = ci[k];
+            new_v[at] = v[k];
+            ++at;
+        }
+        if (!placed) {
+            new_ci[at] = I(r);
+            new_v[at] = T(0);
+        }
+    }
+}
+
+
 #define CV_LAUNCH(kernel, n, ...)                                                     \
     do {                                                                              \
         if ((n) > 0) {                                                                \
@@ -1136,3 +1238,51 @@ GKOC_DEF_SPGEMM(double, f64, int32_t, i32)
 GKOC_DEF_SPGEMM(double, f64, int64_t, i64)
 GKOC_DEF_SPGEMM(float, f32, int32_t, i32)
 GKOC_DEF_SPGEMM(float, f32, int64_t, i64)
+
+#define GKOC_DEF_L1(T, TN, I, IN)                                                                       \
+    extern "C" int gkoc_jacobi_scalar_l1_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* rp,      \
+                                                     const I* ci, const T* v, T* diag)                  \
+    {                                                                                                   \
+        CV_LAUNCH((jacobi_scalar_l1_kernel<T, I>), n_rows, n_rows, rp, ci, v, diag);                    \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_jacobi_block_l1_##TN##_##IN(gkoc_stream_t s, int64_t num_blocks,                \
+                                                    const I* block_ptrs, const I* rp, const I* ci,      \
+                                                    T* v)                                               \
+    {                                                                                                   \
+        CV_LAUNCH((jacobi_block_l1_kernel<T, I>), num_blocks, num_blocks, block_ptrs, rp, ci, v);       \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_csr_add_diagonal_fill_##TN##_##IN(gkoc_stream_t s, int64_t n_rows,              \
+                                                          const I* rp, const I* ci, const T* v,         \
+                                                          const I* shift, I* new_rp, I* new_ci,         \
+                                                          T* new_v)                                     \
+    {                                                                                                   \
+        GKOC_REQUIRE(n_rows >= 0 && rp && shift && new_rp, GKOC_E_INVALID, "bad argument");             \
+        CV_LAUNCH((add_diagonal_fill_kernel<T, I>), n_rows + 1, n_rows, rp, ci, v, shift, new_rp,       \
+                  new_ci, new_v);                                                                       \
+        return GKOC_OK;                                                                                 \
+    }
+GKOC_DEF_L1(double, f64, int32_t, i32)
+GKOC_DEF_L1(double, f64, int64_t, i64)
+GKOC_DEF_L1(float, f32, int32_t, i32)
+GKOC_DEF_L1(float, f32, int64_t, i64)
+
+// shift (n_rows + 1): exclusive sums of "row r lacks its diagonal entry"; *missing_host = their number
+#define GKOC_DEF_MISSING(I, IN)                                                                         \
+    extern "C" int gkoc_csr_missing_diagonal_shift_##IN(gkoc_stream_t s, int64_t n_rows,                \
+                                                        int64_t n_cols, const I* rp, const I* ci,       \
+                                                        I* shift, int64_t* missing_host)                \
+    {                                                                                                   \
+        GKOC_REQUIRE(n_rows >= 0 && rp && shift && missing_host, GKOC_E_INVALID, "bad argument");       \
+        CV_LAUNCH(missing_diagonal_count_kernel<I>, n_rows + 1, n_rows, n_cols, rp, ci, shift);         \
+        GKOC_TRY(device_exclusive_scan<I>(as_stream(s), shift, n_rows + 1));                            \
+        I total = 0;                                                                                    \
+        GKOC_HIP(hipMemcpyAsync(&total, shift + n_rows, sizeof(I), hipMemcpyDeviceToHost,               \
+                                as_stream(s)));                                                         \
+        GKOC_HIP(hipStreamSynchronize(as_stream(s)));                                                   \
+        *missing_host = int64_t(total);                                                                 \
+        return GKOC_OK;                                                                                 \
+    }
+GKOC_DEF_MISSING(int32_t, i32)
+GKOC_DEF_MISSING(int64_t, i64)

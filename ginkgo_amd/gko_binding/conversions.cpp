@@ -12,6 +12,8 @@
 
 #include "core/components/absolute_array_kernels.hpp"
 #include "core/components/fill_array_kernels.hpp"
+#include "core/factorization/factorization_kernels.hpp"
+#include "core/preconditioner/jacobi_kernels.hpp"
 #include "core/matrix/csr_builder.hpp"
 #include "core/matrix/coo_kernels.hpp"
 #include "core/matrix/csr_kernels.hpp"
@@ -766,6 +768,63 @@ FOR_VT(DEF)
 #undef DEF
 
 }  // namespace coo
+
+
+namespace jacobi {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void scalar_l1<T, I>(exec_t exec, const matrix::Csr<T, I>* csr, matrix::Diagonal<T>* diag)      \
+    {                                                                                               \
+        GKOC_CALL(gkoc_jacobi_scalar_l1_##TN##_##IN(                                                \
+            stream_of(exec), static_cast<int64_t>(csr->get_size()[0]), csr->get_const_row_ptrs(),   \
+            csr->get_const_col_idxs(), csr->get_const_values(), diag->get_values()));               \
+    }                                                                                               \
+    template <>                                                                                     \
+    void block_l1<T, I>(exec_t exec, size_type num_blocks, const array<I>& block_pointers,          \
+                        matrix::Csr<T, I>* csr)                                                     \
+    {                                                                                               \
+        GKOC_CALL(gkoc_jacobi_block_l1_##TN##_##IN(                                                 \
+            stream_of(exec), static_cast<int64_t>(num_blocks), block_pointers.get_const_data(),     \
+            csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_values()));              \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace jacobi
+
+
+namespace factorization {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void add_diagonal_elements<T, I>(exec_t exec, matrix::Csr<T, I>* mtx, bool)                     \
+    {                                                                                               \
+        const auto s = stream_of(exec);                                                             \
+        const auto n = static_cast<int64_t>(mtx->get_size()[0]);                                    \
+        array<I> shift{exec, static_cast<size_type>(n + 1)};                                        \
+        int64_t missing = 0;                                                                        \
+        GKOC_CALL(gkoc_csr_missing_diagonal_shift_##IN(                                             \
+            s, n, static_cast<int64_t>(mtx->get_size()[1]), mtx->get_const_row_ptrs(),              \
+            mtx->get_const_col_idxs(), shift.get_data(), &missing));                                \
+        if (missing == 0) return;                                                                   \
+        const auto new_nnz = mtx->get_num_stored_elements() + static_cast<size_type>(missing);      \
+        array<T> new_values{exec, new_nnz};                                                         \
+        array<I> new_cols{exec, new_nnz};                                                           \
+        array<I> new_ptrs{exec, static_cast<size_type>(n + 1)};                                     \
+        GKOC_CALL(gkoc_csr_add_diagonal_fill_##TN##_##IN(                                           \
+            s, n, mtx->get_const_row_ptrs(), mtx->get_const_col_idxs(), mtx->get_const_values(),    \
+            shift.get_const_data(), new_ptrs.get_data(), new_cols.get_data(),                       \
+            new_values.get_data()));                                                                \
+        exec->copy(static_cast<size_type>(n + 1), new_ptrs.get_const_data(), mtx->get_row_ptrs());  \
+        matrix::CsrBuilder<T, I> builder{mtx};                                                      \
+        builder.get_value_array() = std::move(new_values);                                          \
+        builder.get_col_idx_array() = std::move(new_cols);                                          \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+}  // namespace factorization
 
 
 namespace permutation {

@@ -1106,6 +1106,31 @@ GKOC_DECL_SPGEMM(double, f64, int64_t, i64)
 GKOC_DECL_SPGEMM(float, f32, int32_t, i32)
 GKOC_DECL_SPGEMM(float, f32, int64_t, i64)
 
+/* L1 block-Jacobi (Jacobi::with_aggregate_l1; reference/preconditioner/jacobi_kernels.cpp:728-780,
+ * reference/factorization/factorization_kernels.cpp:55-128): scalar_l1 adds to diag[r] the sum of
+ * |a_rj|, j != r; block_l1 adds to the stored diagonal entry of every row the sum of |a_rj| over the
+ * entries outside the row's diagonal block (both in storage order); add_diagonal_elements = shift
+ * (which rows lack a diagonal entry, scanned; their number on the host) + fill (the matrix with an
+ * explicit zero inserted before the first larger column of such a row). */
+#define GKOC_DECL_L1(T, TN, I, IN)                                                                    \
+    int gkoc_jacobi_scalar_l1_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* rp, const I* ci,  \
+                                          const T* v, T* diag);                                       \
+    int gkoc_jacobi_block_l1_##TN##_##IN(gkoc_stream_t s, int64_t num_blocks, const I* block_ptrs,    \
+                                         const I* rp, const I* ci, T* v);                             \
+    int gkoc_csr_add_diagonal_fill_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* rp,          \
+                                               const I* ci, const T* v, const I* shift, I* new_rp,    \
+                                               I* new_ci, T* new_v);
+GKOC_DECL_L1(double, f64, int32_t, i32)
+GKOC_DECL_L1(double, f64, int64_t, i64)
+GKOC_DECL_L1(float, f32, int32_t, i32)
+GKOC_DECL_L1(float, f32, int64_t, i64)
+int gkoc_csr_missing_diagonal_shift_i32(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,
+                                        const int32_t* rp, const int32_t* ci, int32_t* shift,
+                                        int64_t* missing_host);
+int gkoc_csr_missing_diagonal_shift_i64(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,
+                                        const int64_t* rp, const int64_t* ci, int64_t* shift,
+                                        int64_t* missing_host);
+
 /* ------------------------------------------------- COO SpMV, CSR -> Hybrid
  * coo::{spmv, advanced_spmv, spmv2, advanced_spmv2} (core/matrix/coo_kernels.hpp:24-58;
  * reference/matrix/coo_kernels.cpp:33-100): c = A b, c = alpha A b + beta c,
