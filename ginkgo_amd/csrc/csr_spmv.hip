@@ -66,8 +66,8 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         reinterpret_cast<uintptr_t>(col_idxs) % (EV * sizeof(I)) == 0;
     if (nrhs >= 5 && n_seg < (int64_t(1) << 31)) {
         // 5+ right-hand sides: row-ordered gather from an LDS-staged segment, 8 columns per
-        // pass (L256, 8 columns: 5.0 ms against 6.8 ms for the ring kernel; for 2-4 columns
-        // the ring kernel below is faster, 1.7-2.8 ms against 3.4-3.6 ms)
+        // pass (L256, 8 columns: 5.0 ms against 5.1 - 6.5 ms for the ring kernel; for 2-4 columns
+        // the ring kernel below is faster, 1.5-2.3 ms against 3.4-3.6 ms)
         const dim3 g64(static_cast<unsigned>(n_seg));
 #define GKOC_LAUNCH_ROWMULTI(NR_)                                                        \
     csr_spmv_rowmulti_kernel<T, I, ADV, NR_><<<g64, block, 0, as_stream(s)>>>(           \
@@ -80,14 +80,20 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     if (nrhs >= 2 && vec_ok) {
         // several right-hand sides: one pass over the matrix per chunk of 2 or 4
         // columns (csr_spmv_multi.hpp); b is read as pairs of columns when its
-        // rows allow 2-element vector loads; 16 KB of LDS per wave in both cases
+        // rows allow 2-element vector loads.  The ring stays at 8 KB (512 entries of two, 256 of
+        // four columns; half as many entries per lane and load for four): with the 16 KB rings of
+        // round 1 the kernels took 129 VGPRs and ten waves per CU, now 81 and twenty - L256, 2 / 3 /
+        // 4 columns: 1.67 / 2.70 / 2.76 -> 1.49 / 2.18 / 2.23 ms.  (From four columns on the window
+        // of b that the stencil's planes span - 2 x 65536 rows x 32 B - no longer fits the 4 MB L2
+        // of an XCD: eight columns take 5.0 ms with every variant tried, this kernel in chunks of
+        // four or eight included.)
         const int b_vec_ok = reinterpret_cast<uintptr_t>(b) % (2 * sizeof(T)) == 0 && ldb % 2 == 0;
         if (nrhs == 2) {
-            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV, 2><<<grid, block, 0, as_stream(s)>>>(
+            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 2><<<grid, block, 0, as_stream(s)>>>(
                 n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
                 static_cast<int>(nrhs), alpha, beta, b_vec_ok);
         } else {
-            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 4><<<grid, block, 0, as_stream(s)>>>(
+            csr_spmv_multi_kernel<T, I, ADV, EV / 2, 1, RINGV / 4, 4><<<grid, block, 0, as_stream(s)>>>(
                 n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
                 static_cast<int>(nrhs), alpha, beta, b_vec_ok);
         }
