@@ -12,6 +12,11 @@
 //     simple_apply(b == r)      -> held as well (fast-path block layout, one column)
 //     compute_conj_dot(r, z)    -> ONE launch does all three and leaves ||r|| next to the workspace
 //     compute_norm2(r)          -> 8-byte copy of that value
+// The same for the modified Gram-Schmidt loop of Ginkgo's Gmres (core/solver/gmres.cpp:156-177), which
+// alternates h_i = <v_i, w> and w -= h_i v_i:
+//     sub_scaled(h_i, v_i, w)          -> held
+//     compute_conj_dot(v_{i+1}, w)     -> ONE launch of gkoc_x_gmres_mgs_step_*: the update and the
+//                                         next dot read w once (w bit-identical)
 // EVERY other entry into the backend (any kernel: stream_of(); synchronize, copies, frees, events,
 // timers: runtime.cpp) first launches what is held, unfused and in order, and forgets the cached
 // norm, so nothing outside this file can observe the difference.  What can: code that obtains raw
@@ -28,13 +33,16 @@ thread_local int deferred_state = 0;
 namespace {
 
 struct held_ops {
-    int stage = 0;   // 0 nothing, 1 step_2, 2 step_2 + simple_apply
+    int stage = 0;   // 0 nothing, 1 step_2, 2 step_2 + simple_apply, 3 sub_scaled (y -= alpha x)
     int vt = 0, it = 0;
     gkoc_stream_t s = nullptr;
     int64_t n = 0;
     void *x = nullptr, *r = nullptr;
     const void *p = nullptr, *q = nullptr, *beta = nullptr, *rho = nullptr;
     const uint8_t* stop = nullptr;
+    // stage 3: y -= alpha x
+    const void *ss_alpha = nullptr, *ss_x = nullptr;
+    void* ss_y = nullptr;
     int64_t num_blocks = 0;
     uint32_t max_bs = 0;
     gkoc_jacobi_scheme scheme{};
@@ -95,6 +103,19 @@ void launch_apply(const held_ops& h)
 #undef CASE
 }
 
+void launch_sub_scaled(const held_ops& h)
+{
+    if (h.vt == 0) {
+        GKOC_CALL(gkoc_dense_sub_scaled_f64(h.s, h.n, 1, static_cast<const double*>(h.ss_alpha), 1,
+                                            static_cast<const double*>(h.ss_x), 1,
+                                            static_cast<double*>(h.ss_y), 1));
+    } else {
+        GKOC_CALL(gkoc_dense_sub_scaled_f32(h.s, h.n, 1, static_cast<const float*>(h.ss_alpha), 1,
+                                            static_cast<const float*>(h.ss_x), 1,
+                                            static_cast<float*>(h.ss_y), 1));
+    }
+}
+
 }  // namespace
 
 void flush_deferred()
@@ -103,8 +124,27 @@ void flush_deferred()
     held.stage = 0;
     held.norm_of = nullptr;
     publish();
+    if (h.stage == 3) {
+        launch_sub_scaled(h);
+        return;
+    }
     if (h.stage >= 1) launch_step_2(h);
     if (h.stage >= 2) launch_apply(h);
+}
+
+bool hold_sub_scaled(int vt, gkoc_stream_t s, int64_t n, const void* alpha, const void* x, void* y)
+{
+    // (the caller has been through stream_of(): nothing is held at this point)
+    if (n <= 0 || x == y || !enabled()) return false;
+    held.stage = 3;
+    held.vt = vt;
+    held.s = s;
+    held.n = n;
+    held.ss_alpha = alpha;
+    held.ss_x = x;
+    held.ss_y = y;
+    publish();
+    return true;
 }
 
 bool hold_step_2(int vt, gkoc_stream_t s, int64_t n, void* x, void* r, const void* p, const void* q,
@@ -153,17 +193,50 @@ bool hold_jacobi_apply(int vt, int it, gkoc_stream_t s, int64_t num_blocks, uint
 bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y, void* result,
                array<char>& tmp)
 {
-    held_ops h;
-    {
-            if (held.stage != 2 || held.vt != vt || held.s != s || held.n != n || held.r != x || held.z != y ||
-            result == held.rho || result == held.beta) {
+    if (held.stage == 3) {
+        // w -= h_i v_i is held and this is <v_{i+1}, w> (either operand order): one pass over w
+        const void* other = y == held.ss_y ? x : (x == held.ss_y ? y : nullptr);
+        if (held.vt != vt || held.s != s || held.n != n || other == nullptr || other == held.ss_y ||
+            result == held.ss_alpha || result == held.ss_y) {
+            return false;   // the caller launches what is held, then its own kernel
+        }
+        const held_ops g = held;
+        held.stage = 0;
+        publish();
+        const size_t work = gkoc_x_workspace_bytes(n, vt == 0 ? 8 : 4);
+        bool fits = true;
+        try {
+            if (tmp.get_size() < work) tmp.resize_and_reset(work);
+        } catch (...) {
+            fits = false;
+        }
+        if (!fits) {
+            launch_sub_scaled(g);
             return false;
         }
-        h = held;
-        held.stage = 0;
-        held.norm_of = nullptr;
-        publish();
+        if (vt == 0) {
+            GKOC_CALL(gkoc_x_gmres_mgs_step_f64(g.s, g.n, static_cast<double*>(g.ss_y),
+                                                static_cast<const double*>(g.ss_x),
+                                                static_cast<const double*>(g.ss_alpha),
+                                                static_cast<const double*>(other),
+                                                static_cast<double*>(result), tmp.get_data(), work));
+        } else {
+            GKOC_CALL(gkoc_x_gmres_mgs_step_f32(g.s, g.n, static_cast<float*>(g.ss_y),
+                                                static_cast<const float*>(g.ss_x),
+                                                static_cast<const float*>(g.ss_alpha),
+                                                static_cast<const float*>(other),
+                                                static_cast<float*>(result), tmp.get_data(), work));
+        }
+        return true;
     }
+    if (held.stage != 2 || held.vt != vt || held.s != s || held.n != n || held.r != x || held.z != y ||
+        result == held.rho || result == held.beta) {
+        return false;
+    }
+    const held_ops h = held;
+    held.stage = 0;
+    held.norm_of = nullptr;
+    publish();
     // from here on nothing is held: resizing tmp may free memory, which comes back through flush_deferred()
     const size_t vsize = vt == 0 ? 8 : 4;
     const size_t work = (gkoc_x_workspace_bytes(n, vsize) + 15) / 16 * 16;

@@ -387,6 +387,12 @@ inline void* scratch(array<char>& tmp, int64_t n, int64_t nrhs, size_t& bytes)
     void sub_scaled<T, T>(exec_t exec, const matrix::Dense<T>* alpha,           \
                           const matrix::Dense<T>* x, matrix::Dense<T>* y)       \
     {                                                                           \
+        if (cols(x) == 1 && cols(alpha) == 1 && ld(x) == 1 && ld(y) == 1 &&     \
+            cdna4::hold_sub_scaled(cdna4::vt_of<T>(), stream_of(exec), rows(x), \
+                                   alpha->get_const_values(),                   \
+                                   x->get_const_values(), y->get_values())) {   \
+            return; /* Gmres' modified Gram-Schmidt: fused with the next dot */ \
+        }                                                                       \
         GKOC_CALL(gkoc_dense_sub_scaled_##TN(                                   \
             stream_of(exec), rows(x), cols(x), alpha->get_const_values(),       \
             cols(alpha), x->get_const_values(), ld(x), y->get_values(),         \

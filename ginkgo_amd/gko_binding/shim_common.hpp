@@ -55,6 +55,7 @@ bool hold_step_2(int vt, gkoc_stream_t s, int64_t n, void* x, void* r, const voi
 bool hold_jacobi_apply(int vt, int it, gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
                        gkoc_jacobi_scheme scheme, const void* block_ptrs, const void* blocks,
                        const void* b, int64_t n, void* z);
+bool hold_sub_scaled(int vt, gkoc_stream_t s, int64_t n, const void* alpha, const void* x, void* y);
 bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y, void* result,
                array<char>& tmp);
 bool cached_norm2(int vt, gkoc_stream_t s, int64_t n, const void* x, void* result);

@@ -22,6 +22,7 @@
 #include <ginkgo/core/matrix/sellp.hpp>
 #include <ginkgo/core/preconditioner/jacobi.hpp>
 #include <ginkgo/core/solver/cg.hpp>
+#include <ginkgo/core/solver/gmres.hpp>
 #include <ginkgo/core/stop/combined.hpp>
 #include <ginkgo/core/stop/iteration.hpp>
 #include <ginkgo/core/stop/residual_norm.hpp>
@@ -134,5 +135,28 @@ int main(int argc, char** argv)
     const auto iters = logger->get_num_iterations();
     std::printf("gko::solver::Cg + Jacobi(8)  %lu iterations, %8.4f ms/iteration, %8.1f it/s   [generate %.3f s]\n",
                 static_cast<unsigned long>(iters), s * 1e3 / iters, iters / s, gen_s);
+    {
+        // GMRES(30) + block-Jacobi(8), two restart cycles (modified Gram-Schmidt, Ginkgo's default)
+        auto gm = gko::solver::Gmres<vt>::build()
+                      .with_krylov_dim(30u)
+                      .with_criteria(gko::stop::Iteration::build().with_max_iters(60u),
+                                     gko::stop::ResidualNorm<vt>::build().with_reduction_factor(1e-30))
+                      .with_preconditioner(gko::preconditioner::Jacobi<vt, it>::build().with_max_block_size(8u))
+                      .on(hip)
+                      ->generate(a);
+        auto glog = gko::share(gko::log::Convergence<vt>::create());
+        gm->add_logger(glog);
+        x->fill(0.0);
+        gm->apply(rhs, x);   // warm-up
+        x->fill(0.0);
+        hip->synchronize();
+        auto g0 = std::chrono::steady_clock::now();
+        gm->apply(rhs, x);
+        hip->synchronize();
+        const double gs = std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
+        const auto gi = glog->get_num_iterations();
+        std::printf("gko::solver::Gmres(30) + Jacobi(8)  %lu iterations, %8.4f ms/iteration, %8.1f it/s\n",
+                    static_cast<unsigned long>(gi), gs * 1e3 / gi, gi / gs);
+    }
     return 0;
 }

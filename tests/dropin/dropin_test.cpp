@@ -320,6 +320,18 @@ int main(int argc, char** argv)
         }
         auto x_ref2 = solve(ref, a_ref, true, it_ref);
         auto x_hip2 = solve(hip, a_hip, true, it_hip);
+        {
+            // Gmres' modified Gram-Schmidt loop with the binding's fusion (w -= h_i v_i held and run
+            // with the next dot as one kernel) and without: w is bit-identical, the dots come from
+            // another summation tree
+            int it_unfused = 0;
+            gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 0);
+            auto x_unfused = solve(hip, a_hip, true, it_unfused);
+            gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 1);
+            CHECK(it_unfused == it_hip, "GMRES with fusion across calls: same iteration count as without");
+            CHECK(rel_err(x_hip2.get(), x_unfused.get()) < 1e-11,
+                  "GMRES with fusion across calls: same solution");
+        }
         std::cout << "GMRES(30)+Jacobi(8): iterations reference " << it_ref << ", hip " << it_hip << std::endl;
         CHECK(std::abs(it_ref - it_hip) <= 1, "GMRES iteration count matches reference");
         CHECK(rel_err(x_hip2.get(), x_ref2.get()) < 1e-8, "GMRES solution matches reference");
