@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void mark_nonzeros_kernel(int64_t nnz,
 {
     const int64_t stride = int64_t(gridDim.x) * 256;
     for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i <= nnz; i += stride) {
-        pos[i] = (i < nnz && vals[i] != T(0)) ? 1 : 0;
+        pos[i] = (i < nnz && vals[i] != zero_of<T>()) ? 1 : 0;
     }
 }
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void sum_runs_kernel(
     for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < nnz; i += stride) {
         const int64_t o = pos[i];
         if (pos[i + 1] != o) {
-            T sum = T(0);
+            T sum = zero_of<T>();
             int64_t k = i;
             do {
                 sum += vals[k];
@@ -189,12 +189,15 @@ extern "C" size_t gkoc_sort_row_major_workspace_bytes(int64_t nnz, size_t value_
                                                       size_t index_size)
 {
     if (nnz < 0) nnz = 0;
+    // value_size 4 / 8 / 16: float, double or complex<float>, complex<double>
     if (index_size == 8) {
-        return value_size == 8 ? sort_work_bytes<double, int64_t>(nnz)
-                               : sort_work_bytes<float, int64_t>(nnz);
+        return value_size == 16  ? sort_work_bytes<gkoc_c128, int64_t>(nnz)
+               : value_size == 8 ? sort_work_bytes<double, int64_t>(nnz)
+                                 : sort_work_bytes<float, int64_t>(nnz);
     }
-    return value_size == 8 ? sort_work_bytes<double, int32_t>(nnz)
-                           : sort_work_bytes<float, int32_t>(nnz);
+    return value_size == 16  ? sort_work_bytes<gkoc_c128, int32_t>(nnz)
+           : value_size == 8 ? sort_work_bytes<double, int32_t>(nnz)
+                             : sort_work_bytes<float, int32_t>(nnz);
 }
 
 extern "C" size_t gkoc_compact_workspace_bytes(int64_t nnz)
@@ -285,6 +288,11 @@ GKOC_DEF_ASSEMBLY(double, f64, int32_t, i32)
 GKOC_DEF_ASSEMBLY(double, f64, int64_t, i64)
 GKOC_DEF_ASSEMBLY(float, f32, int32_t, i32)
 GKOC_DEF_ASSEMBLY(float, f32, int64_t, i64)
+// complex values: moved as pairs, zero if both parts are, summed component-wise
+GKOC_DEF_ASSEMBLY(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_ASSEMBLY(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_ASSEMBLY(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_ASSEMBLY(gkoc_c64, c64, int64_t, i64)
 
 #define GKOC_DEF_COUNT_NZ(T, TN)                                                            \
     extern "C" int gkoc_remove_zeros_count_##TN(gkoc_stream_t s, int64_t nnz,               \
@@ -303,6 +311,8 @@ GKOC_DEF_ASSEMBLY(float, f32, int64_t, i64)
     }
 GKOC_DEF_COUNT_NZ(double, f64)
 GKOC_DEF_COUNT_NZ(float, f32)
+GKOC_DEF_COUNT_NZ(gkoc_c128, c128)
+GKOC_DEF_COUNT_NZ(gkoc_c64, c64)
 
 #define GKOC_DEF_COUNT_RUNS(I, IN)                                                          \
     extern "C" int gkoc_sum_duplicates_count_##IN(gkoc_stream_t s, int64_t nnz,             \

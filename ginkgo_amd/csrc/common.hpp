@@ -73,6 +73,43 @@ int64_t tune_value(int key);
 
 #ifdef __HIPCC__
 
+// ---- complex pairs (gkoc_c128 / gkoc_c64): what the data-movement kernels need ----------
+template <typename T>
+__host__ __device__ __forceinline__ T zero_of()
+{
+    return T(0);
+}
+template <>
+__host__ __device__ __forceinline__ gkoc_c128 zero_of<gkoc_c128>()
+{
+    return gkoc_c128{0.0, 0.0};
+}
+template <>
+__host__ __device__ __forceinline__ gkoc_c64 zero_of<gkoc_c64>()
+{
+    return gkoc_c64{0.0f, 0.0f};
+}
+__host__ __device__ __forceinline__ bool operator!=(const gkoc_c128& a, const gkoc_c128& b)
+{
+    return a.re != b.re || a.im != b.im;
+}
+__host__ __device__ __forceinline__ bool operator!=(const gkoc_c64& a, const gkoc_c64& b)
+{
+    return a.re != b.re || a.im != b.im;
+}
+__host__ __device__ __forceinline__ gkoc_c128& operator+=(gkoc_c128& a, const gkoc_c128& b)
+{
+    a.re += b.re;
+    a.im += b.im;
+    return a;
+}
+__host__ __device__ __forceinline__ gkoc_c64& operator+=(gkoc_c64& a, const gkoc_c64& b)
+{
+    a.re += b.re;
+    a.im += b.im;
+    return a;
+}
+
 // ---- wave / block reductions (64-lane) ---------------------------------
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v)

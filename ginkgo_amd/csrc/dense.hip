@@ -478,6 +478,102 @@ extern "C" size_t gkoc_reduction_workspace_bytes(int64_t, int64_t nrhs,
 GKOC_DEF_DENSE(double, f64)
 GKOC_DEF_DENSE(float, f32)
 
+// ---- complex pairs: fill, fill_seq, column 2-norms ------------------------------------------
+namespace gkoc {
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_pair_kernel(int64_t n, T* __restrict__ data, T value, int seq)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+        T v = value;
+        if (seq) {
+            v.re = decltype(v.re)(i);
+            v.im = 0;
+        }
+        data[i] = v;
+    }
+}
+
+// stage 1 of the column norms of a complex matrix: x as real numbers, ld in real elements
+template <typename R>
+__global__ __launch_bounds__(red_block) void cnorm2_stage1(int64_t rows, const R* __restrict__ x,
+                                                           int64_t ld, R* __restrict__ partial)
+{
+    __shared__ R lds[red_block / 64];
+    const int64_t col = blockIdx.y;
+    R acc = R(0);
+    const int64_t nthreads = int64_t(gridDim.x) * red_block;
+    for (int64_t i = int64_t(blockIdx.x) * red_block + threadIdx.x; i < rows; i += nthreads) {
+        const R re = x[i * ld + 2 * col], im = x[i * ld + 2 * col + 1];
+        acc += re * re + im * im;   // squared_norm(z) = real(conj(z) z)
+    }
+    const R r = block_sum<red_block>(acc, lds);
+    if (threadIdx.x == 0) partial[col * gridDim.x + blockIdx.x] = r;
+}
+
+template <typename R>
+int launch_cnorm2(gkoc_stream_t s, int64_t rows, int64_t cols, const R* x, int64_t ld_complex, R* result,
+                  void* work, size_t work_bytes)
+{
+    GKOC_REQUIRE(rows >= 0 && cols >= 0, GKOC_E_INVALID, "negative dimension");
+    if (cols == 0) return GKOC_OK;
+    GKOC_REQUIRE(result, GKOC_E_INVALID, "null result");
+    if (rows == 0) {
+        GKOC_HIP(hipMemsetAsync(result, 0, sizeof(R) * cols, as_stream(s)));
+        return GKOC_OK;
+    }
+    GKOC_REQUIRE(x && work_bytes >= gkoc_reduction_workspace_bytes(rows, cols, sizeof(R)), GKOC_E_WORKSPACE,
+                 "reduction workspace too small");
+    R* partial = static_cast<R*>(work);
+    int64_t nb = ceildiv(rows, int64_t(red_block) * 4);
+    const int64_t cap = max_partials / (cols < max_partials ? cols : max_partials);
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    cnorm2_stage1<R><<<dim3(unsigned(nb), unsigned(cols)), dim3(red_block), 0, as_stream(s)>>>(
+        rows, x, 2 * ld_complex, partial);
+    GKOC_LAUNCH_OK();
+    reduce_stage2<R, true><<<dim3(unsigned(cols)), dim3(red_block), 0, as_stream(s)>>>(int(nb), partial,
+                                                                                       result);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+}  // namespace
+}  // namespace gkoc
+
+#define GKOC_DEF_COMPLEX(T, TN, R)                                                                   \
+    extern "C" int gkoc_fill_array_##TN(gkoc_stream_t s, T* data, int64_t n, T value)                \
+    {                                                                                                \
+        if (n <= 0) return GKOC_OK;                                                                  \
+        int64_t nb = gkoc::ceildiv(n, 256);                                                          \
+        if (nb > gkoc::max_stream_blocks) nb = gkoc::max_stream_blocks;                              \
+        gkoc::fill_pair_kernel<T><<<dim3(unsigned(nb)), dim3(256), 0, gkoc::as_stream(s)>>>(n, data, \
+                                                                                            value, 0); \
+        GKOC_LAUNCH_OK();                                                                            \
+        return GKOC_OK;                                                                              \
+    }                                                                                                \
+    extern "C" int gkoc_fill_seq_array_##TN(gkoc_stream_t s, T* data, int64_t n)                     \
+    {                                                                                                \
+        if (n <= 0) return GKOC_OK;                                                                  \
+        int64_t nb = gkoc::ceildiv(n, 256);                                                          \
+        if (nb > gkoc::max_stream_blocks) nb = gkoc::max_stream_blocks;                              \
+        gkoc::fill_pair_kernel<T><<<dim3(unsigned(nb)), dim3(256), 0, gkoc::as_stream(s)>>>(         \
+            n, data, T{0, 0}, 1);                                                                    \
+        GKOC_LAUNCH_OK();                                                                            \
+        return GKOC_OK;                                                                              \
+    }                                                                                                \
+    extern "C" int gkoc_dense_compute_norm2_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,        \
+                                                 const T* x, int64_t ldx, R* result, void* work,     \
+                                                 size_t work_bytes)                                  \
+    {                                                                                                \
+        return gkoc::launch_cnorm2<R>(s, rows, cols, reinterpret_cast<const R*>(x), ldx, result,     \
+                                      work, work_bytes);                                             \
+    }
+GKOC_DEF_COMPLEX(gkoc_c128, c128, double)
+GKOC_DEF_COMPLEX(gkoc_c64, c64, float)
+
 extern "C" int gkoc_fill_array_f64(gkoc_stream_t s, double* data, int64_t n,
                                    double value)
 {

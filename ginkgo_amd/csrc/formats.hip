@@ -639,6 +639,26 @@ GKOC_DEF_ELL_MIXED(int64_t, i64)
         GKOC_LAUNCH_OK();                                                      \
         return GKOC_OK;                                                        \
     }
+#define GKOC_DEF_COMPLEX_MD(T, TN, I, IN)                                       \
+    extern "C" int gkoc_aos_to_soa_##TN##_##IN(gkoc_stream_t s, int64_t nnz,   \
+                                               const void* entries,            \
+                                               I* row_idxs, I* col_idxs,       \
+                                               T* vals)                        \
+    {                                                                          \
+        if (nnz <= 0) return GKOC_OK;                                          \
+        int64_t nb = ceildiv(nnz, 256);                                        \
+        if (nb > max_stream_blocks) nb = max_stream_blocks;                    \
+        aos_to_soa_kernel<T, I>                                                \
+            <<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(              \
+                nnz, static_cast<const md_entry<T, I>*>(entries), row_idxs,    \
+                col_idxs, vals);                                               \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }
+GKOC_DEF_COMPLEX_MD(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_COMPLEX_MD(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_COMPLEX_MD(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_COMPLEX_MD(gkoc_c64, c64, int64_t, i64)
 GKOC_DEF_MD(double, f64, int32_t, i32)
 GKOC_DEF_MD(double, f64, int64_t, i64)
 GKOC_DEF_MD(float, f32, int32_t, i32)

@@ -909,6 +909,40 @@ GKOC_DECL_XI(double, f64, int64_t, i64)
 GKOC_DECL_XI(float, f32, int32_t, i32)
 GKOC_DECL_XI(float, f32, int64_t, i64)
 
+/* ------------------------------------------------------ complex value types
+ * complex<double> / complex<float> (the C++ standard library types Ginkgo uses) as plain pairs.  Only what moves or measures complex
+ * data without multiplying it: device_matrix_data assembly (aos_to_soa / soa_to_aos / sort_row_major
+ * / remove_zeros / sum_duplicates: a value is zero if both parts are, sums are component-wise),
+ * fill_array / fill_seq_array, and the 2-norm of the columns of a complex Dense (what
+ * stop::ResidualNorm needs).  SpMV, BLAS-1 with complex scalars and the solvers are real-valued. */
+typedef struct { double re, im; } gkoc_c128;
+typedef struct { float re, im; } gkoc_c64;
+int gkoc_remove_zeros_count_c128(gkoc_stream_t s, int64_t nnz, const gkoc_c128* vals, void* work,
+                                 size_t work_bytes, int64_t* count_host);
+int gkoc_remove_zeros_count_c64(gkoc_stream_t s, int64_t nnz, const gkoc_c64* vals, void* work,
+                                size_t work_bytes, int64_t* count_host);
+int gkoc_fill_array_c128(gkoc_stream_t s, gkoc_c128* data, int64_t n, gkoc_c128 value);
+int gkoc_fill_array_c64(gkoc_stream_t s, gkoc_c64* data, int64_t n, gkoc_c64 value);
+int gkoc_fill_seq_array_c128(gkoc_stream_t s, gkoc_c128* data, int64_t n);
+int gkoc_fill_seq_array_c64(gkoc_stream_t s, gkoc_c64* data, int64_t n);
+/* result[j] = sqrt(sum_i |x(i, j)|^2); ldx in complex elements; work: gkoc_reduction_workspace_bytes
+ * (rows, cols, sizeof(real type)) */
+int gkoc_dense_compute_norm2_c128(gkoc_stream_t s, int64_t rows, int64_t cols, const gkoc_c128* x,
+                                  int64_t ldx, double* result, void* work, size_t work_bytes);
+int gkoc_dense_compute_norm2_c64(gkoc_stream_t s, int64_t rows, int64_t cols, const gkoc_c64* x,
+                                 int64_t ldx, float* result, void* work, size_t work_bytes);
+#define GKOC_DECL_COMPLEX_MD(T, TN, I, IN)                                                            \
+    int gkoc_aos_to_soa_##TN##_##IN(gkoc_stream_t s, int64_t nnz, const void* entries, I* row_idxs,   \
+                                    I* col_idxs, T* vals);
+GKOC_DECL_COMPLEX_MD(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_COMPLEX_MD(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_COMPLEX_MD(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_COMPLEX_MD(gkoc_c64, c64, int64_t, i64)
+GKOC_DECL_ASSEMBLY(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_ASSEMBLY(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_ASSEMBLY(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_ASSEMBLY(gkoc_c64, c64, int64_t, i64)
+
 /* ---------------------------------------------------- mixed-precision SpMV
  * csr::spmv / ell::spmv<MatrixValueType = float, InputValueType = OutputValueType = double>
  * (core/matrix/csr_kernels.hpp:34-52, ell_kernels.hpp:24-41; arithmetic_type = highest_precision =

@@ -58,5 +58,6 @@ def test_hot_path_suites_are_fully_green():
                   "stop_combined_kernels_hip", "base_executor_hip", "base_timer_hip",
                   "preconditioner_jacobi_kernels_hip", "matrix_ell_kernels_hip", "matrix_sellp_kernels_hip",
                   "matrix_coo_kernels_hip", "matrix_hybrid_kernels_hip", "solver_bicg_kernels_hip",
-                  "solver_minres_kernels_hip"):
+                  "solver_minres_kernels_hip", "base_device_matrix_data_kernels_hip",
+                  "components_fill_array_kernels_hip"):
         assert EXPECTED[suite]["known_failures"] == {}, suite
