@@ -8,7 +8,9 @@ Metric : CSR SpMV GB/s on the 27-pt 3-D Laplacian 256^3, fp64 values / int32
 Extras : CG iterations/s for configs[2] (CG + block-Jacobi(8), same matrix),
          `roofline` for the SpMV kernel (HIP events on the launch stream),
          `cpu_baseline` (the reference's OmpExecutor from oracle/_ref when
-         present, else the plain-C oracle) on a bounded sample.
+         present, else the plain-C oracle) on a bounded sample, and `ginkgo_api`:
+         the same SpMV and CG through the UNMODIFIED Ginkgo core on the drop-in
+         backend (gko::HipExecutor, tests/dropin/dropin_bench.cpp).
 N > 1  : the 256^3 problem is row-partitioned into z-slabs (strong scaling),
          one process per GPU, halo exchange + all-reduce over RCCL.
 
@@ -42,77 +44,135 @@ def _cpu_model():
     return "unknown"
 
 
-def _interleave_host_memory(on):
-    """The reference's arrays are first touched by ONE thread (the copy into the
-    executor), i.e. they would all sit on one NUMA node while OpenMP threads of every
-    socket read them.  set_mempolicy(MPOL_INTERLEAVE) over all nodes for the
-    allocations of the baseline spreads the pages instead.  Returns what was done."""
-    import ctypes as C
+def _physical_cores():
+    """(physical cores, hardware threads) of this host from /proc/cpuinfo"""
+    cores, threads, phys, core = set(), 0, None, None
     try:
-        nodes = [d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()]
-        n = len(nodes)
-        if n < 2:
-            return f"{max(n, 1)} NUMA node"
-        libc = C.CDLL(None, use_errno=True)
-        mask = C.c_ulong((1 << n) - 1 if on else 0)
-        mode = 3 if on else 0          # MPOL_INTERLEAVE / MPOL_DEFAULT
-        rc = libc.syscall(238, C.c_int(mode), C.byref(mask), C.c_ulong(64))   # SYS_set_mempolicy, x86-64
-        if rc != 0:
-            return f"{n} NUMA nodes, first touch by one thread (set_mempolicy refused)"
-        return f"pages interleaved over {n} NUMA nodes"
-    except Exception:
-        return "unknown"
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                threads += 1
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+                cores.add((phys, core))
+    except OSError:
+        pass
+    threads = threads or (os.cpu_count() or 1)
+    return (len(cores) or threads), threads
+
+
+def cpu_baseline_child(grid, budget_s):
+    """`bench.py --cpu-baseline-child GRID BUDGET` (a process of its own, so that the OpenMP
+    run-time reads OMP_NUM_THREADS / OMP_PROC_BIND / OMP_PLACES before anything else started it):
+    gko::OmpExecutor's Csr::apply of the unmodified reference (oracle/_ref) on the 27-pt grid^3
+    matrix, generated into the executor's arrays by the threads that multiply the rows later
+    (parallel first touch, oracle/ref_shim.cpp ref_omp_spmv_bench).  Prints one JSON object."""
+    import ctypes as C
+    from oracle import ref_shim
+    rl = ref_shim.lib()
+    rl.ref_omp_spmv_bench.restype = C.c_double
+    reps, thr, tri, setup = C.c_int64(0), C.c_int(0), C.c_double(0), C.c_double(0)
+    gbs = rl.ref_omp_spmv_bench(C.c_int64(grid), C.c_double(budget_s), C.c_int64(400), C.byref(reps),
+                                C.byref(thr), C.byref(tri), C.byref(setup))
+    print(json.dumps({"gbs": gbs, "reps": reps.value, "threads": thr.value, "triad_gbs": tri.value,
+                      "setup_s": setup.value}))
 
 
 def cpu_baseline(grid, csr_host=None, budget_s=12.0):
-    """Time the CPU reference on rank 0 on the SAME matrix as the GPU run
-    (`csr_host` = (row_ptrs, cols, vals) copied back from the device; generated
-    by the oracle when absent): 27-pt `grid`^3 CSR SpMV (fp64/int32).
-    kind = "reference": gko::OmpExecutor from the unmodified reference built
-    into oracle/_ref (strategy classical); kind = "port": the sequential plain-C
-    oracle.  The vectors are allocated once; only `apply` calls are timed."""
-    import ctypes as C
-    import numpy as np
-    from oracle import gko_oracle as o
-    numa = _interleave_host_memory(True)
-    own = csr_host is not None
-    if csr_host is None:
-        csr_host = o.stencil_csr(3, grid)
-    row_ptrs, cols, vals = csr_host
-    n, nnz = len(row_ptrs) - 1, len(vals)
-    b = np.random.default_rng(42).uniform(-1, 1, n).reshape(n, 1)
-    out = np.zeros((n, 1))
-    nbytes = spmv_algorithmic_bytes(n, n, nnz)
-    kind, cores, fn, keep = "port", 1, None, None
+    """The CPU figure beside the GPU one (a reported baseline, not the target): the reference's
+    OWN OpenMP backend - gko::OmpExecutor, omp/matrix/csr_kernels.cpp:86-225, strategy classical -
+    from the unmodified reference built into oracle/_ref, on the same 27-pt `grid`^3 fp64/int32
+    matrix, run the way an OpenMP code should be: one thread per PHYSICAL core, threads bound
+    (OMP_PROC_BIND=spread, OMP_PLACES=cores), every array first touched by the thread that reads it.
+    The STREAM triad of the same threads is reported next to it (`host_triad_gbs`): it is what this
+    host's memory gives an OpenMP loop, `frac_of_host_triad` says how much of that the reference's
+    SpMV reaches.  Falls back to the sequential plain-C oracle (kind "port") without oracle/_ref."""
+    import subprocess
+    cores, hw_threads = _physical_cores()
     try:
         from oracle import ref_shim
-        if ref_shim.available():
-            cores = os.cpu_count() or 1
-            keep = ref_shim.CsrHandle("omp", row_ptrs, cols, vals)
-            rl = ref_shim.lib()
-            pb, po = b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)
-            one = C.c_int64(1)
-            fn = lambda: rl.ref_csr_spmv(keep.h, pb, one, po, one, one)
-            kind = "reference"
+        have_ref = ref_shim.available()
     except Exception:
-        fn = None
-    if fn is None:
-        fn = lambda: o.csr_spmv(row_ptrs, cols, vals, b[:, 0])
-    fn()
-    t0 = time.perf_counter()
-    reps = 0
+        have_ref = False
+    if have_ref:
+        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="spread", OMP_PLACES="cores")
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child",
+                                str(grid), str(budget_s)], capture_output=True, text=True,
+                               timeout=600, env=env, cwd=ROOT)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+            r = json.loads(line)
+            return {"value": round(r["gbs"], 3), "unit": "GB/s", "cores": r["threads"],
+                    "kind": "reference (gko::OmpExecutor)", "cpu": _cpu_model(),
+                    "threads": f"{r['threads']} OpenMP threads = physical cores ({hw_threads} hardware "
+                               "threads on the host), OMP_PROC_BIND=spread OMP_PLACES=cores",
+                    "numa": "parallel first touch: matrix, b and c are written by the threads that "
+                            "read them (static schedule over rows)",
+                    "host_triad_gbs": round(r["triad_gbs"], 1),
+                    "frac_of_host_triad": round(r["gbs"] / r["triad_gbs"], 3) if r["triad_gbs"] else None,
+                    "sample": f"27-pt {grid}^3 CSR SpMV fp64/int32 (same generator as the GPU run, "
+                              f"index-exact), {r['reps']} reps in a {budget_s:.0f} s budget, "
+                              f"set-up {r['setup_s']:.1f} s"}
+        except Exception as e:      # noqa: BLE001 - the baseline must not take the bench line down
+            print(f"[bench] OpenMP baseline failed ({e}); falling back to the sequential port",
+                  file=sys.stderr)
+    import numpy as np
+    from oracle import gko_oracle as o
+    g = min(grid, 128)              # the sequential port: a bounded sample
+    row_ptrs, cols, vals = o.stencil_csr(3, g)
+    n, nnz = len(row_ptrs) - 1, len(vals)
+    b = np.random.default_rng(42).uniform(-1, 1, n)
+    nbytes = spmv_algorithmic_bytes(n, n, nnz)
+    o.csr_spmv(row_ptrs, cols, vals, b)
+    t0, reps = time.perf_counter(), 0
     while True:
-        fn()
+        o.csr_spmv(row_ptrs, cols, vals, b)
         reps += 1
         el = time.perf_counter() - t0
         if el > budget_s or reps >= 200:
             break
-    _interleave_host_memory(False)
-    return {"value": round(nbytes * reps / el / 1e9, 3), "unit": "GB/s",
-            "cores": cores, "kind": kind, "cpu": _cpu_model(), "numa": numa,
-            "sample": f"27-pt {grid}^3 CSR SpMV fp64/int32"
-                      f"{' (the matrix of the GPU run, copied to the host)' if own else ''}, "
-                      f"{reps} reps in {el:.1f} s"}
+    return {"value": round(nbytes * reps / el / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+            "cpu": _cpu_model(), "sample": f"27-pt {g}^3 CSR SpMV fp64/int32, sequential plain-C "
+                                           f"oracle, {reps} reps in {el:.1f} s"}
+
+
+def ginkgo_api_bench(grid, steps, cg_iters):
+    """The same two figures through the UNMODIFIED Ginkgo core on the drop-in backend
+    (gko::matrix::Csr::apply and gko::solver::Cg + gko::preconditioner::Jacobi(8) on
+    gko::HipExecutor, timed with gko::Timer; tests/dropin/dropin_bench.cpp): the north-star product
+    is the gko::Executor path, bench.py's own line goes Python -> ctypes -> C ABI.  A process of
+    its own; None when the binary has not been built (needs the reference's headers)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "dropin", "dropin_bench")
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    for fused in (0, 1):
+        env = dict(os.environ, GKOC_TUNE_5=str(fused))
+        try:
+            p = subprocess.run([exe, str(grid), str(steps), str(cg_iters), "--json"], capture_output=True,
+                               text=True, timeout=600, env=env, cwd=os.path.dirname(exe))
+            r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as e:      # noqa: BLE001
+            out["error"] = f"dropin_bench failed: {e}"
+            break
+        if fused == 0:
+            nbytes = spmv_algorithmic_bytes(r["n"], r["n"], r["nnz"])
+            out.update({"through": "gko::HipExecutor (drop-in libginkgo_hip.so), gko::Timer",
+                        "csr_apply_ms": r["csr_apply_ms"],
+                        "csr_apply_gbs": round(nbytes / r["csr_apply_ms"] / 1e6, 1),
+                        "frac": round(nbytes / r["csr_apply_ms"] / 1e6 / HBM_PEAK_GBS, 4),
+                        "cg_iters_per_s": r["cg_iters_per_s"], "cg_ms_per_iter": r["cg_ms_per_iter"],
+                        "cg_iterations": r["cg_iterations"], "memory_classes": r["memory_classes"],
+                        "fused_across_calls": False})
+        else:
+            out["with_fusion_across_calls"] = {"csr_apply_ms": r["csr_apply_ms"],
+                                               "cg_iters_per_s": r["cg_iters_per_s"],
+                                               "note": "opt-in GKOC_TUNE_DEFERRED_FUSION=1 "
+                                                       "(INTEGRATION.md): cg::step_2 + Jacobi + dots "
+                                                       "held and run as one kernel"}
+    return out
 
 
 def main():
@@ -124,9 +184,12 @@ def main():
     ap.add_argument("--cg-iters", type=int, default=100,
                     help="fixed CG iterations timed for the iters/s figure")
     ap.add_argument("--cpu-grid", type=int, default=0,
-                    help="0 = time the CPU reference on the GPU run's own matrix; "
-                         "otherwise a separately generated grid^3 matrix")
+                    help="0 = the CPU baseline runs the GPU run's grid; otherwise this one")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ginkgo-api", action="store_true",
+                    help="skip the second measurement through the unmodified Ginkgo core")
+    ap.add_argument("--cpu-baseline-child", nargs=2, metavar=("GRID", "BUDGET_S"), default=None,
+                    help=argparse.SUPPRESS)
     ap.add_argument("--pipe-cg", action="store_true",
                     help="distributed runs: also time PipeCg + block-Jacobi(8) (one all-reduce per "
                          "iteration) and report pipe_cg_iters_per_s next to cg_iters_per_s")
@@ -134,6 +197,8 @@ def main():
                     help="GKOC_ARENA mode of the library's allocator: 2 = memory-class regions "
                          "(default), 1 = plain chunks, 0 = one hipMalloc per array (DESIGN.md 3.2)")
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(int(args.cpu_baseline_child[0]), float(args.cpu_baseline_child[1]))
     if args.arena is not None:
         os.environ["GKOC_ARENA"] = str(args.arena)
 
@@ -216,6 +281,9 @@ def main():
         op = gd.DistributedStencil(ex, part, rank)
         nnz_global = op.global_nnz
         n_local = op.n_local
+        # known-answer test of every collective form the solvers use + their latencies here;
+        # wrong data raises on all ranks, a hang ends the job with a message (not a timeout)
+        comm_check = gd.comm_self_check(ex, op.comm, n_elems=grid * grid)
         if args.cg_iters > 0:
             t_setup = op.prepare_cg(args.cg_iters, barrier)
         x = op.random_vector(42)
@@ -223,6 +291,7 @@ def main():
         step = lambda: op.apply(x, y)
 
     total_bytes = spmv_algorithmic_bytes(n_global, n_global, nnz_global)
+    dist_profile = op.profile(x, y) if use_dist else None
 
     for _ in range(args.warmup):
         step()
@@ -310,6 +379,9 @@ def main():
                          "algorithmic_bytes_per_launch": int(per_gpu_bytes)},
         }
         out.update(cg)
+        if use_dist:
+            out["comm_check"] = comm_check
+            out["rank0_profile"] = dist_profile
         if not use_dist:
             import ctypes as C
             from ginkgo_amd import _lib
@@ -336,12 +408,13 @@ def main():
                 "used_gib": round(info.used_bytes / 2 ** 30, 2),
                 "spare_gib": round(info.spare_bytes / 2 ** 30, 2),
                 "granules_walked": info.granules_walked, "probe_launches": info.probes}
+        if not args.no_ginkgo_api and not use_dist:
+            torch.cuda.synchronize()
+            api = ginkgo_api_bench(grid, args.steps, args.cg_iters if args.cg_iters > 0 else 20)
+            if api is not None:
+                out["ginkgo_api"] = api
         if not args.no_cpu and not use_dist:
-            if args.cpu_grid:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_grid)
-            else:
-                host = tuple(t.cpu().numpy() for t in (a.row_ptrs, a.col_idxs, a.values))
-                out["cpu_baseline"] = cpu_baseline(grid, host)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_grid or grid)
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
     if use_dist:

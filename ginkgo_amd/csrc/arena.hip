@@ -32,13 +32,26 @@
 // Modes (gkoc_arena_configure or the environment variable GKOC_ARENA):
 //   0  off: hipMalloc / hipFree per request (the reference's behaviour)
 //   1  plain chunks from hipMalloc, first fit, no classes
-//   2  class regions as described (default)
+//   2  class regions as described (default ON THE PART THEY WERE MEASURED ON: gfx950 with at
+//      least 200 GiB of device memory in one partition; any other device starts in mode 1
+//      unless GKOC_ARENA=2 asks for it)
 // Chunk size of mode 1: GKOC_ARENA_CHUNK_MB (default 8192); granule size of mode 2:
 // GKOC_ARENA_GRANULE_MB (default and minimum 1024, power of two).  Fresh device
 // memory costs about 30 ms per GiB whoever asks for it (the driver clears it).
+// Bounds (a search must never eat the device): one search for a granule of a wanted class
+// creates at most GKOC_ARENA_MAX_WALK granules (default 24, i.e. < 1 s); if the FIRST THREE
+// classes do not show up within that bound the arena settles for the classes it has (two:
+// vectors apart from the matrix arrays; one: mode 1).  At most GKOC_ARENA_SPARE_MB (default
+// 8192) wait in the pools; gkoc_arena_trim() releases the pools AND the trailing free granules
+// of every region (their addresses are retired, never mapped again).
+// Peer access: granules are mapped for the owning device only; GKOC_ARENA_PEER_ACCESS=1 also
+// grants read/write access to every device that can reach it (hipDeviceCanAccessPeer).  Without
+// it arena memory must not be handed to P2P copies or hipIpc (RCCL stages user buffers through
+// its own, so the distributed path does not need it).
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <mutex>
 #include <vector>
 
@@ -121,6 +134,8 @@ struct span {
 
 struct region : span {
     size_t reserved = 0;                                    // bytes of virtual address space
+    size_t retired = 0;        // bytes of [0, size) whose granules went back to the driver (trim)
+    size_t tail_retired = 0;   // the part of them that sits at the very end of [0, size)
     std::vector<hipMemGenericAllocationHandle_t> granules;  // mapped back to back from base
 };
 
@@ -128,7 +143,7 @@ struct device_arena {
     std::vector<span*> small;     // hipMalloc'ed 64 MiB chunks (modes 1, 2)
     std::vector<span*> plain;     // mode 1 chunks
     // mode 2
-    bool ready = false, no_more_classes = false, failed = false;
+    bool ready = false, no_more_classes = false, failed = false, gated = false;
     int n_cls = 0;
     region reg[max_classes];
     // Virtual addresses for classifying candidates.  Every address is used for ONE
@@ -149,6 +164,9 @@ size_t g_chunk_bytes = 0;
 size_t g_granule_bytes = 0, g_spare_bytes = 0;
 int g_sync_free = 1;
 int g_verbose = 0;
+int g_peer_access = 0;
+int g_max_walk = 24;
+bool g_mode_from_env = false;
 device_arena g_arena[64];
 
 void read_env_locked()
@@ -156,6 +174,7 @@ void read_env_locked()
     if (g_mode >= 0) return;
     const char* m = std::getenv("GKOC_ARENA");
     g_mode = m ? std::atoi(m) : 2;
+    g_mode_from_env = m != nullptr;
     if (g_mode < 0 || g_mode > 2) g_mode = 2;
     const char* c = std::getenv("GKOC_ARENA_CHUNK_MB");
     const long long mb = c ? std::atoll(c) : 8192;
@@ -164,7 +183,12 @@ void read_env_locked()
     g_granule_bytes = GiB;
     while (gm && g_granule_bytes < size_t(std::atoll(gm)) * MiB) g_granule_bytes *= 2;
     const char* sp = std::getenv("GKOC_ARENA_SPARE_MB");
-    g_spare_bytes = size_t(sp ? std::atoll(sp) : 16384) * MiB;
+    g_spare_bytes = size_t(sp ? std::atoll(sp) : 8192) * MiB;
+    const char* pa = std::getenv("GKOC_ARENA_PEER_ACCESS");
+    g_peer_access = pa ? std::atoi(pa) : 0;
+    const char* lim = std::getenv("GKOC_ARENA_MAX_WALK");
+    g_max_walk = lim ? std::atoi(lim) : 24;
+    if (g_max_walk < 1) g_max_walk = 1;
     const char* sf = std::getenv("GKOC_ARENA_SYNC_FREE");
     g_sync_free = sf ? std::atoi(sf) : 1;
     const char* v = std::getenv("GKOC_ARENA_VERBOSE");
@@ -266,11 +290,29 @@ hipError_t map_granule(char* va, size_t bytes, hipMemGenericAllocationHandle_t h
 {
     hipError_t e = hipMemMap(va, bytes, 0, h, 0);
     if (e != hipSuccess) return e;
-    hipMemAccessDesc acc{};
-    acc.location.type = hipMemLocationTypeDevice;
-    acc.location.id = dev;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    e = hipMemSetAccess(va, bytes, &acc, 1);
+    std::vector<hipMemAccessDesc> acc(1);
+    acc[0].location.type = hipMemLocationTypeDevice;
+    acc[0].location.id = dev;
+    acc[0].flags = hipMemAccessFlagsProtReadWrite;
+    if (g_peer_access) {
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
+        for (int p = 0; p < n_dev; ++p) {
+            int can = 0;
+            if (p != dev && hipDeviceCanAccessPeer(&can, p, dev) == hipSuccess && can) {
+                hipMemAccessDesc d = acc[0];
+                d.location.id = p;
+                acc.push_back(d);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    e = hipMemSetAccess(va, bytes, acc.data(), acc.size());
+    if (e != hipSuccess && acc.size() > 1) {
+        // the peers refused: the owner alone, as without the option
+        (void)hipGetLastError();
+        e = hipMemSetAccess(va, bytes, acc.data(), 1);
+    }
     if (e != hipSuccess) (void)hipMemUnmap(va, bytes);
     return e;
 }
@@ -327,8 +369,7 @@ hipError_t acquire_granule(device_arena& A, int dev, int want, hipMemGenericAllo
     const hipMemAllocationProp prop = granule_prop(dev);
     std::vector<hipMemGenericAllocationHandle_t> unknown;
     hipError_t result = hipErrorOutOfMemory;
-    const char* lim = std::getenv("GKOC_ARENA_MAX_WALK");
-    const int max_walk = lim ? std::atoi(lim) : 256;
+    const int max_walk = g_max_walk;
     for (int step = 0; step < max_walk; ++step) {
         hipMemGenericAllocationHandle_t h;
         hipError_t e = hipMemCreate(&h, gr, &prop, 0);
@@ -415,6 +456,7 @@ hipError_t extend_region(device_arena& A, int dev, int cls, size_t count)
         R.granules.push_back(h);
         R.add_free(R.size, gr);
         R.size += gr;
+        R.tail_retired = 0;     // retired addresses in front of the new granule stay dead
     }
     return hipSuccess;
 }
@@ -427,7 +469,8 @@ hipError_t classes_init(device_arena& A, int dev)
     void* va = nullptr;
     size_t total = 0, free_b = 0;
     (void)hipMemGetInfo(&free_b, &total);
-    const size_t reserve = round_up(total ? total : size_t(288) * GiB, gr);
+    // twice the device memory: addresses retired by gkoc_arena_trim are never used again
+    const size_t reserve = 2 * round_up(total ? total : size_t(288) * GiB, gr);
     for (int k = 0; k < max_classes; ++k) {
         e = hipMemAddressReserve(&va, reserve, gr, nullptr, 0);
         if (e != hipSuccess) return e;
@@ -531,6 +574,19 @@ int arena_malloc(void** ptr, size_t bytes, int role)
     const size_t need = round_up(bytes, 256);
     if (bytes < small_limit) return span_list_malloc(A.small, small_chunk, ptr, need, 256);
     const size_t align = 2 * MiB;
+    if (g_mode == 2 && !A.gated) {
+        // the class layout was measured on MI355X (gfx950, 288 GiB, one memory partition): on
+        // anything else class regions are opt-in (GKOC_ARENA=2 / gkoc_arena_configure)
+        A.gated = true;
+        if (!g_mode_from_env) {
+            hipDeviceProp_t prop;
+            const bool known = hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                               std::string(prop.gcnArchName).rfind("gfx950", 0) == 0 &&
+                               prop.totalGlobalMem >= size_t(200) * GiB;
+            (void)hipGetLastError();
+            if (!known) A.failed = true;
+        }
+    }
     if (g_mode == 1 || A.failed) {
         return span_list_malloc(A.plain, g_chunk_bytes, ptr, need, align);
     }
@@ -561,7 +617,7 @@ int arena_malloc(void** ptr, size_t bytes, int role)
             if (need > A.max_large) A.max_large = need;
             return GKOC_OK;
         }
-        const size_t tail = R.free_tail();
+        const size_t tail = R.tail_retired ? 0 : R.free_tail();
         const size_t count = tail >= need + 2 * MiB ? 1 : (need + 2 * MiB - tail + gr - 1) / gr;
         if (extend_region(A, dev, cls, count) == hipSuccess) {
             if (void* p = R.take(need, align)) {
@@ -690,6 +746,7 @@ int gkoc_arena_configure(int mode, size_t chunk_bytes, int sync_on_free)
     std::lock_guard<std::mutex> g(g_mtx);
     read_env_locked();
     g_mode = mode;
+    g_mode_from_env = true;     // an explicit request counts like the environment variable
     if (chunk_bytes) g_chunk_bytes = round_up(chunk_bytes, 2 * MiB);
     g_sync_free = sync_on_free ? 1 : 0;
     return GKOC_OK;
@@ -719,10 +776,10 @@ int gkoc_arena_stats(gkoc_arena_info* info)
     for (int k = 0; k < A.n_cls; ++k) {
         const region& R = A.reg[k];
         info->num_chunks += int64_t(R.granules.size());
-        info->reserved_bytes += int64_t(R.size);
+        info->reserved_bytes += int64_t(R.size - R.retired);
         info->used_bytes += int64_t(R.in_use);
         info->num_allocations += int64_t(R.used.size());
-        info->class_reserved_bytes[k] = int64_t(R.size);
+        info->class_reserved_bytes[k] = int64_t(R.size - R.retired);
         info->class_used_bytes[k] = int64_t(R.in_use);
     }
     return GKOC_OK;
@@ -769,8 +826,33 @@ int gkoc_arena_trim(void)
         for (auto h : A.spare[k]) (void)hipMemRelease(h);
         A.spare[k].clear();
     }
-    // the granules mapped into the regions stay: their addresses could not be used
-    // for other memory again (stale translations, see device_arena::scratch)
+    // trailing free granules of the regions go back to the driver.  Their addresses are RETIRED
+    // (the range stays inside the region, neither free nor used: a later extension maps fresh
+    // addresses behind it), because an address that was unmapped must not be mapped to other
+    // memory again on this system (stale translations, see device_arena::scratch).
+    const size_t gr = granule_bytes();
+    for (int k = 0; k < A.n_cls; ++k) {
+        region& R = A.reg[k];
+        while (R.granules.size() > 1 && !R.free_list.empty()) {
+            const size_t live_end = R.size - R.tail_retired;
+            auto last = std::prev(R.free_list.end());
+            if (last->first + last->second != live_end || last->second < gr) break;
+            const size_t off = live_end - gr;
+            if (hipMemUnmap(R.base + off, gr) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            if (last->first < off) {
+                last->second = off - last->first;
+            } else {
+                R.free_list.erase(last);
+            }
+            (void)hipMemRelease(R.granules.back());
+            R.granules.pop_back();
+            R.tail_retired += gr;
+            R.retired += gr;
+        }
+    }
     return GKOC_OK;
 }
 

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void coo_row_ptrs_kernel(int64_t nnz,
             const int64_t i = i0 + e;
             if (i >= nnz) break;
             const int64_t cur = r[e + 1], pv = r[e];
-            if (cur < 0 || cur >= n_rows || (i > 0 && cur < pv)) {
+            // a predecessor outside [0, n_rows) makes this entry bad as well: its range of
+            // pointers would start before (or reach behind) the array
+            if (cur < 0 || cur >= n_rows || (i > 0 && (cur < pv || pv < 0 || pv >= n_rows))) {
                 bad = true;
                 continue;
             }

@@ -934,6 +934,22 @@ __global__ __launch_bounds__(256) void jacobi_step2_apply_kernel(
     }
 }
 
+// does the fused step_2 + apply have room for its two rows of partial sums in the workspace of
+// gkoc_x_workspace_bytes(n_rows, value_size)?  (blocks much smaller than max_block_size: no)
+inline bool step2_apply_fits(int64_t num_blocks, int64_t n_rows, gkoc_jacobi_scheme scheme,
+                             size_t value_size)
+{
+    const int64_t bo = scheme.block_offset;
+    if (!(bo >= 1 && bo <= 16 && (bo << scheme.group_power) == 64 && (bo & (bo - 1)) == 0)) return false;
+    if (num_blocks <= 0 || n_rows <= 0) return false;
+    const int64_t groups = ceildiv(num_blocks, int64_t(1) << scheme.group_power);
+    const int gpw = (bo * int64_t(value_size) >= 128) ? 1 : 2;
+    const int64_t nb = ceildiv(groups, 4 * gpw);
+    const int64_t total = int64_t(fused_workspace_bytes(n_rows, value_size) / value_size);
+    const int64_t pstride = (total - 2 * fold_chunks) / 2;
+    return nb <= pstride;
+}
+
 template <typename T, typename I>
 int launch_step2_apply(gkoc_stream_t s, int64_t num_blocks, int64_t n_rows, uint32_t max_bs,
                        gkoc_jacobi_scheme scheme, const I* block_ptrs, const T* blocks, T* x, T* r,
@@ -961,7 +977,8 @@ int launch_step2_apply(gkoc_stream_t s, int64_t num_blocks, int64_t n_rows, uint
     // groups of 8+ rows)
     const int64_t total = int64_t(fused_workspace_bytes(n_rows, sizeof(T)) / sizeof(T));
     const int64_t pstride = (total - 2 * fold_chunks) / 2;
-    GKOC_REQUIRE(nb <= pstride, GKOC_E_INVALID, "n_rows does not match the block count");
+    GKOC_REQUIRE(nb <= pstride, GKOC_E_WORKSPACE,
+                 "too many blocks for the workspace (ask gkoc_x_cg_step_2_jacobi_apply_fits first)");
     T* partial = static_cast<T*>(work);
     T* scratch = partial + 2 * pstride;
     const int64_t go = scheme.group_offset;
@@ -1303,6 +1320,12 @@ using namespace gkoc;
                                         block_ptrs, blocks, alpha, b, ldb,     \
                                         beta, x, ldx, nrhs);                   \
     }
+
+extern "C" int gkoc_x_cg_step_2_jacobi_apply_fits(int64_t num_blocks, int64_t n_rows,
+                                                  gkoc_jacobi_scheme scheme, size_t value_size)
+{
+    return gkoc::step2_apply_fits(num_blocks, n_rows, scheme, value_size) ? 1 : 0;
+}
 
 namespace gkoc {
 namespace {

@@ -166,7 +166,8 @@ class RcclComm(TorchComm):
 
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path = C.c_char_p(path.encode()) if os.path.exists(path) else None
-        agree(lib().gkoc_comm_load_rccl(path) == 0, "binding librccl")
+        agree(lib().gkoc_comm_load_rccl(path) == 0 and not _inject_failure("load", self.rank),
+              "binding librccl")
         ident = (C.c_uint8 * 128)()
         agree(self.rank != 0 or lib().gkoc_comm_unique_id(ident) == 0, "ncclGetUniqueId")
         if self.size > 1:
@@ -175,8 +176,13 @@ class RcclComm(TorchComm):
                            group=group)
             ident = (C.c_uint8 * 128)(*t.cpu().tolist())
         self._handle = C.c_void_p(0)
-        agree(lib().gkoc_comm_create(C.byref(self._handle), C.c_int(self.size), C.c_int(self.rank),
-                                     ident) == 0, "ncclCommInitRank")
+        # every rank enters ncclCommInitRank (it is collective); its outcome is agreed on after
+        rc = lib().gkoc_comm_create(C.byref(self._handle), C.c_int(self.size), C.c_int(self.rank), ident)
+        try:
+            agree(rc == 0 and not _inject_failure("init", self.rank), "ncclCommInitRank")
+        except GkoError:
+            self.close()
+            raise
         self._cnt = {}
 
     tapeable = True
@@ -238,36 +244,165 @@ class RcclComm(TorchComm):
         return None
 
 
+def _inject_failure(stage, rank):
+    """GKO_COMM_INJECT_FAIL="<rank>:<stage>" (tests only): make `stage` of the communicator
+    bring-up fail on `rank` so that the all-ranks-together fallback can be exercised"""
+    import os
+    spec = os.environ.get("GKO_COMM_INJECT_FAIL", "")
+    if not spec:
+        return False
+    r, _, st = spec.partition(":")
+    return st == stage and r.isdigit() and int(r) == rank
+
+
 def default_comm(exec_, group=None):
     """The communicator of the product path: RcclComm when the process group runs
     on RCCL and the library's own communicator comes up and passes a known-answer
     all-reduce on every rank; otherwise (gloo, one rank, GKO_COMM=torch, or any
-    failure - reported on stderr) torch.distributed itself."""
+    failure - reported on stderr) torch.distributed itself.  Every decision is taken
+    by ALL ranks together (a MIN all-reduce of "it worked here"), so a rank on which
+    the bring-up fails never leaves the others inside a collective.
+    GKO_COMM=rccl forces the attempt also when the process group is gloo (tests)."""
     import os
     import sys
     base = TorchComm(group)
-    if base.size == 1 or base.host_staging or os.environ.get("GKO_COMM", "") == "torch":
+    want = os.environ.get("GKO_COMM", "")
+    if base.size == 1 or want == "torch" or (base.host_staging and want != "rccl"):
         return base
     ok, comm = True, None
     try:
         comm = RcclComm(exec_, group)
         t = torch.full((2,), float(comm.rank + 1), dtype=torch.float64, device=exec_.device)
         comm.all_reduce_sum_(t)
-        want = comm.size * (comm.size + 1) / 2
-        ok = bool((t == want).all().item())
+        want_v = comm.size * (comm.size + 1) / 2
+        ok = bool((t == want_v).all().item()) and not _inject_failure("answer", base.rank)
     except Exception as e:        # noqa: BLE001 - any failure means "use torch.distributed"
-        print(f"[ginkgo_amd] RcclComm unavailable, using torch.distributed: {e}", file=sys.stderr)
+        print(f"[ginkgo_amd] rank {base.rank}: RcclComm unavailable, using torch.distributed: {e}",
+              file=sys.stderr)
         ok = False
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=exec_.device)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                        device=torch.device("cpu") if base.host_staging else exec_.device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     if bool(flag.item()):
         return comm
+    if ok:
+        print(f"[ginkgo_amd] rank {base.rank}: RcclComm is fine here but failed on another rank; "
+              "all ranks use torch.distributed", file=sys.stderr)
     if comm is not None:
         try:
             comm.close()
         except Exception:          # noqa: BLE001
             pass
     return base
+
+
+class _Watchdog:
+    """Abort the process (exit code 86) with a message when the guarded block does not finish
+    in `seconds`: a hung collective cannot be cancelled, but the launcher can be told WHY the
+    job died instead of being left to its own timeout."""
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what = seconds, what
+
+    def __enter__(self):
+        import os
+        import sys
+        import threading
+
+        def fire():
+            print(f"[ginkgo_amd] FATAL: {self.what} did not finish within {self.seconds} s "
+                  f"(rank {os.environ.get('RANK', '0')}): a collective hangs - check that every rank "
+                  "reached it, HSA_ENABLE_IPC_MODE_LEGACY=0, and the RCCL transport; "
+                  "GKO_COMM=torch selects torch.distributed for the data path", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(86)
+
+        self.t = threading.Timer(self.seconds, fire)
+        self.t.daemon = True
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def comm_self_check(exec_, comm, n_elems=65536, reps=20, timeout_s=180.0, dtype=torch.float64):
+    """Known-answer test of every collective form the solvers use, for ANY rank count, plus
+    their latencies on this machine: (1) the 2-value all-reduce of DistributedCg, (2) the
+    overlapped 3-value all-reduce of DistributedPipeCg (side stream, begin / end), (3) a
+    neighbour exchange of `n_elems` values with rank - 1 and rank + 1 - the halo pattern of a
+    slab partition - overlapped on the side stream when the communicator can.  Wrong data
+    raises GkoError on all ranks together; a hang ends the process through _Watchdog.
+    Returns {"all_reduce_us", "all_reduce_overlapped_us", "exchange_us", "communicator"}."""
+    import time
+    rank, size = comm.rank, comm.size
+    dev = exec_.device
+    side = torch.cuda.Stream(device=dev)
+    direct = getattr(comm, "direct", False)
+    res = {"communicator": type(comm).__name__, "ranks": size}
+    bad = []
+    with _Watchdog(timeout_s, "the communicator self-check"):
+        # (1) in-stream all-reduce
+        t = torch.empty(2, dtype=dtype, device=dev)
+        for k in range(reps + 1):
+            if k == 1:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            t[0] = rank + 1
+            t[1] = 0.5 * (rank + 1)
+            comm.all_reduce_sum_(t)
+        torch.cuda.synchronize(dev)
+        res["all_reduce_us"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+        tot = size * (size + 1) / 2
+        if t.cpu().tolist() != [tot, 0.5 * tot]:
+            bad.append(f"all-reduce gave {t.cpu().tolist()}, expected {[tot, 0.5 * tot]}")
+        # (2) overlapped all-reduce (PipeCg)
+        t3 = torch.empty(3, dtype=dtype, device=dev)
+        for k in range(reps + 1):
+            if k == 1:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            t3.fill_(rank + 1)
+            comm.all_reduce_begin(t3, side)
+            comm.all_reduce_end()
+        torch.cuda.synchronize(dev)
+        res["all_reduce_overlapped_us"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+        if t3.cpu().tolist() != [tot] * 3:
+            bad.append(f"overlapped all-reduce gave {t3.cpu().tolist()}, expected {[tot] * 3}")
+        # (3) neighbour exchange: the boundary planes of a slab partition
+        peers = [p for p in (rank - 1, rank + 1) if 0 <= p < size]
+        counts = [n_elems if p in peers else 0 for p in range(size)]
+        send = torch.empty(n_elems * len(peers), dtype=dtype, device=dev)
+        recv = torch.zeros(n_elems * len(peers), dtype=dtype, device=dev)
+        for i, p in enumerate(peers):
+            send[i * n_elems:(i + 1) * n_elems] = rank * 1000.0 + p     # "from rank to p"
+        for k in range(reps + 1):
+            if k == 1:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            if direct:
+                comm.exchange_begin(recv, send, counts, counts, side)
+                comm.exchange_end()
+            else:
+                comm.all_to_all_v(recv, send, counts, counts)
+        torch.cuda.synchronize(dev)
+        res["exchange_us"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+        res["exchange_bytes_per_peer"] = n_elems * send.element_size()
+        got = recv.cpu()
+        for i, p in enumerate(peers):
+            seg = got[i * n_elems:(i + 1) * n_elems]
+            if not bool((seg == p * 1000.0 + rank).all()):
+                bad.append(f"exchange: data from rank {p} is wrong (first value {float(seg[0])})")
+        # everybody learns whether anybody failed
+        flag = torch.tensor([0 if bad else 1], dtype=torch.int32,
+                            device=torch.device("cpu") if comm.host_staging else dev)
+        if size > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.group)
+    if not bool(flag.item()):
+        raise GkoError(f"communicator self-check failed (rank {rank}: "
+                       f"{'; '.join(bad) if bad else 'fine here, wrong on another rank'})")
+    return res
 
 
 class HipBackend:
@@ -1003,6 +1138,26 @@ class DistributedStencil:
 
     def apply(self, x, y):
         return self.matrix.apply(x, y)
+
+    def profile(self, x, y, steps=20):
+        """device time of the pieces of one distributed apply on THIS rank (events on the
+        executor's stream): the local block alone and the boundary rows alone; the bench
+        line carries them next to the whole apply so that an N-GPU record shows where the
+        time of a rank goes (the exchange latency is in comm_self_check's numbers)"""
+        m, be = self.matrix, self.backend
+        out = {}
+        for name, fn in (("local_spmv_ms", lambda: be.spmv(m.local, x, y)),
+                         ("boundary_rows_ms", lambda: be.rowlist_add(m.nl, m.recv_buf, y))):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            out[name] = round(e0.elapsed_time(e1) / steps, 4)
+        out["n_local_rows"], out["n_halo"], out["n_boundary_rows"] = m.n_local, m.n_halo, m.nl["n"]
+        return out
 
     def prepare_cg(self, iters, barrier):
         """set-up + one warm-up solve; returns the set-up time"""

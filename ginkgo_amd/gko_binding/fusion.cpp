@@ -175,7 +175,8 @@ bool hold_jacobi_apply(int vt, int it, gkoc_stream_t s, int64_t num_blocks, uint
     const bool fast_layout = bo >= 1 && bo <= 16 && (bo & (bo - 1)) == 0 &&
                              (bo << scheme.group_power) == 64 && int64_t(max_bs) <= bo;
     if (held.stage != 1 || held.vt != vt || held.s != s || held.n != n || held.r != b || z == b ||
-        z == held.x || num_blocks <= 0 || !fast_layout) {
+        z == held.x || num_blocks <= 0 || !fast_layout ||
+        !gkoc_x_cg_step_2_jacobi_apply_fits(num_blocks, n, scheme, vt == 0 ? 8 : 4)) {
         return false;
     }
     held.stage = 2;
@@ -252,17 +253,25 @@ bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y,
         return false;
     }
     char* norm_at = tmp.get_data() + work;
+    int rc = GKOC_E_NOT_SUPPORTED;
 #define CASE(VT, IT, T, I, TN, IN)                                                                    \
     if (h.vt == VT && h.it == IT) {                                                                   \
-        GKOC_CALL(gkoc_x_cg_step_2_jacobi_apply_##TN##_##IN(                                          \
+        rc = gkoc_x_cg_step_2_jacobi_apply_##TN##_##IN(                                               \
             h.s, h.num_blocks, h.n, h.max_bs, h.scheme, static_cast<const I*>(h.block_ptrs),          \
             static_cast<const T*>(h.blocks), static_cast<T*>(h.x), static_cast<T*>(h.r),              \
             static_cast<const T*>(h.p), static_cast<const T*>(h.q), static_cast<const T*>(h.beta),    \
             static_cast<const T*>(h.rho), h.stop, static_cast<T*>(h.z), static_cast<T*>(result),      \
-            reinterpret_cast<T*>(norm_at), 1, tmp.get_data(), work));                                 \
+            reinterpret_cast<T*>(norm_at), 1, tmp.get_data(), work);                                  \
     }
     GKOC_FUSION_TYPES(CASE)
 #undef CASE
+    if (rc != GKOC_OK) {
+        // the argument checks of the fused entry refuse BEFORE anything is launched: the held
+        // kernels run one by one and the caller computes its dot product itself
+        launch_step_2(h);
+        launch_apply(h);
+        return false;
+    }
     held.norm_of = h.r;
     held.norm_at = norm_at;
     held.norm_vt = vt;

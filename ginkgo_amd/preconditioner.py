@@ -257,10 +257,10 @@ class Jacobi(LinOp):
         gkoc_x_workspace_bytes: enough unless the blocks are tiny (< 2 rows on average)"""
         if not self.can_fuse_dot(b) or self.max_block_size == 1:
             return False
-        groups = -(-self.num_blocks // (1 << self.scheme.group_power))
-        per_wave = 1 if self.scheme.block_offset * b.values.element_size() >= 128 else 2
-        n_partials = -(-groups // (4 * per_wave))
-        return n_partials <= ((self.size[0] + 63) // 64 + 4096 - 1024) // 2
+        from ._lib import lib
+        return bool(lib().gkoc_x_cg_step_2_jacobi_apply_fits(
+            C.c_int64(self.num_blocks), C.c_int64(self.size[0]), self.scheme,
+            C.c_size_t(b.values.element_size())))
 
     def step_2_apply_dot(self, x, r, p, q, beta, rho, stop_status, z, rho_out, norm_out, take_sqrt,
                          work):

@@ -130,8 +130,11 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                       their own, then the CSR kernel */
 #define GKOC_TUNE_DEFERRED_FUSION 5 /* binding for the unmodified Ginkgo core (gko_binding/fusion.cpp): cg::step_2 and
                                       the block-Jacobi application after it are held until the next call and run
-                                      as one kernel with the dot product that follows (default 1); 0: every call
-                                      launches its own kernel */
+                                      as one kernel with the dot product that follows.  OPT-IN (default 0: every
+                                      call launches its own kernel when it returns, Ginkgo's contract): with 1, code
+                                      that launches its OWN kernels on exec->get_stream() with raw pointers of a
+                                      solver's internal vectors - e.g. a matrix-free preconditioner - would read
+                                      them before the held kernels ran ("Fusion across calls") */
 /* key 2: reserved (round-2 experiments with the CSR kernel's ring size / lane layout, all rejected) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
@@ -908,6 +911,12 @@ GKOC_DECL_XI(double, f64, int32_t, i32)
 GKOC_DECL_XI(double, f64, int64_t, i64)
 GKOC_DECL_XI(float, f32, int32_t, i32)
 GKOC_DECL_XI(float, f32, int64_t, i64)
+/* 1 if gkoc_x_cg_step_2_jacobi_apply_* can run on this block layout: fast-path scheme and room for
+ * its two rows of per-workgroup partial sums in gkoc_x_workspace_bytes(n_rows, value_size) (blocks
+ * much smaller than max_block_size produce more partials than the workspace holds); 0 otherwise -
+ * the caller then issues cg::step_2 and jacobi::simple_apply separately. */
+int gkoc_x_cg_step_2_jacobi_apply_fits(int64_t num_blocks, int64_t n_rows,
+                                       gkoc_jacobi_scheme scheme, size_t value_size);
 
 /* ------------------------------------------------------ complex value types
  * complex<double> / complex<float> (the C++ standard library types Ginkgo uses) as plain pairs.  Only what moves or measures complex

@@ -15,10 +15,40 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def fallback_case(mode):
+    """default_comm(): the bring-up of the library's RCCL communicator fails on ONE rank (injected
+    through GKO_COMM_INJECT_FAIL, stage named in the mode) - every rank must end up on
+    torch.distributed together, with no rank left inside a collective, and the result of a
+    distributed apply must be the usual one."""
+    import types
+    import ginkgo_amd.distributed as gd
+    rank, world = dist.get_rank(), dist.get_world_size()
+    os.environ["GKO_COMM"] = "rccl"                 # attempt it although the group is gloo
+    if mode.endswith("cpu"):
+        ex = types.SimpleNamespace(device=torch.device("cpu"), stream=None)
+    else:
+        import ginkgo_amd as g
+        ex = g.Cdna4Executor.create(0)
+    comm = gd.default_comm(ex)
+    assert type(comm) is gd.TorchComm, type(comm)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    comm.all_reduce_sum_(t)
+    assert float(t) == world * (world + 1) / 2
+    if not mode.endswith("cpu"):
+        chk = gd.comm_self_check(ex, comm, n_elems=1000, reps=2)
+        assert chk["communicator"] == "TorchComm" and chk["ranks"] == world
+    dist.barrier()
+    if rank == 0:
+        print(f"dist_worker OK mode={mode} world={world}")
+    dist.destroy_process_group()
+
+
 def main():
     mode, grid = sys.argv[1], int(sys.argv[2])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    if mode.startswith("fallback"):
+        return fallback_case(mode)
     from oracle import gko_oracle as o
     import ginkgo_amd.distributed as gd
 

@@ -5,9 +5,12 @@
 // Ginkgo's device arrays by the backend's generator (assembling 449 M entries
 // through matrix_data on the host would take minutes); everything after that is
 // Ginkgo code calling gko::kernels::hip::* symbols.
-//   dropin_bench [grid=256] [reps=50] [cg_iters=100]
+//   dropin_bench [grid=256] [reps=50] [cg_iters=100] [--json]
+// --json: only Csr::apply and Cg + Jacobi(8), and one JSON object as the last line (bench.py's
+// `ginkgo_api` object reads it)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <random>
 #include <vector>
@@ -55,6 +58,7 @@ int main(int argc, char** argv)
     const gko::int64 grid = argc > 1 ? std::atoll(argv[1]) : 256;
     const int reps = argc > 2 ? std::atoi(argv[2]) : 50;
     const int cg_iters = argc > 3 ? std::atoi(argv[3]) : 100;
+    const bool json = argc > 4 && std::strcmp(argv[4], "--json") == 0;
     auto ref = gko::ReferenceExecutor::create();
     auto hip = gko::HipExecutor::create(0, ref);
     const gko::size_type n = grid * grid * grid;
@@ -79,9 +83,9 @@ int main(int argc, char** argv)
     auto b = gko::clone(hip, b_host);
     auto x = Dense::create(hip, gko::dim<2>{n, 1});
 
+    int cv = -1, cc = -1, cr = -1, cb = -1, cx = -1;
     {
         // where the backend's allocator (HipAllocator -> csrc/arena.hip) put Ginkgo's arrays
-        int cv = -1, cc = -1, cr = -1, cb = -1, cx = -1;
         gkoc_arena_class_of(a->get_const_values(), &cv);
         gkoc_arena_class_of(a->get_const_col_idxs(), &cc);
         gkoc_arena_class_of(a->get_const_row_ptrs(), &cr);
@@ -91,9 +95,10 @@ int main(int argc, char** argv)
     }
     const double bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     double ms = time_ms(hip, reps, [&] { a->apply(b, x); });
+    const double csr_ms = ms;
     std::printf("gko::matrix::Csr::apply      %8.4f ms  %8.1f GB/s  (%.1f %% of 8 TB/s)\n", ms,
                 bytes / ms / 1e6, bytes / ms / 1e6 / 80.0);
-    {
+    if (!json) {
         auto ell = gko::matrix::Ell<vt, it>::create(hip);
         double conv = time_ms(hip, 2, [&] { a->convert_to(ell); });
         ms = time_ms(hip, reps, [&] { ell->apply(b, x); });
@@ -101,7 +106,7 @@ int main(int argc, char** argv)
         std::printf("gko::matrix::Ell::apply      %8.4f ms  %8.1f GB/s  (%.1f %%)   [Csr->Ell convert_to %.2f ms]\n", ms,
                     eb / ms / 1e6, eb / ms / 1e6 / 80.0, conv);
     }
-    {
+    if (!json) {
         auto sp = gko::matrix::Sellp<vt, it>::create(hip);
         double conv = time_ms(hip, 2, [&] { a->convert_to(sp); });
         ms = time_ms(hip, reps, [&] { sp->apply(b, x); });
@@ -135,6 +140,18 @@ int main(int argc, char** argv)
     const auto iters = logger->get_num_iterations();
     std::printf("gko::solver::Cg + Jacobi(8)  %lu iterations, %8.4f ms/iteration, %8.1f it/s   [generate %.3f s]\n",
                 static_cast<unsigned long>(iters), s * 1e3 / iters, iters / s, gen_s);
+    if (json) {
+        int64_t fused = 0;
+        gkoc_tune_get(GKOC_TUNE_DEFERRED_FUSION, &fused);
+        std::printf("{\"n\": %lu, \"nnz\": %lld, \"csr_apply_ms\": %.5f, \"cg_iterations\": %lu, "
+                    "\"cg_ms_per_iter\": %.5f, \"cg_iters_per_s\": %.2f, \"fused_across_calls\": %d, "
+                    "\"memory_classes\": {\"values\": %d, \"col_idxs\": %d, \"row_ptrs\": %d, \"b\": %d, "
+                    "\"x\": %d}}\n",
+                    static_cast<unsigned long>(n), static_cast<long long>(nnz), csr_ms,
+                    static_cast<unsigned long>(iters), s * 1e3 / iters, iters / s, int(fused), cv, cc, cr, cb,
+                    cx);
+        return 0;
+    }
     {
         // GMRES(30) + block-Jacobi(8), two restart cycles (modified Gram-Schmidt, Ginkgo's default)
         auto gm = gko::solver::Gmres<vt>::build()

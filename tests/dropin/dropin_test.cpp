@@ -288,7 +288,7 @@ int main(int argc, char** argv)
                 if (h) solver->add_logger(h);
                 solver->apply(rhs, x);
                 iters = static_cast<int>(conv->get_num_iterations());
-                gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 1);
+                gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 0);   // the default: opt-in
                 // the criterion's own ||r|| (with the mechanism on: the value the fused kernel left behind)
                 const double tau = gko::clone(ref, gko::as<Dense>(conv->get_residual_norm()))->at(0, 0);
                 return std::make_pair(gko::clone(ref, x), tau);
@@ -318,18 +318,65 @@ int main(int argc, char** argv)
                       std::abs(plain.second - off.second) <= 1e-10 * off.second,
                   "criterion's ||r|| (left behind by the fused kernel) is the norm of r on the device");
         }
+        {
+            // User-supplied block pointers whose blocks are small against max_block_size on a system
+            // large enough that the fused step_2 + apply kernel would need more partial sums than
+            // its workspace holds (64^3 rows, blocks of 4, max_block_size 16): the binding must
+            // decline to hold the pair (gkoc_x_cg_step_2_jacobi_apply_fits) - same solve with the
+            // mechanism on and off, no exception.
+            auto big = generate_stencil<vt, it>("27pt", gko::size_type{64} * 64 * 64);
+            auto ab_ref = gko::share(Csr::create(ref));
+            ab_ref->read(big.first);
+            auto ab = gko::share(gko::clone(hip, ab_ref));
+            const auto nb_rows = ab->get_size()[0];
+            gko::array<it> ptrs(ref, nb_rows / 4 + 1);
+            for (gko::size_type i = 0; i <= nb_rows / 4; ++i) ptrs.get_data()[i] = static_cast<it>(4 * i);
+            auto run_small = [&](int fused, int& iters) {
+                gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, fused);
+                auto rhs = Dense::create(hip, gko::dim<2>{nb_rows, 1});
+                rhs->fill(1.0);
+                auto x = Dense::create(hip, gko::dim<2>{nb_rows, 1});
+                x->fill(0.0);
+                auto conv = gko::share(gko::log::Convergence<vt>::create());
+                auto solver =
+                    gko::solver::Cg<vt>::build()
+                        .with_criteria(gko::stop::Iteration::build().with_max_iters(60u),
+                                       gko::stop::ResidualNorm<vt>::build().with_reduction_factor(1e-8))
+                        .with_preconditioner(gko::preconditioner::Jacobi<vt, it>::build()
+                                                 .with_max_block_size(16u)
+                                                 .with_block_pointers(ptrs))
+                        .on(hip)
+                        ->generate(ab);
+                solver->add_logger(conv);
+                bool threw = false;
+                try {
+                    solver->apply(rhs, x);
+                } catch (const std::exception& e) {
+                    std::cout << "  exception: " << e.what() << std::endl;
+                    threw = true;
+                }
+                gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 0);
+                iters = threw ? -1 : static_cast<int>(conv->get_num_iterations());
+                return gko::clone(ref, x);
+            };
+            int it_f = 0, it_u = 0;
+            auto xf = run_small(1, it_f);
+            auto xu = run_small(0, it_u);
+            CHECK(it_f > 0 && it_f == it_u, "CG with small user blocks (fused kernel has no room): runs, same iterations");
+            CHECK(rel_err(xf.get(), xu.get()) < 1e-12, "CG with small user blocks: same solution with fusion on and off");
+        }
         auto x_ref2 = solve(ref, a_ref, true, it_ref);
         auto x_hip2 = solve(hip, a_hip, true, it_hip);
         {
             // Gmres' modified Gram-Schmidt loop with the binding's fusion (w -= h_i v_i held and run
             // with the next dot as one kernel) and without: w is bit-identical, the dots come from
             // another summation tree
-            int it_unfused = 0;
-            gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 0);
-            auto x_unfused = solve(hip, a_hip, true, it_unfused);
+            int it_fused = 0;
             gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 1);
-            CHECK(it_unfused == it_hip, "GMRES with fusion across calls: same iteration count as without");
-            CHECK(rel_err(x_hip2.get(), x_unfused.get()) < 1e-11,
+            auto x_fused = solve(hip, a_hip, true, it_fused);
+            gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 0);
+            CHECK(it_fused == it_hip, "GMRES with fusion across calls: same iteration count as without");
+            CHECK(rel_err(x_hip2.get(), x_fused.get()) < 1e-11,
                   "GMRES with fusion across calls: same solution");
         }
         std::cout << "GMRES(30)+Jacobi(8): iterations reference " << it_ref << ", hip " << it_hip << std::endl;

@@ -20,12 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(mode, world, grid, timeout=600):
+def _launch(mode, world, grid, timeout=600, extra_env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(grid)]
-    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     for attempt in range(2):       # one retry: the rendezvous port can race
         cmd[cmd.index("--master-port") + 1] = str(_free_port())
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
@@ -46,14 +46,71 @@ def test_partition_helpers():
         gd.Partition([0, 5, 3])
 
 
-@pytest.mark.parametrize("world,grid", [(2, 8), (3, 9)])
+# (8, 8): one plane per rank - every row of an interior rank is a boundary row with halo from
+# both sides; (8, 16): the 8-rank slab partition of the bench; (5, 12): uneven slabs (3,3,2,2,2)
+@pytest.mark.parametrize("world,grid", [(2, 8), (3, 9), (8, 8), (8, 16), (5, 12)])
 def test_distributed_cpu_gloo(world, grid):
     _launch("cpu", world, grid)
+
+
+@pytest.mark.parametrize("stage", ["load", "init"])
+def test_default_comm_fallback_is_taken_by_all_ranks_cpu(stage):
+    """a failure of the RCCL bring-up injected on rank 1 of 3: all ranks fall back together"""
+    _launch("fallback-cpu", 3, 0, extra_env={"GKO_COMM_INJECT_FAIL": f"1:{stage}"})
 
 
 @pytest.mark.gpu
 def test_distributed_gpu_two_ranks_one_device():
     _launch("gpu", 2, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [32, 64])
+def test_distributed_gpu_eight_ranks_one_device(grid):
+    """world_size = 8 (BASELINE configs[3]'s rank count): eight processes sharing cuda:0,
+    HIP kernels, exchange staged through gloo.  32^3 = 4-plane slabs, 64^3 = 8-plane slabs;
+    DistributedCg / PipeCg / Gmres against the single-domain oracle (iterations +-1, solution
+    1e-8, boundary rows 1e-14, interior rows bit-exact) - tests/dist_worker.py"""
+    _launch("gpu", 8, grid, timeout=1500)
+
+
+@pytest.mark.gpu
+def test_default_comm_fallback_is_taken_by_all_ranks_gpu():
+    """the same injection with the real executor (2 ranks on cuda:0), followed by the
+    communicator self-check of bench.py on the fallback communicator"""
+    _launch("fallback-gpu", 2, 0, extra_env={"GKO_COMM_INJECT_FAIL": "1:load"})
+
+
+def _bench(world, args, env_extra, timeout=1500):
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world)] + args
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n--- stderr ---\n" + p.stderr[-12000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-3000:]          # rank 0 only, one line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_command_path_with_eight_ranks():
+    """the driver's exact multi-GPU command (torch.distributed.run ... bench.py --gpus 8 --steps K
+    --warmup W) on one GPU: GKO_BENCH_BACKEND=gloo lets the 8 ranks share cuda:0.  Process group,
+    SlabPartition(.., 8), communicator self-check, max-over-ranks timing, JSON from rank 0 only."""
+    d = _bench(8, ["--steps", "3", "--warmup", "1", "--grid", "64", "--cg-iters", "20", "--pipe-cg"],
+               {"GKO_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["partition"] == "8 z-slab(s)"
+    n, nnz = 64 ** 3, (3 * 64 - 2) ** 3
+    assert f"n={n}, nnz={nnz}" in d["config"]["workload"]
+    assert d["cg_iterations"] == 20 and d["pipe_cg_iterations"] == 20 and d["cg_iters_per_s"] > 0
+    assert d["comm_check"]["ranks"] == 8 and d["comm_check"]["exchange_us"] > 0
+    prof = d["rank0_profile"]
+    assert prof["n_local_rows"] == n // 8 and prof["n_halo"] == 64 * 64      # rank 0: one neighbour
+    assert prof["local_spmv_ms"] > 0
 
 
 @pytest.mark.gpu

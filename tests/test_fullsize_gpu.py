@@ -187,6 +187,80 @@ def test_cg_block_jacobi_full_size(gexec, big):
     assert np.abs(x3 - x3.transpose(2, 1, 0)).max() <= 1e-7 * scale
 
 
+def test_cg_and_gmres_full_size_against_the_reference_omp_executor(gexec, big):
+    """configs[2] at the size BASELINE names, against GINKGO ITSELF: the unmodified reference
+    (oracle/_ref, gko::OmpExecutor on the box's host cores - the sequential ReferenceExecutor
+    would need half an hour) solves the same system with solver::Cg + Jacobi(8), rhs = 1,
+    x0 = 0, ResidualNorm(1e-10, rhs_norm) (core/solver/cg.cpp:93-181,
+    test/solver/cg_kernels.cpp:106-191).  Asserted: iteration count +-1, solution to 1e-9,
+    the residual norm after 1 / 10 / 100 iterations and at the end to 1e-10 relative... of the
+    FIRST residual (absolute differences of the history are bounded by 1e-10 ||r_0||; the
+    relative agreement at iteration 1 / 10 is ~1e-14).  Then Gmres(30) + Jacobi(8), a fixed 60
+    iterations (two restarts), solution and residual norm.  About 2-3 minutes of host time;
+    GKO_SKIP_SLOW=1 skips it."""
+    import os
+    if os.environ.get("GKO_SKIP_SLOW") == "1":
+        pytest.skip("GKO_SKIP_SLOW=1")
+    from oracle import ref_shim
+    if not ref_shim.available():
+        pytest.skip("oracle/_ref (the compiled reference) is not in the tree")
+    g, a = big
+    rp, ci, v = (t.cpu().numpy() for t in (a.row_ptrs, a.col_idxs, a.values))
+    ref = ref_shim.CsrHandle("omp", rp, ci, v)
+    ones = np.ones(N)
+
+    def hip_cg(max_iters):
+        x = g.Dense.from_numpy(gexec, np.zeros(N))
+        s = (g.Cg.build()
+             .with_criteria(g.stop.Iteration.build().with_max_iters(max_iters),
+                            g.stop.ResidualNorm.build().with_reduction_factor(1e-10))
+             .with_preconditioner(g.Jacobi.build().with_max_block_size(8))
+             .on(gexec).generate(a))
+        s.apply(g.Dense.from_numpy(gexec, ones), x)
+        return x, s
+
+    r0 = float(np.sqrt(N))                       # x0 = 0: r_0 = b, ||b|| = 4096
+    # --- residual history at fixed iteration counts (the criterion never fires before 100)
+    for k in (1, 10, 100):
+        x, s = hip_cg(k)
+        xr, it_r, rn_r = ref.cg_solve(ones, max_iters=k, reduction=1e-10, precond_block_size=8)
+        assert s.num_iterations == it_r == k
+        rn_h = float(np.ravel(s.residual_norm)[0])
+        assert abs(rn_h - rn_r) <= 1e-10 * r0, (k, rn_h, rn_r)
+        assert abs(rn_h - rn_r) <= 1e-9 * rn_r, (k, rn_h, rn_r)
+        xh = x.to_numpy()[:, 0]
+        assert np.linalg.norm(xh - xr) <= 1e-11 * np.linalg.norm(xr), k
+    # --- the full solve
+    x, s = hip_cg(3000)
+    xr, it_r, rn_r = ref.cg_solve(ones, max_iters=3000, reduction=1e-10, precond_block_size=8)
+    assert s.has_converged and abs(s.num_iterations - it_r) <= 1, (s.num_iterations, it_r)
+    xh = x.to_numpy()[:, 0]
+    assert np.linalg.norm(xh - xr) <= 1e-9 * np.linalg.norm(xr)
+    rn_h = float(np.ravel(s.residual_norm)[0])
+    assert rn_h <= 1e-10 * r0 and rn_r <= 1e-10 * r0
+    if s.num_iterations == it_r:
+        assert abs(rn_h - rn_r) <= 1e-10 * r0
+    print(f"CG + Jacobi(8) on 256^3: hip {s.num_iterations} iterations / reference (omp) {it_r}; "
+          f"final ||r|| {rn_h:.6e} / {rn_r:.6e}; "
+          f"||x_hip - x_ref|| / ||x_ref|| = {np.linalg.norm(xh - xr) / np.linalg.norm(xr):.2e}")
+    del x, xh, xr
+    # --- Gmres(30) + Jacobi(8), 60 iterations (gmres.cpp:321-621; MGS, the default)
+    xg = g.Dense.from_numpy(gexec, np.zeros(N))
+    sg = (g.Gmres.build().with_krylov_dim(30)
+          .with_criteria(g.stop.Iteration.build().with_max_iters(60),
+                         g.stop.ResidualNorm.build().with_reduction_factor(1e-30))
+          .with_preconditioner(g.Jacobi.build().with_max_block_size(8))
+          .on(gexec).generate(a))
+    sg.apply(g.Dense.from_numpy(gexec, ones), xg)
+    xr, it_r, rn_r = ref.gmres_solve(ones, krylov_dim=30, ortho="mgs", max_iters=60, reduction=1e-30,
+                                     precond_block_size=8)
+    assert sg.num_iterations == it_r == 60
+    xh = xg.to_numpy()[:, 0]
+    assert np.linalg.norm(xh - xr) <= 1e-9 * np.linalg.norm(xr)
+    print(f"Gmres(30) + Jacobi(8) on 256^3, 60 iterations: "
+          f"||x_hip - x_ref|| / ||x_ref|| = {np.linalg.norm(xh - xr) / np.linalg.norm(xr):.2e}")
+
+
 def test_int64_indices_beyond_2_31_nonzeros(gexec):
     """27-pt 512^3 on ONE GPU with int64 indices: n = 134 217 728, nnz = 1534^3 =
     3 609 741 304 > 2^31 (58 GB of matrix).  Row sums and a linear field have

@@ -272,6 +272,24 @@ def _ref():
     return ref_shim
 
 
+@pytest.mark.parametrize("grid", [1, 2, 3, 7, 16])
+def test_cpu_baseline_generator_is_the_benchmark_matrix(oracle, grid):
+    """bench.py's cpu_baseline lets the OpenMP threads generate the 27-pt matrix straight into the
+    OmpExecutor's arrays (parallel first touch, oracle/ref_shim.cpp): the same row pointers, column
+    indices and values as the oracle's / the reference's generator"""
+    import ctypes as C
+    rl = _ref().lib()
+    rl.ref_stencil27_nnz.restype = C.c_int64
+    rl.ref_stencil27_csr.restype = C.c_int64
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    nnz = rl.ref_stencil27_nnz(C.c_int64(grid))
+    assert nnz == len(v)
+    rp2, ci2, v2 = np.zeros(grid ** 3 + 1, np.int32), np.zeros(nnz, np.int32), np.zeros(nnz)
+    assert rl.ref_stencil27_csr(C.c_int64(grid), rp2.ctypes.data_as(C.c_void_p),
+                                ci2.ctypes.data_as(C.c_void_p), v2.ctypes.data_as(C.c_void_p)) == nnz
+    assert np.array_equal(rp, rp2) and np.array_equal(ci, ci2) and np.array_equal(v, v2)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_live_reference_spmv(oracle, seed):
     ref = _ref()
