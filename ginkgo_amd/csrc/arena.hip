@@ -671,6 +671,19 @@ static int arena_free_impl(void* ptr, bool sync)
 
 int arena_free(void* ptr) { return arena_free_impl(ptr, true); }
 
+// is ptr inside memory the arena hands out (any mode, any device)?
+bool arena_owns(const void* ptr)
+{
+    std::lock_guard<std::mutex> g(g_mtx);
+    for (int dev = 0; dev < 64; ++dev) {
+        const device_arena& A = g_arena[dev];
+        for (const span* c : A.small) if (c->owns(ptr)) return true;
+        for (const span* c : A.plain) if (c->owns(ptr)) return true;
+        for (int k = 0; k < A.n_cls; ++k) if (A.reg[k].owns(ptr)) return true;
+    }
+    return false;
+}
+
 // ---- stream-ordered scratch ---------------------------------------------------
 namespace {
 struct pending_free {

@@ -296,6 +296,44 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
     return GKOC_OK;
 }
 
+// MPI_Alltoallv over RCCL: byte counts and byte offsets per peer on both sides, one grouped
+// send / recv on `s`; the part a rank sends to itself is a device copy
+int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* send_buf,
+                                 const int64_t* send_bytes, const int64_t* send_offsets, void* recv_buf,
+                                 const int64_t* recv_bytes, const int64_t* recv_offsets)
+{
+    GKOC_REQUIRE(comm && send_bytes && send_offsets && recv_bytes && recv_offsets, GKOC_E_INVALID,
+                 "bad argument");
+    GKOC_REQUIRE(!comm->pending_side && !comm->pending_reduce, GKOC_E_INVALID,
+                 "gkoc_comm_all_to_all_v_bytes while an overlapped operation is pending");
+    hipStream_t st = as_stream(s);
+    const char* sp = static_cast<const char*>(send_buf);
+    char* rp = static_cast<char*>(recv_buf);
+    for (int p = 0; p < comm->n_ranks; ++p) {
+        GKOC_REQUIRE(send_bytes[p] >= 0 && recv_bytes[p] >= 0 && send_offsets[p] >= 0 && recv_offsets[p] >= 0,
+                     GKOC_E_INVALID, "negative count or offset");
+    }
+    const int me = comm->rank;
+    if (send_bytes[me] > 0) {
+        GKOC_REQUIRE(send_bytes[me] == recv_bytes[me], GKOC_E_INVALID, "self message sizes differ");
+        GKOC_HIP(hipMemcpyAsync(rp + recv_offsets[me], sp + send_offsets[me], size_t(send_bytes[me]),
+                                hipMemcpyDeviceToDevice, st));
+    }
+    GKOC_RCCL(g_rccl.GroupStart());
+    int e = nccl_success;
+    for (int p = 0; p < comm->n_ranks && e == nccl_success; ++p) {
+        if (p == me) continue;
+        if (send_bytes[p]) e = g_rccl.Send(sp + send_offsets[p], size_t(send_bytes[p]), nccl_uint8, p, comm->comm, st);
+        if (recv_bytes[p] && e == nccl_success) {
+            e = g_rccl.Recv(rp + recv_offsets[p], size_t(recv_bytes[p]), nccl_uint8, p, comm->comm, st);
+        }
+    }
+    int e2 = g_rccl.GroupEnd();
+    if (e != nccl_success) return rccl_fail(e, "ncclSend/ncclRecv", __LINE__);
+    if (e2 != nccl_success) return rccl_fail(e2, "ncclGroupEnd", __LINE__);
+    return GKOC_OK;
+}
+
 int gkoc_comm_exchange_end(gkoc_comm_t comm, gkoc_stream_t main_stream)
 {
     GKOC_REQUIRE(comm, GKOC_E_INVALID, "comm == NULL");

@@ -52,6 +52,7 @@ const device_props& current_device_props();
 // gkoc_malloc / gkoc_free go through the arena (arena.hip)
 int arena_malloc(void** ptr, size_t bytes, int role);
 int arena_free(void* ptr);
+bool arena_owns(const void* ptr);
 // Stream-ordered scratch for the library's own temporaries (flags, scan partials,
 // find_blocks work arrays): taken from the arena, handed back once `st` has passed the
 // point of scratch_free.  NOT hipMallocAsync / hipFreeAsync: their pool unmaps and

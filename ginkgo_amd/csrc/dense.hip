@@ -362,6 +362,7 @@ extern "C" size_t gkoc_reduction_workspace_bytes(int64_t, int64_t nrhs,
                                          int64_t alpha_cols, T* x,             \
                                          int64_t ldx)                          \
     {                                                                          \
+        if (rows <= 0 || cols <= 0) return GKOC_OK; /* nothing to do: alpha may be 1 x 0 / NULL */ \
         GKOC_REQUIRE(alpha && (alpha_cols == 1 || alpha_cols == cols),         \
                      GKOC_E_INVALID, "bad alpha");                             \
         ew_operands<T, 1, 1> a{};                                              \
@@ -378,6 +379,7 @@ extern "C" size_t gkoc_reduction_workspace_bytes(int64_t, int64_t nrhs,
                                              int64_t alpha_cols, T* x,         \
                                              int64_t ldx)                      \
     {                                                                          \
+        if (rows <= 0 || cols <= 0) return GKOC_OK; /* nothing to do: alpha may be 1 x 0 / NULL */ \
         GKOC_REQUIRE(alpha && (alpha_cols == 1 || alpha_cols == cols),         \
                      GKOC_E_INVALID, "bad alpha");                             \
         ew_operands<T, 1, 1> a{};                                              \
@@ -393,6 +395,7 @@ extern "C" size_t gkoc_reduction_workspace_bytes(int64_t, int64_t nrhs,
         gkoc_stream_t s, int64_t rows, int64_t cols, const T* alpha,           \
         int64_t alpha_cols, const T* x, int64_t ldx, T* y, int64_t ldy)        \
     {                                                                          \
+        if (rows <= 0 || cols <= 0) return GKOC_OK; /* nothing to do: alpha may be 1 x 0 / NULL */ \
         GKOC_REQUIRE(alpha && (alpha_cols == 1 || alpha_cols == cols),         \
                      GKOC_E_INVALID, "bad alpha");                             \
         ew_operands<T, 2, 1> a{};                                              \
@@ -410,6 +413,7 @@ extern "C" size_t gkoc_reduction_workspace_bytes(int64_t, int64_t nrhs,
         gkoc_stream_t s, int64_t rows, int64_t cols, const T* alpha,           \
         int64_t alpha_cols, const T* x, int64_t ldx, T* y, int64_t ldy)        \
     {                                                                          \
+        if (rows <= 0 || cols <= 0) return GKOC_OK; /* nothing to do: alpha may be 1 x 0 / NULL */ \
         GKOC_REQUIRE(alpha && (alpha_cols == 1 || alpha_cols == cols),         \
                      GKOC_E_INVALID, "bad alpha");                             \
         ew_operands<T, 2, 1> a{};                                              \
@@ -496,6 +500,16 @@ __global__ __launch_bounds__(256) void fill_pair_kernel(int64_t n, T* __restrict
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void fill_pair_2d_kernel(int64_t rows, int64_t cols, T* __restrict__ x,
+                                                          int64_t ld, T value)
+{
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < rows * cols; i += stride) {
+        x[(i / cols) * ld + i % cols] = value;
+    }
+}
+
 // stage 1 of the column norms of a complex matrix: x as real numbers, ld in real elements
 template <typename R>
 __global__ __launch_bounds__(red_block) void cnorm2_stage1(int64_t rows, const R* __restrict__ x,
@@ -551,6 +565,17 @@ int launch_cnorm2(gkoc_stream_t s, int64_t rows, int64_t cols, const R* x, int64
         if (nb > gkoc::max_stream_blocks) nb = gkoc::max_stream_blocks;                              \
         gkoc::fill_pair_kernel<T><<<dim3(unsigned(nb)), dim3(256), 0, gkoc::as_stream(s)>>>(n, data, \
                                                                                             value, 0); \
+        GKOC_LAUNCH_OK();                                                                            \
+        return GKOC_OK;                                                                              \
+    }                                                                                                \
+    extern "C" int gkoc_dense_fill_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, T* x,           \
+                                        int64_t ldx, T value)                                        \
+    {                                                                                                \
+        if (rows <= 0 || cols <= 0) return GKOC_OK;                                                  \
+        int64_t nb = gkoc::ceildiv(rows * cols, 256);                                                \
+        if (nb > gkoc::max_stream_blocks) nb = gkoc::max_stream_blocks;                              \
+        gkoc::fill_pair_2d_kernel<T><<<dim3(unsigned(nb)), dim3(256), 0, gkoc::as_stream(s)>>>(      \
+            rows, cols, x, ldx, value);                                                              \
         GKOC_LAUNCH_OK();                                                                            \
         return GKOC_OK;                                                                              \
     }                                                                                                \

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <mutex>
 
+#include <unistd.h>
+
 #include "common.hpp"
 
 namespace gkoc {
@@ -260,6 +262,37 @@ int gkoc_memcpy_h2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s)
 {
     if (bytes == 0) return GKOC_OK;
     GKOC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(s)));
+    return GKOC_OK;
+}
+
+int gkoc_pointer_is_device(const void* ptr, int* is_device)
+{
+    GKOC_REQUIRE(is_device, GKOC_E_INVALID, "null result");
+    *is_device = 0;
+    if (!ptr) return GKOC_OK;
+    if (arena_owns(ptr)) {
+        *is_device = 1;
+        return GKOC_OK;
+    }
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();      // an ordinary host pointer
+        return GKOC_OK;
+    }
+    *is_device = attr.type == hipMemoryTypeDevice ? 1 : 0;
+    return GKOC_OK;
+}
+
+int gkoc_device_identity(char* out, size_t out_bytes)
+{
+    GKOC_REQUIRE(out && out_bytes >= 64, GKOC_E_INVALID, "need 64 bytes");
+    int dev = 0;
+    GKOC_HIP(hipGetDevice(&dev));
+    char bus[32] = {0};
+    GKOC_HIP(hipDeviceGetPCIBusId(bus, sizeof(bus), dev));
+    char host[24] = {0};
+    if (gethostname(host, sizeof(host) - 1) != 0) host[0] = 0;
+    snprintf(out, out_bytes, "%s/%s", host, bus);
     return GKOC_OK;
 }
 

@@ -171,6 +171,13 @@ namespace dense {
                                    matrix::Dense<R>* result, array<char>& tmp)                   \
     {                                                                                            \
         compute_norm2<C>(exec, x, result, tmp);                                                  \
+    }                                                                                            \
+    template <>                                                                                  \
+    void fill<C>(exec_t exec, matrix::Dense<C>* mat, C value)                                    \
+    {                                                                                            \
+        GKOC_CALL(gkoc_dense_fill_##TN(stream_of(exec), rows(mat), cols(mat),                    \
+                                       pairs(mat->get_values()), ld(mat),                        \
+                                       P{value.real(), value.imag()}));                          \
     }
 FOR_CT(DEF)
 #undef DEF

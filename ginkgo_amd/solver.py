@@ -294,9 +294,16 @@ class Cg(_IterativeSolver):
         self.stop_status = stop_status
         st = stop_status.cpu()
         self.has_converged = bool(((st & 0x80) != 0).all().item())
-        for c in crit.criteria:
-            if getattr(c, "last_tau", None) is not None and not c.implicit:
-                self.residual_norm = c.last_tau.to_numpy()[0]
+        # log::Convergence semantics (core/log/convergence.cpp): the residual norm of the iterate
+        # the solver stopped at.  With the fused step_2 + norm kernels tau already holds ||r||
+        # (a stopped column leaves r alone, so the run-ahead iterations recompute the same value);
+        # otherwise - the iteration limit hit before ResidualNorm looked at this r - it is computed
+        if have_tau:
+            self.residual_norm = tau.to_numpy()[0]
+        else:
+            fin = self._scal("final_norm", b)
+            r.compute_norm2(fin)
+            self.residual_norm = fin.to_numpy()[0]
 
 
     # ------------------------------------------------------------ hipGraph

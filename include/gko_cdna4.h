@@ -144,6 +144,11 @@ int gkoc_tune_get(int key, int64_t* value);
 int gkoc_malloc_host(void** ptr, size_t bytes);
 int gkoc_free_host(void* ptr);
 int gkoc_malloc_managed(void** ptr, size_t bytes, unsigned int flags);
+/* 1 if ptr is device memory (the arena's or any other HIP device allocation), 0 for host
+ * memory (pageable, pinned or managed); the process' device identity "host/pci-bus-id"
+ * (64 bytes): what the GPU-aware-MPI layer (gko_binding/mpi_rccl.cpp) needs to route buffers */
+int gkoc_pointer_is_device(const void* ptr, int* is_device);
+int gkoc_device_identity(char* out, size_t out_bytes);
 int gkoc_memcpy_h2d(void* dst, const void* src_host, size_t bytes, gkoc_stream_t s);
 int gkoc_memcpy_d2h(void* dst_host, const void* src, size_t bytes, gkoc_stream_t s);
 int gkoc_memcpy_d2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s);
@@ -845,6 +850,144 @@ GKOC_DECL_DIST(double, f64, int64_t, i64)
 GKOC_DECL_DIST(float, f32, int32_t, i32)
 GKOC_DECL_DIST(float, f32, int64_t, i64)
 
+/* ------------------------------------------------- Diagonal, SparsityCsr, components
+ * matrix::Diagonal (core/matrix/diagonal_kernels.hpp; reference/matrix/diagonal_kernels.cpp:
+ * 20-170): c = diag * b (or its inverse), c = b * diag, the same on the values of a Csr whose
+ * structure the caller has copied, Diagonal -> Csr, device_matrix_data -> Diagonal.
+ * SparsityCsr (core/matrix/sparsity_csr_kernels.hpp): the number of diagonal entries per row
+ * (the caller scans it: diagonal_element_prefix_sum) and the adjacency structure without them.
+ * components::reduce_add_array (val[0] += sum(arr)), components::convert_precision. */
+#define GKOC_DECL_MISC_T(T, TN)                                                                  \
+    int gkoc_diagonal_apply_to_dense_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,           \
+                                          const T* diag, const T* b, int64_t ldb, T* c,          \
+                                          int64_t ldc, int inverse);                             \
+    int gkoc_diagonal_right_apply_to_dense_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,     \
+                                                const T* diag, const T* b, int64_t ldb, T* c,    \
+                                                int64_t ldc);                                    \
+    int gkoc_reduce_add_array_##TN(gkoc_stream_t s, int64_t n, const T* arr, T* val);
+GKOC_DECL_MISC_T(double, f64)
+GKOC_DECL_MISC_T(float, f32)
+int gkoc_reduce_add_array_i32(gkoc_stream_t s, int64_t n, const int32_t* arr, int32_t* val);
+int gkoc_reduce_add_array_i64(gkoc_stream_t s, int64_t n, const int64_t* arr, int64_t* val);
+int gkoc_reduce_add_array_u64(gkoc_stream_t s, int64_t n, const uint64_t* arr, uint64_t* val);
+int gkoc_convert_precision_f32_f64(gkoc_stream_t s, int64_t n, const float* in, double* out);
+int gkoc_convert_precision_f64_f32(gkoc_stream_t s, int64_t n, const double* in, float* out);
+#define GKOC_DECL_MISC_TI(T, TN, I, IN)                                                          \
+    int gkoc_diagonal_apply_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const T* diag,   \
+                                               const I* row_ptrs, T* vals, int inverse);         \
+    int gkoc_diagonal_right_apply_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t nnz,               \
+                                                     const T* diag, const I* cols, T* vals);     \
+    int gkoc_diagonal_convert_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t n, const T* diag,      \
+                                                 I* row_ptrs, I* cols, T* vals);                 \
+    int gkoc_diagonal_fill_in_matrix_data_##TN##_##IN(gkoc_stream_t s, int64_t nnz,              \
+                                                      const I* rows, const I* cols,              \
+                                                      const T* vals, T* diag);
+GKOC_DECL_MISC_TI(double, f64, int32_t, i32)
+GKOC_DECL_MISC_TI(double, f64, int64_t, i64)
+GKOC_DECL_MISC_TI(float, f32, int32_t, i32)
+GKOC_DECL_MISC_TI(float, f32, int64_t, i64)
+#define GKOC_DECL_MISC_I(I, IN)                                                                  \
+    int gkoc_sparsity_csr_count_diagonal_##IN(gkoc_stream_t s, int64_t n_rows,                   \
+                                              const I* row_ptrs, const I* cols, I* counts);      \
+    int gkoc_sparsity_csr_remove_diagonal_##IN(gkoc_stream_t s, int64_t n_rows,                  \
+                                               const I* row_ptrs, const I* cols,                 \
+                                               const I* diag_prefix_sum, I* adj_ptrs,            \
+                                               I* adj_idxs);
+GKOC_DECL_MISC_I(int32_t, i32)
+GKOC_DECL_MISC_I(int64_t, i64)
+
+/* ----------------------------------------------- distributed set-up kernels
+ * What experimental::distributed::{Partition, index_map, Matrix / Vector::read_distributed,
+ * assemble_rows_from_neighbors} run on their executor (core/distributed/{partition,
+ * partition_helpers,index_map,matrix,vector,assembly}_kernels.hpp; semantics:
+ * reference/distributed/ *_kernels.cpp and partition_helpers.hpp).  Index work and copies only:
+ * values are moved as words of value_size = 4, 8 or 16 bytes (float, double, complex<float>,
+ * complex<double>).  Suffixes: <L>_<G> = local / global index type (i32_i32, i32_i64, i64_i64).
+ * Outputs whose length depends on the data come from a _count call (sizes to the host, an opaque
+ * state that the matching _fill call consumes and releases). */
+typedef struct gkoc_partition {
+    int64_t num_ranges;
+    int32_t num_parts;
+    const void* range_bounds;           /* G[num_ranges + 1] */
+    const int32_t* part_ids;            /* [num_ranges]: the part that owns each range */
+    const void* range_starting_indices; /* L[num_ranges] */
+    const void* part_sizes;             /* L[num_parts] */
+} gkoc_partition;
+#define GKOC_DECL_DIST_LG(L, LN, G, GN)                                                              \
+    /* distributed_matrix::separate_local_nonlocal (matrix_kernels.hpp:22-42): the entries of the  \
+     * rows of local_part, split by the owner of their column, input order kept */                 \
+    int gkoc_dist_separate_local_nonlocal_count_##LN##_##GN(                                        \
+        gkoc_stream_t s, int64_t nnz, const G* rows, const G* cols, const gkoc_partition* row_part, \
+        const gkoc_partition* col_part, int32_t local_part, void** state, int64_t* n_local,         \
+        int64_t* n_non_local);                                                                      \
+    int gkoc_dist_separate_local_nonlocal_fill_##LN##_##GN(                                         \
+        gkoc_stream_t s, int64_t nnz, const G* rows, const G* cols, const void* vals,               \
+        size_t value_size, const gkoc_partition* row_part, const gkoc_partition* col_part,          \
+        void* state, L* local_rows, L* local_cols, void* local_vals, L* non_local_rows,             \
+        G* non_local_cols, void* non_local_vals);                                                   \
+    /* distributed_vector::build_local (vector_kernels.hpp:23-33) */                                \
+    int gkoc_dist_vector_build_local_##LN##_##GN(                                                   \
+        gkoc_stream_t s, int64_t nnz, const G* rows, const G* cols, const void* vals,               \
+        size_t value_size, const gkoc_partition* part, int32_t local_part, void* local_values,      \
+        int64_t ld);                                                                                \
+    /* index_map::build_mapping / map_to_local / map_to_global (index_map_kernels.hpp:40-102);      \
+     * index_space: 0 local, 1 non_local, 2 combined */                                             \
+    int gkoc_index_map_build_mapping_count_##LN##_##GN(                                             \
+        gkoc_stream_t s, int64_t n, const G* recv_connections, const gkoc_partition* part,          \
+        void** state, int64_t* n_unique, int64_t* n_part_unique);                                   \
+    int gkoc_index_map_build_mapping_fill_##LN##_##GN(                                              \
+        gkoc_stream_t s, const gkoc_partition* part, void* state, int32_t* part_ids,                \
+        L* remote_local_idxs, G* remote_global_idxs, int64_t* remote_sizes);                        \
+    int gkoc_index_map_map_to_local_##LN##_##GN(                                                    \
+        gkoc_stream_t s, int64_t n, const G* global_ids, const gkoc_partition* part,                \
+        int64_t n_targets, const int32_t* remote_target_ids, const G* remote_global_flat,           \
+        const int64_t* remote_offsets, int32_t rank, int index_space, L* local_ids);                \
+    int gkoc_index_map_map_to_global_##LN##_##GN(                                                   \
+        gkoc_stream_t s, int64_t n, const L* local_ids, const G* range_bounds,                      \
+        const L* starting_indices, int64_t local_size, const uint64_t* local_ranges,                \
+        int64_t n_local_ranges, const G* remote_global_flat, int64_t remote_size, int index_space,  \
+        G* global_ids);                                                                             \
+    /* partition::build_starting_indices (partition_kernels.hpp:42-51) */                           \
+    int gkoc_partition_build_starting_indices_##LN##_##GN(                                          \
+        gkoc_stream_t s, const G* range_offsets, const int32_t* range_parts, int64_t num_ranges,    \
+        int32_t num_parts, int32_t* num_empty_parts, L* ranks, L* sizes);                           \
+    /* assembly::count_non_owning_entries (assembly_kernels.hpp); send_count is added to */        \
+    int gkoc_assembly_count_non_owning_entries_##LN##_##GN(                                         \
+        gkoc_stream_t s, int64_t nnz, const G* rows, const gkoc_partition* part, int32_t local_part, \
+        int32_t* send_count, G* send_positions, G* original_positions);
+GKOC_DECL_DIST_LG(int32_t, i32, int32_t, i32)
+GKOC_DECL_DIST_LG(int32_t, i32, int64_t, i64)
+GKOC_DECL_DIST_LG(int64_t, i64, int64_t, i64)
+#define GKOC_DECL_DIST_G(G, GN)                                                                      \
+    int gkoc_partition_build_from_contiguous_##GN(gkoc_stream_t s, int64_t num_ranges,              \
+                                                  const G* ranges, const int32_t* part_id_mapping,  \
+                                                  G* range_bounds, int32_t* part_ids);              \
+    int gkoc_partition_build_from_mapping_##GN(gkoc_stream_t s, int64_t n, const int32_t* mapping,  \
+                                               G* range_bounds, int32_t* part_ids);                 \
+    int gkoc_partition_build_ranges_from_global_size_##GN(gkoc_stream_t s, int32_t num_parts,       \
+                                                          G global_size, G* ranges);                \
+    /* partition_helpers (partition_helpers_kernels.hpp): (start, end) pairs per part */            \
+    int gkoc_partition_helpers_sort_by_range_start_##GN(gkoc_stream_t s, int64_t num_parts,         \
+                                                        G* range_start_ends, int32_t* part_ids);    \
+    int gkoc_partition_helpers_check_consecutive_ranges_##GN(gkoc_stream_t s, int64_t num_parts,    \
+                                                             const G* range_start_ends,             \
+                                                             int* result);                          \
+    int gkoc_partition_helpers_compress_ranges_##GN(gkoc_stream_t s, int64_t n_offsets,             \
+                                                    const G* range_start_ends, G* range_offsets);   \
+    int gkoc_assembly_fill_send_buffers_##GN(                                                       \
+        gkoc_stream_t s, int64_t nnz, const G* rows, const G* cols, const void* vals,               \
+        size_t value_size, const G* send_positions, const G* original_positions, G* send_rows,      \
+        G* send_cols, void* send_vals);
+GKOC_DECL_DIST_G(int32_t, i32)
+GKOC_DECL_DIST_G(int64_t, i64)
+int gkoc_partition_count_ranges(gkoc_stream_t s, int64_t n, const int32_t* mapping,
+                                int64_t* num_ranges);
+int gkoc_partition_build_ranges_by_part(gkoc_stream_t s, const int32_t* range_parts,
+                                        int64_t num_ranges, int32_t num_parts, uint64_t* range_ids,
+                                        int64_t* sizes);
+int gkoc_partition_has_ordered_parts(gkoc_stream_t s, int64_t num_ranges, const int32_t* part_ids,
+                                     int* result);
+
 /* ------------------------------------------------- extensions (gkoc_x_*)
  * NOT part of Ginkgo's kernel set (the shim never calls them): producer
  * kernels that also emit the reduction a Krylov loop needs next, so the
@@ -931,6 +1074,11 @@ int gkoc_remove_zeros_count_c128(gkoc_stream_t s, int64_t nnz, const gkoc_c128* 
 int gkoc_remove_zeros_count_c64(gkoc_stream_t s, int64_t nnz, const gkoc_c64* vals, void* work,
                                 size_t work_bytes, int64_t* count_host);
 int gkoc_fill_array_c128(gkoc_stream_t s, gkoc_c128* data, int64_t n, gkoc_c128 value);
+/* dense::fill of a complex matrix (the rows x cols part of a strided matrix) */
+int gkoc_dense_fill_c128(gkoc_stream_t s, int64_t rows, int64_t cols, gkoc_c128* x, int64_t ldx,
+                         gkoc_c128 value);
+int gkoc_dense_fill_c64(gkoc_stream_t s, int64_t rows, int64_t cols, gkoc_c64* x, int64_t ldx,
+                        gkoc_c64 value);
 int gkoc_fill_array_c64(gkoc_stream_t s, gkoc_c64* data, int64_t n, gkoc_c64 value);
 int gkoc_fill_seq_array_c128(gkoc_stream_t s, gkoc_c128* data, int64_t n);
 int gkoc_fill_seq_array_c64(gkoc_stream_t s, gkoc_c64* data, int64_t n);
@@ -1483,6 +1631,12 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream,
                              const int64_t* send_displs, void* recv_buf,
                              const int64_t* recv_counts, size_t value_size);
 int gkoc_comm_exchange_end(gkoc_comm_t comm, gkoc_stream_t main_stream);
+/* MPI_Alltoallv (mpi.hpp all_to_all_v / i_all_to_all_v) in bytes: counts and offsets per peer on
+ * both sides, enqueued on s as one grouped send / recv */
+int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* send_buf,
+                                 const int64_t* send_bytes, const int64_t* send_offsets,
+                                 void* recv_buf, const int64_t* recv_bytes,
+                                 const int64_t* recv_offsets);
 
 #ifdef __cplusplus
 }
