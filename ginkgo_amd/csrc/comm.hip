@@ -296,6 +296,20 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
     return GKOC_OK;
 }
 
+// like gkoc_comm_exchange_end, but the main stream waits for EVERYTHING that has been enqueued on
+// the exchange's stream since gkoc_comm_exchange_begin - the halo and the kernels that consume it
+// there (the boundary rows of a slab partition, csr_rowlist_full_kernel)
+int gkoc_comm_exchange_join(gkoc_comm_t comm, gkoc_stream_t main_stream)
+{
+    GKOC_REQUIRE(comm, GKOC_E_INVALID, "comm == NULL");
+    if (comm->pending_side) {
+        GKOC_HIP(hipEventRecord(comm->arrived, comm->side_in_use));
+        GKOC_HIP(hipStreamWaitEvent(as_stream(main_stream), comm->arrived, 0));
+        comm->pending_side = false;
+    }
+    return GKOC_OK;
+}
+
 // MPI_Alltoallv over RCCL: byte counts and byte offsets per peer on both sides, one grouped
 // send / recv on `s`; the part a rank sends to itself is a device copy
 int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* send_buf,

@@ -178,6 +178,89 @@ __global__ __launch_bounds__(64) void csr_rowlist_add_kernel(
     }
 }
 
+// ---- boundary rows as COMPLETE rows (slab partitions, one column) ------------------------
+// The rows that have non-local entries, with ALL their entries in the original (global) column
+// order; a column index below n_local refers to the rank's own vector, n_local + h to halo
+// entry h.  y[rows[i]] = sum_k vals[k] * v(cols[k]) in k order: the single-domain row sum, bit
+// for bit.  Such rows need nothing from the local SpMV, so that kernel can skip them (it is
+// launched over the interior row range only) and this one can run on the exchange's stream as
+// soon as the halo has arrived, next to the tail of the local SpMV.
+template <typename I>
+__global__ __launch_bounds__(256) void boundary_len_kernel(int64_t n_list, const I* __restrict__ rows,
+                                                           const I* __restrict__ row_ptrs,
+                                                           I* __restrict__ out)
+{
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i > n_list) return;
+    out[i] = i < n_list ? I(row_ptrs[int64_t(rows[i]) + 1] - row_ptrs[rows[i]]) : I(0);
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void boundary_fill_kernel(
+    int64_t n_list, const I* __restrict__ rows, const I* __restrict__ row_ptrs,
+    const I* __restrict__ cols, const T* __restrict__ vals, int64_t col_lo, int64_t col_hi,
+    const I* __restrict__ col_map, const I* __restrict__ out_ptrs, I* __restrict__ out_cols,
+    T* __restrict__ out_vals)
+{
+    // one wave per listed row
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t(blockIdx.x) * 256 + threadIdx.x) >> 6;
+    if (i >= n_list) return;
+    const int64_t r = rows[i];
+    const int64_t k0 = row_ptrs[r], len = int64_t(row_ptrs[r + 1]) - k0, o0 = out_ptrs[i];
+    for (int64_t t = lane; t < len; t += 64) {
+        const int64_t c = cols[k0 + t];
+        out_cols[o0 + t] = (c >= col_lo && c < col_hi) ? I(c - col_lo) : I(col_hi - col_lo + int64_t(col_map[c]));
+        out_vals[o0 + t] = vals[k0 + t];
+    }
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(64) void csr_rowlist_full_kernel(
+    int64_t n_list, const I* __restrict__ rows, const I* __restrict__ ptrs,
+    const I* __restrict__ cols, const T* __restrict__ vals, int64_t n_local,
+    const T* __restrict__ x, const T* __restrict__ halo, T* __restrict__ y)
+{
+    __shared__ T lv[rl_stage_cap];
+    __shared__ I lc[rl_stage_cap];
+    const int lane = threadIdx.x;
+    const int64_t first = int64_t(blockIdx.x) * 64;
+    const int64_t i = first + lane;
+    const bool valid = i < n_list;
+    const int64_t last = first + 64 < n_list ? first + 64 : n_list;
+    const int64_t K0 = ptrs[first], K1 = ptrs[last];
+    const int64_t ks = ptrs[valid ? i : last], ke = ptrs[valid ? i + 1 : last];
+    const bool staged = K1 - K0 <= rl_stage_cap;
+    if (staged) {
+        for (int t = lane; t < int(K1 - K0); t += 64) {
+            lv[t] = vals[K0 + t];
+            lc[t] = cols[K0 + t];
+        }
+        wave_lds_sync();
+    }
+    if (!valid) return;
+    const int64_t row = rows[i];
+    T sum = T(0);
+    int64_t k = ks;
+    for (; k + 9 <= ke; k += 9) {      // a boundary row of the 27-pt stencil: 2 or 3 groups of nine
+        T v[9], h[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            v[u] = staged ? lv[k + u - K0] : vals[k + u];
+            const int64_t c = staged ? lc[k + u - K0] : cols[k + u];
+            h[u] = c < n_local ? x[c] : halo[c - n_local];
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) sum += v[u] * h[u];
+    }
+    for (; k < ke; ++k) {
+        const T v = staged ? lv[k - K0] : vals[k];
+        const int64_t c = staged ? lc[k - K0] : cols[k];
+        sum += v * (c < n_local ? x[c] : halo[c - n_local]);
+    }
+    y[row] = sum;
+}
+
 // inout[0] += sum of partial[0 .. count) (fixed tree)
 template <typename T>
 __global__ __launch_bounds__(1024) void add_partials_kernel(int64_t count, const T* __restrict__ partial,
@@ -287,6 +370,29 @@ using namespace gkoc;
 GKOC_DEF_DIST_IDX(int32_t, i32)
 GKOC_DEF_DIST_IDX(int64_t, i64)
 
+#define GKOC_DEF_DIST_BND_IDX(I, IN)                                           \
+    extern "C" int gkoc_dist_boundary_count_##IN(                              \
+        gkoc_stream_t s, int64_t n_list, const I* rows, const I* row_ptrs,     \
+        I* out_ptrs, int64_t* nnz_host)                                        \
+    {                                                                          \
+        GKOC_REQUIRE(out_ptrs && nnz_host && n_list >= 0, GKOC_E_INVALID,      \
+                     "bad argument");                                          \
+        hipStream_t st = as_stream(s);                                         \
+        boundary_len_kernel<I><<<grid_for(n_list + 1), dim3(256), 0, st>>>(    \
+            n_list, rows, row_ptrs, out_ptrs);                                 \
+        GKOC_LAUNCH_OK();                                                      \
+        int rc = device_exclusive_scan<I>(st, out_ptrs, n_list + 1);           \
+        if (rc) return rc;                                                     \
+        I h = 0;                                                               \
+        GKOC_HIP(hipMemcpyAsync(&h, out_ptrs + n_list, sizeof(I),              \
+                                hipMemcpyDeviceToHost, st));                   \
+        GKOC_HIP(hipStreamSynchronize(st));                                    \
+        *nnz_host = int64_t(h);                                                \
+        return GKOC_OK;                                                        \
+    }
+GKOC_DEF_DIST_BND_IDX(int32_t, i32)
+GKOC_DEF_DIST_BND_IDX(int64_t, i64)
+
 #define GKOC_DEF_DIST(T, TN, I, IN)                                            \
     extern "C" int gkoc_dist_split_fill_##TN##_##IN(                           \
         gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,     \
@@ -300,6 +406,34 @@ GKOC_DEF_DIST_IDX(int64_t, i64)
                                 local_row_ptrs, nl_row_ptrs_full, local_cols,  \
                                 local_vals, nl_rows, nl_ptrs, nl_cols,         \
                                 nl_vals, recv_gidx);                           \
+    }                                                                          \
+    extern "C" int gkoc_dist_boundary_fill_##TN##_##IN(                        \
+        gkoc_stream_t s, int64_t n_list, const I* rows, const I* row_ptrs,     \
+        const I* cols, const T* vals, int64_t col_lo, int64_t col_hi,          \
+        const I* col_map, const I* out_ptrs, I* out_cols, T* out_vals)         \
+    {                                                                          \
+        if (n_list <= 0) return GKOC_OK;                                       \
+        boundary_fill_kernel<T, I>                                             \
+            <<<dim3(unsigned(ceildiv(n_list * 64, 256))), dim3(256), 0,        \
+               as_stream(s)>>>(n_list, rows, row_ptrs, cols, vals, col_lo,     \
+                               col_hi, col_map, out_ptrs, out_cols, out_vals); \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }                                                                          \
+    extern "C" int gkoc_csr_rowlist_spmv_full_##TN##_##IN(                     \
+        gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \
+        const I* cols, const T* vals, int64_t n_local, const T* x,             \
+        const T* halo, T* y)                                                   \
+    {                                                                          \
+        if (n_list <= 0) return GKOC_OK;                                       \
+        GKOC_REQUIRE(rows && ptrs && x && halo && y, GKOC_E_INVALID,           \
+                     "null pointer");                                          \
+        csr_rowlist_full_kernel<T, I>                                          \
+            <<<dim3(unsigned(ceildiv(n_list, 64))), dim3(64), 0,               \
+               as_stream(s)>>>(n_list, rows, ptrs, cols, vals, n_local, x,     \
+                               halo, y);                                       \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
     }                                                                          \
     extern "C" int gkoc_x_csr_rowlist_spmv_add_dot_##TN##_##IN(                \
         gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \

@@ -1,0 +1,682 @@
+// libgkoc_mpi_rccl.so - device buffers behind Ginkgo's own MPI calls.
+//
+// Ginkgo's distributed classes talk to MPI directly (include/ginkgo/core/base/mpi.hpp): with
+// GINKGO_HAVE_GPU_AWARE_MPI (CMake: GINKGO_FORCE_GPU_AWARE_MPI, CMakeLists.txt:185, 410-417)
+// mpi::requires_host_buffer is false (core/base/mpi.cpp:65-70) and the core hands DEVICE pointers
+// to MPI_Allreduce (distributed/vector.cpp:473-497 and the other reductions, solver/gmres.cpp:215),
+// MPI_Ialltoallv (RowGatherer::apply_finalize, row_gatherer.cpp:118-174, through DenseCommunicator),
+// MPI_Ineighbor_alltoallv (NeighborhoodCommunicator), MPI_Alltoall(v) / MPI_Allgather (assembly,
+// partition helpers).  An MPI that is not GPU-aware cannot take them.  This library is the
+// GPU-aware layer for such an MPI: it defines those MPI_* entry points (link it in front of
+// libmpi, or LD_PRELOAD it) and forwards to PMPI_*, except that buffers in device memory are
+// routed
+//   * over RCCL (csrc/comm.hip: one communicator per MPI communicator, created from an id that
+//     rank 0 broadcasts over MPI; all-reduce = ncclAllReduce, all-to-all-v = grouped ncclSend /
+//     ncclRecv over xGMI) when every rank of the communicator drives its own GPU - no host
+//     staging, no D2H / H2D copies; a non-blocking call returns at once and the exchange
+//     overlaps whatever the caller enqueues next (the local SpMV of distributed::Matrix::apply),
+//     MPI_Wait waits for the side stream;
+//   * through pinned host staging buffers and the plain MPI call when ranks share a GPU (RCCL
+//     refuses two ranks on one device; the single-GPU test box), for operations / datatypes RCCL
+//     has no counterpart for, or with GKOC_MPI_MODE=staged.
+// MPI itself stays the launcher, the control plane and the transport of every host buffer.
+// Counters (gkoc_mpi_stats) tell tests which route each call took.
+//
+// Contract, as for any GPU-aware MPI: the contents of a device send buffer are final when MPI is
+// called (Ginkgo synchronises its executor or the pack event before every such call), results are
+// in the receive buffer when the blocking call or MPI_Wait returns.
+#include <mpi.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gko_cdna4.h"
+
+extern "C" void gko_cdna4_launch_deferred() __attribute__((weak));
+
+namespace {
+
+enum class mode { undecided, rccl, staged };
+
+struct comm_state {
+    mode m = mode::undecided;
+    gkoc_comm_t rccl = nullptr;
+    int size = 0, rank = 0;
+};
+
+struct pending {
+    int kind = 0;                  // 1 rccl (stream work), 2 staged (real request + copy back)
+    MPI_Request inner = MPI_REQUEST_NULL;
+    // staged: device destination, host staging source
+    void* dev_dst = nullptr;
+    void* host_src = nullptr;
+    size_t bytes = 0;
+    void* host_send = nullptr;     // kept alive until completion
+    std::vector<int> keep_i;       // count / displacement arrays MPI may read until completion
+};
+
+std::mutex g_mtx;
+std::map<MPI_Comm, comm_state> g_comms;
+std::map<MPI_Request, pending> g_pending;
+gkoc_stream_t g_stream = nullptr;
+long g_stats[8] = {};              // 0 rccl all-reduce, 1 staged all-reduce, 2 rccl all-to-all-v,
+                                   // 3 staged all-to-all-v, 4 other staged, 5 D2H+H2D bytes, 6 host pass-through
+
+int env_mode()
+{
+    const char* e = std::getenv("GKOC_MPI_MODE");
+    if (!e) return 0;
+    if (!std::strcmp(e, "staged")) return 2;
+    if (!std::strcmp(e, "rccl")) return 1;
+    if (!std::strcmp(e, "off")) return 3;
+    return 0;
+}
+
+bool is_device(const void* p)
+{
+    if (p == nullptr || p == MPI_IN_PLACE) return false;
+    int d = 0;
+    if (gkoc_pointer_is_device(p, &d) != GKOC_OK) return false;
+    return d != 0;
+}
+
+gkoc_stream_t stream()
+{
+    if (!g_stream) gkoc_stream_create(&g_stream);
+    return g_stream;
+}
+
+void flush_binding()
+{
+    if (gko_cdna4_launch_deferred) gko_cdna4_launch_deferred();
+}
+
+// pinned host staging buffers, recycled
+struct host_pool {
+    std::vector<std::pair<void*, size_t>> free_list;
+    void* get(size_t bytes)
+    {
+        for (size_t i = 0; i < free_list.size(); ++i) {
+            if (free_list[i].second >= bytes) {
+                void* p = free_list[i].first;
+                sizes[p] = free_list[i].second;
+                free_list.erase(free_list.begin() + i);
+                return p;
+            }
+        }
+        void* p = nullptr;
+        const size_t cap = bytes < 4096 ? 4096 : bytes;
+        if (gkoc_malloc_host(&p, cap) != GKOC_OK) return nullptr;
+        sizes[p] = cap;
+        return p;
+    }
+    void put(void* p)
+    {
+        if (p) free_list.emplace_back(p, sizes[p]);
+    }
+    std::map<void*, size_t> sizes;
+} g_host;
+
+// decide (collectively, once per communicator) how device buffers travel on `comm`
+comm_state& state_of(MPI_Comm comm)
+{
+    comm_state& st = g_comms[comm];
+    if (st.m != mode::undecided) return st;
+    PMPI_Comm_size(comm, &st.size);
+    PMPI_Comm_rank(comm, &st.rank);
+    const int forced = env_mode();
+    int want_rccl = forced != 2;
+    if (want_rccl && st.size > 1 && forced != 1) {
+        // one GPU per rank?  compare "host/pci-bus-id" of all ranks
+        char mine[64] = {0};
+        if (gkoc_device_identity(mine, sizeof(mine)) != GKOC_OK) mine[0] = 0;
+        std::vector<char> all(size_t(64) * st.size);
+        PMPI_Allgather(mine, 64, MPI_CHAR, all.data(), 64, MPI_CHAR, comm);
+        for (int a = 0; a < st.size && want_rccl; ++a) {
+            for (int b = a + 1; b < st.size; ++b) {
+                if (!std::strncmp(&all[64 * a], &all[64 * b], 64)) {
+                    want_rccl = 0;
+                    break;
+                }
+            }
+        }
+    }
+    int ok = 0;
+    if (want_rccl) {
+        unsigned char id[GKOC_COMM_ID_BYTES] = {0};
+        int have = 1;
+        if (gkoc_comm_load_rccl(nullptr) != GKOC_OK) have = 0;
+        if (have && st.rank == 0 && gkoc_comm_unique_id(id) != GKOC_OK) have = 0;
+        int all_have = 0;
+        PMPI_Allreduce(&have, &all_have, 1, MPI_INT, MPI_MIN, comm);
+        if (all_have) {
+            PMPI_Bcast(id, GKOC_COMM_ID_BYTES, MPI_BYTE, 0, comm);
+            ok = gkoc_comm_create(&st.rccl, st.size, st.rank, id) == GKOC_OK ? 1 : 0;
+            int all_ok = 0;
+            PMPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, comm);
+            if (!all_ok && st.rccl) {
+                gkoc_comm_destroy(st.rccl);
+                st.rccl = nullptr;
+            }
+            ok = all_ok;
+        }
+    }
+    st.m = ok ? mode::rccl : mode::staged;
+    if (std::getenv("GKOC_MPI_VERBOSE") && st.rank == 0) {
+        std::fprintf(stderr, "[gkoc_mpi] communicator of %d ranks: device buffers go %s\n", st.size,
+                     ok ? "over RCCL" : "through host staging");
+    }
+    return st;
+}
+
+size_t type_bytes(MPI_Datatype t)
+{
+    int sz = 0;
+    PMPI_Type_size(t, &sz);
+    return size_t(sz);
+}
+
+// element size RCCL can sum (8 = double / complex<double> as pairs, 4 = float), 0 otherwise
+size_t rccl_sum_element(MPI_Datatype t, MPI_Op op, int count, int64_t* n_elems)
+{
+    if (op != MPI_SUM) return 0;
+    if (t == MPI_DOUBLE) { *n_elems = count; return 8; }
+    if (t == MPI_FLOAT) { *n_elems = count; return 4; }
+    if (t == MPI_C_DOUBLE_COMPLEX || t == MPI_CXX_DOUBLE_COMPLEX || t == MPI_DOUBLE_COMPLEX) { *n_elems = 2 * int64_t(count); return 8; }
+    if (t == MPI_C_FLOAT_COMPLEX || t == MPI_CXX_FLOAT_COMPLEX || t == MPI_COMPLEX) { *n_elems = 2 * int64_t(count); return 4; }
+    return 0;
+}
+
+// a completed-later request the application can hold: a generalized request
+int gq_query(void*, MPI_Status* s)
+{
+    if (s) {
+        MPI_Status_set_elements(s, MPI_BYTE, 0);
+        MPI_Status_set_cancelled(s, 0);
+        s->MPI_SOURCE = MPI_UNDEFINED;
+        s->MPI_TAG = MPI_UNDEFINED;
+    }
+    return MPI_SUCCESS;
+}
+int gq_free(void*) { return MPI_SUCCESS; }
+int gq_cancel(void*, int) { return MPI_SUCCESS; }
+
+MPI_Request new_handle()
+{
+    MPI_Request r = MPI_REQUEST_NULL;
+    PMPI_Grequest_start(gq_query, gq_free, gq_cancel, nullptr, &r);
+    return r;
+}
+
+// bring a pending operation to its end (stream work done / inner request done + copied back)
+int finish(pending& p)
+{
+    int rc = MPI_SUCCESS;
+    if (p.kind == 1) {
+        gkoc_stream_synchronize(stream());
+    } else if (p.kind == 2) {
+        if (p.inner != MPI_REQUEST_NULL) rc = PMPI_Wait(&p.inner, MPI_STATUS_IGNORE);
+        if (p.dev_dst && p.bytes) {
+            gkoc_memcpy_h2d(p.dev_dst, p.host_src, p.bytes, stream());
+            gkoc_stream_synchronize(stream());
+            g_stats[5] += long(p.bytes);
+        }
+        g_host.put(p.host_src);
+        g_host.put(p.host_send);
+    }
+    return rc;
+}
+
+struct span_bytes {
+    size_t lo = 0, hi = 0;     // byte range touched inside a buffer
+};
+
+span_bytes extent(const int* counts, const int* displs, int n, size_t tb)
+{
+    span_bytes s;
+    bool first = true;
+    for (int i = 0; i < n; ++i) {
+        if (counts[i] <= 0) continue;
+        const size_t lo = size_t(displs[i]) * tb, hi = lo + size_t(counts[i]) * tb;
+        if (first || lo < s.lo) s.lo = lo;
+        if (first || hi > s.hi) s.hi = hi;
+        first = false;
+    }
+    return s;
+}
+
+// the all-to-all-v family, blocking or not (request != nullptr), over the peers of `comm`
+int alltoallv_common(const void* sendbuf, const int* scounts, const int* sdispls, MPI_Datatype stype,
+                     void* recvbuf, const int* rcounts, const int* rdispls, MPI_Datatype rtype, MPI_Comm comm,
+                     MPI_Request* request, int n_peers_dense)
+{
+    const bool sdev = is_device(sendbuf), rdev = is_device(recvbuf);
+    if ((!sdev && !rdev) || env_mode() == 3) {
+        g_stats[6]++;
+        return request ? PMPI_Ialltoallv(sendbuf, scounts, sdispls, stype, recvbuf, rcounts, rdispls, rtype, comm,
+                                         request)
+                       : PMPI_Alltoallv(sendbuf, scounts, sdispls, stype, recvbuf, rcounts, rdispls, rtype, comm);
+    }
+    flush_binding();
+    std::lock_guard<std::mutex> g(g_mtx);
+    comm_state& st = state_of(comm);
+    const size_t sb = type_bytes(stype), rb = type_bytes(rtype);
+    const int n = n_peers_dense;
+    if (st.m == mode::rccl && sdev && rdev) {
+        std::vector<int64_t> a(4 * size_t(n));
+        for (int p = 0; p < n; ++p) {
+            a[p] = int64_t(scounts[p]) * int64_t(sb);
+            a[n + p] = int64_t(sdispls[p]) * int64_t(sb);
+            a[2 * n + p] = int64_t(rcounts[p]) * int64_t(rb);
+            a[3 * n + p] = int64_t(rdispls[p]) * int64_t(rb);
+        }
+        if (gkoc_comm_all_to_all_v_bytes(st.rccl, stream(), sendbuf, &a[0], &a[n], recvbuf, &a[2 * n], &a[3 * n]) !=
+            GKOC_OK) {
+            std::fprintf(stderr, "[gkoc_mpi] RCCL all-to-all-v failed: %s\n", gkoc_last_error());
+            return MPI_ERR_OTHER;
+        }
+        g_stats[2]++;
+        if (request) {
+            *request = new_handle();
+            pending p;
+            p.kind = 1;
+            g_pending[*request] = p;
+        } else {
+            gkoc_stream_synchronize(stream());
+        }
+        return MPI_SUCCESS;
+    }
+    // staged: whole touched byte range of each device buffer through pinned memory
+    g_stats[3]++;
+    const span_bytes se = extent(scounts, sdispls, n, sb), re = extent(rcounts, rdispls, n, rb);
+    const void* s_use = sendbuf;
+    void* r_use = recvbuf;
+    void *hs = nullptr, *hr = nullptr;
+    if (sdev && se.hi > se.lo) {
+        hs = g_host.get(se.hi - se.lo);
+        gkoc_memcpy_d2h(hs, static_cast<const char*>(sendbuf) + se.lo, se.hi - se.lo, stream());
+        g_stats[5] += long(se.hi - se.lo);
+        s_use = static_cast<const char*>(hs) - se.lo;
+    }
+    if (rdev && re.hi > re.lo) {
+        hr = g_host.get(re.hi - re.lo);
+        r_use = static_cast<char*>(hr) - re.lo;
+    }
+    if (!request) {
+        int rc = PMPI_Alltoallv(s_use, scounts, sdispls, stype, r_use, rcounts, rdispls, rtype, comm);
+        if (hr) {
+            gkoc_memcpy_h2d(static_cast<char*>(recvbuf) + re.lo, hr, re.hi - re.lo, stream());
+            gkoc_stream_synchronize(stream());
+            g_stats[5] += long(re.hi - re.lo);
+        }
+        g_host.put(hs);
+        g_host.put(hr);
+        return rc;
+    }
+    pending p;
+    p.kind = 2;
+    p.host_send = hs;
+    p.host_src = hr;
+    p.dev_dst = hr ? static_cast<char*>(recvbuf) + re.lo : nullptr;
+    p.bytes = hr ? re.hi - re.lo : 0;
+    int rc = PMPI_Ialltoallv(s_use, scounts, sdispls, stype, r_use, rcounts, rdispls, rtype, comm, &p.inner);
+    *request = new_handle();
+    g_pending[*request] = p;
+    return rc;
+}
+
+// generic staging of one blocking collective: device buffers are replaced by host copies
+struct staged_buf {
+    const void* orig = nullptr;
+    void* host = nullptr;
+    size_t bytes = 0;
+    bool dev = false;
+    staged_buf(const void* p, size_t b, bool copy_in) : orig(p), bytes(b)
+    {
+        dev = is_device(p) && b > 0;
+        if (dev) {
+            host = g_host.get(b);
+            if (copy_in) {
+                gkoc_memcpy_d2h(host, p, b, stream());
+                g_stats[5] += long(b);
+            }
+        }
+    }
+    void* use() const { return dev ? host : const_cast<void*>(orig); }
+    void copy_out()
+    {
+        if (dev) {
+            gkoc_memcpy_h2d(const_cast<void*>(orig), host, bytes, stream());
+            gkoc_stream_synchronize(stream());
+            g_stats[5] += long(bytes);
+        }
+    }
+    ~staged_buf() { g_host.put(host); }
+};
+
+}  // namespace
+
+extern "C" {
+
+// route counters for tests: [rccl all-reduce, staged all-reduce, rccl all-to-all-v, staged
+// all-to-all-v, other staged collectives, bytes copied D2H + H2D, host pass-through]
+void gkoc_mpi_stats(long* out7)
+{
+    std::lock_guard<std::mutex> g(g_mtx);
+    for (int i = 0; i < 7; ++i) out7[i] = g_stats[i];
+}
+
+int MPI_Finalize(void)
+{
+    {
+        std::lock_guard<std::mutex> g(g_mtx);
+        for (auto& kv : g_comms) {
+            if (kv.second.rccl) gkoc_comm_destroy(kv.second.rccl);
+        }
+        g_comms.clear();
+        if (std::getenv("GKOC_MPI_VERBOSE")) {
+            std::fprintf(stderr,
+                         "[gkoc_mpi] all-reduce rccl %ld staged %ld | all-to-all-v rccl %ld staged %ld | other staged "
+                         "%ld | %ld bytes through the host | %ld host calls passed through\n",
+                         g_stats[0], g_stats[1], g_stats[2], g_stats[3], g_stats[4], g_stats[5], g_stats[6]);
+        }
+    }
+    return PMPI_Finalize();
+}
+
+int MPI_Allreduce(const void* sendbuf, void* recvbuf, int count, MPI_Datatype datatype, MPI_Op op, MPI_Comm comm)
+{
+    const bool sdev = is_device(sendbuf), rdev = is_device(recvbuf);
+    if ((!sdev && !rdev) || env_mode() == 3 || count == 0) {
+        g_stats[6]++;
+        return PMPI_Allreduce(sendbuf, recvbuf, count, datatype, op, comm);
+    }
+    flush_binding();
+    std::lock_guard<std::mutex> g(g_mtx);
+    comm_state& st = state_of(comm);
+    int64_t n = 0;
+    const size_t es = rccl_sum_element(datatype, op, count, &n);
+    if (st.m == mode::rccl && es && rdev && (sdev || sendbuf == MPI_IN_PLACE)) {
+        if (sendbuf != MPI_IN_PLACE && sendbuf != recvbuf) {
+            gkoc_memcpy_d2d(recvbuf, sendbuf, size_t(n) * es, stream());
+        }
+        if (gkoc_comm_all_reduce_sum(st.rccl, stream(), recvbuf, n, es) != GKOC_OK) {
+            std::fprintf(stderr, "[gkoc_mpi] RCCL all-reduce failed: %s\n", gkoc_last_error());
+            return MPI_ERR_OTHER;
+        }
+        gkoc_stream_synchronize(stream());
+        g_stats[0]++;
+        return MPI_SUCCESS;
+    }
+    g_stats[1]++;
+    const size_t bytes = size_t(count) * type_bytes(datatype);
+    const bool in_place = sendbuf == MPI_IN_PLACE;
+    staged_buf r(recvbuf, bytes, in_place);
+    if (in_place) {
+        int rc = PMPI_Allreduce(MPI_IN_PLACE, r.use(), count, datatype, op, comm);
+        r.copy_out();
+        return rc;
+    }
+    staged_buf s(sendbuf, bytes, true);
+    int rc = PMPI_Allreduce(s.use(), r.use(), count, datatype, op, comm);
+    r.copy_out();
+    return rc;
+}
+
+int MPI_Iallreduce(const void* sendbuf, void* recvbuf, int count, MPI_Datatype datatype, MPI_Op op, MPI_Comm comm,
+                   MPI_Request* request)
+{
+    if ((!is_device(sendbuf) && !is_device(recvbuf)) || env_mode() == 3) {
+        g_stats[6]++;
+        return PMPI_Iallreduce(sendbuf, recvbuf, count, datatype, op, comm, request);
+    }
+    // device buffers: the blocking route, handed back as an already complete request
+    int rc = MPI_Allreduce(sendbuf, recvbuf, count, datatype, op, comm);
+    std::lock_guard<std::mutex> g(g_mtx);
+    *request = new_handle();
+    pending p;
+    p.kind = 0;
+    g_pending[*request] = p;
+    return rc;
+}
+
+int MPI_Alltoallv(const void* sendbuf, const int* sendcounts, const int* sdispls, MPI_Datatype sendtype,
+                  void* recvbuf, const int* recvcounts, const int* rdispls, MPI_Datatype recvtype, MPI_Comm comm)
+{
+    int n = 0;
+    PMPI_Comm_size(comm, &n);
+    return alltoallv_common(sendbuf, sendcounts, sdispls, sendtype, recvbuf, recvcounts, rdispls, recvtype, comm,
+                            nullptr, n);
+}
+
+int MPI_Ialltoallv(const void* sendbuf, const int* sendcounts, const int* sdispls, MPI_Datatype sendtype,
+                   void* recvbuf, const int* recvcounts, const int* rdispls, MPI_Datatype recvtype, MPI_Comm comm,
+                   MPI_Request* request)
+{
+    int n = 0;
+    PMPI_Comm_size(comm, &n);
+    return alltoallv_common(sendbuf, sendcounts, sdispls, sendtype, recvbuf, recvcounts, rdispls, recvtype, comm,
+                            request, n);
+}
+
+int MPI_Alltoall(const void* sendbuf, int sendcount, MPI_Datatype sendtype, void* recvbuf, int recvcount,
+                 MPI_Datatype recvtype, MPI_Comm comm)
+{
+    if ((!is_device(sendbuf) && !is_device(recvbuf)) || env_mode() == 3) {
+        g_stats[6]++;
+        return PMPI_Alltoall(sendbuf, sendcount, sendtype, recvbuf, recvcount, recvtype, comm);
+    }
+    int n = 0;
+    PMPI_Comm_size(comm, &n);
+    if (sendbuf == MPI_IN_PLACE) {
+        flush_binding();
+        std::lock_guard<std::mutex> g(g_mtx);
+        g_stats[4]++;
+        staged_buf r(recvbuf, size_t(n) * size_t(recvcount) * type_bytes(recvtype), true);
+        int rc = PMPI_Alltoall(MPI_IN_PLACE, sendcount, sendtype, r.use(), recvcount, recvtype, comm);
+        r.copy_out();
+        return rc;
+    }
+    std::vector<int> c(4 * size_t(n));
+    for (int p = 0; p < n; ++p) {
+        c[p] = sendcount;
+        c[n + p] = p * sendcount;
+        c[2 * n + p] = recvcount;
+        c[3 * n + p] = p * recvcount;
+    }
+    return alltoallv_common(sendbuf, &c[0], &c[n], sendtype, recvbuf, &c[2 * n], &c[3 * n], recvtype, comm, nullptr,
+                            n);
+}
+
+int MPI_Allgather(const void* sendbuf, int sendcount, MPI_Datatype sendtype, void* recvbuf, int recvcount,
+                  MPI_Datatype recvtype, MPI_Comm comm)
+{
+    if ((!is_device(sendbuf) && !is_device(recvbuf)) || env_mode() == 3) {
+        g_stats[6]++;
+        return PMPI_Allgather(sendbuf, sendcount, sendtype, recvbuf, recvcount, recvtype, comm);
+    }
+    flush_binding();
+    std::lock_guard<std::mutex> g(g_mtx);
+    g_stats[4]++;
+    int n = 0;
+    PMPI_Comm_size(comm, &n);
+    const bool in_place = sendbuf == MPI_IN_PLACE;
+    staged_buf r(recvbuf, size_t(n) * size_t(recvcount) * type_bytes(recvtype), in_place);
+    int rc;
+    if (in_place) {
+        rc = PMPI_Allgather(MPI_IN_PLACE, sendcount, sendtype, r.use(), recvcount, recvtype, comm);
+    } else {
+        staged_buf s(sendbuf, size_t(sendcount) * type_bytes(sendtype), true);
+        rc = PMPI_Allgather(s.use(), sendcount, sendtype, r.use(), recvcount, recvtype, comm);
+    }
+    r.copy_out();
+    return rc;
+}
+
+int MPI_Bcast(void* buffer, int count, MPI_Datatype datatype, int root, MPI_Comm comm)
+{
+    if (!is_device(buffer) || env_mode() == 3) {
+        g_stats[6]++;
+        return PMPI_Bcast(buffer, count, datatype, root, comm);
+    }
+    flush_binding();
+    std::lock_guard<std::mutex> g(g_mtx);
+    g_stats[4]++;
+    int rank = 0;
+    PMPI_Comm_rank(comm, &rank);
+    staged_buf b(buffer, size_t(count) * type_bytes(datatype), rank == root);
+    int rc = PMPI_Bcast(b.use(), count, datatype, root, comm);
+    if (rank != root) b.copy_out();
+    return rc;
+}
+
+int MPI_Send(const void* buf, int count, MPI_Datatype datatype, int dest, int tag, MPI_Comm comm)
+{
+    if (!is_device(buf) || env_mode() == 3) return PMPI_Send(buf, count, datatype, dest, tag, comm);
+    flush_binding();
+    std::lock_guard<std::mutex> g(g_mtx);
+    g_stats[4]++;
+    staged_buf b(buf, size_t(count) * type_bytes(datatype), true);
+    return PMPI_Send(b.use(), count, datatype, dest, tag, comm);
+}
+
+int MPI_Recv(void* buf, int count, MPI_Datatype datatype, int source, int tag, MPI_Comm comm, MPI_Status* status)
+{
+    if (!is_device(buf) || env_mode() == 3) return PMPI_Recv(buf, count, datatype, source, tag, comm, status);
+    flush_binding();
+    std::lock_guard<std::mutex> g(g_mtx);
+    g_stats[4]++;
+    staged_buf b(buf, size_t(count) * type_bytes(datatype), false);
+    int rc = PMPI_Recv(b.use(), count, datatype, source, tag, comm, status);
+    b.copy_out();
+    return rc;
+}
+
+// neighbourhood collective of NeighborhoodCommunicator: counts per neighbour of the graph topology
+int MPI_Ineighbor_alltoallv(const void* sendbuf, const int* sendcounts, const int* sdispls, MPI_Datatype sendtype,
+                            void* recvbuf, const int* recvcounts, const int* rdispls, MPI_Datatype recvtype,
+                            MPI_Comm comm, MPI_Request* request)
+{
+    if ((!is_device(sendbuf) && !is_device(recvbuf)) || env_mode() == 3) {
+        g_stats[6]++;
+        return PMPI_Ineighbor_alltoallv(sendbuf, sendcounts, sdispls, sendtype, recvbuf, recvcounts, rdispls, recvtype,
+                                        comm, request);
+    }
+    int indeg = 0, outdeg = 0, weighted = 0, n = 0;
+    PMPI_Dist_graph_neighbors_count(comm, &indeg, &outdeg, &weighted);
+    PMPI_Comm_size(comm, &n);
+    std::vector<int> src(indeg ? indeg : 1), dst(outdeg ? outdeg : 1), w(indeg + outdeg + 1);
+    PMPI_Dist_graph_neighbors(comm, indeg, src.data(), w.data(), outdeg, dst.data(), w.data());
+    // dense counts over the ranks of the communicator (a neighbour appears once in Ginkgo's graphs)
+    std::vector<int> c(4 * size_t(n), 0);
+    for (int i = 0; i < outdeg; ++i) {
+        c[dst[i]] = sendcounts[i];
+        c[n + dst[i]] = sdispls[i];
+    }
+    for (int i = 0; i < indeg; ++i) {
+        c[2 * n + src[i]] = recvcounts[i];
+        c[3 * n + src[i]] = rdispls[i];
+    }
+    bool rccl_route;
+    {
+        std::lock_guard<std::mutex> g(g_mtx);
+        rccl_route = state_of(comm).m == mode::rccl && is_device(sendbuf) && is_device(recvbuf);
+    }
+    if (rccl_route) {
+        return alltoallv_common(sendbuf, &c[0], &c[n], sendtype, recvbuf, &c[2 * n], &c[3 * n], recvtype, comm, request,
+                                n);
+    }
+    // staged: keep the neighbourhood call, with host copies of the touched ranges
+    flush_binding();
+    std::lock_guard<std::mutex> g(g_mtx);
+    g_stats[3]++;
+    const size_t sb = type_bytes(sendtype), rb = type_bytes(recvtype);
+    const span_bytes se = extent(sendcounts, sdispls, outdeg, sb), re = extent(recvcounts, rdispls, indeg, rb);
+    const void* s_use = sendbuf;
+    void* r_use = recvbuf;
+    pending p;
+    p.kind = 2;
+    if (is_device(sendbuf) && se.hi > se.lo) {
+        p.host_send = g_host.get(se.hi - se.lo);
+        gkoc_memcpy_d2h(p.host_send, static_cast<const char*>(sendbuf) + se.lo, se.hi - se.lo, stream());
+        g_stats[5] += long(se.hi - se.lo);
+        s_use = static_cast<const char*>(p.host_send) - se.lo;
+    }
+    if (is_device(recvbuf) && re.hi > re.lo) {
+        p.host_src = g_host.get(re.hi - re.lo);
+        p.dev_dst = static_cast<char*>(recvbuf) + re.lo;
+        p.bytes = re.hi - re.lo;
+        r_use = static_cast<char*>(p.host_src) - re.lo;
+    }
+    int rc = PMPI_Ineighbor_alltoallv(s_use, sendcounts, sdispls, sendtype, r_use, recvcounts, rdispls, recvtype, comm,
+                                      &p.inner);
+    *request = new_handle();
+    g_pending[*request] = p;
+    return rc;
+}
+
+static int complete_ours(MPI_Request* request, MPI_Status* status, bool* ours)
+{
+    pending p;
+    {
+        std::lock_guard<std::mutex> g(g_mtx);
+        auto it = g_pending.find(*request);
+        *ours = it != g_pending.end();
+        if (!*ours) return MPI_SUCCESS;
+        p = it->second;
+        g_pending.erase(it);
+        finish(p);
+    }
+    PMPI_Grequest_complete(*request);
+    return PMPI_Wait(request, status);
+}
+
+int MPI_Wait(MPI_Request* request, MPI_Status* status)
+{
+    if (request && *request != MPI_REQUEST_NULL) {
+        bool ours = false;
+        int rc = complete_ours(request, status, &ours);
+        if (ours) return rc;
+    }
+    return PMPI_Wait(request, status);
+}
+
+int MPI_Test(MPI_Request* request, int* flag, MPI_Status* status)
+{
+    if (request && *request != MPI_REQUEST_NULL) {
+        bool ours = false;
+        int rc = complete_ours(request, status, &ours);   // (completing is allowed: it may block)
+        if (ours) {
+            *flag = 1;
+            return rc;
+        }
+    }
+    return PMPI_Test(request, flag, status);
+}
+
+int MPI_Waitall(int count, MPI_Request requests[], MPI_Status statuses[])
+{
+    for (int i = 0; i < count; ++i) {
+        if (requests[i] == MPI_REQUEST_NULL) continue;
+        bool ours = false;
+        complete_ours(&requests[i], statuses == MPI_STATUSES_IGNORE ? MPI_STATUS_IGNORE : &statuses[i], &ours);
+    }
+    return PMPI_Waitall(count, requests, statuses);
+}
+
+int MPI_Request_free(MPI_Request* request)
+{
+    if (request && *request != MPI_REQUEST_NULL) {
+        bool ours = false;
+        int rc = complete_ours(request, MPI_STATUS_IGNORE, &ours);
+        if (ours) return rc;
+    }
+    return PMPI_Request_free(request);
+}
+
+}  // extern "C"

@@ -827,7 +827,28 @@ GKOC_DECL_STENCIL_FILL(float, f32, int64_t, i64)
         int64_t* n_nl_rows_host);
 GKOC_DECL_DIST_IDX(int32_t, i32)
 GKOC_DECL_DIST_IDX(int64_t, i64)
+/* Boundary rows as COMPLETE rows (one column; the fast path of contiguous partitions): the rows
+ * `rows` (= nl_rows of the split) of the owned block with ALL their entries in the original
+ * column order, a column index < n_local = col_hi - col_lo meaning the rank's own vector and
+ * n_local + h halo entry h.  gkoc_csr_rowlist_spmv_full: y[rows[i]] = the k-ordered sum over
+ * that row - the single-domain row sum bit for bit.  These rows need nothing from the local
+ * SpMV: that one is launched over the interior row range only, and this kernel runs on the
+ * exchange's stream right behind the halo, overlapped with it (gkoc_comm_exchange_join). */
+#define GKOC_DECL_DIST_BND_IDX(I, IN)                                          \
+    int gkoc_dist_boundary_count_##IN(gkoc_stream_t s, int64_t n_list,         \
+                                      const I* rows, const I* row_ptrs,        \
+                                      I* out_ptrs, int64_t* nnz_host);
+GKOC_DECL_DIST_BND_IDX(int32_t, i32)
+GKOC_DECL_DIST_BND_IDX(int64_t, i64)
 #define GKOC_DECL_DIST(T, TN, I, IN)                                           \
+    int gkoc_dist_boundary_fill_##TN##_##IN(                                   \
+        gkoc_stream_t s, int64_t n_list, const I* rows, const I* row_ptrs,     \
+        const I* cols, const T* vals, int64_t col_lo, int64_t col_hi,          \
+        const I* col_map, const I* out_ptrs, I* out_cols, T* out_vals);        \
+    int gkoc_csr_rowlist_spmv_full_##TN##_##IN(                                \
+        gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \
+        const I* cols, const T* vals, int64_t n_local, const T* x,             \
+        const T* halo, T* y);                                                  \
     int gkoc_dist_split_fill_##TN##_##IN(                                      \
         gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,     \
         const T* vals, int64_t col_lo, int64_t col_hi, int64_t n_global_cols,  \
@@ -1631,6 +1652,9 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream,
                              const int64_t* send_displs, void* recv_buf,
                              const int64_t* recv_counts, size_t value_size);
 int gkoc_comm_exchange_end(gkoc_comm_t comm, gkoc_stream_t main_stream);
+/* the same, but main_stream also waits for the kernels enqueued on the exchange's stream since
+ * gkoc_comm_exchange_begin (the boundary rows, computed there as soon as the halo is in) */
+int gkoc_comm_exchange_join(gkoc_comm_t comm, gkoc_stream_t main_stream);
 /* MPI_Alltoallv (mpi.hpp all_to_all_v / i_all_to_all_v) in bytes: counts and offsets per peer on
  * both sides, enqueued on s as one grouped send / recv */
 int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* send_buf,

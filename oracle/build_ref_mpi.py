@@ -89,6 +89,52 @@ def main():
         print(f"[build_ref_mpi] link failed:\n{p.stderr[-4000:]}", file=sys.stderr)
         return 1
     print(f"[build_ref_mpi] built {out} in {time.time() - t0:.0f}s")
+    return build_gpu_aware_flavor(ref, objs)
+
+
+def build_gpu_aware_flavor(ref, objs):
+    """The same core once more with GINKGO_HAVE_GPU_AWARE_MPI 1 - what Ginkgo's CMake sets for
+    GINKGO_FORCE_GPU_AWARE_MPI (CMakeLists.txt:185, 410-417) - into oracle/_ref/mpi_ga/:
+    mpi::requires_host_buffer is then false (core/base/mpi.cpp:65-70) and the distributed classes
+    hand DEVICE pointers to MPI, which libgkoc_mpi_rccl.so (ginkgo_amd/gko_binding/mpi_rccl.cpp)
+    routes over RCCL.  The switch is read in exactly one translation unit of the core
+    (core/base/mpi.cpp:69 through mpi.hpp:42-49 is_gpu_aware; `grep -rn is_gpu_aware` over core/,
+    include/), so only that one is compiled again; every other object is the one built above."""
+    ga = os.path.join(REFB, "mpi_ga")
+    for d in ("include/ginkgo", "obj", "lib"):
+        os.makedirs(os.path.join(ga, d), exist_ok=True)
+    cfg = open(os.path.join(OUT, "include", "ginkgo", "config.hpp")).read()
+    assert "#define GINKGO_HAVE_GPU_AWARE_MPI 0" in cfg
+    cfg = cfg.replace("#define GINKGO_HAVE_GPU_AWARE_MPI 0", "#define GINKGO_HAVE_GPU_AWARE_MPI 1")
+    dst = os.path.join(ga, "include", "ginkgo", "config.hpp")
+    if not os.path.exists(dst) or open(dst).read() != cfg:
+        open(dst, "w").write(cfg)
+    rel = "core/base/mpi.cpp"
+    obj = os.path.join(ga, "obj", rel.replace("/", "__") + ".o")
+    if not os.path.exists(obj) or os.path.getmtime(obj) < os.path.getmtime(dst):
+        cmd = ["g++", "-std=c++17", "-O2", "-DNDEBUG", "-fPIC", "-w", "-Dginkgo_EXPORTS",
+               f"-I{ga}/include", f"-I{ref}/include", f"-I{ref}", "-idirafter", f"{MPI_ROOT}/include",
+               "-c", os.path.join(ref, rel), "-o", obj]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode:
+            print(f"[build_ref_mpi] gpu-aware flavor: {rel} failed\n{p.stderr[-4000:]}", file=sys.stderr)
+            return 1
+    plain = os.path.join(OUT, "obj", rel.replace("/", "__") + ".o")
+    use = [o for o in objs if os.path.abspath(o) != os.path.abspath(plain)] + [obj]
+    assert len(use) == len(objs), "core/base/mpi.cpp is not among the core objects"
+    for so in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):
+        if not os.path.exists(os.path.join(ga, "lib", so)):
+            shutil.copy(os.path.join(OUT, "lib", so), os.path.join(ga, "lib", so))
+    out = os.path.join(ga, "lib", "libginkgo.so")
+    cmd = ["g++", "-shared", "-fPIC", "-o", out, "-Wl,-soname,libginkgo.so",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../../lib"] + sorted(use) + \
+        [f"-L{REFB}/lib", "-lginkgo_omp", "-lginkgo_cuda", "-lginkgo_reference", "-lginkgo_hip",
+         "-lginkgo_dpcpp", "-lginkgo_device", os.path.join(ga, "lib", "libmpi.so.12"), "-fopenmp"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        print(f"[build_ref_mpi] gpu-aware flavor: link failed:\n{p.stderr[-4000:]}", file=sys.stderr)
+        return 1
+    print(f"[build_ref_mpi] built {out} (GINKGO_HAVE_GPU_AWARE_MPI 1)")
     return 0
 
 

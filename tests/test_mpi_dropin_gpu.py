@@ -36,6 +36,67 @@ def test_distributed_matrix_vector_cg_vs_reference(ranks, grid):
     assert m and float(m.group(1)) == 0.0, p.stdout
 
 
+BIN_GA = os.path.join(ROOT, "oracle", "_ref", "mpi_ga", "bin")
+
+
+def _routes(out):
+    m = re.search(r"gkoc_mpi routes: all-reduce rccl (\d+) staged (\d+), all-to-all-v rccl (\d+) staged (\d+), "
+                  r"other staged (\d+), bytes through the host (\d+), host calls (\d+)", out)
+    assert m, out[-2000:]
+    return dict(zip(("ar_rccl", "ar_staged", "a2a_rccl", "a2a_staged", "other", "host_bytes", "host_calls"),
+                    map(int, m.groups())))
+
+
+def _need_ga():
+    if not os.path.exists(os.path.join(BIN_GA, "mpi_dist_test")) or not os.path.exists(MPIEXEC):
+        pytest.skip("the GPU-aware flavor (oracle/_ref/mpi_ga) has not been built, or no mpiexec")
+
+
+@pytest.mark.parametrize("ranks,grid", [(2, 24), (3, 20)])
+def test_gpu_aware_core_hands_device_pointers_to_the_mpi_layer(ranks, grid):
+    """The core built with GINKGO_HAVE_GPU_AWARE_MPI 1 (Ginkgo's GINKGO_FORCE_GPU_AWARE_MPI): no host
+    staging inside Ginkgo, device pointers reach MPI_Allreduce / MPI_Ialltoallv, where
+    libgkoc_mpi_rccl.so (ginkgo_amd/gko_binding/mpi_rccl.cpp) takes them.  The ranks share GPU 0
+    here, so the layer stages through pinned memory itself (RCCL refuses two ranks on a device);
+    same results as the host-staged flavor, read_distributed on the device included."""
+    _need_ga()
+    p = subprocess.run([MPIEXEC, "-n", str(ranks), "./mpi_dist_test", str(grid)], cwd=BIN_GA,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "GPU-aware MPI: 1" in p.stdout
+    assert "ALL PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
+    r = _routes(p.stdout)
+    assert r["ar_staged"] > 0 and r["a2a_staged"] > 0 and r["ar_rccl"] == 0 and r["a2a_rccl"] == 0, r
+    m = re.search(r"distributed::Matrix::apply, 2 right-hand sides.*\(([\d.e+-]+)\)", p.stdout)
+    assert m and float(m.group(1)) == 0.0, p.stdout
+
+
+def test_mpi_layer_routes_device_buffers_over_rccl():
+    """One rank with GKOC_MPI_MODE=rccl: every device buffer of Ginkgo's own MPI calls (the
+    all-reduces of the distributed Vector, the all-to-all-v of the RowGatherer) goes through a real
+    RCCL communicator of the layer and NOT A BYTE through the host - what each rank of a
+    one-GPU-per-rank run does, minus the peers."""
+    _need_ga()
+    env = dict(os.environ, GKOC_MPI_MODE="rccl")
+    p = subprocess.run([MPIEXEC, "-n", "1", "./mpi_dist_test", "20"], cwd=BIN_GA, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "ALL PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
+    r = _routes(p.stdout)
+    assert r["ar_rccl"] > 0 and r["ar_staged"] == 0 and r["a2a_staged"] == 0 and r["host_bytes"] == 0, r
+
+
+def test_ginkgos_distributed_solver_example_gpu_aware():
+    """Ginkgo's examples/distributed-solver, unmodified, on the GPU-aware core + the MPI layer"""
+    _need_ga()
+    p = subprocess.run([MPIEXEC, "-n", "2", "./distributed-solver", "hip", "2000"], cwd=BIN_GA,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    its = int(re.search(r"Iteration count: (\d+)", p.stdout).group(1))
+    res = float(re.search(r"Final Res norm: ([\d.e+-]+)", p.stdout).group(1))
+    assert res < 1e-6 and 100 < its < 200, (its, res)
+
+
 def test_ginkgos_distributed_solver_example():
     """examples/distributed-solver/distributed-solver.cpp, unmodified: same iteration count on
     `hip` (this backend) and `reference`"""
