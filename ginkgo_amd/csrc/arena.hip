@@ -39,9 +39,11 @@
 // GKOC_ARENA_GRANULE_MB (default and minimum 1024, power of two).  Fresh device
 // memory costs about 30 ms per GiB whoever asks for it (the driver clears it).
 // Bounds (a search must never eat the device): one search for a granule of a wanted class
-// creates at most GKOC_ARENA_MAX_WALK granules (default 24, i.e. < 1 s); if the FIRST THREE
-// classes do not show up within that bound the arena settles for the classes it has (two:
-// vectors apart from the matrix arrays; one: mode 1).  At most GKOC_ARENA_SPARE_MB (default
+// creates at most GKOC_ARENA_MAX_WALK granules (default 128: the driver hands out a class in runs
+// of up to 64 GiB and more - 83 granules were needed on one box - about 4 s in the worst
+// case, ONCE per process, and only on the part the layout was measured on); if the three classes
+// do not show up within that bound the arena settles for the classes it has (two: vectors apart
+// from the matrix arrays; one: mode 1).  At most GKOC_ARENA_SPARE_MB (default
 // 8192) wait in the pools; gkoc_arena_trim() releases the pools AND the trailing free granules
 // of every region (their addresses are retired, never mapped again).
 // Peer access: granules are mapped for the owning device only; GKOC_ARENA_PEER_ACCESS=1 also
@@ -134,6 +136,7 @@ struct span {
 
 struct region : span {
     size_t reserved = 0;                                    // bytes of virtual address space
+    std::map<size_t, size_t> req;                           // offset -> bytes the caller asked for
     size_t retired = 0;        // bytes of [0, size) whose granules went back to the driver (trim)
     size_t tail_retired = 0;   // the part of them that sits at the very end of [0, size)
     std::vector<hipMemGenericAllocationHandle_t> granules;  // mapped back to back from base
@@ -154,7 +157,10 @@ struct device_arena {
     size_t scratch_left = 0;
     hipStream_t stream = nullptr;
     std::vector<hipMemGenericAllocationHandle_t> spare[max_classes];   // classified, unmapped
-    size_t max_large = 0;         // largest live large request (role heuristic)
+    // role heuristic of gkoc_malloc: sizes (as requested) of arrays that kernels have been seen
+    // to WRITE as vectors (gkoc_arena_note_vector), newest last, a handful at most
+    std::vector<size_t> vector_sizes;
+    int64_t misplaced = 0;        // gkoc_arena_note_vector found a written vector next to matrix arrays
     int64_t probes = 0, walked = 0;
 };
 
@@ -165,7 +171,7 @@ size_t g_granule_bytes = 0, g_spare_bytes = 0;
 int g_sync_free = 1;
 int g_verbose = 0;
 int g_peer_access = 0;
-int g_max_walk = 24;
+int g_max_walk = 128;
 bool g_mode_from_env = false;
 device_arena g_arena[64];
 
@@ -187,7 +193,7 @@ void read_env_locked()
     const char* pa = std::getenv("GKOC_ARENA_PEER_ACCESS");
     g_peer_access = pa ? std::atoi(pa) : 0;
     const char* lim = std::getenv("GKOC_ARENA_MAX_WALK");
-    g_max_walk = lim ? std::atoi(lim) : 24;
+    g_max_walk = lim ? std::atoi(lim) : 128;
     if (g_max_walk < 1) g_max_walk = 1;
     const char* sf = std::getenv("GKOC_ARENA_SYNC_FREE");
     g_sync_free = sf ? std::atoi(sf) : 1;
@@ -494,18 +500,54 @@ bool ensure_class(device_arena& A, int dev, int cls)
     return A.n_cls > cls;
 }
 
+// Does a request of `bytes` look like a vector (or a block of vectors: a Krylov basis, a
+// multi-vector) of a system whose vectors the kernels have already been seen to write?
+bool vector_shaped(const device_arena& A, size_t bytes)
+{
+    for (size_t v : A.vector_sizes) {
+        if (v > 0 && bytes % v == 0 && bytes / v <= 4096) return true;
+    }
+    return false;
+}
+
+// Where a request goes.  An explicit role has its class (values 0, indices 1, vectors 2).
+// gkoc_malloc / HipExecutor::raw_alloc know no role (Ginkgo's raw_alloc has no such argument); what
+// matters is that arrays kernels WRITE do not share a class with the big read-only streams of the
+// kernels that write them.  Rule, evaluated against the allocations that are live
+// NOW (so that what was allocated first is re-judged once the matrix shows up):
+//   * a live or requested array is "small" (a vector) if it is vector-shaped (see above) or smaller
+//     than a quarter of the largest live one, "big" (a matrix array) otherwise;
+//   * a big request goes to the class that holds the fewest small bytes, then the fewest big ones;
+//   * a small request goes to the class that holds the fewest big bytes, then the most small ones.
+// A matrix first: values 0, indices 1, vectors 2 (as with explicit roles).  Vectors first (b, x
+// before A): they spread over two classes while nothing else is known, the matrix arrays then
+// share the third one - no written stream next to a matrix array.  A Krylov basis (a multiple of
+// a vector the kernels have written) joins the vectors although it is the largest request.
 int class_for_role(const device_arena& A, int role, size_t bytes)
 {
-    if (role == GKOC_MEM_AUTO) {
-        // matrix arrays are the largest requests of a solve: at least a quarter of the
-        // largest live one counts as a matrix array, anything smaller as a vector
-        if (bytes * 4 >= A.max_large) {
-            role = A.reg[0].in_use <= A.reg[1].in_use ? GKOC_MEM_VALUES : GKOC_MEM_INDICES;
-        } else {
-            role = GKOC_MEM_VECTOR;
+    if (role != GKOC_MEM_AUTO) return role == GKOC_MEM_VALUES ? 0 : role == GKOC_MEM_INDICES ? 1 : 2;
+    size_t largest = bytes;
+    for (int k = 0; k < max_classes; ++k) {
+        for (const auto& u : A.reg[k].req) largest = std::max(largest, u.second);
+    }
+    auto is_small = [&](size_t b) { return vector_shaped(A, b) || b * 4 < largest; };
+    size_t big_b[max_classes] = {}, small_b[max_classes] = {};
+    for (int k = 0; k < max_classes; ++k) {
+        for (const auto& u : A.reg[k].req) (is_small(u.second) ? small_b[k] : big_b[k]) += u.second;
+    }
+    int best = 0;
+    if (!is_small(bytes)) {
+        for (int k = 1; k < max_classes; ++k) {
+            if (small_b[k] < small_b[best] || (small_b[k] == small_b[best] && big_b[k] < big_b[best])) best = k;
+        }
+    } else {
+        // (ties: the highest class, where explicit roles put vectors)
+        best = max_classes - 1;
+        for (int k = max_classes - 2; k >= 0; --k) {
+            if (big_b[k] < big_b[best] || (big_b[k] == big_b[best] && small_b[k] > small_b[best])) best = k;
         }
     }
-    return role == GKOC_MEM_VALUES ? 0 : role == GKOC_MEM_INDICES ? 1 : 2;
+    return best;
 }
 
 int span_list_malloc(std::vector<span*>& list, size_t chunk_bytes, void** ptr, size_t need,
@@ -614,7 +656,7 @@ int arena_malloc(void** ptr, size_t bytes, int role)
         region& R = A.reg[cls];
         if (void* p = R.take(need, align)) {
             *ptr = p;
-            if (need > A.max_large) A.max_large = need;
+            R.req[size_t(static_cast<char*>(p) - R.base)] = bytes;
             return GKOC_OK;
         }
         const size_t tail = R.tail_retired ? 0 : R.free_tail();
@@ -622,7 +664,7 @@ int arena_malloc(void** ptr, size_t bytes, int role)
         if (extend_region(A, dev, cls, count) == hipSuccess) {
             if (void* p = R.take(need, align)) {
                 *ptr = p;
-                if (need > A.max_large) A.max_large = need;
+                R.req[size_t(static_cast<char*>(p) - R.base)] = bytes;
                 return GKOC_OK;
             }
         }
@@ -655,7 +697,10 @@ static int arena_free_impl(void* ptr, bool sync)
             int r = span_list_free(A.small, ptr, small_chunk, false);
             if (r == 0) r = span_list_free(A.plain, ptr, g_chunk_bytes, true);
             for (int k = 0; r == 0 && k < A.n_cls; ++k) {
-                if (A.reg[k].owns(ptr)) r = A.reg[k].give(ptr) ? 1 : GKOC_E_INVALID;
+                if (A.reg[k].owns(ptr)) {
+                    r = A.reg[k].give(ptr) ? 1 : GKOC_E_INVALID;
+                    if (r == 1) A.reg[k].req.erase(size_t(static_cast<char*>(ptr) - A.reg[k].base));
+                }
             }
             if (r < 0) {
                 set_last_error("gkoc_free: %p is inside the arena but not the start of an "
@@ -807,6 +852,50 @@ int gkoc_arena_class_of(const void* ptr, int* cls)
     for (int k = 0; k < A.n_cls; ++k) {
         if (A.reg[k].owns(ptr)) *cls = k;
     }
+    return GKOC_OK;
+}
+
+// A kernel has written the array that holds ptr as a VECTOR (the output of an SpMV): requests of
+// that size, or of a multiple of it (a Krylov basis, several right-hand sides), are vectors from
+// now on whatever their size relative to the matrix (class_for_role).  Called by the Ginkgo
+// binding; cheap (a map look-up under the arena's lock).
+int gkoc_arena_note_vector(const void* ptr)
+{
+    if (!ptr) return GKOC_OK;
+    std::lock_guard<std::mutex> g(g_mtx);
+    device_arena& A = g_arena[current_device()];
+    for (int k = 0; k < A.n_cls; ++k) {
+        region& R = A.reg[k];
+        if (!R.owns(ptr)) continue;
+        const size_t off = size_t(static_cast<const char*>(ptr) - R.base);
+        auto it = R.req.upper_bound(off);
+        if (it == R.req.begin()) return GKOC_OK;
+        --it;
+        const size_t bytes = it->second;
+        if (off >= it->first + bytes) return GKOC_OK;
+        for (size_t v : A.vector_sizes) {
+            if (v == bytes) return GKOC_OK;
+        }
+        // a written vector that sits in a class with arrays at least four times its size
+        for (const auto& u : R.req) {
+            if (u.second >= 4 * bytes) {
+                ++A.misplaced;
+                break;
+            }
+        }
+        if (A.vector_sizes.size() >= 8) A.vector_sizes.erase(A.vector_sizes.begin());
+        A.vector_sizes.push_back(bytes);
+        return GKOC_OK;
+    }
+    return GKOC_OK;
+}
+
+int gkoc_arena_role_stats(int64_t* n_vector_sizes, int64_t* misplaced_vectors)
+{
+    std::lock_guard<std::mutex> g(g_mtx);
+    const device_arena& A = g_arena[current_device()];
+    if (n_vector_sizes) *n_vector_sizes = int64_t(A.vector_sizes.size());
+    if (misplaced_vectors) *misplaced_vectors = A.misplaced;
     return GKOC_OK;
 }
 

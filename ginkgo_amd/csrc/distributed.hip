@@ -215,30 +215,20 @@ __global__ __launch_bounds__(256) void boundary_fill_kernel(
     }
 }
 
+// No LDS on purpose: this kernel runs NEXT TO the local SpMV, whose waves fill the LDS of every
+// CU (8 KB each, 20 per CU); a workgroup that needed 24 KB of staging space would only be
+// dispatched once the SpMV has drained (measured: 181 us serialised against 159 us).  Lane = row,
+// the row's entries are consecutive, so a lane re-uses each 64-byte line of values / columns it
+// touches; the halo and the own vector are gathered.
 template <typename T, typename I>
-__global__ __launch_bounds__(64) void csr_rowlist_full_kernel(
+__global__ __launch_bounds__(256) void csr_rowlist_full_kernel(
     int64_t n_list, const I* __restrict__ rows, const I* __restrict__ ptrs,
     const I* __restrict__ cols, const T* __restrict__ vals, int64_t n_local,
     const T* __restrict__ x, const T* __restrict__ halo, T* __restrict__ y)
 {
-    __shared__ T lv[rl_stage_cap];
-    __shared__ I lc[rl_stage_cap];
-    const int lane = threadIdx.x;
-    const int64_t first = int64_t(blockIdx.x) * 64;
-    const int64_t i = first + lane;
-    const bool valid = i < n_list;
-    const int64_t last = first + 64 < n_list ? first + 64 : n_list;
-    const int64_t K0 = ptrs[first], K1 = ptrs[last];
-    const int64_t ks = ptrs[valid ? i : last], ke = ptrs[valid ? i + 1 : last];
-    const bool staged = K1 - K0 <= rl_stage_cap;
-    if (staged) {
-        for (int t = lane; t < int(K1 - K0); t += 64) {
-            lv[t] = vals[K0 + t];
-            lc[t] = cols[K0 + t];
-        }
-        wave_lds_sync();
-    }
-    if (!valid) return;
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n_list) return;
+    const int64_t ks = ptrs[i], ke = ptrs[i + 1];
     const int64_t row = rows[i];
     T sum = T(0);
     int64_t k = ks;
@@ -246,17 +236,16 @@ __global__ __launch_bounds__(64) void csr_rowlist_full_kernel(
         T v[9], h[9];
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
-            v[u] = staged ? lv[k + u - K0] : vals[k + u];
-            const int64_t c = staged ? lc[k + u - K0] : cols[k + u];
+            v[u] = vals[k + u];
+            const int64_t c = cols[k + u];
             h[u] = c < n_local ? x[c] : halo[c - n_local];
         }
 #pragma unroll
         for (int u = 0; u < 9; ++u) sum += v[u] * h[u];
     }
     for (; k < ke; ++k) {
-        const T v = staged ? lv[k - K0] : vals[k];
-        const int64_t c = staged ? lc[k - K0] : cols[k];
-        sum += v * (c < n_local ? x[c] : halo[c - n_local]);
+        const int64_t c = cols[k];
+        sum += vals[k] * (c < n_local ? x[c] : halo[c - n_local]);
     }
     y[row] = sum;
 }
@@ -429,7 +418,7 @@ GKOC_DEF_DIST_BND_IDX(int64_t, i64)
         GKOC_REQUIRE(rows && ptrs && x && halo && y, GKOC_E_INVALID,           \
                      "null pointer");                                          \
         csr_rowlist_full_kernel<T, I>                                          \
-            <<<dim3(unsigned(ceildiv(n_list, 64))), dim3(64), 0,               \
+            <<<dim3(unsigned(ceildiv(n_list, 256))), dim3(256), 0,             \
                as_stream(s)>>>(n_list, rows, ptrs, cols, vals, n_local, x,     \
                                halo, y);                                       \
         GKOC_LAUNCH_OK();                                                      \

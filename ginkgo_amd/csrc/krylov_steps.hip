@@ -777,6 +777,171 @@ int launch_pipe_cg_step1_dots(gkoc_stream_t s, int64_t n, T* x, T* r, T* z, T* w
     return GKOC_OK;
 }
 
+// pipe_cg::step_2 of iteration k AND step_1 of iteration k + 1 (pipe_cg.cpp:247-262, then :196-203)
+// with the three reductions that follow: nothing sits between the two element-wise steps but the
+// host's (lagged) look at the stopping criterion, and both are masked by stop_status on the device.
+//   t2 = rho / prev_rho ; beta' = delta - |t2|^2 beta (delta if that is 0; delta and plain copies if
+//   prev_rho == 0) ; p = z + t2 p ; q = w + t2 q ; f = m + t2 f ; g = n + t2 g          (step_2)
+//   t1 = rho / beta' ; x += t1 p ; r -= t1 q ; z -= t1 f ; w -= t1 g                      (step_1)
+//   partials of <r, z>, <w, z>, <r, r>
+// Ten vectors in, eight out (144 B per row; the two kernels it replaces: 96 + 96).  Every element
+// goes through the expressions of op_pipe_cg_step2 / op_pipe_cg_step1 in the same order, so the
+// vectors are bit-identical to the two kernels.  beta is read from beta_in by every thread and
+// written to beta_out (another address: the caller alternates two) by one.
+template <typename T>
+__global__ __launch_bounds__(256) void pipe_cg_step2_step1_dots_kernel(
+    int64_t n, T* __restrict__ x, T* __restrict__ r, T* __restrict__ z, T* __restrict__ w,
+    T* __restrict__ p, T* __restrict__ q, T* __restrict__ f, T* __restrict__ g,
+    const T* __restrict__ m, const T* __restrict__ nv, const T* __restrict__ prev_rho,
+    const T* __restrict__ rho, const T* __restrict__ delta, const T* __restrict__ beta_in,
+    T* __restrict__ beta_out, const uint8_t* __restrict__ stop, T* __restrict__ partial,
+    int64_t pstride, bool vec_ok)
+{
+    __shared__ T lds[4];
+    using V = vec16<T>;
+    constexpr int W = V::width;
+    const bool stopped = status_has_stopped(stop[0]);
+    const T pr = prev_rho[0];
+    const bool plain = pr == T(0);
+    const T t2 = plain ? T(0) : rho[0] / pr;
+    T bnew = beta_in[0];
+    if (!stopped) {
+        if (plain) {
+            bnew = delta[0];
+        } else {
+            const T a = fabs(t2);
+            bnew = delta[0] - a * a * beta_in[0];
+            if (bnew == T(0)) bnew = delta[0];
+        }
+    }
+    // step_1 of the next iteration: a no-op if beta' is zero or the column has stopped
+    const bool noop1 = bnew == T(0) || stopped;
+    const T t1 = noop1 ? T(0) : rho[0] / bnew;
+    const int64_t tid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (tid == 0) beta_out[0] = bnew;
+    const int64_t nthreads = int64_t(gridDim.x) * 256;
+    T a_rz = T(0), a_wz = T(0), a_rr = T(0);
+    int64_t done = 0;
+    if (vec_ok) {
+        const int64_t n_vec = n / W;
+        for (int64_t i = tid; i < n_vec; i += nthreads) {
+            V rv = reinterpret_cast<const V*>(r)[i];
+            V zv = reinterpret_cast<const V*>(z)[i];
+            V wv = reinterpret_cast<const V*>(w)[i];
+            if (!stopped) {
+                V pv = reinterpret_cast<const V*>(p)[i];
+                V qv = reinterpret_cast<const V*>(q)[i];
+                V fv = reinterpret_cast<const V*>(f)[i];
+                V gv = reinterpret_cast<const V*>(g)[i];
+                const V mv = reinterpret_cast<const V*>(m)[i];
+                const V nn = reinterpret_cast<const V*>(nv)[i];
+                V xv = reinterpret_cast<const V*>(x)[i];
+#pragma unroll
+                for (int e = 0; e < W; ++e) {
+                    pv.v[e] = plain ? zv.v[e] : zv.v[e] + t2 * pv.v[e];
+                    qv.v[e] = plain ? wv.v[e] : wv.v[e] + t2 * qv.v[e];
+                    fv.v[e] = plain ? mv.v[e] : mv.v[e] + t2 * fv.v[e];
+                    gv.v[e] = plain ? nn.v[e] : nn.v[e] + t2 * gv.v[e];
+                }
+                reinterpret_cast<V*>(p)[i] = pv;
+                reinterpret_cast<V*>(q)[i] = qv;
+                reinterpret_cast<V*>(f)[i] = fv;
+                reinterpret_cast<V*>(g)[i] = gv;
+                if (!noop1) {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) {
+                        xv.v[e] = xv.v[e] + t1 * pv.v[e];
+                        rv.v[e] = rv.v[e] - t1 * qv.v[e];
+                        zv.v[e] = zv.v[e] - t1 * fv.v[e];
+                        wv.v[e] = wv.v[e] - t1 * gv.v[e];
+                    }
+                    reinterpret_cast<V*>(x)[i] = xv;
+                    reinterpret_cast<V*>(r)[i] = rv;
+                    reinterpret_cast<V*>(z)[i] = zv;
+                    reinterpret_cast<V*>(w)[i] = wv;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                a_rz += rv.v[e] * zv.v[e];
+                a_wz += wv.v[e] * zv.v[e];
+                a_rr += rv.v[e] * rv.v[e];
+            }
+        }
+        done = n_vec * W;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) {
+        T rv = r[i], zv = z[i], wv = w[i];
+        if (!stopped) {
+            const T pv = plain ? zv : zv + t2 * p[i];
+            const T qv = plain ? wv : wv + t2 * q[i];
+            const T fv = plain ? m[i] : m[i] + t2 * f[i];
+            const T gv = plain ? nv[i] : nv[i] + t2 * g[i];
+            p[i] = pv;
+            q[i] = qv;
+            f[i] = fv;
+            g[i] = gv;
+            if (!noop1) {
+                x[i] = x[i] + t1 * pv;
+                rv = rv - t1 * qv;
+                zv = zv - t1 * fv;
+                wv = wv - t1 * gv;
+                r[i] = rv;
+                z[i] = zv;
+                w[i] = wv;
+            }
+        }
+        a_rz += rv * zv;
+        a_wz += wv * zv;
+        a_rr += rv * rv;
+    }
+    const T s0 = block_sum<256>(a_rz, lds);
+    __syncthreads();
+    const T s1 = block_sum<256>(a_wz, lds);
+    __syncthreads();
+    const T s2 = block_sum<256>(a_rr, lds);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s0;
+        partial[pstride + blockIdx.x] = s1;
+        partial[2 * pstride + blockIdx.x] = s2;
+    }
+}
+
+template <typename T>
+int launch_pipe_cg_step2_step1_dots(gkoc_stream_t s, int64_t n, T* x, T* r, T* z, T* w, T* p, T* q, T* f,
+                                    T* g, const T* m, const T* nv, const T* prev_rho, const T* rho,
+                                    const T* delta, const T* beta_in, T* beta_out, const uint8_t* stop,
+                                    T* out3, void* work, size_t work_bytes)
+{
+    GKOC_REQUIRE(n >= 0 && out3, GKOC_E_INVALID, "bad argument");
+    GKOC_REQUIRE(beta_in && beta_out && beta_in != beta_out, GKOC_E_INVALID,
+                 "beta_in and beta_out must be two different scalars");
+    if (n == 0) {
+        GKOC_HIP(hipMemsetAsync(out3, 0, 3 * sizeof(T), as_stream(s)));
+        return GKOC_OK;
+    }
+    GKOC_REQUIRE(x && r && z && w && p && q && f && g && m && nv && prev_rho && rho && delta && stop && work,
+                 GKOC_E_INVALID, "null pointer");
+    constexpr int64_t max_blocks = 1024;
+    GKOC_REQUIRE(work_bytes >= size_t(3 * max_blocks) * sizeof(T), GKOC_E_WORKSPACE,
+                 "workspace too small (gkoc_x_workspace_bytes)");
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(r) |
+                           reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(w) |
+                           reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(q) |
+                           reinterpret_cast<uintptr_t>(f) | reinterpret_cast<uintptr_t>(g) |
+                           reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(nv);
+    int64_t nb = ceildiv(n, int64_t(256) * vec16<T>::width * 2);
+    if (nb > max_blocks) nb = max_blocks;
+    T* partial = static_cast<T*>(work);
+    pipe_cg_step2_step1_dots_kernel<T><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(
+        n, x, r, z, w, p, q, f, g, m, nv, prev_rho, rho, delta, beta_in, beta_out, stop, partial, max_blocks,
+        bits % 16 == 0);
+    GKOC_LAUNCH_OK();
+    fold_rows_kernel<T><<<dim3(3), dim3(1024), 0, as_stream(s)>>>(nb, max_blocks, partial, out3);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
 #define GKOC_DEF_KRYLOV(T, TN)                                                            \
     /* ------------------------------------------------------------ bicgstab */           \
     extern "C" int gkoc_bicgstab_initialize_##TN(                                         \
@@ -982,6 +1147,16 @@ int launch_pipe_cg_step1_dots(gkoc_stream_t s, int64_t n, T* x, T* r, T* z, T* w
         return launch_elementwise<T, op_pipe_cg_step2<T>, 8, 4>(                          \
             s, rows, cols, o.a,                                                           \
             op_pipe_cg_step2<T>{prev_rho, rho, delta, beta, stop_status}, false);         \
+    }                                                                                     \
+    extern "C" int gkoc_x_pipe_cg_step_2_step_1_dots_##TN(                                \
+        gkoc_stream_t s, int64_t rows, T* x, T* r, T* z, T* w, T* p, T* q, T* f, T* g,    \
+        const T* m, const T* n, const T* prev_rho, const T* rho, const T* delta,          \
+        const T* beta_in, T* beta_out, const uint8_t* stop_status, T* out3, void* work,   \
+        size_t work_bytes)                                                                \
+    {                                                                                     \
+        return launch_pipe_cg_step2_step1_dots<T>(s, rows, x, r, z, w, p, q, f, g, m, n,  \
+                                                  prev_rho, rho, delta, beta_in, beta_out, \
+                                                  stop_status, out3, work, work_bytes);   \
     }                                                                                     \
     extern "C" int gkoc_x_pipe_cg_step_1_dots_##TN(                                       \
         gkoc_stream_t s, int64_t rows, T* x, T* r, T* z, T* w, const T* p, const T* q,    \

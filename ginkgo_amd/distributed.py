@@ -237,6 +237,10 @@ class RcclComm(TorchComm):
     def exchange_end(self):
         call("gkoc_comm_exchange_end", self._handle, self.exec.stream)
 
+    def exchange_join(self):
+        """exchange_end that also waits for the kernels enqueued on the side stream behind the halo"""
+        call("gkoc_comm_exchange_join", self._handle, self.exec.stream)
+
     def all_to_all_v(self, recv, send, recv_counts, send_counts, async_op=False):
         if self.size == 1 or not send.is_cuda or not send.dtype.is_floating_point:
             return super().all_to_all_v(recv, send, recv_counts, send_counts, async_op)
@@ -461,6 +465,26 @@ class HipBackend:
         self.placement_log = local.memory_classes() if nnz_l > 0 else None
         nl = dict(rows=nl_rows, ptrs=nl_ptrs, cols=nl_cols, vals=nl_vals, n=n_nl_rows,
                   suffix=f"{vt}_{it}")
+        # Contiguous partitions of stencil-like matrices: the rows with non-local entries are the
+        # first k and the last m local rows.  They are kept a second time as COMPLETE rows (own
+        # and halo columns in the original order), so that the local SpMV can leave them out and
+        # they can be computed on the exchange's stream as soon as the halo is in
+        # (DistributedMatrix.apply, gkoc_csr_rowlist_spmv_full_*).
+        if n_nl_rows > 0:
+            rows_h = nl_rows.cpu().numpy().astype(np.int64)
+            k = int(np.searchsorted(rows_h, n // 2)) if n > 1 else n_nl_rows
+            head, tail = rows_h[:k], rows_h[k:]
+            if np.array_equal(head, np.arange(len(head))) and \
+                    np.array_equal(tail, np.arange(n - len(tail), n)):
+                f_ptrs = ex.alloc((n_nl_rows + 1,), idt)
+                nnz_f = C.c_int64(0)
+                call("gkoc_dist_boundary_count_" + it, ex.stream, n_nl_rows, nl_rows, a.row_ptrs, f_ptrs,
+                     C.byref(nnz_f))
+                f_cols, f_vals = ex.alloc((nnz_f.value,), idt), ex.alloc((nnz_f.value,), a.dtype)
+                call(f"gkoc_dist_boundary_fill_{vt}_{it}", ex.stream, n_nl_rows, nl_rows, a.row_ptrs,
+                     a.col_idxs, a.values, col_lo, col_hi, col_map, f_ptrs, f_cols, f_vals)
+                nl["full"] = dict(ptrs=f_ptrs, cols=f_cols, vals=f_vals, n_local=col_hi - col_lo,
+                                  interior=(len(head), n - len(tail)))
         return local, nl, recv_gidx
 
     def to_host(self, t):
@@ -479,6 +503,26 @@ class HipBackend:
             call("gkoc_csr_rowlist_spmv_add_" + nl["suffix"], self.exec.stream, nl["n"],
                  nl["rows"], nl["ptrs"], nl["cols"], nl["vals"], halo.values, halo.ld,
                  y.values, y.ld, y.size[1])
+
+    def spmv_rows(self, a, r0, r1, x, y):
+        """y[r0:r1] = A[r0:r1, :] x  (the interior rows of a slab: a CSR over the same value /
+        column arrays whose row pointers start at row r0)"""
+        if r1 <= r0:
+            return
+        key = ("rows", r0, r1, y.values.data_ptr())
+        view = a.__dict__.setdefault("_row_views", {}).get(key)
+        if view is None:
+            sub = Csr(self.exec, (r1 - r0, a.size[1]), a.values, a.col_idxs, a.row_ptrs[r0:r1 + 1])
+            view = a._row_views[key] = (sub, Dense(self.exec, y.values[r0:r1]))
+        view[0].apply(x, view[1])
+
+    def rowlist_full(self, nl, x, halo, y, stream=None):
+        """y[boundary rows] = their complete row sums over [x | halo]; on `stream` (the
+        exchange's stream) when given"""
+        f = nl["full"]
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else self.exec.stream
+        call("gkoc_csr_rowlist_spmv_full_" + nl["suffix"], st, nl["n"], nl["rows"], f["ptrs"],
+             f["cols"], f["vals"], f["n_local"], x.values, halo.values, y.values)
 
     def spmv_dot(self, a, x, y, out):
         """y = A_local x and out = local <x, y> in one pass; False if there is no such kernel
@@ -545,6 +589,19 @@ class HipBackend:
         call("gkoc_x_pipe_cg_step_1_dots_" + VT[x.dtype], self.exec.stream, x.size[0], x.values,
              r.values, z.values, w.values, p.values, q.values, f.values, g.values, rho.values,
              beta.values, stop, out3, wk, wb)
+        return True
+
+    def pipe_cg_step_2_step_1_dots(self, x, r, z, w, p, q, f, g, m, n, prev_rho, rho, delta, beta_in,
+                                   beta_out, stop, out3):
+        """pipe_cg::step_2 of this iteration and step_1 of the next one in one pass (ten vectors in,
+        eight out instead of 12 + 12), out3 = local {<r,z>, <w,z>, <r,r>} of the new vectors; False
+        if the layout has no such kernel"""
+        if not all(v.ld == 1 and v.size[1] == 1 for v in (x, r, z, w, p, q, f, g, m, n)):
+            return False
+        wk, wb = self._xwork(x.size[0], x.dtype)
+        call("gkoc_x_pipe_cg_step_2_step_1_dots_" + VT[x.dtype], self.exec.stream, x.size[0], x.values,
+             r.values, z.values, w.values, p.values, q.values, f.values, g.values, m.values, n.values,
+             prev_rho.values, rho.values, delta.values, beta_in.values, beta_out.values, stop, out3, wk, wb)
         return True
 
     def pipe_cg_step_2(self, beta, p, q, f, g, z, w, m, n, prev_rho, rho, delta, stop):
@@ -706,6 +763,11 @@ class DistributedMatrix:
         self._side = backend.side_stream() if hasattr(backend, "side_stream") else None
         self.global_nnz = None
         self.fused_dot_min_rows = 1 << 22
+        import os
+        # boundary rows as complete rows over [x | halo] (single-domain bits, overlapped with the
+        # local SpMV) or, GKO_FULL_BOUNDARY=0, the round-2 form: whole local block, then
+        # boundary rows += halo part
+        self.use_full_boundary = os.environ.get("GKO_FULL_BOUNDARY", "1") != "0"
 
     def apply_dot(self, x, y, out):
         """y_local = A[owned rows, :] x and out = LOCAL part of <x, y> (the caller all-reduces):
@@ -734,6 +796,27 @@ class DistributedMatrix:
         # 1. pack the rows the neighbours need (RowGatherer::apply_prepare)
         if not zero_copy:
             be.gather(x, self.send_idx, self.send_buf)
+        # Contiguous partitions (one column): the boundary rows exist as COMPLETE rows over
+        # [x | halo] (single-domain bits).  The local SpMV then covers the interior rows only and
+        # the boundary rows are computed from the halo directly - with a device-resident
+        # communicator on the exchange's stream, right behind the halo, overlapping the tail of
+        # the local SpMV; otherwise after it in stream order.
+        full = self.nl.get("full") if (dot_out is None and x.ld == 1 and y.ld == 1 and
+                                       x.size[1] == 1 and hasattr(be, "rowlist_full") and
+                                       self.use_full_boundary) else None
+        if full is not None:
+            local_spmv = lambda: be.spmv_rows(self.local, full["interior"][0], full["interior"][1], x, y)
+        if full is not None and direct and hasattr(comm, "exchange_join"):
+            if zero_copy:
+                comm.exchange_begin(self.recv_buf.values, x.values, self.recv_counts,
+                                    self.send_counts, self._side, self.send_displs)
+            else:
+                comm.exchange_begin(self.recv_buf.values, self.send_buf.values, self.recv_counts,
+                                    self.send_counts, self._side)
+            local_spmv()
+            be.rowlist_full(self.nl, x, self.recv_buf, y, self._side)
+            comm.exchange_join()
+            return y
         if direct:
             # 2. exchange on a second stream (ordering by events inside the library),
             # overlapped with 3.
@@ -764,7 +847,9 @@ class DistributedMatrix:
                               self.recv_counts, self.send_counts)
             local_spmv()
         # 4. non-local part on the received halo (boundary rows only)
-        if dot_out is not None:
+        if full is not None:
+            be.rowlist_full(self.nl, x, self.recv_buf, y)
+        elif dot_out is not None:
             be.rowlist_add_dot(self.nl, self.recv_buf, y, x, dot_out)
         else:
             be.rowlist_add(self.nl, self.recv_buf, y)
@@ -939,9 +1024,10 @@ class DistributedPipeCg:
     pipe_cg::step_1 / step_2 are masked by stop_status (pipe_cg_kernels.cpp:79-164)."""
 
     def __init__(self, backend, comm, matrix, max_iters, reduction_factor=1e-10,
-                 max_block_size=8, check_lag=None, fused=True, taped=True):
+                 max_block_size=8, check_lag=None, fused=True, taped=True, fused_steps=True):
         self.be, self.comm, self.a = backend, comm, matrix
         self.taped = bool(taped)
+        self.fused_steps = bool(fused_steps)
         self.max_iters, self.factor = int(max_iters), float(reduction_factor)
         self.m_op = backend.jacobi(matrix.local, max_block_size) if max_block_size else None
         self.num_iterations = 0
@@ -952,6 +1038,7 @@ class DistributedPipeCg:
         (self.r, self.w, self.z, self.p, self.m, self.n, self.q, self.f, self.g) = (
             backend.vector(n, dt) for _ in range(9))
         self.beta, self.tau0 = backend.vector(1, dt), backend.vector(1, dt)
+        self.beta2 = backend.vector(1, dt)     # the fused step_2 + step_1 reads one beta and writes the other
         # [rho, delta, ||r||^2]; the two triples swap roles as (rho, prev_rho)
         self.trip_a = backend.scalar_tuple(3, dt)
         self.trip_b = backend.scalar_tuple(3, dt)
@@ -1042,6 +1129,50 @@ class DistributedPipeCg:
                 t.result = fn(*args)
             tapes[key] = t
             return t.result
+
+        # step_2 of iteration k and step_1 + the three dots of iteration k + 1 as ONE kernel
+        # (gkoc_x_pipe_cg_step_2_step_1_dots_*: 144 instead of 192 bytes per row, one launch less);
+        # the all-reduce of its three values still travels while m = M^-1 w and n = A m run.  Same
+        # vectors bit for bit; beta alternates between two scalars (the kernel reads one, writes
+        # the other).
+        if fused and self.fused_steps and hasattr(be, "pipe_cg_step_2_step_1_dots") and \
+                all(v.ld == 1 and v.size[1] == 1 for v in (x, r, z, w, p, q, f, g, m, n)):
+            betas = (beta, self.beta2)
+
+            def head(cur, prev):                 # the very first step_1 (+ dots): nothing to fuse it with
+                out = prev[0]
+                if not be.pipe_cg_step_1_dots(x, r, z, w, p, q, f, g, cur[1][0], betas[0], self.stop, out):
+                    raise GkoError("DistributedPipeCg: fused step kernels unavailable for this layout")
+
+            def mid(prev):                       # reduce what the last step kernel left in `prev`
+                comm.all_reduce_begin(prev[0], self._side)
+                self._precond(w, m)
+                a.apply(m, n)
+                comm.all_reduce_end()
+
+            def tail(cur, prev, b_in, b_out):    # step_2 (prev_rho = prev, rho / delta = cur) + next step_1
+                be.pipe_cg_step_2_step_1_dots(x, r, z, w, p, q, f, g, m, n, prev[1][0], cur[1][0],
+                                              cur[1][1], b_in, b_out, self.stop, prev[0])
+
+            run(("h",), head, cur, prev)
+            while True:
+                parity = it & 1
+                run(("m", parity), mid, prev)
+                cur, prev = prev, cur
+                it += 1
+                if it >= self.max_iters:
+                    stopped = self._drain(pending, it)
+                    if stopped is not None:
+                        it = stopped
+                    break
+                pending.append((it, self._check_begin(cur[1][2])))
+                stopped = self._drain(pending, it - self.check_lag)
+                if stopped is not None:
+                    it = stopped
+                    break
+                run(("t", parity), tail, cur, prev, betas[parity], betas[1 - parity])
+            self.num_iterations = it
+            return x
 
         while True:
             parity = it & 1

@@ -74,6 +74,17 @@ struct ptrs_as<int32> {
 };
 
 
+// the allocator learns which arrays are vectors from what the kernels write (csrc/arena.hip,
+// gkoc_arena_note_vector); one look-up per NEW output pointer of a thread
+inline void note_written_vector(const void* p)
+{
+    static thread_local const void* last = nullptr;
+    if (p != last) {
+        last = p;
+        gkoc_arena_note_vector(p);
+    }
+}
+
 // ===================================================================== csr
 namespace csr {
 
@@ -82,6 +93,7 @@ namespace csr {
     void spmv<T, T, T, I>(exec_t exec, const matrix::Csr<T, I>* a,              \
                           const matrix::Dense<T>* b, matrix::Dense<T>* c)       \
     {                                                                           \
+        note_written_vector(c->get_const_values());                             \
         GKOC_CALL(gkoc_csr_spmv_##TN##_##IN(                                    \
             stream_of(exec), a->get_size()[0], a->get_size()[1],                \
             a->get_const_row_ptrs(), a->get_const_col_idxs(),                   \

@@ -109,6 +109,13 @@ int gkoc_arena_configure(int mode, size_t chunk_bytes, int sync_on_free);
 int gkoc_arena_stats(gkoc_arena_info* info);
 /* *cls = memory class (0..2) of an address inside a class region, -1 otherwise */
 int gkoc_arena_class_of(const void* ptr, int* cls);
+/* Role feedback for gkoc_malloc (which, like Ginkgo's raw_alloc, is told no role): the array
+ * that holds ptr has been WRITTEN as a vector by a kernel - later requests of that size or a
+ * multiple of it (Krylov bases, multi-vectors) are placed with the vectors.  role_stats: how
+ * many vector sizes are known and how many of them were found next to matrix arrays when first
+ * seen (placed before anything was known about the system). */
+int gkoc_arena_note_vector(const void* ptr);
+int gkoc_arena_role_stats(int64_t* n_vector_sizes, int64_t* misplaced_vectors);
 int gkoc_arena_trim(void);              /* return empty chunks to the driver */
 /* The arena's memory-class probe, exposed for diagnostics: every wavefront reads
  * read_kb_per_wave KiB of x (x_bytes in all, read only) and then writes
@@ -1040,6 +1047,14 @@ size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size);
         gkoc_stream_t s, int64_t rows, T* x, T* r, const T* p, const T* q,     \
         const T* beta, const T* rho, const uint8_t* stop_status, T* norm_out,  \
         int take_sqrt, void* work, size_t work_bytes);                         \
+    /* pipe_cg::step_2 of one iteration and step_1 of the next in one pass, with the partial sums \
+     * of <r,z>, <w,z>, <r,r> (out3): ten vectors in, eight out; vectors bit-identical to the two \
+     * kernels.  beta_in / beta_out: two different scalars (the caller alternates them). */       \
+    int gkoc_x_pipe_cg_step_2_step_1_dots_##TN(                                \
+        gkoc_stream_t s, int64_t rows, T* x, T* r, T* z, T* w, T* p, T* q,     \
+        T* f, T* g, const T* m, const T* n, const T* prev_rho, const T* rho,   \
+        const T* delta, const T* beta_in, T* beta_out,                         \
+        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes);   \
     /* pipe_cg::step_1 (one column, unit strides; vectors bit-identical) and     \
      * out3 = {<r,z>, <w,z>, <r,r>} of the updated vectors: the three values a   \
      * distributed PipeCg iteration all-reduces in one message */              \

@@ -65,6 +65,13 @@ def test_distributed_gpu_two_ranks_one_device():
 
 
 @pytest.mark.gpu
+def test_distributed_gpu_three_ranks_odd_planes():
+    """3 ranks, 9^3: planes of 81 rows - the interior-rows view of the local block starts at a row
+    pointer that is only 4-byte aligned"""
+    _launch("gpu", 3, 9)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("grid", [32, 64])
 def test_distributed_gpu_eight_ranks_one_device(grid):
     """world_size = 8 (BASELINE configs[3]'s rank count): eight processes sharing cuda:0,

@@ -43,6 +43,26 @@ class FakeComm:
     def all_to_all_counts(self, send_counts):
         return list(send_counts)
 
+    # the device-resident exchange of RcclComm, with a device copy of the right size in place of
+    # the transfer: on the side stream, ordered by events like gkoc_comm_exchange_begin / _join
+    direct = True
+
+    def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None, send_displs=None):
+        ev = torch.cuda.Event()
+        ev.record()
+        self._side = side_stream
+        with torch.cuda.stream(side_stream):
+            side_stream.wait_event(ev)
+            recv.view(-1).copy_(send.view(-1)[:recv.numel()])
+
+    def exchange_end(self):
+        self.exchange_join()
+
+    def exchange_join(self):
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        torch.cuda.current_stream().wait_event(ev)
+
     def all_to_all_v(self, recv, send, recv_counts, send_counts, async_op=False):
         if recv.dtype == torch.int64:
             # peers ask for the planes next to the ones we ask them for
@@ -73,10 +93,25 @@ for _ in range(50):
     a.apply(x, y)
 e1.record()
 torch.cuda.synchronize()
-print(f"distributed SpMV (pack + copy-exchange on 2nd stream || local + boundary rows): {e0.elapsed_time(e1)*20:.1f} us")
+print(f"distributed SpMV (copy-exchange + complete boundary rows on the 2nd stream || interior rows): {e0.elapsed_time(e1)*20:.1f} us")
+a.use_full_boundary = False
+for _ in range(5):
+    a.apply(x, y)
+e0.record()
+for _ in range(50):
+    a.apply(x, y)
+e1.record()
+torch.cuda.synchronize()
+print(f"distributed SpMV, round-2 path (exchange || whole local block, then boundary rows += halo part): {e0.elapsed_time(e1)*20:.1f} us")
+a.use_full_boundary = os.environ.get("GKO_SIM_OLD_PATH") != "1"
 for fused, s2, cls in ((False, False, gd.DistributedCg), (True, False, gd.DistributedCg),
-                       (True, True, gd.DistributedCg), (True, True, gd.DistributedPipeCg)):
-    kw = dict(fused_step_2=s2) if cls is gd.DistributedCg else {}
+                       (True, True, gd.DistributedCg), (True, False, gd.DistributedPipeCg),
+                       (True, True, gd.DistributedPipeCg)):
+    if os.environ.get("GKO_SIM_ONLY") == "pipe" and not (cls is gd.DistributedPipeCg and s2):
+        continue
+    if os.environ.get("GKO_SIM_ONLY") == "cg" and not (cls is gd.DistributedCg and s2):
+        continue
+    kw = dict(fused_step_2=s2) if cls is gd.DistributedCg else dict(fused_steps=s2)
     s = cls(be, FakeComm(), a, iters, 1e-300, 8, fused=fused, **kw)
     rhs = be.vector_from(np.ones(hi - lo))
     xs = be.vector(hi - lo)
@@ -87,8 +122,12 @@ for fused, s2, cls in ((False, False, gd.DistributedCg), (True, False, gd.Distri
     s.apply(rhs, xs)
     torch.cuda.synchronize()
     t = time.perf_counter() - t
-    print(f"{cls.__name__:18s} fused={fused!s:5s} step_2+jacobi={s2!s:5s}: {s.num_iterations} its, {t*1e6/max(s.num_iterations,1):8.1f} us/it "
+    print(f"{cls.__name__:18s} fused={fused!s:5s} step_2 fused with its neighbour={s2!s:5s}: {s.num_iterations} its, {t*1e6/max(s.num_iterations,1):8.1f} us/it "
           f"(device side, no RCCL latency) -> {max(s.num_iterations,1)/t:8.1f} it/s")
+
+if os.environ.get("GKO_SIM_ONLY"):
+    sys.exit(0)
+
 
 # ---- pieces of the distributed SpMV
 def tm(name, fn, reps=100):
@@ -107,5 +146,9 @@ def tm(name, fn, reps=100):
 tm("local SpMV only (local columns)", lambda: be.spmv(a.local, x, y))
 tm("pack (row_gather of the send planes)", lambda: be.gather(x, a.send_idx, a.send_buf))
 tm("boundary rows (rowlist += halo part)", lambda: be.rowlist_add(a.nl, a.recv_buf, y))
+if "full" in a.nl:
+    r0, r1 = a.nl["full"]["interior"]
+    tm("interior rows of the local block", lambda: be.spmv_rows(a.local, r0, r1, x, y))
+    tm("complete boundary rows over [x | halo]", lambda: be.rowlist_full(a.nl, x, a.recv_buf, y))
 tm("copy 'exchange' alone", lambda: a.recv_buf.values.copy_(a.send_buf.values))
 tm("whole distributed apply", lambda: a.apply(x, y))
