@@ -216,6 +216,8 @@ __global__ __launch_bounds__(256) void residual_norm_kernel(
     if (threadIdx.x == 0) {
         flags[0] = uint8_t(all_stopped != 0);
         flags[1] = uint8_t(changed != 0);
+        // flags may live in pinned host memory that the host polls without waiting for an event
+        __threadfence_system();
     }
 }
 

@@ -215,39 +215,51 @@ __global__ __launch_bounds__(256) void boundary_fill_kernel(
     }
 }
 
-// No LDS on purpose: this kernel runs NEXT TO the local SpMV, whose waves fill the LDS of every
-// CU (8 KB each, 20 per CU); a workgroup that needed 24 KB of staging space would only be
-// dispatched once the SpMV has drained (measured: 181 us serialised against 159 us).  Lane = row,
-// the row's entries are consecutive, so a lane re-uses each 64-byte line of values / columns it
-// touches; the halo and the own vector are gathered.
+// This kernel runs NEXT TO the local SpMV, whose waves fill the LDS of every CU (8 KB each, 20 per
+// CU): a workgroup that needs more LDS than one such wave frees is only dispatched once the SpMV
+// has drained (a first version staged 24 KB per wave: 181 us serialised against 159 us), and one
+// whose lanes walk their rows' entries straight from memory (64 lines per load instruction)
+// slows the SpMV down by a quarter while it runs beside it.  So, like the SpMV kernel itself:
+// one wave per 32 listed rows = one contiguous range of at most rl_full_cap entries; the lanes
+// read values / columns with coalesced loads (entry = lane + 64 j), gather x / halo, and leave the
+// PRODUCTS in LDS (8 B each, <= 7 KB per wave); lane = row then adds its products in k order.
+// Longer ranges take the lane-per-row walk.
+constexpr int rl_full_rows = 32;
+constexpr int rl_full_cap = 896;
+
 template <typename T, typename I>
-__global__ __launch_bounds__(256) void csr_rowlist_full_kernel(
+__global__ __launch_bounds__(64) void csr_rowlist_full_kernel(
     int64_t n_list, const I* __restrict__ rows, const I* __restrict__ ptrs,
     const I* __restrict__ cols, const T* __restrict__ vals, int64_t n_local,
     const T* __restrict__ x, const T* __restrict__ halo, T* __restrict__ y)
 {
-    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (i >= n_list) return;
-    const int64_t ks = ptrs[i], ke = ptrs[i + 1];
-    const int64_t row = rows[i];
-    T sum = T(0);
-    int64_t k = ks;
-    for (; k + 9 <= ke; k += 9) {      // a boundary row of the 27-pt stencil: 2 or 3 groups of nine
-        T v[9], h[9];
-#pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            v[u] = vals[k + u];
-            const int64_t c = cols[k + u];
-            h[u] = c < n_local ? x[c] : halo[c - n_local];
+    __shared__ T prod[rl_full_cap];
+    const int lane = threadIdx.x;
+    const int64_t first = int64_t(blockIdx.x) * rl_full_rows;
+    const int64_t last = first + rl_full_rows < n_list ? first + rl_full_rows : n_list;
+    const int64_t K0 = ptrs[first], K1 = ptrs[last];
+    const int64_t i = first + lane;
+    const bool valid = lane < rl_full_rows && i < last;
+    const int64_t ks = valid ? int64_t(ptrs[i]) : K1, ke = valid ? int64_t(ptrs[i + 1]) : K1;
+    if (K1 - K0 <= rl_full_cap) {
+        for (int64_t t = K0 + lane; t < K1; t += 64) {
+            const int64_t c = cols[t];
+            prod[t - K0] = vals[t] * (c < n_local ? x[c] : halo[c - n_local]);
         }
-#pragma unroll
-        for (int u = 0; u < 9; ++u) sum += v[u] * h[u];
+        wave_lds_sync();
+        if (!valid) return;
+        T sum = T(0);
+        for (int64_t k = ks; k < ke; ++k) sum += prod[k - K0];
+        y[rows[i]] = sum;
+        return;
     }
-    for (; k < ke; ++k) {
+    if (!valid) return;
+    T sum = T(0);
+    for (int64_t k = ks; k < ke; ++k) {
         const int64_t c = cols[k];
         sum += vals[k] * (c < n_local ? x[c] : halo[c - n_local]);
     }
-    y[row] = sum;
+    y[rows[i]] = sum;
 }
 
 // inout[0] += sum of partial[0 .. count) (fixed tree)
@@ -418,7 +430,7 @@ GKOC_DEF_DIST_BND_IDX(int64_t, i64)
         GKOC_REQUIRE(rows && ptrs && x && halo && y, GKOC_E_INVALID,           \
                      "null pointer");                                          \
         csr_rowlist_full_kernel<T, I>                                          \
-            <<<dim3(unsigned(ceildiv(n_list, 256))), dim3(256), 0,             \
+            <<<dim3(unsigned(ceildiv(n_list, rl_full_rows))), dim3(64), 0,     \
                as_stream(s)>>>(n_list, rows, ptrs, cols, vals, n_local, x,     \
                                halo, y);                                       \
         GKOC_LAUNCH_OK();                                                      \

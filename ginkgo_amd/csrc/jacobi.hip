@@ -934,6 +934,166 @@ __global__ __launch_bounds__(256) void jacobi_step2_apply_kernel(
     }
 }
 
+// PipeCg: pipe_cg::step_2 of iteration k, step_1 of iteration k + 1 (krylov_steps.hip,
+// pipe_cg_step2_step1_dots_kernel: the same expressions in the same order, so p, q, f, g, x, r, z, w
+// are bit-identical to the two kernels), the three partial sums <r,z>, <w,z>, <r,r> AND the
+// preconditioner application m = M w of iteration k + 1 (pipe_cg.cpp:211), with the new w going
+// from the registers that computed it into the block product (neighbours' values by shuffle), as
+// in jacobi_step2_apply_kernel.  Lane = (block, row) of the 64-wide storage group.  m is read
+// (step_2: f = m + t2 f) and then overwritten by the lane that owns the row.
+template <typename T, typename I, int BO, int GPW>
+__global__ __launch_bounds__(256) void jacobi_pipe_steps_kernel(
+    int64_t num_blocks, int64_t num_groups, int64_t group_offset,
+    const I* __restrict__ block_ptrs, const T* __restrict__ blocks, T* __restrict__ x,
+    T* __restrict__ r, T* __restrict__ z, T* __restrict__ w, T* __restrict__ p, T* __restrict__ q,
+    T* __restrict__ f, T* __restrict__ g, T* __restrict__ m, const T* __restrict__ nv,
+    const T* __restrict__ prev_rho, const T* __restrict__ rho, const T* __restrict__ delta,
+    const T* __restrict__ beta_in, T* __restrict__ beta_out, const uint8_t* __restrict__ stop,
+    T* __restrict__ partial, int64_t pstride)
+{
+    __shared__ T lds[4];
+    constexpr int LOG_BO = BO == 1 ? 0 : BO == 2 ? 1 : BO == 4 ? 2 : BO == 8 ? 3 : 4;
+    constexpr int GP = 6 - LOG_BO;
+    const int lane = threadIdx.x & 63;
+    const int rr = lane & (BO - 1);
+    const int lane0 = lane - rr;
+    const int64_t wg = blockIdx.x;
+    const int64_t group0 = (wg * 4 + (threadIdx.x >> 6)) * GPW;
+    const bool stopped = status_has_stopped(stop[0]);
+    const T pr = prev_rho[0];
+    const bool plain = pr == T(0);
+    const T t2 = plain ? T(0) : rho[0] / pr;
+    T bnew = beta_in[0];
+    if (!stopped) {
+        if (plain) {
+            bnew = delta[0];
+        } else {
+            const T a = fabs(t2);
+            bnew = delta[0] - a * a * beta_in[0];
+            if (bnew == T(0)) bnew = delta[0];
+        }
+    }
+    const bool noop1 = bnew == T(0) || stopped;
+    const T t1 = noop1 ? T(0) : rho[0] / bnew;
+    if (wg == 0 && threadIdx.x == 0) beta_out[0] = bnew;
+    T a_rz = T(0), a_wz = T(0), a_rr = T(0);
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+        const int64_t group = group0 + gi;
+        const int64_t blk = (group << GP) + (lane >> LOG_BO);
+        const bool have = group < num_groups && blk < num_blocks;
+        I start = 0, end = 0;
+        if (have) {
+            start = block_ptrs[blk];
+            end = block_ptrs[blk + 1];
+        }
+        const int bs = have && rr < int(end - start) ? int(end - start) : 0;
+        const int64_t row = int64_t(start) + rr;
+        T mc[BO];
+        T rv = T(0), zv = T(0), wv = T(0);
+        if (bs > 0) {
+            const T* gp = blocks + group_offset * group + lane;
+#pragma unroll
+            for (int c = 0; c < BO; ++c) mc[c] = gp[c * 64];
+            rv = r[row];
+            zv = z[row];
+            wv = w[row];
+            if (!stopped) {
+                const T pv = plain ? zv : zv + t2 * p[row];
+                const T qv = plain ? wv : wv + t2 * q[row];
+                const T fv = plain ? m[row] : m[row] + t2 * f[row];
+                const T gv = plain ? nv[row] : nv[row] + t2 * g[row];
+                p[row] = pv;
+                q[row] = qv;
+                f[row] = fv;
+                g[row] = gv;
+                if (!noop1) {
+                    x[row] = x[row] + t1 * pv;
+                    rv = rv - t1 * qv;
+                    zv = zv - t1 * fv;
+                    wv = wv - t1 * gv;
+                    r[row] = rv;
+                    z[row] = zv;
+                    w[row] = wv;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < BO; ++c) mc[c] = T(0);
+        }
+        // m = M w on the new w: column c of the block times w of the block's row c
+        T sum = T(0);
+#pragma unroll
+        for (int c = 0; c < BO; ++c) {
+            const T bc = __shfl(wv, lane0 + c, 64);
+            const T t = mc[c] * bc;
+            sum = c < bs ? sum + t : sum;
+        }
+        if (bs > 0) {
+            m[row] = sum;
+            a_rz += rv * zv;
+            a_wz += wv * zv;
+            a_rr += rv * rv;
+        }
+    }
+    const T s0 = block_sum<256>(a_rz, lds);
+    __syncthreads();
+    const T s1 = block_sum<256>(a_wz, lds);
+    __syncthreads();
+    const T s2 = block_sum<256>(a_rr, lds);
+    if (threadIdx.x == 0) {
+        partial[wg] = s0;
+        partial[pstride + wg] = s1;
+        partial[2 * pstride + wg] = s2;
+    }
+}
+
+template <typename T, typename I>
+int launch_pipe_steps(gkoc_stream_t s, int64_t num_blocks, int64_t n_rows, uint32_t max_bs,
+                      gkoc_jacobi_scheme scheme, const I* block_ptrs, const T* blocks, T* x, T* r, T* z,
+                      T* w, T* p, T* q, T* f, T* g, T* m, const T* nv, const T* prev_rho, const T* rho,
+                      const T* delta, const T* beta_in, T* beta_out, const uint8_t* stop, T* out3, void* work,
+                      size_t work_bytes)
+{
+    GKOC_REQUIRE(out3 && num_blocks > 0 && n_rows > 0, GKOC_E_INVALID, "bad argument");
+    GKOC_REQUIRE(block_ptrs && blocks && x && r && z && w && p && q && f && g && m && nv && prev_rho && rho &&
+                     delta && stop && work,
+                 GKOC_E_INVALID, "null pointer");
+    GKOC_REQUIRE(beta_in && beta_out && beta_in != beta_out, GKOC_E_INVALID,
+                 "beta_in and beta_out must be two different scalars");
+    const int64_t bo = scheme.block_offset;
+    GKOC_REQUIRE(bo >= 1 && bo <= 16 && (bo << scheme.group_power) == 64 && (bo & (bo - 1)) == 0,
+                 GKOC_E_NOT_SUPPORTED, "needs block_offset in {1,2,4,8,16} and a 64-wide group");
+    GKOC_REQUIRE(max_bs <= uint64_t(bo), GKOC_E_INVALID, "max_block_size exceeds block_offset");
+    GKOC_REQUIRE(work_bytes >= fused_workspace_bytes(n_rows, sizeof(T)), GKOC_E_WORKSPACE,
+                 "workspace too small (gkoc_x_workspace_bytes)");
+    const int64_t groups = ceildiv(num_blocks, int64_t(1) << scheme.group_power);
+    const int gpw = (bo * int64_t(sizeof(T)) >= 128) ? 1 : 2;
+    const int64_t nb = ceildiv(groups, 4 * gpw);
+    const int64_t total = int64_t(fused_workspace_bytes(n_rows, sizeof(T)) / sizeof(T));
+    GKOC_REQUIRE(3 * nb <= total, GKOC_E_WORKSPACE, "too many blocks for the workspace");
+    T* partial = static_cast<T*>(work);
+    const int64_t go = scheme.group_offset;
+#define GKOC_JAC_PS(BO_)                                                                              \
+    jacobi_pipe_steps_kernel<T, I, BO_, ((BO_ * sizeof(T) >= 128) ? 1 : 2)>                            \
+        <<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(num_blocks, groups, go, block_ptrs, blocks, \
+                                                             x, r, z, w, p, q, f, g, m, nv, prev_rho,  \
+                                                             rho, delta, beta_in, beta_out, stop,      \
+                                                             partial, nb)
+    switch (int(bo)) {
+    case 1: GKOC_JAC_PS(1); break;
+    case 2: GKOC_JAC_PS(2); break;
+    case 4: GKOC_JAC_PS(4); break;
+    case 8: GKOC_JAC_PS(8); break;
+    default: GKOC_JAC_PS(16); break;
+    }
+#undef GKOC_JAC_PS
+    GKOC_LAUNCH_OK();
+    fold_rows_kernel<T><<<dim3(3), dim3(1024), 0, as_stream(s)>>>(nb, nb, partial, out3);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
 // does the fused step_2 + apply have room for its two rows of partial sums in the workspace of
 // gkoc_x_workspace_bytes(n_rows, value_size)?  (blocks much smaller than max_block_size: no)
 inline bool step2_apply_fits(int64_t num_blocks, int64_t n_rows, gkoc_jacobi_scheme scheme,
@@ -1308,6 +1468,20 @@ using namespace gkoc;
                                         scheme, block_ptrs, blocks, x, r, p,   \
                                         q, beta, rho, stop_status, z, rho_out, \
                                         norm_out, take_sqrt, work, work_bytes); \
+    }                                                                          \
+    extern "C" int gkoc_x_pipe_cg_steps_jacobi_##TN##_##IN(                    \
+        gkoc_stream_t s, int64_t num_blocks, int64_t n_rows,                   \
+        uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
+        const I* block_ptrs, const T* blocks, T* x, T* r, T* z, T* w, T* p,    \
+        T* q, T* f, T* g, T* m, const T* n, const T* prev_rho, const T* rho,   \
+        const T* delta, const T* beta_in, T* beta_out,                         \
+        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes)    \
+    {                                                                          \
+        return launch_pipe_steps<T, I>(s, num_blocks, n_rows, max_block_size,  \
+                                       scheme, block_ptrs, blocks, x, r, z, w, \
+                                       p, q, f, g, m, n, prev_rho, rho, delta, \
+                                       beta_in, beta_out, stop_status, out3,   \
+                                       work, work_bytes);                      \
     }                                                                          \
     extern "C" int gkoc_jacobi_apply_##TN##_##IN(                              \
         gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,          \

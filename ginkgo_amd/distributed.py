@@ -604,6 +604,23 @@ class HipBackend:
              prev_rho.values, rho.values, delta.values, beta_in.values, beta_out.values, stop, out3, wk, wb)
         return True
 
+    def pipe_cg_steps_jacobi(self, m_op, x, r, z, w, p, q, f, g, m, n, prev_rho, rho, delta, beta_in,
+                             beta_out, stop, out3, probe=False):
+        """the same AND m = M w (block-Jacobi) in one kernel: the new w goes from the registers
+        that computed it into the block product; False if this preconditioner / layout has no
+        such kernel (probe=True: only answer)"""
+        if not (hasattr(m_op, "can_fuse_step_2") and m_op.can_fuse_step_2(r) and
+                all(v.ld == 1 and v.size[1] == 1 for v in (x, r, z, w, p, q, f, g, m, n))):
+            return False
+        if probe:
+            return True
+        wk, wb = self._xwork(x.size[0], x.dtype)
+        call("gkoc_x_pipe_cg_steps_jacobi_" + m_op._suf, self.exec.stream, m_op.num_blocks, m_op.size[0],
+             C.c_uint32(m_op.max_block_size), m_op.scheme, m_op.block_pointers, m_op.blocks, x.values,
+             r.values, z.values, w.values, p.values, q.values, f.values, g.values, m.values, n.values,
+             prev_rho.values, rho.values, delta.values, beta_in.values, beta_out.values, stop, out3, wk, wb)
+        return True
+
     def pipe_cg_step_2(self, beta, p, q, f, g, z, w, m, n, prev_rho, rho, delta, stop):
         call("gkoc_pipe_cg_step_2_" + VT[p.dtype], self.exec.stream, p.size[0], 1, beta.values,
              p.values, p.ld, q.values, q.ld, f.values, f.ld, g.values, g.ld, z.values, z.ld,
@@ -675,15 +692,21 @@ class HipBackend:
     def check_begin(self, tau, tau0, factor, stop, squared=False):
         """squared: tau holds ||r||^2; the criterion kernel of ImplicitResidualNorm
         (sqrt(|tau|) <= factor * tau0, residual_norm.cpp:209-230) then saves the
-        separate sqrt launch"""
+        separate sqrt launch.
+        No event is recorded behind the kernel: on this hardware an event record is a barrier
+        packet that leaves the device idle for ~6 us before the next kernel starts (kernel
+        timelines of an 8-rank iteration, profiles/r03_dist_sim_timelines.txt).  The kernel writes
+        its two flag bytes into a pinned (host-coherent) slot that the host has set to 0xFF; the
+        host polls the slot when it wants the answer - `check_lag` iterations later, when the
+        bytes have long arrived."""
         if not hasattr(self, "_chk_host"):
             self._chk_host = torch.zeros((self._NSLOT, 2), dtype=torch.uint8).pin_memory()
             self._chk_np = self._chk_host.numpy()
-            self._chk_ev = [torch.cuda.Event() for _ in range(self._NSLOT)]
             self._chk_next = 0
             self._chk_tapes = {}
         slot = self._chk_next
         self._chk_next = (slot + 1) % self._NSLOT
+        self._chk_np[slot, 0] = self._chk_np[slot, 1] = 0xFF
         key = (tau.values.data_ptr(), tau0.values.data_ptr(), stop.data_ptr(), factor, slot, squared)
         tape = self._chk_tapes.get(key)
         if tape is None:
@@ -697,12 +720,20 @@ class HipBackend:
             self._chk_tapes[key] = tape
         else:
             tape.replay()
-        self._chk_ev[slot].record()
         return slot
 
     def check_done(self, token, block=True):
-        self._chk_ev[token].synchronize()
-        return bool(self._chk_np[token, 0])
+        flags = self._chk_np[token]
+        spins = 0
+        while flags[0] == 0xFF or flags[1] == 0xFF:
+            spins += 1
+            if spins == 2000:
+                # not there yet: wait for the stream instead of burning the core (the kernel's
+                # stores are visible at the latest when the stream has drained)
+                self.exec.synchronize()
+            elif spins > 2000 and spins % 2000 == 0:
+                raise GkoError("criterion flags did not arrive in pinned memory")
+        return bool(flags[0])
 
     max_check_lag = 6       # must stay below _NSLOT
     check_takes_squared_norm = True
@@ -1024,10 +1055,12 @@ class DistributedPipeCg:
     pipe_cg::step_1 / step_2 are masked by stop_status (pipe_cg_kernels.cpp:79-164)."""
 
     def __init__(self, backend, comm, matrix, max_iters, reduction_factor=1e-10,
-                 max_block_size=8, check_lag=None, fused=True, taped=True, fused_steps=True):
+                 max_block_size=8, check_lag=None, fused=True, taped=True, fused_steps=True,
+                 fused_jacobi=True):
         self.be, self.comm, self.a = backend, comm, matrix
         self.taped = bool(taped)
         self.fused_steps = bool(fused_steps)
+        self.fused_jacobi = bool(fused_jacobi)
         self.max_iters, self.factor = int(max_iters), float(reduction_factor)
         self.m_op = backend.jacobi(matrix.local, max_block_size) if max_block_size else None
         self.num_iterations = 0
@@ -1138,21 +1171,34 @@ class DistributedPipeCg:
         if fused and self.fused_steps and hasattr(be, "pipe_cg_step_2_step_1_dots") and \
                 all(v.ld == 1 and v.size[1] == 1 for v in (x, r, z, w, p, q, f, g, m, n)):
             betas = (beta, self.beta2)
+            # with block-Jacobi in its fast-path layout the step kernel also applies the
+            # preconditioner (m = M w from the registers that hold the new w)
+            with_m = self.m_op is not None and self.fused_jacobi and \
+                hasattr(be, "pipe_cg_steps_jacobi") and \
+                be.pipe_cg_steps_jacobi(self.m_op, x, r, z, w, p, q, f, g, m, n, None, None, None, None,
+                                        None, None, None, probe=True)
 
             def head(cur, prev):                 # the very first step_1 (+ dots): nothing to fuse it with
                 out = prev[0]
                 if not be.pipe_cg_step_1_dots(x, r, z, w, p, q, f, g, cur[1][0], betas[0], self.stop, out):
                     raise GkoError("DistributedPipeCg: fused step kernels unavailable for this layout")
+                if with_m:
+                    self._precond(w, m)
 
             def mid(prev):                       # reduce what the last step kernel left in `prev`
                 comm.all_reduce_begin(prev[0], self._side)
-                self._precond(w, m)
+                if not with_m:
+                    self._precond(w, m)
                 a.apply(m, n)
                 comm.all_reduce_end()
 
             def tail(cur, prev, b_in, b_out):    # step_2 (prev_rho = prev, rho / delta = cur) + next step_1
-                be.pipe_cg_step_2_step_1_dots(x, r, z, w, p, q, f, g, m, n, prev[1][0], cur[1][0],
-                                              cur[1][1], b_in, b_out, self.stop, prev[0])
+                if with_m:
+                    be.pipe_cg_steps_jacobi(self.m_op, x, r, z, w, p, q, f, g, m, n, prev[1][0], cur[1][0],
+                                            cur[1][1], b_in, b_out, self.stop, prev[0])
+                else:
+                    be.pipe_cg_step_2_step_1_dots(x, r, z, w, p, q, f, g, m, n, prev[1][0], cur[1][0],
+                                                  cur[1][1], b_in, b_out, self.stop, prev[0])
 
             run(("h",), head, cur, prev)
             while True:

@@ -1086,6 +1086,22 @@ GKOC_DECL_X(float, f32)
         const T* q, const T* beta, const T* rho, const uint8_t* stop_status,   \
         T* z, T* rho_out, T* norm_out, int take_sqrt, void* work,              \
         size_t work_bytes);
+#define GKOC_DECL_XI2(T, TN, I, IN)                                            \
+    /* PipeCg: pipe_cg::step_2 of one iteration, step_1 of the next, out3 =     \
+     * {<r,z>, <w,z>, <r,r>} and m = M w (block-Jacobi, fast-path layout) in ONE \
+     * kernel; vectors bit-identical to the separate kernels; beta_in / beta_out \
+     * are two different scalars */                                            \
+    int gkoc_x_pipe_cg_steps_jacobi_##TN##_##IN(                               \
+        gkoc_stream_t s, int64_t num_blocks, int64_t n_rows,                   \
+        uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
+        const I* block_ptrs, const T* blocks, T* x, T* r, T* z, T* w, T* p,    \
+        T* q, T* f, T* g, T* m, const T* n, const T* prev_rho, const T* rho,   \
+        const T* delta, const T* beta_in, T* beta_out,                         \
+        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes);
+GKOC_DECL_XI2(double, f64, int32_t, i32)
+GKOC_DECL_XI2(double, f64, int64_t, i64)
+GKOC_DECL_XI2(float, f32, int32_t, i32)
+GKOC_DECL_XI2(float, f32, int64_t, i64)
 GKOC_DECL_XI(double, f64, int32_t, i32)
 GKOC_DECL_XI(double, f64, int64_t, i64)
 GKOC_DECL_XI(float, f32, int32_t, i32)

@@ -85,6 +85,11 @@ def main():
     # rows without non-local entries keep the exact single-domain summation
     interior = slice(grid * grid if rank > 0 else 0, (hi - lo) - (grid * grid if rank < world - 1 else 0))
     assert np.array_equal(got[interior], ref[interior])
+    if mode != "cpu" and "full" in a.nl:
+        # slab fast path of the HIP backend: the boundary rows are computed as COMPLETE rows over
+        # [x | halo] in the original column order - the whole distributed product has the bits of
+        # the single-domain one
+        assert a.use_full_boundary and np.array_equal(got, ref)
     # --- CG + block-Jacobi(8) vs the single-process oracle solve
     solver = gd.DistributedCg(be, comm, a, 500, 1e-10, 8)
     xs = be.vector(hi - lo)

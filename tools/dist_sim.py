@@ -106,12 +106,15 @@ print(f"distributed SpMV, round-2 path (exchange || whole local block, then boun
 a.use_full_boundary = os.environ.get("GKO_SIM_OLD_PATH") != "1"
 for fused, s2, cls in ((False, False, gd.DistributedCg), (True, False, gd.DistributedCg),
                        (True, True, gd.DistributedCg), (True, False, gd.DistributedPipeCg),
-                       (True, True, gd.DistributedPipeCg)):
+                       (True, "steps", gd.DistributedPipeCg), (True, True, gd.DistributedPipeCg)):
     if os.environ.get("GKO_SIM_ONLY") == "pipe" and not (cls is gd.DistributedPipeCg and s2):
         continue
     if os.environ.get("GKO_SIM_ONLY") == "cg" and not (cls is gd.DistributedCg and s2):
         continue
-    kw = dict(fused_step_2=s2) if cls is gd.DistributedCg else dict(fused_steps=s2)
+    if os.environ.get("GKO_SIM_ONLY") == "x" and not s2:
+        continue
+    kw = dict(fused_step_2=s2) if cls is gd.DistributedCg else dict(fused_steps=bool(s2),
+                                                                     fused_jacobi=s2 is True)
     s = cls(be, FakeComm(), a, iters, 1e-300, 8, fused=fused, **kw)
     rhs = be.vector_from(np.ones(hi - lo))
     xs = be.vector(hi - lo)
