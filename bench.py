@@ -137,6 +137,59 @@ def cpu_baseline(grid, csr_host=None, budget_s=12.0):
                                            f"oracle, {reps} reps in {el:.1f} s"}
 
 
+def pmc_traffic(grid):
+    """HBM bytes per launch of the SpMV kernel from the chip's counters, collected NOW: three
+    `rocprofv3 --pmc` passes (kernel-trace only, one counter group each, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a short child run of this script that
+    only does the SpMV.  read bytes = RDREQ_128B * 128 + RDREQ_64B * 64 + the remaining requests
+    * 32; written bytes = WRREQ_64B * 64 + the remaining * 32 (FETCH_SIZE under-reports on gfx950).
+    None if rocprofv3 is not there or a pass fails (the committed summary of the last counter run
+    is then used and labelled as such)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None or os.environ.get("GKO_BENCH_NO_PMC") == "1" or \
+            any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):    # (already under a profiler)
+        return None
+    groups = (("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"),
+              ("TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum"),
+              ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"))
+    mean = {}
+    tmp = tempfile.mkdtemp(prefix="gko_pmc_", dir="/tmp")
+    try:
+        for i, grp in enumerate(groups):
+            out = os.path.join(tmp, f"p{i}")
+            cmd = [prof, "--pmc", *grp, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--grid", str(grid), "--steps", "4", "--warmup", "2",
+                   "--cg-iters", "0", "--no-cpu", "--no-ginkgo-api", "--no-pmc"]
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"))
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                if "csr_spmv_pipe3_kernel" in row.get("Kernel_Name", ""):
+                    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c in grp:
+                if not acc.get(c):
+                    return None
+                mean[c] = sum(acc[c]) / len(acc[c])
+    except Exception:       # noqa: BLE001 - counters are an extra, never the line's problem
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    r128, r64, rall = mean["TCC_EA0_RDREQ_128B_sum"], mean["TCC_EA0_RDREQ_64B_sum"], mean["TCC_EA0_RDREQ_sum"]
+    w64, wall = mean["TCC_EA0_WRREQ_64B_sum"], mean["TCC_EA0_WRREQ_sum"]
+    rd = r128 * 128 + r64 * 64 + max(rall - r128 - r64, 0.0) * 32
+    wr = w64 * 64 + max(wall - w64, 0.0) * 32
+    return {"hbm_bytes_per_launch": int(rd + wr), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
+            "counters_mean_per_launch": {k: round(v, 1) for k, v in mean.items()}}
+
+
 def ginkgo_api_bench(grid, steps, cg_iters):
     """The same two figures through the UNMODIFIED Ginkgo core on the drop-in backend
     (gko::matrix::Csr::apply and gko::solver::Cg + gko::preconditioner::Jacobi(8) on
@@ -186,6 +239,9 @@ def main():
     ap.add_argument("--cpu-grid", type=int, default=0,
                     help="0 = the CPU baseline runs the GPU run's grid; otherwise this one")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not collect the SpMV kernel's HBM traffic with rocprofv3 --pmc passes "
+                         "(roofline.traffic then comes from the committed summary of the last counter run)")
     ap.add_argument("--no-ginkgo-api", action="store_true",
                     help="skip the second measurement through the unmodified Ginkgo core")
     ap.add_argument("--cpu-baseline-child", nargs=2, metavar=("GRID", "BUDGET_S"), default=None,
@@ -363,9 +419,16 @@ def main():
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes over this
         # kernel (counters cannot be read from inside the process): the committed
         # summary of the last such run, NOT a measurement of this run
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_detail = None, None, None
         prof = os.path.join(ROOT, "profiles", "spmv_pmc_latest.json")
-        if not use_dist and grid == 256 and os.path.exists(prof):
+        if not use_dist and not args.no_pmc:
+            torch.cuda.synchronize()
+            traffic_detail = pmc_traffic(grid)
+            if traffic_detail is not None:
+                traffic = traffic_detail["hbm_bytes_per_launch"]
+                traffic_source = ("this run: three rocprofv3 --pmc passes (TCC_EA0_RDREQ / WRREQ by request "
+                                  "size) over a child run of the same SpMV on this device, mean per launch")
+        if traffic is None and not use_dist and grid == 256 and os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
                 traffic_source = "profiles/spmv_pmc_latest.json (separate rocprofv3 --pmc run)"
@@ -387,6 +450,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
+                         **({"traffic_over_algorithmic": round(traffic / per_gpu_bytes, 4)} if traffic else {}),
+                         **({"traffic_counters": traffic_detail["counters_mean_per_launch"]}
+                            if traffic_detail else {}),
                          "kernel": ("csr_spmv_pipe3_kernel<double,int,...>" if not use_dist else
                                     "per-rank distributed apply: halo pack + exchange || local "
                                     "csr_spmv_pipe3_kernel, then boundary rows"),

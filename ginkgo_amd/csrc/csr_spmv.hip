@@ -28,7 +28,7 @@
 namespace gkoc {
 namespace {
 
-template <typename T, typename I, bool ADV>
+template <typename T, typename I, bool ADV, int rows_per_seg = 64>
 int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
                const I* row_ptrs, const I* col_idxs, const T* vals, const T* b,
                int64_t ldb, const T* beta, T* c, int64_t ldc, int64_t nrhs)
@@ -48,8 +48,10 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     // +15 % at 0.26 M rows).  In-order dispatch keeps the set of resident waves
     // on a compact window of rows, which is what lets the b-vector lines shared
     // by neighbouring rows hit in L2.
-    constexpr int rows_per_seg = 64;
     const int64_t n_seg = ceildiv(n_rows, rows_per_seg);
+    // (round 3, measured again on 1 / 2 / 4 / 16.7 M rows, profiles/r03_experiments.txt: forcing one or
+    // two segments per wave or 32-row segments changes nothing or loses: 2.1 M rows 139.8 us with
+    // this rule, 142-147 us with the alternatives)
     const int segs_per_wave = n_seg < 65536 ? 1 : 2;
     const int64_t n_waves = ceildiv(n_seg, segs_per_wave);
     GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED,
