@@ -296,6 +296,64 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
     return GKOC_OK;
 }
 
+// The overlapped all-reduce of a pipelined solver AND the halo exchange of the SpMV that hides it,
+// behind ONE fork and ONE join: main records one event, the side stream waits for it, reduces,
+// exchanges and records one event that gkoc_comm_exchange_end / _join wait for.  Every event
+// record / cross-stream wait on the main stream is a barrier packet that leaves the device idle
+// for 6-7 us before the next kernel (profiles/r03_dist_sim_timelines.txt); all_reduce_begin +
+// exchange_begin + exchange_end + all_reduce_end are four of them, this pair is two.  Both the
+// values to reduce and the send buffer must be final on the main stream at the call.
+int gkoc_comm_all_reduce_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_stream_t side,
+                                        void* reduce_buf, int64_t reduce_n, size_t reduce_value_size,
+                                        const void* send_buf, const int64_t* send_counts,
+                                        const int64_t* send_displs, void* recv_buf,
+                                        const int64_t* recv_counts, size_t value_size)
+{
+    GKOC_REQUIRE(comm && reduce_buf && reduce_n > 0 && send_counts && recv_counts, GKOC_E_INVALID,
+                 "bad argument");
+    GKOC_REQUIRE(reduce_value_size == 8 || reduce_value_size == 4, GKOC_E_NOT_SUPPORTED,
+                 "value_size must be 4 or 8");
+    GKOC_REQUIRE(side != nullptr && side != main_stream, GKOC_E_INVALID, "needs a side stream");
+    GKOC_REQUIRE(!comm->pending_side && !comm->pending_reduce, GKOC_E_INVALID,
+                 "gkoc_comm_all_reduce_exchange_begin: a previous operation has not been ended");
+    hipStream_t ms = as_stream(main_stream), xs = as_stream(side);
+    int64_t n_msgs = 0;
+    for (int p = 0; p < comm->n_ranks; ++p) {
+        GKOC_REQUIRE(send_counts[p] >= 0 && recv_counts[p] >= 0, GKOC_E_INVALID, "negative count");
+        GKOC_REQUIRE(!send_displs || send_displs[p] >= 0, GKOC_E_INVALID, "negative displacement");
+        n_msgs += (send_counts[p] > 0) + (recv_counts[p] > 0);
+    }
+    GKOC_REQUIRE(n_msgs == 0 || (send_buf && recv_buf), GKOC_E_INVALID, "NULL buffer with non-zero counts");
+    GKOC_HIP(hipEventRecord(comm->packed, ms));
+    GKOC_HIP(hipStreamWaitEvent(xs, comm->packed, 0));
+    GKOC_RCCL(g_rccl.AllReduce(reduce_buf, reduce_buf, static_cast<size_t>(reduce_n),
+                               reduce_value_size == 8 ? nccl_float64 : nccl_float32, nccl_sum, comm->comm, xs));
+    if (n_msgs > 0) {
+        const char* sp = static_cast<const char*>(send_buf);
+        char* rp = static_cast<char*>(recv_buf);
+        GKOC_RCCL(g_rccl.GroupStart());
+        int e = nccl_success;
+        for (int p = 0; p < comm->n_ranks && e == nccl_success; ++p) {
+            const size_t sb = static_cast<size_t>(send_counts[p]) * value_size;
+            const size_t rb = static_cast<size_t>(recv_counts[p]) * value_size;
+            if (send_displs) {
+                sp = static_cast<const char*>(send_buf) + static_cast<size_t>(send_displs[p]) * value_size;
+            }
+            if (sb) e = g_rccl.Send(sp, sb, nccl_uint8, p, comm->comm, xs);
+            if (rb && e == nccl_success) e = g_rccl.Recv(rp, rb, nccl_uint8, p, comm->comm, xs);
+            sp += sb;
+            rp += rb;
+        }
+        int e2 = g_rccl.GroupEnd();
+        if (e != nccl_success) return rccl_fail(e, "ncclSend/ncclRecv", __LINE__);
+        if (e2 != nccl_success) return rccl_fail(e2, "ncclGroupEnd", __LINE__);
+    }
+    GKOC_HIP(hipEventRecord(comm->arrived, xs));
+    comm->pending_side = true;     // ended by gkoc_comm_exchange_end / _join: the reduction is done by then too
+    comm->side_in_use = xs;
+    return GKOC_OK;
+}
+
 // like gkoc_comm_exchange_end, but the main stream waits for EVERYTHING that has been enqueued on
 // the exchange's stream since gkoc_comm_exchange_begin - the halo and the kernels that consume it
 // there (the boundary rows of a slab partition, csr_rowlist_full_kernel)

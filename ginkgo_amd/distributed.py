@@ -234,6 +234,15 @@ class RcclComm(TorchComm):
              self._counts(send_displs) if send_displs is not None else None, recv,
              self._counts(recv_counts), C.c_size_t(send.element_size()))
 
+    def all_reduce_exchange_begin(self, t, recv, send, recv_counts, send_counts, side_stream,
+                                  send_displs=None):
+        """all_reduce_begin(t) and exchange_begin(...) behind ONE fork / join pair: the side stream
+        reduces t, then exchanges; exchange_end / exchange_join end both (no all_reduce_end)"""
+        call("gkoc_comm_all_reduce_exchange_begin", self._handle, self.exec.stream,
+             C.c_void_p(side_stream.cuda_stream), t, t.numel(), C.c_size_t(t.element_size()), send,
+             self._counts(send_counts), self._counts(send_displs) if send_displs is not None else None,
+             recv, self._counts(recv_counts), C.c_size_t(send.element_size()))
+
     def exchange_end(self):
         call("gkoc_comm_exchange_end", self._handle, self.exec.stream)
 
@@ -815,9 +824,35 @@ class DistributedMatrix:
         self.apply(x, y, dot_out=out)
         return True
 
-    def apply(self, x, y, dot_out=None):
-        """y_local = A[owned rows, :] x   (x, y: local parts, n_local x 1)"""
+    def can_start_with_reduce(self, x):
+        """the halo exchange of apply(x, .) can be started together with an all-reduce
+        (begin_exchange_with_reduce): device-resident communicator, zero-copy send planes"""
+        comm = self.comm
+        return (comm.size > 1 and self._side is not None and getattr(comm, "direct", False) and
+                hasattr(comm, "all_reduce_exchange_begin") and hasattr(comm, "exchange_join") and
+                self.send_displs is not None and x.ld == 1 and x.size[1] == 1)
+
+    def begin_exchange_with_reduce(self, x, t):
+        """start the all-reduce of t and the halo exchange of x on the side stream behind one
+        fork; apply(x, y, started=True) must follow (its join ends both)"""
+        self.comm.all_reduce_exchange_begin(t, self.recv_buf.values, x.values, self.recv_counts,
+                                            self.send_counts, self._side, self.send_displs)
+
+    def apply(self, x, y, dot_out=None, started=False):
+        """y_local = A[owned rows, :] x   (x, y: local parts, n_local x 1); started: the halo
+        exchange of x is already under way (begin_exchange_with_reduce)"""
         be, comm = self.backend, self.comm
+        if started:
+            full = self.nl.get("full") if (self.use_full_boundary and hasattr(be, "rowlist_full")) else None
+            if full is not None:
+                be.spmv_rows(self.local, full["interior"][0], full["interior"][1], x, y)
+                be.rowlist_full(self.nl, x, self.recv_buf, y, self._side)
+                comm.exchange_join()
+            else:
+                be.spmv(self.local, x, y)
+                comm.exchange_join()
+                be.rowlist_add(self.nl, self.recv_buf, y)
+            return y
         if dot_out is not None:
             local_spmv = lambda: be.spmv_dot(self.local, x, y, dot_out)
         else:
@@ -1185,7 +1220,15 @@ class DistributedPipeCg:
                 if with_m:
                     self._precond(w, m)
 
+            # m is final where the three sums are (the step kernel computed it): reduction and halo
+            # exchange start together behind one fork, the SpMV's join ends both
+            together = with_m and hasattr(a, "can_start_with_reduce") and a.can_start_with_reduce(m)
+
             def mid(prev):                       # reduce what the last step kernel left in `prev`
+                if together:
+                    a.begin_exchange_with_reduce(m, prev[0])
+                    a.apply(m, n, started=True)
+                    return
                 comm.all_reduce_begin(prev[0], self._side)
                 if not with_m:
                     self._precond(w, m)

@@ -1683,6 +1683,17 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream,
                              const int64_t* send_displs, void* recv_buf,
                              const int64_t* recv_counts, size_t value_size);
 int gkoc_comm_exchange_end(gkoc_comm_t comm, gkoc_stream_t main_stream);
+/* gkoc_comm_all_reduce_begin AND gkoc_comm_exchange_begin behind one fork and one join (two
+ * barrier packets on the main stream instead of four): the side stream reduces, then exchanges;
+ * gkoc_comm_exchange_end / _join end both.  What a pipelined solver wants when the vector whose
+ * halo travels is final at the point where its dot products are (PipeCg with the preconditioner
+ * application inside its step kernel). */
+int gkoc_comm_all_reduce_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream,
+                                        gkoc_stream_t side, void* reduce_buf, int64_t reduce_n,
+                                        size_t reduce_value_size, const void* send_buf,
+                                        const int64_t* send_counts, const int64_t* send_displs,
+                                        void* recv_buf, const int64_t* recv_counts,
+                                        size_t value_size);
 /* the same, but main_stream also waits for the kernels enqueued on the exchange's stream since
  * gkoc_comm_exchange_begin (the boundary rows, computed there as soon as the halo is in) */
 int gkoc_comm_exchange_join(gkoc_comm_t comm, gkoc_stream_t main_stream);

@@ -62,6 +62,22 @@ def mirror_problem(grid, direct=False):
         def all_to_all_counts(self, send_counts):
             return list(send_counts)
 
+        def all_reduce_exchange_begin(self, t, recv, send, recv_counts, send_counts, side_stream,
+                                      send_displs=None):
+            # reduction + exchange behind one fork: the real combined RCCL call (to ourselves) ...
+            assert list(recv_counts) == [0, plane] and list(send_counts) == [0, plane]
+            calls["ar_with_exchange"] = calls.get("ar_with_exchange", 0) + 1
+            super().all_reduce_exchange_begin(t, recv, send, [plane], [plane], side_stream,
+                                              None if send_displs is None else [send_displs[1]])
+            self._pending_joint = t
+
+        def exchange_join(self):
+            super().exchange_join()
+            t, self._pending_joint = getattr(self, "_pending_joint", None), None
+            if t is not None:
+                # ... and the peer's equal contribution once the main stream has the result
+                call("gkoc_dense_scale_f64", self.exec.stream, t.numel(), 1, self.two.values, 1, t, 1)
+
         def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None,
                            send_displs=None):
             assert list(recv_counts) == [0, plane] and list(send_counts) == [0, plane]
@@ -181,7 +197,17 @@ def main():
     if direct:
         import ctypes as C  # noqa: F401
         from ginkgo_amd._lib import call
-        assert pipe.taped and calls.get("ar_overlapped", 0) >= 2
+        # default: the reduction starts together with the halo exchange (one fork / join pair) ...
+        assert pipe.taped and calls.get("ar_with_exchange", 0) >= 2, calls
+        # ... without the preconditioner inside the step kernel m is not final at that point:
+        # all_reduce_begin / _end on the side stream, the exchange inside the SpMV
+        sep = gd.DistributedPipeCg(be, comm, a, 500, 1e-10, 8, fused_jacobi=False)
+        xs_ = be.vector(hi - lo)
+        sep.apply(be.vector_from(np.ones(hi - lo)), xs_)
+        assert calls.get("ar_overlapped", 0) >= 2 and sep.num_iterations == pipe.num_iterations, calls
+        # (the three sums come from another reduction tree there, so the iterates agree to rounding)
+        d = np.linalg.norm(xs_.to_numpy() - xq.to_numpy()) / np.linalg.norm(xq.to_numpy())
+        assert d < 1e-9, d
         plain_pipe = gd.DistributedPipeCg(be, comm, a, 500, 1e-10, 8, taped=False, check_lag=0)
         xq0 = be.vector(hi - lo)
         plain_pipe.apply(be.vector_from(np.ones(hi - lo)), xq0)

@@ -34,11 +34,21 @@ class FakeComm:
     def all_reduce_sum_(self, t):
         return t
 
+    # the overlapped all-reduce: no transfer, but the same event records / cross-stream waits as
+    # gkoc_comm_all_reduce_begin / _end (each is a barrier packet on the device)
     def all_reduce_begin(self, t, side_stream=None):
+        if side_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            side_stream.wait_event(ev)
+            self._ar_done = torch.cuda.Event()
+            self._ar_done.record(side_stream)
         return t
 
     def all_reduce_end(self):
-        pass
+        if getattr(self, "_ar_done", None) is not None:
+            torch.cuda.current_stream().wait_event(self._ar_done)
+            self._ar_done = None
 
     def all_to_all_counts(self, send_counts):
         return list(send_counts)
@@ -57,6 +67,11 @@ class FakeComm:
 
     def exchange_end(self):
         self.exchange_join()
+
+    if os.environ.get("GKO_SIM_SEPARATE_REDUCE") != "1":
+        def all_reduce_exchange_begin(self, t, recv, send, recv_counts, send_counts, side_stream,
+                                      send_displs=None):
+            self.exchange_begin(recv, send, recv_counts, send_counts, side_stream, send_displs)
 
     def exchange_join(self):
         ev = torch.cuda.Event()
