@@ -166,7 +166,7 @@ try {
 
     gkoc_stream_t s = nullptr, side = nullptr;
     if (!getenv("GKOC_EXAMPLE_NULL_STREAM")) CK(gkoc_stream_create(&s));   // else: the NULL stream
-    CK(gkoc_stream_create(&side));
+    CK(gkoc_stream_create_high_priority(&side));   // collectives must get onto the device beside the SpMV
 
     // ---- communicator (RCCL), id through a file
     gkoc_comm_t comm = nullptr;
@@ -247,7 +247,7 @@ try {
     // [rho, delta, ||r||^2] - what one iteration all-reduces is adjacent
     dev_array<double> sc(16);
     double *grp_a = sc.p, *grp_b = sc.p + 3, *beta = sc.p + 6, *tau0 = sc.p + 7,
-           *neg_one = sc.p + 9, *two = sc.p + 10, *tmp = sc.p + 11;
+           *neg_one = sc.p + 9, *two = sc.p + 10, *tmp = sc.p + 11, *beta2 = sc.p + 12;
     sc.upload({0, 0, 0, 1, 0, 0, 0, 0, 1, -1, 2, 0, 0, 0, 0, 0});
     dev_array<uint8_t> stop(1);
     const size_t red_bytes = gkoc_reduction_workspace_bytes(n, 1, sizeof(double));
@@ -299,8 +299,8 @@ try {
     // dot != nullptr: also the LOCAL part of <v, y> (fused into the local SpMV, the boundary rows'
     // share next to their update)
     dev_array<double> nl_dot_ws(size_t((n_nl_rows + 63) / 64 + 1));
-    auto dist_apply = [&](const double* v, double* y, double* dot = nullptr) {
-        if (world > 1) {
+    auto dist_apply = [&](const double* v, double* y, double* dot = nullptr, bool started = false) {
+        if (world > 1 && !started) {
             scoped t{spent[T_EXCHANGE]};
             CK(gkoc_comm_exchange_begin(comm, s, side, v, send_counts.data(), send_displs.data(),
                                         halo.p, recv_counts.data(), sizeof(double)));
@@ -345,9 +345,12 @@ try {
         const int slot = next_slot;
         next_slot = (next_slot + 1) % NSLOT;
         // the kernel writes its two flags straight into pinned host memory
-        uint8_t* df = flags_host + 2 * slot;
-        CK(gkoc_implicit_residual_norm_f64(s, 1, tau_sq, tau0, reduction, 2, 1, stop.p, df, nullptr, nullptr));
-        CK(gkoc_event_record(events[slot], s));
+        // (no event behind it: an event record is a barrier packet that idles the device for
+        // 6-7 us; the host sets the slot to 0xFF and polls it when it wants the answer)
+        volatile uint8_t* df = flags_host + 2 * slot;
+        df[0] = df[1] = 0xFF;
+        CK(gkoc_implicit_residual_norm_f64(s, 1, tau_sq, tau0, reduction, 2, 1, stop.p,
+                                           const_cast<uint8_t*>(df), nullptr, nullptr));
         pending.push_back({iteration, slot});
     };
     double wait_seconds = 0;   // time the host spent WAITING for criterion flags (not enqueueing)
@@ -356,9 +359,13 @@ try {
             const pending_check c = pending.front();
             pending.pop_front();
             const auto t0 = std::chrono::steady_clock::now();
-            CK(gkoc_event_synchronize(events[c.slot]));
+            volatile uint8_t* df = flags_host + 2 * c.slot;
+            for (long spins = 0; df[0] == 0xFF || df[1] == 0xFF; ++spins) {
+                if (spins == 100000) CK(gkoc_stream_synchronize(s));   // visible at the latest then
+                if (spins > 200000) throw std::runtime_error("criterion flags did not arrive");
+            }
             wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (flags_host[2 * c.slot] != 0) { stop_it = c.it; return true; }
+            if (df[0] != 0) { stop_it = c.it; return true; }
         }
         return false;
     };
@@ -432,14 +439,28 @@ try {
         if (!drain(0, stop_it)) {
             CK(gkoc_pipe_cg_initialize_2_f64(s, n, 1, p.p, 1, q.p, 1, f->p, 1, g->p, 1, beta, z.p, 1, w->p, 1,
                                              m->p, 1, nn->p, 1, cur + 1));
+            // The first step_1 (+ its three sums) and m = M^-1 w stand alone; from then on step_2 of
+            // iteration k, step_1 of k + 1, the sums and m = M^-1 w are ONE kernel, and the all-reduce
+            // of the sums starts together with the halo exchange of n = A m behind one fork / join
+            // (gkoc_comm_all_reduce_exchange_begin): both travel while the local SpMV runs.
+            double* betas[2] = {beta, beta2};
+            CK(gkoc_x_pipe_cg_step_1_dots_f64(s, n, x.p, r.p, z.p, w->p, p.p, q.p, f->p, g->p, cur, betas[0],
+                                              stop.p, prev, x_ws.p, x_bytes));
+            precond(w->p, m->p);
             for (;;) {
-                // step_1 and the three local sums in one pass; they travel while M^-1 and A run
-                CK(gkoc_x_pipe_cg_step_1_dots_f64(s, n, x.p, r.p, z.p, w->p, p.p, q.p, f->p, g->p, cur, beta,
-                                                  stop.p, prev, x_ws.p, x_bytes));
-                all_reduce_begin(prev, 3);
-                precond(w->p, m->p);
-                dist_apply(m->p, nn->p);
-                all_reduce_end();
+                const int parity = int(it & 1);
+                if (world > 1) {
+                    {
+                        scoped t{spent[T_ALLREDUCE]};
+                        CK(gkoc_comm_all_reduce_exchange_begin(comm, s, side, prev, 3, sizeof(double), m->p,
+                                                               send_counts.data(), send_displs.data(), halo.p,
+                                                               recv_counts.data(), sizeof(double)));
+                    }
+                    dist_apply(m->p, nn->p, nullptr, true);
+                    if (mirror) CK(gkoc_dense_scale_f64(s, 1, 3, two, 1, prev, 3));
+                } else {
+                    dist_apply(m->p, nn->p);
+                }
                 std::swap(cur, prev);   // cur = the new [rho, delta, ||r||^2], prev = the old rho
                 ++it;
                 stop_it = it;
@@ -450,8 +471,10 @@ try {
                 }
                 check_begin(it, cur + 2);
                 if (drain(it - lag, stop_it)) { it = stop_it; break; }
-                CK(gkoc_pipe_cg_step_2_f64(s, n, 1, beta, p.p, 1, q.p, 1, f->p, 1, g->p, 1, z.p, 1, w->p, 1,
-                                           m->p, 1, nn->p, 1, prev, cur, cur + 1, stop.p));
+                CK(gkoc_x_pipe_cg_steps_jacobi_f64_i32(s, num_blocks, n, bs, scheme, block_ptrs.p, blocks.p, x.p,
+                                                       r.p, z.p, w->p, p.p, q.p, f->p, g->p, m->p, nn->p, prev,
+                                                       cur, cur + 1, betas[parity], betas[1 - parity], stop.p,
+                                                       prev, x_ws.p, x_bytes));
             }
         }
     }

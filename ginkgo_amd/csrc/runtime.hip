@@ -327,6 +327,20 @@ int gkoc_stream_create(gkoc_stream_t* s)
     return GKOC_OK;
 }
 
+// a stream whose kernels are dispatched ahead of those of ordinary streams: for the few
+// workgroups of a collective or of the boundary rows that must get onto the device while a
+// device-filling kernel runs on another stream
+int gkoc_stream_create_high_priority(gkoc_stream_t* s)
+{
+    GKOC_REQUIRE(s, GKOC_E_INVALID, "s == NULL");
+    int least = 0, greatest = 0;
+    GKOC_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t st;
+    GKOC_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+    *s = st;
+    return GKOC_OK;
+}
+
 int gkoc_stream_destroy(gkoc_stream_t s)
 {
     if (s) GKOC_HIP(hipStreamDestroy(as_stream(s)));

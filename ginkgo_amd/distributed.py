@@ -758,7 +758,10 @@ class HipBackend:
         self.exec.synchronize()
 
     def side_stream(self):
-        return torch.cuda.Stream(device=self.exec.device)
+        # high priority: what runs here (RCCL's send / recv and all-reduce kernels, the boundary
+        # rows) are a few workgroups that must get onto the device WHILE the local SpMV fills it;
+        # with equal priority they queue behind its tens of thousands of workgroups
+        return torch.cuda.Stream(device=self.exec.device, priority=-1)
 
 
 class DistributedMatrix:

@@ -161,6 +161,7 @@ int gkoc_memcpy_d2h(void* dst_host, const void* src, size_t bytes, gkoc_stream_t
 int gkoc_memcpy_d2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s);
 int gkoc_memset(void* dst, int value, size_t bytes, gkoc_stream_t s);
 int gkoc_stream_create(gkoc_stream_t* s);
+int gkoc_stream_create_high_priority(gkoc_stream_t* s);   /* for the exchange / collective side stream */
 int gkoc_stream_destroy(gkoc_stream_t s);
 int gkoc_stream_synchronize(gkoc_stream_t s);
 int gkoc_device_synchronize(void);
