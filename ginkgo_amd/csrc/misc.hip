@@ -286,3 +286,33 @@ GKOC_DEF_MISC_TI(float, f32, int64_t, i64)
     }
 GKOC_DEF_MISC_I(int32_t, i32)
 GKOC_DEF_MISC_I(int64_t, i64)
+
+// components::fill_array for the small integer types Ginkgo's arrays are instantiated with (bool,
+// char, uint16, uint32: core/components/fill_array_kernels.hpp:18-21 over
+// GKO_INSTANTIATE_FOR_EACH_TEMPLATE_TYPE); elem_bytes 1, 2 or 4, the low bytes of `pattern`
+namespace gkoc {
+namespace {
+template <typename U>
+__global__ __launch_bounds__(256) void fill_small_kernel(int64_t n, U* __restrict__ data, U value)
+{
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) data[i] = value;
+}
+}  // namespace
+}  // namespace gkoc
+
+extern "C" int gkoc_fill_array_small(gkoc_stream_t s, void* data, int64_t n, int elem_bytes, uint32_t pattern)
+{
+    GKOC_REQUIRE(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4, GKOC_E_INVALID, "elem_bytes");
+    if (n <= 0) return GKOC_OK;
+    const dim3 g(grid_of(n));
+    if (elem_bytes == 1) {
+        fill_small_kernel<uint8_t><<<g, dim3(256), 0, as_stream(s)>>>(n, static_cast<uint8_t*>(data), uint8_t(pattern));
+    } else if (elem_bytes == 2) {
+        fill_small_kernel<uint16_t><<<g, dim3(256), 0, as_stream(s)>>>(n, static_cast<uint16_t*>(data),
+                                                                       uint16_t(pattern));
+    } else {
+        fill_small_kernel<uint32_t><<<g, dim3(256), 0, as_stream(s)>>>(n, static_cast<uint32_t*>(data), pattern);
+    }
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}

@@ -7,10 +7,13 @@
 
 #include <ginkgo/core/base/device_matrix_data.hpp>
 #include <ginkgo/core/base/matrix_data.hpp>
+#include <ginkgo/core/matrix/csr.hpp>
 #include <ginkgo/core/matrix/dense.hpp>
+#include <ginkgo/core/matrix/diagonal.hpp>
 
 #include "core/base/device_matrix_data_kernels.hpp"
 #include "core/components/fill_array_kernels.hpp"
+#include "core/matrix/csr_kernels.hpp"
 #include "core/matrix/dense_kernels.hpp"
 #include "shim_common.hpp"
 
@@ -182,7 +185,254 @@ namespace dense {
 FOR_CT(DEF)
 #undef DEF
 
+// BLAS-1 on complex columns (csrc/complex_blas.hip); S = C (complex scalars) or R (real scalars)
+#define DEF_AXPY(C, P, TN, R, S, IS_REAL)                                                        \
+    template <>                                                                                  \
+    void scale<C, S>(exec_t exec, const matrix::Dense<S>* alpha, matrix::Dense<C>* x)            \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_scale_##TN(stream_of(exec), rows(x), cols(x),                      \
+                                         alpha->get_const_values(), cols(alpha), IS_REAL,        \
+                                         pairs(x->get_values()), ld(x)));                        \
+    }                                                                                            \
+    template <>                                                                                  \
+    void inv_scale<C, S>(exec_t exec, const matrix::Dense<S>* alpha, matrix::Dense<C>* x)        \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_inv_scale_##TN(stream_of(exec), rows(x), cols(x),                  \
+                                             alpha->get_const_values(), cols(alpha), IS_REAL,    \
+                                             pairs(x->get_values()), ld(x)));                    \
+    }                                                                                            \
+    template <>                                                                                  \
+    void add_scaled<C, S>(exec_t exec, const matrix::Dense<S>* alpha, const matrix::Dense<C>* x, \
+                          matrix::Dense<C>* y)                                                   \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_add_scaled_##TN(stream_of(exec), rows(y), cols(y),                 \
+                                              alpha->get_const_values(), cols(alpha), IS_REAL,   \
+                                              pairs(x->get_const_values()), ld(x),               \
+                                              pairs(y->get_values()), ld(y)));                   \
+    }                                                                                            \
+    template <>                                                                                  \
+    void sub_scaled<C, S>(exec_t exec, const matrix::Dense<S>* alpha, const matrix::Dense<C>* x, \
+                          matrix::Dense<C>* y)                                                   \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_sub_scaled_##TN(stream_of(exec), rows(y), cols(y),                 \
+                                              alpha->get_const_values(), cols(alpha), IS_REAL,   \
+                                              pairs(x->get_const_values()), ld(x),               \
+                                              pairs(y->get_values()), ld(y)));                   \
+    }
+#define DEF(C, P, TN, R, RN) DEF_AXPY(C, P, TN, R, C, 0) DEF_AXPY(C, P, TN, R, R, 1)
+FOR_CT(DEF)
+#undef DEF
+#undef DEF_AXPY
+
+#define DEF(C, P, TN, R, RN)                                                                     \
+    template <>                                                                                  \
+    void compute_dot<C>(exec_t exec, const matrix::Dense<C>* x, const matrix::Dense<C>* y,       \
+                        matrix::Dense<C>* result, array<char>&)                                  \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_compute_dot_##TN(stream_of(exec), rows(x), cols(x),                \
+                                               pairs(x->get_const_values()), ld(x),              \
+                                               pairs(y->get_const_values()), ld(y),              \
+                                               pairs(result->get_values()), 0));                 \
+    }                                                                                            \
+    template <>                                                                                  \
+    void compute_dot_dispatch<C>(exec_t exec, const matrix::Dense<C>* x,                         \
+                                 const matrix::Dense<C>* y, matrix::Dense<C>* result,            \
+                                 array<char>& tmp)                                               \
+    {                                                                                            \
+        compute_dot<C>(exec, x, y, result, tmp);                                                 \
+    }                                                                                            \
+    template <>                                                                                  \
+    void compute_conj_dot<C>(exec_t exec, const matrix::Dense<C>* x, const matrix::Dense<C>* y,  \
+                             matrix::Dense<C>* result, array<char>&)                             \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_compute_dot_##TN(stream_of(exec), rows(x), cols(x),                \
+                                               pairs(x->get_const_values()), ld(x),              \
+                                               pairs(y->get_const_values()), ld(y),              \
+                                               pairs(result->get_values()), 1));                 \
+    }                                                                                            \
+    template <>                                                                                  \
+    void compute_conj_dot_dispatch<C>(exec_t exec, const matrix::Dense<C>* x,                    \
+                                      const matrix::Dense<C>* y, matrix::Dense<C>* result,       \
+                                      array<char>& tmp)                                          \
+    {                                                                                            \
+        compute_conj_dot<C>(exec, x, y, result, tmp);                                            \
+    }                                                                                            \
+    template <>                                                                                  \
+    void compute_squared_norm2<C>(exec_t exec, const matrix::Dense<C>* x,                        \
+                                  matrix::Dense<R>* result, array<char>&)                        \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_compute_squared_norm2_##TN(stream_of(exec), rows(x), cols(x),      \
+                                                         pairs(x->get_const_values()), ld(x),    \
+                                                         result->get_values()));                 \
+    }                                                                                            \
+    template <>                                                                                  \
+    void compute_mean<C>(exec_t exec, const matrix::Dense<C>* x, matrix::Dense<C>* result,       \
+                         array<char>&)                                                           \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_compute_mean_##TN(stream_of(exec), rows(x), cols(x),               \
+                                                pairs(x->get_const_values()), ld(x),             \
+                                                pairs(result->get_values())));                   \
+    }                                                                                            \
+    template <>                                                                                  \
+    void compute_mean<R>(exec_t exec, const matrix::Dense<R>* x, matrix::Dense<R>* result,       \
+                         array<char>&)                                                           \
+    {                                                                                            \
+        GKOC_CALL(gkoc_dense_compute_mean_##RN(stream_of(exec), rows(x), cols(x),                \
+                                               x->get_const_values(), ld(x),                     \
+                                               result->get_values()));                           \
+    }                                                                                            \
+    template <>                                                                                  \
+    void make_complex<R>(exec_t exec, const matrix::Dense<R>* source, matrix::Dense<C>* result)  \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_convert_##TN(stream_of(exec), rows(source), cols(source),          \
+                                           source->get_const_values(), ld(source),               \
+                                           result->get_values(), ld(result), 0));                \
+    }                                                                                            \
+    template <>                                                                                  \
+    void make_complex<C>(exec_t exec, const matrix::Dense<C>* source, matrix::Dense<C>* result)  \
+    {                                                                                            \
+        GKOC_CALL(gkoc_dense_copy_##RN(stream_of(exec), rows(source), 2 * cols(source),          \
+                                       reinterpret_cast<const R*>(source->get_const_values()),   \
+                                       2 * ld(source),                                           \
+                                       reinterpret_cast<R*>(result->get_values()),               \
+                                       2 * ld(result)));                                         \
+    }                                                                                            \
+    template <>                                                                                  \
+    void get_real<C>(exec_t exec, const matrix::Dense<C>* source, matrix::Dense<R>* result)      \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_convert_##TN(stream_of(exec), rows(source), cols(source),          \
+                                           source->get_const_values(), ld(source),               \
+                                           result->get_values(), ld(result), 1));                \
+    }                                                                                            \
+    template <>                                                                                  \
+    void get_imag<C>(exec_t exec, const matrix::Dense<C>* source, matrix::Dense<R>* result)      \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_convert_##TN(stream_of(exec), rows(source), cols(source),          \
+                                           source->get_const_values(), ld(source),               \
+                                           result->get_values(), ld(result), 2));                \
+    }                                                                                            \
+    template <>                                                                                  \
+    void conj_transpose<C>(exec_t exec, const matrix::Dense<C>* orig, matrix::Dense<C>* trans)   \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_convert_##TN(stream_of(exec), rows(orig), cols(orig),              \
+                                           orig->get_const_values(), ld(orig),                   \
+                                           trans->get_values(), ld(trans), 3));                  \
+    }
+FOR_CT(DEF)
+#undef DEF
+
+#define DEF(C, P, TN, R, RN)                                                                     \
+    template <>                                                                                  \
+    void inplace_absolute_dense<C>(exec_t exec, matrix::Dense<C>* source)                        \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_absolute_##TN(stream_of(exec), rows(source), cols(source),         \
+                                            pairs(source->get_values()), ld(source), nullptr, 0, \
+                                            0));                                                 \
+    }                                                                                            \
+    template <>                                                                                  \
+    void outplace_absolute_dense<C>(exec_t exec, const matrix::Dense<C>* source,                 \
+                                    matrix::Dense<R>* result)                                    \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_absolute_##TN(stream_of(exec), rows(source), cols(source),         \
+                                            const_cast<P*>(pairs(source->get_const_values())),   \
+                                            ld(source), result->get_values(), ld(result), 1));   \
+    }                                                                                            \
+    template <>                                                                                  \
+    void compute_norm1<C>(exec_t exec, const matrix::Dense<C>* x, matrix::Dense<R>* result,      \
+                          array<char>&)                                                          \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_compute_norm1_##TN(stream_of(exec), rows(x), cols(x),              \
+                                                 pairs(x->get_const_values()), ld(x),            \
+                                                 result->get_values()));                         \
+    }
+FOR_CT(DEF)
+#undef DEF
+
+#define DEF(C, TN, I, IN)                                                                        \
+    template <>                                                                                  \
+    void row_gather<C, C, I>(exec_t exec, const I* gather_indices, const matrix::Dense<C>* orig, \
+                             matrix::Dense<C>* row_collection)                                   \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_row_gather_##TN##_##IN(                                            \
+            stream_of(exec), rows(row_collection), cols(orig), gather_indices,                   \
+            pairs(orig->get_const_values()), ld(orig), pairs(row_collection->get_values()),      \
+            ld(row_collection)));                                                                \
+    }                                                                                            \
+    template <>                                                                                  \
+    void fill_in_matrix_data<C, I>(exec_t exec, const device_matrix_data<C, I>& data,            \
+                                   matrix::Dense<C>* output)                                     \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_fill_in_matrix_data_##TN##_##IN(                                   \
+            stream_of(exec), static_cast<int64_t>(data.get_num_stored_elements()),               \
+            data.get_const_row_idxs(), data.get_const_col_idxs(), pairs(data.get_const_values()),\
+            pairs(output->get_values()), ld(output)));                                           \
+    }
+FOR_CT_IT(DEF)
+#undef DEF
+
 }  // namespace dense
+
+
+namespace csr {
+
+// Csr with complex values: plain kernels (csrc/complex_blas.hip), so that Ginkgo's distributed
+// Matrix / Schwarz work for every value type their tests instantiate
+#define DEF(C, TN, I, IN)                                                                        \
+    template <>                                                                                  \
+    void spmv<C, C, C, I>(exec_t exec, const matrix::Csr<C, I>* a, const matrix::Dense<C>* b,    \
+                          matrix::Dense<C>* c)                                                   \
+    {                                                                                            \
+        GKOC_CALL(gkoc_ccsr_spmv_##TN##_##IN(                                                    \
+            stream_of(exec), rows(c), cols(c), a->get_const_row_ptrs(), a->get_const_col_idxs(), \
+            pairs(a->get_const_values()), nullptr, pairs(b->get_const_values()), ld(b), nullptr, \
+            pairs(c->get_values()), ld(c)));                                                     \
+    }                                                                                            \
+    template <>                                                                                  \
+    void advanced_spmv<C, C, C, I>(exec_t exec, const matrix::Dense<C>* alpha,                   \
+                                   const matrix::Csr<C, I>* a, const matrix::Dense<C>* b,        \
+                                   const matrix::Dense<C>* beta, matrix::Dense<C>* c)            \
+    {                                                                                            \
+        GKOC_CALL(gkoc_ccsr_spmv_##TN##_##IN(                                                    \
+            stream_of(exec), rows(c), cols(c), a->get_const_row_ptrs(), a->get_const_col_idxs(), \
+            pairs(a->get_const_values()), pairs(alpha->get_const_values()),                      \
+            pairs(b->get_const_values()), ld(b), pairs(beta->get_const_values()),                \
+            pairs(c->get_values()), ld(c)));                                                     \
+    }                                                                                            \
+    template <>                                                                                  \
+    void extract_diagonal<C, I>(exec_t exec, const matrix::Csr<C, I>* orig,                      \
+                                matrix::Diagonal<C>* diag)                                       \
+    {                                                                                            \
+        GKOC_CALL(gkoc_ccsr_row_scan_##TN##_##IN(                                                \
+            stream_of(exec), static_cast<int64_t>(diag->get_size()[0]),                          \
+            orig->get_const_row_ptrs(), orig->get_const_col_idxs(),                              \
+            pairs(orig->get_const_values()), pairs(diag->get_values()), 0));                     \
+    }                                                                                            \
+    template <>                                                                                  \
+    void row_wise_absolute_sum<C, I>(exec_t exec, const matrix::Csr<C, I>* orig, array<C>& sum)  \
+    {                                                                                            \
+        GKOC_CALL(gkoc_ccsr_row_scan_##TN##_##IN(                                                \
+            stream_of(exec), static_cast<int64_t>(orig->get_size()[0]),                          \
+            orig->get_const_row_ptrs(), orig->get_const_col_idxs(),                              \
+            pairs(orig->get_const_values()), pairs(sum.get_data()), 1));                         \
+    }
+FOR_CT_IT(DEF)
+#undef DEF
+
+#define DEF(T, TN, I, IN)                                                                        \
+    template <>                                                                                  \
+    void row_wise_absolute_sum<T, I>(exec_t exec, const matrix::Csr<T, I>* orig, array<T>& sum)  \
+    {                                                                                            \
+        GKOC_CALL(gkoc_csr_row_wise_absolute_sum_##TN##_##IN(                                    \
+            stream_of(exec), static_cast<int64_t>(orig->get_size()[0]),                          \
+            orig->get_const_row_ptrs(), orig->get_const_values(), sum.get_data()));              \
+    }
+DEF(double, f64, int32, i32)
+DEF(double, f64, int64, i64)
+DEF(float, f32, int32, i32)
+DEF(float, f32, int64, i64)
+#undef DEF
+
+}  // namespace csr
 
 
 }  // namespace hip

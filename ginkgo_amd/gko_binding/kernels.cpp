@@ -1065,6 +1065,19 @@ void fill_array<size_type>(exec_t exec, size_type* data, size_type n,
                                   reinterpret_cast<int64_t*>(data), n,
                                   static_cast<int64_t>(val)));
 }
+#define DEF(U)                                                                      \
+    template <>                                                                     \
+    void fill_array<U>(exec_t exec, U* data, size_type n, U val)                    \
+    {                                                                               \
+        GKOC_CALL(gkoc_fill_array_small(stream_of(exec), data, static_cast<int64_t>(n), \
+                                        static_cast<int>(sizeof(U)),                \
+                                        static_cast<uint32_t>(val)));               \
+    }
+DEF(bool)
+DEF(char)
+DEF(uint16)
+DEF(uint32)
+#undef DEF
 template <>
 void fill_seq_array<int32>(exec_t exec, int32* data, size_type n)
 {

@@ -91,9 +91,16 @@ gkoc_stream_t stream()
     return g_stream;
 }
 
+// What a GPU-aware MPI does implicitly when it is handed a device buffer: the kernels that produced
+// it are complete before the buffer is read.  Ginkgo's reductions and the RowGatherer synchronize
+// themselves (vector.cpp:484-657, row_gatherer.cpp:165: the wait below finds an idle device), but
+// assemble_rows_from_neighbors (core/distributed/assembly.cpp:69-96) fills its send buffers on the
+// executor's stream and calls MPI_Ialltoallv at once - a library that copies with hipMemcpy gets the
+// ordering from the legacy null stream, the side stream of this layer does not.
 void flush_binding()
 {
     if (gko_cdna4_launch_deferred) gko_cdna4_launch_deferred();
+    gkoc_device_synchronize();
 }
 
 // pinned host staging buffers, recycled

@@ -1141,6 +1141,88 @@ int gkoc_dense_compute_norm2_c128(gkoc_stream_t s, int64_t rows, int64_t cols, c
                                   int64_t ldx, double* result, void* work, size_t work_bytes);
 int gkoc_dense_compute_norm2_c64(gkoc_stream_t s, int64_t rows, int64_t cols, const gkoc_c64* x,
                                  int64_t ldx, float* result, void* work, size_t work_bytes);
+/* Dense BLAS-1 on complex columns (csrc/complex_blas.hip) - the complex instantiations of
+ * dense::{scale, inv_scale, add_scaled, sub_scaled, compute_dot, compute_conj_dot,
+ * compute_squared_norm2, compute_mean, make_complex, get_real, get_imag, conj_transpose, row_gather,
+ * fill_in_matrix_data} (core/matrix/dense_kernels.hpp:34-135, :236-262, :355-373; semantics
+ * reference/matrix/dense_kernels.cpp:184-440, :832-841, :916-925, :1208-1250).  ld* in complex
+ * elements.  alpha: 1 or `cols` scalars on the device, complex pairs, or reals when scalar_is_real
+ * (Ginkgo's ScalarType = remove_complex<ValueType> instantiation). */
+#define GKOC_DECL_CBLAS(P, TN, R)                                                                      \
+    int gkoc_cdense_scale_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const void* alpha,         \
+                               int64_t alpha_cols, int scalar_is_real, P* x, int64_t ldx);             \
+    int gkoc_cdense_inv_scale_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const void* alpha,     \
+                                   int64_t alpha_cols, int scalar_is_real, P* x, int64_t ldx);         \
+    int gkoc_cdense_add_scaled_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const void* alpha,    \
+                                    int64_t alpha_cols, int scalar_is_real, const P* x, int64_t ldx,   \
+                                    P* y, int64_t ldy);                                                \
+    int gkoc_cdense_sub_scaled_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const void* alpha,    \
+                                    int64_t alpha_cols, int scalar_is_real, const P* x, int64_t ldx,   \
+                                    P* y, int64_t ldy);                                                \
+    /* result[j] = sum_i x(i,j) y(i,j), or sum_i conj(x(i,j)) y(i,j) when conjugate_x */               \
+    int gkoc_cdense_compute_dot_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* x,          \
+                                     int64_t ldx, const P* y, int64_t ldy, P* result,                  \
+                                     int conjugate_x);                                                 \
+    int gkoc_cdense_compute_squared_norm2_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,            \
+                                               const P* x, int64_t ldx, R* result);                    \
+    int gkoc_cdense_compute_mean_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* x,         \
+                                      int64_t ldx, P* result);                                         \
+    /* mode 0 make_complex (in: reals, out: pairs), 1 get_real, 2 get_imag (in: pairs, out: reals),    \
+     * 3 conj_transpose (in rows x cols, out cols x rows, both pairs) */                               \
+    int gkoc_cdense_convert_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const void* in,          \
+                                 int64_t ld_in, void* out, int64_t ld_out, int mode);
+GKOC_DECL_CBLAS(gkoc_c128, c128, double)
+GKOC_DECL_CBLAS(gkoc_c64, c64, float)
+#define GKOC_DECL_CBLAS_I(P, TN, I, IN)                                                                \
+    int gkoc_cdense_row_gather_##TN##_##IN(gkoc_stream_t s, int64_t n_gather, int64_t cols,            \
+                                           const I* rows, const P* orig, int64_t ld_orig, P* gathered, \
+                                           int64_t ld_gathered);                                       \
+    int gkoc_cdense_fill_in_matrix_data_##TN##_##IN(gkoc_stream_t s, int64_t nnz, const I* rows,       \
+                                                    const I* cols, const P* vals, P* out, int64_t ld);
+GKOC_DECL_CBLAS_I(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_CBLAS_I(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_CBLAS_I(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_CBLAS_I(gkoc_c64, c64, int64_t, i64)
+/* absolute values and 1-norms of complex columns (dense::inplace_absolute_dense,
+ * outplace_absolute_dense, compute_norm1; |z| = hypot(re, im)) */
+#define GKOC_DECL_CABS(P, TN, R)                                                                       \
+    /* mode 0: x = |x| in place (imaginary parts 0), out unused; 1: out (reals, ld_out) = |x| */       \
+    int gkoc_cdense_absolute_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, P* x, int64_t ldx,      \
+                                  R* out, int64_t ld_out, int mode);                                   \
+    int gkoc_cdense_compute_norm1_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* x,        \
+                                       int64_t ldx, R* result);
+GKOC_DECL_CABS(gkoc_c128, c128, double)
+GKOC_DECL_CABS(gkoc_c64, c64, float)
+/* CSR with complex values (csr::spmv / advanced_spmv / extract_diagonal / row_wise_absolute_sum of
+ * core/matrix/csr_kernels.hpp for complex values): one thread per (row, right-hand side) - the complex
+ * instantiations exist so that Ginkgo's distributed classes work for every value type its tests
+ * instantiate, they are not a tuned path.  alpha == NULL: y = A x; else y = alpha[0] A x + beta[0] y.
+ * row_scan mode 0: out[row] = a(row, row) where stored; 1: out[row] = sum_k |a(row, k)| */
+#define GKOC_DECL_CCSR(P, TN, I, IN)                                                                   \
+    int gkoc_ccsr_spmv_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t nrhs, const I* row_ptrs,     \
+                                   const I* col_idxs, const P* vals, const P* alpha, const P* x,       \
+                                   int64_t ldx, const P* beta, P* y, int64_t ldy);                     \
+    int gkoc_ccsr_row_scan_##TN##_##IN(gkoc_stream_t s, int64_t rows, const I* row_ptrs,               \
+                                       const I* col_idxs, const P* vals, P* out, int mode);
+GKOC_DECL_CCSR(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_CCSR(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_CCSR(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_CCSR(gkoc_c64, c64, int64_t, i64)
+/* csr::row_wise_absolute_sum (core/matrix/csr_kernels.hpp:287-290) for real values: sums[row] =
+ * sum_k |a(row, k)| (the L1 smoother of the Schwarz preconditioner) */
+#define GKOC_DECL_RWAS(T, TN, I, IN)                                                                   \
+    int gkoc_csr_row_wise_absolute_sum_##TN##_##IN(gkoc_stream_t s, int64_t rows, const I* row_ptrs,   \
+                                                   const T* vals, T* sums);
+GKOC_DECL_RWAS(double, f64, int32_t, i32)
+GKOC_DECL_RWAS(double, f64, int64_t, i64)
+GKOC_DECL_RWAS(float, f32, int32_t, i32)
+GKOC_DECL_RWAS(float, f32, int64_t, i64)
+/* dense::compute_mean for real columns (core/matrix/dense_kernels.hpp:98-102): result[j] =
+ * (sum_i x(i,j)) / rows */
+int gkoc_dense_compute_mean_f64(gkoc_stream_t s, int64_t rows, int64_t cols, const double* x,
+                                int64_t ldx, double* result);
+int gkoc_dense_compute_mean_f32(gkoc_stream_t s, int64_t rows, int64_t cols, const float* x,
+                                int64_t ldx, float* result);
 #define GKOC_DECL_COMPLEX_MD(T, TN, I, IN)                                                            \
     int gkoc_aos_to_soa_##TN##_##IN(gkoc_stream_t s, int64_t nnz, const void* entries, I* row_idxs,   \
                                     I* col_idxs, T* vals);
@@ -1212,6 +1294,9 @@ GKOC_DECL_MIXED(int64_t, i64)
 GKOC_DECL_CV_DENSE(double, f64)
 GKOC_DECL_CV_DENSE(float, f32)
 int gkoc_fill_seq_array_u64(gkoc_stream_t s, uint64_t* data, int64_t n);
+/* components::fill_array for bool / char / uint16 / uint32 arrays
+ * (core/components/fill_array_kernels.hpp:18-21): elem_bytes 1, 2 or 4, value = low bytes of pattern */
+int gkoc_fill_array_small(gkoc_stream_t s, void* data, int64_t n, int elem_bytes, uint32_t pattern);
 #define GKOC_DECL_CV(T, TN, I, IN)                                                                    \
     /* out_vals == NULL: pattern only (SparsityCsr) */                                                \
     int gkoc_dense_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,       \

@@ -5,6 +5,8 @@
 // the tests run, every rank runs every test, ranks other than 0 keep quiet, and the exit status is
 // the MAXIMUM over the ranks (a test that fails on one rank fails the run).
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 
 #include <mpi.h>
 
@@ -31,7 +33,11 @@ int main(int argc, char** argv)
     ::testing::AddGlobalTestEnvironment(new DeviceEnvironment(rank));
     if (rank != 0) {
         // one report, from rank 0; the other ranks' failures reach it through the exit status
-        if (!std::freopen("/dev/null", "w", stdout)) return 2;
+        // (GKOC_TEST_RANK_LOG=<prefix>: their output goes to <prefix>.rank<k>.log instead)
+        const char* prefix = std::getenv("GKOC_TEST_RANK_LOG");
+        std::string to = "/dev/null";
+        if (prefix && *prefix) to = std::string(prefix) + ".rank" + std::to_string(rank) + ".log";
+        if (!std::freopen(to.c_str(), "w", stdout)) return 2;
     }
     int result = RUN_ALL_TESTS();
     int worst = 0;

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT/oracle/_ref/mpi_ga/reftests
 for n in distributed_assembly distributed_matrix distributed_partition_helpers distributed_row_gatherer distributed_vector solver_solver preconditioner_schwarz; do
   np=3; [ $n = distributed_row_gatherer ] && np=6
-  timeout 600 /opt/conda/bin/mpiexec -n $np ./${n}_mpi_hip > $OUT/${n}_mpi_hip.log 2>&1; rc=$?
+  GKOC_TEST_RANK_LOG=$OUT/$n timeout 600 /opt/conda/bin/mpiexec -n $np ./${n}_mpi_hip > $OUT/${n}_mpi_hip.log 2>&1; rc=$?
   ran=$(grep -o "^\[==========\] [0-9]* tests ran" $OUT/${n}_mpi_hip.log | grep -o "[0-9]*" | head -1)
   pass=$(grep -o "^\[  PASSED  \] [0-9]* tests" $OUT/${n}_mpi_hip.log | grep -o "[0-9]*" | head -1)
   fail=$(grep -o "^\[  FAILED  \] [0-9]* tests" $OUT/${n}_mpi_hip.log | grep -o "[0-9]*" | head -1)
