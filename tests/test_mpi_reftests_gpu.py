@@ -1,0 +1,66 @@
+"""Ginkgo's OWN MPI tests (test/mpi/**: distributed Matrix / Vector / RowGatherer / assembly /
+partition helpers, the distributed solvers, Schwarz) on this backend: the sources are compiled
+unmodified by oracle/build_mpi_dropin.py against the core built with GINKGO_HAVE_GPU_AWARE_MPI 1,
+the drop-in libginkgo_hip.so and the MPI layer libgkoc_mpi_rccl.so (device pointers go to MPI and
+are taken there), and run under mpiexec with the rank counts of the reference's CMake files.  All
+ranks share GPU 0 here.
+
+Every suite must run to its end on every rank; a test may fail (on any rank) only if it is listed in
+tests/dropin/mpi_reftests_expected.json - complex-valued Jacobi / Diagonal / Dense->Csr kernels and the
+Pgm (multigrid) kernels, which this backend leaves to Ginkgo's NotCompiled stubs (outside SURVEY.md
+8).  No listed failure is a wrong number, and no test of a real value type is listed apart from the
+ones that build a Pgm hierarchy."""
+import glob
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "oracle", "_ref", "mpi_ga", "reftests")
+MPIEXEC = os.environ.get("MPIEXEC", "/opt/conda/bin/mpiexec")
+EXPECTED = json.load(open(os.path.join(ROOT, "tests", "dropin", "mpi_reftests_expected.json")))
+
+
+def _failed(txt):
+    return {f for f in re.findall(r"^\[  FAILED  \] (.+)$", txt, re.M)
+            if not re.match(r"\d+ tests?, listed below:", f) and not f.startswith("on a rank other than 0")}
+
+
+@pytest.mark.parametrize("suite", sorted(EXPECTED))
+def test_reference_mpi_suite(suite, tmp_path):
+    exe = os.path.join(BIN, suite + "_mpi_hip")
+    if not os.path.exists(exe) or not os.path.exists(MPIEXEC):
+        pytest.skip("oracle/build_mpi_dropin.py has not been run (needs /root/reference), or no mpiexec")
+    exp = EXPECTED[suite]
+    env = dict(os.environ, GKOC_TEST_RANK_LOG=str(tmp_path / suite))
+    p = subprocess.run([MPIEXEC, "-n", str(exp["ranks"]), exe], cwd=BIN, env=env, capture_output=True, text=True,
+                       timeout=900)
+    ran = re.search(r"^\[==========\] (\d+) tests ran", p.stdout, re.M)
+    assert ran, f"{suite} did not run to its end (rc {p.returncode}):\n{p.stdout[-2000:]}{p.stderr[-2000:]}"
+    failed = _failed(p.stdout)
+    logs = sorted(glob.glob(str(tmp_path / (suite + ".rank*.log"))))
+    assert len(logs) == exp["ranks"] - 1, logs
+    for g in logs:
+        txt = open(g, errors="replace").read()
+        assert re.search(r"^\[==========\] (\d+) tests ran", txt, re.M), f"{g} did not run to its end"
+        failed |= _failed(txt)
+    known = set(exp["known_failures"])
+    new = failed - known
+    assert not new, f"{suite}: tests failing that are not known limitations: {sorted(new)}\n" + p.stdout[-3000:]
+    assert int(ran.group(1)) == exp["ran"], (ran.group(1), exp["ran"])
+    if not failed:
+        assert p.returncode == 0, p.stdout[-2000:]
+    print(f"{suite}: {exp['ran']} ran on {exp['ranks']} ranks, {exp['ran'] - len(failed)} passed, {len(failed)} known")
+
+
+def test_real_value_types_fail_only_where_a_pgm_hierarchy_is_built():
+    for suite, exp in EXPECTED.items():
+        for t, why in exp["known_failures"].items():
+            if "complex" in t:
+                continue
+            assert "find_strongest_neighbor" in why, (suite, t, why)
