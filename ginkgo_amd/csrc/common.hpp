@@ -69,7 +69,7 @@ int scratch_free(hipStream_t st, void* ptr);
     } while (0)
 
 // tuning switches (runtime.hip; keys = GKOC_TUNE_* of gko_cdna4.h)
-constexpr int tune_num_keys = 6;
+constexpr int tune_num_keys = 7;
 int64_t tune_value(int key);
 
 #ifdef __HIPCC__
@@ -149,6 +149,22 @@ __device__ __forceinline__ T block_sum(T v, T* lds /* BLOCK/64 entries */)
         r = wave_sum(r);
     }
     return r;
+}
+
+// Workgroup b runs on XCD b % 8 (observed dispatch rule; a wrong guess costs speed, never
+// correctness - the map is a bijection on [0, nblocks)).  Hand every XCD chunks of `chunk`
+// consecutive logical blocks in turn instead of every 8th block: with a chunk of 1/8 of a matrix'
+// far band offset (the stencil's plane), the b rows an XCD touches through the far bands are the
+// rows of its OWN chunks of the neighbouring planes - its L2 then has to hold 3 chunks of b instead
+// of two whole planes.  chunk <= 0: identity.
+__device__ __forceinline__ int64_t xcd_chunked_block(int64_t b, int64_t nblocks, int64_t chunk)
+{
+    if (chunk <= 0) return b;
+    const int64_t period = 8 * chunk;
+    if (b >= (nblocks / period) * period) return b;
+    const int64_t xcd = b & 7, slot = b >> 3;
+    const int64_t round = slot / chunk;
+    return (round * 8 + xcd) * chunk + (slot - round * chunk);
 }
 
 // make this wave's LDS writes visible to its own other lanes (single-wave

@@ -66,39 +66,56 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     const bool vec_ok =
         reinterpret_cast<uintptr_t>(vals) % (EV * sizeof(T)) == 0 &&
         reinterpret_cast<uintptr_t>(col_idxs) % (EV * sizeof(I)) == 0;
-    if (nrhs >= 5 && n_seg < (int64_t(1) << 31)) {
-        // 5+ right-hand sides: row-ordered gather from an LDS-staged segment, 8 columns per
-        // pass (L256, 8 columns: 5.0 ms against 5.1 - 6.5 ms for the ring kernel; for 2-4 columns
-        // the ring kernel below is faster, 1.5-2.3 ms against 3.4-3.6 ms)
-        const dim3 g64(static_cast<unsigned>(n_seg));
-#define GKOC_LAUNCH_ROWMULTI(NR_)                                                        \
-    csr_spmv_rowmulti_kernel<T, I, ADV, NR_><<<g64, block, 0, as_stream(s)>>>(           \
-        n_rows, row_ptrs, col_idxs, vals, b, ldb, c, ldc, static_cast<int>(nrhs), alpha, beta)
-        GKOC_LAUNCH_ROWMULTI(8);
-#undef GKOC_LAUNCH_ROWMULTI
+    if (nrhs >= 3) {
+        // several right-hand sides, fragment layout (csr_spmv_frag_kernel in csr_spmv_multi.hpp): the
+        // lanes of a gather cover whole rows of b.  Small waves - 16 rows, 6 KB of LDS - so that 20+
+        // of them are resident per CU.  L256 (profiles/r03_multi_rhs_256.txt): 3 / 4 / 8 columns
+        // 2.17 / 2.23 / 5.08 ms with the ring and row-ordered kernels of round 2 -> 1.77 / 1.77 /
+        // 1.97 ms.  Measured variants: 32 / 64 rows per wave (12 / 24 KB: 2.2 - 4.6 ms), 2 - 8 entries
+        // per step (+- 3 %; 3 for eight columns, 4 for four); two columns stay with the ring kernel
+        // below (1.46 ms, this layout 2.36 ms with 32-row waves).
+        const bool idx32 = n_cols * ldb < (int64_t(1) << 32);
+        const bool pairs_ok = reinterpret_cast<uintptr_t>(b) % (2 * sizeof(T)) == 0 && ldb % 2 == 0 &&
+                              reinterpret_cast<uintptr_t>(c) % (2 * sizeof(T)) == 0 && ldc % 2 == 0;
+        const int64_t chunk_rows = tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS);
+#define GKOC_LAUNCH_CSR_FRAG(NR_, CPL_, KU_)                                                     \
+    do {                                                                                         \
+        constexpr int rows_ = 64 * CPL_ / NR_;                                                   \
+        const int64_t nwg = ceildiv(n_rows, rows_);                                              \
+        GKOC_REQUIRE(nwg < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 waves");    \
+        const dim3 gf(static_cast<unsigned>(nwg));                                               \
+        if (idx32) {                                                                             \
+            csr_spmv_frag_kernel<T, I, ADV, NR_, CPL_, 1, KU_, true>                             \
+                <<<gf, block, 0, as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals, b, ldb, c,    \
+                                                 ldc, static_cast<int>(nrhs), alpha, beta,       \
+                                                 chunk_rows / rows_);                            \
+        } else {                                                                                 \
+            csr_spmv_frag_kernel<T, I, ADV, NR_, CPL_, 1, KU_, false>                            \
+                <<<gf, block, 0, as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals, b, ldb, c,    \
+                                                 ldc, static_cast<int>(nrhs), alpha, beta,       \
+                                                 chunk_rows / rows_);                            \
+        }                                                                                        \
+    } while (0)
+        if (nrhs <= 4) {
+            GKOC_LAUNCH_CSR_FRAG(4, 1, 4);          // four lanes per row, one column each
+        } else if (pairs_ok) {
+            GKOC_LAUNCH_CSR_FRAG(8, 2, 3);          // four lanes per row, a pair of columns each
+        } else {
+            GKOC_LAUNCH_CSR_FRAG(8, 1, 4);
+        }
+#undef GKOC_LAUNCH_CSR_FRAG
         GKOC_LAUNCH_OK();
         return GKOC_OK;
     }
-    if (nrhs >= 2 && vec_ok) {
-        // several right-hand sides: one pass over the matrix per chunk of 2 or 4
-        // columns (csr_spmv_multi.hpp); b is read as pairs of columns when its
-        // rows allow 2-element vector loads.  The ring stays at 8 KB (512 entries of two, 256 of
-        // four columns; half as many entries per lane and load for four): with the 16 KB rings of
-        // round 1 the kernels took 129 VGPRs and ten waves per CU, now 81 and twenty - L256, 2 / 3 /
-        // 4 columns: 1.67 / 2.70 / 2.76 -> 1.49 / 2.18 / 2.23 ms.  (From four columns on the window
-        // of b that the stencil's planes span - 2 x 65536 rows x 32 B - no longer fits the 4 MB L2
-        // of an XCD: eight columns take 5.0 ms with every variant tried, this kernel in chunks of
-        // four or eight included.)
+    if (nrhs == 2 && vec_ok) {
+        // two right-hand sides: the row-segment walk of the single-column kernel with the two
+        // products of an entry side by side in the LDS ring (csr_spmv_multi_kernel; 8 KB ring of 512
+        // entries).  L256: 1.46 ms against 2.18 ms for one pass per column.
         const int b_vec_ok = reinterpret_cast<uintptr_t>(b) % (2 * sizeof(T)) == 0 && ldb % 2 == 0;
-        if (nrhs == 2) {
-            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 2><<<grid, block, 0, as_stream(s)>>>(
-                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
-                static_cast<int>(nrhs), alpha, beta, b_vec_ok);
-        } else {
-            csr_spmv_multi_kernel<T, I, ADV, EV / 2, 1, RINGV / 4, 4><<<grid, block, 0, as_stream(s)>>>(
-                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
-                static_cast<int>(nrhs), alpha, beta, b_vec_ok);
-        }
+        csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 2><<<grid, block, 0, as_stream(s)>>>(
+            n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
+            static_cast<int>(nrhs), alpha, beta, b_vec_ok,
+            tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / (64 * segs_per_wave));
         GKOC_LAUNCH_OK();
         return GKOC_OK;
     }

@@ -3,27 +3,22 @@
 // The single-column kernel (csr_spmv_pipe.hpp) run once per column re-reads the
 // whole matrix for every column and gathers b with a stride of ldb values
 // (L256: 1.17 / 2.18 / 3.67 / 5.45 / 16.8 ms for 1 / 2 / 3 / 4 / 8 columns).
-// Here a wave streams its val / col range ONCE per chunk of NR columns:
-//   * same row-segment-per-wavefront walk, two register sets, 16/32 B vector
-//     loads of the matrix stream as in csr_spmv_pipe3_kernel;
-//   * lane = E consecutive nonzeros: for every nonzero the NR values
-//     b[col, j0 .. j0+NR) are one contiguous run of the row-major b (one or two
-//     16 B loads when b allows it), so a chunk costs the b traffic of ONE gather
-//     with NR times the payload per line;
-//   * the NR products of a nonzero sit next to each other in the LDS ring
-//     (ring[(k mod RING) * NR + jj]); lane = row then adds them in k order per
-//     column - the reference's summation order, separate multiply and add =>
-//     bit-identical per column to the sequential reference, and to the
-//     single-column kernel;
-//   * the results of a segment leave as 64 runs of NR contiguous values
-//     (one contiguous block when ldc == NR).
-// That kernel (csr_spmv_multi_kernel) serves 2-4 columns; for 5 and more,
-// csr_spmv_rowmulti_kernel below stages the segment in LDS and gathers in ROW order,
-// 8 columns per pass (the launcher in csr_spmv.hip holds the measured crossover).
-// Columns beyond nrhs in the last chunk are computed on a clamped column index
-// and not stored.  Rows longer than GKOC_CSR_LONG_ROW take the cooperative wave
-// path of the single-column kernel (tolerance-compared, include/gko_cdna4.h).
+// Two kernels stream the matrix ONCE per chunk of columns instead:
+//   * csr_spmv_multi_kernel, two columns: the row-segment-per-wavefront walk of
+//     csr_spmv_pipe3_kernel (two register sets, 32 B vector loads of the matrix
+//     stream); lane = E consecutive nonzeros gathers the two values b[col, j0..j0+2)
+//     as one 16 B load, the two products of a nonzero sit next to each other in the
+//     LDS ring, lane = row adds them in k order per column;
+//   * csr_spmv_frag_kernel, three and more columns (chunks of 4 or 8): 16-row waves
+//     with the segment staged in LDS and several lanes per row, so that the lanes of
+//     one gather instruction cover whole rows of b (see there).
+// In both, every (row, column) sum is formed in the reference's order with separate
+// multiply and add => bit-identical per column to the sequential reference and to the
+// single-column kernel.  Columns beyond nrhs in the last chunk are not stored.
+// fmt_row_sum_multi below is the lane = row walk the ELL / SELL-P fallback kernels use.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 #include "csr_spmv_pipe.hpp"
 
@@ -98,39 +93,51 @@ __device__ __forceinline__ void fmt_row_sum_multi(T (&sum)[NR], int64_t len, int
     }
 }
 
-// CSR, several right-hand sides, ROW-ORDERED gather: the wave's 64 rows own one
-// contiguous val / col range, which is staged in LDS with coalesced loads; then
-// lane = row walks its entries in k order (fmt_row_sum_multi on the staged copy) with
-// NR sums in registers.  The 64 lanes of a gather instruction then read the b rows
-// of entry i of 64 consecutive matrix rows - for banded / stencil matrices one
-// contiguous run of b - instead of the scattered neighbours of a few rows.
-// Segments above multi_stage_cap entries walk global memory directly (still exact).
-constexpr int multi_stage_cap = 2048;
-
-template <typename T, typename I, bool ADV, int NR>
-__global__ __launch_bounds__(64) void csr_spmv_rowmulti_kernel(
+// CSR, several right-hand sides, FRAGMENT layout (the CSR form of fmt_spmv_frag_kernel in
+// formats.hip): the wave's ROWS-row segment is staged in LDS with coalesced loads as above, then
+// NR / 2 neighbouring lanes share a row, each owning two neighbouring columns, and the wave walks
+// TT groups of 128 / NR rows side by side, KU entries per step.  The lanes of one gather
+// instruction then cover whole rows of b - for banded / stencil matrices 32 (four columns) or 16
+// (eight) consecutive rows, one contiguous run - where lane = row reads 16 B per lane from 64
+// different rows, and it is the vector L1's line-access rate, not HBM, that bounds the lane = row
+// kernels from four columns on (rocprofv3, profiles/r03_multi_rhs_pmc.txt).  The column index and
+// value of an entry come from LDS (same address for the lanes of a row: a broadcast).  Every (row,
+// column) sum is formed by ONE lane in entry order, separate multiply and add: bit-identical to
+// the reference.  No branches in the entry loop: an entry past the end of a row reads entry 0 of
+// the segment and row 0 of b, and its product is not added.
+template <typename T, typename I, bool ADV, int NR, int CPL, int TT, int KU, bool IDX32>
+__global__ __launch_bounds__(64) void csr_spmv_frag_kernel(
     int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
     const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb, T* __restrict__ c,
-    int64_t ldc, int nrhs, const T* __restrict__ alpha_p, const T* __restrict__ beta_p)
+    int64_t ldc, int nrhs, const T* __restrict__ alpha_p, const T* __restrict__ beta_p,
+    int64_t xcd_chunk)
 {
-    __shared__ __attribute__((aligned(16))) T lv[multi_stage_cap];
-    __shared__ __attribute__((aligned(16))) I lc[multi_stage_cap];
+    static_assert(NR == 2 || NR == 4 || NR == 8, "chunks of 2, 4 or 8 columns");
+    static_assert(CPL == 1 || CPL == 2, "one or two columns per lane");
+    constexpr int LPR = NR / CPL;     // lanes per row
+    constexpr int RPP = 64 / LPR;     // rows per group
+    constexpr int ROWS = RPP * TT;    // rows per wave
+    constexpr int CAP = ROWS * 32;    // staged entries (12 B each)
+    using BV = vecT<T, CPL>;
+    __shared__ __attribute__((aligned(16))) T lv[CAP];
+    __shared__ __attribute__((aligned(16))) I lc[CAP];
     const int lane = threadIdx.x;
-    const int64_t g = blockIdx.x;
-    const int64_t row = g * 64 + lane;
-    const bool valid = row < n_rows;
-    const int64_t last = (g + 1) * 64 < n_rows ? (g + 1) * 64 : n_rows;
-    const int64_t rs = row_ptrs[valid ? row : last];
-    const int64_t re = row_ptrs[valid ? row + 1 : last];
-    const int64_t K0 = row_ptrs[g * 64];
+    const int sub = lane % LPR, rl = lane / LPR;
+    const int64_t g = xcd_chunked_block(blockIdx.x, gridDim.x, xcd_chunk);
+    const int64_t row0 = g * ROWS;
+    if (row0 >= n_rows) return;
+    const int64_t last = row0 + ROWS < n_rows ? row0 + ROWS : n_rows;
+    const int64_t K0 = row_ptrs[row0];
     const int64_t K1 = row_ptrs[last];
     T alpha = T(1), beta = T(0);
     if (ADV) {
         alpha = alpha_p[0];
         beta = beta_p[0];
     }
-    const bool staged = K1 - K0 <= multi_stage_cap;
-    if (staged) {
+    // a segment of up to CAP entries is staged as it lies in memory; a longer one in rounds of 32
+    // entries of every row (slot = 32 * row + entry)
+    const bool whole = K1 - K0 <= CAP;
+    if (whole) {
         const int seg = int(K1 - K0);
         for (int i = lane; i < seg; i += 64) {
             lv[i] = vals[K0 + i];
@@ -138,22 +145,116 @@ __global__ __launch_bounds__(64) void csr_spmv_rowmulti_kernel(
         }
         wave_lds_sync();
     }
-    const T* pv = staged ? lv : vals + K0;
-    const I* pc = staged ? lc : cols + K0;
+    int64_t row[TT];
+    int rs[TT], len[TT];
+    int maxlen = 0;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        row[t] = row0 + rl + RPP * t;
+        const int64_t r = row[t] < last ? row[t] : last;
+        const int64_t a = row_ptrs[r];
+        const int64_t e = row[t] < last ? int64_t(row_ptrs[r + 1]) : a;
+        rs[t] = int(a - K0);
+        len[t] = int(e - a);
+        maxlen = len[t] > maxlen ? len[t] : maxlen;
+    }
+    int wave_maxlen = maxlen;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(wave_maxlen, off, 64);
+        wave_maxlen = o > wave_maxlen ? o : wave_maxlen;
+    }
     for (int j0 = 0; j0 < nrhs; j0 += NR) {
-        int jcol[NR];
-        T sum[NR];
+        const int jc = j0 + CPL * sub;                       // the lane's first column
+        const int ncol = nrhs - jc >= CPL ? CPL : nrhs - jc; // its valid columns: CPL ... <= 0
+        // what is loaded: with one valid column of a pair the neighbour lies inside the row as well
+        // (ldb is even where pairs are used, so ldb > nrhs when nrhs is odd); a lane without
+        // columns reads the first ones
+        const int jl = ncol >= 1 ? jc : 0;
+        T sum[TT][CPL];
 #pragma unroll
-        for (int jj = 0; jj < NR; ++jj) {
-            jcol[jj] = j0 + jj < nrhs ? j0 + jj : nrhs - 1;
-            sum[jj] = T(0);
-            if (ADV && beta != T(0) && valid) sum[jj] = c[row * ldc + jcol[jj]] * beta;
+        for (int t = 0; t < TT; ++t) {
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                sum[t][q] = T(0);
+                if (ADV && beta != T(0) && row[t] < last && q < ncol) {
+                    sum[t][q] = c[row[t] * ldc + jc + q] * beta;
+                }
+            }
         }
-        if (valid) {
-            fmt_row_sum_multi<T, I, ADV, NR>(sum, re - rs, rs - K0, 1, pc, pv, b, ldb, jcol, alpha);
+        // entries [kb, ke) of every row, entry k of the lane's row t at LDS slot base[t] + k
+        auto walk = [&](auto tiled_tag, int kb, int ke, const int (&base)[TT]) {
+            constexpr bool TILED = decltype(tiled_tag)::value;
+            const int kend = TILED && ke < maxlen ? ke : maxlen;
+            for (int k = kb; k < kend; k += KU) {
+                BV x[KU][TT];
+                T vv[KU][TT];
+                bool ok[KU][TT];
 #pragma unroll
-            for (int jj = 0; jj < NR; ++jj) {
-                if (j0 + jj < nrhs) c[row * ldc + j0 + jj] = sum[jj];
+                for (int u = 0; u < KU; ++u) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        ok[u][t] = k + u < len[t] && (!TILED || k + u < ke);
+                        const int at = ok[u][t] ? base[t] + k + u : 0;
+                        const I cc = lc[at];
+                        vv[u][t] = lv[at];
+                        const I ce = ok[u][t] ? cc : I(0);
+                        if (IDX32) {
+                            const uint32_t off = uint32_t(ce) * uint32_t(ldb) + uint32_t(jl);
+                            x[u][t] = *reinterpret_cast<const BV*>(b + off);
+                        } else {
+                            x[u][t] = *reinterpret_cast<const BV*>(b + int64_t(ce) * ldb + jl);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) {
+                        const T a = ADV ? alpha * vv[u][t] : vv[u][t];
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q) {
+                            const T nx = sum[t][q] + a * x[u][t].v[q];
+                            sum[t][q] = ok[u][t] ? nx : sum[t][q];
+                        }
+                    }
+                }
+            }
+        };
+        if (whole) {
+            if (K1 > K0) walk(std::false_type{}, 0, 0, rs);
+        } else {
+            for (int c0 = 0; c0 < wave_maxlen; c0 += 32) {
+                wave_lds_sync();   // the previous round has been read
+                for (int i = lane; i < CAP; i += 64) {
+                    const int64_t r = row0 + (i >> 5);
+                    if (r < last) {
+                        const int64_t a = row_ptrs[r];
+                        if (a + c0 + (i & 31) < int64_t(row_ptrs[r + 1])) {
+                            lv[i] = vals[a + c0 + (i & 31)];
+                            lc[i] = cols[a + c0 + (i & 31)];
+                        }
+                    }
+                }
+                wave_lds_sync();
+                int base[TT];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) base[t] = 32 * (rl + RPP * t) - c0;
+                walk(std::true_type{}, c0, c0 + 32, base);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            if (row[t] < last && ncol > 0) {
+                T* __restrict__ cp = c + row[t] * ldc + jc;
+                if (ncol == CPL) {
+                    BV q;
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) q.v[i] = sum[t][i];
+                    *reinterpret_cast<BV*>(cp) = q;
+                } else {
+                    cp[0] = sum[t][0];
+                }
             }
         }
     }
@@ -165,7 +266,7 @@ __global__ __launch_bounds__(64) void csr_spmv_multi_kernel(
     const I* __restrict__ row_ptrs, const I* __restrict__ cols,
     const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb,
     T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
-    const T* __restrict__ beta_p, int b_vec_ok)
+    const T* __restrict__ beta_p, int b_vec_ok, int64_t xcd_chunk = 0)
 {
     static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
     static_assert(NR == 2 || NR == 4, "chunks of 2 or 4 columns");
@@ -178,7 +279,7 @@ __global__ __launch_bounds__(64) void csr_spmv_multi_kernel(
     __shared__ __attribute__((aligned(16))) T ring[RING * NR];
 
     const int lane = threadIdx.x;
-    const int64_t sb = int64_t(blockIdx.x) * segs_per_wave;
+    const int64_t sb = xcd_chunked_block(blockIdx.x, gridDim.x, xcd_chunk) * segs_per_wave;
     const int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
     if (sb >= se) return;
     const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;

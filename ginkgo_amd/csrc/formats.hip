@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void fmt_spmv_multi_kernel(
     const uint64_t* __restrict__ slice_sets, const uint64_t* __restrict__ slice_lengths,
     const I* __restrict__ cols, const T* __restrict__ vals, const T* __restrict__ b,
     int64_t ldb, T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
-    const T* __restrict__ beta_p)
+    const T* __restrict__ beta_p, int64_t xcd_chunk = 0)
 {
-    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t row = xcd_chunked_block(blockIdx.x, gridDim.x, xcd_chunk) * 256 + threadIdx.x;
     if (row >= n_rows) return;
     T alpha = T(1), beta = T(0);
     if (ADV) {
@@ -132,6 +132,149 @@ __global__ __launch_bounds__(256) void fmt_spmv_multi_kernel(
             if (j0 + jj < nrhs) c[row * ldc + j0 + jj] = sum[jj];
         }
     }
+}
+
+// ELL / SELL-P SpMV with several right-hand sides, FRAGMENT layout: NR / 2 neighbouring lanes share a
+// row, each owning two neighbouring columns of the chunk (one 16 B piece of the row-major b and c),
+// and a wave walks its 64 rows in NR / 2 passes of 128 / NR rows that run side by side.  What this
+// buys is the number of cache-line accesses of the vector L1: with lane = row (fmt_spmv_multi_kernel)
+// every 16 B load of a lane is a line access of its own - 64 per instruction, 4 instructions per
+// entry for eight columns - and the kernels ran AT the L1's rate of about one access per clock and
+// CU (rocprofv3: 2.63 G accesses in 4.7 ms on L256 with eight columns; profiles/r03_multi_rhs_pmc.txt)
+// while HBM idled at 2.9 TB/s.  Here the lanes of an instruction cover whole rows of b, 16 (eight
+// columns) or 32 (four) contiguous 64 / 32 B runs.  The column index and value of an entry are
+// loaded by all lanes of its row (same address: one access).  Every (row, column) sum is still
+// formed by ONE lane in entry order, separate multiply and add: bit-identical to the reference.
+template <typename T, typename I, bool ADV, int NR, bool SELL, bool IDX32>
+__global__ __launch_bounds__(256) void fmt_spmv_frag_kernel(
+    int64_t n_rows, int64_t k_per_row, int64_t stride, int64_t slice_size,
+    const uint64_t* __restrict__ slice_sets, const uint64_t* __restrict__ slice_lengths,
+    const I* __restrict__ cols, const T* __restrict__ vals, const T* __restrict__ b,
+    int64_t ldb, T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
+    const T* __restrict__ beta_p, int64_t xcd_chunk)
+{
+    static_assert(NR == 4 || NR == 8, "chunks of 4 or 8 columns");
+    constexpr int LPR = NR / 2;      // lanes per row
+    constexpr int RPP = 64 / LPR;    // rows per pass
+    constexpr int TT = LPR;          // passes side by side: 64 rows per wave
+    using BV = vecT<T, 2>;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, rl = lane / LPR;
+    const int64_t row_base =
+        (xcd_chunked_block(blockIdx.x, gridDim.x, xcd_chunk) * 4 + (threadIdx.x >> 6)) * 64;
+    if (row_base >= n_rows) return;
+    T alpha = T(1), beta = T(0);
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    // lane = row view of the wave's 64 rows: the column index and value of entry k are loaded ONCE
+    // per row (one coalesced instruction each) and handed to the row's NR / 2 lanes with
+    // ds_bpermute; loading them from every lane of the row cost two of three vector-memory
+    // instructions, and it is the instruction count the texture addresser is busy with
+    // (rocprofv3: TA busy 90 % of the kernel's cycles; profiles/r03_multi_rhs_pmc.txt).
+    const int64_t nrow = row_base + lane;
+    const int64_t nr = nrow < n_rows ? nrow : n_rows - 1;
+    int nlen = int(k_per_row);
+    int64_t nfirst = nr, step = stride;
+    if (SELL) {
+        const int64_t slice = nr / slice_size;
+        nlen = int(slice_lengths[slice]);
+        nfirst = int64_t(slice_sets[slice]) * slice_size + (nr - slice * slice_size);
+        step = slice_size;
+    }
+    if (nrow >= n_rows) nlen = 0;
+    int maxlen = nlen;   // wave-wide maximum
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(maxlen, off, 64);
+        maxlen = o > maxlen ? o : maxlen;
+    }
+    // The entry loop has NO branches: every lane always loads (an entry past the end of its row
+    // re-reads the row's first entry and counts as padding, a padding entry gathers row 0 of b, a
+    // lane whose columns lie past nrhs gathers columns 0 and 1) and the sums are selected -
+    // conditional loads made the compiler wait for each of them in turn.
+    for (int j0 = 0; j0 < nrhs; j0 += NR) {
+        const int jc = j0 + 2 * sub;                         // the lane's first column
+        const int ncol = nrhs - jc >= 2 ? 2 : nrhs - jc;     // its valid columns: 2, 1 or <= 0
+        // the pair that is loaded: with one valid column its neighbour lies inside the row as well
+        // (ldb is even where this kernel runs, so ldb > nrhs when nrhs is odd)
+        const int jl = ncol >= 1 ? jc : 0;
+        int64_t row[TT];
+        T s0[TT], s1[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            row[t] = row_base + rl + RPP * t;
+            const bool live = row[t] < n_rows && ncol > 0;
+            s0[t] = s1[t] = T(0);
+            if (ADV && beta != T(0) && live) {
+                s0[t] = beta * c[row[t] * ldc + jc];
+                if (ncol == 2) s1[t] = beta * c[row[t] * ldc + jc + 1];
+            }
+        }
+        I ncc = I(-1);
+        T nvv = T(0);
+        if (maxlen > 0) {
+            const I c_ = cols[nfirst];
+            nvv = vals[nfirst];
+            ncc = 0 < nlen ? c_ : I(-1);
+        }
+        for (int k = 0; k < maxlen; ++k) {
+            I cc[TT];
+            T vv[TT];
+            BV x[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                cc[t] = __shfl(ncc, rl + RPP * t, 64);
+                vv[t] = __shfl(nvv, rl + RPP * t, 64);
+                const I ce = cc[t] >= 0 ? cc[t] : I(0);
+                if (IDX32) {
+                    const uint32_t off = uint32_t(ce) * uint32_t(ldb) + uint32_t(jl);
+                    x[t] = *reinterpret_cast<const BV*>(b + off);
+                } else {
+                    x[t] = *reinterpret_cast<const BV*>(b + int64_t(ce) * ldb + jl);
+                }
+            }
+            {
+                const bool more = k + 1 < nlen;
+                const int64_t at = nfirst + (more ? int64_t(k + 1) * step : int64_t(0));
+                const I c_ = cols[at];
+                nvv = vals[at];
+                ncc = more ? c_ : I(-1);
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const T a = ADV ? alpha * vv[t] : vv[t];
+                const T n0 = s0[t] + a * x[t].v[0];
+                const T n1 = s1[t] + a * x[t].v[1];
+                s0[t] = cc[t] >= 0 ? n0 : s0[t];
+                s1[t] = cc[t] >= 0 ? n1 : s1[t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            if (row[t] < n_rows && ncol > 0) {
+                T* __restrict__ cp = c + row[t] * ldc + jc;
+                if (ncol == 2) {
+                    BV q;
+                    q.v[0] = s0[t];
+                    q.v[1] = s1[t];
+                    *reinterpret_cast<BV*>(cp) = q;
+                } else {
+                    cp[0] = s0[t];
+                }
+            }
+        }
+    }
+}
+
+// the fragment layout serves three and more columns (two: the lane = row kernel is as fast, L256
+// 1.30 ms both) and needs pairs of columns as aligned 2-element vectors of b and c
+template <typename T>
+inline bool frag_layout(int64_t nrhs, const T* b, int64_t ldb, const T* c, int64_t ldc)
+{
+    return nrhs >= 3 && reinterpret_cast<uintptr_t>(b) % (2 * sizeof(T)) == 0 && ldb % 2 == 0 &&
+           reinterpret_cast<uintptr_t>(c) % (2 * sizeof(T)) == 0 && ldc % 2 == 0;
 }
 
 // ELL / SELL-P SpMV: lane = row, and every lane owns TWO rows, 64 apart, of the
@@ -429,21 +572,46 @@ int launch_ell(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t k,
                  GKOC_E_INVALID, "bad ELL dimensions");
     if (n_rows == 0 || nrhs == 0) return GKOC_OK;
     if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
+    if (nrhs >= 2 && frag_layout(nrhs, b, ldb, c, ldc)) {
+        const dim3 grid(unsigned(ceildiv(n_rows, 256)));
+        const int64_t chunk = tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / 256;
+        const bool idx32 = n_cols * ldb < (int64_t(1) << 32);
+#define GKOC_LAUNCH_FRAG(NR_)                                                                    \
+    do {                                                                                         \
+        if (idx32) {                                                                             \
+            fmt_spmv_frag_kernel<T, I, ADV, NR_, false, true><<<grid, dim3(256), 0, as_stream(s)>>>( \
+                n_rows, k, stride, 0, nullptr, nullptr, cols, vals, b, ldb, c, ldc, int(nrhs),   \
+                alpha, beta, chunk);                                                             \
+        } else {                                                                                 \
+            fmt_spmv_frag_kernel<T, I, ADV, NR_, false, false><<<grid, dim3(256), 0, as_stream(s)>>>( \
+                n_rows, k, stride, 0, nullptr, nullptr, cols, vals, b, ldb, c, ldc, int(nrhs),   \
+                alpha, beta, chunk);                                                             \
+        }                                                                                        \
+    } while (0)
+        if (nrhs <= 4) {
+            GKOC_LAUNCH_FRAG(4);
+        } else {
+            GKOC_LAUNCH_FRAG(8);
+        }
+#undef GKOC_LAUNCH_FRAG
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     if (nrhs >= 2) {
         const dim3 grid(unsigned(ceildiv(n_rows, 256)));
         if (nrhs == 2) {
             fmt_spmv_multi_kernel<T, I, ADV, 2, false><<<grid, dim3(256), 0, as_stream(s)>>>(
                 n_rows, k, stride, 0, nullptr, nullptr, cols, vals, b, ldb, c, ldc, int(nrhs),
-                alpha, beta);
+                alpha, beta, tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / 256);
         } else if (nrhs <= 4) {
             fmt_spmv_multi_kernel<T, I, ADV, 4, false><<<grid, dim3(256), 0, as_stream(s)>>>(
                 n_rows, k, stride, 0, nullptr, nullptr, cols, vals, b, ldb, c, ldc, int(nrhs),
-                alpha, beta);
+                alpha, beta, tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / 256);
         } else {
             // wider blocks: 8 columns per pass use every gathered b line in full
             fmt_spmv_multi_kernel<T, I, ADV, 8, false><<<grid, dim3(256), 0, as_stream(s)>>>(
                 n_rows, k, stride, 0, nullptr, nullptr, cols, vals, b, ldb, c, ldc, int(nrhs),
-                alpha, beta);
+                alpha, beta, tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / 256);
         }
         GKOC_LAUNCH_OK();
         return GKOC_OK;
@@ -482,20 +650,48 @@ int launch_sellp(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,
                  "bad SELL-P dimensions");
     if (n_rows == 0 || nrhs == 0) return GKOC_OK;
     if (ADV) GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha/beta");
+    if (nrhs >= 2 && frag_layout(nrhs, b, ldb, c, ldc)) {
+        const dim3 grid(unsigned(ceildiv(n_rows, 256)));
+        const int64_t chunk = tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / 256;
+        const bool idx32 = n_cols * ldb < (int64_t(1) << 32);
+#define GKOC_LAUNCH_FRAG(NR_)                                                                    \
+    do {                                                                                         \
+        if (idx32) {                                                                             \
+            fmt_spmv_frag_kernel<T, I, ADV, NR_, true, true><<<grid, dim3(256), 0, as_stream(s)>>>( \
+                n_rows, 0, 0, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c, ldc,     \
+                int(nrhs), alpha, beta, chunk);                                                  \
+        } else {                                                                                 \
+            fmt_spmv_frag_kernel<T, I, ADV, NR_, true, false><<<grid, dim3(256), 0, as_stream(s)>>>( \
+                n_rows, 0, 0, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c, ldc,     \
+                int(nrhs), alpha, beta, chunk);                                                  \
+        }                                                                                        \
+    } while (0)
+        if (nrhs <= 4) {
+            GKOC_LAUNCH_FRAG(4);
+        } else {
+            GKOC_LAUNCH_FRAG(8);
+        }
+#undef GKOC_LAUNCH_FRAG
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     if (nrhs >= 2) {
         const dim3 grid(unsigned(ceildiv(n_rows, 256)));
         if (nrhs == 2) {
             fmt_spmv_multi_kernel<T, I, ADV, 2, true><<<grid, dim3(256), 0, as_stream(s)>>>(
                 n_rows, 0, 0, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c, ldc,
-                int(nrhs), alpha, beta);
+                int(nrhs), alpha, beta,
+                tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / 256);
         } else if (nrhs <= 4) {
             fmt_spmv_multi_kernel<T, I, ADV, 4, true><<<grid, dim3(256), 0, as_stream(s)>>>(
                 n_rows, 0, 0, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c, ldc,
-                int(nrhs), alpha, beta);
+                int(nrhs), alpha, beta,
+                tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / 256);
         } else {
             fmt_spmv_multi_kernel<T, I, ADV, 8, true><<<grid, dim3(256), 0, as_stream(s)>>>(
                 n_rows, 0, 0, slice_size, slice_sets, slice_lengths, cols, vals, b, ldb, c, ldc,
-                int(nrhs), alpha, beta);
+                int(nrhs), alpha, beta,
+                tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / 256);
         }
         GKOC_LAUNCH_OK();
         return GKOC_OK;

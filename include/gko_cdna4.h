@@ -142,6 +142,9 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                       that launches its OWN kernels on exec->get_stream() with raw pointers of a
                                       solver's internal vectors - e.g. a matrix-free preconditioner - would read
                                       them before the held kernels ran ("Fusion across calls") */
+#define GKOC_TUNE_MULTI_XCD_CHUNK_ROWS 6 /* SpMV with several right-hand sides (CSR / ELL / SELL-P): rows per chunk
+                                      that one XCD walks before the next XCD's chunk begins (csrc/common.hpp,
+                                      xcd_chunked_block); 0: every 8th workgroup (plain dispatch order) */
 /* key 2: reserved (round-2 experiments with the CSR kernel's ring size / lane layout, all rejected) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);

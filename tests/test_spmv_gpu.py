@@ -222,7 +222,7 @@ def test_dimension_mismatch(gexec):
         a.apply(g.Dense.create(gexec, (2, 2)), g.Dense.create(gexec, (2, 1)))
 
 
-@pytest.mark.parametrize("nrhs", [1, 2, 3, 5, 11])
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 4, 5, 6, 8, 11])
 @pytest.mark.parametrize("idx", [np.int32, np.int64])
 def test_ell_bit_exact(gexec, oracle, nrhs, idx):
     import ginkgo_amd as g
@@ -245,9 +245,19 @@ def test_ell_bit_exact(gexec, oracle, nrhs, idx):
         ell.apply(g.scalar(gexec, 2.0), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.0), y)
         assert np.array_equal(y.to_numpy(),
                               oracle.ell_spmv(532, k, st, ec, ev, b, alpha=2.0, beta=-1.0, c=c0))
+        # even strides of b and c: three and more columns take the fragment-layout kernel
+        # (several lanes per row, csrc/formats.hip), also when the last chunk is partial
+        sb, sc = nrhs + nrhs % 2, nrhs + 2 + nrhs % 2
+        y = g.Dense.from_numpy(gexec, c0, stride=sc)
+        ell.apply(g.Dense.from_numpy(gexec, b, stride=sb), y)
+        assert np.array_equal(y.to_numpy(), oracle.csr_spmv(rp, ci, v, b))
+        y = g.Dense.from_numpy(gexec, c0, stride=sc)
+        ell.apply(g.scalar(gexec, 2.0), g.Dense.from_numpy(gexec, b, stride=sb), g.scalar(gexec, -1.0), y)
+        assert np.array_equal(y.to_numpy(),
+                              oracle.ell_spmv(532, k, st, ec, ev, b, alpha=2.0, beta=-1.0, c=c0))
 
 
-@pytest.mark.parametrize("nrhs", [1, 2, 3, 5, 11])
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 4, 5, 8, 11])
 @pytest.mark.parametrize("slice_size,stride_factor", [(64, 1), (32, 2), (2, 2)])
 def test_sellp_bit_exact(gexec, oracle, nrhs, slice_size, stride_factor):
     import ginkgo_amd as g
@@ -268,6 +278,13 @@ def test_sellp_bit_exact(gexec, oracle, nrhs, slice_size, stride_factor):
     assert np.array_equal(y.to_numpy(), oracle.csr_spmv(rp, ci, v, b))
     y = g.Dense.from_numpy(gexec, c0)
     sp_.apply(g.scalar(gexec, 2.0), g.Dense.from_numpy(gexec, b), g.scalar(gexec, -1.0), y)
+    assert np.array_equal(
+        y.to_numpy(), oracle.sellp_spmv(532, slice_size, sets, lens, sc, sv, b,
+                                        alpha=2.0, beta=-1.0, c=c0))
+    # even strides: the fragment-layout kernel from three columns on
+    ldb, ldc = nrhs + nrhs % 2, nrhs + 2 + nrhs % 2
+    y = g.Dense.from_numpy(gexec, c0, stride=ldc)
+    sp_.apply(g.scalar(gexec, 2.0), g.Dense.from_numpy(gexec, b, stride=ldb), g.scalar(gexec, -1.0), y)
     assert np.array_equal(
         y.to_numpy(), oracle.sellp_spmv(532, slice_size, sets, lens, sc, sv, b,
                                         alpha=2.0, beta=-1.0, c=c0))
