@@ -336,8 +336,11 @@ int launch_coo(gkoc_stream_t s, int mode, int64_t n_rows, int64_t n_cols, int64_
             // advanced_spmv2 (alpha, 1); a literal 1 multiplies exactly
             const T* ka = mode == 0 ? nullptr : (mode == 2 ? w.one : alpha);
             const T* kb = mode == 1 ? beta : w.one;
+            // four entries per lane and load, one load group (the 2 x 3 layout of the CSR launcher costs
+            // this mode - 99 VGPRs already - a wave per SIMD: L256 1.57 ms against 1.44)
+            constexpr int CE = EV, CU = 1;
 #define GKOC_LAUNCH_COO(ADV_, MODE_)                                                                    \
-    csr_spmv_pipe3_kernel<T, I, ADV_, 64, EV, 1, RINGV, 1, MODE_ | 128><<<grid, block, 0, st>>>(          \
+    csr_spmv_pipe3_kernel<T, I, ADV_, 64, CE, CU, RINGV, 1, MODE_ | 128><<<grid, block, 0, st>>>(        \
         n_rows, n_seg, segs_per_wave, w.ptrs, cols, vals, b, ldb, c, ldc, 1, ka, kb, nullptr, 0, rows,  \
         w.flag)
             if (mode == 0) {

@@ -132,11 +132,17 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     // against 288), 32-row segments (294), one or two entries per lane and load so that neighbouring
     // lanes gather neighbouring columns (301-305).  What helped was the row-phase loop
     // (csr_spmv_pipe.hpp): 295 -> 277 us.
+    // Entries per lane and load x load groups in flight (ring 8 KB): 2 x 3 for double, 4 x 2 for
+    // float - 16 B of values per lane and load, 48 / 32 B in flight.  Measured in one process on L256
+    // (tools/f32_variants.py, profiles/r03_experiments.txt): double 4 x 1 (rounds 1-2) 985 us, 2 x 3
+    // 954, 2 x 4 960, 1 x 6 968, 4 x 2 980, 1 x 8 978, 1 x 4 986; float 8 x 1 (rounds 1-2) 847 us,
+    // 4 x 2 793, 4 x 3 823, 8 x 2 / 4 x 4 / 2 x 8 slower.
+    constexpr int PE = sizeof(T) == 8 ? 2 : 4, PU = sizeof(T) == 8 ? 3 : 2;
     if (vec_ok) {
         if (segs_per_wave == 2) {
-            GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);
+            GKOC_LAUNCH_PIPE3(PE, PU, 0x2000);
         } else {
-            GKOC_LAUNCH_PIPE3(EV, 1, 0x1000);
+            GKOC_LAUNCH_PIPE3(PE, PU, 0x1000);
         }
     } else {
         if (segs_per_wave == 2) {
@@ -181,6 +187,8 @@ int launch_csr_mixed(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* a
         alpha, beta, nullptr, 0)
     if (vec_ok) {
         if (segs_per_wave == 2) {
+            // (round 3: 2 x 1, 2 x 2, 1 x 2, 1 x 4, 4 x 2 entries x groups all lose, 1000 - 1440 us
+            // against 879)
             GKOC_LAUNCH_MIXED(EV, 1, 0x2000);
         } else {
             GKOC_LAUNCH_MIXED(EV, 1, 0x1000);
@@ -229,6 +237,7 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
         reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
         reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;  // E = 4 below
     const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
+    constexpr int PE = sizeof(T) == 8 ? 2 : 4, PU = sizeof(T) == 8 ? 3 : 2;   // as in launch_csr
 #define GKOC_LAUNCH_DOT(E_, U_, MODE_)                                               \
     csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, E_, U_, 1024, 1, MODE_>         \
         <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs, col_idxs, \
@@ -236,9 +245,9 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
                                            partial, xcd_map)
     if (vec_ok) {
         if (segs_per_wave == 2) {
-            GKOC_LAUNCH_DOT(4, 1, 0x2040);
+            GKOC_LAUNCH_DOT(PE, PU, 0x2040);
         } else {
-            GKOC_LAUNCH_DOT(4, 1, 0x1040);
+            GKOC_LAUNCH_DOT(PE, PU, 0x1040);
         }
     } else {
         if (segs_per_wave == 2) {

@@ -21,7 +21,7 @@ for vt, it in ((torch.float64, torch.int32), (torch.float64, torch.int64),
     y = g.Dense.create(ex, (n, 1), vt)
     nbytes = nnz * (vb + ib) + (n + 1) * ib + 2 * n * vb
     for name, op in (("csr", a), ("ell", a.convert_to_ell()), ("sellp", a.convert_to_sellp())):
-        for _ in range(3):
+        for _ in range(25):      # the first launches after an idle phase run at lower clocks
             op.apply(x, y)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
