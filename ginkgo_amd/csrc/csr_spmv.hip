@@ -136,10 +136,20 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     // float - 16 B of values per lane and load, 48 / 32 B in flight.  Measured in one process on L256
     // (tools/f32_variants.py, profiles/r03_experiments.txt): double 4 x 1 (rounds 1-2) 985 us, 2 x 3
     // 954, 2 x 4 960, 1 x 6 968, 4 x 2 980, 1 x 8 978, 1 x 4 986; float 8 x 1 (rounds 1-2) 847 us,
-    // 4 x 2 793, 4 x 3 823, 8 x 2 / 4 x 4 / 2 x 8 slower.
+    // 4 x 2 793, 4 x 3 823, 8 x 2 / 4 x 4 / 2 x 8 slower.  By size (tools/csr_layout_ab.py, double): 4.1 M rows
+    // 251 -> 246 us, 8.4 M 510 -> 495, 16.8 M 985 -> 953; the Flan-like matrix (81 per row) 272 both;
+    // 5-pt 4096^2 397 -> 405.
     constexpr int PE = sizeof(T) == 8 ? 2 : 4, PU = sizeof(T) == 8 ? 3 : 2;
     if (vec_ok) {
-        if (segs_per_wave == 2) {
+        // below 2 M rows the grid is a few rounds deep and the wider layout of rounds 1-2 is as fast or
+        // faster (64^3: 18.4 against 20.7 us; 1 - 2 M rows: equal); key 1 forces it for A/B runs
+        if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_seg < 32768) {
+            if (segs_per_wave == 2) {
+                GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);
+            } else {
+                GKOC_LAUNCH_PIPE3(EV, 1, 0x1000);
+            }
+        } else if (segs_per_wave == 2) {
             GKOC_LAUNCH_PIPE3(PE, PU, 0x2000);
         } else {
             GKOC_LAUNCH_PIPE3(PE, PU, 0x1000);

@@ -145,7 +145,9 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
 #define GKOC_TUNE_MULTI_XCD_CHUNK_ROWS 6 /* SpMV with several right-hand sides (CSR / ELL / SELL-P): rows per chunk
                                       that one XCD walks before the next XCD's chunk begins (csrc/common.hpp,
                                       xcd_chunked_block); 0: every 8th workgroup (plain dispatch order) */
-/* key 2: reserved (round-2 experiments with the CSR kernel's ring size / lane layout, all rejected) */
+#define GKOC_TUNE_CSR_LOAD_GROUPS 2 /* csr::spmv, one column: 0 (default) two entries per lane and load, three load
+                                      groups in flight (float: four entries, two groups); 1: four (eight) entries,
+                                      one group - the layout of rounds 1-2, kept for A/B measurements */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,
