@@ -490,6 +490,24 @@ GKOC_DEF_CSR(double, f64, int64_t, i64)
 GKOC_DEF_CSR(float, f32, int32_t, i32)
 GKOC_DEF_CSR(float, f32, int64_t, i64)
 
+// csr::sort_by_column_index for complex values (pairs; the kernel only moves them)
+#define GKOC_DEF_CSR_SORT(T, TN, I, IN)                                        \
+    extern "C" int gkoc_csr_sort_by_column_index_##TN##_##IN(                  \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, I* col_idxs,       \
+        T* vals)                                                               \
+    {                                                                          \
+        if (n_rows <= 0) return GKOC_OK;                                       \
+        sort_rows_kernel<T, I>                                                 \
+            <<<dim3(unsigned(ceildiv(n_rows, 64))), dim3(64), 0,               \
+               as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals);              \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }
+GKOC_DEF_CSR_SORT(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_CSR_SORT(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_CSR_SORT(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_CSR_SORT(gkoc_c64, c64, int64_t, i64)
+
 #define GKOC_DEF_CSR_MIXED(I, IN)                                                                  \
     extern "C" int gkoc_csr_spmv_f32_f64_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,     \
                                               const I* row_ptrs, const I* col_idxs,                \

@@ -316,3 +316,122 @@ extern "C" int gkoc_fill_array_small(gkoc_stream_t s, void* data, int64_t n, int
     GKOC_LAUNCH_OK();
     return GKOC_OK;
 }
+
+// csr::spgemm_reuse / advanced_spgemm_reuse / spgeam_numeric (core/matrix/csr_kernels.hpp:60-92;
+// reference/matrix/csr_kernels.cpp:304-436, :474-499): the values of a product or sum whose
+// sparsity pattern exists already.  One lane per row of C, entries added in the reference's
+// order.  The position of a column in C's row is found by bisection of its (sorted) column
+// indices - Ginkgo's per-row lookup structures (bitmaps / hash tables, csr_lookup.hpp) are
+// consumed by device kernels only, so this backend keeps none (build_lookup_offsets /
+// build_lookup of the binding write empty ones).
+namespace gkoc {
+namespace {
+
+template <typename I>
+__device__ __forceinline__ int64_t find_col(const I* __restrict__ cols, int64_t b, int64_t e, I col)
+{
+    int64_t lo = b, hi = e;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cols[mid] < col) {
+            lo = mid + 1;
+        } else {
+            hi = mid;
+        }
+    }
+    if (lo < e && cols[lo] == col) return lo;
+    for (int64_t k = b; k < e; ++k) {   // an unsorted row
+        if (cols[k] == col) return k;
+    }
+    return -1;
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void spgemm_reuse_kernel(
+    int64_t n_rows, const I* __restrict__ a_ptrs, const I* __restrict__ a_cols, const T* __restrict__ a_vals,
+    const I* __restrict__ b_ptrs, const I* __restrict__ b_cols, const T* __restrict__ b_vals,
+    const T* __restrict__ alpha, const T* __restrict__ beta, const I* __restrict__ d_ptrs,
+    const I* __restrict__ d_cols, const T* __restrict__ d_vals, const I* __restrict__ c_ptrs,
+    const I* __restrict__ c_cols, T* __restrict__ c_vals)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    const int64_t cb = c_ptrs[row], ce = c_ptrs[row + 1];
+    for (int64_t k = cb; k < ce; ++k) c_vals[k] = T(0);
+    const bool adv = alpha != nullptr;
+    const T va = adv ? alpha[0] : T(1);
+    for (int64_t an = a_ptrs[row]; an < a_ptrs[row + 1]; ++an) {
+        const int64_t ac = a_cols[an];
+        const T av = a_vals[an];
+        for (int64_t bn = b_ptrs[ac]; bn < b_ptrs[ac + 1]; ++bn) {
+            const int64_t pos = find_col<I>(c_cols, cb, ce, b_cols[bn]);
+            if (pos >= 0) c_vals[pos] += adv ? va * av * b_vals[bn] : av * b_vals[bn];
+        }
+    }
+    if (adv) {
+        const T vb = beta[0];
+        for (int64_t dn = d_ptrs[row]; dn < d_ptrs[row + 1]; ++dn) {
+            const int64_t pos = find_col<I>(c_cols, cb, ce, d_cols[dn]);
+            if (pos >= 0) c_vals[pos] += vb * d_vals[dn];
+        }
+    }
+}
+
+// merge of the sorted rows of a and b; C's row holds the union of their columns in order
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void spgeam_numeric_kernel(
+    int64_t n_rows, const T* __restrict__ alpha, const I* __restrict__ a_ptrs, const I* __restrict__ a_cols,
+    const T* __restrict__ a_vals, const T* __restrict__ beta, const I* __restrict__ b_ptrs,
+    const I* __restrict__ b_cols, const T* __restrict__ b_vals, const I* __restrict__ c_ptrs,
+    T* __restrict__ c_vals)
+{
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n_rows) return;
+    const T va = alpha[0], vb = beta[0];
+    int64_t ia = a_ptrs[row], ib = b_ptrs[row], out = c_ptrs[row];
+    const int64_t ea = a_ptrs[row + 1], eb = b_ptrs[row + 1], ec = c_ptrs[row + 1];
+    while ((ia < ea || ib < eb) && out < ec) {
+        const int64_t ca = ia < ea ? int64_t(a_cols[ia]) : INT64_MAX;
+        const int64_t cbv = ib < eb ? int64_t(b_cols[ib]) : INT64_MAX;
+        const int64_t col = ca < cbv ? ca : cbv;
+        const T av = ca == col ? a_vals[ia] : T(0);
+        const T bv = cbv == col ? b_vals[ib] : T(0);
+        c_vals[out++] = va * av + vb * bv;
+        ia += ca == col;
+        ib += cbv == col;
+    }
+}
+
+}  // namespace
+}  // namespace gkoc
+
+#define GKOC_DEF_REUSE(T, TN, I, IN)                                                                        \
+    extern "C" int gkoc_csr_spgemm_reuse_##TN##_##IN(                                                       \
+        gkoc_stream_t s, int64_t n_rows, const I* a_ptrs, const I* a_cols, const T* a_vals,                 \
+        const I* b_ptrs, const I* b_cols, const T* b_vals, const T* alpha, const T* beta,                   \
+        const I* d_ptrs, const I* d_cols, const T* d_vals, const I* c_ptrs, const I* c_cols, T* c_vals)     \
+    {                                                                                                       \
+        if (n_rows <= 0) return GKOC_OK;                                                                    \
+        GKOC_REQUIRE((alpha == nullptr) == (beta == nullptr) && (alpha == nullptr || d_ptrs),               \
+                     GKOC_E_INVALID, "alpha, beta and d go together");                                      \
+        spgemm_reuse_kernel<T, I><<<dim3(grid_of(n_rows)), dim3(256), 0, as_stream(s)>>>(                   \
+            n_rows, a_ptrs, a_cols, a_vals, b_ptrs, b_cols, b_vals, alpha, beta, d_ptrs, d_cols, d_vals,    \
+            c_ptrs, c_cols, c_vals);                                                                        \
+        GKOC_LAUNCH_OK();                                                                                   \
+        return GKOC_OK;                                                                                     \
+    }                                                                                                       \
+    extern "C" int gkoc_csr_spgeam_numeric_##TN##_##IN(                                                     \
+        gkoc_stream_t s, int64_t n_rows, const T* alpha, const I* a_ptrs, const I* a_cols,                  \
+        const T* a_vals, const T* beta, const I* b_ptrs, const I* b_cols, const T* b_vals,                  \
+        const I* c_ptrs, T* c_vals)                                                                         \
+    {                                                                                                       \
+        if (n_rows <= 0) return GKOC_OK;                                                                    \
+        spgeam_numeric_kernel<T, I><<<dim3(grid_of(n_rows)), dim3(256), 0, as_stream(s)>>>(                 \
+            n_rows, alpha, a_ptrs, a_cols, a_vals, beta, b_ptrs, b_cols, b_vals, c_ptrs, c_vals);           \
+        GKOC_LAUNCH_OK();                                                                                   \
+        return GKOC_OK;                                                                                     \
+    }
+GKOC_DEF_REUSE(double, f64, int32_t, i32)
+GKOC_DEF_REUSE(double, f64, int64_t, i64)
+GKOC_DEF_REUSE(float, f32, int32_t, i32)
+GKOC_DEF_REUSE(float, f32, int64_t, i64)

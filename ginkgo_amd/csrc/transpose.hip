@@ -128,3 +128,8 @@ GKOC_DEF_TRANSPOSE(double, f64, int32_t, i32)
 GKOC_DEF_TRANSPOSE(double, f64, int64_t, i64)
 GKOC_DEF_TRANSPOSE(float, f32, int32_t, i32)
 GKOC_DEF_TRANSPOSE(float, f32, int64_t, i64)
+// complex values move as pairs (conj_transpose: the binding conjugates the moved values)
+GKOC_DEF_TRANSPOSE(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_TRANSPOSE(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_TRANSPOSE(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_TRANSPOSE(gkoc_c64, c64, int64_t, i64)

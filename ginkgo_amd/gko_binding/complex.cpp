@@ -12,9 +12,14 @@
 #include <ginkgo/core/matrix/diagonal.hpp>
 
 #include "core/base/device_matrix_data_kernels.hpp"
+#include "core/components/absolute_array_kernels.hpp"
+#include "core/components/precision_conversion_kernels.hpp"
+#include "core/components/reduce_array_kernels.hpp"
 #include "core/components/fill_array_kernels.hpp"
 #include "core/matrix/csr_kernels.hpp"
 #include "core/matrix/dense_kernels.hpp"
+#include "core/matrix/diagonal_kernels.hpp"
+#include "core/stop/residual_norm_kernels.hpp"
 #include "shim_common.hpp"
 
 namespace gko {
@@ -151,6 +156,60 @@ FOR_CT(DEF)
     }
 FOR_CT_IT(DEF)
 #undef DEF
+
+// |z| of a complex array (a column of n rows), sums and precision changes of complex arrays
+#define DEF(C, P, TN, R, RN)                                                                     \
+    template <>                                                                                  \
+    void inplace_absolute_array<C>(exec_t exec, C* data, size_type n)                            \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_absolute_##TN(stream_of(exec), static_cast<int64_t>(n), 1,         \
+                                            pairs(data), 1, nullptr, 0, 0));                     \
+    }                                                                                            \
+    template <>                                                                                  \
+    void outplace_absolute_array<C>(exec_t exec, const C* in, size_type n, R* out)               \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_absolute_##TN(stream_of(exec), static_cast<int64_t>(n), 1,         \
+                                            const_cast<P*>(pairs(in)), 1, out, 1, 1));           \
+    }                                                                                            \
+    template <>                                                                                  \
+    void reduce_add_array<C>(exec_t exec, const array<C>& arr, array<C>& val)                    \
+    {                                                                                            \
+        /* val[0] += sum: the mean of the column times its length would round differently, so    \
+         * the sum goes through the dot product with a column of ones */                         \
+        const auto n = static_cast<int64_t>(arr.get_size());                                     \
+        array<C> tmp(exec, 2);                                                                   \
+        array<C> ones(exec, arr.get_size() + 1);                                                 \
+        const auto s = stream_of(exec);                                                          \
+        GKOC_CALL(gkoc_fill_array_##TN(s, pairs(ones.get_data()), n + 1, P{1, 0}));              \
+        GKOC_CALL(gkoc_cdense_compute_dot_##TN(s, n, 1, pairs(arr.get_const_data()), 1,          \
+                                               pairs(ones.get_const_data()), 1,                  \
+                                               pairs(tmp.get_data()), 0));                       \
+        GKOC_CALL(gkoc_cdense_add_scaled_##TN(s, 1, 1, ones.get_const_data(), 1, 0,              \
+                                              pairs(tmp.get_const_data()), 1,                    \
+                                              pairs(val.get_data()), 1));                        \
+        exec->synchronize(); /* the temporaries are released on return */                        \
+    }
+FOR_CT(DEF)
+#undef DEF
+
+template <>
+void convert_precision<std::complex<float>, std::complex<double>>(exec_t exec, size_type size,
+                                                                  const std::complex<float>* in,
+                                                                  std::complex<double>* out)
+{
+    GKOC_CALL(gkoc_convert_precision_f32_f64(stream_of(exec), 2 * static_cast<int64_t>(size),
+                                             reinterpret_cast<const float*>(in),
+                                             reinterpret_cast<double*>(out)));
+}
+template <>
+void convert_precision<std::complex<double>, std::complex<float>>(exec_t exec, size_type size,
+                                                                  const std::complex<double>* in,
+                                                                  std::complex<float>* out)
+{
+    GKOC_CALL(gkoc_convert_precision_f64_f32(stream_of(exec), 2 * static_cast<int64_t>(size),
+                                             reinterpret_cast<const double*>(in),
+                                             reinterpret_cast<float*>(out)));
+}
 
 }  // namespace components
 
@@ -418,6 +477,56 @@ namespace csr {
 FOR_CT_IT(DEF)
 #undef DEF
 
+#define DEF(C, TN, I, IN)                                                                        \
+    template <>                                                                                  \
+    void is_sorted_by_column_index<C, I>(exec_t exec, const matrix::Csr<C, I>* to_check,         \
+                                         bool* is_sorted)                                        \
+    {                                                                                            \
+        int flag = 1; /* a question about the column indices only */                             \
+        GKOC_CALL(gkoc_csr_is_sorted_by_column_index_f64_##IN(                                   \
+            stream_of(exec), to_check->get_size()[0], to_check->get_const_row_ptrs(),            \
+            to_check->get_const_col_idxs(), &flag));                                             \
+        *is_sorted = flag != 0;                                                                  \
+    }                                                                                            \
+    template <>                                                                                  \
+    void sort_by_column_index<C, I>(exec_t exec, matrix::Csr<C, I>* to_sort)                     \
+    {                                                                                            \
+        GKOC_CALL(gkoc_csr_sort_by_column_index_##TN##_##IN(                                     \
+            stream_of(exec), to_sort->get_size()[0], to_sort->get_const_row_ptrs(),              \
+            to_sort->get_col_idxs(), pairs(to_sort->get_values())));                             \
+    }                                                                                            \
+    static void ctranspose_impl_##TN##_##IN(exec_t exec, const matrix::Csr<C, I>* orig,          \
+                                            matrix::Csr<C, I>* trans, bool conjugate)            \
+    {                                                                                            \
+        const int64_t nnz = orig->get_num_stored_elements();                                     \
+        array<char> work(exec, gkoc_csr_transpose_workspace_bytes(nnz, orig->get_size()[1],      \
+                                                                  sizeof(I)));                   \
+        GKOC_CALL(gkoc_csr_transpose_##TN##_##IN(                                                \
+            stream_of(exec), orig->get_size()[0], orig->get_size()[1],                           \
+            orig->get_const_row_ptrs(), orig->get_const_col_idxs(),                              \
+            pairs(orig->get_const_values()), nnz, trans->get_row_ptrs(), trans->get_col_idxs(),  \
+            pairs(trans->get_values()), work.get_data(), work.get_size()));                      \
+        if (conjugate && nnz > 0) {                                                              \
+            /* conj of the nnz x 1 column, in place */                                           \
+            GKOC_CALL(gkoc_cdense_convert_##TN(stream_of(exec), nnz, 1, trans->get_const_values(), \
+                                               1, trans->get_values(), nnz, 3));                 \
+        }                                                                                        \
+        exec->synchronize(); /* work is released on return */                                    \
+    }                                                                                            \
+    template <>                                                                                  \
+    void transpose<C, I>(exec_t exec, const matrix::Csr<C, I>* orig, matrix::Csr<C, I>* trans)   \
+    {                                                                                            \
+        ctranspose_impl_##TN##_##IN(exec, orig, trans, false);                                   \
+    }                                                                                            \
+    template <>                                                                                  \
+    void conj_transpose<C, I>(exec_t exec, const matrix::Csr<C, I>* orig,                        \
+                              matrix::Csr<C, I>* trans)                                          \
+    {                                                                                            \
+        ctranspose_impl_##TN##_##IN(exec, orig, trans, true);                                    \
+    }
+FOR_CT_IT(DEF)
+#undef DEF
+
 #define DEF(T, TN, I, IN)                                                                        \
     template <>                                                                                  \
     void row_wise_absolute_sum<T, I>(exec_t exec, const matrix::Csr<T, I>* orig, array<T>& sum)  \
@@ -433,6 +542,54 @@ DEF(float, f32, int64, i64)
 #undef DEF
 
 }  // namespace csr
+
+
+namespace diagonal {
+
+#define DEF(C, P, TN, R, RN)                                                                     \
+    template <>                                                                                  \
+    void conj_transpose<C>(exec_t exec, const matrix::Diagonal<C>* orig,                         \
+                           matrix::Diagonal<C>* trans)                                           \
+    {                                                                                            \
+        const auto n = static_cast<int64_t>(orig->get_size()[0]);                                \
+        GKOC_CALL(gkoc_cdense_convert_##TN(stream_of(exec), n, 1, orig->get_const_values(), 1,   \
+                                           trans->get_values(), n, 3));                          \
+    }
+FOR_CT(DEF)
+#undef DEF
+
+}  // namespace diagonal
+
+
+namespace implicit_residual_norm {
+
+// sqrt(|tau|) <= goal * orig_tau with a complex tau: |tau| first, then the real criterion
+#define DEF(C, P, TN, R, RN)                                                                     \
+    template <>                                                                                  \
+    void implicit_residual_norm<C>(exec_t exec, const matrix::Dense<C>* tau,                     \
+                                   const matrix::Dense<R>* orig_tau, R rel_residual_goal,        \
+                                   uint8 stoppingId, bool setFinalized,                          \
+                                   array<stopping_status>* stop_status,                          \
+                                   array<bool>* device_storage, bool* all_converged,             \
+                                   bool* one_changed)                                            \
+    {                                                                                            \
+        if (device_storage->get_size() < 2) device_storage->resize_and_reset(2);                 \
+        array<R> mod(exec, tau->get_size()[1]);                                                  \
+        GKOC_CALL(gkoc_cdense_absolute_##TN(stream_of(exec), 1, cols(tau),                       \
+                                            const_cast<P*>(pairs(tau->get_const_values())),      \
+                                            ld(tau), mod.get_data(), cols(tau), 1));             \
+        int allc = 0, chg = 0;                                                                   \
+        GKOC_CALL(gkoc_implicit_residual_norm_##RN(                                              \
+            stream_of(exec), cols(tau), mod.get_const_data(), orig_tau->get_const_values(),      \
+            rel_residual_goal, stoppingId, setFinalized ? 1 : 0, cdna4::raw(stop_status),        \
+            reinterpret_cast<uint8_t*>(device_storage->get_data()), &allc, &chg));               \
+        *all_converged = allc != 0;                                                              \
+        *one_changed = chg != 0;                                                                 \
+    }
+FOR_CT(DEF)
+#undef DEF
+
+}  // namespace implicit_residual_norm
 
 
 }  // namespace hip

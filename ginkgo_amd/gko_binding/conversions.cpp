@@ -748,8 +748,66 @@ namespace csr {
         /* alpha A's entries come first ("D"), then beta B's: 0 + alpha a + beta b */               \
         from_contributions_##TN##_##IN(exec, beta->get_const_values(), b, nullptr,                  \
                                        alpha->get_const_values(), a, c);                            \
+    }                                                                                               \
+    /* the values of a product / sum whose pattern exists (Csr::multiply_reuse etc.): positions     \
+     * by bisection of C's sorted rows, Ginkgo's lookup structures are not used */                  \
+    template <>                                                                                     \
+    void spgemm_reuse<T, I>(exec_t exec, const matrix::Csr<T, I>* a, const matrix::Csr<T, I>* b,    \
+                            const matrix::csr::lookup_data<I>&, matrix::Csr<T, I>* c)               \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_spgemm_reuse_##TN##_##IN(                                                \
+            stream_of(exec), static_cast<int64_t>(c->get_size()[0]), a->get_const_row_ptrs(),       \
+            a->get_const_col_idxs(), a->get_const_values(), b->get_const_row_ptrs(),                \
+            b->get_const_col_idxs(), b->get_const_values(), nullptr, nullptr, nullptr, nullptr,     \
+            nullptr, c->get_const_row_ptrs(), c->get_const_col_idxs(), c->get_values()));           \
+    }                                                                                               \
+    template <>                                                                                     \
+    void advanced_spgemm_reuse<T, I>(exec_t exec, const matrix::Dense<T>* alpha,                    \
+                                     const matrix::Csr<T, I>* a, const matrix::Csr<T, I>* b,        \
+                                     const matrix::Dense<T>* beta, const matrix::Csr<T, I>* d,      \
+                                     const matrix::csr::lookup_data<I>&, matrix::Csr<T, I>* c)      \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_spgemm_reuse_##TN##_##IN(                                                \
+            stream_of(exec), static_cast<int64_t>(c->get_size()[0]), a->get_const_row_ptrs(),       \
+            a->get_const_col_idxs(), a->get_const_values(), b->get_const_row_ptrs(),                \
+            b->get_const_col_idxs(), b->get_const_values(), alpha->get_const_values(),              \
+            beta->get_const_values(), d->get_const_row_ptrs(), d->get_const_col_idxs(),             \
+            d->get_const_values(), c->get_const_row_ptrs(), c->get_const_col_idxs(),                \
+            c->get_values()));                                                                      \
+    }                                                                                               \
+    template <>                                                                                     \
+    void spgeam_numeric<T, I>(exec_t exec, const matrix::Dense<T>* alpha,                           \
+                              const matrix::Csr<T, I>* a, const matrix::Dense<T>* beta,             \
+                              const matrix::Csr<T, I>* b, matrix::Csr<T, I>* c)                     \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_spgeam_numeric_##TN##_##IN(                                              \
+            stream_of(exec), static_cast<int64_t>(c->get_size()[0]), alpha->get_const_values(),     \
+            a->get_const_row_ptrs(), a->get_const_col_idxs(), a->get_const_values(),                \
+            beta->get_const_values(), b->get_const_row_ptrs(), b->get_const_col_idxs(),             \
+            b->get_const_values(), c->get_const_row_ptrs(), c->get_values()));                      \
     }
 FOR_VT_IT(DEF)
+#undef DEF
+
+// Ginkgo's per-row lookup structures are read by device kernels only; this backend finds positions
+// by bisection (csrc/misc.hip) and writes empty ones: no storage, "full" descriptors never read
+#define DEF(I, IN)                                                                                  \
+    template <>                                                                                     \
+    void build_lookup_offsets<I>(exec_t exec, const I*, const I*, size_type num_rows,               \
+                                 matrix::csr::sparsity_type, I* storage_offsets)                    \
+    {                                                                                               \
+        GKOC_CALL(gkoc_fill_array_##IN(stream_of(exec), storage_offsets,                            \
+                                       static_cast<int64_t>(num_rows) + 1, I(0)));                  \
+    }                                                                                               \
+    template <>                                                                                     \
+    void build_lookup<I>(exec_t exec, const I*, const I*, size_type num_rows,                       \
+                         matrix::csr::sparsity_type, const I*, int64* row_desc, int32*)             \
+    {                                                                                               \
+        GKOC_CALL(gkoc_fill_array_i64(stream_of(exec), row_desc, static_cast<int64_t>(num_rows),    \
+                                      int64_t(0)));                                                 \
+    }
+DEF(int32, i32)
+DEF(int64, i64)
 #undef DEF
 
 }  // namespace csr

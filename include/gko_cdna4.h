@@ -1222,6 +1222,19 @@ GKOC_DECL_RWAS(double, f64, int32_t, i32)
 GKOC_DECL_RWAS(double, f64, int64_t, i64)
 GKOC_DECL_RWAS(float, f32, int32_t, i32)
 GKOC_DECL_RWAS(float, f32, int64_t, i64)
+/* csr::sort_by_column_index and csr::transpose for complex values (pairs are only moved; a
+ * conj_transpose conjugates them afterwards: gkoc_cdense_convert mode 3 on the n x 1 array) */
+#define GKOC_DECL_CCSR_MOVE(P, TN, I, IN)                                                              \
+    int gkoc_csr_sort_by_column_index_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,  \
+                                                  I* col_idxs, P* vals);                               \
+    int gkoc_csr_transpose_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,                \
+                                       const I* row_ptrs, const I* col_idxs, const P* vals,            \
+                                       int64_t nnz, I* t_row_ptrs, I* t_col_idxs, P* t_vals,           \
+                                       void* work, size_t work_bytes);
+GKOC_DECL_CCSR_MOVE(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_CCSR_MOVE(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_CCSR_MOVE(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_CCSR_MOVE(gkoc_c64, c64, int64_t, i64)
 /* dense::compute_mean for real columns (core/matrix/dense_kernels.hpp:98-102): result[j] =
  * (sum_i x(i,j)) / rows */
 int gkoc_dense_compute_mean_f64(gkoc_stream_t s, int64_t rows, int64_t cols, const double* x,
@@ -1299,6 +1312,24 @@ GKOC_DECL_MIXED(int64_t, i64)
 GKOC_DECL_CV_DENSE(double, f64)
 GKOC_DECL_CV_DENSE(float, f32)
 int gkoc_fill_seq_array_u64(gkoc_stream_t s, uint64_t* data, int64_t n);
+/* csr::spgemm_reuse / advanced_spgemm_reuse (alpha != NULL: c = alpha a b + beta d) and
+ * csr::spgeam_numeric (c = alpha a + beta b) - core/matrix/csr_kernels.hpp:60-92: the VALUES of a
+ * product / sum whose pattern (c_ptrs, c_cols; rows sorted by column) exists already; entries are
+ * added in the reference's order (reference/matrix/csr_kernels.cpp:304-436, :474-499) */
+#define GKOC_DECL_REUSE(T, TN, I, IN)                                                                  \
+    int gkoc_csr_spgemm_reuse_##TN##_##IN(                                                             \
+        gkoc_stream_t s, int64_t n_rows, const I* a_ptrs, const I* a_cols, const T* a_vals,            \
+        const I* b_ptrs, const I* b_cols, const T* b_vals, const T* alpha, const T* beta,              \
+        const I* d_ptrs, const I* d_cols, const T* d_vals, const I* c_ptrs, const I* c_cols,           \
+        T* c_vals);                                                                                    \
+    int gkoc_csr_spgeam_numeric_##TN##_##IN(                                                           \
+        gkoc_stream_t s, int64_t n_rows, const T* alpha, const I* a_ptrs, const I* a_cols,             \
+        const T* a_vals, const T* beta, const I* b_ptrs, const I* b_cols, const T* b_vals,             \
+        const I* c_ptrs, T* c_vals);
+GKOC_DECL_REUSE(double, f64, int32_t, i32)
+GKOC_DECL_REUSE(double, f64, int64_t, i64)
+GKOC_DECL_REUSE(float, f32, int32_t, i32)
+GKOC_DECL_REUSE(float, f32, int64_t, i64)
 /* components::fill_array for bool / char / uint16 / uint32 arrays
  * (core/components/fill_array_kernels.hpp:18-21): elem_bytes 1, 2 or 4, value = low bytes of pattern */
 int gkoc_fill_array_small(gkoc_stream_t s, void* data, int64_t n, int elem_bytes, uint32_t pattern);

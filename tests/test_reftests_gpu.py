@@ -4,10 +4,10 @@ unmodified by oracle/build_reftests.py (EXEC_TYPE=HipExecutor, GKO_DEVICE_NAMESP
 cmake/create_test.cmake:399-463 does) against the drop-in libginkgo_hip.so and run here.
 
 Every suite must run to its end, and every test in it must pass unless it is listed in
-tests/dropin/reftests_expected.json: those are the kernels / value types this backend
-leaves to Ginkgo's `NotCompiled` stubs (arithmetic on complex values, the reuse forms of SpGEMM,
-the Fbcsr format and the triangular solvers that test/matrix/matrix.cpp and test/solver/solver.cpp
-instantiate next to the in-scope formats and solvers - outside SURVEY.md 8).  No listed failure is
+tests/dropin/reftests_expected.json: those are the kernels this backend leaves to Ginkgo's
+`NotCompiled` stubs (the Fbcsr format and the triangular solvers that test/matrix/matrix.cpp and
+test/solver/solver.cpp instantiate next to the in-scope formats and solvers, complex IDR - outside
+SURVEY.md 8).  No listed failure is
 a wrong number."""
 import json
 import os
@@ -67,5 +67,9 @@ def test_hot_path_suites_are_fully_green():
                   "distributed_matrix_kernels_hip", "distributed_partition_helper_kernels_hip",
                   "distributed_partition_kernels_hip", "distributed_vector_kernels_hip",
                   "matrix_sparsity_csr_kernels_hip", "matrix_permutation_kernels_hip",
-                  "matrix_scaled_permutation_kernels_hip"):
+                  "matrix_scaled_permutation_kernels_hip",
+                  # ... with the complex kernels and the reuse forms of SpGEMM / SpGEAM
+                  "matrix_dense_kernels_hip", "matrix_csr_kernels2_hip", "matrix_diagonal_kernels_hip",
+                  "stop_residual_norm_kernels_hip", "components_absolute_array_kernels_hip",
+                  "components_reduce_array_kernels_hip", "components_precision_conversion_kernels_hip"):
         assert EXPECTED[suite]["known_failures"] == {}, suite
