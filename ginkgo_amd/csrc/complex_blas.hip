@@ -323,6 +323,113 @@ __global__ __launch_bounds__(256) void csr_row_scan_kernel(int64_t rows, const I
     }
 }
 
+// scalar Jacobi and Diagonal products on complex values (jacobi::{invert_diagonal,
+// simple_scalar_apply, scalar_apply}, diagonal::{apply_to_csr, right_apply_to_csr};
+// reference/preconditioner/jacobi_kernels.cpp:535-592, reference/matrix/diagonal_kernels.cpp:60-102)
+template <typename R>
+__global__ __launch_bounds__(256) void cx_invert_kernel(int64_t n, const cx<R>* __restrict__ d, cx<R>* __restrict__ inv)
+{
+    GKOC_FOR2(i, n)
+    {
+        const cx<R> v = is_zero(d[i]) ? cx<R>{R(1), R(0)} : d[i];
+        inv[i] = cx<R>{R(1), R(0)} / v;
+    }
+}
+
+// x(i,j) = b(i,j) d[i], or beta x(i,j) + (alpha b(i,j)) d[i]
+template <typename R, bool ADVANCED>
+__global__ __launch_bounds__(256) void cx_row_scale_kernel(int64_t rows, int64_t cols, const cx<R>* __restrict__ d,
+                                                          const cx<R>* __restrict__ alpha,
+                                                          const cx<R>* __restrict__ b, int64_t ldb,
+                                                          const cx<R>* __restrict__ beta, cx<R>* __restrict__ x,
+                                                          int64_t ldx)
+{
+    GKOC_FOR2(i, rows * cols)
+    {
+        const int64_t r = i / cols, c = i - r * cols;
+        if (ADVANCED) {
+            x[r * ldx + c] = beta[0] * x[r * ldx + c] + (alpha[0] * b[r * ldb + c]) * d[r];
+        } else {
+            x[r * ldx + c] = b[r * ldb + c] * d[r];
+        }
+    }
+}
+
+// mode 0: vals[k] *= d[row]; 1: vals[k] *= 1 / d[row]; 2: vals[k] *= d[col[k]]
+template <typename R, typename I>
+__global__ __launch_bounds__(256) void cx_csr_scale_kernel(int64_t n_rows, const I* __restrict__ row_ptrs,
+                                                          const I* __restrict__ cols, const cx<R>* __restrict__ d,
+                                                          int mode, cx<R>* __restrict__ vals)
+{
+    GKOC_FOR2(r, n_rows)
+    {
+        const cx<R> s = mode == 1 ? cx<R>{R(1), R(0)} / d[r] : d[r];
+        for (I k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+            vals[k] = vals[k] * (mode == 2 ? d[cols[k]] : s);
+        }
+    }
+}
+
+// Dense -> Csr with complex values (dense::count_nonzeros_per_row / convert_to_csr): one lane per
+// row; the entries of a row keep their column order
+template <typename R>
+__global__ __launch_bounds__(256) void cx_dense_count_kernel(int64_t rows, int64_t cols, const cx<R>* __restrict__ in,
+                                                            int64_t ld, void* __restrict__ out, int out_bytes)
+{
+    GKOC_FOR2(r, rows)
+    {
+        int64_t n = 0;
+        for (int64_t c = 0; c < cols; ++c) n += !is_zero(in[r * ld + c]);
+        if (out_bytes == 4) {
+            static_cast<int32_t*>(out)[r] = int32_t(n);
+        } else {
+            static_cast<int64_t*>(out)[r] = n;
+        }
+    }
+}
+
+template <typename R, typename I>
+__global__ __launch_bounds__(256) void cx_dense_to_csr_kernel(int64_t rows, int64_t cols, const cx<R>* __restrict__ in,
+                                                             int64_t ld, const I* __restrict__ row_ptrs,
+                                                             I* __restrict__ out_cols, cx<R>* __restrict__ out_vals)
+{
+    GKOC_FOR2(r, rows)
+    {
+        int64_t k = row_ptrs[r];
+        for (int64_t c = 0; c < cols; ++c) {
+            const cx<R> v = in[r * ld + c];
+            if (!is_zero(v)) {
+                out_cols[k] = I(c);
+                out_vals[k] = v;
+                ++k;
+            }
+        }
+    }
+}
+
+// Coo with complex values: c(row, j) += [alpha] val b(col, j), entry by entry with atomic adds of the
+// real and imaginary parts (the only kernels of this library whose summation order is not fixed:
+// the complex instantiations exist so that Ginkgo's distributed Matrix runs with a Coo non-local
+// part on complex data, they are not a tuned path)
+template <typename R, typename I>
+__global__ __launch_bounds__(256) void cx_coo_spmv2_kernel(int64_t nnz, int64_t nrhs, const I* __restrict__ rows,
+                                                          const I* __restrict__ cols,
+                                                          const cx<R>* __restrict__ vals,
+                                                          const cx<R>* __restrict__ alpha,
+                                                          const cx<R>* __restrict__ b, int64_t ldb,
+                                                          cx<R>* __restrict__ c, int64_t ldc)
+{
+    GKOC_FOR2(i, nnz * nrhs)
+    {
+        const int64_t k = i / nrhs, j = i - k * nrhs;
+        cx<R> t = vals[k] * b[int64_t(cols[k]) * ldb + j];
+        if (alpha) t = alpha[0] * t;
+        cx<R>* dst = c + int64_t(rows[k]) * ldc + j;
+        atomicAdd(&dst->re, t.re);
+        atomicAdd(&dst->im, t.im);
+    }
+}
+
 template <typename R, typename S, int OP>
 int cx_axpy(gkoc_stream_t s, int64_t rows, int64_t cols, const void* alpha, int64_t alpha_cols, const void* x,
             int64_t ldx, void* y, int64_t ldy)
@@ -555,3 +662,105 @@ GKOC_DEF_RWAS(double, f64, int32_t, i32)
 GKOC_DEF_RWAS(double, f64, int64_t, i64)
 GKOC_DEF_RWAS(float, f32, int32_t, i32)
 GKOC_DEF_RWAS(float, f32, int64_t, i64)
+
+#define GKOC_DEF_CJAC(P, TN, R)                                                                             \
+    extern "C" int gkoc_cjacobi_invert_diagonal_##TN(gkoc_stream_t s, int64_t n, const P* diag, P* inv)     \
+    {                                                                                                       \
+        if (n <= 0) return GKOC_OK;                                                                         \
+        cx_invert_kernel<R><<<dim3(grid_of(n)), dim3(256), 0, as_stream(s)>>>(                              \
+            n, reinterpret_cast<const cx<R>*>(diag), reinterpret_cast<cx<R>*>(inv));                        \
+        GKOC_LAUNCH_OK();                                                                                   \
+        return GKOC_OK;                                                                                     \
+    }                                                                                                       \
+    /* alpha == NULL: x = diag b (row-wise); else x = beta x + alpha b diag */                              \
+    extern "C" int gkoc_cjacobi_scalar_apply_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,              \
+                                                  const P* diag, const P* alpha, const P* b, int64_t ldb,   \
+                                                  const P* beta, P* x, int64_t ldx)                         \
+    {                                                                                                       \
+        if (rows <= 0 || cols <= 0) return GKOC_OK;                                                         \
+        GKOC_REQUIRE((alpha == nullptr) == (beta == nullptr), GKOC_E_INVALID, "alpha and beta go together");\
+        const dim3 g(grid_of(rows * cols));                                                                 \
+        if (alpha) {                                                                                        \
+            cx_row_scale_kernel<R, true><<<g, dim3(256), 0, as_stream(s)>>>(                                \
+                rows, cols, reinterpret_cast<const cx<R>*>(diag), reinterpret_cast<const cx<R>*>(alpha),    \
+                reinterpret_cast<const cx<R>*>(b), ldb, reinterpret_cast<const cx<R>*>(beta),               \
+                reinterpret_cast<cx<R>*>(x), ldx);                                                          \
+        } else {                                                                                            \
+            cx_row_scale_kernel<R, false><<<g, dim3(256), 0, as_stream(s)>>>(                               \
+                rows, cols, reinterpret_cast<const cx<R>*>(diag), nullptr,                                  \
+                reinterpret_cast<const cx<R>*>(b), ldb, nullptr, reinterpret_cast<cx<R>*>(x), ldx);         \
+        }                                                                                                   \
+        GKOC_LAUNCH_OK();                                                                                   \
+        return GKOC_OK;                                                                                     \
+    }
+GKOC_DEF_CJAC(gkoc_c128, c128, double)
+GKOC_DEF_CJAC(gkoc_c64, c64, float)
+
+#define GKOC_DEF_CCSR_SCALE(P, TN, R, I, IN)                                                                \
+    /* mode 0: vals *= diag[row]; 1: vals *= 1 / diag[row]; 2: vals *= diag[col] */                         \
+    extern "C" int gkoc_ccsr_scale_by_diagonal_##TN##_##IN(gkoc_stream_t s, int64_t n_rows,                 \
+                                                           const I* row_ptrs, const I* col_idxs,            \
+                                                           const P* diag, int mode, P* vals)                \
+    {                                                                                                       \
+        GKOC_REQUIRE(mode >= 0 && mode <= 2, GKOC_E_INVALID, "mode");                                       \
+        if (n_rows <= 0) return GKOC_OK;                                                                    \
+        cx_csr_scale_kernel<R, I><<<dim3(grid_of(n_rows)), dim3(256), 0, as_stream(s)>>>(                   \
+            n_rows, row_ptrs, col_idxs, reinterpret_cast<const cx<R>*>(diag), mode,                         \
+            reinterpret_cast<cx<R>*>(vals));                                                                \
+        GKOC_LAUNCH_OK();                                                                                   \
+        return GKOC_OK;                                                                                     \
+    }
+GKOC_DEF_CCSR_SCALE(gkoc_c128, c128, double, int32_t, i32)
+GKOC_DEF_CCSR_SCALE(gkoc_c128, c128, double, int64_t, i64)
+GKOC_DEF_CCSR_SCALE(gkoc_c64, c64, float, int32_t, i32)
+GKOC_DEF_CCSR_SCALE(gkoc_c64, c64, float, int64_t, i64)
+
+#define GKOC_DEF_CDENSE_CSR(P, TN, R)                                                                       \
+    /* out: int32 / int64 / uint64 counts (out_bytes 4 or 8) */                                             \
+    extern "C" int gkoc_cdense_count_nonzeros_per_row_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,     \
+                                                           const P* in, int64_t ld, void* out,              \
+                                                           int out_bytes)                                   \
+    {                                                                                                       \
+        GKOC_REQUIRE(out_bytes == 4 || out_bytes == 8, GKOC_E_INVALID, "out_bytes");                        \
+        if (rows <= 0) return GKOC_OK;                                                                      \
+        cx_dense_count_kernel<R><<<dim3(grid_of(rows)), dim3(256), 0, as_stream(s)>>>(                      \
+            rows, cols, reinterpret_cast<const cx<R>*>(in), ld, out, out_bytes);                            \
+        GKOC_LAUNCH_OK();                                                                                   \
+        return GKOC_OK;                                                                                     \
+    }
+GKOC_DEF_CDENSE_CSR(gkoc_c128, c128, double)
+GKOC_DEF_CDENSE_CSR(gkoc_c64, c64, float)
+#define GKOC_DEF_CDENSE_CSR_I(P, TN, R, I, IN)                                                              \
+    extern "C" int gkoc_cdense_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* in, \
+                                                  int64_t ld, const I* row_ptrs, I* out_cols, P* out_vals)  \
+    {                                                                                                       \
+        if (rows <= 0) return GKOC_OK;                                                                      \
+        cx_dense_to_csr_kernel<R, I><<<dim3(grid_of(rows)), dim3(256), 0, as_stream(s)>>>(                  \
+            rows, cols, reinterpret_cast<const cx<R>*>(in), ld, row_ptrs, out_cols,                         \
+            reinterpret_cast<cx<R>*>(out_vals));                                                            \
+        GKOC_LAUNCH_OK();                                                                                   \
+        return GKOC_OK;                                                                                     \
+    }
+GKOC_DEF_CDENSE_CSR_I(gkoc_c128, c128, double, int32_t, i32)
+GKOC_DEF_CDENSE_CSR_I(gkoc_c128, c128, double, int64_t, i64)
+GKOC_DEF_CDENSE_CSR_I(gkoc_c64, c64, float, int32_t, i32)
+GKOC_DEF_CDENSE_CSR_I(gkoc_c64, c64, float, int64_t, i64)
+
+#define GKOC_DEF_CCOO(P, TN, R, I, IN)                                                                      \
+    /* c += [alpha] A b (alpha == NULL: 1); for c = A b clear c first, for c = alpha A b + beta c scale it */ \
+    extern "C" int gkoc_ccoo_spmv2_##TN##_##IN(gkoc_stream_t s, int64_t nnz, int64_t nrhs, const I* rows,   \
+                                               const I* cols, const P* vals, const P* alpha, const P* b,    \
+                                               int64_t ldb, P* c, int64_t ldc)                              \
+    {                                                                                                       \
+        if (nnz <= 0 || nrhs <= 0) return GKOC_OK;                                                          \
+        cx_coo_spmv2_kernel<R, I><<<dim3(grid_of(nnz * nrhs)), dim3(256), 0, as_stream(s)>>>(               \
+            nnz, nrhs, rows, cols, reinterpret_cast<const cx<R>*>(vals),                                    \
+            reinterpret_cast<const cx<R>*>(alpha), reinterpret_cast<const cx<R>*>(b), ldb,                  \
+            reinterpret_cast<cx<R>*>(c), ldc);                                                              \
+        GKOC_LAUNCH_OK();                                                                                   \
+        return GKOC_OK;                                                                                     \
+    }
+GKOC_DEF_CCOO(gkoc_c128, c128, double, int32_t, i32)
+GKOC_DEF_CCOO(gkoc_c128, c128, double, int64_t, i64)
+GKOC_DEF_CCOO(gkoc_c64, c64, float, int32_t, i32)
+GKOC_DEF_CCOO(gkoc_c64, c64, float, int64_t, i64)

@@ -7,6 +7,7 @@
 
 #include <ginkgo/core/base/device_matrix_data.hpp>
 #include <ginkgo/core/base/matrix_data.hpp>
+#include <ginkgo/core/matrix/coo.hpp>
 #include <ginkgo/core/matrix/csr.hpp>
 #include <ginkgo/core/matrix/dense.hpp>
 #include <ginkgo/core/matrix/diagonal.hpp>
@@ -16,9 +17,11 @@
 #include "core/components/precision_conversion_kernels.hpp"
 #include "core/components/reduce_array_kernels.hpp"
 #include "core/components/fill_array_kernels.hpp"
+#include "core/matrix/coo_kernels.hpp"
 #include "core/matrix/csr_kernels.hpp"
 #include "core/matrix/dense_kernels.hpp"
 #include "core/matrix/diagonal_kernels.hpp"
+#include "core/preconditioner/jacobi_kernels.hpp"
 #include "core/stop/residual_norm_kernels.hpp"
 #include "shim_common.hpp"
 
@@ -242,6 +245,47 @@ namespace dense {
                                        P{value.real(), value.imag()}));                          \
     }
 FOR_CT(DEF)
+#undef DEF
+
+// Dense -> Csr
+#define DEF(C, P, TN, R, RN)                                                                     \
+    template <>                                                                                  \
+    void count_nonzeros_per_row<C, int32>(exec_t exec, const matrix::Dense<C>* source,           \
+                                          int32* result)                                         \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_count_nonzeros_per_row_##TN(                                       \
+            stream_of(exec), rows(source), cols(source), pairs(source->get_const_values()),      \
+            ld(source), result, 4));                                                             \
+    }                                                                                            \
+    template <>                                                                                  \
+    void count_nonzeros_per_row<C, int64>(exec_t exec, const matrix::Dense<C>* source,           \
+                                          int64* result)                                         \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_count_nonzeros_per_row_##TN(                                       \
+            stream_of(exec), rows(source), cols(source), pairs(source->get_const_values()),      \
+            ld(source), result, 8));                                                             \
+    }                                                                                            \
+    template <>                                                                                  \
+    void count_nonzeros_per_row<C, size_type>(exec_t exec, const matrix::Dense<C>* source,       \
+                                              size_type* result)                                 \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_count_nonzeros_per_row_##TN(                                       \
+            stream_of(exec), rows(source), cols(source), pairs(source->get_const_values()),      \
+            ld(source), result, 8));                                                             \
+    }
+FOR_CT(DEF)
+#undef DEF
+#define DEF(C, TN, I, IN)                                                                        \
+    template <>                                                                                  \
+    void convert_to_csr<C, I>(exec_t exec, const matrix::Dense<C>* source,                       \
+                              matrix::Csr<C, I>* result)                                         \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cdense_to_csr_##TN##_##IN(                                                \
+            stream_of(exec), rows(source), cols(source), pairs(source->get_const_values()),      \
+            ld(source), result->get_const_row_ptrs(), result->get_col_idxs(),                    \
+            pairs(result->get_values())));                                                       \
+    }
+FOR_CT_IT(DEF)
 #undef DEF
 
 // BLAS-1 on complex columns (csrc/complex_blas.hip); S = C (complex scalars) or R (real scalars)
@@ -559,6 +603,133 @@ FOR_CT(DEF)
 #undef DEF
 
 }  // namespace diagonal
+
+
+namespace diagonal {
+
+#define DEF(C, TN, I, IN)                                                                        \
+    template <>                                                                                  \
+    void apply_to_csr<C, I>(exec_t exec, const matrix::Diagonal<C>* a, const matrix::Csr<C, I>* b, \
+                            matrix::Csr<C, I>* c, bool inverse)                                  \
+    {                                                                                            \
+        c->copy_from(b);                                                                         \
+        GKOC_CALL(gkoc_ccsr_scale_by_diagonal_##TN##_##IN(                                       \
+            stream_of(exec), static_cast<int64_t>(c->get_size()[0]), c->get_const_row_ptrs(),    \
+            c->get_const_col_idxs(), pairs(a->get_const_values()), inverse ? 1 : 0,              \
+            pairs(c->get_values())));                                                            \
+    }                                                                                            \
+    template <>                                                                                  \
+    void convert_to_csr<C, I>(exec_t exec, const matrix::Diagonal<C>* source,                    \
+                              matrix::Csr<C, I>* result)                                         \
+    {                                                                                            \
+        /* row i holds the one entry (i, i): pointers and columns count up, the values move */   \
+        const auto n = static_cast<int64_t>(source->get_size()[0]);                              \
+        const auto s = stream_of(exec);                                                          \
+        GKOC_CALL(gkoc_fill_seq_array_##IN(s, result->get_row_ptrs(), n + 1));                   \
+        GKOC_CALL(gkoc_fill_seq_array_##IN(s, result->get_col_idxs(), n));                       \
+        GKOC_CALL(gkoc_memcpy_d2d(result->get_values(), source->get_const_values(),              \
+                                  sizeof(C) * static_cast<size_t>(n), s));                       \
+    }                                                                                            \
+    template <>                                                                                  \
+    void right_apply_to_csr<C, I>(exec_t exec, const matrix::Diagonal<C>* a,                     \
+                                  const matrix::Csr<C, I>* b, matrix::Csr<C, I>* c)              \
+    {                                                                                            \
+        c->copy_from(b);                                                                         \
+        GKOC_CALL(gkoc_ccsr_scale_by_diagonal_##TN##_##IN(                                       \
+            stream_of(exec), static_cast<int64_t>(c->get_size()[0]), c->get_const_row_ptrs(),    \
+            c->get_const_col_idxs(), pairs(a->get_const_values()), 2, pairs(c->get_values())));  \
+    }
+FOR_CT_IT(DEF)
+#undef DEF
+
+}  // namespace diagonal
+
+
+namespace jacobi {
+
+#define DEF(C, P, TN, R, RN)                                                                     \
+    template <>                                                                                  \
+    void invert_diagonal<C>(exec_t exec, const array<C>& diag, array<C>& inv_diag)               \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cjacobi_invert_diagonal_##TN(stream_of(exec),                             \
+                                                    static_cast<int64_t>(diag.get_size()),       \
+                                                    pairs(diag.get_const_data()),                \
+                                                    pairs(inv_diag.get_data())));                \
+    }                                                                                            \
+    template <>                                                                                  \
+    void simple_scalar_apply<C>(exec_t exec, const array<C>& diag, const matrix::Dense<C>* b,    \
+                                matrix::Dense<C>* x)                                             \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cjacobi_scalar_apply_##TN(stream_of(exec), rows(x), cols(x),              \
+                                                 pairs(diag.get_const_data()), nullptr,          \
+                                                 pairs(b->get_const_values()), ld(b), nullptr,   \
+                                                 pairs(x->get_values()), ld(x)));                \
+    }                                                                                            \
+    template <>                                                                                  \
+    void scalar_apply<C>(exec_t exec, const array<C>& diag, const matrix::Dense<C>* alpha,       \
+                         const matrix::Dense<C>* b, const matrix::Dense<C>* beta,                \
+                         matrix::Dense<C>* x)                                                    \
+    {                                                                                            \
+        GKOC_CALL(gkoc_cjacobi_scalar_apply_##TN(                                                \
+            stream_of(exec), rows(x), cols(x), pairs(diag.get_const_data()),                     \
+            pairs(alpha->get_const_values()), pairs(b->get_const_values()), ld(b),               \
+            pairs(beta->get_const_values()), pairs(x->get_values()), ld(x)));                    \
+    }                                                                                            \
+    template <>                                                                                  \
+    void scalar_conj<C>(exec_t exec, const array<C>& diag, array<C>& conj_diag)                  \
+    {                                                                                            \
+        const auto n = static_cast<int64_t>(diag.get_size());                                    \
+        GKOC_CALL(gkoc_cdense_convert_##TN(stream_of(exec), n, 1, diag.get_const_data(), 1,      \
+                                           conj_diag.get_data(), n, 3));                         \
+    }
+FOR_CT(DEF)
+#undef DEF
+
+}  // namespace jacobi
+
+
+namespace coo {
+
+#define DEF(C, TN, I, IN)                                                                        \
+    template <>                                                                                  \
+    void spmv2<C, I>(exec_t exec, const matrix::Coo<C, I>* a, const matrix::Dense<C>* b,         \
+                     matrix::Dense<C>* c)                                                        \
+    {                                                                                            \
+        GKOC_CALL(gkoc_ccoo_spmv2_##TN##_##IN(                                                   \
+            stream_of(exec), static_cast<int64_t>(a->get_num_stored_elements()), cols(b),        \
+            a->get_const_row_idxs(), a->get_const_col_idxs(), pairs(a->get_const_values()),      \
+            nullptr, pairs(b->get_const_values()), ld(b), pairs(c->get_values()), ld(c)));       \
+    }                                                                                            \
+    template <>                                                                                  \
+    void advanced_spmv2<C, I>(exec_t exec, const matrix::Dense<C>* alpha,                        \
+                              const matrix::Coo<C, I>* a, const matrix::Dense<C>* b,             \
+                              matrix::Dense<C>* c)                                               \
+    {                                                                                            \
+        GKOC_CALL(gkoc_ccoo_spmv2_##TN##_##IN(                                                   \
+            stream_of(exec), static_cast<int64_t>(a->get_num_stored_elements()), cols(b),        \
+            a->get_const_row_idxs(), a->get_const_col_idxs(), pairs(a->get_const_values()),      \
+            pairs(alpha->get_const_values()), pairs(b->get_const_values()), ld(b),               \
+            pairs(c->get_values()), ld(c)));                                                     \
+    }                                                                                            \
+    template <>                                                                                  \
+    void spmv<C, I>(exec_t exec, const matrix::Coo<C, I>* a, const matrix::Dense<C>* b,          \
+                    matrix::Dense<C>* c)                                                         \
+    {                                                                                            \
+        dense::fill<C>(exec, c, C{});                                                            \
+        spmv2<C, I>(exec, a, b, c);                                                              \
+    }                                                                                            \
+    template <>                                                                                  \
+    void advanced_spmv<C, I>(exec_t exec, const matrix::Dense<C>* alpha,                         \
+                             const matrix::Coo<C, I>* a, const matrix::Dense<C>* b,              \
+                             const matrix::Dense<C>* beta, matrix::Dense<C>* c)                  \
+    {                                                                                            \
+        dense::scale<C, C>(exec, beta, c);                                                       \
+        advanced_spmv2<C, I>(exec, alpha, a, b, c);                                              \
+    }
+FOR_CT_IT(DEF)
+#undef DEF
+
+}  // namespace coo
 
 
 namespace implicit_residual_norm {

@@ -1222,6 +1222,49 @@ GKOC_DECL_RWAS(double, f64, int32_t, i32)
 GKOC_DECL_RWAS(double, f64, int64_t, i64)
 GKOC_DECL_RWAS(float, f32, int32_t, i32)
 GKOC_DECL_RWAS(float, f32, int64_t, i64)
+/* scalar Jacobi and Diagonal products on complex values: jacobi::{invert_diagonal (a zero entry
+ * inverts as one), simple_scalar_apply, scalar_apply}, diagonal::{apply_to_csr, right_apply_to_csr}
+ * (core/preconditioner/jacobi_kernels.hpp:42-81, core/matrix/diagonal_kernels.hpp:33-43) */
+#define GKOC_DECL_CJAC(P, TN)                                                                          \
+    int gkoc_cjacobi_invert_diagonal_##TN(gkoc_stream_t s, int64_t n, const P* diag, P* inv);          \
+    /* alpha == NULL: x = diag b (row-wise); else x = beta x + alpha b diag */                         \
+    int gkoc_cjacobi_scalar_apply_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* diag,     \
+                                       const P* alpha, const P* b, int64_t ldb, const P* beta, P* x,   \
+                                       int64_t ldx);
+GKOC_DECL_CJAC(gkoc_c128, c128)
+GKOC_DECL_CJAC(gkoc_c64, c64)
+#define GKOC_DECL_CCSR_SCALE(P, TN, I, IN)                                                             \
+    /* mode 0: vals *= diag[row]; 1: vals *= 1 / diag[row]; 2: vals *= diag[col] */                    \
+    int gkoc_ccsr_scale_by_diagonal_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,    \
+                                                const I* col_idxs, const P* diag, int mode, P* vals);
+GKOC_DECL_CCSR_SCALE(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_CCSR_SCALE(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_CCSR_SCALE(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_CCSR_SCALE(gkoc_c64, c64, int64_t, i64)
+/* Coo with complex values (coo::spmv2 / advanced_spmv2; spmv / advanced_spmv clear or scale c
+ * first): c += [alpha] A b entry by entry with atomic adds - the one place where the summation
+ * order is not fixed */
+#define GKOC_DECL_CCOO(P, TN, I, IN)                                                                   \
+    int gkoc_ccoo_spmv2_##TN##_##IN(gkoc_stream_t s, int64_t nnz, int64_t nrhs, const I* rows,         \
+                                    const I* cols, const P* vals, const P* alpha, const P* b,          \
+                                    int64_t ldb, P* c, int64_t ldc);
+GKOC_DECL_CCOO(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_CCOO(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_CCOO(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_CCOO(gkoc_c64, c64, int64_t, i64)
+/* Dense -> Csr with complex values: dense::count_nonzeros_per_row (out: int32 / int64 / uint64 by
+ * out_bytes) and dense::convert_to_csr (row pointers are an input, as for the real types) */
+int gkoc_cdense_count_nonzeros_per_row_c128(gkoc_stream_t s, int64_t rows, int64_t cols,
+                                            const gkoc_c128* in, int64_t ld, void* out, int out_bytes);
+int gkoc_cdense_count_nonzeros_per_row_c64(gkoc_stream_t s, int64_t rows, int64_t cols,
+                                           const gkoc_c64* in, int64_t ld, void* out, int out_bytes);
+#define GKOC_DECL_CDENSE_CSR(P, TN, I, IN)                                                             \
+    int gkoc_cdense_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* in,       \
+                                       int64_t ld, const I* row_ptrs, I* out_cols, P* out_vals);
+GKOC_DECL_CDENSE_CSR(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_CDENSE_CSR(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_CDENSE_CSR(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_CDENSE_CSR(gkoc_c64, c64, int64_t, i64)
 /* csr::sort_by_column_index and csr::transpose for complex values (pairs are only moved; a
  * conj_transpose conjugates them afterwards: gkoc_cdense_convert mode 3 on the n x 1 array) */
 #define GKOC_DECL_CCSR_MOVE(P, TN, I, IN)                                                              \
