@@ -839,6 +839,125 @@ __global__ __launch_bounds__(256) void jacobi_apply_fixed_kernel(
     }
 }
 
+// Several right-hand sides, fast-path layout (one 64-lane group per wave): the single-column
+// kernel's scheme - lane = row of its block, the block's rows in BO registers from coalesced loads,
+// the block's b values by wave shuffle - with the matrix registers reused for every column: a lane
+// loads ITS row's values of a chunk of four columns (one or two 16 B loads: neighbouring lanes,
+// neighbouring rows - the wave's b tile is one contiguous piece when ldb == nrhs), the 8 x 4
+// products per row come from shuffles, and the row's four results leave as one 32 B piece.  The
+// general kernel (jacobi_apply_kernel) re-reads the block per column and gathers b with a stride of
+// ldb values per lane; the matrix-core kernel reads b / x in 16-column fragments that are mostly
+// empty below 16 columns.  Same operations per (row, column) as the single-column kernel: separate
+// multiply and add in column order of the block => bit-identical to it and to the reference.
+template <typename T, typename I, bool ADV, int BO, int PC>
+__global__ __launch_bounds__(256) void jacobi_apply_fixed_multi_kernel(
+    int64_t num_blocks, int64_t num_groups, int64_t group_offset, const I* __restrict__ block_ptrs,
+    const T* __restrict__ blocks, const T* __restrict__ alpha_p, const T* __restrict__ b, int64_t ldb,
+    const T* __restrict__ beta_p, T* __restrict__ x, int64_t ldx, int nrhs, int pairs_ok)
+{
+    static_assert(PC == 4 || PC == 8, "four or eight columns per pass");
+    constexpr int LOG_BO = BO == 1 ? 0 : BO == 2 ? 1 : BO == 4 ? 2 : BO == 8 ? 3 : BO == 16 ? 4 : BO == 32 ? 5 : 6;
+    constexpr int GP = 6 - LOG_BO;  // group_power
+    struct alignas(2 * sizeof(T)) BV {
+        T v[2];
+    };
+    const int lane = threadIdx.x & 63;
+    const int r = lane & (BO - 1);
+    const int lane0 = lane - r;
+    const int64_t group = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (group >= num_groups) return;
+    T alpha = T(1), beta = T(0);
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    const int64_t blk = (group << GP) + (lane >> LOG_BO);
+    I start = 0, end = 0;
+    if (blk < num_blocks) {
+        start = block_ptrs[blk];
+        end = block_ptrs[blk + 1];
+    }
+    const int bs = blk < num_blocks && r < int(end - start) ? int(end - start) : 0;
+    const int64_t row = int64_t(start) + r;
+    T m[BO];
+    const T* gp = blocks + group_offset * group + lane;
+#pragma unroll
+    for (int c = 0; c < BO; ++c) m[c] = bs > 0 ? gp[c * 64] : T(0);
+    // the lane's own row, columns [j0, j0 + PC): values of b, and beta x as the start of the sums
+    auto load = [&](int j0, T(&bv)[PC], T(&sum)[PC]) {
+        const int nc = nrhs - j0 < PC ? nrhs - j0 : PC;
+#pragma unroll
+        for (int q = 0; q < PC; ++q) {
+            bv[q] = T(0);
+            sum[q] = T(0);
+        }
+        if (bs > 0 && nc > 0) {
+            const T* bp = b + row * ldb + j0;
+            const T* xp = x + row * ldx + j0;
+            if (pairs_ok && nc == PC) {
+#pragma unroll
+                for (int q = 0; q < PC; q += 2) {
+                    const BV p = *reinterpret_cast<const BV*>(bp + q);
+                    bv[q] = p.v[0];
+                    bv[q + 1] = p.v[1];
+                    if (ADV && beta != T(0)) {
+                        const BV o = *reinterpret_cast<const BV*>(xp + q);
+                        sum[q] = o.v[0] * beta;
+                        sum[q + 1] = o.v[1] * beta;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < PC; ++q) {
+                    if (q < nc) {
+                        bv[q] = bp[q];
+                        if (ADV && beta != T(0)) sum[q] = xp[q] * beta;
+                    }
+                }
+            }
+        }
+    };
+    T bv[PC], sum[PC], bvn[PC], sumn[PC];
+    load(0, bv, sum);
+    for (int j0 = 0; j0 < nrhs; j0 += PC) {
+        const int nc = nrhs - j0 < PC ? nrhs - j0 : PC;
+        // the next pass's loads travel while this pass's products are formed.  (When b and x are
+        // the same array the next pass reads columns this pass does not write.)
+        load(j0 + PC, bvn, sumn);
+#pragma unroll
+        for (int c = 0; c < BO; ++c) {
+#pragma unroll
+            for (int q = 0; q < PC; ++q) {
+                const T bc = __shfl(bv[q], lane0 + c, 64);
+                const T t = ADV ? (alpha * m[c]) * bc : m[c] * bc;
+                sum[q] = c < bs ? sum[q] + t : sum[q];
+            }
+        }
+        if (bs > 0) {
+            T* xo = x + row * ldx + j0;
+            if (pairs_ok && nc == PC) {
+#pragma unroll
+                for (int q = 0; q < PC; q += 2) {
+                    BV o;
+                    o.v[0] = sum[q];
+                    o.v[1] = sum[q + 1];
+                    *reinterpret_cast<BV*>(xo + q) = o;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < PC; ++q) {
+                    if (q < nc) xo[q] = sum[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PC; ++q) {
+            bv[q] = bvn[q];
+            sum[q] = sumn[q];
+        }
+    }
+}
+
 // cg::step_2 fused with the preconditioner application that follows it in the next iteration
 // (cg.cpp:167-171, then :133-136; one column, unit strides, fast-path layout):
 //   t = rho / beta ;  x += t p ;  r -= t q ;  z = M r ;  partials of <r, z> and <r, r>.
@@ -1268,13 +1387,48 @@ int launch_apply(gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
         GKOC_LAUNCH_OK();
         return GKOC_OK;
     }
+    // GKOC_TUNE_JACOBI_MFMA: 0 never, 1 from two columns, 2 (default) from nine, 3 from four
+    const int64_t mfma_mode = tune_value(GKOC_TUNE_JACOBI_MFMA);
+    const int64_t mfma_from = mfma_mode == 1 ? 2 : mfma_mode == 3 ? 4 : 9;
+    const bool mfma = sizeof(T) == 8 && mfma_mode != 0 && nrhs >= mfma_from && bo == 8 &&
+                      scheme.group_power == 3 && b != x;
+    if (nrhs >= 2 && (bo << scheme.group_power) == 64 && bo <= 16 && !mfma) {
+        // several right-hand sides, fast-path layout: the blocks stay in registers for all columns
+        // (L256, block size 8, profiles/r03_jacobi_multi_256.txt: 2 / 4 / 8 columns 279 / 375 / 630 us =
+        // 72 / 72 / 64 % of 8 TB/s; round 2: 530 / 654 / 778 with the general and the matrix-core
+        // kernel; 16 / 32 columns 1472 / 2974 us against 949 / 1787 on the matrix cores)
+        const int pairs_ok = reinterpret_cast<uintptr_t>(b) % (2 * sizeof(T)) == 0 && ldb % 2 == 0 &&
+                             reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0 && ldx % 2 == 0;
+        const dim3 gm(unsigned(ceildiv(groups, 4)));
+#define GKOC_JAC_MULTI(BO)                                                                        \
+    do {                                                                                          \
+        if (nrhs <= 4) {                                                                          \
+            jacobi_apply_fixed_multi_kernel<T, I, ADV, BO, 4><<<gm, dim3(256), 0, as_stream(s)>>>( \
+                num_blocks, groups, scheme.group_offset, block_ptrs, blocks, alpha, b, ldb, beta, \
+                x, ldx, int(nrhs), pairs_ok);                                                     \
+        } else {                                                                                  \
+            jacobi_apply_fixed_multi_kernel<T, I, ADV, BO, 8><<<gm, dim3(256), 0, as_stream(s)>>>( \
+                num_blocks, groups, scheme.group_offset, block_ptrs, blocks, alpha, b, ldb, beta, \
+                x, ldx, int(nrhs), pairs_ok);                                                     \
+        }                                                                                         \
+    } while (0)
+        switch (int(bo)) {
+        case 1: GKOC_JAC_MULTI(1); break;
+        case 2: GKOC_JAC_MULTI(2); break;
+        case 4: GKOC_JAC_MULTI(4); break;
+        case 8: GKOC_JAC_MULTI(8); break;
+        default: GKOC_JAC_MULTI(16); break;
+        }
+#undef GKOC_JAC_MULTI
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     if constexpr (sizeof(T) == 8) {
         // matrix-core path (fused multiply-adds: ~5e-16 off the reference's bits).  Measured on
         // L256 (profiles/r02_jacobi_mfma_256.txt): 2 columns 603 us against 530 us for the lane =
-        // row kernel, 4: 654 / 1251, 8: 778 / 3779, 16: 987 / 9680 -> from four columns on.
-        const int64_t mode = tune_value(GKOC_TUNE_JACOBI_MFMA);
-        if (mode != 0 && nrhs >= (mode == 1 ? 2 : 4) && bo == 8 && scheme.group_power == 3 &&
-            b != x) {
+        // row kernel, 4: 654 / 1251, 8: 778 / 3779, 16: 987 / 9680; since round 3 the exact
+        // multi-column kernel above serves up to eight columns -> from nine columns on.
+        if (mfma) {
             jacobi_apply_mfma_kernel<I, ADV>
                 <<<dim3(unsigned(ceildiv(groups, 4))), dim3(256), 0, as_stream(s)>>>(
                     num_blocks, groups, scheme.group_offset, block_ptrs, blocks, alpha, b, ldb,

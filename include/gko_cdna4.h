@@ -131,7 +131,8 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
 #define GKOC_TUNE_JACOBI_XCD_MAP 1 /* same for the block-Jacobi apply                     */
 #define GKOC_TUNE_JACOBI_MFMA 3     /* block-Jacobi(8) apply, several right-hand sides, on the f64 matrix cores
                                       (fused multiply-adds: ~5e-16 off the reference's bits): 0 never,
-                                      1 from two columns, 2 (default) from four columns on */
+                                      1 from two columns, 2 (default) from nine columns on (two to eight
+                                      take the exact multi-column kernel), 3 from four columns on */
 #define GKOC_TUNE_COO_FUSED 4       /* coo::spmv, one column: one pass over values, columns and rows with the row
                                       pointers derived while streaming (default 1); 0: row pointers in a pass of
                                       their own, then the CSR kernel */
