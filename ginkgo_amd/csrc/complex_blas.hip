@@ -493,6 +493,12 @@ using namespace gkoc;
         return cx_reduce<R, 2>(s, rows, cols, reinterpret_cast<const cx<R>*>(x), ldx, nullptr, 0, result,   \
                                1);                                                                          \
     }                                                                                                       \
+    extern "C" int gkoc_cdense_compute_sum_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* x,    \
+                                                int64_t ldx, P* result)                                     \
+    {                                                                                                       \
+        return cx_reduce<R, 3>(s, rows, cols, reinterpret_cast<const cx<R>*>(x), ldx, nullptr, 0, result,   \
+                               0);                                                                          \
+    }                                                                                                       \
     extern "C" int gkoc_cdense_compute_mean_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* x,   \
                                                  int64_t ldx, P* result)                                    \
     {                                                                                                       \

@@ -177,17 +177,14 @@ FOR_CT_IT(DEF)
     template <>                                                                                  \
     void reduce_add_array<C>(exec_t exec, const array<C>& arr, array<C>& val)                    \
     {                                                                                            \
-        /* val[0] += sum: the mean of the column times its length would round differently, so    \
-         * the sum goes through the dot product with a column of ones */                         \
         const auto n = static_cast<int64_t>(arr.get_size());                                     \
         array<C> tmp(exec, 2);                                                                   \
-        array<C> ones(exec, arr.get_size() + 1);                                                 \
         const auto s = stream_of(exec);                                                          \
-        GKOC_CALL(gkoc_fill_array_##TN(s, pairs(ones.get_data()), n + 1, P{1, 0}));              \
-        GKOC_CALL(gkoc_cdense_compute_dot_##TN(s, n, 1, pairs(arr.get_const_data()), 1,          \
-                                               pairs(ones.get_const_data()), 1,                  \
-                                               pairs(tmp.get_data()), 0));                       \
-        GKOC_CALL(gkoc_cdense_add_scaled_##TN(s, 1, 1, ones.get_const_data(), 1, 0,              \
+        GKOC_CALL(gkoc_fill_array_##TN(s, pairs(tmp.get_data()) + 1, 1, P{1, 0}));               \
+        GKOC_CALL(gkoc_cdense_compute_sum_##TN(s, n, 1, pairs(arr.get_const_data()), 1,          \
+                                               pairs(tmp.get_data())));                          \
+        /* val[0] += 1 * sum */                                                                  \
+        GKOC_CALL(gkoc_cdense_add_scaled_##TN(s, 1, 1, tmp.get_const_data() + 1, 1, 0,           \
                                               pairs(tmp.get_const_data()), 1,                    \
                                               pairs(val.get_data()), 1));                        \
         exec->synchronize(); /* the temporaries are released on return */                        \

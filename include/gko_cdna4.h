@@ -1171,6 +1171,9 @@ int gkoc_dense_compute_norm2_c64(gkoc_stream_t s, int64_t rows, int64_t cols, co
                                      int conjugate_x);                                                 \
     int gkoc_cdense_compute_squared_norm2_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,            \
                                                const P* x, int64_t ldx, R* result);                    \
+    /* result[j] = sum_i x(i,j) (components::reduce_add_array adds it to its accumulator) */           \
+    int gkoc_cdense_compute_sum_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* x,          \
+                                     int64_t ldx, P* result);                                          \
     int gkoc_cdense_compute_mean_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const P* x,         \
                                       int64_t ldx, P* result);                                         \
     /* mode 0 make_complex (in: reals, out: pairs), 1 get_real, 2 get_imag (in: pairs, out: reals),    \
