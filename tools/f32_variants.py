@@ -1,5 +1,7 @@
-"""f32 / mixed CSR SpMV on the 27-pt 256^3 matrix, variants of entries per lane and load via tuning
-key 2 (development tool)."""
+"""f64 / f32 / mixed CSR SpMV on the 27-pt 256^3 matrix: the load layout of round 3 (GKOC_TUNE_CSR_LOAD_GROUPS
+= 0) against the one of rounds 1-2 (= 1), interleaved repetitions in one process.  (The other variants
+listed in profiles/r03_experiments.txt were instantiated through the same key while they were measured.)
+Development tool."""
 import ctypes as C
 import os
 import sys
@@ -19,7 +21,7 @@ xs = np.random.default_rng(1).uniform(-1, 1, n)
 
 
 def run(op, x, y, tag, nbytes, ref=None):
-    for v in (0, 0, 1, 2, 3, 4, 5, 6, 0, 4, 0):
+    for v in (0, 0, 1, 0, 1, 0, 1):
         assert g._lib.lib().gkoc_tune_set(C.c_int(2), C.c_int64(v)) == 0
         for _ in range(10):
             op.apply(x, y)
