@@ -138,7 +138,7 @@ def main():
         newest = max(os.path.getmtime(o) for o in objs[lib])
         if os.path.exists(out) and os.path.getmtime(out) >= newest:
             continue
-        cmd = [a.cxx, "-shared", "-fPIC", "-o", out,
+        cmd = [a.cxx, "-shared", "-fPIC", "-s", "-o", out,
                f"-Wl,-soname,{LIB_NAME[lib]}", "-Wl,-rpath,$ORIGIN"] + \
             sorted(objs[lib]) + [f"-L{OUT}/lib"] + \
             ["-l" + LIB_NAME[d][3:-3] for d in LIB_DEPS[lib]]

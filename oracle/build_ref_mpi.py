@@ -80,7 +80,7 @@ def main():
         if not os.path.exists(os.path.join(OUT, "lib", so)):
             shutil.copy(os.path.realpath(os.path.join(MPI_ROOT, "lib", so)), os.path.join(OUT, "lib", so))
     out = os.path.join(OUT, "lib", "libginkgo.so")
-    cmd = ["g++", "-shared", "-fPIC", "-o", out, "-Wl,-soname,libginkgo.so",
+    cmd = ["g++", "-shared", "-fPIC", "-s", "-o", out, "-Wl,-soname,libginkgo.so",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../../lib"] + sorted(objs) + \
         [f"-L{REFB}/lib", "-lginkgo_omp", "-lginkgo_cuda", "-lginkgo_reference", "-lginkgo_hip",
          "-lginkgo_dpcpp", "-lginkgo_device", os.path.join(OUT, "lib", "libmpi.so.12"), "-fopenmp"]
@@ -126,7 +126,7 @@ def build_gpu_aware_flavor(ref, objs):
         if not os.path.exists(os.path.join(ga, "lib", so)):
             shutil.copy(os.path.join(OUT, "lib", so), os.path.join(ga, "lib", so))
     out = os.path.join(ga, "lib", "libginkgo.so")
-    cmd = ["g++", "-shared", "-fPIC", "-o", out, "-Wl,-soname,libginkgo.so",
+    cmd = ["g++", "-shared", "-fPIC", "-s", "-o", out, "-Wl,-soname,libginkgo.so",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../../lib"] + sorted(use) + \
         [f"-L{REFB}/lib", "-lginkgo_omp", "-lginkgo_cuda", "-lginkgo_reference", "-lginkgo_hip",
          "-lginkgo_dpcpp", "-lginkgo_device", os.path.join(ga, "lib", "libmpi.so.12"), "-fopenmp"]
