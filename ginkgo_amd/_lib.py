@@ -131,6 +131,18 @@ def call(name, *args):
         _tape.keep.append(args)
 
 
+def bump(counter):
+    """counter.value += 1 (a ctypes integer that is passed by value to later calls), now and
+    again at this point of every replay of the tape being recorded: arguments of recorded calls
+    are fixed, an argument that must count is such an object"""
+    def step():
+        counter.value += 1
+        return 0
+    step()
+    if _tape is not None:
+        _tape.calls.append((step, (), "bump"))
+
+
 VT = {torch.float64: "f64", torch.float32: "f32"}
 IT = {torch.int32: "i32", torch.int64: "i64"}
 

@@ -370,6 +370,19 @@ int gkoc_comm_exchange_join(gkoc_comm_t comm, gkoc_stream_t main_stream)
 
 // MPI_Alltoallv over RCCL: byte counts and byte offsets per peer on both sides, one grouped
 // send / recv on `s`; the part a rank sends to itself is a device copy
+// The consumer of the halo waits for it by itself (gkoc_csr_spmv_gated_* behind a gkoc_gate_open on
+// the side stream): the exchange is over for the communicator, and the main stream does not wait for
+// the side stream.  The next exchange is ordered behind whatever the main stream runs until then by
+// its own fork.
+int gkoc_comm_exchange_forget(gkoc_comm_t comm)
+{
+    GKOC_REQUIRE(comm, GKOC_E_INVALID, "comm == NULL");
+    // (an all-reduce begun with gkoc_comm_all_reduce_begin keeps its own end; one begun TOGETHER with
+    // the exchange - gkoc_comm_all_reduce_exchange_begin - needs gkoc_comm_exchange_join)
+    comm->pending_side = false;
+    return GKOC_OK;
+}
+
 int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* send_buf,
                                  const int64_t* send_bytes, const int64_t* send_offsets, void* recv_buf,
                                  const int64_t* recv_bytes, const int64_t* recv_offsets)

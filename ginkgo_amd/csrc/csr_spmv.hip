@@ -166,6 +166,53 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     return GKOC_OK;
 }
 
+// The distributed product in ONE kernel (csr_spmv_pipe.hpp, GATE): the rank's rows over [local columns
+// | halo], b = [local vector | halo] (unit stride), the rows that read halo entries are the first
+// head_rows and the last tail_rows; gate = three counters in device memory (zero at the start).
+__global__ void gate_open_kernel(uint32_t* gate, uint32_t epoch)
+{
+    __hip_atomic_store(gate, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <typename T, typename I>
+int launch_csr_gated(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const I* row_ptrs, const I* col_idxs,
+                     const T* vals, const T* b, T* c, int64_t head_rows, int64_t tail_rows, const uint32_t* gate,
+                     uint32_t epoch)
+{
+    GKOC_REQUIRE(n_rows > 0 && n_cols >= 0 && head_rows >= 0 && tail_rows >= 0 &&
+                     head_rows + tail_rows <= n_rows,
+                 GKOC_E_INVALID, "bad dimensions");
+    GKOC_REQUIRE(row_ptrs && col_idxs && vals && b && c && gate, GKOC_E_INVALID, "null pointer");
+    constexpr int EV = 32 / sizeof(T);
+    constexpr int RINGV = 8192 / sizeof(T);
+    GKOC_REQUIRE(reinterpret_cast<uintptr_t>(vals) % (EV * sizeof(T)) == 0 &&
+                     reinterpret_cast<uintptr_t>(col_idxs) % (EV * sizeof(I)) == 0,
+                 GKOC_E_NOT_SUPPORTED, "values / column indices not aligned for vector loads");
+    const int64_t n_seg = ceildiv(n_rows, 64);
+    GKOC_REQUIRE(n_seg < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 row segments");
+    int64_t head_segs = ceildiv(head_rows, 64);
+    int64_t tail_segs = tail_rows > 0 ? n_seg - (n_rows - tail_rows) / 64 : 0;
+    if (head_segs + tail_segs > n_seg) {   // every segment reads halo entries
+        head_segs = n_seg;
+        tail_segs = 0;
+    }
+    GKOC_REQUIRE(head_segs + tail_segs > 0, GKOC_E_INVALID, "no boundary rows: use gkoc_csr_spmv_*");
+    const dim3 grid(static_cast<unsigned>(n_seg)), block(64);
+    constexpr int PE = sizeof(T) == 8 ? 2 : 4, PU = sizeof(T) == 8 ? 3 : 2;
+#define GKOC_LAUNCH_GATED(E_, U_)                                                                 \
+    csr_spmv_pipe3_kernel<T, I, false, 64, E_, U_, RINGV, 1, 0x11000><<<grid, block, 0, as_stream(s)>>>( \
+        n_rows, n_seg, 1, row_ptrs, col_idxs, vals, b, 1, c, 1, 1, nullptr, nullptr, nullptr, 0,  \
+        nullptr, nullptr, head_segs, tail_segs, gate, epoch)
+    if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_seg < 32768) {
+        GKOC_LAUNCH_GATED(EV, 1);
+    } else {
+        GKOC_LAUNCH_GATED(PE, PU);
+    }
+#undef GKOC_LAUNCH_GATED
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
 // Mixed precision: values stored as V (float), vectors and arithmetic T (double).  8 instead of
 // 12 bytes per stored entry; the result has the bits of the T kernel on the widened values.
 // Columns one after the other (the matrix is streamed once per column).
@@ -507,6 +554,29 @@ GKOC_DEF_CSR_SORT(gkoc_c128, c128, int32_t, i32)
 GKOC_DEF_CSR_SORT(gkoc_c128, c128, int64_t, i64)
 GKOC_DEF_CSR_SORT(gkoc_c64, c64, int32_t, i32)
 GKOC_DEF_CSR_SORT(gkoc_c64, c64, int64_t, i64)
+
+#define GKOC_DEF_CSR_GATED(T, TN, I, IN)                                                             \
+    extern "C" int gkoc_csr_spmv_gated_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,   \
+                                                   const I* row_ptrs, const I* col_idxs,              \
+                                                   const T* vals, const T* b, T* c,                   \
+                                                   int64_t head_rows, int64_t tail_rows,              \
+                                                   const uint32_t* gate, uint32_t epoch)              \
+    {                                                                                                 \
+        return launch_csr_gated<T, I>(s, n_rows, n_cols, row_ptrs, col_idxs, vals, b, c, head_rows,   \
+                                      tail_rows, gate, epoch);                                        \
+    }
+GKOC_DEF_CSR_GATED(double, f64, int32_t, i32)
+GKOC_DEF_CSR_GATED(double, f64, int64_t, i64)
+GKOC_DEF_CSR_GATED(float, f32, int32_t, i32)
+GKOC_DEF_CSR_GATED(float, f32, int64_t, i64)
+
+extern "C" int gkoc_gate_open(gkoc_stream_t s, uint32_t* gate, uint32_t epoch)
+{
+    GKOC_REQUIRE(gate, GKOC_E_INVALID, "gate == NULL");
+    gkoc::gate_open_kernel<<<dim3(1), dim3(1), 0, as_stream(s)>>>(gate, epoch);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
 
 #define GKOC_DEF_CSR_MIXED(I, IN)                                                                  \
     extern "C" int gkoc_csr_spmv_f32_f64_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,     \

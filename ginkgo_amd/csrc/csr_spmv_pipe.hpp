@@ -54,7 +54,8 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
     const T* __restrict__ beta_p, T* __restrict__ dot_partial = nullptr,
     int xcd_map = 0, const I* __restrict__ row_idxs = nullptr,
-    int* __restrict__ unsorted_flag = nullptr)
+    int* __restrict__ unsorted_flag = nullptr, int64_t head_segs = 0, int64_t tail_segs = 0,
+    const uint32_t* __restrict__ gate = nullptr, uint32_t gate_epoch = 0)
 {
     static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
     constexpr int G = 64 * E * U;
@@ -105,6 +106,44 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
         const int64_t nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
         const int64_t xcd = wave_id & 7, slot = wave_id >> 3;
         wave_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    // GATE = ABL & 0x10000 (distributed product, one segment per wave): the matrix holds a rank's
+    // rows over [local columns | halo] and b is the local vector with the halo BEHIND it; the first
+    // head_segs and the last tail_segs row segments read halo entries.  They are given to the LAST
+    // waves of the grid, and those wait - every wave for itself - until the exchange, which travels
+    // on another stream while the interior rows are computed, has delivered the halo: *gate holds
+    // the number of the last exchange that has arrived (gkoc_gate_open on the exchange's stream),
+    // gate_epoch is the number of the exchange this product needs (the caller counts).  No second
+    // kernel beside this one, no event the stream waits for, no atomic read-modify-write (2048
+    // same-address atomics of the boundary waves cost 15 us when tried): by the time the last waves
+    // start the halo has long arrived, and a wave that does have to wait polls with s_sleep (after
+    // ~10 s it gives up, sets gate[1] and goes on with whatever the halo holds: the caller checks).  Nothing has read the halo since the launch,
+    // so no cache holds an old line of it.
+    constexpr bool GATE = (ABL & 0x10000) != 0;
+    if constexpr (GATE) {
+        const int64_t n_int = n_segments - head_segs - tail_segs;
+        if (wave_id >= n_int) {
+            const int64_t jb = wave_id - n_int;
+            wave_id = jb < head_segs ? jb : n_segments - tail_segs + (jb - head_segs);
+            if (lane == 0) {
+                bool waited = false;
+                long spins = 0;
+                while (int32_t(__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) -
+                               gate_epoch) < 0) {
+                    __builtin_amdgcn_s_sleep(32);
+                    waited = true;
+                    if (++spins > (long(1) << 23)) {   // ~10 s: give up, say so, go on (the caller checks gate[1])
+                        __hip_atomic_store(const_cast<uint32_t*>(gate) + 1, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+                if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            wave_id += head_segs;
+        }
     }
     const int64_t sb = wave_id * segs_per_wave;
     const int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;

@@ -18,12 +18,13 @@ touched; the matrix is generated and split on the device.
 logic under gloo.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from ._lib import IT, VT, GkoError, call, lib
+from ._lib import IT, VT, GkoError, bump, call, lib
 from ._lib import record as _record
 from .executor import MEM_INDICES, MEM_VALUES
 from .matrix import Csr, Dense, scalar, stencil_csr
@@ -249,6 +250,11 @@ class RcclComm(TorchComm):
     def exchange_join(self):
         """exchange_end that also waits for the kernels enqueued on the side stream behind the halo"""
         call("gkoc_comm_exchange_join", self._handle, self.exec.stream)
+
+    def exchange_forget(self):
+        """ends an exchange without a wait on the executor's stream: the reader of the halo waits
+        for it itself (HipBackend.gate_open / spmv_gated)"""
+        call("gkoc_comm_exchange_forget", self._handle)
 
     def all_to_all_v(self, recv, send, recv_counts, send_counts, async_op=False):
         if self.size == 1 or not send.is_cuda or not send.dtype.is_floating_point:
@@ -494,6 +500,18 @@ class HipBackend:
                      a.col_idxs, a.values, col_lo, col_hi, col_map, f_ptrs, f_cols, f_vals)
                 nl["full"] = dict(ptrs=f_ptrs, cols=f_cols, vals=f_vals, n_local=col_hi - col_lo,
                                   interior=(len(head), n - len(tail)))
+                # ... and ALL rows once more over [local columns | halo] for the product in one
+                # kernel (gkoc_csr_spmv_gated_*): b is then the local vector with the halo behind it
+                if os.environ.get("GKO_GATED_SPMV", "1") != "0":
+                    all_rows = torch.arange(n, dtype=idt, device=a.row_ptrs.device)
+                    e_cols = ex.alloc((a.col_idxs.numel(),), idt, MEM_INDICES)
+                    e_vals = ex.alloc((a.values.numel(),), a.dtype, MEM_VALUES)
+                    call(f"gkoc_dist_boundary_fill_{vt}_{it}", ex.stream, n, all_rows, a.row_ptrs,
+                         a.col_idxs, a.values, col_lo, col_hi, col_map, a.row_ptrs, e_cols, e_vals)
+                    e_ptrs = ex.alloc((n + 1,), idt, MEM_INDICES)
+                    e_ptrs.copy_(a.row_ptrs)
+                    nl["ext"] = dict(ptrs=e_ptrs, cols=e_cols, vals=e_vals, head=len(head), tail=len(tail),
+                                     n_cols=(col_hi - col_lo) + n_halo)
         return local, nl, recv_gidx
 
     def to_host(self, t):
@@ -532,6 +550,23 @@ class HipBackend:
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self.exec.stream
         call("gkoc_csr_rowlist_spmv_full_" + nl["suffix"], st, nl["n"], nl["rows"], f["ptrs"],
              f["cols"], f["vals"], f["n_local"], x.values, halo.values, y.values)
+
+    def gate_new(self):
+        """the word of gkoc_csr_spmv_gated_* / gkoc_gate_open (device) and the exchange count (host)"""
+        return self.exec.zeros((2,), torch.int32), C.c_uint32(0)
+
+    def gate_open(self, stream, gate):
+        """on `stream` (the exchange's stream): the halo in front of this call has arrived; counts
+        the exchange (also in replays of a recorded iteration)"""
+        bump(gate[1])
+        call("gkoc_gate_open", C.c_void_p(stream.cuda_stream), gate[0], gate[1])
+
+    def spmv_gated(self, nl, x_ext, y, gate):
+        """y = A [x | halo] for ALL local rows in one kernel; x_ext: the local vector with the halo
+        behind it; the boundary rows wait for the gate_open in front of this call"""
+        e = nl["ext"]
+        call("gkoc_csr_spmv_gated_" + nl["suffix"], self.exec.stream, y.size[0], e["n_cols"], e["ptrs"],
+             e["cols"], e["vals"], x_ext, y.values, e["head"], e["tail"], gate[0], gate[1])
 
     def spmv_dot(self, a, x, y, out):
         """y = A_local x and out = local <x, y> in one pass; False if there is no such kernel
@@ -811,6 +846,35 @@ class DistributedMatrix:
         # local SpMV) or, GKO_FULL_BOUNDARY=0, the round-2 form: whole local block, then
         # boundary rows += halo part
         self.use_full_boundary = os.environ.get("GKO_FULL_BOUNDARY", "1") != "0"
+        # the whole product in ONE kernel whose last waves (the boundary rows) wait for the halo by
+        # themselves: for vectors from ext_vector() (the solvers' search directions), a
+        # device-resident communicator and zero-copy send planes
+        self._gate = (backend.gate_new() if "ext" in self.nl and hasattr(backend, "spmv_gated") and
+                      self._side is not None and getattr(comm, "direct", False) and
+                      hasattr(comm, "exchange_forget") and self.send_displs is not None else None)
+
+    def ext_vector(self):
+        """a zero local vector whose storage continues with room for the halo: apply() of such a
+        vector receives the halo right behind it and runs as one kernel (gkoc_csr_spmv_gated_*).
+        An ordinary vector where that path does not exist."""
+        be = self.backend
+        if self._gate is None:
+            return be.vector(self.n_local, self.dtype)
+        store = be.exec.zeros((self.n_local + max(self.n_halo, 1),), self.dtype)
+        v = Dense(be.exec, store[:self.n_local].view(self.n_local, 1))
+        v._ext_store, v._ext_halo = store, store[self.n_local:self.n_local + self.n_halo]
+        return v
+
+    def check_gate(self):
+        """raises if a boundary wave of the one-kernel product ever gave up waiting for its halo
+        (synchronises; the solvers call it when they return)"""
+        if self._gate is not None and int(self._gate[0][1].item()) != 0:
+            raise GkoError("DistributedMatrix: the halo exchange did not arrive within the one-kernel "
+                           "product's patience (GKO_GATED_SPMV=0 selects the join-based product)")
+
+    def _gated(self, x, y):
+        return (self._gate is not None and getattr(x, "_ext_halo", None) is not None and
+                x.ld == 1 and y.ld == 1 and x.size[1] == 1 and self.use_full_boundary)
 
     def apply_dot(self, x, y, out):
         """y_local = A[owned rows, :] x and out = LOCAL part of <x, y> (the caller all-reduces):
@@ -838,13 +902,21 @@ class DistributedMatrix:
     def begin_exchange_with_reduce(self, x, t):
         """start the all-reduce of t and the halo exchange of x on the side stream behind one
         fork; apply(x, y, started=True) must follow (its join ends both)"""
-        self.comm.all_reduce_exchange_begin(t, self.recv_buf.values, x.values, self.recv_counts,
+        recv = x._ext_halo if getattr(x, "_ext_halo", None) is not None and self._gate is not None \
+            else self.recv_buf.values
+        self.comm.all_reduce_exchange_begin(t, recv, x.values, self.recv_counts,
                                             self.send_counts, self._side, self.send_displs)
 
     def apply(self, x, y, dot_out=None, started=False):
         """y_local = A[owned rows, :] x   (x, y: local parts, n_local x 1); started: the halo
         exchange of x is already under way (begin_exchange_with_reduce)"""
         be, comm = self.backend, self.comm
+        if started and self._gated(x, y):
+            # (the all-reduce that was started with the exchange still ends with the join)
+            be.gate_open(self._side, self._gate)
+            be.spmv_gated(self.nl, x._ext_store, y, self._gate)
+            comm.exchange_join()
+            return y
         if started:
             full = self.nl.get("full") if (self.use_full_boundary and hasattr(be, "rowlist_full")) else None
             if full is not None:
@@ -855,6 +927,13 @@ class DistributedMatrix:
                 be.spmv(self.local, x, y)
                 comm.exchange_join()
                 be.rowlist_add(self.nl, self.recv_buf, y)
+            return y
+        if dot_out is None and comm.size > 1 and self._gated(x, y):
+            comm.exchange_begin(x._ext_halo, x.values, self.recv_counts, self.send_counts, self._side,
+                                self.send_displs)
+            be.gate_open(self._side, self._gate)
+            be.spmv_gated(self.nl, x._ext_store, y, self._gate)
+            comm.exchange_forget()
             return y
         if dot_out is not None:
             local_spmv = lambda: be.spmv_dot(self.local, x, y, dot_out)
@@ -955,6 +1034,8 @@ class DistributedCg:
         self.fused = bool(fused)
         n, dt = matrix.n_local, matrix.dtype
         self.r, self.z, self.p, self.q = (backend.vector(n, dt) for _ in range(4))
+        if hasattr(matrix, "ext_vector"):
+            self.p = matrix.ext_vector()     # the SpMV's input: halo room behind it (one-kernel product)
         self.beta, self.tau0 = backend.vector(1, dt), backend.vector(1, dt)
         # [rho, ||r||^2] pairs; the two pairs swap roles as rho / prev_rho
         self.pair_a = backend.scalar_pair(dt)
@@ -1071,6 +1152,8 @@ class DistributedCg:
             have_sq = run(("b", parity), seg_b, cur, prev)
             cur, prev = prev, cur
         self.num_iterations = it
+        if hasattr(self.a, "check_gate"):
+            self.a.check_gate()
         return x
 
 
@@ -1108,6 +1191,8 @@ class DistributedPipeCg:
         n, dt = matrix.n_local, matrix.dtype
         (self.r, self.w, self.z, self.p, self.m, self.n, self.q, self.f, self.g) = (
             backend.vector(n, dt) for _ in range(9))
+        if hasattr(matrix, "ext_vector"):
+            self.m = matrix.ext_vector()     # the SpMV's input: halo room behind it (one-kernel product)
         self.beta, self.tau0 = backend.vector(1, dt), backend.vector(1, dt)
         self.beta2 = backend.vector(1, dt)     # the fused step_2 + step_1 reads one beta and writes the other
         # [rho, delta, ||r||^2]; the two triples swap roles as (rho, prev_rho)
@@ -1264,6 +1349,8 @@ class DistributedPipeCg:
                     break
                 run(("t", parity), tail, cur, prev, betas[parity], betas[1 - parity])
             self.num_iterations = it
+            if hasattr(self.a, "check_gate"):
+                self.a.check_gate()
             return x
 
         while True:
@@ -1283,6 +1370,8 @@ class DistributedPipeCg:
                 break
             run(("t", parity), seg_step2, cur, prev)
         self.num_iterations = it
+        if hasattr(self.a, "check_gate"):
+            self.a.check_gate()
         return x
 
 
@@ -1354,6 +1443,11 @@ class DistributedStencil:
     def random_vector(self, seed):
         lo, hi = self.part.range_of(self.rank)
         full = np.random.default_rng(seed).uniform(-1, 1, self.part.n_global)
+        if hasattr(self.matrix, "ext_vector"):
+            # halo room behind the vector: its products run as one kernel (DistributedMatrix.apply)
+            v = self.matrix.ext_vector()
+            v.values.copy_(torch.from_numpy(np.ascontiguousarray(full[lo:hi])).view(-1, 1))
+            return v
         return Dense.from_numpy(self.exec, full[lo:hi])
 
     def zeros_vector(self):

@@ -848,6 +848,26 @@ GKOC_DECL_DIST_IDX(int64_t, i64)
  * that row - the single-domain row sum bit for bit.  These rows need nothing from the local
  * SpMV: that one is launched over the interior row range only, and this kernel runs on the
  * exchange's stream right behind the halo, overlapped with it (gkoc_comm_exchange_join). */
+/* The distributed product in ONE kernel: the rank's rows as a CSR over [local columns | halo]
+ * (gkoc_dist_boundary_fill_* over all rows), b = the local vector with the halo BEHIND it in the
+ * same array (unit stride), c the local result.  The rows that read halo entries - the first
+ * head_rows and the last tail_rows - are computed by the last waves of the grid, which wait for
+ * gkoc_gate_open(.., epoch) (enqueued on the exchange's stream behind the transfer that fills b's halo
+ * part): no second kernel beside the local SpMV and no event its stream waits for.  gate: two uint32
+ * in device memory, zero at the start (gate[0] the number of the last exchange that arrived, gate[1]
+ * set to 1 by a wave that waited ~10 s in vain - the result is then undefined, check it); epoch: the number of the exchange (1, 2, ... - the caller
+ * counts; the product with the same number waits for it).  Results: complete rows in the original
+ * column order = the single-domain bits. */
+#define GKOC_DECL_CSR_GATED(T, TN, I, IN)                                                              \
+    int gkoc_csr_spmv_gated_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,               \
+                                        const I* row_ptrs, const I* col_idxs, const T* vals,           \
+                                        const T* b, T* c, int64_t head_rows, int64_t tail_rows,        \
+                                        const uint32_t* gate, uint32_t epoch);
+GKOC_DECL_CSR_GATED(double, f64, int32_t, i32)
+GKOC_DECL_CSR_GATED(double, f64, int64_t, i64)
+GKOC_DECL_CSR_GATED(float, f32, int32_t, i32)
+GKOC_DECL_CSR_GATED(float, f32, int64_t, i64)
+int gkoc_gate_open(gkoc_stream_t s, uint32_t* gate, uint32_t epoch);
 #define GKOC_DECL_DIST_BND_IDX(I, IN)                                          \
     int gkoc_dist_boundary_count_##IN(gkoc_stream_t s, int64_t n_list,         \
                                       const I* rows, const I* row_ptrs,        \
@@ -1866,6 +1886,9 @@ int gkoc_comm_all_reduce_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_str
 /* the same, but main_stream also waits for the kernels enqueued on the exchange's stream since
  * gkoc_comm_exchange_begin (the boundary rows, computed there as soon as the halo is in) */
 int gkoc_comm_exchange_join(gkoc_comm_t comm, gkoc_stream_t main_stream);
+/* ends an exchange WITHOUT making the main stream wait: the kernel that reads the halo waits for
+ * it itself (gkoc_gate_open on the side stream + gkoc_csr_spmv_gated_*) */
+int gkoc_comm_exchange_forget(gkoc_comm_t comm);
 /* MPI_Alltoallv (mpi.hpp all_to_all_v / i_all_to_all_v) in bytes: counts and offsets per peer on
  * both sides, enqueued on s as one grouped send / recv */
 int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* send_buf,

@@ -78,6 +78,9 @@ class FakeComm:
         ev.record(self._side)
         torch.cuda.current_stream().wait_event(ev)
 
+    def exchange_forget(self):
+        pass
+
     def all_to_all_v(self, recv, send, recv_counts, send_counts, async_op=False):
         if recv.dtype == torch.int64:
             # peers ask for the planes next to the ones we ask them for
@@ -170,3 +173,12 @@ if "full" in a.nl:
     tm("complete boundary rows over [x | halo]", lambda: be.rowlist_full(a.nl, x, a.recv_buf, y))
 tm("copy 'exchange' alone", lambda: a.recv_buf.values.copy_(a.send_buf.values))
 tm("whole distributed apply", lambda: a.apply(x, y))
+if a._gate is not None:
+    xe = a.ext_vector()
+    xe.values.copy_(x.values)
+    tm("whole distributed apply, one-kernel product", lambda: a.apply(xe, y))
+    y1 = y.values.clone()
+    a.apply(x, y)
+    torch.cuda.synchronize()
+    print("   one-kernel product == join-based product bit for bit:", bool(torch.equal(y1, y.values)))
+    a.check_gate()
