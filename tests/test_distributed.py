@@ -213,6 +213,46 @@ def test_overlap_branch_with_mirror_comm(gexec, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("grid,world,rank", [(12, 3, 1), (16, 2, 0), (9, 3, 2), (20, 4, 2)])
+def test_one_kernel_product_has_the_single_domain_bits(gexec, oracle, grid, world, rank):
+    """gkoc_csr_spmv_gated_* (the rank's rows over [local columns | halo], b = the local vector
+    with the halo behind it, the boundary segments computed by the last waves of the grid behind
+    a gate): every row equals the single-domain product bit for bit - interior ranks (halo on both
+    sides), first and last rank, planes that are not multiples of the 64-row segments - and the
+    gate counts across repeated products."""
+    import torch
+    import ginkgo_amd as g
+    import ginkgo_amd.distributed as gd
+
+    n = grid ** 3
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    part = gd.SlabPartition(grid, world)
+    lo, hi = part.range_of(rank)
+    z0, z1 = part.plane_offsets[rank], part.plane_offsets[rank + 1]
+    owned = g.stencil_csr(gexec, 3, grid, z0=z0, nz=z1 - z0)
+    be = gd.HipBackend(gexec)
+    local, nl, recv_gidx = be.split(owned, lo, hi, n)
+    assert "ext" in nl and nl["ext"]["n_cols"] == (hi - lo) + recv_gidx.numel()
+    xg = np.random.default_rng(grid + rank).uniform(-1, 1, n)
+    ref = oracle.csr_spmv(rp, ci, v, xg)[lo:hi]
+    store = gexec.zeros((nl["ext"]["n_cols"],), torch.float64)
+    store[:hi - lo] = torch.from_numpy(xg[lo:hi]).to(store.device)
+    y = be.vector(hi - lo)
+    gate = be.gate_new()
+    halo = torch.from_numpy(xg[recv_gidx.cpu().numpy().astype(np.int64)]).to(store.device)
+    for rep in range(3):
+        store[hi - lo:] = halo if rep != 1 else 0.0      # rep 1: a wrong halo must show
+        be.gate_open(torch.cuda.current_stream(), gate)   # the "exchange" is done: same stream, in front
+        be.spmv_gated(nl, store, y, gate)
+        got = y.to_numpy()[:, 0]
+        if rep == 1 and recv_gidx.numel():
+            assert not np.array_equal(got, ref)
+        else:
+            assert np.array_equal(got, ref), rep
+    assert int(gate[0][0].item()) == 3 and int(gate[0][1].item()) == 0 and gate[1].value == 3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("how", ["torch", "direct"])
 def test_collectives_through_rccl_one_rank(how):
     """the same mirror construction with every collective issued through RCCL on the
