@@ -73,3 +73,23 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.replace("INTEGRATION", ""), \
                     f"{os.path.join(dirpath, f)} mentions the oracle"
+
+
+def test_counting_arguments_survive_the_call_tape():
+    """host logic of ginkgo_amd._lib: the arguments of recorded calls are fixed, an argument that has
+    to count (the exchange number of the one-kernel distributed product) is a ctypes integer that
+    bump() increments - now and at the same point of every replay"""
+    import ctypes as C
+    from ginkgo_amd import _lib
+    c = C.c_uint32(0)
+    seen = []
+    with _lib.record() as tape:
+        _lib.bump(c)
+        tape.calls.append((lambda v: seen.append(v.value) or 0, (c,), "observe"))   # a "call" taking c
+        _lib.bump(c)
+    assert c.value == 2 and [name for _, _, name in tape.calls] == ["bump", "observe", "bump"]
+    tape.replay()
+    tape.replay()
+    assert c.value == 6 and seen == [3, 5]
+    _lib.bump(c)                      # outside a recording: just counts
+    assert c.value == 7
