@@ -851,7 +851,8 @@ class DistributedMatrix:
         # device-resident communicator and zero-copy send planes
         self._gate = (backend.gate_new() if "ext" in self.nl and hasattr(backend, "spmv_gated") and
                       self._side is not None and getattr(comm, "direct", False) and
-                      hasattr(comm, "exchange_forget") and self.send_displs is not None else None)
+                      hasattr(comm, "exchange_forget") and self.send_displs is not None and
+                      self.use_full_boundary else None)
 
     def ext_vector(self):
         """a zero local vector whose storage continues with room for the halo: apply() of such a
