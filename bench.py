@@ -228,6 +228,19 @@ def ginkgo_api_bench(grid, steps, cg_iters):
     return out
 
 
+def self_launch(n):
+    """re-run this command line under torch.distributed.run --nproc-per-node n"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,6 +272,10 @@ def main():
         return cpu_baseline_child(int(args.cpu_baseline_child[0]), float(args.cpu_baseline_child[1]))
     if args.arena is not None:
         os.environ["GKOC_ARENA"] = str(args.arena)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, the way the
+        # driver does (one process per GPU, rendezvous on 127.0.0.1); rank 0 prints the line
+        return self_launch(args.gpus)
 
     # stdout carries exactly one line, the JSON result: everything else written to
     # file descriptor 1 by this process (RCCL prints a version banner there from C
@@ -276,7 +293,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}; launch "
-                         "with torch.distributed.run --nproc-per-node N")
+                         "with torch.distributed.run --nproc-per-node N (or without a launcher: "
+                         "bench.py starts its own ranks)")
     # one rank per GPU over RCCL.  GKO_BENCH_BACKEND=gloo (ranks may then share a
     # device, halo/all-reduce staged through the host) exists only to exercise
     # this N > 1 code path on a single-GPU box; its numbers mean nothing.
@@ -413,6 +431,16 @@ def main():
             else:
                 cg.setdefault("pipe_cg_error", "failed on another rank")
 
+    # every rank's kernel time and what its allocator found (N > 1: a slow rank explains itself)
+    per_rank = None
+    if use_dist:
+        ai = ex.arena_info()
+        mine = torch.tensor([kernel_ms, float(ai["num_classes"]), ai["search_ns"] / 1e6,
+                             float(ai["granules_walked"])], dtype=torch.float64, device=ex.device)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [[round(float(v), 4) for v in t.tolist()] for t in gathered]
+
     if rank == 0:
         per_gpu_bytes = total_bytes / world
         achieved = per_gpu_bytes / (kernel_ms * 1e-3) / 1e9
@@ -463,39 +491,67 @@ def main():
         if use_dist:
             out["comm_check"] = comm_check
             out["rank0_profile"] = dist_profile
+            out["roofline"]["per_rank"] = [
+                {"rank": r, "kernel_ms": v[0],
+                 "achieved": round(per_gpu_bytes / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None,
+                 "frac": round(per_gpu_bytes / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 else None,
+                 "memory_classes_found": int(v[1]), "search_ms": v[2], "granules_walked": int(v[3])}
+                for r, v in enumerate(per_rank)]
+            out["roofline"]["traffic_note"] = ("counters are collected at N = 1 only (a rocprofv3 --pmc pass "
+                                               "per counter group over a child run)")
+        info = ex.arena_info()
+        placement = {
+            "note": "device allocator of the library (csrc/arena.hip): one region per memory "
+                    "class of the MI355X, found by ONE galloping walk over 1 GiB granules whose "
+                    "class is measured by a probe; nothing tuned per run",
+            "arena_mode": info["mode"], "memory_classes_found": info["num_classes"],
+            "reserved_gib": round(info["reserved_bytes"] / 2 ** 30, 2),
+            "used_gib": round(info["used_bytes"] / 2 ** 30, 2),
+            "spare_gib": round(info["spare_bytes"] / 2 ** 30, 2),
+            "granules_walked": info["granules_walked"],
+            "granules_classified": info["granules_classified"],
+            "probe_launches": info["probes"], "probe_retries": info["probe_retries"],
+            "search_ms": round(info["search_ns"] / 1e6, 1)}
         if not use_dist:
-            import ctypes as C
-            from ginkgo_amd import _lib
-
-            class ArenaInfo(C.Structure):
-                _fields_ = [("mode", C.c_int32), ("num_classes", C.c_int32),
-                            ("chunk_bytes", C.c_int64), ("num_chunks", C.c_int64),
-                            ("reserved_bytes", C.c_int64), ("used_bytes", C.c_int64),
-                            ("num_allocations", C.c_int64), ("probes", C.c_int64),
-                            ("granules_walked", C.c_int64), ("spare_bytes", C.c_int64),
-                            ("class_reserved_bytes", C.c_int64 * 3),
-                            ("class_used_bytes", C.c_int64 * 3)]
-            info = ArenaInfo()
-            _lib.call("gkoc_arena_stats", C.byref(info))
-            out["placement"] = {
-                "note": "device allocator of the library (csrc/arena.hip): one region per memory "
-                        "class of the MI355X, class of every 1 GiB granule measured by a probe; "
-                        "nothing tuned per run",
-                "arena_mode": info.mode, "memory_classes_found": info.num_classes,
-                "class_of": {"values": ex.memory_class(a.values), "col_idxs": ex.memory_class(a.col_idxs),
-                             "row_ptrs": ex.memory_class(a.row_ptrs), "x": ex.memory_class(x.values),
-                             "y": ex.memory_class(y.values)},
-                "reserved_gib": round(info.reserved_bytes / 2 ** 30, 2),
-                "used_gib": round(info.used_bytes / 2 ** 30, 2),
-                "spare_gib": round(info.spare_bytes / 2 ** 30, 2),
-                "granules_walked": info.granules_walked, "probe_launches": info.probes}
+            placement["class_of"] = {"values": ex.memory_class(a.values), "col_idxs": ex.memory_class(a.col_idxs),
+                                     "row_ptrs": ex.memory_class(a.row_ptrs), "x": ex.memory_class(x.values),
+                                     "y": ex.memory_class(y.values)}
+        else:
+            placement["class_of"] = getattr(op.backend, "placement_log", None)
+        out["placement"] = placement
+        # a slow line must explain itself: the classes belong to the configuration
+        out["config"]["memory_classes_found"] = info["num_classes"]
+        out["config"]["class_of"] = placement["class_of"]
         if not args.no_ginkgo_api and not use_dist:
             torch.cuda.synchronize()
             api = ginkgo_api_bench(grid, args.steps, args.cg_iters if args.cg_iters > 0 else 20)
             if api is not None:
                 out["ginkgo_api"] = api
+        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gko_bench_cpu_baseline_{grid}.json")
         if not args.no_cpu and not use_dist:
             out["cpu_baseline"] = cpu_baseline(args.cpu_grid or grid)
+            try:
+                json.dump(out["cpu_baseline"], open(cache, "w"))
+            except OSError:
+                pass
+        elif use_dist:
+            # no CPU twin at N > 1 (the baseline is one host running the whole problem): the N = 1
+            # figure is carried - this host's, if an N = 1 run left it here, else the committed one
+            base, src = None, None
+            for path, what in ((cache, "the N = 1 run of this script on this host"),
+                               (os.path.join(ROOT, "profiles", "bench_line_latest.json"),
+                                "the committed N = 1 line profiles/bench_line_latest.json (another box)")):
+                try:
+                    d = json.load(open(path))
+                    base, src = d.get("cpu_baseline", d), what
+                    break
+                except (OSError, ValueError):
+                    continue
+            if base is not None and "value" in base:
+                out["cpu_baseline"] = dict(base, note=f"no CPU twin at N > 1; carried from {src}")
+            else:
+                out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": None, "kind": None,
+                                       "sample": None, "note": "no CPU twin at N > 1 and no N = 1 figure at hand"}
         result_out.write(json.dumps(out) + "\n")
         result_out.flush()
     if use_dist:

@@ -51,6 +51,7 @@
 // it arena memory must not be handed to P2P copies or hipIpc (RCCL stages user buffers through
 // its own, so the distributed path does not need it).
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <map>
 #include <string>
@@ -161,7 +162,8 @@ struct device_arena {
     // to WRITE as vectors (gkoc_arena_note_vector), newest last, a handful at most
     std::vector<size_t> vector_sizes;
     int64_t misplaced = 0;        // gkoc_arena_note_vector found a written vector next to matrix arrays
-    int64_t probes = 0, walked = 0;
+    int64_t probes = 0, walked = 0, classified = 0, search_ns = 0, retried = 0;
+    bool surveyed = false;        // the one search for all three classes has run (survey_classes)
 };
 
 std::mutex g_mtx;
@@ -171,7 +173,8 @@ size_t g_granule_bytes = 0, g_spare_bytes = 0;
 int g_sync_free = 1;
 int g_verbose = 0;
 int g_peer_access = 0;
-int g_max_walk = 128;
+int g_max_walk = 0;         // granules one search may create; 0 = bounded by the free memory only
+int g_max_classes = 3;      // GKOC_ARENA_MAX_CLASSES: stop the survey at fewer classes (tests)
 bool g_mode_from_env = false;
 device_arena g_arena[64];
 
@@ -193,8 +196,11 @@ void read_env_locked()
     const char* pa = std::getenv("GKOC_ARENA_PEER_ACCESS");
     g_peer_access = pa ? std::atoi(pa) : 0;
     const char* lim = std::getenv("GKOC_ARENA_MAX_WALK");
-    g_max_walk = lim ? std::atoi(lim) : 128;
-    if (g_max_walk < 1) g_max_walk = 1;
+    g_max_walk = lim ? std::atoi(lim) : 0;
+    if (g_max_walk < 0) g_max_walk = 0;
+    const char* mc = std::getenv("GKOC_ARENA_MAX_CLASSES");
+    g_max_classes = mc ? std::atoi(mc) : max_classes;
+    if (g_max_classes < 1 || g_max_classes > max_classes) g_max_classes = max_classes;
     const char* sf = std::getenv("GKOC_ARENA_SYNC_FREE");
     g_sync_free = sf ? std::atoi(sf) : 1;
     const char* v = std::getenv("GKOC_ARENA_VERBOSE");
@@ -323,25 +329,53 @@ hipError_t map_granule(char* va, size_t bytes, hipMemGenericAllocationHandle_t h
     return e;
 }
 
-// class of the granule mapped at `cand`: an existing class id, A.n_cls for "none of
-// the known classes", -1 if the probe failed
+// The verdict of one comparison: t(read class k, write cand) / t(read class k, write class k's own
+// target).  Same class: ~1.00, another class: ~0.90 (lab4_probe_vs_known_classes.txt).  Between
+// the bands nothing is decided.
+constexpr double ratio_same = 0.965, ratio_other = 0.935;
+
+// class of the granule mapped at `cand`: an existing class id, A.n_cls for "none of the known
+// classes", -1 if the probe failed or stayed contradictory.
+// Round 4: the candidate is measured against EVERY known class and the verdict must be one-hot -
+// exactly one class "same", the others clearly "other" (or none "same": a new class, which is
+// only believed when a second, longer measurement says so again).  Round 3 stopped at the first
+// class whose ratio exceeded 0.95: tools/class_lab.hip shows isolated wrong verdicts of that rule
+// inside 16 - 64 GiB blocks of one class (about 3 % of the granules), and one such granule in a
+// region puts whatever lands on it into the wrong class.
 int classify_at(device_arena& A, char* cand)
 {
-    for (int k = 0; k < A.n_cls; ++k) {
-        const char* x = A.reg[k].base + probe_target;
-        int64_t t_ref = 0, t_new = 0;
-        if (probe_ns(A.stream, x, probe_x_bytes, A.reg[k].base, probe_read_kb, probe_write_b, 2, &t_ref) ||
-            probe_ns(A.stream, x, probe_x_bytes, cand, probe_read_kb, probe_write_b, 2, &t_new)) {
-            return -1;
+    int new_votes = 0;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const int reps = 2 + 2 * attempt;
+        int same = -1, n_same = 0, n_unsure = 0;
+        for (int k = 0; k < A.n_cls; ++k) {
+            const char* x = A.reg[k].base + probe_target;
+            int64_t t_ref = 0, t_new = 0;
+            if (probe_ns(A.stream, x, probe_x_bytes, A.reg[k].base, probe_read_kb, probe_write_b, reps, &t_ref) ||
+                probe_ns(A.stream, x, probe_x_bytes, cand, probe_read_kb, probe_write_b, reps, &t_new)) {
+                return -1;
+            }
+            A.probes += 2 * (reps + 1);
+            const double r = double(t_new) / double(t_ref);
+            if (g_verbose > 1) {
+                fprintf(stderr, "[gkoc arena]   probe vs class %d: %.0f us, reference %.0f us (%.3f)\n", k,
+                        t_new / 1e3, t_ref / 1e3, r);
+            }
+            if (r >= ratio_same) {
+                same = k;
+                ++n_same;
+            } else if (r > ratio_other) {
+                ++n_unsure;
+            }
         }
-        A.probes += 2;
-        if (g_verbose > 1) {
-            fprintf(stderr, "[gkoc arena]   probe vs class %d: %.0f us, reference %.0f us\n", k,
-                    t_new / 1e3, t_ref / 1e3);
+        if (n_unsure == 0 && n_same == 1) return same;
+        if (n_unsure == 0 && n_same == 0 && A.n_cls < max_classes) {
+            if (++new_votes >= 2 || A.n_cls == 0) return A.n_cls;
+            continue;       // a new class: measure once more before a region is founded on it
         }
-        if (double(t_new) > 0.95 * double(t_ref)) return k;
+        ++A.retried;
     }
-    return A.n_cls;
+    return -1;
 }
 
 // region of the next class = [probe target | free space] on granule h
@@ -360,23 +394,60 @@ bool start_class(device_arena& A, int dev, hipMemGenericAllocationHandle_t h)
     return true;
 }
 
-// a granule of class `want` (want == A.n_cls: of a class not seen yet), from the pool
-// or from the driver.  Granules of other classes met on the way go to the pool of
-// their class; nothing is released during a search (the driver would hand the same
-// block out again), afterwards the pools are cut back to GKOC_ARENA_SPARE_MB.
-hipError_t acquire_granule(device_arena& A, int dev, int want, hipMemGenericAllocationHandle_t* out)
+// ---- the search -------------------------------------------------------------------------
+// What the driver does (measured, tools/class_lab.hip, profiles/r04_class_survey.txt): the three
+// classes are contiguous thirds of the physical address space, the driver's buddy allocator
+// serves a 1 GiB request from the SMALLEST free block that holds it, so consecutive handles walk
+// through the free blocks in order of size - 1, 2, 4 ... 64 GiB - and every block lies in one
+// class (only the 64 GiB block across the 96 GiB mark does not).  Which class owns the small
+// blocks is an accident of what else lives on the device: on the builder's boxes all three show up
+// within 13 - 33 handles, on the box that timed round 3 one class owned the first 95 GiB and
+// round 3's walk (128 handles at most, every one of them probed) gave up with two classes.
+// hipMemCreate costs nothing measurable at any size on clean memory (< 0.1 ms for 64 GiB); what a
+// step costs is mapping the handle and the probe launches (about 5 ms with three known classes).
+// So the walk (1) is bounded by the free memory, not by a count: up to three quarters of what is
+// free when it starts; (2) GALLOPS: handles 0 .. 15 are all classified, then every 2nd up to 32,
+// every 4th up to 64, every 8th up to 128, every 16th beyond - runs get longer as the blocks get
+// bigger, and a class that is absent from the small blocks can only begin with a long run; (3)
+// when a late hit ends it, the next handles are classified as well and pooled, because the
+// region that needed the class will need it again and a second walk would have to come as far.
+// Skipped handles are released unclassified when the walk ends; nothing is released during a
+// walk (the driver would hand the same block out again).  A device walk of 288 handles costs
+// about 60 classifications = 0.3 s.
+int walk_stride(int step)
+{
+    return step < 16 ? 1 : step < 32 ? 2 : step < 64 ? 4 : step < 128 ? 8 : 16;
+}
+
+// Walks fresh granules until the goal is reached: want >= 0 (a known class): its pool holds
+// n_want granules; want == -1: all classes are known (the survey; a granule of a class nobody
+// has met founds its region, start_class).  hipSuccess if reached.
+hipError_t walk(device_arena& A, int dev, int want, int n_want)
 {
     const size_t gr = granule_bytes();
-    if (want < max_classes && !A.spare[want].empty()) {
-        *out = A.spare[want].front();
-        A.spare[want].erase(A.spare[want].begin());
-        return hipSuccess;
-    }
     const hipMemAllocationProp prop = granule_prop(dev);
-    std::vector<hipMemGenericAllocationHandle_t> unknown;
+    std::vector<hipMemGenericAllocationHandle_t> skipped;
+    auto t_start = std::chrono::steady_clock::now();
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        free_b = size_t(64) * GiB;
+    }
+    int64_t max_steps = int64_t(free_b / 4 * 3 / gr);
+    if (g_max_walk > 0 && max_steps > g_max_walk) max_steps = g_max_walk;
+    if (max_steps < 1) max_steps = 1;
+    auto reached = [&] {
+        if (want < 0) return A.n_cls >= g_max_classes;
+        if (want >= A.n_cls) return false;
+        return int(A.spare[want].size()) >= n_want;
+    };
     hipError_t result = hipErrorOutOfMemory;
-    const int max_walk = g_max_walk;
-    for (int step = 0; step < max_walk; ++step) {
+    int tail = -1;       // > 0: a late hit, this many more handles are classified one by one
+    for (int64_t step = 0; step < max_steps; ++step) {
+        if (reached() && (want >= 0 || tail <= 0)) {
+            result = hipSuccess;
+            break;
+        }
         hipMemGenericAllocationHandle_t h;
         hipError_t e = hipMemCreate(&h, gr, &prop, 0);
         if (e != hipSuccess) {
@@ -385,6 +456,10 @@ hipError_t acquire_granule(device_arena& A, int dev, int want, hipMemGenericAllo
             break;
         }
         ++A.walked;
+        if (tail < 0 && step % walk_stride(int(step)) != 0) {
+            skipped.push_back(h);
+            continue;
+        }
         int cls = 0;
         if (A.n_cls > 0) {
             if (A.scratch_left < gr) {
@@ -409,27 +484,34 @@ hipError_t acquire_granule(device_arena& A, int dev, int want, hipMemGenericAllo
                 break;
             }
             cls = classify_at(A, cand);
+            ++A.classified;
             (void)hipMemUnmap(cand, gr);
         }
         if (g_verbose) {
-            fprintf(stderr, "[gkoc arena] granule %lld: class %d (want %d)\n", (long long)A.walked, cls,
-                    want);
+            fprintf(stderr, "[gkoc arena] granule %lld: class %d (want %d)\n", (long long)A.walked, cls, want);
         }
-        if (cls == want) {
-            *out = h;
-            result = hipSuccess;
-            break;
-        }
+        const bool hit = want >= 0 ? cls == want : (cls == A.n_cls && cls < g_max_classes);
         if (cls >= 0 && cls < A.n_cls) {
             A.spare[cls].push_back(h);
-        } else if (cls == A.n_cls && cls < max_classes && start_class(A, dev, h)) {
-            // a class nobody has asked for yet: its region starts with this granule
+        } else if (cls == A.n_cls && cls < g_max_classes && start_class(A, dev, h)) {
+            // a class nobody has met yet: its region starts with this granule
         } else {
-            unknown.push_back(h);   // failed probe
+            (void)hipMemRelease(h);     // failed or contradictory probe (or a class beyond the cap)
         }
+        if (hit && tail < 0 && walk_stride(int(step)) > 1) tail = 2 * (n_want > 0 ? n_want : 1) + 2;
+        if (tail > 0 && --tail == 0) tail = -1;
     }
-    for (auto h : unknown) (void)hipMemRelease(h);
-    // cut the pools back, largest first
+    if (result != hipSuccess && reached()) result = hipSuccess;
+    for (auto h : skipped) (void)hipMemRelease(h);
+    A.search_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start)
+                       .count();
+    return result;
+}
+
+// the pools hold at most GKOC_ARENA_SPARE_MB: cut them back, largest first
+void trim_pools(device_arena& A)
+{
+    const size_t gr = granule_bytes();
     for (;;) {
         size_t total = 0;
         int big = 0;
@@ -441,7 +523,19 @@ hipError_t acquire_granule(device_arena& A, int dev, int want, hipMemGenericAllo
         (void)hipMemRelease(A.spare[big].back());
         A.spare[big].pop_back();
     }
-    return result;
+}
+
+// a granule of the KNOWN class `want`, from the pool or from the driver; n_want: how many the
+// caller is going to ask for in a row (a late hit of the walk pools that many)
+hipError_t acquire_granule(device_arena& A, int dev, int want, int n_want, hipMemGenericAllocationHandle_t* out)
+{
+    if (A.spare[want].empty()) {
+        const hipError_t e = walk(A, dev, want, n_want > 0 ? n_want : 1);
+        if (A.spare[want].empty()) return e != hipSuccess ? e : hipErrorOutOfMemory;
+    }
+    *out = A.spare[want].front();
+    A.spare[want].erase(A.spare[want].begin());
+    return hipSuccess;
 }
 
 // map `count` more granules of its class at the end of region `cls`
@@ -452,7 +546,7 @@ hipError_t extend_region(device_arena& A, int dev, int cls, size_t count)
     for (size_t i = 0; i < count; ++i) {
         if (R.size + gr > R.reserved) return hipErrorOutOfMemory;
         hipMemGenericAllocationHandle_t h;
-        hipError_t e = acquire_granule(A, dev, cls, &h);
+        hipError_t e = acquire_granule(A, dev, cls, int(count - i), &h);
         if (e != hipSuccess) return e;
         e = map_granule(R.base + R.size, gr, h, dev);
         if (e != hipSuccess) {
@@ -464,6 +558,7 @@ hipError_t extend_region(device_arena& A, int dev, int cls, size_t count)
         R.size += gr;
         R.tail_retired = 0;     // retired addresses in front of the new granule stay dead
     }
+    trim_pools(A);
     return hipSuccess;
 }
 
@@ -488,24 +583,31 @@ hipError_t classes_init(device_arena& A, int dev)
     return hipSuccess;
 }
 
-// make class `cls` exist (classes are discovered in order); false if it cannot
-bool ensure_class(device_arena& A, int dev, int cls)
+// The classes of this device, found ONCE, in one walk, before anything is placed in a second
+// class (round 3 found them one by one as the roles asked for them: when the third did not show
+// up, the index arrays already sat in class 1 and the vectors had to join them - BENCH_r03).
+// With fewer than three classes the roles are mapped onto what exists (class_for_role).
+void survey_classes(device_arena& A, int dev)
 {
-    while (A.n_cls <= cls && !A.no_more_classes) {
-        hipMemGenericAllocationHandle_t h;
-        if (acquire_granule(A, dev, A.n_cls, &h) != hipSuccess || !start_class(A, dev, h)) {
-            A.no_more_classes = true;
-        }
+    if (A.surveyed) return;
+    A.surveyed = true;
+    (void)walk(A, dev, -1, 0);
+    (void)hipGetLastError();
+    trim_pools(A);
+    if (g_verbose) {
+        fprintf(stderr, "[gkoc arena] survey: %d class(es), %lld granules created, %lld classified, %.0f ms\n",
+                A.n_cls, (long long)A.walked, (long long)A.classified, A.search_ns / 1e6);
     }
-    return A.n_cls > cls;
 }
 
 // Does a request of `bytes` look like a vector (or a block of vectors: a Krylov basis, a
-// multi-vector) of a system whose vectors the kernels have already been seen to write?
+// multi-vector) of a system whose vectors the kernels have already been seen to write?  Multiples
+// up to 64 only: the value / index arrays of a matrix with a constant number of entries per row
+// (k n values of 8 bytes) are exact multiples of its n-vector as well.
 bool vector_shaped(const device_arena& A, size_t bytes)
 {
     for (size_t v : A.vector_sizes) {
-        if (v > 0 && bytes % v == 0 && bytes / v <= 4096) return true;
+        if (v > 0 && bytes % v == 0 && bytes / v <= 64) return true;
     }
     return false;
 }
@@ -523,27 +625,35 @@ bool vector_shaped(const device_arena& A, size_t bytes)
 // before A): they spread over two classes while nothing else is known, the matrix arrays then
 // share the third one - no written stream next to a matrix array.  A Krylov basis (a multiple of
 // a vector the kernels have written) joins the vectors although it is the largest request.
-int class_for_role(const device_arena& A, int role, size_t bytes)
+// ncls: the number of classes to choose from (3 while the device has not been surveyed).  With two
+// classes the matrix arrays share class 0 and everything kernels write gets class 1 (values and
+// indices in one class cost 2 %, a written vector next to either costs 6 - 11 %: DESIGN.md 3.2);
+// with one class there is nothing to choose.
+int class_for_role(const device_arena& A, int role, size_t bytes, int ncls)
 {
-    if (role != GKOC_MEM_AUTO) return role == GKOC_MEM_VALUES ? 0 : role == GKOC_MEM_INDICES ? 1 : 2;
+    if (ncls <= 1) return 0;
+    if (role != GKOC_MEM_AUTO) {
+        if (ncls == 2) return role == GKOC_MEM_VECTOR ? 1 : 0;
+        return role == GKOC_MEM_VALUES ? 0 : role == GKOC_MEM_INDICES ? 1 : 2;
+    }
     size_t largest = bytes;
     for (int k = 0; k < max_classes; ++k) {
         for (const auto& u : A.reg[k].req) largest = std::max(largest, u.second);
     }
     auto is_small = [&](size_t b) { return vector_shaped(A, b) || b * 4 < largest; };
     size_t big_b[max_classes] = {}, small_b[max_classes] = {};
-    for (int k = 0; k < max_classes; ++k) {
+    for (int k = 0; k < ncls; ++k) {
         for (const auto& u : A.reg[k].req) (is_small(u.second) ? small_b[k] : big_b[k]) += u.second;
     }
     int best = 0;
     if (!is_small(bytes)) {
-        for (int k = 1; k < max_classes; ++k) {
+        for (int k = 1; k < ncls; ++k) {
             if (small_b[k] < small_b[best] || (small_b[k] == small_b[best] && big_b[k] < big_b[best])) best = k;
         }
     } else {
         // (ties: the highest class, where explicit roles put vectors)
-        best = max_classes - 1;
-        for (int k = max_classes - 2; k >= 0; --k) {
+        best = ncls - 1;
+        for (int k = ncls - 2; k >= 0; --k) {
             if (big_b[k] < big_b[best] || (big_b[k] == big_b[best] && small_b[k] > small_b[best])) best = k;
         }
     }
@@ -641,16 +751,22 @@ int arena_malloc(void** ptr, size_t bytes, int role)
             return span_list_malloc(A.plain, g_chunk_bytes, ptr, need, align);
         }
     }
-    int cls = class_for_role(A, role, bytes);
-    if (!ensure_class(A, dev, cls)) {
-        if (A.n_cls == 0) {
+    if (A.n_cls == 0) {
+        // the first granule is class 0 by definition
+        hipMemGenericAllocationHandle_t h;
+        const hipMemAllocationProp prop = granule_prop(dev);
+        if (hipMemCreate(&h, granule_bytes(), &prop, 0) != hipSuccess || !start_class(A, dev, h)) {
+            (void)hipGetLastError();
             A.failed = true;
             return span_list_malloc(A.plain, g_chunk_bytes, ptr, need, align);
         }
-        // fewer classes than roles: vectors keep a class of their own as long as
-        // there are two
-        cls = (cls == 2 && A.n_cls == 2) ? 1 : 0;
+        ++A.walked;
     }
+    // a request that wants a second class sends the survey out (once); afterwards the roles are
+    // mapped onto the classes that exist
+    if (!A.surveyed && class_for_role(A, role, bytes, max_classes) >= A.n_cls) survey_classes(A, dev);
+    int cls = class_for_role(A, role, bytes, A.surveyed ? A.n_cls : max_classes);
+    if (cls >= A.n_cls) cls = A.n_cls - 1;
     const size_t gr = granule_bytes();
     for (int attempt = 0; attempt < max_classes; ++attempt) {
         region& R = A.reg[cls];
@@ -823,6 +939,10 @@ int gkoc_arena_stats(gkoc_arena_info* info)
     info->num_classes = A.n_cls;
     info->probes = A.probes;
     info->granules_walked = A.walked;
+    info->granules_classified = A.classified;
+    info->search_ns = A.search_ns;
+    info->probe_retries = A.retried;
+    info->surveyed = A.surveyed ? 1 : 0;
     auto add = [&](const span* c) {
         info->num_chunks += 1;
         info->reserved_bytes += int64_t(c->size);
@@ -928,6 +1048,9 @@ int gkoc_arena_trim(void)
         for (auto h : A.spare[k]) (void)hipMemRelease(h);
         A.spare[k].clear();
     }
+    // (without the synchronisation of gkoc_free a kernel in flight may still touch a block that
+    // was handed back a moment ago: nothing is unmapped under it)
+    if (!g_sync_free) (void)hipDeviceSynchronize();
     // trailing free granules of the regions go back to the driver.  Their addresses are RETIRED
     // (the range stays inside the region, neither free nor used: a later extension maps fresh
     // addresses behind it), because an address that was unmapped must not be mapped to other

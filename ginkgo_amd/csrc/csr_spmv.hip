@@ -166,44 +166,65 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     return GKOC_OK;
 }
 
-// The distributed product in ONE kernel (csr_spmv_pipe.hpp, GATE): the rank's rows over [local columns
-// | halo], b = [local vector | halo] (unit stride), the rows that read halo entries are the first
-// head_rows and the last tail_rows; gate = three counters in device memory (zero at the start).
+// The distributed product in ONE kernel (csr_spmv_pipe.hpp, GATE): the interior rows of the rank's
+// local block and, on the last waves of the grid, the boundary rows as complete rows over [local
+// columns | halo]; b = [local vector | halo] (unit stride); gate = two counters in device memory
+// (zero at the start).
 __global__ void gate_open_kernel(uint32_t* gate, uint32_t epoch)
 {
     __hip_atomic_store(gate, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <typename T, typename I>
-int launch_csr_gated(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const I* row_ptrs, const I* col_idxs,
-                     const T* vals, const T* b, T* c, int64_t head_rows, int64_t tail_rows, const uint32_t* gate,
-                     uint32_t epoch)
+// Boundary waves may SPIN (their halo travels on another stream), and a spinning wave keeps its
+// slot and its 8 KB of LDS until the gate opens.  The kernels that open it - the exchange's
+// (RCCL's send / recv workgroups) and gkoc_gate_open - need room on the device to run at all, and
+// stream priority does not preempt resident waves.  So at most 8 boundary waves per CU are ever
+// launched (2048 on an MI355X, of about 5120 that are resident at a time with 8 KB of LDS each):
+// more than half of every resource stays with waves that finish by themselves.  Above that bound
+// the caller takes the join-based product (local rows || exchange, stream-ordered boundary rows),
+// whose waiting is the stream's, as in the reference (core/distributed/matrix.cpp:450-509 req.wait()).
+int64_t gated_wave_cap() { return int64_t(current_device_props().num_cu) * 8; }
+
+bool gated_fits(int64_t n_rows, int64_t head_rows, int64_t tail_rows)
 {
-    GKOC_REQUIRE(n_rows > 0 && n_cols >= 0 && head_rows >= 0 && tail_rows >= 0 &&
-                     head_rows + tail_rows <= n_rows,
+    if (n_rows <= 0 || head_rows < 0 || tail_rows < 0 || head_rows + tail_rows > n_rows ||
+        head_rows + tail_rows == 0) {
+        return false;
+    }
+    return ceildiv(head_rows + tail_rows, 64) <= gated_wave_cap();
+}
+
+template <typename T, typename I>
+int launch_csr_gated(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs, const T* vals,
+                     const I* bnd_ptrs, const I* bnd_cols, const T* bnd_vals, const T* b, T* c,
+                     int64_t head_rows, int64_t tail_rows, const uint32_t* gate, uint32_t epoch)
+{
+    GKOC_REQUIRE(n_rows > 0 && head_rows >= 0 && tail_rows >= 0 && head_rows + tail_rows <= n_rows,
                  GKOC_E_INVALID, "bad dimensions");
-    GKOC_REQUIRE(row_ptrs && col_idxs && vals && b && c && gate, GKOC_E_INVALID, "null pointer");
+    GKOC_REQUIRE(head_rows + tail_rows > 0, GKOC_E_INVALID, "no boundary rows: use gkoc_csr_spmv_*");
+    GKOC_REQUIRE(row_ptrs && col_idxs && vals && bnd_ptrs && bnd_cols && bnd_vals && b && c && gate,
+                 GKOC_E_INVALID, "null pointer");
+    GKOC_REQUIRE(gated_fits(n_rows, head_rows, tail_rows), GKOC_E_NOT_SUPPORTED,
+                 "more boundary rows than may wait on the device at once (gkoc_csr_spmv_gated_fits): "
+                 "use the join-based product");
     constexpr int EV = 32 / sizeof(T);
     constexpr int RINGV = 8192 / sizeof(T);
-    GKOC_REQUIRE(reinterpret_cast<uintptr_t>(vals) % (EV * sizeof(T)) == 0 &&
-                     reinterpret_cast<uintptr_t>(col_idxs) % (EV * sizeof(I)) == 0,
-                 GKOC_E_NOT_SUPPORTED, "values / column indices not aligned for vector loads");
-    const int64_t n_seg = ceildiv(n_rows, 64);
-    GKOC_REQUIRE(n_seg < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 row segments");
-    int64_t head_segs = ceildiv(head_rows, 64);
-    int64_t tail_segs = tail_rows > 0 ? n_seg - (n_rows - tail_rows) / 64 : 0;
-    if (head_segs + tail_segs > n_seg) {   // every segment reads halo entries
-        head_segs = n_seg;
-        tail_segs = 0;
-    }
-    GKOC_REQUIRE(head_segs + tail_segs > 0, GKOC_E_INVALID, "no boundary rows: use gkoc_csr_spmv_*");
-    const dim3 grid(static_cast<unsigned>(n_seg)), block(64);
+    auto aligned = [](const void* v, const void* i) {
+        return reinterpret_cast<uintptr_t>(v) % (EV * sizeof(T)) == 0 &&
+               reinterpret_cast<uintptr_t>(i) % (EV * sizeof(I)) == 0;
+    };
+    GKOC_REQUIRE(aligned(vals, col_idxs) && aligned(bnd_vals, bnd_cols), GKOC_E_NOT_SUPPORTED,
+                 "values / column indices not aligned for vector loads");
+    const int64_t n_int = ceildiv(n_rows - head_rows - tail_rows, 64);
+    const int64_t n_bnd = ceildiv(head_rows + tail_rows, 64);
+    GKOC_REQUIRE(n_int + n_bnd < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 row segments");
+    const dim3 grid(static_cast<unsigned>(n_int + n_bnd)), block(64);
     constexpr int PE = sizeof(T) == 8 ? 2 : 4, PU = sizeof(T) == 8 ? 3 : 2;
 #define GKOC_LAUNCH_GATED(E_, U_)                                                                 \
     csr_spmv_pipe3_kernel<T, I, false, 64, E_, U_, RINGV, 1, 0x11000><<<grid, block, 0, as_stream(s)>>>( \
-        n_rows, n_seg, 1, row_ptrs, col_idxs, vals, b, 1, c, 1, 1, nullptr, nullptr, nullptr, 0,  \
-        nullptr, nullptr, head_segs, tail_segs, gate, epoch)
-    if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_seg < 32768) {
+        n_rows, n_int + n_bnd, 1, row_ptrs, col_idxs, vals, b, 1, c, 1, 1, nullptr, nullptr, nullptr, 0, \
+        nullptr, nullptr, head_rows, tail_rows, gate, epoch, bnd_ptrs, bnd_cols, bnd_vals)
+    if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_int < 32768) {
         GKOC_LAUNCH_GATED(EV, 1);
     } else {
         GKOC_LAUNCH_GATED(PE, PU);
@@ -211,6 +232,17 @@ int launch_csr_gated(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const I* r
 #undef GKOC_LAUNCH_GATED
     GKOC_LAUNCH_OK();
     return GKOC_OK;
+}
+
+// Diagnostic: `blocks` workgroups of `threads` threads and `lds_bytes` of LDS each that stay on
+// the device for `usec` microseconds (tests: a late exchange, an RCCL-sized kernel that must find
+// room next to waiting waves)
+__global__ void delay_kernel(long long ticks)
+{
+    extern __shared__ char delay_lds[];
+    if (threadIdx.x == 0) delay_lds[0] = 0;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
 // Mixed precision: values stored as V (float), vectors and arithmetic T (double).  8 instead of
@@ -556,24 +588,40 @@ GKOC_DEF_CSR_SORT(gkoc_c64, c64, int32_t, i32)
 GKOC_DEF_CSR_SORT(gkoc_c64, c64, int64_t, i64)
 
 #define GKOC_DEF_CSR_GATED(T, TN, I, IN)                                                             \
-    extern "C" int gkoc_csr_spmv_gated_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,   \
-                                                   const I* row_ptrs, const I* col_idxs,              \
-                                                   const T* vals, const T* b, T* c,                   \
-                                                   int64_t head_rows, int64_t tail_rows,              \
-                                                   const uint32_t* gate, uint32_t epoch)              \
+    extern "C" int gkoc_csr_spmv_gated_##TN##_##IN(                                                   \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs, const T* vals,         \
+        const I* bnd_ptrs, const I* bnd_cols, const T* bnd_vals, const T* b, T* c, int64_t head_rows, \
+        int64_t tail_rows, const uint32_t* gate, uint32_t epoch)                                      \
     {                                                                                                 \
-        return launch_csr_gated<T, I>(s, n_rows, n_cols, row_ptrs, col_idxs, vals, b, c, head_rows,   \
-                                      tail_rows, gate, epoch);                                        \
+        return launch_csr_gated<T, I>(s, n_rows, row_ptrs, col_idxs, vals, bnd_ptrs, bnd_cols,        \
+                                      bnd_vals, b, c, head_rows, tail_rows, gate, epoch);             \
     }
 GKOC_DEF_CSR_GATED(double, f64, int32_t, i32)
 GKOC_DEF_CSR_GATED(double, f64, int64_t, i64)
 GKOC_DEF_CSR_GATED(float, f32, int32_t, i32)
 GKOC_DEF_CSR_GATED(float, f32, int64_t, i64)
 
+extern "C" int gkoc_csr_spmv_gated_fits(int64_t n_rows, int64_t head_rows, int64_t tail_rows)
+{
+    return gkoc::gated_fits(n_rows, head_rows, tail_rows) ? 1 : 0;
+}
+
 extern "C" int gkoc_gate_open(gkoc_stream_t s, uint32_t* gate, uint32_t epoch)
 {
     GKOC_REQUIRE(gate, GKOC_E_INVALID, "gate == NULL");
     gkoc::gate_open_kernel<<<dim3(1), dim3(1), 0, as_stream(s)>>>(gate, epoch);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+extern "C" int gkoc_debug_delay(gkoc_stream_t s, int64_t usec, int blocks, int threads, int lds_bytes)
+{
+    GKOC_REQUIRE(usec >= 0 && blocks > 0 && threads > 0 && threads <= 1024 && lds_bytes >= 0 &&
+                     lds_bytes <= 64 * 1024,
+                 GKOC_E_INVALID, "bad delay arguments");
+    /* wall_clock64 counts at 100 MHz on gfx950 */                                                    
+    gkoc::delay_kernel<<<dim3(unsigned(blocks)), dim3(unsigned(threads)), size_t(lds_bytes), as_stream(s)>>>(
+        (long long)usec * 100);
     GKOC_LAUNCH_OK();
     return GKOC_OK;
 }

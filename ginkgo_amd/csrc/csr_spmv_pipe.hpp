@@ -48,15 +48,24 @@ struct alignas(sizeof(T) * E) vecT {
 template <typename T, typename I, bool ADV, int ROWS, int E, int U, int RING,
           int WPS, int ABL = 0, typename V = T>
 __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
-    int64_t n_rows, int64_t n_segments, int64_t segs_per_wave,
-    const I* __restrict__ row_ptrs, const I* __restrict__ cols,
-    const V* __restrict__ vals, const T* __restrict__ b, int64_t ldb,
-    T* __restrict__ c, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
+    int64_t n_rows_in, int64_t n_segments_in, int64_t segs_per_wave,
+    const I* __restrict__ row_ptrs_in, const I* __restrict__ cols_in,
+    const V* __restrict__ vals_in, const T* __restrict__ b, int64_t ldb,
+    T* __restrict__ c_in, int64_t ldc, int nrhs, const T* __restrict__ alpha_p,
     const T* __restrict__ beta_p, T* __restrict__ dot_partial = nullptr,
     int xcd_map = 0, const I* __restrict__ row_idxs = nullptr,
-    int* __restrict__ unsorted_flag = nullptr, int64_t head_segs = 0, int64_t tail_segs = 0,
-    const uint32_t* __restrict__ gate = nullptr, uint32_t gate_epoch = 0)
+    int* __restrict__ unsorted_flag = nullptr, int64_t head_rows = 0, int64_t tail_rows = 0,
+    const uint32_t* __restrict__ gate = nullptr, uint32_t gate_epoch = 0,
+    const I* __restrict__ bnd_ptrs = nullptr, const I* __restrict__ bnd_cols = nullptr,
+    const V* __restrict__ bnd_vals = nullptr)
 {
+    // (GATE mode points a wave at one of two matrices; everywhere else these are the arguments)
+    int64_t n_rows = n_rows_in, n_segments = n_segments_in;
+    const I* __restrict__ row_ptrs = row_ptrs_in;
+    const I* __restrict__ cols = cols_in;
+    const V* __restrict__ vals = vals_in;
+    T* __restrict__ c = c_in;
+    int64_t out_jump_at = 0, out_jump = 0;      // GATE: output row = r < jump_at ? r : r + jump
     static_assert((RING & (RING - 1)) == 0, "RING must be a power of two");
     constexpr int G = 64 * E * U;
     static_assert(RING >= 2 * G, "ring too small for the group size");
@@ -107,42 +116,58 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
         const int64_t xcd = wave_id & 7, slot = wave_id >> 3;
         wave_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
     }
-    // GATE = ABL & 0x10000 (distributed product, one segment per wave): the matrix holds a rank's
-    // rows over [local columns | halo] and b is the local vector with the halo BEHIND it; the first
-    // head_segs and the last tail_segs row segments read halo entries.  They are given to the LAST
-    // waves of the grid, and those wait - every wave for itself - until the exchange, which travels
-    // on another stream while the interior rows are computed, has delivered the halo: *gate holds
-    // the number of the last exchange that has arrived (gkoc_gate_open on the exchange's stream),
-    // gate_epoch is the number of the exchange this product needs (the caller counts).  No second
-    // kernel beside this one, no event the stream waits for, no atomic read-modify-write (2048
-    // same-address atomics of the boundary waves cost 15 us when tried): by the time the last waves
-    // start the halo has long arrived, and a wave that does have to wait polls with s_sleep (after
-    // ~10 s it gives up, sets gate[1] and goes on with whatever the halo holds: the caller checks).  Nothing has read the halo since the launch,
-    // so no cache holds an old line of it.
+    // GATE = ABL & 0x10000 (distributed product, one segment per wave).  Two matrices in one launch:
+    //   * the rank's LOCAL block (row_ptrs / cols / vals, columns = local indices): its rows
+    //     [head_rows, n_rows - tail_rows) read no halo entry and are complete - the interior waves
+    //     compute them (row pointers and output shifted by head_rows);
+    //   * the boundary rows - the first head_rows and the last tail_rows - as COMPLETE rows over
+    //     [local columns | halo] (bnd_ptrs / bnd_cols / bnd_vals, head rows then tail rows; b is the
+    //     local vector with the halo behind it).  They are given to the LAST waves of the grid, and
+    //     those wait - every wave for itself - until the exchange, which travels on another stream
+    //     while the interior rows are computed, has delivered the halo: *gate holds the number of
+    //     the last exchange that has arrived (gkoc_gate_open on the exchange's stream), gate_epoch is
+    //     the number of the exchange this product needs (the caller counts).
+    // No second kernel beside this one, no event the stream waits for, no atomic read-modify-write
+    // (2048 same-address atomics of the boundary waves cost 15 us when tried), no second copy of the
+    // matrix (round 3 kept all rows again over [local | halo]).  By the time the last waves start the
+    // halo has usually arrived; a wave that has to wait polls with s_sleep (after ~10 s it gives up,
+    // sets gate[1] and goes on with whatever the halo holds: the caller checks).  The acquire fence
+    // is unconditional: the halo sits right behind the local vector, and an interior wave that read
+    // the last local entries may have pulled the first halo line into this XCD's L2 before the
+    // exchange wrote it.  Forward progress: the launcher admits at most 8 spinning waves per CU
+    // (gkoc_csr_spmv_gated_fits), so the exchange's kernels and gkoc_gate_open always find room.
     constexpr bool GATE = (ABL & 0x10000) != 0;
     if constexpr (GATE) {
-        const int64_t n_int = n_segments - head_segs - tail_segs;
+        const int64_t n_int_rows = n_rows_in - head_rows - tail_rows;
+        const int64_t n_int = (n_int_rows + ROWS - 1) / ROWS;
         if (wave_id >= n_int) {
-            const int64_t jb = wave_id - n_int;
-            wave_id = jb < head_segs ? jb : n_segments - tail_segs + (jb - head_segs);
+            wave_id -= n_int;
+            row_ptrs = bnd_ptrs;
+            cols = bnd_cols;
+            vals = bnd_vals;
+            n_rows = head_rows + tail_rows;
+            n_segments = (n_rows + ROWS - 1) / ROWS;
+            out_jump_at = head_rows;
+            out_jump = n_rows_in - tail_rows - head_rows;
             if (lane == 0) {
-                bool waited = false;
                 long spins = 0;
                 while (int32_t(__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) -
                                gate_epoch) < 0) {
                     __builtin_amdgcn_s_sleep(32);
-                    waited = true;
                     if (++spins > (long(1) << 23)) {   // ~10 s: give up, say so, go on (the caller checks gate[1])
                         __hip_atomic_store(const_cast<uint32_t*>(gate) + 1, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                 }
-                if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         } else {
-            wave_id += head_segs;
+            row_ptrs = row_ptrs_in + head_rows;
+            c = c_in + head_rows;
+            n_rows = n_int_rows;
+            n_segments = n_int;
         }
     }
     const int64_t sb = wave_id * segs_per_wave;
@@ -452,10 +477,11 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
 #pragma unroll
                         for (int t = 0; t < DEFER; ++t) ys[t] = t == kseg ? sum : ys[t];
                     } else if (lane < ROWS && row < n_rows) {
+                        const int64_t orow = GATE && row >= out_jump_at ? row + out_jump : row;
                         if (ABL & 32) {
-                            __builtin_nontemporal_store(sum, &c[row * ldc + j]);
+                            __builtin_nontemporal_store(sum, &c[orow * ldc + j]);
                         } else {
-                            c[row * ldc + j] = sum;
+                            c[orow * ldc + j] = sum;
                         }
                     }
 #ifdef GKOC_LAB_TIMESTAMPS
@@ -491,7 +517,8 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
 #pragma unroll
             for (int t = 0; t < DEFER; ++t) {
                 const int64_t row = (sb + t) * ROWS + lane;
-                if (sb + t < se && lane < ROWS && row < n_rows) c[row * ldc + j] = ys[t];
+                const int64_t orow = GATE && row >= out_jump_at ? row + out_jump : row;
+                if (sb + t < se && lane < ROWS && row < n_rows) c[orow * ldc + j] = ys[t];
             }
         }
     }

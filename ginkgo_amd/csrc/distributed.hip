@@ -180,8 +180,8 @@ __global__ __launch_bounds__(64) void csr_rowlist_add_kernel(
 
 // ---- boundary rows as COMPLETE rows (slab partitions, one column) ------------------------
 // The rows that have non-local entries, with ALL their entries in the original (global) column
-// order; a column index below n_local refers to the rank's own vector, n_local + h to halo
-// entry h.  y[rows[i]] = sum_k vals[k] * v(cols[k]) in k order: the single-domain row sum, bit
+// order; a column index below halo_base (>= n_local; the kernels' `n_local` argument) refers to
+// the rank's own vector, halo_base + h to halo entry h.  y[rows[i]] = sum_k vals[k] * v(cols[k]) in k order: the single-domain row sum, bit
 // for bit.  Such rows need nothing from the local SpMV, so that kernel can skip them (it is
 // launched over the interior row range only) and this one can run on the exchange's stream as
 // soon as the halo has arrived, next to the tail of the local SpMV.
@@ -199,8 +199,8 @@ template <typename T, typename I>
 __global__ __launch_bounds__(256) void boundary_fill_kernel(
     int64_t n_list, const I* __restrict__ rows, const I* __restrict__ row_ptrs,
     const I* __restrict__ cols, const T* __restrict__ vals, int64_t col_lo, int64_t col_hi,
-    const I* __restrict__ col_map, const I* __restrict__ out_ptrs, I* __restrict__ out_cols,
-    T* __restrict__ out_vals)
+    int64_t halo_base, const I* __restrict__ col_map, const I* __restrict__ out_ptrs,
+    I* __restrict__ out_cols, T* __restrict__ out_vals)
 {
     // one wave per listed row
     const int lane = threadIdx.x & 63;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void boundary_fill_kernel(
     const int64_t k0 = row_ptrs[r], len = int64_t(row_ptrs[r + 1]) - k0, o0 = out_ptrs[i];
     for (int64_t t = lane; t < len; t += 64) {
         const int64_t c = cols[k0 + t];
-        out_cols[o0 + t] = (c >= col_lo && c < col_hi) ? I(c - col_lo) : I(col_hi - col_lo + int64_t(col_map[c]));
+        out_cols[o0 + t] = (c >= col_lo && c < col_hi) ? I(c - col_lo) : I(halo_base + int64_t(col_map[c]));
         out_vals[o0 + t] = vals[k0 + t];
     }
 }
@@ -411,13 +411,17 @@ GKOC_DEF_DIST_BND_IDX(int64_t, i64)
     extern "C" int gkoc_dist_boundary_fill_##TN##_##IN(                        \
         gkoc_stream_t s, int64_t n_list, const I* rows, const I* row_ptrs,     \
         const I* cols, const T* vals, int64_t col_lo, int64_t col_hi,          \
-        const I* col_map, const I* out_ptrs, I* out_cols, T* out_vals)         \
+        int64_t halo_base, const I* col_map, const I* out_ptrs, I* out_cols,   \
+        T* out_vals)                                                           \
     {                                                                          \
         if (n_list <= 0) return GKOC_OK;                                       \
+        GKOC_REQUIRE(halo_base >= col_hi - col_lo, GKOC_E_INVALID,             \
+                     "halo_base inside the local columns");                    \
         boundary_fill_kernel<T, I>                                             \
             <<<dim3(unsigned(ceildiv(n_list * 64, 256))), dim3(256), 0,        \
                as_stream(s)>>>(n_list, rows, row_ptrs, cols, vals, col_lo,     \
-                               col_hi, col_map, out_ptrs, out_cols, out_vals); \
+                               col_hi, halo_base, col_map, out_ptrs, out_cols, \
+                               out_vals);                                      \
         GKOC_LAUNCH_OK();                                                      \
         return GKOC_OK;                                                        \
     }                                                                          \

@@ -496,22 +496,23 @@ class HipBackend:
                 call("gkoc_dist_boundary_count_" + it, ex.stream, n_nl_rows, nl_rows, a.row_ptrs, f_ptrs,
                      C.byref(nnz_f))
                 f_cols, f_vals = ex.alloc((nnz_f.value,), idt), ex.alloc((nnz_f.value,), a.dtype)
+                # halo entry h has column halo_base + h: the local size rounded up to 128 bytes, so that
+                # a halo kept BEHIND the local vector (the one-kernel product below) starts on a cache
+                # line of its own - the last local entries and the first halo entries never share one
+                n_local = col_hi - col_lo
+                halo_base = -(-n_local // 32) * 32
                 call(f"gkoc_dist_boundary_fill_{vt}_{it}", ex.stream, n_nl_rows, nl_rows, a.row_ptrs,
-                     a.col_idxs, a.values, col_lo, col_hi, col_map, f_ptrs, f_cols, f_vals)
-                nl["full"] = dict(ptrs=f_ptrs, cols=f_cols, vals=f_vals, n_local=col_hi - col_lo,
-                                  interior=(len(head), n - len(tail)))
-                # ... and ALL rows once more over [local columns | halo] for the product in one
-                # kernel (gkoc_csr_spmv_gated_*): b is then the local vector with the halo behind it
-                if os.environ.get("GKO_GATED_SPMV", "1") != "0":
-                    all_rows = torch.arange(n, dtype=idt, device=a.row_ptrs.device)
-                    e_cols = ex.alloc((a.col_idxs.numel(),), idt, MEM_INDICES)
-                    e_vals = ex.alloc((a.values.numel(),), a.dtype, MEM_VALUES)
-                    call(f"gkoc_dist_boundary_fill_{vt}_{it}", ex.stream, n, all_rows, a.row_ptrs,
-                         a.col_idxs, a.values, col_lo, col_hi, col_map, a.row_ptrs, e_cols, e_vals)
-                    e_ptrs = ex.alloc((n + 1,), idt, MEM_INDICES)
-                    e_ptrs.copy_(a.row_ptrs)
-                    nl["ext"] = dict(ptrs=e_ptrs, cols=e_cols, vals=e_vals, head=len(head), tail=len(tail),
-                                     n_cols=(col_hi - col_lo) + n_halo)
+                     a.col_idxs, a.values, col_lo, col_hi, halo_base, col_map, f_ptrs, f_cols, f_vals)
+                nl["full"] = dict(ptrs=f_ptrs, cols=f_cols, vals=f_vals, n_local=n_local, halo_base=halo_base,
+                                  interior=(len(head), n - len(tail)), head=len(head), tail=len(tail),
+                                  n_halo=n_halo)
+                # The product in one kernel (gkoc_csr_spmv_gated_*) reads the interior rows from the
+                # local block and these complete boundary rows from the same launch: no further copy of
+                # the matrix (round 3 kept ALL rows a second time).  It exists where the boundary rows
+                # are few enough for their waves to wait on the device without starving the exchange.
+                if os.environ.get("GKO_GATED_SPMV", "1") != "0" and nnz_l > 0:
+                    nl["full"]["gated"] = bool(lib().gkoc_csr_spmv_gated_fits(
+                        C.c_int64(n), C.c_int64(len(head)), C.c_int64(len(tail))))
         return local, nl, recv_gidx
 
     def to_host(self, t):
@@ -549,7 +550,7 @@ class HipBackend:
         f = nl["full"]
         st = C.c_void_p(stream.cuda_stream) if stream is not None else self.exec.stream
         call("gkoc_csr_rowlist_spmv_full_" + nl["suffix"], st, nl["n"], nl["rows"], f["ptrs"],
-             f["cols"], f["vals"], f["n_local"], x.values, halo.values, y.values)
+             f["cols"], f["vals"], f["halo_base"], x.values, halo.values, y.values)
 
     def gate_new(self):
         """the word of gkoc_csr_spmv_gated_* / gkoc_gate_open (device) and the exchange count (host)"""
@@ -561,12 +562,15 @@ class HipBackend:
         bump(gate[1])
         call("gkoc_gate_open", C.c_void_p(stream.cuda_stream), gate[0], gate[1])
 
-    def spmv_gated(self, nl, x_ext, y, gate):
-        """y = A [x | halo] for ALL local rows in one kernel; x_ext: the local vector with the halo
-        behind it; the boundary rows wait for the gate_open in front of this call"""
-        e = nl["ext"]
-        call("gkoc_csr_spmv_gated_" + nl["suffix"], self.exec.stream, y.size[0], e["n_cols"], e["ptrs"],
-             e["cols"], e["vals"], x_ext, y.values, e["head"], e["tail"], gate[0], gate[1])
+    def spmv_gated(self, local, nl, x_ext, y, gate):
+        """y = A [x | halo] for ALL local rows in one kernel: the interior rows from the local
+        block, the boundary rows (complete rows, nl["full"]) on its last waves, which wait for the
+        gate_open in front of this call; x_ext: the local vector with the halo behind it, starting
+        at entry nl["full"]["halo_base"]"""
+        f = nl["full"]
+        call("gkoc_csr_spmv_gated_" + nl["suffix"], self.exec.stream, y.size[0], local.row_ptrs,
+             local.col_idxs, local.values, f["ptrs"], f["cols"], f["vals"], x_ext, y.values, f["head"],
+             f["tail"], gate[0], gate[1])
 
     def spmv_dot(self, a, x, y, out):
         """y = A_local x and out = local <x, y> in one pass; False if there is no such kernel
@@ -849,7 +853,7 @@ class DistributedMatrix:
         # the whole product in ONE kernel whose last waves (the boundary rows) wait for the halo by
         # themselves: for vectors from ext_vector() (the solvers' search directions), a
         # device-resident communicator and zero-copy send planes
-        self._gate = (backend.gate_new() if "ext" in self.nl and hasattr(backend, "spmv_gated") and
+        self._gate = (backend.gate_new() if self.nl.get("full", {}).get("gated") and hasattr(backend, "spmv_gated") and
                       self._side is not None and getattr(comm, "direct", False) and
                       hasattr(comm, "exchange_forget") and self.send_displs is not None and
                       self.use_full_boundary else None)
@@ -861,9 +865,10 @@ class DistributedMatrix:
         be = self.backend
         if self._gate is None:
             return be.vector(self.n_local, self.dtype)
-        store = be.exec.zeros((self.n_local + max(self.n_halo, 1),), self.dtype)
+        base = self.nl["full"]["halo_base"]          # the halo starts on a 128-byte boundary
+        store = be.exec.zeros((base + max(self.n_halo, 1),), self.dtype)
         v = Dense(be.exec, store[:self.n_local].view(self.n_local, 1))
-        v._ext_store, v._ext_halo = store, store[self.n_local:self.n_local + self.n_halo]
+        v._ext_store, v._ext_halo = store, store[base:base + self.n_halo]
         return v
 
     def check_gate(self):
@@ -915,7 +920,7 @@ class DistributedMatrix:
         if started and self._gated(x, y):
             # (the all-reduce that was started with the exchange still ends with the join)
             be.gate_open(self._side, self._gate)
-            be.spmv_gated(self.nl, x._ext_store, y, self._gate)
+            be.spmv_gated(self.local, self.nl, x._ext_store, y, self._gate)
             comm.exchange_join()
             return y
         if started:
@@ -933,7 +938,7 @@ class DistributedMatrix:
             comm.exchange_begin(x._ext_halo, x.values, self.recv_counts, self.send_counts, self._side,
                                 self.send_displs)
             be.gate_open(self._side, self._gate)
-            be.spmv_gated(self.nl, x._ext_store, y, self._gate)
+            be.spmv_gated(self.local, self.nl, x._ext_store, y, self._gate)
             comm.exchange_forget()
             return y
         if dot_out is not None:

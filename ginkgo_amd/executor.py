@@ -140,6 +140,26 @@ class Cdna4Executor:
         out.copy_(src)
         return out
 
+    def arena_info(self):
+        """gkoc_arena_stats as a dict (include/gko_cdna4.h gkoc_arena_info)"""
+        class Info(C.Structure):
+            _fields_ = [("mode", C.c_int32), ("num_classes", C.c_int32),
+                        ("chunk_bytes", C.c_int64), ("num_chunks", C.c_int64),
+                        ("reserved_bytes", C.c_int64), ("used_bytes", C.c_int64),
+                        ("num_allocations", C.c_int64), ("probes", C.c_int64),
+                        ("granules_walked", C.c_int64), ("spare_bytes", C.c_int64),
+                        ("class_reserved_bytes", C.c_int64 * 3),
+                        ("class_used_bytes", C.c_int64 * 3),
+                        ("granules_classified", C.c_int64), ("search_ns", C.c_int64),
+                        ("probe_retries", C.c_int64), ("surveyed", C.c_int64)]
+        info = Info()
+        with torch.cuda.device(self.device):
+            _lib.call("gkoc_arena_stats", C.byref(info))
+        out = {name: getattr(info, name) for name, _ in Info._fields_}
+        out["class_reserved_bytes"] = list(info.class_reserved_bytes)
+        out["class_used_bytes"] = list(info.class_used_bytes)
+        return out
+
     def memory_class(self, tensor):
         """memory class (0..2) of a tensor inside the arena's class regions, else -1"""
         c = C.c_int(-1)

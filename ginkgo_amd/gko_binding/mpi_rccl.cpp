@@ -257,13 +257,97 @@ span_bytes extent(const int* counts, const int* displs, int n, size_t tb)
     return s;
 }
 
+// How an exchange travels is a property of the COMMUNICATOR AND THE CALL, never of one rank's
+// pointers: Ginkgo passes nullptr for empty arrays, so an end rank of a
+// one-sided pattern, a rank without halo or an empty rank sees no device pointer at all - if it
+// took the plain MPI call while its peers issued ncclSend / ncclRecv, the job would hang.  Every
+// rank of the communicator enters here on every all-to-all-v (the comm_state is created
+// collectively on the first one); where device buffers can go over RCCL the ranks agree with one
+// two-int all-reduce - does anyone hold a non-empty HOST buffer, does anyone hold a DEVICE buffer:
+//   0 plain MPI (nobody holds a device buffer, or the layer is off)
+//   1 RCCL      (device buffers everywhere they are not empty; a rank with nothing to send or
+//                receive takes part with zero counts and issues no RCCL call)
+//   2 staged    (ranks share a GPU, or host and device buffers are mixed: the MPI call with
+//                host copies of the device ranges - compatible with peers that pass host buffers)
+enum { route_mpi = 0, route_rccl = 1, route_staged = 2 };
+
+bool all_zero(const int* counts, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        if (counts[i] != 0) return false;
+    }
+    return true;
+}
+
+int route_of(MPI_Comm comm, const void* sendbuf, bool send_empty, const void* recvbuf, bool recv_empty)
+{
+    if (env_mode() == 3) return route_mpi;
+    const bool sdev = is_device(sendbuf), rdev = is_device(recvbuf);
+    comm_state* st;
+    {
+        std::lock_guard<std::mutex> g(g_mtx);
+        st = &state_of(comm);       // collective on first use: every rank is here
+    }
+    if (st->m != mode::rccl || st->size == 1) {
+        // every route left is the MPI call itself: a local matter
+        if (st->m == mode::rccl && sdev && rdev) return route_rccl;
+        return (sdev || rdev) ? route_staged : route_mpi;
+    }
+    int mine[2] = {((!sdev && !send_empty) || (!rdev && !recv_empty)) ? 1 : 0, (sdev || rdev) ? 1 : 0};
+    int any[2] = {0, 0};
+    PMPI_Allreduce(mine, any, 2, MPI_INT, MPI_MAX, comm);
+    if (!any[1]) return route_mpi;
+    return any[0] ? route_staged : route_rccl;
+}
+
+// the exchange as grouped ncclSend / ncclRecv on the layer's stream (g_mtx held)
+int rccl_alltoallv_locked(comm_state& st, const void* sendbuf, const int* scounts, const int* sdispls, size_t sb,
+                          void* recvbuf, const int* rcounts, const int* rdispls, size_t rb, MPI_Request* request,
+                          int n)
+{
+    std::vector<int64_t> a(4 * size_t(n));
+    for (int p = 0; p < n; ++p) {
+        a[p] = int64_t(scounts[p]) * int64_t(sb);
+        a[n + p] = int64_t(sdispls[p]) * int64_t(sb);
+        a[2 * n + p] = int64_t(rcounts[p]) * int64_t(rb);
+        a[3 * n + p] = int64_t(rdispls[p]) * int64_t(rb);
+    }
+    if (gkoc_comm_all_to_all_v_bytes(st.rccl, stream(), sendbuf, &a[0], &a[n], recvbuf, &a[2 * n], &a[3 * n]) !=
+        GKOC_OK) {
+        std::fprintf(stderr, "[gkoc_mpi] RCCL all-to-all-v failed: %s\n", gkoc_last_error());
+        return MPI_ERR_OTHER;
+    }
+    g_stats[2]++;
+    if (request) {
+        *request = new_handle();
+        pending p;
+        p.kind = 1;
+        g_pending[*request] = p;
+    } else {
+        gkoc_stream_synchronize(stream());
+    }
+    return MPI_SUCCESS;
+}
+
+int rccl_alltoallv(const void* sendbuf, const int* scounts, const int* sdispls, MPI_Datatype stype, void* recvbuf,
+                   const int* rcounts, const int* rdispls, MPI_Datatype rtype, MPI_Comm comm, MPI_Request* request,
+                   int n)
+{
+    flush_binding();
+    std::lock_guard<std::mutex> g(g_mtx);
+    return rccl_alltoallv_locked(state_of(comm), sendbuf, scounts, sdispls, type_bytes(stype), recvbuf, rcounts,
+                                 rdispls, type_bytes(rtype), request, n);
+}
+
 // the all-to-all-v family, blocking or not (request != nullptr), over the peers of `comm`
 int alltoallv_common(const void* sendbuf, const int* scounts, const int* sdispls, MPI_Datatype stype,
                      void* recvbuf, const int* rcounts, const int* rdispls, MPI_Datatype rtype, MPI_Comm comm,
                      MPI_Request* request, int n_peers_dense)
 {
     const bool sdev = is_device(sendbuf), rdev = is_device(recvbuf);
-    if ((!sdev && !rdev) || env_mode() == 3) {
+    const int n = n_peers_dense;
+    const int route = route_of(comm, sendbuf, all_zero(scounts, n), recvbuf, all_zero(rcounts, n));
+    if (route == route_mpi) {
         g_stats[6]++;
         return request ? PMPI_Ialltoallv(sendbuf, scounts, sdispls, stype, recvbuf, rcounts, rdispls, rtype, comm,
                                          request)
@@ -273,30 +357,8 @@ int alltoallv_common(const void* sendbuf, const int* scounts, const int* sdispls
     std::lock_guard<std::mutex> g(g_mtx);
     comm_state& st = state_of(comm);
     const size_t sb = type_bytes(stype), rb = type_bytes(rtype);
-    const int n = n_peers_dense;
-    if (st.m == mode::rccl && sdev && rdev) {
-        std::vector<int64_t> a(4 * size_t(n));
-        for (int p = 0; p < n; ++p) {
-            a[p] = int64_t(scounts[p]) * int64_t(sb);
-            a[n + p] = int64_t(sdispls[p]) * int64_t(sb);
-            a[2 * n + p] = int64_t(rcounts[p]) * int64_t(rb);
-            a[3 * n + p] = int64_t(rdispls[p]) * int64_t(rb);
-        }
-        if (gkoc_comm_all_to_all_v_bytes(st.rccl, stream(), sendbuf, &a[0], &a[n], recvbuf, &a[2 * n], &a[3 * n]) !=
-            GKOC_OK) {
-            std::fprintf(stderr, "[gkoc_mpi] RCCL all-to-all-v failed: %s\n", gkoc_last_error());
-            return MPI_ERR_OTHER;
-        }
-        g_stats[2]++;
-        if (request) {
-            *request = new_handle();
-            pending p;
-            p.kind = 1;
-            g_pending[*request] = p;
-        } else {
-            gkoc_stream_synchronize(stream());
-        }
-        return MPI_SUCCESS;
+    if (route == route_rccl) {
+        return rccl_alltoallv_locked(st, sendbuf, scounts, sdispls, sb, recvbuf, rcounts, rdispls, rb, request, n);
     }
     // staged: whole touched byte range of each device buffer through pinned memory
     g_stats[3]++;
@@ -394,6 +456,32 @@ int MPI_Finalize(void)
         }
     }
     return PMPI_Finalize();
+}
+
+// Ginkgo creates and frees dist-graph and split communicators per matrix: the state attached to a
+// handle must go with it, or a recycled handle would pick up an RCCL communicator of other ranks
+static void forget_comm(MPI_Comm comm)
+{
+    std::lock_guard<std::mutex> g(g_mtx);
+    auto it = g_comms.find(comm);
+    if (it == g_comms.end()) return;
+    if (it->second.rccl) {
+        gkoc_stream_synchronize(stream());
+        gkoc_comm_destroy(it->second.rccl);
+    }
+    g_comms.erase(it);
+}
+
+int MPI_Comm_free(MPI_Comm* comm)
+{
+    if (comm && *comm != MPI_COMM_NULL) forget_comm(*comm);
+    return PMPI_Comm_free(comm);
+}
+
+int MPI_Comm_disconnect(MPI_Comm* comm)
+{
+    if (comm && *comm != MPI_COMM_NULL) forget_comm(*comm);
+    return PMPI_Comm_disconnect(comm);
 }
 
 int MPI_Allreduce(const void* sendbuf, void* recvbuf, int count, MPI_Datatype datatype, MPI_Op op, MPI_Comm comm)
@@ -569,7 +657,7 @@ int MPI_Ineighbor_alltoallv(const void* sendbuf, const int* sendcounts, const in
                             void* recvbuf, const int* recvcounts, const int* rdispls, MPI_Datatype recvtype,
                             MPI_Comm comm, MPI_Request* request)
 {
-    if ((!is_device(sendbuf) && !is_device(recvbuf)) || env_mode() == 3) {
+    if (env_mode() == 3) {
         g_stats[6]++;
         return PMPI_Ineighbor_alltoallv(sendbuf, sendcounts, sdispls, sendtype, recvbuf, recvcounts, rdispls, recvtype,
                                         comm, request);
@@ -577,26 +665,28 @@ int MPI_Ineighbor_alltoallv(const void* sendbuf, const int* sendcounts, const in
     int indeg = 0, outdeg = 0, weighted = 0, n = 0;
     PMPI_Dist_graph_neighbors_count(comm, &indeg, &outdeg, &weighted);
     PMPI_Comm_size(comm, &n);
-    std::vector<int> src(indeg ? indeg : 1), dst(outdeg ? outdeg : 1), w(indeg + outdeg + 1);
-    PMPI_Dist_graph_neighbors(comm, indeg, src.data(), w.data(), outdeg, dst.data(), w.data());
-    // dense counts over the ranks of the communicator (a neighbour appears once in Ginkgo's graphs)
-    std::vector<int> c(4 * size_t(n), 0);
-    for (int i = 0; i < outdeg; ++i) {
-        c[dst[i]] = sendcounts[i];
-        c[n + dst[i]] = sdispls[i];
+    // the route is agreed by all ranks of the communicator (route_of), not read off local pointers
+    const int route = route_of(comm, sendbuf, all_zero(sendcounts, outdeg), recvbuf, all_zero(recvcounts, indeg));
+    if (route == route_mpi) {
+        g_stats[6]++;
+        return PMPI_Ineighbor_alltoallv(sendbuf, sendcounts, sdispls, sendtype, recvbuf, recvcounts, rdispls, recvtype,
+                                        comm, request);
     }
-    for (int i = 0; i < indeg; ++i) {
-        c[2 * n + src[i]] = recvcounts[i];
-        c[3 * n + src[i]] = rdispls[i];
-    }
-    bool rccl_route;
-    {
-        std::lock_guard<std::mutex> g(g_mtx);
-        rccl_route = state_of(comm).m == mode::rccl && is_device(sendbuf) && is_device(recvbuf);
-    }
-    if (rccl_route) {
-        return alltoallv_common(sendbuf, &c[0], &c[n], sendtype, recvbuf, &c[2 * n], &c[3 * n], recvtype, comm, request,
-                                n);
+    if (route == route_rccl) {
+        std::vector<int> src(indeg ? indeg : 1), dst(outdeg ? outdeg : 1), w(indeg + outdeg + 1);
+        PMPI_Dist_graph_neighbors(comm, indeg, src.data(), w.data(), outdeg, dst.data(), w.data());
+        // dense counts over the ranks of the communicator (a neighbour appears once in Ginkgo's graphs)
+        std::vector<int> c(4 * size_t(n), 0);
+        for (int i = 0; i < outdeg; ++i) {
+            c[dst[i]] = sendcounts[i];
+            c[n + dst[i]] = sdispls[i];
+        }
+        for (int i = 0; i < indeg; ++i) {
+            c[2 * n + src[i]] = recvcounts[i];
+            c[3 * n + src[i]] = rdispls[i];
+        }
+        return rccl_alltoallv(sendbuf, &c[0], &c[n], sendtype, recvbuf, &c[2 * n], &c[3 * n], recvtype, comm, request,
+                              n);
     }
     // staged: keep the neighbourhood call, with host copies of the touched ranges
     flush_binding();

@@ -84,7 +84,10 @@ int gkoc_free(void* ptr);               /* device and managed memory */
  * the role from the size (>= 1/4 of the largest live request: matrix array),
  * gkoc_malloc_role states it.  chunk_bytes (mode 1) 0 keeps the current size (8 GiB,
  * GKOC_ARENA_CHUNK_MB); sync_on_free != 0 keeps hipFree's implicit device
- * synchronisation.  Environment: GKOC_ARENA=<mode>, GKOC_ARENA_VERBOSE=1.
+ * synchronisation.  Environment: GKOC_ARENA=<mode>, GKOC_ARENA_VERBOSE=1,
+ * GKOC_ARENA_MAX_CLASSES=1|2 (use fewer classes: what a device whose free memory lacks a
+ * class looks like), GKOC_ARENA_MAX_WALK=<granules> (bound of one search; default: three
+ * quarters of the free memory).
  * Configure before the first gkoc_malloc. */
 #define GKOC_MEM_AUTO 0
 #define GKOC_MEM_VALUES 1   /* large read-only stream no. 1 (matrix values, Jacobi blocks) */
@@ -103,6 +106,10 @@ typedef struct gkoc_arena_info {
     int64_t spare_bytes;          /* classified granules waiting in the pools      */
     int64_t class_reserved_bytes[3];
     int64_t class_used_bytes[3];
+    int64_t granules_classified;  /* ... of them mapped and probed (the walk gallops)  */
+    int64_t search_ns;            /* host time spent in the searches                    */
+    int64_t probe_retries;        /* classifications repeated: verdict not one-hot      */
+    int64_t surveyed;             /* 1: the one search for all classes has run          */
 } gkoc_arena_info;
 int gkoc_malloc_role(void** ptr, size_t bytes, int role);
 int gkoc_arena_configure(int mode, size_t chunk_bytes, int sync_on_free);
@@ -843,31 +850,47 @@ GKOC_DECL_DIST_IDX(int32_t, i32)
 GKOC_DECL_DIST_IDX(int64_t, i64)
 /* Boundary rows as COMPLETE rows (one column; the fast path of contiguous partitions): the rows
  * `rows` (= nl_rows of the split) of the owned block with ALL their entries in the original
- * column order, a column index < n_local = col_hi - col_lo meaning the rank's own vector and
- * n_local + h halo entry h.  gkoc_csr_rowlist_spmv_full: y[rows[i]] = the k-ordered sum over
+ * column order, a column index < halo_base meaning the rank's own vector and halo_base + h halo
+ * entry h (halo_base >= n_local = col_hi - col_lo: n_local itself, or n_local rounded up so that
+ * a halo stored behind the local vector starts on a 128-byte boundary).  gkoc_csr_rowlist_spmv_full: y[rows[i]] = the k-ordered sum over
  * that row - the single-domain row sum bit for bit.  These rows need nothing from the local
  * SpMV: that one is launched over the interior row range only, and this kernel runs on the
  * exchange's stream right behind the halo, overlapped with it (gkoc_comm_exchange_join). */
-/* The distributed product in ONE kernel: the rank's rows as a CSR over [local columns | halo]
- * (gkoc_dist_boundary_fill_* over all rows), b = the local vector with the halo BEHIND it in the
- * same array (unit stride), c the local result.  The rows that read halo entries - the first
- * head_rows and the last tail_rows - are computed by the last waves of the grid, which wait for
- * gkoc_gate_open(.., epoch) (enqueued on the exchange's stream behind the transfer that fills b's halo
- * part): no second kernel beside the local SpMV and no event its stream waits for.  gate: two uint32
- * in device memory, zero at the start (gate[0] the number of the last exchange that arrived, gate[1]
- * set to 1 by a wave that waited ~10 s in vain - the result is then undefined, check it); epoch: the number of the exchange (1, 2, ... - the caller
- * counts; the product with the same number waits for it).  Results: complete rows in the original
- * column order = the single-domain bits. */
+/* The distributed product in ONE kernel (replaces the local SpMV + the non-local SpMV of
+ * distributed::Matrix::apply, core/distributed/matrix.cpp:450-509, for contiguous partitions):
+ * row_ptrs / col_idxs / vals = the rank's LOCAL block (n_rows rows, local column indices), whose
+ * rows [head_rows, n_rows - tail_rows) read no halo entry; bnd_* = the first head_rows and the last
+ * tail_rows rows as COMPLETE rows over [local columns | halo] in the original column order
+ * (gkoc_dist_boundary_count_* / gkoc_dist_boundary_fill_*: head rows, then tail rows); b = the
+ * local vector with the halo BEHIND it in the same array (unit stride; let the halo start on a
+ * 128-byte boundary: entry n_cols_local of b); c the local result.  The boundary rows are computed
+ * by the last waves of the grid, which wait for gkoc_gate_open(.., epoch) (enqueued on the
+ * exchange's stream behind the transfer that fills b's halo part): no second kernel beside the
+ * local SpMV, no event its stream waits for, no second copy of the matrix.  gate: two uint32 in
+ * device memory, zero at the start (gate[0] the number of the last exchange that arrived, gate[1]
+ * set to 1 by a wave that waited ~10 s in vain - the result is then undefined, check it); epoch:
+ * the number of the exchange (1, 2, ... - the caller counts; the product with the same number
+ * waits for it).  Results: complete rows in the original column order = the single-domain bits.
+ * gkoc_csr_spmv_gated_fits: 1 if the boundary rows are few enough (64 rows per wave, at most 8
+ * waiting waves per compute unit) for the waiting waves to leave the exchange's kernels room on
+ * the device; otherwise the entry refuses (GKOC_E_NOT_SUPPORTED) and the caller runs the
+ * stream-ordered product (gkoc_csr_rowlist_spmv_full_* behind gkoc_comm_exchange_join). */
 #define GKOC_DECL_CSR_GATED(T, TN, I, IN)                                                              \
-    int gkoc_csr_spmv_gated_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,               \
-                                        const I* row_ptrs, const I* col_idxs, const T* vals,           \
-                                        const T* b, T* c, int64_t head_rows, int64_t tail_rows,        \
-                                        const uint32_t* gate, uint32_t epoch);
+    int gkoc_csr_spmv_gated_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,            \
+                                        const I* col_idxs, const T* vals, const I* bnd_ptrs,           \
+                                        const I* bnd_cols, const T* bnd_vals, const T* b, T* c,        \
+                                        int64_t head_rows, int64_t tail_rows, const uint32_t* gate,    \
+                                        uint32_t epoch);
 GKOC_DECL_CSR_GATED(double, f64, int32_t, i32)
 GKOC_DECL_CSR_GATED(double, f64, int64_t, i64)
 GKOC_DECL_CSR_GATED(float, f32, int32_t, i32)
 GKOC_DECL_CSR_GATED(float, f32, int64_t, i64)
+int gkoc_csr_spmv_gated_fits(int64_t n_rows, int64_t head_rows, int64_t tail_rows);
 int gkoc_gate_open(gkoc_stream_t s, uint32_t* gate, uint32_t epoch);
+/* Diagnostic: `blocks` workgroups of `threads` threads with `lds_bytes` of LDS each that stay on
+ * the device for `usec` microseconds (tests of the gated product: a late exchange, an RCCL-sized
+ * kernel that has to find room next to waiting waves). */
+int gkoc_debug_delay(gkoc_stream_t s, int64_t usec, int blocks, int threads, int lds_bytes);
 #define GKOC_DECL_DIST_BND_IDX(I, IN)                                          \
     int gkoc_dist_boundary_count_##IN(gkoc_stream_t s, int64_t n_list,         \
                                       const I* rows, const I* row_ptrs,        \
@@ -878,10 +901,11 @@ GKOC_DECL_DIST_BND_IDX(int64_t, i64)
     int gkoc_dist_boundary_fill_##TN##_##IN(                                   \
         gkoc_stream_t s, int64_t n_list, const I* rows, const I* row_ptrs,     \
         const I* cols, const T* vals, int64_t col_lo, int64_t col_hi,          \
-        const I* col_map, const I* out_ptrs, I* out_cols, T* out_vals);        \
+        int64_t halo_base, const I* col_map, const I* out_ptrs, I* out_cols,   \
+        T* out_vals);                                                          \
     int gkoc_csr_rowlist_spmv_full_##TN##_##IN(                                \
         gkoc_stream_t s, int64_t n_list, const I* rows, const I* ptrs,         \
-        const I* cols, const T* vals, int64_t n_local, const T* x,             \
+        const I* cols, const T* vals, int64_t halo_base, const T* x,           \
         const T* halo, T* y);                                                  \
     int gkoc_dist_split_fill_##TN##_##IN(                                      \
         gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,     \

@@ -121,6 +121,31 @@ def test_bench_command_path_with_eight_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_starts_its_own_ranks_and_the_line_has_every_key():
+    """`python bench.py --gpus 8 ...` WITHOUT a launcher: the script starts
+    its ranks itself; the N > 1 line carries cpu_baseline (the N = 1 figure, labelled), the per-rank
+    roofline, the communicator check and what every rank's allocator found."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--grid", "64", "--steps", "3",
+           "--warmup", "1", "--cg-iters", "10"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GKO_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n--- stderr ---\n" + p.stderr[-12000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["partition"] == "8 z-slab(s)"
+    assert "cpu_baseline" in d and "no CPU twin at N > 1" in d["cpu_baseline"]["note"]
+    pr = d["roofline"]["per_rank"]
+    assert len(pr) == 8 and all(r["kernel_ms"] > 0 and r["frac"] > 0 for r in pr)
+    assert all(1 <= r["memory_classes_found"] <= 3 for r in pr)
+    assert d["comm_check"]["ranks"] == 8 and "memory_classes_found" in d["config"]
+    assert d["cg_iterations"] == 10 and d["pipe_cg_iterations"] == 10
+
+
+@pytest.mark.gpu
 def test_distributed_single_rank_matches_plain(gexec, oracle):
     """world = 1: the distributed wrapper degenerates to the plain SpMV / CG"""
     import torch.distributed as dist
@@ -212,44 +237,158 @@ def test_overlap_branch_with_mirror_comm(gexec, oracle):
     assert np.linalg.norm(xg_.to_numpy()[:, 0] - xo2[lo:hi]) / np.linalg.norm(xo2[lo:hi]) < 1e-7
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("grid,world,rank", [(12, 3, 1), (16, 2, 0), (9, 3, 2), (20, 4, 2)])
-def test_one_kernel_product_has_the_single_domain_bits(gexec, oracle, grid, world, rank):
-    """gkoc_csr_spmv_gated_* (the rank's rows over [local columns | halo], b = the local vector
-    with the halo behind it, the boundary segments computed by the last waves of the grid behind
-    a gate): every row equals the single-domain product bit for bit - interior ranks (halo on both
-    sides), first and last rank, planes that are not multiples of the 64-row segments - and the
-    gate counts across repeated products."""
-    import torch
+def _slab(gexec, oracle_, grid, world, rank, nz=None):
+    """one rank's slab of the 27-pt grid^3 problem, split on the device"""
     import ginkgo_amd as g
     import ginkgo_amd.distributed as gd
-
-    n = grid ** 3
-    rp, ci, v = oracle.stencil_csr(3, grid)
     part = gd.SlabPartition(grid, world)
     lo, hi = part.range_of(rank)
     z0, z1 = part.plane_offsets[rank], part.plane_offsets[rank + 1]
     owned = g.stencil_csr(gexec, 3, grid, z0=z0, nz=z1 - z0)
     be = gd.HipBackend(gexec)
-    local, nl, recv_gidx = be.split(owned, lo, hi, n)
-    assert "ext" in nl and nl["ext"]["n_cols"] == (hi - lo) + recv_gidx.numel()
+    local, nl, recv_gidx = be.split(owned, lo, hi, grid ** 3)
+    return be, local, nl, recv_gidx, lo, hi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid,world,rank", [(12, 3, 1), (16, 2, 0), (9, 3, 2), (20, 4, 2), (12, 12, 5)])
+def test_one_kernel_product_has_the_single_domain_bits(gexec, oracle, grid, world, rank):
+    """gkoc_csr_spmv_gated_* (interior rows from the rank's local block, the boundary rows as
+    complete rows over [local columns | halo] on the last waves of the same launch, behind a gate;
+    b = the local vector with the halo behind it on a 128-byte boundary): every row equals the
+    single-domain product bit for bit - interior ranks (halo on both sides), first and last rank,
+    planes that are not multiples of the 64-row segments, a one-plane slab where EVERY row is a
+    boundary row - and the gate counts across repeated products."""
+    import torch
+
+    n = grid ** 3
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    be, local, nl, recv_gidx, lo, hi = _slab(gexec, oracle, grid, world, rank)
+    f = nl["full"]
+    assert f["gated"] and f["halo_base"] % 32 == 0 and f["halo_base"] >= hi - lo
+    assert f["head"] + f["tail"] == nl["n"] and "ext" not in nl      # no second copy of the matrix
     xg = np.random.default_rng(grid + rank).uniform(-1, 1, n)
     ref = oracle.csr_spmv(rp, ci, v, xg)[lo:hi]
-    store = gexec.zeros((nl["ext"]["n_cols"],), torch.float64)
+    store = gexec.zeros((f["halo_base"] + recv_gidx.numel(),), torch.float64)
     store[:hi - lo] = torch.from_numpy(xg[lo:hi]).to(store.device)
     y = be.vector(hi - lo)
     gate = be.gate_new()
     halo = torch.from_numpy(xg[recv_gidx.cpu().numpy().astype(np.int64)]).to(store.device)
     for rep in range(3):
-        store[hi - lo:] = halo if rep != 1 else 0.0      # rep 1: a wrong halo must show
+        store[f["halo_base"]:] = halo if rep != 1 else 0.0      # rep 1: a wrong halo must show
         be.gate_open(torch.cuda.current_stream(), gate)   # the "exchange" is done: same stream, in front
-        be.spmv_gated(nl, store, y, gate)
+        be.spmv_gated(local, nl, store, y, gate)
         got = y.to_numpy()[:, 0]
         if rep == 1 and recv_gidx.numel():
             assert not np.array_equal(got, ref)
         else:
             assert np.array_equal(got, ref), rep
     assert int(gate[0][0].item()) == 3 and int(gate[0][1].item()) == 0 and gate[1].value == 3
+
+
+def _late_gate(gexec, be, local, nl, recv_gidx, x_local, halo_vals, delay_us=5000):
+    """the product on the main stream, its halo and gate_open on a side stream BEHIND a kernel that
+    sleeps delay_us and an RCCL-sized kernel (64 workgroups x 512 threads, 32 KB of LDS each) that
+    has to find room next to the waiting boundary waves; returns (y, elapsed ms, gate words)"""
+    import ctypes as C
+    import torch
+    from ginkgo_amd._lib import call
+    f = nl["full"]
+    n = x_local.numel()
+    store = gexec.zeros((f["halo_base"] + max(recv_gidx.numel(), 1),), torch.float64)
+    store[:n] = x_local
+    y = be.vector(n)
+    gate = be.gate_new()
+    side = be.side_stream()
+    main = torch.cuda.current_stream()
+    # warm both kernels up with an open gate (first launches load code objects)
+    be.gate_open(main, gate)
+    be.spmv_gated(local, nl, store, y, gate)
+    call("gkoc_debug_delay", C.c_void_p(side.cuda_stream), C.c_int64(10), 1, 64, 0)
+    torch.cuda.synchronize()
+    store[f["halo_base"]:f["halo_base"] + recv_gidx.numel()] = 0.0    # the halo of the "previous iteration"
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sst = C.c_void_p(side.cuda_stream)
+    e0.record(main)
+    call("gkoc_debug_delay", sst, C.c_int64(delay_us), 1, 64, 0)        # the exchange is late ...
+    with torch.cuda.stream(side):
+        store[f["halo_base"]:f["halo_base"] + recv_gidx.numel()].copy_(halo_vals)     # ... arrives ...
+    call("gkoc_debug_delay", sst, C.c_int64(20), 64, 512, 32768)        # ... through RCCL-sized kernels
+    be.gate_open(side, gate)
+    be.spmv_gated(local, nl, store, y, gate)                              # main stream: no event, no join
+    e1.record(main)
+    torch.cuda.synchronize()
+    return y, e0.elapsed_time(e1), [int(v) for v in gate[0].tolist()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid,world,rank", [(256, 8, 3), (64, 64, 7)])
+def test_one_kernel_product_waits_for_a_late_halo(gexec, oracle, grid, world, rank):
+    """The waiting branch: the halo arrives 5 ms AFTER the product was
+    launched, behind kernels on another stream that need room on the device while the boundary waves
+    spin - (256, 8): the per-rank slab of the 8-GPU run, 2048 waiting waves; (64, 64): a one-plane
+    slab, every wave waits.  The product must wait (about 5 ms, not the 10 s of its give-up), take
+    the late halo (bit-identical to the single-domain rows) and leave gate[1] == 0."""
+    import torch
+    n = grid ** 3
+    be, local, nl, recv_gidx, lo, hi = _slab(gexec, oracle, grid, world, rank)
+    assert nl["full"]["gated"]
+    xg = torch.from_numpy(np.random.default_rng(7).uniform(-1, 1, n)).to(gexec.device)
+    halo = xg[recv_gidx.long()]
+    y, ms, words = _late_gate(gexec, be, local, nl, recv_gidx, xg[lo:hi], halo)
+    assert words[1] == 0, "a boundary wave gave up waiting"
+    assert 4.5 < ms < 60.0, ms
+    # reference: the same rows through the stream-ordered kernels (bit-identical to the oracle's
+    # single-domain rows: test_one_kernel_product_has_the_single_domain_bits)
+    import ginkgo_amd as g
+    f = nl["full"]
+    y2 = be.vector(hi - lo)
+    xl = g.Dense(gexec, xg[lo:hi].clone().view(-1, 1))
+    hv = g.Dense(gexec, halo.clone().view(-1, 1))
+    be.spmv_rows(local, f["interior"][0], f["interior"][1], xl, y2)
+    be.rowlist_full(nl, xl, hv, y2)
+    assert torch.equal(y.values, y2.values)
+    if grid <= 64:
+        rp, ci, v = oracle.stencil_csr(3, grid)
+        assert np.array_equal(y.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v, xg.cpu().numpy())[lo:hi])
+
+
+@pytest.mark.gpu
+def test_big_slabs_take_the_join_based_product(gexec, oracle):
+    """config 3's slab has 512^2-row planes: 2 x 4096 boundary waves, more than may wait on the device
+    at once.  The one-kernel product refuses it (gkoc_csr_spmv_gated_fits / GKOC_E_NOT_SUPPORTED) and
+    DistributedMatrix falls back to the stream-ordered product; checked on a thin slab of that
+    cross-section."""
+    import ctypes as C
+    import torch
+    import ginkgo_amd as g
+    import ginkgo_amd.distributed as gd
+    from ginkgo_amd import _lib
+    L = _lib.lib()
+    assert L.gkoc_csr_spmv_gated_fits(C.c_int64(8 * 256 * 256), C.c_int64(256 * 256), C.c_int64(256 * 256)) == 1
+    assert L.gkoc_csr_spmv_gated_fits(C.c_int64(64 * 512 * 512), C.c_int64(512 * 512), C.c_int64(512 * 512)) == 0
+    assert L.gkoc_csr_spmv_gated_fits(C.c_int64(100), C.c_int64(0), C.c_int64(0)) == 0
+    # a slab of 4 planes out of 512 x 512 x 12 (the generator takes any plane range of a cube; use a
+    # 512-cube's planes 4..8 so that both neighbours exist)
+    grid, z0, nz = 512, 4, 4
+    n_plane = grid * grid
+    owned = g.stencil_csr(gexec, 3, grid, z0=z0, nz=nz)
+    be = gd.HipBackend(gexec)
+    lo, hi = z0 * n_plane, (z0 + nz) * n_plane
+    local, nl, recv_gidx = be.split(owned, lo, hi, grid ** 3)
+    f = nl["full"]
+    assert f["head"] == n_plane and f["tail"] == n_plane and not f["gated"]
+    gate = be.gate_new()
+    store = gexec.zeros((f["halo_base"] + recv_gidx.numel(),), torch.float64)
+    y = be.vector(hi - lo)
+    rc = L.gkoc_csr_spmv_gated_f64_i32(gexec.stream, C.c_int64(hi - lo), C.c_void_p(local.row_ptrs.data_ptr()),
+                                       C.c_void_p(local.col_idxs.data_ptr()), C.c_void_p(local.values.data_ptr()),
+                                       C.c_void_p(f["ptrs"].data_ptr()), C.c_void_p(f["cols"].data_ptr()),
+                                       C.c_void_p(f["vals"].data_ptr()), C.c_void_p(store.data_ptr()),
+                                       C.c_void_p(y.values.data_ptr()), C.c_int64(n_plane), C.c_int64(n_plane),
+                                       C.c_void_p(gate[0].data_ptr()), C.c_uint32(1))
+    assert rc != 0 and b"gkoc_csr_spmv_gated_fits" in L.gkoc_last_error()
 
 
 @pytest.mark.gpu

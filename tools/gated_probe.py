@@ -1,5 +1,5 @@
-"""one rank of 8 (256^3): the local block, the ext matrix ([local | halo] columns) through the plain CSR
-kernel, and the gated one-kernel product with the gate opened in advance (development probe)."""
+"""one rank of 8 (256^3): the local block through the plain CSR kernel, the join-based product's two
+kernels, and the gated one-kernel product with the gate opened in advance (development probe)."""
 import ctypes as C
 import os
 import sys
@@ -21,13 +21,12 @@ owned = g.stencil_csr(ex, 3, grid, z0=z0, nz=z1 - z0)
 be = gd.HipBackend(ex)
 local, nl, recv_gidx = be.split(owned, lo, hi, grid ** 3)
 n = hi - lo
-e = nl["ext"]
-ext = g.Csr(ex, (n, e["n_cols"]), e["vals"], e["cols"], e["ptrs"])
-print("classes local", local.memory_classes(), "ext", ext.memory_classes())
-store = ex.zeros((e["n_cols"],), torch.float64)
-store.copy_(torch.rand(e["n_cols"], dtype=torch.float64, device=store.device))
+f = nl["full"]
+print("classes local", local.memory_classes(), "gated admitted:", f.get("gated"))
+store = ex.zeros((f["halo_base"] + f["n_halo"],), torch.float64)
+store.copy_(torch.rand(store.numel(), dtype=torch.float64, device=store.device))
 x = g.Dense(ex, store[:n].view(n, 1))
-xe = g.Dense(ex, store.view(-1, 1))
+halo = g.Dense(ex, store[f["halo_base"]:].view(-1, 1))
 y = g.Dense.create(ex, (n, 1))
 y2 = g.Dense.create(ex, (n, 1))
 gate = be.gate_new()
@@ -48,13 +47,20 @@ def tm(name, fn, reps=50):
 
 
 tm("local block (local columns only)", lambda: local.apply(x, y))
-tm("ext matrix, plain CSR kernel over [x | halo]", lambda: ext.apply(xe, y))
+
+
+def joined():
+    be.spmv_rows(local, f["interior"][0], f["interior"][1], x, y)
+    be.rowlist_full(nl, x, halo, y)
+
+
+tm("interior rows + complete boundary rows, two kernels", joined)
 
 
 def gated():
     be.gate_open(torch.cuda.current_stream(), gate)     # opened in front of the kernel, same stream
-    be.spmv_gated(nl, store, y2, gate)
+    be.spmv_gated(local, nl, store, y2, gate)
 
 
 tm("gated one-kernel product, gate opened in advance", gated)
-print("same bits as the plain kernel on the ext matrix:", bool(torch.equal(y.values, y2.values)))
+print("same bits as the two kernels:", bool(torch.equal(y.values, y2.values)))
