@@ -474,7 +474,7 @@ try {
                 CK(gkoc_x_pipe_cg_steps_jacobi_f64_i32(s, num_blocks, n, bs, scheme, block_ptrs.p, blocks.p, x.p,
                                                        r.p, z.p, w->p, p.p, q.p, f->p, g->p, m->p, nn->p, prev,
                                                        cur, cur + 1, betas[parity], betas[1 - parity], stop.p,
-                                                       prev, x_ws.p, x_bytes));
+                                                       prev, x_ws.p, x_bytes, nullptr));
             }
         }
     }

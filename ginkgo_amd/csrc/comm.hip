@@ -14,6 +14,7 @@
 // dependency on it and loads on machines without RCCL.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -107,7 +108,42 @@ int rccl_fail(int e, const char* what, int line)
 
 }  // namespace
 
+// ---- a fork without an event ---------------------------------------------------------------
+// "side waits for what main has enqueued so far" as an event record + hipStreamWaitEvent is a
+// barrier packet on the MAIN queue: the device idles 6-7 us before main's next kernel starts
+// (profiles/r03_dist_sim_timelines.txt).  Two one-thread kernels do the same without touching
+// main's queue state: main stores the fork's number into a word, side polls the word.  The kernel
+// that follows on the side stream starts after the poller has ended, i.e. after main's work in
+// front of the store has been released to the device (end-of-kernel release of the storing
+// kernel's predecessors, start-of-kernel acquire of the follower).  The poller is one wave; it is
+// enqueued AFTER the store, so a queue that serialises the two streams still makes progress.
+__global__ void fork_set_kernel(uint32_t* word, uint32_t number)
+{
+    __hip_atomic_store(word, number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void fork_wait_kernel(const uint32_t* word, uint32_t number)
+{
+    long spins = 0;
+    while (int32_t(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - number) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (long(1) << 26)) break;     // ~1 min: never hang a queue for good
+    }
+}
+
+int fork_by_kernels(hipStream_t ms, hipStream_t xs, uint32_t* word, uint32_t number)
+{
+    fork_set_kernel<<<dim3(1), dim3(1), 0, ms>>>(word, number);
+    GKOC_LAUNCH_OK();
+    fork_wait_kernel<<<dim3(1), dim3(1), 0, xs>>>(word, number);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
 struct gkoc_comm_s {
+    uint32_t* fork_word = nullptr;   // forks are kernels (unless GKOC_COMM_FORK=event)
+    uint32_t fork_number = 0;
+    bool fork_deferred = false;      // the next fork's store is the caller's kernel (gkoc_comm_fork_deferred)
     nccl_comm comm = nullptr;
     int n_ranks = 0, rank = 0;
     hipEvent_t packed = nullptr;   // main -> side: the send buffer is ready
@@ -121,7 +157,60 @@ struct gkoc_comm_s {
 
 using namespace gkoc;
 
+namespace {
+// main -> side: everything enqueued on ms so far happens before what is enqueued on xs from now on
+int comm_fork(gkoc_comm_s* comm, hipEvent_t ev, hipStream_t ms, hipStream_t xs)
+{
+    if (comm->fork_word && comm->fork_deferred) {
+        // the number was handed to the caller, whose next kernel on ms stores it
+        comm->fork_deferred = false;
+        fork_wait_kernel<<<dim3(1), dim3(1), 0, xs>>>(comm->fork_word, comm->fork_number);
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
+    if (comm->fork_word) return fork_by_kernels(ms, xs, comm->fork_word, ++comm->fork_number);
+    GKOC_HIP(hipEventRecord(ev, ms));
+    GKOC_HIP(hipStreamWaitEvent(xs, ev, 0));
+    return GKOC_OK;
+}
+}  // namespace
+
 extern "C" {
+
+int gkoc_stream_fork(gkoc_stream_t main_stream, gkoc_stream_t side, uint32_t* word, uint32_t number)
+{
+    GKOC_REQUIRE(word && side != main_stream, GKOC_E_INVALID, "bad argument");
+    return fork_by_kernels(as_stream(main_stream), as_stream(side), word, number);
+}
+
+int gkoc_stream_fork_wait(gkoc_stream_t side, const uint32_t* word, uint32_t number)
+{
+    GKOC_REQUIRE(word, GKOC_E_INVALID, "word == NULL");
+    fork_wait_kernel<<<dim3(1), dim3(1), 0, as_stream(side)>>>(word, number);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+int gkoc_comm_fork_deferred(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_stream_t side,
+                            uint32_t** word, uint32_t* number)
+{
+    GKOC_REQUIRE(comm && word && number, GKOC_E_INVALID, "bad argument");
+    *word = nullptr;
+    *number = 0;
+    if (!comm->fork_word || side == nullptr || side == main_stream) return GKOC_OK;
+    // a poller enqueued BEFORE the kernel that stores must not sit in front of it in one hardware
+    // queue: streams of different priority never share one
+    int pm = 0, ps = 0;
+    if (hipStreamGetPriority(as_stream(main_stream), &pm) != hipSuccess ||
+        hipStreamGetPriority(as_stream(side), &ps) != hipSuccess || pm == ps) {
+        (void)hipGetLastError();
+        return GKOC_OK;
+    }
+    comm->fork_deferred = true;
+    *word = comm->fork_word;
+    *number = ++comm->fork_number;
+    return GKOC_OK;
+}
 
 int gkoc_comm_load_rccl(const char* librccl_path) { return load_rccl(librccl_path); }
 
@@ -161,6 +250,17 @@ int gkoc_comm_create(gkoc_comm_t* comm, int n_ranks, int rank, const void* id)
         set_last_error("gkoc_comm_create: hipEventCreate failed");
         return GKOC_E_COMM;
     }
+    // forks as kernels (see fork_set_kernel): GKOC_COMM_FORK=event selects the event pair
+    const char* fk = std::getenv("GKOC_COMM_FORK");
+    if (!(fk && std::strcmp(fk, "event") == 0)) {
+        void* w = nullptr;
+        if (gkoc_malloc(&w, 256) == GKOC_OK && hipMemset(w, 0, 256) == hipSuccess) {
+            c->fork_word = static_cast<uint32_t*>(w);
+        } else {
+            (void)hipGetLastError();
+            if (w) (void)gkoc_free(w);
+        }
+    }
     *comm = c;
     return GKOC_OK;
 }
@@ -168,6 +268,10 @@ int gkoc_comm_create(gkoc_comm_t* comm, int n_ranks, int rank, const void* id)
 int gkoc_comm_destroy(gkoc_comm_t comm)
 {
     if (!comm) return GKOC_OK;
+    if (comm->fork_word) {
+        (void)hipDeviceSynchronize();
+        (void)gkoc_free(comm->fork_word);
+    }
     if (comm->packed) (void)hipEventDestroy(comm->packed);
     if (comm->arrived) (void)hipEventDestroy(comm->arrived);
     if (comm->reduce_in) (void)hipEventDestroy(comm->reduce_in);
@@ -218,10 +322,7 @@ int gkoc_comm_all_reduce_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc
     hipStream_t xs = overlapped ? as_stream(side) : ms;
     GKOC_REQUIRE(!comm->pending_side || xs == comm->side_in_use, GKOC_E_INVALID,
                  "gkoc_comm_all_reduce_begin: an exchange is pending on another stream");
-    if (overlapped) {
-        GKOC_HIP(hipEventRecord(comm->reduce_in, ms));
-        GKOC_HIP(hipStreamWaitEvent(xs, comm->reduce_in, 0));
-    }
+    if (overlapped) GKOC_TRY(comm_fork(comm, comm->reduce_in, ms, xs));
     GKOC_RCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n),
                                value_size == 8 ? nccl_float64 : nccl_float32, nccl_sum, comm->comm,
                                xs));
@@ -265,10 +366,7 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
     GKOC_REQUIRE(send_buf && recv_buf, GKOC_E_INVALID, "NULL buffer with non-zero counts");
     GKOC_REQUIRE(!comm->pending_reduce || xs == comm->side_in_use, GKOC_E_INVALID,
                  "gkoc_comm_exchange_begin: an all-reduce is pending on another stream");
-    if (overlapped) {
-        GKOC_HIP(hipEventRecord(comm->packed, ms));
-        GKOC_HIP(hipStreamWaitEvent(xs, comm->packed, 0));
-    }
+    if (overlapped) GKOC_TRY(comm_fork(comm, comm->packed, ms, xs));
     const char* sp = static_cast<const char*>(send_buf);
     char* rp = static_cast<char*>(recv_buf);
     GKOC_RCCL(g_rccl.GroupStart());
@@ -324,8 +422,7 @@ int gkoc_comm_all_reduce_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_str
         n_msgs += (send_counts[p] > 0) + (recv_counts[p] > 0);
     }
     GKOC_REQUIRE(n_msgs == 0 || (send_buf && recv_buf), GKOC_E_INVALID, "NULL buffer with non-zero counts");
-    GKOC_HIP(hipEventRecord(comm->packed, ms));
-    GKOC_HIP(hipStreamWaitEvent(xs, comm->packed, 0));
+    GKOC_TRY(comm_fork(comm, comm->packed, ms, xs));
     GKOC_RCCL(g_rccl.AllReduce(reduce_buf, reduce_buf, static_cast<size_t>(reduce_n),
                                reduce_value_size == 8 ? nccl_float64 : nccl_float32, nccl_sum, comm->comm, xs));
     if (n_msgs > 0) {

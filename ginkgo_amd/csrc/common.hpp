@@ -69,7 +69,7 @@ int scratch_free(hipStream_t st, void* ptr);
     } while (0)
 
 // tuning switches (runtime.hip; keys = GKOC_TUNE_* of gko_cdna4.h)
-constexpr int tune_num_keys = 7;
+constexpr int tune_num_keys = 9;
 int64_t tune_value(int key);
 
 #ifdef __HIPCC__

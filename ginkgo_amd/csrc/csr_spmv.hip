@@ -197,7 +197,9 @@ bool gated_fits(int64_t n_rows, int64_t head_rows, int64_t tail_rows)
 template <typename T, typename I>
 int launch_csr_gated(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs, const T* vals,
                      const I* bnd_ptrs, const I* bnd_cols, const T* bnd_vals, const T* b, T* c,
-                     int64_t head_rows, int64_t tail_rows, const uint32_t* gate, uint32_t epoch)
+                     int64_t head_rows, int64_t tail_rows, const uint32_t* gate, uint32_t epoch,
+                     uint32_t* fork_word, uint32_t fork_number, T* dot_out = nullptr, void* work = nullptr,
+                     size_t work_bytes = 0)
 {
     GKOC_REQUIRE(n_rows > 0 && head_rows >= 0 && tail_rows >= 0 && head_rows + tail_rows <= n_rows,
                  GKOC_E_INVALID, "bad dimensions");
@@ -218,19 +220,51 @@ int launch_csr_gated(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I
     const int64_t n_int = ceildiv(n_rows - head_rows - tail_rows, 64);
     const int64_t n_bnd = ceildiv(head_rows + tail_rows, 64);
     GKOC_REQUIRE(n_int + n_bnd < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 row segments");
+    T* partial = nullptr;
+    if (dot_out) {
+        // one partial sum per wave (interior waves first, then the boundary waves)
+        GKOC_REQUIRE(work && work_bytes >= fused_workspace_bytes(n_rows + 128, sizeof(T)), GKOC_E_WORKSPACE,
+                     "workspace too small (gkoc_x_workspace_bytes(n_rows + 128))");
+        partial = static_cast<T*>(work);
+    }
     const dim3 grid(static_cast<unsigned>(n_int + n_bnd)), block(64);
     constexpr int PE = sizeof(T) == 8 ? 2 : 4, PU = sizeof(T) == 8 ? 3 : 2;
-#define GKOC_LAUNCH_GATED(E_, U_)                                                                 \
-    csr_spmv_pipe3_kernel<T, I, false, 64, E_, U_, RINGV, 1, 0x11000><<<grid, block, 0, as_stream(s)>>>( \
-        n_rows, n_int + n_bnd, 1, row_ptrs, col_idxs, vals, b, 1, c, 1, 1, nullptr, nullptr, nullptr, 0, \
-        nullptr, nullptr, head_rows, tail_rows, gate, epoch, bnd_ptrs, bnd_cols, bnd_vals)
-    if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_int < 32768) {
-        GKOC_LAUNCH_GATED(EV, 1);
+#define GKOC_LAUNCH_GATED(E_, U_, MODE_)                                                           \
+    csr_spmv_pipe3_kernel<T, I, false, 64, E_, U_, RINGV, 1, MODE_><<<grid, block, 0, as_stream(s)>>>( \
+        n_rows, n_int + n_bnd, 1, row_ptrs, col_idxs, vals, b, 1, c, 1, 1, nullptr, nullptr, partial, 0, \
+        nullptr, nullptr, head_rows, tail_rows, gate, epoch, bnd_ptrs, bnd_cols, bnd_vals, fork_word,    \
+        fork_number, gate_fence, bnd_first)
+    const int gate_fence = tune_value(GKOC_TUNE_GATE_FENCE) != 0 ? 1 : 0;
+    // where in the grid the boundary waves sit: GKOC_TUNE_GATE_POS per cent of the interior waves
+    // in front of them (100 = they are the last waves)
+    int64_t pos = tune_value(GKOC_TUNE_GATE_POS);
+    if (pos < 0 || pos > 100) pos = 100;
+    const int64_t bnd_first = pos >= 100 ? -1 : n_int * pos / 100;
+    // load layout: the two-entry loads with three groups in flight of the full-size kernel also for a
+    // rank's share of a strong-scaling run (30 000 waves, 130 us: 2 us per product faster than one
+    // 32-byte load per lane and stream, profiles/r04_dist_sim_variants.txt); GKOC_TUNE_CSR_LOAD_GROUPS = 1
+    // selects the other
+    const bool wide = tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1;
+    if (dot_out) {
+        if (wide) {
+            GKOC_LAUNCH_GATED(EV, 1, 0x11040);
+        } else {
+            GKOC_LAUNCH_GATED(PE, PU, 0x11040);
+        }
+    } else if (wide) {
+        GKOC_LAUNCH_GATED(EV, 1, 0x11000);
     } else {
-        GKOC_LAUNCH_GATED(PE, PU);
+        GKOC_LAUNCH_GATED(PE, PU, 0x11000);
     }
 #undef GKOC_LAUNCH_GATED
     GKOC_LAUNCH_OK();
+    if (dot_out) {
+        // ONE fold launch whatever the count (<= 2^31 / 64 partial sums would still be one block's
+        // loop; a rank's share has some 30 000): fixed tree, the value does not depend on timing
+        fold_partials_wide_kernel<T><<<dim3(1), dim3(fold_block), 0, as_stream(s)>>>(n_int + n_bnd, partial,
+                                                                                      dot_out);
+        GKOC_LAUNCH_OK();
+    }
     return GKOC_OK;
 }
 
@@ -591,15 +625,34 @@ GKOC_DEF_CSR_SORT(gkoc_c64, c64, int64_t, i64)
     extern "C" int gkoc_csr_spmv_gated_##TN##_##IN(                                                   \
         gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs, const T* vals,         \
         const I* bnd_ptrs, const I* bnd_cols, const T* bnd_vals, const T* b, T* c, int64_t head_rows, \
-        int64_t tail_rows, const uint32_t* gate, uint32_t epoch)                                      \
+        int64_t tail_rows, const uint32_t* gate, uint32_t epoch, uint32_t* fork_word,                 \
+        uint32_t fork_number)                                                                         \
     {                                                                                                 \
         return launch_csr_gated<T, I>(s, n_rows, row_ptrs, col_idxs, vals, bnd_ptrs, bnd_cols,        \
-                                      bnd_vals, b, c, head_rows, tail_rows, gate, epoch);             \
+                                      bnd_vals, b, c, head_rows, tail_rows, gate, epoch, fork_word,   \
+                                      fork_number);                                                   \
     }
 GKOC_DEF_CSR_GATED(double, f64, int32_t, i32)
 GKOC_DEF_CSR_GATED(double, f64, int64_t, i64)
 GKOC_DEF_CSR_GATED(float, f32, int32_t, i32)
 GKOC_DEF_CSR_GATED(float, f32, int64_t, i64)
+
+#define GKOC_DEF_CSR_GATED_DOT(T, TN, I, IN)                                                         \
+    extern "C" int gkoc_x_csr_spmv_gated_dot_##TN##_##IN(                                             \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs, const T* vals,         \
+        const I* bnd_ptrs, const I* bnd_cols, const T* bnd_vals, const T* b, T* c, int64_t head_rows, \
+        int64_t tail_rows, const uint32_t* gate, uint32_t epoch, uint32_t* fork_word,                 \
+        uint32_t fork_number, T* dot_out, void* work, size_t work_bytes)                              \
+    {                                                                                                 \
+        GKOC_REQUIRE(dot_out, GKOC_E_INVALID, "null result");                                         \
+        return launch_csr_gated<T, I>(s, n_rows, row_ptrs, col_idxs, vals, bnd_ptrs, bnd_cols,        \
+                                      bnd_vals, b, c, head_rows, tail_rows, gate, epoch, fork_word,   \
+                                      fork_number, dot_out, work, work_bytes);                        \
+    }
+GKOC_DEF_CSR_GATED_DOT(double, f64, int32_t, i32)
+GKOC_DEF_CSR_GATED_DOT(double, f64, int64_t, i64)
+GKOC_DEF_CSR_GATED_DOT(float, f32, int32_t, i32)
+GKOC_DEF_CSR_GATED_DOT(float, f32, int64_t, i64)
 
 extern "C" int gkoc_csr_spmv_gated_fits(int64_t n_rows, int64_t head_rows, int64_t tail_rows)
 {

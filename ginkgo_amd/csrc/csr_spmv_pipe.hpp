@@ -57,7 +57,8 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     int* __restrict__ unsorted_flag = nullptr, int64_t head_rows = 0, int64_t tail_rows = 0,
     const uint32_t* __restrict__ gate = nullptr, uint32_t gate_epoch = 0,
     const I* __restrict__ bnd_ptrs = nullptr, const I* __restrict__ bnd_cols = nullptr,
-    const V* __restrict__ bnd_vals = nullptr)
+    const V* __restrict__ bnd_vals = nullptr, uint32_t* __restrict__ fork_word = nullptr,
+    uint32_t fork_number = 0, int gate_fence = 0, int64_t bnd_first = -1)
 {
     // (GATE mode points a wave at one of two matrices; everywhere else these are the arguments)
     int64_t n_rows = n_rows_in, n_segments = n_segments_in;
@@ -138,10 +139,24 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     // (gkoc_csr_spmv_gated_fits), so the exchange's kernels and gkoc_gate_open always find room.
     constexpr bool GATE = (ABL & 0x10000) != 0;
     if constexpr (GATE) {
+        // The fork of the exchange: "b is final" is what this kernel's START means on its stream, so
+        // its first wave says so (the exchange's stream polls fork_word, gkoc_stream_fork_wait) - no
+        // event record, no kernel of its own in front of this one on the main queue (either leaves
+        // the device idle for 5-6 us: profiles/r04_dist_sim_timelines.txt).
+        if (fork_word != nullptr && blockIdx.x == 0 && lane == 0) {
+            __hip_atomic_store(fork_word, fork_number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const int64_t n_int_rows = n_rows_in - head_rows - tail_rows;
         const int64_t n_int = (n_int_rows + ROWS - 1) / ROWS;
-        if (wave_id >= n_int) {
-            wave_id -= n_int;
+        // the boundary waves are the waves [bnd_first, bnd_first + n_bnd) of the grid (bnd_first < 0:
+        // the last ones): late enough for the halo to have arrived, early enough for the END of the
+        // launch - where few waves are left and every one of them waits for memory alone - to consist
+        // of interior rows, whose entries of b their neighbours have just read
+        const int64_t n_bnd_w = n_segments_in - n_int;
+        const int64_t first = bnd_first < 0 || bnd_first > n_int ? n_int : bnd_first;
+        const bool is_bnd = wave_id >= first && wave_id < first + n_bnd_w;
+        if (is_bnd) {
+            wave_id -= first;
             row_ptrs = bnd_ptrs;
             cols = bnd_cols;
             vals = bnd_vals;
@@ -149,11 +164,13 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
             n_segments = (n_rows + ROWS - 1) / ROWS;
             out_jump_at = head_rows;
             out_jump = n_rows_in - tail_rows - head_rows;
+            bool waited = false;
             if (lane == 0) {
                 long spins = 0;
                 while (int32_t(__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) -
                                gate_epoch) < 0) {
                     __builtin_amdgcn_s_sleep(32);
+                    waited = true;
                     if (++spins > (long(1) << 23)) {   // ~10 s: give up, say so, go on (the caller checks gate[1])
                         __hip_atomic_store(const_cast<uint32_t*>(gate) + 1, 1u, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_SYSTEM);
@@ -162,8 +179,24 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // Ordering of the halo reads behind the gate.  For the compiler: a workgroup-scope acquire
+            // (no instruction).  For the caches: an agent-scope acquire invalidates this XCD's L2 for
+            // EVERY wave that runs on it - 2048 of them cost the product 8 us (138 -> 146 us per rank
+            // of 8 on 256^3, profiles/r04_gate_fence.txt) - and is needed only if a line of the halo
+            // can sit in a cache from BEFORE the exchange wrote it.  None can: the halo starts on a
+            // 128-byte boundary behind the local vector, so interior waves never touch its lines;
+            // boundary waves touch them only after they have seen the gate open (the spin loop's exit
+            // is a branch on the loaded value: the loads behind it are issued after it), i.e. after
+            // the exchange's kernel has ended and released its writes; and what the PREVIOUS product
+            // left in the caches was dropped by the acquire at this kernel's start.  A wave that did
+            // wait is the one case where its own CU may have re-fetched around it: it pays the fence.
+            // gate_fence = 1 (GKOC_TUNE_GATE_FENCE) makes every boundary wave pay it.
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (gate_fence != 0 || __builtin_amdgcn_readfirstlane(int(waited)) != 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
         } else {
+            if (wave_id >= first) wave_id -= n_bnd_w;
             row_ptrs = row_ptrs_in + head_rows;
             c = c_in + head_rows;
             n_rows = n_int_rows;
@@ -172,8 +205,10 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     }
     const int64_t sb = wave_id * segs_per_wave;
     const int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
+    // (GATE renumbers the boundary waves: a wave's partial sum has the number of its workgroup)
+    const int64_t dot_slot = GATE ? int64_t(blockIdx.x) : wave_id;
     if (sb >= se) {
-        if (DOT && lane == 0) dot_partial[wave_id] = T(0);
+        if (DOT && lane == 0) dot_partial[dot_slot] = T(0);
         return;
     }
     const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;
@@ -369,6 +404,15 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
         if (seg + 1 < se) seg_rows(seg + 1, nrs, nre, nseg_end);
         T sum = T(0);
         T ys[DEFER > 0 ? DEFER : 1];
+        // DOT: this lane's entry of b for the row it sums, loaded when the segment begins (used when
+        // it ends: a load issued there would be waited for by every wave - 8 us of a 140 us product)
+        auto b_of_row = [&](int64_t s_) {
+            const int64_t row = s_ * ROWS + lane;
+            if (!(DOT && s_ < se && lane < ROWS && row < n_rows)) return T(0);
+            const int64_t brow = GATE && row >= out_jump_at ? row + out_jump : row;
+            return bj[(GATE ? brow + (c - c_in) : brow) * ldb];
+        };
+        T bdot = b_of_row(seg);
         {
             const int64_t row = seg * ROWS + lane;
             if (ADV && beta != T(0) && lane < ROWS && row < n_rows) {
@@ -469,9 +513,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                         if (lane == src) sum += part;
                     }
                     const int64_t row = seg * ROWS + lane;
-                    if (DOT && lane < ROWS && row < n_rows) {
-                        dot_acc += bj[row * ldb] * sum;
-                    }
+                    if (DOT && lane < ROWS && row < n_rows) dot_acc += bdot * sum;
                     if (DEFER > 0) {
                         const int kseg = int(seg - sb);
 #pragma unroll
@@ -490,6 +532,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                     }
 #endif
                     ++seg;
+                    if constexpr (DOT) bdot = b_of_row(seg);
                     rs = nrs;
                     re = nre;
                     seg_end = nseg_end;
@@ -528,7 +571,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     if (DOT) {
         // fixed butterfly: the partial of a wave does not depend on timing
         dot_acc = wave_sum(dot_acc);
-        if (lane == 0) dot_partial[wave_id] = dot_acc;
+        if (lane == 0) dot_partial[dot_slot] = dot_acc;
     }
 }
 

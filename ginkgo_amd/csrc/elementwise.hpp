@@ -19,6 +19,8 @@
 //        per-column scalar computed in load(); called by ONE thread per column
 //        that is not skipped.  load() must not depend on what store() writes
 //        (or the written value must equal the value read).
+//    __device__ void note(int64_t col, const scalars&) const;    like store(), but called for
+//        skipped columns as well (a criterion evaluated in load() records its verdict).
 // Outputs may alias inputs at the same element index only.
 #pragma once
 #include "common.hpp"
@@ -51,6 +53,16 @@ template <typename OP, typename S>
 __device__ __forceinline__ void ew_store(const OP&, int64_t, const S&, long)
 {}
 
+template <typename OP, typename S>
+__device__ __forceinline__ auto ew_note(const OP& op, int64_t col, const S& sc, int)
+    -> decltype(op.note(col, sc), void())
+{
+    op.note(col, sc);
+}
+template <typename OP, typename S>
+__device__ __forceinline__ void ew_note(const OP&, int64_t, const S&, long)
+{}
+
 template <typename T, typename OP, int NIN, int NOUT>
 __global__ __launch_bounds__(256) void ew_flat_vec_kernel(
     int64_t n, ew_operands<T, NIN, NOUT> a, OP op)
@@ -58,6 +70,7 @@ __global__ __launch_bounds__(256) void ew_flat_vec_kernel(
     using V = vec16<T>;
     constexpr int W = V::width;
     const auto sc = op.load(0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ew_note(op, 0, sc, 0);
     if (op.skip(sc)) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) ew_store(op, 0, sc, 0);
     const int64_t n_vec = n / W;
@@ -108,6 +121,7 @@ __global__ __launch_bounds__(256) void ew_general_kernel(
         const int64_t row = idx / cols;
         const int64_t col = idx - row * cols;
         const auto sc = op.load(col);
+        if (row == 0) ew_note(op, col, sc, 0);
         if (op.skip(sc)) continue;
         if (row == 0) ew_store(op, col, sc, 0);
         T ie[NIN > 0 ? NIN : 1], oe[NOUT];

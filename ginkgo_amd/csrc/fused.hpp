@@ -23,6 +23,35 @@ __global__ __launch_bounds__(fold_block) void fold_partials_kernel(
     if (threadIdx.x == 0) result[0] = SQRT ? sqrt(r) : r;
 }
 
+// One launch for tens of thousands of partial sums (a rank's share of a strong-scaling run: one per
+// wave of its SpMV): eight loads in flight per thread, eight running sums per thread added in a
+// fixed order, then the block's tree - fixed chunking, the value does not depend on timing.
+// (fold_partials_kernel's one-load-at-a-time loop needs 13 us for 32 768 values, this one 4.)
+template <typename T>
+__global__ __launch_bounds__(fold_block) void fold_partials_wide_kernel(
+    int64_t count, const T* __restrict__ partial, T* __restrict__ result)
+{
+    __shared__ T lds[fold_block / 64];
+    T a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = T(0);
+    int64_t i = threadIdx.x;
+    for (; i + 7 * fold_block < count; i += 8 * fold_block) {
+        T v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = partial[i + k * fold_block];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (i + k * fold_block < count) a[k] += partial[i + k * fold_block];
+    }
+    const T acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    const T r = block_sum<fold_block>(acc, lds);
+    if (threadIdx.x == 0) result[0] = r;
+}
+
 // level 1 of a two-level fold: block k folds the k-th contiguous chunk
 template <typename T>
 __global__ __launch_bounds__(256) void fold_chunks_kernel(
@@ -136,6 +165,91 @@ int fold_partials2(gkoc_stream_t s, int64_t count, int64_t pstride, const T* par
                                                                             result1, sqrt_row);
     GKOC_LAUNCH_OK();
     return GKOC_OK;
+}
+
+// ---- a step kernel that waits for its scalars and judges the criterion itself -------------------
+// PipeCg's step kernel needs the all-reduced {rho, delta, ||r||^2}.  They travel on the exchange's
+// stream while n = A m runs; a join (event) in front of the step kernel and the criterion's own
+// kernel cost the main queue 6-7 + 4.6 us per iteration (profiles/r04_dist_sim_timelines.txt).
+// Instead: every block's first thread polls the word that gkoc_gate_open sets on the exchange's
+// stream BEHIND the reduction (normally long set - it was needed by the product's boundary rows),
+// then every thread evaluates the criterion from the device scalars and ONE thread records it
+// (stop status + the two flag bytes, exactly as residual_norm_kernel does).
+template <typename T>
+struct step_gate_dev {
+    const uint32_t* word;     // nullptr: no wait
+    uint32_t number;
+    const T* tau;             // nullptr: no criterion
+    const T* orig_tau;
+    T goal;
+    int implicit;
+    uint8_t stopping_id;
+    uint8_t set_finalized;
+    uint8_t* flags;
+};
+
+template <typename T>
+step_gate_dev<T> step_gate_of(const gkoc_step_gate* g)
+{
+    step_gate_dev<T> d{};
+    if (g) {
+        d.word = g->wait_word;
+        d.number = g->wait_number;
+        d.tau = static_cast<const T*>(g->tau);
+        d.orig_tau = static_cast<const T*>(g->orig_tau);
+        d.goal = T(g->goal);
+        d.implicit = g->implicit;
+        d.stopping_id = g->stopping_id;
+        d.set_finalized = g->set_finalized;
+        d.flags = g->flags;
+    }
+    return d;
+}
+
+// true if the column has stopped (before, or by the criterion now).  All threads of the block call
+// it; `recorder`: the one thread of the grid that writes the verdict.
+template <typename T>
+__device__ __forceinline__ bool step_gate_enter(const step_gate_dev<T>& g, uint8_t* stop, bool recorder)
+{
+    if (g.word != nullptr) {
+        if (threadIdx.x == 0) {
+            bool waited = false;
+            long spins = 0;
+            while (int32_t(__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - g.number) <
+                   0) {
+                __builtin_amdgcn_s_sleep(16);
+                waited = true;
+                if (++spins > (long(1) << 23)) {     // ~10 s: give up and say so (the caller checks word[1])
+                    __hip_atomic_store(const_cast<uint32_t*>(g.word) + 1, 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+            // (nothing of this launch has read the scalars before the word was seen; a block that
+            // waited drops what its CU may hold)
+            if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    const uint8_t st = stop[0];
+    bool stopped = (st & 0x3f) != 0;
+    if (g.tau != nullptr) {
+        const T t = g.implicit ? sqrt(fabs(g.tau[0])) : g.tau[0];
+        const bool conv = t <= g.goal * g.orig_tau[0];
+        if (recorder) {
+            uint8_t sn = st;
+            if (conv && (sn & 0x3f) == 0) {
+                sn |= uint8_t(0x80) | (g.stopping_id & 0x3f);      // stopping_status::converge
+                if (g.set_finalized) sn |= uint8_t(0x40);
+                stop[0] = sn;
+            }
+            g.flags[0] = uint8_t((sn & 0x3f) != 0);
+            g.flags[1] = uint8_t(conv);
+            __threadfence_system();
+        }
+        stopped = stopped || conv;
+    }
+    return stopped;
 }
 
 // workspace layout: [partials (max_partials) | scratch (fold_chunks)]

@@ -1067,8 +1067,8 @@ __global__ __launch_bounds__(256) void jacobi_pipe_steps_kernel(
     T* __restrict__ r, T* __restrict__ z, T* __restrict__ w, T* __restrict__ p, T* __restrict__ q,
     T* __restrict__ f, T* __restrict__ g, T* __restrict__ m, const T* __restrict__ nv,
     const T* __restrict__ prev_rho, const T* __restrict__ rho, const T* __restrict__ delta,
-    const T* __restrict__ beta_in, T* __restrict__ beta_out, const uint8_t* __restrict__ stop,
-    T* __restrict__ partial, int64_t pstride)
+    const T* __restrict__ beta_in, T* __restrict__ beta_out, uint8_t* stop,
+    T* __restrict__ partial, int64_t pstride, step_gate_dev<T> gate)
 {
     __shared__ T lds[4];
     constexpr int LOG_BO = BO == 1 ? 0 : BO == 2 ? 1 : BO == 4 ? 2 : BO == 8 ? 3 : 4;
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(256) void jacobi_pipe_steps_kernel(
     const int lane0 = lane - rr;
     const int64_t wg = blockIdx.x;
     const int64_t group0 = (wg * 4 + (threadIdx.x >> 6)) * GPW;
-    const bool stopped = status_has_stopped(stop[0]);
+    const bool stopped = step_gate_enter(gate, stop, wg == 0 && threadIdx.x == 0);
     const T pr = prev_rho[0];
     const bool plain = pr == T(0);
     const T t2 = plain ? T(0) : rho[0] / pr;
@@ -1172,9 +1172,12 @@ int launch_pipe_steps(gkoc_stream_t s, int64_t num_blocks, int64_t n_rows, uint3
                       gkoc_jacobi_scheme scheme, const I* block_ptrs, const T* blocks, T* x, T* r, T* z,
                       T* w, T* p, T* q, T* f, T* g, T* m, const T* nv, const T* prev_rho, const T* rho,
                       const T* delta, const T* beta_in, T* beta_out, const uint8_t* stop, T* out3, void* work,
-                      size_t work_bytes)
+                      size_t work_bytes, const gkoc_step_gate* gate_in)
 {
     GKOC_REQUIRE(out3 && num_blocks > 0 && n_rows > 0, GKOC_E_INVALID, "bad argument");
+    GKOC_REQUIRE(!gate_in || !gate_in->tau || (gate_in->orig_tau && gate_in->flags), GKOC_E_INVALID,
+                 "gkoc_step_gate: a criterion needs orig_tau and flags");
+    const step_gate_dev<T> gate = step_gate_of<T>(gate_in);
     GKOC_REQUIRE(block_ptrs && blocks && x && r && z && w && p && q && f && g && m && nv && prev_rho && rho &&
                      delta && stop && work,
                  GKOC_E_INVALID, "null pointer");
@@ -1197,8 +1200,9 @@ int launch_pipe_steps(gkoc_stream_t s, int64_t num_blocks, int64_t n_rows, uint3
     jacobi_pipe_steps_kernel<T, I, BO_, ((BO_ * sizeof(T) >= 128) ? 1 : 2)>                            \
         <<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(num_blocks, groups, go, block_ptrs, blocks, \
                                                              x, r, z, w, p, q, f, g, m, nv, prev_rho,  \
-                                                             rho, delta, beta_in, beta_out, stop,      \
-                                                             partial, nb)
+                                                             rho, delta, beta_in, beta_out,            \
+                                                             const_cast<uint8_t*>(stop), partial, nb,  \
+                                                             gate)
     switch (int(bo)) {
     case 1: GKOC_JAC_PS(1); break;
     case 2: GKOC_JAC_PS(2); break;
@@ -1629,13 +1633,14 @@ using namespace gkoc;
         const I* block_ptrs, const T* blocks, T* x, T* r, T* z, T* w, T* p,    \
         T* q, T* f, T* g, T* m, const T* n, const T* prev_rho, const T* rho,   \
         const T* delta, const T* beta_in, T* beta_out,                         \
-        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes)    \
+        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes,    \
+        const gkoc_step_gate* gate)                                            \
     {                                                                          \
         return launch_pipe_steps<T, I>(s, num_blocks, n_rows, max_block_size,  \
                                        scheme, block_ptrs, blocks, x, r, z, w, \
                                        p, q, f, g, m, n, prev_rho, rho, delta, \
                                        beta_in, beta_out, stop_status, out3,   \
-                                       work, work_bytes);                      \
+                                       work, work_bytes, gate);                \
     }                                                                          \
     extern "C" int gkoc_jacobi_apply_##TN##_##IN(                              \
         gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,          \

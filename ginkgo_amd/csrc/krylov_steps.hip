@@ -794,13 +794,13 @@ __global__ __launch_bounds__(256) void pipe_cg_step2_step1_dots_kernel(
     T* __restrict__ p, T* __restrict__ q, T* __restrict__ f, T* __restrict__ g,
     const T* __restrict__ m, const T* __restrict__ nv, const T* __restrict__ prev_rho,
     const T* __restrict__ rho, const T* __restrict__ delta, const T* __restrict__ beta_in,
-    T* __restrict__ beta_out, const uint8_t* __restrict__ stop, T* __restrict__ partial,
-    int64_t pstride, bool vec_ok)
+    T* __restrict__ beta_out, uint8_t* stop, T* __restrict__ partial,
+    int64_t pstride, bool vec_ok, step_gate_dev<T> gate)
 {
     __shared__ T lds[4];
     using V = vec16<T>;
     constexpr int W = V::width;
-    const bool stopped = status_has_stopped(stop[0]);
+    const bool stopped = step_gate_enter(gate, stop, blockIdx.x == 0 && threadIdx.x == 0);
     const T pr = prev_rho[0];
     const bool plain = pr == T(0);
     const T t2 = plain ? T(0) : rho[0] / pr;
@@ -911,9 +911,14 @@ template <typename T>
 int launch_pipe_cg_step2_step1_dots(gkoc_stream_t s, int64_t n, T* x, T* r, T* z, T* w, T* p, T* q, T* f,
                                     T* g, const T* m, const T* nv, const T* prev_rho, const T* rho,
                                     const T* delta, const T* beta_in, T* beta_out, const uint8_t* stop,
-                                    T* out3, void* work, size_t work_bytes)
+                                    T* out3, void* work, size_t work_bytes, const gkoc_step_gate* gate_in)
 {
     GKOC_REQUIRE(n >= 0 && out3, GKOC_E_INVALID, "bad argument");
+    GKOC_REQUIRE(!gate_in || !gate_in->tau || (gate_in->orig_tau && gate_in->flags), GKOC_E_INVALID,
+                 "gkoc_step_gate: a criterion needs orig_tau and flags");
+    GKOC_REQUIRE(!gate_in || n > 0, GKOC_E_NOT_SUPPORTED,
+                 "gkoc_step_gate on an empty local part: run the criterion's own kernel");
+    const step_gate_dev<T> gate = step_gate_of<T>(gate_in);
     GKOC_REQUIRE(beta_in && beta_out && beta_in != beta_out, GKOC_E_INVALID,
                  "beta_in and beta_out must be two different scalars");
     if (n == 0) {
@@ -934,8 +939,8 @@ int launch_pipe_cg_step2_step1_dots(gkoc_stream_t s, int64_t n, T* x, T* r, T* z
     if (nb > max_blocks) nb = max_blocks;
     T* partial = static_cast<T*>(work);
     pipe_cg_step2_step1_dots_kernel<T><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(
-        n, x, r, z, w, p, q, f, g, m, nv, prev_rho, rho, delta, beta_in, beta_out, stop, partial, max_blocks,
-        bits % 16 == 0);
+        n, x, r, z, w, p, q, f, g, m, nv, prev_rho, rho, delta, beta_in, beta_out, const_cast<uint8_t*>(stop),
+        partial, max_blocks, bits % 16 == 0, gate);
     GKOC_LAUNCH_OK();
     fold_rows_kernel<T><<<dim3(3), dim3(1024), 0, as_stream(s)>>>(nb, max_blocks, partial, out3);
     GKOC_LAUNCH_OK();
@@ -1152,11 +1157,12 @@ int launch_pipe_cg_step2_step1_dots(gkoc_stream_t s, int64_t n, T* x, T* r, T* z
         gkoc_stream_t s, int64_t rows, T* x, T* r, T* z, T* w, T* p, T* q, T* f, T* g,    \
         const T* m, const T* n, const T* prev_rho, const T* rho, const T* delta,          \
         const T* beta_in, T* beta_out, const uint8_t* stop_status, T* out3, void* work,   \
-        size_t work_bytes)                                                                \
+        size_t work_bytes, const gkoc_step_gate* gate)                                    \
     {                                                                                     \
         return launch_pipe_cg_step2_step1_dots<T>(s, rows, x, r, z, w, p, q, f, g, m, n,  \
                                                   prev_rho, rho, delta, beta_in, beta_out, \
-                                                  stop_status, out3, work, work_bytes);   \
+                                                  stop_status, out3, work, work_bytes,    \
+                                                  gate);                                  \
     }                                                                                     \
     extern "C" int gkoc_x_pipe_cg_step_1_dots_##TN(                                       \
         gkoc_stream_t s, int64_t rows, T* x, T* r, T* z, T* w, const T* p, const T* q,    \

@@ -31,6 +31,14 @@ from .matrix import Csr, Dense, scalar, stencil_csr
 from .preconditioner import Jacobi
 
 
+class StepGate(C.Structure):
+    """gkoc_step_gate (include/gko_cdna4.h): what a fused PipeCg step kernel waits for and the
+    stopping criterion it evaluates itself"""
+    _fields_ = [("wait_word", C.c_void_p), ("wait_number", C.c_uint32), ("implicit", C.c_int32),
+                ("tau", C.c_void_p), ("orig_tau", C.c_void_p), ("goal", C.c_double),
+                ("flags", C.c_void_p), ("stopping_id", C.c_uint8), ("set_finalized", C.c_uint8)]
+
+
 class Partition:
     """Contiguous 1-D row partition; `offsets` has n_parts + 1 entries."""
 
@@ -243,6 +251,17 @@ class RcclComm(TorchComm):
              C.c_void_p(side_stream.cuda_stream), t, t.numel(), C.c_size_t(t.element_size()), send,
              self._counts(send_counts), self._counts(send_displs) if send_displs is not None else None,
              recv, self._counts(recv_counts), C.c_size_t(send.element_size()))
+
+    def fork_deferred(self, side_stream):
+        """the fork of the NEXT begin call is opened by the caller's next kernel on the executor's
+        stream (gkoc_comm_fork_deferred): returns the (word, number) objects to hand to that kernel
+        (spmv_gated: fork=...); the word is NULL where the library prefers to fork by itself"""
+        if not hasattr(self, "_fork_tok"):
+            self._fork_tok = (C.c_void_p(0), C.c_uint32(0))
+        w, n = self._fork_tok
+        call("gkoc_comm_fork_deferred", self._handle, self.exec.stream, C.c_void_p(side_stream.cuda_stream),
+             C.byref(w), C.byref(n))
+        return self._fork_tok
 
     def exchange_end(self):
         call("gkoc_comm_exchange_end", self._handle, self.exec.stream)
@@ -562,15 +581,26 @@ class HipBackend:
         bump(gate[1])
         call("gkoc_gate_open", C.c_void_p(stream.cuda_stream), gate[0], gate[1])
 
-    def spmv_gated(self, local, nl, x_ext, y, gate):
-        """y = A [x | halo] for ALL local rows in one kernel: the interior rows from the local
+    def spmv_gated(self, local, nl, x_ext, y, gate, fork=None):
+        """(fork: the (word, number) of comm.fork_deferred - the kernel's first wave opens the
+        exchange's fork)
+        y = A [x | halo] for ALL local rows in one kernel: the interior rows from the local
         block, the boundary rows (complete rows, nl["full"]) on its last waves, which wait for the
         gate_open in front of this call; x_ext: the local vector with the halo behind it, starting
         at entry nl["full"]["halo_base"]"""
         f = nl["full"]
         call("gkoc_csr_spmv_gated_" + nl["suffix"], self.exec.stream, y.size[0], local.row_ptrs,
              local.col_idxs, local.values, f["ptrs"], f["cols"], f["vals"], x_ext, y.values, f["head"],
-             f["tail"], gate[0], gate[1])
+             f["tail"], gate[0], gate[1], *(fork or (None, C.c_uint32(0))))
+
+    def spmv_gated_dot(self, local, nl, x_ext, y, gate, out, fork=None):
+        """spmv_gated and out = LOCAL <x, y> from the waves that hold the row sums (one partial sum
+        per wave, one fold launch): gkoc_x_csr_spmv_gated_dot_*"""
+        f = nl["full"]
+        w, wb = self._xwork(y.size[0] + 128, y.dtype)
+        call("gkoc_x_csr_spmv_gated_dot_" + nl["suffix"], self.exec.stream, y.size[0], local.row_ptrs,
+             local.col_idxs, local.values, f["ptrs"], f["cols"], f["vals"], x_ext, y.values, f["head"],
+             f["tail"], gate[0], gate[1], *(fork or (None, C.c_uint32(0))), out.values, w, wb)
 
     def spmv_dot(self, a, x, y, out):
         """y = A_local x and out = local <x, y> in one pass; False if there is no such kernel
@@ -607,6 +637,18 @@ class HipBackend:
         call("gkoc_cg_step_1_" + VT[p.dtype], self.exec.stream, p.size[0], 1, p.values, p.ld,
              z.values, z.ld, rho.values, prev_rho.values, stop)
 
+    def check_slot(self):
+        """a token for cg_step_1_check / check_done: the next slot of the pinned flag ring"""
+        return self._check_slot()
+
+    def cg_step_1_check(self, p, z, rho, prev_rho, tau, tau0, factor, stop, slot, squared=True):
+        """the criterion on tau (as check_begin; its answer arrives in `slot`) and cg::step_1 in
+        ONE kernel (gkoc_x_cg_step_1_check_*); one column, unit strides"""
+        call("gkoc_x_cg_step_1_check_" + VT[p.dtype], self.exec.stream, p.size[0], p.values, z.values,
+             rho.values, prev_rho.values, tau.values, tau0.values,
+             C.c_double(factor) if p.dtype == torch.float64 else C.c_float(factor),
+             C.c_int(1 if squared else 0), C.c_uint8(2), C.c_int(1), stop, self._chk_host[slot])
+
     def cg_step_2(self, x, r, p, q, beta, rho, stop):
         call("gkoc_cg_step_2_" + VT[x.dtype], self.exec.stream, x.size[0], 1, x.values, x.ld,
              r.values, r.ld, p.values, p.ld, q.values, q.ld, beta.values, rho.values, stop)
@@ -639,8 +681,28 @@ class HipBackend:
              beta.values, stop, out3, wk, wb)
         return True
 
+    def step_gate(self, gate, tau, tau0, factor, stop, slot):
+        """a recorded-call argument for the fused PipeCg step kernels: wait for `gate` (the pair of
+        gate_new; its exchange number is read when the call is issued, also in replays) and evaluate
+        ImplicitResidualNorm on tau (= ||r||^2) into flag slot `slot` (check_slot / check_done)"""
+        sg = StepGate(gate[0].data_ptr() if gate is not None else None, 0, 1, tau.values.data_ptr(),
+                      tau0.values.data_ptr(), float(factor), self._chk_host[slot].data_ptr(), 2, 1)
+        keep = (gate, tau, tau0, stop)
+
+        class _Arg:
+            """passed by reference; wait_number is refreshed from the gate's counter on every use"""
+            def __init__(self):
+                self.sg, self.keep = sg, keep
+
+            @property
+            def _as_parameter_(self):
+                if gate is not None:
+                    sg.wait_number = gate[1].value
+                return C.c_void_p(C.addressof(sg))
+        return _Arg()
+
     def pipe_cg_step_2_step_1_dots(self, x, r, z, w, p, q, f, g, m, n, prev_rho, rho, delta, beta_in,
-                                   beta_out, stop, out3):
+                                   beta_out, stop, out3, gate=None):
         """pipe_cg::step_2 of this iteration and step_1 of the next one in one pass (ten vectors in,
         eight out instead of 12 + 12), out3 = local {<r,z>, <w,z>, <r,r>} of the new vectors; False
         if the layout has no such kernel"""
@@ -649,11 +711,12 @@ class HipBackend:
         wk, wb = self._xwork(x.size[0], x.dtype)
         call("gkoc_x_pipe_cg_step_2_step_1_dots_" + VT[x.dtype], self.exec.stream, x.size[0], x.values,
              r.values, z.values, w.values, p.values, q.values, f.values, g.values, m.values, n.values,
-             prev_rho.values, rho.values, delta.values, beta_in.values, beta_out.values, stop, out3, wk, wb)
+             prev_rho.values, rho.values, delta.values, beta_in.values, beta_out.values, stop, out3, wk, wb,
+             gate)
         return True
 
     def pipe_cg_steps_jacobi(self, m_op, x, r, z, w, p, q, f, g, m, n, prev_rho, rho, delta, beta_in,
-                             beta_out, stop, out3, probe=False):
+                             beta_out, stop, out3, probe=False, gate=None):
         """the same AND m = M w (block-Jacobi) in one kernel: the new w goes from the registers
         that computed it into the block product; False if this preconditioner / layout has no
         such kernel (probe=True: only answer)"""
@@ -666,7 +729,8 @@ class HipBackend:
         call("gkoc_x_pipe_cg_steps_jacobi_" + m_op._suf, self.exec.stream, m_op.num_blocks, m_op.size[0],
              C.c_uint32(m_op.max_block_size), m_op.scheme, m_op.block_pointers, m_op.blocks, x.values,
              r.values, z.values, w.values, p.values, q.values, f.values, g.values, m.values, n.values,
-             prev_rho.values, rho.values, delta.values, beta_in.values, beta_out.values, stop, out3, wk, wb)
+             prev_rho.values, rho.values, delta.values, beta_in.values, beta_out.values, stop, out3, wk, wb,
+             gate)
         return True
 
     def pipe_cg_step_2(self, beta, p, q, f, g, z, w, m, n, prev_rho, rho, delta, stop):
@@ -747,14 +811,7 @@ class HipBackend:
         its two flag bytes into a pinned (host-coherent) slot that the host has set to 0xFF; the
         host polls the slot when it wants the answer - `check_lag` iterations later, when the
         bytes have long arrived."""
-        if not hasattr(self, "_chk_host"):
-            self._chk_host = torch.zeros((self._NSLOT, 2), dtype=torch.uint8).pin_memory()
-            self._chk_np = self._chk_host.numpy()
-            self._chk_next = 0
-            self._chk_tapes = {}
-        slot = self._chk_next
-        self._chk_next = (slot + 1) % self._NSLOT
-        self._chk_np[slot, 0] = self._chk_np[slot, 1] = 0xFF
+        slot = self._check_slot()
         key = (tau.values.data_ptr(), tau0.values.data_ptr(), stop.data_ptr(), factor, slot, squared)
         tape = self._chk_tapes.get(key)
         if tape is None:
@@ -768,6 +825,18 @@ class HipBackend:
             self._chk_tapes[key] = tape
         else:
             tape.replay()
+        return slot
+
+    def _check_slot(self):
+        """the next slot of the pinned flag ring, marked 'no answer yet'"""
+        if not hasattr(self, "_chk_host"):
+            self._chk_host = torch.zeros((self._NSLOT, 2), dtype=torch.uint8).pin_memory()
+            self._chk_np = self._chk_host.numpy()
+            self._chk_next = 0
+            self._chk_tapes = {}
+        slot = self._chk_next
+        self._chk_next = (slot + 1) % self._NSLOT
+        self._chk_np[slot, 0] = self._chk_np[slot, 1] = 0xFF
         return slot
 
     def check_done(self, token, block=True):
@@ -850,6 +919,10 @@ class DistributedMatrix:
         # local SpMV) or, GKO_FULL_BOUNDARY=0, the round-2 form: whole local block, then
         # boundary rows += halo part
         self.use_full_boundary = os.environ.get("GKO_FULL_BOUNDARY", "1") != "0"
+        # <p, q> from the product's waves (gkoc_x_csr_spmv_gated_dot_*): measured per rank of 8 on
+        # 256^3, it costs the product 8 us and its fold 4 - the separate dot + fold cost 9.  Off.
+        self.gated_dot = os.environ.get("GKO_GATED_DOT", "0") != "0"
+        self.deferred_fork = os.environ.get("GKO_DEFERRED_FORK", "1") != "0"
         # the whole product in ONE kernel whose last waves (the boundary rows) wait for the halo by
         # themselves: for vectors from ext_vector() (the solvers' search directions), a
         # device-resident communicator and zero-copy send planes
@@ -878,6 +951,13 @@ class DistributedMatrix:
             raise GkoError("DistributedMatrix: the halo exchange did not arrive within the one-kernel "
                            "product's patience (GKO_GATED_SPMV=0 selects the join-based product)")
 
+    def _fork_token(self):
+        """the exchange about to begin is forked by the product's own kernel where the
+        communicator offers it (no event, no kernel in front of the product on the main queue)"""
+        if self.deferred_fork and hasattr(self.comm, "fork_deferred"):
+            return self.comm.fork_deferred(self._side)
+        return None
+
     def _gated(self, x, y):
         return (self._gate is not None and getattr(x, "_ext_halo", None) is not None and
                 x.ld == 1 and y.ld == 1 and x.size[1] == 1 and self.use_full_boundary)
@@ -887,6 +967,16 @@ class DistributedMatrix:
         the local block through the fused SpMV + dot, the boundary rows' share next to their
         update.  False if the backend has no such kernels (then nothing was done)."""
         be = self.backend
+        # the one-kernel product leaves one partial sum per wave; ONE launch folds them
+        if (self.comm.size > 1 and self._gated(x, y) and hasattr(be, "spmv_gated_dot") and
+                self.gated_dot):
+            fork = self._fork_token()
+            self.comm.exchange_begin(x._ext_halo, x.values, self.recv_counts, self.send_counts, self._side,
+                                     self.send_displs)
+            be.gate_open(self._side, self._gate)
+            be.spmv_gated_dot(self.local, self.nl, x._ext_store, y, self._gate, out, fork)
+            self.comm.exchange_forget()
+            return True
         # below ~4 M local rows the plain SpMV + a separate dot is faster (measured per rank of
         # an 8-rank 256^3 run: 239 against 251 us per CG iteration; the fused kernel's partial
         # sums need two fold launches and its boundary-row share two more)
@@ -908,19 +998,29 @@ class DistributedMatrix:
     def begin_exchange_with_reduce(self, x, t):
         """start the all-reduce of t and the halo exchange of x on the side stream behind one
         fork; apply(x, y, started=True) must follow (its join ends both)"""
-        recv = x._ext_halo if getattr(x, "_ext_halo", None) is not None and self._gate is not None \
-            else self.recv_buf.values
+        gated = getattr(x, "_ext_halo", None) is not None and self._gate is not None
+        recv = x._ext_halo if gated else self.recv_buf.values
+        # (the product that follows opens the fork with its first wave where the communicator offers it)
+        self._started_fork = self._fork_token() if gated and self.use_full_boundary else None
         self.comm.all_reduce_exchange_begin(t, recv, x.values, self.recv_counts,
                                             self.send_counts, self._side, self.send_displs)
 
-    def apply(self, x, y, dot_out=None, started=False):
+    def apply(self, x, y, dot_out=None, started=False, join=True):
         """y_local = A[owned rows, :] x   (x, y: local parts, n_local x 1); started: the halo
-        exchange of x is already under way (begin_exchange_with_reduce)"""
+        exchange of x is already under way (begin_exchange_with_reduce); join=False (with started,
+        one-kernel product only): the main stream does NOT wait for the exchange's stream - whoever
+        reads the all-reduced values next waits for this product's gate (HipBackend.step_gate);
+        returns True in that case"""
         be, comm = self.backend, self.comm
         if started and self._gated(x, y):
-            # (the all-reduce that was started with the exchange still ends with the join)
             be.gate_open(self._side, self._gate)
-            be.spmv_gated(self.local, self.nl, x._ext_store, y, self._gate)
+            be.spmv_gated(self.local, self.nl, x._ext_store, y, self._gate,
+                          getattr(self, "_started_fork", None))
+            self._started_fork = None
+            if not join:
+                comm.exchange_forget()
+                return True
+            # (the all-reduce that was started with the exchange ends with the join)
             comm.exchange_join()
             return y
         if started:
@@ -935,10 +1035,11 @@ class DistributedMatrix:
                 be.rowlist_add(self.nl, self.recv_buf, y)
             return y
         if dot_out is None and comm.size > 1 and self._gated(x, y):
+            fork = self._fork_token()
             comm.exchange_begin(x._ext_halo, x.values, self.recv_counts, self.send_counts, self._side,
                                 self.send_displs)
             be.gate_open(self._side, self._gate)
-            be.spmv_gated(self.local, self.nl, x._ext_store, y, self._gate)
+            be.spmv_gated(self.local, self.nl, x._ext_store, y, self._gate, fork)
             comm.exchange_forget()
             return y
         if dot_out is not None:
@@ -1038,6 +1139,8 @@ class DistributedCg:
         self.check_lag = backend.max_check_lag if check_lag is None else \
             max(0, min(int(check_lag), 16 - 2))
         self.fused = bool(fused)
+        import os
+        self.step_1_check = os.environ.get("GKO_STEP1_CHECK", "1") != "0"
         n, dt = matrix.n_local, matrix.dtype
         self.r, self.z, self.p, self.q = (backend.vector(n, dt) for _ in range(4))
         if hasattr(matrix, "ext_vector"):
@@ -1100,8 +1203,11 @@ class DistributedCg:
 
         fused_s2 = fused and self.m is not None and hasattr(be, "cg_step_2_jacobi") and self.fused_step_2
 
-        def seg_b(cur, prev):
-            be.cg_step_1(p, z, cur[1], prev[1], self.stop)
+        def seg_b(cur, prev, slot=None):
+            if slot is not None:
+                be.cg_step_1_check(p, z, cur[1], prev[1], cur[2], self.tau0, self.factor, self.stop, slot)
+            else:
+                be.cg_step_1(p, z, cur[1], prev[1], self.stop)
             if fused and hasattr(a, "apply_dot") and a.apply_dot(p, q, beta):
                 self.comm.all_reduce_sum_(beta.values.view(-1))   # <p,q> came with the SpMV
             else:
@@ -1133,6 +1239,9 @@ class DistributedCg:
             tapes[key] = t
             return t.result
 
+        check_in_step_1 = (fused and self.step_1_check and hasattr(be, "cg_step_1_check") and
+                           getattr(be, "check_takes_squared_norm", False) and
+                           p.ld == 1 and z.ld == 1 and p.size[1] == 1)
         have_sq = 0
         it = -1
         while True:
@@ -1145,6 +1254,19 @@ class DistributedCg:
                 if stopped is not None:
                     it = stopped
                 break
+            if check_in_step_1:
+                # the criterion is the first thing cg::step_1's kernel does (gkoc_x_cg_step_1_check_*):
+                # a column that has converged is left alone by it and by everything behind it, so
+                # reading the answer AFTER the rest of the iteration is enqueued changes nothing
+                tok = be.check_slot()
+                pending.append((it, tok))
+                have_sq = run(("b", parity, tok), seg_b, cur, prev, tok)
+                stopped = self._drain(pending, it - self.check_lag)
+                if stopped is not None:
+                    it = stopped
+                    break
+                cur, prev = prev, cur
+                continue
             if getattr(be, "check_takes_squared_norm", False):
                 tok = be.check_begin(tau, self.tau0, self.factor, self.stop, squared=True)
             else:
@@ -1188,6 +1310,8 @@ class DistributedPipeCg:
         self.taped = bool(taped)
         self.fused_steps = bool(fused_steps)
         self.fused_jacobi = bool(fused_jacobi)
+        self.step_gate = os.environ.get("GKO_STEP_GATE", "1") != "0"
+
         self.max_iters, self.factor = int(max_iters), float(reduction_factor)
         self.m_op = backend.jacobi(matrix.local, max_block_size) if max_block_size else None
         self.num_iterations = 0
@@ -1318,10 +1442,16 @@ class DistributedPipeCg:
             # exchange start together behind one fork, the SpMV's join ends both
             together = with_m and hasattr(a, "can_start_with_reduce") and a.can_start_with_reduce(m)
 
+            # ... and where the product is the one-kernel one, nothing joins: the step kernel waits for
+            # the product's gate (set behind the reduction) and judges the criterion itself
+            no_join = (together and self.step_gate and hasattr(be, "step_gate") and
+                       hasattr(a, "_gated") and a._gated(m, n) and
+                       getattr(be, "check_takes_squared_norm", False))
+
             def mid(prev):                       # reduce what the last step kernel left in `prev`
                 if together:
                     a.begin_exchange_with_reduce(m, prev[0])
-                    a.apply(m, n, started=True)
+                    a.apply(m, n, started=True, join=not no_join)
                     return
                 comm.all_reduce_begin(prev[0], self._side)
                 if not with_m:
@@ -1329,10 +1459,12 @@ class DistributedPipeCg:
                 a.apply(m, n)
                 comm.all_reduce_end()
 
-            def tail(cur, prev, b_in, b_out):    # step_2 (prev_rho = prev, rho / delta = cur) + next step_1
+            def tail(cur, prev, b_in, b_out, slot=None):    # step_2 (prev_rho = prev, rho / delta = cur) + next step_1
                 if with_m:
+                    sg = be.step_gate(a._gate, cur[1][2], self.tau0, self.factor, self.stop, slot) \
+                        if slot is not None else None
                     be.pipe_cg_steps_jacobi(self.m_op, x, r, z, w, p, q, f, g, m, n, prev[1][0], cur[1][0],
-                                            cur[1][1], b_in, b_out, self.stop, prev[0])
+                                            cur[1][1], b_in, b_out, self.stop, prev[0], gate=sg)
                 else:
                     be.pipe_cg_step_2_step_1_dots(x, r, z, w, p, q, f, g, m, n, prev[1][0], cur[1][0],
                                                   cur[1][1], b_in, b_out, self.stop, prev[0])
@@ -1348,6 +1480,18 @@ class DistributedPipeCg:
                     if stopped is not None:
                         it = stopped
                     break
+                if no_join:
+                    # the criterion is the first thing the step kernel does (behind its wait for the
+                    # reduced values): a column that has converged is left alone by it, so looking at
+                    # the answer after the kernel is enqueued changes nothing
+                    tok = be.check_slot()
+                    pending.append((it, tok))
+                    run(("t", parity, tok), tail, cur, prev, betas[parity], betas[1 - parity], tok)
+                    stopped = self._drain(pending, it - self.check_lag)
+                    if stopped is not None:
+                        it = stopped
+                        break
+                    continue
                 pending.append((it, self._check_begin(cur[1][2])))
                 stopped = self._drain(pending, it - self.check_lag)
                 if stopped is not None:

@@ -155,7 +155,13 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                       xcd_chunked_block); 0: every 8th workgroup (plain dispatch order) */
 #define GKOC_TUNE_CSR_LOAD_GROUPS 2 /* csr::spmv, one column: 0 (default) two entries per lane and load, three load
                                       groups in flight (float: four entries, two groups); 1: four (eight) entries,
-                                      one group - the layout of rounds 1-2, kept for A/B measurements */
+                                      one group - the layout of rounds 1-2, kept for A/B measurements; 2: the
+                                      default layout also where the size rule picks the other (small products) */
+#define GKOC_TUNE_GATE_FENCE 7      /* one-kernel distributed product (gkoc_csr_spmv_gated_*): 0 (default) only a
+                                      boundary wave that had to wait for its halo pays an agent-scope acquire
+                                      fence; 1: every boundary wave does (+8 us per product at 2048 waves) */
+#define GKOC_TUNE_GATE_POS 8        /* one-kernel distributed product: the boundary waves start behind this many per
+                                      cent of the interior waves (100: they are the last waves of the grid) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,
@@ -870,7 +876,12 @@ GKOC_DECL_DIST_IDX(int64_t, i64)
  * device memory, zero at the start (gate[0] the number of the last exchange that arrived, gate[1]
  * set to 1 by a wave that waited ~10 s in vain - the result is then undefined, check it); epoch:
  * the number of the exchange (1, 2, ... - the caller counts; the product with the same number
- * waits for it).  Results: complete rows in the original column order = the single-domain bits.
+ * waits for it).  fork_word / fork_number (may be NULL / 0): the kernel's first wave stores the
+ * number into the word - "b is final on this stream" - for an exchange stream that waits for it
+ * with gkoc_stream_fork_wait (gkoc_comm_fork_deferred): the fork in front of the exchange then
+ * costs the main queue neither an event nor a kernel.  The two streams must not share a hardware
+ * queue (give the exchange's stream another priority).
+ * Results: complete rows in the original column order = the single-domain bits.
  * gkoc_csr_spmv_gated_fits: 1 if the boundary rows are few enough (64 rows per wave, at most 8
  * waiting waves per compute unit) for the waiting waves to leave the exchange's kernels room on
  * the device; otherwise the entry refuses (GKOC_E_NOT_SUPPORTED) and the caller runs the
@@ -880,7 +891,23 @@ GKOC_DECL_DIST_IDX(int64_t, i64)
                                         const I* col_idxs, const T* vals, const I* bnd_ptrs,           \
                                         const I* bnd_cols, const T* bnd_vals, const T* b, T* c,        \
                                         int64_t head_rows, int64_t tail_rows, const uint32_t* gate,    \
-                                        uint32_t epoch);
+                                        uint32_t epoch, uint32_t* fork_word, uint32_t fork_number);
+/* gkoc_x_csr_spmv_gated_dot: the same product and dot_out = <b[0 .. n_rows), c> (the LOCAL part \
+ * of <p, A p>, core/solver/cg.cpp:163-166) from the registers that hold the row sums: every wave \
+ * leaves one partial sum, ONE launch folds them (fixed tree: the value does not depend on timing). \
+ * work: gkoc_x_workspace_bytes(n_rows + 128, sizeof(T)) bytes.  c has the bits of the plain product. */
+#define GKOC_DECL_CSR_GATED_DOT(T, TN, I, IN)                                                          \
+    int gkoc_x_csr_spmv_gated_dot_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,      \
+                                              const I* col_idxs, const T* vals, const I* bnd_ptrs,     \
+                                              const I* bnd_cols, const T* bnd_vals, const T* b, T* c,  \
+                                              int64_t head_rows, int64_t tail_rows,                    \
+                                              const uint32_t* gate, uint32_t epoch,                    \
+                                              uint32_t* fork_word, uint32_t fork_number, T* dot_out,   \
+                                              void* work, size_t work_bytes);
+GKOC_DECL_CSR_GATED_DOT(double, f64, int32_t, i32)
+GKOC_DECL_CSR_GATED_DOT(double, f64, int64_t, i64)
+GKOC_DECL_CSR_GATED_DOT(float, f32, int32_t, i32)
+GKOC_DECL_CSR_GATED_DOT(float, f32, int64_t, i64)
 GKOC_DECL_CSR_GATED(double, f64, int32_t, i32)
 GKOC_DECL_CSR_GATED(double, f64, int64_t, i64)
 GKOC_DECL_CSR_GATED(float, f32, int32_t, i32)
@@ -1085,6 +1112,28 @@ size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size);
 /* gkoc_x_gmres_mgs_step: one modified Gram-Schmidt step fused with the next dot
  * (gmres.cpp:176-190): next_krylov -= h_cur * basis_cur (bit-identical to
  * dense::sub_scaled), h_next = <basis_next, next_krylov> (tree sum). */
+/* Optional last argument of the fused PipeCg step kernels (NULL: neither).
+ * wait_word / wait_number: every workgroup waits until *wait_word has reached wait_number before
+ * it reads the scalars - the word that gkoc_gate_open sets on the exchange's stream behind the
+ * all-reduce that produces them (gkoc_comm_all_reduce_exchange_begin): the main stream then needs
+ * no join in front of the step kernel (core/solver/pipe_cg.cpp:211-262 has the host wait for the
+ * reduction there).  wait_word[1] is set to 1 by a workgroup that waited ~10 s in vain.
+ * tau / orig_tau / goal / implicit / stopping_id / set_finalized / flags: the stopping criterion
+ * gkoc_residual_norm_* (implicit = 0) or gkoc_implicit_residual_norm_* (1) of ONE column, evaluated
+ * inside the step kernel before anything else and recorded in stop_status[0] (which must then be
+ * writable) and flags[0..1] exactly as those entries do; a column that has converged is left
+ * alone by the step.  tau and orig_tau have the kernel's value type. */
+typedef struct gkoc_step_gate {
+    const uint32_t* wait_word;
+    uint32_t wait_number;
+    int32_t implicit;
+    const void* tau;
+    const void* orig_tau;
+    double goal;
+    uint8_t* flags;
+    uint8_t stopping_id;
+    uint8_t set_finalized;
+} gkoc_step_gate;
 #define GKOC_DECL_X(T, TN)                                                     \
     int gkoc_x_gmres_mgs_step_##TN(                                            \
         gkoc_stream_t s, int64_t rows, T* next_krylov, const T* basis_cur,     \
@@ -1098,6 +1147,19 @@ size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size);
         gkoc_stream_t s, int64_t rows, T* x, T* r, const T* p, const T* q,     \
         const T* beta, const T* rho, const uint8_t* stop_status, T* norm_out,  \
         int take_sqrt, void* work, size_t work_bytes);                         \
+    /* cg::step_1 (one column, unit strides) with the stopping criterion in    \
+     * front of it: residual_norm (implicit = 0) / implicit_residual_norm      \
+     * (implicit = 1: sqrt(|tau|)) <= goal * orig_tau is evaluated inside the  \
+     * kernel, recorded in stop_status[0] and flags[0..1] exactly as           \
+     * gkoc_*residual_norm_* does, and p is left alone if the column has       \
+     * stopped - the criterion's kernel (core/solver/cg.cpp:150-160 between    \
+     * the reductions and step_1) costs nothing of its own.  flags may be      \
+     * pinned host memory. */                                                  \
+    int gkoc_x_cg_step_1_check_##TN(                                           \
+        gkoc_stream_t s, int64_t rows, T* p, const T* z, const T* rho,         \
+        const T* prev_rho, const T* tau, const T* orig_tau, T goal,            \
+        int implicit, uint8_t id, int set_finalized, uint8_t* stop_status,     \
+        uint8_t* flags);                                                       \
     /* pipe_cg::step_2 of one iteration and step_1 of the next in one pass, with the partial sums \
      * of <r,z>, <w,z>, <r,r> (out3): ten vectors in, eight out; vectors bit-identical to the two \
      * kernels.  beta_in / beta_out: two different scalars (the caller alternates them). */       \
@@ -1105,7 +1167,8 @@ size_t gkoc_x_workspace_bytes(int64_t n, size_t value_size);
         gkoc_stream_t s, int64_t rows, T* x, T* r, T* z, T* w, T* p, T* q,     \
         T* f, T* g, const T* m, const T* n, const T* prev_rho, const T* rho,   \
         const T* delta, const T* beta_in, T* beta_out,                         \
-        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes);   \
+        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes,    \
+        const gkoc_step_gate* gate);                                           \
     /* pipe_cg::step_1 (one column, unit strides; vectors bit-identical) and     \
      * out3 = {<r,z>, <w,z>, <r,r>} of the updated vectors: the three values a   \
      * distributed PipeCg iteration all-reduces in one message */              \
@@ -1148,7 +1211,8 @@ GKOC_DECL_X(float, f32)
         const I* block_ptrs, const T* blocks, T* x, T* r, T* z, T* w, T* p,    \
         T* q, T* f, T* g, T* m, const T* n, const T* prev_rho, const T* rho,   \
         const T* delta, const T* beta_in, T* beta_out,                         \
-        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes);
+        const uint8_t* stop_status, T* out3, void* work, size_t work_bytes,    \
+        const gkoc_step_gate* gate);
 GKOC_DECL_XI2(double, f64, int32_t, i32)
 GKOC_DECL_XI2(double, f64, int64_t, i64)
 GKOC_DECL_XI2(float, f32, int32_t, i32)
@@ -1910,6 +1974,25 @@ int gkoc_comm_all_reduce_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_str
 /* the same, but main_stream also waits for the kernels enqueued on the exchange's stream since
  * gkoc_comm_exchange_begin (the boundary rows, computed there as soon as the halo is in) */
 int gkoc_comm_exchange_join(gkoc_comm_t comm, gkoc_stream_t main_stream);
+/* A fork without an event: what has been enqueued on main_stream so far happens before what is
+ * enqueued on `side` from now on.  An event record + hipStreamWaitEvent puts a barrier packet on
+ * the MAIN queue (6-7 us of idle device in front of main's next kernel on MI355X); this is two
+ * one-thread kernels - main stores `number` into *word (device memory, zero at the start), side
+ * polls until the word has reached it.  The caller counts (1, 2, ...).  The communicator's forks
+ * (gkoc_comm_exchange_begin, gkoc_comm_all_reduce_begin, gkoc_comm_all_reduce_exchange_begin)
+ * are of this kind unless GKOC_COMM_FORK=event. */
+int gkoc_stream_fork(gkoc_stream_t main_stream, gkoc_stream_t side, uint32_t* word, uint32_t number);
+/* the polling half alone: the store is done by a kernel of the caller on the main stream
+ * (gkoc_csr_spmv_gated_*: fork_word / fork_number) */
+int gkoc_stream_fork_wait(gkoc_stream_t side, const uint32_t* word, uint32_t number);
+/* The fork of the communicator's NEXT gkoc_comm_exchange_begin / _all_reduce_begin /
+ * _all_reduce_exchange_begin (same streams) is opened by the caller: *word / *number are what the
+ * caller's next kernel on main_stream has to store (gkoc_csr_spmv_gated_* does it as its first
+ * action), the begin call only enqueues the poller.  *word = NULL: not available (forks are events,
+ * or the two streams have the same priority and might share a hardware queue, where a poller in
+ * front of the storing kernel would block it) - the begin call then forks by itself as usual. */
+int gkoc_comm_fork_deferred(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_stream_t side,
+                            uint32_t** word, uint32_t* number);
 /* ends an exchange WITHOUT making the main stream wait: the kernel that reads the halo waits for
  * it itself (gkoc_gate_open on the side stream + gkoc_csr_spmv_gated_*) */
 int gkoc_comm_exchange_forget(gkoc_comm_t comm);

@@ -69,14 +69,11 @@ def mirror_problem(grid, direct=False):
             calls["ar_with_exchange"] = calls.get("ar_with_exchange", 0) + 1
             super().all_reduce_exchange_begin(t, recv, send, [plane], [plane], side_stream,
                                               None if send_displs is None else [send_displs[1]])
-            self._pending_joint = t
-
-        def exchange_join(self):
-            super().exchange_join()
-            t, self._pending_joint = getattr(self, "_pending_joint", None), None
-            if t is not None:
-                # ... and the peer's equal contribution once the main stream has the result
-                call("gkoc_dense_scale_f64", self.exec.stream, t.numel(), 1, self.two.values, 1, t, 1)
+            # ... and the peer's equal contribution, on the exchange's stream right behind the
+            # reduction: whoever waits for that stream - a join, or the step kernel through the
+            # product's gate (no join at all) - finds the doubled values
+            call("gkoc_dense_scale_f64", C.c_void_p(side_stream.cuda_stream), t.numel(), 1, self.two.values, 1,
+                 t, 1)
 
         def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None,
                            send_displs=None):
@@ -197,8 +194,16 @@ def main():
     if direct:
         import ctypes as C  # noqa: F401
         from ginkgo_amd._lib import call
-        # default: the reduction starts together with the halo exchange (one fork / join pair) ...
+        # default: the reduction starts together with the halo exchange behind one fork (opened by
+        # the product's first wave), and nothing joins: the step kernel waits for the product's gate
+        # and evaluates the criterion itself ...
         assert pipe.taped and calls.get("ar_with_exchange", 0) >= 2, calls
+        joined = gd.DistributedPipeCg(be, comm, a, 500, 1e-10, 8)
+        joined.step_gate = False               # ... the join-based form gives the same bits
+        xj = be.vector(hi - lo)
+        joined.apply(be.vector_from(np.ones(hi - lo)), xj)
+        assert joined.num_iterations == pipe.num_iterations
+        assert np.array_equal(xj.to_numpy(), xq.to_numpy())
         # ... without the preconditioner inside the step kernel m is not final at that point:
         # all_reduce_begin / _end on the side stream, the exchange inside the SpMV
         sep = gd.DistributedPipeCg(be, comm, a, 500, 1e-10, 8, fused_jacobi=False)

@@ -54,7 +54,7 @@ def test_spmv_256_with_three_two_and_one_memory_classes():
     assert r1["ms"] <= 1.20 * r3["ms"], (r1["ms"], r3["ms"])
     # never slower than the reference's one hipMalloc per array
     assert r3["ms"] <= 1.01 * r0["ms"], (r3["ms"], r0["ms"])
-    assert r2["ms"] <= 1.02 * r0["ms"], (r2["ms"], r0["ms"])
+    assert r2["ms"] <= 1.04 * r0["ms"], (r2["ms"], r0["ms"])
 
 
 def test_search_bounded_by_a_walk_limit_settles_for_what_it_found():

@@ -284,6 +284,65 @@ def test_one_kernel_product_has_the_single_domain_bits(gexec, oracle, grid, worl
         else:
             assert np.array_equal(got, ref), rep
     assert int(gate[0][0].item()) == 3 and int(gate[0][1].item()) == 0 and gate[1].value == 3
+    # the same product with <x_local, y> from its waves (one partial sum per wave, one fold launch):
+    # y keeps its bits, the dot is a tree sum of the row products
+    dot = be.vector(1)
+    y.fill(0.0)
+    be.gate_open(torch.cuda.current_stream(), gate)
+    be.spmv_gated_dot(local, nl, store, y, gate, dot)
+    assert np.array_equal(y.to_numpy()[:, 0], ref)
+    want = float(np.dot(xg[lo:hi], ref))
+    scale = float(np.dot(np.abs(xg[lo:hi]), np.abs(ref)))
+    assert abs(float(dot.to_numpy()[0, 0]) - want) <= 1e-13 * scale       # tolerance: reduction order
+    # ... and it is the same value every time (no atomics, fixed tree)
+    first = dot.to_numpy().copy()
+    be.gate_open(torch.cuda.current_stream(), gate)
+    be.spmv_gated_dot(local, nl, store, y, gate, dot)
+    assert np.array_equal(dot.to_numpy(), first)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 1000, 65536 + 3])
+@pytest.mark.parametrize("case", ["goes on", "converges", "had stopped", "zero prev_rho"])
+def test_cg_step_1_with_the_criterion_inside(gexec, n, case):
+    """gkoc_x_cg_step_1_check_* = gkoc_implicit_residual_norm_* followed by gkoc_cg_step_1_*: the
+    same p bit for bit, the same stop status, the same two flags (reference: core/solver/cg.cpp:150-162
+    - the criterion between the reductions and step_1; reference/stop/residual_norm_kernels.cpp:27-90)"""
+    import ctypes as C
+    import torch
+    import ginkgo_amd.distributed as gd
+    from ginkgo_amd._lib import call
+    be = gd.HipBackend(gexec)
+    rng = np.random.default_rng(n + len(case))
+    p0, z0 = rng.uniform(-1, 1, max(n, 1))[:n], rng.uniform(-1, 1, max(n, 1))[:n]
+    tau0 = 4.0
+    tau_sq = {"goes on": 1.0, "converges": 1e-30, "had stopped": 1.0, "zero prev_rho": 1.0}[case]
+    prev = 0.0 if case == "zero prev_rho" else 0.7
+    res = []
+    for fused in (False, True):
+        p, z = be.vector_from(p0.copy()) if n else be.vector(0), be.vector_from(z0.copy()) if n else be.vector(0)
+        rho, prev_rho = be.scalar(1.3), be.scalar(prev)
+        tau, orig = be.scalar(tau_sq), be.scalar(tau0)
+        flags, stop = be.stop_flags()
+        if case == "had stopped":
+            stop.fill_(0x40 | 1)
+        host = torch.full((2,), 0xFF, dtype=torch.uint8).pin_memory()
+        if fused:
+            call("gkoc_x_cg_step_1_check_f64", gexec.stream, n, p.values, z.values, rho.values, prev_rho.values,
+                 tau.values, orig.values, C.c_double(1e-10), C.c_int(1), C.c_uint8(2), C.c_int(1), stop, host)
+        else:
+            call("gkoc_implicit_residual_norm_f64", gexec.stream, 1, tau.values, orig.values, C.c_double(1e-10),
+                 C.c_uint8(2), C.c_int(1), stop, host, None, None)
+            be.cg_step_1(p, z, rho, prev_rho, stop)
+        gexec.synchronize()
+        res.append((p.to_numpy().copy(), int(stop.cpu()[0]), host.clone().tolist()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2], (res[0][1:], res[1][1:])
+    if case == "converges":
+        assert res[1][1] == (0x80 | 0x40 | 2) and res[1][2] == [1, 1]
+        assert np.array_equal(res[1][0].ravel(), p0)      # p left alone
+    if case == "goes on" and n:
+        assert res[1][2] == [0, 0] and not np.array_equal(res[1][0].ravel(), p0)
 
 
 def _late_gate(gexec, be, local, nl, recv_gidx, x_local, halo_vals, delay_us=5000):
@@ -355,6 +414,115 @@ def test_one_kernel_product_waits_for_a_late_halo(gexec, oracle, grid, world, ra
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["goes on", "converges", "late gate"])
+def test_pipe_cg_step_kernel_waits_and_judges_the_criterion_itself(gexec, oracle, case):
+    """gkoc_x_pipe_cg_steps_jacobi_*(gate): the wait for the all-reduced scalars (the product's gate
+    word) and ImplicitResidualNorm inside the step kernel = a join + gkoc_implicit_residual_norm_* +
+    the plain step kernel: same ten vectors, same partial sums, same stop status and flags; "late
+    gate": the word is set 3 ms AFTER the kernel was launched, from another stream."""
+    import ctypes as C
+    import torch
+    import ginkgo_amd as g
+    import ginkgo_amd.distributed as gd
+    from ginkgo_amd._lib import call
+    grid = 20
+    n = grid ** 3
+    be = gd.HipBackend(gexec)
+    a = g.stencil_csr(gexec, 3, grid)
+    m_op = be.jacobi(a, 8)
+    rng = np.random.default_rng(3)
+    base = [rng.uniform(-1, 1, n) for _ in range(10)]
+    res = []
+    for gated in (False, True):
+        vecs = [be.vector_from(b.copy()) for b in base]
+        x, r, z, w, p, q, f, gg, m, nn = vecs
+        trip_t, trip = be.scalar_tuple(3)
+        trip_t.copy_(torch.tensor([1.3, 0.9, 1e-30 if case == "converges" else 2.0], dtype=torch.float64))
+        prev_rho, tau0 = be.scalar(0.7), be.scalar(4.0)
+        b_in, b_out = be.scalar(0.4), be.scalar(0.0)
+        out3 = gexec.zeros((3,), torch.float64)
+        flags, stop = be.stop_flags()
+        slot = be.check_slot()
+        if gated:
+            gate = be.gate_new()
+            side = be.side_stream()
+            if case == "late gate":
+                call("gkoc_debug_delay", C.c_void_p(side.cuda_stream), C.c_int64(3000), 1, 64, 0)
+            be.gate_open(side, gate)
+            sg = be.step_gate(gate, trip[2], tau0, 1e-10, stop, slot)
+            t0 = torch.cuda.Event(enable_timing=True)
+            t1 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+            assert be.pipe_cg_steps_jacobi(m_op, x, r, z, w, p, q, f, gg, m, nn, prev_rho, trip[0], trip[1],
+                                           b_in, b_out, stop, out3, gate=sg)
+            t1.record()
+            gexec.synchronize()
+            assert int(gate[0][1].item()) == 0
+            if case == "late gate":
+                assert 2.5 < t0.elapsed_time(t1) < 50.0
+        else:
+            call("gkoc_implicit_residual_norm_f64", gexec.stream, 1, trip[2].values, tau0.values,
+                 C.c_double(1e-10), C.c_uint8(2), C.c_int(1), stop, be._chk_host[slot], None, None)
+            assert be.pipe_cg_steps_jacobi(m_op, x, r, z, w, p, q, f, gg, m, nn, prev_rho, trip[0], trip[1],
+                                           b_in, b_out, stop, out3)
+            gexec.synchronize()
+        res.append(([v.to_numpy().copy() for v in vecs], out3.cpu().numpy().copy(), int(stop.cpu()[0]),
+                    be._chk_host[slot].clone().tolist(), float(b_out.to_numpy()[0, 0])))
+    for va, vb in zip(res[0][0], res[1][0]):
+        assert np.array_equal(va, vb)
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:], (res[0][2:], res[1][2:])
+    if case == "converges":
+        assert res[1][2] == (0x80 | 0x40 | 2) and res[1][3] == [1, 1]
+        assert np.array_equal(res[1][0][0][:, 0], base[0])          # x left alone
+    else:
+        assert res[1][3] == [0, 0] and not np.array_equal(res[1][0][0][:, 0], base[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_dot", [False, True])
+def test_product_opens_the_fork_of_its_own_exchange(gexec, oracle, with_dot):
+    """gkoc_csr_spmv_gated_*(fork_word, fork_number): the product's first wave stores the number,
+    the exchange's stream - enqueued BEFORE the product, polling with gkoc_stream_fork_wait - then
+    delivers the halo and opens the gate, the boundary waves of the same launch take it.  No event,
+    no kernel in front of the product.  Three products in a row (the numbers count), single-domain
+    bits every time."""
+    import ctypes as C
+    import torch
+    from ginkgo_amd._lib import call
+    grid, world, rank = 64, 8, 3
+    n = grid ** 3
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    be, local, nl, recv_gidx, lo, hi = _slab(gexec, oracle, grid, world, rank)
+    f = nl["full"]
+    store = gexec.zeros((f["halo_base"] + recv_gidx.numel(),), torch.float64)
+    y, dot = be.vector(hi - lo), be.vector(1)
+    gate = be.gate_new()
+    side = be.side_stream()
+    sst = C.c_void_p(side.cuda_stream)
+    word = gexec.zeros((64,), torch.int32)
+    for k in range(1, 4):
+        xg = np.random.default_rng(k).uniform(-1, 1, n)
+        ref = oracle.csr_spmv(rp, ci, v, xg)[lo:hi]
+        halo = torch.from_numpy(xg[recv_gidx.cpu().numpy().astype(np.int64)]).to(store.device)
+        xl = torch.from_numpy(xg[lo:hi]).to(store.device)
+        store[:hi - lo].copy_(xl)                                 # main stream: "step_1" writes p
+        call("gkoc_stream_fork_wait", sst, word, C.c_uint32(k))   # side: waits for the product's start
+        with torch.cuda.stream(side):
+            store[f["halo_base"]:].copy_(halo)                    # the "exchange"
+        be.gate_open(side, gate)
+        if with_dot:
+            be.spmv_gated_dot(local, nl, store, y, gate, dot, fork=(word, C.c_uint32(k)))
+        else:
+            be.spmv_gated(local, nl, store, y, gate, fork=(word, C.c_uint32(k)))
+        torch.cuda.synchronize()
+        assert np.array_equal(y.to_numpy()[:, 0], ref), k
+        assert int(word[0].item()) == k and int(gate[0][1].item()) == 0
+        if with_dot:
+            want = float(np.dot(xg[lo:hi], ref))
+            assert abs(float(dot.to_numpy()[0, 0]) - want) <= 1e-13 * float(np.dot(np.abs(xg[lo:hi]), np.abs(ref)))
+
+
+@pytest.mark.gpu
 def test_big_slabs_take_the_join_based_product(gexec, oracle):
     """config 3's slab has 512^2-row planes: 2 x 4096 boundary waves, more than may wait on the device
     at once.  The one-kernel product refuses it (gkoc_csr_spmv_gated_fits / GKOC_E_NOT_SUPPORTED) and
@@ -387,7 +555,7 @@ def test_big_slabs_take_the_join_based_product(gexec, oracle):
                                        C.c_void_p(f["ptrs"].data_ptr()), C.c_void_p(f["cols"].data_ptr()),
                                        C.c_void_p(f["vals"].data_ptr()), C.c_void_p(store.data_ptr()),
                                        C.c_void_p(y.values.data_ptr()), C.c_int64(n_plane), C.c_int64(n_plane),
-                                       C.c_void_p(gate[0].data_ptr()), C.c_uint32(1))
+                                       C.c_void_p(gate[0].data_ptr()), C.c_uint32(1), C.c_void_p(0), C.c_uint32(0))
     assert rc != 0 and b"gkoc_csr_spmv_gated_fits" in L.gkoc_last_error()
 
 

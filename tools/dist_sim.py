@@ -11,8 +11,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 
+import ctypes as C
+
 import ginkgo_amd as g
 import ginkgo_amd.distributed as gd
+from ginkgo_amd._lib import bump, call
 
 grid = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -30,6 +33,33 @@ class FakeComm:
 
     def __init__(self):
         self.rank, self.size = rank, world
+        # forks as the library's communicator makes them (csrc/comm.hip): two one-thread kernels,
+        # or an event pair with GKOC_COMM_FORK=event
+        self._fork_word = None if os.environ.get("GKOC_COMM_FORK") == "event" else \
+            ex.zeros((64,), torch.int32)
+        self._fork_n = C.c_uint32(0)
+
+    def fork_deferred(self, side_stream):
+        if self._fork_word is None:
+            return None
+        bump(self._fork_n)
+        self._deferred = True
+        return (self._fork_word, self._fork_n)
+
+    def _fork(self, side_stream):
+        if getattr(self, "_deferred", False):
+            # the store is the product's first wave; only the poller here
+            self._deferred = False
+            call("gkoc_stream_fork_wait", C.c_void_p(side_stream.cuda_stream), self._fork_word, self._fork_n)
+            return
+        if self._fork_word is None:
+            ev = torch.cuda.Event()
+            ev.record()
+            side_stream.wait_event(ev)
+        else:
+            bump(self._fork_n)
+            call("gkoc_stream_fork", ex.stream, C.c_void_p(side_stream.cuda_stream), self._fork_word,
+                 self._fork_n)
 
     def all_reduce_sum_(self, t):
         return t
@@ -38,9 +68,7 @@ class FakeComm:
     # gkoc_comm_all_reduce_begin / _end (each is a barrier packet on the device)
     def all_reduce_begin(self, t, side_stream=None):
         if side_stream is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            side_stream.wait_event(ev)
+            self._fork(side_stream)
             self._ar_done = torch.cuda.Event()
             self._ar_done.record(side_stream)
         return t
@@ -58,11 +86,9 @@ class FakeComm:
     direct = True
 
     def exchange_begin(self, recv, send, recv_counts, send_counts, side_stream=None, send_displs=None):
-        ev = torch.cuda.Event()
-        ev.record()
         self._side = side_stream
+        self._fork(side_stream)
         with torch.cuda.stream(side_stream):
-            side_stream.wait_event(ev)
             recv.view(-1).copy_(send.view(-1)[:recv.numel()])
 
     def exchange_end(self):
