@@ -201,7 +201,10 @@ def ginkgo_api_bench(grid, steps, cg_iters):
     if not os.path.exists(exe):
         return None
     out = {}
-    for fused in (0, 1):
+    # GKOC_TUNE_DEFERRED_FUSION: 0 = by-products (the default: nothing held back, cg::step_2 leaves
+    # ||r|| and the block-Jacobi application <r, z> behind), 2 = one kernel per call, 1 = calls held
+    # back and fused (opt-in)
+    for fused in (0, 2, 1):
         env = dict(os.environ, GKOC_TUNE_5=str(fused))
         try:
             p = subprocess.run([exe, str(grid), str(steps), str(cg_iters), "--json"], capture_output=True,
@@ -218,7 +221,12 @@ def ginkgo_api_bench(grid, steps, cg_iters):
                         "frac": round(nbytes / r["csr_apply_ms"] / 1e6 / HBM_PEAK_GBS, 4),
                         "cg_iters_per_s": r["cg_iters_per_s"], "cg_ms_per_iter": r["cg_ms_per_iter"],
                         "cg_iterations": r["cg_iterations"], "memory_classes": r["memory_classes"],
-                        "fused_across_calls": False})
+                        "fused_across_calls": False,
+                        "note": "default: no call is held back; ||r|| and <r,z> come with cg::step_2 and "
+                                "the block-Jacobi application (gko_binding/fusion.cpp, by-products)"})
+        elif fused == 2:
+            out["one_kernel_per_call"] = {"cg_iters_per_s": r["cg_iters_per_s"],
+                                          "note": "GKOC_TUNE_DEFERRED_FUSION=2"}
         else:
             out["with_fusion_across_calls"] = {"csr_apply_ms": r["csr_apply_ms"],
                                                "cg_iters_per_s": r["cg_iters_per_s"],
@@ -524,7 +532,7 @@ def main():
         out["config"]["class_of"] = placement["class_of"]
         if not args.no_ginkgo_api and not use_dist:
             torch.cuda.synchronize()
-            api = ginkgo_api_bench(grid, args.steps, args.cg_iters if args.cg_iters > 0 else 20)
+            api = ginkgo_api_bench(grid, args.steps, max(args.cg_iters, 200) if args.cg_iters > 0 else 20)
             if api is not None:
                 out["ginkgo_api"] = api
         cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gko_bench_cpu_baseline_{grid}.json")

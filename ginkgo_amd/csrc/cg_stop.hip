@@ -300,6 +300,42 @@ int launch_residual_norm(gkoc_stream_t s, int64_t cols, const T* tau,
                  GKOC_E_INVALID, "pass both host results or neither");
     GKOC_REQUIRE(cols >= 0, GKOC_E_INVALID, "negative dimension");
     GKOC_REQUIRE(flags, GKOC_E_INVALID, "null flag storage");
+    if (all_converged) {
+        // The synchronous form (Ginkgo's core reads the two answers at once, residual_norm.cpp): the
+        // kernel writes them into a pinned word of this thread and the host polls it - the answer is
+        // there a few microseconds after the kernel has run, where a 2-byte copy + stream
+        // synchronisation costs an interrupt round trip per iteration.  Falls back to the copy if
+        // pinned memory is not to be had or the word does not arrive.
+        thread_local volatile uint8_t* pinned = nullptr;
+        thread_local bool tried = false;
+        if (!tried) {
+            tried = true;
+            void* hp = nullptr;
+            if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess) {
+                pinned = static_cast<volatile uint8_t*>(hp);
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (pinned) {
+            pinned[0] = pinned[1] = 0xFF;
+            residual_norm_kernel<T, IMPLICIT><<<dim3(1), dim3(256), 0, as_stream(s)>>>(
+                cols, tau, orig_tau, goal, id, set_finalized != 0, stop, const_cast<uint8_t*>(pinned));
+            GKOC_LAUNCH_OK();
+            for (long spins = 0; pinned[0] == 0xFF || pinned[1] == 0xFF; ++spins) {
+                if (spins == (long(1) << 22)) {
+                    // not there after ~10 ms of polling: let the stream drain (the stores are visible then)
+                    GKOC_HIP(hipStreamSynchronize(as_stream(s)));
+                } else if (spins > (long(1) << 22) + 1000) {
+                    set_last_error("residual_norm: the criterion's flags did not arrive in pinned memory");
+                    return GKOC_E_INVALID;
+                }
+            }
+            *all_converged = pinned[0];
+            *one_changed = pinned[1];
+            return GKOC_OK;
+        }
+    }
     residual_norm_kernel<T, IMPLICIT><<<dim3(1), dim3(256), 0, as_stream(s)>>>(
         cols, tau, orig_tau, goal, id, set_finalized != 0, stop, flags);
     GKOC_LAUNCH_OK();

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
             // Ordering of the halo reads behind the gate.  For the compiler: a workgroup-scope acquire
             // (no instruction).  For the caches: an agent-scope acquire invalidates this XCD's L2 for
             // EVERY wave that runs on it - 2048 of them cost the product 8 us (138 -> 146 us per rank
-            // of 8 on 256^3, profiles/r04_gate_fence.txt) - and is needed only if a line of the halo
+            // of 8 on 256^3, profiles/r04_dist_sim_variants.txt) - and is needed only if a line of the halo
             // can sit in a cache from BEFORE the exchange wrote it.  None can: the halo starts on a
             // 128-byte boundary behind the local vector, so interior waves never touch its lines;
             // boundary waves touch them only after they have seen the gate open (the spin loop's exit

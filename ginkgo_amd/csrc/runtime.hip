@@ -74,6 +74,11 @@ int64_t tune_value(int key)
     return g_tune[key];
 }
 
+__global__ void small_copy_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int words)
+{
+    if (int(threadIdx.x) < words) dst[threadIdx.x] = src[threadIdx.x];
+}
+
 }  // namespace gkoc
 
 using namespace gkoc;
@@ -307,6 +312,15 @@ int gkoc_memcpy_d2h(void* dst, const void* src, size_t bytes, gkoc_stream_t s)
 int gkoc_memcpy_d2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s)
 {
     if (bytes == 0) return GKOC_OK;
+    // a scalar or two (a reduction's result handed on): one wave of our own instead of the
+    // runtime's copy path
+    if (bytes <= 256 && bytes % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(src) % 4 == 0) {
+        gkoc::small_copy_kernel<<<dim3(1), dim3(64), 0, as_stream(s)>>>(
+            static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), int(bytes / 4));
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     GKOC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(s)));
     return GKOC_OK;
 }

@@ -23,6 +23,24 @@
 // device pointers of a solver's INTERNAL vectors and reads them with its own launches between two
 // backend calls - GKOC_TUNE_DEFERRED_FUSION = 0 (gkoc_tune_set / env GKOC_TUNE_5) switches the
 // mechanism off.
+//
+// BY-PRODUCTS (the default, GKOC_TUNE_DEFERRED_FUSION = 0): nothing is held, every call launches at
+// once - but two of the kernels leave something behind that a later call would otherwise compute
+// with a pass of its own:
+//     cg::step_2                   also leaves ||r|| (gkoc_x_cg_step_2_norm_*: the new r is in registers)
+//     jacobi::simple_apply(b -> z) also leaves <b, z> (gkoc_x_jacobi_simple_apply_dot_*)
+//     compute_conj_dot(r, z)       -> an 8-byte copy if (operands, length, stream) are those of the
+//                                     apply and nothing has entered the backend since, else a reduction
+//     compute_norm2(r)             -> the same for ||r||
+// x, r, z have the bits of the separate kernels and exist when the call returns, so code that reads
+// a solver's vectors with its own launches between two calls (the case ADVICE r03 raised against
+// holding calls back) sees what the reference would show it.  A by-product is forgotten by EVERY
+// entry into the backend except the reading calls above (stream_of() -> flush_deferred()): a kernel
+// that rewrites r or z is such an entry.  Per-iteration saving on the 27-pt 256^3 problem: the two
+// reductions' passes over r and z, 70 of 1610 us.  GKOC_TUNE_DEFERRED_FUSION = 2: one kernel per call.
+#include <map>
+#include <utility>
+
 #include "shim_common.hpp"
 
 namespace gko {
@@ -62,14 +80,59 @@ struct held_ops {
 // launch it.
 thread_local held_ops held;
 
-int enabled()
+// 0: by-products (default), 1: calls held back and fused (opt-in), 2: one kernel per call
+int mode()
 {
-    int64_t v = 1;
+    int64_t v = 0;
     gkoc_tune_get(GKOC_TUNE_DEFERRED_FUSION, &v);
-    return v != 0;
+    return static_cast<int>(v);
 }
 
-void publish() { deferred_state = held.stage | (held.norm_of ? 4 : 0); }
+int enabled() { return mode() == 1; }
+
+// <b, z> left behind by the block-Jacobi application
+struct dot_byproduct {
+    const void* x = nullptr;
+    const void* y = nullptr;
+    const void* at = nullptr;
+    int vt = 0;
+    int64_t n = 0;
+    gkoc_stream_t s = nullptr;
+};
+thread_local dot_byproduct bp_dot;
+// how often a reduction was answered by a by-product (tests)
+thread_local int64_t hits_norm = 0, hits_dot = 0;
+
+void publish() { deferred_state = held.stage | (held.norm_of ? 4 : 0) | (bp_dot.x ? 8 : 0); }
+
+// Device memory of the by-products, one block per (device, stream) this thread has used:
+// [||r|| : 64 B | <b,z> : 64 B | workspace of the step_2 pass | workspace of the apply pass].
+// Kept for the life of the thread (a few MB: 8 bytes per 64 rows, twice).
+struct side_block {
+    char* p = nullptr;
+    size_t work = 0;
+};
+thread_local std::map<std::pair<int, gkoc_stream_t>, side_block> side_blocks;
+
+side_block* side_for(int dev, gkoc_stream_t s, size_t work)
+{
+    work = (work + 255) / 256 * 256;
+    auto& b = side_blocks[{dev, s}];
+    if (b.p == nullptr || b.work < work) {
+        if (b.p) {
+            gkoc_free(b.p);      // (synchronises: nothing in flight uses it)
+            b.p = nullptr;
+        }
+        void* mem = nullptr;
+        if (gkoc_malloc(&mem, 128 + 2 * work) != GKOC_OK) {
+            b.work = 0;
+            return nullptr;
+        }
+        b.p = static_cast<char*>(mem);
+        b.work = work;
+    }
+    return &b;
+}
 
 void launch_step_2(const held_ops& h)
 {
@@ -123,6 +186,7 @@ void flush_deferred()
     const held_ops h = held;
     held.stage = 0;
     held.norm_of = nullptr;
+    bp_dot.x = nullptr;
     publish();
     if (h.stage == 3) {
         launch_sub_scaled(h);
@@ -191,9 +255,102 @@ bool hold_jacobi_apply(int vt, int it, gkoc_stream_t s, int64_t num_blocks, uint
     return true;
 }
 
+// cg::step_2 that leaves ||r_new|| behind (by-product mode; the caller has been through stream_of())
+bool step_2_with_norm(int vt, int dev, gkoc_stream_t s, int64_t n, void* x, void* r, const void* p,
+                      const void* q, const void* beta, const void* rho, const uint8_t* stop)
+{
+    if (n <= 0 || mode() != 0) return false;
+    const size_t work = gkoc_x_workspace_bytes(n, vt == 0 ? 8 : 4);
+    side_block* b = side_for(dev, s, work);
+    if (!b) return false;
+    int rc;
+    if (vt == 0) {
+        rc = gkoc_x_cg_step_2_norm_f64(s, n, static_cast<double*>(x), static_cast<double*>(r),
+                                       static_cast<const double*>(p), static_cast<const double*>(q),
+                                       static_cast<const double*>(beta), static_cast<const double*>(rho), stop,
+                                       reinterpret_cast<double*>(b->p), 1, b->p + 128, b->work);
+    } else {
+        rc = gkoc_x_cg_step_2_norm_f32(s, n, static_cast<float*>(x), static_cast<float*>(r),
+                                       static_cast<const float*>(p), static_cast<const float*>(q),
+                                       static_cast<const float*>(beta), static_cast<const float*>(rho), stop,
+                                       reinterpret_cast<float*>(b->p), 1, b->p + 128, b->work);
+    }
+    if (rc != GKOC_OK) return false;    // refused before anything was launched: the plain kernel runs
+    held.norm_of = r;
+    held.norm_at = b->p;
+    held.norm_vt = vt;
+    held.norm_n = n;
+    held.norm_s = s;
+    publish();
+    return true;
+}
+
+// jacobi::simple_apply(b -> z) that leaves <b, z> behind (by-product mode).  A reading call: what
+// step_2 left behind stays valid unless z is the vector it belongs to.
+bool jacobi_apply_with_dot(int vt, int it, int dev, gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
+                           gkoc_jacobi_scheme scheme, const void* block_ptrs, const void* blocks,
+                           const void* b, int64_t n, void* z)
+{
+    if (mode() != 0 || held.stage != 0 || n <= 0 || num_blocks <= 0 || z == b) return false;
+    const int64_t bo = scheme.block_offset;
+    const bool fast_layout = bo >= 1 && bo <= 16 && (bo & (bo - 1)) == 0 &&
+                             (bo << scheme.group_power) == 64 && int64_t(max_bs) <= bo;
+    if (!fast_layout) return false;
+    if (z == held.norm_of) held.norm_of = nullptr;
+    bp_dot.x = nullptr;
+    publish();
+    const size_t work = gkoc_x_workspace_bytes(n, vt == 0 ? 8 : 4);
+    side_block* sb = side_for(dev, s, work);
+    if (!sb) return false;
+    if (held.norm_of && held.norm_at != sb->p) {
+        // (the block was re-allocated under a by-product of this stream: gone)
+        held.norm_of = nullptr;
+        publish();
+    }
+    char* dot_at = sb->p + 64;
+    char* wk = sb->p + 128 + sb->work;
+    int rc = GKOC_E_NOT_SUPPORTED;
+#define CASE(VT, IT, T, I, TN, IN)                                                                     \
+    if (vt == VT && it == IT) {                                                                        \
+        rc = gkoc_x_jacobi_simple_apply_dot_##TN##_##IN(                                               \
+            s, num_blocks, n, max_bs, scheme, static_cast<const I*>(block_ptrs),                       \
+            static_cast<const T*>(blocks), static_cast<const T*>(b), static_cast<T*>(z),               \
+            reinterpret_cast<T*>(dot_at), wk, sb->work);                                               \
+    }
+    GKOC_FUSION_TYPES(CASE)
+#undef CASE
+    if (rc != GKOC_OK) return false;    // refused before anything was launched
+    bp_dot.x = b;
+    bp_dot.y = z;
+    bp_dot.at = dot_at;
+    bp_dot.vt = vt;
+    bp_dot.n = n;
+    bp_dot.s = s;
+    publish();
+    return true;
+}
+
+// A call that only READS vectors (a reduction into `result`) is about to launch: what is held is
+// launched, by-products stay unless the result overwrites something they belong to.
+void launch_deferred_for_read(const void* result)
+{
+    if (deferred_state == 0) return;
+    if (held.stage != 0 || result == held.norm_of || result == bp_dot.x || result == bp_dot.y) {
+        flush_deferred();
+    }
+}
+
 bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y, void* result,
                array<char>& tmp)
 {
+    if (held.stage == 0 && bp_dot.x != nullptr && bp_dot.vt == vt && bp_dot.s == s && bp_dot.n == n &&
+        ((x == bp_dot.x && y == bp_dot.y) || (x == bp_dot.y && y == bp_dot.x)) && result != x &&
+        result != y) {
+        // <b, z> came with the block-Jacobi application and nothing has entered the backend since
+        GKOC_CALL(gkoc_memcpy_d2d(result, bp_dot.at, vt == 0 ? 8 : 4, s));
+        ++hits_dot;
+        return true;
+    }
     if (held.stage == 3) {
         // w -= h_i v_i is held and this is <v_{i+1}, w> (either operand order): one pass over w
         const void* other = y == held.ss_y ? x : (x == held.ss_y ? y : nullptr);
@@ -292,6 +449,7 @@ bool cached_norm2(int vt, gkoc_stream_t s, int64_t n, const void* x, void* resul
     }
     if (!src) return false;
     GKOC_CALL(gkoc_memcpy_d2d(result, src, vt == 0 ? 8 : 4, s));
+    ++hits_norm;
     // the value stays valid: nothing has touched r
     return true;
 }
@@ -301,3 +459,9 @@ bool cached_norm2(int vt, gkoc_stream_t s, int64_t n, const void* x, void* resul
 
 // for code outside the binding that launches on the executor's stream (rccl_communicator.hpp)
 extern "C" void gko_cdna4_launch_deferred() { gko::cdna4::launch_deferred(); }
+// reductions of the calling thread that were answered by a value another kernel had left behind
+extern "C" void gko_cdna4_byproduct_hits(int64_t* norms, int64_t* dots)
+{
+    if (norms) *norms = gko::cdna4::hits_norm;
+    if (dots) *dots = gko::cdna4::hits_dot;
+}

@@ -420,14 +420,16 @@ inline void* scratch(array<char>& tmp, int64_t n, int64_t nrhs, size_t& bytes)
                              cdna4::stream_keeping_deferred(exec), rows(x),     \
                              x->get_const_values(), y->get_const_values(),      \
                              result->get_values(), tmp)) {                      \
-            return; /* step_2 + block-Jacobi + this dot in one launch */        \
+            return; /* step_2 + block-Jacobi + this dot in one launch, or the   \
+                       value the block-Jacobi application left behind */        \
         }                                                                       \
-        cdna4::launch_deferred();                                               \
+        cdna4::launch_deferred_for_read(result->get_values());                  \
         size_t bytes = 0;                                                       \
         void* w = scratch<T>(tmp, rows(x), cols(x), bytes);                     \
         GKOC_CALL(gkoc_dense_compute_dot_##TN(                                  \
-            stream_of(exec), rows(x), cols(x), x->get_const_values(), ld(x),    \
-            y->get_const_values(), ld(y), result->get_values(), w, bytes));     \
+            cdna4::stream_keeping_deferred(exec), rows(x), cols(x),             \
+            x->get_const_values(), ld(x), y->get_const_values(), ld(y),         \
+            result->get_values(), w, bytes));                                   \
     }                                                                           \
     template <>                                                                 \
     void compute_dot_dispatch<T>(exec_t exec, const matrix::Dense<T>* x,        \
@@ -461,12 +463,12 @@ inline void* scratch(array<char>& tmp, int64_t n, int64_t nrhs, size_t& bytes)
                                 x->get_const_values(), result->get_values())) { \
             return; /* computed by the fused launch that produced x */          \
         }                                                                       \
-        cdna4::launch_deferred();                                               \
+        cdna4::launch_deferred_for_read(result->get_values());                  \
         size_t bytes = 0;                                                       \
         void* w = scratch<T>(tmp, rows(x), cols(x), bytes);                     \
         GKOC_CALL(gkoc_dense_compute_norm2_##TN(                                \
-            stream_of(exec), rows(x), cols(x), x->get_const_values(), ld(x),    \
-            result->get_values(), w, bytes));                                   \
+            cdna4::stream_keeping_deferred(exec), rows(x), cols(x),             \
+            x->get_const_values(), ld(x), result->get_values(), w, bytes));     \
     }                                                                           \
     template <>                                                                 \
     void compute_norm2_dispatch<T>(exec_t exec, const matrix::Dense<T>* x,      \
@@ -600,6 +602,16 @@ namespace cg {
                                beta->get_const_values(),                        \
                                rho->get_const_values(), raw(stop_status))) {    \
             return; /* launched by the next call into the backend */           \
+        }                                                                       \
+        if (cols(x) == 1 && ld(x) == 1 && ld(r) == 1 && ld(p) == 1 &&           \
+            ld(q) == 1 &&                                                       \
+            cdna4::step_2_with_norm(                                            \
+                cdna4::vt_of<T>(), exec->get_device_id(),                       \
+                cdna4::stream_keeping_deferred(exec), rows(x), x->get_values(), \
+                r->get_values(), p->get_const_values(), q->get_const_values(),  \
+                beta->get_const_values(), rho->get_const_values(),              \
+                raw(stop_status))) {                                            \
+            return; /* step_2, and ||r|| for the criterion left behind */       \
         }                                                                       \
         GKOC_CALL(gkoc_cg_step_2_##TN(                                          \
             stream_of(exec), rows(x), cols(x), x->get_values(), ld(x),          \
@@ -904,6 +916,16 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
                 block_pointers.get_const_data(), blocks.get_const_data(),       \
                 b->get_const_values(), rows(b), x->get_values())) {             \
             return; /* follows a held cg::step_2: see fusion.cpp */             \
+        }                                                                       \
+        if (!has_precisions<T>(block_precisions) && cols(b) == 1 &&             \
+            ld(b) == 1 && ld(x) == 1 &&                                         \
+            cdna4::jacobi_apply_with_dot(                                       \
+                cdna4::vt_of<T>(), cdna4::it_of<I>(), exec->get_device_id(),    \
+                cdna4::stream_keeping_deferred(exec), num_blocks,               \
+                max_block_size, scheme_of(storage_scheme),                      \
+                block_pointers.get_const_data(), blocks.get_const_data(),       \
+                b->get_const_values(), rows(b), x->get_values())) {             \
+            return; /* x = M b, and <b, x> left behind for the dot that follows */ \
         }                                                                       \
         if (has_precisions<T>(block_precisions)) {                              \
             GKOC_CALL(adaptive_abi<I>::apply(                                   \

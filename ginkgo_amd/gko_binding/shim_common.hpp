@@ -59,6 +59,14 @@ bool hold_sub_scaled(int vt, gkoc_stream_t s, int64_t n, const void* alpha, cons
 bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y, void* result,
                array<char>& tmp);
 bool cached_norm2(int vt, gkoc_stream_t s, int64_t n, const void* x, void* result);
+// by-products (fusion.cpp): nothing held, two kernels leave ||r|| / <b, z> behind for the calls
+// that would otherwise compute them with a pass of their own
+bool step_2_with_norm(int vt, int dev, gkoc_stream_t s, int64_t n, void* x, void* r, const void* p,
+                      const void* q, const void* beta, const void* rho, const uint8_t* stop);
+bool jacobi_apply_with_dot(int vt, int it, int dev, gkoc_stream_t s, int64_t num_blocks, uint32_t max_bs,
+                           gkoc_jacobi_scheme scheme, const void* block_ptrs, const void* blocks,
+                           const void* b, int64_t n, void* z);
+void launch_deferred_for_read(const void* result);
 
 // the stream of a kernel launch: what was held back is launched first
 inline gkoc_stream_t stream_of(const std::shared_ptr<const HipExecutor>& exec)

@@ -49,6 +49,7 @@ using it = gko::int32;
 using Csr = gko::matrix::Csr<vt, it>;
 using Dense = gko::matrix::Dense<vt>;
 
+extern "C" void gko_cdna4_byproduct_hits(int64_t* norms, int64_t* dots);
 static int failures = 0;
 template <typename T>
 struct type_tag {
@@ -294,10 +295,28 @@ int main(int argc, char** argv)
                 return std::make_pair(gko::clone(ref, x), tau);
             };
             auto h_on = std::make_shared<history>(), h_off = std::make_shared<history>();
-            int it_on = 0, it_off = 0, it_plain = 0;
+            int it_on = 0, it_off = 0, it_plain = 0, it_by = 0;
             auto on = run(1, h_on, it_on);
-            auto off = run(0, h_off, it_off);
+            auto off = run(2, h_off, it_off);         // one kernel per call
             auto plain = run(1, nullptr, it_plain);   // no logger in between: every iteration fuses
+            // the default: nothing held, cg::step_2 leaves ||r|| and the block-Jacobi application <r, z>
+            int64_t n0 = 0, d0 = 0, n1 = 0, d1 = 0;
+            gko_cdna4_byproduct_hits(&n0, &d0);
+            auto h_by = std::make_shared<history>();
+            auto by = run(0, h_by, it_by);
+            gko_cdna4_byproduct_hits(&n1, &d1);
+            std::cout << "  by-products: " << it_by << " iterations, " << (n1 - n0) << " norms and " << (d1 - d0)
+                      << " dots answered without a pass of their own" << std::endl;
+            CHECK(it_by == it_off && rel_err(by.first.get(), off.first.get()) < 1e-12,
+                  "CG with by-products (default): same iterations and solution as one kernel per call");
+            CHECK(n1 - n0 >= it_by - 1 && d1 - d0 >= it_by - 1,
+                  "CG with by-products: ||r|| and <r,z> of every iteration came with step_2 / the Jacobi application");
+            // (the logger above reads r on the host AFTER the criterion has used the value step_2 left)
+            std::cout << "  criterion's ||r|| " << by.second << ", norm of r on the device " << h_by->rnorm.back()
+                      << ", one kernel per call " << off.second << std::endl;
+            CHECK(std::abs(by.second - h_by->rnorm.back()) <= 1e-13 * h_by->rnorm.back() &&
+                      std::abs(by.second - off.second) <= 1e-8 * off.second,
+                  "CG with by-products: the criterion's ||r|| is the norm of r on the device");
             CHECK(it_on == it_off && it_on == it_plain && it_on == it_hip,
                   "CG with fusion across calls: same iteration count as without");
             CHECK(rel_err(on.first.get(), off.first.get()) < 1e-12 &&
@@ -361,9 +380,80 @@ int main(int argc, char** argv)
             };
             int it_f = 0, it_u = 0;
             auto xf = run_small(1, it_f);
-            auto xu = run_small(0, it_u);
+            auto xu = run_small(2, it_u);
             CHECK(it_f > 0 && it_f == it_u, "CG with small user blocks (fused kernel has no room): runs, same iterations");
             CHECK(rel_err(xf.get(), xu.get()) < 1e-12, "CG with small user blocks: same solution with fusion on and off");
+        }
+        {
+            // A preconditioner the backend knows nothing about: a user LinOp that launches ITS OWN work
+            // on the executor's stream (here through the C ABI directly, not through a Ginkgo kernel,
+            // so the binding sees no call): z = r / 26.  It reads r right after cg::step_2 - with
+            // by-products nothing is delayed, so it must see the new r; ||r|| of the criterion still
+            // comes with step_2, <r, z> is a reduction of its own.  Iterates = the reference's.
+            struct UserScale : gko::EnableLinOp<UserScale> {
+                UserScale(std::shared_ptr<const gko::Executor> e, gko::dim<2> sz = {})
+                    : gko::EnableLinOp<UserScale>(e, sz)
+                {}
+                void apply_impl(const gko::LinOp* b, gko::LinOp* x) const override
+                {
+                    auto bd = gko::as<Dense>(b);
+                    auto xd = gko::as<Dense>(x);
+                    const auto nn = bd->get_size()[0];
+                    if (auto h = std::dynamic_pointer_cast<const gko::HipExecutor>(this->get_executor())) {
+                        auto st = reinterpret_cast<gkoc_stream_t>(h->get_stream());
+                        gkoc_memcpy_d2d(xd->get_values(), bd->get_const_values(), nn * sizeof(vt), st);
+                        static std::shared_ptr<Dense> inv;
+                        if (!inv) inv = gko::initialize<Dense>({1.0 / 26.0}, h);
+                        gkoc_dense_scale_f64(st, static_cast<int64_t>(nn), 1, inv->get_const_values(), 1,
+                                             xd->get_values(), 1);   /* rows, cols, alpha, alpha_cols, x, ldx */
+                    } else {
+                        for (gko::size_type i = 0; i < nn; ++i) xd->at(i, 0) = bd->at(i, 0) * (1.0 / 26.0);
+                    }
+                }
+                void apply_impl(const gko::LinOp*, const gko::LinOp* b, const gko::LinOp*,
+                                gko::LinOp* x) const override
+                {
+                    apply_impl(b, x);
+                }
+            };
+            auto run_user = [&](std::shared_ptr<const gko::Executor> e, std::shared_ptr<Csr> a, int mode,
+                                int& iters) {
+                gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, mode);
+                auto rhs = Dense::create(e, gko::dim<2>{n, 1});
+                rhs->fill(1.0);
+                auto x = Dense::create(e, gko::dim<2>{n, 1});
+                x->fill(0.0);
+                auto conv = gko::share(gko::log::Convergence<vt>::create());
+                auto solver =
+                    gko::solver::Cg<vt>::build()
+                        .with_criteria(gko::stop::Iteration::build().with_max_iters(500u),
+                                       gko::stop::ResidualNorm<vt>::build().with_reduction_factor(1e-10))
+                        .with_generated_preconditioner(gko::share(
+                            std::make_shared<UserScale>(e, gko::dim<2>{n, n})))
+                        .on(e)
+                        ->generate(a);
+                solver->add_logger(conv);
+                solver->apply(rhs, x);
+                iters = static_cast<int>(conv->get_num_iterations());
+                gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 0);
+                return gko::clone(ref, x);
+            };
+            int iu_ref = 0, iu_by = 0, iu_plain = 0;
+            int64_t n0 = 0, d0 = 0, n1 = 0, d1 = 0;
+            auto xu_ref = run_user(ref, a_ref, 0, iu_ref);
+            gko_cdna4_byproduct_hits(&n0, &d0);
+            auto xu_by = run_user(hip, a_hip, 0, iu_by);
+            gko_cdna4_byproduct_hits(&n1, &d1);
+            auto xu_plain = run_user(hip, a_hip, 2, iu_plain);
+            std::cout << "  user preconditioner: iterations reference " << iu_ref << ", hip (by-products) " << iu_by
+                      << ", hip (one kernel per call) " << iu_plain << "; norms answered by step_2: " << (n1 - n0)
+                      << ", dots: " << (d1 - d0) << std::endl;
+            CHECK(iu_by == iu_plain && std::abs(iu_by - iu_ref) <= 1,
+                  "CG + user LinOp preconditioner with its own launches: iteration counts agree");
+            CHECK(rel_err(xu_by.get(), xu_plain.get()) < 1e-12 && rel_err(xu_by.get(), xu_ref.get()) < 1e-8,
+                  "CG + user LinOp preconditioner: the reference's solution");
+            CHECK(n1 - n0 >= iu_by - 1 && d1 - d0 == 0,
+                  "CG + user LinOp preconditioner: ||r|| still comes with step_2, <r,z> is computed");
         }
         auto x_ref2 = solve(ref, a_ref, true, it_ref);
         auto x_hip2 = solve(hip, a_hip, true, it_hip);
