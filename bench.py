@@ -249,6 +249,207 @@ def self_launch(n):
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
+def matrix_bench(args):
+    """BASELINE configs[4] as a configuration: a MatrixMarket file (--matrix, e.g. SuiteSparse
+    Janna/Flan_1565) or, without one, the stand-in of that scale (ginkgo_amd/workloads.py); SpMV in
+    CSR and SELL-P (matrix::Sellp, slice size 64), CG + block-Jacobi(--block-size) on --format; at
+    N ranks the rows are split into contiguous ranges with equal shares of the ENTRIES
+    (Partition::build_from_contiguous), halo exchange + all-reduce as in the stencil run.
+    Reference: benchmark/utils/generator.hpp, core/base/mtx_io.cpp,
+    include/ginkgo/core/distributed/partition.hpp:262."""
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import ginkgo_amd as g
+    from ginkgo_amd import distributed as gd
+    from ginkgo_amd import workloads as wl
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    backend = os.environ.get("GKO_BENCH_BACKEND", "nccl")
+    dev_id = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_id)
+    ex = g.Cdna4Executor.create(dev_id)
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_id))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    bs = max(1, args.block_size)
+    t_load = time.perf_counter()
+    if args.matrix:
+        # every rank reads the file (a parallel file system serves N readers; the parse is the cost)
+        n, n_cols, r_, c_, v_ = wl.read_mtx(args.matrix)
+        if n != n_cols:
+            raise SystemExit("--matrix: the solver configurations need a square matrix")
+        rp, ci, vv = wl.csr_from_triplets(n, n, r_, c_, v_)
+        del r_, c_, v_
+        prefix = rp.astype(np.int64)
+        offsets = wl.partition_by_nnz(prefix, world, align=bs)
+        lo, hi = offsets[rank], offsets[rank + 1]
+        own = ((rp[lo:hi + 1] - rp[lo]).astype(np.int32), ci[rp[lo]:rp[hi]], vv[rp[lo]:rp[hi]])
+        nnz = int(rp[-1])
+        name = os.path.basename(args.matrix)
+        data = f"file {name}"
+        workload = f"{name}: n = {n}, nnz = {nnz}"
+        del rp, ci, vv
+    else:
+        grid = args.flan_grid
+        n, nnz = wl.flan_like_dims(grid)
+        prefix = wl.flan_like_row_prefix(grid)
+        offsets = wl.partition_by_nnz(prefix, world, align=bs if 3 % bs == 0 or bs % 3 == 0 else 3 * bs)
+        lo, hi = offsets[rank], offsets[rank + 1]
+        own = wl.flan_like_rows(grid, lo, hi)
+        data = "synthetic stand-in for Flan_1565"
+        workload = (f"stand-in for SuiteSparse Janna/Flan_1565 (file not available offline): "
+                    f"L27({grid}^3) (x) B3, n = {n}, nnz = {nnz}, up to 81 per row")
+    t_load = time.perf_counter() - t_load
+    n_local = hi - lo
+    owned = g.Csr.from_arrays(ex, (n_local, n), *own)
+    del own
+    rng = np.random.default_rng(42)
+    xg = rng.uniform(-1, 1, n)
+
+    def time_op(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        barrier()
+        wall = time.perf_counter() - t0
+        t = torch.tensor([wall], dtype=torch.float64, device=ex.device)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / steps, e0.elapsed_time(e1) / steps
+
+    formats, cg, comm_check = {}, {}, None
+    csr_bytes = spmv_algorithmic_bytes(n, n, nnz)
+    if not use_dist:
+        a = owned
+        x = g.Dense.from_numpy(ex, xg)
+        y = g.Dense.create(ex, (n, 1))
+        ops = {"csr": a, "sellp": a.convert_to_sellp()}
+        stored = {"csr": nnz, "sellp": int(ops["sellp"].values.numel())}
+        digest = {}
+        for name_, op in ops.items():
+            wall, kms = time_op(lambda: op.apply(x, y), args.steps, args.warmup)
+            nb = csr_bytes if name_ == "csr" else 12 * stored[name_] + 8 * (-(-n // 64) + 1) + 16 * n
+            formats[name_] = {"ms": round(kms, 5), "gbs_algorithmic_csr_bytes": round(csr_bytes / kms / 1e6, 1),
+                              "frac_of_own_bytes": round(nb / kms / 1e6 / HBM_PEAK_GBS, 4),
+                              "stored_over_nnz": round(stored[name_] / nnz, 4), "wall_ms": round(wall * 1e3, 5)}
+            digest[name_] = y.values.clone()
+        # the two formats add a row's entries in the same order: the same bits
+        formats["sellp"]["bit_identical_to_csr"] = bool(torch.equal(digest["csr"], digest["sellp"]))
+        if args.cg_iters > 0:
+            prec = g.Jacobi.build().with_max_block_size(bs).on(ex).generate(a) if bs > 1 else None
+            for name_, op in ops.items():
+                b = (g.Cg.build().with_criteria(g.stop.Iteration.build().with_max_iters(args.cg_iters),
+                                                g.stop.ResidualNorm.build().with_reduction_factor(1e-30)))
+                if prec is not None:
+                    b = b.with_generated_preconditioner(prec)
+                else:
+                    b = b.with_preconditioner(g.Jacobi.build().with_max_block_size(1))
+                s_ = b.on(ex).generate(op)
+                rhs, sol = g.Dense.from_numpy(ex, np.ones(n)), g.Dense.from_numpy(ex, np.zeros(n))
+                s_.apply(rhs, sol)
+                barrier()
+                sol.fill(0.0)
+                t0 = time.perf_counter()
+                s_.apply(rhs, sol)
+                barrier()
+                t_cg = time.perf_counter() - t0
+                cg[name_] = {"cg_iters_per_s": round(s_.num_iterations / t_cg, 2), "cg_iterations": s_.num_iterations}
+        kernel_ms = formats[args.format]["ms"]
+        wall_ms = formats[args.format]["wall_ms"]
+    else:
+        comm = gd.default_comm(ex)
+        be = gd.HipBackend(ex)
+        part = gd.Partition(offsets)
+        comm_check = gd.comm_self_check(ex, comm, n_elems=4096)
+        for name_ in ("csr", "sellp"):
+            dm = gd.DistributedMatrix(be, comm, part, owned, local_format=name_)
+            x = be.vector_from(xg[lo:hi])
+            y = be.vector(n_local)
+            wall, kms = time_op(lambda: dm.apply(x, y), args.steps, args.warmup)
+            formats[name_] = {"ms": round(kms, 5), "wall_ms": round(wall * 1e3, 5),
+                              "gbs_algorithmic_csr_bytes": round(csr_bytes / wall / 1e9, 1),
+                              "halo_values_in": dm.n_halo, "peers": sum(1 for c in dm.recv_counts if c > 0),
+                              "one_kernel_product": dm._gate is not None}
+            if args.cg_iters > 0:
+                s_ = gd.DistributedCg(be, comm, dm, args.cg_iters, 1e-300, bs if bs > 1 else 1)
+                rhs, sol = be.vector_from(np.ones(n_local)), be.vector(n_local)
+                s_.apply(rhs, sol)
+                barrier()
+                sol.fill(0.0)
+                t0 = time.perf_counter()
+                s_.apply(rhs, sol)
+                barrier()
+                tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=ex.device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                cg[name_] = {"cg_iters_per_s": round(s_.num_iterations / float(tt.item()), 2),
+                             "cg_iterations": s_.num_iterations}
+        kernel_ms = formats[args.format]["ms"]
+        wall_ms = formats[args.format]["wall_ms"]
+    # every rank's share (a slow rank explains itself)
+    per_rank = None
+    if use_dist:
+        mine = torch.tensor([kernel_ms, float(n_local), float(prefix[hi] - prefix[lo])], dtype=torch.float64,
+                            device=ex.device)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [{"rank": r, "kernel_ms": round(float(t[0]), 5), "rows": int(t[1]), "nnz": int(t[2])}
+                    for r, t in enumerate(gathered)]
+    if rank == 0:
+        achieved = csr_bytes / world / (kernel_ms * 1e-3) / 1e9
+        info = ex.arena_info()
+        out = {"metric": "spmv_effective_bandwidth", "value": round(csr_bytes / (wall_ms * 1e-3) / 1e9, 1),
+               "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(wall_ms, 5), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "f64", "data": data,
+               "config": {"workload": workload, "format": args.format, "value_type": "f64", "index_type": "int32",
+                          "partition": "contiguous rows, equal shares of the stored entries" if use_dist else "one domain",
+                          "preconditioner": f"block-Jacobi({bs})", "load_s": round(t_load, 2),
+                          "memory_classes_found": info["num_classes"],
+                          "bytes": "CSR model of SURVEY 8(d): 12 nnz + 4 (n + 1) + 16 n, for every format"},
+               "formats": formats, "cg": cg,
+               "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "kernel_ms": round(kernel_ms, 5),
+                            "traffic_note": "counters are collected for the 256^3 headline only"},
+               "cpu_baseline": {"value": None, "unit": "GB/s", "cores": None, "kind": None, "sample": None,
+                                "note": "the CPU twin of this workload is tools/flan_bench.py's scipy product; "
+                                        "the bounded OmpExecutor baseline belongs to the headline line"}}
+        if per_rank:
+            out["roofline"]["per_rank"] = per_rank
+            out["comm_check"] = comm_check
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +473,14 @@ def main():
                     help="distributed runs: do NOT time PipeCg + block-Jacobi(8) (one all-reduce per "
                          "iteration, overlapped) next to Cg; by default pipe_cg_iters_per_s is reported "
                          "beside cg_iters_per_s")
+    ap.add_argument("--matrix", default=None,
+                    help="a MatrixMarket file: run configs[4] (SELL-P vs CSR, CG + block-Jacobi) on it")
+    ap.add_argument("--workload", default=None, choices=[None, "flan"],
+                    help="flan: configs[4] on the stand-in for Flan_1565 (no file at hand)")
+    ap.add_argument("--format", default="csr", choices=["csr", "sellp"],
+                    help="--matrix / --workload flan: the format `value` is quoted on")
+    ap.add_argument("--flan-grid", type=int, default=80, help="stand-in size: L27(g^3) (x) B3")
+    ap.add_argument("--block-size", type=int, default=3, help="--matrix / flan: block-Jacobi block size")
     ap.add_argument("--arena", type=int, default=None,
                     help="GKOC_ARENA mode of the library's allocator: 2 = memory-class regions "
                          "(default), 1 = plain chunks, 0 = one hipMalloc per array (DESIGN.md 3.2)")
@@ -284,6 +493,8 @@ def main():
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, the way the
         # driver does (one process per GPU, rendezvous on 127.0.0.1); rank 0 prints the line
         return self_launch(args.gpus)
+    if args.matrix or args.workload == "flan":
+        return matrix_bench(args)
 
     # stdout carries exactly one line, the JSON result: everything else written to
     # file descriptor 1 by this process (RCCL prints a version banner there from C

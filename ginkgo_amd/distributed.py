@@ -878,7 +878,10 @@ class DistributedMatrix:
     `owned` holds this rank's rows (CSR, GLOBAL column indices).  Set-up follows
     read_distributed (matrix.cpp:300-381); apply follows apply_impl (:450-509)."""
 
-    def __init__(self, backend, comm, partition, owned):
+    def __init__(self, backend, comm, partition, owned, local_format="csr"):
+        """local_format: "csr", or "sellp" - the local block is converted to matrix::Sellp
+        (slice size 64) and multiplied in that format (BASELINE configs[4]: SELL-P vs CSR); the
+        non-local block stays a row list"""
         self.backend, self.comm, self.partition = backend, comm, partition
         self.rank = comm.rank
         lo, hi = partition.range_of(self.rank)
@@ -919,6 +922,13 @@ class DistributedMatrix:
         # local SpMV) or, GKO_FULL_BOUNDARY=0, the round-2 form: whole local block, then
         # boundary rows += halo part
         self.use_full_boundary = os.environ.get("GKO_FULL_BOUNDARY", "1") != "0"
+        self.local_format = local_format
+        self.local_op = self.local
+        if local_format == "sellp":
+            self.local_op = self.local.convert_to_sellp()
+            self.use_full_boundary = False       # (the row-range products are CSR kernels)
+        elif local_format != "csr":
+            raise GkoError(f"DistributedMatrix: unknown local format {local_format}")
         # <p, q> from the product's waves (gkoc_x_csr_spmv_gated_dot_*): measured per rank of 8 on
         # 256^3, it costs the product 8 us and its fold 4 - the separate dot + fold cost 9.  Off.
         self.gated_dot = os.environ.get("GKO_GATED_DOT", "0") != "0"
@@ -981,7 +991,7 @@ class DistributedMatrix:
         # an 8-rank 256^3 run: 239 against 251 us per CG iteration; the fused kernel's partial
         # sums need two fold launches and its boundary-row share two more)
         if not (hasattr(be, "spmv_dot") and x.ld == 1 and y.ld == 1 and x.size[1] == 1 and
-                isinstance(self.local, Csr) and self.local.size[0] == self.local.size[1] and
+                self.local_format == "csr" and isinstance(self.local, Csr) and self.local.size[0] == self.local.size[1] and
                 self.n_local >= self.fused_dot_min_rows):
             return False
         self.apply(x, y, dot_out=out)
@@ -1030,7 +1040,7 @@ class DistributedMatrix:
                 be.rowlist_full(self.nl, x, self.recv_buf, y, self._side)
                 comm.exchange_join()
             else:
-                be.spmv(self.local, x, y)
+                be.spmv(self.local_op, x, y)
                 comm.exchange_join()
                 be.rowlist_add(self.nl, self.recv_buf, y)
             return y
@@ -1045,7 +1055,7 @@ class DistributedMatrix:
         if dot_out is not None:
             local_spmv = lambda: be.spmv_dot(self.local, x, y, dot_out)
         else:
-            local_spmv = lambda: be.spmv(self.local, x, y)
+            local_spmv = lambda: be.spmv(self.local_op, x, y)
         direct = comm.size > 1 and self._side is not None and getattr(comm, "direct", False)
         zero_copy = direct and self.send_displs is not None and x.ld == 1 and x.size[1] == 1
         # 1. pack the rows the neighbours need (RowGatherer::apply_prepare)

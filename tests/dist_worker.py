@@ -162,6 +162,7 @@ def main():
     #     rows reach into EVERY other rank (halo from several peers, scattered
     #     indices, uneven part sizes) - nothing slab-specific may be assumed
     irregular_case(mode, o, gd, be, comm, rank, world)
+    flan_case(mode, o, gd, be, comm, rank, world)
     dist.barrier()
     if rank == 0:
         print(f"dist_worker OK mode={mode} world={world} grid={grid} iters={solver.num_iterations}")
@@ -205,6 +206,46 @@ def irregular_case(mode, o, gd, be, comm, rank, world):
     assert abs(solver.num_iterations - iters) <= 1, (solver.num_iterations, iters)
     e = np.linalg.norm(xs.to_numpy()[:, 0] - xo[lo:hi]) / np.linalg.norm(xo[lo:hi])
     assert e < 1e-8, f"rank {rank}: irregular cg err {e}"
+
+
+def flan_case(mode, o, gd, be, comm, rank, world):
+    """configs[4]'s stand-in (ginkgo_amd/workloads.py: L27(g) (x) B3, 3 unknowns per node, up to 81
+    entries per row) on an ENTRY-balanced contiguous partition: the product in CSR and - on the GPU -
+    with the local block in SELL-P, CG + block-Jacobi(3), against the single-domain oracle"""
+    from ginkgo_amd import workloads as wl
+    grid = 7
+    n, nnz = wl.flan_like_dims(grid)
+    rp, ci, v = wl.flan_like_rows(grid)
+    assert rp[-1] == nnz
+    offsets = wl.partition_by_nnz(wl.flan_like_row_prefix(grid), world, align=3)
+    part = gd.Partition(offsets)
+    lo, hi = part.range_of(rank)
+    lrp, lci, lv = wl.flan_like_rows(grid, lo, hi)
+    xg = np.random.default_rng(11).uniform(-1, 1, n)
+    ref = o.csr_spmv(rp, ci, v, xg)[lo:hi]
+    formats = ("csr",) if mode == "cpu" else ("csr", "sellp")
+    for fmt in formats:
+        if mode == "cpu":
+            from cpu_backend import CpuCsr
+            owned = CpuCsr(hi - lo, n, lrp, lci, lv)
+            a = gd.DistributedMatrix(be, comm, part, owned)
+        else:
+            import ginkgo_amd as g
+            owned = g.Csr.from_arrays(be.exec, (hi - lo, n), lrp, lci, lv)
+            a = gd.DistributedMatrix(be, comm, part, owned, local_format=fmt)
+        x, y = be.vector_from(xg[lo:hi]), be.vector(hi - lo)
+        a.apply(x, y)
+        err = np.max(np.abs(y.to_numpy()[:, 0] - ref)) / np.max(np.abs(ref)) if hi > lo else 0.0
+        assert err < 1e-14, f"rank {rank}: flan-like spmv ({fmt}) err {err}"
+        solver = gd.DistributedCg(be, comm, a, 400, 1e-10, 3)
+        xs = be.vector(hi - lo)
+        solver.apply(be.vector_from(np.ones(hi - lo)), xs)
+        xo, iters, _ = o.cg_solve(rp, ci, v, np.ones(n), max_iters=400, reduction=1e-10, precond="block",
+                                  max_block_size=3)
+        assert abs(solver.num_iterations - iters) <= 1, (fmt, solver.num_iterations, iters)
+        if hi > lo:
+            e = np.linalg.norm(xs.to_numpy()[:, 0] - xo[lo:hi]) / np.linalg.norm(xo[lo:hi])
+            assert e < 1e-8, f"rank {rank}: flan-like cg ({fmt}) err {e}"
 
 
 if __name__ == "__main__":

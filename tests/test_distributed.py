@@ -145,6 +145,53 @@ def test_bench_starts_its_own_ranks_and_the_line_has_every_key():
     assert d["cg_iterations"] == 10 and d["pipe_cg_iterations"] == 10
 
 
+def _bench_plain(args, env_extra=None):
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n--- stderr ---\n" + p.stderr[-12000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_configs4_stand_in_one_and_eight_ranks(tmp_path):
+    """BASELINE configs[4] as a configuration of bench.py: the Flan_1565
+    stand-in and a MatrixMarket file, SELL-P vs CSR, CG + block-Jacobi(3), on one rank and on eight
+    (gloo, sharing the GPU); the eight-rank numerics against the oracle are tests/dist_worker.py's
+    flan_case (test_distributed_gpu_eight_ranks_one_device)."""
+    common = ["--steps", "3", "--warmup", "1", "--cg-iters", "10", "--flan-grid", "12"]
+    d1 = _bench_plain(["--workload", "flan", "--format", "sellp", *common])
+    n, nnz = 3 * 12 ** 3, 9 * 34 ** 3
+    assert d1["data"] == "synthetic stand-in for Flan_1565" and f"n = {n}, nnz = {nnz}" in d1["config"]["workload"]
+    assert d1["config"]["format"] == "sellp" and d1["n_gpus"] == 1
+    assert d1["formats"]["sellp"]["bit_identical_to_csr"] and d1["formats"]["sellp"]["stored_over_nnz"] >= 1.0
+    assert d1["cg"]["csr"]["cg_iterations"] == 10 and d1["cg"]["sellp"]["cg_iterations"] == 10
+    assert d1["roofline"]["frac"] > 0 and d1["cpu_baseline"]["note"]
+    d8 = _bench_plain(["--gpus", "8", "--workload", "flan", "--format", "csr", *common],
+                      {"GKO_BENCH_BACKEND": "gloo"})
+    assert d8["n_gpus"] == 8 and d8["config"]["partition"].startswith("contiguous rows")
+    pr = d8["roofline"]["per_rank"]
+    assert len(pr) == 8 and sum(r["rows"] for r in pr) == n and sum(r["nnz"] for r in pr) == nnz
+    assert max(r["nnz"] for r in pr) <= 1.15 * nnz / 8 and all(r["rows"] % 3 == 0 for r in pr)
+    assert d8["cg"]["csr"]["cg_iterations"] == 10 and d8["cg"]["sellp"]["cg_iterations"] == 10
+    assert d8["formats"]["csr"]["peers"] >= 1 and d8["comm_check"]["ranks"] == 8
+    # ... and from a file: a symmetric MatrixMarket file of the same matrix at a smaller size
+    import scipy.sparse as sp
+    from ginkgo_amd import workloads as wl
+    rp, ci, v = wl.flan_like_rows(6)
+    a = sp.csr_matrix((v, ci, rp), shape=(3 * 216, 3 * 216))
+    path = str(tmp_path / "flan6.mtx")
+    wl.write_mtx(path, a, symmetric=True)
+    df = _bench_plain(["--matrix", path, "--format", "csr", "--steps", "3", "--warmup", "1", "--cg-iters", "5"])
+    assert df["data"] == "file flan6.mtx" and f"n = {3 * 216}, nnz = {a.nnz}" in df["config"]["workload"]
+    assert df["formats"]["sellp"]["bit_identical_to_csr"] and df["cg"]["csr"]["cg_iterations"] == 5
+
+
 @pytest.mark.gpu
 def test_distributed_single_rank_matches_plain(gexec, oracle):
     """world = 1: the distributed wrapper degenerates to the plain SpMV / CG"""
