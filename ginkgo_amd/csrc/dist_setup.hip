@@ -1067,3 +1067,23 @@ extern "C" int gkoc_partition_has_ordered_parts(gkoc_stream_t s, int64_t num_ran
     *result = h ? 0 : 1;
     return rc;
 }
+
+// A count / fill pair that is abandoned between the two calls (the caller's resize threw): what the
+// count call handed out as `state` goes back.  NULL is fine.
+extern "C" int gkoc_dist_separate_state_free(gkoc_stream_t s, void* state)
+{
+    if (!state) return GKOC_OK;
+    return gkoc::scratch_free(gkoc::as_stream(s), state);
+}
+
+extern "C" int gkoc_index_map_mapping_state_free(gkoc_stream_t s, void* state)
+{
+    if (!state) return GKOC_OK;
+    auto* ms = static_cast<gkoc::mapping_state*>(state);
+    hipStream_t st = gkoc::as_stream(s);
+    (void)gkoc::scratch_free(st, ms->parts);
+    (void)gkoc::scratch_free(st, ms->gids);
+    (void)gkoc::scratch_free(st, ms->pos_u);
+    delete ms;
+    return GKOC_OK;
+}

@@ -789,22 +789,28 @@ namespace csr {
 FOR_VT_IT(DEF)
 #undef DEF
 
-// Ginkgo's per-row lookup structures are read by device kernels only; this backend finds positions
-// by bisection (csrc/misc.hip) and writes empty ones: no storage, "full" descriptors never read
+// Ginkgo's per-row lookup structures (core/matrix/csr_lookup.hpp), built on the device with the
+// reference's bits (csrc/csr_lookup.hip).  This backend's own spgemm_reuse / spgeam kernels find
+// positions by bisection and do not read them; Ginkgo's factorisations would (out of scope, stubs).
 #define DEF(I, IN)                                                                                  \
     template <>                                                                                     \
-    void build_lookup_offsets<I>(exec_t exec, const I*, const I*, size_type num_rows,               \
-                                 matrix::csr::sparsity_type, I* storage_offsets)                    \
+    void build_lookup_offsets<I>(exec_t exec, const I* row_ptrs, const I* col_idxs,                 \
+                                 size_type num_rows, matrix::csr::sparsity_type allowed,            \
+                                 I* storage_offsets)                                                \
     {                                                                                               \
-        GKOC_CALL(gkoc_fill_array_##IN(stream_of(exec), storage_offsets,                            \
-                                       static_cast<int64_t>(num_rows) + 1, I(0)));                  \
+        GKOC_CALL(gkoc_csr_build_lookup_offsets_##IN(stream_of(exec), static_cast<int64_t>(num_rows), \
+                                                     row_ptrs, col_idxs, static_cast<int>(allowed), \
+                                                     storage_offsets));                             \
     }                                                                                               \
     template <>                                                                                     \
-    void build_lookup<I>(exec_t exec, const I*, const I*, size_type num_rows,                       \
-                         matrix::csr::sparsity_type, const I*, int64* row_desc, int32*)             \
+    void build_lookup<I>(exec_t exec, const I* row_ptrs, const I* col_idxs, size_type num_rows,     \
+                         matrix::csr::sparsity_type allowed, const I* storage_offsets,              \
+                         int64* row_desc, int32* storage)                                           \
     {                                                                                               \
-        GKOC_CALL(gkoc_fill_array_i64(stream_of(exec), row_desc, static_cast<int64_t>(num_rows),    \
-                                      int64_t(0)));                                                 \
+        GKOC_CALL(gkoc_csr_build_lookup_##IN(stream_of(exec), static_cast<int64_t>(num_rows),       \
+                                             row_ptrs, col_idxs, static_cast<int>(allowed),         \
+                                             storage_offsets, reinterpret_cast<int64_t*>(row_desc), \
+                                             reinterpret_cast<int32_t*>(storage)));                 \
     }
 DEF(int32, i32)
 DEF(int64, i64)

@@ -61,6 +61,17 @@ int index_space_id(experimental::distributed::index_space is)
         M(std::complex<double>, L, LN, G, GN)
 
 
+// the scratch state of a count / fill pair goes back if the resizes between them throw
+struct state_guard {
+    gkoc_stream_t s;
+    void* state;
+    int (*give_back)(gkoc_stream_t, void*);
+    ~state_guard()
+    {
+        if (state) give_back(s, state);
+    }
+};
+
 // ====================================================================== distributed_matrix
 namespace distributed_matrix {
 
@@ -80,12 +91,14 @@ namespace distributed_matrix {
         GKOC_CALL(gkoc_dist_separate_local_nonlocal_count_##LN##_##GN(                              \
             stream_of(exec), nnz, input.get_const_row_idxs(), input.get_const_col_idxs(), &rp, &cp, \
             local_part, &state, &nl, &nn));                                                         \
+        state_guard guard{stream_of(exec), state, gkoc_dist_separate_state_free};                   \
         local_row_idxs.resize_and_reset(nl);                                                        \
         local_col_idxs.resize_and_reset(nl);                                                        \
         local_values.resize_and_reset(nl);                                                          \
         non_local_row_idxs.resize_and_reset(nn);                                                    \
         non_local_col_idxs.resize_and_reset(nn);                                                    \
         non_local_values.resize_and_reset(nn);                                                      \
+        guard.state = nullptr; /* the fill call frees it, also when it fails */                     \
         GKOC_CALL(gkoc_dist_separate_local_nonlocal_fill_##LN##_##GN(                               \
             stream_of(exec), nnz, input.get_const_row_idxs(), input.get_const_col_idxs(),           \
             input.get_const_values(), sizeof(V), &rp, &cp, state, local_row_idxs.get_data(),        \
@@ -140,10 +153,12 @@ namespace index_map {
         GKOC_CALL(gkoc_index_map_build_mapping_count_##LN##_##GN(                                   \
             stream_of(exec), static_cast<int64_t>(recv_connections.get_size()),                     \
             recv_connections.get_const_data(), &p, &state, &nu, &np));                              \
+        state_guard guard{stream_of(exec), state, gkoc_index_map_mapping_state_free};               \
         remote_global_idxs.resize_and_reset(nu);                                                    \
         remote_local_idxs.resize_and_reset(nu);                                                     \
         part_ids.resize_and_reset(np);                                                              \
         remote_sizes.resize_and_reset(np);                                                          \
+        guard.state = nullptr; /* the fill call frees it, also when it fails */                     \
         GKOC_CALL(gkoc_index_map_build_mapping_fill_##LN##_##GN(                                    \
             stream_of(exec), &p, state, part_ids.get_data(), remote_local_idxs.get_data(),          \
             remote_global_idxs.get_data(), remote_sizes.get_data()));                               \

@@ -401,6 +401,23 @@ GKOC_DECL_ASSEMBLY(float, f32, int64_t, i64)
                                                  int64_t n);                   \
     int gkoc_fill_array_##IN(gkoc_stream_t s, I* data, int64_t n, I value);    \
     int gkoc_fill_seq_array_##IN(gkoc_stream_t s, I* data, int64_t n);
+/* csr::build_lookup_offsets / csr::build_lookup (core/matrix/csr_kernels.hpp, format
+ * core/matrix/csr_lookup.hpp:26-85, reference/matrix/csr_kernels.cpp:1425-1573): per row a 64-bit
+ * descriptor and int32 storage (full / bitmap / hash, `allowed` = bit set 1 | 2 | 4 of the kinds the
+ * caller accepts) that locate an entry without a search; sorted columns.  storage_offsets: n_rows + 1
+ * entries (exclusive sums of the storage per row).  Tables bit-identical to the reference's. */
+#define GKOC_DECL_LOOKUP(I, IN)                                                                        \
+    int gkoc_csr_build_lookup_offsets_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,         \
+                                           const I* col_idxs, int allowed, I* storage_offsets);        \
+    int gkoc_csr_build_lookup_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,                 \
+                                   const I* col_idxs, int allowed, const I* storage_offsets,           \
+                                   int64_t* row_desc, int32_t* storage);
+/* what a *_count call of the distributed set-up handed out as `state`, when the matching *_fill
+ * call is not going to happen (the fill frees it otherwise) */
+int gkoc_dist_separate_state_free(gkoc_stream_t s, void* state);
+int gkoc_index_map_mapping_state_free(gkoc_stream_t s, void* state);
+GKOC_DECL_LOOKUP(int32_t, i32)
+GKOC_DECL_LOOKUP(int64_t, i64)
 GKOC_DECL_IDX(int32_t, i32)
 GKOC_DECL_IDX(int64_t, i64)
 /* components::fill_array for value types (core/components/fill_array_kernels.hpp) */

@@ -49,6 +49,8 @@ using it = gko::int32;
 using Csr = gko::matrix::Csr<vt, it>;
 using Dense = gko::matrix::Dense<vt>;
 
+#include "core/matrix/csr_kernels.hpp"
+#include "core/matrix/csr_lookup.hpp"
 extern "C" void gko_cdna4_byproduct_hits(int64_t* norms, int64_t* dots);
 static int failures = 0;
 template <typename T>
@@ -454,6 +456,65 @@ int main(int argc, char** argv)
                   "CG + user LinOp preconditioner: the reference's solution");
             CHECK(n1 - n0 >= iu_by - 1 && d1 - d0 == 0,
                   "CG + user LinOp preconditioner: ||r|| still comes with step_2, <r,z> is computed");
+        }
+        {
+            // csr::build_lookup_offsets / build_lookup: descriptors and storage bit-identical to the
+            // reference's for every combination of allowed kinds - on the 27-pt matrix (bitmap rows)
+            // and on a matrix with full rows, an empty row, a long scattered row (hash)
+            using gko::matrix::csr::sparsity_type;
+            gko::matrix_data<vt, it> md(gko::dim<2>{40, 3000});
+            for (it c = 5; c < 17; ++c) md.nonzeros.emplace_back(0, c, 1.0);            // full
+            for (it c = 0; c < 30; ++c) md.nonzeros.emplace_back(2, 97 * c + 3, 1.0);   // hash
+            for (it c = 0; c < 64; c += 3) md.nonzeros.emplace_back(3, 1000 + c, 1.0);  // bitmap
+            md.nonzeros.emplace_back(7, 2999, 1.0);                                     // single entry
+            for (it r = 10; r < 40; ++r) {
+                for (it c = 0; c < r; ++c) md.nonzeros.emplace_back(r, (c * c + r) % 3000, 1.0);
+            }
+            md.sum_duplicates();
+            auto odd_ref = gko::share(Csr::create(ref));
+            odd_ref->read(md);
+            auto odd_hip = gko::share(gko::clone(hip, odd_ref));
+            bool all_same = true;
+            for (auto pair : {std::make_pair(a_ref, a_hip), std::make_pair(odd_ref, odd_hip)}) {
+                const auto nr = pair.first->get_size()[0];
+                for (int allowed = 0; allowed < 8; ++allowed) {
+                    const auto al = static_cast<sparsity_type>(allowed);
+                    gko::array<it> off_r(ref, nr + 1), off_h(hip, nr + 1);
+                    gko::kernels::reference::csr::build_lookup_offsets(
+                        ref, pair.first->get_const_row_ptrs(), pair.first->get_const_col_idxs(), nr, al,
+                        off_r.get_data());
+                    gko::kernels::hip::csr::build_lookup_offsets(
+                        hip, pair.second->get_const_row_ptrs(), pair.second->get_const_col_idxs(), nr, al,
+                        off_h.get_data());
+                    gko::array<it> off_hh(ref, off_h);
+                    bool same = true;
+                    for (gko::size_type i = 0; i <= nr; ++i) {
+                        same = same && off_r.get_const_data()[i] == off_hh.get_const_data()[i];
+                    }
+                    const auto total = static_cast<gko::size_type>(off_r.get_const_data()[nr]);
+                    gko::array<gko::int64> d_r(ref, nr), d_h(hip, nr);
+                    gko::array<gko::int32> s_r(ref, total), s_h(hip, total);
+                    s_r.fill(-7);
+                    s_h.fill(-7);
+                    gko::kernels::reference::csr::build_lookup(
+                        ref, pair.first->get_const_row_ptrs(), pair.first->get_const_col_idxs(), nr, al,
+                        off_r.get_const_data(), d_r.get_data(), s_r.get_data());
+                    gko::kernels::hip::csr::build_lookup(
+                        hip, pair.second->get_const_row_ptrs(), pair.second->get_const_col_idxs(), nr, al,
+                        off_h.get_const_data(), d_h.get_data(), s_h.get_data());
+                    gko::array<gko::int64> d_hh(ref, d_h);
+                    gko::array<gko::int32> s_hh(ref, s_h);
+                    for (gko::size_type i = 0; same && i < nr; ++i) {
+                        same = d_r.get_const_data()[i] == d_hh.get_const_data()[i];
+                    }
+                    for (gko::size_type i = 0; same && i < total; ++i) {
+                        same = s_r.get_const_data()[i] == s_hh.get_const_data()[i];
+                    }
+                    all_same = all_same && same;
+                }
+            }
+            CHECK(all_same, "csr::build_lookup_offsets / build_lookup: offsets, descriptors and storage "
+                            "identical to the reference for all eight sets of allowed kinds");
         }
         auto x_ref2 = solve(ref, a_ref, true, it_ref);
         auto x_hip2 = solve(hip, a_hip, true, it_hip);
