@@ -397,7 +397,9 @@ __global__ __launch_bounds__(256) void scalar_jacobi_kernel(
 
 using namespace gkoc;
 
-#define GKOC_DEF_CG(T, TN)                                                     \
+// cg::{initialize, step_1, step_2} for all four value types (the complex instantiations run the same
+// templates on gkoc_cplx, complex_type.hpp)
+#define GKOC_DEF_CG_STEPS(T, TN)                                                     \
     extern "C" int gkoc_cg_initialize_##TN(                                    \
         gkoc_stream_t s, int64_t rows, int64_t cols, const T* b, int64_t ldb,  \
         T* r, int64_t ldr, T* z, int64_t ldz, T* p, int64_t ldp, T* q,         \
@@ -439,6 +441,33 @@ using namespace gkoc;
             s, rows, cols, a, op_cg_step1<T>{rho, prev_rho, stop_status},      \
             false);                                                            \
     }                                                                          \
+    extern "C" int gkoc_cg_step_2_##TN(                                        \
+        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* r,  \
+        int64_t ldr, const T* p, int64_t ldp, const T* q, int64_t ldq,         \
+        const T* beta, const T* rho, const uint8_t* stop_status)               \
+    {                                                                          \
+        ew_operands<T, 4, 2> a{};                                              \
+        a.in[0] = x;                                                           \
+        a.ld_in[0] = ldx;                                                      \
+        a.in[1] = r;                                                           \
+        a.ld_in[1] = ldr;                                                      \
+        a.in[2] = p;                                                           \
+        a.ld_in[2] = ldp;                                                      \
+        a.in[3] = q;                                                           \
+        a.ld_in[3] = ldq;                                                      \
+        a.out[0] = x;                                                          \
+        a.ld_out[0] = ldx;                                                     \
+        a.out[1] = r;                                                          \
+        a.ld_out[1] = ldr;                                                     \
+        return launch_elementwise<T, op_cg_step2<T>, 4, 2>(                    \
+            s, rows, cols, a, op_cg_step2<T>{beta, rho, stop_status}, false);  \
+    }
+GKOC_DEF_CG_STEPS(double, f64)
+GKOC_DEF_CG_STEPS(float, f32)
+GKOC_DEF_CG_STEPS(gkoc_c128, c128)
+GKOC_DEF_CG_STEPS(gkoc_c64, c64)
+
+#define GKOC_DEF_CG(T, TN)                                                     \
     extern "C" int gkoc_x_cg_step_1_check_##TN(                                \
         gkoc_stream_t s, int64_t rows, T* p, const T* z, const T* rho,         \
         const T* prev_rho, const T* tau, const T* orig_tau, T goal,            \
@@ -480,27 +509,6 @@ using namespace gkoc;
                                         id, set_finalized != 0, stop_status,   \
                                         flags},                                \
             false);                                                            \
-    }                                                                          \
-    extern "C" int gkoc_cg_step_2_##TN(                                        \
-        gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* r,  \
-        int64_t ldr, const T* p, int64_t ldp, const T* q, int64_t ldq,         \
-        const T* beta, const T* rho, const uint8_t* stop_status)               \
-    {                                                                          \
-        ew_operands<T, 4, 2> a{};                                              \
-        a.in[0] = x;                                                           \
-        a.ld_in[0] = ldx;                                                      \
-        a.in[1] = r;                                                           \
-        a.ld_in[1] = ldr;                                                      \
-        a.in[2] = p;                                                           \
-        a.ld_in[2] = ldp;                                                      \
-        a.in[3] = q;                                                           \
-        a.ld_in[3] = ldq;                                                      \
-        a.out[0] = x;                                                          \
-        a.ld_out[0] = ldx;                                                     \
-        a.out[1] = r;                                                          \
-        a.ld_out[1] = ldr;                                                     \
-        return launch_elementwise<T, op_cg_step2<T>, 4, 2>(                    \
-            s, rows, cols, a, op_cg_step2<T>{beta, rho, stop_status}, false);  \
     }                                                                          \
     extern "C" int gkoc_x_cg_step_2_norm_##TN(                                 \
         gkoc_stream_t s, int64_t rows, T* x, T* r, const T* p, const T* q,     \

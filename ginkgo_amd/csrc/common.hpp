@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 
+#include "complex_type.hpp"
 #include "gko_cdna4.h"
 
 namespace gkoc {
@@ -90,26 +91,7 @@ __host__ __device__ __forceinline__ gkoc_c64 zero_of<gkoc_c64>()
 {
     return gkoc_c64{0.0f, 0.0f};
 }
-__host__ __device__ __forceinline__ bool operator!=(const gkoc_c128& a, const gkoc_c128& b)
-{
-    return a.re != b.re || a.im != b.im;
-}
-__host__ __device__ __forceinline__ bool operator!=(const gkoc_c64& a, const gkoc_c64& b)
-{
-    return a.re != b.re || a.im != b.im;
-}
-__host__ __device__ __forceinline__ gkoc_c128& operator+=(gkoc_c128& a, const gkoc_c128& b)
-{
-    a.re += b.re;
-    a.im += b.im;
-    return a;
-}
-__host__ __device__ __forceinline__ gkoc_c64& operator+=(gkoc_c64& a, const gkoc_c64& b)
-{
-    a.re += b.re;
-    a.im += b.im;
-    return a;
-}
+// (==, !=, +=, ... of the two complex types: complex_type.hpp)
 
 // ---- wave / block reductions (64-lane) ---------------------------------
 template <typename T>

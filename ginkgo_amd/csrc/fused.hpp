@@ -20,7 +20,11 @@ __global__ __launch_bounds__(fold_block) void fold_partials_kernel(
     T acc = T(0);
     for (int64_t i = threadIdx.x; i < count; i += fold_block) acc += partial[i];
     const T r = block_sum<fold_block>(acc, lds);
-    if (threadIdx.x == 0) result[0] = SQRT ? sqrt(r) : r;
+    if constexpr (SQRT) {
+        if (threadIdx.x == 0) result[0] = sqrt(r);
+    } else {
+        if (threadIdx.x == 0) result[0] = r;
+    }
 }
 
 // One launch for tens of thousands of partial sums (a rank's share of a strong-scaling run: one per

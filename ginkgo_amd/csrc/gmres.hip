@@ -31,7 +31,7 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void gmres_restart_kernel(
     int64_t rows, int64_t cols, const T* __restrict__ residual, int64_t ldr,
-    const T* __restrict__ residual_norm, T* __restrict__ rnc,
+    const real_t<T>* __restrict__ residual_norm, T* __restrict__ rnc,
     T* __restrict__ krylov, int64_t ldk, uint64_t* __restrict__ final_iter_nums)
 {
     const int64_t total = rows * cols;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void gmres_restart_kernel(
     }
     const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (t < cols) {
-        rnc[t] = residual_norm[t];  // row 0 of residual_norm_collection
+        rnc[t] = T(residual_norm[t]);  // row 0 of residual_norm_collection
         final_iter_nums[t] = 0;
     }
 }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void gmres_mgs_step_kernel(
                 reinterpret_cast<V*>(w)[i] = wv;
             }
 #pragma unroll
-            for (int e = 0; e < W; ++e) acc += nv.v[e] * wv.v[e];
+            for (int e = 0; e < W; ++e) acc += conj_v(nv.v[e]) * wv.v[e];
         }
         done = n_vec * W;
     }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void gmres_mgs_step_kernel(
             wv = wv - t;
             w[i] = wv;
         }
-        acc += v_next[i] * wv;
+        acc += conj_v(v_next[i]) * wv;
     }
     const T r = block_sum<256>(acc, lds);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void gmres_multi_dot_stage1(
         for (int u = 0; u < md_items; ++u) {
             const int64_t r = base + u * 256 + threadIdx.x;
             const T kv = r < rows ? krylov[(int64_t(d) * rows + r) * ldk + col] : T(0);
-            acc += kv * nv[u];
+            acc += conj_v(kv) * nv[u];       // conj(krylov) * next (gmres_kernels.cpp multi_dot)
         }
         const T s = block_sum<256>(acc, lds);
         if (threadIdx.x == 0) {
@@ -259,32 +259,26 @@ __global__ __launch_bounds__(256) void gmres_multi_dot_stage2(
 }
 
 template <typename T>
-__device__ __forceinline__ T dabs(T v)
-{
-    return v < T(0) ? -v : v;
-}
-
-// reference common_gmres_kernels.cpp:28-117 + hessenberg_qr :146-165
-template <typename T>
 __global__ __launch_bounds__(256) void gmres_hessenberg_qr_kernel(
     int64_t cols, T* __restrict__ gsin, int64_t lds_, T* __restrict__ gcos,
-    int64_t ldc, T* __restrict__ residual_norm, T* __restrict__ rnc,
+    int64_t ldc, real_t<T>* __restrict__ residual_norm, T* __restrict__ rnc,
     int64_t ldr, T* __restrict__ h, int64_t ldh, int64_t iter,
     uint64_t* __restrict__ final_iter_nums, const uint8_t* __restrict__ stop)
 {
+    using R = real_t<T>;
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (i >= cols) return;
     if (stop[i] & 0x3f) return;
     final_iter_nums[i]++;
-    // givens_rotation
+    // givens_rotation (common_gmres_kernels.cpp:52-90; conj_v is the identity for real T)
     for (int64_t j = 0; j < iter; ++j) {
         const T c = gcos[j * ldc + i], s = gsin[j * lds_ + i];
         const T hj = h[j * ldh + i], hj1 = h[(j + 1) * ldh + i];
         const T temp = c * hj + s * hj1;
-        h[(j + 1) * ldh + i] = -s * hj + c * hj1;
+        h[(j + 1) * ldh + i] = -conj_v(s) * hj + conj_v(c) * hj1;
         h[j * ldh + i] = temp;
     }
-    // calculate_sin_and_cos
+    // calculate_sin_and_cos (:29-48)
     const T this_h = h[iter * ldh + i];
     const T next_h = h[(iter + 1) * ldh + i];
     T c, s;
@@ -292,25 +286,24 @@ __global__ __launch_bounds__(256) void gmres_hessenberg_qr_kernel(
         c = T(0);
         s = T(1);
     } else {
-        const T scale = dabs(this_h) + dabs(next_h);
-        const T hyp = scale * sqrt(dabs(this_h / scale) * dabs(this_h / scale) +
-                                   dabs(next_h / scale) * dabs(next_h / scale));
-        c = this_h / hyp;
-        s = next_h / hyp;
+        const R scale = abs_v(this_h) + abs_v(next_h);
+        const R hyp = scale * sqrt(abs_v(this_h / scale) * abs_v(this_h / scale) +
+                                   abs_v(next_h / scale) * abs_v(next_h / scale));
+        c = conj_v(this_h) / hyp;
+        s = conj_v(next_h) / hyp;
     }
     gcos[iter * ldc + i] = c;
     gsin[iter * lds_ + i] = s;
     h[iter * ldh + i] = c * this_h + s * next_h;
     h[(iter + 1) * ldh + i] = T(0);
-    // calculate_next_residual_norm
+    // calculate_next_residual_norm (:93-113)
     const T r = rnc[iter * ldr + i];
-    const T rn = -s * r;
+    const T rn = -conj_v(s) * r;
     rnc[(iter + 1) * ldr + i] = rn;
     rnc[iter * ldr + i] = c * r;
-    residual_norm[i] = dabs(rn);
+    residual_norm[i] = abs_v(rn);
 }
 
-// reference common_gmres_kernels.cpp:171-193: H(i, j) at hessenberg(j, i*cols + k)
 template <typename T>
 __global__ __launch_bounds__(256) void gmres_solve_krylov_kernel(
     int64_t cols, const T* __restrict__ rnc, int64_t ldr,
@@ -371,7 +364,8 @@ extern "C" size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrh
     }                                                                          \
     extern "C" int gkoc_gmres_restart_##TN(                                    \
         gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* residual,        \
-        int64_t ldr, const T* residual_norm, T* residual_norm_collection,      \
+        int64_t ldr, const gkoc::real_t<T>* residual_norm,                     \
+        T* residual_norm_collection,                                           \
         T* krylov_bases, int64_t ldk, uint64_t* final_iter_nums)               \
     {                                                                          \
         if (nrhs <= 0) return GKOC_OK;                                         \
@@ -478,7 +472,7 @@ extern "C" size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrh
     }                                                                          \
     extern "C" int gkoc_common_gmres_hessenberg_qr_##TN(                       \
         gkoc_stream_t s, int64_t nrhs, T* givens_sin, int64_t ld_sin,          \
-        T* givens_cos, int64_t ld_cos, T* residual_norm,                       \
+        T* givens_cos, int64_t ld_cos, gkoc::real_t<T>* residual_norm,         \
         T* residual_norm_collection, int64_t ld_rnc, T* hessenberg_iter,       \
         int64_t ld_h, int64_t iter, uint64_t* final_iter_nums,                 \
         const uint8_t* stop_status)                                            \
@@ -510,3 +504,6 @@ extern "C" size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrh
 
 GKOC_DEF_GMRES(double, f64)
 GKOC_DEF_GMRES(float, f32)
+// complex value types: the same templates (conj_v / abs_v / real_t are the identity for real T)
+GKOC_DEF_GMRES(gkoc_c128, c128)
+GKOC_DEF_GMRES(gkoc_c64, c64)

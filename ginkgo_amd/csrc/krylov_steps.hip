@@ -389,7 +389,7 @@ struct op_pipe_cg_step2 {
         if (s.plain) {
             beta[c] = delta[c];
         } else {
-            const T a = fabs(s.tmp);
+            const real_t<T> a = abs_v(s.tmp);          // |rho / prev_rho| (real for complex T as well)
             T b = delta[c] - a * a * beta[c];
             if (b == T(0)) b = delta[c];
             beta[c] = b;
@@ -567,7 +567,8 @@ struct op_minres_step2 {
 // in = {x, residual, p, Ap}, out = {x, residual}
 template <typename T>
 struct op_gcr_step1 {
-    const T *ap_norm, *rap;
+    const real_t<T>* ap_norm;     // Dense<remove_complex<ValueType>> (core/solver/gcr_kernels.hpp:42)
+    const T* rap;
     const uint8_t* stop;
     struct scalars {
         T tmp;
@@ -575,8 +576,8 @@ struct op_gcr_step1 {
     };
     __device__ scalars load(int64_t c) const
     {
-        const T nrm = ap_norm[c];
-        const bool nz = nrm != T(0);
+        const real_t<T> nrm = ap_norm[c];
+        const bool nz = nrm != real_t<T>(0);
         return {nz ? rap[c] / nrm : T(0), !nz || status_has_stopped(stop[c])};
     }
     __device__ bool skip(const scalars& s) const { return s.noop; }
@@ -1152,7 +1153,9 @@ int launch_pipe_cg_step2_step1_dots(gkoc_stream_t s, int64_t n, T* x, T* r, T* z
         return launch_elementwise<T, op_pipe_cg_step2<T>, 8, 4>(                          \
             s, rows, cols, o.a,                                                           \
             op_pipe_cg_step2<T>{prev_rho, rho, delta, beta, stop_status}, false);         \
-    }                                                                                     \
+    }
+
+#define GKOC_DEF_KRYLOV_X(T, TN)                                                          \
     extern "C" int gkoc_x_pipe_cg_step_2_step_1_dots_##TN(                                \
         gkoc_stream_t s, int64_t rows, T* x, T* r, T* z, T* w, T* p, T* q, T* f, T* g,    \
         const T* m, const T* n, const T* prev_rho, const T* rho, const T* delta,          \
@@ -1175,6 +1178,11 @@ int launch_pipe_cg_step2_step1_dots(gkoc_stream_t s, int64_t n, T* x, T* r, T* z
 
 GKOC_DEF_KRYLOV(double, f64)
 GKOC_DEF_KRYLOV(float, f32)
+// (complex value types: the same templates on gkoc_cplx; agree with the reference to rounding)
+GKOC_DEF_KRYLOV(gkoc_c128, c128)
+GKOC_DEF_KRYLOV(gkoc_c64, c64)
+GKOC_DEF_KRYLOV_X(double, f64)
+GKOC_DEF_KRYLOV_X(float, f32)
 
 #define GKOC_DEF_BICG(T, TN)                                                              \
     extern "C" int gkoc_bicg_initialize_##TN(                                             \
@@ -1216,6 +1224,8 @@ GKOC_DEF_KRYLOV(float, f32)
     }
 GKOC_DEF_BICG(double, f64)
 GKOC_DEF_BICG(float, f32)
+GKOC_DEF_BICG(gkoc_c128, c128)
+GKOC_DEF_BICG(gkoc_c64, c64)
 
 #define GKOC_DEF_MINRES(T, TN)                                                            \
     extern "C" int gkoc_minres_initialize_##TN(                                           \
@@ -1301,7 +1311,7 @@ GKOC_DEF_MINRES(float, f32)
     extern "C" int gkoc_gcr_step_1_##TN(                                                  \
         gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx, T* residual,      \
         int64_t ldr, const T* p, int64_t ldp, const T* ap, int64_t ldap,                  \
-        const T* ap_norm, const T* rap, const uint8_t* stop_status)                       \
+        const gkoc::real_t<T>* ap_norm, const T* rap, const uint8_t* stop_status)         \
     {                                                                                     \
         operand_list<T, 4, 2> o;                                                          \
         o.in(x, ldx).in(residual, ldr).in(p, ldp).in(ap, ldap).out(x, ldx)                \
@@ -1311,6 +1321,8 @@ GKOC_DEF_MINRES(float, f32)
     }
 GKOC_DEF_GCR(double, f64)
 GKOC_DEF_GCR(float, f32)
+GKOC_DEF_GCR(gkoc_c128, c128)
+GKOC_DEF_GCR(gkoc_c64, c64)
 
 #define GKOC_DEF_CHEB(T, TN)                                                              \
     extern "C" int gkoc_chebyshev_init_update_##TN(                                       \

@@ -49,6 +49,16 @@ extern "C" {
 
 typedef void* gkoc_stream_t;
 
+/* complex<double> / complex<float> of the value-type lists (include/ginkgo/core/base/types.hpp:471,
+ * 689): two reals, real part first (the layout of the C and C++ complex types).  Complex kernels follow the
+ * reference's expressions with the textbook complex product and a scaled quotient: they agree with the
+ * reference to rounding (its own tolerance r<value_type>), not bit for bit. */
+#ifndef GKOC_COMPLEX_TYPES_DEFINED   /* (the library defines the same two layouts with arithmetic) */
+typedef struct { double re, im; } gkoc_c128;
+typedef struct { float re, im; } gkoc_c64;
+#endif
+
+
 /* ------------------------------------------------------------------ runtime
  * replaces HipExecutor::{raw_alloc,raw_free,raw_copy_to,synchronize,
  * get_num_devices,set_gpu_property} (core/device_hooks/hip_hooks.cpp:21-252,
@@ -265,6 +275,10 @@ GKOC_DECL_ELL(double, f64, int32_t, i32)
 GKOC_DECL_ELL(double, f64, int64_t, i64)
 GKOC_DECL_ELL(float, f32, int32_t, i32)
 GKOC_DECL_ELL(float, f32, int64_t, i64)
+GKOC_DECL_ELL(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_ELL(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_ELL(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_ELL(gkoc_c64, c64, int64_t, i64)
 
 /* ------------------------------------------------------------ SELL-P SpMV
  * sellp::spmv / advanced_spmv  core/matrix/sellp_kernels.hpp:20-31
@@ -289,6 +303,10 @@ GKOC_DECL_SELLP(double, f64, int32_t, i32)
 GKOC_DECL_SELLP(double, f64, int64_t, i64)
 GKOC_DECL_SELLP(float, f32, int32_t, i32)
 GKOC_DECL_SELLP(float, f32, int64_t, i64)
+GKOC_DECL_SELLP(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_SELLP(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_SELLP(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_SELLP(gkoc_c64, c64, int64_t, i64)
 
 /* ---------------------------------------------------- format conversions
  * csr::convert_to_ell / convert_to_sellp, ell::compute_max_row_nnz,
@@ -537,6 +555,8 @@ GKOC_DECL_DENSE(float, f32)
                             const uint8_t* stop_status);
 GKOC_DECL_CG(double, f64)
 GKOC_DECL_CG(float, f32)
+GKOC_DECL_CG(gkoc_c128, c128)
+GKOC_DECL_CG(gkoc_c64, c64)
 
 /* ----------------------------------------------------------------- GMRES
  * gmres::{restart,multi_axpy,multi_dot}  core/solver/gmres_kernels.hpp:23-45,
@@ -551,7 +571,8 @@ GKOC_DECL_CG(float, f32)
  * (tolerance 1e-13); everything else is bit-identical to the reference. */
 size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrhs,
                                             int64_t num_dots, size_t value_size);
-#define GKOC_DECL_GMRES(T, TN)                                                 \
+/* (R = remove_complex<T>: residual_norm is real also for complex value types) */
+#define GKOC_DECL_GMRES(T, TN, R)                                                 \
     int gkoc_common_gmres_initialize_##TN(                                     \
         gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* b, int64_t ldb,  \
         T* residual, int64_t ldr, T* givens_sin, int64_t ld_sin,               \
@@ -559,7 +580,7 @@ size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrhs,
         uint8_t* stop_status);                                                 \
     int gkoc_gmres_restart_##TN(                                               \
         gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* residual,        \
-        int64_t ldr, const T* residual_norm, T* residual_norm_collection,      \
+        int64_t ldr, const R* residual_norm, T* residual_norm_collection,      \
         T* krylov_bases, int64_t ldk, uint64_t* final_iter_nums);              \
     int gkoc_gmres_multi_axpy_##TN(                                            \
         gkoc_stream_t s, int64_t rows, int64_t nrhs, const T* krylov_bases,    \
@@ -571,7 +592,7 @@ size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrhs,
         T* hessenberg_col, int64_t ldh, void* work, size_t work_bytes);        \
     int gkoc_common_gmres_hessenberg_qr_##TN(                                  \
         gkoc_stream_t s, int64_t nrhs, T* givens_sin, int64_t ld_sin,          \
-        T* givens_cos, int64_t ld_cos, T* residual_norm,                       \
+        T* givens_cos, int64_t ld_cos, R* residual_norm,                       \
         T* residual_norm_collection, int64_t ld_rnc, T* hessenberg_iter,       \
         int64_t ld_h, int64_t iter, uint64_t* final_iter_nums,                 \
         const uint8_t* stop_status);                                           \
@@ -579,8 +600,10 @@ size_t gkoc_gmres_multi_dot_workspace_bytes(int64_t rows, int64_t nrhs,
         gkoc_stream_t s, int64_t nrhs, const T* residual_norm_collection,      \
         int64_t ld_rnc, const T* hessenberg, int64_t ld_h, T* y, int64_t ldy,  \
         const uint64_t* final_iter_nums, const uint8_t* stop_status);
-GKOC_DECL_GMRES(double, f64)
-GKOC_DECL_GMRES(float, f32)
+GKOC_DECL_GMRES(double, f64, double)
+GKOC_DECL_GMRES(float, f32, float)
+GKOC_DECL_GMRES(gkoc_c128, c128, double)
+GKOC_DECL_GMRES(gkoc_c64, c64, float)
 
 /* ---------------------------------------------------------------- IDR(s)
  * idr::{initialize, step_1, step_2, step_3, compute_omega}  core/solver/idr_kernels.hpp:22-72,
@@ -1151,7 +1174,7 @@ typedef struct gkoc_step_gate {
     uint8_t stopping_id;
     uint8_t set_finalized;
 } gkoc_step_gate;
-#define GKOC_DECL_X(T, TN)                                                     \
+#define GKOC_DECL_X_GMRES(T, TN)                                               \
     int gkoc_x_gmres_mgs_step_##TN(                                            \
         gkoc_stream_t s, int64_t rows, T* next_krylov, const T* basis_cur,     \
         const T* h_cur, const T* basis_next, T* h_next, void* work,            \
@@ -1159,7 +1182,12 @@ typedef struct gkoc_step_gate {
     int gkoc_x_gmres_multi_sub_scaled_##TN(                                    \
         gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t num,              \
         const T* krylov_bases, int64_t ldk, const T* h, int64_t ldh,           \
-        T* next_krylov, int64_t ldn);                                          \
+        T* next_krylov, int64_t ldn);
+GKOC_DECL_X_GMRES(double, f64)
+GKOC_DECL_X_GMRES(float, f32)
+GKOC_DECL_X_GMRES(gkoc_c128, c128)
+GKOC_DECL_X_GMRES(gkoc_c64, c64)
+#define GKOC_DECL_X(T, TN)                                                     \
     int gkoc_x_cg_step_2_norm_##TN(                                            \
         gkoc_stream_t s, int64_t rows, T* x, T* r, const T* p, const T* q,     \
         const T* beta, const T* rho, const uint8_t* stop_status, T* norm_out,  \
@@ -1251,8 +1279,7 @@ int gkoc_x_cg_step_2_jacobi_apply_fits(int64_t num_blocks, int64_t n_rows,
  * / remove_zeros / sum_duplicates: a value is zero if both parts are, sums are component-wise),
  * fill_array / fill_seq_array, and the 2-norm of the columns of a complex Dense (what
  * stop::ResidualNorm needs).  SpMV, BLAS-1 with complex scalars and the solvers are real-valued. */
-typedef struct { double re, im; } gkoc_c128;
-typedef struct { float re, im; } gkoc_c64;
+/* (gkoc_c128 / gkoc_c64: declared at the top of this file) */
 int gkoc_remove_zeros_count_c128(gkoc_stream_t s, int64_t nnz, const gkoc_c128* vals, void* work,
                                  size_t work_bytes, int64_t* count_host);
 int gkoc_remove_zeros_count_c64(gkoc_stream_t s, int64_t nnz, const gkoc_c64* vals, void* work,
@@ -1831,6 +1858,8 @@ GKOC_DECL_TRANSPOSE(float, f32, int64_t, i64)
         T* rho, const T* delta, const uint8_t* stop_status);
 GKOC_DECL_KRYLOV(double, f64)
 GKOC_DECL_KRYLOV(float, f32)
+GKOC_DECL_KRYLOV(gkoc_c128, c128)
+GKOC_DECL_KRYLOV(gkoc_c64, c64)
 
 /* bicg::{initialize, step_1, step_2} (core/solver/bicg_kernels.hpp;
  * reference/solver/bicg_kernels.cpp:24-110): the updates of the biconjugate gradient
@@ -1856,13 +1885,15 @@ GKOC_DECL_KRYLOV(float, f32)
         const uint8_t* stop_status);
 GKOC_DECL_BICG(double, f64)
 GKOC_DECL_BICG(float, f32)
+GKOC_DECL_BICG(gkoc_c128, c128)
+GKOC_DECL_BICG(gkoc_c64, c64)
 
 /* gcr::{initialize, restart, step_1} (core/solver/gcr_kernels.hpp;
  * reference/solver/gcr_kernels.cpp:24-88): the restarted generalised conjugate
  * residual method keeps its search directions p and A p in two tall Dense matrices of
  * (krylov_dim + 1) x rows rows; restart copies the preconditioned residual and its
  * image into the first slot, step_1 is the update with t = <r, Ap> / ||Ap||^2. */
-#define GKOC_DECL_GCR(T, TN)                                                   \
+#define GKOC_DECL_GCR(T, TN, R)                                                   \
     int gkoc_gcr_initialize_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,  \
                                  const T* b, int64_t ldb, T* residual,         \
                                  int64_t ldr, uint8_t* stop_status);           \
@@ -1873,10 +1904,12 @@ GKOC_DECL_BICG(float, f32)
     int gkoc_gcr_step_1_##TN(                                                  \
         gkoc_stream_t s, int64_t rows, int64_t cols, T* x, int64_t ldx,        \
         T* residual, int64_t ldr, const T* p, int64_t ldp, const T* ap,        \
-        int64_t ldap, const T* ap_norm, const T* rap,                          \
+        int64_t ldap, const R* ap_norm, const T* rap,                          \
         const uint8_t* stop_status);
-GKOC_DECL_GCR(double, f64)
-GKOC_DECL_GCR(float, f32)
+GKOC_DECL_GCR(double, f64, double)
+GKOC_DECL_GCR(float, f32, float)
+GKOC_DECL_GCR(gkoc_c128, c128, double)
+GKOC_DECL_GCR(gkoc_c64, c64, float)
 
 /* minres::{initialize, step_1, step_2} (core/solver/minres_kernels.hpp;
  * reference/solver/minres_kernels.cpp:24-150): MINRES for symmetric (indefinite)
