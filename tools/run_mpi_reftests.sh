@@ -1,5 +1,6 @@
 #!/bin/bash
-TAG=${1:-r03s15}
+# Ginkgo's own test/mpi binaries (oracle/build_mpi_dropin.py) under mpiexec with per-rank logs: gpurun_out/<tag>/; input of tools/update_mpi_reftests_expected.py
+TAG=${1:-mpi_reftests}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

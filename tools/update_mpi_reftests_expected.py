@@ -1,5 +1,5 @@
 """Rewrite tests/dropin/mpi_reftests_expected.json from the logs of a run of Ginkgo's own MPI test
-binaries on the GPU (tools/r03_s15.sh: <dir>/<suite>_mpi_hip.log is rank 0's report,
+binaries on the GPU (tools/run_mpi_reftests.sh: <dir>/<suite>_mpi_hip.log is rank 0's report,
 <dir>/<suite>.rank<k>.log the other ranks').  A test counts as failing when it fails on ANY rank.
   python tools/update_mpi_reftests_expected.py gpurun_out/r03s17/mpi"""
 import glob
