@@ -1053,6 +1053,68 @@ FOR_VT_IT(DEF)
 FOR_VT(DEF)
 #undef DEF
 
+// jacobi::convert_to_dense / scalar_convert_to_dense (core/preconditioner/jacobi_kernels.hpp:105-118;
+// reference/preconditioner/jacobi_kernels.cpp:670-721): the preconditioner as a dense matrix.  A
+// convenience of small problems - computed as M * I with the apply kernels above (every entry is a
+// stored value times one plus zeros: exact), for every storage precision the apply kernels read.
+namespace {
+template <typename T>
+std::unique_ptr<matrix::Dense<T>> identity_on(exec_t exec, size_type n)
+{
+    auto host = matrix::Dense<T>::create(exec->get_master(), dim<2>{n, n});
+    host->fill(zero<T>());
+    for (size_type i = 0; i < n; ++i) host->at(i, i) = one<T>();
+    return clone(exec, host);
+}
+}  // namespace
+
+#define DEF(T, TN)                                                              \
+    template <>                                                                 \
+    void scalar_convert_to_dense<T>(exec_t exec, const array<T>& blocks,        \
+                                    matrix::Dense<T>* result)                   \
+    {                                                                           \
+        const auto n = result->get_size()[0];                                   \
+        if (n == 0 || result->get_size()[1] == 0) return;                       \
+        auto eye = matrix::Dense<T>::create(exec->get_master(), result->get_size()); \
+        eye->fill(zero<T>());                                                   \
+        for (size_type i = 0; i < std::min(n, result->get_size()[1]); ++i) {    \
+            eye->at(i, i) = one<T>();                                           \
+        }                                                                       \
+        auto dev = clone(exec, eye);                                            \
+        simple_scalar_apply<T>(exec, blocks, dev.get(), result);                \
+        exec->synchronize(); /* the identity is released on return */           \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+#define DEF(T, TN, I, IN)                                                       \
+    template <>                                                                 \
+    void convert_to_dense<T, I>(                                                \
+        exec_t exec, size_type num_blocks,                                      \
+        const array<precision_reduction>& block_precisions,                     \
+        const array<I>& block_pointers, const array<T>& blocks,                 \
+        const preconditioner::block_interleaved_storage_scheme<I>&              \
+            storage_scheme,                                                     \
+        T* result_values, size_type result_stride)                              \
+    {                                                                           \
+        const auto n = static_cast<size_type>(                                  \
+            exec->copy_val_to_host(block_pointers.get_const_data() + num_blocks)); \
+        if (n == 0) return;                                                     \
+        auto eye = identity_on<T>(exec, n);                                     \
+        auto out = matrix::Dense<T>::create(                                    \
+            exec, dim<2>{n, n},                                                 \
+            make_array_view(exec, (n - 1) * result_stride + n, result_values),  \
+            result_stride);                                                     \
+        /* (max_block_size only selects a kernel: the scheme's block_offset bounds it) */ \
+        simple_apply<T, I>(exec, num_blocks,                                    \
+                           static_cast<uint32>(storage_scheme.block_offset),    \
+                           storage_scheme, block_precisions, block_pointers,    \
+                           blocks, eye.get(), out.get());                       \
+        exec->synchronize(); /* the identity is released on return */           \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
 }  // namespace jacobi
 
 

@@ -458,6 +458,38 @@ int main(int argc, char** argv)
                   "CG + user LinOp preconditioner: ||r|| still comes with step_2, <r,z> is computed");
         }
         {
+            // Jacobi::convert_to(Dense): the preconditioner as a dense matrix (jacobi::convert_to_dense,
+            // scalar_convert_to_dense) - block size 8, block size 1 and adaptive block precisions on a
+            // 6^3 stencil, equal to the reference entry by entry
+            auto small = generate_stencil<vt, it>("27pt", gko::size_type{216});
+            auto s_ref = gko::share(Csr::create(ref));
+            s_ref->read(small.first);
+            auto s_hip = gko::share(gko::clone(hip, s_ref));
+            bool same = true;
+            for (int variant = 0; variant < 3; ++variant) {
+                auto make = [&](std::shared_ptr<const gko::Executor> e, std::shared_ptr<Csr> a) {
+                    auto f = gko::preconditioner::Jacobi<vt, it>::build().with_max_block_size(
+                        variant == 1 ? 1u : 8u);
+                    if (variant == 2) {
+                        f.with_storage_optimization(gko::precision_reduction::autodetect());
+                    }
+                    auto j = f.on(e)->generate(a);
+                    auto d = Dense::create(e);
+                    j->convert_to(d);
+                    return gko::clone(ref, d);
+                };
+                auto d_ref = make(ref, s_ref);
+                auto d_hip = make(hip, s_hip);
+                same = same && d_ref->get_size() == d_hip->get_size();
+                for (gko::size_type i = 0; same && i < d_ref->get_size()[0]; ++i) {
+                    for (gko::size_type j = 0; same && j < d_ref->get_size()[1]; ++j) {
+                        same = d_ref->at(i, j) == d_hip->at(i, j);
+                    }
+                }
+            }
+            CHECK(same, "Jacobi::convert_to(Dense) (block 8, scalar, adaptive precisions) equals the reference");
+        }
+        {
             // csr::build_lookup_offsets / build_lookup: descriptors and storage bit-identical to the
             // reference's for every combination of allowed kinds - on the 27-pt matrix (bitmap rows)
             // and on a matrix with full rows, an empty row, a long scattered row (hash)
