@@ -122,12 +122,20 @@ __global__ void fork_set_kernel(uint32_t* word, uint32_t number)
     __hip_atomic_store(word, number, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// word[0]: the number of the last fork whose store has happened; word[16] (another cache line): set
+// by a poller that gave up - about a minute of polling, so that a store that never comes (its kernel
+// was refused after the poller had been enqueued) does not hang the queue for good; what runs behind
+// such a poller is NOT ordered behind the main stream, gkoc_comm_fork_timed_out tells (the solvers
+// of the Python mirror ask it when they return)
 __global__ void fork_wait_kernel(const uint32_t* word, uint32_t number)
 {
     long spins = 0;
     while (int32_t(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - number) < 0) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (long(1) << 26)) break;     // ~1 min: never hang a queue for good
+        if (++spins > (long(1) << 28)) {
+            __hip_atomic_store(const_cast<uint32_t*>(word) + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
     }
 }
 
@@ -209,6 +217,17 @@ int gkoc_comm_fork_deferred(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_st
     comm->fork_deferred = true;
     *word = comm->fork_word;
     *number = ++comm->fork_number;
+    return GKOC_OK;
+}
+
+int gkoc_comm_fork_timed_out(gkoc_comm_t comm, int* timed_out)
+{
+    GKOC_REQUIRE(comm && timed_out, GKOC_E_INVALID, "bad argument");
+    *timed_out = 0;
+    if (!comm->fork_word) return GKOC_OK;
+    uint32_t v = 0;
+    GKOC_HIP(hipMemcpy(&v, comm->fork_word + 16, sizeof(v), hipMemcpyDeviceToHost));
+    *timed_out = v != 0;
     return GKOC_OK;
 }
 
@@ -362,7 +381,10 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
         GKOC_REQUIRE(!send_displs || send_displs[p] >= 0, GKOC_E_INVALID, "negative displacement");
         n_msgs += (send_counts[p] > 0) + (recv_counts[p] > 0);
     }
-    if (n_msgs == 0) return GKOC_OK;
+    if (n_msgs == 0) {
+        comm->fork_deferred = false;     // nothing to order: a fork handed to the caller is void
+        return GKOC_OK;
+    }
     GKOC_REQUIRE(send_buf && recv_buf, GKOC_E_INVALID, "NULL buffer with non-zero counts");
     GKOC_REQUIRE(!comm->pending_reduce || xs == comm->side_in_use, GKOC_E_INVALID,
                  "gkoc_comm_exchange_begin: an all-reduce is pending on another stream");

@@ -263,6 +263,14 @@ class RcclComm(TorchComm):
              C.byref(w), C.byref(n))
         return self._fork_tok
 
+    def check(self):
+        """raises if a fork's poller ever gave up (gkoc_comm_fork_timed_out); synchronises"""
+        flag = C.c_int(0)
+        call("gkoc_comm_fork_timed_out", self._handle, C.byref(flag))
+        if flag.value:
+            raise GkoError("RcclComm: the exchange's stream waited a minute for the kernel that opens its "
+                           "fork and went on without it (GKO_DEFERRED_FORK=0 forks in front of the product)")
+
     def exchange_end(self):
         call("gkoc_comm_exchange_end", self._handle, self.exec.stream)
 
@@ -960,6 +968,8 @@ class DistributedMatrix:
         if self._gate is not None and int(self._gate[0][1].item()) != 0:
             raise GkoError("DistributedMatrix: the halo exchange did not arrive within the one-kernel "
                            "product's patience (GKO_GATED_SPMV=0 selects the join-based product)")
+        if self._gate is not None and hasattr(self.comm, "check"):
+            self.comm.check()
 
     def _fork_token(self):
         """the exchange about to begin is forked by the product's own kernel where the

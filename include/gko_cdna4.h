@@ -2043,6 +2043,9 @@ int gkoc_stream_fork_wait(gkoc_stream_t side, const uint32_t* word, uint32_t num
  * front of the storing kernel would block it) - the begin call then forks by itself as usual. */
 int gkoc_comm_fork_deferred(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_stream_t side,
                             uint32_t** word, uint32_t* number);
+/* *timed_out = 1 if a poller of one of this communicator's forks gave up (about a minute without the
+ * store it waited for: what ran behind it was not ordered behind the main stream); synchronises */
+int gkoc_comm_fork_timed_out(gkoc_comm_t comm, int* timed_out);
 /* ends an exchange WITHOUT making the main stream wait: the kernel that reads the halo waits for
  * it itself (gkoc_gate_open on the side stream + gkoc_csr_spmv_gated_*) */
 int gkoc_comm_exchange_forget(gkoc_comm_t comm);
