@@ -112,10 +112,20 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         // products of an entry side by side in the LDS ring (csr_spmv_multi_kernel; 8 KB ring of 512
         // entries).  L256: 1.46 ms against 2.18 ms for one pass per column.
         const int b_vec_ok = reinterpret_cast<uintptr_t>(b) % (2 * sizeof(T)) == 0 && ldb % 2 == 0;
-        csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 2><<<grid, block, 0, as_stream(s)>>>(
-            n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
-            static_cast<int>(nrhs), alpha, beta, b_vec_ok,
-            tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / (64 * segs_per_wave));
+        // two entries per lane and load, two load groups in flight (more, smaller loads under way: the
+        // single-column kernel's lesson of round 3): L256 1.457 -> 1.38-1.40 ms = 55 % of 8 TB/s
+        // (profiles/r04_experiments.txt); GKOC_TUNE_CSR_LOAD_GROUPS = 1: four entries, one group
+        if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1) {
+            csr_spmv_multi_kernel<T, I, ADV, EV, 1, RINGV / 2, 2><<<grid, block, 0, as_stream(s)>>>(
+                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
+                static_cast<int>(nrhs), alpha, beta, b_vec_ok,
+                tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / (64 * segs_per_wave));
+        } else {
+            csr_spmv_multi_kernel<T, I, ADV, EV / 2, 2, RINGV / 2, 2><<<grid, block, 0, as_stream(s)>>>(
+                n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, ldc,
+                static_cast<int>(nrhs), alpha, beta, b_vec_ok,
+                tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS) / (64 * segs_per_wave));
+        }
         GKOC_LAUNCH_OK();
         return GKOC_OK;
     }
