@@ -579,8 +579,33 @@ def main():
         # known-answer test of every collective form the solvers use + their latencies here;
         # wrong data raises on all ranks, a hang ends the job with a message (not a timeout)
         comm_check = gd.comm_self_check(ex, op.comm, n_elems=grid * grid)
+        # the one-kernel product (boundary waves that wait for their halo inside the kernel) against
+        # the join-based one on THIS communicator before anything is timed; a rank that sees a
+        # difference, a wave that gave up or a fork that timed out sends ALL ranks to the join-based
+        # product (the reference's shape) - the line says which one was measured
+        ok, why = op.matrix.self_check()
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=ex.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            op.matrix.conservative()
+        product_check = {"one_kernel_product": op.matrix._gate is not None,
+                         "self_check": why if float(flag.item()) >= 1.0 or not ok else "failed on another rank"}
         if args.cg_iters > 0:
-            t_setup = op.prepare_cg(args.cg_iters, barrier)
+            # (the warm-up solve ends with the solvers' own checks - a boundary wave that gave up, a
+            # fork that timed out: raised at the END of the solve, after every collective has been
+            # issued, so all ranks arrive here and agree)
+            err = None
+            try:
+                t_setup = op.prepare_cg(args.cg_iters, barrier)
+            except gd.GkoError as e:
+                err = str(e)[:200]
+            flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=ex.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 1.0:
+                op.matrix.conservative()
+                product_check = {"one_kernel_product": False,
+                                 "self_check": "warm-up solve: " + (err or "failed on another rank")}
+                t_setup = op.prepare_cg(args.cg_iters, barrier)
         x = op.random_vector(42)
         y = op.zeros_vector()
         step = lambda: op.apply(x, y)
@@ -709,6 +734,7 @@ def main():
         out.update(cg)
         if use_dist:
             out["comm_check"] = comm_check
+            out["distributed_product"] = product_check
             out["rank0_profile"] = dist_profile
             out["roofline"]["per_rank"] = [
                 {"rank": r, "kernel_ms": v[0],

@@ -971,6 +971,40 @@ class DistributedMatrix:
         if self._gate is not None and hasattr(self.comm, "check"):
             self.comm.check()
 
+    def conservative(self):
+        """from now on: the join-based product (local rows || exchange, boundary rows in stream order,
+        forks in front of the exchange) - the reference's shape, nothing waits inside a kernel"""
+        self._gate = None
+        self.deferred_fork = False
+
+    def self_check(self, seed=7):
+        """The one-kernel product against the join-based one on THIS communicator, before anything
+        is timed: same bits on every local row, no boundary wave that gave up, no fork that timed out.
+        Every rank runs the same collectives.  (ok, what) - on failure the caller agrees with the other
+        ranks and calls conservative() on all of them."""
+        if self._gate is None or self.comm.size == 1:
+            return True, "join-based product (no one-kernel product for this matrix / communicator)"
+        be = self.backend
+        x = self.ext_vector()
+        vals = np.random.default_rng(seed + self.rank).uniform(-1, 1, self.n_local)
+        x.values.copy_(torch.from_numpy(vals).view(-1, 1))
+        y1, y2 = be.vector(self.n_local, self.dtype), be.vector(self.n_local, self.dtype)
+        try:
+            for _ in range(3):
+                self.apply(x, y1)
+            self.check_gate()
+            gate, self._gate = self._gate, None
+            try:
+                self.apply(x, y2)
+            finally:
+                self._gate = gate
+            be.synchronize()
+            if not torch.equal(y1.values, y2.values):
+                return False, "one-kernel product differs from the join-based product"
+        except GkoError as e:
+            return False, str(e)[:200]
+        return True, "one-kernel product == join-based product bit for bit"
+
     def _fork_token(self):
         """the exchange about to begin is forked by the product's own kernel where the
         communicator offers it (no event, no kernel in front of the product on the main queue)"""
