@@ -388,6 +388,11 @@ def matrix_bench(args):
         comm_check = gd.comm_self_check(ex, comm, n_elems=4096)
         for name_ in ("csr", "sellp"):
             dm = gd.DistributedMatrix(be, comm, part, owned, local_format=name_)
+            ok, why = dm.self_check()          # one-kernel product vs join-based one, all ranks agree
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=ex.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 1.0:
+                dm.conservative()
             x = be.vector_from(xg[lo:hi])
             y = be.vector(n_local)
             wall, kms = time_op(lambda: dm.apply(x, y), args.steps, args.warmup)
