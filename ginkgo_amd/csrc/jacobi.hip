@@ -230,11 +230,11 @@ __device__ __forceinline__ bool gauss_jordan_lds(T* Bm, int ld, int bs, int r, i
     wave_lds_sync();
     for (int k = 0; k < max_bs; ++k) {
         const bool act = k < bs && !dead;
-        // pivot = first row in [k, bs) with the largest |B(i,k)|
-        T pa = (act && r >= k && r < bs) ? gabs(Bm[r * ld + k]) : T(-1);
+        // pivot = first row in [k, bs) with the largest |B(i,k)| (a real number for complex T too)
+        real_t<T> pa = (act && r >= k && r < bs) ? abs_v(Bm[r * ld + k]) : real_t<T>(-1);
         int pi = r;
         for (int off = 1; off < sub; off <<= 1) {
-            const T oa = __shfl_xor(pa, off, 64);
+            const real_t<T> oa = __shfl_xor(pa, off, 64);
             const int oi = __shfl_xor(pi, off, 64);
             if (oa > pa || (oa == pa && oi < pi)) {
                 pa = oa;
@@ -1567,10 +1567,126 @@ int launch_generate(gkoc_stream_t s, const I* row_ptrs, const I* cols,
     return GKOC_OK;
 }
 
+// Block-Jacobi application for the value types without a tuned kernel (complex): one lane per
+// (row, right-hand side) walks its row of the inverse block in the interleaved scheme - element
+// (r, c) of block b at group_offset * (b >> gp) + block_offset * (b & mask) + r + c * stride
+// (include/ginkgo/core/preconditioner/jacobi.hpp:37-140) - and adds the products in column order
+// (reference apply_block, reference/preconditioner/jacobi_kernels.cpp:419-531).  row_block[row] = the
+// block of a row (filled by jacobi_row_block_kernel).
+template <typename I>
+__global__ __launch_bounds__(256) void jacobi_row_block_kernel(int64_t num_blocks,
+                                                              const I* __restrict__ block_ptrs,
+                                                              I* __restrict__ row_block)
+{
+    const int64_t b = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (b >= num_blocks) return;
+    for (I r = block_ptrs[b]; r < block_ptrs[b + 1]; ++r) row_block[r] = I(b);
+}
+
+template <typename T, typename I, bool ADV>
+__global__ __launch_bounds__(256) void jacobi_apply_simple_kernel(
+    int64_t n_rows, int64_t nrhs, gkoc_jacobi_scheme scheme, const I* __restrict__ block_ptrs,
+    const I* __restrict__ row_block, const T* __restrict__ blocks, const T* __restrict__ alpha_p,
+    const T* __restrict__ b, int64_t ldb, const T* __restrict__ beta_p, T* __restrict__ x, int64_t ldx)
+{
+    const int64_t total = n_rows * nrhs, step = int64_t(gridDim.x) * 256;
+    const int64_t stride = scheme.block_offset << scheme.group_power;
+    const int64_t mask = (int64_t(1) << scheme.group_power) - 1;
+    for (int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += step) {
+        const int64_t j = idx / n_rows, row = idx - j * n_rows;
+        const int64_t blk = row_block[row];
+        const int64_t start = block_ptrs[blk], bs = int64_t(block_ptrs[blk + 1]) - start;
+        const T* __restrict__ m = blocks + scheme.group_offset * (blk >> scheme.group_power) +
+                                  scheme.block_offset * (blk & mask) + (row - start);
+        T sum = T(0);
+        for (int64_t c = 0; c < bs; ++c) sum += m[c * stride] * b[(start + c) * ldb + j];
+        if (ADV) {
+            const T beta = beta_p[0];
+            const T ax = alpha_p[0] * sum;
+            x[row * ldx + j] = beta == T(0) ? ax : ax + beta * x[row * ldx + j];
+        } else {
+            x[row * ldx + j] = sum;
+        }
+    }
+}
+
+template <typename T, typename I, bool ADV>
+int launch_apply_simple(gkoc_stream_t s, int64_t num_blocks, gkoc_jacobi_scheme scheme, const I* block_ptrs,
+                        const T* blocks, const T* alpha, const T* b, int64_t ldb, const T* beta, T* x,
+                        int64_t ldx, int64_t nrhs)
+{
+    if (num_blocks <= 0 || nrhs <= 0) return GKOC_OK;
+    GKOC_REQUIRE(block_ptrs && blocks && b && x, GKOC_E_INVALID, "null pointer");
+    hipStream_t st = as_stream(s);
+    I last = 0;
+    GKOC_HIP(hipMemcpyAsync(&last, block_ptrs + num_blocks, sizeof(I), hipMemcpyDeviceToHost, st));
+    GKOC_HIP(hipStreamSynchronize(st));
+    const int64_t n_rows = int64_t(last);
+    if (n_rows <= 0) return GKOC_OK;
+    I* row_block = nullptr;
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&row_block), size_t(n_rows) * sizeof(I)));
+    jacobi_row_block_kernel<I><<<dim3(unsigned(ceildiv(num_blocks, 256))), dim3(256), 0, st>>>(
+        num_blocks, block_ptrs, row_block);
+    int64_t nb = ceildiv(n_rows * nrhs, 256);
+    if (nb > 8 * max_stream_blocks) nb = 8 * max_stream_blocks;
+    jacobi_apply_simple_kernel<T, I, ADV><<<dim3(unsigned(nb)), dim3(256), 0, st>>>(
+        n_rows, nrhs, scheme, block_ptrs, row_block, blocks, alpha, b, ldb, beta, x, ldx);
+    const hipError_t e = hipGetLastError();
+    (void)scratch_free(st, row_block);
+    GKOC_HIP(e);
+    return GKOC_OK;
+}
+
 }  // namespace
 }  // namespace gkoc
 
 using namespace gkoc;
+
+// complex block-Jacobi: find_blocks (indices only), generate (the Gauss-Jordan kernel above on
+// gkoc_cplx: pivot by magnitude), simple_apply / apply (jacobi_apply_simple_kernel).  Uniform storage
+// precision only; agrees with the reference to rounding.
+#define GKOC_DEF_CJACOBI(T, TN, I, IN)                                                                  \
+    extern "C" int gkoc_jacobi_find_blocks_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, \
+                                                       const I* col_idxs, uint32_t max_block_size,      \
+                                                       int64_t* num_blocks_host, I* block_ptrs)         \
+    {                                                                                                   \
+        return find_blocks_impl<I>(s, n_rows, row_ptrs, col_idxs, max_block_size, num_blocks_host,      \
+                                   block_ptrs);                                                         \
+    }                                                                                                   \
+    extern "C" int gkoc_jacobi_generate_##TN##_##IN(                                                    \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs, const T* vals,           \
+        int64_t num_blocks, uint32_t max_block_size, gkoc_jacobi_scheme scheme, const I* block_ptrs,    \
+        T* blocks, T* conditioning)                                                                     \
+    {                                                                                                   \
+        (void)n_rows;                                                                                   \
+        GKOC_REQUIRE(conditioning == nullptr, GKOC_E_NOT_SUPPORTED,                                     \
+                     "adaptive-precision block-Jacobi exists for double only");                         \
+        GKOC_REQUIRE(max_block_size <= 32, GKOC_E_NOT_SUPPORTED, "complex blocks: max_block_size <= 32"); \
+        return launch_generate<T, I>(s, row_ptrs, col_idxs, vals, num_blocks, max_block_size, scheme,   \
+                                     block_ptrs, blocks);                                               \
+    }                                                                                                   \
+    extern "C" int gkoc_jacobi_simple_apply_##TN##_##IN(                                                \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size, gkoc_jacobi_scheme scheme,        \
+        const I* block_ptrs, const T* blocks, const T* b, int64_t ldb, T* x, int64_t ldx, int64_t nrhs) \
+    {                                                                                                   \
+        (void)max_block_size;                                                                           \
+        return launch_apply_simple<T, I, false>(s, num_blocks, scheme, block_ptrs, blocks, nullptr, b,  \
+                                                ldb, nullptr, x, ldx, nrhs);                            \
+    }                                                                                                   \
+    extern "C" int gkoc_jacobi_apply_##TN##_##IN(                                                       \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size, gkoc_jacobi_scheme scheme,        \
+        const I* block_ptrs, const T* blocks, const T* alpha, const T* b, int64_t ldb, const T* beta,   \
+        T* x, int64_t ldx, int64_t nrhs)                                                                \
+    {                                                                                                   \
+        (void)max_block_size;                                                                           \
+        GKOC_REQUIRE(alpha && beta, GKOC_E_INVALID, "null alpha / beta");                               \
+        return launch_apply_simple<T, I, true>(s, num_blocks, scheme, block_ptrs, blocks, alpha, b,     \
+                                               ldb, beta, x, ldx, nrhs);                                \
+    }
+GKOC_DEF_CJACOBI(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_CJACOBI(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_CJACOBI(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_CJACOBI(gkoc_c64, c64, int64_t, i64)
 
 #define GKOC_DEF_JACOBI(T, TN, I, IN)                                          \
     extern "C" int gkoc_jacobi_find_blocks_##TN##_##IN(                        \

@@ -10,9 +10,11 @@
 #include <ginkgo/core/matrix/dense.hpp>
 #include <ginkgo/core/matrix/ell.hpp>
 #include <ginkgo/core/matrix/sellp.hpp>
+#include <ginkgo/core/preconditioner/jacobi.hpp>
 
 #include "core/matrix/ell_kernels.hpp"
 #include "core/matrix/sellp_kernels.hpp"
+#include "core/preconditioner/jacobi_kernels.hpp"
 #include "core/solver/cg_kernels.hpp"
 #include "core/solver/common_gmres_kernels.hpp"
 #include "core/solver/gmres_kernels.hpp"
@@ -232,6 +234,83 @@ FOR_C_I(DEF)
 #undef DEF
 
 }  // namespace sellp
+
+
+// block-Jacobi on complex values: uniform storage precision (csrc/jacobi.hip, GKOC_DEF_CJACOBI)
+namespace jacobi {
+
+namespace {
+template <typename I>
+gkoc_jacobi_scheme cscheme(const preconditioner::block_interleaved_storage_scheme<I>& s)
+{
+    return {static_cast<int64_t>(s.block_offset), static_cast<int64_t>(s.group_offset), s.group_power};
+}
+void uniform_only(const array<precision_reduction>& prec)
+{
+    if (prec.get_const_data() != nullptr && prec.get_size() != 0) {
+        throw ::gko::NotSupported(__FILE__, __LINE__, "jacobi",
+                                  "reduced block storage is implemented for double only");
+    }
+}
+}  // namespace
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void find_blocks<T, I>(exec_t exec, const matrix::Csr<T, I>* system_matrix, uint32 max_block_size, \
+                           size_type& num_blocks, array<I>& block_pointers)                         \
+    {                                                                                               \
+        int64_t nb = 0;                                                                             \
+        GKOC_CALL(gkoc_jacobi_find_blocks_##TN##_##IN(                                              \
+            stream_of(exec), system_matrix->get_size()[0], system_matrix->get_const_row_ptrs(),     \
+            system_matrix->get_const_col_idxs(), max_block_size, &nb, block_pointers.get_data()));  \
+        num_blocks = static_cast<size_type>(nb);                                                    \
+    }                                                                                               \
+    template <>                                                                                     \
+    void generate<T, I>(exec_t exec, const matrix::Csr<T, I>* system_matrix, size_type num_blocks,  \
+                        uint32 max_block_size, remove_complex<T>,                                   \
+                        const preconditioner::block_interleaved_storage_scheme<I>& storage_scheme,  \
+                        array<remove_complex<T>>&, array<precision_reduction>& block_precisions,    \
+                        const array<I>& block_pointers, array<T>& blocks)                           \
+    {                                                                                               \
+        uniform_only(block_precisions);                                                             \
+        GKOC_CALL(gkoc_jacobi_generate_##TN##_##IN(                                                 \
+            stream_of(exec), system_matrix->get_size()[0], system_matrix->get_const_row_ptrs(),     \
+            system_matrix->get_const_col_idxs(), px(system_matrix->get_const_values()), num_blocks, \
+            max_block_size, cscheme(storage_scheme), block_pointers.get_const_data(),               \
+            px(blocks.get_data()), nullptr));                                                       \
+    }                                                                                               \
+    template <>                                                                                     \
+    void simple_apply<T, I>(exec_t exec, size_type num_blocks, uint32 max_block_size,               \
+                            const preconditioner::block_interleaved_storage_scheme<I>& storage_scheme, \
+                            const array<precision_reduction>& block_precisions,                     \
+                            const array<I>& block_pointers, const array<T>& blocks,                 \
+                            const matrix::Dense<T>* b, matrix::Dense<T>* x)                         \
+    {                                                                                               \
+        uniform_only(block_precisions);                                                             \
+        GKOC_CALL(gkoc_jacobi_simple_apply_##TN##_##IN(                                             \
+            stream_of(exec), num_blocks, max_block_size, cscheme(storage_scheme),                   \
+            block_pointers.get_const_data(), px(blocks.get_const_data()), px(b->get_const_values()), \
+            ld(b), px(x->get_values()), ld(x), cols(x)));                                           \
+    }                                                                                               \
+    template <>                                                                                     \
+    void apply<T, I>(exec_t exec, size_type num_blocks, uint32 max_block_size,                      \
+                     const preconditioner::block_interleaved_storage_scheme<I>& storage_scheme,     \
+                     const array<precision_reduction>& block_precisions,                            \
+                     const array<I>& block_pointers, const array<T>& blocks,                        \
+                     const matrix::Dense<T>* alpha, const matrix::Dense<T>* b,                      \
+                     const matrix::Dense<T>* beta, matrix::Dense<T>* x)                             \
+    {                                                                                               \
+        uniform_only(block_precisions);                                                             \
+        GKOC_CALL(gkoc_jacobi_apply_##TN##_##IN(                                                    \
+            stream_of(exec), num_blocks, max_block_size, cscheme(storage_scheme),                   \
+            block_pointers.get_const_data(), px(blocks.get_const_data()),                           \
+            px(alpha->get_const_values()), px(b->get_const_values()), ld(b),                        \
+            px(beta->get_const_values()), px(x->get_values()), ld(x), cols(x)));                    \
+    }
+FOR_C_I(DEF)
+#undef DEF
+
+}  // namespace jacobi
 
 }  // namespace hip
 }  // namespace kernels

@@ -755,6 +755,11 @@ GKOC_DECL_JACOBI(double, f64, int32_t, i32)
 GKOC_DECL_JACOBI(double, f64, int64_t, i64)
 GKOC_DECL_JACOBI(float, f32, int32_t, i32)
 GKOC_DECL_JACOBI(float, f32, int64_t, i64)
+/* complex blocks: uniform storage precision, max_block_size <= 32, untuned apply (one lane per row) */
+GKOC_DECL_JACOBI(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_JACOBI(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_JACOBI(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_JACOBI(gkoc_c64, c64, int64_t, i64)
 /* jacobi::transpose_jacobi and conj_transpose_jacobi for real value types
  * (core/preconditioner/jacobi_kernels.hpp; reference/preconditioner/
  * jacobi_kernels.cpp:597-627): every block transposed into out_blocks (same storage

@@ -227,3 +227,81 @@ def test_ell_and_sellp_products_complex(gexec, tn, nrhs):
          _dev(gexec, svals), db, nrhs, _dev(gexec, beta), c, nrhs, nrhs)
     torch.cuda.synchronize()
     _close(_host(c), (alpha[0] * want + beta[0] * c0).astype(ct), 60 * tol)
+
+
+@pytest.mark.parametrize("tn", ["c128", "c64"])
+@pytest.mark.parametrize("it", ["i32", "i64"])
+@pytest.mark.parametrize("max_bs,nrhs", [(4, 1), (13, 3), (32, 2)])
+def test_block_jacobi_complex(gexec, tn, it, max_bs, nrhs):
+    """jacobi::find_blocks / generate / simple_apply / apply on complex values
+    (reference/preconditioner/jacobi_kernels.cpp:130-190, 340-411, 413-520): natural blocks of a block
+    diagonal matrix with some coupling outside the blocks, the inverse of every diagonal block (numpy's
+    inv) applied to b, and x = alpha M b + beta x.  Pivoting is by magnitude, so a block whose leading
+    entry is zero is part of the case."""
+    import scipy.sparse as sp
+    import torch
+    from ginkgo_amd._lib import call
+    from ginkgo_amd.preconditioner import compute_storage_scheme
+    ct, rt, tol = CT[tn]
+    idt = np.int32 if it == "i32" else np.int64
+    rng = np.random.default_rng(7 * max_bs + nrhs)
+    sizes = rng.integers(1, max_bs + 1, 41)
+    sizes[0] = max_bs
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(ptr[-1])
+    dense_blocks = []
+    for k, sz in enumerate(sizes):
+        blk = _rand(rng, (sz, sz), ct) + (2.0 * sz) * np.eye(sz, dtype=ct)
+        if k == 3 and sz > 1:
+            blk[0, 0] = 0          # forces a row exchange
+        dense_blocks.append(blk)
+    a = sp.block_diag(dense_blocks, format="lil", dtype=ct)
+    for _ in range(30):            # entries outside the blocks are not the preconditioner's business
+        i, j = rng.integers(0, n, 2)
+        if np.searchsorted(ptr, i, side="right") != np.searchsorted(ptr, j, side="right"):
+            a[i, j] = ct(0.25 - 0.5j)
+    a = sp.csr_matrix(a)
+    a.sort_indices()
+    drp, dci, dv = _dev(gexec, a.indptr.astype(idt)), _dev(gexec, a.indices.astype(idt)), _dev(gexec, a.data)
+    dptr = _dev(gexec, ptr.astype(idt))
+    scheme = compute_storage_scheme(max_bs)
+    gs = 1 << scheme.group_power
+    nb = len(sizes)
+    blocks = gexec.zeros((((nb + gs - 1) // gs) * scheme.group_offset,), torch.from_numpy(np.zeros(1, ct)).dtype)
+    suf = f"{tn}_{it}"
+    call("gkoc_jacobi_generate_" + suf, gexec.stream, n, drp, dci, dv, nb, C.c_uint32(max_bs), scheme, dptr,
+         blocks, None)
+    b = _rand(rng, (n, nrhs), ct)
+    x0 = _rand(rng, (n, nrhs), ct)
+    db, dx = _dev(gexec, b), _dev(gexec, x0)
+    call("gkoc_jacobi_simple_apply_" + suf, gexec.stream, nb, C.c_uint32(max_bs), scheme, dptr, blocks, db, nrhs,
+         dx, nrhs, nrhs)
+    torch.cuda.synchronize()
+    want = np.concatenate([np.linalg.solve(blk.astype(np.complex128), b[ptr[k]:ptr[k + 1]].astype(np.complex128))
+                           for k, blk in enumerate(dense_blocks)])
+    # conditioning of these blocks: < 10, so the inverse applied in working precision stays within
+    # a few tens of ulps
+    _close(_host(dx), want.astype(ct), 40 * tol)
+    alpha, beta = _rand(rng, (1,), ct), _rand(rng, (1,), ct)
+    dx2 = _dev(gexec, x0)
+    call("gkoc_jacobi_apply_" + suf, gexec.stream, nb, C.c_uint32(max_bs), scheme, dptr, blocks,
+         _dev(gexec, alpha), db, nrhs, _dev(gexec, beta), dx2, nrhs, nrhs)
+    torch.cuda.synchronize()
+    _close(_host(dx2), (alpha[0] * want + beta[0] * x0.astype(np.complex128)).astype(ct), 40 * tol)
+    # natural blocks of the block diagonal part alone: agglomerated up to max_bs like the real kernels
+    # (same find_blocks_impl; the values play no role) - block pointers ascend, end at n, respect max_bs
+    only = sp.csr_matrix(sp.block_diag(dense_blocks, dtype=ct))
+    only.sort_indices()
+    found = gexec.alloc((n + 1,), torch.int32 if it == "i32" else torch.int64)
+    cnt = C.c_int64(0)
+    call("gkoc_jacobi_find_blocks_" + suf, gexec.stream, n, _dev(gexec, only.indptr.astype(idt)),
+         _dev(gexec, only.indices.astype(idt)), C.c_uint32(max_bs), C.byref(cnt), found)
+    torch.cuda.synchronize()
+    fp = _host(found)[:cnt.value + 1]
+    assert fp[0] == 0 and fp[-1] == n and (np.diff(fp) > 0).all() and (np.diff(fp) <= max_bs).all()
+    assert np.isin(fp, ptr).all()      # never through the middle of a dense block
+    # max_block_size above 32 is refused, loudly
+    from ginkgo_amd._lib import NotSupported
+    with pytest.raises(NotSupported):
+        call("gkoc_jacobi_generate_" + suf, gexec.stream, n, drp, dci, dv, nb, C.c_uint32(33), scheme, dptr,
+             blocks, None)
