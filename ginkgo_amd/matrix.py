@@ -171,6 +171,16 @@ class Dense(LinOp):
         """dense.hpp row_gather: gathered(i, :) = self(row_idxs[i], :)."""
         if gathered.size != (row_idxs.numel(), self.size[1]):
             raise DimensionMismatch("row_gather: bad target size")
+        if gathered.dtype != self.dtype:
+            # dense::row_gather<ValueType, OutputType, IndexType> between two precisions
+            # (core/matrix/dense_kernels.hpp:284-288)
+            code = _SparseBase._CODE
+            if self.dtype not in code or gathered.dtype not in code:
+                raise _lib.NotSupported("row_gather: unsupported value types")
+            call("gkoc_dense_row_gather_mixed_" + IT[row_idxs.dtype], self.exec.stream, C.c_int(code[self.dtype]),
+                 C.c_int(code[gathered.dtype]), row_idxs.numel(), self.size[1], None, row_idxs, self.values,
+                 self.ld, None, gathered.values, gathered.ld)
+            return gathered
         call(f"gkoc_dense_row_gather_{self._suf()}_{IT[row_idxs.dtype]}",
              self.exec.stream, row_idxs.numel(), self.size[1], row_idxs,
              self.values, self.ld, gathered.values, gathered.ld)
@@ -185,9 +195,36 @@ def scalar(exec_, value, dtype=torch.float64):
 class _SparseBase(LinOp):
     def _operands(self, b, x):
         if b.dtype != self.dtype or x.dtype != self.dtype:
-            raise _lib.NotSupported("mixed-precision apply: only float32 Csr / Ell values with float64 "
-                                    "vectors (arithmetic in float64)")
+            raise _lib.NotSupported("mixed-precision apply: Csr and Ell only (as in the reference: "
+                                    "core/matrix/{csr,ell}_kernels.hpp declare the triples)")
         return b.values, b.ld, x.values, x.ld, b.size[1]
+
+    _CODE = {torch.float64: 0, torch.float32: 1, torch.complex128: 2, torch.complex64: 3}   # GKOC_VT_*
+
+    def _non_uniform(self, b, x):
+        return b.dtype != self.dtype or x.dtype != self.dtype
+
+    def _apply_triple(self, fmt, alpha, b, beta, x):
+        """csr / ell spmv for a non-uniform (matrix, input, output) value-type triple, as a core
+        built with GINKGO_MIXED_PRECISION dispatches it (precision_dispatch.hpp:
+        mixed_precision_dispatch_real_complex): alpha is taken in the matrix' type, beta in the
+        output's (make_temporary_conversion), arithmetic in the widest type of the three"""
+        codes = [self._CODE.get(t) for t in (self.dtype, b.dtype, x.dtype)]
+        if None in codes or len({c >> 1 for c in codes}) != 1:
+            raise _lib.NotSupported("mixed-precision apply: float32 / float64 or complex64 / complex128 triples")
+        av = bv = None
+        if alpha is not None:
+            av = alpha.values if alpha.dtype == self.dtype else alpha.values.to(self.dtype)
+            bv = beta.values if beta.dtype == x.dtype else beta.values.to(x.dtype)
+        it = IT[self.col_idxs.dtype]
+        codes = [C.c_int(c) for c in codes]
+        if fmt == "csr":
+            call("gkoc_csr_spmv_mixed_" + it, self.exec.stream, *codes, self.size[0], self.size[1], av,
+                 self.row_ptrs, self.col_idxs, self.values, b.values, b.ld, bv, x.values, x.ld, b.size[1])
+        else:
+            call("gkoc_ell_spmv_mixed_" + it, self.exec.stream, *codes, self.size[0], self.size[1],
+                 self.num_stored_per_row, self.stride, av, self.col_idxs, self.values, b.values, b.ld, bv,
+                 x.values, x.ld, b.size[1])
 
     def _mixed(self, b, x, *scalars):
         """float32 values applied to float64 vectors (csr::spmv<float, double, double>, arithmetic
@@ -254,6 +291,8 @@ class Csr(_SparseBase):
                  self.size[1], self.row_ptrs, self.col_idxs, self.values, b.values, b.ld, x.values,
                  x.ld, b.size[1])
             return
+        if self._non_uniform(b, x):
+            return self._apply_triple("csr", None, b, None, x)
         bv, ldb, xv, ldx, nrhs = self._operands(b, x)
         call("gkoc_csr_spmv_" + self._suf(), self.exec.stream, self.size[0],
              self.size[1], self.row_ptrs, self.col_idxs, self.values, bv, ldb,
@@ -265,6 +304,8 @@ class Csr(_SparseBase):
                  self.size[0], self.size[1], alpha.values, self.row_ptrs, self.col_idxs, self.values,
                  b.values, b.ld, beta.values, x.values, x.ld, b.size[1])
             return
+        if self._non_uniform(b, x):
+            return self._apply_triple("csr", alpha, b, beta, x)
         bv, ldb, xv, ldx, nrhs = self._operands(b, x)
         call("gkoc_csr_advanced_spmv_" + self._suf(), self.exec.stream,
              self.size[0], self.size[1], alpha.values, self.row_ptrs,
@@ -609,6 +650,8 @@ class Ell(_SparseBase):
                  self.size[1], self.num_stored_per_row, self.stride, self.col_idxs, self.values,
                  b.values, b.ld, x.values, x.ld, b.size[1])
             return
+        if self._non_uniform(b, x):
+            return self._apply_triple("ell", None, b, None, x)
         bv, ldb, xv, ldx, nrhs = self._operands(b, x)
         call("gkoc_ell_spmv_" + self._suf(), self.exec.stream, self.size[0],
              self.size[1], self.num_stored_per_row, self.stride, self.col_idxs,
@@ -620,6 +663,8 @@ class Ell(_SparseBase):
                  self.size[0], self.size[1], self.num_stored_per_row, self.stride, alpha.values,
                  self.col_idxs, self.values, b.values, b.ld, beta.values, x.values, x.ld, b.size[1])
             return
+        if self._non_uniform(b, x):
+            return self._apply_triple("ell", alpha, b, beta, x)
         bv, ldb, xv, ldx, nrhs = self._operands(b, x)
         call("gkoc_ell_advanced_spmv_" + self._suf(), self.exec.stream,
              self.size[0], self.size[1], self.num_stored_per_row, self.stride,

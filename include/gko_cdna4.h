@@ -1484,6 +1484,43 @@ GKOC_DECL_ASSEMBLY(gkoc_c64, c64, int64_t, i64)
 GKOC_DECL_MIXED(int32_t, i32)
 GKOC_DECL_MIXED(int64_t, i64)
 
+/* Every (matrix, input, output) value-type triple of a core built with GINKGO_MIXED_PRECISION
+ * (core/base/mixed_precision_types.hpp:15-120; csr_kernels.hpp:34-52, ell_kernels.hpp:24-41):
+ * mt / it / ot are GKOC_VT_* codes, all real or all complex.  alpha points to ONE value of the matrix
+ * type, beta to one of the output type (Dense<MatrixValueType>* alpha, Dense<OutputValueType>* beta);
+ * both NULL: c = A b, both set: c = alpha A b + beta c.  arithmetic_type = the widest of the three;
+ * values are widened on load, the result narrowed on the store (reference/matrix/csr_kernels.cpp:
+ * 45-118, ell_kernels.cpp:27-125).  Uniform triples and (float, double, double) run the tuned
+ * kernels above; the others two plain streaming kernels (csrc/mixed_precision.hip).  Real triples are
+ * bit-identical to the reference, complex ones agree to rounding. */
+#define GKOC_VT_F64 0
+#define GKOC_VT_F32 1
+#define GKOC_VT_C128 2
+#define GKOC_VT_C64 3
+#define GKOC_DECL_SPMV_MIXED(I, IN)                                                                   \
+    int gkoc_csr_spmv_mixed_##IN(gkoc_stream_t s, int mt, int it, int ot, int64_t n_rows,             \
+                                 int64_t n_cols, const void* alpha, const I* row_ptrs,                \
+                                 const I* col_idxs, const void* vals, const void* b, int64_t ldb,     \
+                                 const void* beta, void* c, int64_t ldc, int64_t nrhs);               \
+    int gkoc_ell_spmv_mixed_##IN(gkoc_stream_t s, int mt, int it, int ot, int64_t n_rows,             \
+                                 int64_t n_cols, int64_t num_stored_per_row, int64_t stride,          \
+                                 const void* alpha, const I* col_idxs, const void* vals,              \
+                                 const void* b, int64_t ldb, const void* beta, void* c, int64_t ldc,  \
+                                 int64_t nrhs);
+GKOC_DECL_SPMV_MIXED(int32_t, i32)
+GKOC_DECL_SPMV_MIXED(int64_t, i64)
+/* dense::row_gather / advanced_row_gather<ValueType, OutputType, IndexType> for two DIFFERENT
+ * precisions (core/matrix/dense_kernels.hpp:284-295; reference/matrix/dense_kernels.cpp:915-950):
+ * alpha == beta == NULL: out(i, j) = orig(rows[i], j) converted; else (both point to one ValueType
+ * value) out(i, j) = type(alpha orig(rows[i], j)) + type(beta) type(out(i, j)), type = the wider. */
+#define GKOC_DECL_ROW_GATHER_MIXED(I, IN)                                                             \
+    int gkoc_dense_row_gather_mixed_##IN(gkoc_stream_t s, int vt, int ot, int64_t n_gather,           \
+                                         int64_t cols, const void* alpha, const I* rows,              \
+                                         const void* orig, int64_t ld_orig, const void* beta,         \
+                                         void* out, int64_t ld_out);
+GKOC_DECL_ROW_GATHER_MIXED(int32_t, i32)
+GKOC_DECL_ROW_GATHER_MIXED(int64_t, i64)
+
 /* ------------------------------------------- conversions and matrix utilities
  * Everything Ginkgo's matrix classes ask the device for when a matrix moves between formats, and the
  * diagonal / transpose / 1-norm helpers (csrc/conversions.hip; reference/matrix/{dense,csr,coo,ell,

@@ -55,6 +55,175 @@
 #undef I
 #undef SUF
 
+/* ---- (matrix, input, output, index) triples of a GINKGO_MIXED_PRECISION core ---- */
+#define MT double
+#define IT double
+#define OT float
+#define AT double
+#define I int32_t
+#define SUF f64_f64_f32_i32
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT double
+#define IT double
+#define OT float
+#define AT double
+#define I int64_t
+#define SUF f64_f64_f32_i64
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT double
+#define IT float
+#define OT double
+#define AT double
+#define I int32_t
+#define SUF f64_f32_f64_i32
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT double
+#define IT float
+#define OT double
+#define AT double
+#define I int64_t
+#define SUF f64_f32_f64_i64
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT double
+#define IT float
+#define OT float
+#define AT double
+#define I int32_t
+#define SUF f64_f32_f32_i32
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT double
+#define IT float
+#define OT float
+#define AT double
+#define I int64_t
+#define SUF f64_f32_f32_i64
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT float
+#define IT double
+#define OT double
+#define AT double
+#define I int32_t
+#define SUF f32_f64_f64_i32
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT float
+#define IT double
+#define OT double
+#define AT double
+#define I int64_t
+#define SUF f32_f64_f64_i64
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT float
+#define IT double
+#define OT float
+#define AT double
+#define I int32_t
+#define SUF f32_f64_f32_i32
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT float
+#define IT double
+#define OT float
+#define AT double
+#define I int64_t
+#define SUF f32_f64_f32_i64
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT float
+#define IT float
+#define OT double
+#define AT double
+#define I int32_t
+#define SUF f32_f32_f64_i32
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
+#define MT float
+#define IT float
+#define OT double
+#define AT double
+#define I int64_t
+#define SUF f32_f32_f64_i64
+#include "gko_oracle_mixed.inc"
+#undef MT
+#undef IT
+#undef OT
+#undef AT
+#undef I
+#undef SUF
+
 #define T double
 #define SUF f64
 #include "gko_oracle_val.inc"

@@ -168,6 +168,51 @@ def ell_spmv(n_rows, k, stride, cols, vals, b, alpha=None, beta=None, c=None):
     return out if np.asarray(b).ndim == 2 else out[:, 0]
 
 
+def _mixed_suf(vals, b, out_dtype, cols):
+    out_dtype = np.dtype(out_dtype)
+    if vals.dtype == b.dtype == out_dtype:
+        raise ValueError("uniform triple: use csr_spmv / ell_spmv")
+    return "_".join((_VT[vals.dtype], _VT[b.dtype], _VT[out_dtype], _IT[cols.dtype]))
+
+
+def csr_spmv_mixed(row_ptrs, cols, vals, b, out_dtype, alpha=None, beta=None, c=None):
+    """csr::spmv<MatrixValueType, InputValueType, OutputValueType> of a GINKGO_MIXED_PRECISION
+    core: vals / b / the result each float32 or float64, not all the same; alpha is rounded to
+    the matrix' type, beta to the output's (they are Dense<MatrixValueType> / Dense<OutputValueType>)"""
+    b2 = np.ascontiguousarray(_as2d(b))
+    n = len(row_ptrs) - 1
+    nrhs = b2.shape[1]
+    suf = _mixed_suf(vals, b2, out_dtype, cols)
+    if alpha is None:
+        out = np.empty((n, nrhs), dtype=out_dtype)
+        getattr(lib(), "oracle_csr_spmv_mixed_" + suf)(
+            _i64(n), _p(row_ptrs), _p(cols), _p(vals), _p(b2), _i64(nrhs), _p(out), _i64(nrhs), _i64(nrhs))
+    else:
+        out = np.array(_as2d(c), dtype=out_dtype, order="C", copy=True)
+        getattr(lib(), "oracle_csr_advanced_spmv_mixed_" + suf)(
+            _i64(n), _val(vals.dtype, alpha), _p(row_ptrs), _p(cols), _p(vals), _p(b2), _i64(nrhs),
+            _val(out_dtype, beta), _p(out), _i64(nrhs), _i64(nrhs))
+    return out if np.asarray(b).ndim == 2 else out[:, 0]
+
+
+def ell_spmv_mixed(n_rows, k, stride, cols, vals, b, out_dtype, alpha=None, beta=None, c=None):
+    """ell::spmv / advanced_spmv for a non-uniform (matrix, input, output) triple"""
+    b2 = np.ascontiguousarray(_as2d(b))
+    nrhs = b2.shape[1]
+    suf = _mixed_suf(vals, b2, out_dtype, cols)
+    if alpha is None:
+        out = np.empty((n_rows, nrhs), dtype=out_dtype)
+        getattr(lib(), "oracle_ell_spmv_mixed_" + suf)(
+            _i64(n_rows), _i64(k), _i64(stride), _p(cols), _p(vals), _p(b2), _i64(nrhs), _p(out),
+            _i64(nrhs), _i64(nrhs))
+    else:
+        out = np.array(_as2d(c), dtype=out_dtype, order="C", copy=True)
+        getattr(lib(), "oracle_ell_advanced_spmv_mixed_" + suf)(
+            _i64(n_rows), _i64(k), _i64(stride), _val(vals.dtype, alpha), _p(cols), _p(vals), _p(b2),
+            _i64(nrhs), _val(out_dtype, beta), _p(out), _i64(nrhs), _i64(nrhs))
+    return out if np.asarray(b).ndim == 2 else out[:, 0]
+
+
 def sellp_spmv(n_rows, slice_size, slice_sets, slice_lengths, cols, vals, b,
                alpha=None, beta=None, c=None):
     b2 = np.ascontiguousarray(_as2d(b))

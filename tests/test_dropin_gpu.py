@@ -65,3 +65,17 @@ def test_ginkgo_api_benchmark_program_runs():
     for key in ("gko::matrix::Csr::apply", "gko::matrix::Ell::apply", "gko::matrix::Sellp::apply",
                 "gko::solver::Cg + Jacobi(8)  20 iterations"):
         assert key in p.stdout, p.stdout
+
+
+def test_mixed_precision_core_flavor():
+    """tests/dropin/mixed_test.cpp on the core built with GINKGO_MIXED_PRECISION
+    (oracle/build_ref_mixed.py): every (matrix, input, output) value-type triple of csr / ell
+    spmv + advanced_spmv (8 real + 8 complex, int32 / int64, 1 and 3 columns) and the mixed
+    dense::row_gather pairs, hip against ReferenceExecutor in one process - real triples bit for bit"""
+    exe = _need("mixed_test")
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=600, cwd=DROP)
+    print(p.stdout[-4000:])
+    assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
+    assert "MIXED OK" in p.stdout and "FAILED" not in p.stdout
+    n = int(re.search(r"(\d+) checks, 0 failed", p.stdout).group(1))
+    assert n >= 2 * 2 * 2 * 8 * 2 * 3 + 8      # flavors x index types x columns x triples x formats x cases

@@ -126,13 +126,18 @@ def test_mixed_precision_f32_values_f64_vectors(gexec, oracle, idx):
     y = g.Dense.create(gexec, (700, 1))
     a.apply(g.Dense.from_numpy(gexec, b), y)
     assert np.array_equal(y.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v32.astype(np.float64), b))
-    # the other mixed combinations are refused, not silently converted
-    with pytest.raises(g.NotSupported):
-        a.apply(g.Dense.from_numpy(gexec, b.astype(np.float32)), y)
+    # the other (matrix, input, output) triples run as well (csrc/mixed_precision.hip,
+    # tests/test_mixed_gpu.py) - with the reference's roundings, not a silent conversion of the vectors
+    y32 = g.Dense.create(gexec, (700, 1), torch.float32)
+    a.apply(g.Dense.from_numpy(gexec, b.astype(np.float32)), y32)
+    assert np.array_equal(y32.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v32, b.astype(np.float32)))
     a64 = dev_csr(g, gexec, rp, ci, v, (700, 700))
+    a64.apply(g.Dense.from_numpy(gexec, b.astype(np.float32)), y32)
+    assert np.array_equal(y32.to_numpy()[:, 0],
+                          oracle.csr_spmv_mixed(rp, ci, v, b.astype(np.float32), np.float32))
+    # SELL-P has no mixed instantiations in the reference either (core/matrix/sellp_kernels.hpp)
     with pytest.raises(g.NotSupported):
-        a64.apply(g.Dense.from_numpy(gexec, b.astype(np.float32)),
-                  g.Dense.create(gexec, (700, 1), torch.float32))
+        a64.convert_to_sellp().apply(g.Dense.from_numpy(gexec, b.astype(np.float32)), y32)
 
 
 def test_csr_edge_shapes(gexec, oracle):
