@@ -254,6 +254,18 @@ __global__ __launch_bounds__(256) void csr_fill_in_dense_kernel(int64_t n_rows,
     }
 }
 
+template <typename T>
+__device__ __forceinline__ void atomic_add_value(T* p, T v)
+{
+    atomicAdd(p, v);
+}
+template <typename R>
+__device__ __forceinline__ void atomic_add_value(gkoc_cplx<R>* p, gkoc_cplx<R> v)
+{
+    atomicAdd(&p->re, v.re);
+    atomicAdd(&p->im, v.im);
+}
+
 // coo (reference/matrix/coo_kernels.cpp:104-114): +=, so duplicates add up
 template <typename T, typename I>
 __global__ __launch_bounds__(256) void coo_fill_in_dense_kernel(int64_t nnz, const I* __restrict__ rows,
@@ -261,7 +273,7 @@ __global__ __launch_bounds__(256) void coo_fill_in_dense_kernel(int64_t nnz, con
                                                                 const T* __restrict__ vals,
                                                                 T* __restrict__ out, int64_t ld)
 {
-    GKOC_FOR_EACH(k, nnz) atomicAdd(&out[int64_t(rows[k]) * ld + cols[k]], vals[k]);
+    GKOC_FOR_EACH(k, nnz) atomic_add_value(&out[int64_t(rows[k]) * ld + cols[k]], vals[k]);
 }
 
 template <typename T, typename I>
@@ -650,6 +662,56 @@ __global__ __launch_bounds__(256) void csr_span_kernel(int64_t n, int64_t row0, 
 }
 
 
+// csr::calculate_nonzeros_per_row_in_index_set / compute_submatrix_from_index_set
+// (reference/matrix/csr_kernels.cpp:772-812, 853-904): result row t is the t-th row of the row index
+// set (subset j holds the rows [row_begin[j], row_end[j]), its first result row is row_superset[j]); an
+// entry is kept when its column lies in a subset of the column index set and gets the column
+// col_superset[subset] + (column - col_begin[subset]).  One lane per result row, two binary searches.
+template <typename I>
+__device__ __forceinline__ int64_t last_not_above(const I* __restrict__ a, int64_t n, int64_t v)
+{
+    // std::upper_bound(a, a + n, v) - 1, clamped at 0 (the reference's shifted_bucket)
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (int64_t(a[mid]) <= v) {
+            lo = mid + 1;
+        } else {
+            hi = mid;
+        }
+    }
+    return lo == 0 ? 0 : lo - 1;
+}
+
+template <typename T, typename I, bool FILL>
+__global__ __launch_bounds__(256) void csr_index_set_kernel(
+    int64_t n_result_rows, int64_t n_row_subsets, const I* __restrict__ row_begin,
+    const I* __restrict__ row_superset, int64_t n_col_subsets, const I* __restrict__ col_begin,
+    const I* __restrict__ col_end, const I* __restrict__ col_superset, int64_t col_set_size,
+    const I* __restrict__ in_rp, const I* __restrict__ in_ci, const T* __restrict__ in_v, I* __restrict__ counts,
+    const I* __restrict__ out_rp, I* __restrict__ out_ci, T* __restrict__ out_v)
+{
+    GKOC_FOR_EACH(t, n_result_rows)
+    {
+        const int64_t set = last_not_above(row_superset, n_row_subsets, t);
+        const int64_t row = int64_t(row_begin[set]) + (t - int64_t(row_superset[set]));
+        int64_t at = FILL ? int64_t(out_rp[t]) : 0;
+        for (int64_t k = in_rp[row]; k < in_rp[row + 1]; ++k) {
+            const int64_t c = in_ci[k];
+            if (c >= col_set_size) continue;
+            const int64_t b = last_not_above(col_begin, n_col_subsets, c);
+            if (int64_t(col_end[b]) <= c || c < int64_t(col_begin[b])) continue;
+            if (FILL) {
+                out_ci[at] = I(c - int64_t(col_begin[b]) + int64_t(col_superset[b]));
+                out_v[at] = in_v[k];
+            }
+            ++at;
+        }
+        if (!FILL) counts[t] = I(at);
+    }
+}
+
+
 // ------------------------------------------------------- SpGEMM / SpGEAM as triplets
 // C = alpha A B + beta D (csr::spgemm / advanced_spgemm, reference/matrix/csr_kernels.cpp:156-300)
 // and C = alpha A + beta B (csr::spgeam, :425-468) accumulate a row's contributions in a map by
@@ -734,11 +796,11 @@ __global__ __launch_bounds__(256) void jacobi_scalar_l1_kernel(int64_t n_rows, c
 {
     GKOC_FOR_EACH(r, n_rows)
     {
-        T off = T(0);
+        real_t<T> off = 0;
         for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
-            if (int64_t(ci[k]) != r) off += v[k] < T(0) ? -v[k] : v[k];
+            if (int64_t(ci[k]) != r) off += abs_v(v[k]);
         }
-        diag[r] += off;
+        diag[r] += T(off);
     }
 }
 
@@ -752,7 +814,7 @@ __global__ __launch_bounds__(256) void jacobi_block_l1_kernel(int64_t num_blocks
     {
         const int64_t start = block_ptrs[b], end = block_ptrs[b + 1];
         for (int64_t r = start; r < end; ++r) {
-            T off = T(0);
+            real_t<T> off = 0;
             int64_t diag_at = -1;
             for (int64_t k = rp[r]; k < rp[r + 1]; ++k) {
                 const int64_t c = ci[k];
@@ -760,9 +822,9 @@ __global__ __launch_bounds__(256) void jacobi_block_l1_kernel(int64_t num_blocks
                     if (c == r) diag_at = k;
                     continue;
                 }
-                off += v[k] < T(0) ? -v[k] : v[k];
+                off += abs_v(v[k]);
             }
-            if (diag_at >= 0) v[diag_at] += off;
+            if (diag_at >= 0) v[diag_at] += T(off);
         }
     }
 }
@@ -926,6 +988,8 @@ GKOC_DEF_FILL_SEQ(uint64_t, u64)
     }
 GKOC_DEF_CV_DENSE(double, f64)
 GKOC_DEF_CV_DENSE(float, f32)
+GKOC_DEF_CV_DENSE(gkoc_c128, c128)
+GKOC_DEF_CV_DENSE(gkoc_c64, c64)
 
 #define GKOC_DEF_CV(T, TN, I, IN)                                                                       \
     extern "C" int gkoc_dense_to_csr_##TN##_##IN(gkoc_stream_t s, int64_t rows, int64_t cols,           \
@@ -1064,6 +1128,10 @@ GKOC_DEF_CV(double, f64, int32_t, i32)
 GKOC_DEF_CV(double, f64, int64_t, i64)
 GKOC_DEF_CV(float, f32, int32_t, i32)
 GKOC_DEF_CV(float, f32, int64_t, i64)
+GKOC_DEF_CV(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_CV(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_CV(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_CV(gkoc_c64, c64, int64_t, i64)
 
 #define GKOC_DEF_CV_INDEX(I, IN)                                                                        \
     extern "C" int gkoc_ell_count_nonzeros_per_row_##IN(gkoc_stream_t s, int64_t n_rows,                \
@@ -1182,10 +1250,57 @@ GKOC_DEF_CV_INDEX(int64_t, i64)
                   static_cast<I*>(nullptr), out_rp, out_ci, out_v);                                     \
         return GKOC_OK;                                                                                 \
     }
+#define GKOC_DEF_INDEX_SET(T, TN, I, IN)                                                                \
+    extern "C" int gkoc_csr_count_in_index_set_##TN##_##IN(                                             \
+        gkoc_stream_t s, int64_t n_result_rows, int64_t n_row_subsets, const I* row_begin,              \
+        const I* row_superset, int64_t n_col_subsets, const I* col_begin, const I* col_end,             \
+        int64_t col_set_size, const I* in_rp, const I* in_ci, I* counts)                                \
+    {                                                                                                   \
+        GKOC_REQUIRE(n_result_rows >= 0 && n_row_subsets >= 0 && n_col_subsets >= 0, GKOC_E_INVALID,    \
+                     "negative size");                                                                  \
+        GKOC_REQUIRE(n_result_rows == 0 || (n_row_subsets > 0 && n_col_subsets > 0 && row_begin &&      \
+                                            row_superset && col_begin && col_end && in_rp && counts),   \
+                     GKOC_E_INVALID, "empty index set or null pointer");                                \
+        CV_LAUNCH((csr_index_set_kernel<T, I, false>), n_result_rows, n_result_rows, n_row_subsets,     \
+                  row_begin, row_superset, n_col_subsets, col_begin, col_end,                           \
+                  static_cast<const I*>(nullptr), col_set_size, in_rp, in_ci,                           \
+                  static_cast<const T*>(nullptr), counts, static_cast<const I*>(nullptr),               \
+                  static_cast<I*>(nullptr), static_cast<T*>(nullptr));                                  \
+        return GKOC_OK;                                                                                 \
+    }                                                                                                   \
+    extern "C" int gkoc_csr_submatrix_from_index_set_##TN##_##IN(                                       \
+        gkoc_stream_t s, int64_t n_result_rows, int64_t n_row_subsets, const I* row_begin,              \
+        const I* row_superset, int64_t n_col_subsets, const I* col_begin, const I* col_end,             \
+        const I* col_superset, int64_t col_set_size, const I* in_rp, const I* in_ci, const T* in_v,     \
+        const I* out_rp, I* out_ci, T* out_v)                                                           \
+    {                                                                                                   \
+        GKOC_REQUIRE(n_result_rows >= 0 && n_row_subsets >= 0 && n_col_subsets >= 0, GKOC_E_INVALID,    \
+                     "negative size");                                                                  \
+        GKOC_REQUIRE(n_result_rows == 0 || (n_row_subsets > 0 && n_col_subsets > 0 && row_begin &&      \
+                                            row_superset && col_begin && col_end && col_superset &&     \
+                                            in_rp && out_rp),                                           \
+                     GKOC_E_INVALID, "empty index set or null pointer");                                \
+        CV_LAUNCH((csr_index_set_kernel<T, I, true>), n_result_rows, n_result_rows, n_row_subsets,      \
+                  row_begin, row_superset, n_col_subsets, col_begin, col_end, col_superset,             \
+                  col_set_size, in_rp, in_ci, in_v, static_cast<I*>(nullptr), out_rp, out_ci, out_v);   \
+        return GKOC_OK;                                                                                 \
+    }
+GKOC_DEF_INDEX_SET(double, f64, int32_t, i32)
+GKOC_DEF_INDEX_SET(double, f64, int64_t, i64)
+GKOC_DEF_INDEX_SET(float, f32, int32_t, i32)
+GKOC_DEF_INDEX_SET(float, f32, int64_t, i64)
+GKOC_DEF_INDEX_SET(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_INDEX_SET(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_INDEX_SET(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_INDEX_SET(gkoc_c64, c64, int64_t, i64)
 GKOC_DEF_PERMUTE(double, f64, int32_t, i32)
 GKOC_DEF_PERMUTE(double, f64, int64_t, i64)
 GKOC_DEF_PERMUTE(float, f32, int32_t, i32)
 GKOC_DEF_PERMUTE(float, f32, int64_t, i64)
+GKOC_DEF_PERMUTE(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_PERMUTE(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_PERMUTE(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_PERMUTE(gkoc_c64, c64, int64_t, i64)
 
 #define GKOC_DEF_PERMUTATION(I, IN)                                                                     \
     extern "C" int gkoc_permutation_invert_##IN(gkoc_stream_t s, int64_t n, const I* perm, I* out)      \
@@ -1238,6 +1353,10 @@ GKOC_DEF_SPGEMM(double, f64, int32_t, i32)
 GKOC_DEF_SPGEMM(double, f64, int64_t, i64)
 GKOC_DEF_SPGEMM(float, f32, int32_t, i32)
 GKOC_DEF_SPGEMM(float, f32, int64_t, i64)
+GKOC_DEF_SPGEMM(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_SPGEMM(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_SPGEMM(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_SPGEMM(gkoc_c64, c64, int64_t, i64)
 
 #define GKOC_DEF_L1(T, TN, I, IN)                                                                       \
     extern "C" int gkoc_jacobi_scalar_l1_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* rp,      \
@@ -1267,6 +1386,10 @@ GKOC_DEF_L1(double, f64, int32_t, i32)
 GKOC_DEF_L1(double, f64, int64_t, i64)
 GKOC_DEF_L1(float, f32, int32_t, i32)
 GKOC_DEF_L1(float, f32, int64_t, i64)
+GKOC_DEF_L1(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_L1(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_L1(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_L1(gkoc_c64, c64, int64_t, i64)
 
 // shift (n_rows + 1): exclusive sums of "row r lacks its diagonal entry"; *missing_host = their number
 #define GKOC_DEF_MISSING(I, IN)                                                                         \

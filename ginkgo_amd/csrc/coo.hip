@@ -547,7 +547,9 @@ GKOC_DEF_P2I(int64_t, i64)
     {                                                                                       \
         return launch_coo<T, I>(s, 3, n_rows, n_cols, nnz, alpha, row_idxs, col_idxs, vals, \
                                 b, ldb, nullptr, c, ldc, nrhs, work, work_bytes);           \
-    }                                                                                       \
+    }
+// (ell::copy and csr::convert_to_hybrid: for the complex types as well)
+#define GKOC_DEF_COO_CONVERT(T, TN, I, IN)                                                  \
     extern "C" int gkoc_ell_copy_##TN##_##IN(                                               \
         gkoc_stream_t s, int64_t n_rows, int64_t k, int64_t src_stride, const I* src_cols,  \
         const T* src_vals, int64_t dst_stride, I* dst_cols, T* dst_vals)                    \
@@ -586,3 +588,11 @@ GKOC_DEF_COO(double, f64, int32_t, i32)
 GKOC_DEF_COO(double, f64, int64_t, i64)
 GKOC_DEF_COO(float, f32, int32_t, i32)
 GKOC_DEF_COO(float, f32, int64_t, i64)
+GKOC_DEF_COO_CONVERT(double, f64, int32_t, i32)
+GKOC_DEF_COO_CONVERT(double, f64, int64_t, i64)
+GKOC_DEF_COO_CONVERT(float, f32, int32_t, i32)
+GKOC_DEF_COO_CONVERT(float, f32, int64_t, i64)
+GKOC_DEF_COO_CONVERT(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_COO_CONVERT(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_COO_CONVERT(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_COO_CONVERT(gkoc_c64, c64, int64_t, i64)

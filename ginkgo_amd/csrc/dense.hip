@@ -610,3 +610,15 @@ extern "C" int gkoc_fill_array_f32(gkoc_stream_t s, float* data, int64_t n,
 {
     return gkoc_dense_fill_f32(s, n, 1, data, 1, value);
 }
+
+// dense::compute_sqrt for complex values (principal root, complex_type.hpp)
+#define GKOC_DEF_CSQRT(T, TN)                                                  \
+    extern "C" int gkoc_dense_compute_sqrt_##TN(gkoc_stream_t s, int64_t cols, T* x) \
+    {                                                                          \
+        if (cols <= 0) return GKOC_OK;                                         \
+        gkoc::sqrt_kernel<T><<<dim3(unsigned(gkoc::ceildiv(cols, 256))), dim3(256), 0, gkoc::as_stream(s)>>>(cols, x); \
+        GKOC_LAUNCH_OK();                                                      \
+        return GKOC_OK;                                                        \
+    }
+GKOC_DEF_CSQRT(gkoc_c128, c128)
+GKOC_DEF_CSQRT(gkoc_c64, c64)

@@ -112,6 +112,8 @@ using namespace gkoc;
     }
 GKOC_DEF_GEMM(double, f64)
 GKOC_DEF_GEMM(float, f32)
+GKOC_DEF_GEMM(gkoc_c128, c128)
+GKOC_DEF_GEMM(gkoc_c64, c64)
 
 extern "C" int gkoc_dense_convert_f64_f32(gkoc_stream_t s, int64_t rows, int64_t cols,
                                           const double* x, int64_t ldx, float* y, int64_t ldy)

@@ -771,7 +771,9 @@ GKOC_DEF_ELL_MIXED(int64_t, i64)
         return launch_sellp<T, I, true>(s, n_rows, n_cols, slice_size, alpha,  \
                                         slice_sets, slice_lengths, cols, vals, \
                                         b, ldb, beta, c, ldc, nrhs);           \
-    }                                                                          \
+    }
+// (the conversions: also for the complex types - the complex products are in complex_formats.hip)
+#define GKOC_DEF_FMT_CONVERT(T, TN, I, IN)                                     \
     extern "C" int gkoc_csr_convert_to_ell_##TN##_##IN(                        \
         gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* cols,     \
         const T* vals, int64_t k, int64_t stride, I* ell_cols, T* ell_vals)    \
@@ -864,6 +866,14 @@ GKOC_DEF_FMT(double, f64, int32_t, i32)
 GKOC_DEF_FMT(double, f64, int64_t, i64)
 GKOC_DEF_FMT(float, f32, int32_t, i32)
 GKOC_DEF_FMT(float, f32, int64_t, i64)
+GKOC_DEF_FMT_CONVERT(double, f64, int32_t, i32)
+GKOC_DEF_FMT_CONVERT(double, f64, int64_t, i64)
+GKOC_DEF_FMT_CONVERT(float, f32, int32_t, i32)
+GKOC_DEF_FMT_CONVERT(float, f32, int64_t, i64)
+GKOC_DEF_FMT_CONVERT(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_FMT_CONVERT(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_FMT_CONVERT(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_FMT_CONVERT(gkoc_c64, c64, int64_t, i64)
 
 #define GKOC_DEF_IDX(I, IN)                                                    \
     extern "C" int gkoc_compute_max_row_nnz_##IN(                              \

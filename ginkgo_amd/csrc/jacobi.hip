@@ -1851,6 +1851,57 @@ GKOC_DEF_JACOBI_TRANSPOSE(double, f64, int64_t, i64)
 GKOC_DEF_JACOBI_TRANSPOSE(float, f32, int32_t, i32)
 GKOC_DEF_JACOBI_TRANSPOSE(float, f32, int64_t, i64)
 
+// ... and for complex values (uniform storage): conj != 0 conjugates the moved entries
+// (conj_transpose_jacobi, reference/preconditioner/jacobi_kernels.cpp:613-627)
+namespace gkoc {
+namespace {
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void cjacobi_transpose_kernel(int64_t num_blocks, gkoc_jacobi_scheme scheme,
+                                                                const I* __restrict__ block_ptrs,
+                                                                const T* __restrict__ blocks, int conj,
+                                                                T* __restrict__ out)
+{
+    const int64_t bo = scheme.block_offset;
+    const int64_t stride = bo << scheme.group_power;
+    const int64_t gmask = (int64_t(1) << scheme.group_power) - 1;
+    const int64_t total = num_blocks * bo;
+    const int64_t step = int64_t(gridDim.x) * 256;
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < total; t += step) {
+        const int64_t blk = t / bo;
+        const int r = int(t - blk * bo);
+        const int bs = int(block_ptrs[blk + 1] - block_ptrs[blk]);
+        if (r >= bs) continue;
+        const int64_t base = scheme.group_offset * (blk >> scheme.group_power) + bo * (blk & gmask);
+        for (int c = 0; c < bs; ++c) {
+            T v = blocks[base + c + int64_t(r) * stride];      // in(c, r)
+            if (conj) v = conj_v(v);
+            out[base + r + int64_t(c) * stride] = v;           // out(r, c)
+        }
+    }
+}
+}  // namespace
+}  // namespace gkoc
+
+#define GKOC_DEF_CJACOBI_TRANSPOSE(T, TN, I, IN)                                                        \
+    extern "C" int gkoc_cjacobi_transpose_##TN##_##IN(gkoc_stream_t s, int64_t num_blocks,              \
+                                                      gkoc_jacobi_scheme scheme, const I* block_ptrs,   \
+                                                      const T* blocks, int conj, T* out_blocks)         \
+    {                                                                                                   \
+        if (num_blocks <= 0) return GKOC_OK;                                                            \
+        GKOC_REQUIRE(block_ptrs && blocks && out_blocks, GKOC_E_INVALID, "null pointer");               \
+        GKOC_REQUIRE(scheme.block_offset >= 1, GKOC_E_INVALID, "bad storage scheme");                   \
+        int64_t nb = ceildiv(num_blocks * scheme.block_offset, 256);                                    \
+        if (nb > 4 * max_stream_blocks) nb = 4 * max_stream_blocks;                                     \
+        cjacobi_transpose_kernel<T, I><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(             \
+            num_blocks, scheme, block_ptrs, blocks, conj, out_blocks);                                  \
+        GKOC_LAUNCH_OK();                                                                               \
+        return GKOC_OK;                                                                                 \
+    }
+GKOC_DEF_CJACOBI_TRANSPOSE(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_CJACOBI_TRANSPOSE(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_CJACOBI_TRANSPOSE(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_CJACOBI_TRANSPOSE(gkoc_c64, c64, int64_t, i64)
+
 // jacobi::initialize_precisions (reference/preconditioner/jacobi_kernels.cpp:454-462)
 extern "C" int gkoc_jacobi_initialize_precisions(gkoc_stream_t s, const uint8_t* source,
                                                  int64_t source_size, uint8_t* precisions,

@@ -196,6 +196,8 @@ using namespace gkoc;
     }
 GKOC_DEF_MISC_T(double, f64)
 GKOC_DEF_MISC_T(float, f32)
+GKOC_DEF_MISC_T(gkoc_c128, c128)
+GKOC_DEF_MISC_T(gkoc_c64, c64)
 extern "C" int gkoc_reduce_add_array_i32(gkoc_stream_t s, int64_t n, const int32_t* arr, int32_t* val)
 {
     return reduce_add<int32_t>(s, n, arr, val);
@@ -264,6 +266,10 @@ GKOC_DEF_MISC_TI(double, f64, int32_t, i32)
 GKOC_DEF_MISC_TI(double, f64, int64_t, i64)
 GKOC_DEF_MISC_TI(float, f32, int32_t, i32)
 GKOC_DEF_MISC_TI(float, f32, int64_t, i64)
+GKOC_DEF_MISC_TI(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_MISC_TI(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_MISC_TI(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_MISC_TI(gkoc_c64, c64, int64_t, i64)
 
 #define GKOC_DEF_MISC_I(I, IN)                                                                              \
     extern "C" int gkoc_sparsity_csr_count_diagonal_##IN(gkoc_stream_t s, int64_t n_rows,                   \
@@ -435,3 +441,7 @@ GKOC_DEF_REUSE(double, f64, int32_t, i32)
 GKOC_DEF_REUSE(double, f64, int64_t, i64)
 GKOC_DEF_REUSE(float, f32, int32_t, i32)
 GKOC_DEF_REUSE(float, f32, int64_t, i64)
+GKOC_DEF_REUSE(gkoc_c128, c128, int32_t, i32)
+GKOC_DEF_REUSE(gkoc_c128, c128, int64_t, i64)
+GKOC_DEF_REUSE(gkoc_c64, c64, int32_t, i32)
+GKOC_DEF_REUSE(gkoc_c64, c64, int64_t, i64)

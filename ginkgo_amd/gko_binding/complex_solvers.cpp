@@ -7,11 +7,17 @@
 // (textbook complex quotient, include/gko_cdna4.h).
 #include <complex>
 
+#include <ginkgo/core/matrix/csr.hpp>
+#include <ginkgo/core/matrix/diagonal.hpp>
+#include <ginkgo/core/base/device_matrix_data.hpp>
 #include <ginkgo/core/matrix/dense.hpp>
 #include <ginkgo/core/matrix/ell.hpp>
 #include <ginkgo/core/matrix/sellp.hpp>
 #include <ginkgo/core/preconditioner/jacobi.hpp>
 
+#include "core/matrix/csr_kernels.hpp"
+#include "core/matrix/diagonal_kernels.hpp"
+#include "core/matrix/dense_kernels.hpp"
 #include "core/matrix/ell_kernels.hpp"
 #include "core/matrix/sellp_kernels.hpp"
 #include "core/preconditioner/jacobi_kernels.hpp"
@@ -306,6 +312,145 @@ void uniform_only(const array<precision_reduction>& prec)
             block_pointers.get_const_data(), px(blocks.get_const_data()),                           \
             px(alpha->get_const_values()), px(b->get_const_values()), ld(b),                        \
             px(beta->get_const_values()), px(x->get_values()), ld(x), cols(x)));                    \
+    }
+FOR_C_I(DEF)
+#undef DEF
+
+}  // namespace jacobi
+
+
+// conversions on the way to and from the complex products: csr -> ell / sellp
+// (csrc/formats.hip: the same staged kernels as for the real types)
+namespace csr {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void convert_to_ell<T, I>(exec_t exec, const matrix::Csr<T, I>* source, matrix::Ell<T, I>* result) \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_convert_to_ell_##TN##_##IN(                                              \
+            stream_of(exec), source->get_size()[0], source->get_const_row_ptrs(),                   \
+            source->get_const_col_idxs(), source->get_const_values(),                               \
+            result->get_num_stored_elements_per_row(), result->get_stride(), result->get_col_idxs(), \
+            result->get_values()));                                                                 \
+    }                                                                                               \
+    template <>                                                                                     \
+    void convert_to_sellp<T, I>(exec_t exec, const matrix::Csr<T, I>* source,                       \
+                                matrix::Sellp<T, I>* result)                                        \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_convert_to_sellp_##TN##_##IN(                                            \
+            stream_of(exec), source->get_size()[0], result->get_slice_size(),                       \
+            source->get_const_row_ptrs(), source->get_const_col_idxs(), source->get_const_values(), \
+            reinterpret_cast<const uint64_t*>(result->get_const_slice_sets()), result->get_col_idxs(), \
+            result->get_values()));                                                                 \
+    }
+FOR_C_I(DEF)
+#undef DEF
+
+}  // namespace csr
+
+
+namespace diagonal {
+
+#define DEF(T, TN)                                                                                  \
+    template <>                                                                                     \
+    void apply_to_dense<T>(exec_t exec, const matrix::Diagonal<T>* a, const matrix::Dense<T>* b,    \
+                           matrix::Dense<T>* c, bool inverse)                                       \
+    {                                                                                               \
+        GKOC_CALL(gkoc_diagonal_apply_to_dense_##TN(stream_of(exec), rows(b), cols(b),              \
+                                                    a->get_const_values(), b->get_const_values(),   \
+                                                    ld(b), c->get_values(), ld(c), inverse));       \
+    }                                                                                               \
+    template <>                                                                                     \
+    void right_apply_to_dense<T>(exec_t exec, const matrix::Diagonal<T>* a,                         \
+                                 const matrix::Dense<T>* b, matrix::Dense<T>* c)                    \
+    {                                                                                               \
+        GKOC_CALL(gkoc_diagonal_right_apply_to_dense_##TN(stream_of(exec), rows(b), cols(b),        \
+                                                          a->get_const_values(),                    \
+                                                          b->get_const_values(), ld(b),             \
+                                                          c->get_values(), ld(c)));                 \
+    }
+FOR_C(DEF)
+#undef DEF
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void fill_in_matrix_data<T, I>(exec_t exec, const device_matrix_data<T, I>& data,               \
+                                   matrix::Diagonal<T>* output)                                     \
+    {                                                                                               \
+        GKOC_CALL(gkoc_diagonal_fill_in_matrix_data_##TN##_##IN(                                    \
+            stream_of(exec), static_cast<int64_t>(data.get_num_stored_elements()),                  \
+            data.get_const_row_idxs(), data.get_const_col_idxs(), data.get_const_values(),          \
+            output->get_values()));                                                                 \
+    }
+FOR_C_I(DEF)
+#undef DEF
+
+}  // namespace diagonal
+
+
+namespace dense {
+
+#define DEF(T, TN)                                                                                  \
+    template <>                                                                                     \
+    void simple_apply<T>(exec_t exec, const matrix::Dense<T>* a, const matrix::Dense<T>* b,         \
+                         matrix::Dense<T>* c)                                                       \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_simple_apply_##TN(stream_of(exec), rows(c), cols(c), cols(a),          \
+                                               a->get_const_values(), ld(a), b->get_const_values(), \
+                                               ld(b), c->get_values(), ld(c)));                     \
+    }                                                                                               \
+    template <>                                                                                     \
+    void apply<T>(exec_t exec, const matrix::Dense<T>* alpha, const matrix::Dense<T>* a,            \
+                  const matrix::Dense<T>* b, const matrix::Dense<T>* beta, matrix::Dense<T>* c)     \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_apply_##TN(stream_of(exec), rows(c), cols(c), cols(a),                 \
+                                        alpha->get_const_values(), a->get_const_values(), ld(a),    \
+                                        b->get_const_values(), ld(b), beta->get_const_values(),     \
+                                        c->get_values(), ld(c)));                                   \
+    }                                                                                               \
+    template <>                                                                                     \
+    void compute_sqrt<T>(exec_t exec, matrix::Dense<T>* data)                                       \
+    {                                                                                               \
+        for (int64_t r = 0; r < rows(data); ++r) {                                                  \
+            GKOC_CALL(gkoc_dense_compute_sqrt_##TN(stream_of(exec), cols(data),                     \
+                                                   data->get_values() + r * ld(data)));             \
+        }                                                                                           \
+    }
+FOR_C(DEF)
+#undef DEF
+
+}  // namespace dense
+
+
+// Jacobi::transpose() / conj_transpose() of complex blocks (needed by Bicg)
+namespace jacobi {
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void transpose_jacobi<T, I>(exec_t exec, size_type num_blocks, uint32,                          \
+                                const array<precision_reduction>& block_precisions,                 \
+                                const array<I>& block_pointers, const array<T>& blocks,             \
+                                const preconditioner::block_interleaved_storage_scheme<I>& scheme,  \
+                                array<T>& out_blocks)                                               \
+    {                                                                                               \
+        uniform_only(block_precisions);                                                             \
+        GKOC_CALL(gkoc_cjacobi_transpose_##TN##_##IN(stream_of(exec), num_blocks, cscheme(scheme),  \
+                                                     block_pointers.get_const_data(),               \
+                                                     blocks.get_const_data(), 0,                    \
+                                                     out_blocks.get_data()));                       \
+    }                                                                                               \
+    template <>                                                                                     \
+    void conj_transpose_jacobi<T, I>(exec_t exec, size_type num_blocks, uint32,                     \
+                                     const array<precision_reduction>& block_precisions,            \
+                                     const array<I>& block_pointers, const array<T>& blocks,        \
+                                     const preconditioner::block_interleaved_storage_scheme<I>& scheme, \
+                                     array<T>& out_blocks)                                          \
+    {                                                                                               \
+        uniform_only(block_precisions);                                                             \
+        GKOC_CALL(gkoc_cjacobi_transpose_##TN##_##IN(stream_of(exec), num_blocks, cscheme(scheme),  \
+                                                     block_pointers.get_const_data(),               \
+                                                     blocks.get_const_data(), 1,                    \
+                                                     out_blocks.get_data()));                       \
     }
 FOR_C_I(DEF)
 #undef DEF

@@ -23,6 +23,10 @@
 #include "core/matrix/permutation_kernels.hpp"
 #include "core/matrix/scaled_permutation_kernels.hpp"
 #include "core/matrix/sellp_kernels.hpp"
+#include <complex>
+
+#include <ginkgo/core/base/index_set.hpp>
+
 #include "shim_common.hpp"
 
 namespace gko {
@@ -39,6 +43,12 @@ using exec_t = std::shared_ptr<const HipExecutor>;
 #define FOR_VT_IT(M)                                                                \
     M(double, f64, int32, i32) M(double, f64, int64, i64) M(float, f32, int32, i32) \
         M(float, f32, int64, i64)
+// ... and with the two complex types (gkoc_c128 / gkoc_c64 are std::complex here: shim_common.hpp)
+#define FOR_AVT(M) FOR_VT(M) M(std::complex<double>, c128) M(std::complex<float>, c64)
+#define FOR_AVT_IT(M)                                                                            \
+    FOR_VT_IT(M)                                                                                 \
+    M(std::complex<double>, c128, int32, i32) M(std::complex<double>, c128, int64, i64)          \
+        M(std::complex<float>, c64, int32, i32) M(std::complex<float>, c64, int64, i64)
 
 inline const uint64_t* u64(const size_type* p) { return reinterpret_cast<const uint64_t*>(p); }
 inline uint64_t* u64(size_type* p) { return reinterpret_cast<uint64_t*>(p); }
@@ -90,16 +100,46 @@ namespace dense {
                                                 result->get_values(), tmp.get_data(), bytes));      \
     }                                                                                               \
     template <>                                                                                     \
-    void transpose<T>(exec_t exec, const matrix::Dense<T>* orig, matrix::Dense<T>* trans)           \
+    void conj_transpose<T>(exec_t exec, const matrix::Dense<T>* orig, matrix::Dense<T>* trans)      \
     {                                                                                               \
         GKOC_CALL(gkoc_dense_transpose_##TN(stream_of(exec), rows(orig), cols(orig),                \
                                             orig->get_const_values(), ld(orig),                     \
                                             trans->get_values(), ld(trans)));                       \
     }                                                                                               \
     template <>                                                                                     \
-    void conj_transpose<T>(exec_t exec, const matrix::Dense<T>* orig, matrix::Dense<T>* trans)      \
+    void count_nonzeros_per_row<T, int32>(exec_t exec, const matrix::Dense<T>* source,              \
+                                          int32* result)                                            \
     {                                                                                               \
-        transpose<T>(exec, orig, trans);                                                            \
+        GKOC_CALL(gkoc_dense_count_nonzeros_per_row_##TN(stream_of(exec), rows(source),             \
+                                                         cols(source), source->get_const_values(),  \
+                                                         ld(source), result, 4));                   \
+    }                                                                                               \
+    template <>                                                                                     \
+    void count_nonzeros_per_row<T, int64>(exec_t exec, const matrix::Dense<T>* source,              \
+                                          int64* result)                                            \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_count_nonzeros_per_row_##TN(stream_of(exec), rows(source),             \
+                                                         cols(source), source->get_const_values(),  \
+                                                         ld(source), result, 8));                   \
+    }                                                                                               \
+    template <>                                                                                     \
+    void count_nonzeros_per_row<T, size_type>(exec_t exec, const matrix::Dense<T>* source,          \
+                                              size_type* result)                                    \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_count_nonzeros_per_row_##TN(stream_of(exec), rows(source),             \
+                                                         cols(source), source->get_const_values(),  \
+                                                         ld(source), result, 8));                   \
+    }
+FOR_VT(DEF)
+#undef DEF
+
+#define DEF(T, TN)                                                                                  \
+    template <>                                                                                     \
+    void transpose<T>(exec_t exec, const matrix::Dense<T>* orig, matrix::Dense<T>* trans)           \
+    {                                                                                               \
+        GKOC_CALL(gkoc_dense_transpose_##TN(stream_of(exec), rows(orig), cols(orig),                \
+                                            orig->get_const_values(), ld(orig),                     \
+                                            trans->get_values(), ld(trans)));                       \
     }                                                                                               \
     template <>                                                                                     \
     void extract_diagonal<T>(exec_t exec, const matrix::Dense<T>* orig,                             \
@@ -134,30 +174,6 @@ namespace dense {
             x->get_const_values(), y->get_values(), ld(y), 1));                                     \
     }                                                                                               \
     template <>                                                                                     \
-    void count_nonzeros_per_row<T, int32>(exec_t exec, const matrix::Dense<T>* source,              \
-                                          int32* result)                                            \
-    {                                                                                               \
-        GKOC_CALL(gkoc_dense_count_nonzeros_per_row_##TN(stream_of(exec), rows(source),             \
-                                                         cols(source), source->get_const_values(),  \
-                                                         ld(source), result, 4));                   \
-    }                                                                                               \
-    template <>                                                                                     \
-    void count_nonzeros_per_row<T, int64>(exec_t exec, const matrix::Dense<T>* source,              \
-                                          int64* result)                                            \
-    {                                                                                               \
-        GKOC_CALL(gkoc_dense_count_nonzeros_per_row_##TN(stream_of(exec), rows(source),             \
-                                                         cols(source), source->get_const_values(),  \
-                                                         ld(source), result, 8));                   \
-    }                                                                                               \
-    template <>                                                                                     \
-    void count_nonzeros_per_row<T, size_type>(exec_t exec, const matrix::Dense<T>* source,          \
-                                              size_type* result)                                    \
-    {                                                                                               \
-        GKOC_CALL(gkoc_dense_count_nonzeros_per_row_##TN(stream_of(exec), rows(source),             \
-                                                         cols(source), source->get_const_values(),  \
-                                                         ld(source), result, 8));                   \
-    }                                                                                               \
-    template <>                                                                                     \
     void compute_max_nnz_per_row<T>(exec_t exec, const matrix::Dense<T>* source,                    \
                                     size_type& result)                                              \
     {                                                                                               \
@@ -176,7 +192,7 @@ namespace dense {
             static_cast<int64_t>(slice_size), static_cast<int64_t>(stride_factor),                  \
             u64(slice_sets), u64(slice_lengths)));                                                  \
     }
-FOR_VT(DEF)
+FOR_AVT(DEF)
 #undef DEF
 
 #define DEF(T, TN, I, IN)                                                                           \
@@ -198,7 +214,11 @@ FOR_VT(DEF)
                                                 result->get_const_row_ptrs(),                       \
                                                 result->get_col_idxs(), nullptr));                  \
         GKOC_CALL(gkoc_fill_array_##TN(s, result->get_value(), 1, T(1)));                           \
-    }                                                                                               \
+    }
+FOR_VT_IT(DEF)
+#undef DEF
+
+#define DEF(T, TN, I, IN)                                                                           \
     template <>                                                                                     \
     void convert_to_coo<T, I>(exec_t exec, const matrix::Dense<T>* source, const int64* row_ptrs,   \
                               matrix::Coo<T, I>* result)                                            \
@@ -237,7 +257,7 @@ FOR_VT(DEF)
             static_cast<int64_t>(result->get_slice_size()), u64(result->get_const_slice_sets()),    \
             result->get_col_idxs(), result->get_values()));                                         \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 }  // namespace dense
@@ -275,7 +295,7 @@ namespace csr {
             mtx->get_const_col_idxs(), mtx->get_values(), alpha->get_const_values(),                \
             beta->get_const_values()));                                                             \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 }  // namespace csr
@@ -302,7 +322,7 @@ namespace coo {
             orig->get_const_row_idxs(), orig->get_const_col_idxs(), orig->get_const_values(),       \
             diag->get_values()));                                                                   \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 }  // namespace coo
@@ -350,7 +370,7 @@ namespace ell {
             source->get_const_values(), result->get_const_row_ptrs(), result->get_col_idxs(),       \
             result->get_values()));                                                                 \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 }  // namespace ell
@@ -396,7 +416,7 @@ namespace sellp {
             source->get_const_col_idxs(), source->get_const_values(),                               \
             result->get_const_row_ptrs(), result->get_col_idxs(), result->get_values()));           \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 }  // namespace sellp
@@ -419,7 +439,7 @@ namespace hybrid {
             source->get_const_coo_values(), ell_row_ptrs, coo_row_ptrs, result->get_row_ptrs(),     \
             result->get_col_idxs(), result->get_values()));                                         \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 }  // namespace hybrid
@@ -539,7 +559,7 @@ namespace dense {
             gather_indices, orig->get_const_values(), ld(orig), beta->get_const_values(),           \
             row_collection->get_values(), ld(row_collection)));                                     \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 #undef PERMUTE
 
@@ -655,7 +675,7 @@ namespace csr {
             source->get_const_col_idxs(), source->get_const_values(), result->get_const_row_ptrs(), \
             result->get_col_idxs(), result->get_values()));                                         \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 #undef PERMUTE
 
@@ -666,6 +686,24 @@ namespace csr {
 
 // C = alpha A B + beta D and C = alpha A + beta B through triplets (csrc/conversions.hip): expand the
 // contributions row by row, sort them (stable) by (row, column), add up the runs, rows -> pointers
+// x *= alpha / x /= alpha over n contiguous values (one scalar), per value type
+inline int scale_values(gkoc_stream_t s, int64_t n, const double* a, double* x, bool inv)
+{
+    return inv ? gkoc_dense_inv_scale_f64(s, n, 1, a, 1, x, 1) : gkoc_dense_scale_f64(s, n, 1, a, 1, x, 1);
+}
+inline int scale_values(gkoc_stream_t s, int64_t n, const float* a, float* x, bool inv)
+{
+    return inv ? gkoc_dense_inv_scale_f32(s, n, 1, a, 1, x, 1) : gkoc_dense_scale_f32(s, n, 1, a, 1, x, 1);
+}
+inline int scale_values(gkoc_stream_t s, int64_t n, const std::complex<double>* a, std::complex<double>* x, bool inv)
+{
+    return inv ? gkoc_cdense_inv_scale_c128(s, n, 1, a, 1, 0, x, 1) : gkoc_cdense_scale_c128(s, n, 1, a, 1, 0, x, 1);
+}
+inline int scale_values(gkoc_stream_t s, int64_t n, const std::complex<float>* a, std::complex<float>* x, bool inv)
+{
+    return inv ? gkoc_cdense_inv_scale_c64(s, n, 1, a, 1, 0, x, 1) : gkoc_cdense_scale_c64(s, n, 1, a, 1, 0, x, 1);
+}
+
 #define DEF(T, TN, I, IN)                                                                           \
     static void from_contributions_##TN##_##IN(                                                     \
         exec_t exec, const T* alpha, const matrix::Csr<T, I>* a, const matrix::Csr<T, I>* b,        \
@@ -713,17 +751,14 @@ namespace csr {
     template <>                                                                                     \
     void scale<T, I>(exec_t exec, const matrix::Dense<T>* alpha, matrix::Csr<T, I>* to_scale)       \
     {                                                                                               \
-        GKOC_CALL(gkoc_dense_scale_##TN(stream_of(exec),                                            \
-                                        static_cast<int64_t>(to_scale->get_num_stored_elements()),  \
-                                        1, alpha->get_const_values(), 1, to_scale->get_values(),    \
-                                        1));                                                        \
+        GKOC_CALL(scale_values(stream_of(exec), static_cast<int64_t>(to_scale->get_num_stored_elements()), \
+                               alpha->get_const_values(), to_scale->get_values(), false));          \
     }                                                                                               \
     template <>                                                                                     \
     void inv_scale<T, I>(exec_t exec, const matrix::Dense<T>* alpha, matrix::Csr<T, I>* to_scale)   \
     {                                                                                               \
-        GKOC_CALL(gkoc_dense_inv_scale_##TN(                                                        \
-            stream_of(exec), static_cast<int64_t>(to_scale->get_num_stored_elements()), 1,          \
-            alpha->get_const_values(), 1, to_scale->get_values(), 1));                              \
+        GKOC_CALL(scale_values(stream_of(exec), static_cast<int64_t>(to_scale->get_num_stored_elements()), \
+                               alpha->get_const_values(), to_scale->get_values(), true));           \
     }                                                                                               \
     template <>                                                                                     \
     void spgemm<T, I>(exec_t exec, const matrix::Csr<T, I>* a, const matrix::Csr<T, I>* b,          \
@@ -786,7 +821,7 @@ namespace csr {
             beta->get_const_values(), b->get_const_row_ptrs(), b->get_const_col_idxs(),             \
             b->get_const_values(), c->get_const_row_ptrs(), c->get_values()));                      \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 // Ginkgo's per-row lookup structures (core/matrix/csr_lookup.hpp), built on the device with the
@@ -852,7 +887,7 @@ namespace jacobi {
             stream_of(exec), static_cast<int64_t>(num_blocks), block_pointers.get_const_data(),     \
             csr->get_const_row_ptrs(), csr->get_const_col_idxs(), csr->get_values()));              \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 }  // namespace jacobi
@@ -885,7 +920,7 @@ namespace factorization {
         builder.get_value_array() = std::move(new_values);                                          \
         builder.get_col_idx_array() = std::move(new_cols);                                          \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 }  // namespace factorization
@@ -931,11 +966,67 @@ namespace scaled_permutation {
             stream_of(exec), static_cast<int64_t>(size), first_scale, first, second_scale, second,  \
             out_scale, out_perm));                                                                  \
     }
-FOR_VT_IT(DEF)
+FOR_AVT_IT(DEF)
 #undef DEF
 
 }  // namespace scaled_permutation
 
+
+
+// csr::calculate_nonzeros_per_row_in_index_set / compute_submatrix_from_index_set
+// (Csr::create_submatrix(index_set, index_set), core/matrix/csr.cpp:1446-1486) for all four value types
+namespace csr {
+
+namespace {
+inline const double* abi(const double* p) { return p; }
+inline double* abi(double* p) { return p; }
+inline const float* abi(const float* p) { return p; }
+inline float* abi(float* p) { return p; }
+inline const gkoc_c128* abi(const std::complex<double>* p) { return reinterpret_cast<const gkoc_c128*>(p); }
+inline gkoc_c128* abi(std::complex<double>* p) { return reinterpret_cast<gkoc_c128*>(p); }
+inline const gkoc_c64* abi(const std::complex<float>* p) { return reinterpret_cast<const gkoc_c64*>(p); }
+inline gkoc_c64* abi(std::complex<float>* p) { return reinterpret_cast<gkoc_c64*>(p); }
+}  // namespace
+
+#define DEF(T, TN, I, IN)                                                                           \
+    template <>                                                                                     \
+    void calculate_nonzeros_per_row_in_index_set<T, I>(                                             \
+        exec_t exec, const matrix::Csr<T, I>* source, const gko::index_set<I>& row_index_set,       \
+        const gko::index_set<I>& col_index_set, I* row_nnz)                                         \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_count_in_index_set_##TN##_##IN(                                          \
+            stream_of(exec), static_cast<int64_t>(row_index_set.get_num_elems()),                   \
+            static_cast<int64_t>(row_index_set.get_num_subsets()), row_index_set.get_subsets_begin(), \
+            row_index_set.get_superset_indices(), static_cast<int64_t>(col_index_set.get_num_subsets()), \
+            col_index_set.get_subsets_begin(), col_index_set.get_subsets_end(),                     \
+            static_cast<int64_t>(col_index_set.get_size()), source->get_const_row_ptrs(),           \
+            source->get_const_col_idxs(), row_nnz));                                                \
+    }                                                                                               \
+    template <>                                                                                     \
+    void compute_submatrix_from_index_set<T, I>(                                                    \
+        exec_t exec, const matrix::Csr<T, I>* source, const gko::index_set<I>& row_index_set,       \
+        const gko::index_set<I>& col_index_set, matrix::Csr<T, I>* result)                          \
+    {                                                                                               \
+        GKOC_CALL(gkoc_csr_submatrix_from_index_set_##TN##_##IN(                                    \
+            stream_of(exec), static_cast<int64_t>(row_index_set.get_num_elems()),                   \
+            static_cast<int64_t>(row_index_set.get_num_subsets()), row_index_set.get_subsets_begin(), \
+            row_index_set.get_superset_indices(), static_cast<int64_t>(col_index_set.get_num_subsets()), \
+            col_index_set.get_subsets_begin(), col_index_set.get_subsets_end(),                     \
+            col_index_set.get_superset_indices(), static_cast<int64_t>(col_index_set.get_size()),   \
+            source->get_const_row_ptrs(), source->get_const_col_idxs(), abi(source->get_const_values()), \
+            result->get_const_row_ptrs(), result->get_col_idxs(), abi(result->get_values())));      \
+    }
+DEF(double, f64, int32, i32)
+DEF(double, f64, int64, i64)
+DEF(float, f32, int32, i32)
+DEF(float, f32, int64, i64)
+DEF(std::complex<double>, c128, int32, i32)
+DEF(std::complex<double>, c128, int64, i64)
+DEF(std::complex<float>, c64, int32, i32)
+DEF(std::complex<float>, c64, int64, i64)
+#undef DEF
+
+}  // namespace csr
 
 }  // namespace hip
 }  // namespace kernels

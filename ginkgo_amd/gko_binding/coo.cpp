@@ -3,6 +3,8 @@
 // components::convert_ptrs_to_idxs forwarded to the C ABI (csrc/coo.hip).
 // With these, Ginkgo's own Coo and Hybrid (Ell + Coo) matrices apply on this
 // backend, and Csr -> Coo / Hybrid conversions run on the device.
+#include <complex>
+
 #include <ginkgo/core/base/device_matrix_data.hpp>
 #include <ginkgo/core/matrix/coo.hpp>
 #include <ginkgo/core/matrix/csr.hpp>
@@ -113,6 +115,10 @@ namespace ell {
             result->get_col_idxs(), result->get_values()));                               \
     }
 FOR_VT_IT(DEF)
+DEF(std::complex<double>, c128, int32, i32)
+DEF(std::complex<double>, c128, int64, i64)
+DEF(std::complex<float>, c64, int32, i32)
+DEF(std::complex<float>, c64, int64, i64)
 #undef DEF
 
 }  // namespace ell
@@ -162,6 +168,10 @@ void compute_row_nnz(exec_t exec, const array<int64>& row_ptrs, size_type* row_n
         exec->synchronize();                                                              \
     }
 FOR_VT_IT(DEF)
+DEF(std::complex<double>, c128, int32, i32)
+DEF(std::complex<double>, c128, int64, i64)
+DEF(std::complex<float>, c64, int32, i32)
+DEF(std::complex<float>, c64, int64, i64)
 #undef DEF
 
 }  // namespace hybrid
@@ -183,6 +193,10 @@ namespace csr {
             result->get_coo_values()));                                                   \
     }
 FOR_VT_IT(DEF)
+DEF(std::complex<double>, c128, int32, i32)
+DEF(std::complex<double>, c128, int64, i64)
+DEF(std::complex<float>, c64, int32, i32)
+DEF(std::complex<float>, c64, int64, i64)
 #undef DEF
 
 // transpose / conj_transpose (real value types: the same operation)

@@ -231,6 +231,10 @@ FOR_IT(DEF)
         exec->synchronize(); /* the temporary row pointers die here */          \
     }
 FOR_VT_IT(DEF)
+DEF(std::complex<double>, c128, int32, i32)
+DEF(std::complex<double>, c128, int64, i64)
+DEF(std::complex<float>, c64, int32, i32)
+DEF(std::complex<float>, c64, int64, i64)
 #undef DEF
 
 }  // namespace ell
@@ -302,6 +306,10 @@ FOR_IT(DEF)
         exec->synchronize();                                                    \
     }
 FOR_VT_IT(DEF)
+DEF(std::complex<double>, c128, int32, i32)
+DEF(std::complex<double>, c128, int64, i64)
+DEF(std::complex<float>, c64, int32, i32)
+DEF(std::complex<float>, c64, int64, i64)
 #undef DEF
 
 }  // namespace sellp
@@ -1085,6 +1093,8 @@ std::unique_ptr<matrix::Dense<T>> identity_on(exec_t exec, size_type n)
         exec->synchronize(); /* the identity is released on return */           \
     }
 FOR_VT(DEF)
+DEF(std::complex<double>, c128)
+DEF(std::complex<float>, c64)
 #undef DEF
 
 #define DEF(T, TN, I, IN)                                                       \
@@ -1113,6 +1123,10 @@ FOR_VT(DEF)
         exec->synchronize(); /* the identity is released on return */           \
     }
 FOR_VT_IT(DEF)
+DEF(std::complex<double>, c128, int32, i32)
+DEF(std::complex<double>, c128, int64, i64)
+DEF(std::complex<float>, c64, int32, i32)
+DEF(std::complex<float>, c64, int64, i64)
 #undef DEF
 
 }  // namespace jacobi

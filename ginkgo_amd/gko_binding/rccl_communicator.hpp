@@ -27,7 +27,7 @@
 #include <ginkgo/core/distributed/collective_communicator.hpp>
 #include <ginkgo/core/distributed/index_map.hpp>
 
-#include "gko_cdna4.h"
+#include "complex_abi.hpp"
 
 // libginkgo_hip.so of this backend (gko_binding/fusion.cpp): launches kernels the binding holds back
 extern "C" void gko_cdna4_launch_deferred();

@@ -20,7 +20,7 @@
 #include <ginkgo/core/matrix/dense.hpp>
 #include <ginkgo/core/stop/stopping_status.hpp>
 
-#include "gko_cdna4.h"
+#include "complex_abi.hpp"
 
 namespace gko {
 namespace cdna4 {

@@ -327,6 +327,10 @@ GKOC_DECL_CONV(double, f64, int32_t, i32)
 GKOC_DECL_CONV(double, f64, int64_t, i64)
 GKOC_DECL_CONV(float, f32, int32_t, i32)
 GKOC_DECL_CONV(float, f32, int64_t, i64)
+GKOC_DECL_CONV(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_CONV(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_CONV(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_CONV(gkoc_c64, c64, int64_t, i64)
 
 /* components::aos_to_soa (core/base/device_matrix_data_kernels.hpp:27-30):
  * entries is an array of Ginkgo matrix_data_entry<T,I> = struct { I row;
@@ -470,6 +474,11 @@ int gkoc_convert_idxs_to_ptrs_i64_i32(gkoc_stream_t s, int64_t num_idxs,
                               int64_t ldc);
 GKOC_DECL_GEMM(double, f64)
 GKOC_DECL_GEMM(float, f32)
+GKOC_DECL_GEMM(gkoc_c128, c128)
+GKOC_DECL_GEMM(gkoc_c64, c64)
+/* dense::compute_sqrt on complex values (the real ones: GKOC_DECL_DENSE) */
+int gkoc_dense_compute_sqrt_c128(gkoc_stream_t s, int64_t cols, gkoc_c128* x);
+int gkoc_dense_compute_sqrt_c64(gkoc_stream_t s, int64_t cols, gkoc_c64* x);
 int gkoc_dense_convert_f64_f32(gkoc_stream_t s, int64_t rows, int64_t cols,
                                const double* x, int64_t ldx, float* y, int64_t ldy);
 int gkoc_dense_convert_f32_f64(gkoc_stream_t s, int64_t rows, int64_t cols,
@@ -774,6 +783,15 @@ GKOC_DECL_JACOBI_TRANSPOSE(double, f64, int32_t, i32)
 GKOC_DECL_JACOBI_TRANSPOSE(double, f64, int64_t, i64)
 GKOC_DECL_JACOBI_TRANSPOSE(float, f32, int32_t, i32)
 GKOC_DECL_JACOBI_TRANSPOSE(float, f32, int64_t, i64)
+/* ... of complex blocks (uniform storage precision); conj != 0: conj_transpose_jacobi */
+#define GKOC_DECL_CJACOBI_TRANSPOSE(T, TN, I, IN)                              \
+    int gkoc_cjacobi_transpose_##TN##_##IN(                                    \
+        gkoc_stream_t s, int64_t num_blocks, gkoc_jacobi_scheme scheme,        \
+        const I* block_ptrs, const T* blocks, int conj, T* out_blocks);
+GKOC_DECL_CJACOBI_TRANSPOSE(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_CJACOBI_TRANSPOSE(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_CJACOBI_TRANSPOSE(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_CJACOBI_TRANSPOSE(gkoc_c64, c64, int64_t, i64)
 
 /* Block-Jacobi with a fixed reduced storage precision (Jacobi::storage_optimization
  * other than autodetect; include/ginkgo/core/preconditioner/jacobi.hpp, storage types
@@ -1018,6 +1036,8 @@ GKOC_DECL_DIST(float, f32, int64_t, i64)
     int gkoc_reduce_add_array_##TN(gkoc_stream_t s, int64_t n, const T* arr, T* val);
 GKOC_DECL_MISC_T(double, f64)
 GKOC_DECL_MISC_T(float, f32)
+GKOC_DECL_MISC_T(gkoc_c128, c128)
+GKOC_DECL_MISC_T(gkoc_c64, c64)
 int gkoc_reduce_add_array_i32(gkoc_stream_t s, int64_t n, const int32_t* arr, int32_t* val);
 int gkoc_reduce_add_array_i64(gkoc_stream_t s, int64_t n, const int64_t* arr, int64_t* val);
 int gkoc_reduce_add_array_u64(gkoc_stream_t s, int64_t n, const uint64_t* arr, uint64_t* val);
@@ -1037,6 +1057,10 @@ GKOC_DECL_MISC_TI(double, f64, int32_t, i32)
 GKOC_DECL_MISC_TI(double, f64, int64_t, i64)
 GKOC_DECL_MISC_TI(float, f32, int32_t, i32)
 GKOC_DECL_MISC_TI(float, f32, int64_t, i64)
+GKOC_DECL_MISC_TI(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_MISC_TI(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_MISC_TI(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_MISC_TI(gkoc_c64, c64, int64_t, i64)
 #define GKOC_DECL_MISC_I(I, IN)                                                                  \
     int gkoc_sparsity_csr_count_diagonal_##IN(gkoc_stream_t s, int64_t n_rows,                   \
                                               const I* row_ptrs, const I* cols, I* counts);      \
@@ -1530,8 +1554,6 @@ GKOC_DECL_ROW_GATHER_MIXED(int64_t, i64)
  * the caller counts and scans first, as the classes in core/matrix do. */
 #define GKOC_DECL_CV_DENSE(T, TN)                                                                     \
     int gkoc_fill_seq_array_##TN(gkoc_stream_t s, T* data, int64_t n);                                \
-    int gkoc_dense_compute_norm1_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* x,        \
-                                      int64_t ldx, T* result, void* work, size_t work_bytes);         \
     int gkoc_dense_transpose_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,           \
                                   int64_t ldi, T* out, int64_t ldo);                                  \
     int gkoc_dense_extract_diagonal_##TN(gkoc_stream_t s, int64_t n, const T* in, int64_t ld,         \
@@ -1550,8 +1572,15 @@ GKOC_DECL_ROW_GATHER_MIXED(int64_t, i64)
     int gkoc_dense_compute_slice_sets_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, const T* in,  \
                                            int64_t ld, int64_t slice_size, int64_t stride_factor,     \
                                            uint64_t* slice_sets, uint64_t* slice_lengths);
+/* (1-norms per column; real value types - the complex ones are gkoc_cdense_compute_norm1_*) */
+int gkoc_dense_compute_norm1_f64(gkoc_stream_t s, int64_t rows, int64_t cols, const double* x, int64_t ldx,
+                                 double* result, void* work, size_t work_bytes);
+int gkoc_dense_compute_norm1_f32(gkoc_stream_t s, int64_t rows, int64_t cols, const float* x, int64_t ldx,
+                                 float* result, void* work, size_t work_bytes);
 GKOC_DECL_CV_DENSE(double, f64)
 GKOC_DECL_CV_DENSE(float, f32)
+GKOC_DECL_CV_DENSE(gkoc_c128, c128)
+GKOC_DECL_CV_DENSE(gkoc_c64, c64)
 int gkoc_fill_seq_array_u64(gkoc_stream_t s, uint64_t* data, int64_t n);
 /* csr::spgemm_reuse / advanced_spgemm_reuse (alpha != NULL: c = alpha a b + beta d) and
  * csr::spgeam_numeric (c = alpha a + beta b) - core/matrix/csr_kernels.hpp:60-92: the VALUES of a
@@ -1571,6 +1600,10 @@ GKOC_DECL_REUSE(double, f64, int32_t, i32)
 GKOC_DECL_REUSE(double, f64, int64_t, i64)
 GKOC_DECL_REUSE(float, f32, int32_t, i32)
 GKOC_DECL_REUSE(float, f32, int64_t, i64)
+GKOC_DECL_REUSE(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_REUSE(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_REUSE(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_REUSE(gkoc_c64, c64, int64_t, i64)
 /* components::fill_array for bool / char / uint16 / uint32 arrays
  * (core/components/fill_array_kernels.hpp:18-21): elem_bytes 1, 2 or 4, value = low bytes of pattern */
 int gkoc_fill_array_small(gkoc_stream_t s, void* data, int64_t n, int elem_bytes, uint32_t pattern);
@@ -1631,6 +1664,10 @@ GKOC_DECL_CV(double, f64, int32_t, i32)
 GKOC_DECL_CV(double, f64, int64_t, i64)
 GKOC_DECL_CV(float, f32, int32_t, i32)
 GKOC_DECL_CV(float, f32, int64_t, i64)
+GKOC_DECL_CV(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_CV(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_CV(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_CV(gkoc_c64, c64, int64_t, i64)
 #define GKOC_DECL_CV_INDEX(I, IN)                                                                     \
     int gkoc_ell_count_nonzeros_per_row_##IN(gkoc_stream_t s, int64_t n_rows, int64_t ell_k,          \
                                              int64_t stride, const I* cols, I* out);                  \
@@ -1679,6 +1716,34 @@ GKOC_DECL_PERMUTE(double, f64, int32_t, i32)
 GKOC_DECL_PERMUTE(double, f64, int64_t, i64)
 GKOC_DECL_PERMUTE(float, f32, int32_t, i32)
 GKOC_DECL_PERMUTE(float, f32, int64_t, i64)
+GKOC_DECL_PERMUTE(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_PERMUTE(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_PERMUTE(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_PERMUTE(gkoc_c64, c64, int64_t, i64)
+/* csr::calculate_nonzeros_per_row_in_index_set / compute_submatrix_from_index_set
+ * (core/matrix/csr_kernels.hpp; reference/matrix/csr_kernels.cpp:772-812, 853-904; the reference's
+ * own CUDA / HIP backend leaves both unimplemented): the rows of the row index set (subset j =
+ * [row_begin[j], row_end[j]), first result row row_superset[j] = index_set::get_superset_indices())
+ * restricted to the columns of the column index set, renumbered to col_superset[subset] + offset.
+ * counts has n_result_rows entries; out_rp = their exclusive sums (the caller scans). */
+#define GKOC_DECL_INDEX_SET(T, TN, I, IN)                                                             \
+    int gkoc_csr_count_in_index_set_##TN##_##IN(                                                      \
+        gkoc_stream_t s, int64_t n_result_rows, int64_t n_row_subsets, const I* row_begin,            \
+        const I* row_superset, int64_t n_col_subsets, const I* col_begin, const I* col_end,           \
+        int64_t col_set_size, const I* in_rp, const I* in_ci, I* counts);                             \
+    int gkoc_csr_submatrix_from_index_set_##TN##_##IN(                                                \
+        gkoc_stream_t s, int64_t n_result_rows, int64_t n_row_subsets, const I* row_begin,            \
+        const I* row_superset, int64_t n_col_subsets, const I* col_begin, const I* col_end,           \
+        const I* col_superset, int64_t col_set_size, const I* in_rp, const I* in_ci, const T* in_v,   \
+        const I* out_rp, I* out_ci, T* out_v);
+GKOC_DECL_INDEX_SET(double, f64, int32_t, i32)
+GKOC_DECL_INDEX_SET(double, f64, int64_t, i64)
+GKOC_DECL_INDEX_SET(float, f32, int32_t, i32)
+GKOC_DECL_INDEX_SET(float, f32, int64_t, i64)
+GKOC_DECL_INDEX_SET(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_INDEX_SET(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_INDEX_SET(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_INDEX_SET(gkoc_c64, c64, int64_t, i64)
 #define GKOC_DECL_PERMUTATION(I, IN)                                                                  \
     /* out[perm[i]] = i;  out[i] = first[second[i]] */                                                \
     int gkoc_permutation_invert_##IN(gkoc_stream_t s, int64_t n, const I* perm, I* out);              \
@@ -1711,6 +1776,10 @@ GKOC_DECL_SPGEMM(double, f64, int32_t, i32)
 GKOC_DECL_SPGEMM(double, f64, int64_t, i64)
 GKOC_DECL_SPGEMM(float, f32, int32_t, i32)
 GKOC_DECL_SPGEMM(float, f32, int64_t, i64)
+GKOC_DECL_SPGEMM(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_SPGEMM(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_SPGEMM(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_SPGEMM(gkoc_c64, c64, int64_t, i64)
 
 /* L1 block-Jacobi (Jacobi::with_aggregate_l1; reference/preconditioner/jacobi_kernels.cpp:728-780,
  * reference/factorization/factorization_kernels.cpp:55-128): scalar_l1 adds to diag[r] the sum of
@@ -1730,6 +1799,10 @@ GKOC_DECL_L1(double, f64, int32_t, i32)
 GKOC_DECL_L1(double, f64, int64_t, i64)
 GKOC_DECL_L1(float, f32, int32_t, i32)
 GKOC_DECL_L1(float, f32, int64_t, i64)
+GKOC_DECL_L1(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_L1(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_L1(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_L1(gkoc_c64, c64, int64_t, i64)
 int gkoc_csr_missing_diagonal_shift_i32(gkoc_stream_t s, int64_t n_rows, int64_t n_cols,
                                         const int32_t* rp, const int32_t* ci, int32_t* shift,
                                         int64_t* missing_host);
@@ -1781,9 +1854,10 @@ int gkoc_hybrid_compute_coo_row_ptrs(gkoc_stream_t s, int64_t n_rows,
         gkoc_stream_t s, int64_t n_rows, int64_t n_cols, int64_t nnz,          \
         const T* alpha, const I* row_idxs, const I* col_idxs, const T* vals,   \
         const T* b, int64_t ldb, T* c, int64_t ldc, int64_t nrhs, void* work,  \
-        size_t work_bytes);                                                    \
-    /* ell::copy (core/matrix/ell_kernels.hpp:53-56): the stored entries of an \
-     * Ell into one with another stride (Ell / Hybrid assignment, resize) */   \
+        size_t work_bytes);
+/* ell::copy (core/matrix/ell_kernels.hpp:53-56): the stored entries of an Ell into one with another
+ * stride (Ell / Hybrid assignment, resize); csr::convert_to_hybrid.  All four value types. */
+#define GKOC_DECL_COO_CONVERT(T, TN, I, IN)                                    \
     int gkoc_ell_copy_##TN##_##IN(                                             \
         gkoc_stream_t s, int64_t n_rows, int64_t k, int64_t src_stride,        \
         const I* src_cols, const T* src_vals, int64_t dst_stride,              \
@@ -1797,6 +1871,14 @@ GKOC_DECL_COO(double, f64, int32_t, i32)
 GKOC_DECL_COO(double, f64, int64_t, i64)
 GKOC_DECL_COO(float, f32, int32_t, i32)
 GKOC_DECL_COO(float, f32, int64_t, i64)
+GKOC_DECL_COO_CONVERT(double, f64, int32_t, i32)
+GKOC_DECL_COO_CONVERT(double, f64, int64_t, i64)
+GKOC_DECL_COO_CONVERT(float, f32, int32_t, i32)
+GKOC_DECL_COO_CONVERT(float, f32, int64_t, i64)
+GKOC_DECL_COO_CONVERT(gkoc_c128, c128, int32_t, i32)
+GKOC_DECL_COO_CONVERT(gkoc_c128, c128, int64_t, i64)
+GKOC_DECL_COO_CONVERT(gkoc_c64, c64, int32_t, i32)
+GKOC_DECL_COO_CONVERT(gkoc_c64, c64, int64_t, i64)
 
 /* csr::transpose / conj_transpose (real types) (core/matrix/csr_kernels.hpp,
  * GKO_DECLARE_CSR_TRANSPOSE_KERNEL; reference/matrix/csr_kernels.cpp:693-731): the

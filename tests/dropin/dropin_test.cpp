@@ -13,12 +13,16 @@
 
 #include <ginkgo/core/base/device_matrix_data.hpp>
 #include <ginkgo/core/base/executor.hpp>
+#include <ginkgo/core/base/index_set.hpp>
 #include <ginkgo/core/base/matrix_data.hpp>
 #include <ginkgo/core/base/timer.hpp>
 #include <ginkgo/core/log/convergence.hpp>
 #include <ginkgo/core/matrix/coo.hpp>
 #include <ginkgo/core/matrix/csr.hpp>
 #include <ginkgo/core/matrix/hybrid.hpp>
+#include <ginkgo/core/matrix/diagonal.hpp>
+#include <ginkgo/core/matrix/permutation.hpp>
+#include <ginkgo/core/matrix/identity.hpp>
 #include <ginkgo/core/matrix/dense.hpp>
 #include <ginkgo/core/matrix/ell.hpp>
 #include <ginkgo/core/matrix/fbcsr.hpp>
@@ -854,6 +858,34 @@ int main(int argc, char** argv)
         CHECK(identical(gko::clone(ref, y_hip).get(), y_ref.get()),
               "Csr::read(device_matrix_data) on hip + apply bit-identical");
     }
+    // --- Csr::create_submatrix(index_set, index_set): csr::calculate_nonzeros_per_row_in_index_set +
+    // compute_submatrix_from_index_set (the index sets of test/matrix/csr_kernels2.cpp:1711-1770,
+    // scaled to this matrix)
+    {
+        const it step = static_cast<it>(n / 100);
+        gko::array<it> ridx{ref, {42 * step, 7, 8, 9, 10, 22, 25, 26, 34 * step, 35 * step, 36 * step, 36 * step + 1,
+                                  51 * step}};
+        gko::array<it> cidx{ref, 400};
+        for (int k = 0; k < 400; ++k) cidx.get_data()[k] = static_cast<it>((k * 37) % (60 * step) + (k % 3));
+        gko::index_set<it> rset{ref, static_cast<it>(n), ridx};
+        gko::index_set<it> cset{ref, static_cast<it>(n), cidx};
+        gko::index_set<it> drset{hip, rset};
+        gko::index_set<it> dcset{hip, cset};
+        auto s_ref = a_ref->create_submatrix(rset, cset);
+        auto s_hip = gko::clone(ref, a_hip->create_submatrix(drset, dcset));
+        bool same = s_ref->get_size() == s_hip->get_size() &&
+                    s_ref->get_num_stored_elements() == s_hip->get_num_stored_elements();
+        for (gko::size_type r = 0; same && r <= s_ref->get_size()[0]; ++r)
+            same = s_ref->get_const_row_ptrs()[r] == s_hip->get_const_row_ptrs()[r];
+        for (gko::size_type k = 0; same && k < s_ref->get_num_stored_elements(); ++k)
+            same = s_ref->get_const_col_idxs()[k] == s_hip->get_const_col_idxs()[k] &&
+                   s_ref->get_const_values()[k] == s_hip->get_const_values()[k];
+        std::cout << "submatrix from index sets: " << s_ref->get_size()[0] << " x " << s_ref->get_size()[1] << ", "
+                  << s_ref->get_num_stored_elements() << " entries, " << rset.get_num_subsets() << " / "
+                  << cset.get_num_subsets() << " subsets" << std::endl;
+        CHECK(same && s_ref->get_num_stored_elements() > 0,
+              "Csr::create_submatrix(index_set, index_set) on hip identical to reference");
+    }
     // --- complex values: Cg + block-Jacobi(4) on a Hermitian positive definite matrix (the stencil
     // with a phase on the off-diagonal entries: a(i, j) = conj(a(j, i))), hip against reference
     {
@@ -908,6 +940,189 @@ int main(int argc, char** argv)
             den += std::norm(cx_ref->at(i, 0));
         }
         CHECK(std::sqrt(num / den) < 1e-14, "complex jacobi::generate + simple_apply agree with reference to rounding");
+    }
+    // --- complex values on the formats either side of the products: conversions, transposes,
+    // permutations, scaling, SpGEMM / SpGEAM, sub-matrices, Diagonal, Dense products - hip against
+    // reference on a 216 x 216 matrix (dense comparison; complex kernels agree to rounding)
+    {
+        using ct = std::complex<double>;
+        using CCsr = gko::matrix::Csr<ct, it>;
+        using CDense = gko::matrix::Dense<ct>;
+        using CEll = gko::matrix::Ell<ct, it>;
+        using CSellp = gko::matrix::Sellp<ct, it>;
+        using CHybrid = gko::matrix::Hybrid<ct, it>;
+        using CCoo = gko::matrix::Coo<ct, it>;
+        auto small = generate_stencil<vt, it>("27pt", 216);
+        gko::matrix_data<ct, it> md{small.first.size};
+        for (const auto& e : small.first.nonzeros) {
+            const double ph = 0.4 * ((e.row % 7) - 0.5 * (e.column % 3));
+            md.nonzeros.emplace_back(e.row, e.column, ct{e.value * std::cos(ph), e.value * std::sin(ph)});
+        }
+        const gko::size_type m = md.size[0];
+        auto a0 = gko::share(CCsr::create(ref));
+        a0->read(md);
+        auto a1 = gko::share(gko::clone(hip, a0));
+        auto dense_of = [&](auto&& op) {
+            auto d = CDense::create(ref);
+            gko::clone(ref, op)->convert_to(d);
+            return d;
+        };
+        auto dist = [&](const CDense* x, const CDense* y) {
+            double num = 0, den = 0;
+            if (x->get_size() != y->get_size()) return 1.0;
+            for (gko::size_type i = 0; i < x->get_size()[0]; ++i)
+                for (gko::size_type j = 0; j < x->get_size()[1]; ++j) {
+                    num += std::norm(x->at(i, j) - y->at(i, j));
+                    den += std::norm(y->at(i, j));
+                }
+            return den > 0 ? std::sqrt(num / den) : std::sqrt(num);
+        };
+        auto want = dense_of(a0);
+        // conversions out of Csr on the device, and back
+        {
+            auto e = CEll::create(hip);
+            a1->convert_to(e);
+            auto sp = CSellp::create(hip);
+            a1->convert_to(sp);
+            auto hy = CHybrid::create(hip);
+            a1->convert_to(hy);
+            auto co = CCoo::create(hip);
+            a1->convert_to(co);
+            auto de = CDense::create(hip);
+            a1->convert_to(de);
+            CHECK(dist(dense_of(e).get(), want.get()) == 0.0, "complex csr -> ell on hip");
+            CHECK(dist(dense_of(sp).get(), want.get()) == 0.0, "complex csr -> sellp on hip");
+            CHECK(dist(dense_of(hy).get(), want.get()) == 0.0, "complex csr -> hybrid on hip");
+            CHECK(dist(dense_of(co).get(), want.get()) == 0.0, "complex csr -> coo on hip");
+            CHECK(dist(gko::clone(ref, de).get(), want.get()) == 0.0, "complex csr -> dense on hip");
+            auto back = CCsr::create(hip);
+            e->convert_to(back);
+            CHECK(dist(dense_of(back).get(), want.get()) == 0.0, "complex ell -> csr on hip");
+            sp->convert_to(back);
+            CHECK(dist(dense_of(back).get(), want.get()) == 0.0, "complex sellp -> csr on hip");
+            hy->convert_to(back);
+            CHECK(dist(dense_of(back).get(), want.get()) == 0.0, "complex hybrid -> csr on hip");
+            auto e2 = CEll::create(hip);
+            auto sp2 = CSellp::create(hip);
+            auto hy2 = CHybrid::create(hip);
+            auto co2 = CCoo::create(hip);
+            de->convert_to(e2);
+            de->convert_to(sp2);
+            de->convert_to(hy2);
+            de->convert_to(co2);
+            CHECK(dist(dense_of(e2).get(), want.get()) == 0.0 && dist(dense_of(sp2).get(), want.get()) == 0.0 &&
+                      dist(dense_of(hy2).get(), want.get()) == 0.0 && dist(dense_of(co2).get(), want.get()) == 0.0,
+                  "complex dense -> ell / sellp / hybrid / coo on hip");
+            auto diag_vec = [&](auto&& d) {
+                auto h = gko::clone(ref, d);
+                auto v = CDense::create(ref, gko::dim<2>{h->get_size()[0], 1});
+                for (gko::size_type i = 0; i < h->get_size()[0]; ++i) v->at(i, 0) = h->get_const_values()[i];
+                return v;
+            };
+            auto dg_ref = diag_vec(a0->extract_diagonal());
+            CHECK(dist(diag_vec(e->extract_diagonal()).get(), dg_ref.get()) == 0.0 &&
+                      dist(diag_vec(sp->extract_diagonal()).get(), dg_ref.get()) == 0.0 &&
+                      dist(diag_vec(co->extract_diagonal()).get(), dg_ref.get()) == 0.0,
+                  "complex extract_diagonal of ell / sellp / coo on hip");
+        }
+        // transposes, permutations, scaling
+        {
+            CHECK(dist(dense_of(gko::as<CCsr>(a1->conj_transpose())).get(),
+                       dense_of(gko::as<CCsr>(a0->conj_transpose())).get()) == 0.0,
+                  "complex Csr::conj_transpose on hip");
+            gko::array<it> pidx{ref, m};
+            for (gko::size_type i = 0; i < m; ++i) pidx.get_data()[i] = static_cast<it>((i * 5 + 3) % m);
+            auto perm = gko::matrix::Permutation<it>::create(ref, pidx);
+            auto perm_d = gko::clone(hip, perm);
+            for (auto mode : {gko::matrix::permute_mode::symmetric, gko::matrix::permute_mode::rows,
+                              gko::matrix::permute_mode::inverse_columns}) {
+                CHECK(dist(dense_of(a1->permute(perm_d, mode)).get(), dense_of(a0->permute(perm, mode)).get()) == 0.0,
+                      "complex Csr::permute on hip, mode " + std::to_string(static_cast<int>(mode)));
+            }
+            auto d0 = dense_of(a0);
+            auto d1 = gko::clone(hip, d0);
+            CHECK(dist(gko::clone(ref, d1->permute(perm_d, gko::matrix::permute_mode::symmetric)).get(),
+                       d0->permute(perm, gko::matrix::permute_mode::symmetric).get()) == 0.0,
+                  "complex Dense::permute on hip");
+            CHECK(dist(gko::clone(ref, gko::as<CDense>(d1->transpose())).get(), gko::as<CDense>(d0->transpose()).get()) ==
+                      0.0,
+                  "complex Dense::transpose on hip");
+            auto sc = gko::initialize<CDense>({ct{0.5, -1.5}}, ref);
+            auto s0 = gko::clone(ref, a0);
+            auto s1 = gko::clone(hip, a0);
+            s0->scale(sc);
+            s1->scale(gko::clone(hip, sc));
+            CHECK(dist(dense_of(s1).get(), dense_of(s0).get()) < 1e-15, "complex Csr::scale on hip");
+            s0->inv_scale(sc);
+            s1->inv_scale(gko::clone(hip, sc));
+            CHECK(dist(dense_of(s1).get(), dense_of(s0).get()) < 1e-15, "complex Csr::inv_scale on hip");
+        }
+        // SpGEMM, SpGEAM, sub-matrix
+        {
+            auto c0 = CCsr::create(ref, gko::dim<2>{m, m});
+            auto c1 = CCsr::create(hip, gko::dim<2>{m, m});
+            a0->apply(a0, c0);
+            a1->apply(a1, c1);
+            CHECK(dist(dense_of(c1).get(), dense_of(c0).get()) < 1e-14, "complex SpGEMM on hip");
+            auto al = gko::initialize<CDense>({ct{1.0, 0.5}}, ref), be = gko::initialize<CDense>({ct{-0.25, 2.0}}, ref);
+            auto id0 = gko::matrix::Identity<ct>::create(ref, m);
+            auto id1 = gko::matrix::Identity<ct>::create(hip, m);
+            auto g0 = gko::clone(ref, c0);
+            auto g1 = gko::clone(hip, c0);
+            a0->apply(al, id0, be, g0);
+            a1->apply(gko::clone(hip, al), id1, gko::clone(hip, be), g1);
+            CHECK(dist(dense_of(g1).get(), dense_of(g0).get()) < 1e-14, "complex SpGEAM on hip");
+            auto sub0 = a0->create_submatrix(gko::span{10, 150}, gko::span{20, 190});
+            auto sub1 = a1->create_submatrix(gko::span{10, 150}, gko::span{20, 190});
+            CHECK(dist(dense_of(sub1).get(), dense_of(sub0).get()) == 0.0, "complex Csr::create_submatrix on hip");
+        }
+        // Diagonal and Dense products
+        {
+            auto dg0 = a0->extract_diagonal();
+            auto dg1 = gko::clone(hip, dg0);
+            auto x0 = CDense::create(ref, gko::dim<2>{m, 3});
+            for (gko::size_type i = 0; i < m; ++i)
+                for (int j = 0; j < 3; ++j) x0->at(i, j) = ct{std::sin(0.3 * i + j), std::cos(0.7 * i - j)};
+            auto x1 = gko::clone(hip, x0);
+            auto y0 = CDense::create(ref, gko::dim<2>{m, 3});
+            auto y1 = CDense::create(hip, gko::dim<2>{m, 3});
+            dg0->apply(x0, y0);
+            dg1->apply(x1, y1);
+            CHECK(dist(gko::clone(ref, y1).get(), y0.get()) < 1e-15, "complex Diagonal::apply to Dense on hip");
+            dg0->inverse_apply(x0, y0);
+            dg1->inverse_apply(x1, y1);
+            CHECK(dist(gko::clone(ref, y1).get(), y0.get()) < 1e-15, "complex Diagonal::inverse_apply on hip");
+            auto w0 = dense_of(a0);
+            auto w1 = gko::clone(hip, w0);
+            w0->apply(x0, y0);
+            w1->apply(x1, y1);
+            CHECK(dist(gko::clone(ref, y1).get(), y0.get()) < 1e-14, "complex Dense::apply (GEMM) on hip");
+            auto al = gko::initialize<CDense>({ct{0.5, 0.5}}, ref), be = gko::initialize<CDense>({ct{-1.0, 0.25}}, ref);
+            w0->apply(al, x0, be, y0);
+            w1->apply(gko::clone(hip, al), x1, gko::clone(hip, be), y1);
+            CHECK(dist(gko::clone(ref, y1).get(), y0.get()) < 1e-14, "complex Dense::apply advanced on hip");
+        }
+        // Bicg + block-Jacobi: Jacobi::conj_transpose() of complex blocks
+        {
+            auto b0 = CDense::create(ref, gko::dim<2>{m, 1});
+            for (gko::size_type i = 0; i < m; ++i) b0->at(i, 0) = ct{1.0 + 0.1 * (i % 4), -0.5 + 0.05 * (i % 9)};
+            auto make = [&](std::shared_ptr<const gko::Executor> ex, std::shared_ptr<CCsr> mat) {
+                return gko::solver::Bicg<ct>::build()
+                    .with_criteria(gko::stop::Iteration::build().with_max_iters(25u))
+                    .with_preconditioner(gko::preconditioner::Jacobi<ct, it>::build().with_max_block_size(6u))
+                    .on(ex)
+                    ->generate(mat);
+            };
+            auto x0 = CDense::create(ref, gko::dim<2>{m, 1});
+            auto x1 = CDense::create(hip, gko::dim<2>{m, 1});
+            x0->fill(ct{0.0, 0.0});
+            x1->fill(ct{0.0, 0.0});
+            make(ref, a0)->apply(b0, x0);
+            make(hip, a1)->apply(gko::clone(hip, b0), x1);
+            const double d = dist(gko::clone(ref, x1).get(), x0.get());
+            std::cout << "complex Bicg + Jacobi(6), 25 iterations: rel. difference " << d << std::endl;
+            CHECK(d < 1e-9, "complex<double> Bicg + block-Jacobi (conj_transpose_jacobi) on hip agrees with reference");
+        }
     }
     std::cout << (failures == 0 ? "DROPIN OK" : "DROPIN FAILED") << std::endl;
     return failures == 0 ? 0 : 1;
