@@ -6,9 +6,9 @@ are taken there), and run under mpiexec with the rank counts of the reference's 
 ranks share GPU 0 here.
 
 Every suite must run to its end on every rank; a test may fail (on any rank) only if it is listed in
-tests/dropin/mpi_reftests_expected.json - the Pgm (multigrid) kernels, complex Bicgstab and complex
-SpGEAM, which this backend leaves to Ginkgo's NotCompiled stubs (outside SURVEY.md 8).  No listed failure is a wrong number, and no test of a real value type is listed apart from the
-ones that build a Pgm hierarchy."""
+tests/dropin/mpi_reftests_expected.json - the 16 tests that build a Pgm (multigrid) hierarchy, whose
+kernels this backend leaves to Ginkgo's NotCompiled stubs (outside SURVEY.md 8).  No listed failure is
+a wrong number."""
 import glob
 import json
 import os
