@@ -14,6 +14,7 @@
 // one thread per right-hand side.
 #include <cmath>
 #include <random>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(idr_block) void idr_init_m_kernel(int64_t s, int64_
 }
 
 // out[col] = sum_row a[row * lda + acol] * b[row * ldb + col], col < ncols; two stages
-template <typename T>
+template <typename T, bool CONJ = false>
 __global__ __launch_bounds__(idr_block) void idr_dot_stage1(int64_t n, const T* __restrict__ a, int64_t lda,
                                                             const T* __restrict__ b, int64_t ldb,
                                                             int64_t ncols, T* __restrict__ partial)
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(idr_block) void idr_dot_stage1(int64_t n, const T* 
     T acc = T(0);
     const int64_t stride = int64_t(gridDim.x) * idr_block;
     for (int64_t row = int64_t(blockIdx.x) * idr_block + threadIdx.x; row < n; row += stride) {
-        acc += a[row * lda] * b[row * ldb + col];
+        acc += a[row * lda] * (CONJ ? conj_v(b[row * ldb + col]) : b[row * ldb + col]);
     }
     const T r = block_sum<idr_block>(acc, lds);
     if (threadIdx.x == 0) partial[col * gridDim.x + blockIdx.x] = r;
@@ -83,20 +84,33 @@ struct store_scaled {
     }
 };
 
-template <typename T>
+template <typename T, bool CONJ = false>
 int idr_dots(hipStream_t st, int64_t n, const T* a, int64_t lda, const T* b, int64_t ldb, int64_t ncols,
              T* partial, const uint8_t* stop, store_scaled<T> op)
 {
     int64_t nb = ceildiv(n, idr_block * 4);
     if (nb > idr_max_partials) nb = idr_max_partials;
     if (nb < 1) nb = 1;
-    idr_dot_stage1<T><<<dim3(unsigned(nb), unsigned(ncols)), dim3(idr_block), 0, st>>>(n, a, lda, b, ldb,
+    idr_dot_stage1<T, CONJ><<<dim3(unsigned(nb), unsigned(ncols)), dim3(idr_block), 0, st>>>(n, a, lda, b, ldb,
                                                                                      ncols, partial);
     GKOC_LAUNCH_OK();
     idr_dot_stage2<T, store_scaled<T>><<<dim3(unsigned(ncols)), dim3(idr_block), 0, st>>>(int(nb), partial,
                                                                                           stop, op);
     GKOC_LAUNCH_OK();
     return GKOC_OK;
+}
+
+// detail::get_rand_value (include/ginkgo/core/base/matrix_data.hpp:36-50)
+template <typename T, typename D, typename G>
+T idr_rand_value(D& dist, G& gen)
+{
+    if constexpr (std::is_same<T, real_t<T>>::value) {
+        return T(dist(gen));
+    } else {
+        const auto re = dist(gen);
+        const auto im = dist(gen);
+        return T{static_cast<real_t<T>>(re), static_cast<real_t<T>>(im)};
+    }
 }
 
 // row r of p: p_r -= dot * p_i; and p_r /= norm (orthonormalisation of the shadow space)
@@ -113,9 +127,9 @@ template <typename T>
 __global__ __launch_bounds__(idr_block) void idr_row_normalise_kernel(int64_t n, T* __restrict__ pr,
                                                                       const T* __restrict__ sq)
 {
-    const T norm = sqrt(sq[0]);
+    const real_t<T> norm = sqrt(real_v(sq[0]));
     const int64_t stride = int64_t(gridDim.x) * idr_block;
-    for (int64_t j = int64_t(blockIdx.x) * idr_block + threadIdx.x; j < n; j += stride) pr[j] /= norm;
+    for (int64_t j = int64_t(blockIdx.x) * idr_block + threadIdx.x; j < n; j += stride) pr[j] = pr[j] / norm;
 }
 
 // c = M \ f, one thread per right-hand side (reference solve_lower_triangular)
@@ -219,18 +233,19 @@ __global__ void idr_update_f_kernel(int64_t s, int64_t nrhs, int64_t k, T* f, in
 }
 
 template <typename T>
-__global__ void idr_omega_kernel(int64_t nrhs, T kappa, const T* __restrict__ tht,
-                                 const T* __restrict__ residual_norm, T* omega,
+__global__ void idr_omega_kernel(int64_t nrhs, real_t<T> kappa, const T* __restrict__ tht,
+                                 const real_t<T>* __restrict__ residual_norm, T* omega,
                                  const uint8_t* __restrict__ stop)
 {
+    using R = real_t<T>;
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= nrhs || status_has_stopped(stop[i])) return;
     const T thr = omega[i];
-    const T normt = sqrt(tht[i]);
+    const R normt = sqrt(real_v(tht[i]));
     T om = omega[i] / tht[i];
-    const T absrho = fabs(thr / (normt * residual_norm[i]));
-    if (absrho < kappa) om *= kappa / absrho;
-    if (normt == T(0)) om = T(0);
+    const R absrho = abs_v(thr / (normt * residual_norm[i]));
+    if (absrho < kappa) om = om * (kappa / absrho);
+    if (normt == R(0)) om = T(0);
     omega[i] = om;
 }
 
@@ -253,7 +268,7 @@ int idr_initialize(gkoc_stream_t s_, int64_t nrhs, int64_t s, T* m, int64_t ldm,
         std::vector<T> host(size_t(s) * n);
         std::normal_distribution<> dist(0.0, 1.0);
         std::default_random_engine gen(std::random_device{}());
-        for (auto& v : host) v = T(dist(gen));
+        for (auto& v : host) v = idr_rand_value<T>(dist, gen);   // (complex: two draws, real part first)
         for (int64_t r = 0; r < s; ++r) {
             GKOC_HIP(hipMemcpyAsync(p + r * ldp, host.data() + r * n, sizeof(T) * n, hipMemcpyHostToDevice,
                                     st));
@@ -266,12 +281,13 @@ int idr_initialize(gkoc_stream_t s_, int64_t nrhs, int64_t s, T* m, int64_t ldm,
         T* pr = p + r * ldp;
         for (int64_t i = 0; i < r; ++i) {
             const T* pi = p + i * ldp;
-            GKOC_TRY(idr_dots<T>(st, n, pr, 1, pi, 1, 1, scratch + 1, nullptr,
-                                 store_scaled<T>{scratch, nullptr, 0}));
+            GKOC_TRY((idr_dots<T, true>(st, n, pr, 1, pi, 1, 1, scratch + 1, nullptr,
+                                        store_scaled<T>{scratch, nullptr, 0})));
             idr_row_axpy_kernel<T><<<dim3(idr_blocks(n)), dim3(idr_block), 0, st>>>(n, pr, pi, scratch);
             GKOC_LAUNCH_OK();
         }
-        GKOC_TRY(idr_dots<T>(st, n, pr, 1, pr, 1, 1, scratch + 1, nullptr, store_scaled<T>{scratch, nullptr, 0}));
+        GKOC_TRY((idr_dots<T, true>(st, n, pr, 1, pr, 1, 1, scratch + 1, nullptr,
+                                    store_scaled<T>{scratch, nullptr, 0})));
         idr_row_normalise_kernel<T><<<dim3(idr_blocks(n)), dim3(idr_block), 0, st>>>(n, pr, scratch);
         GKOC_LAUNCH_OK();
     }
@@ -323,7 +339,7 @@ int idr_step_3(gkoc_stream_t s_, int64_t n, int64_t nrhs, int64_t s, int64_t k, 
 
 using namespace gkoc;
 
-#define GKOC_DEF_IDR(T, TN)                                                                              \
+#define GKOC_DEF_IDR(T, TN, R)                                                                              \
     extern "C" int gkoc_idr_initialize_##TN(gkoc_stream_t s, int64_t nrhs, int64_t subspace_dim, T* m,    \
                                             int64_t ldm, int64_t n, T* subspace_vectors, int64_t ldp,     \
                                             int deterministic, uint8_t* stop_status)                     \
@@ -367,8 +383,8 @@ using namespace gkoc;
         return idr_step_3<T>(s, n, nrhs, subspace_dim, k, p, ldp, g, ldg, g_k, ldgk, u, ldu, m, ldm, f,   \
                              ldf, residual, ldr, x, ldx, stop_status);                                   \
     }                                                                                                    \
-    extern "C" int gkoc_idr_compute_omega_##TN(gkoc_stream_t s, int64_t nrhs, T kappa, const T* tht,      \
-                                               const T* residual_norm, T* omega,                         \
+    extern "C" int gkoc_idr_compute_omega_##TN(gkoc_stream_t s, int64_t nrhs, R kappa, const T* tht,      \
+                                               const R* residual_norm, T* omega,                         \
                                                const uint8_t* stop_status)                               \
     {                                                                                                    \
         if (nrhs <= 0) return GKOC_OK;                                                                   \
@@ -377,5 +393,7 @@ using namespace gkoc;
         GKOC_LAUNCH_OK();                                                                                \
         return GKOC_OK;                                                                                  \
     }
-GKOC_DEF_IDR(double, f64)
-GKOC_DEF_IDR(float, f32)
+GKOC_DEF_IDR(double, f64, double)
+GKOC_DEF_IDR(float, f32, float)
+GKOC_DEF_IDR(gkoc_c128, c128, double)
+GKOC_DEF_IDR(gkoc_c64, c64, float)

@@ -509,7 +509,7 @@ __global__ void minres_step1_kernel(int64_t cols, T* alpha, T* beta, T* gamma, T
     const T tmp_d = gamma[j], tmp_a = alpha[j];
     const T c_old = cosv[j], s_old = sinv[j], cp_old = cos_prev[j];
     gamma[j] = cp_old * c_old * tmp_d + s_old * tmp_a;
-    T a = -s_old * cp_old * tmp_d + c_old * tmp_a;
+    T a = -conj_v(s_old) * cp_old * tmp_d + c_old * tmp_a;
     cos_prev[j] = c_old;                      // swap(cos, cos_prev), swap(sin, sin_prev)
     sin_prev[j] = s_old;
     T c, sn;
@@ -517,11 +517,11 @@ __global__ void minres_step1_kernel(int64_t cols, T* alpha, T* beta, T* gamma, T
         c = T(0);
         sn = T(1);
     } else {
-        const T scale = fabs(a) + fabs(bt);
-        const T as = fabs(a / scale), bs = fabs(bt / scale);
-        const T hyp = scale * sqrt(as * as + bs * bs);
-        c = a / hyp;
-        sn = bt / hyp;
+        const real_t<T> scale = abs_v(a) + abs_v(bt);
+        const real_t<T> as = abs_v(a / scale), bs = abs_v(bt / scale);
+        const real_t<T> hyp = scale * sqrt(as * as + bs * bs);
+        c = conj_v(a) / hyp;
+        sn = conj_v(bt) / hyp;
     }
     a = c * a + sn * bt;
     alpha[j] = a;
@@ -530,7 +530,7 @@ __global__ void minres_step1_kernel(int64_t cols, T* alpha, T* beta, T* gamma, T
     tau[j] = sn * sn * tau[j];
     const T e = eta_next[j];
     eta[j] = e;
-    eta_next[j] = -sn * e;
+    eta_next[j] = -conj_v(sn) * e;
 }
 
 // p = (z - gamma p_prev - delta p) / alpha ; x += cos eta p ; q_prev = v ;
@@ -640,6 +640,46 @@ struct op_cheb_update {
         out[0] = static_cast<T>(v);
         out[1] = static_cast<T>(v);
         out[2] = static_cast<T>(static_cast<double>(in[2]) + alpha * v);
+    }
+};
+
+// ... with complex coefficients (coeff_type<complex<float | double>> = complex<double>)
+template <typename R>
+__device__ __forceinline__ gkoc_c128 cheb_widen(gkoc_cplx<R> v)
+{
+    return gkoc_c128{static_cast<double>(v.re), static_cast<double>(v.im)};
+}
+template <typename T>
+__device__ __forceinline__ T cheb_narrow(gkoc_c128 v)
+{
+    using R = real_t<T>;
+    return T{static_cast<R>(v.re), static_cast<R>(v.im)};
+}
+template <typename T>
+struct op_ccheb_init {
+    gkoc_c128 alpha;
+    struct scalars {};
+    __device__ scalars load(int64_t) const { return {}; }
+    __device__ bool skip(const scalars&) const { return false; }
+    __device__ void apply(const scalars&, const T* in, T* out) const
+    {
+        const gkoc_c128 v = cheb_widen(in[0]);
+        out[0] = cheb_narrow<T>(v);
+        out[1] = cheb_narrow<T>(cheb_widen(in[1]) + alpha * v);
+    }
+};
+template <typename T>
+struct op_ccheb_update {
+    gkoc_c128 alpha, beta;
+    struct scalars {};
+    __device__ scalars load(int64_t) const { return {}; }
+    __device__ bool skip(const scalars&) const { return false; }
+    __device__ void apply(const scalars&, const T* in, T* out) const
+    {
+        const gkoc_c128 v = cheb_widen(in[0]) + beta * cheb_widen(in[1]);
+        out[0] = cheb_narrow<T>(v);
+        out[1] = cheb_narrow<T>(v);
+        out[2] = cheb_narrow<T>(cheb_widen(in[2]) + alpha * v);
     }
 };
 
@@ -1280,6 +1320,8 @@ GKOC_DEF_BICG(gkoc_c64, c64)
     }
 GKOC_DEF_MINRES(double, f64)
 GKOC_DEF_MINRES(float, f32)
+GKOC_DEF_MINRES(gkoc_c128, c128)
+GKOC_DEF_MINRES(gkoc_c64, c64)
 
 #define GKOC_DEF_GCR(T, TN)                                                               \
     extern "C" int gkoc_gcr_initialize_##TN(gkoc_stream_t s, int64_t rows, int64_t cols,   \
@@ -1346,3 +1388,29 @@ GKOC_DEF_GCR(gkoc_c64, c64)
     }
 GKOC_DEF_CHEB(double, f64)
 GKOC_DEF_CHEB(float, f32)
+// complex values: the coefficients are HOST complex<double> values, passed by address
+#define GKOC_DEF_CCHEB(T, TN)                                                             \
+    extern "C" int gkoc_chebyshev_init_update_##TN(                                       \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const gkoc_c128* alpha_host,         \
+        const T* inner_sol, int64_t ldi, T* update_sol, int64_t ldu, T* output, int64_t ldo) \
+    {                                                                                     \
+        GKOC_REQUIRE(alpha_host, GKOC_E_INVALID, "null coefficient");                     \
+        operand_list<T, 2, 2> o;                                                          \
+        o.in(inner_sol, ldi).in(output, ldo).out(update_sol, ldu).out(output, ldo);       \
+        return launch_elementwise<T, op_ccheb_init<T>, 2, 2>(s, rows, cols, o.a,          \
+                                                             op_ccheb_init<T>{*alpha_host}, true); \
+    }                                                                                     \
+    extern "C" int gkoc_chebyshev_update_##TN(                                            \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const gkoc_c128* alpha_host,         \
+        const gkoc_c128* beta_host, T* inner_sol, int64_t ldi, T* update_sol, int64_t ldu, \
+        T* output, int64_t ldo)                                                           \
+    {                                                                                     \
+        GKOC_REQUIRE(alpha_host && beta_host, GKOC_E_INVALID, "null coefficient");        \
+        operand_list<T, 3, 3> o;                                                          \
+        o.in(inner_sol, ldi).in(update_sol, ldu).in(output, ldo).out(inner_sol, ldi)      \
+            .out(update_sol, ldu).out(output, ldo);                                       \
+        return launch_elementwise<T, op_ccheb_update<T>, 3, 3>(                           \
+            s, rows, cols, o.a, op_ccheb_update<T>{*alpha_host, *beta_host}, true);       \
+    }
+GKOC_DEF_CCHEB(gkoc_c128, c128)
+GKOC_DEF_CCHEB(gkoc_c64, c64)

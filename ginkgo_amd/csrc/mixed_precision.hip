@@ -442,3 +442,59 @@ GKOC_DEF_SPMV_MIXED(int64_t, i64)
     }
 GKOC_DEF_ROW_GATHER_MIXED(int32_t, i32)
 GKOC_DEF_ROW_GATHER_MIXED(int64_t, i64)
+
+// coo::conj_array on complex values (core/matrix/coo.cpp: conj_transpose of a Coo) and
+// dense::add_scaled_identity<complex, real> (reference/matrix/dense_kernels.cpp: m = beta m + alpha I
+// with REAL scalars on a complex matrix)
+namespace gkoc {
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void conj_array_kernel(int64_t n, T* __restrict__ x)
+{
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        x[i] = conj_v(x[i]);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void add_scaled_identity_real_kernel(int64_t rows, int64_t cols,
+                                                                       const real_t<T>* __restrict__ alpha,
+                                                                       const real_t<T>* __restrict__ beta,
+                                                                       T* __restrict__ m, int64_t ld)
+{
+    const real_t<T> a = alpha[0], b = beta[0];
+    const int64_t total = rows * cols;
+    for (int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; t < total; t += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t i = t / cols, j = t - i * cols;
+        T v = m[i * ld + j] * b;
+        if (i == j) v.re += a;
+        m[i * ld + j] = v;
+    }
+}
+}  // namespace
+}  // namespace gkoc
+
+#define GKOC_DEF_CONJ_ARRAY(T, TN, R)                                                                  \
+    extern "C" int gkoc_conj_array_##TN(gkoc_stream_t s, int64_t n, T* x)                              \
+    {                                                                                                  \
+        if (n <= 0) return GKOC_OK;                                                                    \
+        GKOC_REQUIRE(x, GKOC_E_INVALID, "null pointer");                                               \
+        const int64_t want = gkoc::ceildiv(n, 256);                                                    \
+        gkoc::conj_array_kernel<T><<<dim3(unsigned(want < gkoc::max_stream_blocks ? want : gkoc::max_stream_blocks)), \
+                                     dim3(256), 0, gkoc::as_stream(s)>>>(n, x);                        \
+        GKOC_LAUNCH_OK();                                                                              \
+        return GKOC_OK;                                                                                \
+    }                                                                                                  \
+    extern "C" int gkoc_dense_add_scaled_identity_real_##TN(gkoc_stream_t s, int64_t rows, int64_t cols, \
+                                                            const R* alpha, const R* beta, T* m, int64_t ld) \
+    {                                                                                                  \
+        if (rows <= 0 || cols <= 0) return GKOC_OK;                                                    \
+        GKOC_REQUIRE(alpha && beta && m && ld >= cols, GKOC_E_INVALID, "null pointer or stride");      \
+        const int64_t want = gkoc::ceildiv(rows * cols, 256);                                          \
+        gkoc::add_scaled_identity_real_kernel<T>                                                       \
+            <<<dim3(unsigned(want < gkoc::max_stream_blocks ? want : gkoc::max_stream_blocks)), dim3(256), 0, \
+               gkoc::as_stream(s)>>>(rows, cols, alpha, beta, m, ld);                                  \
+        GKOC_LAUNCH_OK();                                                                              \
+        return GKOC_OK;                                                                                \
+    }
+GKOC_DEF_CONJ_ARRAY(gkoc_c128, c128, double)
+GKOC_DEF_CONJ_ARRAY(gkoc_c64, c64, float)

@@ -1,4 +1,6 @@
 // Ginkgo-side binding of the IDR(s) kernels (core/solver/idr_kernels.hpp:22-72) to the C ABI.
+#include <complex>
+
 #include <ginkgo/core/matrix/dense.hpp>
 
 #include "core/solver/idr_kernels.hpp"
@@ -62,8 +64,9 @@ using exec_t = std::shared_ptr<const HipExecutor>;
                                        raw(stop_status)));                                            \
     }                                                                                                 \
     template <>                                                                                       \
-    void compute_omega<T>(exec_t exec, const size_type nrhs, const T kappa,                            \
-                          const matrix::Dense<T>* tht, const matrix::Dense<T>* residual_norm,         \
+    void compute_omega<T>(exec_t exec, const size_type nrhs, const remove_complex<T> kappa,           \
+                          const matrix::Dense<T>* tht,                                                \
+                          const matrix::Dense<remove_complex<T>>* residual_norm,                      \
                           matrix::Dense<T>* omega, const array<stopping_status>* stop_status)         \
     {                                                                                                 \
         GKOC_CALL(gkoc_idr_compute_omega_##TN(stream_of(exec), nrhs, kappa, tht->get_const_values(),  \
@@ -72,6 +75,8 @@ using exec_t = std::shared_ptr<const HipExecutor>;
     }
 DEF(double, f64)
 DEF(float, f32)
+DEF(std::complex<double>, c128)
+DEF(std::complex<float>, c64)
 #undef DEF
 
 }  // namespace idr

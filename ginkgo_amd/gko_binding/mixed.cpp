@@ -8,10 +8,12 @@
 // Kernels: csrc/mixed_precision.hip (gkoc_{csr,ell}_spmv_mixed_*, gkoc_dense_row_gather_mixed_*).
 #include <complex>
 
+#include <ginkgo/core/matrix/coo.hpp>
 #include <ginkgo/core/matrix/csr.hpp>
 #include <ginkgo/core/matrix/dense.hpp>
 #include <ginkgo/core/matrix/ell.hpp>
 
+#include "core/matrix/coo_kernels.hpp"
 #include "core/matrix/csr_kernels.hpp"
 #include "core/matrix/dense_kernels.hpp"
 #include "core/matrix/ell_kernels.hpp"
@@ -150,7 +152,38 @@ namespace dense {
 FOR_PAIRS(DEF)
 #undef DEF
 
+// m = beta m + alpha I with real scalars on a complex matrix
+#define DEF(T, TN)                                                                                     \
+    template <>                                                                                        \
+    void add_scaled_identity<T, remove_complex<T>>(exec_t exec, const matrix::Dense<remove_complex<T>>* alpha, \
+                                                   const matrix::Dense<remove_complex<T>>* beta,       \
+                                                   matrix::Dense<T>* mtx)                              \
+    {                                                                                                  \
+        GKOC_CALL(gkoc_dense_add_scaled_identity_real_##TN(stream_of(exec), rows(mtx), cols(mtx),      \
+                                                           alpha->get_const_values(),                  \
+                                                           beta->get_const_values(), mtx->get_values(), \
+                                                           ld(mtx)));                                  \
+    }
+DEF(std::complex<double>, c128)
+DEF(std::complex<float>, c64)
+#undef DEF
+
 }  // namespace dense
+
+
+namespace coo {
+
+#define DEF(T, TN)                                                                       \
+    template <>                                                                          \
+    void conj_array<T>(exec_t exec, size_type num, T* values)                            \
+    {                                                                                    \
+        GKOC_CALL(gkoc_conj_array_##TN(stream_of(exec), static_cast<int64_t>(num), values)); \
+    }
+DEF(std::complex<double>, c128)
+DEF(std::complex<float>, c64)
+#undef DEF
+
+}  // namespace coo
 
 }  // namespace hip
 }  // namespace kernels

@@ -55,6 +55,34 @@ DEF(double, f64)
 DEF(float, f32)
 #undef DEF
 
+// complex values: coeff_type is complex<double>, handed over by address
+#define DEF(T, TN)                                                                          \
+    template <>                                                                             \
+    void init_update<T>(exec_t exec, const solver::detail::coeff_type<T> alpha,             \
+                        const matrix::Dense<T>* inner_sol, matrix::Dense<T>* update_sol,    \
+                        matrix::Dense<T>* output)                                           \
+    {                                                                                       \
+        const std::complex<double> a = alpha;                                               \
+        GKOC_CALL(gkoc_chebyshev_init_update_##TN(                                          \
+            stream_of(exec), rows(output), cols(output), &a, inner_sol->get_const_values(), \
+            ld(inner_sol), update_sol->get_values(), ld(update_sol), output->get_values(),  \
+            ld(output)));                                                                   \
+    }                                                                                       \
+    template <>                                                                             \
+    void update<T>(exec_t exec, const solver::detail::coeff_type<T> alpha,                  \
+                   const solver::detail::coeff_type<T> beta, matrix::Dense<T>* inner_sol,   \
+                   matrix::Dense<T>* update_sol, matrix::Dense<T>* output)                  \
+    {                                                                                       \
+        const std::complex<double> a = alpha, b = beta;                                     \
+        GKOC_CALL(gkoc_chebyshev_update_##TN(                                               \
+            stream_of(exec), rows(output), cols(output), &a, &b, inner_sol->get_values(),   \
+            ld(inner_sol), update_sol->get_values(), ld(update_sol), output->get_values(),  \
+            ld(output)));                                                                   \
+    }
+DEF(std::complex<double>, c128)
+DEF(std::complex<float>, c64)
+#undef DEF
+
 }  // namespace chebyshev
 
 }  // namespace hip

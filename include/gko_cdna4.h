@@ -621,7 +621,7 @@ GKOC_DECL_GMRES(gkoc_c64, c64, float)
  * g / u  n x (s nrhs), g_k / v / residual / x  n x nrhs.  Updates in the reference's term order;
  * the dots <p_j, g_k> use a fixed two-level tree.  deterministic == 0: shadow vectors drawn on the
  * host from N(0,1) with a random seed, like the reference. */
-#define GKOC_DECL_IDR(T, TN)                                                    \
+#define GKOC_DECL_IDR(T, TN, R)                                                    \
     int gkoc_idr_initialize_##TN(gkoc_stream_t s, int64_t nrhs,                 \
                                  int64_t subspace_dim, T* m, int64_t ldm,       \
                                  int64_t n, T* subspace_vectors, int64_t ldp,   \
@@ -643,11 +643,13 @@ GKOC_DECL_GMRES(gkoc_c64, c64, float)
                              int64_t ldgk, T* u, int64_t ldu, T* m, int64_t ldm, \
                              T* f, int64_t ldf, T* residual, int64_t ldr, T* x, \
                              int64_t ldx, const uint8_t* stop_status);          \
-    int gkoc_idr_compute_omega_##TN(gkoc_stream_t s, int64_t nrhs, T kappa,     \
-                                    const T* tht, const T* residual_norm,       \
+    int gkoc_idr_compute_omega_##TN(gkoc_stream_t s, int64_t nrhs, R kappa,     \
+                                    const T* tht, const R* residual_norm,       \
                                     T* omega, const uint8_t* stop_status);
-GKOC_DECL_IDR(double, f64)
-GKOC_DECL_IDR(float, f32)
+GKOC_DECL_IDR(double, f64, double)
+GKOC_DECL_IDR(float, f32, float)
+GKOC_DECL_IDR(gkoc_c128, c128, double)   /* kappa and residual_norm are real */
+GKOC_DECL_IDR(gkoc_c64, c64, float)
 
 /* ------------------------------------------------------------- CB-GMRES
  * cb_gmres::{restart, arnoldi, solve_krylov}  core/solver/cb_gmres_kernels.hpp:101-142,
@@ -1544,6 +1546,14 @@ GKOC_DECL_SPMV_MIXED(int64_t, i64)
                                          void* out, int64_t ld_out);
 GKOC_DECL_ROW_GATHER_MIXED(int32_t, i32)
 GKOC_DECL_ROW_GATHER_MIXED(int64_t, i64)
+/* coo::conj_array (x[i] = conj(x[i]); Coo::conj_transpose) and dense::add_scaled_identity<complex,
+ * real>: m = beta m + alpha I with REAL device scalars on a complex matrix */
+int gkoc_conj_array_c128(gkoc_stream_t s, int64_t n, gkoc_c128* x);
+int gkoc_conj_array_c64(gkoc_stream_t s, int64_t n, gkoc_c64* x);
+int gkoc_dense_add_scaled_identity_real_c128(gkoc_stream_t s, int64_t rows, int64_t cols, const double* alpha,
+                                             const double* beta, gkoc_c128* m, int64_t ld);
+int gkoc_dense_add_scaled_identity_real_c64(gkoc_stream_t s, int64_t rows, int64_t cols, const float* alpha,
+                                            const float* beta, gkoc_c64* m, int64_t ld);
 
 /* ------------------------------------------- conversions and matrix utilities
  * Everything Ginkgo's matrix classes ask the device for when a matrix moves between formats, and the
@@ -2061,6 +2071,8 @@ GKOC_DECL_GCR(gkoc_c64, c64, float)
         const uint8_t* stop_status);
 GKOC_DECL_MINRES(double, f64)
 GKOC_DECL_MINRES(float, f32)
+GKOC_DECL_MINRES(gkoc_c128, c128)
+GKOC_DECL_MINRES(gkoc_c64, c64)
 
 /* ir::initialize (core/solver/ir_kernels.hpp:19-21; reference/solver/ir_kernels.cpp:20-27):
  * reset the stopping status; used by Ir and Chebyshev.
@@ -2081,6 +2093,18 @@ int gkoc_ir_initialize(gkoc_stream_t s, int64_t cols, uint8_t* stop_status);
         T* output, int64_t ldo);
 GKOC_DECL_CHEB(double, f64)
 GKOC_DECL_CHEB(float, f32)
+/* complex values: coeff_type = complex<double>; the two coefficients are HOST values passed by address */
+#define GKOC_DECL_CCHEB(T, TN)                                                 \
+    int gkoc_chebyshev_init_update_##TN(                                       \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const gkoc_c128* alpha_host, \
+        const T* inner_sol, int64_t ldi, T* update_sol, int64_t ldu,           \
+        T* output, int64_t ldo);                                               \
+    int gkoc_chebyshev_update_##TN(                                            \
+        gkoc_stream_t s, int64_t rows, int64_t cols, const gkoc_c128* alpha_host, \
+        const gkoc_c128* beta_host, T* inner_sol, int64_t ldi, T* update_sol,  \
+        int64_t ldu, T* output, int64_t ldo);
+GKOC_DECL_CCHEB(gkoc_c128, c128)
+GKOC_DECL_CCHEB(gkoc_c64, c64)
 
 /* ------------------------------------------------- communicator (RCCL over xGMI)
  * Replaces, for device buffers, what the distributed path asks of

@@ -34,6 +34,7 @@
 #include <ginkgo/core/solver/cg.hpp>
 #include <ginkgo/core/solver/cgs.hpp>
 #include <ginkgo/core/solver/chebyshev.hpp>
+#include <ginkgo/core/solver/idr.hpp>
 #include <ginkgo/core/solver/ir.hpp>
 #include <ginkgo/core/solver/minres.hpp>
 #include <ginkgo/core/solver/fcg.hpp>
@@ -1101,6 +1102,76 @@ int main(int argc, char** argv)
             w0->apply(al, x0, be, y0);
             w1->apply(gko::clone(hip, al), x1, gko::clone(hip, be), y1);
             CHECK(dist(gko::clone(ref, y1).get(), y0.get()) < 1e-14, "complex Dense::apply advanced on hip");
+        }
+        // Idr, Minres, Chebyshev on complex values; Coo::conj_transpose; add_scaled_identity
+        {
+            auto b0 = CDense::create(ref, gko::dim<2>{m, 1});
+            for (gko::size_type i = 0; i < m; ++i) b0->at(i, 0) = ct{std::cos(0.2 * i), 0.3 + std::sin(0.5 * i)};
+            auto run = [&](auto factory_of, const char* name, double tol) {
+                auto x0 = CDense::create(ref, gko::dim<2>{m, 1});
+                auto x1 = CDense::create(hip, gko::dim<2>{m, 1});
+                x0->fill(ct{0.0, 0.0});
+                x1->fill(ct{0.0, 0.0});
+                factory_of(ref)->generate(a0)->apply(b0, x0);
+                factory_of(hip)->generate(a1)->apply(gko::clone(hip, b0), x1);
+                const double d = dist(gko::clone(ref, x1).get(), x0.get());
+                std::cout << "complex " << name << ": rel. difference to reference " << d << std::endl;
+                CHECK(d < tol, std::string("complex<double> ") + name + " on hip agrees with reference");
+            };
+            // Hermitian part of the matrix for Minres: (A + A^H) / 2 has the same pattern
+            run([&](std::shared_ptr<const gko::Executor> ex) {
+                return gko::solver::Idr<ct>::build()
+                    .with_criteria(gko::stop::Iteration::build().with_max_iters(12u))
+                    .with_subspace_dim(3u)
+                    .with_deterministic(true)
+                    .on(ex);
+            }, "Idr(3)", 1e-9);
+            run([&](std::shared_ptr<const gko::Executor> ex) {
+                return gko::solver::Chebyshev<ct>::build()
+                    .with_criteria(gko::stop::Iteration::build().with_max_iters(10u))
+                    .with_foci(std::pair<ct, ct>{ct{8.0, 0.0}, ct{44.0, 0.0}})
+                    .on(ex);
+            }, "Chebyshev", 1e-12);
+            {
+                auto h_md = md;
+                gko::matrix_data<ct, it> herm{md.size};
+                auto d0 = dense_of(a0);
+                for (gko::size_type i = 0; i < m; ++i)
+                    for (gko::size_type j = 0; j < m; ++j) {
+                        const ct v = 0.5 * (d0->at(i, j) + std::conj(d0->at(j, i)));
+                        if (v != ct{0.0, 0.0}) herm.nonzeros.emplace_back(i, j, v);
+                    }
+                auto h0 = gko::share(CCsr::create(ref));
+                h0->read(herm);
+                auto h1 = gko::share(gko::clone(hip, h0));
+                auto x0 = CDense::create(ref, gko::dim<2>{m, 1});
+                auto x1 = CDense::create(hip, gko::dim<2>{m, 1});
+                x0->fill(ct{0.0, 0.0});
+                x1->fill(ct{0.0, 0.0});
+                auto fac = [&](std::shared_ptr<const gko::Executor> ex) {
+                    return gko::solver::Minres<ct>::build()
+                        .with_criteria(gko::stop::Iteration::build().with_max_iters(20u))
+                        .on(ex);
+                };
+                fac(ref)->generate(h0)->apply(b0, x0);
+                fac(hip)->generate(h1)->apply(gko::clone(hip, b0), x1);
+                const double d = dist(gko::clone(ref, x1).get(), x0.get());
+                std::cout << "complex Minres, 20 iterations: rel. difference " << d << std::endl;
+                CHECK(d < 1e-10, "complex<double> Minres on hip agrees with reference");
+            }
+            auto co0 = CCoo::create(ref);
+            a0->convert_to(co0);
+            auto co1 = gko::clone(hip, co0);
+            CHECK(dist(dense_of(gko::as<CCoo>(co1->conj_transpose())).get(),
+                       dense_of(gko::as<CCoo>(co0->conj_transpose())).get()) == 0.0,
+                  "complex Coo::conj_transpose on hip");
+            auto ca = gko::initialize<CDense>({ct{0.75, 0.25}}, ref);
+            auto cb = gko::initialize<CDense>({ct{-1.5, 0.5}}, ref);
+            auto w0 = dense_of(a0);
+            auto w1 = gko::clone(hip, w0);
+            w0->add_scaled_identity(ca, cb);
+            w1->add_scaled_identity(gko::clone(hip, ca), gko::clone(hip, cb));
+            CHECK(dist(gko::clone(ref, w1).get(), w0.get()) < 1e-15, "complex Dense::add_scaled_identity on hip");
         }
         // Bicg + block-Jacobi: Jacobi::conj_transpose() of complex blocks
         {
