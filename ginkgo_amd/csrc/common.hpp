@@ -69,8 +69,12 @@ int scratch_free(hipStream_t st, void* ptr);
         if (gkoc_rc_ != GKOC_OK) return gkoc_rc_;   \
     } while (0)
 
+// A zero-initialised device word per (device, stream) for kernels whose last block finishes a
+// reduction (the word is 0 again when such a kernel ends; launches of one stream do not overlap).
+int stream_ticket(hipStream_t st, unsigned** word);
+
 // tuning switches (runtime.hip; keys = GKOC_TUNE_* of gko_cdna4.h)
-constexpr int tune_num_keys = 9;
+constexpr int tune_num_keys = 10;
 int64_t tune_value(int key);
 
 #ifdef __HIPCC__

@@ -134,10 +134,16 @@ __device__ __forceinline__ T red_term(T x, T y)
 }
 
 // flat (ld == 1, one column) stage 1
-template <typename T, int SQUARE>
+// FOLD != 0: the block that finishes LAST also does stage 2 (the same 256 threads, the same strided
+// sums and the same tree as reduce_stage2: the same bits), FOLD == 2 with the square root.  `ticket`
+// is a device word that is 0 between launches (one per stream: launches of a stream do not overlap);
+// the partial sums reach memory before the ticket is taken (agent-scope fences on both sides: the
+// blocks run on eight XCDs with an L2 each).
+template <typename T, int SQUARE, int FOLD = 0>
 __global__ __launch_bounds__(red_block) void reduce_flat_stage1(
     int64_t n, const T* __restrict__ x, const T* __restrict__ y,
-    T* __restrict__ partial, bool vec_ok)
+    T* __restrict__ partial, bool vec_ok, unsigned* __restrict__ ticket = nullptr,
+    T* __restrict__ result = nullptr)
 {
     __shared__ T lds[red_block / 64];
     using V = vec16<T>;
@@ -186,6 +192,27 @@ __global__ __launch_bounds__(red_block) void reduce_flat_stage1(
     }
     const T r = block_sum<red_block>(acc, lds);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
+    if constexpr (FOLD != 0) {
+        __shared__ unsigned last;
+        if (threadIdx.x == 0) {
+            __threadfence();                                  // release: the partial sum first
+            last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (last == 0u) return;
+        __threadfence();                                      // acquire: every thread that reads the sums
+        const T* all = partial;
+        T acc2 = T(0);
+        for (int i = threadIdx.x; i < int(gridDim.x); i += red_block) {
+            acc2 += __builtin_nontemporal_load(all + i);
+        }
+        __syncthreads();                                      // (lds is reused)
+        const T total = block_sum<red_block>(acc2, lds);
+        if (threadIdx.x == 0) {
+            result[0] = FOLD == 2 ? sqrt(total) : total;
+            *ticket = 0u;                                     // ready for the stream's next launch
+        }
+    }
 }
 
 // general (strided, multi-column) stage 1: grid = (blocks_x, cols)
@@ -249,6 +276,16 @@ int launch_reduce(gkoc_stream_t s, int64_t rows, int64_t cols, const T* x,
         int64_t nb = ceildiv(rows, per_block);
         if (nb > max_partials) nb = max_partials;
         n_partials = static_cast<int>(nb);
+        if (nb > 1 && tune_value(GKOC_TUNE_REDUCE_ONE_KERNEL) != 0) {
+            // one launch: the last block folds (5 us of launch + tiny kernel per reduction otherwise)
+            unsigned* ticket = nullptr;
+            GKOC_TRY(stream_ticket(as_stream(s), &ticket));
+            reduce_flat_stage1<T, SQUARE, SQRT ? 2 : 1>
+                <<<dim3(unsigned(nb)), dim3(red_block), 0, as_stream(s)>>>(
+                    rows, x, y, partial, vec_ok, ticket, result);
+            GKOC_LAUNCH_OK();
+            return GKOC_OK;
+        }
         reduce_flat_stage1<T, SQUARE>
             <<<dim3(unsigned(nb)), dim3(red_block), 0, as_stream(s)>>>(
                 rows, x, y, partial, vec_ok);

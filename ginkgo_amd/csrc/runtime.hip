@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include <unistd.h>
 
@@ -55,6 +57,51 @@ const device_props& current_device_props()
     return cache[dev];
 }
 
+// (device, stream) -> a zeroed device word; a slab of 1024 words per device, handed out once per stream
+int stream_ticket(hipStream_t st, unsigned** word)
+{
+    struct slab {
+        unsigned* base = nullptr;
+        int used = 0;
+    };
+    static std::mutex mtx;
+    static slab slabs[64];
+    static thread_local struct {
+        int dev;
+        hipStream_t st;
+        unsigned* word;
+    } last = {-1, nullptr, nullptr};
+    int dev = 0;
+    GKOC_HIP(hipGetDevice(&dev));
+    if (last.word && last.dev == dev && last.st == st) {
+        *word = last.word;
+        return GKOC_OK;
+    }
+    GKOC_REQUIRE(dev >= 0 && dev < 64, GKOC_E_NOT_SUPPORTED, "device id above 63");
+    static std::vector<std::pair<std::pair<int, hipStream_t>, unsigned*>> table;
+    std::lock_guard<std::mutex> g(mtx);
+    for (const auto& e : table) {
+        if (e.first.first == dev && e.first.second == st) {
+            last = {dev, st, e.second};
+            *word = e.second;
+            return GKOC_OK;
+        }
+    }
+    slab& sl = slabs[dev];
+    if (!sl.base) {
+        GKOC_HIP(hipMalloc(reinterpret_cast<void**>(&sl.base), 1024 * 64));
+        GKOC_HIP(hipMemset(sl.base, 0, 1024 * 64));
+    }
+    // one word per 64-byte line; a process with more than 1024 streams shares the last one's word
+    // with later streams (their reductions then must not run at the same time: not supported)
+    GKOC_REQUIRE(sl.used < 1024, GKOC_E_NOT_SUPPORTED, "more than 1024 streams use one-kernel reductions");
+    unsigned* w = sl.base + size_t(sl.used++) * 16;
+    table.push_back({{dev, st}, w});
+    last = {dev, st, w};
+    *word = w;
+    return GKOC_OK;
+}
+
 static int64_t g_tune[tune_num_keys] = {};
 static bool g_tune_set[tune_num_keys] = {};
 
@@ -62,7 +109,7 @@ static bool g_tune_set[tune_num_keys] = {};
 // GKOC_TUNE_<n>, else the default chosen by measurement
 int64_t tune_value(int key)
 {
-    static const int64_t defaults[tune_num_keys] = {0, 0, 0, 2, 1, 0, 0, 0, 100};   // measured: the XCD-contiguous order loses 1-8 %
+    static const int64_t defaults[tune_num_keys] = {0, 0, 0, 2, 1, 0, 0, 0, 100, 0};   // measured: the XCD-contiguous order loses 1-8 %
     if (key < 0 || key >= tune_num_keys) return 0;
     if (!g_tune_set[key]) {
         char name[32];

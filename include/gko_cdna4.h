@@ -172,6 +172,11 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                       fence; 1: every boundary wave does (+8 us per product at 2048 waves) */
 #define GKOC_TUNE_GATE_POS 8        /* one-kernel distributed product: the boundary waves start behind this many per
                                       cent of the interior waves (100: they are the last waves of the grid) */
+#define GKOC_TUNE_REDUCE_ONE_KERNEL 9 /* dot / norm2 / squared_norm2 of one contiguous column: 1: the block that finishes
+                                     * last folds the partial sums (one launch, the same bits as the two-launch
+                                     * form: same threads, same tree); 0 (default): two launches.  Measured: the
+                                     * agent-scope fences cost more than the launch they save (one rank's CG
+                                     * iteration of 256^3 / 8: 209 -> 235 us, profiles/r04_experiments.txt) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,
