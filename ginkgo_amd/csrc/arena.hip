@@ -50,6 +50,10 @@
 // grants read/write access to every device that can reach it (hipDeviceCanAccessPeer).  Without
 // it arena memory must not be handed to P2P copies or hipIpc (RCCL stages user buffers through
 // its own, so the distributed path does not need it).
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -422,8 +426,42 @@ int walk_stride(int step)
 // Walks fresh granules until the goal is reached: want >= 0 (a known class): its pool holds
 // n_want granules; want == -1: all classes are known (the survey; a granule of a class nobody
 // has met founds its region, start_class).  hipSuccess if reached.
+// Processes that share one device (MPI ranks of a test box, eight bench ranks under gloo) take turns:
+// a walk holds its handles until it ends and times its probes, eight of them at once starve each other
+// of memory and spoil each other's timings (a 64^3 test with 8 ranks on one GPU: minutes).  An advisory
+// lock on a file per device; whoever cannot get it within 20 s walks anyway, a process that dies
+// releases it with its descriptor.  One process per GPU - production - never waits.
+struct walk_turn {
+    int fd = -1;
+    explicit walk_turn(int dev)
+    {
+        const char* dir = std::getenv("TMPDIR");
+        char path[512];
+        snprintf(path, sizeof(path), "%s/gkoc_arena_dev%d_uid%u.lock", dir && *dir ? dir : "/tmp", dev,
+                 unsigned(getuid()));
+        fd = ::open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (fd < 0) return;
+        for (int tries = 0; tries < 2000; ++tries) {
+            if (::flock(fd, LOCK_EX | LOCK_NB) == 0) return;
+            ::usleep(10000);
+        }
+        ::close(fd);      // did not get it: go on without
+        fd = -1;
+    }
+    ~walk_turn()
+    {
+        if (fd >= 0) {
+            (void)::flock(fd, LOCK_UN);
+            ::close(fd);
+        }
+    }
+    walk_turn(const walk_turn&) = delete;
+    walk_turn& operator=(const walk_turn&) = delete;
+};
+
 hipError_t walk(device_arena& A, int dev, int want, int n_want)
 {
+    const walk_turn turn(dev);
     const size_t gr = granule_bytes();
     const hipMemAllocationProp prop = granule_prop(dev);
     std::vector<hipMemGenericAllocationHandle_t> skipped;

@@ -26,6 +26,10 @@ def _launch(mode, world, grid, timeout=600, extra_env=None):
            "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(grid)]
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    if world > 2:
+        # several ranks share ONE GPU here: each one's memory-class survey is kept short (they also take
+        # turns, csrc/arena.hip walk_turn) - the layout of the arena is not what these tests are about
+        env.setdefault("GKOC_ARENA_MAX_WALK", "24")
     for attempt in range(2):       # one retry: the rendezvous port can race
         cmd[cmd.index("--master-port") + 1] = str(_free_port())
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
@@ -95,6 +99,8 @@ def _bench(world, args, env_extra, timeout=1500):
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(world)] + args
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    if world > 2 and env.get("GKO_BENCH_BACKEND") == "gloo":
+        env.setdefault("GKOC_ARENA_MAX_WALK", "24")      # ranks sharing one GPU: short surveys (see _launch)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + "\n--- stderr ---\n" + p.stderr[-12000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -129,6 +135,7 @@ def test_bench_starts_its_own_ranks_and_the_line_has_every_key():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--grid", "64", "--steps", "3",
            "--warmup", "1", "--cg-iters", "10"]
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GKO_BENCH_BACKEND="gloo")
+    env.setdefault("GKOC_ARENA_MAX_WALK", "24")          # eight ranks on one GPU: short surveys (see _launch)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
