@@ -26,6 +26,7 @@
 #include <ginkgo/core/matrix/dense.hpp>
 #include <ginkgo/core/matrix/ell.hpp>
 #include <ginkgo/core/matrix/fbcsr.hpp>
+#include <ginkgo/core/matrix/scaled_permutation.hpp>
 #include <ginkgo/core/matrix/sellp.hpp>
 #include <ginkgo/core/preconditioner/jacobi.hpp>
 #include <ginkgo/core/solver/bicg.hpp>
@@ -1172,6 +1173,78 @@ int main(int argc, char** argv)
             w0->add_scaled_identity(ca, cb);
             w1->add_scaled_identity(gko::clone(hip, ca), gko::clone(hip, cb));
             CHECK(dist(gko::clone(ref, w1).get(), w0.get()) < 1e-15, "complex Dense::add_scaled_identity on hip");
+        }
+        // scaled permutations, the *_reuse forms of SpGEMM, Csr::add_scaled_identity, L1 Jacobi
+        {
+            using SPerm = gko::matrix::ScaledPermutation<ct, it>;
+            gko::array<it> pidx{ref, m};
+            gko::array<ct> pscale{ref, m};
+            for (gko::size_type i = 0; i < m; ++i) {
+                pidx.get_data()[i] = static_cast<it>((i * 7 + 5) % m);
+                pscale.get_data()[i] = ct{1.0 + 0.01 * (i % 13), 0.5 - 0.02 * (i % 7)};
+            }
+            auto sp0 = SPerm::create(ref, pscale, pidx);
+            auto sp1 = gko::clone(hip, sp0);
+            for (auto mode : {gko::matrix::permute_mode::symmetric, gko::matrix::permute_mode::rows,
+                              gko::matrix::permute_mode::columns, gko::matrix::permute_mode::inverse_symmetric,
+                              gko::matrix::permute_mode::inverse_rows, gko::matrix::permute_mode::inverse_columns}) {
+                CHECK(dist(dense_of(a1->scale_permute(sp1, mode)).get(), dense_of(a0->scale_permute(sp0, mode)).get()) <
+                          1e-15,
+                      "complex Csr::scale_permute on hip, mode " + std::to_string(static_cast<int>(mode)));
+            }
+            auto d0 = dense_of(a0);
+            auto d1 = gko::clone(hip, d0);
+            CHECK(dist(gko::clone(ref, d1->scale_permute(sp1, gko::matrix::permute_mode::symmetric)).get(),
+                       d0->scale_permute(sp0, gko::matrix::permute_mode::symmetric).get()) < 1e-15,
+                  "complex Dense::scale_permute on hip");
+            auto inv0 = sp0->compute_inverse();
+            auto inv1 = gko::clone(ref, sp1->compute_inverse());
+            auto cmp0 = sp0->compose(inv0);
+            auto cmp1 = gko::clone(ref, sp1->compose(sp1->compute_inverse()));
+            bool same = true;
+            double worst = 0;
+            for (gko::size_type i = 0; i < m; ++i) {
+                same = same && inv0->get_const_permutation()[i] == inv1->get_const_permutation()[i] &&
+                       cmp0->get_const_permutation()[i] == cmp1->get_const_permutation()[i];
+                worst = std::max(worst, std::abs(inv0->get_const_scaling_factors()[i] -
+                                                 inv1->get_const_scaling_factors()[i]));
+                worst = std::max(worst, std::abs(cmp0->get_const_scaling_factors()[i] -
+                                                 cmp1->get_const_scaling_factors()[i]));
+            }
+            CHECK(same && worst < 1e-15, "complex ScaledPermutation::compute_inverse / compose on hip");
+            // C = A A with reuse, then new values
+            auto r0 = a0->multiply_reuse(a0);
+            auto r1 = a1->multiply_reuse(a1);
+            CHECK(dist(dense_of(r1.first).get(), dense_of(r0.first).get()) < 1e-14, "complex Csr::multiply_reuse on hip");
+            auto sc = gko::initialize<CDense>({ct{0.5, 0.25}}, ref);
+            auto b0 = gko::clone(ref, a0);
+            auto b1 = gko::clone(hip, a0);
+            b0->scale(sc);
+            b1->scale(gko::clone(hip, sc));
+            r0.second.update_values(b0, a0, r0.first);
+            r1.second.update_values(b1, a1, r1.first);
+            CHECK(dist(dense_of(r1.first).get(), dense_of(r0.first).get()) < 1e-14,
+                  "complex multiply_reuse_info::update_values on hip");
+            auto al = gko::initialize<CDense>({ct{2.0, -1.0}}, ref), be = gko::initialize<CDense>({ct{0.5, 0.5}}, ref);
+            auto i0 = gko::clone(ref, a0);
+            auto i1 = gko::clone(hip, a0);
+            i0->add_scaled_identity(al, be);
+            i1->add_scaled_identity(gko::clone(hip, al), gko::clone(hip, be));
+            CHECK(dist(dense_of(i1).get(), dense_of(i0).get()) < 1e-15, "complex Csr::add_scaled_identity on hip");
+            auto x0 = CDense::create(ref, gko::dim<2>{m, 1});
+            for (gko::size_type i = 0; i < m; ++i) x0->at(i, 0) = ct{1.0 + 0.1 * (i % 5), 0.3 * (i % 3)};
+            for (gko::uint32 bs : {1u, 4u}) {
+                auto j0 = gko::preconditioner::Jacobi<ct, it>::build().with_max_block_size(bs).with_aggregate_l1(true)
+                              .on(ref)->generate(a0);
+                auto j1 = gko::preconditioner::Jacobi<ct, it>::build().with_max_block_size(bs).with_aggregate_l1(true)
+                              .on(hip)->generate(a1);
+                auto y0 = CDense::create(ref, gko::dim<2>{m, 1});
+                auto y1 = CDense::create(hip, gko::dim<2>{m, 1});
+                j0->apply(x0, y0);
+                j1->apply(gko::clone(hip, x0), y1);
+                CHECK(dist(gko::clone(ref, y1).get(), y0.get()) < 1e-14,
+                      "complex L1 Jacobi(" + std::to_string(bs) + ") on hip");
+            }
         }
         // Bicg + block-Jacobi: Jacobi::conj_transpose() of complex blocks
         {
