@@ -104,7 +104,8 @@ def cpu_baseline(grid, csr_host=None, budget_s=12.0):
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
             r = json.loads(line)
             return {"value": round(r["gbs"], 3), "unit": "GB/s", "cores": r["threads"],
-                    "kind": "reference (gko::OmpExecutor)", "cpu": _cpu_model(),
+                    "kind": "reference", "through": "gko::OmpExecutor of oracle/_ref (the unmodified reference)",
+                    "cpu": _cpu_model(),
                     "threads": f"{r['threads']} OpenMP threads = physical cores ({hw_threads} hardware "
                                "threads on the host), OMP_PROC_BIND=spread OMP_PLACES=cores",
                     "numa": "parallel first touch: matrix, b and c are written by the threads that "
