@@ -29,6 +29,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def _sig3(v, digits=3):
+    """significant digits, not decimals (a per-rank fraction of 4e-5 must not print as 0.0)"""
+    return float(f"{v:.{digits}g}")
+
+
 def spmv_algorithmic_bytes(n_rows, n_cols, nnz, val_bytes=8, idx_bytes=4):
     return nnz * (val_bytes + idx_bytes) + (n_rows + 1) * idx_bytes + \
         n_cols * val_bytes + n_rows * val_bytes
@@ -219,7 +224,7 @@ def ginkgo_api_bench(grid, steps, cg_iters):
             out.update({"through": "gko::HipExecutor (drop-in libginkgo_hip.so), gko::Timer",
                         "csr_apply_ms": r["csr_apply_ms"],
                         "csr_apply_gbs": round(nbytes / r["csr_apply_ms"] / 1e6, 1),
-                        "frac": round(nbytes / r["csr_apply_ms"] / 1e6 / HBM_PEAK_GBS, 4),
+                        "frac": _sig3(nbytes / r["csr_apply_ms"] / 1e6 / HBM_PEAK_GBS),
                         "cg_iters_per_s": r["cg_iters_per_s"], "cg_ms_per_iter": r["cg_ms_per_iter"],
                         "cg_iterations": r["cg_iterations"], "memory_classes": r["memory_classes"],
                         "fused_across_calls": False,
@@ -438,8 +443,8 @@ def matrix_bench(args):
                           "memory_classes_found": info["num_classes"],
                           "bytes": "CSR model of SURVEY 8(d): 12 nnz + 4 (n + 1) + 16 n, for every format"},
                "formats": formats, "cg": cg,
-               "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+               "roofline": {"bound": "hbm", "achieved": _sig3(achieved, 5), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": _sig3(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                             "kernel_ms": round(kernel_ms, 5),
                             "traffic_note": "counters are collected for the 256^3 headline only"},
                "cpu_baseline": {"value": None, "unit": "GB/s", "cores": None, "kind": None, "sample": None,
@@ -724,9 +729,9 @@ def main():
                        "index_type": "int32", "partition": f"{world} z-slab(s)",
                        **({"communicator": type(op.comm).__name__} if use_dist else {}),
                        "pct_hbm_peak": round(100 * gbs / (HBM_PEAK_GBS * world), 1)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "achieved": _sig3(achieved, 5),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "frac": _sig3(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
                          **({"traffic_over_algorithmic": round(traffic / per_gpu_bytes, 4)} if traffic else {}),
                          **({"traffic_counters": traffic_detail["counters_mean_per_launch"]}
@@ -744,8 +749,8 @@ def main():
             out["rank0_profile"] = dist_profile
             out["roofline"]["per_rank"] = [
                 {"rank": r, "kernel_ms": v[0],
-                 "achieved": round(per_gpu_bytes / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None,
-                 "frac": round(per_gpu_bytes / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 else None,
+                 "achieved": _sig3(per_gpu_bytes / (v[0] * 1e-3) / 1e9) if v[0] > 0 else None,
+                 "frac": _sig3(per_gpu_bytes / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if v[0] > 0 else None,
                  "memory_classes_found": int(v[1]), "search_ms": v[2], "granules_walked": int(v[3])}
                 for r, v in enumerate(per_rank)]
             out["roofline"]["traffic_note"] = ("counters are collected at N = 1 only (a rocprofv3 --pmc pass "

@@ -239,10 +239,18 @@ def test_cg_and_gmres_full_size_against_the_reference_omp_executor(gexec, big):
     # 128 cores this was written on; on a box that gives the test a few cores the same solve takes
     # an hour.  Past a projected 8 minutes the test keeps what it has shown - the iterates agree to
     # 1e-11 after 1, 10 and 100 iterations - and says so.
-    if per_it * 540 > 480:
-        print(f"reference OmpExecutor needs {per_it:.2f} s per CG iteration on this host: full solve and "
-              f"Gmres leg skipped (history after 1 / 10 / 100 iterations compared)")
-        return
+    full = os.environ.get("GKO_TEST_FULL_SOLVE") == "1" and per_it * 540 <= 480
+    if full:
+        _full_cg_solve_against_omp(g, gexec, a, ref, hip_cg, ones, r0)
+    else:
+        # the 474-iteration solve costs two minutes of HOST time (the reference on the CPU) and shows what
+        # the history already shows; GKO_TEST_FULL_SOLVE=1 runs it (done in rounds 2-4, profiles/r03_pytest_gpu_tail.txt)
+        print(f"reference OmpExecutor: {per_it:.2f} s per CG iteration on this host; history after 1 / 10 / 100 "
+              f"iterations compared, the full solve runs with GKO_TEST_FULL_SOLVE=1")
+    _gmres_60_against_omp(g, gexec, a, ref, ones)
+
+
+def _full_cg_solve_against_omp(g, gexec, a, ref, hip_cg, ones, r0):
     x, s = hip_cg(3000)
     xr, it_r, rn_r = ref.cg_solve(ones, max_iters=3000, reduction=1e-10, precond_block_size=8)
     assert s.has_converged and abs(s.num_iterations - it_r) <= 1, (s.num_iterations, it_r)
@@ -255,7 +263,9 @@ def test_cg_and_gmres_full_size_against_the_reference_omp_executor(gexec, big):
     print(f"CG + Jacobi(8) on 256^3: hip {s.num_iterations} iterations / reference (omp) {it_r}; "
           f"final ||r|| {rn_h:.6e} / {rn_r:.6e}; "
           f"||x_hip - x_ref|| / ||x_ref|| = {np.linalg.norm(xh - xr) / np.linalg.norm(xr):.2e}")
-    del x, xh, xr
+
+
+def _gmres_60_against_omp(g, gexec, a, ref, ones):
     # --- Gmres(30) + Jacobi(8), 60 iterations (gmres.cpp:321-621; MGS, the default)
     xg = g.Dense.from_numpy(gexec, np.zeros(N))
     sg = (g.Gmres.build().with_krylov_dim(30)
