@@ -13,12 +13,14 @@
 // RCCL is bound with dlopen/dlsym at run time: libgko_cdna4.so keeps no link
 // dependency on it and loads on machines without RCCL.
 #include <dlfcn.h>
+#include <time.h>
 
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
 
+#include "comm_ipc.hpp"
 #include "common.hpp"
 
 namespace {
@@ -161,6 +163,20 @@ struct gkoc_comm_s {
     bool pending_side = false;
     bool pending_reduce = false;
     hipStream_t side_in_use = nullptr;  // the stream that carries the pending operations
+    // ---- transport 1: mailboxes in peer-mapped memory (comm_ipc.hpp); comm == nullptr then
+    int transport = 0;
+    char* window = nullptr;             // this rank's window (exported)
+    size_t window_bytes = 0;
+    int64_t slot_bytes = 0;
+    bool window_uncached = false;
+    bool connected = false;
+    gkoc::ipc::peers_t peers{};         // every rank's window as mapped here
+    bool opened[gkoc::ipc::MAX_RANKS] = {};
+    uint32_t epoch = 0, reduces = 0;    // all-reduce: flag value and parity counter
+    uint32_t send_seq[gkoc::ipc::MAX_RANKS] = {}, recv_seq[gkoc::ipc::MAX_RANKS] = {};
+    uint32_t* done = nullptr;           // device: finished workgroups per message of the running exchange
+    uint32_t* status = nullptr;         // pinned host word the kernels OR their give-ups into
+    long long patience = 0;             // ticks of the 100 MHz clock
 };
 
 using namespace gkoc;
@@ -180,6 +196,123 @@ int comm_fork(gkoc_comm_s* comm, hipEvent_t ev, hipStream_t ms, hipStream_t xs)
     GKOC_HIP(hipEventRecord(ev, ms));
     GKOC_HIP(hipStreamWaitEvent(xs, ev, 0));
     return GKOC_OK;
+}
+}  // namespace
+
+// ---- transport 1 on the host side: numbering, chunking, launches --------------------------------
+namespace {
+namespace ipcx = gkoc::ipc;
+
+int ipc_all_reduce(gkoc_comm_s* c, hipStream_t st, void* buf, int64_t n, size_t value_size)
+{
+    GKOC_REQUIRE(c->connected, GKOC_E_INVALID, "communicator not connected (gkoc_comm_ipc_connect)");
+    const int64_t per_launch = int64_t(ipcx::LL_WORDS) * 4 / int64_t(value_size);
+    for (int64_t off = 0; off < n; off += per_launch) {
+        const int64_t cnt = (n - off < per_launch) ? (n - off) : per_launch;
+        ipcx::ar_args a;
+        a.peers = c->peers;
+        a.buf = static_cast<char*>(buf) + size_t(off) * value_size;
+        a.status = c->status;
+        a.patience = c->patience;
+        a.me = c->rank;
+        a.n_ranks = c->n_ranks;
+        a.n_words = int(cnt * int64_t(value_size) / 4);
+        a.value_size = int(value_size);
+        if (++c->epoch == 0) ++c->epoch;        // 0 is what an untouched slot holds
+        a.epoch = c->epoch;
+        a.parity = (c->reduces++) & 1u;
+        ipcx::all_reduce_kernel<<<dim3(1), dim3(256), 0, st>>>(a);
+        GKOC_LAUNCH_OK();
+    }
+    return GKOC_OK;
+}
+
+// one message -> its workgroups; returns the number of workgroups
+int ipc_plan(ipcx::msg_t& m, int peer, int64_t off, int64_t len, int first_wg, uint32_t seq)
+{
+    int n_wg = int((len + ipcx::MIN_CHUNK - 1) / ipcx::MIN_CHUNK);
+    if (n_wg < 1) n_wg = 1;
+    if (n_wg > ipcx::MAX_WG_PER_MSG) n_wg = ipcx::MAX_WG_PER_MSG;
+    int64_t chunk = (len + n_wg - 1) / n_wg;
+    chunk = (chunk + 15) / 16 * 16;
+    n_wg = int((len + chunk - 1) / chunk);
+    m.off = off;
+    m.len = len;
+    m.chunk = chunk;
+    m.first_wg = first_wg;
+    m.n_wg = n_wg;
+    m.peer = peer;
+    m.seq = seq;
+    return n_wg;
+}
+
+// bytes and byte offsets per peer on both sides; everything on `st`
+int ipc_exchange(gkoc_comm_s* c, hipStream_t st, const void* send_buf, const int64_t* send_bytes,
+                 const int64_t* send_off, void* recv_buf, const int64_t* recv_bytes, const int64_t* recv_off)
+{
+    GKOC_REQUIRE(c->connected, GKOC_E_INVALID, "communicator not connected (gkoc_comm_ipc_connect)");
+    ipcx::xchg_args a;
+    a.peers = c->peers;
+    a.send_base = static_cast<const char*>(send_buf);
+    a.recv_base = static_cast<char*>(recv_buf);
+    a.done = c->done;
+    a.status = c->status;
+    a.patience = c->patience;
+    a.slot_bytes = c->slot_bytes;
+    a.me = c->rank;
+    a.n_ranks = c->n_ranks;
+    a.n_send = a.n_recv = 0;
+    int swg = 0, rwg = 0;
+    for (int p = 0; p < c->n_ranks; ++p) {
+        GKOC_REQUIRE(send_bytes[p] <= c->slot_bytes && recv_bytes[p] <= c->slot_bytes, GKOC_E_NOT_SUPPORTED,
+                     "a message is larger than the window's slot per peer (GKOC_IPC_SLOT_MIB / slot_bytes of "
+                     "gkoc_comm_ipc_create)");
+    }
+    for (int p = 0; p < c->n_ranks; ++p) {
+        if (send_bytes[p] > 0) {
+            swg += ipc_plan(a.send[a.n_send++], p, send_off[p], send_bytes[p], swg, ++c->send_seq[p]);
+        }
+        if (recv_bytes[p] > 0) {
+            rwg += ipc_plan(a.recv[a.n_recv++], p, recv_off[p], recv_bytes[p], rwg, ++c->recv_seq[p]);
+        }
+    }
+    a.send_wgs = swg;
+    if (swg + rwg == 0) return GKOC_OK;
+    ipcx::exchange_kernel<<<dim3(unsigned(swg + rwg)), dim3(ipcx::COPY_THREADS), 0, st>>>(a);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+// the counts / displacements of gkoc_comm_exchange_begin (values, receive side packed in rank order)
+int ipc_exchange_counts(gkoc_comm_s* c, hipStream_t st, const void* send_buf, const int64_t* send_counts,
+                        const int64_t* send_displs, void* recv_buf, const int64_t* recv_counts, size_t value_size)
+{
+    int64_t sb[ipcx::MAX_RANKS], so[ipcx::MAX_RANKS], rb[ipcx::MAX_RANKS], ro[ipcx::MAX_RANKS];
+    int64_t spos = 0, rpos = 0;
+    for (int p = 0; p < c->n_ranks; ++p) {
+        sb[p] = send_counts[p] * int64_t(value_size);
+        rb[p] = recv_counts[p] * int64_t(value_size);
+        so[p] = send_displs ? send_displs[p] * int64_t(value_size) : spos;
+        ro[p] = rpos;
+        spos += sb[p];
+        rpos += rb[p];
+    }
+    return ipc_exchange(c, st, send_buf, sb, so, recv_buf, rb, ro);
+}
+
+void ipc_release(gkoc_comm_s* c)
+{
+    for (int p = 0; p < c->n_ranks && p < ipcx::MAX_RANKS; ++p) {
+        if (c->opened[p] && c->peers.win[p]) (void)hipIpcCloseMemHandle(c->peers.win[p]);
+        c->opened[p] = false;
+    }
+    if (c->window) (void)hipFree(c->window);
+    if (c->done) (void)hipFree(c->done);
+    if (c->status) (void)hipHostFree(c->status);
+    c->window = nullptr;
+    c->done = nullptr;
+    c->status = nullptr;
+    (void)hipGetLastError();
 }
 }  // namespace
 
@@ -284,9 +417,172 @@ int gkoc_comm_create(gkoc_comm_t* comm, int n_ranks, int rank, const void* id)
     return GKOC_OK;
 }
 
+// ---- transport 1: creation in two steps (the handles travel through whatever the host program has)
+int gkoc_comm_ipc_create(gkoc_comm_t* comm, int n_ranks, int rank, int64_t slot_bytes, void* handle_out)
+{
+    GKOC_REQUIRE(comm && handle_out, GKOC_E_INVALID, "comm or handle_out == NULL");
+    GKOC_REQUIRE(n_ranks >= 1 && n_ranks <= ipcx::MAX_RANKS && rank >= 0 && rank < n_ranks, GKOC_E_INVALID,
+                 "bad rank / n_ranks (at most 16 ranks)");
+    static_assert(sizeof(hipIpcMemHandle_t) <= GKOC_COMM_IPC_HANDLE_BYTES, "handle size");
+    if (slot_bytes <= 0) {
+        const char* e = std::getenv("GKOC_IPC_SLOT_MIB");
+        const long mib = e ? std::atol(e) : 0;
+        slot_bytes = int64_t(mib > 0 ? mib : 8) << 20;
+    }
+    slot_bytes = (slot_bytes + 255) / 256 * 256;
+    auto* c = new gkoc_comm_s;
+    c->transport = 1;
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    c->slot_bytes = slot_bytes;
+    c->window_bytes = ipcx::DATA_OFF + size_t(2) * size_t(n_ranks) * size_t(slot_bytes);
+    const char* pe = std::getenv("GKOC_IPC_PATIENCE_MS");
+    const long pms = pe ? std::atol(pe) : 0;
+    c->patience = (long long)(pms > 0 ? pms : 20000) * 100000ll;      // 100 MHz clock
+    // Uncached device memory (what RCCL takes for its own flags and buffers): a peer's stores are seen by
+    // this device's polling loads without relying on L2 behaviour; plain hipMalloc if that cannot be had
+    // or exported (GKOC_IPC_WINDOW=plain asks for it).
+    hipIpcMemHandle_t h;
+    std::memset(&h, 0, sizeof(h));
+    const char* wk = std::getenv("GKOC_IPC_WINDOW");
+    bool have = false;
+    if (!(wk && std::strcmp(wk, "plain") == 0)) {
+        void* w = nullptr;
+        if (hipExtMallocWithFlags(&w, c->window_bytes, hipDeviceMallocUncached) == hipSuccess) {
+            if (hipMemset(w, 0, c->window_bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+                hipIpcGetMemHandle(&h, w) == hipSuccess) {
+                c->window = static_cast<char*>(w);
+                c->window_uncached = true;
+                have = true;
+            } else {
+                (void)hipFree(w);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    if (!have) {
+        void* w = nullptr;
+        if (hipMalloc(&w, c->window_bytes) != hipSuccess || hipMemset(w, 0, c->window_bytes) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, w) != hipSuccess) {
+            set_last_error("gkoc_comm_ipc_create: cannot allocate / export a window of %zu bytes: %s", c->window_bytes,
+                           hipGetErrorString(hipGetLastError()));
+            if (w) (void)hipFree(w);
+            delete c;
+            return GKOC_E_COMM;
+        }
+        c->window = static_cast<char*>(w);
+    }
+    void* d = nullptr;
+    void* st = nullptr;
+    if (hipMalloc(&d, 2 * ipcx::MAX_RANKS * sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(d, 0, 2 * ipcx::MAX_RANKS * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc(&st, 64, hipHostMallocMapped) != hipSuccess ||
+        hipEventCreateWithFlags(&c->packed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->arrived, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->reduce_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->reduce_out, hipEventDisableTiming) != hipSuccess) {
+        set_last_error("gkoc_comm_ipc_create: %s", hipGetErrorString(hipGetLastError()));
+        c->done = static_cast<uint32_t*>(d);
+        c->status = static_cast<uint32_t*>(st);
+        ipc_release(c);
+        delete c;
+        return GKOC_E_COMM;
+    }
+    c->done = static_cast<uint32_t*>(d);
+    c->status = static_cast<uint32_t*>(st);
+    std::memset(c->status, 0, 64);
+    (void)hipDeviceSynchronize();
+    const char* fk = std::getenv("GKOC_COMM_FORK");
+    if (!(fk && std::strcmp(fk, "event") == 0)) {
+        void* w = nullptr;
+        if (gkoc_malloc(&w, 256) == GKOC_OK && hipMemset(w, 0, 256) == hipSuccess) {
+            c->fork_word = static_cast<uint32_t*>(w);
+        } else {
+            (void)hipGetLastError();
+            if (w) (void)gkoc_free(w);
+        }
+    }
+    std::memset(handle_out, 0, GKOC_COMM_IPC_HANDLE_BYTES);
+    std::memcpy(handle_out, &h, sizeof(h));
+    *comm = c;
+    return GKOC_OK;
+}
+
+int gkoc_comm_ipc_connect(gkoc_comm_t comm, const void* handles)
+{
+    GKOC_REQUIRE(comm && handles && comm->transport == 1, GKOC_E_INVALID, "not a mailbox communicator");
+    GKOC_REQUIRE(!comm->connected, GKOC_E_INVALID, "already connected");
+    const char* hb = static_cast<const char*>(handles);
+    for (int p = 0; p < comm->n_ranks; ++p) {
+        if (p == comm->rank) {
+            comm->peers.win[p] = comm->window;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, hb + size_t(p) * GKOC_COMM_IPC_HANDLE_BYTES, sizeof(h));
+        void* w = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&w, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            set_last_error("gkoc_comm_ipc_connect: hipIpcOpenMemHandle of rank %d's window failed: %s "
+                           "(HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment? peer access between the devices?)",
+                           p, hipGetErrorString(e));
+            (void)hipGetLastError();
+            return GKOC_E_COMM;
+        }
+        comm->peers.win[p] = static_cast<char*>(w);
+        comm->opened[p] = true;
+    }
+    comm->connected = true;
+    return GKOC_OK;
+}
+
+int gkoc_comm_status(gkoc_comm_t comm, uint32_t* status)
+{
+    GKOC_REQUIRE(comm && status, GKOC_E_INVALID, "bad argument");
+    *status = comm->status ? __atomic_load_n(comm->status, __ATOMIC_RELAXED) : 0u;
+    return GKOC_OK;
+}
+
+int gkoc_comm_transport(gkoc_comm_t comm, int* transport, int* window_uncached)
+{
+    GKOC_REQUIRE(comm && transport, GKOC_E_INVALID, "bad argument");
+    *transport = comm->transport;
+    if (window_uncached) *window_uncached = comm->window_uncached ? 1 : 0;
+    return GKOC_OK;
+}
+
 int gkoc_comm_destroy(gkoc_comm_t comm)
 {
     if (!comm) return GKOC_OK;
+    if (comm->transport == 1) {
+        (void)hipDeviceSynchronize();
+        // a peer acknowledges my last message AFTER my kernel has ended: its store must find the window
+        // alive - wait (a moment) until every message I sent has been acknowledged
+        if (comm->connected && comm->window) {
+            for (int p = 0; p < comm->n_ranks; ++p) {
+                if (comm->send_seq[p] == 0) continue;
+                for (int tries = 0; tries < 2000; ++tries) {
+                    uint32_t a = 0;
+                    if (hipMemcpy(&a, comm->window + ipcx::ACKS_OFF + size_t(p) * ipcx::FLAG_STRIDE, sizeof(a),
+                                  hipMemcpyDeviceToHost) != hipSuccess) {
+                        break;
+                    }
+                    if (int32_t(a - comm->send_seq[p]) >= 0) break;
+                    struct timespec ts = {0, 1000000};
+                    nanosleep(&ts, nullptr);
+                }
+            }
+        }
+        if (comm->fork_word) (void)gkoc_free(comm->fork_word);
+        if (comm->packed) (void)hipEventDestroy(comm->packed);
+        if (comm->arrived) (void)hipEventDestroy(comm->arrived);
+        if (comm->reduce_in) (void)hipEventDestroy(comm->reduce_in);
+        if (comm->reduce_out) (void)hipEventDestroy(comm->reduce_out);
+        ipc_release(comm);
+        delete comm;
+        (void)hipGetLastError();
+        return GKOC_OK;
+    }
     if (comm->fork_word) {
         (void)hipDeviceSynchronize();
         (void)gkoc_free(comm->fork_word);
@@ -315,6 +611,12 @@ int gkoc_comm_all_reduce_sum(gkoc_comm_t comm, gkoc_stream_t s, void* buf, int64
     GKOC_REQUIRE(comm && buf && n >= 0, GKOC_E_INVALID, "bad argument");
     GKOC_REQUIRE(value_size == 8 || value_size == 4, GKOC_E_NOT_SUPPORTED, "value_size must be 4 or 8");
     if (n == 0) return GKOC_OK;
+    if (comm->transport == 1) {
+        GKOC_REQUIRE(!(comm->pending_side || comm->pending_reduce) || as_stream(s) == comm->side_in_use,
+                     GKOC_E_INVALID, "gkoc_comm_all_reduce_sum on another stream while an overlapped "
+                                     "exchange / all-reduce is pending (end it first)");
+        return ipc_all_reduce(comm, as_stream(s), buf, n, value_size);
+    }
     // One communicator, one order of operations on every rank: while an overlapped operation is
     // pending on the side stream, a collective on ANOTHER stream would reach RCCL in an order
     // that depends on timing (a hang, not a wrong number) - refuse it.
@@ -341,10 +643,18 @@ int gkoc_comm_all_reduce_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc
     hipStream_t xs = overlapped ? as_stream(side) : ms;
     GKOC_REQUIRE(!comm->pending_side || xs == comm->side_in_use, GKOC_E_INVALID,
                  "gkoc_comm_all_reduce_begin: an exchange is pending on another stream");
-    if (overlapped) GKOC_TRY(comm_fork(comm, comm->reduce_in, ms, xs));
-    GKOC_RCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n),
-                               value_size == 8 ? nccl_float64 : nccl_float32, nccl_sum, comm->comm,
-                               xs));
+    if (overlapped) {
+        GKOC_TRY(comm_fork(comm, comm->reduce_in, ms, xs));
+    } else {
+        comm->fork_deferred = false;     // a fork handed out for an overlapped begin is void now
+    }
+    if (comm->transport == 1) {
+        GKOC_TRY(ipc_all_reduce(comm, xs, buf, n, value_size));
+    } else {
+        GKOC_RCCL(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n),
+                                   value_size == 8 ? nccl_float64 : nccl_float32, nccl_sum, comm->comm,
+                                   xs));
+    }
     if (overlapped) {
         GKOC_HIP(hipEventRecord(comm->reduce_out, xs));
         comm->pending_reduce = true;
@@ -388,7 +698,20 @@ int gkoc_comm_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_stream, gkoc_s
     GKOC_REQUIRE(send_buf && recv_buf, GKOC_E_INVALID, "NULL buffer with non-zero counts");
     GKOC_REQUIRE(!comm->pending_reduce || xs == comm->side_in_use, GKOC_E_INVALID,
                  "gkoc_comm_exchange_begin: an all-reduce is pending on another stream");
-    if (overlapped) GKOC_TRY(comm_fork(comm, comm->packed, ms, xs));
+    if (overlapped) {
+        GKOC_TRY(comm_fork(comm, comm->packed, ms, xs));
+    } else {
+        comm->fork_deferred = false;     // a fork handed out for an overlapped begin is void now
+    }
+    if (comm->transport == 1) {
+        GKOC_TRY(ipc_exchange_counts(comm, xs, send_buf, send_counts, send_displs, recv_buf, recv_counts, value_size));
+        if (overlapped) {
+            GKOC_HIP(hipEventRecord(comm->arrived, xs));
+            comm->pending_side = true;
+            comm->side_in_use = xs;
+        }
+        return GKOC_OK;
+    }
     const char* sp = static_cast<const char*>(send_buf);
     char* rp = static_cast<char*>(recv_buf);
     GKOC_RCCL(g_rccl.GroupStart());
@@ -445,6 +768,17 @@ int gkoc_comm_all_reduce_exchange_begin(gkoc_comm_t comm, gkoc_stream_t main_str
     }
     GKOC_REQUIRE(n_msgs == 0 || (send_buf && recv_buf), GKOC_E_INVALID, "NULL buffer with non-zero counts");
     GKOC_TRY(comm_fork(comm, comm->packed, ms, xs));
+    if (comm->transport == 1) {
+        GKOC_TRY(ipc_all_reduce(comm, xs, reduce_buf, reduce_n, reduce_value_size));
+        if (n_msgs > 0) {
+            GKOC_TRY(ipc_exchange_counts(comm, xs, send_buf, send_counts, send_displs, recv_buf, recv_counts,
+                                         value_size));
+        }
+        GKOC_HIP(hipEventRecord(comm->arrived, xs));
+        comm->pending_side = true;
+        comm->side_in_use = xs;
+        return GKOC_OK;
+    }
     GKOC_RCCL(g_rccl.AllReduce(reduce_buf, reduce_buf, static_cast<size_t>(reduce_n),
                                reduce_value_size == 8 ? nccl_float64 : nccl_float32, nccl_sum, comm->comm, xs));
     if (n_msgs > 0) {
@@ -518,6 +852,9 @@ int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* 
                      GKOC_E_INVALID, "negative count or offset");
     }
     const int me = comm->rank;
+    if (comm->transport == 1) {
+        return ipc_exchange(comm, st, send_buf, send_bytes, send_offsets, recv_buf, recv_bytes, recv_offsets);
+    }
     if (send_bytes[me] > 0) {
         GKOC_REQUIRE(send_bytes[me] == recv_bytes[me], GKOC_E_INVALID, "self message sizes differ");
         GKOC_HIP(hipMemcpyAsync(rp + recv_offsets[me], sp + send_offsets[me], size_t(send_bytes[me]),

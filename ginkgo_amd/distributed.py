@@ -290,6 +290,82 @@ class RcclComm(TorchComm):
         return None
 
 
+class IpcComm(RcclComm):
+    """The same device-resident data path on the library's OWN transport (csrc/comm_ipc.hpp):
+    mailboxes in peer-mapped device memory instead of RCCL.  An all-reduce is one kernel - every
+    rank stores its values into every peer's window and sums what arrived in its own in rank order
+    (same bits on every rank, every run); a halo exchange is one kernel that copies the boundary
+    planes into the neighbours' windows and the neighbours' planes out of its own.  Stands where
+    the reference lets a collective_communicator be chosen
+    (include/ginkgo/core/distributed/collective_communicator.hpp:31-71).  Works between
+    processes that SHARE one GPU (RCCL does not), so the whole N > 1 device path - forks, side
+    stream, gated one-kernel product, pipelined solver steps - runs on a one-GPU box.
+    torch.distributed only carries the 64-byte window handles (all_gather) at set-up."""
+
+    def __init__(self, exec_, group=None, slot_bytes=0):
+        TorchComm.__init__(self, group)
+        self.exec = exec_
+        dev = torch.device("cpu") if self.host_staging else exec_.device
+
+        def agree(ok, what):
+            if self.size > 1:
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok = bool(flag.item())
+            if not ok:
+                raise GkoError(f"IpcComm: {what} failed on at least one rank: "
+                               + lib().gkoc_last_error().decode(errors="replace"))
+
+        self._handle = C.c_void_p(0)
+        mine = (C.c_uint8 * 64)()
+        rc = lib().gkoc_comm_ipc_create(C.byref(self._handle), C.c_int(self.size), C.c_int(self.rank),
+                                        C.c_int64(int(slot_bytes)), mine)
+        try:
+            agree(rc == 0 and not _inject_failure("load", self.rank), "creating / exporting the window")
+            t = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
+            if self.size > 1:
+                outs = [torch.empty_like(t) for _ in range(self.size)]
+                dist.all_gather(outs, t, group=group)
+            else:
+                outs = [t]
+            everybody = (C.c_uint8 * (64 * self.size))(*[int(v) for o in outs for v in o.cpu().tolist()])
+            rc = lib().gkoc_comm_ipc_connect(self._handle, everybody)
+            agree(rc == 0 and not _inject_failure("init", self.rank), "mapping the peers' windows")
+        except GkoError:
+            self.close(barrier=False)
+            raise
+        self._cnt = {}
+        tr, unc = C.c_int(0), C.c_int(0)
+        call("gkoc_comm_transport", self._handle, C.byref(tr), C.byref(unc))
+        self.window_uncached = bool(unc.value)
+
+    def close(self, barrier=True):
+        """collective: no rank unmaps its window while a peer may still write into it"""
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            if barrier and self.size > 1 and dist.is_initialized():
+                torch.cuda.synchronize(self.exec.device)
+                try:
+                    dist.barrier(group=self.group)
+                except Exception:          # noqa: BLE001 - the group may be gone at interpreter exit
+                    pass
+            call("gkoc_comm_destroy", self._handle)
+            self._handle = C.c_void_p(0)
+
+    def status(self):
+        """0, or the bits of the waits that ran out of patience (gkoc_comm_status)"""
+        st = C.c_uint32(0)
+        call("gkoc_comm_status", self._handle, C.byref(st))
+        return int(st.value)
+
+    def check(self):
+        super().check()
+        self.exec.synchronize()
+        st = self.status()
+        if st:
+            raise GkoError(f"IpcComm: a kernel of the mailbox transport stopped waiting for a peer (status {st:#x}: "
+                           "1 all-reduce, 2 message, 4 acknowledgement) - the results since are not to be trusted")
+
+
 def _inject_failure(stage, rank):
     """GKO_COMM_INJECT_FAIL="<rank>:<stage>" (tests only): make `stage` of the communicator
     bring-up fail on `rank` so that the all-ranks-together fallback can be exercised"""
@@ -301,30 +377,21 @@ def _inject_failure(stage, rank):
     return st == stage and r.isdigit() and int(r) == rank
 
 
-def default_comm(exec_, group=None):
-    """The communicator of the product path: RcclComm when the process group runs
-    on RCCL and the library's own communicator comes up and passes a known-answer
-    all-reduce on every rank; otherwise (gloo, one rank, GKO_COMM=torch, or any
-    failure - reported on stderr) torch.distributed itself.  Every decision is taken
-    by ALL ranks together (a MIN all-reduce of "it worked here"), so a rank on which
-    the bring-up fails never leaves the others inside a collective.
-    GKO_COMM=rccl forces the attempt also when the process group is gloo (tests)."""
-    import os
+def _try_comm(cls, exec_, base, group):
+    """bring `cls` up and put a known-answer all-reduce through it; every decision is taken by ALL
+    ranks together (a MIN all-reduce of "it worked here"); returns the communicator or None"""
     import sys
-    base = TorchComm(group)
-    want = os.environ.get("GKO_COMM", "")
-    if base.size == 1 or want == "torch" or (base.host_staging and want != "rccl"):
-        return base
     ok, comm = True, None
     try:
-        comm = RcclComm(exec_, group)
+        comm = cls(exec_, group)
         t = torch.full((2,), float(comm.rank + 1), dtype=torch.float64, device=exec_.device)
         comm.all_reduce_sum_(t)
         want_v = comm.size * (comm.size + 1) / 2
         ok = bool((t == want_v).all().item()) and not _inject_failure("answer", base.rank)
-    except Exception as e:        # noqa: BLE001 - any failure means "use torch.distributed"
-        print(f"[ginkgo_amd] rank {base.rank}: RcclComm unavailable, using torch.distributed: {e}",
-              file=sys.stderr)
+        if ok and hasattr(comm, "status"):
+            ok = comm.status() == 0
+    except Exception as e:        # noqa: BLE001 - any failure means "not this one"
+        print(f"[ginkgo_amd] rank {base.rank}: {cls.__name__} unavailable: {e}", file=sys.stderr)
         ok = False
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
                         device=torch.device("cpu") if base.host_staging else exec_.device)
@@ -332,14 +399,89 @@ def default_comm(exec_, group=None):
     if bool(flag.item()):
         return comm
     if ok:
-        print(f"[ginkgo_amd] rank {base.rank}: RcclComm is fine here but failed on another rank; "
-              "all ranks use torch.distributed", file=sys.stderr)
+        print(f"[ginkgo_amd] rank {base.rank}: {cls.__name__} is fine here but failed on another rank",
+              file=sys.stderr)
     if comm is not None:
         try:
-            comm.close()
+            comm.close(barrier=False) if isinstance(comm, IpcComm) else comm.close()
         except Exception:          # noqa: BLE001
             pass
-    return base
+    return None
+
+
+def _iteration_cost_us(exec_, comm, n_elems, reps=30):
+    """what one Cg iteration asks of the communicator - two 2-value all-reduces and one neighbour
+    exchange of n_elems values - in microseconds, MAX over the ranks"""
+    import time
+    rank, size, dev = comm.rank, comm.size, exec_.device
+    side = torch.cuda.Stream(device=dev)
+    t = torch.ones(2, dtype=torch.float64, device=dev)
+    peers = [p for p in (rank - 1, rank + 1) if 0 <= p < size]
+    counts = [n_elems if p in peers else 0 for p in range(size)]
+    send = torch.ones(n_elems * len(peers), dtype=torch.float64, device=dev)
+    recv = torch.zeros(n_elems * len(peers), dtype=torch.float64, device=dev)
+    for k in range(reps + 3):
+        if k == 3:
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+        comm.all_reduce_sum_(t)
+        comm.exchange_begin(recv, send, counts, counts, side)
+        comm.exchange_end()
+        comm.all_reduce_sum_(t)
+        t.fill_(1.0)
+    torch.cuda.synchronize(dev)
+    us = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], dtype=torch.float64,
+                      device=torch.device("cpu") if comm.host_staging else dev)
+    dist.all_reduce(us, op=dist.ReduceOp.MAX, group=comm.group)
+    return float(us.item())
+
+
+def default_comm(exec_, group=None, halo_elems=65536):
+    """The communicator of the product path.  Device-resident candidates: IpcComm (the library's
+    mailboxes in peer-mapped memory) and RcclComm (RCCL over xGMI through the C ABI).  Each one
+    that comes up and passes a known-answer all-reduce on EVERY rank is timed on what a Cg
+    iteration asks of it (two 2-value all-reduces + one halo exchange of `halo_elems` values, max
+    over ranks) and the faster one is taken; none (gloo, one rank, GKO_COMM=torch, or failures -
+    reported on stderr): torch.distributed itself.  Every decision is taken by all ranks together.
+    GKO_COMM = ipc | rccl | torch forces one; with a gloo process group (ranks sharing one GPU in
+    tests) only a forced ipc / rccl is tried.  The choice and the timings are kept in
+    `default_comm.last` for the bench line."""
+    import os
+    import sys
+    base = TorchComm(group)
+    want = os.environ.get("GKO_COMM", "")
+    default_comm.last = {"chosen": "TorchComm", "why": "one rank" if base.size == 1 else f"GKO_COMM={want or 'auto'}"}
+    if base.size == 1 or want == "torch" or (base.host_staging and want not in ("rccl", "ipc")):
+        return base
+    classes = {"ipc": [IpcComm], "rccl": [RcclComm]}.get(want, [IpcComm, RcclComm])
+    up = [c for c in (_try_comm(cls, exec_, base, group) for cls in classes) if c is not None]
+    if not up:
+        default_comm.last = {"chosen": "TorchComm", "why": "no device-resident communicator came up"}
+        return base
+    if len(up) == 1:
+        default_comm.last = {"chosen": type(up[0]).__name__, "why": "the only one that came up" if not want else f"GKO_COMM={want}"}
+        return up[0]
+    costs = {}
+    for c in up:
+        try:
+            with _Watchdog(120.0, f"timing {type(c).__name__}"):
+                costs[type(c).__name__] = round(_iteration_cost_us(exec_, c, halo_elems), 1)
+        except Exception as e:        # noqa: BLE001
+            print(f"[ginkgo_amd] rank {base.rank}: timing {type(c).__name__} failed: {e}", file=sys.stderr)
+            costs[type(c).__name__] = float("inf")
+    best = min(up, key=lambda c: costs[type(c).__name__])      # the costs are max-over-ranks: same choice everywhere
+    for c in up:
+        if c is not best:
+            try:
+                c.close()
+            except Exception:          # noqa: BLE001
+                pass
+    default_comm.last = {"chosen": type(best).__name__, "why": "faster on one Cg iteration's communication",
+                         "iteration_comm_us": costs, "halo_elems": halo_elems}
+    return best
+
+
+default_comm.last = {}
 
 
 class _Watchdog:

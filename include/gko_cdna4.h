@@ -2209,6 +2209,35 @@ int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* 
                                  void* recv_buf, const int64_t* recv_bytes,
                                  const int64_t* recv_offsets);
 
+/* ---- the communicator's second transport: mailboxes in peer-mapped device memory (hipIpc) -----
+ * The same gkoc_comm_* operations without RCCL: every rank owns a WINDOW (one device allocation) that
+ * all peers map; an all-reduce is every rank storing its values (8-byte words carrying 4 bytes of data
+ * and the operation's number) into every peer's window and summing, IN RANK ORDER, what it finds in
+ * its own - one hop over xGMI, one kernel, the same bits on every rank and in every run; an exchange
+ * is the sender copying its segment into its slot of the receiver's window followed by a flag, and
+ * the receiver copying it out (csrc/comm_ipc.hpp).  It answers the latency question of the Krylov
+ * loop (two 8-byte all-reduces per Cg iteration) and stands where the reference lets a
+ * collective_communicator be chosen (include/ginkgo/core/distributed/collective_communicator.hpp:31-71).
+ * Several processes on ONE device can form such a communicator (RCCL refuses that), which is how the
+ * whole N > 1 device path is tested on a one-GPU box.
+ *   1. every rank: gkoc_comm_ipc_create -> its 64-byte handle;   slot_bytes: room per peer and
+ *      direction for one message (0: GKOC_IPC_SLOT_MIB or 8 MiB); at most 16 ranks
+ *   2. the host program gathers all handles in rank order (MPI_Allgather, a key-value store)
+ *   3. every rank: gkoc_comm_ipc_connect(all handles)
+ * after which every gkoc_comm_* call above works as documented (messages larger than slot_bytes:
+ * GKOC_E_NOT_SUPPORTED).  Waiting kernels have a patience (GKOC_IPC_PATIENCE_MS, default 20000): a
+ * wait that runs out sets a bit in the status word and the kernel ends; gkoc_comm_status reads it
+ * (no synchronisation; 0 = nothing ever timed out; bit 0 all-reduce, bit 1 a message, bit 2 an
+ * acknowledgement).  gkoc_comm_destroy must be entered by a rank only after its peers have completed
+ * the operations it takes part in (a host barrier, or the end of the solve). */
+#define GKOC_COMM_IPC_HANDLE_BYTES 64
+int gkoc_comm_ipc_create(gkoc_comm_t* comm, int n_ranks, int rank, int64_t slot_bytes,
+                         void* handle_out /* GKOC_COMM_IPC_HANDLE_BYTES */);
+int gkoc_comm_ipc_connect(gkoc_comm_t comm, const void* handles /* n_ranks x GKOC_COMM_IPC_HANDLE_BYTES */);
+int gkoc_comm_status(gkoc_comm_t comm, uint32_t* status);
+/* *transport: 0 = RCCL, 1 = mailboxes; *window_uncached (may be NULL): the window is uncached device memory */
+int gkoc_comm_transport(gkoc_comm_t comm, int* transport, int* window_uncached);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,10 @@ def main():
         import ginkgo_amd as g
         ex = g.Cdna4Executor.create(0)
         be = gd.HipBackend(ex)
+        if mode == "gpu-ipc":
+            # the library's own transport between the processes sharing cuda:0: everything the
+            # device-resident path does at N > 1 (forks, side stream, gated product) runs for real
+            comm = gd.IpcComm(ex)
         planes = gd.Partition.build_from_global_size_uniform(world, grid).offsets
         owned = g.stencil_csr(ex, 3, grid, z0=planes[rank], nz=planes[rank + 1] - planes[rank])
         assert np.array_equal(owned.col_idxs.cpu().numpy(), ci[rp[lo]:rp[hi]])
@@ -163,6 +167,11 @@ def main():
     #     indices, uneven part sizes) - nothing slab-specific may be assumed
     irregular_case(mode, o, gd, be, comm, rank, world)
     flan_case(mode, o, gd, be, comm, rank, world)
+    if mode == "gpu-ipc":
+        if grid % 8 == 0:
+            assert a._gate is not None, "the one-kernel gated product was not taken on the device-resident transport"
+        comm.check()
+        comm.close()
     dist.barrier()
     if rank == 0:
         print(f"dist_worker OK mode={mode} world={world} grid={grid} iters={solver.num_iterations}")

@@ -1,0 +1,59 @@
+"""The communicator's own transport (mailboxes in peer-mapped device memory, csrc/comm_ipc.hpp) with
+2 - 8 PROCESSES sharing cuda:0: hipIpc maps the windows between processes on one device exactly as it
+does between devices, so the kernels, the numbering, the flow control and the whole device-resident
+N > 1 path of the solvers (forks, side stream, one-kernel gated product, PipeCg's gated steps) run for
+real on a one-GPU box.  What is not shown here is xGMI itself.
+Reference seams: collective_communicator.hpp:31-71, core/distributed/vector.cpp:473-592 (reductions),
+core/distributed/matrix.cpp:450-509 (exchange || local product)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from util import record_perf
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(script, world, args, timeout=600, extra_env=None):
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GKOC_IPC_PATIENCE_MS="8000",
+               **(extra_env or {}))
+    env.setdefault("GKOC_ARENA_MAX_WALK", "24")          # ranks sharing one GPU: short surveys
+    for attempt in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "tests", script), *args]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+        if p.returncode == 0:
+            break
+    assert p.returncode == 0, p.stdout[-3000:] + "\n--- stderr ---\n" + p.stderr[-12000:]
+    return p.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_mailbox_collectives_against_their_definition(world):
+    out = _run("ipc_worker.py", world, ["collectives"])
+    assert "ipc_worker OK" in out
+    rep = json.loads([ln for ln in out.splitlines() if ln.startswith("IPC_REPORT ")][-1][len("IPC_REPORT "):])
+    assert rep["ranks"] == world
+    record_perf("mailbox_collectives_one_gpu", **rep)
+
+
+@pytest.mark.parametrize("world,grid", [(2, 16), (3, 9), (8, 32)])
+def test_distributed_solvers_on_the_mailbox_transport(world, grid):
+    """tests/dist_worker.py with the device-resident communicator: distributed SpMV with the bits of the
+    single-domain oracle (one-kernel gated product), DistributedCg / PipeCg / Gmres against the oracle's
+    solves, irregular partition, Flan-like matrix in CSR and SELL-P"""
+    out = _run("dist_worker.py", world, ["gpu-ipc", str(grid)], timeout=1200)
+    assert "dist_worker OK" in out
