@@ -392,6 +392,7 @@ def matrix_bench(args):
         be = gd.HipBackend(ex)
         part = gd.Partition(offsets)
         comm_check = gd.comm_self_check(ex, comm, n_elems=4096)
+        comm_check["transport_choice"] = dict(gd.default_comm.last)
         for name_ in ("csr", "sellp"):
             dm = gd.DistributedMatrix(be, comm, part, owned, local_format=name_)
             ok, why = dm.self_check()          # one-kernel product vs join-based one, all ranks agree
@@ -590,6 +591,9 @@ def main():
         # known-answer test of every collective form the solvers use + their latencies here;
         # wrong data raises on all ranks, a hang ends the job with a message (not a timeout)
         comm_check = gd.comm_self_check(ex, op.comm, n_elems=grid * grid)
+        # which transport carries the data path and what each candidate cost on one Cg iteration's
+        # communication (IpcComm: the library's mailboxes in peer-mapped memory; RcclComm: RCCL)
+        comm_check["transport_choice"] = dict(gd.default_comm.last)
         # the one-kernel product (boundary waves that wait for their halo inside the kernel) against
         # the join-based one on THIS communicator before anything is timed; a rank that sees a
         # difference, a wave that gave up or a fork that timed out sends ALL ranks to the join-based

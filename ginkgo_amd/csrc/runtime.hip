@@ -361,8 +361,28 @@ int gkoc_memcpy_d2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s)
     if (bytes == 0) return GKOC_OK;
     // a scalar or two (a reduction's result handed on): one wave of our own instead of the
     // runtime's copy path
+    // - only where a kernel on the CURRENT device may dereference both pointers: with several devices in
+    // the process (HipExecutor::raw_copy_to between two executors, hip/base/executor.hip.cpp:150-190
+    // uses hipMemcpyPeerAsync there) both must be device memory of this device; nothing here enables
+    // peer access, so everything else takes the runtime's copy
+    static const int n_devices = [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) n = 2;
+        (void)hipGetLastError();
+        return n;
+    }();
+    auto local_device_memory = [](const void* p) {
+        hipPointerAttribute_t a;
+        int dev = -1;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess || hipGetDevice(&dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return a.type == hipMemoryTypeDevice && a.device == dev;
+    };
     if (bytes <= 256 && bytes % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 &&
-        reinterpret_cast<uintptr_t>(src) % 4 == 0) {
+        reinterpret_cast<uintptr_t>(src) % 4 == 0 &&
+        (n_devices == 1 || (local_device_memory(dst) && local_device_memory(src)))) {
         gkoc::small_copy_kernel<<<dim3(1), dim3(64), 0, as_stream(s)>>>(
             static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), int(bytes / 4));
         GKOC_LAUNCH_OK();

@@ -1775,7 +1775,7 @@ class DistributedStencil:
 
     def __init__(self, exec_, part, rank, comm=None):
         self.exec, self.part, self.rank = exec_, part, rank
-        self.comm = comm or default_comm(exec_)
+        self.comm = comm or default_comm(exec_, halo_elems=part.grid ** 2)
         z0, z1 = part.plane_offsets[rank], part.plane_offsets[rank + 1]
         owned = stencil_csr(exec_, 3, part.grid, z0=z0, nz=z1 - z0)
         self.backend = HipBackend(exec_)

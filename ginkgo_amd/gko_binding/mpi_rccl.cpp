@@ -283,14 +283,17 @@ int route_of(MPI_Comm comm, const void* sendbuf, bool send_empty, const void* re
 {
     if (env_mode() == 3) return route_mpi;
     const bool sdev = is_device(sendbuf), rdev = is_device(recvbuf);
-    comm_state* st;
+    mode m;
+    int size;
     {
         std::lock_guard<std::mutex> g(g_mtx);
-        st = &state_of(comm);       // collective on first use: every rank is here
+        const comm_state& st = state_of(comm);       // collective on first use: every rank is here
+        m = st.m;                                     // (read under the lock: the map may be rebalanced by
+        size = st.size;                               // another thread's first use of another communicator)
     }
-    if (st->m != mode::rccl || st->size == 1) {
+    if (m != mode::rccl || size == 1) {
         // every route left is the MPI call itself: a local matter
-        if (st->m == mode::rccl && sdev && rdev) return route_rccl;
+        if (m == mode::rccl && sdev && rdev) return route_rccl;
         return (sdev || rdev) ? route_staged : route_mpi;
     }
     int mine[2] = {((!sdev && !send_empty) || (!rdev && !recv_empty)) ? 1 : 0, (sdev || rdev) ? 1 : 0};

@@ -130,6 +130,19 @@ def test_bench_command_path_with_eight_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_command_path_on_the_device_resident_transport():
+    """the same command with GKO_COMM=ipc: the eight ranks sharing cuda:0 talk through the library's
+    mailbox transport, so bench.py's N > 1 path is the DEVICE-RESIDENT one the 8-GPU run takes (forks,
+    side stream, one-kernel gated product, PipeCg with gated steps) - not the host-staged gloo one"""
+    d = _bench(8, ["--steps", "3", "--warmup", "1", "--grid", "32", "--cg-iters", "20", "--pipe-cg"],
+               {"GKO_BENCH_BACKEND": "gloo", "GKO_COMM": "ipc", "GKOC_IPC_PATIENCE_MS": "8000"})
+    assert d["n_gpus"] == 8 and d["cg_iterations"] == 20 and d["pipe_cg_iterations"] == 20
+    assert d["comm_check"]["communicator"] == "IpcComm" and d["comm_check"]["transport_choice"]["chosen"] == "IpcComm"
+    assert d["distributed_product"]["one_kernel_product"], d["distributed_product"]
+    record_perf("bench_eight_ranks_one_gpu_mailbox", comm_check=d["comm_check"], cg_iters_per_s=d["cg_iters_per_s"])
+
+
+@pytest.mark.gpu
 def test_bench_starts_its_own_ranks_and_the_line_has_every_key():
     """`python bench.py --gpus 8 ...` WITHOUT a launcher: the script starts
     its ranks itself; the N > 1 line carries cpu_baseline (the N = 1 figure, labelled), the per-rank
