@@ -244,7 +244,11 @@ int launch_csr_gated(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I
         n_rows, n_int + n_bnd, 1, row_ptrs, col_idxs, vals, b, 1, c, 1, 1, nullptr, nullptr, partial, 0, \
         nullptr, nullptr, head_rows, tail_rows, gate, epoch, bnd_ptrs, bnd_cols, bnd_vals, fork_word,    \
         fork_number, gate_fence, bnd_first)
-    const int gate_fence = tune_value(GKOC_TUNE_GATE_FENCE) != 0 ? 1 : 0;
+    // the cheap gate (no agent-scope acquire for a wave that did not wait) rests on the halo lying on
+    // 128-byte lines of its own: b on a line boundary and the halo at a multiple of 128 bytes behind it
+    // (the documented layout: n_rows rounded up to 32 entries).  A b that is not aligned cannot have that.
+    const int gate_fence =
+        (tune_value(GKOC_TUNE_GATE_FENCE) != 0 || reinterpret_cast<uintptr_t>(b) % 128 != 0) ? 1 : 0;
     // where in the grid the boundary waves sit: GKOC_TUNE_GATE_POS per cent of the interior waves
     // in front of them (100 = they are the last waves)
     int64_t pos = tune_value(GKOC_TUNE_GATE_POS);

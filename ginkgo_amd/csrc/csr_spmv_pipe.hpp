@@ -132,10 +132,13 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     // (2048 same-address atomics of the boundary waves cost 15 us when tried), no second copy of the
     // matrix (round 3 kept all rows again over [local | halo]).  By the time the last waves start the
     // halo has usually arrived; a wave that has to wait polls with s_sleep (after ~10 s it gives up,
-    // sets gate[1] and goes on with whatever the halo holds: the caller checks).  The acquire fence
-    // is unconditional: the halo sits right behind the local vector, and an interior wave that read
-    // the last local entries may have pulled the first halo line into this XCD's L2 before the
-    // exchange wrote it.  Forward progress: the launcher admits at most 8 spinning waves per CU
+    // sets gate[1] and goes on with whatever the halo holds: the caller checks).  The agent-scope acquire
+    // behind the gate is paid only by a wave that HAD to wait (or by all of them with gate_fence = 1,
+    // GKOC_TUNE_GATE_FENCE): see the argument at the fence below - it rests on the halo starting on a
+    // 128-byte line of its own, which the launcher checks (launch_csr_gated: b and the halo offset
+    // aligned, otherwise gate_fence is forced to 1).  Soaked: tests/test_gate_soak_gpu.py, 10^4 products
+    // with a halo rewritten every iteration by a kernel on all XCDs, gate early and late.
+    // Forward progress: the launcher admits at most 8 spinning waves per CU
     // (gkoc_csr_spmv_gated_fits), so the exchange's kernels and gkoc_gate_open always find room.
     constexpr bool GATE = (ABL & 0x10000) != 0;
     if constexpr (GATE) {

@@ -938,8 +938,10 @@ GKOC_DECL_DIST_IDX(int64_t, i64)
  * rows [head_rows, n_rows - tail_rows) read no halo entry; bnd_* = the first head_rows and the last
  * tail_rows rows as COMPLETE rows over [local columns | halo] in the original column order
  * (gkoc_dist_boundary_count_* / gkoc_dist_boundary_fill_*: head rows, then tail rows); b = the
- * local vector with the halo BEHIND it in the same array (unit stride; let the halo start on a
- * 128-byte boundary: entry n_cols_local of b); c the local result.  The boundary rows are computed
+ * local vector with the halo BEHIND it in the same array (unit stride; PRECONDITION of the cheap
+ * gate: b itself on a 128-byte boundary and the halo at a multiple of 128 bytes behind it, so that no
+ * cache line holds local entries and halo entries - a b that is not aligned makes every boundary wave
+ * pay the agent-scope acquire, as GKOC_TUNE_GATE_FENCE=1 does); c the local result.  The boundary rows are computed
  * by the last waves of the grid, which wait for gkoc_gate_open(.., epoch) (enqueued on the
  * exchange's stream behind the transfer that fills b's halo part): no second kernel beside the
  * local SpMV, no event its stream waits for, no second copy of the matrix.  gate: two uint32 in

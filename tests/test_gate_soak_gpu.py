@@ -96,6 +96,19 @@ def test_gated_product_soak(gexec, grid, world, rank, iters):
     el = time.perf_counter() - t0
     assert int(bad.item()) == 0 and int(gate[0][1].item()) == 0
     assert int(word[0].item()) == iters
+    # negative control - the comparison does see a stale halo: the gate opened BEFORE the halo is rewritten
+    k = iters + 1
+    call("gkoc_stream_fork", mst, sst, word, C.c_uint32(k))
+    be.gate_open(side, gate)
+    call("gkoc_debug_delay", sst, C.c_int64(2000), 1, 64, 0)
+    with torch.cuda.stream(side):
+        torch.mul(base, 3.0, out=halo_live)
+    be.spmv_gated(local, nl, store, y, gate)
+    torch.mul(base, 3.0, out=hv.values.view(-1))
+    be.spmv_rows(local, f["interior"][0], f["interior"][1], xl, y2)
+    be.rowlist_full(nl, xl, hv, y2)
+    torch.cuda.synchronize()
+    assert int((y.values != y2.values).sum().item()) > 0, "the soak's comparison cannot see a stale halo"
     record_perf("gated_product_soak", grid=grid, world=world, rank=rank, iters=iters, seconds=round(el, 2),
                 boundary_waves=(f["head"] + f["tail"] + 63) // 64)
 
