@@ -579,6 +579,7 @@ namespace cg {
                        matrix::Dense<T>* prev_rho, matrix::Dense<T>* rho,       \
                        array<stopping_status>* stop_status)                     \
     {                                                                           \
+        cdna4::forget_learned(); /* a new solve confirms its shape anew */     \
         GKOC_CALL(gkoc_cg_initialize_##TN(                                      \
             stream_of(exec), rows(b), cols(b), b->get_const_values(), ld(b),    \
             r->get_values(), ld(r), z->get_values(), ld(z), p->get_values(),    \
@@ -898,6 +899,7 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
                 reinterpret_cast<double*>(blocks.get_data())));                 \
             return;                                                             \
         }                                                                       \
+        cdna4::forget_learned();                                                \
         GKOC_CALL(gkoc_jacobi_generate_##TN##_##IN(                             \
             stream_of(exec), system_matrix->get_size()[0],                      \
             system_matrix->get_const_row_ptrs(),                                \

@@ -207,6 +207,7 @@ void HipExecutor::raw_free(void* ptr) const noexcept
     try {
         cdna4::device_guard g(this->get_device_id());
         cdna4::launch_deferred();   // a held kernel may still have to read or write ptr
+        cdna4::forget_learned_if(ptr);   // ... and what a solve has shown may name what goes away
         alloc_->deallocate(ptr);
     } catch (...) {
     }

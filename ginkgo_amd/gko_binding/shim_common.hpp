@@ -67,6 +67,10 @@ bool jacobi_apply_with_dot(int vt, int it, int dev, gkoc_stream_t s, int64_t num
                            gkoc_jacobi_scheme scheme, const void* block_ptrs, const void* blocks,
                            const void* b, int64_t n, void* z);
 void launch_deferred_for_read(const void* result);
+// what the by-product mode has learned about the running solve (step_2 -> block-Jacobi application of r)
+// is void: a new solve begins, memory is freed, a preconditioner is generated
+void forget_learned();
+void forget_learned_if(const void* freed);
 
 // the stream of a kernel launch: what was held back is launched first
 inline gkoc_stream_t stream_of(const std::shared_ptr<const HipExecutor>& exec)

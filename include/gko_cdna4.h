@@ -177,6 +177,11 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                      * form: same threads, same tree); 0 (default): two launches.  Measured: the
                                      * agent-scope fences cost more than the launch they save (one rank's CG
                                      * iteration of 256^3 / 8: 209 -> 235 us, profiles/r04_experiments.txt) */
+#define GKOC_TUNE_ANTICIPATE 10     /* binding for the unmodified Ginkgo core, by-product mode (gko_binding/fusion.cpp):
+                                      1 (default): once a Cg solve has shown cg::step_2(x, r) followed directly by
+                                      jacobi::simple_apply(M, r -> z), the next step_2 runs as ONE kernel with that
+                                      application (x, r exist when step_2 returns as always; z = M r is written
+                                      early, the application call that follows launches nothing); 0: off */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,

@@ -38,11 +38,10 @@ using Csr = gko::matrix::Csr<vt, it>;
 using Dense = gko::matrix::Dense<vt>;
 
 template <typename F>
-static double time_ms(std::shared_ptr<const gko::Executor> exec, int reps, F f)
+static double time_ms(std::shared_ptr<const gko::Executor> exec, int reps, F f, int warm = 2)
 {
     auto timer = gko::Timer::create_for_executor(exec);
-    f();
-    f();
+    for (int i = 0; i < warm; ++i) f();
     exec->synchronize();
     auto t0 = timer->create_time_point();
     auto t1 = timer->create_time_point();
@@ -94,7 +93,10 @@ int main(int argc, char** argv)
         std::printf("memory classes: values %d, col_idxs %d, row_ptrs %d, b %d, x %d\n", cv, cc, cr, cb, cx);
     }
     const double bytes = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
-    double ms = time_ms(hip, reps, [&] { a->apply(b, x); });
+    // 30 untimed applies first: an idle MI355X needs ~20 ms of load to reach its clocks (the first fifteen
+    // launches of a fresh process take 1.06 ms, the rest 0.97: profiles/r05_ginkgo_api_timeline.txt) - the
+    // same warm-up bench.py's native line gets
+    double ms = time_ms(hip, reps, [&] { a->apply(b, x); }, 30);
     const double csr_ms = ms;
     std::printf("gko::matrix::Csr::apply      %8.4f ms  %8.1f GB/s  (%.1f %% of 8 TB/s)\n", ms,
                 bytes / ms / 1e6, bytes / ms / 1e6 / 80.0);

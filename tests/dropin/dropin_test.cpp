@@ -59,6 +59,7 @@ using Dense = gko::matrix::Dense<vt>;
 #include "core/matrix/csr_kernels.hpp"
 #include "core/matrix/csr_lookup.hpp"
 extern "C" void gko_cdna4_byproduct_hits(int64_t* norms, int64_t* dots);
+extern "C" void gko_cdna4_anticipated_applies(int64_t* applies);
 static int failures = 0;
 template <typename T>
 struct type_tag {
@@ -312,8 +313,28 @@ int main(int argc, char** argv)
             int64_t n0 = 0, d0 = 0, n1 = 0, d1 = 0;
             gko_cdna4_byproduct_hits(&n0, &d0);
             auto h_by = std::make_shared<history>();
+            int64_t a0 = 0, a1 = 0;
+            gko_cdna4_anticipated_applies(&a0);
             auto by = run(0, h_by, it_by);
             gko_cdna4_byproduct_hits(&n1, &d1);
+            gko_cdna4_anticipated_applies(&a1);
+            std::cout << "  anticipated: " << (a1 - a0) << " of " << it_by
+                      << " block-Jacobi applications were done by the cg::step_2 in front of them" << std::endl;
+            CHECK(a1 - a0 >= it_by - 3,
+                  "CG with by-products: from the third iteration on step_2 and the Jacobi application are one kernel");
+            {
+                // switched off: same iterations, same solution to rounding (the one-kernel form has the bits of
+                // the two kernels for x, r, z; <r,z> and ||r|| come from another reduction tree)
+                gkoc_tune_set(GKOC_TUNE_ANTICIPATE, 0);
+                int it_no = 0;
+                int64_t b0 = 0, b1 = 0;
+                gko_cdna4_anticipated_applies(&b0);
+                auto no = run(0, nullptr, it_no);
+                gko_cdna4_anticipated_applies(&b1);
+                gkoc_tune_set(GKOC_TUNE_ANTICIPATE, 1);
+                CHECK(b1 == b0 && it_no == it_by && rel_err(no.first.get(), by.first.get()) < 1e-12,
+                      "GKOC_TUNE_ANTICIPATE=0: nothing anticipated, same iterations and solution");
+            }
             std::cout << "  by-products: " << it_by << " iterations, " << (n1 - n0) << " norms and " << (d1 - d0)
                       << " dots answered without a pass of their own" << std::endl;
             CHECK(it_by == it_off && rel_err(by.first.get(), off.first.get()) < 1e-12,
