@@ -165,6 +165,9 @@ struct device_arena {
     // role heuristic of gkoc_malloc: sizes (as requested) of arrays that kernels have been seen
     // to WRITE as vectors (gkoc_arena_note_vector), newest last, a handful at most
     std::vector<size_t> vector_sizes;
+    // ... and of arrays the SpMV kernels have been handed as MATRIX arrays (gkoc_arena_note_matrix): a
+    // request of such a size is a matrix array although it may be a multiple of a vector's size
+    std::vector<size_t> matrix_sizes;
     int64_t misplaced = 0;        // gkoc_arena_note_vector found a written vector next to matrix arrays
     int64_t probes = 0, walked = 0, classified = 0, search_ns = 0, retried = 0;
     bool surveyed = false;        // the one search for all three classes has run (survey_classes)
@@ -644,6 +647,12 @@ void survey_classes(device_arena& A, int dev)
 // (k n values of 8 bytes) are exact multiples of its n-vector as well.
 bool vector_shaped(const device_arena& A, size_t bytes)
 {
+    // what the binding KNOWS beats what the size suggests: the values of an ELL matrix with k entries per
+    // row are k n values - a multiple of the n-vector - and were classified as vectors once an SpMV
+    // output had been seen
+    for (size_t m : A.matrix_sizes) {
+        if (m == bytes) return false;
+    }
     for (size_t v : A.vector_sizes) {
         if (v > 0 && bytes % v == 0 && bytes / v <= 64) return true;
     }
@@ -1043,6 +1052,40 @@ int gkoc_arena_note_vector(const void* ptr)
         }
         if (A.vector_sizes.size() >= 8) A.vector_sizes.erase(A.vector_sizes.begin());
         A.vector_sizes.push_back(bytes);
+        return GKOC_OK;
+    }
+    return GKOC_OK;
+}
+
+// The array at `ptr` is a matrix array (values / column indices handed to an SpMV kernel): later
+// requests of its size are matrix arrays for class_for_role, whatever multiple of a vector they are -
+// e.g. the next matrix of the same shape, or this one re-created after a conversion.
+int gkoc_arena_note_matrix(const void* ptr)
+{
+    if (!ptr) return GKOC_OK;
+    std::lock_guard<std::mutex> g(g_mtx);
+    device_arena& A = g_arena[current_device()];
+    for (int k = 0; k < A.n_cls; ++k) {
+        region& R = A.reg[k];
+        if (!R.owns(ptr)) continue;
+        const size_t off = size_t(static_cast<const char*>(ptr) - R.base);
+        auto it = R.req.upper_bound(off);
+        if (it == R.req.begin()) return GKOC_OK;
+        --it;
+        const size_t bytes = it->second;
+        if (off >= it->first + bytes) return GKOC_OK;
+        for (size_t m : A.matrix_sizes) {
+            if (m == bytes) return GKOC_OK;
+        }
+        if (A.matrix_sizes.size() >= 16) A.matrix_sizes.erase(A.matrix_sizes.begin());
+        A.matrix_sizes.push_back(bytes);
+        // (a size noted as a vector's earlier by mistake - k n values seen before any SpMV - is none)
+        for (size_t i = 0; i < A.vector_sizes.size(); ++i) {
+            if (A.vector_sizes[i] == bytes) {
+                A.vector_sizes.erase(A.vector_sizes.begin() + i);
+                break;
+            }
+        }
         return GKOC_OK;
     }
     return GKOC_OK;

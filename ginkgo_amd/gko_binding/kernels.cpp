@@ -85,6 +85,17 @@ inline void note_written_vector(const void* p)
     }
 }
 
+// ... and which arrays are matrix arrays from what the SpMV entries are handed (gkoc_arena_note_matrix)
+inline void note_matrix_arrays(const void* values, const void* col_idxs)
+{
+    static thread_local const void* last = nullptr;
+    if (values != last) {
+        last = values;
+        gkoc_arena_note_matrix(values);
+        gkoc_arena_note_matrix(col_idxs);
+    }
+}
+
 // ===================================================================== csr
 namespace csr {
 
@@ -94,6 +105,7 @@ namespace csr {
                           const matrix::Dense<T>* b, matrix::Dense<T>* c)       \
     {                                                                           \
         note_written_vector(c->get_const_values());                             \
+        note_matrix_arrays(a->get_const_values(), a->get_const_col_idxs());     \
         GKOC_CALL(gkoc_csr_spmv_##TN##_##IN(                                    \
             stream_of(exec), a->get_size()[0], a->get_size()[1],                \
             a->get_const_row_ptrs(), a->get_const_col_idxs(),                   \
@@ -178,6 +190,8 @@ namespace ell {
     void spmv<T, T, T, I>(exec_t exec, const matrix::Ell<T, I>* a,              \
                           const matrix::Dense<T>* b, matrix::Dense<T>* c)       \
     {                                                                           \
+        note_written_vector(c->get_const_values());                             \
+        note_matrix_arrays(a->get_const_values(), a->get_const_col_idxs());     \
         GKOC_CALL(gkoc_ell_spmv_##TN##_##IN(                                    \
             stream_of(exec), a->get_size()[0], a->get_size()[1],                \
             a->get_num_stored_elements_per_row(), a->get_stride(),              \
@@ -248,6 +262,8 @@ namespace sellp {
     void spmv<T, I>(exec_t exec, const matrix::Sellp<T, I>* a,                  \
                     const matrix::Dense<T>* b, matrix::Dense<T>* c)             \
     {                                                                           \
+        note_written_vector(c->get_const_values());                             \
+        note_matrix_arrays(a->get_const_values(), a->get_const_col_idxs());     \
         GKOC_CALL(gkoc_sellp_spmv_##TN##_##IN(                                  \
             stream_of(exec), a->get_size()[0], a->get_size()[1],                \
             a->get_slice_size(),                                                \

@@ -132,6 +132,10 @@ int gkoc_arena_class_of(const void* ptr, int* cls);
  * many vector sizes are known and how many of them were found next to matrix arrays when first
  * seen (placed before anything was known about the system). */
 int gkoc_arena_note_vector(const void* ptr);
+/* ... and the counterpart: the array at ptr is a MATRIX array (values / column indices handed to an SpMV
+ * entry): requests of its size are matrix arrays from now on, although k n values of a matrix with k
+ * entries per row are a multiple of the n-vector */
+int gkoc_arena_note_matrix(const void* ptr);
 int gkoc_arena_role_stats(int64_t* n_vector_sizes, int64_t* misplaced_vectors);
 int gkoc_arena_trim(void);              /* return empty chunks to the driver */
 /* The arena's memory-class probe, exposed for diagnostics: every wavefront reads

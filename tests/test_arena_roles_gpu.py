@@ -46,3 +46,52 @@ def test_written_arrays_never_share_a_class_with_matrix_arrays(scenario):
         k = r"30 iterations,"
         print(f"{scenario}: Gmres(30) {t(out, k):.4f} ms/iteration with the arena, "
               f"{t(out0, k):.4f} with GKOC_ARENA=0")
+
+
+def test_matrix_arrays_noted_by_the_spmv_entries_are_no_vectors():
+    """gkoc_arena_note_matrix: the values of a matrix with a constant number of
+    entries per row (ELL, 27 n values) are a multiple of the n-vector and were taken for vectors once an SpMV
+    output of n values had been seen.  What the binding KNOWS - the arrays an SpMV entry is handed are matrix
+    arrays - overrides the guess: the next request of that size is placed as a matrix array, away from the
+    vectors.  A fresh process (the arena's knowledge is per process)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, json, sys
+sys.path.insert(0, ".")
+import ginkgo_amd as g
+from ginkgo_amd import _lib
+ex = g.Cdna4Executor.create(0)
+def alloc(nbytes):
+    p = C.c_void_p()
+    _lib.call("gkoc_malloc", C.byref(p), C.c_size_t(nbytes))
+    return p
+def cls(p):
+    c = C.c_int(-2)
+    _lib.call("gkoc_arena_class_of", p, C.byref(c))
+    return c.value
+n = 4 * 1000 * 1000 + 24
+big = alloc(40 * 8 * n)              # some matrix, so that "a quarter of the largest" does not decide
+y = alloc(8 * n)
+_lib.call("gkoc_arena_note_vector", y)
+a1 = alloc(27 * 8 * n)               # 27 n values: looks like a block of 27 vectors
+_lib.call("gkoc_arena_note_matrix", a1)
+a2 = alloc(27 * 8 * n)               # the same size again: known to be a matrix array now
+basis = alloc(31 * 8 * n)            # a Gmres(30) basis: still vector-shaped
+info = ex.arena_info()
+print(json.dumps({"classes": info["num_classes"], "y": cls(y), "a1": cls(a1), "a2": cls(a2), "basis": cls(basis)}))
+'''
+    e = dict(os.environ)
+    for k in list(e):
+        if k.startswith("GKOC_ARENA"):
+            del e[k]
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert p.returncode == 0, p.stdout + p.stderr
+    import json
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    print(r)
+    if r["classes"] < 3:
+        pytest.skip(f"the survey found {r['classes']} class(es) on this box: nothing to place apart")
+    assert r["a1"] == r["y"], "(the guess this test documents: 27 n values are taken for vectors)"
+    assert r["a2"] != r["y"], "a size noted as a matrix array was placed with the vectors"
+    assert r["basis"] == r["y"], "a Krylov basis no longer joins the vectors"
