@@ -74,7 +74,7 @@ int scratch_free(hipStream_t st, void* ptr);
 int stream_ticket(hipStream_t st, unsigned** word);
 
 // tuning switches (runtime.hip; keys = GKOC_TUNE_* of gko_cdna4.h)
-constexpr int tune_num_keys = 11;
+constexpr int tune_num_keys = 12;
 int64_t tune_value(int key);
 
 #ifdef __HIPCC__

@@ -78,32 +78,47 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         const bool pairs_ok = reinterpret_cast<uintptr_t>(b) % (2 * sizeof(T)) == 0 && ldb % 2 == 0 &&
                               reinterpret_cast<uintptr_t>(c) % (2 * sizeof(T)) == 0 && ldc % 2 == 0;
         const int64_t chunk_rows = tune_value(GKOC_TUNE_MULTI_XCD_CHUNK_ROWS);
-#define GKOC_LAUNCH_CSR_FRAG(NR_, CPL_, KU_)                                                     \
+#define GKOC_LAUNCH_CSR_FRAG(NR_, CPL_, KU_) GKOC_LAUNCH_CSR_FRAG_T(NR_, CPL_, 1, KU_)
+#define GKOC_LAUNCH_CSR_FRAG_T(NR_, CPL_, TT_, KU_)                                              \
     do {                                                                                         \
-        constexpr int rows_ = 64 * CPL_ / NR_;                                                   \
+        constexpr int rows_ = 64 * CPL_ / NR_ * TT_;                                             \
         const int64_t nwg = ceildiv(n_rows, rows_);                                              \
         GKOC_REQUIRE(nwg < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 waves");    \
         const dim3 gf(static_cast<unsigned>(nwg));                                               \
         if (idx32) {                                                                             \
-            csr_spmv_frag_kernel<T, I, ADV, NR_, CPL_, 1, KU_, true>                             \
+            csr_spmv_frag_kernel<T, I, ADV, NR_, CPL_, TT_, KU_, true>                           \
                 <<<gf, block, 0, as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals, b, ldb, c,    \
                                                  ldc, static_cast<int>(nrhs), alpha, beta,       \
                                                  chunk_rows / rows_);                            \
         } else {                                                                                 \
-            csr_spmv_frag_kernel<T, I, ADV, NR_, CPL_, 1, KU_, false>                            \
+            csr_spmv_frag_kernel<T, I, ADV, NR_, CPL_, TT_, KU_, false>                          \
                 <<<gf, block, 0, as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals, b, ldb, c,    \
                                                  ldc, static_cast<int>(nrhs), alpha, beta,       \
                                                  chunk_rows / rows_);                            \
         }                                                                                        \
     } while (0)
-        if (nrhs <= 4) {
+        const int64_t variant = tune_value(GKOC_TUNE_CSR_MULTI_VARIANT);
+        if (nrhs <= 4 && pairs_ok && variant == 1) {
+            GKOC_LAUNCH_CSR_FRAG(4, 2, 3);          // two lanes per row, a pair of columns each: 32-row waves
+        } else if (nrhs <= 4 && pairs_ok && variant == 2) {
+            GKOC_LAUNCH_CSR_FRAG(4, 2, 4);
+        } else if (nrhs <= 4 && pairs_ok && variant == 3) {
+            GKOC_LAUNCH_CSR_FRAG(4, 2, 2);
+        } else if (nrhs <= 4) {
             GKOC_LAUNCH_CSR_FRAG(4, 1, 4);          // four lanes per row, one column each
+        } else if (pairs_ok && variant == 1) {
+            GKOC_LAUNCH_CSR_FRAG(8, 2, 4);
+        } else if (pairs_ok && variant == 2) {
+            GKOC_LAUNCH_CSR_FRAG_T(8, 2, 2, 2);     // 32-row waves, two groups side by side
+        } else if (pairs_ok && variant == 3) {
+            GKOC_LAUNCH_CSR_FRAG(8, 2, 5);
         } else if (pairs_ok) {
             GKOC_LAUNCH_CSR_FRAG(8, 2, 3);          // four lanes per row, a pair of columns each
         } else {
             GKOC_LAUNCH_CSR_FRAG(8, 1, 4);
         }
 #undef GKOC_LAUNCH_CSR_FRAG
+#undef GKOC_LAUNCH_CSR_FRAG_T
         GKOC_LAUNCH_OK();
         return GKOC_OK;
     }

@@ -186,6 +186,8 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                       jacobi::simple_apply(M, r -> z), the next step_2 runs as ONE kernel with that
                                       application (x, r exist when step_2 returns as always; z = M r is written
                                       early, the application call that follows launches nothing); 0: off */
+#define GKOC_TUNE_CSR_MULTI_VARIANT 11 /* csr::spmv with three to eight right-hand sides: layout variants kept for A/B
+                                      measurements (csrc/csr_spmv.hip); 0 = the default chosen by measurement */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,

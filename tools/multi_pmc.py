@@ -18,8 +18,10 @@ ex = g.Cdna4Executor.create(0)
 a = g.stencil_csr(ex, 3, grid)
 n = a.size[0]
 xs = np.random.default_rng(1).uniform(-1, 1, (n, 8))
-for name, op in (("ell", a.convert_to_ell()),) + ((("csr", a),) if "NOCSR" not in os.environ else ()):
-    for k in (1, 2, 4, 8):
+ops = ((("ell", a.convert_to_ell()),) if "NOELL" not in os.environ else ()) + \
+    ((("csr", a),) if "NOCSR" not in os.environ else ())
+for name, op in ops:
+    for k in [int(v) for v in os.environ.get("NRHS", "1,2,4,8").split(",")]:
         x = g.Dense.from_numpy(ex, xs[:, :k].copy())
         y = g.Dense.create(ex, (n, k))
         for _ in range(3):
