@@ -98,6 +98,49 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         }                                                                                        \
     } while (0)
         const int64_t variant = tune_value(GKOC_TUNE_CSR_MULTI_VARIANT);
+#define GKOC_LAUNCH_CSR_FRAG_PIPE(NR_, CPL_, KU_, SEGS_) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(NR_, CPL_, KU_, SEGS_, 1)
+#define GKOC_LAUNCH_CSR_FRAG_PIPE_ST(NR_, CPL_, KU_, SEGS_, ST_)                                 \
+    do {                                                                                         \
+        constexpr int rows_ = 64 * CPL_ / NR_;                                                   \
+        const int64_t nwg = ceildiv(ceildiv(n_rows, rows_), SEGS_);                              \
+        GKOC_REQUIRE(nwg < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 waves");    \
+        const dim3 gf(static_cast<unsigned>(nwg));                                               \
+        if (idx32) {                                                                             \
+            csr_spmv_frag_pipe_kernel<T, I, ADV, NR_, CPL_, KU_, true, ST_>                      \
+                <<<gf, block, 0, as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals, b, ldb, c,    \
+                                                 ldc, static_cast<int>(nrhs), alpha, beta,       \
+                                                 SEGS_, chunk_rows / (rows_ * SEGS_));           \
+        } else {                                                                                 \
+            csr_spmv_frag_pipe_kernel<T, I, ADV, NR_, CPL_, KU_, false, ST_>                     \
+                <<<gf, block, 0, as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals, b, ldb, c,    \
+                                                 ldc, static_cast<int>(nrhs), alpha, beta,       \
+                                                 SEGS_, chunk_rows / (rows_ * SEGS_));           \
+        }                                                                                        \
+    } while (0)
+        // default (round 5): the pipelined form, four segments per wave - L256 3 / 4 / 8 columns 1.87 / 1.90 /
+        // 2.10 -> 1.76 / 1.79 / 2.00 ms (profiles/r05_multi_rhs_pmc.txt); GKOC_TUNE_CSR_MULTI_VARIANT: 9 = the
+        // kernel of rounds 3-4, 1 .. 3 its layout variants, >= 10 the pipeline's own (segments per wave x 10
+        // + 1000 x entries-per-step choice)
+        const int segs = variant >= 10 ? int(variant % 1000 / 10) : 4;
+        const bool pipe = variant == 0 || variant >= 10;
+        if (pipe && nrhs <= 4) {
+            if (variant / 1000 == 1) GKOC_LAUNCH_CSR_FRAG_PIPE(4, 1, 2, segs);
+            else if (variant / 1000 == 3) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(4, 1, 3, segs, 3);
+            else if (variant / 1000 == 4) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(4, 1, 2, segs, 3);
+            else if (variant / 1000 == 2) GKOC_LAUNCH_CSR_FRAG_PIPE(4, 1, 3, segs);
+            else GKOC_LAUNCH_CSR_FRAG_PIPE(4, 1, 4, segs);
+            GKOC_LAUNCH_OK();
+            return GKOC_OK;
+        }
+        if (pipe && pairs_ok) {
+            if (variant / 1000 == 1) GKOC_LAUNCH_CSR_FRAG_PIPE(8, 2, 2, segs);
+            else if (variant / 1000 == 3) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(8, 2, 3, segs, 3);
+            else if (variant / 1000 == 4) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(8, 2, 2, segs, 3);
+            else if (variant / 1000 == 2) GKOC_LAUNCH_CSR_FRAG_PIPE(8, 2, 4, segs);
+            else GKOC_LAUNCH_CSR_FRAG_PIPE(8, 2, 3, segs);
+            GKOC_LAUNCH_OK();
+            return GKOC_OK;
+        }
         if (nrhs <= 4 && pairs_ok && variant == 1) {
             GKOC_LAUNCH_CSR_FRAG(4, 2, 3);          // two lanes per row, a pair of columns each: 32-row waves
         } else if (nrhs <= 4 && pairs_ok && variant == 2) {
@@ -119,6 +162,8 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         }
 #undef GKOC_LAUNCH_CSR_FRAG
 #undef GKOC_LAUNCH_CSR_FRAG_T
+#undef GKOC_LAUNCH_CSR_FRAG_PIPE
+#undef GKOC_LAUNCH_CSR_FRAG_PIPE_ST
         GKOC_LAUNCH_OK();
         return GKOC_OK;
     }

@@ -260,6 +260,256 @@ __global__ __launch_bounds__(64) void csr_spmv_frag_kernel(
     }
 }
 
+// The fragment layout as a PIPELINE (round 5).  Counters (profiles/r05_multi_rhs_pmc.txt) show the kernel
+// above latency-bound: a wave lives 13.7 us for 432 entries, 84 % of it waiting, through a chain of dependent
+// memory phases (row pointers -> the segment's values / indices -> 27 / KU rounds of gathers), with the
+// number of resident waves capped by the LDS; neither the L1 access count nor the LDS is the wall.  Here a
+// wave walks SEGS consecutive 16-row segments and keeps the next one's memory requests in flight while it
+// works on the current one:
+//   * the row pointers of segment s + 1 are requested when segment s begins (one load per lane, the lanes
+//     hand them round by wave shuffle: no per-row pointer loads behind the staging);
+//   * the values / indices of segment s + 1 travel into REGISTERS (PF entries per lane, coalesced) while
+//     the gathers of segment s run, and go to the LDS when segment s is done: the matrix stream's HBM
+//     latency is paid once per wave, not once per segment;
+//   * two rounds of gathers are in flight: round k + 1 is requested before round k's products are added.
+// Same LDS footprint per wave (one 6 KB buffer), same sums: every (row, column) sum by ONE lane in entry
+// order, separate multiply and add - bit-identical to the kernel above and to the reference.  A segment
+// with more than CAP entries takes the rounds of the kernel above (not pipelined).
+template <typename T, typename I, bool ADV, int NR, int CPL, int KU, bool IDX32, int ST = 1>
+__global__ __launch_bounds__(64) void csr_spmv_frag_pipe_kernel(
+    int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
+    const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb, T* __restrict__ c,
+    int64_t ldc, int nrhs, const T* __restrict__ alpha_p, const T* __restrict__ beta_p,
+    int segs_per_wave, int64_t xcd_chunk)
+{
+    static_assert(NR == 4 || NR == 8, "chunks of 4 or 8 columns");
+    static_assert(CPL == 1 || CPL == 2, "one or two columns per lane");
+    constexpr int LPR = NR / CPL;     // lanes per row
+    constexpr int ROWS = 64 / LPR;    // rows per segment (16)
+    constexpr int CAP = ROWS * 32;    // staged entries (12 B each)
+    constexpr int PF = CAP / 64;      // entries per lane that travel ahead in registers
+    using BV = vecT<T, CPL>;
+    __shared__ __attribute__((aligned(16))) T lv[CAP];
+    __shared__ __attribute__((aligned(16))) I lc[CAP];
+    const int lane = threadIdx.x;
+    const int sub = lane % LPR, rl = lane / LPR;
+    const int64_t n_seg = (n_rows + ROWS - 1) / ROWS;
+    const int64_t w = xcd_chunked_block(blockIdx.x, gridDim.x, xcd_chunk);
+    int64_t seg = w * segs_per_wave;
+    const int64_t seg_end = seg + segs_per_wave < n_seg ? seg + segs_per_wave : n_seg;
+    if (seg >= seg_end) return;
+    T alpha = T(1), beta = T(0);
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    // row pointer `lane` of a segment (lanes 0 .. ROWS), clamped to the matrix
+    auto load_rp = [&](int64_t sg) -> int64_t {
+        const int64_t r = sg * ROWS + (lane <= ROWS ? lane : ROWS);
+        return int64_t(row_ptrs[r < n_rows ? r : n_rows]);
+    };
+    T pv[PF];
+    I pc[PF];
+    auto prefetch = [&](int64_t k0, int count) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int i = lane + 64 * j;
+            if (i < count) {
+                pv[j] = vals[k0 + i];
+                pc[j] = cols[k0 + i];
+            }
+        }
+    };
+    int64_t rp = load_rp(seg);
+    int64_t K0 = __shfl(rp, 0, 64), K1 = __shfl(rp, ROWS, 64);
+    bool staged_ahead = K1 - K0 <= CAP;
+    if (staged_ahead) prefetch(K0, int(K1 - K0));
+    int64_t nrp = seg + 1 < seg_end ? load_rp(seg + 1) : 0;
+
+    while (seg < seg_end) {
+        const int64_t row0 = seg * ROWS;
+        const int64_t last = row0 + ROWS < n_rows ? row0 + ROWS : n_rows;
+        const bool whole = staged_ahead;
+        const int count = int(K1 - K0);
+        if (whole) {
+            wave_lds_sync();          // the previous segment has been read
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int i = lane + 64 * j;
+                if (i < count) {
+                    lv[i] = pv[j];
+                    lc[i] = pc[j];
+                }
+            }
+            wave_lds_sync();
+        }
+        // this segment's rows as this lane sees them
+        const int64_t row = row0 + rl;
+        const int64_t a = __shfl(rp, rl, 64), e = __shfl(rp, rl + 1, 64);
+        const int rs = int(a - K0);
+        const int len = row < last ? int(e - a) : 0;
+        int maxlen = len;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o = __shfl_xor(maxlen, off, 64);
+            maxlen = o > maxlen ? o : maxlen;
+        }
+        // the next segment: its pointers are here (requested one segment ago), its entries start to travel
+        // now; the pointers of the one after are requested
+        int64_t nK0 = 0, nK1 = 0;
+        bool next_ahead = false;
+        if (seg + 1 < seg_end) {
+            nK0 = __shfl(nrp, 0, 64);
+            nK1 = __shfl(nrp, ROWS, 64);
+            next_ahead = nK1 - nK0 <= CAP;
+            if (next_ahead) prefetch(nK0, int(nK1 - nK0));
+        }
+        const int64_t nnrp = seg + 2 < seg_end ? load_rp(seg + 2) : 0;
+
+        for (int j0 = 0; j0 < nrhs; j0 += NR) {
+            const int jc = j0 + CPL * sub;
+            const int ncol = nrhs - jc >= CPL ? CPL : nrhs - jc;
+            const int jl = ncol >= 1 ? jc : 0;
+            T sum[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                sum[q] = T(0);
+                if (ADV && beta != T(0) && row < last && q < ncol) sum[q] = c[row * ldc + jc + q] * beta;
+            }
+            // entries [kb, kend) of the lane's row, entry k at LDS slot base + k; two rounds of KU gathers in flight
+            auto walk = [&](int kb, int kend, int klimit, int base) {
+                BV x0[KU], x1[KU];
+                T v0[KU], v1[KU];
+                bool ok0[KU], ok1[KU];
+                auto request = [&](int k, BV(&x)[KU], T(&vv)[KU], bool(&ok)[KU]) {
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) {
+                        ok[u] = k + u < len && k + u < klimit;
+                        const int at = ok[u] ? base + k + u : 0;
+                        const I cc = lc[at];
+                        vv[u] = lv[at];
+                        const I ce = ok[u] ? cc : I(0);
+                        if (IDX32) {
+                            const uint32_t off = uint32_t(ce) * uint32_t(ldb) + uint32_t(jl);
+                            x[u] = *reinterpret_cast<const BV*>(b + off);
+                        } else {
+                            x[u] = *reinterpret_cast<const BV*>(b + int64_t(ce) * ldb + jl);
+                        }
+                    }
+                };
+                auto add = [&](const BV(&x)[KU], const T(&vv)[KU], const bool(&ok)[KU]) {
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) {
+                        const T av = ADV ? alpha * vv[u] : vv[u];
+#pragma unroll
+                        for (int q = 0; q < CPL; ++q) {
+                            const T nx = sum[q] + av * x[u].v[q];
+                            sum[q] = ok[u] ? nx : sum[q];
+                        }
+                    }
+                };
+                if (kb >= kend) return;
+                if constexpr (ST > 1) {
+                    // STRIDED rounds.  Neighbouring entries of a row of a banded / stencil matrix are
+                    // neighbouring rows of b, and the 16 rows of the wave make the gathers of entries k and
+                    // k + 1 overlap in 15 of their 16 rows: the second gather hits lines that are still on
+                    // their way, and the vector L1 - in order - stalls on such a hit until the data is back
+                    // (TCP_PENDING_STALL_CYCLES = 44 % of the cycles, profiles/r05_multi_rhs_pmc.txt).  So
+                    // a round asks for entries k, k + ST, k + 2 ST, ... (different lines), waits for them,
+                    // and only then for k + 1, k + 1 + ST, ... - which now HIT.  The products are added in
+                    // entry order afterwards: the same sums.
+                    for (int k = kb; k < kend; k += KU * ST) {
+                        BV x[ST][KU];
+                        T vv[ST][KU];
+                        bool ok[ST][KU];
+#pragma unroll
+                        for (int st = 0; st < ST; ++st) {
+#pragma unroll
+                            for (int u = 0; u < KU; ++u) {
+                                const int kk = k + st + ST * u;
+                                ok[st][u] = kk < len && kk < klimit;
+                                const int at = ok[st][u] ? base + kk : 0;
+                                const I cc = lc[at];
+                                vv[st][u] = lv[at];
+                                const I ce = ok[st][u] ? cc : I(0);
+                                if (IDX32) {
+                                    const uint32_t off = uint32_t(ce) * uint32_t(ldb) + uint32_t(jl);
+                                    x[st][u] = *reinterpret_cast<const BV*>(b + off);
+                                } else {
+                                    x[st][u] = *reinterpret_cast<const BV*>(b + int64_t(ce) * ldb + jl);
+                                }
+                            }
+                            if (st + 1 < ST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+#pragma unroll
+                        for (int u = 0; u < KU; ++u) {
+#pragma unroll
+                            for (int st = 0; st < ST; ++st) {
+                                const T av = ADV ? alpha * vv[st][u] : vv[st][u];
+#pragma unroll
+                                for (int q = 0; q < CPL; ++q) {
+                                    const T nx = sum[q] + av * x[st][u].v[q];
+                                    sum[q] = ok[st][u] ? nx : sum[q];
+                                }
+                            }
+                        }
+                    }
+                    return;
+                }
+                request(kb, x0, v0, ok0);
+                int k = kb;
+                while (true) {
+                    if (k + KU < kend) request(k + KU, x1, v1, ok1);
+                    add(x0, v0, ok0);
+                    k += KU;
+                    if (k >= kend) break;
+                    if (k + KU < kend) request(k + KU, x0, v0, ok0);
+                    add(x1, v1, ok1);
+                    k += KU;
+                    if (k >= kend) break;
+                }
+            };
+            if (whole) {
+                if (count > 0) walk(0, maxlen, maxlen, rs);
+            } else {
+                for (int c0 = 0; c0 < maxlen; c0 += 32) {
+                    wave_lds_sync();
+                    for (int i = lane; i < CAP; i += 64) {
+                        const int64_t r = row0 + (i >> 5);
+                        if (r < last) {
+                            const int64_t ra = row_ptrs[r];
+                            if (ra + c0 + (i & 31) < int64_t(row_ptrs[r + 1])) {
+                                lv[i] = vals[ra + c0 + (i & 31)];
+                                lc[i] = cols[ra + c0 + (i & 31)];
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                    const int ke = c0 + 32 < maxlen ? c0 + 32 : maxlen;
+                    walk(c0, ke, c0 + 32, 32 * rl - c0);
+                }
+            }
+            if (row < last && ncol > 0) {
+                T* __restrict__ cp = c + row * ldc + jc;
+                if (ncol == CPL) {
+                    BV q;
+#pragma unroll
+                    for (int i = 0; i < CPL; ++i) q.v[i] = sum[i];
+                    *reinterpret_cast<BV*>(cp) = q;
+                } else {
+                    cp[0] = sum[0];
+                }
+            }
+        }
+        ++seg;
+        rp = nrp;
+        nrp = nnrp;
+        K0 = nK0;
+        K1 = nK1;
+        staged_ahead = next_ahead;
+    }
+}
+
 template <typename T, typename I, bool ADV, int E, int U, int RING, int NR>
 __global__ __launch_bounds__(64) void csr_spmv_multi_kernel(
     int64_t n_rows, int64_t n_segments, int64_t segs_per_wave,
