@@ -71,7 +71,7 @@ def cls(p):
     _lib.call("gkoc_arena_class_of", p, C.byref(c))
     return c.value
 n = 4 * 1000 * 1000 + 24
-big = alloc(40 * 8 * n)              # some matrix, so that "a quarter of the largest" does not decide
+big = alloc(40 * 8 * n + 4096)       # some matrix (no multiple of a vector), so that "a quarter of the largest" does not decide
 y = alloc(8 * n)
 _lib.call("gkoc_arena_note_vector", y)
 a1 = alloc(27 * 8 * n)               # 27 n values: looks like a block of 27 vectors
