@@ -314,6 +314,20 @@ def matrix_bench(args):
         data = f"file {name}"
         workload = f"{name}: n = {n}, nnz = {nnz}"
         del rp, ci, vv
+    elif args.workload == "irregular":
+        n = args.irr_n
+        prefix = wl.irregular_row_prefix(n)
+        nnz = int(prefix[-1])
+        offsets = wl.partition_by_nnz(prefix, world, align=bs)
+        lo, hi = offsets[rank], offsets[rank + 1]
+        own = wl.irregular_rows(n, lo, hi)
+        lens = np.diff(prefix)
+        data = "synthetic heavy-tailed stand-in for an irregular SuiteSparse matrix"
+        workload = (f"irregular stand-in for configs[4] (ginkgo_amd/workloads.py irregular_rows): symmetric positive "
+                    f"definite, power-law row lengths + {wl.IRR_HUBS} hub rows, n = {n}, nnz = {nnz}; entries per row: "
+                    f"mean {lens.mean():.1f}, median {int(np.median(lens))}, 99.9 % {int(np.percentile(lens, 99.9))}, "
+                    f"max {int(lens.max())}, {int((lens > 4096).sum())} rows beyond GKOC_CSR_LONG_ROW = 4096")
+        del lens
     else:
         grid = args.flan_grid
         n, nnz = wl.flan_like_dims(grid)
@@ -487,8 +501,10 @@ def main():
                          "beside cg_iters_per_s")
     ap.add_argument("--matrix", default=None,
                     help="a MatrixMarket file: run configs[4] (SELL-P vs CSR, CG + block-Jacobi) on it")
-    ap.add_argument("--workload", default=None, choices=[None, "flan"],
-                    help="flan: configs[4] on the stand-in for Flan_1565 (no file at hand)")
+    ap.add_argument("--workload", default=None, choices=[None, "flan", "irregular"],
+                    help="configs[4] without the file: flan = the regular stand-in L27(g^3) (x) B3 (24 - 81 entries per "
+                         "row); irregular = the heavy-tailed one (power-law row lengths, hub rows beyond 4096 entries)")
+    ap.add_argument("--irr-n", type=int, default=4000000, help="--workload irregular: order of the matrix")
     ap.add_argument("--format", default="csr", choices=["csr", "sellp"],
                     help="--matrix / --workload flan: the format `value` is quoted on")
     ap.add_argument("--flan-grid", type=int, default=80, help="stand-in size: L27(g^3) (x) B3")
@@ -505,7 +521,7 @@ def main():
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, the way the
         # driver does (one process per GPU, rendezvous on 127.0.0.1); rank 0 prints the line
         return self_launch(args.gpus)
-    if args.matrix or args.workload == "flan":
+    if args.matrix or args.workload in ("flan", "irregular"):
         return matrix_bench(args)
 
     # stdout carries exactly one line, the JSON result: everything else written to

@@ -210,3 +210,108 @@ def flan_like_row_prefix(grid):
     per_node = (one[None, None, :] * one[None, :, None] * one[:, None, None]).reshape(-1)   # z, y, x
     lens = np.repeat(3 * per_node, 3)
     return np.concatenate([[0], np.cumsum(lens)])
+
+
+# ---- a second stand-in for configs[4], IRREGULAR on purpose -------------------
+# flan_like_rows has 24 - 81 entries in every row; "irregular nnz/row" is what BASELINE names.  This one
+# has a heavy tail: a symmetric positive definite matrix (strictly diagonally dominant) whose row lengths
+# follow a power law - most rows a dozen entries, one in a thousand some hundreds - plus a few HUB rows with
+# 10^3 .. 10^5 entries, beyond GKOC_CSR_LONG_ROW (4096), where the CSR kernel sums a row with the whole
+# wave and SELL-P (slice size 64, padded to the longest row of the slice) stores a multiple of the entries.
+# Everything is a pure function of the indices, so a rank builds its own rows only:
+#   * row a is linked to a + S[k] for k < d(a), d(a) = min(96, floor(2 / u(a)^0.7)), u(a) a hash of a in
+#     (0, 1]  (P(d >= k) ~ k^-1.43) - and, by symmetry, row b to b - S[k] wherever k < d(b - S[k]);
+#   * hub j (row H_j) is linked to every row r with (r + 131 j) mod M_j == 0, M_j = 16 .. 6144;
+#   * weights w(a, b) in [0.5, 1.5) from a hash of (min, max); a_rr = 1 + sum of the row's weights.
+IRR_KMAX = 96
+IRR_HUBS = 24
+
+
+def _irr_offsets():
+    k = np.arange(IRR_KMAX, dtype=np.int64)
+    return 1 + 37 * k * k + 1009 * k
+
+
+def _irr_degree(idx):
+    h = (idx.astype(np.uint64) * np.uint64(2654435761) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
+    u = ((h >> np.uint64(8)).astype(np.float64) + 1.0) / float(1 << 24)
+    return np.minimum(IRR_KMAX, np.floor(2.0 / u ** 0.7)).astype(np.int64)
+
+
+def _irr_weight(a, b):
+    lo, hi = np.minimum(a, b).astype(np.uint64), np.maximum(a, b).astype(np.uint64)
+    h = (lo * np.uint64(2654435761) + hi * np.uint64(40503)) & np.uint64(0x3FF)
+    return 0.5 + h.astype(np.float64) / 1024.0
+
+
+def _irr_hubs(n):
+    j = np.arange(IRR_HUBS, dtype=np.int64)
+    rows = (j + 1) * n // (IRR_HUBS + 1)
+    mods = 16 * (1 << (j % 8)) * (1 + j // 8)
+    return rows, mods
+
+
+def irregular_rows(n, lo=0, hi=None, index_dtype=np.int32):
+    """rows [lo, hi) of the heavy-tailed stand-in of order n as sorted CSR with GLOBAL columns"""
+    import scipy.sparse as sp
+    hi = n if hi is None else hi
+    r = np.arange(lo, hi, dtype=np.int64)
+    s = _irr_offsets()
+    d_own = _irr_degree(r)
+    rows_l, cols_l = [], []
+    for k in range(IRR_KMAX):
+        up = (k < d_own) & (r + s[k] < n)                   # r -> r + s_k
+        rows_l.append(r[up])
+        cols_l.append(r[up] + s[k])
+        below = r - s[k]
+        ok = below >= 0
+        dn = np.zeros(r.size, dtype=bool)
+        dn[ok] = k < _irr_degree(below[ok])                   # (r - s_k) -> r, seen from r
+        rows_l.append(r[dn])
+        cols_l.append(below[dn])
+    hub_rows, hub_mods = _irr_hubs(n)
+    for j in range(IRR_HUBS):
+        hj, mj = int(hub_rows[j]), int(hub_mods[j])
+        mine = r[((r + 131 * j) % mj == 0) & (r != hj)]       # ordinary rows of the range linked to hub j
+        rows_l.append(mine)
+        cols_l.append(np.full(mine.size, hj, dtype=np.int64))
+        if lo <= hj < hi:                                     # the hub's own row: all its spokes
+            first = (-131 * j) % mj
+            spokes = np.arange(first, n, mj, dtype=np.int64)
+            spokes = spokes[spokes != hj]
+            rows_l.append(np.full(spokes.size, hj, dtype=np.int64))
+            cols_l.append(spokes)
+    rows = np.concatenate(rows_l)
+    cols = np.concatenate(cols_l)
+    # a link reached twice (an offset that is also a spoke) is one link
+    key = np.unique(rows * np.int64(n) + cols)
+    rows, cols = key // n, key % n
+    w = -_irr_weight(rows, cols)
+    a = sp.csr_matrix((w, (rows - lo, cols)), shape=(hi - lo, n))
+    diag = 1.0 - np.asarray(a.sum(axis=1)).ravel()
+    a = (a + sp.csr_matrix((diag, (np.arange(hi - lo), r)), shape=(hi - lo, n))).tocsr()
+    a.sort_indices()
+    return a.indptr.astype(index_dtype), a.indices.astype(index_dtype), a.data.astype(np.float64)
+
+
+def irregular_row_prefix(n):
+    """row_ptrs of the whole stand-in without its entries (for partition_by_nnz); exact: the same links,
+    counted"""
+    r = np.arange(n, dtype=np.int64)
+    s = _irr_offsets()
+    d = _irr_degree(r)
+    keys = []
+    for k in range(IRR_KMAX):
+        up = (k < d) & (r + s[k] < n)
+        keys.append(r[up] * np.int64(n) + r[up] + s[k])
+        keys.append((r[up] + s[k]) * np.int64(n) + r[up])
+    hub_rows, hub_mods = _irr_hubs(n)
+    for j in range(IRR_HUBS):
+        hj, mj = int(hub_rows[j]), int(hub_mods[j])
+        spokes = np.arange((-131 * j) % mj, n, mj, dtype=np.int64)
+        spokes = spokes[spokes != hj]
+        keys.append(spokes * np.int64(n) + hj)
+        keys.append(hj * np.int64(n) + spokes)
+    key = np.unique(np.concatenate(keys))
+    lens = np.bincount(key // n, minlength=n) + 1             # + the diagonal
+    return np.concatenate([[0], np.cumsum(lens)])

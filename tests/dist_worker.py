@@ -167,6 +167,7 @@ def main():
     #     indices, uneven part sizes) - nothing slab-specific may be assumed
     irregular_case(mode, o, gd, be, comm, rank, world)
     flan_case(mode, o, gd, be, comm, rank, world)
+    heavy_tail_case(mode, o, gd, be, comm, rank, world)
     if mode == "gpu-ipc":
         if grid % 8 == 0:
             assert a._gate is not None, "the one-kernel gated product was not taken on the device-resident transport"
@@ -255,6 +256,49 @@ def flan_case(mode, o, gd, be, comm, rank, world):
         if hi > lo:
             e = np.linalg.norm(xs.to_numpy()[:, 0] - xo[lo:hi]) / np.linalg.norm(xo[lo:hi])
             assert e < 1e-8, f"rank {rank}: flan-like cg ({fmt}) err {e}"
+
+
+def heavy_tail_case(mode, o, gd, be, comm, rank, world):
+    """configs[4]'s irregular stand-in (workloads.irregular_rows: power-law row lengths, hub rows linked to
+    rows of EVERY rank) on an entry-balanced contiguous partition: each rank builds its own rows only; the
+    distributed product in CSR and - on the GPU - SELL-P, CG + block-Jacobi(4), against the single-domain
+    oracle (core/distributed/matrix.cpp:450-509, partition.hpp:262)"""
+    from ginkgo_amd import workloads as wl
+    n = 6000
+    rp, ci, v = wl.irregular_rows(n)
+    prefix = wl.irregular_row_prefix(n)
+    assert np.array_equal(prefix, rp.astype(np.int64))
+    offsets = wl.partition_by_nnz(prefix, world, align=4)
+    part = gd.Partition(offsets)
+    lo, hi = part.range_of(rank)
+    lrp, lci, lv = wl.irregular_rows(n, lo, hi)
+    assert np.array_equal(lci, ci[rp[lo]:rp[hi]]) and np.array_equal(lv, v[rp[lo]:rp[hi]])
+    shares = np.diff(prefix[offsets])
+    assert shares.max() <= 1.25 * prefix[-1] / world + 400           # (a hub row cannot be split)
+    xg = np.random.default_rng(13).uniform(-1, 1, n)
+    ref = o.csr_spmv(rp, ci, v, xg)[lo:hi]
+    xo, iters, _ = o.cg_solve(rp, ci, v, np.ones(n), max_iters=400, reduction=1e-10, precond="block",
+                              max_block_size=4)
+    for fmt in (("csr",) if mode == "cpu" else ("csr", "sellp")):
+        if mode == "cpu":
+            from cpu_backend import CpuCsr
+            a = gd.DistributedMatrix(be, comm, part, CpuCsr(hi - lo, n, lrp, lci, lv))
+        else:
+            import ginkgo_amd as g
+            owned = g.Csr.from_arrays(be.exec, (hi - lo, n), lrp, lci, lv)
+            a = gd.DistributedMatrix(be, comm, part, owned, local_format=fmt)
+        if world > 1:
+            assert sum(1 for c in a.recv_counts if c > 0) == world - 1, "the hubs reach every rank"
+        x, y = be.vector_from(xg[lo:hi]), be.vector(hi - lo)
+        a.apply(x, y)
+        err = np.max(np.abs(y.to_numpy()[:, 0] - ref)) / np.max(np.abs(ref))
+        assert err < 1e-14, f"rank {rank}: heavy-tailed spmv ({fmt}) err {err}"
+        solver = gd.DistributedCg(be, comm, a, 400, 1e-10, 4)
+        xs = be.vector(hi - lo)
+        solver.apply(be.vector_from(np.ones(hi - lo)), xs)
+        assert abs(solver.num_iterations - iters) <= 1, (fmt, solver.num_iterations, iters)
+        e = np.linalg.norm(xs.to_numpy()[:, 0] - xo[lo:hi]) / np.linalg.norm(xo[lo:hi])
+        assert e < 1e-8, f"rank {rank}: heavy-tailed cg ({fmt}) err {e}"
 
 
 if __name__ == "__main__":

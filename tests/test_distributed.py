@@ -170,6 +170,28 @@ def test_bench_starts_its_own_ranks_and_the_line_has_every_key():
     assert d["cg_iterations"] == 10 and d["pipe_cg_iterations"] == 10
 
 
+@pytest.mark.gpu
+def test_bench_configs4_irregular_stand_in_one_and_eight_ranks():
+    """`bench.py --workload irregular`: the heavy-tailed stand-in - power-law row
+    lengths, hub rows beyond GKOC_CSR_LONG_ROW that reach into every rank - SELL-P vs CSR on one GPU and on 8
+    ranks (entry-balanced contiguous rows); the line says what the matrix looks like"""
+    common = ["--workload", "irregular", "--irr-n", "120000", "--steps", "3", "--warmup", "1", "--cg-iters", "10",
+              "--block-size", "4"]
+    d1 = _bench_plain(["--format", "sellp", *common])
+    w = d1["config"]["workload"]
+    assert "irregular stand-in" in w and "n = 120000" in w and "rows beyond GKOC_CSR_LONG_ROW" in w
+    assert d1["formats"]["sellp"]["stored_over_nnz"] > 1.3 and d1["formats"]["csr"]["stored_over_nnz"] == 1.0
+    assert d1["formats"]["csr"]["ms"] > 0 and d1["formats"]["sellp"]["ms"] > 0
+    assert d1["cg"]["csr"]["cg_iterations"] == 10 and d1["cg"]["sellp"]["cg_iterations"] == 10
+    record_perf("bench_irregular_stand_in_120k", formats=d1["formats"], cg=d1["cg"])
+    d8 = _bench_plain(["--gpus", "8", "--format", "csr", *common], {"GKO_BENCH_BACKEND": "gloo"})
+    pr = d8["roofline"]["per_rank"]
+    assert d8["n_gpus"] == 8 and len(pr) == 8 and sum(r["rows"] for r in pr) == 120000
+    assert max(r["nnz"] for r in pr) <= 1.3 * sum(r["nnz"] for r in pr) / 8
+    assert d8["formats"]["csr"]["peers"] == 7                     # the hubs reach every rank
+    assert d8["cg"]["csr"]["cg_iterations"] == 10 and d8["cg"]["sellp"]["cg_iterations"] == 10
+
+
 def _bench_plain(args, env_extra=None):
     import json
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]

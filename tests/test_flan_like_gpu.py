@@ -70,3 +70,49 @@ def test_flan_like_cg_block_jacobi(gexec, oracle):
         assert s.has_converged and abs(s.num_iterations - iters) <= 1
         assert rel_frobenius(x.to_numpy()[:, 0], xo) < 1e-9
         assert np.linalg.norm(rhs - a @ x.to_numpy()[:, 0]) <= 1.01e-10 * np.linalg.norm(rhs)
+
+
+def test_heavy_tailed_stand_in_formats_and_cg(gexec, oracle):
+    """configs[4]'s SECOND stand-in, irregular on purpose (ginkgo_amd/workloads.py irregular_rows): power-law row
+    lengths and hub rows - at n = 80 000 one hub has 5 000 entries, beyond GKOC_CSR_LONG_ROW = 4096, where
+    the CSR kernel sums the row with the whole wave (csr_spmv_pipe.hpp: partial sums per lane, folded - the
+    one place where the row sum is not formed in entry order).  CSR: bit-identical to the oracle on every
+    row up to 4096 entries, 1e-15 on the hub rows; SELL-P (lane = row, entry order): bit-identical on ALL rows;
+    CG + block-Jacobi on both formats against the oracle's solve.
+    Reference: reference/matrix/csr_kernels.cpp:58-94, reference/matrix/sellp_kernels.cpp:27-100."""
+    import ginkgo_amd as g
+    from ginkgo_amd import workloads as wl
+    n = 80000
+    rp, ci, v = wl.irregular_rows(n)
+    lens = np.diff(rp)
+    assert lens.max() > 4096 and np.median(lens) <= 12 and np.percentile(lens, 99.9) < 100     # a heavy tail
+    a = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    assert abs(a - a.T).max() == 0.0
+    da = g.Csr.from_arrays(gexec, (n, n), rp, ci, v)
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    ref = oracle.csr_spmv(rp, ci, v, x)
+    y = g.Dense.create(gexec, (n, 1))
+    da.apply(g.Dense.from_numpy(gexec, x), y)
+    got = y.to_numpy()[:, 0]
+    short = lens <= 4096
+    assert np.array_equal(got[short], ref[short])
+    scale = np.abs(a) @ np.abs(x)
+    assert np.all(np.abs(got[~short] - ref[~short]) <= 1e-15 * scale[~short] * np.sqrt(lens[~short]))
+    sl = da.convert_to_sellp()
+    y2 = g.Dense.create(gexec, (n, 1))
+    sl.apply(g.Dense.from_numpy(gexec, x), y2)
+    assert np.array_equal(y2.to_numpy()[:, 0], ref)
+    # what the comparison of configs[4] is about: SELL-P pads every 64-row slice to its longest row
+    assert sl.values.numel() > 1.3 * a.nnz
+    rhs = np.ones(n)
+    xo, iters, _ = oracle.cg_solve(rp, ci, v, rhs, max_iters=500, reduction=1e-10, precond="block", max_block_size=4)
+    prec = g.Jacobi.build().with_max_block_size(4).on(gexec).generate(da)
+    for op in (da, sl):
+        s = (g.Cg.build()
+             .with_criteria(g.stop.Iteration.build().with_max_iters(500),
+                            g.stop.ResidualNorm.build().with_reduction_factor(1e-10))
+             .with_generated_preconditioner(prec).on(gexec).generate(op))
+        xs = g.Dense.from_numpy(gexec, np.zeros(n))
+        s.apply(g.Dense.from_numpy(gexec, rhs), xs)
+        assert s.has_converged and abs(s.num_iterations - iters) <= 1, (s.num_iterations, iters)
+        assert rel_frobenius(xs.to_numpy()[:, 0], xo) < 1e-9

@@ -93,3 +93,31 @@ def test_partition_by_nnz_balances_entries_and_respects_blocks():
     # more parts than rows: empty parts at the end, never a decreasing offset
     off = w.partition_by_nnz(np.array([0, 3, 6]), 5)
     assert off[0] == 0 and off[-1] == 2 and all(b >= a for a, b in zip(off, off[1:]))
+
+
+def test_irregular_stand_in_is_what_it_says():
+    """workloads.irregular_rows: symmetric, strictly diagonally dominant, heavy-tailed row lengths with hub rows;
+    any row range equals the same rows of the whole matrix (a rank builds its own rows only); the row-pointer
+    prefix used for the entry-balanced partition is exact"""
+    import numpy as np
+    import scipy.sparse as sp
+    from ginkgo_amd import workloads as wl
+    n = 30000
+    rp, ci, v = wl.irregular_rows(n)
+    a = sp.csr_matrix((v, ci, rp), shape=(n, n))
+    assert abs(a - a.T).max() == 0.0
+    off = abs(a).sum(axis=1).A1 - a.diagonal()
+    assert np.all(a.diagonal() == 1.0 + off) or np.allclose(a.diagonal(), 1.0 + off, rtol=1e-15)
+    lens = np.diff(rp)
+    assert np.median(lens) <= 12 and lens.max() > 1000 and np.percentile(lens, 99) < 60
+    assert np.all(np.diff(ci.astype(np.int64))[np.setdiff1d(np.arange(ci.size - 1), rp[1:-1] - 1)] > 0)   # sorted rows
+    assert np.array_equal(wl.irregular_row_prefix(n), rp.astype(np.int64))
+    hub = int(wl._irr_hubs(n)[0][0])
+    for lo, hi in ((0, 17), (12345, 12400), (hub - 2, hub + 3), (n - 9, n)):
+        r2, c2, v2 = wl.irregular_rows(n, lo, hi)
+        assert np.array_equal(r2, rp[lo:hi + 1] - rp[lo])
+        assert np.array_equal(c2, ci[rp[lo]:rp[hi]]) and np.array_equal(v2, v[rp[lo]:rp[hi]])
+    offs = wl.partition_by_nnz(rp, 8, align=4)
+    shares = np.diff(rp[offs].astype(np.int64))
+    assert offs[0] == 0 and offs[-1] == n and all(o % 4 == 0 for o in offs[:-1])
+    assert shares.max() <= 1.3 * rp[-1] / 8
