@@ -73,8 +73,11 @@ int scratch_free(hipStream_t st, void* ptr);
 // reduction (the word is 0 again when such a kernel ends; launches of one stream do not overlap).
 int stream_ticket(hipStream_t st, unsigned** word);
 
+// csr::spmv's memory of which segments of a matrix hold very long rows (csr_spmv.hip): forgotten when the
+// row-pointer array is freed
+void csr_long_rows_forget(const void* ptr);
 // tuning switches (runtime.hip; keys = GKOC_TUNE_* of gko_cdna4.h)
-constexpr int tune_num_keys = 12;
+constexpr int tune_num_keys = 13;
 int64_t tune_value(int key);
 
 #ifdef __HIPCC__

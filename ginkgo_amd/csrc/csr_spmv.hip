@@ -20,12 +20,140 @@
 //
 // Algorithmic HBM bytes: nnz*(sizeof(T)+sizeof(I)) + (n+1)*sizeof(I)
 //                        + n_cols*sizeof(T) (b once) + n*sizeof(T) (c).
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 #include "common.hpp"
+#include "csr_long_rows.hpp"
 #include "csr_spmv_multi.hpp"
 #include "csr_spmv_pipe.hpp"
 #include "fused.hpp"
 
 namespace gkoc {
+namespace {
+
+// ---- which 64-row segments of a matrix hold a row beyond GKOC_CSR_LONG_ROW (csr_long_rows.hpp) --------
+// Found by one scan of the row pointers the first time a (device, row_ptrs, n_rows) is multiplied, kept
+// here; gkoc_free forgets the entries of a pointer that goes away (csr_long_rows_forget).  A few dozen
+// matrices at most: the oldest entry makes room.
+std::mutex g_long_mtx;
+std::map<std::tuple<int, const void*, int64_t>, csr_long_info> g_long_cache;
+std::atomic<int> g_long_cached{0};
+constexpr size_t long_cache_cap = 128;
+constexpr int64_t long_list_cap = 4096;      // more flagged segments than this: the matrix has no "few long rows"
+
+thread_local bool t_long_releasing = false;      // gkoc_free below comes back through csr_long_rows_forget
+
+void long_info_release(csr_long_info& f)
+{
+    t_long_releasing = true;
+    if (f.bits) (void)gkoc_free(f.bits);
+    if (f.list) (void)gkoc_free(f.list);
+    if (f.partial) (void)gkoc_free(f.partial);
+    if (f.tickets) (void)gkoc_free(f.tickets);
+    f = csr_long_info{};
+    t_long_releasing = false;
+}
+
+template <typename T, typename I>
+int long_info_of(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, csr_long_info* out)
+{
+    int dev = 0;
+    GKOC_HIP(hipGetDevice(&dev));
+    const auto key = std::make_tuple(dev, static_cast<const void*>(row_ptrs), n_rows);
+    std::lock_guard<std::mutex> g(g_long_mtx);
+    auto it = g_long_cache.find(key);
+    if (it != g_long_cache.end()) {
+        *out = it->second;
+        return GKOC_OK;
+    }
+    if (g_long_cache.size() >= long_cache_cap) {
+        GKOC_HIP(hipStreamSynchronize(as_stream(s)));       // (its scratch may be in use by a product in flight)
+        long_info_release(g_long_cache.begin()->second);
+        g_long_cache.erase(g_long_cache.begin());
+    }
+    csr_long_info f;
+    const int64_t n_seg = ceildiv(n_rows, int64_t(64));
+    const size_t bit_bytes = size_t(ceildiv(n_seg, int64_t(32))) * 4;
+    const size_t list_bytes = size_t(1 + long_list_cap) * 8;
+    void *bits = nullptr, *list = nullptr;
+    GKOC_TRY(gkoc_malloc(&bits, bit_bytes));
+    if (gkoc_malloc(&list, list_bytes) != GKOC_OK) {
+        t_long_releasing = true;
+        (void)gkoc_free(bits);
+        t_long_releasing = false;
+        return GKOC_E_INVALID;
+    }
+    hipStream_t st = as_stream(s);
+    unsigned long long count = 0;
+    bool ok = hipMemsetAsync(bits, 0, bit_bytes, st) == hipSuccess && hipMemsetAsync(list, 0, 8, st) == hipSuccess;
+    if (ok) {
+        csr_long_row_scan_kernel<I><<<dim3(unsigned(ceildiv(n_seg, int64_t(4)))), dim3(256), 0, st>>>(
+            n_rows, row_ptrs, static_cast<uint32_t*>(bits), static_cast<unsigned long long*>(list), long_list_cap);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(&count, list, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    if (!ok || count == 0 || int64_t(count) > long_list_cap) {
+        // none (the common case), or so many that "a few long rows" is not what this matrix has: the
+        // row-segment kernel does everything, as before
+        (void)hipGetLastError();
+        t_long_releasing = true;
+        (void)gkoc_free(bits);
+        (void)gkoc_free(list);
+        t_long_releasing = false;
+    } else {
+        f.count = int64_t(count);
+        f.bits = static_cast<uint32_t*>(bits);
+        f.list = static_cast<unsigned long long*>(list);
+        void *partial = nullptr, *tickets = nullptr;
+        if (gkoc_malloc(&partial, size_t(count) * LONG_MAX_PER_SEG * LONG_PARTS * 8) != GKOC_OK ||
+            gkoc_malloc(&tickets, size_t(count) * 4) != GKOC_OK ||
+            hipMemsetAsync(tickets, 0, size_t(count) * 4, st) != hipSuccess) {
+            (void)hipGetLastError();
+            t_long_releasing = true;
+            if (partial) (void)gkoc_free(partial);
+            if (tickets) (void)gkoc_free(tickets);
+            t_long_releasing = false;
+            long_info_release(f);
+        } else {
+            f.partial = partial;
+            f.tickets = static_cast<uint32_t*>(tickets);
+        }
+    }
+    g_long_cache[key] = f;
+    g_long_cached.store(int(g_long_cache.size()));
+    *out = f;
+    return GKOC_OK;
+}
+
+}  // namespace
+
+void csr_long_rows_forget(const void* ptr)
+{
+    if (ptr == nullptr || t_long_releasing || g_long_cached.load(std::memory_order_relaxed) == 0) return;
+    std::vector<csr_long_info> gone;
+    {
+        std::lock_guard<std::mutex> g(g_long_mtx);
+        for (auto it = g_long_cache.begin(); it != g_long_cache.end();) {
+            if (std::get<1>(it->first) == ptr) {
+                gone.push_back(it->second);
+                it = g_long_cache.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        g_long_cached.store(int(g_long_cache.size()));
+    }
+    for (auto& f : gone) {
+        if (f.count > 0) (void)hipDeviceSynchronize();      // a product in flight may still use the scratch
+        long_info_release(f);
+    }
+}
+
 namespace {
 
 template <typename T, typename I, bool ADV, int rows_per_seg = 64>
@@ -189,11 +317,24 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         GKOC_LAUNCH_OK();
         return GKOC_OK;
     }
+    // rows far longer than the rest: their segments are left out here and done by many workgroups
+    // (csr_long_rows.hpp); one right-hand side, 64-row segments
+    csr_long_info lng;
+    if (nrhs == 1 && rows_per_seg == 64 && tune_value(GKOC_TUNE_CSR_LONG_ROWS) != 0) {
+        GKOC_TRY((long_info_of<T, I>(s, n_rows, row_ptrs, &lng)));
+    }
+    const uint32_t* seg_skip = lng.count > 0 ? lng.bits : nullptr;
 #define GKOC_LAUNCH_PIPE3(E_, U_, MODE_)                                       \
     csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, E_, U_, RINGV, 1, MODE_>    \
         <<<grid, block, 0, as_stream(s)>>>(                                    \
             n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, \
-            ldc, static_cast<int>(nrhs), alpha, beta, nullptr, xcd_map)
+            ldc, static_cast<int>(nrhs), alpha, beta, nullptr, xcd_map,        \
+            static_cast<const I*>(nullptr), static_cast<int*>(nullptr),        \
+            int64_t(0), int64_t(0), static_cast<const uint32_t*>(nullptr),     \
+            uint32_t(0), static_cast<const I*>(nullptr),                       \
+            static_cast<const I*>(nullptr), static_cast<const T*>(nullptr),    \
+            static_cast<uint32_t*>(nullptr), uint32_t(0), 0, int64_t(-1),      \
+            seg_skip)
     // XCD-contiguous wave order needs enough waves per XCD to keep the in-order
     // window argument valid; below that the plain order is used
     const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
@@ -233,6 +374,13 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     }
 #undef GKOC_LAUNCH_PIPE3
     GKOC_LAUNCH_OK();
+    if (lng.count > 0) {
+        csr_flagged_segments_kernel<T, I, ADV>
+            <<<dim3(unsigned(lng.count * LONG_PARTS)), dim3(LONG_WG), 0, as_stream(s)>>>(
+                n_rows, row_ptrs, col_idxs, vals, b, ldb, c, ldc, alpha, beta, lng.list,
+                static_cast<T*>(lng.partial), lng.tickets);
+        GKOC_LAUNCH_OK();
+    }
     return GKOC_OK;
 }
 

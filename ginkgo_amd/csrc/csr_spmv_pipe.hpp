@@ -58,7 +58,8 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
     const uint32_t* __restrict__ gate = nullptr, uint32_t gate_epoch = 0,
     const I* __restrict__ bnd_ptrs = nullptr, const I* __restrict__ bnd_cols = nullptr,
     const V* __restrict__ bnd_vals = nullptr, uint32_t* __restrict__ fork_word = nullptr,
-    uint32_t fork_number = 0, int gate_fence = 0, int64_t bnd_first = -1)
+    uint32_t fork_number = 0, int gate_fence = 0, int64_t bnd_first = -1,
+    const uint32_t* __restrict__ seg_skip = nullptr)
 {
     // (GATE mode points a wave at one of two matrices; everywhere else these are the arguments)
     int64_t n_rows = n_rows_in, n_segments = n_segments_in;
@@ -206,8 +207,14 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
             n_segments = n_int;
         }
     }
-    const int64_t sb = wave_id * segs_per_wave;
-    const int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
+    int64_t sb = wave_id * segs_per_wave;
+    int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
+    if (seg_skip != nullptr) {
+        // segments that hold a row far longer than the rest belong to csr_flagged_segments_kernel
+        // (csr_long_rows.hpp): a wave owns one or two segments, so what is left is one range
+        while (sb < se && ((seg_skip[sb >> 5] >> (sb & 31)) & 1u) != 0) ++sb;
+        while (se > sb && ((seg_skip[(se - 1) >> 5] >> ((se - 1) & 31)) & 1u) != 0) --se;
+    }
     // (GATE renumbers the boundary waves: a wave's partial sum has the number of its workgroup)
     const int64_t dot_slot = GATE ? int64_t(blockIdx.x) : wave_id;
     if (sb >= se) {

@@ -109,7 +109,7 @@ static bool g_tune_set[tune_num_keys] = {};
 // GKOC_TUNE_<n>, else the default chosen by measurement
 int64_t tune_value(int key)
 {
-    static const int64_t defaults[tune_num_keys] = {0, 0, 0, 2, 1, 0, 0, 0, 100, 0, 1, 0};   // measured: the XCD-contiguous order loses 1-8 %
+    static const int64_t defaults[tune_num_keys] = {0, 0, 0, 2, 1, 0, 0, 0, 100, 0, 1, 0, 1};   // measured: the XCD-contiguous order loses 1-8 %
     if (key < 0 || key >= tune_num_keys) return 0;
     if (!g_tune_set[key]) {
         char name[32];
@@ -292,7 +292,11 @@ int gkoc_malloc_managed(void** ptr, size_t bytes, unsigned int flags)
     return GKOC_OK;
 }
 
-int gkoc_free(void* ptr) { return arena_free(ptr); }
+int gkoc_free(void* ptr)
+{
+    gkoc::csr_long_rows_forget(ptr);     // what csr::spmv remembers about a matrix at this address (csr_spmv.hip)
+    return arena_free(ptr);
+}
 
 int gkoc_tune_set(int key, int64_t value)
 {

@@ -188,6 +188,12 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                       early, the application call that follows launches nothing); 0: off */
 #define GKOC_TUNE_CSR_MULTI_VARIANT 11 /* csr::spmv with three to eight right-hand sides: layout variants kept for A/B
                                       measurements (csrc/csr_spmv.hip); 0 = the default chosen by measurement */
+#define GKOC_TUNE_CSR_LONG_ROWS 12   /* csr::spmv, one right-hand side: 1 (default) the 64-row segments that hold a row
+                                      longer than GKOC_CSR_LONG_ROW are found once per matrix (one scan of the row
+                                      pointers, remembered per (row_ptrs, n_rows)) and multiplied by many workgroups
+                                      each (csrc/csr_long_rows.hpp) instead of by one wave; 0: one wave, as before.
+                                      Two products with the SAME matrix must not run at the same time on two streams
+                                      when it has such rows (they share the chunk sums' scratch) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,

@@ -98,6 +98,35 @@ def test_heavy_tailed_stand_in_formats_and_cg(gexec, oracle):
     assert np.array_equal(got[short], ref[short])
     scale = np.abs(a) @ np.abs(x)
     assert np.all(np.abs(got[~short] - ref[~short]) <= 1e-15 * scale[~short] * np.sqrt(lens[~short]))
+    # the segments with hub rows are multiplied by 64 workgroups each (csrc/csr_long_rows.hpp): the same bits
+    # every time (no floating-point atomics), the tickets are reset for the next product
+    first = got.copy()
+    for _ in range(3):
+        da.apply(g.Dense.from_numpy(gexec, x), y)
+        assert np.array_equal(y.to_numpy()[:, 0], first)
+    # c = alpha A b + beta c, int64 indices
+    c0 = np.random.default_rng(4).uniform(-1, 1, n)
+    ref_adv = oracle.csr_spmv(rp, ci, v, x, alpha=-0.75, beta=1.5, c=c0)
+    da64 = g.Csr.from_arrays(gexec, (n, n), rp.astype(np.int64), ci.astype(np.int64), v)
+    for mat in (da, da64):
+        ya = g.Dense.from_numpy(gexec, c0.copy())
+        mat.apply(g.scalar(gexec, -0.75), g.Dense.from_numpy(gexec, x), g.scalar(gexec, 1.5), ya)
+        ga = ya.to_numpy()[:, 0]
+        assert np.array_equal(ga[short], np.ravel(ref_adv)[short])
+        assert np.all(np.abs(ga[~short] - np.ravel(ref_adv)[~short]) <=
+                      2e-15 * (scale[~short] + np.abs(c0[~short])) * np.sqrt(lens[~short]))
+    # the answer does not depend on the switch (GKOC_TUNE_CSR_LONG_ROWS = 0: one wave per long row, as before)
+    import ctypes as C
+    from ginkgo_amd import _lib
+    _lib.call("gkoc_tune_set", C.c_int(12), C.c_int64(0))
+    try:
+        y0 = g.Dense.create(gexec, (n, 1))
+        da.apply(g.Dense.from_numpy(gexec, x), y0)
+    finally:
+        _lib.call("gkoc_tune_set", C.c_int(12), C.c_int64(1))
+    g0 = y0.to_numpy()[:, 0]
+    assert np.array_equal(g0[short], got[short])
+    assert np.all(np.abs(g0[~short] - got[~short]) <= 2e-15 * scale[~short] * np.sqrt(lens[~short]))
     sl = da.convert_to_sellp()
     y2 = g.Dense.create(gexec, (n, 1))
     sl.apply(g.Dense.from_numpy(gexec, x), y2)
