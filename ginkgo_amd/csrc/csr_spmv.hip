@@ -567,6 +567,25 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
     GKOC_REQUIRE(row_ptrs && b && c && work, GKOC_E_INVALID, "null pointer");
     GKOC_REQUIRE(work_bytes >= fused_workspace_bytes(n, sizeof(T)), GKOC_E_WORKSPACE,
                  "workspace too small (gkoc_x_workspace_bytes)");
+    // a matrix with rows far beyond the rest: the product with its long rows spread over many workgroups
+    // (csr_long_rows.hpp), then the dot product as a pass of its own - the fusion saves one pass over two
+    // vectors, a hub row summed by one wave costs milliseconds
+    if (tune_value(GKOC_TUNE_CSR_LONG_ROWS) != 0) {
+        csr_long_info lng;
+        GKOC_TRY((long_info_of<T, I>(s, n, row_ptrs, &lng)));
+        if (lng.count > 0) {
+            GKOC_TRY((launch_csr<T, I, false>(s, n, n, nullptr, row_ptrs, col_idxs, vals, b, 1, nullptr, c, 1, 1)));
+            if constexpr (sizeof(T) == 8) {
+                return gkoc_dense_compute_dot_f64(s, n, 1, reinterpret_cast<const double*>(b), 1,
+                                                  reinterpret_cast<const double*>(c), 1,
+                                                  reinterpret_cast<double*>(dot_out), work, work_bytes);
+            } else {
+                return gkoc_dense_compute_dot_f32(s, n, 1, reinterpret_cast<const float*>(b), 1,
+                                                  reinterpret_cast<const float*>(c), 1,
+                                                  reinterpret_cast<float*>(dot_out), work, work_bytes);
+            }
+        }
+    }
     constexpr int rows_per_seg = 64;
     const int64_t n_seg = ceildiv(n, rows_per_seg);
     // one segment per wave below 4 M rows, as in the plain kernel (a rank's share of a

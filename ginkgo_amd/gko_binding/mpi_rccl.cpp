@@ -30,7 +30,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -45,12 +47,39 @@ enum class mode { undecided, rccl, staged };
 
 struct comm_state {
     mode m = mode::undecided;
-    gkoc_comm_t rccl = nullptr;
+    gkoc_comm_t rccl = nullptr;    // the device-resident communicator: RCCL, or the library's mailboxes (ipc)
     int size = 0, rank = 0;
+    bool ipc = false;              // rccl is a mailbox communicator (csrc/comm_ipc.hpp): ranks may share a GPU
+    int64_t slot_bytes = 0;        //   ... whose messages are bounded
+};
+
+// A NONBLOCKING all-to-all-v whose route has to be agreed by the ranks first (route_of): the two-int
+// agreement travels as PMPI_Iallreduce inside the request, and the exchange itself is carried out when the
+// request is completed (MPI_Wait / a successful MPI_Test) - a blocking all-reduce inside MPI_Ialltoallv
+// would synchronise the ranks in a call MPI defines as local, and can deadlock a legal program in which a
+// rank posts the collective and then serves a point-to-point message its peer sends BEFORE posting its own
+// (ADVICE round 4).  The core's pattern - post, launch the local product, wait - loses nothing: the kernel
+// is already running when MPI_Wait starts the exchange.  The buffers and count arrays stay valid until
+// completion (MPI-3.1, 5.12).
+struct deferred_call {
+    int which = 0;                 // 0 MPI_Ialltoallv, 1 MPI_Ineighbor_alltoallv
+    const void* sendbuf = nullptr;
+    const int *scounts = nullptr, *sdispls = nullptr;
+    MPI_Datatype stype = MPI_DATATYPE_NULL;
+    void* recvbuf = nullptr;
+    const int *rcounts = nullptr, *rdispls = nullptr;
+    MPI_Datatype rtype = MPI_DATATYPE_NULL;
+    MPI_Comm comm = MPI_COMM_NULL;
+    int n = 0;
+    int mine[2] = {0, 0}, any[2] = {0, 0};
+    long seq = 0;                  // order of issue on its communicator: carried out in that order on every rank
+    int rc = MPI_SUCCESS;
+    bool done = false;
 };
 
 struct pending {
-    int kind = 0;                  // 1 rccl (stream work), 2 staged (real request + copy back)
+    int kind = 0;                  // 1 rccl (stream work), 2 staged (real request + copy back), 3 deferred
+    std::shared_ptr<deferred_call> call;
     MPI_Request inner = MPI_REQUEST_NULL;
     // staged: device destination, host staging source
     void* dev_dst = nullptr;
@@ -173,10 +202,43 @@ comm_state& state_of(MPI_Comm comm)
             ok = all_ok;
         }
     }
+    // No RCCL communicator (ranks that share a GPU - RCCL refuses that -, no librccl, a failed bring-up): the
+    // library's own transport, mailboxes in peer-mapped device memory (gkoc_comm_ipc_*), serves the same
+    // gkoc_comm_* calls; GKOC_MPI_TRANSPORT=rccl keeps to RCCL only, =ipc asks for the mailboxes first.
+    // Every step is agreed by all ranks (they all arrive here: state_of is collective).
+    const char* tr = std::getenv("GKOC_MPI_TRANSPORT");
+    const bool ipc_allowed = forced != 2 && st.size > 1 && st.size <= 16 && !(tr && !std::strcmp(tr, "rccl"));
+    if (!ok && ipc_allowed) {
+        unsigned char mine_h[GKOC_COMM_IPC_HANDLE_BYTES] = {0};
+        int have = gkoc_comm_ipc_create(&st.rccl, st.size, st.rank, 0, mine_h) == GKOC_OK ? 1 : 0;
+        int all_have = 0;
+        PMPI_Allreduce(&have, &all_have, 1, MPI_INT, MPI_MIN, comm);
+        if (all_have) {
+            std::vector<unsigned char> all(size_t(GKOC_COMM_IPC_HANDLE_BYTES) * st.size);
+            PMPI_Allgather(mine_h, GKOC_COMM_IPC_HANDLE_BYTES, MPI_BYTE, all.data(), GKOC_COMM_IPC_HANDLE_BYTES,
+                           MPI_BYTE, comm);
+            int conn = gkoc_comm_ipc_connect(st.rccl, all.data()) == GKOC_OK ? 1 : 0;
+            int all_conn = 0;
+            PMPI_Allreduce(&conn, &all_conn, 1, MPI_INT, MPI_MIN, comm);
+            ok = all_conn;
+        }
+        if (!ok && st.rccl) {
+            PMPI_Barrier(comm);            // nobody unmaps while a peer is still mapping
+            gkoc_comm_destroy(st.rccl);
+            st.rccl = nullptr;
+        }
+        if (ok) {
+            st.ipc = true;
+            const char* e = std::getenv("GKOC_IPC_SLOT_MIB");
+            const long mib = e ? std::atol(e) : 0;
+            st.slot_bytes = int64_t(mib > 0 ? mib : 8) << 20;
+        }
+    }
     st.m = ok ? mode::rccl : mode::staged;
     if (std::getenv("GKOC_MPI_VERBOSE") && st.rank == 0) {
         std::fprintf(stderr, "[gkoc_mpi] communicator of %d ranks: device buffers go %s\n", st.size,
-                     ok ? "over RCCL" : "through host staging");
+                     ok ? (st.ipc ? "through the library's mailboxes in peer-mapped device memory" : "over RCCL")
+                        : "through host staging");
     }
     return st;
 }
@@ -279,28 +341,38 @@ bool all_zero(const int* counts, int n)
     return true;
 }
 
-int route_of(MPI_Comm comm, const void* sendbuf, bool send_empty, const void* recvbuf, bool recv_empty)
+int route_from(const int any[2])
+{
+    if (!any[1]) return route_mpi;
+    return any[0] ? route_staged : route_rccl;
+}
+
+// the route where it is a local matter, else -1 with mine[] = what this rank contributes to the agreement
+int route_local(MPI_Comm comm, const void* sendbuf, bool send_empty, const void* recvbuf, bool recv_empty, int mine[2],
+                size_t max_message_bytes = 0)
 {
     if (env_mode() == 3) return route_mpi;
     const bool sdev = is_device(sendbuf), rdev = is_device(recvbuf);
     mode m;
     int size;
+    int64_t slot = 0;
     {
         std::lock_guard<std::mutex> g(g_mtx);
         const comm_state& st = state_of(comm);       // collective on first use: every rank is here
-        m = st.m;                                     // (read under the lock: the map may be rebalanced by
-        size = st.size;                               // another thread's first use of another communicator)
+        m = st.m;
+        size = st.size;
+        slot = st.ipc ? st.slot_bytes : 0;
     }
     if (m != mode::rccl || size == 1) {
-        // every route left is the MPI call itself: a local matter
         if (m == mode::rccl && sdev && rdev) return route_rccl;
         return (sdev || rdev) ? route_staged : route_mpi;
     }
-    int mine[2] = {((!sdev && !send_empty) || (!rdev && !recv_empty)) ? 1 : 0, (sdev || rdev) ? 1 : 0};
-    int any[2] = {0, 0};
-    PMPI_Allreduce(mine, any, 2, MPI_INT, MPI_MAX, comm);
-    if (!any[1]) return route_mpi;
-    return any[0] ? route_staged : route_rccl;
+    // (a message that does not fit the mailbox transport's slot sends everybody through the staged route,
+    // like a host buffer does)
+    const bool oversize = slot > 0 && int64_t(max_message_bytes) > slot;
+    mine[0] = ((!sdev && !send_empty) || (!rdev && !recv_empty) || oversize) ? 1 : 0;
+    mine[1] = (sdev || rdev) ? 1 : 0;
+    return -1;
 }
 
 // the exchange as grouped ncclSend / ncclRecv on the layer's stream (g_mtx held)
@@ -343,13 +415,62 @@ int rccl_alltoallv(const void* sendbuf, const int* scounts, const int* sdispls, 
 }
 
 // the all-to-all-v family, blocking or not (request != nullptr), over the peers of `comm`
+std::map<MPI_Comm, long> g_seq;             // deferred calls issued per communicator (g_mtx)
+
+int alltoallv_routed(int route, const void* sendbuf, const int* scounts, const int* sdispls, MPI_Datatype stype,
+                     void* recvbuf, const int* rcounts, const int* rdispls, MPI_Datatype rtype, MPI_Comm comm,
+                     MPI_Request* request, int n);
+
 int alltoallv_common(const void* sendbuf, const int* scounts, const int* sdispls, MPI_Datatype stype,
                      void* recvbuf, const int* rcounts, const int* rdispls, MPI_Datatype rtype, MPI_Comm comm,
                      MPI_Request* request, int n_peers_dense)
 {
-    const bool sdev = is_device(sendbuf), rdev = is_device(recvbuf);
     const int n = n_peers_dense;
-    const int route = route_of(comm, sendbuf, all_zero(scounts, n), recvbuf, all_zero(rcounts, n));
+    int mine[2] = {0, 0};
+    size_t biggest = 0;
+    for (int p = 0; p < n; ++p) {
+        biggest = std::max(biggest, std::max(size_t(scounts[p]) * type_bytes(stype), size_t(rcounts[p]) * type_bytes(rtype)));
+    }
+    int route = route_local(comm, sendbuf, all_zero(scounts, n), recvbuf, all_zero(rcounts, n), mine, biggest);
+    if (route < 0 && request != nullptr) {
+        auto d = std::make_shared<deferred_call>();
+        d->which = 0;
+        d->sendbuf = sendbuf;
+        d->scounts = scounts;
+        d->sdispls = sdispls;
+        d->stype = stype;
+        d->recvbuf = recvbuf;
+        d->rcounts = rcounts;
+        d->rdispls = rdispls;
+        d->rtype = rtype;
+        d->comm = comm;
+        d->n = n;
+        d->mine[0] = mine[0];
+        d->mine[1] = mine[1];
+        pending p;
+        p.kind = 3;
+        p.call = d;
+        int rc = PMPI_Iallreduce(d->mine, d->any, 2, MPI_INT, MPI_MAX, comm, &p.inner);
+        std::lock_guard<std::mutex> g(g_mtx);
+        d->seq = ++g_seq[comm];
+        *request = new_handle();
+        g_pending[*request] = p;
+        return rc;
+    }
+    if (route < 0) {
+        int any[2] = {0, 0};
+        PMPI_Allreduce(mine, any, 2, MPI_INT, MPI_MAX, comm);      // a blocking collective may synchronise
+        route = route_from(any);
+    }
+    return alltoallv_routed(route, sendbuf, scounts, sdispls, stype, recvbuf, rcounts, rdispls, rtype, comm, request,
+                            n);
+}
+
+int alltoallv_routed(int route, const void* sendbuf, const int* scounts, const int* sdispls, MPI_Datatype stype,
+                     void* recvbuf, const int* rcounts, const int* rdispls, MPI_Datatype rtype, MPI_Comm comm,
+                     MPI_Request* request, int n)
+{
+    const bool sdev = is_device(sendbuf), rdev = is_device(recvbuf);
     if (route == route_mpi) {
         g_stats[6]++;
         return request ? PMPI_Ialltoallv(sendbuf, scounts, sdispls, stype, recvbuf, rcounts, rdispls, rtype, comm,
@@ -447,6 +568,13 @@ int MPI_Finalize(void)
 {
     {
         std::lock_guard<std::mutex> g(g_mtx);
+        bool any_ipc = false;
+        for (auto& kv : g_comms) any_ipc = any_ipc || kv.second.ipc;
+        if (any_ipc) {
+            // (MPI_Finalize is collective: nobody unmaps a window a peer's kernel may still write into)
+            gkoc_device_synchronize();
+            PMPI_Barrier(MPI_COMM_WORLD);
+        }
         for (auto& kv : g_comms) {
             if (kv.second.rccl) gkoc_comm_destroy(kv.second.rccl);
         }
@@ -470,6 +598,9 @@ static void forget_comm(MPI_Comm comm)
     if (it == g_comms.end()) return;
     if (it->second.rccl) {
         gkoc_stream_synchronize(stream());
+        // (MPI_Comm_free is collective: every rank is here; no rank unmaps its window while a peer's kernel
+        // may still acknowledge into it)
+        if (it->second.ipc) PMPI_Barrier(comm);
         gkoc_comm_destroy(it->second.rccl);
     }
     g_comms.erase(it);
@@ -655,6 +786,10 @@ int MPI_Recv(void* buf, int count, MPI_Datatype datatype, int source, int tag, M
     return rc;
 }
 
+int neighbor_routed(int route, const void* sendbuf, const int* sendcounts, const int* sdispls, MPI_Datatype sendtype,
+                    void* recvbuf, const int* recvcounts, const int* rdispls, MPI_Datatype recvtype, MPI_Comm comm,
+                    MPI_Request* request);
+
 // neighbourhood collective of NeighborhoodCommunicator: counts per neighbour of the graph topology
 int MPI_Ineighbor_alltoallv(const void* sendbuf, const int* sendcounts, const int* sdispls, MPI_Datatype sendtype,
                             void* recvbuf, const int* recvcounts, const int* rdispls, MPI_Datatype recvtype,
@@ -668,12 +803,57 @@ int MPI_Ineighbor_alltoallv(const void* sendbuf, const int* sendcounts, const in
     int indeg = 0, outdeg = 0, weighted = 0, n = 0;
     PMPI_Dist_graph_neighbors_count(comm, &indeg, &outdeg, &weighted);
     PMPI_Comm_size(comm, &n);
-    // the route is agreed by all ranks of the communicator (route_of), not read off local pointers
-    const int route = route_of(comm, sendbuf, all_zero(sendcounts, outdeg), recvbuf, all_zero(recvcounts, indeg));
+    // the route is agreed by all ranks of the communicator, not read off local pointers - without blocking:
+    // the agreement travels in the request, the exchange is carried out at completion (deferred_call)
+    int mine[2] = {0, 0};
+    size_t biggest = 0;
+    for (int i = 0; i < outdeg; ++i) biggest = std::max(biggest, size_t(sendcounts[i]) * type_bytes(sendtype));
+    for (int i = 0; i < indeg; ++i) biggest = std::max(biggest, size_t(recvcounts[i]) * type_bytes(recvtype));
+    const int route = route_local(comm, sendbuf, all_zero(sendcounts, outdeg), recvbuf, all_zero(recvcounts, indeg),
+                                  mine, biggest);
+    if (route < 0) {
+        auto d = std::make_shared<deferred_call>();
+        d->which = 1;
+        d->sendbuf = sendbuf;
+        d->scounts = sendcounts;
+        d->sdispls = sdispls;
+        d->stype = sendtype;
+        d->recvbuf = recvbuf;
+        d->rcounts = recvcounts;
+        d->rdispls = rdispls;
+        d->rtype = recvtype;
+        d->comm = comm;
+        d->n = n;
+        d->mine[0] = mine[0];
+        d->mine[1] = mine[1];
+        pending p;
+        p.kind = 3;
+        p.call = d;
+        int rc = PMPI_Iallreduce(d->mine, d->any, 2, MPI_INT, MPI_MAX, comm, &p.inner);
+        std::lock_guard<std::mutex> g(g_mtx);
+        d->seq = ++g_seq[comm];
+        *request = new_handle();
+        g_pending[*request] = p;
+        return rc;
+    }
+    return neighbor_routed(route, sendbuf, sendcounts, sdispls, sendtype, recvbuf, recvcounts, rdispls, recvtype, comm,
+                           request);
+}
+
+// request == nullptr: the blocking form (a deferred call at its completion)
+int neighbor_routed(int route, const void* sendbuf, const int* sendcounts, const int* sdispls, MPI_Datatype sendtype,
+                    void* recvbuf, const int* recvcounts, const int* rdispls, MPI_Datatype recvtype, MPI_Comm comm,
+                    MPI_Request* request)
+{
+    int indeg = 0, outdeg = 0, weighted = 0, n = 0;
+    PMPI_Dist_graph_neighbors_count(comm, &indeg, &outdeg, &weighted);
+    PMPI_Comm_size(comm, &n);
     if (route == route_mpi) {
         g_stats[6]++;
-        return PMPI_Ineighbor_alltoallv(sendbuf, sendcounts, sdispls, sendtype, recvbuf, recvcounts, rdispls, recvtype,
-                                        comm, request);
+        return request ? PMPI_Ineighbor_alltoallv(sendbuf, sendcounts, sdispls, sendtype, recvbuf, recvcounts, rdispls,
+                                                  recvtype, comm, request)
+                       : PMPI_Neighbor_alltoallv(sendbuf, sendcounts, sdispls, sendtype, recvbuf, recvcounts, rdispls,
+                                                 recvtype, comm);
     }
     if (route == route_rccl) {
         std::vector<int> src(indeg ? indeg : 1), dst(outdeg ? outdeg : 1), w(indeg + outdeg + 1);
@@ -713,6 +893,18 @@ int MPI_Ineighbor_alltoallv(const void* sendbuf, const int* sendcounts, const in
         p.bytes = re.hi - re.lo;
         r_use = static_cast<char*>(p.host_src) - re.lo;
     }
+    if (!request) {
+        int rc = PMPI_Neighbor_alltoallv(s_use, sendcounts, sdispls, sendtype, r_use, recvcounts, rdispls, recvtype,
+                                         comm);
+        if (p.dev_dst && p.bytes) {
+            gkoc_memcpy_h2d(p.dev_dst, p.host_src, p.bytes, stream());
+            gkoc_stream_synchronize(stream());
+            g_stats[5] += long(p.bytes);
+        }
+        g_host.put(p.host_src);
+        g_host.put(p.host_send);
+        return rc;
+    }
     int rc = PMPI_Ineighbor_alltoallv(s_use, sendcounts, sdispls, sendtype, r_use, recvcounts, rdispls, recvtype, comm,
                                       &p.inner);
     *request = new_handle();
@@ -720,9 +912,25 @@ int MPI_Ineighbor_alltoallv(const void* sendbuf, const int* sendcounts, const in
     return rc;
 }
 
+// carry out one deferred call (its agreement first); g_mtx NOT held
+static void run_deferred(pending& p)
+{
+    deferred_call& d = *p.call;
+    if (d.done) return;
+    if (p.inner != MPI_REQUEST_NULL) PMPI_Wait(&p.inner, MPI_STATUS_IGNORE);
+    const int route = route_from(d.any);
+    d.rc = d.which == 0
+               ? alltoallv_routed(route, d.sendbuf, d.scounts, d.sdispls, d.stype, d.recvbuf, d.rcounts, d.rdispls,
+                                  d.rtype, d.comm, nullptr, d.n)
+               : neighbor_routed(route, d.sendbuf, d.scounts, d.sdispls, d.stype, d.recvbuf, d.rcounts, d.rdispls,
+                                 d.rtype, d.comm, nullptr);
+    d.done = true;
+}
+
 static int complete_ours(MPI_Request* request, MPI_Status* status, bool* ours)
 {
     pending p;
+    std::vector<pending> earlier;
     {
         std::lock_guard<std::mutex> g(g_mtx);
         auto it = g_pending.find(*request);
@@ -730,10 +938,30 @@ static int complete_ours(MPI_Request* request, MPI_Status* status, bool* ours)
         if (!*ours) return MPI_SUCCESS;
         p = it->second;
         g_pending.erase(it);
-        finish(p);
+        if (p.kind == 3) {
+            // collectives of a communicator are carried out in the order they were ISSUED, on every rank -
+            // whatever order the application completes its requests in
+            for (auto& q : g_pending) {
+                if (q.second.kind == 3 && q.second.call->comm == p.call->comm && q.second.call->seq < p.call->seq &&
+                    !q.second.call->done) {
+                    earlier.push_back(q.second);
+                }
+            }
+        } else {
+            finish(p);
+        }
+    }
+    int rc = MPI_SUCCESS;
+    if (p.kind == 3) {
+        std::sort(earlier.begin(), earlier.end(),
+                  [](const pending& a, const pending& b) { return a.call->seq < b.call->seq; });
+        for (auto& q : earlier) run_deferred(q);      // (their requests find the work done when they are completed)
+        run_deferred(p);
+        rc = p.call->rc;
     }
     PMPI_Grequest_complete(*request);
-    return PMPI_Wait(request, status);
+    int rc2 = PMPI_Wait(request, status);
+    return rc != MPI_SUCCESS ? rc : rc2;
 }
 
 int MPI_Wait(MPI_Request* request, MPI_Status* status)
@@ -749,6 +977,20 @@ int MPI_Wait(MPI_Request* request, MPI_Status* status)
 int MPI_Test(MPI_Request* request, int* flag, MPI_Status* status)
 {
     if (request && *request != MPI_REQUEST_NULL) {
+        {
+            // a deferred call whose agreement is still travelling is not complete (and MPI_Test does not wait)
+            std::lock_guard<std::mutex> g(g_mtx);
+            auto it = g_pending.find(*request);
+            if (it != g_pending.end() && it->second.kind == 3 && !it->second.call->done &&
+                it->second.inner != MPI_REQUEST_NULL) {
+                int arrived = 0;
+                PMPI_Test(&it->second.inner, &arrived, MPI_STATUS_IGNORE);
+                if (!arrived) {
+                    *flag = 0;
+                    return MPI_SUCCESS;
+                }
+            }
+        }
         bool ours = false;
         int rc = complete_ours(request, status, &ours);   // (completing is allowed: it may block)
         if (ours) {
