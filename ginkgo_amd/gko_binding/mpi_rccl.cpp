@@ -389,7 +389,11 @@ int rccl_alltoallv_locked(comm_state& st, const void* sendbuf, const int* scount
     }
     if (gkoc_comm_all_to_all_v_bytes(st.rccl, stream(), sendbuf, &a[0], &a[n], recvbuf, &a[2 * n], &a[3 * n]) !=
         GKOC_OK) {
-        std::fprintf(stderr, "[gkoc_mpi] RCCL all-to-all-v failed: %s\n", gkoc_last_error());
+        std::fprintf(stderr, "[gkoc_mpi] device all-to-all-v failed: %s\n", gkoc_last_error());
+        for (int p = 0; p < n; ++p) {
+            std::fprintf(stderr, "[gkoc_mpi]   peer %d: send %lld bytes at %lld, recv %lld bytes at %lld\n", p,
+                         (long long)a[p], (long long)a[n + p], (long long)a[2 * n + p], (long long)a[3 * n + p]);
+        }
         return MPI_ERR_OTHER;
     }
     g_stats[2]++;
@@ -438,11 +442,11 @@ int alltoallv_common(const void* sendbuf, const int* scounts, const int* sdispls
         d->sendbuf = sendbuf;
         d->scounts = scounts;
         d->sdispls = sdispls;
-        d->stype = stype;
+        PMPI_Type_dup(stype, &d->stype);      // the caller may free its datatype before the wait (MPI-3.1, 4.1.9)
         d->recvbuf = recvbuf;
         d->rcounts = rcounts;
         d->rdispls = rdispls;
-        d->rtype = rtype;
+        PMPI_Type_dup(rtype, &d->rtype);
         d->comm = comm;
         d->n = n;
         d->mine[0] = mine[0];
@@ -817,11 +821,11 @@ int MPI_Ineighbor_alltoallv(const void* sendbuf, const int* sendcounts, const in
         d->sendbuf = sendbuf;
         d->scounts = sendcounts;
         d->sdispls = sdispls;
-        d->stype = sendtype;
+        PMPI_Type_dup(sendtype, &d->stype);   // the caller may free its datatype before the wait (MPI-3.1, 4.1.9)
         d->recvbuf = recvbuf;
         d->rcounts = recvcounts;
         d->rdispls = rdispls;
-        d->rtype = recvtype;
+        PMPI_Type_dup(recvtype, &d->rtype);
         d->comm = comm;
         d->n = n;
         d->mine[0] = mine[0];
@@ -924,6 +928,8 @@ static void run_deferred(pending& p)
                                   d.rtype, d.comm, nullptr, d.n)
                : neighbor_routed(route, d.sendbuf, d.scounts, d.sdispls, d.stype, d.recvbuf, d.rcounts, d.rdispls,
                                  d.rtype, d.comm, nullptr);
+    PMPI_Type_free(&d.stype);
+    PMPI_Type_free(&d.rtype);
     d.done = true;
 }
 

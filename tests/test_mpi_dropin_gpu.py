@@ -110,3 +110,21 @@ def test_ginkgos_distributed_solver_example():
         res = float(re.search(r"Final Res norm: ([\d.e+-]+)", p.stdout).group(1))
         assert res < 1e-6
     assert abs(its["hip"] - its["reference"]) <= 1, its
+
+
+@pytest.mark.parametrize("ranks", [2, 3, 5])
+def test_mpi_layer_by_itself_on_the_mailbox_transport(ranks):
+    """tests/dropin/mpi_layer_test.cpp: MPI_Allreduce / Alltoall / (I)alltoallv / Ineighbor_alltoallv with DEVICE
+    buffers against what MPI defines - ranks sharing the GPU talk through the library's mailboxes, so the device
+    route of the layer runs here: the nonblocking agreement that travels in the request, two requests completed
+    in different orders on different ranks, MPI_Test before completion, a datatype freed before the wait"""
+    _need_ga()
+    exe = os.path.join(BIN_GA, "mpi_layer_test")
+    if not os.path.exists(exe):
+        pytest.skip("mpi_layer_test has not been built")
+    env = dict(os.environ, GKOC_MPI_VERBOSE="1", GKOC_IPC_PATIENCE_MS="8000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([MPIEXEC, "-n", str(ranks), exe], cwd=BIN_GA, capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert p.returncode == 0 and "MPI LAYER: ALL PASSED" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "mailboxes in peer-mapped device memory" in p.stderr
+    assert "staged 0 | all-to-all-v rccl" in p.stderr           # nothing went through the host
