@@ -57,18 +57,29 @@ def test_gpu_aware_core_hands_device_pointers_to_the_mpi_layer(ranks, grid):
     """The core built with GINKGO_HAVE_GPU_AWARE_MPI 1 (Ginkgo's GINKGO_FORCE_GPU_AWARE_MPI): no host
     staging inside Ginkgo, device pointers reach MPI_Allreduce / MPI_Ialltoallv, where
     libgkoc_mpi_rccl.so (ginkgo_amd/gko_binding/mpi_rccl.cpp) takes them.  The ranks share GPU 0
-    here, so the layer stages through pinned memory itself (RCCL refuses two ranks on a device);
-    same results as the host-staged flavor, read_distributed on the device included."""
+    here (RCCL refuses two ranks on a device): since round 5 the layer's device route runs on the
+    library's mailbox transport (csrc/comm_ipc.hpp) - every all-reduce of the distributed Vector and
+    every all-to-all-v of the RowGatherer stays on the device, NOT A BYTE through the host;
+    GKOC_MPI_TRANSPORT=rccl keeps to RCCL, i.e. here to the layer's staging through pinned memory.
+    Same results either way, read_distributed on the device included."""
     _need_ga()
-    p = subprocess.run([MPIEXEC, "-n", str(ranks), "./mpi_dist_test", str(grid)], cwd=BIN_GA,
-                       capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-    assert "GPU-aware MPI: 1" in p.stdout
-    assert "ALL PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
-    r = _routes(p.stdout)
-    assert r["ar_staged"] > 0 and r["a2a_staged"] > 0 and r["ar_rccl"] == 0 and r["a2a_rccl"] == 0, r
-    m = re.search(r"distributed::Matrix::apply, 2 right-hand sides.*\(([\d.e+-]+)\)", p.stdout)
-    assert m and float(m.group(1)) == 0.0, p.stdout
+    for transport in ("", "rccl"):
+        env = dict(os.environ, GKOC_IPC_PATIENCE_MS="8000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if transport:
+            env["GKOC_MPI_TRANSPORT"] = transport
+        p = subprocess.run([MPIEXEC, "-n", str(ranks), "./mpi_dist_test", str(grid)], cwd=BIN_GA,
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+        assert "GPU-aware MPI: 1" in p.stdout
+        assert "ALL PASSED" in p.stdout and "FAILED" not in p.stdout, p.stdout
+        r = _routes(p.stdout)
+        if transport == "rccl":
+            assert r["ar_staged"] > 0 and r["a2a_staged"] > 0 and r["ar_rccl"] == 0 and r["a2a_rccl"] == 0, r
+        else:
+            assert r["ar_rccl"] > 0 and r["a2a_rccl"] > 0 and r["ar_staged"] == 0 and r["a2a_staged"] == 0, r
+            assert r["host_bytes"] == 0, r
+        m = re.search(r"distributed::Matrix::apply, 2 right-hand sides.*\(([\d.e+-]+)\)", p.stdout)
+        assert m and float(m.group(1)) == 0.0, p.stdout
 
 
 def test_mpi_layer_routes_device_buffers_over_rccl():
