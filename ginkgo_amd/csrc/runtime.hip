@@ -396,6 +396,23 @@ int gkoc_memcpy_d2d(void* dst, const void* src, size_t bytes, gkoc_stream_t s)
     return GKOC_OK;
 }
 
+int gkoc_stream_query(gkoc_stream_t s, int* done)
+{
+    GKOC_REQUIRE(done, GKOC_E_INVALID, "done == NULL");
+    const hipError_t e = hipStreamQuery(as_stream(s));
+    if (e == hipSuccess) {
+        *done = 1;
+        return GKOC_OK;
+    }
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        *done = 0;
+        return GKOC_OK;
+    }
+    GKOC_HIP(e);
+    return GKOC_OK;
+}
+
 int gkoc_memset(void* dst, int value, size_t bytes, gkoc_stream_t s)
 {
     if (bytes == 0) return GKOC_OK;

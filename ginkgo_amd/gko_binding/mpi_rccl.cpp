@@ -120,6 +120,22 @@ gkoc_stream_t stream()
     return g_stream;
 }
 
+// Wait for the layer's stream WITHOUT starving MPI: a kernel of the mailbox transport (or of RCCL) may be
+// waiting for a peer whose own exchange starts only when ITS agreement - a PMPI_Iallreduce this rank takes
+// part in - has completed, and nonblocking collectives of MPICH advance only inside MPI calls.  A rank that
+// sat in hipStreamSynchronize would keep its peers' agreements from arriving (seen with two requests
+// completed in different orders on different ranks: tests/dropin/mpi_layer_test.cpp).
+void sync_progressing()
+{
+    for (;;) {
+        int done = 0;
+        if (gkoc_stream_query(stream(), &done) != GKOC_OK || done) break;
+        int flag = 0;
+        PMPI_Iprobe(MPI_ANY_SOURCE, MPI_ANY_TAG, MPI_COMM_WORLD, &flag, MPI_STATUS_IGNORE);   // drives the progress engine
+    }
+    gkoc_stream_synchronize(stream());
+}
+
 // What a GPU-aware MPI does implicitly when it is handed a device buffer: the kernels that produced
 // it are complete before the buffer is read.  Ginkgo's reductions and the RowGatherer synchronize
 // themselves (vector.cpp:484-657, row_gatherer.cpp:165: the wait below finds an idle device), but
@@ -206,6 +222,9 @@ comm_state& state_of(MPI_Comm comm)
     // library's own transport, mailboxes in peer-mapped device memory (gkoc_comm_ipc_*), serves the same
     // gkoc_comm_* calls; GKOC_MPI_TRANSPORT=rccl keeps to RCCL only, =ipc asks for the mailboxes first.
     // Every step is agreed by all ranks (they all arrive here: state_of is collective).
+    // (MPI knows no time-outs: a peer may reach its wait minutes after this rank - the kernels of the mailbox
+    // transport get ten minutes of patience here unless the environment says otherwise)
+    if (!std::getenv("GKOC_IPC_PATIENCE_MS")) setenv("GKOC_IPC_PATIENCE_MS", "600000", 0);
     const char* tr = std::getenv("GKOC_MPI_TRANSPORT");
     const bool ipc_allowed = forced != 2 && st.size > 1 && st.size <= 16 && !(tr && !std::strcmp(tr, "rccl"));
     if (!ok && ipc_allowed) {
@@ -287,7 +306,7 @@ int finish(pending& p)
 {
     int rc = MPI_SUCCESS;
     if (p.kind == 1) {
-        gkoc_stream_synchronize(stream());
+        sync_progressing();
     } else if (p.kind == 2) {
         if (p.inner != MPI_REQUEST_NULL) rc = PMPI_Wait(&p.inner, MPI_STATUS_IGNORE);
         if (p.dev_dst && p.bytes) {
@@ -403,7 +422,7 @@ int rccl_alltoallv_locked(comm_state& st, const void* sendbuf, const int* scount
         p.kind = 1;
         g_pending[*request] = p;
     } else {
-        gkoc_stream_synchronize(stream());
+        sync_progressing();
     }
     return MPI_SUCCESS;
 }
@@ -580,6 +599,15 @@ int MPI_Finalize(void)
             PMPI_Barrier(MPI_COMM_WORLD);
         }
         for (auto& kv : g_comms) {
+            if (kv.second.rccl && kv.second.ipc) {
+                // a wait of the mailbox transport that ran out of patience is an error the job must hear of
+                uint32_t st = 0;
+                if (gkoc_comm_status(kv.second.rccl, &st) == GKOC_OK && st != 0) {
+                    std::fprintf(stderr, "[gkoc_mpi] rank %d: the mailbox transport stopped waiting for a peer (status "
+                                         "%#x: 1 all-reduce, 2 message, 4 acknowledgement) - results since are suspect\n",
+                                 kv.second.rank, st);
+                }
+            }
             if (kv.second.rccl) gkoc_comm_destroy(kv.second.rccl);
         }
         g_comms.clear();
@@ -642,7 +670,7 @@ int MPI_Allreduce(const void* sendbuf, void* recvbuf, int count, MPI_Datatype da
             std::fprintf(stderr, "[gkoc_mpi] RCCL all-reduce failed: %s\n", gkoc_last_error());
             return MPI_ERR_OTHER;
         }
-        gkoc_stream_synchronize(stream());
+        sync_progressing();
         g_stats[0]++;
         return MPI_SUCCESS;
     }

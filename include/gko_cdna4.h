@@ -215,6 +215,8 @@ int gkoc_stream_create(gkoc_stream_t* s);
 int gkoc_stream_create_high_priority(gkoc_stream_t* s);   /* for the exchange / collective side stream */
 int gkoc_stream_destroy(gkoc_stream_t s);
 int gkoc_stream_synchronize(gkoc_stream_t s);
+/* *done = 1 if everything enqueued on s has completed, 0 if not (hipStreamQuery); never waits */
+int gkoc_stream_query(gkoc_stream_t s, int* done);
 int gkoc_device_synchronize(void);
 /* ROCTX ranges (log::begin_roctx / end_roctx, hip/base/roctx.hip.cpp:30-36; ProfilerHook::
  * create_roctx): librocprofiler-sdk-roctx / libroctx64 bound with dlopen at first use, no-ops

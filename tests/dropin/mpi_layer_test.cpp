@@ -48,6 +48,12 @@ int main(int argc, char** argv)
     MPI_Comm_rank(MPI_COMM_WORLD, &rank);
     MPI_Comm_size(MPI_COMM_WORLD, &size);
     gkoc_set_device(0);
+    double t_last = MPI_Wtime();
+    auto lap = [&](const char* what) {
+        const double t = MPI_Wtime();
+        if (rank == 0 && std::getenv("GKOC_MPI_VERBOSE")) std::fprintf(stderr, "[mpi_layer_test] %-40s %8.3f ms\n", what, (t - t_last) * 1e3);
+        t_last = t;
+    };
 
     // all_reduce: in place and out of place, doubles
     {
@@ -61,6 +67,7 @@ int main(int argc, char** argv)
         h = a.get();
         CHECK(h[0] == tot && h[1] == 0.5 * tot, "all-reduce, in place");
     }
+    lap("all-reduce (incl. bringing the communicator up)");
     // all_to_all of one int per rank (the sizes of read_distributed)
     {
         dev_array<int> s(size), r(size);
@@ -73,6 +80,7 @@ int main(int argc, char** argv)
         for (int p = 0; p < size; ++p) ok = ok && h[p] == 100 * p + rank;
         CHECK(ok, "all-to-all of one int per rank");
     }
+    lap("all-to-all");
     // all_to_all_v, blocking and nonblocking, uneven counts with gaps, some of them zero
     for (int nonblocking = 0; nonblocking < 3; ++nonblocking) {
         std::vector<int> sc(size), sd(size), rc(size), rd(size);
@@ -88,7 +96,7 @@ int main(int argc, char** argv)
         dev_array<double> s(spos + 4), r(rpos + 4);
         std::vector<double> hs(spos + 4, -1.0);
         for (int p = 0; p < size; ++p) {
-            for (int i = 0; i < sc[p]; ++i) hs[sd[p] + i] = 1000.0 * rank + 10.0 * p + 0.001 * i;
+            for (int i = 0; i < sc[p]; ++i) hs[sd[p] + i] = 1000.0 * rank + 10.0 * p + 0.001 * i + 1e5 * nonblocking;
         }
         s.put(hs);
         r.put(std::vector<double>(rpos + 4, -7.0));
@@ -125,10 +133,11 @@ int main(int argc, char** argv)
         auto h = r.get();
         bool ok = true;
         for (int p = 0; p < size; ++p) {
-            for (int i = 0; i < rc[p]; ++i) ok = ok && h[rd[p] + i] == 1000.0 * p + 10.0 * rank + 0.001 * i;
+            for (int i = 0; i < rc[p]; ++i) ok = ok && h[rd[p] + i] == 1000.0 * p + 10.0 * rank + 0.001 * i + 1e5 * nonblocking;
         }
         CHECK(ok, nonblocking == 0 ? "all-to-all-v" : nonblocking == 1 ? "nonblocking all-to-all-v" : "... data");
     }
+    lap("all-to-all-v x 3");
     // a derived datatype that is freed BEFORE the wait (core/distributed/row_gatherer.cpp apply_async: the
     // contiguous type of a multi-column vector lives in the scope that posts the exchange)
     {
@@ -156,6 +165,7 @@ int main(int argc, char** argv)
         }
         CHECK(ok, "nonblocking all-to-all-v with a datatype freed before the wait");
     }
+    lap("freed datatype");
     // the neighbourhood form on a ring (every rank talks to rank - 1 and rank + 1)
     if (size > 1) {
         const int left = (rank + size - 1) % size, right = (rank + 1) % size;
@@ -183,6 +193,7 @@ int main(int argc, char** argv)
         CHECK(ok, "nonblocking neighbourhood all-to-all-v on a ring");
         MPI_Comm_free(&ring);
     }
+    lap("neighbourhood all-to-all-v + Comm_free");
     int all = 0;
     MPI_Allreduce(&failures, &all, 1, MPI_INT, MPI_SUM, MPI_COMM_WORLD);
     if (rank == 0) std::printf(all == 0 ? "MPI LAYER: ALL PASSED (%d ranks)\n" : "MPI LAYER: %d FAILED\n", all == 0 ? size : all);

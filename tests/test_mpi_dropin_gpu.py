@@ -139,3 +139,4 @@ def test_mpi_layer_by_itself_on_the_mailbox_transport(ranks):
     assert p.returncode == 0 and "MPI LAYER: ALL PASSED" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
     assert "mailboxes in peer-mapped device memory" in p.stderr
     assert "staged 0 | all-to-all-v rccl" in p.stderr           # nothing went through the host
+    assert "stopped waiting for a peer" not in p.stderr        # no kernel of the transport ran out of patience
