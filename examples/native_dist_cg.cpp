@@ -129,6 +129,43 @@ static void exchange_id(int rank, unsigned char* id)
     throw std::runtime_error("no communicator id in " + path);
 }
 
+// the mailbox transport (gkoc_comm_ipc_*): every rank publishes the 64-byte handle of its window in
+// <path>.<rank> and reads the others' - ranks may share one GPU (RCCL refuses that)
+static std::string rendezvous_path()
+{
+    if (const char* f = getenv("GKOC_ID_FILE")) return f;
+    if (const char* port = getenv("MASTER_PORT")) return std::string("/tmp/gkoc_comm_id.") + port;
+    return "/tmp/gkoc_comm_id." + std::to_string(getppid());
+}
+
+static void exchange_handles(int rank, int world, const unsigned char* mine, std::vector<unsigned char>& all)
+{
+    const std::string base = rendezvous_path() + ".ipc.";
+    {
+        const std::string path = base + std::to_string(rank), tmp = path + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(mine, 1, GKOC_COMM_IPC_HANDLE_BYTES, f) != GKOC_COMM_IPC_HANDLE_BYTES) {
+            throw std::runtime_error("cannot write " + tmp);
+        }
+        fclose(f);
+        if (rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+    }
+    all.assign(size_t(world) * GKOC_COMM_IPC_HANDLE_BYTES, 0);
+    for (int r = 0; r < world; ++r) {
+        const std::string path = base + std::to_string(r);
+        bool ok = false;
+        for (int tries = 0; tries < 6000 && !ok; ++tries) {
+            if (FILE* f = fopen(path.c_str(), "rb")) {
+                ok = fread(&all[size_t(r) * GKOC_COMM_IPC_HANDLE_BYTES], 1, GKOC_COMM_IPC_HANDLE_BYTES, f) ==
+                     GKOC_COMM_IPC_HANDLE_BYTES;
+                fclose(f);
+            }
+            if (!ok) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        if (!ok) throw std::runtime_error("no window handle in " + path);
+    }
+}
+
 int main(int argc, char** argv)
 try {
     const int64_t grid = argc > 1 ? atoll(argv[1]) : 64;
@@ -138,8 +175,10 @@ try {
     int lag = argc > 5 ? atoi(argv[5]) : 4;
     bool mirror = false;
     std::string dump;
+    bool use_ipc = getenv("GKOC_EXAMPLE_TRANSPORT") && !strcmp(getenv("GKOC_EXAMPLE_TRANSPORT"), "ipc");
     for (int i = 6; i < argc; ++i) {
         if (!strcmp(argv[i], "mirror")) mirror = true;
+        if (!strcmp(argv[i], "ipc")) use_ipc = true;
         if (!strncmp(argv[i], "dump=", 5)) dump = argv[i] + 5;
     }
     if (lag < 0) lag = 0;
@@ -170,7 +209,14 @@ try {
 
     // ---- communicator (RCCL), id through a file
     gkoc_comm_t comm = nullptr;
-    if (world > 1) {
+    if (world > 1 && use_ipc && !mirror) {
+        // the library's own transport: mailboxes in peer-mapped device memory, one window per rank
+        unsigned char mine[GKOC_COMM_IPC_HANDLE_BYTES] = {};
+        std::vector<unsigned char> all;
+        CK(gkoc_comm_ipc_create(&comm, real_world, real_rank, 0, mine));
+        exchange_handles(real_rank, real_world, mine, all);
+        CK(gkoc_comm_ipc_connect(comm, all.data()));
+    } else if (world > 1) {
         unsigned char id[GKOC_COMM_ID_BYTES] = {};
         CK(gkoc_comm_load_rccl(getenv("GKOC_RCCL_PATH")));
         if (real_rank == 0) CK(gkoc_comm_unique_id(id));
@@ -519,6 +565,16 @@ try {
     }
     for (auto& e : events) gkoc_event_destroy(e);
     gkoc_free_host(flags_host);
+    if (comm && use_ipc && !mirror) {
+        // nobody unmaps its window while a peer may still write into it: a last all-reduce is behind every
+        // rank's exchanges in stream order, and its own stores have arrived when it completes
+        dev_array<double> last(1);
+        CK(gkoc_comm_all_reduce_sum(comm, s, last.p, 1, sizeof(double)));
+        CK(gkoc_stream_synchronize(s));
+        uint32_t st = 0;
+        CK(gkoc_comm_status(comm, &st));
+        if (st != 0) throw std::runtime_error("the mailbox transport stopped waiting for a peer (status " + std::to_string(st) + ")");
+    }
     if (comm) gkoc_comm_destroy(comm);
     return 0;
 } catch (const std::exception& e) {

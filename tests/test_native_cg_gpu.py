@@ -98,3 +98,53 @@ def test_native_distributed_driver_matches_oracle(oracle, solver, tmp_path):
     # iteration limit
     r = _run_dist(grid, 7, 1e-30, solver, 4, "mirror")
     assert r["iterations"] == 7 and not r["converged"]
+
+
+@pytest.mark.skipif(not os.path.exists(DEXE), reason="examples/native_dist_cg not built (run build())")
+@pytest.mark.parametrize("solver,world", [("cg", 2), ("pipe_cg", 4), ("cg", 8)])
+def test_native_distributed_driver_real_ranks_on_the_mailbox_transport(oracle, solver, world, tmp_path):
+    """the same C++ driver as REAL processes - `world` of them sharing cuda:0 - over the library's mailbox
+    transport (argument `ipc`: gkoc_comm_ipc_create / _connect, window handles through files): every all-reduce
+    and every halo exchange of the loop crosses process boundaries on the device; each rank's slab of x against
+    the single-process oracle, the same iteration count on every rank"""
+    grid = 16
+    n, plane = grid ** 3, grid * grid
+    rp, ci, v = oracle.stencil_csr(3, grid)
+    if solver == "cg":
+        xo, iters, _ = oracle.cg_solve(rp, ci, v, np.ones(n), max_iters=1000, reduction=1e-10,
+                                       precond="block", max_block_size=8)
+    else:
+        xo, iters, _ = oracle.krylov_solve("pipe_cg", rp, ci, v, np.ones(n), max_iters=1000,
+                                           reduction=1e-10, precond="block")
+    dump = str(tmp_path / f"x_{solver}_{world}")
+    idfile = str(tmp_path / "rendezvous")
+    procs = []
+    for r in range(world):
+        e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                 GKOC_ID_FILE=idfile, GKOC_IPC_PATIENCE_MS="20000", GKOC_ARENA_MAX_WALK="24")
+        for k in ("PMI_RANK", "PMI_SIZE"):
+            e.pop(k, None)
+        procs.append(subprocess.Popen([DEXE, str(grid), "1000", "1e-10", solver, "4", "ipc", "dump=" + dump],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e))
+    outs = []
+    try:
+        for p in procs:
+            so, se = p.communicate(timeout=300)
+            outs.append((p.returncode, so, se))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for rc, so, se in outs:
+        assert rc == 0, so[-1500:] + se[-3000:]
+    its = set()
+    planes = [(grid // world) * r + min(r, grid % world) for r in range(world + 1)]
+    for r, (rc, so, se) in enumerate(outs):
+        line = json.loads([ln for ln in so.strip().splitlines() if ln.startswith("{")][-1])
+        assert line["world"] == world and line["rank"] == r and line["converged"]
+        its.add(line["iterations"])
+        x = np.fromfile(dump + f".{r}", dtype=np.float64)
+        lo, hi = planes[r] * plane, planes[r + 1] * plane
+        assert x.shape == (hi - lo,)
+        assert np.linalg.norm(x - xo[lo:hi]) <= 1e-8 * np.linalg.norm(xo[lo:hi])
+    assert len(its) == 1 and abs(its.pop() - iters) <= 1
