@@ -449,7 +449,8 @@ int gkoc_comm_ipc_create(gkoc_comm_t* comm, int n_ranks, int rank, int64_t slot_
     if (!(wk && std::strcmp(wk, "plain") == 0)) {
         void* w = nullptr;
         if (hipExtMallocWithFlags(&w, c->window_bytes, hipDeviceMallocUncached) == hipSuccess) {
-            if (hipMemset(w, 0, c->window_bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+            // (only the words that are polled start at zero; the data slots are written before they are read)
+            if (hipMemset(w, 0, ipcx::DATA_OFF) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
                 hipIpcGetMemHandle(&h, w) == hipSuccess) {
                 c->window = static_cast<char*>(w);
                 c->window_uncached = true;
@@ -462,7 +463,7 @@ int gkoc_comm_ipc_create(gkoc_comm_t* comm, int n_ranks, int rank, int64_t slot_
     }
     if (!have) {
         void* w = nullptr;
-        if (hipMalloc(&w, c->window_bytes) != hipSuccess || hipMemset(w, 0, c->window_bytes) != hipSuccess ||
+        if (hipMalloc(&w, c->window_bytes) != hipSuccess || hipMemset(w, 0, ipcx::DATA_OFF) != hipSuccess ||
             hipDeviceSynchronize() != hipSuccess || hipIpcGetMemHandle(&h, w) != hipSuccess) {
             set_last_error("gkoc_comm_ipc_create: cannot allocate / export a window of %zu bytes: %s", c->window_bytes,
                            hipGetErrorString(hipGetLastError()));

@@ -46,6 +46,15 @@ struct kind_of<int16> {
     static constexpr int value = GKOC_CB_I16;
 };
 
+template <>
+struct kind_of<std::complex<double>> {
+    static constexpr int value = GKOC_CB_KEEP;
+};
+template <>
+struct kind_of<std::complex<float>> {
+    static constexpr int value = GKOC_CB_F32;    // complex<double> arithmetic, basis stored as complex<float>
+};
+
 // storage pointer, strides and scalars of either accessor kind
 template <typename T>
 struct unwrapped {
@@ -98,6 +107,21 @@ GKOC_CB_ABI(float, f32);
 template <typename T>
 constexpr bool is_real_v = std::is_same<T, double>::value || std::is_same<T, float>::value;
 
+// complex value types: csrc/cb_gmres_complex.hip (no scalars: the basis is a reduced_row_major accessor)
+template <typename T>
+struct cx_abi;
+#define GKOC_CB_CX_ABI(T, TN)                                                   \
+    template <>                                                                 \
+    struct cx_abi<T> {                                                          \
+        static constexpr auto initialize = gkoc_common_gmres_initialize_##TN;   \
+        static constexpr auto restart = gkoc_cb_gmres_restart_##TN;             \
+        static constexpr auto arnoldi = gkoc_cb_gmres_arnoldi_##TN;             \
+        static constexpr auto solve_krylov = gkoc_cb_gmres_solve_krylov_##TN;   \
+    }
+GKOC_CB_CX_ABI(std::complex<double>, c128);
+GKOC_CB_CX_ABI(std::complex<float>, c64);
+#undef GKOC_CB_CX_ABI
+
 }  // namespace
 
 
@@ -115,7 +139,10 @@ void initialize_impl(exec_t exec, const matrix::Dense<ValueType>* b, matrix::Den
             ld(residual), givens_sin->get_values(), ld(givens_sin), givens_cos->get_values(),
             ld(givens_cos), static_cast<int64_t>(krylov_dim), raw(stop_status)));
     } else {
-        GKO_NOT_COMPILED(hip);
+        GKOC_CALL(cx_abi<ValueType>::initialize(
+            stream_of(exec), rows(b), cols(b), b->get_const_values(), ld(b), residual->get_values(),
+            ld(residual), givens_sin->get_values(), ld(givens_sin), givens_cos->get_values(),
+            ld(givens_cos), static_cast<int64_t>(krylov_dim), raw(stop_status)));
     }
 }
 
@@ -139,7 +166,13 @@ void restart_impl(exec_t exec, const matrix::Dense<ValueType>* residual,
             next_krylov_basis->get_values(), ld(next_krylov_basis),
             reinterpret_cast<uint64_t*>(final_iter_nums->get_data())));
     } else {
-        GKO_NOT_COMPILED(hip);
+        const auto u = unwrap<ValueType>(krylov_bases);
+        GKOC_CALL(cx_abi<ValueType>::restart(
+            stream_of(exec), rows(residual), cols(residual), static_cast<int64_t>(krylov_dim),
+            residual->get_const_values(), ld(residual), residual_norm->get_values(),
+            residual_norm_collection->get_values(), ld(residual_norm_collection), u.kind, u.bases, u.st0,
+            u.st1, next_krylov_basis->get_values(), ld(next_krylov_basis),
+            reinterpret_cast<uint64_t*>(final_iter_nums->get_data())));
     }
 }
 
@@ -171,7 +204,18 @@ void arnoldi_impl(exec_t exec, matrix::Dense<ValueType>* next_krylov_basis,
             arnoldi_norm->get_values(), ld(arnoldi_norm),
             reinterpret_cast<uint64_t*>(final_iter_nums->get_data()), raw(stop_status)));
     } else {
-        GKO_NOT_COMPILED(hip);
+        const auto u = unwrap<ValueType>(krylov_bases);
+        const bool has_buffer = buffer_iter && rows(buffer_iter) >= static_cast<int64_t>(iter) + 1 &&
+                                cols(buffer_iter) >= cols(next_krylov_basis);
+        GKOC_CALL(cx_abi<ValueType>::arnoldi(
+            stream_of(exec), rows(next_krylov_basis), cols(next_krylov_basis),
+            static_cast<int64_t>(iter), next_krylov_basis->get_values(), ld(next_krylov_basis),
+            givens_sin->get_values(), ld(givens_sin), givens_cos->get_values(), ld(givens_cos),
+            residual_norm->get_values(), residual_norm_collection->get_values(),
+            ld(residual_norm_collection), u.kind, u.bases, u.st0, u.st1, hessenberg_iter->get_values(),
+            ld(hessenberg_iter), has_buffer ? buffer_iter->get_values() : nullptr,
+            has_buffer ? ld(buffer_iter) : 0, arnoldi_norm->get_values(), ld(arnoldi_norm),
+            reinterpret_cast<uint64_t*>(final_iter_nums->get_data()), raw(stop_status)));
     }
 }
 
@@ -192,7 +236,13 @@ void solve_krylov_impl(exec_t exec, const matrix::Dense<ValueType>* residual_nor
             y->get_values(), ld(y), before_preconditioner->get_values(), ld(before_preconditioner),
             reinterpret_cast<const uint64_t*>(final_iter_nums->get_const_data())));
     } else {
-        GKO_NOT_COMPILED(hip);
+        const auto u = unwrap<ValueType>(krylov_bases);
+        GKOC_CALL(cx_abi<ValueType>::solve_krylov(
+            stream_of(exec), rows(before_preconditioner), cols(before_preconditioner),
+            residual_norm_collection->get_const_values(), ld(residual_norm_collection), u.kind,
+            u.bases, u.st0, u.st1, hessenberg->get_const_values(), ld(hessenberg), y->get_values(), ld(y),
+            before_preconditioner->get_values(), ld(before_preconditioner),
+            reinterpret_cast<const uint64_t*>(final_iter_nums->get_const_data())));
     }
 }
 

@@ -229,7 +229,13 @@ comm_state& state_of(MPI_Comm comm)
     const bool ipc_allowed = forced != 2 && st.size > 1 && st.size <= 16 && !(tr && !std::strcmp(tr, "rccl"));
     if (!ok && ipc_allowed) {
         unsigned char mine_h[GKOC_COMM_IPC_HANDLE_BYTES] = {0};
-        int have = gkoc_comm_ipc_create(&st.rccl, st.size, st.rank, 0, mine_h) == GKOC_OK ? 1 : 0;
+        // Ginkgo creates communicators per matrix (dist-graph, split): a window per communicator must be cheap -
+        // 1 MiB per peer and direction unless GKOC_IPC_SLOT_MIB says otherwise (a halo of 131 072 doubles per
+        // neighbour; larger messages take the staged route, agreed by all ranks)
+        const char* se = std::getenv("GKOC_IPC_SLOT_MIB");
+        const long smib = se ? std::atol(se) : 0;
+        const int64_t slot = int64_t(smib > 0 ? smib : 1) << 20;
+        int have = gkoc_comm_ipc_create(&st.rccl, st.size, st.rank, slot, mine_h) == GKOC_OK ? 1 : 0;
         int all_have = 0;
         PMPI_Allreduce(&have, &all_have, 1, MPI_INT, MPI_MIN, comm);
         if (all_have) {
@@ -248,9 +254,7 @@ comm_state& state_of(MPI_Comm comm)
         }
         if (ok) {
             st.ipc = true;
-            const char* e = std::getenv("GKOC_IPC_SLOT_MIB");
-            const long mib = e ? std::atol(e) : 0;
-            st.slot_bytes = int64_t(mib > 0 ? mib : 8) << 20;
+            st.slot_bytes = slot;
         }
     }
     st.m = ok ? mode::rccl : mode::staged;

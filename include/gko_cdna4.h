@@ -717,6 +717,35 @@ GKOC_DECL_IDR(gkoc_c64, c64, float)
         T* before_preconditioner, int64_t ldo, const uint64_t* final_iter_nums);
 GKOC_DECL_CB_GMRES(double, f64)
 GKOC_DECL_CB_GMRES(float, f32)
+/* complex value types (csrc/cb_gmres_complex.hip): the basis is stored as complex<double> (GKOC_CB_KEEP) or,
+ * for complex<double> arithmetic, as complex<float> (GKOC_CB_F32) - the accessor reduced_row_major of
+ * GKO_INSTANTIATE_FOR_EACH_CB_GMRES_TYPE; no scaled integer storage for complex values; residual_norm and
+ * arnoldi_norm are real (R = remove_complex<T>).  Re-orthogonalisation as in the stock device kernels
+ * (common/cuda_hip/solver/cb_gmres_kernels.cpp update_next_krylov_kernel): no conjugate on the basis in the
+ * update.  Agrees with the ReferenceExecutor to rounding. */
+#define GKOC_DECL_CB_GMRES_CX(T, TN, R)                                          \
+    int gkoc_cb_gmres_restart_##TN(                                              \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t krylov_dim,         \
+        const T* residual, int64_t ldr, R* residual_norm,                        \
+        T* residual_norm_collection, int64_t ld_rnc, int storage_kind,           \
+        void* bases, int64_t st0, int64_t st1, T* next_krylov, int64_t ldn,      \
+        uint64_t* final_iter_nums);                                              \
+    int gkoc_cb_gmres_arnoldi_##TN(                                              \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs, int64_t iter,               \
+        T* next_krylov, int64_t ldn, T* givens_sin, int64_t ld_sin,              \
+        T* givens_cos, int64_t ld_cos, R* residual_norm,                         \
+        T* residual_norm_collection, int64_t ld_rnc, int storage_kind,           \
+        void* bases, int64_t st0, int64_t st1, T* hessenberg_iter, int64_t ld_h, \
+        T* buffer_iter, int64_t ld_buf, R* arnoldi_norm, int64_t ld_an,          \
+        uint64_t* final_iter_nums, const uint8_t* stop_status);                  \
+    int gkoc_cb_gmres_solve_krylov_##TN(                                         \
+        gkoc_stream_t s, int64_t rows, int64_t nrhs,                             \
+        const T* residual_norm_collection, int64_t ld_rnc, int storage_kind,     \
+        const void* bases, int64_t st0, int64_t st1, const T* hessenberg,        \
+        int64_t ld_h, T* y, int64_t ldy, T* before_preconditioner, int64_t ldo,  \
+        const uint64_t* final_iter_nums);
+GKOC_DECL_CB_GMRES_CX(gkoc_c128, c128, double)
+GKOC_DECL_CB_GMRES_CX(gkoc_c64, c64, float)
 
 /* ------------------------------------------------------- stopping criteria
  * residual_norm::residual_norm, implicit_residual_norm::implicit_residual_norm,

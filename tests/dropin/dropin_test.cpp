@@ -1154,6 +1154,46 @@ int main(int argc, char** argv)
                     .with_foci(std::pair<ct, ct>{ct{8.0, 0.0}, ct{44.0, 0.0}})
                     .on(ex);
             }, "Chebyshev", 1e-12);
+            // CbGmres on complex values (round 5: csrc/cb_gmres_complex.hip): the Krylov basis kept as
+            // complex<double> and reduced to complex<float> (cb_gmres_kernels.hpp:37-94), a fixed number of
+            // iterations with one restart, against the ReferenceExecutor
+            {
+                using gko::solver::cb_gmres::storage_precision;
+                const storage_precision precs[] = {storage_precision::keep, storage_precision::reduce1};
+                const char* pnames[] = {"keep", "reduce1 (complex<float> basis)"};
+                for (int pi = 0; pi < 2; ++pi) {
+                    const auto prec = precs[pi];
+                    run([&](std::shared_ptr<const gko::Executor> ex) {
+                        return gko::solver::CbGmres<ct>::build()
+                            .with_criteria(gko::stop::Iteration::build().with_max_iters(14u))
+                            .with_krylov_dim(8u)
+                            .with_storage_precision(prec)
+                            .on(ex);
+                    }, (std::string("CbGmres(8), 14 iterations, ") + pnames[pi]).c_str(), pi == 0 ? 1e-10 : 1e-5);
+                }
+                // ... and to convergence: the true residual on the device
+                auto solver = gko::solver::CbGmres<ct>::build()
+                                  .with_criteria(gko::stop::Iteration::build().with_max_iters(400u),
+                                                 gko::stop::ResidualNorm<ct>::build().with_reduction_factor(1e-10))
+                                  .with_krylov_dim(20u)
+                                  .on(hip)
+                                  ->generate(a1);
+                auto xb = CDense::create(hip, gko::dim<2>{m, 1});
+                xb->fill(ct{0.0, 0.0});
+                auto bd = gko::clone(hip, b0);
+                solver->apply(bd, xb);
+                auto rr = gko::clone(hip, bd);
+                auto one_c = gko::initialize<CDense>({ct{1.0, 0.0}}, hip);
+                auto neg_c = gko::initialize<CDense>({ct{-1.0, 0.0}}, hip);
+                a1->apply(neg_c, xb, one_c, rr);
+                auto nr = gko::matrix::Dense<double>::create(ref, gko::dim<2>{1, 1});
+                auto nb = gko::matrix::Dense<double>::create(ref, gko::dim<2>{1, 1});
+                gko::clone(ref, rr)->compute_norm2(nr);
+                b0->compute_norm2(nb);
+                std::cout << "complex CbGmres(20) to 1e-10: true relative residual " << nr->at(0, 0) / nb->at(0, 0)
+                          << std::endl;
+                CHECK(nr->at(0, 0) <= 2e-10 * nb->at(0, 0), "complex<double> CbGmres converges on hip (true residual)");
+            }
             {
                 auto h_md = md;
                 gko::matrix_data<ct, it> herm{md.size};

@@ -64,7 +64,8 @@ def main():
         comm.all_reduce_begin(t, side)
         comm.all_reduce_end()
         want = rank_order_sum(gather_host(mine))
-        assert t.cpu().numpy().tobytes() == want.tobytes(), (rank, rep)
+        ex.synchronize()
+        assert t.cpu().numpy().tobytes() == want.tobytes(), (rank, rep, hex(comm.status()), t.cpu().tolist(), want.tolist())
     # ---- many in a row with values that change every time (parities, epochs): checked at the end ----
     iters = 2000
     acc = torch.zeros(2, dtype=torch.float64, device=dev)

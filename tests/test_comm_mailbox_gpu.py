@@ -27,7 +27,7 @@ def _free_port():
 
 
 def _run(script, world, args, timeout=600, extra_env=None):
-    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GKOC_IPC_PATIENCE_MS="8000",
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", GKOC_IPC_PATIENCE_MS="60000",
                **(extra_env or {}))
     env.setdefault("GKOC_ARENA_MAX_WALK", "24")          # ranks sharing one GPU: short surveys
     for attempt in range(2):

@@ -135,7 +135,7 @@ def test_bench_command_path_on_the_device_resident_transport():
     mailbox transport, so bench.py's N > 1 path is the DEVICE-RESIDENT one the 8-GPU run takes (forks,
     side stream, one-kernel gated product, PipeCg with gated steps) - not the host-staged gloo one"""
     d = _bench(8, ["--steps", "3", "--warmup", "1", "--grid", "32", "--cg-iters", "20", "--pipe-cg"],
-               {"GKO_BENCH_BACKEND": "gloo", "GKO_COMM": "ipc", "GKOC_IPC_PATIENCE_MS": "8000"})
+               {"GKO_BENCH_BACKEND": "gloo", "GKO_COMM": "ipc", "GKOC_IPC_PATIENCE_MS": "60000"})
     assert d["n_gpus"] == 8 and d["cg_iterations"] == 20 and d["pipe_cg_iterations"] == 20
     assert d["comm_check"]["communicator"] == "IpcComm" and d["comm_check"]["transport_choice"]["chosen"] == "IpcComm"
     assert d["distributed_product"]["one_kernel_product"], d["distributed_product"]

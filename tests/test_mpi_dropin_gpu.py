@@ -64,7 +64,7 @@ def test_gpu_aware_core_hands_device_pointers_to_the_mpi_layer(ranks, grid):
     Same results either way, read_distributed on the device included."""
     _need_ga()
     for transport in ("", "rccl"):
-        env = dict(os.environ, GKOC_IPC_PATIENCE_MS="8000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, GKOC_IPC_PATIENCE_MS="60000", HSA_ENABLE_IPC_MODE_LEGACY="0")
         if transport:
             env["GKOC_MPI_TRANSPORT"] = transport
         p = subprocess.run([MPIEXEC, "-n", str(ranks), "./mpi_dist_test", str(grid)], cwd=BIN_GA,
@@ -133,7 +133,7 @@ def test_mpi_layer_by_itself_on_the_mailbox_transport(ranks):
     exe = os.path.join(BIN_GA, "mpi_layer_test")
     if not os.path.exists(exe):
         pytest.skip("mpi_layer_test has not been built")
-    env = dict(os.environ, GKOC_MPI_VERBOSE="1", GKOC_IPC_PATIENCE_MS="8000", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, GKOC_MPI_VERBOSE="1", GKOC_IPC_PATIENCE_MS="60000", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([MPIEXEC, "-n", str(ranks), exe], cwd=BIN_GA, capture_output=True, text=True, timeout=600,
                        env=env)
     assert p.returncode == 0 and "MPI LAYER: ALL PASSED" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]

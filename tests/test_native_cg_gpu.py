@@ -121,7 +121,7 @@ def test_native_distributed_driver_real_ranks_on_the_mailbox_transport(oracle, s
     procs = []
     for r in range(world):
         e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                 GKOC_ID_FILE=idfile, GKOC_IPC_PATIENCE_MS="20000", GKOC_ARENA_MAX_WALK="24")
+                 GKOC_ID_FILE=idfile, GKOC_IPC_PATIENCE_MS="60000", GKOC_ARENA_MAX_WALK="24")
         for k in ("PMI_RANK", "PMI_SIZE"):
             e.pop(k, None)
         procs.append(subprocess.Popen([DEXE, str(grid), "1000", "1e-10", solver, "4", "ipc", "dump=" + dump],
