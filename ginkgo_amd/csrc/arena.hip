@@ -440,9 +440,19 @@ struct walk_turn {
     {
         const char* dir = std::getenv("TMPDIR");
         char path[512];
-        snprintf(path, sizeof(path), "%s/gkoc_arena_dev%d_uid%u.lock", dir && *dir ? dir : "/tmp", dev,
+        // keyed by the PHYSICAL device (PCI bus id): under HIP_VISIBLE_DEVICES two processes call the same GPU
+        // by different ordinals and different GPUs by the same one
+        char bus[32] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus), dev) != hipSuccess) {
+            (void)hipGetLastError();
+            snprintf(bus, sizeof(bus), "dev%d", dev);
+        }
+        for (char* c = bus; *c; ++c) {
+            if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+        }
+        snprintf(path, sizeof(path), "%s/gkoc_arena_%s_uid%u.lock", dir && *dir ? dir : "/tmp", bus,
                  unsigned(getuid()));
-        fd = ::open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        fd = ::open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
         if (fd < 0) return;
         for (int tries = 0; tries < 2000; ++tries) {
             if (::flock(fd, LOCK_EX | LOCK_NB) == 0) return;
