@@ -41,7 +41,10 @@ def _run(script, world, args, timeout=600, extra_env=None):
     return p.stdout
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
+# (8 processes with a torch runtime each oversubscribe the hardware queues of ONE device: 5 s on a fresh box,
+# minutes inside the whole suite - eight REAL processes run in test_native_cg_gpu.py (C++ driver, 2 s) and in
+# the solvers test below; the collectives' definitions do not depend on the count)
+@pytest.mark.parametrize("world", [2, 3, 5] + ([8] if os.environ.get("GKO_TEST_FULL_SOLVE") == "1" else []))
 def test_mailbox_collectives_against_their_definition(world):
     out = _run("ipc_worker.py", world, ["collectives"])
     assert "ipc_worker OK" in out
