@@ -438,7 +438,9 @@ int gkoc_comm_ipc_create(gkoc_comm_t* comm, int n_ranks, int rank, int64_t slot_
     c->window_bytes = ipcx::DATA_OFF + size_t(2) * size_t(n_ranks) * size_t(slot_bytes);
     const char* pe = std::getenv("GKOC_IPC_PATIENCE_MS");
     const long pms = pe ? std::atol(pe) : 0;
-    c->patience = (long long)(pms > 0 ? pms : 20000) * 100000ll;      // 100 MHz clock
+    // (two minutes: ranks of a real job reach their first collectives seconds apart - allocator surveys,
+    // matrix set-up - and a peer that is merely late must not be taken for one that is gone)
+    c->patience = (long long)(pms > 0 ? pms : 120000) * 100000ll;     // 100 MHz clock
     // Uncached device memory (what RCCL takes for its own flags and buffers): a peer's stores are seen by
     // this device's polling loads without relying on L2 behaviour; plain hipMalloc if that cannot be had
     // or exported (GKOC_IPC_WINDOW=plain asks for it).

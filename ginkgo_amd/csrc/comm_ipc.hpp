@@ -30,7 +30,7 @@
 //       receive buffer and the last one acknowledges.  Messages are numbered per PAIR, so a rank
 //       talks to its neighbours only.
 //
-// Everything that waits has a patience (GKOC_IPC_PATIENCE_MS, 20 s): a wait that runs out sets a
+// Everything that waits has a patience (GKOC_IPC_PATIENCE_MS, two minutes): a wait that runs out sets a
 // bit in the communicator's status word (gkoc_comm_status) and lets the kernel end - a wrong number
 // that is reported, not a hung device.
 #ifndef GKOC_COMM_IPC_HPP_
