@@ -131,6 +131,6 @@ def test_no_kernel_of_the_path_is_left_on_a_stub():
     assert len(strong) >= 220, len(strong)
     # every value type: the path's kernels exist for the two complex types as for the real ones
     for kernel in ("csr::spmv", "ell::spmv", "sellp::spmv", "coo::spmv2", "cg::step_2", "jacobi::generate",
-                   "idr::step_3", "minres::step_1", "csr::spgemm", "dense::apply"):
+                   "idr::step_3", "minres::step_1", "csr::spgemm", "dense::apply", "cb_gmres::arnoldi"):
         pat = re.compile(r" T .*gko::kernels::hip::" + kernel.replace("::", "::") + r"<std::complex<double>")
         assert any(pat.search(l) for l in out.splitlines()), kernel + " has no complex<double> definition"
