@@ -70,6 +70,14 @@ int long_info_of(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, csr_long_in
         *out = it->second;
         return GKOC_OK;
     }
+    // a stream that is being captured into a hipGraph cannot be synchronised: a matrix first seen there is
+    // multiplied by the row-segment kernel alone (correct for any row), and looked at on its next product
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(as_stream(s), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        *out = csr_long_info{};
+        return GKOC_OK;
+    }
     if (g_long_cache.size() >= long_cache_cap) {
         GKOC_HIP(hipStreamSynchronize(as_stream(s)));       // (its scratch may be in use by a product in flight)
         long_info_release(g_long_cache.begin()->second);
