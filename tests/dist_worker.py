@@ -23,12 +23,17 @@ def fallback_case(mode):
     import types
     import ginkgo_amd.distributed as gd
     rank, world = dist.get_rank(), dist.get_world_size()
-    os.environ["GKO_COMM"] = "rccl"                 # attempt it although the group is gloo
     if mode.endswith("cpu"):
         ex = types.SimpleNamespace(device=torch.device("cpu"), stream=None)
     else:
         import ginkgo_amd as g
         ex = g.Cdna4Executor.create(0)
+    # both device-resident transports, each attempted although the group is gloo: the library's mailboxes
+    # (IpcComm; on a box without a GPU its window cannot be created on ANY rank) and RCCL
+    os.environ["GKO_COMM"] = "ipc"
+    comm = gd.default_comm(ex)
+    assert type(comm) is gd.TorchComm and gd.default_comm.last["chosen"] == "TorchComm", (type(comm), gd.default_comm.last)
+    os.environ["GKO_COMM"] = "rccl"
     comm = gd.default_comm(ex)
     assert type(comm) is gd.TorchComm, type(comm)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
