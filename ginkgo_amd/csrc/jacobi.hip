@@ -1644,7 +1644,7 @@ using namespace gkoc;
 
 // complex block-Jacobi: find_blocks (indices only), generate (the Gauss-Jordan kernel above on
 // gkoc_cplx: pivot by magnitude), simple_apply / apply (jacobi_apply_simple_kernel).  Uniform storage
-// precision only; agrees with the reference to rounding.
+// precision (block-wise / adaptive: the end of this file); agrees with the reference to rounding.
 #define GKOC_DEF_CJACOBI(T, TN, I, IN)                                                                  \
     extern "C" int gkoc_jacobi_find_blocks_##TN##_##IN(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, \
                                                        const I* col_idxs, uint32_t max_block_size,      \
@@ -1660,7 +1660,7 @@ using namespace gkoc;
     {                                                                                                   \
         (void)n_rows;                                                                                   \
         GKOC_REQUIRE(conditioning == nullptr, GKOC_E_NOT_SUPPORTED,                                     \
-                     "adaptive-precision block-Jacobi exists for double only");                         \
+                     "condition numbers: gkoc_jacobi_generate_adaptive_* computes them");               \
         GKOC_REQUIRE(max_block_size <= 32, GKOC_E_NOT_SUPPORTED, "complex blocks: max_block_size <= 32"); \
         return launch_generate<T, I>(s, row_ptrs, col_idxs, vals, num_blocks, max_block_size, scheme,   \
                                      block_ptrs, blocks);                                               \
@@ -1838,7 +1838,7 @@ __global__ __launch_bounds__(256) void jacobi_transpose_kernel(
         GKOC_REQUIRE(block_ptrs && blocks && out_blocks, GKOC_E_INVALID, "null pointer");   \
         GKOC_REQUIRE(scheme.block_offset >= 1, GKOC_E_INVALID, "bad storage scheme");       \
         GKOC_REQUIRE(precisions == nullptr || sizeof(T) == 8, GKOC_E_NOT_SUPPORTED,         \
-                     "reduced block storage is implemented for double only");               \
+                     "reduced float blocks: gkoc_jacobi_transpose_adaptive_f32_*");         \
         int64_t nb = ceildiv(num_blocks * scheme.block_offset, 256);                        \
         if (nb > 4 * max_stream_blocks) nb = 4 * max_stream_blocks;                         \
         jacobi_transpose_kernel<T, I><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(  \
@@ -2086,3 +2086,422 @@ GKOC_DEF_JACOBI(double, f64, int32_t, i32)
 GKOC_DEF_JACOBI(double, f64, int64_t, i64)
 GKOC_DEF_JACOBI(float, f32, int32_t, i32)
 GKOC_DEF_JACOBI(float, f32, int64_t, i64)
+
+// =========================================================================================
+// Adaptive / block-wise storage precision for the value types float, complex<float> and
+// complex<double> (VT instantiations of jacobi::generate / apply / transpose the reference
+// compiles for every value type, core/preconditioner/jacobi_kernels.hpp:30-103).  A path of its
+// own: the double kernels above stay as tuned.  The rules are the reference's, per component type
+// R = remove_complex<T> (core/preconditioner/jacobi_utils.hpp:104-176, include/ginkgo/core/base/
+// math.hpp:365-383, :546-582):
+//   R = double: the five reduced types of the double path (float, half, the upper 32 / 16 bits of
+//               the double, the upper 16 bits of the float);
+//   R = float:  reduce_precision<float> = half and nothing below it, truncate_type<float> = the
+//               upper 16 bits and nothing below them, so the five precision_reduction values fall
+//               on two 16-bit types: (0,1) (0,2) (1,1) -> half, (1,0) (2,0) -> upper 16 bits.
+// A complex value is stored as its two parts in the reduced type.  One wave per storage group;
+// any group size of a 64-wide scheme (max_block_size <= 32).
+namespace gkoc {
+namespace {
+
+template <typename T>
+struct is_cplx {
+    static constexpr bool value = false;
+};
+template <typename R>
+struct is_cplx<gkoc_cplx<R>> {
+    static constexpr bool value = true;
+};
+
+// precision_reduction byte -> storage kind in the codes of stored<> (0 = the value type itself)
+template <typename R>
+__host__ __device__ __forceinline__ int storage_kind(int p);
+template <>
+__host__ __device__ __forceinline__ int storage_kind<double>(int p)
+{
+    return (p == 0x01 || p == 0x02 || p == 0x10 || p == 0x11 || p == 0x20) ? p : 0;
+}
+template <>
+__host__ __device__ __forceinline__ int storage_kind<float>(int p)
+{
+    return (p == 0x01 || p == 0x02 || p == 0x11) ? 0x02 : (p == 0x10 || p == 0x20) ? 0x11 : 0;
+}
+
+template <typename R>
+__device__ __forceinline__ R load_part(int kind, const void* group, int64_t i)
+{
+    if (kind == 0) return reinterpret_cast<const R*>(group)[i];
+    return R(load_stored(kind, reinterpret_cast<const double*>(group), i));
+}
+template <typename R>
+__device__ __forceinline__ void store_part(int kind, void* group, int64_t i, R v)
+{
+    if (kind == 0) {
+        reinterpret_cast<R*>(group)[i] = v;
+    } else {
+        store_stored(kind, reinterpret_cast<double*>(group), i, double(v));
+    }
+}
+template <typename R>
+__device__ __forceinline__ R round_part(int kind, R v)
+{
+    switch (kind) {
+    case 0x01: return R(stored<0x01>::load(stored<0x01>::store(double(v))));
+    case 0x02: return R(stored<0x02>::load(stored<0x02>::store(double(v))));
+    case 0x10: return R(stored<0x10>::load(stored<0x10>::store(double(v))));
+    case 0x11: return R(stored<0x11>::load(stored<0x11>::store(double(v))));
+    case 0x20: return R(stored<0x20>::load(stored<0x20>::store(double(v))));
+    default: return v;
+    }
+}
+
+template <typename R>
+__device__ __forceinline__ R load_value(int kind, const R* group, int64_t idx)
+{
+    return load_part<R>(kind, group, idx);
+}
+template <typename R>
+__device__ __forceinline__ gkoc_cplx<R> load_value(int kind, const gkoc_cplx<R>* group, int64_t idx)
+{
+    return {load_part<R>(kind, group, 2 * idx), load_part<R>(kind, group, 2 * idx + 1)};
+}
+template <typename R>
+__device__ __forceinline__ void store_value(int kind, R* group, int64_t idx, R v)
+{
+    store_part<R>(kind, group, idx, v);
+}
+template <typename R>
+__device__ __forceinline__ void store_value(int kind, gkoc_cplx<R>* group, int64_t idx, gkoc_cplx<R> v)
+{
+    store_part<R>(kind, group, 2 * idx, v.re);
+    store_part<R>(kind, group, 2 * idx + 1, v.im);
+}
+template <typename R>
+__device__ __forceinline__ R round_value(int kind, R v)
+{
+    return round_part<R>(kind, v);
+}
+template <typename R>
+__device__ __forceinline__ gkoc_cplx<R> round_value(int kind, gkoc_cplx<R> v)
+{
+    return {round_part<R>(kind, v.re), round_part<R>(kind, v.im)};
+}
+
+// the unit round-offs get_supported_storage_reductions compares with (jacobi_utils.hpp:118-146;
+// float_traits<>::eps, core/base/extended_float.hpp): p2n0, p1n1, p0n2, p1n0, p0n1, the value
+// type's own, and the storage kinds the two verificators round to
+template <typename R>
+struct reduction_rules;
+template <>
+struct reduction_rules<double> {
+    static constexpr double p2n0 = 1.0 / 16, p1n1 = 1.0 / 128, p0n2 = 1.0 / 2048, p1n0 = 1.0 / 1048576,
+                            p0n1 = 1.0 / 16777216, own = 1.0 / 9007199254740992.0;
+    static constexpr int verify1 = 0x01, verify2 = 0x02;
+};
+template <>
+struct reduction_rules<float> {
+    static constexpr float p2n0 = 1.0f / 128, p1n1 = 1.0f / 2048, p0n2 = 1.0f / 2048, p1n0 = 1.0f / 128,
+                           p0n1 = 1.0f / 2048, own = 1.0f / 16777216;
+    static constexpr int verify1 = 0x02, verify2 = 0x02;
+};
+
+// compute_inf_norm as block_norm_lds above, any value type (|z| of a complex entry)
+template <typename T>
+__device__ __forceinline__ real_t<T> block_norm_any(const T* Bm, int ld, int bs, int r, int sub)
+{
+    using R = real_t<T>;
+    R t = R(0);
+    if (r < bs) {
+        for (int j = 0; j < bs; ++j) t += abs_v(Bm[j * ld + r]);
+    }
+    for (int off = 1; off < sub; off <<= 1) {
+        const R o = __shfl_xor(t, off, 64);
+        t = o > t ? o : t;
+    }
+    return t;
+}
+
+// validate_precision_reduction_feasibility (reference :280-307) for a storage kind
+template <typename T>
+__device__ __forceinline__ bool feasible_any(int kind, const T* Bm, T* Tm, int ld, int bs, int r, int g,
+                                             int sub, int max_bs)
+{
+    using R = real_t<T>;
+    if (r < bs) {
+        for (int j = 0; j < bs; ++j) Tm[r * ld + j] = round_value(kind, Bm[r * ld + j]);
+    }
+    wave_lds_sync();
+    R cond = block_norm_any<T>(Tm, ld, bs, r, sub);
+    int perm = r;
+    const bool ok = gauss_jordan_lds<T>(Tm, ld, bs, r, g, sub, max_bs, perm);
+    cond *= block_norm_any<T>(Tm, ld, bs, r, sub);
+    wave_lds_sync();
+    return ok && cond >= R(1) && cond * reduction_rules<R>::own < R(1e-3);
+}
+
+// dynamic LDS: 2 * (64/SUB) * SUB * ld values
+template <typename T, typename I>
+__global__ __launch_bounds__(64) void jacobi_generate_adaptive_any_kernel(
+    const I* __restrict__ row_ptrs, const I* __restrict__ cols, const T* __restrict__ vals,
+    int64_t num_blocks, int sub, int ld, gkoc_jacobi_scheme scheme, const I* __restrict__ block_ptrs,
+    real_t<T> accuracy, uint8_t* __restrict__ precisions, real_t<T>* __restrict__ conditioning,
+    T* __restrict__ blocks)
+{
+    using R = real_t<T>;
+    using rules = reduction_rules<R>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+    const int lane = threadIdx.x;
+    const int per_wave = 64 / sub;
+    const int g = lane / sub;
+    const int r = lane % sub;
+    T* Bm = lds + int64_t(g) * sub * ld;
+    T* Tm = lds + int64_t(per_wave) * sub * ld + int64_t(g) * sub * ld;
+    const int64_t blk = int64_t(blockIdx.x) * per_wave + g;
+    int64_t start = 0;
+    int bs = 0;
+    if (blk < num_blocks) {
+        start = block_ptrs[blk];
+        bs = int(block_ptrs[blk + 1] - start);
+    }
+    if (r < bs) {
+        for (int j = 0; j < bs; ++j) Bm[r * ld + j] = T(0);
+        const int64_t a = row_ptrs[start + r], e = row_ptrs[start + r + 1];
+        for (int64_t k = a; k < e; ++k) {
+            const int64_t c = int64_t(cols[k]) - start;
+            if (c >= 0 && c < bs) Bm[r * ld + c] = vals[k];
+        }
+    }
+    const int max_bs = wave_max(bs);
+    wave_lds_sync();
+    R cond = block_norm_any<T>(Bm, ld, bs, r, sub);
+    int perm = r;
+    gauss_jordan_lds<T>(Bm, ld, bs, r, g, sub, max_bs, perm);
+    cond *= block_norm_any<T>(Bm, ld, bs, r, sub);
+    // autodetect needs the condition numbers (reference :347: "... && cond"): without the array the
+    // request reads as "keep the value type"
+    int request = blk < num_blocks ? int(precisions[blk]) : -1;
+    if (request == 0xff && conditioning == nullptr) request = 0;
+    uint32_t desc = 0xffffffffu;
+    const bool any_auto = __ballot(request == 0xff) != 0;
+    bool v1 = false, v2 = false;
+    if (any_auto) {
+        v1 = feasible_any<T>(rules::verify1, Bm, Tm, ld, bs, r, g, sub, max_bs);
+        v2 = rules::verify2 == rules::verify1
+                 ? v1
+                 : feasible_any<T>(rules::verify2, Bm, Tm, ld, bs, r, g, sub, max_bs);
+    }
+    if (request == 0xff) {
+        int verified1 = 2;
+        desc = 0;
+        if (cond * rules::p2n0 < accuracy) desc |= 0x04;
+        if (cond * rules::p1n1 < accuracy) {
+            verified1 = v1 ? 1 : 0;
+            if (v1) desc |= 0x02;
+        }
+        if (cond * rules::p0n2 < accuracy && verified1 != 0 && v2) desc |= 0x01;
+        if (cond * rules::p1n0 < accuracy) desc |= 0x10;
+        if (cond * rules::p0n1 < accuracy) {
+            if (verified1 == 2) verified1 = v1 ? 1 : 0;
+            if (verified1 == 1) desc |= 0x08;
+        }
+    } else if (request >= 0) {
+        desc = request == 0x01 ? 0x08u : request == 0x02 ? 0x01u : request == 0x10 ? 0x10u
+             : request == 0x11 ? 0x02u : request == 0x20 ? 0x04u : 0u;
+    }
+    for (int off = 1; off < 64; off <<= 1) desc &= __shfl_xor(desc, off, 64);
+    const int p = (desc & 0x01) ? 0x02 : (desc & 0x02) ? 0x11 : (desc & 0x04) ? 0x20
+                : (desc & 0x08) ? 0x01 : (desc & 0x10) ? 0x10 : 0x00;
+    if (blk < num_blocks && r == 0) {
+        precisions[blk] = uint8_t(p);
+        if (conditioning) conditioning[blk] = cond;
+    }
+    const int kind = storage_kind<R>(p);
+    const int64_t gsize = int64_t(1) << scheme.group_power;
+    const int64_t stride = scheme.block_offset << scheme.group_power;
+    T* group = blocks + scheme.group_offset * (blk >> scheme.group_power);
+    const int64_t boff = scheme.block_offset * (blk & (gsize - 1));
+    for (int j = 0; j < max_bs; ++j) {
+        const int pj = __shfl(perm, g * sub + j, 64);
+        if (r < bs && j < bs) store_value(kind, group, boff + r + int64_t(pj) * stride, Bm[r * ld + j]);
+    }
+}
+
+template <typename T, typename I>
+int launch_generate_adaptive_any(gkoc_stream_t s, const I* row_ptrs, const I* cols, const T* vals,
+                                 int64_t num_blocks, uint32_t max_bs, gkoc_jacobi_scheme scheme,
+                                 const I* block_ptrs, real_t<T> accuracy, uint8_t* precisions,
+                                 real_t<T>* conditioning, T* blocks)
+{
+    if (num_blocks <= 0) return GKOC_OK;
+    GKOC_REQUIRE(row_ptrs && cols && vals && block_ptrs && precisions && blocks, GKOC_E_INVALID,
+                 "null pointer");
+    GKOC_REQUIRE(wave_group_layout(scheme) && max_bs >= 1 && max_bs <= uint64_t(scheme.block_offset),
+                 GKOC_E_NOT_SUPPORTED,
+                 "adaptive block-Jacobi needs max_block_size <= 32 and groups that fill a wavefront "
+                 "(max_block_stride 64)");
+    const int sub = subwarp_of(scheme);
+    const int per_wave = 64 / sub;
+    // rows padded by one entry against bank conflicts where two blocks per lane group fit in 64 KB
+    int ld = sub + 1;
+    if (2 * size_t(per_wave) * sub * ld * sizeof(T) > 65536) ld = sub;
+    const size_t lds = 2 * size_t(per_wave) * sub * ld * sizeof(T);
+    jacobi_generate_adaptive_any_kernel<T, I>
+        <<<dim3(unsigned(ceildiv(num_blocks, per_wave))), dim3(64), lds, as_stream(s)>>>(
+            row_ptrs, cols, vals, num_blocks, sub, ld, scheme, block_ptrs, accuracy, precisions,
+            conditioning, blocks);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+// x = M b / x = alpha M b + beta x, one thread per (row, right-hand side), blocks widened on load
+// (reference apply_block with the resolved precision, :425-470)
+template <typename T, typename I, bool ADV>
+__global__ __launch_bounds__(256) void jacobi_apply_adaptive_any_kernel(
+    int64_t n_rows, int64_t nrhs, gkoc_jacobi_scheme scheme, const I* __restrict__ block_ptrs,
+    const I* __restrict__ row_block, const T* __restrict__ blocks,
+    const uint8_t* __restrict__ precisions, const T* __restrict__ alpha_p, const T* __restrict__ b,
+    int64_t ldb, const T* __restrict__ beta_p, T* __restrict__ x, int64_t ldx)
+{
+    using R = real_t<T>;
+    const int64_t total = n_rows * nrhs, step = int64_t(gridDim.x) * 256;
+    const int64_t stride = scheme.block_offset << scheme.group_power;
+    const int64_t mask = (int64_t(1) << scheme.group_power) - 1;
+    for (int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x; idx < total; idx += step) {
+        const int64_t j = idx / n_rows, row = idx - j * n_rows;
+        const int64_t blk = row_block[row];
+        const int64_t start = block_ptrs[blk], bs = int64_t(block_ptrs[blk + 1]) - start;
+        const int kind = precisions ? storage_kind<R>(int(precisions[blk])) : 0;
+        const T* group = blocks + scheme.group_offset * (blk >> scheme.group_power);
+        const int64_t first = scheme.block_offset * (blk & mask) + (row - start);
+        T sum = T(0);
+        for (int64_t c = 0; c < bs; ++c) {
+            sum += load_value(kind, group, first + c * stride) * b[(start + c) * ldb + j];
+        }
+        if (ADV) {
+            const T beta = beta_p[0];
+            const T ax = alpha_p[0] * sum;
+            x[row * ldx + j] = beta == T(0) ? ax : ax + beta * x[row * ldx + j];
+        } else {
+            x[row * ldx + j] = sum;
+        }
+    }
+}
+
+template <typename T, typename I, bool ADV>
+int launch_apply_adaptive_any(gkoc_stream_t s, int64_t num_blocks, gkoc_jacobi_scheme scheme,
+                              const I* block_ptrs, const T* blocks, const uint8_t* precisions,
+                              const T* alpha, const T* b, int64_t ldb, const T* beta, T* x, int64_t ldx,
+                              int64_t nrhs)
+{
+    if (num_blocks <= 0 || nrhs <= 0) return GKOC_OK;
+    GKOC_REQUIRE(block_ptrs && blocks && b && x, GKOC_E_INVALID, "null pointer");
+    hipStream_t st = as_stream(s);
+    I last = 0;
+    GKOC_HIP(hipMemcpyAsync(&last, block_ptrs + num_blocks, sizeof(I), hipMemcpyDeviceToHost, st));
+    GKOC_HIP(hipStreamSynchronize(st));
+    const int64_t n_rows = int64_t(last);
+    if (n_rows <= 0) return GKOC_OK;
+    I* row_block = nullptr;
+    GKOC_TRY(scratch_malloc(st, reinterpret_cast<void**>(&row_block), size_t(n_rows) * sizeof(I)));
+    jacobi_row_block_kernel<I><<<dim3(unsigned(ceildiv(num_blocks, 256))), dim3(256), 0, st>>>(
+        num_blocks, block_ptrs, row_block);
+    int64_t nb = ceildiv(n_rows * nrhs, 256);
+    if (nb > 8 * max_stream_blocks) nb = 8 * max_stream_blocks;
+    jacobi_apply_adaptive_any_kernel<T, I, ADV><<<dim3(unsigned(nb)), dim3(256), 0, st>>>(
+        n_rows, nrhs, scheme, block_ptrs, row_block, blocks, precisions, alpha, b, ldb, beta, x, ldx);
+    const hipError_t e = hipGetLastError();
+    (void)scratch_free(st, row_block);
+    GKOC_HIP(e);
+    return GKOC_OK;
+}
+
+// out block = (conjugate) transpose of the block, in the storage type of its group
+// (reference transpose_jacobi / conj_transpose_jacobi, :528-600: the reduced values move as they are)
+template <typename T, typename I>
+__global__ __launch_bounds__(256) void jacobi_transpose_adaptive_any_kernel(
+    int64_t num_blocks, gkoc_jacobi_scheme scheme, const I* __restrict__ block_ptrs,
+    const T* __restrict__ blocks, const uint8_t* __restrict__ precisions, int conj, T* __restrict__ out)
+{
+    using R = real_t<T>;
+    const int64_t bo = scheme.block_offset;
+    const int64_t stride = bo << scheme.group_power;
+    const int64_t gmask = (int64_t(1) << scheme.group_power) - 1;
+    const int64_t total = num_blocks * bo;
+    const int64_t step = int64_t(gridDim.x) * 256;
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < total; t += step) {
+        const int64_t blk = t / bo;
+        const int r = int(t - blk * bo);
+        const int bs = int(block_ptrs[blk + 1] - block_ptrs[blk]);
+        if (r >= bs) continue;
+        const int kind = precisions ? storage_kind<R>(int(precisions[blk])) : 0;
+        const int64_t goff = scheme.group_offset * (blk >> scheme.group_power);
+        const int64_t base = bo * (blk & gmask);
+        for (int c = 0; c < bs; ++c) {
+            T v = load_value(kind, blocks + goff, base + c + int64_t(r) * stride);   // in(c, r)
+            if (conj) v = conj_v(v);
+            store_value(kind, out + goff, base + r + int64_t(c) * stride, v);        // out(r, c)
+        }
+    }
+}
+
+template <typename T, typename I>
+int launch_transpose_adaptive_any(gkoc_stream_t s, int64_t num_blocks, gkoc_jacobi_scheme scheme,
+                                  const I* block_ptrs, const T* blocks, const uint8_t* precisions,
+                                  int conj, T* out)
+{
+    if (num_blocks <= 0) return GKOC_OK;
+    GKOC_REQUIRE(block_ptrs && blocks && out, GKOC_E_INVALID, "null pointer");
+    GKOC_REQUIRE(scheme.block_offset >= 1, GKOC_E_INVALID, "storage scheme");
+    int64_t nb = ceildiv(num_blocks * scheme.block_offset, 256);
+    if (nb > 8 * max_stream_blocks) nb = 8 * max_stream_blocks;
+    jacobi_transpose_adaptive_any_kernel<T, I><<<dim3(unsigned(nb)), dim3(256), 0, as_stream(s)>>>(
+        num_blocks, scheme, block_ptrs, blocks, precisions, conj, out);
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+
+}  // namespace
+}  // namespace gkoc
+
+#define GKOC_DEF_JACOBI_ADAPTIVE_ANY(T, R, TN, I, IN)                                               \
+    extern "C" int gkoc_jacobi_generate_adaptive_##TN##_##IN(                                       \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I* col_idxs, const T* vals,       \
+        int64_t num_blocks, uint32_t max_block_size, gkoc_jacobi_scheme scheme, const I* block_ptrs, \
+        R accuracy, uint8_t* precisions, R* conditioning, T* blocks)                                \
+    {                                                                                               \
+        (void)n_rows;                                                                               \
+        return launch_generate_adaptive_any<T, I>(s, row_ptrs, col_idxs, vals, num_blocks,          \
+                                                  max_block_size, scheme, block_ptrs, accuracy,     \
+                                                  precisions, conditioning, blocks);                \
+    }                                                                                               \
+    extern "C" int gkoc_jacobi_apply_adaptive_##TN##_##IN(                                          \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size, gkoc_jacobi_scheme scheme,    \
+        const I* block_ptrs, const T* blocks, const uint8_t* precisions, const T* alpha, const T* b, \
+        int64_t ldb, const T* beta, T* x, int64_t ldx, int64_t nrhs)                                \
+    {                                                                                               \
+        (void)max_block_size;                                                                       \
+        GKOC_REQUIRE((alpha == nullptr) == (beta == nullptr), GKOC_E_INVALID,                       \
+                     "pass alpha and beta, or neither");                                            \
+        if (alpha) {                                                                                \
+            return launch_apply_adaptive_any<T, I, true>(s, num_blocks, scheme, block_ptrs, blocks, \
+                                                         precisions, alpha, b, ldb, beta, x, ldx,   \
+                                                         nrhs);                                     \
+        }                                                                                           \
+        return launch_apply_adaptive_any<T, I, false>(s, num_blocks, scheme, block_ptrs, blocks,    \
+                                                      precisions, nullptr, b, ldb, nullptr, x, ldx, \
+                                                      nrhs);                                        \
+    }                                                                                               \
+    extern "C" int gkoc_jacobi_transpose_adaptive_##TN##_##IN(                                      \
+        gkoc_stream_t s, int64_t num_blocks, gkoc_jacobi_scheme scheme, const I* block_ptrs,        \
+        const T* blocks, const uint8_t* precisions, int conj, T* out_blocks)                        \
+    {                                                                                               \
+        return launch_transpose_adaptive_any<T, I>(s, num_blocks, scheme, block_ptrs, blocks,       \
+                                                   precisions, conj, out_blocks);                   \
+    }
+GKOC_DEF_JACOBI_ADAPTIVE_ANY(float, float, f32, int32_t, i32)
+GKOC_DEF_JACOBI_ADAPTIVE_ANY(float, float, f32, int64_t, i64)
+GKOC_DEF_JACOBI_ADAPTIVE_ANY(gkoc_c128, double, c128, int32_t, i32)
+GKOC_DEF_JACOBI_ADAPTIVE_ANY(gkoc_c128, double, c128, int64_t, i64)
+GKOC_DEF_JACOBI_ADAPTIVE_ANY(gkoc_c64, float, c64, int32_t, i32)
+GKOC_DEF_JACOBI_ADAPTIVE_ANY(gkoc_c64, float, c64, int64_t, i64)

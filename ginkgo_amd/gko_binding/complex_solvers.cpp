@@ -242,7 +242,8 @@ FOR_C_I(DEF)
 }  // namespace sellp
 
 
-// block-Jacobi on complex values: uniform storage precision (csrc/jacobi.hip, GKOC_DEF_CJACOBI)
+// block-Jacobi on complex values (csrc/jacobi.hip: GKOC_DEF_CJACOBI for uniform storage,
+// GKOC_DEF_JACOBI_ADAPTIVE_ANY where the factory asked for block-wise / adaptive precision)
 namespace jacobi {
 
 namespace {
@@ -251,12 +252,13 @@ gkoc_jacobi_scheme cscheme(const preconditioner::block_interleaved_storage_schem
 {
     return {static_cast<int64_t>(s.block_offset), static_cast<int64_t>(s.group_offset), s.group_power};
 }
-void uniform_only(const array<precision_reduction>& prec)
+bool has_precisions(const array<precision_reduction>& prec)
 {
-    if (prec.get_const_data() != nullptr && prec.get_size() != 0) {
-        throw ::gko::NotSupported(__FILE__, __LINE__, "jacobi",
-                                  "reduced block storage is implemented for double only");
-    }
+    return prec.get_const_data() != nullptr && prec.get_size() != 0;
+}
+const uint8_t* bytes(const array<precision_reduction>& prec)
+{
+    return reinterpret_cast<const uint8_t*>(prec.get_const_data());
 }
 }  // namespace
 
@@ -273,12 +275,22 @@ void uniform_only(const array<precision_reduction>& prec)
     }                                                                                               \
     template <>                                                                                     \
     void generate<T, I>(exec_t exec, const matrix::Csr<T, I>* system_matrix, size_type num_blocks,  \
-                        uint32 max_block_size, remove_complex<T>,                                   \
+                        uint32 max_block_size, remove_complex<T> accuracy,                          \
                         const preconditioner::block_interleaved_storage_scheme<I>& storage_scheme,  \
-                        array<remove_complex<T>>&, array<precision_reduction>& block_precisions,    \
+                        array<remove_complex<T>>& conditioning,                                     \
+                        array<precision_reduction>& block_precisions,                               \
                         const array<I>& block_pointers, array<T>& blocks)                           \
     {                                                                                               \
-        uniform_only(block_precisions);                                                             \
+        if (has_precisions(block_precisions)) {                                                     \
+            GKOC_CALL(gkoc_jacobi_generate_adaptive_##TN##_##IN(                                    \
+                stream_of(exec), system_matrix->get_size()[0], system_matrix->get_const_row_ptrs(), \
+                system_matrix->get_const_col_idxs(), px(system_matrix->get_const_values()),         \
+                num_blocks, max_block_size, cscheme(storage_scheme),                                \
+                block_pointers.get_const_data(), accuracy,                                          \
+                reinterpret_cast<uint8_t*>(block_precisions.get_data()), conditioning.get_data(),   \
+                px(blocks.get_data())));                                                            \
+            return;                                                                                 \
+        }                                                                                           \
         GKOC_CALL(gkoc_jacobi_generate_##TN##_##IN(                                                 \
             stream_of(exec), system_matrix->get_size()[0], system_matrix->get_const_row_ptrs(),     \
             system_matrix->get_const_col_idxs(), px(system_matrix->get_const_values()), num_blocks, \
@@ -292,7 +304,14 @@ void uniform_only(const array<precision_reduction>& prec)
                             const array<I>& block_pointers, const array<T>& blocks,                 \
                             const matrix::Dense<T>* b, matrix::Dense<T>* x)                         \
     {                                                                                               \
-        uniform_only(block_precisions);                                                             \
+        if (has_precisions(block_precisions)) {                                                     \
+            GKOC_CALL(gkoc_jacobi_apply_adaptive_##TN##_##IN(                                       \
+                stream_of(exec), num_blocks, max_block_size, cscheme(storage_scheme),               \
+                block_pointers.get_const_data(), px(blocks.get_const_data()),                       \
+                bytes(block_precisions), nullptr, px(b->get_const_values()), ld(b), nullptr,        \
+                px(x->get_values()), ld(x), cols(x)));                                              \
+            return;                                                                                 \
+        }                                                                                           \
         GKOC_CALL(gkoc_jacobi_simple_apply_##TN##_##IN(                                             \
             stream_of(exec), num_blocks, max_block_size, cscheme(storage_scheme),                   \
             block_pointers.get_const_data(), px(blocks.get_const_data()), px(b->get_const_values()), \
@@ -306,7 +325,14 @@ void uniform_only(const array<precision_reduction>& prec)
                      const matrix::Dense<T>* alpha, const matrix::Dense<T>* b,                      \
                      const matrix::Dense<T>* beta, matrix::Dense<T>* x)                             \
     {                                                                                               \
-        uniform_only(block_precisions);                                                             \
+        if (has_precisions(block_precisions)) {                                                     \
+            GKOC_CALL(gkoc_jacobi_apply_adaptive_##TN##_##IN(                                       \
+                stream_of(exec), num_blocks, max_block_size, cscheme(storage_scheme),               \
+                block_pointers.get_const_data(), px(blocks.get_const_data()),                       \
+                bytes(block_precisions), px(alpha->get_const_values()), px(b->get_const_values()),  \
+                ld(b), px(beta->get_const_values()), px(x->get_values()), ld(x), cols(x)));         \
+            return;                                                                                 \
+        }                                                                                           \
         GKOC_CALL(gkoc_jacobi_apply_##TN##_##IN(                                                    \
             stream_of(exec), num_blocks, max_block_size, cscheme(storage_scheme),                   \
             block_pointers.get_const_data(), px(blocks.get_const_data()),                           \
@@ -433,7 +459,13 @@ namespace jacobi {
                                 const preconditioner::block_interleaved_storage_scheme<I>& scheme,  \
                                 array<T>& out_blocks)                                               \
     {                                                                                               \
-        uniform_only(block_precisions);                                                             \
+        if (has_precisions(block_precisions)) {                                                     \
+            GKOC_CALL(gkoc_jacobi_transpose_adaptive_##TN##_##IN(                                   \
+                stream_of(exec), num_blocks, cscheme(scheme), block_pointers.get_const_data(),      \
+                px(blocks.get_const_data()), bytes(block_precisions), 0,                            \
+                px(out_blocks.get_data())));                                                        \
+            return;                                                                                 \
+        }                                                                                           \
         GKOC_CALL(gkoc_cjacobi_transpose_##TN##_##IN(stream_of(exec), num_blocks, cscheme(scheme),  \
                                                      block_pointers.get_const_data(),               \
                                                      blocks.get_const_data(), 0,                    \
@@ -446,7 +478,13 @@ namespace jacobi {
                                      const preconditioner::block_interleaved_storage_scheme<I>& scheme, \
                                      array<T>& out_blocks)                                          \
     {                                                                                               \
-        uniform_only(block_precisions);                                                             \
+        if (has_precisions(block_precisions)) {                                                     \
+            GKOC_CALL(gkoc_jacobi_transpose_adaptive_##TN##_##IN(                                   \
+                stream_of(exec), num_blocks, cscheme(scheme), block_pointers.get_const_data(),      \
+                px(blocks.get_const_data()), bytes(block_precisions), 1,                            \
+                px(out_blocks.get_data())));                                                        \
+            return;                                                                                 \
+        }                                                                                           \
         GKOC_CALL(gkoc_cjacobi_transpose_##TN##_##IN(stream_of(exec), num_blocks, cscheme(scheme),  \
                                                      block_pointers.get_const_data(),               \
                                                      blocks.get_const_data(), 1,                    \

@@ -845,27 +845,32 @@ inline gkoc_jacobi_scheme scheme_of(
 template <typename T>
 inline bool has_precisions(const array<precision_reduction>& prec)
 {
-    if (prec.get_const_data() == nullptr || prec.get_size() == 0) {
-        return false;
-    }
-    if (!std::is_same<T, double>::value) {
-        throw ::gko::NotSupported(__FILE__, __LINE__, "jacobi",
-                                  "reduced block storage is implemented for double only");
-    }
-    return true;
+    return prec.get_const_data() != nullptr && prec.get_size() != 0;
 }
 
-template <typename I>
+// the C ABI of block-wise / adaptive storage per value type: double has kernels of its own
+// (csrc/jacobi.hip, bit-identical to the reference), float goes through the generic ones
+template <typename T, typename I>
 struct adaptive_abi;
 template <>
-struct adaptive_abi<int32> {
+struct adaptive_abi<double, int32> {
     static constexpr auto generate = gkoc_jacobi_generate_adaptive_f64_i32;
     static constexpr auto apply = gkoc_jacobi_apply_adaptive_f64_i32;
 };
 template <>
-struct adaptive_abi<int64> {
+struct adaptive_abi<double, int64> {
     static constexpr auto generate = gkoc_jacobi_generate_adaptive_f64_i64;
     static constexpr auto apply = gkoc_jacobi_apply_adaptive_f64_i64;
+};
+template <>
+struct adaptive_abi<float, int32> {
+    static constexpr auto generate = gkoc_jacobi_generate_adaptive_f32_i32;
+    static constexpr auto apply = gkoc_jacobi_apply_adaptive_f32_i32;
+};
+template <>
+struct adaptive_abi<float, int64> {
+    static constexpr auto generate = gkoc_jacobi_generate_adaptive_f32_i64;
+    static constexpr auto apply = gkoc_jacobi_apply_adaptive_f32_i64;
 };
 
 void initialize_precisions(exec_t exec, const array<precision_reduction>& source,
@@ -902,17 +907,15 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
         const array<I>& block_pointers, array<T>& blocks)                       \
     {                                                                           \
         if (has_precisions<T>(block_precisions)) {                              \
-            GKOC_CALL(adaptive_abi<I>::generate(                                \
+            GKOC_CALL((adaptive_abi<T, I>::generate(                            \
                 stream_of(exec), system_matrix->get_size()[0],                  \
                 system_matrix->get_const_row_ptrs(),                            \
                 system_matrix->get_const_col_idxs(),                            \
-                reinterpret_cast<const double*>(                                \
-                    system_matrix->get_const_values()),                         \
-                num_blocks, max_block_size, scheme_of(storage_scheme),          \
-                block_pointers.get_const_data(), static_cast<double>(accuracy), \
+                system_matrix->get_const_values(), num_blocks, max_block_size,  \
+                scheme_of(storage_scheme), block_pointers.get_const_data(),     \
+                accuracy,                                                       \
                 reinterpret_cast<uint8_t*>(block_precisions.get_data()),        \
-                reinterpret_cast<double*>(conditioning.get_data()),             \
-                reinterpret_cast<double*>(blocks.get_data())));                 \
+                conditioning.get_data(), blocks.get_data())));                  \
             return;                                                             \
         }                                                                       \
         cdna4::forget_learned();                                                \
@@ -954,15 +957,14 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
             return; /* x = M b, and <b, x> left behind for the dot that follows */ \
         }                                                                       \
         if (has_precisions<T>(block_precisions)) {                              \
-            GKOC_CALL(adaptive_abi<I>::apply(                                   \
+            GKOC_CALL((adaptive_abi<T, I>::apply(                               \
                 stream_of(exec), num_blocks, max_block_size,                    \
                 scheme_of(storage_scheme), block_pointers.get_const_data(),     \
-                reinterpret_cast<const double*>(blocks.get_const_data()),       \
+                blocks.get_const_data(),                                        \
                 reinterpret_cast<const uint8_t*>(                               \
                     block_precisions.get_const_data()),                         \
-                nullptr, reinterpret_cast<const double*>(b->get_const_values()), \
-                ld(b), nullptr, reinterpret_cast<double*>(x->get_values()),     \
-                ld(x), cols(b)));                                               \
+                nullptr, b->get_const_values(), ld(b), nullptr,                 \
+                x->get_values(), ld(x), cols(b))));                             \
             return;                                                             \
         }                                                                       \
         GKOC_CALL(gkoc_jacobi_simple_apply_##TN##_##IN(                         \
@@ -982,16 +984,14 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
         const matrix::Dense<T>* beta, matrix::Dense<T>* x)                      \
     {                                                                           \
         if (has_precisions<T>(block_precisions)) {                              \
-            GKOC_CALL(adaptive_abi<I>::apply(                                   \
+            GKOC_CALL((adaptive_abi<T, I>::apply(                               \
                 stream_of(exec), num_blocks, max_block_size,                    \
                 scheme_of(storage_scheme), block_pointers.get_const_data(),     \
-                reinterpret_cast<const double*>(blocks.get_const_data()),       \
+                blocks.get_const_data(),                                        \
                 reinterpret_cast<const uint8_t*>(                               \
                     block_precisions.get_const_data()),                         \
-                reinterpret_cast<const double*>(alpha->get_const_values()),     \
-                reinterpret_cast<const double*>(b->get_const_values()), ld(b),  \
-                reinterpret_cast<const double*>(beta->get_const_values()),      \
-                reinterpret_cast<double*>(x->get_values()), ld(x), cols(b)));   \
+                alpha->get_const_values(), b->get_const_values(), ld(b),        \
+                beta->get_const_values(), x->get_values(), ld(x), cols(b))));   \
             return;                                                             \
         }                                                                       \
         GKOC_CALL(gkoc_jacobi_apply_##TN##_##IN(                                \
@@ -1012,13 +1012,21 @@ FOR_VT_IT(DEF)
         const preconditioner::block_interleaved_storage_scheme<I>& scheme,      \
         array<T>& out_blocks)                                                   \
     {                                                                           \
+        const auto prec = has_precisions<T>(block_precisions)                   \
+                              ? reinterpret_cast<const uint8_t*>(               \
+                                    block_precisions.get_const_data())          \
+                              : nullptr;                                        \
+        if (prec && std::is_same<T, float>::value) {                            \
+            GKOC_CALL(gkoc_jacobi_transpose_adaptive_f32_##IN(                  \
+                stream_of(exec), num_blocks, scheme_of(scheme),                 \
+                block_pointers.get_const_data(),                                \
+                reinterpret_cast<const float*>(blocks.get_const_data()), prec,  \
+                0, reinterpret_cast<float*>(out_blocks.get_data())));           \
+            return;                                                             \
+        }                                                                       \
         GKOC_CALL(gkoc_jacobi_transpose_##TN##_##IN(                            \
             stream_of(exec), num_blocks, max_block_size, scheme_of(scheme),     \
-            block_pointers.get_const_data(), blocks.get_const_data(),           \
-            has_precisions<T>(block_precisions)                                 \
-                ? reinterpret_cast<const uint8_t*>(                             \
-                      block_precisions.get_const_data())                        \
-                : nullptr,                                                      \
+            block_pointers.get_const_data(), blocks.get_const_data(), prec,     \
             out_blocks.get_data()));                                            \
     }                                                                           \
     template <>                                                                 \

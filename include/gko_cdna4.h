@@ -819,7 +819,8 @@ GKOC_DECL_JACOBI(double, f64, int32_t, i32)
 GKOC_DECL_JACOBI(double, f64, int64_t, i64)
 GKOC_DECL_JACOBI(float, f32, int32_t, i32)
 GKOC_DECL_JACOBI(float, f32, int64_t, i64)
-/* complex blocks: uniform storage precision, max_block_size <= 32, untuned apply (one lane per row) */
+/* complex blocks, uniform storage precision (block-wise / adaptive: GKOC_DECL_JACOBI_ADAPTIVE_ANY
+ * below): max_block_size <= 32, untuned apply (one lane per row) */
 GKOC_DECL_JACOBI(gkoc_c128, c128, int32_t, i32)
 GKOC_DECL_JACOBI(gkoc_c128, c128, int64_t, i64)
 GKOC_DECL_JACOBI(gkoc_c64, c64, int32_t, i32)
@@ -908,6 +909,41 @@ int gkoc_jacobi_apply_stored_f64_i64(
         int64_t nrhs);
 GKOC_DECL_JACOBI_ADAPTIVE(int32_t, i32)
 GKOC_DECL_JACOBI_ADAPTIVE(int64_t, i64)
+
+/* ... for the value types float, complex<float>, complex<double> (the other instantiations of
+ * jacobi::generate / simple_apply / apply / transpose_jacobi / conj_transpose_jacobi with a
+ * precision array, core/preconditioner/jacobi_kernels.hpp:30-103).  Same meaning of the arguments;
+ * accuracy and conditioning are of the component type.  The storage types follow the component
+ * type (core/preconditioner/jacobi_utils.hpp:15-38 with include/ginkgo/core/base/math.hpp:365-383,
+ * :546-582): for double components the five of the double path; for float components (0,1), (0,2),
+ * (1,1) = half and (1,0), (2,0) = the upper 16 bits of the float; a complex entry is its two parts
+ * in that type.  Decisions and stored blocks of float follow the reference's operation order;
+ * complex ones agree to rounding (the complex quotient, csrc/complex_type.hpp).  Any number of
+ * right-hand sides and strides; 64-wide storage groups (max_block_size <= 32).
+ * transpose_adaptive: out block = transpose (conj != 0: conjugate transpose) of the block, in
+ * the storage type of its group (precisions == NULL: the value type). */
+#define GKOC_DECL_JACOBI_ADAPTIVE_ANY(T, R, TN, I, IN)                         \
+    int gkoc_jacobi_generate_adaptive_##TN##_##IN(                             \
+        gkoc_stream_t s, int64_t n_rows, const I* row_ptrs,                    \
+        const I* col_idxs, const T* vals, int64_t num_blocks,                  \
+        uint32_t max_block_size, gkoc_jacobi_scheme scheme,                    \
+        const I* block_ptrs, R accuracy, uint8_t* precisions,                  \
+        R* conditioning, T* blocks);                                           \
+    int gkoc_jacobi_apply_adaptive_##TN##_##IN(                                \
+        gkoc_stream_t s, int64_t num_blocks, uint32_t max_block_size,          \
+        gkoc_jacobi_scheme scheme, const I* block_ptrs, const T* blocks,       \
+        const uint8_t* precisions, const T* alpha, const T* b, int64_t ldb,    \
+        const T* beta, T* x, int64_t ldx, int64_t nrhs);                       \
+    int gkoc_jacobi_transpose_adaptive_##TN##_##IN(                            \
+        gkoc_stream_t s, int64_t num_blocks, gkoc_jacobi_scheme scheme,        \
+        const I* block_ptrs, const T* blocks, const uint8_t* precisions,       \
+        int conj, T* out_blocks);
+GKOC_DECL_JACOBI_ADAPTIVE_ANY(float, float, f32, int32_t, i32)
+GKOC_DECL_JACOBI_ADAPTIVE_ANY(float, float, f32, int64_t, i64)
+GKOC_DECL_JACOBI_ADAPTIVE_ANY(gkoc_c128, double, c128, int32_t, i32)
+GKOC_DECL_JACOBI_ADAPTIVE_ANY(gkoc_c128, double, c128, int64_t, i64)
+GKOC_DECL_JACOBI_ADAPTIVE_ANY(gkoc_c64, float, c64, int32_t, i32)
+GKOC_DECL_JACOBI_ADAPTIVE_ANY(gkoc_c64, float, c64, int64_t, i64)
 
 #define GKOC_DECL_JACOBI_SCALAR(T, TN)                                         \
     /* inv_diag[i] = 1 / diag[i] */                                            \

@@ -100,6 +100,158 @@ static bool identical(const Dense* a, const Dense* b)
     return true;
 }
 
+// Jacobi with a fixed reduced, block-wise or adaptive storage precision for the value types that go
+// through the generic kernels (float, complex<float>, complex<double>): the decisions (precision of
+// every block), the condition numbers, apply / advanced apply with several right-hand sides,
+// transpose(), conj_transpose() and convert_to(Dense), each against the ReferenceExecutor
+template <typename T>
+static T value_of(double re, double im)
+{
+    using R = gko::remove_complex<T>;
+    if constexpr (gko::is_complex<T>()) {
+        return T(R(re), R(im));
+    } else {
+        return T(R(re));
+    }
+}
+
+template <typename T>
+static double distance(const gko::matrix::Dense<T>* a, const gko::matrix::Dense<T>* b)
+{
+    double num = 0, den = 0;
+    for (gko::size_type i = 0; i < a->get_size()[0]; ++i) {
+        for (gko::size_type j = 0; j < a->get_size()[1]; ++j) {
+            num += double(gko::squared_norm(a->at(i, j) - b->at(i, j)));
+            den += double(gko::squared_norm(b->at(i, j)));
+        }
+    }
+    return std::sqrt(num / (den > 0 ? den : 1.0));
+}
+
+template <typename T>
+static void reduced_jacobi_of(std::shared_ptr<gko::ReferenceExecutor> ref,
+                              std::shared_ptr<gko::HipExecutor> hip, const std::string& name,
+                              gko::uint32 max_bs)
+{
+    using R = gko::remove_complex<T>;
+    using M = gko::matrix::Csr<T, it>;
+    using V = gko::matrix::Dense<T>;
+    using J = gko::preconditioner::Jacobi<T, it>;
+    const gko::size_type n = 1000 + max_bs / 2 + 1;
+    const double tol = sizeof(R) == 4 ? 2e-5 : 1e-12;
+    gko::matrix_data<T, it> md{gko::dim<2>{n, n}};
+    for (gko::size_type i = 0; i < n; ++i) {
+        // blocks from well conditioned to nearly singular, a few hundred rows each
+        static const double shift[] = {2.0, 0.5, 0.01, 1e-4};
+        const double d = 2.0 + shift[(i / 250) % 4];
+        md.nonzeros.emplace_back(it(i), it(i), value_of<T>(d, 0.2));
+        if (i > 0) md.nonzeros.emplace_back(it(i), it(i - 1), value_of<T>(-1.0, 0.3));
+        if (i + 1 < n) md.nonzeros.emplace_back(it(i), it(i + 1), value_of<T>(-1.0, -0.25));
+        if (i + 41 < n) md.nonzeros.emplace_back(it(i), it(i + 41), value_of<T>(-0.1, 0.05));
+    }
+    md.sort_row_major();
+    auto a_ref = gko::share(M::create(ref));
+    a_ref->read(md);
+    auto a_hip = gko::share(gko::clone(hip, a_ref));
+    auto b = V::create(ref, gko::dim<2>{n, 3});
+    for (gko::size_type i = 0; i < n; ++i)
+        for (int j = 0; j < 3; ++j) b->at(i, j) = value_of<T>(std::cos(0.11 * i + j), std::sin(0.07 * i - j));
+    auto alpha = gko::initialize<V>({value_of<T>(1.5, -0.5)}, ref);
+    auto beta = gko::initialize<V>({value_of<T>(-0.75, 0.25)}, ref);
+
+    struct request {
+        const char* what;
+        gko::precision_reduction all;
+        bool block_wise;
+        double accuracy;
+    };
+    const request requests[] = {
+        {"(0,1)", gko::precision_reduction(0, 1), false, 1e-1},
+        {"(0,2)", gko::precision_reduction(0, 2), false, 1e-1},
+        {"(1,0)", gko::precision_reduction(1, 0), false, 1e-1},
+        {"(1,1)", gko::precision_reduction(1, 1), false, 1e-1},
+        {"(2,0)", gko::precision_reduction(2, 0), false, 1e-1},
+        {"autodetect 1e-1", gko::precision_reduction::autodetect(), false, 1e-1},
+        {"autodetect 1e-3", gko::precision_reduction::autodetect(), false, 1e-3},
+        {"block-wise mix", gko::precision_reduction(0, 0), true, 1e-2},
+    };
+    for (const auto& q : requests) {
+        auto jac = [&](auto exec, auto a) {
+            // the same storage groups on both executors (the host's default stride is 32, the
+            // device's its wavefront size, include/ginkgo/core/preconditioner/jacobi.hpp:589-620):
+            // blocks of a group share one precision, so the decisions depend on the grouping
+            auto f = J::build().with_max_block_size(max_bs).with_max_block_stride(64u).with_accuracy(
+                R(q.accuracy));
+            if (q.block_wise) {
+                // a pattern of requests, replicated over the blocks (Jacobi::generate, core/
+                // preconditioner/jacobi.cpp:386-396): fixed ones and autodetect side by side
+                f.with_storage_optimization(gko::array<gko::precision_reduction>(
+                    exec, {gko::precision_reduction(0, 1), gko::precision_reduction::autodetect(),
+                           gko::precision_reduction(2, 0), gko::precision_reduction(0, 0),
+                           gko::precision_reduction::autodetect(), gko::precision_reduction(1, 1),
+                           gko::precision_reduction(0, 2)}));
+            } else {
+                f.with_storage_optimization(q.all);
+            }
+            return f.on(exec)->generate(a);
+        };
+        auto j_ref = jac(ref, a_ref);
+        auto j_hip = jac(hip, a_hip);
+        const auto nb = j_ref->get_num_blocks();
+        bool same = nb == j_hip->get_num_blocks();
+        gko::array<gko::precision_reduction> p_ref(ref, j_ref->get_parameters().storage_optimization.block_wise);
+        gko::array<gko::precision_reduction> p_hip(ref, j_hip->get_parameters().storage_optimization.block_wise);
+        int kinds[256] = {};
+        for (gko::size_type k = 0; same && k < nb; ++k) {
+            const auto pr = static_cast<gko::uint8>(p_ref.get_const_data()[k]);
+            const auto ph = static_cast<gko::uint8>(p_hip.get_const_data()[k]);
+            if (pr != ph) {
+                std::cout << "  block " << k << ": reference precision " << int(pr) << ", hip " << int(ph) << std::endl;
+            }
+            same = same && pr == ph;
+            ++kinds[pr];
+        }
+        std::string hist;
+        for (int k = 0; k < 256; ++k)
+            if (kinds[k]) hist += " 0x" + std::to_string(k >> 4) + std::to_string(k & 15) + ":" + std::to_string(kinds[k]);
+        std::cout << "Jacobi<" << name << ">(" << max_bs << ") " << q.what << ": " << nb << " blocks, precisions"
+                  << hist << std::endl;
+        CHECK(same, ("Jacobi<" + name + "> " + q.what + ": block precisions equal the reference's").c_str());
+        gko::array<R> c_hip(ref, nb);
+        ref->copy_from(hip, nb, j_hip->get_conditioning(), c_hip.get_data());
+        bool cond_ok = true;
+        for (gko::size_type k = 0; k < nb; ++k) {
+            const double cr = j_ref->get_conditioning()[k], ch = c_hip.get_const_data()[k];
+            cond_ok = cond_ok && std::abs(cr - ch) <= 50 * tol * std::abs(cr);
+        }
+        CHECK(cond_ok, ("Jacobi<" + name + "> " + q.what + ": condition numbers").c_str());
+        auto y_ref = V::create(ref, gko::dim<2>{n, 3});
+        auto y_hip = V::create(hip, gko::dim<2>{n, 3});
+        j_ref->apply(b, y_ref);
+        j_hip->apply(gko::clone(hip, b), y_hip);
+        double worst = distance<T>(gko::clone(ref, y_hip).get(), y_ref.get());
+        j_ref->apply(alpha, b, beta, y_ref);
+        j_hip->apply(gko::clone(hip, alpha), gko::clone(hip, b), gko::clone(hip, beta), y_hip);
+        worst = std::max(worst, distance<T>(gko::clone(ref, y_hip).get(), y_ref.get()));
+        auto through = [&](auto op_ref, auto op_hip) {
+            op_ref->apply(b, y_ref);
+            op_hip->apply(gko::clone(hip, b), y_hip);
+            return distance<T>(gko::clone(ref, y_hip).get(), y_ref.get());
+        };
+        worst = std::max(worst, through(j_ref->transpose(), j_hip->transpose()));
+        worst = std::max(worst, through(j_ref->conj_transpose(), j_hip->conj_transpose()));
+        auto d_ref = V::create(ref), d_hip = V::create(hip);
+        j_ref->convert_to(d_ref);
+        j_hip->convert_to(d_hip);
+        worst = std::max(worst, distance<T>(gko::clone(ref, d_hip).get(), d_ref.get()));
+        std::cout << "  apply / advanced apply / transpose / conj_transpose / dense vs reference: " << worst
+                  << std::endl;
+        // the stored values are the same numbers (same decisions, same rounding to the storage
+        // type up to the last place of the inverse): what remains is the order of sums
+        CHECK(worst < 50 * tol, ("Jacobi<" + name + "> " + q.what + ": results match the reference").c_str());
+    }
+}
+
 int main(int argc, char** argv)
 {
     const int grid = argc > 1 ? std::atoi(argv[1]) : 24;
@@ -728,6 +880,13 @@ int main(int argc, char** argv)
             CHECK(same_cond, "Jacobi block condition numbers identical to reference");
         }
     }
+
+    // --- ... and for the other value types (generic kernels of csrc/jacobi.hip)
+    reduced_jacobi_of<float>(ref, hip, "float", 8u);
+    reduced_jacobi_of<float>(ref, hip, "float", 32u);
+    reduced_jacobi_of<std::complex<double>>(ref, hip, "complex<double>", 8u);
+    reduced_jacobi_of<std::complex<double>>(ref, hip, "complex<double>", 32u);
+    reduced_jacobi_of<std::complex<float>>(ref, hip, "complex<float>", 13u);
 
     // --- Ginkgo's own Bicgstab / Cgs / Fcg / PipeCg drivers on this backend
     {
