@@ -171,6 +171,9 @@ struct device_arena {
     int64_t misplaced = 0;        // gkoc_arena_note_vector found a written vector next to matrix arrays
     int64_t probes = 0, walked = 0, classified = 0, search_ns = 0, retried = 0;
     bool surveyed = false;        // the one search for all three classes has run (survey_classes)
+    // a search for class k that came back empty: what the driver reported free afterwards.  Until it
+    // reports a granule more than that, another search would walk the same handles to the same end.
+    size_t exhausted_free[max_classes] = {};      // that number + 1; 0 = no mark
 };
 
 std::mutex g_mtx;
@@ -581,8 +584,25 @@ void trim_pools(device_arena& A)
 hipError_t acquire_granule(device_arena& A, int dev, int want, int n_want, hipMemGenericAllocationHandle_t* out)
 {
     if (A.spare[want].empty()) {
+        size_t free_b = 0, total_b = 0;
+        if (A.exhausted_free[want] != 0) {
+            // the last search for this class found none (do not walk again - up to three
+            // quarters of the free memory in handles - until memory has come back to the driver)
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                free_b + 1 < A.exhausted_free[want] + granule_bytes()) {
+                return hipErrorOutOfMemory;
+            }
+            (void)hipGetLastError();
+            A.exhausted_free[want] = 0;
+        }
         const hipError_t e = walk(A, dev, want, n_want > 0 ? n_want : 1);
-        if (A.spare[want].empty()) return e != hipSuccess ? e : hipErrorOutOfMemory;
+        if (A.spare[want].empty()) {
+            // what the search pooled of the other classes goes back before the mark is taken
+            trim_pools(A);
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) A.exhausted_free[want] = free_b + 1;
+            (void)hipGetLastError();
+            return e != hipSuccess ? e : hipErrorOutOfMemory;
+        }
     }
     *out = A.spare[want].front();
     A.spare[want].erase(A.spare[want].begin());
