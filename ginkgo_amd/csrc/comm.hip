@@ -546,6 +546,18 @@ int gkoc_comm_status(gkoc_comm_t comm, uint32_t* status)
     return GKOC_OK;
 }
 
+int gkoc_comm_set_patience_ms(gkoc_comm_t comm, int64_t ms)
+{
+    GKOC_REQUIRE(comm, GKOC_E_INVALID, "comm == NULL");
+    if (ms <= 0) {
+        const char* pe = std::getenv("GKOC_IPC_PATIENCE_MS");
+        const long pms = pe ? std::atol(pe) : 0;
+        ms = pms > 0 ? pms : 120000;
+    }
+    comm->patience = (long long)ms * 100000ll;     // 100 MHz clock
+    return GKOC_OK;
+}
+
 int gkoc_comm_transport(gkoc_comm_t comm, int* transport, int* window_uncached)
 {
     GKOC_REQUIRE(comm && transport, GKOC_E_INVALID, "bad argument");

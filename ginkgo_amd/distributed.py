@@ -351,6 +351,10 @@ class IpcComm(RcclComm):
             call("gkoc_comm_destroy", self._handle)
             self._handle = C.c_void_p(0)
 
+    def set_patience_ms(self, ms):
+        """patience of the waits enqueued from now on (0: GKOC_IPC_PATIENCE_MS / the default)"""
+        call("gkoc_comm_set_patience_ms", self._handle, C.c_int64(int(ms)))
+
     def status(self):
         """0, or the bits of the waits that ran out of patience (gkoc_comm_status)"""
         st = C.c_uint32(0)
@@ -380,16 +384,24 @@ def _inject_failure(stage, rank):
 def _try_comm(cls, exec_, base, group):
     """bring `cls` up and put a known-answer all-reduce through it; every decision is taken by ALL
     ranks together (a MIN all-reduce of "it worked here"); returns the communicator or None"""
+    import os
     import sys
-    ok, comm = True, None
+    ok, comm, probing = True, None, False
     try:
         comm = cls(exec_, group)
+        probing = hasattr(comm, "set_patience_ms") and not os.environ.get("GKOC_IPC_PATIENCE_MS")
+        if probing:
+            # every rank is here (the hand-shake has just ended): a transport whose stores do not reach
+            # the peers shows within seconds, not after the two minutes a late peer of a real job is given
+            comm.set_patience_ms(20000)
         t = torch.full((2,), float(comm.rank + 1), dtype=torch.float64, device=exec_.device)
         comm.all_reduce_sum_(t)
         want_v = comm.size * (comm.size + 1) / 2
         ok = bool((t == want_v).all().item()) and not _inject_failure("answer", base.rank)
         if ok and hasattr(comm, "status"):
             ok = comm.status() == 0
+        if probing:
+            comm.set_patience_ms(0)
     except Exception as e:        # noqa: BLE001 - any failure means "not this one"
         print(f"[ginkgo_amd] rank {base.rank}: {cls.__name__} unavailable: {e}", file=sys.stderr)
         ok = False

@@ -2321,6 +2321,10 @@ int gkoc_comm_ipc_create(gkoc_comm_t* comm, int n_ranks, int rank, int64_t slot_
                          void* handle_out /* GKOC_COMM_IPC_HANDLE_BYTES */);
 int gkoc_comm_ipc_connect(gkoc_comm_t comm, const void* handles /* n_ranks x GKOC_COMM_IPC_HANDLE_BYTES */);
 int gkoc_comm_status(gkoc_comm_t comm, uint32_t* status);
+/* the patience of the operations enqueued from now on (milliseconds; <= 0: back to GKOC_IPC_PATIENCE_MS /
+ * the default).  A first known-answer collective right after the hand-shake - all ranks are there - can
+ * be given seconds instead of minutes.  No effect on an RCCL communicator. */
+int gkoc_comm_set_patience_ms(gkoc_comm_t comm, int64_t ms);
 /* *transport: 0 = RCCL, 1 = mailboxes; *window_uncached (may be NULL): the window is uncached device memory */
 int gkoc_comm_transport(gkoc_comm_t comm, int* transport, int* window_uncached);
 

@@ -164,6 +164,25 @@ def main():
     report.update({k: chk[k] for k in ("all_reduce_us", "all_reduce_overlapped_us", "exchange_us")})
     comm.check()
     assert comm.status() == 0
+    # ---- patience (gkoc_comm_set_patience_ms): a peer that is late beyond it is REPORTED, the kernel
+    # ends instead of waiting; the late rank itself finds every word there.  The last operation of this
+    # communicator: what the impatient rank computed is not a sum.
+    if world == 2:
+        comm.set_patience_ms(200)
+        t = torch.ones(2, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        if rank == 0:
+            time.sleep(1.5)
+        comm.all_reduce_sum_(t)
+        torch.cuda.synchronize(dev)
+        st = comm.status()
+        if rank == 0:
+            assert st == 0 and t.cpu().tolist() == [2.0, 2.0], (hex(st), t.cpu().tolist())
+        else:
+            assert st & 1, hex(st)
+        report["impatient_status"] = st
+        comm.set_patience_ms(0)
     comm.close()
     dist.barrier()
     if rank == 0:
