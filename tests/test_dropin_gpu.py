@@ -30,6 +30,11 @@ def test_dropin_program():
     assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
     assert "DROPIN OK" in p.stdout
     assert "bit-identical" in p.stdout and "FAILED" not in p.stdout
+    # the checks of the later rounds ran (none of them is skipped silently): block-wise / adaptive
+    # block-Jacobi for the three value types next to double, 8 requests x 3 checks each and case
+    for vt, cases in (("float", 2), ("complex<double>", 2), ("complex<float>", 1)):
+        got = len(re.findall(r"^ok: Jacobi<" + re.escape(vt) + "> ", p.stdout, re.M))
+        assert got == 24 * cases, (vt, got)
 
 
 def _numbers(block):
