@@ -1,0 +1,85 @@
+"""Block-Jacobi with a fixed reduced, autodetected or block-wise storage precision for the value types
+float, complex<float>, complex<double> (gkoc_jacobi_{generate,apply,transpose}_adaptive_{f32,c64,c128}_i32)
+THROUGH THE C ABI against tests/golden/jacobi_types.npz - what the unmodified reference computes on
+gko::ReferenceExecutor (tests/golden/make_jacobi_types_golden.py: reference/preconditioner/
+jacobi_kernels.cpp:313-411 generate, :419-531 apply, :528-627 transposes; the rules per component type
+core/preconditioner/jacobi_utils.hpp:104-176).
+Bit-exact: the blocks found and EVERY block's precision.  Tolerances (relative, Frobenius): condition
+numbers 1e-4 / 1e-11, products 1e-5 (float), 1e-4 (complex<float>: blocks kept in half), 1e-12
+(complex<double>) - the complex quotient of the inversion is not libstdc++'s bit for bit."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jacobi_types.npz"))
+CASES = sorted({tuple(k.split("/")[:3]) for k in GOLD.files if k.count("/") == 3})
+DT = {"f32": (torch.float32, torch.float32, 1e-5, 1e-4), "c64": (torch.complex64, torch.float32, 1e-4, 1e-4),
+      "c128": (torch.complex128, torch.float64, 1e-12, 1e-11)}
+
+
+def _rel(got, want):
+    den = np.linalg.norm(want.ravel())
+    return np.linalg.norm((got - want).ravel()) / (den if den > 0 else 1.0)
+
+
+@pytest.mark.parametrize("vt,max_bs,tag", CASES)
+def test_precisions_and_products_equal_the_reference(gexec, vt, max_bs, tag):
+    from ginkgo_amd._lib import call
+    from ginkgo_amd.preconditioner import compute_storage_scheme
+    ex = gexec
+    dt, rdt, tol, ctol = DT[vt]
+    gold = lambda k: GOLD[f"{vt}/{max_bs}/{tag}/{k}"]      # noqa: E731
+    rp, ci, vals, b = (GOLD[f"{vt}/{k}"] for k in ("row_ptrs", "col_idxs", "values", "b"))
+    n, nrhs, bs = len(rp) - 1, b.shape[1], int(max_bs)
+    d_rp, d_ci, d_v, d_b = (ex.to_device(a) for a in (rp, ci, vals, b))
+    # the blocks (indices: exact)
+    d_bp = ex.zeros((n + 1,), torch.int32)
+    nb_c = C.c_int64(0)
+    call(f"gkoc_jacobi_find_blocks_{vt}_i32", ex.stream, n, d_rp, d_ci, C.c_uint32(bs), C.byref(nb_c), d_bp)
+    nb = nb_c.value
+    assert nb == len(gold("block_ptrs")) - 1
+    assert np.array_equal(d_bp[:nb + 1].cpu().numpy(), gold("block_ptrs"))
+    d_bp = d_bp[:nb + 1].contiguous()
+    scheme = compute_storage_scheme(bs, 64)
+    gs = 1 << scheme.group_power
+    storage = ((nb + gs - 1) // gs) * scheme.group_offset
+    blocks = ex.zeros((storage,), dt)
+    # the requests replicated over the blocks; in place they become the decisions
+    prec = ex.to_device(np.resize(gold("request"), nb).astype(np.uint8))
+    cond = ex.zeros((nb,), rdt)
+    acc = float(gold("accuracy")[0])
+    call(f"gkoc_jacobi_generate_adaptive_{vt}_i32", ex.stream, n, d_rp, d_ci, d_v, nb, C.c_uint32(bs), scheme,
+         d_bp, C.c_float(acc) if rdt == torch.float32 else C.c_double(acc), prec, cond, blocks)
+    ex.synchronize()
+    assert np.array_equal(prec.cpu().numpy(), gold("prec")), (prec.cpu().numpy(), gold("prec"))
+    assert _rel(cond.cpu().numpy().astype(np.float64), gold("cond")) < ctol
+
+    def product(blk):
+        x = ex.zeros((n, nrhs), dt)
+        call(f"gkoc_jacobi_apply_adaptive_{vt}_i32", ex.stream, nb, C.c_uint32(bs), scheme, d_bp, blk, prec, None,
+             d_b, nrhs, None, x, nrhs, nrhs)
+        ex.synchronize()
+        return x.cpu().numpy()
+
+    want = gold("x")
+    assert _rel(product(blocks), want) < tol
+    # x = alpha M b + beta x
+    alpha = ex.to_device(np.asarray([1.5], want.dtype))
+    beta = ex.to_device(np.asarray([-0.75], want.dtype))
+    x0 = np.ascontiguousarray(b[::-1]).copy()
+    x = ex.to_device(x0.copy())
+    call(f"gkoc_jacobi_apply_adaptive_{vt}_i32", ex.stream, nb, C.c_uint32(bs), scheme, d_bp, blocks, prec, alpha,
+         d_b, nrhs, beta, x, nrhs, nrhs)
+    ex.synchronize()
+    assert _rel(x.cpu().numpy(), 1.5 * want - 0.75 * x0) < 4 * tol
+    # transpose_jacobi / conj_transpose_jacobi: the blocks move in their storage type
+    for conj, key in ((0, "xt"), (1, "xh")):
+        out = ex.zeros((storage,), dt)
+        call(f"gkoc_jacobi_transpose_adaptive_{vt}_i32", ex.stream, nb, scheme, d_bp, blocks, prec, C.c_int(conj),
+             out)
+        assert _rel(product(out), gold(key)) < tol
