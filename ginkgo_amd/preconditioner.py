@@ -7,7 +7,7 @@ blocks (jacobi::find_blocks), inverts them (jacobi::generate) and applies them
 (jacobi::simple_apply / apply), all on the device through libgko_cdna4.so.
 max_block_size == 1 takes Ginkgo's scalar path (extract_diagonal +
 invert_diagonal + simple_scalar_apply).  Adaptive precision
-(`with_storage_optimization`) is supported for fp64 values: block-wise and
+(`with_storage_optimization`) is supported for fp64 and fp32 values: block-wise and
 autodetected precisions for any max_block_size <= 32, one fixed reduced
 precision for all blocks for max_block_size in {2, 4, 8, 16}.
 """
@@ -116,9 +116,13 @@ class Jacobi(LinOp):
         self.dtype = a.dtype
         self.storage_precision = factory.storage_precision
         self.precisions = self.conditioning = None
-        adaptive = factory.block_wise is not None
-        if (self.storage_precision or adaptive) and a.dtype != torch.float64:
-            raise NotSupported("block-Jacobi: reduced storage precision needs fp64 values")
+        block_wise = factory.block_wise
+        adaptive = block_wise is not None
+        if a.dtype != torch.float64 and self.storage_precision:
+            # one reduced precision for every block of a float matrix: that request block by block
+            # (Jacobi::generate replicates it the same way, core/preconditioner/jacobi.cpp:386-396) -
+            # the generic kernels of csrc/jacobi.hip; the in-place conversion below is fp64's
+            block_wise, adaptive, self.storage_precision = [self.storage_precision], True, 0
         if self.storage_precision and self.max_block_size not in (2, 4, 8, 16):
             # the in-place conversion of ONE precision for all blocks works on 64-wide groups;
             # block-wise / autodetected precisions take any max_block_size <= 32
@@ -172,12 +176,13 @@ class Jacobi(LinOp):
         # the inverse blocks are the apply's one large read stream: not with the vectors
         self.blocks = ex.zeros((storage,), a.dtype, MEM_INDICES)
         if adaptive:
-            req = np.resize(np.asarray(factory.block_wise, np.uint8), self.num_blocks)
+            req = np.resize(np.asarray(block_wise, np.uint8), self.num_blocks)
             self.precisions = ex.to_device(req)
-            self.conditioning = ex.alloc((self.num_blocks,), torch.float64)
-            call("gkoc_jacobi_generate_adaptive_f64_" + IT[a.col_idxs.dtype], ex.stream, n,
+            self.conditioning = ex.alloc((self.num_blocks,), a.dtype)
+            accuracy = C.c_double(factory.accuracy) if a.dtype == torch.float64 else C.c_float(factory.accuracy)
+            call("gkoc_jacobi_generate_adaptive_" + self._suf, ex.stream, n,
                  a.row_ptrs, a.col_idxs, a.values, self.num_blocks, C.c_uint32(self.max_block_size),
-                 self.scheme, self.block_pointers, C.c_double(factory.accuracy), self.precisions,
+                 self.scheme, self.block_pointers, accuracy, self.precisions,
                  self.conditioning, self.blocks)
             return
         call("gkoc_jacobi_generate_" + self._suf, ex.stream, n, a.row_ptrs,
@@ -190,7 +195,7 @@ class Jacobi(LinOp):
 
     def _apply_stored(self, alpha, b, beta, x):
         if self.precisions is not None:
-            call("gkoc_jacobi_apply_adaptive_f64_" + IT[self.block_pointers.dtype], self.exec.stream,
+            call("gkoc_jacobi_apply_adaptive_" + self._suf, self.exec.stream,
                  self.num_blocks, C.c_uint32(self.max_block_size), self.scheme, self.block_pointers,
                  self.blocks, self.precisions, None if alpha is None else alpha.values, b.values,
                  b.ld, None if beta is None else beta.values, x.values, x.ld, b.size[1])
@@ -210,6 +215,10 @@ class Jacobi(LinOp):
             return t
         t.blocks = self.exec.zeros((self.blocks.numel(),), self.blocks.dtype)
         prec = self.precisions
+        if prec is not None and self.dtype != torch.float64:
+            call("gkoc_jacobi_transpose_adaptive_" + self._suf, self.exec.stream, self.num_blocks, self.scheme,
+                 self.block_pointers, self.blocks, prec, C.c_int(0), t.blocks)
+            return t
         if prec is None and self.storage_precision:
             prec = self.exec.to_device(np.full(self.num_blocks, self.storage_precision, np.uint8))
         call("gkoc_jacobi_transpose_" + self._suf, self.exec.stream, self.num_blocks,

@@ -83,3 +83,33 @@ def test_precisions_and_products_equal_the_reference(gexec, vt, max_bs, tag):
         call(f"gkoc_jacobi_transpose_adaptive_{vt}_i32", ex.stream, nb, scheme, d_bp, blocks, prec, C.c_int(conj),
              out)
         assert _rel(product(out), gold(key)) < tol
+
+
+@pytest.mark.parametrize("max_bs,tag", [(c[1], c[2]) for c in CASES if c[0] == "f32"])
+def test_python_mirror_on_float_values(gexec, max_bs, tag):
+    """the same fixture through the host-side mirror of the reference interface:
+    Jacobi.build().with_storage_optimization(...).with_accuracy(...).on(exec).generate(A) on a float matrix"""
+    import ginkgo_amd as g
+    gold = lambda k: GOLD[f"f32/{max_bs}/{tag}/{k}"]      # noqa: E731
+    rp, ci, vals, b = (GOLD[f"f32/{k}"] for k in ("row_ptrs", "col_idxs", "values", "b"))
+    n, nrhs = len(rp) - 1, b.shape[1]
+    a = g.Csr.from_arrays(gexec, (n, n), rp, ci, vals)
+    name = lambda r: "autodetect" if r == 0xff else (int(r) >> 4, int(r) & 15)      # noqa: E731
+    req = gold("request")
+    f = g.Jacobi.build().with_max_block_size(int(max_bs)).with_accuracy(float(gold("accuracy")[0]))
+    if len(req) > 1:
+        f.with_storage_optimization([name(r) for r in req])
+    elif req[0] == 0xff:
+        f.with_storage_optimization("autodetect")
+    else:
+        f.with_storage_optimization(*name(req[0]))
+    jac = f.on(gexec).generate(a)
+    assert jac.get_num_blocks() == len(gold("prec"))
+    assert np.array_equal(jac.block_pointers.cpu().numpy(), gold("block_ptrs"))
+    assert np.array_equal(jac.precisions.cpu().numpy(), gold("prec"))
+    assert _rel(jac.conditioning.cpu().numpy().astype(np.float64), gold("cond")) < 1e-4
+    db = g.Dense.from_numpy(gexec, b)
+    for op, key in ((jac, "x"), (jac.transpose(), "xt"), (jac.conj_transpose(), "xh")):
+        x = g.Dense.from_numpy(gexec, np.zeros((n, nrhs), np.float32))
+        op.apply(db, x)
+        assert x.to_numpy().dtype == np.float32 and _rel(x.to_numpy(), gold(key)) < 1e-5, key
