@@ -778,6 +778,84 @@ void oracle_jacobi_apply_adaptive_f64_i32(int64_t num_blocks, int64_t block_offs
     }
 }
 
+/* ---- the same for float, complex<float>, complex<double> (gko_oracle_jacobi_types.inc) ---------- */
+#define KIND_OF_DOUBLE(p) ((p) == 0x01 || (p) == 0x02 || (p) == 0x10 || (p) == 0x11 || (p) == 0x20 ? (p) : 0)
+#define KIND_OF_FLOAT(p) ((p) == 0x01 || (p) == 0x02 || (p) == 0x11 ? 0x02 : ((p) == 0x10 || (p) == 0x20 ? 0x11 : 0))
+
+/* float components: eps of truncated<float,2>, half, half, truncated<float,2>, half; own 2^-24 */
+#define EPS_P2N0 (1.0 / 128)
+#define EPS_P1N1 (1.0 / 2048)
+#define EPS_P0N2 (1.0 / 2048)
+#define EPS_P1N0 (1.0 / 128)
+#define EPS_P0N1 (1.0 / 2048)
+#define EPS_OWN (1.0 / 16777216)
+#define VERIFY1 0x02
+#define VERIFY2 0x02
+#define KIND(p) KIND_OF_FLOAT(p)
+#define R float
+
+#define T float
+#define SUFT f32_i32
+#define ABS_T(v) fabsf(v)
+#define CPLX 0
+#include "gko_oracle_jacobi_types.inc"
+#undef T
+#undef SUFT
+#undef ABS_T
+#undef CPLX
+
+#define T float _Complex
+#define SUFT c64_i32
+#define ABS_T(v) __builtin_cabsf(v)
+#define CPLX 1
+#include "gko_oracle_jacobi_types.inc"
+#undef T
+#undef SUFT
+#undef ABS_T
+#undef CPLX
+
+#undef EPS_P2N0
+#undef EPS_P1N1
+#undef EPS_P0N2
+#undef EPS_P1N0
+#undef EPS_P0N1
+#undef EPS_OWN
+#undef VERIFY1
+#undef VERIFY2
+#undef KIND
+#undef R
+
+/* double components: eps of truncated<double,4>, truncated<float,2>, half, truncated<double,2>, float */
+#define EPS_P2N0 (1.0 / 16)
+#define EPS_P1N1 (1.0 / 128)
+#define EPS_P0N2 (1.0 / 2048)
+#define EPS_P1N0 (1.0 / 1048576)
+#define EPS_P0N1 (1.0 / 16777216)
+#define EPS_OWN (1.0 / 9007199254740992.0)
+#define VERIFY1 0x01
+#define VERIFY2 0x02
+#define KIND(p) KIND_OF_DOUBLE(p)
+#define R double
+#define T double _Complex
+#define SUFT c128_i32
+#define ABS_T(v) __builtin_cabs(v)
+#define CPLX 1
+#include "gko_oracle_jacobi_types.inc"
+#undef T
+#undef SUFT
+#undef ABS_T
+#undef CPLX
+#undef EPS_P2N0
+#undef EPS_P1N1
+#undef EPS_P0N2
+#undef EPS_P1N0
+#undef EPS_P0N1
+#undef EPS_OWN
+#undef VERIFY1
+#undef VERIFY2
+#undef KIND
+#undef R
+
 /* ---- CG driver ---------------------------------------------------------
  * core/solver/cg.cpp:93-181 (Cg::apply_dense_impl) with
  *   - preconditioner: 0 = Identity (z = r), 1 = scalar Jacobi, 2 = block Jacobi

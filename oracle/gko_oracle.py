@@ -385,6 +385,55 @@ def jacobi_apply_adaptive(num_blocks, scheme, block_ptrs, blocks, prec, b, alpha
     return out if np.asarray(b).ndim == 2 else out[:, 0]
 
 
+_JT = {np.dtype(np.float32): ("f32", np.float32), np.dtype(np.complex64): ("c64", np.float32),
+       np.dtype(np.complex128): ("c128", np.float64)}
+
+
+def jacobi_generate_adaptive_t(row_ptrs, cols, vals, num_blocks, scheme, block_ptrs, accuracy=1e-1,
+                               requested=None):
+    """jacobi_generate_adaptive for float32 / complex64 / complex128 values (gko_oracle_jacobi_types.inc):
+    (blocks in the value type's words, precision per block, conditioning in the component type)"""
+    bo, go, gp = scheme
+    vals = np.ascontiguousarray(vals)
+    name, rdt = _JT[vals.dtype]
+    gs = 1 << gp
+    blocks = np.zeros(((num_blocks + gs - 1) // gs) * go, vals.dtype)
+    prec = np.full(num_blocks, 0xff, np.uint8) if requested is None else \
+        np.resize(np.asarray(requested, np.uint8), num_blocks).copy()
+    cond = np.zeros(num_blocks, rdt)
+    getattr(lib(), f"oracle_jacobi_generate_adaptive_{name}_i32")(
+        _p(np.ascontiguousarray(row_ptrs, np.int32)), _p(np.ascontiguousarray(cols, np.int32)), _p(vals),
+        _i64(num_blocks), _i64(bo), _i64(go), C.c_uint32(gp), _p(np.ascontiguousarray(block_ptrs, np.int32)),
+        _val(rdt, accuracy), _p(prec), _p(cond), _p(blocks))
+    return blocks, prec, cond
+
+
+def jacobi_apply_adaptive_t(num_blocks, scheme, block_ptrs, blocks, prec, b, alpha=None, beta=None, x=None):
+    """x = M b (alpha is None) or x = alpha M b + beta x, blocks widened from their storage types"""
+    bo, go, gp = scheme
+    dt = blocks.dtype
+    name, _ = _JT[dt]
+    b2 = np.ascontiguousarray(_as2d(b), dtype=dt)
+    nrhs = b2.shape[1]
+    out = np.zeros_like(b2) if x is None else np.array(_as2d(x), dtype=dt, order="C", copy=True)
+    a_, b_ = (None, None) if alpha is None else (np.asarray([alpha], dt), np.asarray([beta], dt))
+    getattr(lib(), f"oracle_jacobi_apply_adaptive_{name}_i32")(
+        _i64(num_blocks), _i64(bo), _i64(go), C.c_uint32(gp), _p(np.ascontiguousarray(block_ptrs, np.int32)),
+        _p(blocks), _p(np.ascontiguousarray(prec, np.uint8)), _p(a_), _p(b2), _i64(nrhs), _p(b_), _p(out),
+        _i64(nrhs), _i64(nrhs))
+    return out if np.asarray(b).ndim == 2 else out[:, 0]
+
+
+def jacobi_transpose_adaptive_t(num_blocks, scheme, block_ptrs, blocks, prec, conj=False):
+    bo, go, gp = scheme
+    name, _ = _JT[blocks.dtype]
+    out = np.zeros_like(blocks)
+    getattr(lib(), f"oracle_jacobi_transpose_adaptive_{name}_i32")(
+        _i64(num_blocks), _i64(bo), _i64(go), C.c_uint32(gp), _p(np.ascontiguousarray(block_ptrs, np.int32)),
+        _p(blocks), _p(np.ascontiguousarray(prec, np.uint8)), C.c_int(1 if conj else 0), _p(out))
+    return out
+
+
 def jacobi_invert_diagonal(diag):
     inv = np.empty_like(diag)
     getattr(lib(), "oracle_jacobi_invert_diagonal_" + _VT[diag.dtype])(

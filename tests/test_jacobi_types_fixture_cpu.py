@@ -41,3 +41,32 @@ def test_the_fixture_equals_the_live_reference():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_jacobi_types_golden.py"),
                         "--check"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "fixture == live reference" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def _cases():
+    g = np.load(GOLD)
+    return sorted({tuple(k.split("/")[:3]) for k in g.files if k.count("/") == 3})
+
+
+@pytest.mark.parametrize("vt,max_bs,tag", _cases())
+def test_the_oracle_restatement_is_pinned_by_the_fixture(vt, max_bs, tag):
+    """oracle/gko_oracle_jacobi_types.inc against the reference's vectors, BIT FOR BIT: the blocks' precisions,
+    the condition numbers, M b, M^T b and M^H b for the three value types (the C restatement runs the
+    reference's operations in the reference's order, complex products and quotients through the same
+    libgcc routines std::complex uses)"""
+    from oracle import gko_oracle as o
+    g = np.load(GOLD)
+    gold = lambda k: g[f"{vt}/{max_bs}/{tag}/{k}"]      # noqa: E731
+    rp, ci, vals, b = (g[f"{vt}/{k}"] for k in ("row_ptrs", "col_idxs", "values", "b"))
+    ptrs = gold("block_ptrs")
+    nb = len(ptrs) - 1
+    scheme = o.jacobi_storage_scheme(int(max_bs))
+    blocks, prec, cond = o.jacobi_generate_adaptive_t(rp, ci, vals, nb, scheme, ptrs, float(gold("accuracy")[0]),
+                                                      gold("request"))
+    assert np.array_equal(prec, gold("prec"))
+    assert cond.astype(np.float64).tobytes() == gold("cond").tobytes()
+    x = o.jacobi_apply_adaptive_t(nb, scheme, ptrs, blocks, prec, b)
+    assert x.tobytes() == gold("x").tobytes()
+    for conj, key in ((False, "xt"), (True, "xh")):
+        t = o.jacobi_transpose_adaptive_t(nb, scheme, ptrs, blocks, prec, conj)
+        assert o.jacobi_apply_adaptive_t(nb, scheme, ptrs, t, prec, b).tobytes() == gold(key).tobytes(), key
