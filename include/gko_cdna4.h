@@ -917,8 +917,9 @@ GKOC_DECL_JACOBI_ADAPTIVE(int64_t, i64)
  * type (core/preconditioner/jacobi_utils.hpp:15-38 with include/ginkgo/core/base/math.hpp:365-383,
  * :546-582): for double components the five of the double path; for float components (0,1), (0,2),
  * (1,1) = half and (1,0), (2,0) = the upper 16 bits of the float; a complex entry is its two parts
- * in that type.  Decisions and stored blocks of float follow the reference's operation order;
- * complex ones agree to rounding (the complex quotient, csrc/complex_type.hpp).  Any number of
+ * in that type.  float: decisions, condition numbers, stored blocks and x = M b bit-identical to the
+ * reference (tests/test_jacobi_types_gpu.py); complex: the same decisions, values to rounding (the
+ * complex quotient, csrc/complex_type.hpp).  Any number of
  * right-hand sides and strides; 64-wide storage groups (max_block_size <= 32).
  * transpose_adaptive: out block = transpose (conj != 0: conjugate transpose) of the block, in
  * the storage type of its group (precisions == NULL: the value type). */
