@@ -242,6 +242,71 @@ def ginkgo_api_bench(grid, steps, cg_iters):
     return out
 
 
+def measured_peaks(g, ex, torch, a, reps=10):
+    """SURVEY 8(d)'s second denominator, measured in THIS run on THIS device with the library's own
+    kernels: a pure read (the 2-norm of the matrix's value array taken as one long vector - nnz * 8
+    bytes = 3.6 GB at 256^3, far beyond the 256 MB memory-side cache) and a triad (y += alpha x on
+    two vectors of the same length: 24 bytes per element).  HIP events on the launch stream."""
+    nnz = a.values.numel()
+    out = {}
+    v = g.Dense(ex, a.values.view(-1, 1))
+    res = g.Dense.create(ex, (1, 1))
+
+    def timed(fn, nbytes):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return nbytes / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+
+    out["read_gbs"] = round(timed(lambda: v.compute_norm2(res), nnz * a.values.element_size()), 1)
+    m = min(nnz, 1 << 28)                       # 2 GiB per vector at most
+    x1 = g.Dense.create(ex, (m, 1))
+    y1 = g.Dense.create(ex, (m, 1))
+    x1.fill(1.0)
+    y1.fill(0.0)
+    alpha = g.Dense.from_numpy(ex, __import__("numpy").array([[1e-9]]))
+    out["triad_gbs"] = round(timed(lambda: y1.add_scaled(alpha, x1), 24 * m), 1)
+    out["read_bytes"], out["triad_bytes"] = nnz * a.values.element_size(), 24 * m
+    del x1, y1
+    return out
+
+
+def gmres_bench(g, ex, a, rhs, sol, barrier, iters=60, krylov_dim=30):
+    """Gmres(30) + block-Jacobi(8), fixed iteration count (two restart cycles), the reference's default
+    orthogonalisation (modified Gram-Schmidt, core/solver/gmres.cpp:157-300); bytes per iteration by the
+    reference's own model (gmres.cpp:427-446) and by what the launched kernels need."""
+    solver = (g.Gmres.build().with_krylov_dim(krylov_dim)
+              .with_criteria(g.stop.Iteration.build().with_max_iters(iters),
+                             g.stop.ResidualNorm.build().with_reduction_factor(1e-30))
+              .with_preconditioner(g.Jacobi.build().with_max_block_size(8))
+              .on(ex).generate(a))
+    solver.apply(rhs, sol.fill(0.0))            # warm-up (allocates the Krylov basis)
+    barrier()
+    t0 = time.perf_counter()
+    solver.apply(rhs, sol.fill(0.0))
+    barrier()
+    t = time.perf_counter() - t0
+    it = solver.num_iterations
+    n, nnz, d = a.size[0], a.get_num_stored_elements(), krylov_dim
+    storage = 12 * nnz + 4 * (n + 1) + 64.5 * n                     # matrix + block-Jacobi(8)
+    model = (2.5 * d + 10.5 + 14.0 / d) * n * 8 + (1 + 1.0 / d) * storage
+    # launched kernels, iteration k of a cycle: Jacobi 2n, SpMV 2n, <v0,w> 2n, k fused steps (w, v_i, v_i+1
+    # read, w written: 4n), last update 3n, norm 1n, scaling 2n  =>  (10 + 4k) n values; the restart as in the model
+    fused = (10 + 2.0 * (d - 1) + (1 + 14.0 / d)) * n * 8 + (1 + 1.0 / d) * storage
+    return {"gmres_iters_per_s": round(it / t, 2), "gmres_ms_per_iter": round(t * 1e3 / it, 4),
+            "gmres_iterations": it, "gmres_krylov_dim": d, "gmres_ortho": "mgs (the reference's default)",
+            "gmres_precond": "block-Jacobi(8)",
+            "gmres_model_bytes_per_iter": int(model),
+            "gmres_model_frac": _sig3(model * it / t / 1e9 / HBM_PEAK_GBS, 3),
+            "gmres_bytes_fused_per_iter": int(fused),
+            "gmres_frac": _sig3(fused * it / t / 1e9 / HBM_PEAK_GBS, 3)}
+
+
 def self_launch(n):
     """re-run this command line under torch.distributed.run --nproc-per-node n"""
     import socket
@@ -281,6 +346,8 @@ def matrix_bench(args):
     backend = os.environ.get("GKO_BENCH_BACKEND", "nccl")
     dev_id = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_id)
+    if os.environ.get("GKO_TEST_ONE_CLASS_RANK") == str(rank):
+        os.environ["GKOC_ARENA_MAX_CLASSES"] = "1"       # (tests: what one rank's allocator finds is its own)
     ex = g.Cdna4Executor.create(dev_id)
     use_dist = world > 1
     if use_dist:
@@ -409,11 +476,7 @@ def matrix_bench(args):
         comm_check["transport_choice"] = dict(gd.default_comm.last)
         for name_ in ("csr", "sellp"):
             dm = gd.DistributedMatrix(be, comm, part, owned, local_format=name_)
-            ok, why = dm.self_check()          # one-kernel product vs join-based one, all ranks agree
-            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=ex.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag.item()) < 1.0:
-                dm.conservative()
+            dm.agreed_self_check()             # one-kernel product vs join-based one, all ranks agree
             x = be.vector_from(xg[lo:hi])
             y = be.vector(n_local)
             wall, kms = time_op(lambda: dm.apply(x, y), args.steps, args.warmup)
@@ -484,6 +547,8 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--cg-iters", type=int, default=100,
                     help="fixed CG iterations timed for the iters/s figure")
+    ap.add_argument("--gmres-iters", type=int, default=60,
+                    help="fixed Gmres(30) + block-Jacobi(8) iterations timed at N = 1 (0 = skip)")
     ap.add_argument("--cpu-grid", type=int, default=0,
                     help="0 = the CPU baseline runs the GPU run's grid; otherwise this one")
     ap.add_argument("--no-cpu", action="store_true")
@@ -548,6 +613,8 @@ def main():
     backend = os.environ.get("GKO_BENCH_BACKEND", "nccl")
     dev_id = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_id)
+    if os.environ.get("GKO_TEST_ONE_CLASS_RANK") == str(rank):
+        os.environ["GKOC_ARENA_MAX_CLASSES"] = "1"       # (tests: what one rank's allocator finds is its own)
     ex = g.Cdna4Executor.create(dev_id)
     # GKO_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, barriers,
     # max-over-ranks, DistributedStencil) with a single rank - checks the RCCL calls
@@ -601,42 +668,81 @@ def main():
     else:
         from ginkgo_amd import distributed as gd
         part = gd.SlabPartition(grid, world)
-        op = gd.DistributedStencil(ex, part, rank)
+
+        # a hang cannot be cancelled, but it can be NAMED: the watchdogs of ginkgo_amd.distributed end the
+        # process (exit code 86); rank 0 leaves a line that says what was running
+        def dying_line(what):
+            if rank == 0:
+                result_out.write(json.dumps({
+                    "metric": f"CSR SpMV GB/s (27-pt 3D Laplacian {grid}^3, fp64/int32)", "value": None,
+                    "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "error": f"watchdog: {what} did not finish (a collective hangs); nothing was measured",
+                    "comm_check": {"transport_choice": dict(gd.default_comm.last)}}) + "\n")
+                result_out.flush()
+        gd._Watchdog.on_fire = staticmethod(dying_line)
+
+        class TransportDead(Exception):
+            pass
+
+        def agree_min(ok):
+            f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=ex.device)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return float(f.item()) >= 1.0
+
+        def bring_up(comm):
+            """operator, communicator check, product check, warm-up solve on `comm` (None: default_comm
+            chooses).  Every failure is agreed on by all ranks before anybody acts on it; a transport whose
+            waits ran out of patience is reported as TransportDead on ALL ranks."""
+            op = gd.DistributedStencil(ex, part, rank, comm=comm)
+            # known-answer test of every collective form the solvers use + their latencies here;
+            # wrong data raises on all ranks, a hang ends the job with a message (not a timeout)
+            cc = gd.comm_self_check(ex, op.comm, n_elems=grid * grid)
+            # which transport carries the data path and what each candidate cost on one Cg iteration's
+            # communication (IpcComm: the library's mailboxes in peer-mapped memory; RcclComm: RCCL)
+            cc["transport_choice"] = dict(gd.default_comm.last) if comm is None else \
+                {"chosen": type(comm).__name__, "why": "second attempt"}
+            # who is where: what the communicator itself counted (ncclCommCount), RCCL's version, every
+            # rank's device - "did it see N ranks" must be answerable from the line
+            cc["topology"] = op.comm.topology() if hasattr(op.comm, "topology") else \
+                {"transport": f"torch.distributed ({backend})", "ranks": world, "ranks_seen": dist.get_world_size()}
+            # the one-kernel product (boundary waves that wait for their halo inside the kernel) against
+            # the join-based one on THIS communicator before anything is timed; a rank that sees a
+            # difference, a wave that gave up or a fork that timed out sends ALL ranks to the join-based
+            # product (the reference's shape) - the line says which one was measured
+            pc = op.matrix.agreed_self_check()
+            ts = 0.0
+            if args.cg_iters > 0:
+                # (the warm-up solve ends with the solvers' own checks - a boundary wave that gave up, a
+                # fork that timed out, a mailbox wait that ran out of patience: raised at the END of the
+                # solve, after every collective has been issued, so all ranks arrive here and agree)
+                err = None
+                try:
+                    ts = op.prepare_cg(args.cg_iters, barrier)
+                except gd.GkoError as e:
+                    err = str(e)[:200]
+                if not agree_min(err is None):
+                    dead = hasattr(op.comm, "status") and op.comm.status() != 0
+                    if not agree_min(not dead):
+                        raise TransportDead(err or "a wait of the transport ran out of patience on another rank")
+                    op.matrix.conservative()
+                    pc = dict(pc, one_kernel_product=False,
+                              self_check="warm-up solve: " + (err or "failed on another rank"))
+                    ts = op.prepare_cg(args.cg_iters, barrier)
+            return op, cc, pc, ts
+
+        try:
+            op, comm_check, product_check, t_setup = bring_up(None)
+        except (gd.GkoError, TransportDead) as e:
+            # (both are raised on every rank together.)  The process group that brought the ranks here
+            # still works: the data path goes through it - RCCL under torch.distributed on one rank per
+            # GPU - and the line says so
+            first = f"{type(e).__name__}: {e}"[:300]
+            print(f"[bench] rank {rank}: {first} - second attempt on torch.distributed", file=sys.stderr)
+            op, comm_check, product_check, t_setup = bring_up(gd.TorchComm())
+            comm_check["transport_choice"] = {"chosen": "TorchComm", "first_choice": dict(gd.default_comm.last),
+                                              "why": "the first choice failed after it had come up: " + first}
         nnz_global = op.global_nnz
         n_local = op.n_local
-        # known-answer test of every collective form the solvers use + their latencies here;
-        # wrong data raises on all ranks, a hang ends the job with a message (not a timeout)
-        comm_check = gd.comm_self_check(ex, op.comm, n_elems=grid * grid)
-        # which transport carries the data path and what each candidate cost on one Cg iteration's
-        # communication (IpcComm: the library's mailboxes in peer-mapped memory; RcclComm: RCCL)
-        comm_check["transport_choice"] = dict(gd.default_comm.last)
-        # the one-kernel product (boundary waves that wait for their halo inside the kernel) against
-        # the join-based one on THIS communicator before anything is timed; a rank that sees a
-        # difference, a wave that gave up or a fork that timed out sends ALL ranks to the join-based
-        # product (the reference's shape) - the line says which one was measured
-        ok, why = op.matrix.self_check()
-        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=ex.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag.item()) < 1.0:
-            op.matrix.conservative()
-        product_check = {"one_kernel_product": op.matrix._gate is not None,
-                         "self_check": why if float(flag.item()) >= 1.0 or not ok else "failed on another rank"}
-        if args.cg_iters > 0:
-            # (the warm-up solve ends with the solvers' own checks - a boundary wave that gave up, a
-            # fork that timed out: raised at the END of the solve, after every collective has been
-            # issued, so all ranks arrive here and agree)
-            err = None
-            try:
-                t_setup = op.prepare_cg(args.cg_iters, barrier)
-            except gd.GkoError as e:
-                err = str(e)[:200]
-            flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=ex.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag.item()) < 1.0:
-                op.matrix.conservative()
-                product_check = {"one_kernel_product": False,
-                                 "self_check": "warm-up solve: " + (err or "failed on another rank")}
-                t_setup = op.prepare_cg(args.cg_iters, barrier)
         x = op.random_vector(42)
         y = op.zeros_vector()
         step = lambda: op.apply(x, y)
@@ -681,10 +787,24 @@ def main():
         t_cg = float(tt.item())
         n, nnz = n_global, nnz_global
         cg_bytes = 12 * nnz + 4 * (n + 1) + 64.5 * n + 144 * n  # cg.cpp:133-141 model
+        # what the three kernels of an iteration really need (the model's 18 n vector
+        # values are those of the UNFUSED loop): SpMV + <p,q> (the product's bytes + p once more),
+        # step_2 + block-Jacobi + both sums (64n + 4(n/8+1) blocks, x r p q in, x r z out = 56n), step_1 24n
+        cg_fused = (12 * nnz + 4 * (n + 1) + 16 * n + 8 * n) + (64 * n + 4 * (n // 8 + 1) + 56 * n) + 24 * n
         cg = {"cg_iters_per_s": round(iters / t_cg, 2), "cg_iterations": iters,
               "cg_ms_per_iter": round(t_cg * 1e3 / iters, 4),
               "cg_model_gbs": round(cg_bytes * iters / t_cg / 1e9, 1),
+              "cg_model_note": "Ginkgo's model of the UNFUSED loop (cg.cpp:133-141, 18 n vector values): an "
+                               "upper bound on the bytes moved, not the fraction",
+              "cg_bytes_fused": int(cg_fused),
+              "cg_fused_gbs": round(cg_fused * iters / t_cg / 1e9 / world, 1),
+              "cg_frac": _sig3(cg_fused * iters / t_cg / 1e9 / (HBM_PEAK_GBS * world), 3),
               "cg_precond": "block-Jacobi(8)", "cg_setup_s": round(t_setup, 3)}
+        if not use_dist and args.gmres_iters > 0:
+            try:
+                cg.update(gmres_bench(g, ex, a, rhs, sol, barrier, iters=args.gmres_iters))
+            except Exception as e:      # noqa: BLE001 - an extra must not take the line down
+                cg["gmres_error"] = f"{type(e).__name__}: {e}"[:300]
         if use_dist and not args.no_pipe_cg:
             # the pipelined CG (core/solver/pipe_cg.cpp:95-297): ONE all-reduce per iteration, travelling
             # while the preconditioner and the SpMV run - the solver for a latency-bound strong-scaling
@@ -763,6 +883,19 @@ def main():
                          "algorithmic_bytes_per_launch": int(per_gpu_bytes)},
         }
         out.update(cg)
+        if not use_dist:
+            try:
+                pk = measured_peaks(g, ex, torch, a)
+                out["roofline"]["peak_measured"] = pk["read_gbs"]
+                out["roofline"]["frac_of_measured"] = _sig3(achieved / pk["read_gbs"], 4)
+                out["roofline"]["peak_measured_how"] = (
+                    f"same run, same device: gkoc_dense_compute_norm2 over the matrix's value array "
+                    f"({pk['read_bytes']} bytes read per launch); triad y += a x on two {pk['triad_bytes'] // 24 * 8} "
+                    f"byte vectors: {pk['triad_gbs']} GB/s")
+                out["roofline"]["triad_measured"] = pk["triad_gbs"]
+            except Exception as e:      # noqa: BLE001
+                out["roofline"]["peak_measured"] = None
+                out["roofline"]["peak_measured_error"] = f"{type(e).__name__}: {e}"[:200]
         if use_dist:
             out["comm_check"] = comm_check
             out["distributed_product"] = product_check
@@ -773,6 +906,8 @@ def main():
                  "frac": _sig3(per_gpu_bytes / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if v[0] > 0 else None,
                  "memory_classes_found": int(v[1]), "search_ms": v[2], "granules_walked": int(v[3])}
                 for r, v in enumerate(per_rank)]
+            out["roofline"]["search_ms_max_over_ranks"] = max(v[2] for v in per_rank)
+            out["roofline"]["memory_classes_min_over_ranks"] = int(min(v[1] for v in per_rank))
             out["roofline"]["traffic_note"] = ("counters are collected at N = 1 only (a rocprofv3 --pmc pass "
                                                "per counter group over a child run)")
         info = ex.arena_info()
@@ -787,7 +922,11 @@ def main():
             "granules_walked": info["granules_walked"],
             "granules_classified": info["granules_classified"],
             "probe_launches": info["probes"], "probe_retries": info["probe_retries"],
-            "search_ms": round(info["search_ns"] / 1e6, 1)}
+            "search_ms": round(info["search_ns"] / 1e6, 1),
+            "search_budget_ms": info["search_budget_ms"], "search_budget_spent": bool(info["search_budget_spent"]),
+            "granules_unclassified": info["granules_unclassified"]}
+        # what a process pays before its first product: the allocator's searches + the solver's set-up
+        out["startup_s"] = round(info["search_ns"] / 1e9 + (t_setup or 0.0), 3)
         if not use_dist:
             placement["class_of"] = {"values": ex.memory_class(a.values), "col_idxs": ex.memory_class(a.col_idxs),
                                      "row_ptrs": ex.memory_class(a.row_ptrs), "x": ex.memory_class(x.values),

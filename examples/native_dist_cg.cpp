@@ -215,8 +215,18 @@ try {
         std::vector<unsigned char> all;
         CK(gkoc_comm_ipc_create(&comm, real_world, real_rank, 0, mine));
         exchange_handles(real_rank, real_world, mine, all);
-        CK(gkoc_comm_ipc_connect(comm, all.data()));
-    } else if (world > 1) {
+        const int rc = gkoc_comm_ipc_connect(comm, all.data());
+        if (rc == GKOC_E_NOT_SUPPORTED) {
+            // refused on EVERY rank alike (the cards say: different devices, a window in plain memory): RCCL
+            if (real_rank == 0) fprintf(stderr, "mailbox transport refused (%s): RCCL\n", gkoc_last_error());
+            CK(gkoc_comm_destroy(comm));
+            comm = nullptr;
+            use_ipc = false;
+        } else {
+            CK(rc);
+        }
+    }
+    if (world > 1 && !mirror && comm == nullptr) {
         unsigned char id[GKOC_COMM_ID_BYTES] = {};
         CK(gkoc_comm_load_rccl(getenv("GKOC_RCCL_PATH")));
         if (real_rank == 0) CK(gkoc_comm_unique_id(id));

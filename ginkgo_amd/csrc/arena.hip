@@ -174,6 +174,10 @@ struct device_arena {
     // a search for class k that came back empty: what the driver reported free afterwards.  Until it
     // reports a granule more than that, another search would walk the same handles to the same end.
     size_t exhausted_free[max_classes] = {};      // that number + 1; 0 = no mark
+    // the searches of this device have used up their wall-clock budget (GKOC_ARENA_SURVEY_MS): no
+    // further walk; a region that needs a granule takes the driver's next one UNCLASSIFIED
+    bool budget_spent = false;
+    int64_t unclassified = 0;     // granules mapped into a region without a probe (after the budget)
 };
 
 std::mutex g_mtx;
@@ -185,6 +189,13 @@ int g_verbose = 0;
 int g_peer_access = 0;
 int g_max_walk = 0;         // granules one search may create; 0 = bounded by the free memory only
 int g_max_classes = 3;      // GKOC_ARENA_MAX_CLASSES: stop the survey at fewer classes (tests)
+// GKOC_ARENA_SURVEY_MS: wall-clock budget of ALL searches of a device in this process (survey + the
+// directed walks that extend a region), 0 = bounded by the free memory only.  On a device whose memory
+// has been used the driver clears every handle it creates (30 - 60 ms per GiB), and a class that owns
+// the allocator's first 150 GiB costs 150 such handles to get past: BENCH_r05 paid 9.8 s for the third
+// class, which is worth 3.3 % of the SpMV.  With the budget spent the survey accepts the classes it has
+// (two: matrix arrays | everything kernels write) and later granules are mapped unclassified.
+int g_survey_ms = 1500;
 bool g_mode_from_env = false;
 device_arena g_arena[64];
 
@@ -211,6 +222,9 @@ void read_env_locked()
     const char* mc = std::getenv("GKOC_ARENA_MAX_CLASSES");
     g_max_classes = mc ? std::atoi(mc) : max_classes;
     if (g_max_classes < 1 || g_max_classes > max_classes) g_max_classes = max_classes;
+    const char* sm = std::getenv("GKOC_ARENA_SURVEY_MS");
+    g_survey_ms = sm ? std::atoi(sm) : 1500;
+    if (g_survey_ms < 0) g_survey_ms = 0;
     const char* sf = std::getenv("GKOC_ARENA_SYNC_FREE");
     g_sync_free = sf ? std::atoi(sf) : 1;
     const char* v = std::getenv("GKOC_ARENA_VERBOSE");
@@ -497,10 +511,31 @@ hipError_t walk(device_arena& A, int dev, int want, int n_want)
     };
     hipError_t result = hipErrorOutOfMemory;
     int tail = -1;       // > 0: a late hit, this many more handles are classified one by one
+    // the budget is checked BEFORE a step against what the dearest step so far has cost (creating a
+    // handle of used memory is one driver call of 30 - 60 ms), so that the total stays below it
+    const int64_t budget_ns = int64_t(g_survey_ms) * 1000000;
+    int64_t dearest_step_ns = 0, t_prev_ns = 0;
+    auto elapsed_ns = [&] {
+        return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start)
+            .count();
+    };
     for (int64_t step = 0; step < max_steps; ++step) {
         if (reached() && (want >= 0 || tail <= 0)) {
             result = hipSuccess;
             break;
+        }
+        if (budget_ns > 0) {
+            const int64_t now_ns = elapsed_ns();
+            dearest_step_ns = std::max(dearest_step_ns, now_ns - t_prev_ns);
+            t_prev_ns = now_ns;
+            if (A.budget_spent || A.search_ns + now_ns + dearest_step_ns > budget_ns) {
+                A.budget_spent = true;
+                if (g_verbose) {
+                    fprintf(stderr, "[gkoc arena] search budget of %d ms spent after %lld granules (%d classes)\n",
+                            g_survey_ms, (long long)A.walked, A.n_cls);
+                }
+                break;
+            }
         }
         hipMemGenericAllocationHandle_t h;
         hipError_t e = hipMemCreate(&h, gr, &prop, 0);
@@ -557,8 +592,7 @@ hipError_t walk(device_arena& A, int dev, int want, int n_want)
     }
     if (result != hipSuccess && reached()) result = hipSuccess;
     for (auto h : skipped) (void)hipMemRelease(h);
-    A.search_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start)
-                       .count();
+    A.search_ns += elapsed_ns();
     return result;
 }
 
@@ -583,6 +617,14 @@ void trim_pools(device_arena& A)
 // caller is going to ask for in a row (a late hit of the walk pools that many)
 hipError_t acquire_granule(device_arena& A, int dev, int want, int n_want, hipMemGenericAllocationHandle_t* out)
 {
+    if (A.spare[want].empty() && A.budget_spent) {
+        // no time left to look for the class: the driver's next granule, whatever it is (what one
+        // hipMalloc per array - the reference's behaviour - gets for every array)
+        const hipMemAllocationProp prop = granule_prop(dev);
+        const hipError_t e = hipMemCreate(out, granule_bytes(), &prop, 0);
+        if (e == hipSuccess) ++A.unclassified;
+        return e;
+    }
     if (A.spare[want].empty()) {
         size_t free_b = 0, total_b = 0;
         if (A.exhausted_free[want] != 0) {
@@ -596,6 +638,7 @@ hipError_t acquire_granule(device_arena& A, int dev, int want, int n_want, hipMe
             A.exhausted_free[want] = 0;
         }
         const hipError_t e = walk(A, dev, want, n_want > 0 ? n_want : 1);
+        if (A.spare[want].empty() && A.budget_spent) return acquire_granule(A, dev, want, n_want, out);
         if (A.spare[want].empty()) {
             // what the search pooled of the other classes goes back before the mark is taken
             trim_pools(A);
@@ -1020,6 +1063,9 @@ int gkoc_arena_stats(gkoc_arena_info* info)
     info->search_ns = A.search_ns;
     info->probe_retries = A.retried;
     info->surveyed = A.surveyed ? 1 : 0;
+    info->search_budget_ms = g_survey_ms;
+    info->search_budget_spent = A.budget_spent ? 1 : 0;
+    info->granules_unclassified = A.unclassified;
     auto add = [&](const span* c) {
         info->num_chunks += 1;
         info->reserved_bytes += int64_t(c->size);

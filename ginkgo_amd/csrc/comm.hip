@@ -46,6 +46,10 @@ struct rccl_api {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    // optional (diagnostics of gkoc_comm_topology_get): absent symbols leave the fields at 0
+    int (*CommCount)(nccl_comm, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, nccl_comm, hipStream_t) = nullptr;
     bool ok = false;
 };
 
@@ -88,6 +92,9 @@ int load_rccl(const char* path)
     a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
     if (!all) return GKOC_E_COMM;
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
+    a.GetVersion = reinterpret_cast<decltype(a.GetVersion)>(dlsym(h, "ncclGetVersion"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
     a.ok = true;
     g_rccl = a;
     return GKOC_OK;
@@ -177,7 +184,61 @@ struct gkoc_comm_s {
     uint32_t* done = nullptr;           // device: finished workgroups per message of the running exchange
     uint32_t* status = nullptr;         // pinned host word the kernels OR their give-ups into
     long long patience = 0;             // ticks of the 100 MHz clock
+    // ---- who is where (gkoc_comm_topology_get): PCI bus id of every rank's device
+    char bus_ids[gkoc::ipc::MAX_RANKS][GKOC_COMM_BUS_ID_BYTES] = {};
+    int ranks_seen = 0;                 // ncclCommCount / window cards read
+    int rccl_version = 0;
+    bool cross_device = false;          // at least one peer's device is not mine
+    bool all_uncached = false;          // transport 1: every rank's window is uncached memory
+    long mute_after = -1, all_reduces_seen = 0;     // GKOC_IPC_INJECT_MUTE (tests)
 };
+
+// what travels with a window handle from gkoc_comm_ipc_create to gkoc_comm_ipc_connect
+struct ipc_card {
+    hipIpcMemHandle_t handle;
+    char bus_id[GKOC_COMM_BUS_ID_BYTES];    // device that holds the window
+    uint8_t window_uncached;
+    uint8_t version;                        // 1
+    uint8_t pad[GKOC_COMM_IPC_HANDLE_BYTES - sizeof(hipIpcMemHandle_t) - GKOC_COMM_BUS_ID_BYTES - 2];
+};
+static_assert(sizeof(ipc_card) == GKOC_COMM_IPC_HANDLE_BYTES, "card size");
+
+// PCI bus id of the current device; GKOC_COMM_FAKE_BUS_ID="<rank>=<id>[,<rank>=<id>...]" (tests only) makes
+// `rank` report another one, so that the rules for peers on OTHER devices can be exercised on a one-GPU box
+static void own_bus_id(int rank, char* out)
+{
+    std::memset(out, 0, GKOC_COMM_BUS_ID_BYTES);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(out, GKOC_COMM_BUS_ID_BYTES - 1, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        snprintf(out, GKOC_COMM_BUS_ID_BYTES, "dev%d", dev);
+    }
+    const char* fake = std::getenv("GKOC_COMM_FAKE_BUS_ID");
+    while (fake && *fake) {
+        char* end = nullptr;
+        const long r = std::strtol(fake, &end, 10);
+        if (end == fake || *end != '=') break;
+        const char* v = end + 1;
+        const char* stop = std::strchr(v, ',');
+        const size_t len = stop ? size_t(stop - v) : std::strlen(v);
+        if (r == rank && len > 0 && len < GKOC_COMM_BUS_ID_BYTES) {
+            std::memset(out, 0, GKOC_COMM_BUS_ID_BYTES);
+            std::memcpy(out, v, len);
+        }
+        fake = stop ? stop + 1 : nullptr;
+    }
+}
+
+// a communicator with a peer on another device is up: the gated kernels pay the full fence until the
+// caller's self-check has passed on it (common.hpp gate_fence_policy)
+static void note_topology(gkoc_comm_s* c)
+{
+    c->cross_device = false;
+    for (int p = 0; p < c->n_ranks && p < gkoc::ipc::MAX_RANKS; ++p) {
+        if (std::strncmp(c->bus_ids[p], c->bus_ids[c->rank], GKOC_COMM_BUS_ID_BYTES) != 0) c->cross_device = true;
+    }
+    if (c->cross_device) gkoc::gate_fence_policy_set(2);
+}
 
 using namespace gkoc;
 
@@ -207,6 +268,16 @@ int ipc_all_reduce(gkoc_comm_s* c, hipStream_t st, void* buf, int64_t n, size_t 
 {
     GKOC_REQUIRE(c->connected, GKOC_E_INVALID, "communicator not connected (gkoc_comm_ipc_connect)");
     const int64_t per_launch = int64_t(ipcx::LL_WORDS) * 4 / int64_t(value_size);
+    // tests: GKOC_IPC_INJECT_MUTE="<rank>:<k>" - from its k-th all-reduce on, `rank` contributes nothing (its
+    // peers' waits run out of patience): the fault "a peer went away in the middle of a solve"
+    if (c->mute_after < 0) {
+        c->mute_after = 0;
+        const char* mu = std::getenv("GKOC_IPC_INJECT_MUTE");
+        int r = -1;
+        long k = 0;
+        if (mu && std::sscanf(mu, "%d:%ld", &r, &k) == 2 && r == c->rank && k > 0) c->mute_after = k;
+    }
+    if (c->mute_after > 0 && ++c->all_reduces_seen >= c->mute_after) return GKOC_OK;
     for (int64_t off = 0; off < n; off += per_launch) {
         const int64_t cnt = (n - off < per_launch) ? (n - off) : per_launch;
         ipcx::ar_args a;
@@ -413,6 +484,36 @@ int gkoc_comm_create(gkoc_comm_t* comm, int n_ranks, int rank, const void* id)
             if (w) (void)gkoc_free(w);
         }
     }
+    // who is where: what RCCL itself counts, its version, and every rank's device (one small all-gather -
+    // collective like the init it follows; a failure here is recorded, not fatal).  RCCL admits one rank per
+    // device, so with more than one rank every peer is on another device whatever the gather says.
+    own_bus_id(rank, c->bus_ids[rank < ipc::MAX_RANKS ? rank : 0]);
+    if (g_rccl.CommCount && g_rccl.CommCount(c->comm, &c->ranks_seen) != nccl_success) c->ranks_seen = -1;
+    if (g_rccl.GetVersion && g_rccl.GetVersion(&c->rccl_version) != nccl_success) c->rccl_version = -1;
+    if (n_ranks > 1 && n_ranks <= ipc::MAX_RANKS && g_rccl.AllGather) {
+        void* d = nullptr;
+        const size_t each = GKOC_COMM_BUS_ID_BYTES;
+        if (hipMalloc(&d, each * size_t(n_ranks + 1)) == hipSuccess) {
+            char* all = static_cast<char*>(d);
+            char* mine = all + each * size_t(n_ranks);
+            bool ok = hipMemcpy(mine, c->bus_ids[rank], each, hipMemcpyHostToDevice) == hipSuccess &&
+                      g_rccl.AllGather(mine, all, each, nccl_uint8, c->comm, nullptr) == nccl_success &&
+                      hipStreamSynchronize(nullptr) == hipSuccess &&
+                      hipMemcpy(c->bus_ids, all, each * size_t(n_ranks), hipMemcpyDeviceToHost) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                std::memset(c->bus_ids, 0, sizeof(c->bus_ids));
+                own_bus_id(rank, c->bus_ids[rank]);
+            }
+            (void)hipFree(d);
+        }
+        (void)hipGetLastError();
+    }
+    note_topology(c);
+    if (n_ranks > 1) {
+        c->cross_device = true;
+        gate_fence_policy_set(2);
+    }
     *comm = c;
     return GKOC_OK;
 }
@@ -423,7 +524,7 @@ int gkoc_comm_ipc_create(gkoc_comm_t* comm, int n_ranks, int rank, int64_t slot_
     GKOC_REQUIRE(comm && handle_out, GKOC_E_INVALID, "comm or handle_out == NULL");
     GKOC_REQUIRE(n_ranks >= 1 && n_ranks <= ipcx::MAX_RANKS && rank >= 0 && rank < n_ranks, GKOC_E_INVALID,
                  "bad rank / n_ranks (at most 16 ranks)");
-    static_assert(sizeof(hipIpcMemHandle_t) <= GKOC_COMM_IPC_HANDLE_BYTES, "handle size");
+    static_assert(sizeof(hipIpcMemHandle_t) + GKOC_COMM_BUS_ID_BYTES + 2 <= GKOC_COMM_IPC_HANDLE_BYTES, "handle size");
     if (slot_bytes <= 0) {
         const char* e = std::getenv("GKOC_IPC_SLOT_MIB");
         const long mib = e ? std::atol(e) : 0;
@@ -505,8 +606,13 @@ int gkoc_comm_ipc_create(gkoc_comm_t* comm, int n_ranks, int rank, int64_t slot_
             if (w) (void)gkoc_free(w);
         }
     }
-    std::memset(handle_out, 0, GKOC_COMM_IPC_HANDLE_BYTES);
-    std::memcpy(handle_out, &h, sizeof(h));
+    ipc_card card;
+    std::memset(&card, 0, sizeof(card));
+    card.handle = h;
+    own_bus_id(rank, card.bus_id);
+    card.window_uncached = c->window_uncached ? 1 : 0;
+    card.version = 1;
+    std::memcpy(handle_out, &card, sizeof(card));
     *comm = c;
     return GKOC_OK;
 }
@@ -516,6 +622,30 @@ int gkoc_comm_ipc_connect(gkoc_comm_t comm, const void* handles)
     GKOC_REQUIRE(comm && handles && comm->transport == 1, GKOC_E_INVALID, "not a mailbox communicator");
     GKOC_REQUIRE(!comm->connected, GKOC_E_INVALID, "already connected");
     const char* hb = static_cast<const char*>(handles);
+    // Who is where.  EVERY rank reads the same cards, so every rank reaches the same verdict without another
+    // round of talking: a window that is plain (coarse-grained) device memory must not be polled from ANOTHER
+    // device - this device's caches may serve a polling load from a line they already hold for ever, and the
+    // failure would be a patience timeout on the first real multi-GPU run.  Between
+    // processes that share one device it works and is tested.  The caller takes RCCL.
+    bool all_uncached = true;
+    for (int p = 0; p < comm->n_ranks; ++p) {
+        ipc_card card;
+        std::memcpy(&card, hb + size_t(p) * GKOC_COMM_IPC_HANDLE_BYTES, sizeof(card));
+        GKOC_REQUIRE(card.version == 1, GKOC_E_INVALID, "not a window card of this library version");
+        std::memcpy(comm->bus_ids[p], card.bus_id, GKOC_COMM_BUS_ID_BYTES);
+        comm->bus_ids[p][GKOC_COMM_BUS_ID_BYTES - 1] = 0;
+        all_uncached = all_uncached && card.window_uncached != 0;
+    }
+    comm->ranks_seen = comm->n_ranks;
+    comm->all_uncached = all_uncached;
+    note_topology(comm);
+    const char* allow = std::getenv("GKOC_IPC_ALLOW_PLAIN_ACROSS_DEVICES");
+    if (comm->cross_device && !all_uncached && !(allow && std::atoi(allow) != 0)) {
+        set_last_error("gkoc_comm_ipc_connect: the ranks sit on different devices and at least one rank's window is "
+                       "plain device memory (uncached memory could not be had or exported there): mailboxes in "
+                       "coarse-grained memory are not polled across devices - refused on every rank, use RCCL");
+        return GKOC_E_NOT_SUPPORTED;
+    }
     for (int p = 0; p < comm->n_ranks; ++p) {
         if (p == comm->rank) {
             comm->peers.win[p] = comm->window;
@@ -523,6 +653,12 @@ int gkoc_comm_ipc_connect(gkoc_comm_t comm, const void* handles)
         }
         hipIpcMemHandle_t h;
         std::memcpy(&h, hb + size_t(p) * GKOC_COMM_IPC_HANDLE_BYTES, sizeof(h));
+        const char* deny = std::getenv("GKOC_IPC_INJECT_OPEN_FAIL");      // tests: "<rank>" whose opens are denied
+        if (deny && *deny && std::atoi(deny) == comm->rank) {
+            set_last_error("gkoc_comm_ipc_connect: hipIpcOpenMemHandle of rank %d's window failed: injected "
+                           "(GKOC_IPC_INJECT_OPEN_FAIL)", p);
+            return GKOC_E_COMM;
+        }
         void* w = nullptr;
         hipError_t e = hipIpcOpenMemHandle(&w, h, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) {
@@ -563,6 +699,23 @@ int gkoc_comm_transport(gkoc_comm_t comm, int* transport, int* window_uncached)
     GKOC_REQUIRE(comm && transport, GKOC_E_INVALID, "bad argument");
     *transport = comm->transport;
     if (window_uncached) *window_uncached = comm->window_uncached ? 1 : 0;
+    return GKOC_OK;
+}
+
+int gkoc_comm_topology_get(gkoc_comm_t comm, gkoc_comm_topology* out)
+{
+    GKOC_REQUIRE(comm && out, GKOC_E_INVALID, "bad argument");
+    std::memset(out, 0, sizeof(*out));
+    out->transport = comm->transport;
+    out->n_ranks = comm->n_ranks;
+    out->rank = comm->rank;
+    out->ranks_seen = comm->ranks_seen;
+    out->rccl_version = comm->rccl_version;
+    out->cross_device = comm->cross_device ? 1 : 0;
+    out->window_uncached = comm->transport == 1 ? (comm->connected ? comm->all_uncached : comm->window_uncached) : 0;
+    out->gate_fence = gate_fence_policy();
+    const int n = comm->n_ranks < ipc::MAX_RANKS ? comm->n_ranks : ipc::MAX_RANKS;
+    for (int p = 0; p < n; ++p) std::memcpy(out->bus_id[p], comm->bus_ids[p], GKOC_COMM_BUS_ID_BYTES);
     return GKOC_OK;
 }
 

@@ -32,7 +32,8 @@
 //
 // Everything that waits has a patience (GKOC_IPC_PATIENCE_MS, two minutes): a wait that runs out sets a
 // bit in the communicator's status word (gkoc_comm_status) and lets the kernel end - a wrong number
-// that is reported, not a hung device.
+// that is reported, not a hung device; every later wait of that communicator gives up within a
+// millisecond (out_of_patience), so a solve that has lost its transport ends in seconds.
 #ifndef GKOC_COMM_IPC_HPP_
 #define GKOC_COMM_IPC_HPP_
 
@@ -71,6 +72,23 @@ struct ar_args {
     uint32_t epoch, parity;
 };
 
+// A transport on which one wait has run out is DEAD (its numbering is off by one from then on): every
+// later wait would otherwise sit out the whole patience again - minutes per operation of a solve that is
+// already lost.  A waiter therefore looks at the status word once per millisecond of waiting (a load from
+// pinned host memory: never on the fast path) and gives up at once when a bit is set.
+constexpr long long DEAD_CHECK_TICKS = 100000;      // 1 ms of the 100 MHz clock
+
+__device__ __forceinline__ bool out_of_patience(long long waited, long long patience, long long& next_look,
+                                                const uint32_t* status)
+{
+    if (waited > patience) return true;
+    if (waited > next_look) {
+        next_look = waited + DEAD_CHECK_TICKS;
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return true;
+    }
+    return false;
+}
+
 __device__ __forceinline__ uint64_t* ll_slot(char* win, uint32_t parity, int src)
 {
     return reinterpret_cast<uint64_t*>(win) + (size_t(parity) * MAX_RANKS + src) * LL_WORDS;
@@ -90,13 +108,14 @@ __global__ __launch_bounds__(256) void all_reduce_kernel(ar_args a)
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const long long t0 = wall_clock64();
+    long long next_look = DEAD_CHECK_TICKS;
     bool gave_up = false;
     for (int idx = tid; idx < total; idx += blockDim.x) {
         const int p = idx / a.n_words, w = idx - p * a.n_words;
         const uint64_t* src = ll_slot(a.peers.win[a.me], a.parity, p) + w;
         uint64_t v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while (uint32_t(v >> 32) != a.epoch) {
-            if (wall_clock64() - t0 > a.patience) {
+            if (out_of_patience(wall_clock64() - t0, a.patience, next_look, a.status)) {
                 gave_up = true;
                 break;
             }
@@ -191,14 +210,16 @@ __device__ __forceinline__ void copy_bytes(char* dst, const char* src, int64_t l
 
 // waits (thread 0 of the workgroup polls, the others wait at the barrier) until *word has reached
 // `want`; false if the patience ran out
-__device__ __forceinline__ bool wait_reached(const uint32_t* word, uint32_t want, long long patience)
+__device__ __forceinline__ bool wait_reached(const uint32_t* word, uint32_t want, long long patience,
+                                             const uint32_t* status)
 {
     __shared__ int ok;
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64();
+        long long next_look = DEAD_CHECK_TICKS;
         int good = 1;
         while (int32_t(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-            if (wall_clock64() - t0 > patience) {
+            if (out_of_patience(wall_clock64() - t0, patience, next_look, status)) {
                 good = 0;
                 break;
             }
@@ -228,7 +249,7 @@ __global__ __launch_bounds__(COPY_THREADS) void exchange_kernel(xchg_args a)
         const int64_t begin = int64_t(part) * g.chunk;
         const int64_t len = (begin + g.chunk <= g.len) ? g.chunk : (g.len - begin);
         // the slot of parity seq % 2 still holds message seq - 2 until the receiver has copied it out
-        if (!wait_reached(ack_of(a.peers.win[a.me], g.peer), g.seq - 2u, a.patience)) {
+        if (!wait_reached(ack_of(a.peers.win[a.me], g.peer), g.seq - 2u, a.patience, a.status)) {
             if (tid == 0) __hip_atomic_fetch_or(a.status, ST_ACK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         char* dst = data_of(a.peers.win[g.peer], g.seq & 1u, a.me, a.n_ranks, a.slot_bytes) + begin;
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(COPY_THREADS) void exchange_kernel(xchg_args a)
     const int part = rwg - g.first_wg;
     const int64_t begin = int64_t(part) * g.chunk;
     const int64_t len = (begin + g.chunk <= g.len) ? g.chunk : (g.len - begin);
-    if (!wait_reached(flag_of(a.peers.win[a.me], g.peer), g.seq, a.patience)) {
+    if (!wait_reached(flag_of(a.peers.win[a.me], g.peer), g.seq, a.patience, a.status)) {
         if (tid == 0) __hip_atomic_fetch_or(a.status, ST_FLAG_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const char* src = data_of(a.peers.win[a.me], g.seq & 1u, g.peer, a.n_ranks, a.slot_bytes) + begin;

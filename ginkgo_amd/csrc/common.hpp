@@ -76,6 +76,14 @@ int stream_ticket(hipStream_t st, unsigned** word);
 // csr::spmv's memory of which segments of a matrix hold very long rows (csr_spmv.hip): forgotten when the
 // row-pointer array is freed
 void csr_long_rows_forget(const void* ptr);
+// What a wave (block) that reads data behind a gate word pays before its first read (csr_spmv_pipe.hpp GATE,
+// fused.hpp step_gate_enter): 0 = the cheap gate (an agent-scope acquire only if it had to wait), 1 = every
+// such wave an agent-scope acquire, 2 = every one a SYSTEM-scope acquire.  A communicator that has a peer on
+// ANOTHER device sets 2 when it comes up (comm.hip) - the cheap gate's argument has only ever been soaked with
+// writers on the same device - and the caller may lower it again once its own self-check on that communicator
+// has passed (gkoc_gate_fence_policy).
+int gate_fence_policy();
+void gate_fence_policy_set(int policy);
 // tuning switches (runtime.hip; keys = GKOC_TUNE_* of gko_cdna4.h)
 constexpr int tune_num_keys = 13;
 int64_t tune_value(int key);

@@ -20,6 +20,7 @@
 //
 // Algorithmic HBM bytes: nnz*(sizeof(T)+sizeof(I)) + (n+1)*sizeof(I)
 //                        + n_cols*sizeof(T) (b once) + n*sizeof(T) (c).
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -463,8 +464,11 @@ int launch_csr_gated(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, const I
     // the cheap gate (no agent-scope acquire for a wave that did not wait) rests on the halo lying on
     // 128-byte lines of its own: b on a line boundary and the halo at a multiple of 128 bytes behind it
     // (the documented layout: n_rows rounded up to 32 entries).  A b that is not aligned cannot have that.
-    const int gate_fence =
-        (tune_value(GKOC_TUNE_GATE_FENCE) != 0 || reinterpret_cast<uintptr_t>(b) % 128 != 0) ? 1 : 0;
+    // ... and on the halo's writer being THIS device: with a peer on another device the policy is 2 until the
+    // caller's self-check on that communicator has passed (common.hpp gate_fence_policy)
+    const int gate_fence = std::max(
+        gate_fence_policy(),
+        (tune_value(GKOC_TUNE_GATE_FENCE) != 0 || reinterpret_cast<uintptr_t>(b) % 128 != 0) ? 1 : 0);
     // where in the grid the boundary waves sit: GKOC_TUNE_GATE_POS per cent of the interior waves
     // in front of them (100 = they are the last waves)
     int64_t pos = tune_value(GKOC_TUNE_GATE_POS);

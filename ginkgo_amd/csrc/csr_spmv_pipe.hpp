@@ -196,7 +196,12 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
             // wait is the one case where its own CU may have re-fetched around it: it pays the fence.
             // gate_fence = 1 (GKOC_TUNE_GATE_FENCE) makes every boundary wave pay it.
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (gate_fence != 0 || __builtin_amdgcn_readfirstlane(int(waited)) != 0) {
+            // gate_fence = 2 (a peer of the communicator sits on ANOTHER device, gate_fence_policy):
+            // every boundary wave a SYSTEM-scope acquire - nothing is assumed about which agent wrote the
+            // halo or about what this device's caches hold of lines another device has written.
+            if (gate_fence >= 2) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            } else if (gate_fence != 0 || __builtin_amdgcn_readfirstlane(int(waited)) != 0) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         } else {

@@ -190,12 +190,14 @@ struct step_gate_dev {
     uint8_t stopping_id;
     uint8_t set_finalized;
     uint8_t* flags;
+    int fence;                // gate_fence_policy() at launch (common.hpp)
 };
 
 template <typename T>
 step_gate_dev<T> step_gate_of(const gkoc_step_gate* g)
 {
     step_gate_dev<T> d{};
+    d.fence = gate_fence_policy();
     if (g) {
         d.word = g->wait_word;
         d.number = g->wait_number;
@@ -231,7 +233,11 @@ __device__ __forceinline__ bool step_gate_enter(const step_gate_dev<T>& g, uint8
             }
             // (nothing of this launch has read the scalars before the word was seen; a block that
             // waited drops what its CU may hold)
-            if (waited) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (g.fence >= 2) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (a peer on another device: system scope, always)
+            } else if (waited || g.fence == 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
         }
         __syncthreads();
     }

@@ -2,6 +2,7 @@
 // stream management.  These are the C-ABI equivalents of the HipExecutor
 // member functions that Ginkgo stubs in core/device_hooks/hip_hooks.cpp:21-252
 // and implements for its own backend in hip/base/executor.hip.cpp.
+#include <atomic>
 #include <dlfcn.h>
 
 #include <cstdarg>
@@ -104,6 +105,11 @@ int stream_ticket(hipStream_t st, unsigned** word)
 
 static int64_t g_tune[tune_num_keys] = {};
 static bool g_tune_set[tune_num_keys] = {};
+
+// (common.hpp) what a wave behind a gate word pays before its first read
+static std::atomic<int> g_gate_fence_policy{0};
+int gate_fence_policy() { return g_gate_fence_policy.load(std::memory_order_relaxed); }
+void gate_fence_policy_set(int policy) { g_gate_fence_policy.store(policy < 0 ? 0 : policy > 2 ? 2 : policy); }
 
 // process-wide tuning switches: gkoc_tune_set, else the environment variable
 // GKOC_TUNE_<n>, else the default chosen by measurement
@@ -303,6 +309,14 @@ int gkoc_tune_set(int key, int64_t value)
     GKOC_REQUIRE(key >= 0 && key < tune_num_keys, GKOC_E_INVALID, "unknown tuning key");
     g_tune[key] = value;
     g_tune_set[key] = true;
+    return GKOC_OK;
+}
+
+int gkoc_gate_fence_policy(int set, int* now)
+{
+    GKOC_REQUIRE(set >= -1 && set <= 2, GKOC_E_INVALID, "policy must be -1 (query), 0, 1 or 2");
+    if (set >= 0) gate_fence_policy_set(set);
+    if (now) *now = gate_fence_policy();
     return GKOC_OK;
 }
 

@@ -31,6 +31,26 @@ from .matrix import Csr, Dense, scalar, stencil_csr
 from .preconditioner import Jacobi
 
 
+IPC_HANDLE_BYTES = 128        # GKOC_COMM_IPC_HANDLE_BYTES
+BUS_ID_BYTES = 32             # GKOC_COMM_BUS_ID_BYTES
+
+
+class CommTopology(C.Structure):
+    """gkoc_comm_topology (include/gko_cdna4.h)"""
+    _fields_ = [("transport", C.c_int32), ("n_ranks", C.c_int32), ("rank", C.c_int32),
+                ("ranks_seen", C.c_int32), ("rccl_version", C.c_int32), ("cross_device", C.c_int32),
+                ("window_uncached", C.c_int32), ("gate_fence", C.c_int32),
+                ("bus_id", (C.c_char * BUS_ID_BYTES) * 16)]
+
+
+def gate_fence_policy(set_to=-1):
+    """gkoc_gate_fence_policy: what the kernels that read behind a gate word pay per waiting wave (0 cheap
+    gate, 1 agent-scope acquire, 2 system-scope acquire); returns the policy in force afterwards"""
+    now = C.c_int(0)
+    call("gkoc_gate_fence_policy", C.c_int(int(set_to)), C.byref(now))
+    return int(now.value)
+
+
 class StepGate(C.Structure):
     """gkoc_step_gate (include/gko_cdna4.h): what a fused PipeCg step kernel waits for and the
     stopping criterion it evaluates itself"""
@@ -263,6 +283,18 @@ class RcclComm(TorchComm):
              C.byref(w), C.byref(n))
         return self._fork_tok
 
+    def topology(self):
+        """gkoc_comm_topology_get as a dict: did the communicator see N ranks, on which devices, which RCCL"""
+        t = CommTopology()
+        call("gkoc_comm_topology_get", self._handle, C.byref(t))
+        n = min(t.n_ranks, 16)
+        return {"transport": "mailboxes" if t.transport == 1 else "rccl", "ranks": t.n_ranks,
+                "ranks_seen": t.ranks_seen, "rccl_version": t.rccl_version or None,
+                "cross_device": bool(t.cross_device),
+                "window_uncached": bool(t.window_uncached) if t.transport == 1 else None,
+                "gate_fence": t.gate_fence,
+                "bus_ids": [t.bus_id[p].raw.split(b"\0", 1)[0].decode(errors="replace") for p in range(n)]}
+
     def check(self):
         """raises if a fork's poller ever gave up (gkoc_comm_fork_timed_out); synchronises"""
         flag = C.c_int(0)
@@ -300,7 +332,9 @@ class IpcComm(RcclComm):
     (include/ginkgo/core/distributed/collective_communicator.hpp:31-71).  Works between
     processes that SHARE one GPU (RCCL does not), so the whole N > 1 device path - forks, side
     stream, gated one-kernel product, pipelined solver steps - runs on a one-GPU box.
-    torch.distributed only carries the 64-byte window handles (all_gather) at set-up."""
+    torch.distributed only carries the window cards (handle + PCI bus id + kind of memory, all_gather) at
+    set-up; gkoc_comm_ipc_connect refuses - on every rank alike - windows in plain device memory between
+    DIFFERENT devices (default_comm then takes RCCL)."""
 
     def __init__(self, exec_, group=None, slot_bytes=0):
         TorchComm.__init__(self, group)
@@ -317,7 +351,7 @@ class IpcComm(RcclComm):
                                + lib().gkoc_last_error().decode(errors="replace"))
 
         self._handle = C.c_void_p(0)
-        mine = (C.c_uint8 * 64)()
+        mine = (C.c_uint8 * IPC_HANDLE_BYTES)()
         rc = lib().gkoc_comm_ipc_create(C.byref(self._handle), C.c_int(self.size), C.c_int(self.rank),
                                         C.c_int64(int(slot_bytes)), mine)
         try:
@@ -328,7 +362,8 @@ class IpcComm(RcclComm):
                 dist.all_gather(outs, t, group=group)
             else:
                 outs = [t]
-            everybody = (C.c_uint8 * (64 * self.size))(*[int(v) for o in outs for v in o.cpu().tolist()])
+            everybody = (C.c_uint8 * (IPC_HANDLE_BYTES * self.size))(
+                *[int(v) for o in outs for v in o.cpu().tolist()])
             rc = lib().gkoc_comm_ipc_connect(self._handle, everybody)
             agree(rc == 0 and not _inject_failure("init", self.rank), "mapping the peers' windows")
         except GkoError:
@@ -501,6 +536,8 @@ class _Watchdog:
     in `seconds`: a hung collective cannot be cancelled, but the launcher can be told WHY the
     job died instead of being left to its own timeout."""
 
+    on_fire = None      # bench.py: leave a line that says what was running before the process ends
+
     def __init__(self, seconds, what):
         self.seconds, self.what = seconds, what
 
@@ -515,6 +552,11 @@ class _Watchdog:
                   "reached it, HSA_ENABLE_IPC_MODE_LEGACY=0, and the RCCL transport; "
                   "GKO_COMM=torch selects torch.distributed for the data path", file=sys.stderr)
             sys.stderr.flush()
+            try:
+                if _Watchdog.on_fire is not None:
+                    _Watchdog.on_fire(self.what)
+            except Exception:          # noqa: BLE001
+                pass
             os._exit(86)
 
         self.t = threading.Timer(self.seconds, fire)
@@ -1131,33 +1173,70 @@ class DistributedMatrix:
         self._gate = None
         self.deferred_fork = False
 
-    def self_check(self, seed=7):
+    def self_check(self, seed=7, rounds=1):
         """The one-kernel product against the join-based one on THIS communicator, before anything
         is timed: same bits on every local row, no boundary wave that gave up, no fork that timed out.
         Every rank runs the same collectives.  (ok, what) - on failure the caller agrees with the other
-        ranks and calls conservative() on all of them."""
+        ranks and calls conservative() on all of them (agreed_self_check does both).  rounds > 1: a
+        short soak - a NEW x (so a new halo from every neighbour) per round, each compared."""
         if self._gate is None or self.comm.size == 1:
             return True, "join-based product (no one-kernel product for this matrix / communicator)"
         be = self.backend
         x = self.ext_vector()
-        vals = np.random.default_rng(seed + self.rank).uniform(-1, 1, self.n_local)
-        x.values.copy_(torch.from_numpy(vals).view(-1, 1))
         y1, y2 = be.vector(self.n_local, self.dtype), be.vector(self.n_local, self.dtype)
+        rng = np.random.default_rng(seed + self.rank)
         try:
-            for _ in range(3):
-                self.apply(x, y1)
-            self.check_gate()
-            gate, self._gate = self._gate, None
-            try:
-                self.apply(x, y2)
-            finally:
-                self._gate = gate
-            be.synchronize()
-            if not torch.equal(y1.values, y2.values):
-                return False, "one-kernel product differs from the join-based product"
+            for r in range(max(1, int(rounds))):
+                x.values.copy_(torch.from_numpy(rng.uniform(-1, 1, self.n_local)).view(-1, 1))
+                for _ in range(3 if r == 0 else 1):
+                    self.apply(x, y1)
+                self.check_gate()
+                gate, self._gate = self._gate, None
+                try:
+                    self.apply(x, y2)
+                finally:
+                    self._gate = gate
+                be.synchronize()
+                if not torch.equal(y1.values, y2.values):
+                    return False, f"one-kernel product differs from the join-based product (round {r})"
         except GkoError as e:
             return False, str(e)[:200]
-        return True, "one-kernel product == join-based product bit for bit"
+        return True, ("one-kernel product == join-based product bit for bit" +
+                      (f" in {rounds} rounds with fresh halos" if rounds > 1 else ""))
+
+    def agreed_self_check(self, soak_rounds=64):
+        """self_check + the agreement of all ranks + its consequences, collectively: a rank that sees a
+        difference (or a wave that gave up, a fork that timed out) sends ALL ranks to the join-based product.
+        With a peer on ANOTHER device (comm.topology()) the gated kernels pay a system-scope acquire per
+        waiting wave (csrc/common.hpp gate_fence_policy) and the check is a soak of `soak_rounds` products with
+        fresh halos; only when that has passed on every rank is the cheap gate trusted on this communicator
+        (GKO_GATE_TRUST=0 keeps the fence whatever the soak says).  Returns what the bench line prints."""
+        import os
+        topo = self.comm.topology() if hasattr(self.comm, "topology") else None
+        cross = bool(topo and topo["cross_device"])
+        ok, why = self.self_check(rounds=soak_rounds if cross and self._gate is not None else 1)
+        if self.comm.size > 1:
+            flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64,
+                                device=torch.device("cpu") if self.comm.host_staging else self.backend.exec.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.comm.group)
+            all_ok = float(flag.item()) >= 1.0
+        else:
+            all_ok = ok
+        if not all_ok:
+            self.conservative()
+        fence = None
+        if topo is not None:
+            if all_ok and cross and self._gate is not None and os.environ.get("GKO_GATE_TRUST", "1") != "0":
+                fence = gate_fence_policy(0)
+            else:
+                fence = gate_fence_policy(-1)
+        return {"one_kernel_product": self._gate is not None,
+                "self_check": why if all_ok or not ok else "failed on another rank",
+                "peers_on_other_devices": cross,
+                "gate_fence": {None: None, 0: "cheap gate (acquire only for a wave that waited)" +
+                               (", trusted after the soak on this communicator" if cross else ""),
+                               1: "agent-scope acquire per waiting wave",
+                               2: "system-scope acquire per waiting wave (a peer on another device)"}[fence]}
 
     def _fork_token(self):
         """the exchange about to begin is forked by the product's own kernel where the

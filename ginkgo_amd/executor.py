@@ -151,7 +151,9 @@ class Cdna4Executor:
                         ("class_reserved_bytes", C.c_int64 * 3),
                         ("class_used_bytes", C.c_int64 * 3),
                         ("granules_classified", C.c_int64), ("search_ns", C.c_int64),
-                        ("probe_retries", C.c_int64), ("surveyed", C.c_int64)]
+                        ("probe_retries", C.c_int64), ("surveyed", C.c_int64),
+                        ("search_budget_ms", C.c_int64), ("search_budget_spent", C.c_int64),
+                        ("granules_unclassified", C.c_int64)]
         info = Info()
         with torch.cuda.device(self.device):
             _lib.call("gkoc_arena_stats", C.byref(info))

@@ -120,6 +120,10 @@ typedef struct gkoc_arena_info {
     int64_t search_ns;            /* host time spent in the searches                    */
     int64_t probe_retries;        /* classifications repeated: verdict not one-hot      */
     int64_t surveyed;             /* 1: the one search for all classes has run          */
+    int64_t search_budget_ms;     /* GKOC_ARENA_SURVEY_MS (default 1500): wall-clock bound of all searches of
+                                   * this device in this process; 0 = bounded by the free memory only        */
+    int64_t search_budget_spent;  /* 1: a search stopped at the bound - the classes found so far are final   */
+    int64_t granules_unclassified;/* granules mapped into a region without a probe after the bound was hit   */
 } gkoc_arena_info;
 int gkoc_malloc_role(void** ptr, size_t bytes, int role);
 int gkoc_arena_configure(int mode, size_t chunk_bytes, int sync_on_free);
@@ -2307,7 +2311,7 @@ int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* 
  * collective_communicator be chosen (include/ginkgo/core/distributed/collective_communicator.hpp:31-71).
  * Several processes on ONE device can form such a communicator (RCCL refuses that), which is how the
  * whole N > 1 device path is tested on a one-GPU box.
- *   1. every rank: gkoc_comm_ipc_create -> its 64-byte handle;   slot_bytes: room per peer and
+ *   1. every rank: gkoc_comm_ipc_create -> its handle card (GKOC_COMM_IPC_HANDLE_BYTES);   slot_bytes: room per peer and
  *      direction for one message (0: GKOC_IPC_SLOT_MIB or 8 MiB); at most 16 ranks
  *   2. the host program gathers all handles in rank order (MPI_Allgather, a key-value store)
  *   3. every rank: gkoc_comm_ipc_connect(all handles)
@@ -2317,7 +2321,9 @@ int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* 
  * (no synchronisation; 0 = nothing ever timed out; bit 0 all-reduce, bit 1 a message, bit 2 an
  * acknowledgement).  gkoc_comm_destroy must be entered by a rank only after its peers have completed
  * the operations it takes part in (a host barrier, or the end of the solve). */
-#define GKOC_COMM_IPC_HANDLE_BYTES 64
+#define GKOC_COMM_IPC_HANDLE_BYTES 128    /* the hipIpc handle of the window + where it lives: PCI bus id of the
+                                           * device, whether the window is uncached memory, a version byte */
+#define GKOC_COMM_BUS_ID_BYTES 32
 int gkoc_comm_ipc_create(gkoc_comm_t* comm, int n_ranks, int rank, int64_t slot_bytes,
                          void* handle_out /* GKOC_COMM_IPC_HANDLE_BYTES */);
 int gkoc_comm_ipc_connect(gkoc_comm_t comm, const void* handles /* n_ranks x GKOC_COMM_IPC_HANDLE_BYTES */);
@@ -2328,6 +2334,29 @@ int gkoc_comm_status(gkoc_comm_t comm, uint32_t* status);
 int gkoc_comm_set_patience_ms(gkoc_comm_t comm, int64_t ms);
 /* *transport: 0 = RCCL, 1 = mailboxes; *window_uncached (may be NULL): the window is uncached device memory */
 int gkoc_comm_transport(gkoc_comm_t comm, int* transport, int* window_uncached);
+/* Who is where - the answer to "did the communicator see N ranks, on which devices" (bench.py prints it in the
+ * N > 1 line).  RCCL: ranks_seen = ncclCommCount, rccl_version = ncclGetVersion, bus ids from one small
+ * all-gather at creation; mailboxes: from the cards.  cross_device = 1: at least one peer sits on another
+ * device.  Two rules follow from it (replacing core/distributed/matrix.cpp:450-509's req.wait() by waits inside
+ * kernels needs them): (1) gkoc_comm_ipc_connect REFUSES - on every rank alike, GKOC_E_NOT_SUPPORTED - windows
+ * in plain (coarse-grained) memory between different devices; (2) the kernels that read behind a gate word
+ * (gkoc_csr_spmv_gated_*, the gated PipeCg steps) pay a system-scope acquire per waiting wave from then on
+ * (gate_fence = 2), until the caller lowers it with gkoc_gate_fence_policy after its own check on that
+ * communicator (the one-kernel product against the join-based one) has passed on every rank. */
+typedef struct gkoc_comm_topology {
+    int32_t transport, n_ranks, rank;
+    int32_t ranks_seen;       /* ncclCommCount (RCCL) / cards read (mailboxes); 0: not asked, -1: the call failed */
+    int32_t rccl_version;     /* ncclGetVersion, 0 for mailboxes */
+    int32_t cross_device;
+    int32_t window_uncached;  /* mailboxes: every rank's window is uncached memory */
+    int32_t gate_fence;       /* the current gkoc_gate_fence_policy */
+    char bus_id[16][GKOC_COMM_BUS_ID_BYTES];   /* PCI bus id of every rank's device (first 16 ranks) */
+} gkoc_comm_topology;
+int gkoc_comm_topology_get(gkoc_comm_t comm, gkoc_comm_topology* out);
+/* set: -1 = query only, 0 = the cheap gate (an agent-scope acquire only for a wave that had to wait), 1 = every
+ * waiting wave an agent-scope acquire, 2 = a system-scope one; *now (may be NULL) = the policy afterwards.
+ * Process-wide.  Raised to 2 by any communicator that comes up with a peer on another device. */
+int gkoc_gate_fence_policy(int set, int* now);
 
 #ifdef __cplusplus
 }

@@ -142,6 +142,76 @@ def test_bench_command_path_on_the_device_resident_transport():
     record_perf("bench_eight_ranks_one_gpu_mailbox", comm_check=d["comm_check"], cg_iters_per_s=d["cg_iters_per_s"])
 
 
+# ---- first contact with a real multi-GPU node must be survivable: every fault below
+# ---- has to end in ONE printed line that says what ran - never a hang, never a traceback without a line
+_FAULT_ARGS = ["--steps", "2", "--warmup", "1", "--grid", "32", "--no-pipe-cg"]
+
+
+@pytest.mark.gpu
+def test_bench_survives_a_denied_ipc_open_on_one_rank():
+    """hipIpcOpenMemHandle refused on rank 1 (GKOC_IPC_INJECT_OPEN_FAIL): the mailbox transport is given up by
+    ALL ranks together, the data path goes through the process group, the line says so"""
+    d = _bench(4, [*_FAULT_ARGS, "--cg-iters", "10"],
+               {"GKO_BENCH_BACKEND": "gloo", "GKO_COMM": "ipc", "GKOC_IPC_INJECT_OPEN_FAIL": "1"}, timeout=600)
+    assert d["comm_check"]["transport_choice"]["chosen"] == "TorchComm", d["comm_check"]
+    assert d["comm_check"]["communicator"] == "TorchComm" and d["cg_iterations"] == 10
+    assert d["distributed_product"]["one_kernel_product"] is False
+
+
+@pytest.mark.gpu
+def test_bench_survives_an_all_reduce_that_runs_out_of_patience():
+    """rank 1 stops contributing to the all-reduces in the middle of the warm-up solve (GKOC_IPC_INJECT_MUTE): its
+    peers' waits run out of patience ONCE (3 s here), every later wait gives up within a millisecond, the solve
+    ends, all ranks agree that the transport is dead and measure on the process group instead"""
+    d = _bench(4, [*_FAULT_ARGS, "--cg-iters", "100"],
+               {"GKO_BENCH_BACKEND": "gloo", "GKO_COMM": "ipc", "GKOC_IPC_INJECT_MUTE": "1:150",
+                "GKOC_IPC_PATIENCE_MS": "3000"}, timeout=600)
+    tc = d["comm_check"]["transport_choice"]
+    assert tc["chosen"] == "TorchComm" and tc["first_choice"]["chosen"] == "IpcComm", tc
+    assert "failed after it had come up" in tc["why"] and d["cg_iterations"] == 100
+
+
+@pytest.mark.gpu
+def test_bench_survives_a_failed_rccl_init_on_one_rank():
+    """ncclCommInitRank fails on rank 1 (GKO_COMM_INJECT_FAIL=1:init): no rank is left inside a collective,
+    the line names the communicator that carried the data"""
+    d = _bench(2, [*_FAULT_ARGS, "--cg-iters", "10"],
+               {"GKO_BENCH_BACKEND": "gloo", "GKO_COMM": "rccl", "GKO_COMM_INJECT_FAIL": "1:load"}, timeout=600)
+    assert d["comm_check"]["transport_choice"]["chosen"] == "TorchComm", d["comm_check"]
+    assert d["cg_iterations"] == 10
+
+
+@pytest.mark.gpu
+def test_bench_line_when_one_rank_finds_a_single_memory_class():
+    """the allocator of ONE rank is held to one class (the others survey as usual): the line is printed, the
+    per-rank part shows which rank it was, and the minimum over ranks is there to read"""
+    d = _bench(4, [*_FAULT_ARGS, "--cg-iters", "10"],
+               {"GKO_BENCH_BACKEND": "gloo", "GKO_COMM": "ipc", "GKO_TEST_ONE_CLASS_RANK": "2"}, timeout=600)
+    pr = d["roofline"]["per_rank"]
+    assert pr[2]["memory_classes_found"] <= 1 and d["roofline"]["memory_classes_min_over_ranks"] <= 1
+    assert "search_ms_max_over_ranks" in d["roofline"] and d["cg_iterations"] == 10
+
+
+@pytest.mark.gpu
+def test_peers_on_other_devices_plain_windows_are_refused_and_the_gate_pays_the_full_fence():
+    """what a multi-GPU node changes, exercised on one GPU by letting rank 1 REPORT another PCI bus id
+    (GKOC_COMM_FAKE_BUS_ID): (a) windows in plain device memory are refused by every rank alike -> no mailbox
+    transport; (b) with uncached windows the transport comes up, the gated kernels start with the system-scope
+    fence and the cheap gate is trusted only after the product's soak on that communicator has passed"""
+    fake = {"GKO_BENCH_BACKEND": "gloo", "GKO_COMM": "ipc", "GKOC_COMM_FAKE_BUS_ID": "1=ffff:ff:1f.7"}
+    d = _bench(2, [*_FAULT_ARGS, "--cg-iters", "10"], dict(fake, GKOC_IPC_WINDOW="plain"), timeout=600)
+    assert d["comm_check"]["transport_choice"]["chosen"] == "TorchComm", d["comm_check"]
+    d = _bench(2, [*_FAULT_ARGS, "--cg-iters", "10"], fake, timeout=600)
+    topo = d["comm_check"]["topology"]
+    assert d["comm_check"]["communicator"] == "IpcComm" and topo["cross_device"] and topo["window_uncached"]
+    assert topo["ranks_seen"] == 2 and topo["bus_ids"][1] == "ffff:ff:1f.7" and topo["bus_ids"][0] != topo["bus_ids"][1]
+    dp = d["distributed_product"]
+    assert dp["peers_on_other_devices"] and dp["one_kernel_product"]
+    assert "trusted after the soak" in dp["gate_fence"] and "64 rounds" in dp["self_check"], dp
+    d = _bench(2, [*_FAULT_ARGS, "--cg-iters", "10"], dict(fake, GKO_GATE_TRUST="0"), timeout=600)
+    assert "system-scope" in d["distributed_product"]["gate_fence"], d["distributed_product"]
+
+
 @pytest.mark.gpu
 def test_bench_starts_its_own_ranks_and_the_line_has_every_key():
     """`python bench.py --gpus 8 ...` WITHOUT a launcher: the script starts

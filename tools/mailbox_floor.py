@@ -14,7 +14,7 @@ from ginkgo_amd._lib import call
 
 ex = g.Cdna4Executor.create(0)
 h = C.c_void_p(0)
-mine = (C.c_uint8 * 64)()
+mine = (C.c_uint8 * 128)()
 call("gkoc_comm_ipc_create", C.byref(h), C.c_int(1), C.c_int(0), C.c_int64(1 << 20), mine)
 call("gkoc_comm_ipc_connect", h, mine)
 for n in (2, 3, 32):
