@@ -15,12 +15,18 @@
 //     the launcher (csr_spmv.hip), so a regular matrix pays one scan in its first product and nothing after;
 //   * the row-segment kernel leaves flagged segments out (a wave owns one or two segments: it shortens
 //     its range at its start - the only change to that kernel);
-//   * csr_flagged_segments_kernel does them: PARTS workgroups per flagged segment.  The ordinary rows of
-//     the segment are summed by one lane each in entry order with separate multiply and add - the
-//     reference's bits, as everywhere; a long row is cut into PARTS equal chunks, chunk p summed by
-//     workgroup p (per thread: entries first + t, + 256, ... in order; the 256 partial sums folded by a
-//     fixed tree), the PARTS chunk sums folded in chunk order by the workgroup that finishes last.  No
-//     floating-point atomics: the same bits every run, on every device (PARTS is a constant).
+//   * csr_flagged_segments_kernel does them: PARTS = 64 workgroups per flagged segment.  Workgroup p takes the
+//     segment's ORDINARY row p: its 256 threads form the products (coalesced loads of values and columns, the
+//     gathers in flight together) into LDS and one thread adds them in entry order, separate multiply and
+//     add - the reference's bits, as everywhere.  (Round 5 let one lane walk its row through global memory:
+//     two dependent loads per entry at 1.3 us each - a 170-entry row next to a hub cost 220 us, as long as
+//     the whole rest of the product: profiles/r06_irregular_pmc.txt.)  A long row is cut into PARTS equal
+//     chunks, chunk p summed by workgroup p (per thread: entries first + t, + 256, ... in order; the 256
+//     partial sums folded by a fixed tree);
+//   * csr_long_rows_fold_kernel adds the PARTS chunk sums of every long row in chunk order.  No
+//     floating-point atomics, no "last workgroup" tickets: the same bits every run, on every device (PARTS
+//     is a constant), and the chunk sums live in stream-ordered scratch of THIS launch - two products of one
+//     matrix on two streams do not share them.
 // A stale flag set (the arrays were rewritten in place under the same pointer) costs speed, never
 // correctness: both kernels read the SAME flags, and each handles any row.
 #pragma once
@@ -33,6 +39,7 @@ namespace gkoc {
 constexpr int LONG_PARTS = 64;        // workgroups per flagged segment (a constant: results do not depend on the device)
 constexpr int LONG_WG = 256;
 constexpr int LONG_MAX_PER_SEG = 8;   // long rows of one segment that are cut into chunks (more: summed by one workgroup)
+constexpr int LONG_STAGE = 4096;      // products of an ordinary row that wait in LDS for their turn (>= GKOC_CSR_LONG_ROW)
 
 // bit s of `bits` = segment s holds a row longer than GKOC_CSR_LONG_ROW; list[0] = how many, list[1 ..] = which
 template <typename I>
@@ -53,14 +60,15 @@ __global__ __launch_bounds__(256) void csr_long_row_scan_kernel(int64_t n_rows, 
     }
 }
 
-// c[rows of the listed segments] = A b  (ADV: alpha A b + beta c), one right-hand side (column j of b / c)
+// c[rows of the listed segments] = A b  (ADV: alpha A b + beta c), one right-hand side (column j of b / c);
+// the long rows' chunk sums go to `partial`, csr_long_rows_fold_kernel finishes them
 template <typename T, typename I, bool ADV, typename V = T>
 __global__ __launch_bounds__(LONG_WG) void csr_flagged_segments_kernel(
     int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols, const V* __restrict__ vals,
     const T* __restrict__ b, int64_t ldb, T* __restrict__ c, int64_t ldc, const T* __restrict__ alpha_p,
-    const T* __restrict__ beta_p, const unsigned long long* __restrict__ list, T* __restrict__ partial,
-    uint32_t* __restrict__ tickets)
+    const T* __restrict__ beta_p, const unsigned long long* __restrict__ list, T* __restrict__ partial)
 {
+    static_assert(LONG_PARTS == 64, "workgroup p of a segment takes its ordinary row p");
     const int64_t li = blockIdx.x / LONG_PARTS;          // which flagged segment
     const int part = blockIdx.x % LONG_PARTS;
     const int64_t seg = int64_t(list[1 + li]);
@@ -72,29 +80,21 @@ __global__ __launch_bounds__(LONG_WG) void csr_flagged_segments_kernel(
     }
     __shared__ int64_t rp[65];
     __shared__ T red[LONG_WG];
+    __shared__ T prod[LONG_STAGE];
     __shared__ int long_rows[LONG_MAX_PER_SEG];
-    __shared__ int n_long, n_over;
-    __shared__ uint32_t ticket;
+    __shared__ int n_long;
     const int64_t row0 = seg * 64;
     if (tid <= 64) {
         const int64_t r = row0 + tid < n_rows ? row0 + tid : n_rows;
         rp[tid] = int64_t(row_ptrs[r]);
     }
-    if (tid == 0) {
-        n_long = 0;
-        n_over = 0;
-    }
+    if (tid == 0) n_long = 0;
     __syncthreads();
     if (tid == 0) {
-        // the long rows of the segment, in row order (every workgroup of the segment finds the same list)
+        // the long rows of the segment that are cut into chunks, in row order (every workgroup of the
+        // segment finds the same list)
         for (int r = 0; r < 64; ++r) {
-            if (rp[r + 1] - rp[r] > GKOC_CSR_LONG_ROW) {
-                if (n_long < LONG_MAX_PER_SEG) {
-                    long_rows[n_long++] = r;
-                } else {
-                    ++n_over;
-                }
-            }
+            if (rp[r + 1] - rp[r] > GKOC_CSR_LONG_ROW && n_long < LONG_MAX_PER_SEG) long_rows[n_long++] = r;
         }
     }
     __syncthreads();
@@ -102,24 +102,36 @@ __global__ __launch_bounds__(LONG_WG) void csr_flagged_segments_kernel(
         const T xb = b[int64_t(cols[k]) * ldb];
         return ADV ? (alpha * T(vals[k])) * xb : T(vals[k]) * xb;
     };
-    if (part == 0 && tid < 64 && row0 + tid < n_rows) {
-        // the ordinary rows: lane = row, entry order, separate multiply and add (the reference's bits)
-        const int64_t a = rp[tid], e = rp[tid + 1];
-        const bool chunked = e - a > GKOC_CSR_LONG_ROW;
-        bool mine = !chunked;
-        if (chunked && n_over > 0) {
-            // a long row beyond the LONG_MAX_PER_SEG that are cut into chunks: summed here, in order
-            mine = true;
-            for (int q = 0; q < n_long; ++q) mine = mine && long_rows[q] != tid;
-        }
+    // ---- row `part` of the segment, unless it is one of the chunked ones: products by everybody, sum by one
+    {
+        bool mine = row0 + part < n_rows;
+        for (int q = 0; q < n_long; ++q) mine = mine && long_rows[q] != part;
         if (mine) {
+            const int64_t a = rp[part], e = rp[part + 1];
             T sum = T(0);
-            if (ADV && beta != T(0)) sum = c[(row0 + tid) * ldc] * beta;
-            for (int64_t k = a; k < e; ++k) sum += product(k);
-            c[(row0 + tid) * ldc] = sum;
+            if (ADV && beta != T(0) && tid == 0) sum = c[(row0 + part) * ldc] * beta;
+            // (a row beyond the stage - a ninth long row of one segment - goes through it in rounds)
+            for (int64_t k0 = a; k0 < e; k0 += LONG_STAGE) {
+                const int cnt = int(e - k0 < LONG_STAGE ? e - k0 : LONG_STAGE);
+                for (int i = tid; i < cnt; i += LONG_WG) prod[i] = product(k0 + i);
+                __syncthreads();
+                if (tid == 0) {
+                    int i = 0;
+                    for (; i + 4 <= cnt; i += 4) {
+                        const T p0 = prod[i], p1 = prod[i + 1], p2 = prod[i + 2], p3 = prod[i + 3];
+                        sum += p0;
+                        sum += p1;
+                        sum += p2;
+                        sum += p3;
+                    }
+                    for (; i < cnt; ++i) sum += prod[i];
+                }
+                __syncthreads();
+            }
+            if (tid == 0) c[(row0 + part) * ldc] = sum;
         }
     }
-    // the long rows: chunk `part` of each
+    // ---- the long rows: chunk `part` of each
     for (int q = 0; q < n_long; ++q) {
         const int r = long_rows[q];
         const int64_t a = rp[r], len = rp[r + 1] - rp[r];
@@ -138,22 +150,29 @@ __global__ __launch_bounds__(LONG_WG) void csr_flagged_segments_kernel(
         if (tid == 0) partial[(li * LONG_MAX_PER_SEG + q) * LONG_PARTS + part] = red[0];
         __syncthreads();
     }
-    if (n_long == 0) return;
-    // the workgroup of the segment that finishes last adds the chunk sums in chunk order
-    __threadfence();
-    if (tid == 0) ticket = atomicAdd(tickets + li, 1u);
-    __syncthreads();
-    if (ticket != uint32_t(LONG_PARTS - 1)) return;
-    __threadfence();
-    if (tid < n_long) {
-        const int r = long_rows[tid];
-        const volatile T* p = partial + (li * LONG_MAX_PER_SEG + tid) * LONG_PARTS;
-        T s = p[0];
-        for (int i = 1; i < LONG_PARTS; ++i) s += p[i];
-        const int64_t row = row0 + r;
-        c[row * ldc] = (ADV && beta != T(0)) ? c[row * ldc] * beta + s : s;
-    }
-    if (tid == 0) tickets[li] = 0;      // ready for the next product
+}
+
+// one wave per flagged segment: lane q adds the chunk sums of the segment's q-th long row in chunk order
+template <typename T, typename I, bool ADV>
+__global__ __launch_bounds__(64) void csr_long_rows_fold_kernel(
+    int64_t n_rows, const I* __restrict__ row_ptrs, T* __restrict__ c, int64_t ldc,
+    const T* __restrict__ beta_p, const unsigned long long* __restrict__ list, const T* __restrict__ partial)
+{
+    const int64_t li = blockIdx.x;
+    const int64_t row0 = int64_t(list[1 + li]) * 64;
+    const int lane = threadIdx.x;
+    const int64_t r = row0 + lane;
+    const bool lng = r < n_rows && int64_t(row_ptrs[r + 1]) - int64_t(row_ptrs[r]) > GKOC_CSR_LONG_ROW;
+    // position of this row among the segment's long rows = long rows in front of it
+    const unsigned long long m = __ballot(lng);
+    const int q = __popcll(m & ((1ull << lane) - 1ull));
+    if (!lng || q >= LONG_MAX_PER_SEG) return;
+    const T* p = partial + (li * LONG_MAX_PER_SEG + q) * LONG_PARTS;
+    T s = p[0];
+    for (int i = 1; i < LONG_PARTS; ++i) s += p[i];
+    T beta = T(0);
+    if (ADV) beta = beta_p[0];
+    c[r * ldc] = (ADV && beta != T(0)) ? c[r * ldc] * beta + s : s;
 }
 
 #endif  // __HIPCC__
@@ -163,8 +182,8 @@ struct csr_long_info {
     int64_t count = 0;                   // flagged segments (0: none - the common case)
     uint32_t* bits = nullptr;            // device: one bit per segment
     unsigned long long* list = nullptr;  // device: [count, segment indices ...]
-    void* partial = nullptr;             // device: chunk sums
-    uint32_t* tickets = nullptr;         // device: one per flagged segment, zero between launches
+    int64_t nnz = -1;                    // row_ptrs[n_rows] when the matrix was looked at (-1: unknown)
+    uint64_t seq = 0;                    // order of arrival in the launcher's cache (the oldest entry makes room)
 };
 
 }  // namespace gkoc

@@ -38,8 +38,12 @@ namespace {
 
 // ---- which 64-row segments of a matrix hold a row beyond GKOC_CSR_LONG_ROW (csr_long_rows.hpp) --------
 // Found by one scan of the row pointers the first time a (device, row_ptrs, n_rows) is multiplied, kept
-// here; gkoc_free forgets the entries of a pointer that goes away (csr_long_rows_forget).  A few dozen
-// matrices at most: the oldest entry makes room.
+// here (read-only from then on: the chunk sums of a product live in stream-ordered scratch of that launch, so
+// products of one matrix on several streams share nothing that is written); gkoc_free forgets the entries of
+// a pointer that goes away (csr_long_rows_forget).  A few dozen matrices at most: the OLDEST entry makes room,
+// after a device synchronisation (a product on any stream may still read its flags).  The first product of a
+// matrix therefore synchronises its stream once (the scan's answer is needed on the host) - documented in
+// gko_cdna4.h; inside a stream capture the matrix is multiplied by the row-segment kernel alone.
 std::mutex g_long_mtx;
 std::map<std::tuple<int, const void*, int64_t>, csr_long_info> g_long_cache;
 std::atomic<int> g_long_cached{0};
@@ -53,8 +57,6 @@ void long_info_release(csr_long_info& f)
     t_long_releasing = true;
     if (f.bits) (void)gkoc_free(f.bits);
     if (f.list) (void)gkoc_free(f.list);
-    if (f.partial) (void)gkoc_free(f.partial);
-    if (f.tickets) (void)gkoc_free(f.tickets);
     f = csr_long_info{};
     t_long_releasing = false;
 }
@@ -80,11 +82,17 @@ int long_info_of(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, csr_long_in
         return GKOC_OK;
     }
     if (g_long_cache.size() >= long_cache_cap) {
-        GKOC_HIP(hipStreamSynchronize(as_stream(s)));       // (its scratch may be in use by a product in flight)
-        long_info_release(g_long_cache.begin()->second);
-        g_long_cache.erase(g_long_cache.begin());
+        auto oldest = g_long_cache.begin();
+        for (auto jt = g_long_cache.begin(); jt != g_long_cache.end(); ++jt) {
+            if (jt->second.seq < oldest->second.seq) oldest = jt;
+        }
+        if (oldest->second.count > 0) GKOC_HIP(hipDeviceSynchronize());   // (a product in flight may read its flags)
+        long_info_release(oldest->second);
+        g_long_cache.erase(oldest);
     }
     csr_long_info f;
+    static uint64_t arrivals = 0;
+    f.seq = ++arrivals;
     const int64_t n_seg = ceildiv(n_rows, int64_t(64));
     const size_t bit_bytes = size_t(ceildiv(n_seg, int64_t(32))) * 4;
     const size_t list_bytes = size_t(1 + long_list_cap) * 8;
@@ -98,14 +106,18 @@ int long_info_of(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, csr_long_in
     }
     hipStream_t st = as_stream(s);
     unsigned long long count = 0;
+    I nnz_dev = I(0);
     bool ok = hipMemsetAsync(bits, 0, bit_bytes, st) == hipSuccess && hipMemsetAsync(list, 0, 8, st) == hipSuccess;
     if (ok) {
         csr_long_row_scan_kernel<I><<<dim3(unsigned(ceildiv(n_seg, int64_t(4)))), dim3(256), 0, st>>>(
             n_rows, row_ptrs, static_cast<uint32_t*>(bits), static_cast<unsigned long long*>(list), long_list_cap);
+        // (the number of stored entries comes with the same wait: the launcher sizes a wave's share by it)
         ok = hipGetLastError() == hipSuccess &&
              hipMemcpyAsync(&count, list, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipMemcpyAsync(&nnz_dev, row_ptrs + n_rows, sizeof(I), hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipStreamSynchronize(st) == hipSuccess;
     }
+    if (ok) f.nnz = int64_t(nnz_dev);
     if (!ok || count == 0 || int64_t(count) > long_list_cap) {
         // none (the common case), or so many that "a few long rows" is not what this matrix has: the
         // row-segment kernel does everything, as before
@@ -118,20 +130,6 @@ int long_info_of(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, csr_long_in
         f.count = int64_t(count);
         f.bits = static_cast<uint32_t*>(bits);
         f.list = static_cast<unsigned long long*>(list);
-        void *partial = nullptr, *tickets = nullptr;
-        if (gkoc_malloc(&partial, size_t(count) * LONG_MAX_PER_SEG * LONG_PARTS * 8) != GKOC_OK ||
-            gkoc_malloc(&tickets, size_t(count) * 4) != GKOC_OK ||
-            hipMemsetAsync(tickets, 0, size_t(count) * 4, st) != hipSuccess) {
-            (void)hipGetLastError();
-            t_long_releasing = true;
-            if (partial) (void)gkoc_free(partial);
-            if (tickets) (void)gkoc_free(tickets);
-            t_long_releasing = false;
-            long_info_release(f);
-        } else {
-            f.partial = partial;
-            f.tickets = static_cast<uint32_t*>(tickets);
-        }
     }
     g_long_cache[key] = f;
     g_long_cached.store(int(g_long_cache.size()));
@@ -193,7 +191,7 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     const int64_t n_waves = ceildiv(n_seg, segs_per_wave);
     GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED,
                  "more than 2^31 row segments");
-    dim3 grid(static_cast<unsigned>(n_waves)), block(64);
+    dim3 grid(static_cast<unsigned>(n_waves)), block(64);     // (the single-column path re-sizes it below)
     // 32 B of values per lane and load: 4 doubles or 8 floats (ring = 8 KB)
     constexpr int EV = 32 / sizeof(T);
     constexpr int RINGV = 8192 / sizeof(T);
@@ -236,19 +234,20 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     } while (0)
         const int64_t variant = tune_value(GKOC_TUNE_CSR_MULTI_VARIANT);
 #define GKOC_LAUNCH_CSR_FRAG_PIPE(NR_, CPL_, KU_, SEGS_) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(NR_, CPL_, KU_, SEGS_, 1)
-#define GKOC_LAUNCH_CSR_FRAG_PIPE_ST(NR_, CPL_, KU_, SEGS_, ST_)                                 \
+#define GKOC_LAUNCH_CSR_FRAG_PIPE_ST(NR_, CPL_, KU_, SEGS_, ST_) GKOC_LAUNCH_CSR_FRAG_PIPE_NB(NR_, CPL_, KU_, SEGS_, ST_, false)
+#define GKOC_LAUNCH_CSR_FRAG_PIPE_NB(NR_, CPL_, KU_, SEGS_, ST_, NB_)                            \
     do {                                                                                         \
         constexpr int rows_ = 64 * CPL_ / NR_;                                                   \
         const int64_t nwg = ceildiv(ceildiv(n_rows, rows_), SEGS_);                              \
         GKOC_REQUIRE(nwg < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 waves");    \
         const dim3 gf(static_cast<unsigned>(nwg));                                               \
         if (idx32) {                                                                             \
-            csr_spmv_frag_pipe_kernel<T, I, ADV, NR_, CPL_, KU_, true, ST_>                      \
+            csr_spmv_frag_pipe_kernel<T, I, ADV, NR_, CPL_, KU_, true, ST_, NB_>                 \
                 <<<gf, block, 0, as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals, b, ldb, c,    \
                                                  ldc, static_cast<int>(nrhs), alpha, beta,       \
                                                  SEGS_, chunk_rows / (rows_ * SEGS_));           \
         } else {                                                                                 \
-            csr_spmv_frag_pipe_kernel<T, I, ADV, NR_, CPL_, KU_, false, ST_>                     \
+            csr_spmv_frag_pipe_kernel<T, I, ADV, NR_, CPL_, KU_, false, ST_, NB_>                \
                 <<<gf, block, 0, as_stream(s)>>>(n_rows, row_ptrs, col_idxs, vals, b, ldb, c,    \
                                                  ldc, static_cast<int>(nrhs), alpha, beta,       \
                                                  SEGS_, chunk_rows / (rows_ * SEGS_));           \
@@ -261,7 +260,10 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         const int segs = variant >= 10 ? int(variant % 1000 / 10) : 4;
         const bool pipe = variant == 0 || variant >= 10;
         if (pipe && nrhs <= 4) {
-            if (variant / 1000 == 1) GKOC_LAUNCH_CSR_FRAG_PIPE(4, 1, 2, segs);
+            if (variant / 1000 == 5) GKOC_LAUNCH_CSR_FRAG_PIPE_NB(4, 1, 4, segs, 1, true);
+            else if (variant / 1000 == 6) GKOC_LAUNCH_CSR_FRAG_PIPE_NB(4, 1, 3, segs, 1, true);
+            else if (variant / 1000 == 7) GKOC_LAUNCH_CSR_FRAG_PIPE_NB(4, 1, 2, segs, 1, true);
+            else if (variant / 1000 == 1) GKOC_LAUNCH_CSR_FRAG_PIPE(4, 1, 2, segs);
             else if (variant / 1000 == 3) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(4, 1, 3, segs, 3);
             else if (variant / 1000 == 4) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(4, 1, 2, segs, 3);
             else if (variant / 1000 == 2) GKOC_LAUNCH_CSR_FRAG_PIPE(4, 1, 3, segs);
@@ -270,7 +272,10 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
             return GKOC_OK;
         }
         if (pipe && pairs_ok) {
-            if (variant / 1000 == 1) GKOC_LAUNCH_CSR_FRAG_PIPE(8, 2, 2, segs);
+            if (variant / 1000 == 5) GKOC_LAUNCH_CSR_FRAG_PIPE_NB(8, 2, 3, segs, 1, true);
+            else if (variant / 1000 == 6) GKOC_LAUNCH_CSR_FRAG_PIPE_NB(8, 2, 4, segs, 1, true);
+            else if (variant / 1000 == 7) GKOC_LAUNCH_CSR_FRAG_PIPE_NB(8, 2, 2, segs, 1, true);
+            else if (variant / 1000 == 1) GKOC_LAUNCH_CSR_FRAG_PIPE(8, 2, 2, segs);
             else if (variant / 1000 == 3) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(8, 2, 3, segs, 3);
             else if (variant / 1000 == 4) GKOC_LAUNCH_CSR_FRAG_PIPE_ST(8, 2, 2, segs, 3);
             else if (variant / 1000 == 2) GKOC_LAUNCH_CSR_FRAG_PIPE(8, 2, 4, segs);
@@ -301,6 +306,7 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
 #undef GKOC_LAUNCH_CSR_FRAG_T
 #undef GKOC_LAUNCH_CSR_FRAG_PIPE
 #undef GKOC_LAUNCH_CSR_FRAG_PIPE_ST
+#undef GKOC_LAUNCH_CSR_FRAG_PIPE_NB
         GKOC_LAUNCH_OK();
         return GKOC_OK;
     }
@@ -333,10 +339,32 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         GKOC_TRY((long_info_of<T, I>(s, n_rows, row_ptrs, &lng)));
     }
     const uint32_t* seg_skip = lng.count > 0 ? lng.bits : nullptr;
+    // SHORT rows: a wave that owns one or two segments of a matrix with a dozen entries per row has a
+    // few hundred entries to stream - it lives 2-3 us, and the workgroup dispatcher, not the memory,
+    // paces the kernel (GKOC_TUNE_CSR_SEGS_PER_WAVE in gko_cdna4.h).  The wave then walks up to eight
+    // segments (about 3000 entries, what a 128-row wave of the 27-point matrix carries), as long as
+    // the grid stays two rounds of the resident waves deep.
+    int spw = segs_per_wave;
+    const int64_t forced_spw = tune_value(GKOC_TUNE_CSR_SEGS_PER_WAVE);
+    if (forced_spw == 1 || forced_spw == 2 || forced_spw == 4 || forced_spw == 8) {
+        spw = int(forced_spw);
+    } else if (lng.nnz >= 0 && vec_ok) {
+        const int64_t per_seg = lng.nnz / n_seg;
+        if (per_seg < 1200) {
+            int64_t want = per_seg > 0 ? ceildiv(3000, per_seg) : 8;
+            if (want > 8) want = 8;
+            while (want > 1 && ceildiv(n_seg, want) < 10240) --want;
+            const int pow2 = want >= 8 ? 8 : want >= 4 ? 4 : want >= 2 ? 2 : 1;
+            if (pow2 > spw) spw = pow2;
+        }
+    }
+    const int64_t n_waves_1 = ceildiv(n_seg, spw);
+    GKOC_REQUIRE(n_waves_1 < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 row segments");
+    grid = dim3(static_cast<unsigned>(n_waves_1));
 #define GKOC_LAUNCH_PIPE3(E_, U_, MODE_)                                       \
     csr_spmv_pipe3_kernel<T, I, ADV, rows_per_seg, E_, U_, RINGV, 1, MODE_>    \
         <<<grid, block, 0, as_stream(s)>>>(                                    \
-            n_rows, n_seg, segs_per_wave, row_ptrs, col_idxs, vals, b, ldb, c, \
+            n_rows, n_seg, spw, row_ptrs, col_idxs, vals, b, ldb, c,           \
             ldc, static_cast<int>(nrhs), alpha, beta, nullptr, xcd_map,        \
             static_cast<const I*>(nullptr), static_cast<int*>(nullptr),        \
             int64_t(0), int64_t(0), static_cast<const uint32_t*>(nullptr),     \
@@ -346,7 +374,7 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
             seg_skip)
     // XCD-contiguous wave order needs enough waves per XCD to keep the in-order
     // window argument valid; below that the plain order is used
-    const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
+    const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves_1 >= 8 * 1024) ? 1 : 0;
     // Measured and rejected on the Flan-like matrix and on L256 (profiles/r02_experiments,
     // profiles/r02_flan_pmc): 16 / 32 KB rings with 2-4 load groups (fewer resident waves: 299-475 us
     // against 288), 32-row segments (294), one or two entries per lane and load so that neighbouring
@@ -363,19 +391,23 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     if (vec_ok) {
         // below 2 M rows the grid is a few rounds deep and the wider layout of rounds 1-2 is as fast or
         // faster (64^3: 18.4 against 20.7 us; 1 - 2 M rows: equal); key 1 forces it for A/B runs
-        if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_seg < 32768) {
-            if (segs_per_wave == 2) {
+        if (spw == 8) {
+            GKOC_LAUNCH_PIPE3(PE, PU, 0x8000);
+        } else if (spw == 4) {
+            GKOC_LAUNCH_PIPE3(PE, PU, 0x4000);
+        } else if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_seg < 32768) {
+            if (spw == 2) {
                 GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);
             } else {
                 GKOC_LAUNCH_PIPE3(EV, 1, 0x1000);
             }
-        } else if (segs_per_wave == 2) {
+        } else if (spw == 2) {
             GKOC_LAUNCH_PIPE3(PE, PU, 0x2000);
         } else {
             GKOC_LAUNCH_PIPE3(PE, PU, 0x1000);
         }
     } else {
-        if (segs_per_wave == 2) {
+        if (spw == 2) {
             GKOC_LAUNCH_PIPE3(1, 4, 0x2000);
         } else {
             GKOC_LAUNCH_PIPE3(1, 4, 0x1000);
@@ -384,11 +416,19 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
 #undef GKOC_LAUNCH_PIPE3
     GKOC_LAUNCH_OK();
     if (lng.count > 0) {
+        // the chunk sums of THIS launch: stream-ordered scratch, handed back behind the fold
+        void* partial = nullptr;
+        GKOC_TRY(scratch_malloc(as_stream(s), &partial, size_t(lng.count) * LONG_MAX_PER_SEG * LONG_PARTS * sizeof(T)));
         csr_flagged_segments_kernel<T, I, ADV>
             <<<dim3(unsigned(lng.count * LONG_PARTS)), dim3(LONG_WG), 0, as_stream(s)>>>(
-                n_rows, row_ptrs, col_idxs, vals, b, ldb, c, ldc, alpha, beta, lng.list,
-                static_cast<T*>(lng.partial), lng.tickets);
-        GKOC_LAUNCH_OK();
+                n_rows, row_ptrs, col_idxs, vals, b, ldb, c, ldc, alpha, beta, lng.list, static_cast<T*>(partial));
+        const hipError_t e1 = hipGetLastError();
+        csr_long_rows_fold_kernel<T, I, ADV><<<dim3(unsigned(lng.count)), dim3(64), 0, as_stream(s)>>>(
+            n_rows, row_ptrs, c, ldc, beta, lng.list, static_cast<const T*>(partial));
+        const hipError_t e2 = hipGetLastError();
+        GKOC_TRY(scratch_free(as_stream(s), partial));
+        GKOC_HIP(e1);
+        GKOC_HIP(e2);
     }
     return GKOC_OK;
 }

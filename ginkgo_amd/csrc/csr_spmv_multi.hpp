@@ -275,7 +275,19 @@ __global__ __launch_bounds__(64) void csr_spmv_frag_kernel(
 // Same LDS footprint per wave (one 6 KB buffer), same sums: every (row, column) sum by ONE lane in entry
 // order, separate multiply and add - bit-identical to the kernel above and to the reference.  A segment
 // with more than CAP entries takes the rounds of the kernel above (not pipelined).
-template <typename T, typename I, bool ADV, int NR, int CPL, int KU, bool IDX32, int ST = 1>
+//
+// NB (round 6): a value of b that the row BELOW has just gathered is taken from that row's lanes instead of
+// the memory system.  In a banded / stencil matrix entry k of row r and entry k - 1 of row r + 1 are the same
+// column (r + 1 + dx - 1 = r + dx): the 16 rows of a wave ask for the same 15 rows of b again with every step
+// through a run of neighbouring columns, and the in-order vector L1 stalls on every one of those hits while
+// the line is still on its way (TCP_PENDING_STALL_CYCLES 44 %, 0.59 line accesses per cycle and CU where the
+// single-column kernel sustains 0.99: profiles/r05_multi_rhs_pmc.txt).  The test is on the column INDICES
+// (both in LDS), so it holds for any matrix: entry k of my row is taken from the lanes of the next row iff
+// that row's entry k - 1 has the same column; everybody else gathers.  A lane that takes the neighbour's value
+// still issues its load - branch-free, the compiler keeps all loads of a round in flight - but from row 0 of
+// b, one line for all of them: a gather instruction touches 2 lines instead of 8.  The values are the same
+// numbers whichever way they come: the sums keep the reference's bits.
+template <typename T, typename I, bool ADV, int NR, int CPL, int KU, bool IDX32, int ST = 1, bool NB = false>
 __global__ __launch_bounds__(64) void csr_spmv_frag_pipe_kernel(
     int64_t n_rows, const I* __restrict__ row_ptrs, const I* __restrict__ cols,
     const T* __restrict__ vals, const T* __restrict__ b, int64_t ldb, T* __restrict__ c,
@@ -354,6 +366,10 @@ __global__ __launch_bounds__(64) void csr_spmv_frag_pipe_kernel(
             const int o = __shfl_xor(maxlen, off, 64);
             maxlen = o > maxlen ? o : maxlen;
         }
+        // NB: the lanes of the row below (same columns), where that row starts in the LDS and how long it is
+        const int nb_lane = lane + LPR < 64 ? lane + LPR : lane;
+        const int nb_rs = __shfl(rs, nb_lane, 64);
+        const int nb_len = (lane + LPR < 64) ? __shfl(len, nb_lane, 64) : 0;
         // the next segment: its pointers are here (requested one segment ago), its entries start to travel
         // now; the pointers of the one after are requested
         int64_t nK0 = 0, nK1 = 0;
@@ -377,11 +393,15 @@ __global__ __launch_bounds__(64) void csr_spmv_frag_pipe_kernel(
                 if (ADV && beta != T(0) && row < last && q < ncol) sum[q] = c[row * ldc + jc + q] * beta;
             }
             // entries [kb, kend) of the lane's row, entry k at LDS slot base + k; two rounds of KU gathers in flight
-            auto walk = [&](int kb, int kend, int klimit, int base) {
+            auto walk = [&](int kb, int kend, int klimit, int base, bool nb_on) {
                 BV x0[KU], x1[KU];
                 T v0[KU], v1[KU];
                 bool ok0[KU], ok1[KU];
-                auto request = [&](int k, BV(&x)[KU], T(&vv)[KU], bool(&ok)[KU]) {
+                bool nb0[KU], nb1[KU];       // NB: entry comes from the lanes of the row below
+                BV xlast;                    // NB: this lane's value of the entry in front of the round being added
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) xlast.v[q] = T(0);
+                auto request = [&](int k, BV(&x)[KU], T(&vv)[KU], bool(&ok)[KU], bool(&nb)[KU]) {
 #pragma unroll
                     for (int u = 0; u < KU; ++u) {
                         ok[u] = k + u < len && k + u < klimit;
@@ -389,17 +409,35 @@ __global__ __launch_bounds__(64) void csr_spmv_frag_pipe_kernel(
                         const I cc = lc[at];
                         vv[u] = lv[at];
                         const I ce = ok[u] ? cc : I(0);
+                        nb[u] = false;
+                        if constexpr (NB) {
+                            // the row below, one entry back: the same column?  (k + u - 1 >= kb: that entry
+                            // belongs to this walk, so its value is or will be in that row's registers)
+                            const bool can = nb_on && ok[u] && k + u - 1 >= kb && k + u - 1 < nb_len;
+                            const I nc = lc[can ? nb_rs + k + u - 1 : 0];
+                            nb[u] = can && nc == cc;
+                        }
                         if (IDX32) {
-                            const uint32_t off = uint32_t(ce) * uint32_t(ldb) + uint32_t(jl);
+                            const uint32_t off = nb[u] ? uint32_t(jl) : uint32_t(ce) * uint32_t(ldb) + uint32_t(jl);
                             x[u] = *reinterpret_cast<const BV*>(b + off);
                         } else {
-                            x[u] = *reinterpret_cast<const BV*>(b + int64_t(ce) * ldb + jl);
+                            x[u] = *reinterpret_cast<const BV*>(b + (nb[u] ? int64_t(jl) : int64_t(ce) * ldb + jl));
                         }
                     }
                 };
-                auto add = [&](const BV(&x)[KU], const T(&vv)[KU], const bool(&ok)[KU]) {
+                auto add = [&](BV(&x)[KU], const T(&vv)[KU], const bool(&ok)[KU], const bool(&nb)[KU]) {
 #pragma unroll
                     for (int u = 0; u < KU; ++u) {
+                        if constexpr (NB) {
+                            // in entry order: the row below has settled its entry k + u - 1 in the step before
+                            // (u - 1 of this round, or the last one of the round before)
+#pragma unroll
+                            for (int q = 0; q < CPL; ++q) {
+                                const T mine = u == 0 ? xlast.v[q] : x[u - 1].v[q];
+                                const T theirs = __shfl(mine, nb_lane, 64);
+                                x[u].v[q] = nb[u] ? theirs : x[u].v[q];
+                            }
+                        }
                         const T av = ADV ? alpha * vv[u] : vv[u];
 #pragma unroll
                         for (int q = 0; q < CPL; ++q) {
@@ -407,6 +445,7 @@ __global__ __launch_bounds__(64) void csr_spmv_frag_pipe_kernel(
                             sum[q] = ok[u] ? nx : sum[q];
                         }
                     }
+                    if constexpr (NB) xlast = x[KU - 1];
                 };
                 if (kb >= kend) return;
                 if constexpr (ST > 1) {
@@ -456,21 +495,21 @@ __global__ __launch_bounds__(64) void csr_spmv_frag_pipe_kernel(
                     }
                     return;
                 }
-                request(kb, x0, v0, ok0);
+                request(kb, x0, v0, ok0, nb0);
                 int k = kb;
                 while (true) {
-                    if (k + KU < kend) request(k + KU, x1, v1, ok1);
-                    add(x0, v0, ok0);
+                    if (k + KU < kend) request(k + KU, x1, v1, ok1, nb1);
+                    add(x0, v0, ok0, nb0);
                     k += KU;
                     if (k >= kend) break;
-                    if (k + KU < kend) request(k + KU, x0, v0, ok0);
-                    add(x1, v1, ok1);
+                    if (k + KU < kend) request(k + KU, x0, v0, ok0, nb0);
+                    add(x1, v1, ok1, nb1);
                     k += KU;
                     if (k >= kend) break;
                 }
             };
             if (whole) {
-                if (count > 0) walk(0, maxlen, maxlen, rs);
+                if (count > 0) walk(0, maxlen, maxlen, rs, true);
             } else {
                 for (int c0 = 0; c0 < maxlen; c0 += 32) {
                     wave_lds_sync();
@@ -486,7 +525,7 @@ __global__ __launch_bounds__(64) void csr_spmv_frag_pipe_kernel(
                     }
                     wave_lds_sync();
                     const int ke = c0 + 32 < maxlen ? c0 + 32 : maxlen;
-                    walk(c0, ke, c0 + 32, 32 * rl - c0);
+                    walk(c0, ke, c0 + 32, 32 * rl - c0, false);
                 }
             }
             if (row < last && ncol > 0) {

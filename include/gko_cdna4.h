@@ -198,6 +198,14 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                       each (csrc/csr_long_rows.hpp) instead of by one wave; 0: one wave, as before.
                                       Two products with the SAME matrix must not run at the same time on two streams
                                       when it has such rows (they share the chunk sums' scratch) */
+#define GKOC_TUNE_CSR_SEGS_PER_WAVE 13 /* csr::spmv, one right-hand side: 64-row segments a wave walks.  0 (default): two
+                                      from 4 M rows on, one below - and, for matrices whose 64-row segments hold fewer
+                                      than 1200 entries (known from the first product's look at the row pointers),
+                                      up to eight, so that a wave carries about 3000 entries: with a dozen entries
+                                      per row a one-segment wave lives 2.8 us and the workgroup dispatcher (one
+                                      workgroup per ~29 ns and XCD) keeps 3 waves per CU resident - the product of
+                                      the heavy-tailed stand-in ran at 37 % of the rate its bytes allow
+                                      (profiles/r06_irregular_pmc.txt).  1, 2, 4, 8: that many */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,

@@ -438,3 +438,161 @@ def test_arena_c_abi(gexec):
     for q, _ in ptrs:
         _lib.call("gkoc_free", C.c_void_p(q))
     assert L.gkoc_malloc_role(C.byref(p), C.c_size_t(10), C.c_int(7)) != 0      # unknown role
+
+
+def _tune(key, value):
+    import ctypes as C
+    from ginkgo_amd import _lib
+    _lib.call("gkoc_tune_set", C.c_int(key), C.c_int64(value))
+
+
+def _short_rows_with_hubs(rng, n, ncols, hubs):
+    """a dozen entries per row at most, a few rows of thousands (sorted columns)"""
+    lens = rng.integers(0, 14, n)
+    for r, l in hubs:
+        lens[r] = l
+    rp = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(ncols, l, replace=False)) for l in lens]).astype(np.int32)
+    return lens, rp, ci, rng.uniform(-1, 1, rp[-1])
+
+
+@pytest.mark.parametrize("spw", [0, 1, 2, 4, 8])
+def test_csr_short_rows_several_segments_per_wave(gexec, oracle, spw):
+    """round 6: matrices with short rows give a wave up to eight 64-row segments (GKOC_TUNE_CSR_SEGS_PER_WAVE,
+    0 = the launcher's rule).  Segments with a row beyond GKOC_CSR_LONG_ROW are left to the flagged-segments
+    kernel - here they sit at the start, in the middle and at the end of an eight-segment wave, and two of them
+    are neighbours - and the ordinary rows next to a hub (170 and 3000 entries among them) keep the reference's
+    bits through the products-in-LDS path.  c = A b and c = alpha A b + beta c."""
+    import ginkgo_amd as g
+    rng = np.random.default_rng(100 + spw)
+    n, ncols = 64 * 37 + 11, 20000
+    hubs = [(5, 9000), (64 * 3 + 1, 5000), (64 * 3 + 2, 170), (64 * 4 + 9, 4500), (64 * 4 + 10, 3000),
+            (64 * 7 + 63, 6000), (64 * 20, 4097), (64 * 20 + 1, 4096), (n - 1, 7000)]
+    lens, rp, ci, v = _short_rows_with_hubs(rng, n, ncols, hubs)
+    b = rng.uniform(-1, 1, ncols)
+    c0 = rng.uniform(-1, 1, n)
+    ref = oracle.csr_spmv(rp, ci, v, b)
+    ref_adv = np.ravel(oracle.csr_spmv(rp, ci, v, b, alpha=-0.75, beta=1.5, c=c0))
+    short = lens <= 4096
+    scale = np.abs(sp_csr(rp, ci, v, (n, ncols))) @ np.abs(b)
+    _tune(13, spw)
+    try:
+        a = dev_csr(g, gexec, rp, ci, v, (n, ncols))
+        y = g.Dense.create(gexec, (n, 1))
+        for _ in range(2):                      # (the second product finds the matrix in the launcher's cache)
+            a.apply(g.Dense.from_numpy(gexec, b), y.fill(7.0))
+            got = y.to_numpy()[:, 0]
+            assert np.array_equal(got[short], ref[short])
+            assert np.all(np.abs(got[~short] - ref[~short]) <= 1e-15 * scale[~short] * np.sqrt(lens[~short]))
+        ya = g.Dense.from_numpy(gexec, c0.copy())
+        a.apply(g.scalar(gexec, -0.75), g.Dense.from_numpy(gexec, b), g.scalar(gexec, 1.5), ya)
+        ga = ya.to_numpy()[:, 0]
+        assert np.array_equal(ga[short], ref_adv[short])
+        assert np.all(np.abs(ga[~short] - ref_adv[~short]) <=
+                      2e-15 * (scale[~short] + np.abs(c0[~short])) * np.sqrt(lens[~short]))
+    finally:
+        _tune(13, 0)
+
+
+def sp_csr(rp, ci, v, shape):
+    import scipy.sparse as sp
+    return sp.csr_matrix((v, ci, rp), shape=shape)
+
+
+def test_csr_short_rows_large_takes_the_rule(gexec, oracle):
+    """large enough for the launcher's own rule to hand out several segments per wave (n = 1.5 M rows of 0 .. 13
+    entries: 64-row segments of ~400 entries): bit-identical to the oracle"""
+    import ginkgo_amd as g
+    rng = np.random.default_rng(5)
+    n = 1500000
+    lens = rng.integers(0, 14, n)
+    rp = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    # banded: columns near the diagonal (cheap to generate, sorted by construction)
+    ci = (np.repeat(np.arange(n), lens) + np.concatenate([np.arange(l) for l in lens]) * 3) % n
+    order = np.lexsort((ci, np.repeat(np.arange(n), lens)))
+    ci = ci[order].astype(np.int32)
+    v = rng.uniform(-1, 1, rp[-1])
+    b = rng.uniform(-1, 1, n)
+    a = dev_csr(g, gexec, rp, ci, v, (n, n))
+    y = g.Dense.create(gexec, (n, 1))
+    a.apply(g.Dense.from_numpy(gexec, b), y)
+    assert np.array_equal(y.to_numpy()[:, 0], oracle.csr_spmv(rp, ci, v, b))
+
+
+def test_csr_long_rows_two_streams_at_once(gexec, oracle):
+    """two products of ONE matrix with hub rows in flight on two streams share nothing that is
+    written (the chunk sums are stream-ordered scratch of each launch): both results are right, many times over"""
+    import ginkgo_amd as g
+    rng = np.random.default_rng(77)
+    n, ncols = 64 * 50, 60000
+    hubs = [(64 * k + 3, 30000 + 1000 * k) for k in range(0, 50, 5)]
+    lens, rp, ci, v = _short_rows_with_hubs(rng, n, ncols, hubs)
+    a = dev_csr(g, gexec, rp, ci, v, (n, ncols))
+    b1, b2 = rng.uniform(-1, 1, ncols), rng.uniform(-1, 1, ncols)
+    d1, d2 = g.Dense.from_numpy(gexec, b1), g.Dense.from_numpy(gexec, b2)
+    y1, y2 = g.Dense.create(gexec, (n, 1)), g.Dense.create(gexec, (n, 1))
+    a.apply(d1, y1)
+    a.apply(d2, y2)
+    torch.cuda.synchronize()
+    w1, w2 = y1.values.clone(), y2.values.clone()         # one at a time: the answers
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(50):
+        y1.fill(0.0)
+        y2.fill(0.0)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            for _ in range(4):
+                a.apply(d1, y1)
+        with torch.cuda.stream(s2):
+            for _ in range(4):
+                a.apply(d2, y2)
+        torch.cuda.synchronize()
+        assert torch.equal(y1.values, w1) and torch.equal(y2.values, w2)
+    short = lens <= 4096
+    assert np.array_equal(w1.cpu().numpy()[short, 0], oracle.csr_spmv(rp, ci, v, b1)[short])
+
+
+@pytest.mark.parametrize("variant", [5040, 6040, 7040, 5020])
+@pytest.mark.parametrize("nrhs", [3, 4, 8])
+def test_csr_multi_rhs_neighbour_reuse_variants(gexec, oracle, variant, nrhs):
+    """round 6 (csr_spmv_frag_pipe_kernel NB): a value of b the row below has just gathered is taken from that
+    row's lanes - decided on the column indices, so any matrix may come: a banded one (where it applies almost
+    everywhere), a random one (almost nowhere), rows of different lengths, empty rows, one past the staging
+    capacity; every column bit-identical to the sequential reference"""
+    import ginkgo_amd as g
+    rng = np.random.default_rng(variant + nrhs)
+    n = 16 * 40 + 5
+    cases = []
+    # banded: row r holds columns r + d for a handful of d (clipped): neighbours share all but one column
+    offs = np.array([-40, -39, -38, -1, 0, 1, 38, 39, 40, 200])
+    rows, cols = [], []
+    for r in range(n):
+        c = r + offs
+        c = c[(c >= 0) & (c < n)]
+        if r % 17 == 3:
+            c = c[:0]                              # an empty row
+        if r % 11 == 5:
+            c = c[::2]                             # a row with holes
+        rows.append(np.full(len(c), r))
+        cols.append(c)
+    lens = np.array([len(c) for c in cols])
+    cases.append((lens, np.concatenate(cols)))
+    lens2 = np.concatenate(([0, 600, 3], rng.integers(0, 40, n - 5), [0, 2]))
+    cases.append((lens2, np.concatenate([np.sort(rng.choice(n, l, replace=False)) for l in lens2])))
+    _tune(11, variant)
+    try:
+        for lens, ci in cases:
+            rp = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+            ci = ci.astype(np.int32)
+            v = rng.uniform(-1, 1, len(ci))
+            b = rng.uniform(-1, 1, (n, nrhs))
+            c0 = rng.uniform(-1, 1, (len(lens), nrhs))
+            a = dev_csr(g, gexec, rp, ci, v, (len(lens), n))
+            dc = g.Dense.create(gexec, (len(lens), nrhs))
+            a.apply(g.Dense.from_numpy(gexec, b), dc)
+            assert np.array_equal(dc.to_numpy(), oracle.csr_spmv(rp, ci, v, b))
+            dc = g.Dense.from_numpy(gexec, c0)
+            a.apply(g.scalar(gexec, -0.5), g.Dense.from_numpy(gexec, b), g.scalar(gexec, 1.5), dc)
+            assert np.array_equal(dc.to_numpy(), oracle.csr_spmv(rp, ci, v, b, alpha=-0.5, beta=1.5, c=c0))
+    finally:
+        _tune(11, 0)
