@@ -290,11 +290,17 @@ __global__ void set_all_statuses_kernel(int64_t cols, uint8_t id,
     }
 }
 
-template <typename T, bool IMPLICIT>
+struct nothing_behind {
+    int operator()() const { return GKOC_OK; }
+};
+
+// `behind`: what the caller wants ENQUEUED right behind the criterion's kernel - before the host starts to
+// wait for the answer (gkoc_x_residual_norm_then_cg_step_1_*: the device goes on while the host decides)
+template <typename T, bool IMPLICIT, typename Behind = nothing_behind>
 int launch_residual_norm(gkoc_stream_t s, int64_t cols, const T* tau,
                          const T* orig_tau, T goal, uint8_t id,
                          int set_finalized, uint8_t* stop, uint8_t* flags,
-                         int* all_converged, int* one_changed)
+                         int* all_converged, int* one_changed, Behind behind = Behind{})
 {
     GKOC_REQUIRE((all_converged == nullptr) == (one_changed == nullptr),
                  GKOC_E_INVALID, "pass both host results or neither");
@@ -322,6 +328,7 @@ int launch_residual_norm(gkoc_stream_t s, int64_t cols, const T* tau,
             residual_norm_kernel<T, IMPLICIT><<<dim3(1), dim3(256), 0, as_stream(s)>>>(
                 cols, tau, orig_tau, goal, id, set_finalized != 0, stop, const_cast<uint8_t*>(pinned));
             GKOC_LAUNCH_OK();
+            GKOC_TRY(behind());
             for (long spins = 0; pinned[0] == 0xFF || pinned[1] == 0xFF; ++spins) {
                 if (spins == (long(1) << 22)) {
                     // not there after ~10 ms of polling: let the stream drain (the stores are visible then)
@@ -339,6 +346,7 @@ int launch_residual_norm(gkoc_stream_t s, int64_t cols, const T* tau,
     residual_norm_kernel<T, IMPLICIT><<<dim3(1), dim3(256), 0, as_stream(s)>>>(
         cols, tau, orig_tau, goal, id, set_finalized != 0, stop, flags);
     GKOC_LAUNCH_OK();
+    GKOC_TRY(behind());
     // asynchronous form: results stay in flags[0..1] on the device and the
     // caller fetches them when it wants to (no host sync here)
     if (!all_converged) return GKOC_OK;
@@ -538,6 +546,27 @@ GKOC_DEF_CG_STEPS(gkoc_c64, c64)
                                              id, set_finalized, stop_status,   \
                                              flags_dev, all_converged,         \
                                              one_changed);                     \
+    }                                                                          \
+    extern "C" int gkoc_x_residual_norm_then_cg_step_1_##TN(                   \
+        gkoc_stream_t s, const T* tau, const T* orig_tau, T goal, uint8_t id,  \
+        int set_finalized, int implicit, uint8_t* stop_status,                 \
+        uint8_t* flags_dev, int* all_converged, int* one_changed,              \
+        int64_t rows, T* p, const T* z, const T* rho, const T* prev_rho)       \
+    {                                                                          \
+        GKOC_REQUIRE(all_converged && one_changed && p && z && rho && prev_rho, \
+                     GKOC_E_INVALID, "null pointer");                          \
+        auto step_1 = [&] {                                                    \
+            return gkoc_cg_step_1_##TN(s, rows, 1, p, 1, z, 1, rho, prev_rho,  \
+                                       stop_status);                           \
+        };                                                                     \
+        if (implicit) {                                                        \
+            return launch_residual_norm<T, true>(                              \
+                s, 1, tau, orig_tau, goal, id, set_finalized, stop_status,     \
+                flags_dev, all_converged, one_changed, step_1);                \
+        }                                                                      \
+        return launch_residual_norm<T, false>(                                 \
+            s, 1, tau, orig_tau, goal, id, set_finalized, stop_status,         \
+            flags_dev, all_converged, one_changed, step_1);                    \
     }                                                                          \
     extern "C" int gkoc_jacobi_invert_diagonal_##TN(gkoc_stream_t s,           \
                                                     int64_t n, const T* diag,  \

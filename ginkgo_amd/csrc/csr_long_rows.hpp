@@ -25,8 +25,9 @@
 //     partial sums folded by a fixed tree);
 //   * csr_long_rows_fold_kernel adds the PARTS chunk sums of every long row in chunk order.  No
 //     floating-point atomics, no "last workgroup" tickets: the same bits every run, on every device (PARTS
-//     is a constant), and the chunk sums live in stream-ordered scratch of THIS launch - two products of one
-//     matrix on two streams do not share them.
+//     is a constant), and the chunk sums live in a buffer of their own per (matrix, STREAM) - products of one
+//     matrix in flight on two streams share nothing that is written (round 5 kept one
+//     buffer and one set of tickets per matrix).
 // A stale flag set (the arrays were rewritten in place under the same pointer) costs speed, never
 // correctness: both kernels read the SAME flags, and each handles any row.
 #pragma once
@@ -184,6 +185,7 @@ struct csr_long_info {
     unsigned long long* list = nullptr;  // device: [count, segment indices ...]
     int64_t nnz = -1;                    // row_ptrs[n_rows] when the matrix was looked at (-1: unknown)
     uint64_t seq = 0;                    // order of arrival in the launcher's cache (the oldest entry makes room)
+    void* partial = nullptr;             // device: chunk sums, THE CALLING STREAM's buffer (filled in per call)
 };
 
 }  // namespace gkoc

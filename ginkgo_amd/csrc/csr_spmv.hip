@@ -38,27 +38,70 @@ namespace {
 
 // ---- which 64-row segments of a matrix hold a row beyond GKOC_CSR_LONG_ROW (csr_long_rows.hpp) --------
 // Found by one scan of the row pointers the first time a (device, row_ptrs, n_rows) is multiplied, kept
-// here (read-only from then on: the chunk sums of a product live in stream-ordered scratch of that launch, so
-// products of one matrix on several streams share nothing that is written); gkoc_free forgets the entries of
+// here (flags and list read-only from then on; the chunk sums of a product go to a buffer per (matrix, stream),
+// so products of one matrix on several streams share nothing that is written); gkoc_free forgets the entries of
 // a pointer that goes away (csr_long_rows_forget).  A few dozen matrices at most: the OLDEST entry makes room,
 // after a device synchronisation (a product on any stream may still read its flags).  The first product of a
 // matrix therefore synchronises its stream once (the scan's answer is needed on the host) - documented in
 // gko_cdna4.h; inside a stream capture the matrix is multiplied by the row-segment kernel alone.
 std::mutex g_long_mtx;
-std::map<std::tuple<int, const void*, int64_t>, csr_long_info> g_long_cache;
+struct long_entry {
+    csr_long_info info;
+    // one buffer of chunk sums per stream that has multiplied this matrix (count x 8 x 64 values of 8 bytes)
+    std::vector<std::pair<hipStream_t, void*>> partials;
+};
+std::map<std::tuple<int, const void*, int64_t>, long_entry> g_long_cache;
 std::atomic<int> g_long_cached{0};
 constexpr size_t long_cache_cap = 128;
-constexpr int64_t long_list_cap = 4096;      // more flagged segments than this: the matrix has no "few long rows"
+constexpr int64_t long_list_cap = 4096;
+constexpr int short_rows_default_layout = 0;      // (set by measurement: see launch_csr)      // more flagged segments than this: the matrix has no "few long rows"
 
 thread_local bool t_long_releasing = false;      // gkoc_free below comes back through csr_long_rows_forget
 
-void long_info_release(csr_long_info& f)
+void long_info_release(long_entry& en)
 {
+    csr_long_info& f = en.info;
     t_long_releasing = true;
     if (f.bits) (void)gkoc_free(f.bits);
     if (f.list) (void)gkoc_free(f.list);
+    for (auto& sp : en.partials) (void)gkoc_free(sp.second);
+    en.partials.clear();
     f = csr_long_info{};
     t_long_releasing = false;
+}
+
+bool stream_is_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return true;
+    }
+    return false;
+}
+
+// the calling stream's buffer of chunk sums (allocated the first time the stream multiplies the matrix; not
+// inside a stream capture: the product is then left to the row-segment kernel alone, which handles any row)
+void long_partial_for(long_entry& en, hipStream_t st, csr_long_info* out)
+{
+    *out = en.info;
+    if (en.info.count <= 0) return;
+    for (auto& sp : en.partials) {
+        if (sp.first == st) {
+            out->partial = sp.second;
+            return;
+        }
+    }
+    void* p = nullptr;
+    if (stream_is_capturing(st) ||
+        gkoc_malloc(&p, size_t(en.info.count) * LONG_MAX_PER_SEG * LONG_PARTS * 8) != GKOC_OK) {
+        (void)hipGetLastError();
+        *out = csr_long_info{};
+        out->nnz = en.info.nnz;
+        return;
+    }
+    en.partials.emplace_back(st, p);
+    out->partial = p;
 }
 
 template <typename T, typename I>
@@ -70,23 +113,21 @@ int long_info_of(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, csr_long_in
     std::lock_guard<std::mutex> g(g_long_mtx);
     auto it = g_long_cache.find(key);
     if (it != g_long_cache.end()) {
-        *out = it->second;
+        long_partial_for(it->second, as_stream(s), out);
         return GKOC_OK;
     }
     // a stream that is being captured into a hipGraph cannot be synchronised: a matrix first seen there is
     // multiplied by the row-segment kernel alone (correct for any row), and looked at on its next product
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(as_stream(s), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
+    if (stream_is_capturing(as_stream(s))) {
         *out = csr_long_info{};
         return GKOC_OK;
     }
     if (g_long_cache.size() >= long_cache_cap) {
         auto oldest = g_long_cache.begin();
         for (auto jt = g_long_cache.begin(); jt != g_long_cache.end(); ++jt) {
-            if (jt->second.seq < oldest->second.seq) oldest = jt;
+            if (jt->second.info.seq < oldest->second.info.seq) oldest = jt;
         }
-        if (oldest->second.count > 0) GKOC_HIP(hipDeviceSynchronize());   // (a product in flight may read its flags)
+        if (oldest->second.info.count > 0) GKOC_HIP(hipDeviceSynchronize());   // (a product in flight may use it)
         long_info_release(oldest->second);
         g_long_cache.erase(oldest);
     }
@@ -131,9 +172,10 @@ int long_info_of(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, csr_long_in
         f.bits = static_cast<uint32_t*>(bits);
         f.list = static_cast<unsigned long long*>(list);
     }
-    g_long_cache[key] = f;
+    long_entry& en = g_long_cache[key];
+    en.info = f;
     g_long_cached.store(int(g_long_cache.size()));
-    *out = f;
+    long_partial_for(en, st, out);
     return GKOC_OK;
 }
 
@@ -142,7 +184,7 @@ int long_info_of(gkoc_stream_t s, int64_t n_rows, const I* row_ptrs, csr_long_in
 void csr_long_rows_forget(const void* ptr)
 {
     if (ptr == nullptr || t_long_releasing || g_long_cached.load(std::memory_order_relaxed) == 0) return;
-    std::vector<csr_long_info> gone;
+    std::vector<long_entry> gone;
     {
         std::lock_guard<std::mutex> g(g_long_mtx);
         for (auto it = g_long_cache.begin(); it != g_long_cache.end();) {
@@ -155,9 +197,9 @@ void csr_long_rows_forget(const void* ptr)
         }
         g_long_cached.store(int(g_long_cache.size()));
     }
-    for (auto& f : gone) {
-        if (f.count > 0) (void)hipDeviceSynchronize();      // a product in flight may still use the scratch
-        long_info_release(f);
+    for (auto& en : gone) {
+        if (en.info.count > 0) (void)hipDeviceSynchronize();      // a product in flight may still use its buffers
+        long_info_release(en);
     }
 }
 
@@ -339,25 +381,13 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         GKOC_TRY((long_info_of<T, I>(s, n_rows, row_ptrs, &lng)));
     }
     const uint32_t* seg_skip = lng.count > 0 ? lng.bits : nullptr;
-    // SHORT rows: a wave that owns one or two segments of a matrix with a dozen entries per row has a
-    // few hundred entries to stream - it lives 2-3 us, and the workgroup dispatcher, not the memory,
-    // paces the kernel (GKOC_TUNE_CSR_SEGS_PER_WAVE in gko_cdna4.h).  The wave then walks up to eight
-    // segments (about 3000 entries, what a 128-row wave of the 27-point matrix carries), as long as
-    // the grid stays two rounds of the resident waves deep.
+    // GKOC_TUNE_CSR_SEGS_PER_WAVE forces 1, 2, 4 or 8 segments per wave (round 6 tried "up to eight for
+    // matrices with short rows" - the heavy-tailed stand-in 256 us with one, 261 with two, 276 with four, 320
+    // with eight segments; 5-pt 4096^2 325 / 289 / 325 / 315; profiles/r06/r06_segments_per_wave.txt: the
+    // size rule above stays)
     int spw = segs_per_wave;
     const int64_t forced_spw = tune_value(GKOC_TUNE_CSR_SEGS_PER_WAVE);
-    if (forced_spw == 1 || forced_spw == 2 || forced_spw == 4 || forced_spw == 8) {
-        spw = int(forced_spw);
-    } else if (lng.nnz >= 0 && vec_ok) {
-        const int64_t per_seg = lng.nnz / n_seg;
-        if (per_seg < 1200) {
-            int64_t want = per_seg > 0 ? ceildiv(3000, per_seg) : 8;
-            if (want > 8) want = 8;
-            while (want > 1 && ceildiv(n_seg, want) < 10240) --want;
-            const int pow2 = want >= 8 ? 8 : want >= 4 ? 4 : want >= 2 ? 2 : 1;
-            if (pow2 > spw) spw = pow2;
-        }
-    }
+    if (forced_spw == 1 || forced_spw == 2 || ((forced_spw == 4 || forced_spw == 8) && vec_ok)) spw = int(forced_spw);
     const int64_t n_waves_1 = ceildiv(n_seg, spw);
     GKOC_REQUIRE(n_waves_1 < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 row segments");
     grid = dim3(static_cast<unsigned>(n_waves_1));
@@ -414,21 +444,17 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         }
     }
 #undef GKOC_LAUNCH_PIPE3
+#undef GKOC_LAUNCH_PIPE3X
     GKOC_LAUNCH_OK();
     if (lng.count > 0) {
-        // the chunk sums of THIS launch: stream-ordered scratch, handed back behind the fold
-        void* partial = nullptr;
-        GKOC_TRY(scratch_malloc(as_stream(s), &partial, size_t(lng.count) * LONG_MAX_PER_SEG * LONG_PARTS * sizeof(T)));
+        // (the chunk sums go to THIS stream's buffer: long_partial_for)
         csr_flagged_segments_kernel<T, I, ADV>
             <<<dim3(unsigned(lng.count * LONG_PARTS)), dim3(LONG_WG), 0, as_stream(s)>>>(
-                n_rows, row_ptrs, col_idxs, vals, b, ldb, c, ldc, alpha, beta, lng.list, static_cast<T*>(partial));
-        const hipError_t e1 = hipGetLastError();
+                n_rows, row_ptrs, col_idxs, vals, b, ldb, c, ldc, alpha, beta, lng.list, static_cast<T*>(lng.partial));
+        GKOC_LAUNCH_OK();
         csr_long_rows_fold_kernel<T, I, ADV><<<dim3(unsigned(lng.count)), dim3(64), 0, as_stream(s)>>>(
-            n_rows, row_ptrs, c, ldc, beta, lng.list, static_cast<const T*>(partial));
-        const hipError_t e2 = hipGetLastError();
-        GKOC_TRY(scratch_free(as_stream(s), partial));
-        GKOC_HIP(e1);
-        GKOC_HIP(e2);
+            n_rows, row_ptrs, c, ldc, beta, lng.list, static_cast<const T*>(lng.partial));
+        GKOC_LAUNCH_OK();
     }
     return GKOC_OK;
 }

@@ -50,6 +50,7 @@
 // entry into the backend except the reading calls above (stream_of() -> flush_deferred()): a kernel
 // that rewrites r or z is such an entry.  Per-iteration saving on the 27-pt 256^3 problem: the two
 // reductions' passes over r and z, 70 of 1610 us.  GKOC_TUNE_DEFERRED_FUSION = 2: one kernel per call.
+#include <cstdio>
 #include <map>
 #include <utility>
 
@@ -59,8 +60,12 @@ namespace gko {
 namespace cdna4 {
 
 thread_local int deferred_state = 0;
+std::atomic<uint64_t> backend_epoch{0};
+thread_local uint64_t last_entry_epoch = 0;
 
 namespace {
+// the number of the last call of THIS thread that took part in a chain of by-products (see shim_common.hpp)
+thread_local uint64_t chain_epoch = ~uint64_t(0);
 
 struct held_ops {
     int stage = 0;   // 0 nothing, 1 step_2, 2 step_2 + simple_apply, 3 sub_scaled (y -= alpha x)
@@ -141,17 +146,81 @@ thread_local just_stepped last_step_2;
 thread_local bool anticipated = false;      // z = M r of `learned` is in place, its call has not come yet
 thread_local int64_t hits_apply = 0;
 
-int anticipate_enabled()
+int anticipate_level()
 {
     int64_t v = 1;
     gkoc_tune_get(GKOC_TUNE_ANTICIPATE, &v);
-    return v != 0;
+    return static_cast<int>(v);
 }
+int anticipate_enabled() { return anticipate_level() != 0; }
+
+// ---- round 6: the NEXT step_1 behind the criterion, and results written where they are wanted ------------
+// Ginkgo's Cg waits on the host for the criterion's answer and then calls cg::step_1 (core/solver/cg.cpp:148-
+// 165): 29 - 37 us per iteration in which the device has nothing to do (profiles/r05_ginkgo_api_timeline.txt).
+// Once THIS solve has shown the criterion followed directly by cg::step_1(p, z, rho, prev_rho), the criterion's
+// entry enqueues the predicted step_1 behind its own kernel before it starts to wait (the two scalars have
+// changed places, as `swap(prev_rho, rho)` at the end of the loop body says; the dot product that has just
+// written rho is checked against that).  The step is masked by stop_status: if the criterion stops the column,
+// p stays as it is.  The cg::step_1 that arrives finds its work done.  If the solve ends instead (iteration
+// limit), p - dead from there on - has been advanced once more.
+// In the same way the one-kernel step_2 + application writes <r, z> and ||r|| straight to where the dot
+// product and the norm of the previous iteration were asked to put them (rho alternates between two scalars,
+// the criterion's norm has one home): the two calls then launch nothing at all, not even an 8-byte copy.
+// GKOC_TUNE_ANTICIPATE: 0 nothing, 1 (default) all of it, 2 only the application (round 5's behaviour).
+struct step1_call {
+    bool valid = false;
+    int vt = 0;
+    gkoc_stream_t s = nullptr;
+    int64_t n = 0;
+    void* p = nullptr;
+    const void *z = nullptr, *rho = nullptr, *prev_rho = nullptr;
+    const uint8_t* stop = nullptr;
+};
+thread_local step1_call learned_step1;      // the last cg::step_1 of this solve, seen directly behind the criterion
+thread_local step1_call ahead;              // the step_1 the criterion's entry has run ahead of its call
+thread_local bool step1_is_ahead = false;
+thread_local uint64_t criterion_epoch = ~uint64_t(0) - 1;
+thread_local const void* last_dot_dest = nullptr;     // where the last single-column dot product was written
+thread_local const void* last_norm_of = nullptr;      // the last single-column norm: of what, where to
+thread_local void* last_norm_dest = nullptr;
+thread_local int64_t hits_step1 = 0;
 
 void publish()
 {
     deferred_state = held.stage | (held.norm_of ? 4 : 0) | (bp_dot.x ? 8 : 0) | (last_step_2.r ? 16 : 0) |
                      (anticipated ? 32 : 0);
+}
+
+// what this thread's earlier calls left behind is void (another entry into the backend - of any thread - has
+// come between): the values are simply not used; z = M r written ahead of its call stays what it is
+void drop_byproducts()
+{
+    if (held.norm_of == nullptr && bp_dot.x == nullptr && last_step_2.r == nullptr && !anticipated) return;
+    held.norm_of = nullptr;
+    bp_dot.x = nullptr;
+    last_step_2.r = nullptr;
+    anticipated = false;
+    publish();
+}
+
+// a READING call (dot, norm2): may it use what is left behind?  It takes no number itself.
+bool chain_intact_for_read()
+{
+    if (backend_epoch.load(std::memory_order_acquire) == chain_epoch) return true;
+    drop_byproducts();
+    return false;
+}
+
+// a WRITING call that takes part (the block-Jacobi application): it takes the next number; the chain
+// goes on iff that is the number right behind the chain's last one
+bool chain_step()
+{
+    const uint64_t e = backend_epoch.fetch_add(1, std::memory_order_acq_rel) + 1;
+    const bool intact = e == chain_epoch + 1;
+    chain_epoch = e;
+    last_entry_epoch = e;
+    if (!intact) drop_byproducts();
+    return intact;
 }
 
 // Device memory of the by-products, one block per (device, stream) this thread has used:
@@ -286,6 +355,8 @@ bool hold_jacobi_apply(int vt, int it, gkoc_stream_t s, int64_t num_blocks, uint
                        gkoc_jacobi_scheme scheme, const void* block_ptrs, const void* blocks,
                        const void* b, int64_t n, void* z)
 {
+    // (the first thing a single-column jacobi::simple_apply does: its number in the order of entries)
+    chain_step();
     const int64_t bo = scheme.block_offset;
     const bool fast_layout = bo >= 1 && bo <= 16 && (bo & (bo - 1)) == 0 &&
                              (bo << scheme.group_power) == 64 && int64_t(max_bs) <= bo;
@@ -312,14 +383,94 @@ bool hold_jacobi_apply(int vt, int it, gkoc_stream_t s, int64_t num_blocks, uint
 void forget_learned_if(const void* freed)
 {
     const followup& f = learned;
-    if (f.valid && (freed == f.blocks || freed == f.block_ptrs || freed == f.z || freed == f.r || freed == f.x)) {
+    const step1_call& c = learned_step1;
+    if ((f.valid && (freed == f.blocks || freed == f.block_ptrs || freed == f.z || freed == f.r || freed == f.x)) ||
+        (c.valid && (freed == c.p || freed == c.z || freed == c.rho || freed == c.prev_rho || freed == c.stop)) ||
+        (freed != nullptr && (freed == last_dot_dest || freed == last_norm_dest || freed == last_norm_of))) {
         forget_learned();
     }
+}
+
+// ---- the criterion (one column, synchronous form) with the predicted cg::step_1 behind its kernel ------------
+bool criterion_then_step_1(int vt, gkoc_stream_t s, const void* tau, const void* orig_tau, double goal,
+                           uint8_t stopping_id, bool set_finalized, bool implicit, uint8_t* stop, uint8_t* flags,
+                           int* all_converged, int* one_changed)
+{
+    // (the caller has been through stream_of(): this entry's number)
+    criterion_epoch = last_entry_epoch;
+    step1_is_ahead = false;
+    const step1_call& c = learned_step1;
+    if (!c.valid || c.vt != vt || c.s != s || c.stop != stop || anticipate_level() != 1 || mode() != 0 ||
+        last_dot_dest == nullptr || last_dot_dest != c.prev_rho) {
+        return false;
+    }
+    // this iteration's scalars: rho is where the dot product has just been written = last iteration's prev_rho
+    int rc;
+    if (vt == 0) {
+        rc = gkoc_x_residual_norm_then_cg_step_1_f64(
+            s, static_cast<const double*>(tau), static_cast<const double*>(orig_tau), goal, stopping_id,
+            set_finalized ? 1 : 0, implicit ? 1 : 0, stop, flags, all_converged, one_changed, c.n,
+            static_cast<double*>(c.p), static_cast<const double*>(c.z), static_cast<const double*>(c.prev_rho),
+            static_cast<const double*>(c.rho));
+    } else {
+        rc = gkoc_x_residual_norm_then_cg_step_1_f32(
+            s, static_cast<const float*>(tau), static_cast<const float*>(orig_tau), float(goal), stopping_id,
+            set_finalized ? 1 : 0, implicit ? 1 : 0, stop, flags, all_converged, one_changed, c.n,
+            static_cast<float*>(c.p), static_cast<const float*>(c.z), static_cast<const float*>(c.prev_rho),
+            static_cast<const float*>(c.rho));
+    }
+    GKOC_CALL(rc);
+    ahead = c;
+    ahead.rho = c.prev_rho;
+    ahead.prev_rho = c.rho;
+    step1_is_ahead = true;
+    return true;
+}
+
+// cg::step_1 (one column) arrives: has the criterion's entry done it already?  Either way this solve's
+// pattern is noted (only a step_1 DIRECTLY behind the criterion counts).
+bool step_1_done_ahead(int vt, gkoc_stream_t s, int64_t n, void* p, const void* z, const void* rho,
+                       const void* prev_rho, const uint8_t* stop)
+{
+    const bool was = step1_is_ahead;
+    step1_is_ahead = false;
+    // this call's number in the order of entries (it writes p, whoever launches it)
+    const uint64_t e = backend_epoch.fetch_add(1, std::memory_order_acq_rel) + 1;
+    last_entry_epoch = e;
+    step1_call now;
+    now.valid = e == criterion_epoch + 1;
+    now.vt = vt;
+    now.s = s;
+    now.n = n;
+    now.p = p;
+    now.z = z;
+    now.rho = rho;
+    now.prev_rho = prev_rho;
+    now.stop = stop;
+    learned_step1 = now;
+    if (!was) return false;
+    if (ahead.vt == vt && ahead.s == s && ahead.n == n && ahead.p == p && ahead.z == z && ahead.rho == rho &&
+        ahead.prev_rho == prev_rho && ahead.stop == stop) {
+        ++hits_step1;
+        if (deferred_state != 0) flush_deferred();      // (what any writing entry does to this thread's by-products)
+        return true;
+    }
+    // a step_1 other than the predicted one: p has been advanced by a step the solver did not ask for.
+    // Ginkgo's Cg cannot get here (its loop has no other exit between the criterion and step_1); say so loudly.
+    std::fprintf(stderr, "[gko-cdna4] cg::step_1 arrived with other operands than the step run ahead of it; "
+                         "GKOC_TUNE_ANTICIPATE=2 switches the prediction off\n");
+    learned_step1.valid = false;
+    return false;
 }
 
 void forget_learned()
 {
     learned.valid = false;
+    learned_step1.valid = false;
+    step1_is_ahead = false;
+    last_dot_dest = nullptr;
+    last_norm_of = nullptr;
+    last_norm_dest = nullptr;
     if (last_step_2.r || anticipated) {
         last_step_2.r = nullptr;
         anticipated = false;
@@ -342,6 +493,19 @@ bool step_2_anticipating(int vt, int dev, gkoc_stream_t s, int64_t n, void* x, v
     if (!b || b->work < work) return false;
     char* norm_at = b->p;
     char* dot_at = b->p + 64;
+    if (anticipate_level() == 1) {
+        // <r, z> goes where the NEXT dot product will be asked to put it: the scalar that was prev_rho in this
+        // iteration's step_1 (cg.cpp:176 swaps the two); ||r|| where the criterion's norm of r went last time.
+        // Nothing reads either before those calls come (prev_rho's last reader was step_1).
+        const step1_call& c = learned_step1;
+        if (c.valid && c.vt == vt && c.s == s && c.rho == rho && c.prev_rho != nullptr && c.prev_rho != rho &&
+            c.prev_rho != beta && c.prev_rho != last_norm_dest) {
+            dot_at = static_cast<char*>(const_cast<void*>(c.prev_rho));
+        }
+        if (last_norm_of == r && last_norm_dest != nullptr && last_norm_dest != rho && last_norm_dest != beta) {
+            norm_at = static_cast<char*>(last_norm_dest);
+        }
+    }
     int rc = GKOC_E_NOT_SUPPORTED;
 #define CASE(VT, IT, T, I, TN, IN)                                                                    \
     if (vt == VT && f.it == IT) {                                                                     \
@@ -368,6 +532,7 @@ bool step_2_anticipating(int vt, int dev, gkoc_stream_t s, int64_t n, void* x, v
     bp_dot.s = s;
     anticipated = true;
     last_step_2.r = nullptr;
+    chain_epoch = last_entry_epoch;      // (step_2 came in through stream_of(): that entry's number)
     publish();
     return true;
 }
@@ -408,6 +573,7 @@ bool step_2_with_norm(int vt, int dev, gkoc_stream_t s, int64_t n, void* x, void
     last_step_2.vt = vt;
     last_step_2.n = n;
     last_step_2.s = s;
+    chain_epoch = last_entry_epoch;      // (step_2 came in through stream_of(): that entry's number)
     publish();
     return true;
 }
@@ -512,11 +678,14 @@ void launch_deferred_for_read(const void* result)
 bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y, void* result,
                array<char>& tmp)
 {
+    if (deferred_state != 0 && held.stage == 0) chain_intact_for_read();
+    last_dot_dest = result;
     if (held.stage == 0 && bp_dot.x != nullptr && bp_dot.vt == vt && bp_dot.s == s && bp_dot.n == n &&
         ((x == bp_dot.x && y == bp_dot.y) || (x == bp_dot.y && y == bp_dot.x)) && result != x &&
         result != y) {
         // <b, z> came with the block-Jacobi application and nothing has entered the backend since
-        GKOC_CALL(gkoc_memcpy_d2d(result, bp_dot.at, vt == 0 ? 8 : 4, s));
+        // (if it was written straight to `result`, there is nothing left to do)
+        if (result != bp_dot.at) GKOC_CALL(gkoc_memcpy_d2d(result, bp_dot.at, vt == 0 ? 8 : 4, s));
         ++hits_dot;
         return true;
     }
@@ -610,6 +779,9 @@ bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y,
 bool cached_norm2(int vt, gkoc_stream_t s, int64_t n, const void* x, void* result)
 {
     const void* src = nullptr;
+    if (deferred_state != 0 && held.stage == 0) chain_intact_for_read();
+    last_norm_of = x;
+    last_norm_dest = result;
     {
             if (held.stage == 0 && held.norm_of && held.norm_of == x && held.norm_vt == vt && held.norm_n == n &&
             held.norm_s == s) {
@@ -617,7 +789,7 @@ bool cached_norm2(int vt, gkoc_stream_t s, int64_t n, const void* x, void* resul
         }
     }
     if (!src) return false;
-    GKOC_CALL(gkoc_memcpy_d2d(result, src, vt == 0 ? 8 : 4, s));
+    if (src != result) GKOC_CALL(gkoc_memcpy_d2d(result, src, vt == 0 ? 8 : 4, s));
     ++hits_norm;
     // the value stays valid: nothing has touched r
     return true;
@@ -635,6 +807,10 @@ extern "C" void gko_cdna4_byproduct_hits(int64_t* norms, int64_t* dots)
     if (dots) *dots = gko::cdna4::hits_dot;
 }
 // block-Jacobi applications of the calling thread that a preceding cg::step_2 had already done
+extern "C" void gko_cdna4_anticipated_steps(int64_t* steps)
+{
+    if (steps) *steps = gko::cdna4::hits_step1;
+}
 extern "C" void gko_cdna4_anticipated_applies(int64_t* applies)
 {
     if (applies) *applies = gko::cdna4::hits_apply;

@@ -608,6 +608,14 @@ namespace cg {
                    const matrix::Dense<T>* prev_rho,                            \
                    const array<stopping_status>* stop_status)                   \
     {                                                                           \
+        if (cols(p) == 1 && ld(p) == 1 && ld(z) == 1 &&                         \
+            cdna4::step_1_done_ahead(                                           \
+                cdna4::vt_of<T>(), cdna4::stream_keeping_deferred(exec),        \
+                rows(p), p->get_values(), z->get_const_values(),                \
+                rho->get_const_values(), prev_rho->get_const_values(),          \
+                raw(stop_status))) {                                            \
+            return; /* run behind the criterion's kernel: fusion.cpp */         \
+        }                                                                       \
         GKOC_CALL(gkoc_cg_step_1_##TN(                                          \
             stream_of(exec), rows(p), cols(p), p->get_values(), ld(p),          \
             z->get_const_values(), ld(z), rho->get_const_values(),              \
@@ -773,8 +781,20 @@ namespace residual_norm {
     {                                                                           \
         if (device_storage->get_size() < 2) device_storage->resize_and_reset(2); \
         int allc = 0, chg = 0;                                                  \
+        const auto st_ = stream_of(exec);                                       \
+        if (cols(tau) == 1 &&                                                   \
+            cdna4::criterion_then_step_1(                                       \
+                cdna4::vt_of<T>(), st_, tau->get_const_values(),                \
+                orig_tau->get_const_values(), double(rel_residual_goal),        \
+                stoppingId, setFinalized, false, raw(stop_status),             \
+                reinterpret_cast<uint8_t*>(device_storage->get_data()), &allc,  \
+                &chg)) {                                                        \
+            *all_converged = allc != 0;                                         \
+            *one_changed = chg != 0;                                            \
+            return; /* and the cg::step_1 that follows is under way */          \
+        }                                                                       \
         GKOC_CALL(gkoc_residual_norm_##TN(                                      \
-            stream_of(exec), cols(tau), tau->get_const_values(),                \
+            st_, cols(tau), tau->get_const_values(),                            \
             orig_tau->get_const_values(), rel_residual_goal, stoppingId,        \
             setFinalized ? 1 : 0, raw(stop_status),                             \
             reinterpret_cast<uint8_t*>(device_storage->get_data()), &allc,      \
@@ -800,8 +820,20 @@ namespace implicit_residual_norm {
     {                                                                           \
         if (device_storage->get_size() < 2) device_storage->resize_and_reset(2); \
         int allc = 0, chg = 0;                                                  \
+        const auto st_ = stream_of(exec);                                       \
+        if (cols(tau) == 1 &&                                                   \
+            cdna4::criterion_then_step_1(                                       \
+                cdna4::vt_of<T>(), st_, tau->get_const_values(),                \
+                orig_tau->get_const_values(), double(rel_residual_goal),        \
+                stoppingId, setFinalized, true, raw(stop_status),             \
+                reinterpret_cast<uint8_t*>(device_storage->get_data()), &allc,  \
+                &chg)) {                                                        \
+            *all_converged = allc != 0;                                         \
+            *one_changed = chg != 0;                                            \
+            return; /* and the cg::step_1 that follows is under way */          \
+        }                                                                       \
         GKOC_CALL(gkoc_implicit_residual_norm_##TN(                             \
-            stream_of(exec), cols(tau), tau->get_const_values(),                \
+            st_, cols(tau), tau->get_const_values(),                            \
             orig_tau->get_const_values(), rel_residual_goal, stoppingId,        \
             setFinalized ? 1 : 0, raw(stop_status),                             \
             reinterpret_cast<uint8_t*>(device_storage->get_data()), &allc,      \

@@ -9,6 +9,7 @@
 // link-compatible replacement for libginkgo_hip.so.  No device code and no HIP
 // headers are needed here: everything goes through the C ABI.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -46,8 +47,17 @@ inline void check(int status, const char* file, int line, const char* what)
 // product.  Everything that enters the backend goes through launch_deferred() first.
 extern thread_local int deferred_state;   // != 0: this thread holds something or caches a norm
 void flush_deferred();
+// "Nothing has entered the backend since" is a statement about ALL host threads: Executor::run may be called
+// from any thread on one executor and one stream (include/ginkgo/core/base/executor.hpp:1283-1289), and what
+// thread A's cg::step_2 left behind for ||r|| is void once thread B has written r.  Every entry into the
+// backend, from any thread, therefore takes a number from ONE process-wide counter; a thread's by-products
+// carry the number of the call that produced them, and a later call of that thread may use them only if no
+// number has been handed out in between (fusion.cpp: chain_epoch).  Reading calls (dot, norm2) take no number.
+extern std::atomic<uint64_t> backend_epoch;
+extern thread_local uint64_t last_entry_epoch;      // the number this thread's last entry was given
 inline void launch_deferred()
 {
+    last_entry_epoch = backend_epoch.fetch_add(1, std::memory_order_acq_rel) + 1;
     if (deferred_state != 0) flush_deferred();
 }
 bool hold_step_2(int vt, gkoc_stream_t s, int64_t n, void* x, void* r, const void* p, const void* q,
@@ -67,6 +77,12 @@ bool jacobi_apply_with_dot(int vt, int it, int dev, gkoc_stream_t s, int64_t num
                            gkoc_jacobi_scheme scheme, const void* block_ptrs, const void* blocks,
                            const void* b, int64_t n, void* z);
 void launch_deferred_for_read(const void* result);
+// round 6 (fusion.cpp): the criterion's entry runs the cg::step_1 this solve has shown to follow it
+bool criterion_then_step_1(int vt, gkoc_stream_t s, const void* tau, const void* orig_tau, double goal,
+                           uint8_t stopping_id, bool set_finalized, bool implicit, uint8_t* stop, uint8_t* flags,
+                           int* all_converged, int* one_changed);
+bool step_1_done_ahead(int vt, gkoc_stream_t s, int64_t n, void* p, const void* z, const void* rho,
+                       const void* prev_rho, const uint8_t* stop);
 // what the by-product mode has learned about the running solve (step_2 -> block-Jacobi application of r)
 // is void: a new solve begins, memory is freed, a preconditioner is generated
 void forget_learned();

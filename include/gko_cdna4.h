@@ -199,13 +199,13 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                       Two products with the SAME matrix must not run at the same time on two streams
                                       when it has such rows (they share the chunk sums' scratch) */
 #define GKOC_TUNE_CSR_SEGS_PER_WAVE 13 /* csr::spmv, one right-hand side: 64-row segments a wave walks.  0 (default): two
-                                      from 4 M rows on, one below - and, for matrices whose 64-row segments hold fewer
-                                      than 1200 entries (known from the first product's look at the row pointers),
-                                      up to eight, so that a wave carries about 3000 entries: with a dozen entries
-                                      per row a one-segment wave lives 2.8 us and the workgroup dispatcher (one
-                                      workgroup per ~29 ns and XCD) keeps 3 waves per CU resident - the product of
-                                      the heavy-tailed stand-in ran at 37 % of the rate its bytes allow
-                                      (profiles/r06_irregular_pmc.txt).  1, 2, 4, 8: that many */
+                                      from 4 M rows on, one below; 1, 2, 4, 8: that many (A/B runs: more than two
+                                      never paid, not even on rows of a dozen entries - profiles/r06/) */
+#define GKOC_TUNE_CSR_SHORT_ROWS 14 /* csr::spmv, one right-hand side, matrices whose 64-row segments hold fewer than
+                                      1200 entries on average: load layout and ring size of the row-segment kernel.
+                                      0 (default): the launcher's rule; 1: two entries per lane, one load group, 2 KB
+                                      ring; 2: two entries, two groups, 4 KB ring; 3: one entry, two groups, 2 KB
+                                      ring; -1: the layout of the long-row matrices */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,
@@ -1358,6 +1358,22 @@ GKOC_DECL_X_GMRES(gkoc_c64, c64)
         const uint8_t* stop_status, T* out3, void* work, size_t work_bytes);
 GKOC_DECL_X(double, f64)
 GKOC_DECL_X(float, f32)
+/* The stopping criterion of one column in its SYNCHRONOUS form (gkoc_residual_norm_* / gkoc_implicit_residual_norm_*
+ * with host results) and, enqueued right behind its kernel - BEFORE the host starts to wait for the answer -,
+ * cg::step_1(p, z, rho, prev_rho) of the iteration that follows if the criterion lets the solve go on
+ * (core/solver/cg.cpp:148-165: check, then step_1).  The step is masked by stop_status like every step kernel: a
+ * column the criterion has just stopped is left alone.  For a caller that KNOWS step_1 comes next (the binding
+ * for Ginkgo's core has seen it in this solve: gko_binding/fusion.cpp) - the device works through the 30 - 40 us
+ * the host needs to read the answer and come back with the next launch. */
+#define GKOC_DECL_X_CRIT(T, TN)                                                \
+    int gkoc_x_residual_norm_then_cg_step_1_##TN(                              \
+        gkoc_stream_t s, const T* tau, const T* orig_tau, T goal,              \
+        uint8_t stopping_id, int set_finalized, int implicit,                  \
+        uint8_t* stop_status, uint8_t* flags_dev, int* all_converged,          \
+        int* one_changed, int64_t rows, T* p, const T* z, const T* rho,        \
+        const T* prev_rho);
+GKOC_DECL_X_CRIT(double, f64)
+GKOC_DECL_X_CRIT(float, f32)
 #define GKOC_DECL_XI(T, TN, I, IN)                                             \
     int gkoc_x_csr_spmv_dot_##TN##_##IN(                                       \
         gkoc_stream_t s, int64_t n, const I* row_ptrs, const I* col_idxs,      \

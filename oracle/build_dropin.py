@@ -40,7 +40,7 @@ def main():
         return 1
     os.makedirs(OUT, exist_ok=True)
     inc = [f"-I{REFB}/include", f"-I{ref}/include", f"-I{ref}", f"-I{ROOT}/include"]
-    flags = ["-std=c++17", "-O2", "-fPIC", "-w"]
+    flags = ["-std=c++17", "-O2", "-fPIC", "-w", "-pthread"]
     # 1. + 2. the product's own build (ginkgo_amd/gko_binding/build.py -> ginkgo_amd/lib/); the test
     #    programs below find the library next to them, as a Ginkgo build tree would have it
     p = subprocess.run([sys.executable, os.path.join(ROOT, "ginkgo_amd", "gko_binding", "build.py")],
@@ -59,6 +59,9 @@ def main():
         [f"-L{os.path.dirname(cdna)}", "-lgko_cdna4"])     # gkoc_tune_set: the fusion switch
     run(["g++"] + flags + inc + [os.path.join(ROOT, "tests", "dropin", "dropin_bench.cpp"), "-o",
                                  os.path.join(OUT, "dropin_bench")] + link +
+        [f"-L{os.path.dirname(cdna)}", "-lgko_cdna4"])
+    run(["g++"] + flags + inc + [os.path.join(ROOT, "tests", "dropin", "round5_bench.cpp"), "-o",
+                                 os.path.join(OUT, "round5_bench")] + link +
         [f"-L{os.path.dirname(cdna)}", "-lgko_cdna4"])
     run(["g++"] + flags + inc + [os.path.join(ROOT, "tests", "dropin", "arena_roles_test.cpp"), "-o",
                                  os.path.join(OUT, "arena_roles_test")] + link +

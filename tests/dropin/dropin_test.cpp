@@ -10,6 +10,9 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <thread>
+
+#include "core/solver/cg_kernels.hpp"
 
 #include <ginkgo/core/base/device_matrix_data.hpp>
 #include <ginkgo/core/base/executor.hpp>
@@ -60,6 +63,7 @@ using Dense = gko::matrix::Dense<vt>;
 #include "core/matrix/csr_lookup.hpp"
 extern "C" void gko_cdna4_byproduct_hits(int64_t* norms, int64_t* dots);
 extern "C" void gko_cdna4_anticipated_applies(int64_t* applies);
+extern "C" void gko_cdna4_anticipated_steps(int64_t* steps);
 static int failures = 0;
 template <typename T>
 struct type_tag {
@@ -487,6 +491,29 @@ int main(int argc, char** argv)
                 CHECK(b1 == b0 && it_no == it_by && rel_err(no.first.get(), by.first.get()) < 1e-12,
                       "GKOC_TUNE_ANTICIPATE=0: nothing anticipated, same iterations and solution");
             }
+            {
+                // round 6: without a logger between the criterion and cg::step_1 the criterion's entry runs the
+                // step_1 this solve has shown to follow it behind its own kernel (the device works while the
+                // host reads the answer), and <r,z> / ||r|| are written where the dot product and the norm were
+                // asked to put them last time.  Same iterations, same solution; a logger that enters the
+                // backend in between (h_by above) keeps the prediction from ever being learned.
+                int it_st = 0;
+                int64_t s0 = 0, s1 = 0, s2 = 0;
+                gko_cdna4_anticipated_steps(&s0);
+                auto st = run(0, nullptr, it_st);
+                gko_cdna4_anticipated_steps(&s1);
+                std::cout << "  anticipated: " << (s1 - s0) << " of " << it_st
+                          << " cg::step_1 calls had been run behind the criterion's kernel" << std::endl;
+                CHECK(s1 - s0 >= it_st - 4 && it_st == it_off && rel_err(st.first.get(), off.first.get()) < 1e-12,
+                      "CG with by-products: step_1 runs behind the criterion from the third iteration on, same solution");
+                gkoc_tune_set(GKOC_TUNE_ANTICIPATE, 2);
+                int it_2 = 0;
+                auto only_z = run(0, nullptr, it_2);
+                gko_cdna4_anticipated_steps(&s2);
+                gkoc_tune_set(GKOC_TUNE_ANTICIPATE, 1);
+                CHECK(s2 == s1 && it_2 == it_off && rel_err(only_z.first.get(), off.first.get()) < 1e-12,
+                      "GKOC_TUNE_ANTICIPATE=2: only the block-Jacobi application is anticipated");
+            }
             std::cout << "  by-products: " << it_by << " iterations, " << (n1 - n0) << " norms and " << (d1 - d0)
                       << " dots answered without a pass of their own" << std::endl;
             CHECK(it_by == it_off && rel_err(by.first.get(), off.first.get()) < 1e-12,
@@ -636,6 +663,49 @@ int main(int argc, char** argv)
                   "CG + user LinOp preconditioner: the reference's solution");
             CHECK(n1 - n0 >= iu_by - 1 && d1 - d0 == 0,
                   "CG + user LinOp preconditioner: ||r|| still comes with step_2, <r,z> is computed");
+        }
+        {
+            // TWO host threads on one executor and one stream (Executor::run is const and callable from any
+            // thread: include/ginkgo/core/base/executor.hpp:1283-1289).  Thread A's cg::step_2 leaves ||r||
+            // behind; thread B then rewrites r through the backend; thread A's compute_norm2(r) must be the
+            // norm of what r holds NOW.  "Nothing has entered the backend since" is judged over all threads
+            // (gko_binding/fusion.cpp: one process-wide counter of entries), not per thread.
+            gkoc_tune_set(GKOC_TUNE_DEFERRED_FUSION, 0);
+            const gko::size_type m = 100000;
+            auto mk = [&](double v) {
+                auto d = Dense::create(hip, gko::dim<2>{m, 1});
+                d->fill(v);
+                return d;
+            };
+            auto x2 = mk(0.0), r2 = mk(1.0), p2 = mk(0.5), q2 = mk(0.25);
+            auto beta2 = gko::initialize<Dense>({2.0}, hip), rho2 = gko::initialize<Dense>({1.0}, hip);
+            auto two = gko::initialize<Dense>({2.0}, hip);
+            gko::array<gko::stopping_status> st2(hip, 1);
+            gkoc_memset(st2.get_data(), 0, 1, reinterpret_cast<gkoc_stream_t>(hip->get_stream()));
+            auto nrm = Dense::create(hip, gko::dim<2>{1, 1});
+            int64_t n0 = 0, n1 = 0, n2 = 0, dd = 0;
+            // (1) one thread: the by-product answers the norm
+            gko_cdna4_byproduct_hits(&n0, &dd);
+            gko::kernels::hip::cg::step_2(hip, x2.get(), r2.get(), p2.get(), q2.get(), beta2.get(), rho2.get(), &st2);
+            r2->compute_norm2(nrm.get());
+            gko_cdna4_byproduct_hits(&n1, &dd);
+            const double one_thread = hip->copy_val_to_host(nrm->get_const_values());
+            const double want1 = std::sqrt(double(m)) * (1.0 - 0.5 * 0.25);      // r = 1 - (rho / beta) q
+            // (2) the same with another thread writing r in between
+            gko::kernels::hip::cg::step_2(hip, x2.get(), r2.get(), p2.get(), q2.get(), beta2.get(), rho2.get(), &st2);
+            std::thread other([&] { r2->scale(two.get()); });
+            other.join();
+            r2->compute_norm2(nrm.get());
+            gko_cdna4_byproduct_hits(&n2, &dd);
+            const double two_threads = hip->copy_val_to_host(nrm->get_const_values());
+            const double want2 = std::sqrt(double(m)) * 2.0 * (1.0 - 2.0 * 0.5 * 0.25);
+            std::cout << "  two threads: ||r|| " << one_thread << " (by-product, want " << want1 << "), after another "
+                      << "thread scaled r: " << two_threads << " (want " << want2 << "); by-product hits " << (n1 - n0)
+                      << " then " << (n2 - n1) << std::endl;
+            CHECK(n1 - n0 == 1 && std::abs(one_thread - want1) <= 1e-12 * want1,
+                  "by-products: ||r|| of a lone thread comes with cg::step_2");
+            CHECK(n2 - n1 == 0 && std::abs(two_threads - want2) <= 1e-12 * want2,
+                  "by-products: another thread's write between step_2 and compute_norm2 voids the value left behind");
         }
         {
             // Jacobi::convert_to(Dense): the preconditioner as a dense matrix (jacobi::convert_to_dense,

@@ -524,7 +524,7 @@ def test_csr_long_rows_two_streams_at_once(gexec, oracle):
     written (the chunk sums are stream-ordered scratch of each launch): both results are right, many times over"""
     import ginkgo_amd as g
     rng = np.random.default_rng(77)
-    n, ncols = 64 * 50, 60000
+    n, ncols = 64 * 50, 100000
     hubs = [(64 * k + 3, 30000 + 1000 * k) for k in range(0, 50, 5)]
     lens, rp, ci, v = _short_rows_with_hubs(rng, n, ncols, hubs)
     a = dev_csr(g, gexec, rp, ci, v, (n, ncols))
