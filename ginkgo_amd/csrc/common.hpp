@@ -85,7 +85,7 @@ void csr_long_rows_forget(const void* ptr);
 int gate_fence_policy();
 void gate_fence_policy_set(int policy);
 // tuning switches (runtime.hip; keys = GKOC_TUNE_* of gko_cdna4.h)
-constexpr int tune_num_keys = 15;
+constexpr int tune_num_keys = 18;
 int64_t tune_value(int key);
 
 #ifdef __HIPCC__

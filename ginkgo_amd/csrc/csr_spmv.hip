@@ -381,13 +381,14 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         GKOC_TRY((long_info_of<T, I>(s, n_rows, row_ptrs, &lng)));
     }
     const uint32_t* seg_skip = lng.count > 0 ? lng.bits : nullptr;
-    // GKOC_TUNE_CSR_SEGS_PER_WAVE forces 1, 2, 4 or 8 segments per wave (round 6 tried "up to eight for
-    // matrices with short rows" - the heavy-tailed stand-in 256 us with one, 261 with two, 276 with four, 320
-    // with eight segments; 5-pt 4096^2 325 / 289 / 325 / 315; profiles/r06/r06_segments_per_wave.txt: the
-    // size rule above stays)
+    // GKOC_TUNE_CSR_SEGS_PER_WAVE forces 1 or 2 segments per wave (round 6 tried "up to eight for matrices
+    // with short rows" - the heavy-tailed stand-in 256 us with one, 261 with two, 276 with four, 320 with eight
+    // segments; 5-pt 4096^2 325 / 289 / 325 / 315; profiles/r06/r06_segments_per_wave.txt: the size rule above
+    // stays, and the four / eight-segment variants - whose loop over runs of unflagged segments cost every
+    // variant of the kernel 12-16 VGPRs - are gone again)
     int spw = segs_per_wave;
     const int64_t forced_spw = tune_value(GKOC_TUNE_CSR_SEGS_PER_WAVE);
-    if (forced_spw == 1 || forced_spw == 2 || ((forced_spw == 4 || forced_spw == 8) && vec_ok)) spw = int(forced_spw);
+    if (forced_spw == 1 || forced_spw == 2) spw = int(forced_spw);
     const int64_t n_waves_1 = ceildiv(n_seg, spw);
     GKOC_REQUIRE(n_waves_1 < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 row segments");
     grid = dim3(static_cast<unsigned>(n_waves_1));
@@ -421,11 +422,7 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     if (vec_ok) {
         // below 2 M rows the grid is a few rounds deep and the wider layout of rounds 1-2 is as fast or
         // faster (64^3: 18.4 against 20.7 us; 1 - 2 M rows: equal); key 1 forces it for A/B runs
-        if (spw == 8) {
-            GKOC_LAUNCH_PIPE3(PE, PU, 0x8000);
-        } else if (spw == 4) {
-            GKOC_LAUNCH_PIPE3(PE, PU, 0x4000);
-        } else if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_seg < 32768) {
+        if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_seg < 32768) {
             if (spw == 2) {
                 GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);
             } else {
@@ -680,8 +677,12 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
         reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;  // E = 4 below
     const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
     constexpr int PE = sizeof(T) == 8 ? 2 : 4, PU = sizeof(T) == 8 ? 3 : 2;   // as in launch_csr
+    // four waves per SIMD, like the plain product: the dot's registers (and, since round 6, the loop over runs
+    // of unflagged segments) had taken the double / int32 kernel to 133 VGPRs = three waves - 985 -> 1107 us on
+    // L256 (profiles/r06/r06_bench_kernel_stats_regression.csv); with the bound the compiler stays at 128
+    constexpr int DOT_WPS = sizeof(I) == 4 ? 4 : 1;      // (64-bit indices: 161 VGPRs, the bound would spill)
 #define GKOC_LAUNCH_DOT(E_, U_, MODE_)                                               \
-    csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, E_, U_, 1024, 1, MODE_>         \
+    csr_spmv_pipe3_kernel<T, I, false, rows_per_seg, E_, U_, 1024, DOT_WPS, MODE_>   \
         <<<grid, block, 0, as_stream(s)>>>(n, n_seg, segs_per_wave, row_ptrs, col_idxs, \
                                            vals, b, 1, c, 1, 1, nullptr, nullptr,    \
                                            partial, xcd_map)

@@ -212,33 +212,29 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
             n_segments = n_int;
         }
     }
-    const int64_t sb_all = wave_id * segs_per_wave;
-    const int64_t se_all = sb_all + segs_per_wave < n_segments ? sb_all + segs_per_wave : n_segments;
+    int64_t sb = wave_id * segs_per_wave;
+    int64_t se = sb + segs_per_wave < n_segments ? sb + segs_per_wave : n_segments;
+    if (seg_skip != nullptr) {
+        // segments that hold a row far longer than the rest belong to csr_flagged_segments_kernel
+        // (csr_long_rows.hpp): a wave owns one or two segments (the launcher sees to that when a matrix has
+        // flagged segments), so what is left is one range.  (Round 6 walked the RUNS between flagged segments
+        // in a loop, for waves of up to eight short-row segments: never faster, and the loop cost every
+        // variant of this kernel 12-16 VGPRs - a wave per SIMD for most of them, L256 with the dot 985 ->
+        // 1107 us; profiles/r06/r06_bench_kernel_stats_regression.csv.)
+        while (sb < se && ((seg_skip[sb >> 5] >> (sb & 31)) & 1u) != 0) ++sb;
+        while (se > sb && ((seg_skip[(se - 1) >> 5] >> ((se - 1) & 31)) & 1u) != 0) --se;
+    }
     // (GATE renumbers the boundary waves: a wave's partial sum has the number of its workgroup)
     const int64_t dot_slot = GATE ? int64_t(blockIdx.x) : wave_id;
-    bool coo_bad = false;
-    // Segments that hold a row far longer than the rest belong to csr_flagged_segments_kernel
-    // (csr_long_rows.hpp): the wave walks the RUNS of its other segments one after the other (a wave of
-    // one or two segments has one run at most; with up to eight segments of short rows - round 6 - a
-    // flagged segment may sit in the middle).  Without flags: one run, the wave's whole range.
-    auto flagged = [&](int64_t sg) { return ((seg_skip[sg >> 5] >> (sg & 31)) & 1u) != 0; };
-    int64_t run_b = sb_all;
-    for (;;) {
-    if (seg_skip != nullptr) {
-        while (run_b < se_all && flagged(run_b)) ++run_b;
+    if (sb >= se) {
+        if (DOT && lane == 0) dot_partial[dot_slot] = T(0);
+        return;
     }
-    if (run_b >= se_all) break;
-    int64_t run_e = se_all;
-    if (seg_skip != nullptr) {
-        run_e = run_b + 1;
-        while (run_e < se_all && !flagged(run_e)) ++run_e;
-    }
-    const int64_t sb = run_b, se = run_e;
     const int64_t row_e = se * ROWS < n_rows ? se * ROWS : n_rows;
     const int64_t K0 = COO ? row_ptrs[sb] : row_ptrs[sb * ROWS];
     const int64_t K1r = COO ? row_ptrs[se] : row_ptrs[row_e];
     const int64_t NNZ = COO ? row_ptrs[n_segments] : row_ptrs[n_rows];
-    coo_bad = COO && K1r < K0;
+    bool coo_bad = COO && K1r < K0;
     const int64_t K1 = coo_bad ? K0 : K1r;
     const int64_t K0a = K0 & ~int64_t(E - 1);
     const int64_t R0 = sb * ROWS;              // COO: first row of the wave
@@ -596,10 +592,6 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                 if (sb + t < se && lane < ROWS && row < n_rows) c[orow * ldc + j] = ys[t];
             }
         }
-    }
-    run_b = run_e;
-    if (seg_skip == nullptr) break;
-    wave_lds_sync();          // the next run starts with an empty ring
     }
     if constexpr (COO) {
         if (__ballot(coo_bad) && lane == 0) *unsorted_flag = 1;

@@ -1573,6 +1573,12 @@ int launch_generate(gkoc_stream_t s, const I* row_ptrs, const I* cols,
 // (include/ginkgo/core/preconditioner/jacobi.hpp:37-140) - and adds the products in column order
 // (reference apply_block, reference/preconditioner/jacobi_kernels.cpp:419-531).  row_block[row] = the
 // block of a row (filled by jacobi_row_block_kernel).
+// (defined with the adaptive kernels at the end of this file)
+template <typename T, typename I, bool ADV>
+bool launch_apply_lanes_any(hipStream_t st, int64_t num_blocks, gkoc_jacobi_scheme scheme, const I* block_ptrs,
+                            const T* blocks, const uint8_t* precisions, const T* alpha, const T* b, int64_t ldb,
+                            const T* beta, T* x, int64_t ldx, int64_t nrhs);
+
 template <typename I>
 __global__ __launch_bounds__(256) void jacobi_row_block_kernel(int64_t num_blocks,
                                                               const I* __restrict__ block_ptrs,
@@ -1618,6 +1624,13 @@ int launch_apply_simple(gkoc_stream_t s, int64_t num_blocks, gkoc_jacobi_scheme 
     if (num_blocks <= 0 || nrhs <= 0) return GKOC_OK;
     GKOC_REQUIRE(block_ptrs && blocks && b && x, GKOC_E_INVALID, "null pointer");
     hipStream_t st = as_stream(s);
+    // complex values (the only users of this launcher): lane = (block, row), jacobi_apply_lanes_any_kernel
+    if (tune_value(GKOC_TUNE_JACOBI_LANES) != 1 &&
+        launch_apply_lanes_any<T, I, ADV>(st, num_blocks, scheme, block_ptrs, blocks, nullptr, alpha, b, ldb, beta,
+                                          x, ldx, nrhs)) {
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     I last = 0;
     GKOC_HIP(hipMemcpyAsync(&last, block_ptrs + num_blocks, sizeof(I), hipMemcpyDeviceToHost, st));
     GKOC_HIP(hipStreamSynchronize(st));
@@ -2354,6 +2367,183 @@ int launch_generate_adaptive_any(gkoc_stream_t s, const I* row_ptrs, const I* co
     return GKOC_OK;
 }
 
+// ---- round 6: lane = (block, row) for every value type and storage precision -------------------------
+// The thread-per-row kernels above (jacobi_apply_simple_kernel, jacobi_apply_adaptive_any_kernel) need a
+// row -> block table (a pass of its own plus a device-to-host copy of the row count) and read the block with
+// one strided load per entry and lane: L256, block size 8: float adaptive 373 us = 13.5 % of 8 TB/s,
+// complex<double> adaptive 582 us = 23 %, complex<double> full storage 586 us = 57 %
+// (profiles/r06/r06_round5_additions.txt).  This is the scheme of jacobi_apply_fixed_kernel for them:
+// one wave per storage group (GPW groups per wave), lane = (block, row) = the group's interleaved storage
+// order, so column c of all blocks of the group is ONE contiguous run (lane + c * stride) in whatever type
+// the group is stored in; the block's b values come from the block's other lanes by shuffle instead of
+// `bs` gathers per lane; all loads of a group are requested before the first use.  SUB = the lanes of a
+// block (the power of two at or above block_offset), so every 64-wide scheme is covered, block_offset 13
+// included.  Per (row, column) the operations and their order are those of the thread-per-row kernels:
+// sum = 0, sum += B(row, c) * b(c) for c = 0 .. bs-1, then alpha * sum (+ beta * x) - the same bits.
+template <typename T, int KIND>
+struct entry_loader {
+    using R = real_t<T>;
+    using S = typename stored<KIND>::type;
+    __device__ static __forceinline__ T get(const T* group, int64_t idx)
+    {
+        if constexpr (is_cplx<T>::value) {
+            const S* sp = reinterpret_cast<const S*>(group) + 2 * idx;
+            const S re = sp[0], im = sp[1];
+            return T(R(stored<KIND>::load(re)), R(stored<KIND>::load(im)));
+        } else {
+            return T(stored<KIND>::load(reinterpret_cast<const S*>(group)[idx]));
+        }
+    }
+};
+
+template <typename T, typename I, bool ADV, int SUB, int GPW>
+__global__ __launch_bounds__(256) void jacobi_apply_lanes_any_kernel(
+    int64_t num_blocks, int64_t num_groups, gkoc_jacobi_scheme scheme, const I* __restrict__ block_ptrs,
+    const T* __restrict__ blocks, const uint8_t* __restrict__ precisions, const T* __restrict__ alpha_p,
+    const T* __restrict__ b, int64_t ldb, const T* __restrict__ beta_p, T* __restrict__ x, int64_t ldx,
+    int nrhs, int xcd_map)
+{
+    using R = real_t<T>;
+    const int lane = threadIdx.x & 63;
+    const int bo = int(scheme.block_offset);
+    const int stride = bo << scheme.group_power;          // lanes of a group that hold a row
+    const int big = lane / bo;                            // block within the group
+    const int r = lane - big * bo;
+    const int lane0 = lane - r;
+    int64_t wg = blockIdx.x;
+    if (xcd_map) {
+        const int64_t nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7;
+        const int64_t xcd = wg & 7, slot = wg >> 3;
+        wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + slot;
+    }
+    const int64_t group0 = (wg * 4 + (threadIdx.x >> 6)) * GPW;
+    T m[GPW][SUB];
+    int64_t row[GPW];
+    int bs[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int64_t group = group0 + g;
+        const int64_t blk = (group << scheme.group_power) + big;
+        const bool have = lane < stride && group < num_groups && blk < num_blocks;
+        I start = 0, end = 0;
+        if (have) {
+            start = block_ptrs[blk];
+            end = block_ptrs[blk + 1];
+        }
+        bs[g] = have && r < int(end - start) ? int(end - start) : 0;
+        row[g] = int64_t(start) + r;
+    }
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        const int64_t group = group0 + g;
+        const T* gp = blocks + scheme.group_offset * (group < num_groups ? group : num_groups - 1);
+        const int ln = lane < stride ? lane : 0;
+        int kind = 0;
+        if (precisions != nullptr && bs[g] > 0) {
+            kind = storage_kind<R>(int(precisions[(group << scheme.group_power) + big]));
+        }
+        // one storage type per group (generate gives a group ONE precision): decide once, typed loads;
+        // a caller's array that mixes types inside a group is read entry by entry
+        const unsigned long long act = __ballot(bs[g] > 0);
+        const int k0 = act ? __shfl(kind, __builtin_ctzll(act), 64) : 0;
+        const bool uniform = __ballot(bs[g] > 0 && kind != k0) == 0;
+        // every load unconditional (a conditional load is waited for before the next one is issued) and
+        // in bounds: a lane without a row reads lane 0's entries, a column past the block's last one reads the
+        // last one again; what they deliver is never used
+#define GKOC_LOAD_ENTRIES(K_)                                                                   \
+    _Pragma("unroll") for (int c = 0; c < SUB; ++c)                                             \
+    {                                                                                           \
+        m[g][c] = entry_loader<T, K_>::get(gp, ln + int64_t(c < bo ? c : bo - 1) * stride);     \
+    }
+        if (!uniform) {
+#pragma unroll
+            for (int c = 0; c < SUB; ++c) {
+                m[g][c] = load_value(kind, gp, ln + int64_t(c < bo ? c : bo - 1) * stride);
+            }
+        } else if (k0 == 0) {
+#pragma unroll
+            for (int c = 0; c < SUB; ++c) m[g][c] = gp[ln + int64_t(c < bo ? c : bo - 1) * stride];
+        } else if (k0 == 0x02) {
+            GKOC_LOAD_ENTRIES(0x02)
+        } else if (k0 == 0x11) {
+            GKOC_LOAD_ENTRIES(0x11)
+        } else if constexpr (sizeof(R) == 8) {
+            if (k0 == 0x01) {
+                GKOC_LOAD_ENTRIES(0x01)
+            } else if (k0 == 0x10) {
+                GKOC_LOAD_ENTRIES(0x10)
+            } else {
+                GKOC_LOAD_ENTRIES(0x20)
+            }
+        }
+#undef GKOC_LOAD_ENTRIES
+    }
+    T alpha = T(R(1)), beta = T(R(0));
+    if (ADV) {
+        alpha = alpha_p[0];
+        beta = beta_p[0];
+    }
+    for (int j = 0; j < nrhs; ++j) {
+        T bv[GPW], xv[GPW];
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+            bv[g] = T(R(0));
+            xv[g] = T(R(0));
+            if (bs[g] > 0) {
+                bv[g] = b[row[g] * ldb + j];
+                if (ADV && beta != T(R(0))) xv[g] = x[row[g] * ldx + j];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+            T sum = T(R(0));
+#pragma unroll
+            for (int c = 0; c < SUB; ++c) {
+                const T bc = __shfl(bv[g], lane0 + c, 64);
+                if (c < bs[g]) sum += m[g][c] * bc;
+            }
+            if (bs[g] > 0) {
+                if (ADV) {
+                    const T ax = alpha * sum;
+                    x[row[g] * ldx + j] = beta == T(R(0)) ? ax : ax + beta * xv[g];
+                } else {
+                    x[row[g] * ldx + j] = sum;
+                }
+            }
+        }
+    }
+}
+
+// true: launched (the scheme fills a wavefront per group); false: the caller's thread-per-row path
+template <typename T, typename I, bool ADV>
+bool launch_apply_lanes_any(hipStream_t st, int64_t num_blocks, gkoc_jacobi_scheme scheme, const I* block_ptrs,
+                            const T* blocks, const uint8_t* precisions, const T* alpha, const T* b, int64_t ldb,
+                            const T* beta, T* x, int64_t ldx, int64_t nrhs)
+{
+    if (!wave_group_layout(scheme) || nrhs > 0x7fffffff || b == x) return false;
+    const int64_t groups = ceildiv(num_blocks, int64_t(1) << scheme.group_power);
+#define GKOC_JAC_LANES(SUB_, GPW_)                                                                       \
+    {                                                                                                    \
+        const int64_t nwg = ceildiv(groups, 4 * GPW_);                                                   \
+        jacobi_apply_lanes_any_kernel<T, I, ADV, SUB_, GPW_><<<dim3(unsigned(nwg)), dim3(256), 0, st>>>( \
+            num_blocks, groups, scheme, block_ptrs, blocks, precisions, alpha, b, ldb, beta, x, ldx,     \
+            int(nrhs), jacobi_xcd_map(nwg));                                                             \
+    }
+    // groups per wave: what a wave keeps in flight is SUB loads of 64 stored entries per group - with half
+    // storage 128 B each; four groups for the value types of up to eight bytes, two / one for complex<double>
+    constexpr int G8 = sizeof(T) <= 8 ? 4 : 2, G16 = sizeof(T) <= 8 ? 2 : 1;
+    switch (subwarp_of(scheme)) {
+    case 1: GKOC_JAC_LANES(1, G8) break;
+    case 2: GKOC_JAC_LANES(2, G8) break;
+    case 4: GKOC_JAC_LANES(4, G8) break;
+    case 8: GKOC_JAC_LANES(8, G8) break;
+    case 16: GKOC_JAC_LANES(16, G16) break;
+    default: GKOC_JAC_LANES(32, 1) break;
+    }
+#undef GKOC_JAC_LANES
+    return true;
+}
+
 // x = M b / x = alpha M b + beta x, one thread per (row, right-hand side), blocks widened on load
 // (reference apply_block with the resolved precision, :425-470)
 template <typename T, typename I, bool ADV>
@@ -2397,6 +2587,12 @@ int launch_apply_adaptive_any(gkoc_stream_t s, int64_t num_blocks, gkoc_jacobi_s
     if (num_blocks <= 0 || nrhs <= 0) return GKOC_OK;
     GKOC_REQUIRE(block_ptrs && blocks && b && x, GKOC_E_INVALID, "null pointer");
     hipStream_t st = as_stream(s);
+    if (tune_value(GKOC_TUNE_JACOBI_LANES) != 1 &&
+        launch_apply_lanes_any<T, I, ADV>(st, num_blocks, scheme, block_ptrs, blocks, precisions, alpha, b, ldb,
+                                          beta, x, ldx, nrhs)) {
+        GKOC_LAUNCH_OK();
+        return GKOC_OK;
+    }
     I last = 0;
     GKOC_HIP(hipMemcpyAsync(&last, block_ptrs + num_blocks, sizeof(I), hipMemcpyDeviceToHost, st));
     GKOC_HIP(hipStreamSynchronize(st));

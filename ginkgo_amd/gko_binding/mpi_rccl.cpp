@@ -75,6 +75,10 @@ struct deferred_call {
     long seq = 0;                  // order of issue on its communicator: carried out in that order on every rank
     int rc = MPI_SUCCESS;
     bool done = false;
+    // round 6: MPI_Test starts the exchange in its NONBLOCKING form and looks at it again later,
+    // instead of carrying it out to the end (which waits for the peers' kernels - MPI_Test must not)
+    bool launched = false;
+    MPI_Request sub = MPI_REQUEST_NULL;      // the started exchange: one of ours (rccl / staged) or MPI's
 };
 
 struct pending {
@@ -948,11 +952,28 @@ int neighbor_routed(int route, const void* sendbuf, const int* sendcounts, const
     return rc;
 }
 
+static void deferred_ended(deferred_call& d)
+{
+    if (d.done) return;
+    PMPI_Type_free(&d.stype);
+    PMPI_Type_free(&d.rtype);
+    d.done = true;
+}
+
 // carry out one deferred call (its agreement first); g_mtx NOT held
 static void run_deferred(pending& p)
 {
     deferred_call& d = *p.call;
     if (d.done) return;
+    if (d.launched) {
+        // MPI_Test has started it: bring the started exchange to its end (MPI_Wait of this layer knows both kinds)
+        if (d.sub != MPI_REQUEST_NULL) {
+            const int rc = MPI_Wait(&d.sub, MPI_STATUS_IGNORE);
+            if (rc != MPI_SUCCESS) d.rc = rc;
+        }
+        deferred_ended(d);
+        return;
+    }
     if (p.inner != MPI_REQUEST_NULL) PMPI_Wait(&p.inner, MPI_STATUS_IGNORE);
     const int route = route_from(d.any);
     d.rc = d.which == 0
@@ -960,9 +981,65 @@ static void run_deferred(pending& p)
                                   d.rtype, d.comm, nullptr, d.n)
                : neighbor_routed(route, d.sendbuf, d.scounts, d.sdispls, d.stype, d.recvbuf, d.rcounts, d.rdispls,
                                  d.rtype, d.comm, nullptr);
-    PMPI_Type_free(&d.stype);
-    PMPI_Type_free(&d.rtype);
-    d.done = true;
+    deferred_ended(d);
+}
+
+// MPI_Test's half of the same: START the exchange (the agreement has arrived), never wait for it.  g_mtx NOT held
+static void start_deferred(deferred_call& d)
+{
+    if (d.done || d.launched) return;
+    const int route = route_from(d.any);
+    d.rc = d.which == 0
+               ? alltoallv_routed(route, d.sendbuf, d.scounts, d.sdispls, d.stype, d.recvbuf, d.rcounts, d.rdispls,
+                                  d.rtype, d.comm, &d.sub, d.n)
+               : neighbor_routed(route, d.sendbuf, d.scounts, d.sdispls, d.stype, d.recvbuf, d.rcounts, d.rdispls,
+                                 d.rtype, d.comm, &d.sub);
+    d.launched = true;
+}
+
+// has a started exchange reached its end?  Looks, never waits (a look at the stream / PMPI_Test, which also
+// drives MPI's progress engine); finishes the local part (copy back, release) when it has.  g_mtx NOT held
+static bool started_has_ended(deferred_call& d)
+{
+    if (d.sub == MPI_REQUEST_NULL) return true;
+    pending sp;
+    bool ours = false;
+    {
+        std::lock_guard<std::mutex> g(g_mtx);
+        auto it = g_pending.find(d.sub);
+        ours = it != g_pending.end();
+        if (ours) sp = it->second;
+    }
+    if (!ours) {
+        int f = 0;
+        const int rc = PMPI_Test(&d.sub, &f, MPI_STATUS_IGNORE);
+        if (rc != MPI_SUCCESS) d.rc = rc;
+        return f != 0;
+    }
+    if (sp.kind == 1) {
+        int done = 0;
+        if (gkoc_stream_query(stream(), &done) != GKOC_OK) done = 1;
+        if (!done) {
+            int flag = 0;
+            PMPI_Iprobe(MPI_ANY_SOURCE, MPI_ANY_TAG, MPI_COMM_WORLD, &flag, MPI_STATUS_IGNORE);
+            return false;
+        }
+    } else if (sp.kind == 2 && sp.inner != MPI_REQUEST_NULL) {
+        int f = 0;
+        const int rc = PMPI_Test(&sp.inner, &f, MPI_STATUS_IGNORE);
+        if (rc != MPI_SUCCESS) d.rc = rc;
+        if (!f) return false;
+        sp.inner = MPI_REQUEST_NULL;
+    }
+    {
+        std::lock_guard<std::mutex> g(g_mtx);
+        g_pending.erase(d.sub);
+        const int rc = finish(sp);       // kind 1: the stream is idle; kind 2: the copy back (local)
+        if (rc != MPI_SUCCESS) d.rc = rc;
+    }
+    PMPI_Grequest_complete(d.sub);
+    PMPI_Wait(&d.sub, MPI_STATUS_IGNORE);
+    return true;
 }
 
 static int complete_ours(MPI_Request* request, MPI_Status* status, bool* ours)
@@ -1015,22 +1092,79 @@ int MPI_Wait(MPI_Request* request, MPI_Status* status)
 int MPI_Test(MPI_Request* request, int* flag, MPI_Status* status)
 {
     if (request && *request != MPI_REQUEST_NULL) {
+        // A deferred call (and the deferred calls issued before it on its communicator: collectives are carried
+        // out in the order of issue on every rank) is STARTED here once its agreement has arrived and looked at
+        // again by later calls: MPI_Test returns flag = 0 until the started exchange has ended.  It never waits
+        // for a peer - a rank that polls MPI_Test and serves point-to-point messages in between stays live
+        // (tests/dropin/mpi_layer_test.cpp "MPI_Test does not wait for the peers").
+        std::vector<std::shared_ptr<deferred_call>> chain;
+        bool deferred = false;
         {
-            // a deferred call whose agreement is still travelling is not complete (and MPI_Test does not wait)
             std::lock_guard<std::mutex> g(g_mtx);
             auto it = g_pending.find(*request);
-            if (it != g_pending.end() && it->second.kind == 3 && !it->second.call->done &&
-                it->second.inner != MPI_REQUEST_NULL) {
-                int arrived = 0;
-                PMPI_Test(&it->second.inner, &arrived, MPI_STATUS_IGNORE);
-                if (!arrived) {
+            if (it != g_pending.end() && it->second.kind == 3 && !it->second.call->done) {
+                deferred = true;
+                const auto mine = it->second.call;
+                std::vector<pending*> order;
+                for (auto& q : g_pending) {
+                    if (q.second.kind == 3 && q.second.call->comm == mine->comm && q.second.call->seq <= mine->seq &&
+                        !q.second.call->done) {
+                        order.push_back(&q.second);
+                    }
+                }
+                std::sort(order.begin(), order.end(),
+                          [](const pending* a, const pending* b) { return a->call->seq < b->call->seq; });
+                for (pending* q : order) {
+                    if (q->inner != MPI_REQUEST_NULL) {
+                        int arrived = 0;
+                        PMPI_Test(&q->inner, &arrived, MPI_STATUS_IGNORE);      // (sets inner to null when it has)
+                        if (!arrived) {
+                            *flag = 0;
+                            return MPI_SUCCESS;
+                        }
+                    }
+                    chain.push_back(q->call);
+                }
+            }
+        }
+        if (deferred) {
+            for (auto& d : chain) {
+                start_deferred(*d);
+                if (!started_has_ended(*d)) {
+                    *flag = 0;
+                    return MPI_SUCCESS;
+                }
+                deferred_ended(*d);
+            }
+        } else {
+            // a started exchange of ours (rccl / staged): look, do not wait
+            pending sp;
+            bool ours = false;
+            {
+                std::lock_guard<std::mutex> g(g_mtx);
+                auto it = g_pending.find(*request);
+                ours = it != g_pending.end();
+                if (ours) sp = it->second;
+            }
+            if (ours && sp.kind == 1) {
+                int done = 0;
+                if (gkoc_stream_query(stream(), &done) == GKOC_OK && !done) {
+                    int f = 0;
+                    PMPI_Iprobe(MPI_ANY_SOURCE, MPI_ANY_TAG, MPI_COMM_WORLD, &f, MPI_STATUS_IGNORE);
+                    *flag = 0;
+                    return MPI_SUCCESS;
+                }
+            } else if (ours && sp.kind == 2 && sp.inner != MPI_REQUEST_NULL) {
+                int f = 0;
+                PMPI_Request_get_status(sp.inner, &f, MPI_STATUS_IGNORE);       // (does not free the request)
+                if (!f) {
                     *flag = 0;
                     return MPI_SUCCESS;
                 }
             }
         }
         bool ours = false;
-        int rc = complete_ours(request, status, &ours);   // (completing is allowed: it may block)
+        int rc = complete_ours(request, status, &ours);   // everything it would wait for has ended
         if (ours) {
             *flag = 1;
             return rc;

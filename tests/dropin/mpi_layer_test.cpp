@@ -138,6 +138,58 @@ int main(int argc, char** argv)
         CHECK(ok, nonblocking == 0 ? "all-to-all-v" : nonblocking == 1 ? "nonblocking all-to-all-v" : "... data");
     }
     lap("all-to-all-v x 3");
+    // MPI_Test does not wait for the peers.  Even ranks post the exchange and then POLL it with
+    // MPI_Test while serving a synchronous point-to-point message of their odd neighbour; odd ranks post the
+    // exchange, send that message and only then wait.  An MPI_Test that carried the exchange out to its end would
+    // sit in the device exchange until the neighbour's kernel starts - which it does in the neighbour's MPI_Wait,
+    // behind an MPI_Ssend that only returns once this rank has received: a deadlock in a legal program.
+    {
+        std::vector<int> c(size, 4), d(size);
+        for (int p = 0; p < size; ++p) d[p] = 4 * p;
+        dev_array<double> s(size_t(size) * 4), r(size_t(size) * 4);
+        std::vector<double> hs(size_t(size) * 4);
+        for (int p = 0; p < size; ++p) {
+            for (int i = 0; i < 4; ++i) hs[4 * p + i] = 7.0 * rank + 0.5 * p + 0.01 * i;
+        }
+        s.put(hs);
+        r.put(std::vector<double>(size_t(size) * 4, -3.0));
+        MPI_Request q;
+        MPI_Ialltoallv(s.p, c.data(), d.data(), MPI_DOUBLE, r.p, c.data(), d.data(), MPI_DOUBLE, MPI_COMM_WORLD, &q);
+        long token = 0;
+        int tests = 0;
+        if (rank % 2 == 0) {
+            const int partner = rank + 1 < size ? rank + 1 : -1;
+            bool got = partner < 0;
+            int done = 0;
+            while (!done || !got) {
+                if (!done) {
+                    MPI_Test(&q, &done, MPI_STATUS_IGNORE);
+                    ++tests;
+                }
+                if (!got) {
+                    int there = 0;
+                    MPI_Iprobe(partner, 77, MPI_COMM_WORLD, &there, MPI_STATUS_IGNORE);
+                    if (there) {
+                        MPI_Recv(&token, 1, MPI_LONG, partner, 77, MPI_COMM_WORLD, MPI_STATUS_IGNORE);
+                        got = true;
+                    }
+                }
+            }
+            CHECK(partner < 0 || token == 1000 + partner, "the point-to-point message served between two MPI_Test");
+        } else {
+            token = 1000 + rank;
+            MPI_Ssend(&token, 1, MPI_LONG, rank - 1, 77, MPI_COMM_WORLD);
+            MPI_Wait(&q, MPI_STATUS_IGNORE);
+        }
+        auto h = r.get();
+        bool ok = true;
+        for (int p = 0; p < size; ++p) {
+            for (int i = 0; i < 4; ++i) ok = ok && h[4 * p + i] == 7.0 * p + 0.5 * rank + 0.01 * i;
+        }
+        CHECK(ok, "MPI_Test does not wait for the peers: the polled exchange delivered");
+        if (rank == 0 && std::getenv("GKOC_MPI_VERBOSE")) std::fprintf(stderr, "[mpi_layer_test] rank 0 polled %d times\n", tests);
+    }
+    lap("polled all-to-all-v beside a synchronous send");
     // a derived datatype that is freed BEFORE the wait (core/distributed/row_gatherer.cpp apply_async: the
     // contiguous type of a multi-column vector lives in the scope that posts the exchange)
     {

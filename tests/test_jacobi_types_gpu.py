@@ -195,3 +195,80 @@ def test_larger_problems_against_the_oracle(gexec, oracle, vt, max_bs):
         bitwise.append((got_cond.tobytes() == want_cond.tobytes(), x.cpu().numpy().tobytes() == want_x.tobytes()))
     if vt == "f32":
         assert all(c and x_ for c, x_ in bitwise), bitwise
+
+
+@pytest.mark.parametrize("max_bs", [1, 3, 8, 13, 32])
+@pytest.mark.parametrize("vt", ["f32", "c64", "c128"])
+def test_lane_layout_equals_the_thread_per_row_kernels_bit_for_bit(gexec, vt, max_bs):
+    """round 6: jacobi_apply_lanes_any_kernel (lane = (block, row) of a storage group, blocks in registers,
+    b by shuffle) against the round-5 thread-per-row kernels (GKOC_TUNE_JACOBI_LANES = 1) on the same blocks:
+    adaptive storage (x = M b, x = alpha M b + beta x, beta = 0 with NaN in x) and, for complex values, the
+    full-storage simple_apply / apply - the same operations in the same order, so the same bits."""
+    from ginkgo_amd._lib import call, lib
+    from ginkgo_amd.preconditioner import compute_storage_scheme
+    ex = gexec
+    dt, rdt, _, _ = DT[vt]
+    rp, ci, vals, b = _problem(vt, max_bs, 1500, 77 * max_bs + len(vt))
+    n, nrhs = len(rp) - 1, b.shape[1]
+    d_rp, d_ci, d_v, d_b = (ex.to_device(a) for a in (rp, ci, vals, b))
+    d_bp = ex.zeros((n + 1,), torch.int32)
+    nb_c = C.c_int64(0)
+    call(f"gkoc_jacobi_find_blocks_{vt}_i32", ex.stream, n, d_rp, d_ci, C.c_uint32(max_bs), C.byref(nb_c), d_bp)
+    nb = nb_c.value
+    d_bp = d_bp[:nb + 1].contiguous()
+    scheme = compute_storage_scheme(max_bs, 64)
+    gs = 1 << scheme.group_power
+    storage = ((nb + gs - 1) // gs) * scheme.group_offset
+    blocks = ex.zeros((storage,), dt)
+    prec = ex.to_device(np.resize(np.asarray([0xff, 0x01, 0xff, 0x20, 0xff, 0x00, 0x11, 0x02], np.uint8), nb))
+    cond = ex.zeros((nb,), rdt)
+    call(f"gkoc_jacobi_generate_adaptive_{vt}_i32", ex.stream, n, d_rp, d_ci, d_v, nb, C.c_uint32(max_bs), scheme,
+         d_bp, C.c_float(1e-2) if rdt == torch.float32 else C.c_double(1e-2), prec, cond, blocks)
+    full = ex.zeros((storage,), dt)
+    if vt != "f32":
+        call(f"gkoc_jacobi_generate_{vt}_i32", ex.stream, n, d_rp, d_ci, d_v, nb, C.c_uint32(max_bs), scheme, d_bp,
+             full, None)
+    np_dt = b.dtype
+    alpha = ex.to_device(np.asarray([1.5], np_dt))
+    beta = ex.to_device(np.asarray([-0.75], np_dt))
+    zero = ex.to_device(np.asarray([0.0], np_dt))
+    x0 = np.ascontiguousarray(b[::-1]).copy()
+
+    def products():
+        out = []
+        for al, be, start in ((None, None, None), (alpha, beta, x0), (alpha, zero, np.full_like(x0, np.nan))):
+            x = ex.zeros((n, nrhs), dt) if start is None else ex.to_device(start.copy())
+            call(f"gkoc_jacobi_apply_adaptive_{vt}_i32", ex.stream, nb, C.c_uint32(max_bs), scheme, d_bp, blocks,
+                 prec, al, d_b, nrhs, be, x, nrhs, nrhs)
+            out.append(x.cpu().numpy().tobytes())
+            # one column with a stride (ldb = nrhs, one right-hand side)
+            x1 = ex.zeros((n, nrhs), dt) if start is None else ex.to_device(start.copy())
+            call(f"gkoc_jacobi_apply_adaptive_{vt}_i32", ex.stream, nb, C.c_uint32(max_bs), scheme, d_bp, blocks,
+                 prec, al, d_b, nrhs, be, x1, nrhs, 1)
+            out.append(x1.cpu().numpy().tobytes())
+            if vt != "f32":
+                x2 = ex.zeros((n, nrhs), dt) if start is None else ex.to_device(start.copy())
+                if al is None:
+                    call(f"gkoc_jacobi_simple_apply_{vt}_i32", ex.stream, nb, C.c_uint32(max_bs), scheme, d_bp, full,
+                         d_b, nrhs, x2, nrhs, nrhs)
+                else:
+                    call(f"gkoc_jacobi_apply_{vt}_i32", ex.stream, nb, C.c_uint32(max_bs), scheme, d_bp, full, al,
+                         d_b, nrhs, be, x2, nrhs, nrhs)
+                out.append(x2.cpu().numpy().tobytes())
+        ex.synchronize()
+        return out
+
+    key = 15    # GKOC_TUNE_JACOBI_LANES
+    try:
+        lib().gkoc_tune_set(C.c_int(key), C.c_int64(1))
+        old = products()
+        lib().gkoc_tune_set(C.c_int(key), C.c_int64(0))
+        new = products()
+    finally:
+        lib().gkoc_tune_set(C.c_int(key), C.c_int64(0))
+    assert [a == b_ for a, b_ in zip(old, new)] == [True] * len(old)
+    assert not np.isnan(np.frombuffer(new[4], dtype=np_dt).view(rdt_np(rdt))).any()
+
+
+def rdt_np(rdt):
+    return np.float32 if rdt == torch.float32 else np.float64
