@@ -20,6 +20,8 @@
 // uses two kernels and two blocking 1-byte copies).
 #include <cmath>
 
+#include <chrono>
+
 #include "common.hpp"
 #include "elementwise.hpp"
 #include "fused.hpp"
@@ -329,11 +331,22 @@ int launch_residual_norm(gkoc_stream_t s, int64_t cols, const T* tau,
                 cols, tau, orig_tau, goal, id, set_finalized != 0, stop, const_cast<uint8_t*>(pinned));
             GKOC_LAUNCH_OK();
             GKOC_TRY(behind());
+            // The host is usually a whole iteration AHEAD of the device here (the launches of an iteration take
+            // 35 us, its kernels 1.4 ms on 16.7 M rows), so the answer is an iteration away: poll by the CLOCK.
+            // (Round 5 gave up after 2^22 looks = 1 ms and let the stream drain - which, with cg::step_1
+            // enqueued behind the criterion, waits for that step too and leaves the device idle until the host
+            // is back with the product: 40 us per iteration, profiles/r06/r06_ginkgo_api_timeline.txt.)
+            const auto poll_start = std::chrono::steady_clock::now();
+            bool drained = false;
             for (long spins = 0; pinned[0] == 0xFF || pinned[1] == 0xFF; ++spins) {
-                if (spins == (long(1) << 22)) {
-                    // not there after ~10 ms of polling: let the stream drain (the stores are visible then)
+                if ((spins & 0xfff) != 0xfff) continue;
+                const double waited =
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - poll_start).count();
+                if (!drained && waited > 2.0) {
+                    // not there after two seconds of polling: let the stream drain (the stores are visible then)
                     GKOC_HIP(hipStreamSynchronize(as_stream(s)));
-                } else if (spins > (long(1) << 22) + 1000) {
+                    drained = true;
+                } else if (drained && waited > 2.5) {
                     set_last_error("residual_norm: the criterion's flags did not arrive in pinned memory");
                     return GKOC_E_INVALID;
                 }

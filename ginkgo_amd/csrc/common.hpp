@@ -76,6 +76,12 @@ int stream_ticket(hipStream_t st, unsigned** word);
 // csr::spmv's memory of which segments of a matrix hold very long rows (csr_spmv.hip): forgotten when the
 // row-pointer array is freed
 void csr_long_rows_forget(const void* ptr);
+// csr::spmv / advanced_spmv on complex values through the row-segment kernel of the real types
+// (csr_spmv.hip; complex_blas.hip's gkoc_ccsr_spmv_* calls it).  GKOC_E_NOT_SUPPORTED: the arrays are not
+// aligned for its loads - the caller keeps its thread-per-row kernel for that.
+template <typename T, typename I>
+int csr_spmv_complex(gkoc_stream_t s, int64_t n_rows, int64_t nrhs, const I* row_ptrs, const I* col_idxs,
+                     const T* vals, const T* alpha, const T* b, int64_t ldb, const T* beta, T* c, int64_t ldc);
 // What a wave (block) that reads data behind a gate word pays before its first read (csr_spmv_pipe.hpp GATE,
 // fused.hpp step_gate_enter): 0 = the cheap gate (an agent-scope acquire only if it had to wait), 1 = every
 // such wave an agent-scope acquire, 2 = every one a SYSTEM-scope acquire.  A communicator that has a peer on

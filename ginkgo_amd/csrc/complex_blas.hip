@@ -620,6 +620,13 @@ GKOC_DEF_CABS(gkoc_c64, c64, float)
     {                                                                                                       \
         if (rows <= 0 || nrhs <= 0) return GKOC_OK;                                                         \
         GKOC_REQUIRE((alpha == nullptr) == (beta == nullptr), GKOC_E_INVALID, "alpha and beta go together");\
+        /* the row-segment kernel of the real types (csr_spmv.hip) unless the arrays are not aligned for   \
+           it or GKOC_TUNE_CCSR_THREAD_PER_ROW asks for round 5's kernel (A/B runs) */                      \
+        if (tune_value(GKOC_TUNE_CCSR_THREAD_PER_ROW) == 0) {                                               \
+            const int rc_ = csr_spmv_complex<P, I>(s, rows, nrhs, row_ptrs, col_idxs, vals, alpha, x, ldx,  \
+                                                   beta, y, ldy);                                           \
+            if (rc_ != GKOC_E_NOT_SUPPORTED) return rc_;                                                    \
+        }                                                                                                   \
         const dim3 g(grid_of(rows * nrhs));                                                                 \
         if (alpha) {                                                                                        \
             cx_csr_spmv_kernel<R, I, true><<<g, dim3(256), 0, as_stream(s)>>>(                              \

@@ -405,7 +405,14 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
             seg_skip)
     // XCD-contiguous wave order needs enough waves per XCD to keep the in-order
     // window argument valid; below that the plain order is used
-    const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves_1 >= 8 * 1024) ? 1 : 0;
+    // ... and is the default for a matrix WITH HUB ROWS (flagged segments): its gathers go all over b, and with
+    // one contiguous eighth of the rows per XCD an L2 holds the lines of its own eighth instead of a share of
+    // everybody's.  Heavy-tailed stand-in 246.6 -> 226.0 us; the stencils lose 0.5-3 % with it (27-pt 256^3
+    // 982 -> 1003, 5-pt 4096^2 274 -> 282) and keep the plain order (profiles/r06/r06_waves_per_workgroup.txt).
+    // GKOC_TUNE_CSR_XCD_MAP: 1 = always, 2 = never.
+    const int64_t xcd_choice = tune_value(GKOC_TUNE_CSR_XCD_MAP);
+    const int xcd_map =
+        ((xcd_choice == 1 || (xcd_choice == 0 && lng.count > 0)) && n_waves_1 >= 8 * 1024) ? 1 : 0;
     // Measured and rejected on the Flan-like matrix and on L256 (profiles/r02_experiments,
     // profiles/r02_flan_pmc): 16 / 32 KB rings with 2-4 load groups (fewer resident waves: 299-475 us
     // against 288), 32-row segments (294), one or two entries per lane and load so that neighbouring
@@ -419,6 +426,10 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     // 251 -> 246 us, 8.4 M 510 -> 495, 16.8 M 985 -> 953; the Flan-like matrix (81 per row) 272 both;
     // 5-pt 4096^2 397 -> 405.
     constexpr int PE = sizeof(T) == 8 ? 2 : 4, PU = sizeof(T) == 8 ? 3 : 2;
+    // (round 6 also tried two / four / eight WAVES per workgroup, every wave with its own segments and ring - a
+    // grid of one-wave workgroups of short-row segments is paced by the dispatcher: 3.5 ns per wave chip-wide,
+    // profiles/r06_irregular_pmc.txt.  The pace is per wave, not per workgroup: heavy-tailed stand-in 247 / 241 /
+    // 246 / 299 us, every stencil 10-40 % slower; profiles/r06/r06_waves_per_workgroup.txt.)
     if (vec_ok) {
         // below 2 M rows the grid is a few rounds deep and the wider layout of rounds 1-2 is as fast or
         // faster (64^3: 18.4 against 20.7 us; 1 - 2 M rows: equal); key 1 forces it for A/B runs
@@ -675,7 +686,7 @@ int launch_csr_dot(gkoc_stream_t s, int64_t n, const I* row_ptrs,
     const bool vec_ok =
         reinterpret_cast<uintptr_t>(vals) % (4 * sizeof(T)) == 0 &&
         reinterpret_cast<uintptr_t>(col_idxs) % (4 * sizeof(I)) == 0;  // E = 4 below
-    const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) != 0 && n_waves >= 8 * 1024) ? 1 : 0;
+    const int xcd_map = (tune_value(GKOC_TUNE_CSR_XCD_MAP) == 1 && n_waves >= 8 * 1024) ? 1 : 0;
     constexpr int PE = sizeof(T) == 8 ? 2 : 4, PU = sizeof(T) == 8 ? 3 : 2;   // as in launch_csr
     // four waves per SIMD, like the plain product: the dot's registers (and, since round 6, the loop over runs
     // of unflagged segments) had taken the double / int32 kernel to 133 VGPRs = three waves - 985 -> 1107 us on
@@ -839,6 +850,64 @@ __global__ __launch_bounds__(64) void sort_rows_kernel(
 }
 
 }  // namespace
+
+// Complex values (round 6).  The product of round 5 was one thread per row walking global memory: 15.0 ms on
+// the 27-pt 256^3 matrix with complex<double> values = 0.63 TB/s, 78 % of a CbGmres<complex<double>> iteration
+// (profiles/r06/r06_cb_gmres_complex_kernel_stats.csv).  The row-segment kernel is a template on the value
+// type and needs nothing a complex value does not have: products (textbook expression) go to the LDS ring as
+// 16 / 8-byte entries, lane = row adds them in k order - y(row) = sum_k a(row, k) b(col_k) in the reference's
+// order, (alpha a) b on top of beta y for the advanced form (reference/matrix/csr_kernels.cpp:53-112).
+// One entry per lane and load for complex<double> (16-byte value loads, four load groups in flight), two for
+// complex<float>; 8 KB ring.  Several right-hand sides: one pass per column (the kernel's nrhs loop).
+template <typename T, typename I>
+int csr_spmv_complex(gkoc_stream_t s, int64_t n_rows, int64_t nrhs, const I* row_ptrs, const I* col_idxs,
+                     const T* vals, const T* alpha, const T* b, int64_t ldb, const T* beta, T* c, int64_t ldc)
+{
+    if (n_rows <= 0 || nrhs <= 0) return GKOC_OK;
+    GKOC_REQUIRE(row_ptrs && col_idxs && vals && b && c, GKOC_E_INVALID, "null pointer");
+    GKOC_REQUIRE(nrhs <= 0x7fffffff, GKOC_E_NOT_SUPPORTED, "more than 2^31 right-hand sides");
+    constexpr int E = sizeof(T) == 16 ? 1 : 2, U = sizeof(T) == 16 ? 4 : 2;
+    constexpr int RINGV = 8192 / sizeof(T);
+    if (reinterpret_cast<uintptr_t>(vals) % (E * sizeof(T)) != 0 ||
+        reinterpret_cast<uintptr_t>(col_idxs) % (E * sizeof(I)) != 0 ||
+        reinterpret_cast<uintptr_t>(b) % sizeof(T) != 0 || reinterpret_cast<uintptr_t>(c) % sizeof(T) != 0) {
+        return GKOC_E_NOT_SUPPORTED;
+    }
+    const int64_t n_seg = ceildiv(n_rows, 64);
+    const int spw = n_seg >= 65536 ? 2 : 1;
+    const int64_t n_waves = ceildiv(n_seg, spw);
+    GKOC_REQUIRE(n_waves < (int64_t(1) << 31), GKOC_E_NOT_SUPPORTED, "more than 2^31 row segments");
+    const dim3 grid(static_cast<unsigned>(n_waves)), block(64);
+    // four waves per SIMD where the kernel is within a few registers of it (complex<double>, 32-bit indices: 132)
+    constexpr int CX_WPS = sizeof(I) == 4 ? 4 : 1;
+#define GKOC_LAUNCH_CX(ADV_, MODE_)                                                                 \
+    csr_spmv_pipe3_kernel<T, I, ADV_, 64, E, U, RINGV, (ADV_ ? 1 : CX_WPS), MODE_><<<grid, block, 0, as_stream(s)>>>( \
+        n_rows, n_seg, spw, row_ptrs, col_idxs, vals, b, ldb, c, ldc, static_cast<int>(nrhs), alpha, beta)
+    if (alpha != nullptr) {
+        GKOC_REQUIRE(beta != nullptr, GKOC_E_INVALID, "alpha and beta go together");
+        if (spw == 2) {
+            GKOC_LAUNCH_CX(true, 0x2000);
+        } else {
+            GKOC_LAUNCH_CX(true, 0x1000);
+        }
+    } else if (spw == 2) {
+        GKOC_LAUNCH_CX(false, 0x2000);
+    } else {
+        GKOC_LAUNCH_CX(false, 0x1000);
+    }
+#undef GKOC_LAUNCH_CX
+    GKOC_LAUNCH_OK();
+    return GKOC_OK;
+}
+#define GKOC_INST_CX(T, I)                                                                                       \
+    template int csr_spmv_complex<T, I>(gkoc_stream_t, int64_t, int64_t, const I*, const I*, const T*, const T*, \
+                                        const T*, int64_t, const T*, T*, int64_t);
+GKOC_INST_CX(gkoc_c128, int32_t)
+GKOC_INST_CX(gkoc_c128, int64_t)
+GKOC_INST_CX(gkoc_c64, int32_t)
+GKOC_INST_CX(gkoc_c64, int64_t)
+#undef GKOC_INST_CX
+
 }  // namespace gkoc
 
 using namespace gkoc;

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                         for (int t = 0; t < DEFER; ++t) ys[t] = t == kseg ? sum : ys[t];
                     } else if (lane < ROWS && row < n_rows) {
                         const int64_t orow = GATE && row >= out_jump_at ? row + out_jump : row;
-                        if (ABL & 32) {
+                        if constexpr ((ABL & 32) != 0) {
                             __builtin_nontemporal_store(sum, &c[orow * ldc + j]);
                         } else {
                             c[orow * ldc + j] = sum;

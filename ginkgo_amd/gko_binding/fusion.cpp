@@ -185,6 +185,28 @@ thread_local const void* last_norm_of = nullptr;      // the last single-column 
 thread_local void* last_norm_dest = nullptr;
 thread_local int64_t hits_step1 = 0;
 
+// csr::spmv(A, p -> q) that leaves <p, q> where the dot product behind it will be asked to put it (by-product
+// mode, round 6).  Ginkgo's Cg calls A->apply(p, q) and then p->compute_conj_dot(q, beta) with nothing in between
+// (core/solver/cg.cpp:164-167).  Once THIS solve has shown exactly that - csr::spmv(A, b -> c) as one entry into
+// the backend and compute_dot(b, c -> dest) as the next -, the next csr::spmv with the same operands runs the
+// library's one-pass form (gkoc_x_csr_spmv_dot_*: c has the bits of the plain product, the sum takes the fused
+// kernel's fixed tree) and writes the sum straight to `dest`; the dot product that follows finds its work done
+// and launches nothing.  dest's last reader was the previous iteration's step_2, so writing it one call early
+// is not observable through the solver.  Forgotten with everything else that is learned (forget_learned).
+struct spmv_dot_shape {
+    bool valid = false;
+    int vt = 0, it = 0;
+    gkoc_stream_t s = nullptr;
+    int64_t n = 0;
+    const void *row_ptrs = nullptr, *cols = nullptr, *vals = nullptr, *b = nullptr;
+    void* c = nullptr;
+    void* dest = nullptr;
+};
+thread_local spmv_dot_shape learned_spmv;     // confirmed in this solve
+thread_local spmv_dot_shape last_spmv;        // the product that was this thread's last writing entry (a candidate)
+thread_local uint64_t last_spmv_epoch = 0;
+thread_local int64_t hits_spmv_dot = 0;
+
 void publish()
 {
     deferred_state = held.stage | (held.norm_of ? 4 : 0) | (bp_dot.x ? 8 : 0) | (last_step_2.r ? 16 : 0) |
@@ -467,6 +489,8 @@ void forget_learned()
 {
     learned.valid = false;
     learned_step1.valid = false;
+    learned_spmv.valid = false;
+    last_spmv.valid = false;
     step1_is_ahead = false;
     last_dot_dest = nullptr;
     last_norm_of = nullptr;
@@ -665,6 +689,62 @@ bool jacobi_apply_with_dot(int vt, int it, int dev, gkoc_stream_t s, int64_t num
     return true;
 }
 
+// csr::spmv(A, b -> c), one column, square A (by-product mode; the caller has been through stream_of())
+bool spmv_with_dot(int vt, int it, int dev, gkoc_stream_t s, int64_t n, const void* row_ptrs, const void* cols,
+                   const void* vals, const void* b, void* c)
+{
+    last_spmv.valid = false;
+    if (mode() != 0 || anticipate_level() != 1 || n <= 0 || b == c) return false;
+    spmv_dot_shape now;
+    now.valid = true;
+    now.vt = vt;
+    now.it = it;
+    now.s = s;
+    now.n = n;
+    now.row_ptrs = row_ptrs;
+    now.cols = cols;
+    now.vals = vals;
+    now.b = b;
+    now.c = c;
+    const spmv_dot_shape f = learned_spmv;
+    if (f.valid && f.vt == vt && f.it == it && f.s == s && f.n == n && f.row_ptrs == row_ptrs && f.cols == cols &&
+        f.vals == vals && f.b == b && f.c == c && f.dest != nullptr && f.dest != b && f.dest != c) {
+        const size_t work = gkoc_x_workspace_bytes(n, vt == 0 ? 8 : 4);
+        side_block* sb = side_for(dev, s, work);
+        if (sb && sb->work >= work) {
+            char* wk = sb->p + 128 + sb->work;
+            int rc = GKOC_E_NOT_SUPPORTED;
+#define CASE(VT, IT, T, I, TN, IN)                                                                          \
+    if (vt == VT && it == IT) {                                                                             \
+        rc = gkoc_x_csr_spmv_dot_##TN##_##IN(s, n, static_cast<const I*>(row_ptrs),                         \
+                                             static_cast<const I*>(cols), static_cast<const T*>(vals),      \
+                                             static_cast<const T*>(b), static_cast<T*>(c),                  \
+                                             static_cast<T*>(f.dest), wk, sb->work);                        \
+    }
+            GKOC_FUSION_TYPES(CASE)
+#undef CASE
+            if (rc == GKOC_OK) {
+                bp_dot.x = b;
+                bp_dot.y = c;
+                bp_dot.at = f.dest;
+                bp_dot.vt = vt;
+                bp_dot.n = n;
+                bp_dot.s = s;
+                chain_epoch = last_entry_epoch;
+                publish();
+                ++hits_spmv_dot;
+                now.dest = f.dest;
+                last_spmv = now;                 // (the dot product behind it confirms the shape again)
+                last_spmv_epoch = last_entry_epoch;
+                return true;
+            }
+        }
+    }
+    last_spmv = now;
+    last_spmv_epoch = last_entry_epoch;
+    return false;
+}
+
 // A call that only READS vectors (a reduction into `result`) is about to launch: what is held is
 // launched, by-products stay unless the result overwrites something they belong to.
 void launch_deferred_for_read(const void* result)
@@ -680,6 +760,19 @@ bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y,
 {
     if (deferred_state != 0 && held.stage == 0) chain_intact_for_read();
     last_dot_dest = result;
+    if (last_spmv.valid) {
+        // is this the dot product of the operands of the product that was the last entry into the backend?
+        const spmv_dot_shape t = last_spmv;
+        last_spmv.valid = false;
+        const bool next = backend_epoch.load(std::memory_order_acquire) == last_spmv_epoch;
+        if (next && t.vt == vt && t.s == s && t.n == n && ((x == t.b && y == t.c) || (x == t.c && y == t.b)) &&
+            result != x && result != y) {
+            learned_spmv = t;
+            learned_spmv.dest = result;
+        } else if (learned_spmv.valid && (t.b == learned_spmv.b || t.c == learned_spmv.c)) {
+            learned_spmv.valid = false;      // the product was not followed by its dot product this time
+        }
+    }
     if (held.stage == 0 && bp_dot.x != nullptr && bp_dot.vt == vt && bp_dot.s == s && bp_dot.n == n &&
         ((x == bp_dot.x && y == bp_dot.y) || (x == bp_dot.y && y == bp_dot.x)) && result != x &&
         result != y) {
@@ -810,6 +903,11 @@ extern "C" void gko_cdna4_byproduct_hits(int64_t* norms, int64_t* dots)
 extern "C" void gko_cdna4_anticipated_steps(int64_t* steps)
 {
     if (steps) *steps = gko::cdna4::hits_step1;
+}
+// csr::spmv calls of the calling thread that also left <b, c> for the dot product behind them
+extern "C" void gko_cdna4_spmv_dot_hits(int64_t* products)
+{
+    if (products) *products = gko::cdna4::hits_spmv_dot;
 }
 extern "C" void gko_cdna4_anticipated_applies(int64_t* applies)
 {

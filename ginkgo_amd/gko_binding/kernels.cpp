@@ -106,8 +106,19 @@ namespace csr {
     {                                                                           \
         note_written_vector(c->get_const_values());                             \
         note_matrix_arrays(a->get_const_values(), a->get_const_col_idxs());     \
+        const auto st_ = stream_of(exec);                                       \
+        if (cols(c) == 1 && ld(b) == 1 && ld(c) == 1 &&                         \
+            a->get_size()[0] == a->get_size()[1] &&                             \
+            cdna4::spmv_with_dot(cdna4::vt_of<T>(), cdna4::it_of<I>(),          \
+                                 exec->get_device_id(), st_, rows(c),           \
+                                 a->get_const_row_ptrs(),                       \
+                                 a->get_const_col_idxs(),                       \
+                                 a->get_const_values(), b->get_const_values(),  \
+                                 c->get_values())) {                            \
+            return; /* the product and <b, c> for the dot product behind it */  \
+        }                                                                       \
         GKOC_CALL(gkoc_csr_spmv_##TN##_##IN(                                    \
-            stream_of(exec), a->get_size()[0], a->get_size()[1],                \
+            st_, a->get_size()[0], a->get_size()[1],                            \
             a->get_const_row_ptrs(), a->get_const_col_idxs(),                   \
             a->get_const_values(), b->get_const_values(), ld(b),                \
             c->get_values(), ld(c), cols(c)));                                  \

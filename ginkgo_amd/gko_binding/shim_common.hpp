@@ -77,6 +77,10 @@ bool jacobi_apply_with_dot(int vt, int it, int dev, gkoc_stream_t s, int64_t num
                            gkoc_jacobi_scheme scheme, const void* block_ptrs, const void* blocks,
                            const void* b, int64_t n, void* z);
 void launch_deferred_for_read(const void* result);
+// round 6: csr::spmv(A, b -> c) that also leaves <b, c> where the dot product this solve has shown to follow it
+// will be asked to put it (fusion.cpp); false: the caller runs the plain product
+bool spmv_with_dot(int vt, int it, int dev, gkoc_stream_t s, int64_t n, const void* row_ptrs, const void* cols,
+                   const void* vals, const void* b, void* c);
 // round 6 (fusion.cpp): the criterion's entry runs the cg::step_1 this solve has shown to follow it
 bool criterion_then_step_1(int vt, gkoc_stream_t s, const void* tau, const void* orig_tau, double goal,
                            uint8_t stopping_id, bool set_finalized, bool implicit, uint8_t* stop, uint8_t* flags,

@@ -152,7 +152,8 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
 /* Process-wide tuning switches (defaults chosen by measurement; the
  * environment variable GKOC_TUNE_<key> overrides the default).  Results never
  * depend on them. */
-#define GKOC_TUNE_CSR_XCD_MAP 0    /* 1: each XCD walks one contiguous eighth of the rows (default 0) */
+#define GKOC_TUNE_CSR_XCD_MAP 0    /* each XCD walks one contiguous eighth of the rows: 0 (default) for matrices with
+                                      hub rows (flagged segments) only, 1 always, 2 never */
 #define GKOC_TUNE_JACOBI_XCD_MAP 1 /* same for the block-Jacobi apply                     */
 #define GKOC_TUNE_JACOBI_MFMA 3     /* block-Jacobi(8) apply, several right-hand sides, on the f64 matrix cores
                                       (fused multiply-adds: ~5e-16 off the reference's bits): 0 never,
@@ -209,6 +210,8 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
 #define GKOC_TUNE_JACOBI_LANES 15    /* block-Jacobi apply for float / complex values and adaptive storage of those:
                                       0 (default) lane = (block, row) of a storage group, 1: the thread-per-row
                                       kernels of round 5 (A/B runs) */
+#define GKOC_TUNE_CCSR_THREAD_PER_ROW 16 /* csr::spmv on complex values: 0 (default) the row-segment kernel of the real
+                                      types, 1: one thread per row (round 5; A/B runs) */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,

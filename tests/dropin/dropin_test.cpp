@@ -64,6 +64,7 @@ using Dense = gko::matrix::Dense<vt>;
 extern "C" void gko_cdna4_byproduct_hits(int64_t* norms, int64_t* dots);
 extern "C" void gko_cdna4_anticipated_applies(int64_t* applies);
 extern "C" void gko_cdna4_anticipated_steps(int64_t* steps);
+extern "C" void gko_cdna4_spmv_dot_hits(int64_t* products);
 static int failures = 0;
 template <typename T>
 struct type_tag {
@@ -498,10 +499,16 @@ int main(int argc, char** argv)
                 // asked to put them last time.  Same iterations, same solution; a logger that enters the
                 // backend in between (h_by above) keeps the prediction from ever being learned.
                 int it_st = 0;
-                int64_t s0 = 0, s1 = 0, s2 = 0;
+                int64_t s0 = 0, s1 = 0, s2 = 0, p0 = 0, p1 = 0, p2 = 0;
                 gko_cdna4_anticipated_steps(&s0);
+                gko_cdna4_spmv_dot_hits(&p0);
                 auto st = run(0, nullptr, it_st);
                 gko_cdna4_anticipated_steps(&s1);
+                gko_cdna4_spmv_dot_hits(&p1);
+                std::cout << "  by-products: " << (p1 - p0) << " of " << it_st
+                          << " products A p also left <p, q> where the dot product behind them wanted it" << std::endl;
+                CHECK(p1 - p0 >= it_st - 3,
+                      "CG with by-products: from the second iteration on csr::spmv leaves <p, q> for the dot product");
                 std::cout << "  anticipated: " << (s1 - s0) << " of " << it_st
                           << " cg::step_1 calls had been run behind the criterion's kernel" << std::endl;
                 CHECK(s1 - s0 >= it_st - 4 && it_st == it_off && rel_err(st.first.get(), off.first.get()) < 1e-12,
@@ -510,7 +517,9 @@ int main(int argc, char** argv)
                 int it_2 = 0;
                 auto only_z = run(0, nullptr, it_2);
                 gko_cdna4_anticipated_steps(&s2);
+                gko_cdna4_spmv_dot_hits(&p2);
                 gkoc_tune_set(GKOC_TUNE_ANTICIPATE, 1);
+                CHECK(p2 == p1, "GKOC_TUNE_ANTICIPATE=2: csr::spmv stays the plain product");
                 CHECK(s2 == s1 && it_2 == it_off && rel_err(only_z.first.get(), off.first.get()) < 1e-12,
                       "GKOC_TUNE_ANTICIPATE=2: only the block-Jacobi application is anticipated");
             }

@@ -305,3 +305,85 @@ def test_block_jacobi_complex(gexec, tn, it, max_bs, nrhs):
     with pytest.raises(NotSupported):
         call("gkoc_jacobi_generate_" + suf, gexec.stream, n, drp, dci, dv, nb, C.c_uint32(33), scheme, dptr,
              blocks, None)
+
+
+@pytest.mark.parametrize("tn", ["c128", "c64"])
+@pytest.mark.parametrize("it", ["i32", "i64"])
+@pytest.mark.parametrize("shape", ["stencil", "ragged"])
+def test_csr_spmv_complex_row_segment_kernel(gexec, tn, it, shape):
+    """round 6: csr::spmv / advanced_spmv on complex values through the row-segment kernel of the real types
+    (csrc/csr_spmv.hip csr_spmv_complex) against scipy on the same matrix (reference/matrix/csr_kernels.cpp:53-112:
+    the row sum in storage order) and against round 5's thread-per-row kernel (GKOC_TUNE_CCSR_THREAD_PER_ROW = 1):
+    empty rows, a row of 5000 entries (the cooperative path), rows that do not fill the last segment, 1 and 3
+    right-hand sides with a stride, beta = 0 on NaN."""
+    import scipy.sparse as sp
+    import torch
+    from ginkgo_amd._lib import call, lib
+    ct, rt, tol = CT[tn]
+    rng = np.random.default_rng(11 + len(shape))
+    if shape == "stencil":
+        g = 23
+        n = g ** 3
+        idx = np.arange(n).reshape(g, g, g)
+        rows_l, cols_l = [], []
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    src = idx[max(0, -dz):g - max(0, dz), max(0, -dy):g - max(0, dy), max(0, -dx):g - max(0, dx)]
+                    dst = idx[max(0, dz):g - max(0, -dz), max(0, dy):g - max(0, -dy), max(0, dx):g - max(0, -dx)]
+                    rows_l.append(src.ravel())
+                    cols_l.append(dst.ravel())
+        r_, c_ = np.concatenate(rows_l), np.concatenate(cols_l)
+        a = sp.csr_matrix((np.ones(len(r_)), (r_, c_)), shape=(n, n))
+    else:
+        n = 4099
+        a = sp.random(n, n, density=0.004, format="lil", random_state=3)
+        a[5, :] = 0                      # empty rows
+        a[4000, :] = 0
+        a[77, rng.choice(n, 3000, replace=False)] = 1.0      # (long for this size)
+        a = a.tocsr()
+        big = sp.random(1, 20000, density=0.25, format="csr", random_state=4)     # a row of ~5000 entries
+        a = sp.vstack([sp.hstack([a, sp.csr_matrix((n, 20000 - n))]), big,
+                       sp.csr_matrix((20000 - n - 1, 20000))]).tocsr()
+        n = 20000
+    a.sort_indices()
+    a.data = _rand(rng, a.data.shape, ct)
+    a = a.astype(ct)
+    itype = np.int32 if it == "i32" else np.int64
+    d_rp, d_ci, d_v = _dev(gexec, a.indptr.astype(itype)), _dev(gexec, a.indices.astype(itype)), _dev(gexec, a.data)
+    for nrhs in (1, 3):
+        ld = nrhs + 1
+        x = _rand(rng, (n, ld), ct)
+        y0 = _rand(rng, (n, ld), ct)
+        alpha, beta = _rand(rng, (1,), ct), _rand(rng, (1,), ct)
+        d_x = _dev(gexec, x)
+        d_alpha, d_beta, d_zero = _dev(gexec, alpha), _dev(gexec, beta), _dev(gexec, np.zeros(1, ct))
+        want = a @ x[:, :nrhs]
+        scale = np.abs(a).dot(np.abs(x[:, :nrhs])).max()
+        got = {}
+        for mode in (1, 0):
+            lib().gkoc_tune_set(C.c_int(16), C.c_int64(mode))
+            try:
+                y = _dev(gexec, y0.copy())
+                call(f"gkoc_ccsr_spmv_{tn}_{it}", gexec.stream, n, nrhs, d_rp, d_ci, d_v, None, d_x, ld, None, y, ld)
+                ya = _dev(gexec, y0.copy())
+                call(f"gkoc_ccsr_spmv_{tn}_{it}", gexec.stream, n, nrhs, d_rp, d_ci, d_v, d_alpha, d_x, ld, d_beta, ya,
+                     ld)
+                yn = _dev(gexec, np.full_like(y0, np.nan))
+                call(f"gkoc_ccsr_spmv_{tn}_{it}", gexec.stream, n, nrhs, d_rp, d_ci, d_v, d_alpha, d_x, ld, d_zero, yn,
+                     ld)
+                torch.cuda.synchronize()
+                got[mode] = (_host(y), _host(ya), _host(yn))
+            finally:
+                lib().gkoc_tune_set(C.c_int(16), C.c_int64(0))
+        for mode in (1, 0):
+            y, ya, yn = got[mode]
+            assert np.max(np.abs(y[:, :nrhs] - want)) <= 40 * tol * scale, (mode, nrhs)
+            assert np.array_equal(y[:, nrhs:], y0[:, nrhs:])                       # the padding column is untouched
+            assert np.max(np.abs(ya[:, :nrhs] - (alpha[0] * want + beta[0] * y0[:, :nrhs]))) <= 80 * tol * scale
+            assert np.max(np.abs(yn[:, :nrhs] - alpha[0] * want)) <= 80 * tol * scale
+        # the plain product: the same sums in the same order => the same bits as the thread-per-row kernel,
+        # except on the rows longer than GKOC_CSR_LONG_ROW, which the row-segment kernel sums in 64 chunks
+        lens = np.diff(a.indptr)
+        short = lens <= 4096
+        assert np.array_equal(got[0][0][short, :nrhs], got[1][0][short, :nrhs])

@@ -14,4 +14,4 @@ $EXE 256 50 200 --json > $OUT/plain.txt 2>&1
 rocprofv3 --kernel-trace --hip-trace --stats --output-format csv -d $OUT/trace -o t -- $EXE 256 50 200 --json > $OUT/traced.txt 2>&1
 cd $OUT
 python $ROOT/tools/api_gap_report.py trace > report.txt 2>&1
-find trace -name "*hip_api_trace.csv" -size +8M -delete
+find trace -name "*hip_api_trace.csv" -size +64M -delete

@@ -55,3 +55,25 @@ else:
 for f in glob.glob(os.path.join(d, "**", "*hip_api_stats.csv"), recursive=True):
     print("\n== HIP API stats")
     print("".join(open(f).readlines()[:16]))
+# round 6: one iteration of the timed solve seen from BOTH sides - the HIP calls of the host thread (start,
+# duration) between the kernels' start / end on the device, on one time axis (rocprofv3 reports both in ns of
+# the same clock)
+ha = glob.glob(os.path.join(d, "**", "*hip_api_trace.csv"), recursive=True)
+if ha:
+    api = list(csv.DictReader(open(ha[0])))
+    k0 = spmv[-50]                         # an SpMV in the middle of the timed solve
+    k1 = spmv[-48]
+    w0, w1 = int(rows[k0]["Start_Timestamp"]) - 5000, int(rows[k1]["Start_Timestamp"]) + 5000
+    ev = []
+    for r in rows[k0:k1 + 1]:
+        ev.append((int(r["Start_Timestamp"]), f"    device  START {name(r)}"))
+        ev.append((int(r["End_Timestamp"]), f"    device  END   {name(r)}  ({(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.1f} us)"))
+    for r in api:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if w0 <= s <= w1 and not r["Function"].startswith("__hip"):
+            ev.append((s, f"host  {r['Function']}  ({(e - s) / 1e3:.1f} us)"))
+    ev.sort()
+    print("\n== two iterations, host and device on one axis (us from the first SpMV's start)")
+    base = int(rows[k0]["Start_Timestamp"])
+    for t, what in ev:
+        print(f"{(t - base) / 1e3:10.1f}  {what}")
