@@ -226,7 +226,7 @@ try {
             CK(rc);
         }
     }
-    if (world > 1 && !mirror && comm == nullptr) {
+    if (world > 1 && comm == nullptr) {      // (mirror: a real one-rank RCCL communicator)
         unsigned char id[GKOC_COMM_ID_BYTES] = {};
         CK(gkoc_comm_load_rccl(getenv("GKOC_RCCL_PATH")));
         if (real_rank == 0) CK(gkoc_comm_unique_id(id));

@@ -168,6 +168,11 @@ struct device_arena {
     // ... and of arrays the SpMV kernels have been handed as MATRIX arrays (gkoc_arena_note_matrix): a
     // request of such a size is a matrix array although it may be a multiple of a vector's size
     std::vector<size_t> matrix_sizes;
+    // a size that kernels WRITE as a vector and that an SpMV is handed as a matrix array (nnz == n: a diagonal
+    // or permutation matrix, ELL with one entry per row): after the second change of mind it stays a vector -
+    // such a matrix moves as many bytes as a vector, and the notes would otherwise flip the class of every
+    // n-vector allocated in between
+    std::vector<std::pair<size_t, int>> contested_sizes;
     int64_t misplaced = 0;        // gkoc_arena_note_vector found a written vector next to matrix arrays
     int64_t probes = 0, walked = 0, classified = 0, search_ns = 0, retried = 0;
     bool surveyed = false;        // the one search for all three classes has run (survey_classes)
@@ -1128,6 +1133,16 @@ int gkoc_arena_note_vector(const void* ptr)
         }
         if (A.vector_sizes.size() >= 8) A.vector_sizes.erase(A.vector_sizes.begin());
         A.vector_sizes.push_back(bytes);
+        for (auto& cs : A.contested_sizes) {
+            if (cs.first != bytes || cs.second <= 2) continue;
+            // settled as a vector (see contested_sizes): the matrix note of this size goes
+            for (size_t i = 0; i < A.matrix_sizes.size(); ++i) {
+                if (A.matrix_sizes[i] == bytes) {
+                    A.matrix_sizes.erase(A.matrix_sizes.begin() + i);
+                    break;
+                }
+            }
+        }
         return GKOC_OK;
     }
     return GKOC_OK;
@@ -1152,6 +1167,21 @@ int gkoc_arena_note_matrix(const void* ptr)
         if (off >= it->first + bytes) return GKOC_OK;
         for (size_t m : A.matrix_sizes) {
             if (m == bytes) return GKOC_OK;
+        }
+        for (size_t v : A.vector_sizes) {
+            if (v != bytes) continue;
+            // noted as a written vector before: a mistake the first time (k n values seen before any SpMV),
+            // a matrix with a vector's size if it keeps coming back
+            int* flips = nullptr;
+            for (auto& cs : A.contested_sizes) {
+                if (cs.first == bytes) flips = &cs.second;
+            }
+            if (flips == nullptr) {
+                if (A.contested_sizes.size() >= 16) A.contested_sizes.erase(A.contested_sizes.begin());
+                A.contested_sizes.emplace_back(bytes, 0);
+                flips = &A.contested_sizes.back().second;
+            }
+            if (++*flips > 2) return GKOC_OK;      // stays a vector
         }
         if (A.matrix_sizes.size() >= 16) A.matrix_sizes.erase(A.matrix_sizes.begin());
         A.matrix_sizes.push_back(bytes);

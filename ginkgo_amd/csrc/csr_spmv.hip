@@ -381,6 +381,20 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
         GKOC_TRY((long_info_of<T, I>(s, n_rows, row_ptrs, &lng)));
     }
     const uint32_t* seg_skip = lng.count > 0 ? lng.bits : nullptr;
+    // the hub rows' kernels run BEHIND the row-segment kernel on the caller's stream.  (Round 6 also ran them
+    // BESIDE it - a side stream per calling stream, forked in front of the product and joined behind it by two
+    // events; the two kernels write disjoint rows of c.  The heavy-tailed stand-in took 245.7 us that way
+    // against 231.5 us in sequence, profiles/r06/r06_hub_rows_beside.txt: gone again.)
+    auto hub_kernels = [&](hipStream_t st) {
+        // (the chunk sums go to the CALLING stream's buffer: long_partial_for)
+        csr_flagged_segments_kernel<T, I, ADV><<<dim3(unsigned(lng.count * LONG_PARTS)), dim3(LONG_WG), 0, st>>>(
+            n_rows, row_ptrs, col_idxs, vals, b, ldb, c, ldc, alpha, beta, lng.list, static_cast<T*>(lng.partial));
+        GKOC_LAUNCH_OK();
+        csr_long_rows_fold_kernel<T, I, ADV><<<dim3(unsigned(lng.count)), dim3(64), 0, st>>>(
+            n_rows, row_ptrs, c, ldc, beta, lng.list, static_cast<const T*>(lng.partial));
+        GKOC_LAUNCH_OK();
+        return int(GKOC_OK);
+    };
     // GKOC_TUNE_CSR_SEGS_PER_WAVE forces 1 or 2 segments per wave (round 6 tried "up to eight for matrices
     // with short rows" - the heavy-tailed stand-in 256 us with one, 261 with two, 276 with four, 320 with eight
     // segments; 5-pt 4096^2 325 / 289 / 325 / 315; profiles/r06/r06_segments_per_wave.txt: the size rule above
@@ -454,16 +468,7 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
 #undef GKOC_LAUNCH_PIPE3
 #undef GKOC_LAUNCH_PIPE3X
     GKOC_LAUNCH_OK();
-    if (lng.count > 0) {
-        // (the chunk sums go to THIS stream's buffer: long_partial_for)
-        csr_flagged_segments_kernel<T, I, ADV>
-            <<<dim3(unsigned(lng.count * LONG_PARTS)), dim3(LONG_WG), 0, as_stream(s)>>>(
-                n_rows, row_ptrs, col_idxs, vals, b, ldb, c, ldc, alpha, beta, lng.list, static_cast<T*>(lng.partial));
-        GKOC_LAUNCH_OK();
-        csr_long_rows_fold_kernel<T, I, ADV><<<dim3(unsigned(lng.count)), dim3(64), 0, as_stream(s)>>>(
-            n_rows, row_ptrs, c, ldc, beta, lng.list, static_cast<const T*>(lng.partial));
-        GKOC_LAUNCH_OK();
-    }
+    if (lng.count > 0) GKOC_TRY(hub_kernels(as_stream(s)));
     return GKOC_OK;
 }
 

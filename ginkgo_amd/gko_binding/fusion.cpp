@@ -324,6 +324,10 @@ void launch_sub_scaled(const held_ops& h)
 void flush_deferred()
 {
     const held_ops h = held;
+    // z = M r was written ahead of its call and something ELSE has entered the backend: this solve does not have
+    // the shape that was learned (a logger that launches, a user LinOp between the steps) - it has to show it
+    // again before the next cg::step_2 writes z early
+    if (anticipated) learned.valid = false;
     held.stage = 0;
     held.norm_of = nullptr;
     bp_dot.x = nullptr;

@@ -88,12 +88,18 @@ inline void note_written_vector(const void* p)
 // ... and which arrays are matrix arrays from what the SpMV entries are handed (gkoc_arena_note_matrix)
 inline void note_matrix_arrays(const void* values, const void* col_idxs)
 {
-    static thread_local const void* last = nullptr;
-    if (values != last) {
-        last = values;
-        gkoc_arena_note_matrix(values);
-        gkoc_arena_note_matrix(col_idxs);
+    // the last few value arrays this thread has announced (a solver that alternates two matrices - a
+    // multigrid cycle, a preconditioner with its own matrix - would otherwise take the allocator's mutex with
+    // every product: ADVICE round 5)
+    static thread_local const void* seen[8] = {};
+    static thread_local int next = 0;
+    for (const void* p : seen) {
+        if (p == values) return;
     }
+    seen[next] = values;
+    next = (next + 1) % 8;
+    gkoc_arena_note_matrix(values);
+    gkoc_arena_note_matrix(col_idxs);
 }
 
 // ===================================================================== csr
@@ -949,6 +955,8 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
         array<T>& conditioning, array<precision_reduction>& block_precisions,   \
         const array<I>& block_pointers, array<T>& blocks)                       \
     {                                                                           \
+        cdna4::forget_learned(); /* the blocks change: what a solve has shown \
+                                    about THESE arrays is void (any scheme) */   \
         if (has_precisions<T>(block_precisions)) {                              \
             GKOC_CALL((adaptive_abi<T, I>::generate(                            \
                 stream_of(exec), system_matrix->get_size()[0],                  \
@@ -961,7 +969,6 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
                 conditioning.get_data(), blocks.get_data())));                  \
             return;                                                             \
         }                                                                       \
-        cdna4::forget_learned();                                                \
         GKOC_CALL(gkoc_jacobi_generate_##TN##_##IN(                             \
             stream_of(exec), system_matrix->get_size()[0],                      \
             system_matrix->get_const_row_ptrs(),                                \

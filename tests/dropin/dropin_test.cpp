@@ -659,9 +659,12 @@ int main(int argc, char** argv)
             int iu_ref = 0, iu_by = 0, iu_plain = 0;
             int64_t n0 = 0, d0 = 0, n1 = 0, d1 = 0;
             auto xu_ref = run_user(ref, a_ref, 0, iu_ref);
+            int64_t q0 = 0, q1 = 0;      // (round 6) <p, q> does come with the product A p: those dots are not <r, z>
             gko_cdna4_byproduct_hits(&n0, &d0);
+            gko_cdna4_spmv_dot_hits(&q0);
             auto xu_by = run_user(hip, a_hip, 0, iu_by);
             gko_cdna4_byproduct_hits(&n1, &d1);
+            gko_cdna4_spmv_dot_hits(&q1);
             auto xu_plain = run_user(hip, a_hip, 2, iu_plain);
             std::cout << "  user preconditioner: iterations reference " << iu_ref << ", hip (by-products) " << iu_by
                       << ", hip (one kernel per call) " << iu_plain << "; norms answered by step_2: " << (n1 - n0)
@@ -670,7 +673,7 @@ int main(int argc, char** argv)
                   "CG + user LinOp preconditioner with its own launches: iteration counts agree");
             CHECK(rel_err(xu_by.get(), xu_plain.get()) < 1e-12 && rel_err(xu_by.get(), xu_ref.get()) < 1e-8,
                   "CG + user LinOp preconditioner: the reference's solution");
-            CHECK(n1 - n0 >= iu_by - 1 && d1 - d0 == 0,
+            CHECK(n1 - n0 >= iu_by - 1 && d1 - d0 == q1 - q0,
                   "CG + user LinOp preconditioner: ||r|| still comes with step_2, <r,z> is computed");
         }
         {
