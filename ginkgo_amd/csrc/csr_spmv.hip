@@ -869,8 +869,11 @@ int csr_spmv_complex(gkoc_stream_t s, int64_t n_rows, int64_t nrhs, const I* row
                      const T* vals, const T* alpha, const T* b, int64_t ldb, const T* beta, T* c, int64_t ldc)
 {
     if (n_rows <= 0 || nrhs <= 0) return GKOC_OK;
-    GKOC_REQUIRE(row_ptrs && col_idxs && vals && b && c, GKOC_E_INVALID, "null pointer");
+    GKOC_REQUIRE(row_ptrs && c, GKOC_E_INVALID, "null pointer");
     GKOC_REQUIRE(nrhs <= 0x7fffffff, GKOC_E_NOT_SUPPORTED, "more than 2^31 right-hand sides");
+    // a matrix without entries or without columns (the non-local part of a rank that has no neighbours) comes
+    // with null arrays / a null b: the thread-per-row kernel never touches them, this one's idle lanes read b[0]
+    if (col_idxs == nullptr || vals == nullptr || b == nullptr) return GKOC_E_NOT_SUPPORTED;
     constexpr int E = sizeof(T) == 16 ? 1 : 2, U = sizeof(T) == 16 ? 4 : 2;
     constexpr int RINGV = 8192 / sizeof(T);
     if (reinterpret_cast<uintptr_t>(vals) % (E * sizeof(T)) != 0 ||

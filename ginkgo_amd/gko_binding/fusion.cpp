@@ -205,6 +205,7 @@ struct spmv_dot_shape {
 thread_local spmv_dot_shape learned_spmv;     // confirmed in this solve
 thread_local spmv_dot_shape last_spmv;        // the product that was this thread's last writing entry (a candidate)
 thread_local uint64_t last_spmv_epoch = 0;
+thread_local int spmv_dot_seen = 0;           // consecutive times the same (operands, dest) have been seen
 thread_local int64_t hits_spmv_dot = 0;
 
 void publish()
@@ -415,6 +416,17 @@ void forget_learned_if(const void* freed)
         (freed != nullptr && (freed == last_dot_dest || freed == last_norm_dest || freed == last_norm_of))) {
         forget_learned();
     }
+    // the product + dot shape names the matrix arrays, both vectors and the scalar it writes EARLY: a freed
+    // scalar (the temporary result of a distributed dot product, say) must never be written again
+    for (const spmv_dot_shape* t : {&learned_spmv, &last_spmv}) {
+        if (t->valid && freed != nullptr &&
+            (freed == t->dest || freed == t->b || freed == t->c || freed == t->vals || freed == t->cols ||
+             freed == t->row_ptrs)) {
+            learned_spmv.valid = false;
+            last_spmv.valid = false;
+            spmv_dot_seen = 0;
+        }
+    }
 }
 
 // ---- the criterion (one column, synchronous form) with the predicted cg::step_1 behind its kernel ------------
@@ -424,10 +436,15 @@ bool criterion_then_step_1(int vt, gkoc_stream_t s, const void* tau, const void*
 {
     // (the caller has been through stream_of(): this entry's number)
     criterion_epoch = last_entry_epoch;
-    step1_is_ahead = false;
+    // a Combined criterion may hold TWO residual-norm criteria: the step runs behind the first one only
+    if (step1_is_ahead) return false;
     const step1_call& c = learned_step1;
-    if (!c.valid || c.vt != vt || c.s != s || c.stop != stop || anticipate_level() != 1 || mode() != 0 ||
-        last_dot_dest == nullptr || last_dot_dest != c.prev_rho) {
+    // (a rank without rows - an empty part of a distributed vector - has null vectors: nothing to run ahead, and
+    //  an entry that refuses them must not throw on that rank alone)
+    if (!c.valid || c.vt != vt || c.s != s || c.stop != stop || c.n <= 0 || c.p == nullptr || c.z == nullptr ||
+        c.rho == nullptr || c.prev_rho == nullptr || tau == nullptr || orig_tau == nullptr ||
+        (anticipate_level() != 1 && anticipate_level() != 3) || mode() != 0 || last_dot_dest == nullptr ||
+        last_dot_dest != c.prev_rho) {
         return false;
     }
     // this iteration's scalars: rho is where the dot product has just been written = last iteration's prev_rho
@@ -444,6 +461,10 @@ bool criterion_then_step_1(int vt, gkoc_stream_t s, const void* tau, const void*
             set_finalized ? 1 : 0, implicit ? 1 : 0, stop, flags, all_converged, one_changed, c.n,
             static_cast<float*>(c.p), static_cast<const float*>(c.z), static_cast<const float*>(c.prev_rho),
             static_cast<const float*>(c.rho));
+    }
+    if (rc == GKOC_E_INVALID) {
+        // refused before anything was launched (argument checks): the caller runs the plain criterion
+        return false;
     }
     GKOC_CALL(rc);
     ahead = c;
@@ -495,6 +516,7 @@ void forget_learned()
     learned_step1.valid = false;
     learned_spmv.valid = false;
     last_spmv.valid = false;
+    spmv_dot_seen = 0;
     step1_is_ahead = false;
     last_dot_dest = nullptr;
     last_norm_of = nullptr;
@@ -521,7 +543,7 @@ bool step_2_anticipating(int vt, int dev, gkoc_stream_t s, int64_t n, void* x, v
     if (!b || b->work < work) return false;
     char* norm_at = b->p;
     char* dot_at = b->p + 64;
-    if (anticipate_level() == 1) {
+    if (anticipate_level() == 1 || anticipate_level() == 3) {
         // <r, z> goes where the NEXT dot product will be asked to put it: the scalar that was prev_rho in this
         // iteration's step_1 (cg.cpp:176 swaps the two); ||r|| where the criterion's norm of r went last time.
         // Nothing reads either before those calls come (prev_rho's last reader was step_1).
@@ -711,8 +733,9 @@ bool spmv_with_dot(int vt, int it, int dev, gkoc_stream_t s, int64_t n, const vo
     now.b = b;
     now.c = c;
     const spmv_dot_shape f = learned_spmv;
-    if (f.valid && f.vt == vt && f.it == it && f.s == s && f.n == n && f.row_ptrs == row_ptrs && f.cols == cols &&
-        f.vals == vals && f.b == b && f.c == c && f.dest != nullptr && f.dest != b && f.dest != c) {
+    if (f.valid && spmv_dot_seen >= 2 && f.vt == vt && f.it == it && f.s == s && f.n == n &&
+        f.row_ptrs == row_ptrs && f.cols == cols && f.vals == vals && f.b == b && f.c == c && f.dest != nullptr &&
+        f.dest != b && f.dest != c) {
         const size_t work = gkoc_x_workspace_bytes(n, vt == 0 ? 8 : 4);
         side_block* sb = side_for(dev, s, work);
         if (sb && sb->work >= work) {
@@ -771,10 +794,20 @@ bool fused_dot(int vt, gkoc_stream_t s, int64_t n, const void* x, const void* y,
         const bool next = backend_epoch.load(std::memory_order_acquire) == last_spmv_epoch;
         if (next && t.vt == vt && t.s == s && t.n == n && ((x == t.b && y == t.c) || (x == t.c && y == t.b)) &&
             result != x && result != y) {
+            // the shape counts once it has been seen TWICE in a row with the same operands and the same place
+            // for the result (a result that moves - a temporary - is never written early)
+            const spmv_dot_shape& o = learned_spmv;
+            const bool same = o.dest == result && o.b == t.b && o.c == t.c && o.vals == t.vals && o.cols == t.cols &&
+                              o.row_ptrs == t.row_ptrs && o.n == t.n && o.vt == t.vt && o.it == t.it && o.s == t.s;
+            spmv_dot_seen = same ? spmv_dot_seen + 1 : 1;
             learned_spmv = t;
             learned_spmv.dest = result;
-        } else if (learned_spmv.valid && (t.b == learned_spmv.b || t.c == learned_spmv.c)) {
-            learned_spmv.valid = false;      // the product was not followed by its dot product this time
+            learned_spmv.valid = true;
+        } else {
+            if (learned_spmv.valid && (t.b == learned_spmv.b || t.c == learned_spmv.c)) {
+                learned_spmv.valid = false;      // the product was not followed by its dot product this time
+            }
+            spmv_dot_seen = 0;
         }
     }
     if (held.stage == 0 && bp_dot.x != nullptr && bp_dot.vt == vt && bp_dot.s == s && bp_dot.n == n &&

@@ -2346,7 +2346,10 @@ int gkoc_comm_all_to_all_v_bytes(gkoc_comm_t comm, gkoc_stream_t s, const void* 
  *   2. the host program gathers all handles in rank order (MPI_Allgather, a key-value store)
  *   3. every rank: gkoc_comm_ipc_connect(all handles)
  * after which every gkoc_comm_* call above works as documented (messages larger than slot_bytes:
- * GKOC_E_NOT_SUPPORTED).  Waiting kernels have a patience (GKOC_IPC_PATIENCE_MS, default 120000): a
+ * GKOC_E_NOT_SUPPORTED - the check is per rank, and a rank that passes it counts the exchange: the ranks of a
+ * communicator must AGREE, before they call, on whether an exchange fits - as the MPI layer does with the two-int
+ * agreement it sends ahead of every all-to-all-v, gko_binding/mpi_rccl.cpp route_local; an exchange that one
+ * rank refuses and another starts leaves their per-pair sequence numbers one apart).  Waiting kernels have a patience (GKOC_IPC_PATIENCE_MS, default 120000): a
  * wait that runs out sets a bit in the status word and the kernel ends; gkoc_comm_status reads it
  * (no synchronisation; 0 = nothing ever timed out; bit 0 all-reduce, bit 1 a message, bit 2 an
  * acknowledgement).  gkoc_comm_destroy must be entered by a rank only after its peers have completed
