@@ -310,16 +310,7 @@ __global__ __launch_bounds__(64, WPS) void csr_spmv_pipe3_kernel(
                 for (int u = 0; u < U; ++u) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
-                        if constexpr ((ABL & 4) != 0) {
-                            // (experiment, GKOC_TUNE_CSR_SHORT_ROWS = 4: the gather as a non-temporal load)
-                            xv[u].v[e] = __builtin_nontemporal_load(&bj[int64_t(ci[u].v[e])]);
-                        } else if constexpr ((ABL & 8) != 0) {
-                            // (experiment, = 5: the gather at agent scope - always a miss in the vector L1)
-                            xv[u].v[e] = __hip_atomic_load(&bj[int64_t(ci[u].v[e])], __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT);
-                        } else {
-                            xv[u].v[e] = (ABL & 1) ? T(ci[u].v[e]) : bj[int64_t(ci[u].v[e])];
-                        }
+                        xv[u].v[e] = (ABL & 1) ? T(ci[u].v[e]) : bj[int64_t(ci[u].v[e])];
                     }
                 }
             } else {

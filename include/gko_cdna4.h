@@ -202,11 +202,11 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
 #define GKOC_TUNE_CSR_SEGS_PER_WAVE 13 /* csr::spmv, one right-hand side: 64-row segments a wave walks.  0 (default): two
                                       from 4 M rows on, one below; 1, 2: that many (round 6 tried four and eight
                                       on rows of a dozen entries: never faster - profiles/r06/) */
-#define GKOC_TUNE_CSR_SHORT_ROWS 14 /* csr::spmv, one right-hand side, matrices whose 64-row segments hold fewer than
-                                      1200 entries on average: load layout and ring size of the row-segment kernel.
-                                      0 (default): the launcher's rule; 1: two entries per lane, one load group, 2 KB
-                                      ring; 2: two entries, two groups, 4 KB ring; 3: one entry, two groups, 2 KB
-                                      ring; -1: the layout of the long-row matrices */
+#define GKOC_TUNE_CSR_SHORT_ROWS 14 /* (not read any more) round 6's experiments on matrices with a dozen entries per
+                                      row - smaller rings and load groups, non-temporal / agent-scope gathers, two
+                                      to eight waves per workgroup: none was faster than the launcher's rule, the
+                                      variants are gone (profiles/r06/r06_segments_per_wave.txt,
+                                      r06_waves_per_workgroup.txt) */
 #define GKOC_TUNE_JACOBI_LANES 15    /* block-Jacobi apply for float / complex values and adaptive storage of those:
                                       0 (default) lane = (block, row) of a storage group, 1: the thread-per-row
                                       kernels of round 5 (A/B runs) */

@@ -1,4 +1,5 @@
-"""A/B of the row-segment CSR kernel's launch shapes (development tool): waves per workgroup (GKOC_TUNE_CSR_SHORT_ROWS
+"""(HISTORICAL: the variants this script switched between were removed after the measurement,
+profiles/r06/r06_waves_per_workgroup.txt.)  A/B of the row-segment CSR kernel's launch shapes (development tool): waves per workgroup (GKOC_TUNE_CSR_SHORT_ROWS
 = 6 / 7 / 8: four / two / eight) and the XCD-contiguous order (GKOC_TUNE_CSR_XCD_MAP) on matrices with short and
 long rows; one process, times by HIP events, results compared bit for bit with the default launch."""
 import ctypes as C
