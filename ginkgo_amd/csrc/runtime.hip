@@ -115,7 +115,7 @@ void gate_fence_policy_set(int policy) { g_gate_fence_policy.store(policy < 0 ? 
 // GKOC_TUNE_<n>, else the default chosen by measurement
 int64_t tune_value(int key)
 {
-    static const int64_t defaults[tune_num_keys] = {0, 0, 0, 2, 1, 0, 0, 0, 100, 0, 1, 0, 1, 0, 0, 0, 0, 0};   // measured: the XCD-contiguous order loses 1-8 %
+    static const int64_t defaults[tune_num_keys] = {0, 0, 0, 2, 1, 0, 0, 0, 100, 0, 1, 0, 1, 0, 0, 0, 0, 1};   // measured: the XCD-contiguous order loses 1-8 %
     if (key < 0 || key >= tune_num_keys) return 0;
     if (!g_tune_set[key]) {
         char name[32];

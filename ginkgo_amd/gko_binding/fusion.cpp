@@ -60,6 +60,7 @@ namespace gko {
 namespace cdna4 {
 
 thread_local int deferred_state = 0;
+thread_local int alloc_role_hint = 0;
 std::atomic<uint64_t> backend_epoch{0};
 thread_local uint64_t last_entry_epoch = 0;
 

@@ -932,6 +932,34 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
         static_cast<int64_t>(precisions.get_size())));
 }
 
+// The block array of a block-Jacobi preconditioner is k n values (k = the block size): to the allocator a
+// multi-vector, so Ginkgo's raw_alloc put it among the vectors - and the application, which streams the blocks
+// AND reads / writes vectors, had both in one memory class: the one-kernel cg::step_2 + application
+// took 372 us behind the core against 337 us in the native loop, which allocates the blocks with the index
+// arrays.  generate is the one call that knows what this array is, and it OVERWRITES it: an owning array of a
+// class that holds vectors is re-allocated in the class of the matrix' column indices before it is filled (same
+// size; a view on user memory, a small array, or GKOC_TUNE_JACOBI_REHOME = 0: left alone).
+template <typename T>
+void rehome_jacobi_blocks(exec_t exec, const void* col_idxs, array<T>& blocks)
+{
+    int64_t on = 1;
+    gkoc_tune_get(GKOC_TUNE_JACOBI_REHOME, &on);
+    const size_t bytes = blocks.get_size() * sizeof(T);
+    if (on == 0 || !blocks.is_owning() || bytes < (size_t(16) << 20) || col_idxs == nullptr) return;
+    int have = -1, want = -1;
+    gkoc_arena_class_of(blocks.get_const_data(), &have);
+    gkoc_arena_class_of(col_idxs, &want);
+    if (have < 0 || want < 0 || have == want) return;
+    try {
+        cdna4::alloc_role_hint = want == 0 ? GKOC_MEM_VALUES : want == 1 ? GKOC_MEM_INDICES : GKOC_MEM_VECTOR;
+        array<T> moved(exec, blocks.get_size());
+        cdna4::alloc_role_hint = 0;
+        blocks = std::move(moved);
+    } catch (...) {
+        cdna4::alloc_role_hint = 0;      // no room there: the array stays where it is
+    }
+}
+
 #define DEF(T, TN, I, IN)                                                       \
     template <>                                                                 \
     void find_blocks<T, I>(exec_t exec, const matrix::Csr<T, I>* system_matrix, \
@@ -957,6 +985,7 @@ void initialize_precisions(exec_t exec, const array<precision_reduction>& source
     {                                                                           \
         cdna4::forget_learned(); /* the blocks change: what a solve has shown \
                                     about THESE arrays is void (any scheme) */   \
+        rehome_jacobi_blocks(exec, system_matrix->get_const_col_idxs(), blocks); \
         if (has_precisions<T>(block_precisions)) {                              \
             GKOC_CALL((adaptive_abi<T, I>::generate(                            \
                 stream_of(exec), system_matrix->get_size()[0],                  \

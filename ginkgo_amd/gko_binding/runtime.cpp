@@ -57,7 +57,13 @@ version version_info::get_hip_version() noexcept
 void* HipAllocator::allocate(size_type num_bytes)
 {
     void* p = nullptr;
-    GKOC_CALL(gkoc_malloc(&p, num_bytes));
+    const int role = cdna4::alloc_role_hint;
+    cdna4::alloc_role_hint = 0;
+    if (role != 0) {
+        GKOC_CALL(gkoc_malloc_role(&p, num_bytes, role));
+    } else {
+        GKOC_CALL(gkoc_malloc(&p, num_bytes));
+    }
     return p;
 }
 

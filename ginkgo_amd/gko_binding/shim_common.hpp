@@ -45,6 +45,9 @@ inline void check(int status, const char* file, int line, const char* what)
 // Fusion across calls (fusion.cpp): cg::step_2 and the block-Jacobi application that follows it
 // are held back until the next call shows whether one kernel can do them together with the dot
 // product.  Everything that enters the backend goes through launch_deferred() first.
+// a role for the NEXT HipAllocator::allocate of this thread (GKOC_MEM_*; 0 = none): the one place where the binding
+// knows what an array Ginkgo allocates is for - jacobi::generate re-homes the block array (kernels.cpp)
+extern thread_local int alloc_role_hint;
 extern thread_local int deferred_state;   // != 0: this thread holds something or caches a norm
 void flush_deferred();
 // "Nothing has entered the backend since" is a statement about ALL host threads: Executor::run may be called

@@ -212,6 +212,9 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
                                       kernels of round 5 (A/B runs) */
 #define GKOC_TUNE_CCSR_THREAD_PER_ROW 16 /* csr::spmv on complex values: 0 (default) the row-segment kernel of the real
                                       types, 1: one thread per row (round 5; A/B runs) */
+#define GKOC_TUNE_JACOBI_REHOME 17   /* binding for the unmodified Ginkgo core: 1 (default) jacobi::generate re-allocates
+                                      an owning block array that sits in a memory class with vectors in the class of
+                                      the matrix' column indices before it fills it; 0: left where raw_alloc put it */
 int gkoc_tune_set(int key, int64_t value);
 int gkoc_tune_get(int key, int64_t* value);
 /* HipHostAllocator (pinned host memory) and HipUnifiedAllocator (managed memory,
