@@ -601,6 +601,30 @@ int main(int argc, char** argv)
             auto xu = run_small(2, it_u);
             CHECK(it_f > 0 && it_f == it_u, "CG with small user blocks (fused kernel has no room): runs, same iterations");
             CHECK(rel_err(xf.get(), xu.get()) < 1e-12, "CG with small user blocks: same solution with fusion on and off");
+            // round 6: jacobi::generate re-homes an owning block array (here 262 144 x 16 x 8 B = 32 MiB, to the
+            // allocator a multi-vector) from a memory class with vectors to the class of the matrix' column
+            // indices before it fills it; with the switch off it stays where raw_alloc put it.  Same product.
+            auto classes_of = [&](int rehome, std::shared_ptr<gko::matrix::Dense<vt>>& y) {
+                gkoc_tune_set(GKOC_TUNE_JACOBI_REHOME, rehome);
+                auto jac = gko::preconditioner::Jacobi<vt, it>::build().with_max_block_size(16u).on(hip)->generate(ab);
+                gkoc_tune_set(GKOC_TUNE_JACOBI_REHOME, 1);
+                int cb = -1, cc = -1;
+                gkoc_arena_class_of(jac->get_blocks(), &cb);
+                gkoc_arena_class_of(ab->get_const_col_idxs(), &cc);
+                auto rhs = Dense::create(hip, gko::dim<2>{nb_rows, 1});
+                rhs->fill(1.0);
+                auto out = Dense::create(hip, gko::dim<2>{nb_rows, 1});
+                jac->apply(rhs, out);
+                y = gko::share(gko::clone(ref, out));
+                return std::make_pair(cb, cc);
+            };
+            std::shared_ptr<gko::matrix::Dense<vt>> y_on, y_off;
+            const auto on = classes_of(1, y_on), off = classes_of(0, y_off);
+            std::cout << "  Jacobi blocks: memory class " << on.first << " (column indices " << on.second
+                      << "); with GKOC_TUNE_JACOBI_REHOME=0: " << off.first << std::endl;
+            CHECK(on.first < 0 || on.second < 0 || on.first == on.second,
+                  "jacobi::generate re-homes the block array to the memory class of the column indices");
+            CHECK(rel_err(y_on.get(), y_off.get()) == 0.0, "re-homed blocks: the same application, bit for bit");
         }
         {
             // A preconditioner the backend knows nothing about: a user LinOp that launches ITS OWN work
