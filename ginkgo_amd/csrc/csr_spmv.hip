@@ -447,7 +447,22 @@ int launch_csr(gkoc_stream_t s, int64_t n_rows, int64_t n_cols, const T* alpha,
     if (vec_ok) {
         // below 2 M rows the grid is a few rounds deep and the wider layout of rounds 1-2 is as fast or
         // faster (64^3: 18.4 against 20.7 us; 1 - 2 M rows: equal); key 1 forces it for A/B runs
-        if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_seg < 32768) {
+        // float values and LONG rows (40 and more entries on average; the count comes with the first product's
+        // look at the row pointers): ONE entry per lane and load, eight load groups - neighbouring lanes then
+        // gather neighbouring entries of a row, whose columns come in runs (a 27-pt stencil with 2 / 3 / 5
+        // unknowns per node, 53 / 79 / 130 per row: 172 -> 165, 200 -> 182, 231 -> 207 us against four entries
+        // per lane; 7 and 27 per row lose 5-6 % with it, and for double all layouts are within 1.5 %:
+        // profiles/r06/r06_load_layouts.txt).  GKOC_TUNE_CSR_LOAD_GROUPS: 3 forces it, 4 = two entries x four
+        // groups, 1 = the wide loads.
+        const int64_t lay = tune_value(GKOC_TUNE_CSR_LOAD_GROUPS);
+        const bool long_float_rows = sizeof(T) == 4 && lng.nnz > 0 && lng.nnz >= 40 * n_rows;
+        if (lay == 3 || (lay == 0 && long_float_rows)) {
+            if (spw == 2) GKOC_LAUNCH_PIPE3(1, 8, 0x2000);
+            else GKOC_LAUNCH_PIPE3(1, 8, 0x1000);
+        } else if (lay == 4) {
+            if (spw == 2) GKOC_LAUNCH_PIPE3(2, 4, 0x2000);
+            else GKOC_LAUNCH_PIPE3(2, 4, 0x1000);
+        } else if (tune_value(GKOC_TUNE_CSR_LOAD_GROUPS) == 1 || n_seg < 32768) {
             if (spw == 2) {
                 GKOC_LAUNCH_PIPE3(EV, 1, 0x2000);
             } else {

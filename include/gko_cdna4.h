@@ -175,7 +175,9 @@ int gkoc_arena_probe(const void* x, size_t x_bytes, void* y, int read_kb_per_wav
 #define GKOC_TUNE_CSR_LOAD_GROUPS 2 /* csr::spmv, one column: 0 (default) two entries per lane and load, three load
                                       groups in flight (float: four entries, two groups); 1: four (eight) entries,
                                       one group - the layout of rounds 1-2, kept for A/B measurements; 2: the
-                                      default layout also where the size rule picks the other (small products) */
+                                      default layout also where the size rule picks the other (small products);
+                                      3: one entry per lane and load, eight groups - since round 6 what 0 picks for
+                                      float values with 40 and more entries per row; 4: two entries, four groups */
 #define GKOC_TUNE_GATE_FENCE 7      /* one-kernel distributed product (gkoc_csr_spmv_gated_*): 0 (default) only a
                                       boundary wave that had to wait for its halo pays an agent-scope acquire
                                       fence; 1: every boundary wave does (+8 us per product at 2048 waves) */
