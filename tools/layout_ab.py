@@ -39,6 +39,7 @@ def kron_case(dtype, grid, dof):
     return g.Csr.from_scipy(ex, a.astype(np.float64 if dtype == torch.float64 else np.float32))
 
 
+LAYS = tuple(int(v) for v in os.environ.get('LAYS', '0,1,3,4').split(','))
 cases = []
 for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
     cases += [(f"7pt 200^3 {tag}", lambda dt=dt: g.stencil_csr(ex, 3, 200, restricted=True, dtype=dt)),
@@ -56,7 +57,7 @@ for name, mk in cases:
     ref = y.to_numpy().tobytes()
     best = {}
     for rep in range(3):
-        for lay in (0, 1, 3, 4):
+        for lay in LAYS:
             L.gkoc_tune_set(C.c_int(2), C.c_int64(lay))
             us = t(a, x, y)
             assert y.to_numpy().tobytes() == ref
